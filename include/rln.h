@@ -1,0 +1,173 @@
+/* rln.h -- zerokit-compatible C ABI of the MI355X RLN backend (drop-in for `librln`).
+ *
+ * Same symbols, argument meaning, struct layouts, ownership and error convention as the header safer-ffi
+ * generates from /root/reference/rln/src/ffi/{ffi_rln,ffi_tree,ffi_utils}.rs (cargo run --features headers
+ * --bin generate_headers, rln/src/ffi/mod.rs:11-14).  Each declaration cites the #[ffi_export] it replaces.
+ *
+ *  - `T* const*` / `T**` arguments are safer-ffi's `&repr_c::Box<T>` / `&mut repr_c::Box<T>`: the address of
+ *    the caller's pointer variable (see rln/ffi_c_examples/basic_proof.c:48-49).
+ *  - Vec_T = { ptr, len, cap } (rln/ffi_nim_examples/rln.nim:28-46); strings are Vec_uint8_t, NUL-terminated
+ *    when produced by the library.
+ *  - CResult: `ok` is NULL (or an empty Vec) on failure and `err.ptr` is NULL on success
+ *    (ffi_utils.rs:15-29).  Everything returned is caller-owned and released with its `ffi_*_free`.
+ *  - CFr is opaque; elements of a Vec_CFr_t are contiguous CFr values reachable through ffi_vec_cfr_get
+ *    (ffi_utils.rs:183-185).  In this implementation a CFr is the 32-byte little-endian canonical value.
+ *
+ * Scope: single message-id circuit, in-memory tree.  Not exported: the ffi_rln_v3_* mirror,
+ * partial proofs, multi message-id witnesses, seeded keygen and the sled/pmtree persistence (§8f "next").
+ * Extensions that the reference lacks are marked EXT (deterministic blinding, batch).
+ */
+#ifndef RLN_H
+#define RLN_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct CFr CFr_t;                                 /* ffi_utils.rs:34-36  #[repr(opaque)] */
+typedef struct FFI_RLN FFI_RLN_t;                         /* ffi_rln.rs:16-18 */
+typedef struct FFI_RLNProof FFI_RLNProof_t;               /* ffi_rln.rs:153-155 */
+typedef struct FFI_RLNWitnessInput FFI_RLNWitnessInput_t; /* ffi_rln.rs:322-324 */
+typedef struct FFI_RLNProofValues FFI_RLNProofValues_t;   /* ffi_rln.rs:714-716 */
+
+typedef struct Vec_uint8 { uint8_t* ptr; size_t len; size_t cap; } Vec_uint8_t;
+typedef struct Vec_CFr { CFr_t* ptr; size_t len; size_t cap; } Vec_CFr_t;
+typedef struct Vec_size { size_t* ptr; size_t len; size_t cap; } Vec_size_t;
+
+typedef struct CBoolResult { bool ok; Vec_uint8_t err; } CBoolResult_t;                  /* ffi_utils.rs:24-29 */
+typedef struct FFI_MerkleProof { Vec_CFr_t path_elements; Vec_uint8_t path_index; } FFI_MerkleProof_t; /* ffi_tree.rs:13-18 */
+
+typedef struct { FFI_RLN_t* ok; Vec_uint8_t err; } CResult_FFI_RLN_ptr_Vec_uint8_t;
+typedef struct { FFI_RLNProof_t* ok; Vec_uint8_t err; } CResult_FFI_RLNProof_ptr_Vec_uint8_t;
+typedef struct { FFI_RLNWitnessInput_t* ok; Vec_uint8_t err; } CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t;
+typedef struct { FFI_RLNProofValues_t* ok; Vec_uint8_t err; } CResult_FFI_RLNProofValues_ptr_Vec_uint8_t;
+typedef struct { FFI_MerkleProof_t* ok; Vec_uint8_t err; } CResult_FFI_MerkleProof_ptr_Vec_uint8_t;
+typedef struct { CFr_t* ok; Vec_uint8_t err; } CResult_CFr_ptr_Vec_uint8_t;
+typedef struct { Vec_CFr_t ok; Vec_uint8_t err; } CResult_Vec_CFr_Vec_uint8_t;
+typedef struct { Vec_uint8_t ok; Vec_uint8_t err; } CResult_Vec_uint8_Vec_uint8_t;
+
+/* ---- RLN object ------------------------------------------------------------------------------------ */
+CResult_FFI_RLN_ptr_Vec_uint8_t ffi_rln_new(size_t tree_depth, const char* config_path);      /* ffi_rln.rs:24-57 */
+CResult_FFI_RLN_ptr_Vec_uint8_t ffi_rln_new_with_params(size_t tree_depth, const Vec_uint8_t* zkey_data,
+                                                        const Vec_uint8_t* graph_data,
+                                                        const char* config_path);             /* ffi_rln.rs:76-116 */
+void ffi_rln_free(FFI_RLN_t* rln);                                                            /* ffi_rln.rs:137 */
+size_t ffi_rln_get_tree_depth(FFI_RLN_t* const* rln);                                         /* ffi_rln.rs:142 */
+size_t ffi_rln_get_max_out(FFI_RLN_t* const* rln);                                            /* ffi_rln.rs:147 */
+
+/* ---- proofs ---------------------------------------------------------------------------------------- */
+CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_generate_rln_proof(FFI_RLN_t* const* rln,
+                                                            FFI_RLNWitnessInput_t* const* witness); /* ffi_rln.rs:852-872 */
+CBoolResult_t ffi_verify_rln_proof(FFI_RLN_t* const* rln, FFI_RLNProof_t* const* proof, const CFr_t* x); /* :966-984 */
+CBoolResult_t ffi_verify_with_roots(FFI_RLN_t* const* rln, FFI_RLNProof_t* const* proof, const Vec_CFr_t* roots,
+                                    const CFr_t* x);                                          /* ffi_rln.rs:987-1010 */
+/* EXT: generate_zk_proof_with_rs (protocol/proof.rs:753-777) -- explicit blinding scalars r, s */
+CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_generate_rln_proof_with_rs(FFI_RLN_t* const* rln,
+                                                                    FFI_RLNWitnessInput_t* const* witness,
+                                                                    const CFr_t* r, const CFr_t* s);
+/* EXT: n independent proofs in one device batch.  witnesses: array of n witness pointers; rs: NULL (random
+ * blinding) or 2n CFr (r_0, s_0, r_1, ...); out: array of n proof pointers filled on success. */
+CBoolResult_t ffi_generate_rln_proofs_batch(FFI_RLN_t* const* rln, FFI_RLNWitnessInput_t* const* witnesses, size_t n,
+                                            const CFr_t* rs, FFI_RLNProof_t** out);
+
+FFI_RLNProofValues_t* ffi_rln_proof_get_values(FFI_RLNProof_t* const* proof);                 /* ffi_rln.rs:158 */
+uint8_t ffi_rln_proof_get_version_byte(FFI_RLNProof_t* const* proof);                         /* ffi_rln.rs:165 */
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_proof_to_bytes_le(FFI_RLNProof_t* const* proof);        /* ffi_rln.rs:170 */
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_proof_to_bytes_be(FFI_RLNProof_t* const* proof);        /* ffi_rln.rs:186 */
+CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_bytes_le_to_rln_proof(const Vec_uint8_t* bytes);     /* ffi_rln.rs:202 */
+CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_bytes_be_to_rln_proof(const Vec_uint8_t* bytes);     /* ffi_rln.rs:218 */
+void ffi_rln_proof_free(FFI_RLNProof_t* proof);                                               /* ffi_rln.rs:234 */
+
+/* ---- witness input --------------------------------------------------------------------------------- */
+CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t ffi_rln_witness_input_new_single(
+    const CFr_t* identity_secret, const CFr_t* user_message_limit, const CFr_t* message_id,
+    const Vec_CFr_t* path_elements, const Vec_uint8_t* identity_path_index, const CFr_t* x,
+    const CFr_t* external_nullifier);                                                          /* ffi_rln.rs:327-358 */
+uint8_t ffi_rln_witness_input_get_version_byte(FFI_RLNWitnessInput_t* const* w);               /* ffi_rln.rs:399 */
+CFr_t* ffi_rln_witness_input_get_identity_secret(FFI_RLNWitnessInput_t* const* w);             /* ffi_rln.rs:404 */
+CFr_t* ffi_rln_witness_input_get_user_message_limit(FFI_RLNWitnessInput_t* const* w);          /* ffi_rln.rs:411 */
+CFr_t* ffi_rln_witness_input_get_message_id(FFI_RLNWitnessInput_t* const* w);                  /* ffi_rln.rs:418 */
+Vec_CFr_t ffi_rln_witness_input_get_path_elements(FFI_RLNWitnessInput_t* const* w);            /* ffi_rln.rs:438 */
+Vec_uint8_t ffi_rln_witness_input_get_identity_path_index(FFI_RLNWitnessInput_t* const* w);    /* ffi_rln.rs:451 */
+CFr_t* ffi_rln_witness_input_get_x(FFI_RLNWitnessInput_t* const* w);                           /* ffi_rln.rs:458 */
+CFr_t* ffi_rln_witness_input_get_external_nullifier(FFI_RLNWitnessInput_t* const* w);          /* ffi_rln.rs:463 */
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_witness_to_bytes_le(FFI_RLNWitnessInput_t* const* w);    /* ffi_rln.rs:477 */
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_witness_to_bytes_be(FFI_RLNWitnessInput_t* const* w);    /* ffi_rln.rs:493 */
+CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t ffi_bytes_le_to_rln_witness(const Vec_uint8_t* b); /* ffi_rln.rs:509 */
+CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t ffi_bytes_be_to_rln_witness(const Vec_uint8_t* b); /* ffi_rln.rs:525 */
+void ffi_rln_witness_input_free(FFI_RLNWitnessInput_t* w);                                     /* ffi_rln.rs:557 */
+
+/* ---- proof values ---------------------------------------------------------------------------------- */
+CFr_t* ffi_rln_proof_values_get_root(FFI_RLNProofValues_t* const* pv);                         /* ffi_rln.rs:719 */
+CFr_t* ffi_rln_proof_values_get_x(FFI_RLNProofValues_t* const* pv);                            /* ffi_rln.rs:724 */
+CFr_t* ffi_rln_proof_values_get_external_nullifier(FFI_RLNProofValues_t* const* pv);           /* ffi_rln.rs:729 */
+CResult_CFr_ptr_Vec_uint8_t ffi_rln_proof_values_get_y(FFI_RLNProofValues_t* const* pv);       /* ffi_rln.rs:736 */
+CResult_CFr_ptr_Vec_uint8_t ffi_rln_proof_values_get_nullifier(FFI_RLNProofValues_t* const* pv); /* ffi_rln.rs:746 */
+uint8_t ffi_rln_proof_values_get_version_byte(FFI_RLNProofValues_t* const* pv);                /* ffi_rln.rs:798 */
+Vec_uint8_t ffi_rln_proof_values_to_bytes_le(FFI_RLNProofValues_t* const* pv);                 /* ffi_rln.rs:803 */
+Vec_uint8_t ffi_rln_proof_values_to_bytes_be(FFI_RLNProofValues_t* const* pv);                 /* ffi_rln.rs:808 */
+CResult_FFI_RLNProofValues_ptr_Vec_uint8_t ffi_bytes_le_to_rln_proof_values(const Vec_uint8_t* b); /* ffi_rln.rs:813 */
+CResult_FFI_RLNProofValues_ptr_Vec_uint8_t ffi_bytes_be_to_rln_proof_values(const Vec_uint8_t* b); /* ffi_rln.rs:829 */
+void ffi_rln_proof_values_free(FFI_RLNProofValues_t* pv);                                      /* ffi_rln.rs:845 */
+
+/* ---- Merkle tree (ffi_tree.rs) --------------------------------------------------------------------- */
+CBoolResult_t ffi_set_tree(FFI_RLN_t** rln, size_t tree_depth);                                /* ffi_tree.rs:28-41 */
+CBoolResult_t ffi_delete_leaf(FFI_RLN_t** rln, size_t index);                                  /* ffi_tree.rs:44 */
+CBoolResult_t ffi_set_leaf(FFI_RLN_t** rln, size_t index, const CFr_t* leaf);                  /* ffi_tree.rs:58 */
+CResult_CFr_ptr_Vec_uint8_t ffi_get_leaf(FFI_RLN_t* const* rln, size_t index);                 /* ffi_tree.rs:72 */
+size_t ffi_leaves_set(FFI_RLN_t* const* rln);                                                  /* ffi_tree.rs:89 */
+CBoolResult_t ffi_set_next_leaf(FFI_RLN_t** rln, const CFr_t* leaf);                           /* ffi_tree.rs:94 */
+CBoolResult_t ffi_set_leaves_from(FFI_RLN_t** rln, size_t index, const Vec_CFr_t* leaves);     /* ffi_tree.rs:108 */
+CBoolResult_t ffi_init_tree_with_leaves(FFI_RLN_t** rln, const Vec_CFr_t* leaves);             /* ffi_tree.rs:127 */
+CBoolResult_t ffi_atomic_operation(FFI_RLN_t** rln, size_t index, const Vec_CFr_t* leaves,
+                                   const Vec_size_t* indices);                                 /* ffi_tree.rs:147 */
+CBoolResult_t ffi_seq_atomic_operation(FFI_RLN_t** rln, const Vec_CFr_t* leaves,
+                                       const Vec_uint8_t* indices);                            /* ffi_tree.rs:170 */
+CFr_t* ffi_get_root(FFI_RLN_t* const* rln);                                                    /* ffi_tree.rs:191 */
+CResult_FFI_MerkleProof_ptr_Vec_uint8_t ffi_get_merkle_proof(FFI_RLN_t* const* rln, size_t index); /* ffi_tree.rs:196 */
+void ffi_merkle_proof_free(FFI_MerkleProof_t* proof);                                          /* ffi_tree.rs:21 */
+CBoolResult_t ffi_set_metadata(FFI_RLN_t** rln, const Vec_uint8_t* metadata);                  /* ffi_tree.rs:231 */
+CResult_Vec_uint8_Vec_uint8_t ffi_get_metadata(FFI_RLN_t* const* rln);                         /* ffi_tree.rs:244 */
+CBoolResult_t ffi_flush(FFI_RLN_t** rln);                                                      /* ffi_tree.rs:257 */
+
+/* ---- field / vector helpers (ffi_utils.rs) --------------------------------------------------------- */
+CFr_t* ffi_cfr_zero(void);                                                                     /* ffi_utils.rs:70 */
+CFr_t* ffi_cfr_one(void);                                                                      /* ffi_utils.rs:75 */
+CResult_Vec_uint8_Vec_uint8_t ffi_cfr_to_bytes_le(const CFr_t* cfr);                           /* ffi_utils.rs:80 */
+CResult_Vec_uint8_Vec_uint8_t ffi_cfr_to_bytes_be(const CFr_t* cfr);                           /* ffi_utils.rs:95 */
+CResult_CFr_ptr_Vec_uint8_t ffi_bytes_le_to_cfr(const Vec_uint8_t* bytes);                     /* ffi_utils.rs:110 */
+CResult_CFr_ptr_Vec_uint8_t ffi_bytes_be_to_cfr(const Vec_uint8_t* bytes);                     /* ffi_utils.rs:124 */
+CFr_t* ffi_uint_to_cfr(uint32_t value);                                                        /* ffi_utils.rs:138 */
+Vec_uint8_t ffi_cfr_debug(const CFr_t* cfr);                                                   /* ffi_utils.rs:143 */
+void ffi_cfr_free(CFr_t* cfr);                                                                 /* ffi_utils.rs:151 */
+Vec_CFr_t ffi_vec_cfr_new(size_t capacity);                                                    /* ffi_utils.rs:158 */
+Vec_CFr_t ffi_vec_cfr_from_cfr(const CFr_t* cfr);                                              /* ffi_utils.rs:163 */
+void ffi_vec_cfr_push(Vec_CFr_t* v, const CFr_t* cfr);                                         /* ffi_utils.rs:168 */
+size_t ffi_vec_cfr_len(const Vec_CFr_t* v);                                                    /* ffi_utils.rs:178 */
+const CFr_t* ffi_vec_cfr_get(const Vec_CFr_t* v, size_t i);                                    /* ffi_utils.rs:183 */
+CResult_Vec_uint8_Vec_uint8_t ffi_vec_cfr_to_bytes_le(const Vec_CFr_t* v);                     /* ffi_utils.rs:188 */
+CResult_Vec_uint8_Vec_uint8_t ffi_vec_cfr_to_bytes_be(const Vec_CFr_t* v);                     /* ffi_utils.rs:204 */
+CResult_Vec_CFr_Vec_uint8_t ffi_bytes_le_to_vec_cfr(const Vec_uint8_t* bytes);                 /* ffi_utils.rs:220 */
+CResult_Vec_CFr_Vec_uint8_t ffi_bytes_be_to_vec_cfr(const Vec_uint8_t* bytes);                 /* ffi_utils.rs:240 */
+Vec_uint8_t ffi_vec_cfr_debug(const Vec_CFr_t* v);                                             /* ffi_utils.rs:259 */
+void ffi_vec_cfr_free(Vec_CFr_t v);                                                            /* ffi_utils.rs:270 */
+CResult_Vec_uint8_Vec_uint8_t ffi_vec_u8_to_bytes_le(const Vec_uint8_t* v);                    /* ffi_utils.rs:277 */
+CResult_Vec_uint8_Vec_uint8_t ffi_vec_u8_to_bytes_be(const Vec_uint8_t* v);                    /* ffi_utils.rs:292 */
+CResult_Vec_uint8_Vec_uint8_t ffi_bytes_le_to_vec_u8(const Vec_uint8_t* bytes);                /* ffi_utils.rs:307 */
+CResult_Vec_uint8_Vec_uint8_t ffi_bytes_be_to_vec_u8(const Vec_uint8_t* bytes);                /* ffi_utils.rs:321 */
+Vec_uint8_t ffi_vec_u8_debug(const Vec_uint8_t* v);                                            /* ffi_utils.rs:335 */
+void ffi_vec_u8_free(Vec_uint8_t v);                                                           /* ffi_utils.rs:343 */
+CFr_t* ffi_hash_to_field_le(const Vec_uint8_t* input);                                         /* ffi_utils.rs:349 */
+CFr_t* ffi_hash_to_field_be(const Vec_uint8_t* input);                                         /* ffi_utils.rs:354 */
+CFr_t* ffi_poseidon_hash_pair(const CFr_t* a, const CFr_t* b);                                 /* ffi_utils.rs:359 */
+Vec_CFr_t ffi_key_gen(void);                                                                   /* ffi_utils.rs:366 */
+void ffi_c_string_free(Vec_uint8_t s);                                                         /* ffi_utils.rs:407 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLN_H */

@@ -1,0 +1,112 @@
+/* rln_amd.h -- batch / device-resident extension entry points of the MI355X RLN backend.
+ *
+ * The zerokit-compatible drop-in surface is include/rln.h (same symbols and struct layouts as the header
+ * safer-ffi generates from /root/reference/rln/src/ffi/).  The reference has NO batch, no deterministic
+ * (r, s) and no device-resident API (SURVEY.md §8b "Threading" / "Determinism gap"); the functions below
+ * add exactly those, with plain pointers and sizes only.  All field elements cross this boundary as
+ * 32-byte little-endian canonical integers (the form `fr_to_bytes_le` produces,
+ * /root/reference/rln/src/utils.rs:75-120).
+ *
+ * Every function returns 0 on success and a non-zero code on failure; the message is available from
+ * rlnamd_last_error() (thread-local).  There is no CPU fallback: without a HIP device every compute
+ * entry fails with RLNAMD_ERR_NO_DEVICE.
+ */
+#ifndef RLN_AMD_H
+#define RLN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RLNAMD_OK 0
+#define RLNAMD_ERR 1
+#define RLNAMD_ERR_NO_DEVICE 2
+
+#define RLNAMD_PROVER_STAGES 8
+
+const char* rlnamd_last_error(void);
+int rlnamd_device_count(void);
+int rlnamd_set_device(int ordinal);
+int rlnamd_device_name(char* buf, size_t cap);
+
+/* ---- hashing ----------------------------------------------------------------------------------------
+ * Batched Poseidon: poseidon_hash / poseidon_hash_pair (rln/src/hashers.rs:32-54) over n independent
+ * inputs.  inputs: n * arity * 32 bytes, out: n * 32 bytes (host memory). arity in {1,2,3}. */
+int rlnamd_poseidon_hash(const uint8_t* inputs_le, size_t n, size_t arity, uint8_t* out_le);
+/* hash_to_field_le / _be (rln/src/hashers.rs:73-93): Keccak-256 then reduction mod r.  Host only. */
+int rlnamd_hash_to_field_le(const uint8_t* data, size_t len, uint8_t out_le[32]);
+int rlnamd_hash_to_field_be(const uint8_t* data, size_t len, uint8_t out_le[32]);
+
+/* ---- HBM-resident Poseidon Merkle tree ---------------------------------------------------------------
+ * FullMerkleTree semantics (utils/src/merkle_tree/full_merkle_tree.rs). */
+typedef struct rlnamd_tree rlnamd_tree;
+int rlnamd_tree_new(size_t depth, rlnamd_tree** out);                         /* ::default(depth) :74-80 */
+void rlnamd_tree_free(rlnamd_tree* t);
+int rlnamd_tree_set_range(rlnamd_tree* t, size_t start, const uint8_t* leaves_le, size_t n); /* :197-223 */
+int rlnamd_tree_root(rlnamd_tree* t, uint8_t out_le[32]);                                    /* :137-139 */
+int rlnamd_tree_get_leaf(rlnamd_tree* t, size_t index, uint8_t out_le[32]);                  /* :149-154 */
+/* one proof: elems = depth*32 bytes bottom-up, bits = depth bytes (1 = node is a right child) :288-304 */
+int rlnamd_tree_proof(rlnamd_tree* t, size_t index, uint8_t* elems_le, uint8_t* bits);
+/* `count` proofs for leaves [first, first+count) copied back to host buffers */
+int rlnamd_tree_proofs(rlnamd_tree* t, size_t first, size_t count, uint8_t* elems_le, uint8_t* bits);
+/* Device-resident workload of BASELINE config 3: leaves first_value + i generated in HBM, full rebuild,
+ * all `count` proofs emitted into an internal HBM buffer and (if verify != 0) every proof recomputed to
+ * the root on the device.  ms[0] = build, ms[1] = proof emission (HIP events); bad = failed proofs. */
+int rlnamd_tree_fill_sequential(rlnamd_tree* t, size_t start, size_t n, uint64_t first_value);
+int rlnamd_tree_bench(rlnamd_tree* t, size_t n_leaves, uint64_t first_value, int verify, float ms[2], size_t* bad);
+
+/* ---- batched Groth16 prover --------------------------------------------------------------------------
+ * Replaces generate_zk_proof_with_rs (rln/src/protocol/proof.rs:753-777) + proof_values_from_witness
+ * (protocol/witness.rs:759-804) for n independent proofs at once. */
+typedef struct rlnamd_prover rlnamd_prover;
+/* zkey/graph: the bytes of rln_final.arkzkey and graph.bin (circuit/mod.rs:140-203).
+ * max_batch: workspace capacity; window_bits: 0 = default / RLNAMD_WINDOW_BITS. */
+int rlnamd_prover_new(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_t graph_len,
+                      size_t max_batch, int window_bits, rlnamd_prover** out);
+void rlnamd_prover_free(rlnamd_prover* p);
+typedef struct {
+  uint64_t inputs_size;      /* slots of the witness-graph inputs buffer (slot 0 = 1) */
+  uint64_t num_signals;      /* witness length */
+  uint64_t domain_size;      /* NTT domain */
+  uint64_t tree_depth, max_out;
+  uint64_t capacity;         /* max batch */
+  uint64_t table_bytes;      /* HBM held by the fixed-base tables */
+  int32_t window_bits, windows;
+} rlnamd_prover_info;
+int rlnamd_prover_get_info(rlnamd_prover* p, rlnamd_prover_info* info);
+/* offset/len of a named input signal in the inputs buffer (iden3calc.rs:122-146); returns RLNAMD_ERR if absent */
+int rlnamd_prover_input_slot(rlnamd_prover* p, const char* name, uint32_t* offset, uint32_t* len);
+/* inputs: n * inputs_size * 32 bytes (slot 0 must hold 1); rs: n * 64 bytes (r then s). */
+int rlnamd_prover_upload(rlnamd_prover* p, size_t n, const uint8_t* inputs_le, const uint8_t* rs_le);
+int rlnamd_prover_run(rlnamd_prover* p, size_t n);      /* inputs already resident; blocks until done */
+/* proofs: n*128 (ark-serialize compressed Proof), coords: n*256 (affine A|B|C) or NULL,
+ * values: n*160 (y, root, nullifier, x, external_nullifier) or NULL, errors: n*4 or NULL */
+int rlnamd_prover_download(rlnamd_prover* p, size_t n, uint8_t* proofs, uint8_t* coords, uint8_t* values,
+                           uint32_t* errors);
+int rlnamd_prover_stage_ms(rlnamd_prover* p, float ms[RLNAMD_PROVER_STAGES]);
+const char* rlnamd_prover_stage_name(int i);
+/* parity taps of the last run: full witness (num_signals*32) / h (domain_size*32) of proof `index` */
+int rlnamd_prover_fetch_witness(rlnamd_prover* p, size_t index, uint8_t* out_le);
+int rlnamd_prover_fetch_h(rlnamd_prover* p, size_t index, uint8_t* out_le);
+/* verify_zk_proof (protocol/proof.rs:856-894) on the host CPU, as in the reference.
+ * values: y, root, nullifier, x, external_nullifier.  *ok = 1 valid, 0 invalid. */
+int rlnamd_verify(rlnamd_prover* p, const uint8_t proof[128], const uint8_t values_le[160], int* ok);
+/* same check straight from arkzkey bytes; needs no GPU (host parser + host pairing only) */
+int rlnamd_verify_with_zkey(const uint8_t* zkey, size_t zkey_len, const uint8_t proof[128],
+                            const uint8_t values_le[160], int* ok);
+/* host-only parse of the two circuit resources (zkey_from_raw / graph_from_raw, circuit/mod.rs:140-203);
+ * counts[0..9] = instance vars, witness vars, constraints, a_nnz, b_nnz, |a_query|, |h_query|, |l_query|,
+ * graph nodes, witness signals; counts[10] = tree depth, counts[11] = max_out, counts[12] = inputs size. */
+int rlnamd_parse_resources(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_t graph_len,
+                           uint64_t counts[13]);
+/* ark-serialize point compression helpers (host): coords = A.x A.y B.x.c0 B.x.c1 B.y.c0 B.y.c1 C.x C.y */
+int rlnamd_proof_compress(const uint8_t coords_le[256], uint8_t proof[128]);
+int rlnamd_proof_decompress(const uint8_t proof[128], uint8_t coords_le[256]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLN_AMD_H */

@@ -1,0 +1,65 @@
+// CPU build of the product's __host__ __device__ math (zerokit_amd/csrc/{field,curve}.h) behind a tiny
+// C interface so tests/test_host_math.py can compare it with the Python oracle without a GPU.
+// Test infrastructure only: nothing in the product links this.
+#include <string.h>
+
+#include "curve.h"
+using namespace rlnamd;
+
+template <class F> static F ld(const uint8_t* p) { uint32_t c[8]; memcpy(c, p, 32); return F::from_canonical(c); }
+template <class F> static void st(uint8_t* p, const F& x) { uint32_t c[8]; x.to_canonical(c); memcpy(p, c, 32); }
+static Fq2 ld2(const uint8_t* p) { return {ld<Fq>(p), ld<Fq>(p + 32)}; }
+static void st2(uint8_t* p, const Fq2& x) { st(p, x.c0); st(p + 32, x.c1); }
+
+extern "C" {
+// op: 0 add 1 sub 2 mul 3 inv 4 neg 5 sqr ; field: 0 Fr 1 Fq
+void hm_fp_op(int field, int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  if (field == 0) {
+    Fr x = ld<Fr>(a), y = ld<Fr>(b), r;
+    r = op == 0 ? x + y : op == 1 ? x - y : op == 2 ? x * y : op == 3 ? x.inv() : op == 4 ? x.neg() : x.sqr();
+    st(out, r);
+  } else {
+    Fq x = ld<Fq>(a), y = ld<Fq>(b), r;
+    r = op == 0 ? x + y : op == 1 ? x - y : op == 2 ? x * y : op == 3 ? x.inv() : op == 4 ? x.neg() : x.sqr();
+    st(out, r);
+  }
+}
+void hm_fq2_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  Fq2 x = ld2(a), y = ld2(b), r;
+  r = op == 0 ? x + y : op == 1 ? x - y : op == 2 ? x * y : op == 3 ? x.inv() : op == 4 ? x.neg() : x.sqr();
+  st2(out, r);
+}
+// G1: points as x||y canonical (0,0 = infinity)
+static G1Affine ldg1(const uint8_t* p) { return {ld<Fq>(p), ld<Fq>(p + 32)}; }
+static void stg1(uint8_t* p, const G1Affine& a) { st(p, a.x); st(p + 32, a.y); }
+static G2Affine ldg2(const uint8_t* p) { return {ld2(p), ld2(p + 64)}; }
+static void stg2(uint8_t* p, const G2Affine& a) { st2(p, a.x); st2(p + 64, a.y); }
+
+void hm_g1_add(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  G1XYZZ acc = G1XYZZ::from_affine(ldg1(a));
+  acc.madd(ldg1(b));
+  stg1(out, acc.to_affine());
+}
+void hm_g1_add_full(const uint8_t* a, const uint8_t* b, uint8_t* out) {  // exercises add-2008-s via 3P forms
+  G1XYZZ x = G1XYZZ::dbl_affine(ldg1(a));  // 2a (non-trivial ZZ)
+  G1XYZZ y = G1XYZZ::dbl_affine(ldg1(b));
+  y = y.dbl();                               // 4b
+  x.add(y);
+  stg1(out, x.to_affine());                  // 2a + 4b
+}
+void hm_g1_mul(const uint8_t* a, const uint8_t* k, uint8_t* out) {
+  uint32_t kk[8];
+  memcpy(kk, k, 32);
+  stg1(out, scalar_mul(ldg1(a), kk).to_affine());
+}
+void hm_g2_add(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  G2XYZZ acc = G2XYZZ::from_affine(ldg2(a));
+  acc.madd(ldg2(b));
+  stg2(out, acc.to_affine());
+}
+void hm_g2_mul(const uint8_t* a, const uint8_t* k, uint8_t* out) {
+  uint32_t kk[8];
+  memcpy(kk, k, 32);
+  stg2(out, scalar_mul(ldg2(a), kk).to_affine());
+}
+}

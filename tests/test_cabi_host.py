@@ -1,0 +1,207 @@
+"""CPU-only checks of the C-ABI library: it loads, exports every symbol include/*.h declares, fails loudly
+without a GPU, and its host-side logic (parsers, Keccak, point compression, the Groth16 verifier, wire
+formats) agrees with the oracle / the reference's vectors.  No compute call here needs a GPU."""
+import ctypes as C
+import json
+import os
+import re
+
+import pytest
+
+from oracle.pyref import arkzkey as o_zkey
+from oracle.pyref.keccak import hash_to_field_le as o_htf
+from zerokit_amd import _native, hashers
+from zerokit_amd._native import lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RES = os.path.join(ROOT, "zerokit_amd", "resources", "tree_depth_20")
+
+
+def _decls(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:ffi|rlnamd)_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = lib()
+    names = _decls("rln.h") + _decls("rln_amd.h")
+    assert len(names) > 100
+    for n in names:
+        assert hasattr(L, n), "missing export " + n
+        assert n in _native.SIGNATURES, "no ctypes signature for " + n
+
+
+def test_no_cpu_fallback_without_gpu():
+    if lib().rlnamd_device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(_native.RLNError, match="no HIP device"):
+        hashers.poseidon_hash([1, 2])
+    h = C.c_void_p()
+    z = open(os.path.join(RES, "rln_final.arkzkey"), "rb").read()
+    g = open(os.path.join(RES, "graph.bin"), "rb").read()
+    assert lib().rlnamd_prover_new(z, len(z), g, len(g), 64, 0, C.byref(h)) == 2  # RLNAMD_ERR_NO_DEVICE
+    assert lib().rlnamd_tree_new(4, C.byref(h)) == 2
+
+
+def test_hash_to_field_matches_oracle():
+    for s in (b"", b"test-merkle-proof", b"hey hey", b"x" * 135, b"y" * 136, b"z" * 137, bytes(range(256)) * 3):
+        assert hashers.hash_to_field_le(s) == o_htf(s)
+        assert hashers.hash_to_field_be(s) == o_htf(s)
+
+
+def test_parse_resources_counts():
+    z = open(os.path.join(RES, "rln_final.arkzkey"), "rb").read()
+    g = open(os.path.join(RES, "graph.bin"), "rb").read()
+    counts = (C.c_uint64 * 13)()
+    assert lib().rlnamd_parse_resources(z, len(z), g, len(g), counts) == 0, _native.last_error()
+    assert list(counts) == [6, 5839, 5820, 9658, 13282, 5844, 8192, 5838, 23414, 5844, 20, 1, 46]
+    # loader error cases (circuit/mod.rs:333-368)
+    assert lib().rlnamd_parse_resources(b"", 0, g, len(g), counts) != 0
+    assert "Empty" in _native.last_error()
+    assert lib().rlnamd_parse_resources(z, len(z), b"not a graph file....", 20, counts) != 0
+    assert "magic" in _native.last_error().lower()
+    assert lib().rlnamd_parse_resources(z[:1000], 1000, g, len(g), counts) != 0
+
+
+def _vec(name):
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", "rln_h20_vectors.json")))
+    return next(c for c in d["cases"] if c["name"] == name)
+
+
+SNARKJS_PROOF = (  # rln/tests/public.rs:84-135
+    (606446415626469993821291758185575230335423926365686267140465300918089871829,
+     14881534001609371078663128199084130129622943308489025453376548677995646280161),
+    ((18053812507994813734583839134426913715767914942522332114506614735770984570178,
+      11219916332635123001710279198522635266707985651975761715977705052386984005181),
+     (17371289494006920912949790045699521359436706797224428511776122168520286372970,
+      14038575727257298083893642903204723310279435927688342924358714639926373603890)),
+    (17701377127561410274754535747274973758826089226897242202671882899370780845888,
+     12608543716397255084418384146504333522628400182843246910626782513289789807030))
+SNARKJS_PUBLIC = [  # y, root, nullifier, x, external_nullifier
+    16401008481486069296141645075505218976370369489687327284155463920202585288271,
+    8502402278351299594663821509741133196466235670407051417832304486953898514733,
+    9102791780887227194595604713537772536258726662792598131262022534710887343694,
+    20645213238265527935869146898028115621427162613172918400241870500502509785943,
+    21074405743803627666274838159589343934394162804826017440941339048886754734203]
+
+
+def _verify(proof128, public):
+    z = open(os.path.join(RES, "rln_final.arkzkey"), "rb").read()
+    ok = C.c_int(-1)
+    rc = lib().rlnamd_verify_with_zkey(z, len(z), proof128, b"".join(v.to_bytes(32, "little") for v in public),
+                                       C.byref(ok))
+    assert rc == 0, _native.last_error()
+    return bool(ok.value)
+
+
+def test_host_verifier_snarkjs_kat_and_goldens():
+    proof = o_zkey.proof_compress(*SNARKJS_PROOF)
+    assert _verify(proof, SNARKJS_PUBLIC)
+    wrong = [SNARKJS_PUBLIC[i] for i in (1, 4, 3, 0, 2)]  # serialisation order must fail
+    assert not _verify(proof, wrong)
+    bad = list(SNARKJS_PUBLIC)
+    bad[0] = (bad[0] + 1) % hashers.R
+    assert not _verify(proof, bad)
+    v = _vec("config1_bench_witness")
+    assert _verify(bytes.fromhex(v["proof_compressed"]), [int(x) for x in v["public_inputs"]])
+    # swapping A and C keeps both on the curve but breaks the equation
+    p = bytes.fromhex(v["proof_compressed"])
+    assert not _verify(p[96:128] + p[32:96] + p[0:32], [int(x) for x in v["public_inputs"]])
+
+
+def test_point_compression_matches_oracle():
+    for name in ("config1_bench_witness", "survey_appendix_d", "config2_1"):
+        v = _vec(name)
+        coords = [int(v["a"][0]), int(v["a"][1]), int(v["b"][0][0]), int(v["b"][0][1]), int(v["b"][1][0]),
+                  int(v["b"][1][1]), int(v["c"][0]), int(v["c"][1])]
+        raw = b"".join(c.to_bytes(32, "little") for c in coords)
+        out = C.create_string_buffer(128)
+        assert lib().rlnamd_proof_compress(raw, out) == 0
+        assert out.raw.hex() == v["proof_compressed"]
+        back = C.create_string_buffer(256)
+        assert lib().rlnamd_proof_decompress(out.raw, back) == 0
+        assert back.raw == raw
+    junk = C.create_string_buffer(256)
+    assert lib().rlnamd_proof_decompress(b"\x04" + bytes(127), junk) != 0  # x = 4 is not on the curve
+
+
+def test_ffi_field_and_vector_helpers():
+    from zerokit_amd.public import _cfr, _take_bytes, _vec_cfr, _vec_u8, _take_cfr
+    L = lib()
+    x = 0x1234567890ABCDEF << 100
+    le = _take_bytes(L.ffi_cfr_to_bytes_le(C.byref(_cfr(x))))
+    be = _take_bytes(L.ffi_cfr_to_bytes_be(C.byref(_cfr(x))))
+    assert le == x.to_bytes(32, "little") and be == x.to_bytes(32, "big")
+    v, _k = _vec_u8(be)
+    r = L.ffi_bytes_be_to_cfr(C.byref(v))
+    assert r.ok and _take_cfr(C.cast(C.c_void_p(r.ok), C.POINTER(_native.CFr))) == x
+    # non-canonical element is rejected (serialize.rs:108-110)
+    v, _k = _vec_u8(hashers.R.to_bytes(32, "little"))
+    r = L.ffi_bytes_le_to_cfr(C.byref(v))
+    assert not r.ok and b"Non-canonical" in C.string_at(r.err.ptr, r.err.len)
+    # Vec<Fr>: 8-byte length prefix + elements (utils.rs:123-156)
+    vals = [1, 2, hashers.R - 1]
+    vc, _k = _vec_cfr(vals)
+    b_le = _take_bytes(L.ffi_vec_cfr_to_bytes_le(C.byref(vc)))
+    assert b_le == (3).to_bytes(8, "little") + b"".join(t.to_bytes(32, "little") for t in vals)
+    b_be = _take_bytes(L.ffi_vec_cfr_to_bytes_be(C.byref(vc)))
+    assert b_be == (3).to_bytes(8, "big") + b"".join(t.to_bytes(32, "big") for t in vals)
+    vb, _k = _vec_u8(b_be)
+    rr = L.ffi_bytes_be_to_vec_cfr(C.byref(vb))
+    assert rr.ok.len == 3 and int.from_bytes(bytes(rr.ok.ptr[2].le), "little") == hashers.R - 1
+    L.ffi_vec_cfr_free(rr.ok)
+    # push / get / len
+    vec = L.ffi_vec_cfr_new(0)
+    for t in range(10):
+        L.ffi_vec_cfr_push(C.byref(vec), C.byref(_cfr(t * t)))
+    assert L.ffi_vec_cfr_len(C.byref(vec)) == 10
+    assert int.from_bytes(bytes(L.ffi_vec_cfr_get(C.byref(vec), 7).contents.le), "little") == 49
+    assert not L.ffi_vec_cfr_get(C.byref(vec), 10)
+    L.ffi_vec_cfr_free(vec)
+    dbg = L.ffi_cfr_debug(C.byref(_cfr(12345)))
+    assert C.string_at(dbg.ptr) == b"12345"
+    L.ffi_c_string_free(dbg)
+
+
+def test_witness_and_proof_wire_formats():
+    """rln/tests/serialize.rs round trips + the 837 / 290 byte sizes of SURVEY Appendix B."""
+    from zerokit_amd.public import RLNProof, RLNWitnessInput, RLNError
+    v = _vec("config1_bench_witness")
+    w = v["witness"]
+    wi = RLNWitnessInput(int(w["identity_secret"]), 100, 1, [int(t) for t in w["path_elements"]],
+                         [int(t) for t in w["identity_path_index"]], int(w["x"]), int(w["external_nullifier"]))
+    le, be = wi.to_bytes_le(), wi.to_bytes_be()
+    assert len(le) == 837 and len(be) == 837 and le[0] == 0
+    assert le[1:33] == int(w["identity_secret"]).to_bytes(32, "little")
+    assert be[1:33] == int(w["identity_secret"]).to_bytes(32, "big")
+    assert le[97:105] == (20).to_bytes(8, "little") and be[97:105] == (20).to_bytes(8, "big")
+    assert RLNWitnessInput.from_bytes_le(le).to_bytes_be() == be
+    assert RLNWitnessInput.from_bytes_be(be).to_bytes_le() == le
+    with pytest.raises(RLNError, match="too short"):
+        RLNWitnessInput.from_bytes_le(le[:-1])
+    with pytest.raises(RLNError, match="Expected to read"):
+        RLNWitnessInput.from_bytes_le(le + b"\0")
+    # validation (witness.rs:87-107)
+    with pytest.raises(RLNError, match="cannot be zero"):
+        RLNWitnessInput(1, 0, 0, [1], [0], 1, 1)
+    with pytest.raises(RLNError, match="length mismatch"):
+        RLNWitnessInput(1, 10, 0, [1, 2], [0], 1, 1)
+    with pytest.raises(RLNError, match="not within user_message_limit"):
+        RLNWitnessInput(1, 10, 10, [1], [0], 1, 1)
+    # proof: golden 290-byte LE form parses, re-serialises identically, BE form differs only in the values
+    raw = bytes.fromhex(v["rln_proof_le"])
+    assert len(raw) == 290
+    p = RLNProof.from_bytes_le(raw)
+    assert p.to_bytes_le() == raw
+    be = p.to_bytes_be()
+    assert be[:130] == raw[:130] and be[130:162] == raw[130:162][::-1]
+    assert RLNProof.from_bytes_be(be).to_bytes_le() == raw
+    vals = p.values
+    assert [vals.y, vals.root, vals.nullifier, vals.x, vals.external_nullifier] == [int(t) for t in v["public_inputs"]]
+    with pytest.raises(RLNError):
+        RLNProof.from_bytes_le(raw[:200])
+    with pytest.raises(RLNError, match="version byte"):
+        RLNProof.from_bytes_le(b"\x07" + raw[1:])
+    with pytest.raises(RLNError, match="invalid data"):
+        RLNProof.from_bytes_le(raw[:1] + b"\x04" + bytes(31) + raw[33:])  # x = 4 is not on the curve

@@ -1,0 +1,241 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the oracle and the committed golden
+vectors.  Bit-exact everywhere (integer arithmetic): no tolerances."""
+import hashlib
+import json
+import os
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def _cases():
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "rln_h20_vectors.json")))
+
+
+def _w(case):
+    w = case["witness"]
+    return dict(identity_secret=int(w["identity_secret"]), user_message_limit=int(w["user_message_limit"]),
+                message_id=int(w["message_id"]), path_elements=[int(t) for t in w["path_elements"]],
+                identity_path_index=[int(t) for t in w["identity_path_index"]], x=int(w["x"]),
+                external_nullifier=int(w["external_nullifier"]))
+
+
+def _digest(vals):
+    return hashlib.sha256(b"".join(v.to_bytes(32, "little") for v in vals)).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def prover():
+    from zerokit_amd.batch import BatchProver
+    p = BatchProver(max_batch=128)
+    yield p
+    p.close()
+
+
+# ------------------------------------------------------------------------------------------ Poseidon
+def test_poseidon_kats_and_random_vs_oracle():
+    from oracle.pyref.poseidon import poseidon
+    from zerokit_amd import hashers
+    # utils/tests/poseidon_hash_test.rs:21-66
+    assert hashers.poseidon_hash([0]) == 19014214495641488759237505126948346942972912379615652741039992445865937985820
+    assert hashers.poseidon_hash([1]) == 18586133768512220936620570745912940619677854269274689475585506675881198879027
+    assert hashers.poseidon_hash([0xFFFFFFFFFFFFFFFF]) == \
+        17449307747295017006142981453320720946812828330895590310359634430146721583189
+    # :69-130
+    assert hashers.poseidon_hash_pair(0, 1) == \
+        12583541437132735734108669866114103169564651237895298778035846191048104863326
+    rnd = random.Random(7)
+    for arity in (1, 2, 3):
+        rows = [[rnd.randrange(R) for _ in range(arity)] for _ in range(300)]
+        rows[0] = [0] * arity
+        rows[1] = [R - 1] * arity
+        got = hashers.poseidon_hash_batch(rows)
+        assert got == [poseidon(r) for r in rows]
+    with pytest.raises(Exception):
+        hashers.poseidon_hash([1, 2, 3, 4])  # no parameters on this path for t = 5
+    with pytest.raises(Exception, match="Non-canonical"):
+        hashers.poseidon_hash([R])
+
+
+# ------------------------------------------------------------------------------------------ tree
+def test_depth20_tree_kat():
+    """rln/tests/protocol.rs:14-87 == rln/tests/ffi.rs:325-423"""
+    from tests.test_oracle_kats import PATH_KAT, ROOT_LIMBS
+    from zerokit_amd import hashers
+    from zerokit_amd.batch import PoseidonTree
+    t = PoseidonTree(20)
+    assert t.root() == 0x2134e76ac5d21aab186c2be1dd8f84ee880a1e46eaf712f9d371b6df22191f3e  # empty tree
+    secret = hashers.hash_to_field_le(b"test-merkle-proof")
+    rate_commitment = hashers.poseidon_hash_pair(hashers.poseidon_hash([secret]), 100)
+    t.set(3, rate_commitment)
+    assert t.root() == sum(l << (64 * i) for i, l in enumerate(ROOT_LIMBS))
+    elems, bits = t.proof(3)
+    assert elems == [int(x, 16) for x in PATH_KAT]
+    assert bits == [1, 1] + [0] * 18
+    assert t.get(3) == rate_commitment and t.get(2) == 0
+
+
+def test_tree_ragged_ranges_vs_oracle():
+    from oracle.pyref.rln import FullMerkleTree
+    from zerokit_amd.batch import PoseidonTree
+    rnd = random.Random(11)
+    for depth in (1, 3, 7):
+        ref, dev = FullMerkleTree(depth), PoseidonTree(depth)
+        assert dev.root() == ref.root()
+        cap = 1 << depth
+        for _ in range(6):
+            start = rnd.randrange(cap)
+            n = rnd.randrange(1, cap - start + 1)
+            leaves = [rnd.randrange(R) for _ in range(n)]
+            ref.set_range(start, leaves)
+            dev.set_range(start, leaves)
+            assert dev.root() == ref.root()
+        for i in (0, cap - 1, rnd.randrange(cap)):
+            assert dev.proof(i) == ref.proof(i)
+            assert dev.get(i) == ref.get(i)
+        allp = dev.proofs(0, cap)
+        assert allp == [ref.proof(i) for i in range(cap)]
+        with pytest.raises(Exception):
+            dev.set_range(cap - 1, [1, 2])      # TooManySet
+        with pytest.raises(Exception):
+            dev.proof(cap)                       # InvalidLeaf
+    d0 = PoseidonTree(0)
+    d0.set(0, 5)
+    assert d0.root() == 5 and d0.proof(0) == ([], [])
+
+
+def test_tree_config3_small_and_checksum():
+    """BASELINE config 3 at 2^12 leaves: leaves i+1, all paths recompute the root on the device; root and
+    sampled paths equal the oracle."""
+    from oracle.pyref.rln import FullMerkleTree
+    from zerokit_amd.batch import PoseidonTree
+    depth = 12
+    dev = PoseidonTree(depth)
+    res = dev.bench(1 << depth, first_value=1, verify=True)
+    assert res["bad"] == 0
+    ref = FullMerkleTree(depth)
+    ref.set_range(0, list(range(1, (1 << depth) + 1)))
+    assert dev.root() == ref.root()
+    for i in (0, 1, 2047, 4095):
+        assert dev.proof(i) == ref.proof(i)
+
+
+# ------------------------------------------------------------------------------------------ prover
+def test_witness_and_h_vs_golden(prover):
+    cases = _cases()["cases"]
+    ws = [_w(c) for c in cases]
+    rs = [(int(c["r"]), int(c["s"])) for c in cases]
+    out = prover.prove(ws, rs)
+    for i, c in enumerate(cases):
+        assert out[i]["error"] == 0
+        full = prover.fetch_witness(i)
+        assert full[0] == 1 and [str(v) for v in full[1:6]] == c["public_inputs"]
+        assert _digest(full) == c["witness_sha256"], c["name"]
+        h = prover.fetch_h(i)
+        assert [str(h[0]), str(h[1])] == c["h_first"] and str(h[-1]) == c["h_last"]
+        assert _digest(h) == c["h_sha256"], c["name"]
+
+
+def test_proofs_bit_exact_vs_golden_and_verify(prover):
+    cases = _cases()["cases"]
+    out = prover.prove([_w(c) for c in cases], [(int(c["r"]), int(c["s"])) for c in cases])
+    for o, c in zip(out, cases):
+        assert [str(v) for v in o["public_inputs"]] == c["public_inputs"], c["name"]
+        assert [str(o["a"][0]), str(o["a"][1])] == c["a"], c["name"]
+        assert [[str(o["b"][0][0]), str(o["b"][0][1])], [str(o["b"][1][0]), str(o["b"][1][1])]] == c["b"], c["name"]
+        assert [str(o["c"][0]), str(o["c"][1])] == c["c"], c["name"]
+        assert o["proof"].hex() == c["proof_compressed"], c["name"]
+        assert prover.verify(o["proof"], o["public_inputs"])
+        bad = list(o["public_inputs"])
+        bad[2] = (bad[2] + 1) % R
+        assert not prover.verify(o["proof"], bad)
+
+
+def test_batch_vs_python_oracle_random(prover):
+    """config-2 generator, 70 proofs (crosses a 64-lane boundary): every proof verifies; 2 sampled proofs
+    are recomputed by the Python oracle and must be bit-identical."""
+    from oracle.pyref import arkzkey, groth16, rln, workload, wtns_graph
+    ws, rs = workload.config2_witnesses(70, seed=0xABCDEF)
+    out = prover.prove(ws, rs)
+    assert all(o["error"] == 0 for o in out)
+    for o in out:
+        assert prover.verify(o["proof"], o["public_inputs"])
+    zk, g = rln.load_circuit(20)
+    for i in (5, 69):
+        w = ws[i]
+        wi = rln.WitnessInput(w["identity_secret"], w["user_message_limit"], w["message_id"], w["path_elements"],
+                              w["identity_path_index"], w["x"], w["external_nullifier"])
+        proof, full = rln.generate_zk_proof_with_rs(zk, g, wi, rs[i][0], rs[i][1])
+        assert arkzkey.proof_compress(*proof) == out[i]["proof"]
+        assert rln.public_inputs(rln.proof_values_from_witness(wi)) == out[i]["public_inputs"]
+
+
+def test_batch_is_order_and_size_independent(prover):
+    """the same witness gives the same proof alone, in a batch, and at a different lane"""
+    from oracle.pyref import workload
+    ws, rs = workload.config2_witnesses(9, seed=99)
+    a = prover.prove(ws, rs)
+    b = prover.prove(ws[::-1], rs[::-1])[::-1]
+    c = prover.prove([ws[4]], [rs[4]])
+    assert [o["proof"] for o in a] == [o["proof"] for o in b]
+    assert c[0]["proof"] == a[4]["proof"]
+
+
+# ------------------------------------------------------------------------------------------ zerokit FFI
+def test_ffi_round_trip_like_reference_tests():
+    """rln/tests/protocol.rs:182-198 (prove -> verify) and :222-248 (fixed r=44, s=77 is deterministic),
+    rln/tests/public.rs:349-427 (tree ops equivalence), through the zerokit C ABI."""
+    from zerokit_amd import hashers
+    from zerokit_amd.public import RLN, RLNError, RLNWitnessInput
+    c = next(x for x in _cases()["cases"] if x["name"] == "config1_bench_witness")
+    rln = RLN(20)
+    secret = hashers.hash_to_field_le(b"test-merkle-proof")
+    rate_commitment = hashers.poseidon_hash_pair(hashers.poseidon_hash([secret]), 100)
+    rln.set_leaf(3, rate_commitment)
+    assert str(rln.get_root()) == _cases()["tree_root_config1"]
+    elems, bits = rln.get_merkle_proof(3)
+    w = _w(c)
+    assert elems == w["path_elements"] and bits == w["identity_path_index"]
+    wi = RLNWitnessInput(secret, 100, 1, elems, bits, w["x"], w["external_nullifier"])
+    p1 = rln.generate_rln_proof_with_rs(wi, 44, 77)
+    assert p1.to_bytes_le().hex() == c["rln_proof_le"]
+    assert rln.verify_rln_proof(p1, w["x"])
+    p2 = rln.generate_rln_proof(wi)                       # random blinding: different bytes, still valid
+    assert p2.to_bytes_le() != p1.to_bytes_le()
+    assert rln.verify_rln_proof(p2, w["x"])
+    assert rln.verify_with_roots(p2, w["x"], []) and rln.verify_with_roots(p2, w["x"], [5, rln.get_root()])
+    with pytest.raises(RLNError, match="Signal value does not match"):
+        rln.verify_rln_proof(p2, w["x"] + 1)
+    with pytest.raises(RLNError, match="Expected one of the provided roots"):
+        rln.verify_with_roots(p2, w["x"], [1, 2])
+    rln.set_leaf(4, 7)                                    # root moves: proof no longer matches the tree
+    with pytest.raises(RLNError, match="Expected one of the provided roots"):
+        rln.verify_rln_proof(p2, w["x"])
+    # batch extension == single calls
+    many = rln.generate_rln_proofs_batch([wi, wi], rs=[(44, 77), (1, 2)])
+    assert many[0].to_bytes_le() == p1.to_bytes_le()
+    # wrong path length is rejected before any kernel runs (proof.rs:644-662)
+    with pytest.raises(RLNError, match="path_elements"):
+        rln.generate_rln_proof(RLNWitnessInput(secret, 100, 1, elems[:19], bits[:19], 1, 2))
+    # tree ops: single / next / batch insertion agree (public.rs tests :349-427)
+    leaves = [hashers.poseidon_hash([i + 1]) for i in range(9)]
+    a, b, d = RLN(20), RLN(20), RLN(20)
+    for i, l in enumerate(leaves):
+        a.set_leaf(i, l)
+        b.set_next_leaf(l)
+    d.init_tree_with_leaves(leaves)
+    assert a.get_root() == b.get_root() == d.get_root()
+    assert a.leaves_set() == b.leaves_set() == d.leaves_set() == 9
+    d.set_leaves_from(9, leaves[:3])
+    a.atomic_operation(9, leaves[:3], [])
+    assert a.get_root() == d.get_root() and a.leaves_set() == 12
+    a.delete_leaf(10)
+    assert a.get_leaf(10) == 0 and a.leaves_set() == 12
+    a.delete_leaf(500)                                    # >= next_index: no-op
+    a.set_tree(20)
+    assert a.get_root() == RLN(20).get_root() and a.leaves_set() == 0

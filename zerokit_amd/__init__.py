@@ -1,0 +1,12 @@
+"""zerokit_amd -- MI355X-native RLN proving backend behind zerokit's `rln::public` / C-FFI surface.
+
+Host-side mirror (Python over ctypes) of the reference's operator interface for the proving hot path:
+  zerokit_amd.public.RLN        <-> rln::public::RLN          (/root/reference/rln/src/public.rs:65-771)
+  zerokit_amd.hashers           <-> rln::hashers              (/root/reference/rln/src/hashers.rs)
+  zerokit_amd.batch.BatchProver <-> (extension) n x generate_zk_proof_with_rs (protocol/proof.rs:753-777)
+  zerokit_amd.batch.PoseidonTree<-> utils FullMerkleTree       (utils/src/merkle_tree/full_merkle_tree.rs)
+All compute goes through zerokit_amd/lib/librln.so (HIP kernels for gfx950); nothing here computes.
+"""
+from ._native import LIB_PATH, NativeMissing, RLNError, lib  # noqa: F401
+
+__all__ = ["lib", "LIB_PATH", "NativeMissing", "RLNError"]

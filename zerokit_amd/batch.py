@@ -1,0 +1,192 @@
+"""Extension surface (include/rln_amd.h): device-resident batch prover and Poseidon tree."""
+import ctypes as C
+import os
+
+from ._native import ProverInfo, RLNError, check, lib
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+STAGES = 8
+
+
+def resource_paths(depth=20):
+    d = os.path.join(_HERE, "resources", "tree_depth_%d" % depth)
+    return os.path.join(d, "rln_final.arkzkey"), os.path.join(d, "graph.bin")
+
+
+def _b(x: int) -> bytes:
+    return int(x).to_bytes(32, "little")
+
+
+class BatchProver:
+    """n x generate_zk_proof_with_rs (/root/reference/rln/src/protocol/proof.rs:753-777) +
+    proof_values_from_witness (protocol/witness.rs:759-804) in one device batch."""
+
+    def __init__(self, zkey: bytes = None, graph: bytes = None, max_batch=1024, window_bits=0, depth=20):
+        if zkey is None or graph is None:
+            zp, gp = resource_paths(depth)
+            zkey, graph = open(zp, "rb").read(), open(gp, "rb").read()
+        self._h = C.c_void_p()
+        check(lib().rlnamd_prover_new(zkey, len(zkey), graph, len(graph), max_batch, window_bits, C.byref(self._h)))
+        info = ProverInfo()
+        check(lib().rlnamd_prover_get_info(self._h, C.byref(info)))
+        self.info = info
+        self.inputs_size = int(info.inputs_size)
+        self.slots = {}
+        for name in ("identitySecret", "userMessageLimit", "messageId", "pathElements", "identityPathIndex", "x",
+                     "externalNullifier"):
+            off, ln = C.c_uint32(), C.c_uint32()
+            check(lib().rlnamd_prover_input_slot(self._h, name.encode(), C.byref(off), C.byref(ln)))
+            self.slots[name] = (off.value, ln.value)
+
+    def close(self):
+        if self._h:
+            lib().rlnamd_prover_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def pack_inputs(self, witnesses):
+        """witnesses: dicts with identity_secret, user_message_limit, message_id, path_elements,
+        identity_path_index, x, external_nullifier (ints).  -> bytes (n * inputs_size * 32), the
+        witness-graph inputs buffer of iden3calc.rs:122-181 (slot 0 = 1)."""
+        out = bytearray(len(witnesses) * self.inputs_size * 32)
+        names = {"identitySecret": "identity_secret", "userMessageLimit": "user_message_limit",
+                 "messageId": "message_id", "pathElements": "path_elements",
+                 "identityPathIndex": "identity_path_index", "x": "x", "externalNullifier": "external_nullifier"}
+        for i, w in enumerate(witnesses):
+            base = i * self.inputs_size * 32
+            out[base] = 1
+            for sig, key in names.items():
+                off, ln = self.slots[sig]
+                v = w[key]
+                vals = list(v) if isinstance(v, (list, tuple)) else [v]
+                if len(vals) != ln:
+                    raise RLNError("invalid input length for %s: expected %d, got %d" % (sig, ln, len(vals)))
+                for k, x in enumerate(vals):
+                    out[base + (off + k) * 32: base + (off + k + 1) * 32] = _b(x)
+        return bytes(out)
+
+    def upload(self, inputs: bytes, rs):
+        n = len(inputs) // (self.inputs_size * 32)
+        rsb = b"".join(_b(r) + _b(s) for r, s in rs)
+        assert len(rsb) == 64 * n
+        check(lib().rlnamd_prover_upload(self._h, n, inputs, rsb))
+        return n
+
+    def run(self, n):
+        check(lib().rlnamd_prover_run(self._h, n))
+
+    def download(self, n):
+        proofs = C.create_string_buffer(128 * n)
+        coords = C.create_string_buffer(256 * n)
+        values = C.create_string_buffer(160 * n)
+        errs = (C.c_uint32 * n)()
+        check(lib().rlnamd_prover_download(self._h, n, proofs, coords, values, errs))
+        out = []
+        for i in range(n):
+            c = coords.raw[256 * i:256 * (i + 1)]
+            co = [int.from_bytes(c[32 * k:32 * k + 32], "little") for k in range(8)]
+            v = values.raw[160 * i:160 * (i + 1)]
+            vals = [int.from_bytes(v[32 * k:32 * k + 32], "little") for k in range(5)]
+            out.append(dict(proof=proofs.raw[128 * i:128 * (i + 1)],
+                            a=(co[0], co[1]), b=((co[2], co[3]), (co[4], co[5])), c=(co[6], co[7]),
+                            values=dict(y=vals[0], root=vals[1], nullifier=vals[2], x=vals[3],
+                                        external_nullifier=vals[4]),
+                            public_inputs=vals, error=int(errs[i])))
+        return out
+
+    def prove(self, witnesses, rs):
+        n = self.upload(self.pack_inputs(witnesses), rs)
+        self.run(n)
+        return self.download(n)
+
+    def stage_ms(self):
+        ms = (C.c_float * STAGES)()
+        check(lib().rlnamd_prover_stage_ms(self._h, ms))
+        return {lib().rlnamd_prover_stage_name(i).decode(): float(ms[i]) for i in range(STAGES)}
+
+    def fetch_witness(self, index):
+        n = int(self.info.num_signals)
+        buf = C.create_string_buffer(32 * n)
+        check(lib().rlnamd_prover_fetch_witness(self._h, index, buf))
+        return [int.from_bytes(buf.raw[32 * i:32 * i + 32], "little") for i in range(n)]
+
+    def fetch_h(self, index):
+        n = int(self.info.domain_size)
+        buf = C.create_string_buffer(32 * n)
+        check(lib().rlnamd_prover_fetch_h(self._h, index, buf))
+        return [int.from_bytes(buf.raw[32 * i:32 * i + 32], "little") for i in range(n)]
+
+    def verify(self, proof: bytes, public_inputs):
+        """verify_zk_proof (protocol/proof.rs:856-894); public_inputs = [y, root, nullifier, x, ext]."""
+        ok = C.c_int()
+        check(lib().rlnamd_verify(self._h, proof, b"".join(_b(v) for v in public_inputs), C.byref(ok)))
+        return bool(ok.value)
+
+
+class PoseidonTree:
+    """HBM-resident FullMerkleTree (/root/reference/utils/src/merkle_tree/full_merkle_tree.rs)."""
+
+    def __init__(self, depth):
+        self._h = C.c_void_p()
+        self.depth = depth
+        check(lib().rlnamd_tree_new(depth, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().rlnamd_tree_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_range(self, start, leaves):
+        buf = b"".join(_b(v) for v in leaves)
+        check(lib().rlnamd_tree_set_range(self._h, start, buf, len(leaves)))
+
+    def set(self, index, leaf):
+        self.set_range(index, [leaf])
+
+    def root(self):
+        out = C.create_string_buffer(32)
+        check(lib().rlnamd_tree_root(self._h, out))
+        return int.from_bytes(out.raw, "little")
+
+    def get(self, index):
+        out = C.create_string_buffer(32)
+        check(lib().rlnamd_tree_get_leaf(self._h, index, out))
+        return int.from_bytes(out.raw, "little")
+
+    def proof(self, index):
+        e = C.create_string_buffer(32 * self.depth)
+        b = C.create_string_buffer(max(self.depth, 1))
+        check(lib().rlnamd_tree_proof(self._h, index, e, b))
+        return ([int.from_bytes(e.raw[32 * i:32 * i + 32], "little") for i in range(self.depth)],
+                list(b.raw[:self.depth]))
+
+    def proofs(self, first, count):
+        e = C.create_string_buffer(32 * self.depth * count)
+        b = C.create_string_buffer(max(self.depth * count, 1))
+        check(lib().rlnamd_tree_proofs(self._h, first, count, e, b))
+        out = []
+        for p in range(count):
+            o = p * self.depth
+            out.append(([int.from_bytes(e.raw[32 * (o + i):32 * (o + i + 1)], "little") for i in range(self.depth)],
+                        list(b.raw[o:o + self.depth])))
+        return out
+
+    def fill_sequential(self, start, n, first_value):
+        check(lib().rlnamd_tree_fill_sequential(self._h, start, n, first_value))
+
+    def bench(self, n_leaves, first_value=1, verify=True):
+        ms = (C.c_float * 2)()
+        bad = C.c_size_t()
+        check(lib().rlnamd_tree_bench(self._h, n_leaves, first_value, 1 if verify else 0, ms, C.byref(bad)))
+        return dict(build_ms=float(ms[0]), proofs_ms=float(ms[1]), bad=int(bad.value))

@@ -1,0 +1,353 @@
+// C ABI of the extension surface declared in include/rln_amd.h.
+#include "../../include/rln_amd.h"
+
+#include <string.h>
+
+#include <memory>
+#include <string>
+
+#include "common.h"
+#include "keccak.h"
+#include "merkle.h"
+#include "pairing.h"
+#include "poseidon.h"
+#include "prover.h"
+
+using namespace rlnamd;
+
+namespace rlnamd {
+thread_local std::string g_last_error;
+int fail(const std::exception& e) {
+  g_last_error = e.what();
+  return g_last_error.find("no HIP device") != std::string::npos ? RLNAMD_ERR_NO_DEVICE : RLNAMD_ERR;
+}
+}  // namespace rlnamd
+
+#define RLN_TRY try {
+#define RLN_CATCH                        \
+  return RLNAMD_OK;                      \
+  }                                      \
+  catch (const std::exception& e) {      \
+    return rlnamd::fail(e);              \
+  }                                      \
+  catch (...) {                          \
+    rlnamd::g_last_error = "unknown error"; \
+    return RLNAMD_ERR;                   \
+  }
+
+struct rlnamd_tree {
+  MerkleTreeDev t;
+  DevBuf<uint8_t> bench_elems, bench_bits;
+};
+struct rlnamd_prover {
+  std::unique_ptr<Prover> p;
+};
+
+static void verify_common(const Zkey& zk, const uint8_t proof[128], const uint8_t values_le[160], int* ok);
+
+extern "C" {
+
+const char* rlnamd_last_error(void) { return rlnamd::g_last_error.c_str(); }
+
+int rlnamd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int rlnamd_set_device(int ordinal) {
+  RLN_TRY
+  RLN_HIP(hipSetDevice(ordinal));
+  RLN_CATCH
+}
+
+int rlnamd_device_name(char* buf, size_t cap) {
+  RLN_TRY
+  require_gpu();
+  int dev = 0;
+  RLN_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  RLN_HIP(hipGetDeviceProperties(&prop, dev));
+  std::string s = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+  if (cap) {
+    strncpy(buf, s.c_str(), cap - 1);
+    buf[cap - 1] = 0;
+  }
+  RLN_CATCH
+}
+
+int rlnamd_poseidon_hash(const uint8_t* inputs_le, size_t n, size_t arity, uint8_t* out_le) {
+  RLN_TRY
+  require_gpu();
+  if (arity < 1 || arity > 3) throw Error("Input length must be valid with supported round parameters");
+  if (n == 0) return RLNAMD_OK;
+  for (size_t i = 0; i < n * arity; i++) {
+    uint32_t tmp[8];
+    memcpy(tmp, inputs_le + 32 * i, 32);
+    if (limbs_geq(tmp, FrParams::MOD)) throw Error("Non-canonical field element: value is not in [0, r-1]");
+  }
+  DevBuf<uint8_t> din(n * arity * 32), dout(n * 32);
+  RLN_HIP(hipMemcpy(din.p, inputs_le, n * arity * 32, hipMemcpyHostToDevice));
+  poseidon_hash_batch_device(din.p, n, (int)arity, dout.p, 0);
+  RLN_HIP(hipMemcpy(out_le, dout.p, n * 32, hipMemcpyDeviceToHost));
+  RLN_CATCH
+}
+
+int rlnamd_hash_to_field_le(const uint8_t* data, size_t len, uint8_t out_le[32]) {
+  RLN_TRY
+  hash_to_field_le(data, len, out_le);
+  RLN_CATCH
+}
+int rlnamd_hash_to_field_be(const uint8_t* data, size_t len, uint8_t out_le[32]) {
+  RLN_TRY
+  hash_to_field_be(data, len, out_le);
+  RLN_CATCH
+}
+
+// ---------------------------------------------------------------------------------------------- tree
+int rlnamd_tree_new(size_t depth, rlnamd_tree** out) {
+  RLN_TRY
+  std::unique_ptr<rlnamd_tree> h(new rlnamd_tree);
+  uint8_t zero[32] = {0};
+  if (depth > 30) throw Error("InvalidDepth");
+  h->t.init((int)depth, zero);
+  *out = h.release();
+  RLN_CATCH
+}
+void rlnamd_tree_free(rlnamd_tree* t) { delete t; }
+
+int rlnamd_tree_set_range(rlnamd_tree* t, size_t start, const uint8_t* leaves_le, size_t n) {
+  RLN_TRY
+  for (size_t i = 0; i < n; i++) {
+    uint32_t tmp[8];
+    memcpy(tmp, leaves_le + 32 * i, 32);
+    if (limbs_geq(tmp, FrParams::MOD)) throw Error("field element is not canonical (>= modulus)");
+  }
+  t->t.set_range_host(start, leaves_le, n);
+  RLN_CATCH
+}
+int rlnamd_tree_root(rlnamd_tree* t, uint8_t out_le[32]) {
+  RLN_TRY
+  t->t.get_node_host(0, out_le);
+  RLN_CATCH
+}
+int rlnamd_tree_get_leaf(rlnamd_tree* t, size_t index, uint8_t out_le[32]) {
+  RLN_TRY
+  if (index >= t->t.capacity()) throw Error("InvalidLeaf");
+  t->t.get_node_host(t->t.capacity() - 1 + index, out_le);
+  RLN_CATCH
+}
+int rlnamd_tree_proof(rlnamd_tree* t, size_t index, uint8_t* elems_le, uint8_t* bits) {
+  RLN_TRY
+  t->t.proof_host(index, elems_le, bits);
+  RLN_CATCH
+}
+int rlnamd_tree_proofs(rlnamd_tree* t, size_t first, size_t count, uint8_t* elems_le, uint8_t* bits) {
+  RLN_TRY
+  if (count == 0 || t->t.depth == 0) return RLNAMD_OK;
+  size_t d = t->t.depth;
+  DevBuf<uint8_t> e(count * d * 32), b(count * d);
+  t->t.proofs_device(first, count, e.p, b.p);
+  RLN_HIP(hipMemcpyAsync(elems_le, e.p, count * d * 32, hipMemcpyDeviceToHost, t->t.stream));
+  RLN_HIP(hipMemcpyAsync(bits, b.p, count * d, hipMemcpyDeviceToHost, t->t.stream));
+  RLN_HIP(hipStreamSynchronize(t->t.stream));
+  RLN_CATCH
+}
+int rlnamd_tree_fill_sequential(rlnamd_tree* t, size_t start, size_t n, uint64_t first_value) {
+  RLN_TRY
+  t->t.fill_sequential_device(start, n, first_value);
+  RLN_HIP(hipStreamSynchronize(t->t.stream));
+  RLN_CATCH
+}
+int rlnamd_tree_bench(rlnamd_tree* t, size_t n_leaves, uint64_t first_value, int verify, float ms[2], size_t* bad) {
+  RLN_TRY
+  MerkleTreeDev& T = t->t;
+  if (n_leaves > T.capacity()) throw Error("TooManySet");
+  size_t d = T.depth;
+  if (t->bench_elems.n < n_leaves * d * 32) t->bench_elems.alloc(n_leaves * d * 32);
+  if (t->bench_bits.n < n_leaves * d) t->bench_bits.alloc(n_leaves * d);
+  hipEvent_t e0, e1, e2;
+  RLN_HIP(hipEventCreate(&e0));
+  RLN_HIP(hipEventCreate(&e1));
+  RLN_HIP(hipEventCreate(&e2));
+  RLN_HIP(hipEventRecord(e0, T.stream));
+  T.fill_sequential_device(0, n_leaves, first_value);
+  RLN_HIP(hipEventRecord(e1, T.stream));
+  T.proofs_device(0, n_leaves, t->bench_elems.p, t->bench_bits.p);
+  RLN_HIP(hipEventRecord(e2, T.stream));
+  RLN_HIP(hipStreamSynchronize(T.stream));
+  RLN_HIP(hipEventElapsedTime(&ms[0], e0, e1));
+  RLN_HIP(hipEventElapsedTime(&ms[1], e1, e2));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipEventDestroy(e2);
+  if (bad) *bad = verify ? T.verify_proofs_device(0, n_leaves, t->bench_elems.p, t->bench_bits.p) : 0;
+  RLN_CATCH
+}
+
+// -------------------------------------------------------------------------------------------- prover
+int rlnamd_prover_new(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_t graph_len, size_t max_batch,
+                      int window_bits, rlnamd_prover** out) {
+  RLN_TRY
+  ProverConfig cfg;
+  cfg.max_batch = max_batch ? max_batch : 64;
+  cfg.window_bits = window_bits;
+  std::unique_ptr<rlnamd_prover> h(new rlnamd_prover);
+  h->p.reset(new Prover(zkey, zkey_len, graph, graph_len, cfg));
+  *out = h.release();
+  RLN_CATCH
+}
+void rlnamd_prover_free(rlnamd_prover* p) { delete p; }
+
+int rlnamd_prover_get_info(rlnamd_prover* p, rlnamd_prover_info* info) {
+  RLN_TRY
+  const Prover& P = *p->p;
+  info->inputs_size = P.inputs_per_proof();
+  info->num_signals = P.graph().signals.size();
+  uint64_t dom = 1;
+  while (dom < P.zkey().num_constraints + P.zkey().num_instance_variables) dom <<= 1;
+  info->domain_size = dom;
+  info->tree_depth = P.graph().tree_depth;
+  info->max_out = P.graph().max_out;
+  info->capacity = P.capacity();
+  info->table_bytes = P.table_bytes();
+  info->window_bits = P.window_bits();
+  info->windows = P.windows();
+  RLN_CATCH
+}
+int rlnamd_prover_input_slot(rlnamd_prover* p, const char* name, uint32_t* offset, uint32_t* len) {
+  RLN_TRY
+  auto& m = p->p->graph().input_mapping;
+  auto it = m.find(name);
+  if (it == m.end()) throw Error(std::string("MissingInput: ") + name);
+  *offset = it->second.first;
+  *len = it->second.second;
+  RLN_CATCH
+}
+int rlnamd_prover_upload(rlnamd_prover* p, size_t n, const uint8_t* inputs_le, const uint8_t* rs_le) {
+  RLN_TRY
+  p->p->upload(n, inputs_le, rs_le);
+  RLN_CATCH
+}
+int rlnamd_prover_run(rlnamd_prover* p, size_t n) {
+  RLN_TRY
+  p->p->run(n);
+  RLN_CATCH
+}
+int rlnamd_prover_download(rlnamd_prover* p, size_t n, uint8_t* proofs, uint8_t* coords, uint8_t* values,
+                           uint32_t* errors) {
+  RLN_TRY
+  std::vector<ProofOut> out(n);
+  p->p->download(n, out.data());
+  for (size_t i = 0; i < n; i++) {
+    if (proofs) memcpy(proofs + i * 128, out[i].compressed, 128);
+    if (coords) memcpy(coords + i * 256, out[i].coords, 256);
+    if (values) memcpy(values + i * 160, out[i].values, 160);
+    if (errors) errors[i] = out[i].error;
+  }
+  RLN_CATCH
+}
+int rlnamd_prover_stage_ms(rlnamd_prover* p, float ms[RLNAMD_PROVER_STAGES]) {
+  RLN_TRY
+  p->p->stage_ms(ms);
+  RLN_CATCH
+}
+const char* rlnamd_prover_stage_name(int i) { return (i >= 0 && i < PROVER_STAGES) ? kProverStageNames[i] : ""; }
+
+int rlnamd_prover_fetch_witness(rlnamd_prover* p, size_t index, uint8_t* out_le) {
+  RLN_TRY
+  std::vector<uint8_t> w;
+  p->p->fetch_witness(index, &w);
+  memcpy(out_le, w.data(), w.size());
+  RLN_CATCH
+}
+int rlnamd_prover_fetch_h(rlnamd_prover* p, size_t index, uint8_t* out_le) {
+  RLN_TRY
+  std::vector<uint8_t> h;
+  p->p->fetch_h(index, &h);
+  memcpy(out_le, h.data(), h.size());
+  RLN_CATCH
+}
+
+int rlnamd_verify(rlnamd_prover* p, const uint8_t proof[128], const uint8_t values_le[160], int* ok) {
+  RLN_TRY
+  verify_common(p->p->zkey(), proof, values_le, ok);
+  RLN_CATCH
+}
+
+static void verify_common(const Zkey& zk, const uint8_t proof[128], const uint8_t values_le[160], int* ok) {
+  G1Affine A, C;
+  G2Affine B;
+  *ok = 0;
+  if (!g1_decompress(proof, &A) || !g2_decompress(proof + 32, &B) || !g1_decompress(proof + 96, &C))
+    throw Error("Proof serialization error: the input buffer contained invalid data");
+  std::vector<Fr> in;
+  for (int i = 0; i < 5; i++) {
+    uint32_t c[8];
+    memcpy(c, values_le + 32 * i, 32);
+    if (limbs_geq(c, FrParams::MOD)) throw Error("Non-canonical field element: value is not in [0, r-1]");
+    in.push_back(Fr::from_canonical(c));
+  }
+  *ok = groth16_verify(zk, A, B, C, in) ? 1 : 0;
+}
+
+int rlnamd_verify_with_zkey(const uint8_t* zkey, size_t zkey_len, const uint8_t proof[128],
+                            const uint8_t values_le[160], int* ok) {
+  RLN_TRY
+  Zkey zk = parse_arkzkey(zkey, zkey_len);
+  verify_common(zk, proof, values_le, ok);
+  RLN_CATCH
+}
+
+int rlnamd_parse_resources(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_t graph_len,
+                           uint64_t counts[13]) {
+  RLN_TRY
+  Zkey zk = parse_arkzkey(zkey, zkey_len);
+  Graph g = parse_graph(graph, graph_len);
+  counts[0] = zk.num_instance_variables;
+  counts[1] = zk.num_witness_variables;
+  counts[2] = zk.num_constraints;
+  counts[3] = zk.a_nnz;
+  counts[4] = zk.b_nnz;
+  counts[5] = zk.a_query.size();
+  counts[6] = zk.h_query.size();
+  counts[7] = zk.l_query.size();
+  counts[8] = g.nodes.size();
+  counts[9] = g.signals.size();
+  counts[10] = g.tree_depth;
+  counts[11] = g.max_out;
+  counts[12] = g.inputs_size;
+  RLN_CATCH
+}
+
+int rlnamd_proof_compress(const uint8_t coords_le[256], uint8_t proof[128]) {
+  RLN_TRY
+  auto ld = [&](int k) {
+    uint32_t c[8];
+    memcpy(c, coords_le + 32 * k, 32);
+    if (limbs_geq(c, FqParams::MOD)) throw Error("Non-canonical field element");
+    return Fq::from_canonical(c);
+  };
+  G1Affine A{ld(0), ld(1)}, C{ld(6), ld(7)};
+  G2Affine B{{ld(2), ld(3)}, {ld(4), ld(5)}};
+  g1_compress(A, proof);
+  g2_compress(B, proof + 32);
+  g1_compress(C, proof + 96);
+  RLN_CATCH
+}
+int rlnamd_proof_decompress(const uint8_t proof[128], uint8_t coords_le[256]) {
+  RLN_TRY
+  G1Affine A, C;
+  G2Affine B;
+  if (!g1_decompress(proof, &A) || !g2_decompress(proof + 32, &B) || !g1_decompress(proof + 96, &C))
+    throw Error("Proof serialization error: the input buffer contained invalid data");
+  auto st = [&](int k, const Fq& v) {
+    uint32_t c[8];
+    v.to_canonical(c);
+    memcpy(coords_le + 32 * k, c, 32);
+  };
+  st(0, A.x); st(1, A.y); st(2, B.x.c0); st(3, B.x.c1); st(4, B.y.c0); st(5, B.y.c1); st(6, C.x); st(7, C.y);
+  RLN_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,925 @@
+// zerokit-compatible C ABI (include/rln.h) on top of the HIP modules.
+//
+// Mirrors the delegation structure of the reference: ffi_* (rln/src/ffi/*.rs) -> RLN (rln/src/public.rs)
+// -> protocol / tree.  Every compute call lands in a HIP kernel (prover.hip, merkle.hip, poseidon.hip);
+// only byte shuffling, validation and proof verification (public.rs:725-745, CPU in the reference too)
+// run on the host.
+#include "../../include/rln.h"
+
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <fstream>
+#include <memory>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/rln_amd.h"
+#include "common.h"
+#include "keccak.h"
+#include "merkle.h"
+#include "pairing.h"
+#include "poseidon.h"
+#include "prover.h"
+
+using namespace rlnamd;
+
+struct CFr {
+  uint8_t le[32];
+};
+
+// ---------------------------------------------------------------------------------- small host helpers
+namespace {
+
+Vec_uint8_t no_err() { return {nullptr, 0, 0}; }
+Vec_uint8_t make_str(const std::string& s) {  // NUL-terminated, len excludes the terminator
+  uint8_t* p = (uint8_t*)malloc(s.size() + 1);
+  memcpy(p, s.c_str(), s.size() + 1);
+  return {p, s.size(), s.size() + 1};
+}
+Vec_uint8_t make_bytes(const std::vector<uint8_t>& v) {
+  uint8_t* p = (uint8_t*)malloc(v.size() ? v.size() : 1);
+  if (!v.empty()) memcpy(p, v.data(), v.size());
+  return {p, v.size(), v.size() ? v.size() : 1};
+}
+Vec_CFr_t make_vec_cfr(const std::vector<CFr>& v) {
+  CFr* p = (CFr*)malloc((v.size() ? v.size() : 1) * sizeof(CFr));
+  if (!v.empty()) memcpy(p, v.data(), v.size() * sizeof(CFr));
+  return {(CFr_t*)p, v.size(), v.size() ? v.size() : 1};
+}
+CFr_t* box_cfr(const CFr& v) {
+  CFr* p = (CFr*)malloc(sizeof(CFr));
+  *p = v;
+  return (CFr_t*)p;
+}
+const CFr& R(const CFr_t* p) { return *(const CFr*)p; }
+
+bool is_canonical(const uint8_t* le) {
+  uint32_t c[8];
+  memcpy(c, le, 32);
+  return !limbs_geq(c, FrParams::MOD);
+}
+bool cfr_is_zero(const CFr& a) {
+  for (int i = 0; i < 32; i++)
+    if (a.le[i]) return false;
+  return true;
+}
+int cfr_cmp(const CFr& a, const CFr& b) {
+  for (int i = 31; i >= 0; i--)
+    if (a.le[i] != b.le[i]) return a.le[i] > b.le[i] ? 1 : -1;
+  return 0;
+}
+CFr cfr_from_u64(uint64_t v) {
+  CFr r;
+  memset(r.le, 0, 32);
+  memcpy(r.le, &v, 8);
+  return r;
+}
+std::string cfr_dec(const CFr& a) {  // decimal, as arkworks' Display/Debug for Fp prints it
+  uint32_t v[8];
+  memcpy(v, a.le, 32);
+  std::string out;
+  bool nz = true;
+  while (nz) {
+    uint64_t rem = 0;
+    nz = false;
+    for (int i = 7; i >= 0; i--) {
+      uint64_t cur = (rem << 32) | v[i];
+      v[i] = (uint32_t)(cur / 10);
+      rem = cur % 10;
+      nz |= v[i] != 0;
+    }
+    out.push_back((char)('0' + rem));
+  }
+  std::reverse(out.begin(), out.end());
+  return out;
+}
+void be32(const uint8_t le[32], uint8_t out[32]) {
+  for (int i = 0; i < 32; i++) out[i] = le[31 - i];
+}
+void put_u64(std::vector<uint8_t>& b, uint64_t v, bool be) {
+  for (int i = 0; i < 8; i++) b.push_back((uint8_t)(v >> (be ? 56 - 8 * i : 8 * i)));
+}
+uint64_t get_u64(const uint8_t* p, bool be) {
+  uint64_t v = 0;
+  for (int i = 0; i < 8; i++) v |= (uint64_t)p[i] << (be ? 56 - 8 * i : 8 * i);
+  return v;
+}
+void put_fr(std::vector<uint8_t>& b, const CFr& a, bool be) {
+  uint8_t t[32];
+  if (be) be32(a.le, t); else memcpy(t, a.le, 32);
+  b.insert(b.end(), t, t + 32);
+}
+
+struct Cursor {  // bounds-checked reader with the reference's error texts
+  const uint8_t* d;
+  size_t n, o = 0;
+  bool be;
+  void need(size_t k) {
+    if (o + k > n || o + k < o)
+      throw Error("Input data too short: expected at least " + std::to_string(o + k) + " bytes, got " +
+                  std::to_string(n) + " bytes");
+  }
+  CFr fr() {
+    need(32);
+    CFr r;
+    if (be) be32(d + o, r.le); else memcpy(r.le, d + o, 32);
+    o += 32;
+    if (!is_canonical(r.le)) throw Error("Non-canonical field element: value is not in [0, r-1]");
+    return r;
+  }
+  uint64_t len() {
+    need(8);
+    uint64_t v = get_u64(d + o, be);
+    o += 8;
+    return v;
+  }
+  std::vector<CFr> vec_fr() {
+    uint64_t k = len();
+    if (k > (n - o) / 32) need((size_t)-1 - o);
+    std::vector<CFr> v;
+    for (uint64_t i = 0; i < k; i++) v.push_back(fr());
+    return v;
+  }
+  std::vector<uint8_t> vec_u8() {
+    uint64_t k = len();
+    if (k > n - o) need((size_t)-1 - o);
+    std::vector<uint8_t> v(d + o, d + o + k);
+    o += k;
+    return v;
+  }
+};
+
+std::string lib_dir() {
+  Dl_info info;
+  if (dladdr((void*)&lib_dir, &info) && info.dli_fname) {
+    std::string p = info.dli_fname;
+    size_t k = p.find_last_of('/');
+    return k == std::string::npos ? "." : p.substr(0, k);
+  }
+  return ".";
+}
+std::vector<uint8_t> read_file(const std::string& path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) throw Error("I/O error: cannot open " + path);
+  return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+// The reference embeds the depth-20 resources with include_bytes! (circuit/mod.rs:29-42); here they are
+// the same files shipped beside the library (override with RLNAMD_RESOURCES).
+std::string resource_dir(size_t depth) {
+  const char* env = getenv("RLNAMD_RESOURCES");
+  std::string base = env && *env ? env : lib_dir() + "/../resources";
+  return base + "/tree_depth_" + std::to_string(depth);
+}
+
+CFr random_fr() {
+  static thread_local std::random_device rd;
+  uint8_t b[32];
+  for (int i = 0; i < 8; i++) {
+    uint32_t w = rd();
+    memcpy(b + 4 * i, &w, 4);
+  }
+  b[31] &= 0x3F;  // 254 bits, then reject
+  CFr r;
+  for (;;) {
+    if (is_canonical(b)) break;
+    uint32_t w = rd();
+    memcpy(b, &w, 4);
+    b[31] = (uint8_t)((b[31] + 1) & 0x1F);
+  }
+  memcpy(r.le, b, 32);
+  return r;
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------- object model
+struct FFI_RLNWitnessInput {  // RLNWitnessInput (protocol/witness.rs:44-58), SingleV1 only
+  CFr identity_secret, user_message_limit, message_id;
+  std::vector<CFr> path_elements;
+  std::vector<uint8_t> identity_path_index;
+  CFr x, external_nullifier;
+};
+struct FFI_RLNProofValues {  // RLNProofValues (protocol/proof.rs), SingleV1
+  CFr root, x, external_nullifier, y, nullifier;
+};
+struct FFI_RLNProof {
+  uint8_t proof[128];
+  FFI_RLNProofValues values;
+};
+
+struct FFI_RLN {
+  std::unique_ptr<Prover> prover;
+  MerkleTreeDev tree;
+  size_t next_index = 0;
+  std::vector<uint8_t> leaf_set;  // cached_leaves_indices
+  std::vector<uint8_t> metadata;
+
+  void new_tree(size_t depth) {  // PoseidonTree::default(depth) (public.rs:298-303)
+    if (depth >= 64) throw Error("Tree depth exceeds maximum allowed (must be < 64)");
+    uint8_t zero[32] = {0};
+    tree = MerkleTreeDev();
+    tree.init((int)depth, zero);
+    next_index = 0;
+    leaf_set.assign((size_t)1 << depth, 0);
+  }
+  void set_range(size_t start, const std::vector<CFr>& leaves) {  // full_merkle_tree.rs:197-223
+    if (start + leaves.size() > tree.capacity() || start + leaves.size() < start)
+      throw Error("set_range got too many leaves");
+    if (leaves.empty()) return;
+    tree.set_range_host(start, (const uint8_t*)leaves.data(), leaves.size());
+    for (size_t i = 0; i < leaves.size(); i++) leaf_set[start + i] = 1;
+    next_index = std::max(next_index, start + leaves.size());
+  }
+  void set(size_t index, const CFr& leaf) {  // :141-147
+    if (index >= tree.capacity()) throw Error("set_range got too many leaves");
+    set_range(index, {leaf});
+  }
+  CFr get(size_t index) {
+    if (index >= tree.capacity()) throw Error("Leaf index out of bounds");
+    CFr r;
+    tree.get_node_host(tree.capacity() - 1 + index, r.le);
+    return r;
+  }
+  void del(size_t index) {  // :271-285
+    if (index < next_index) {
+      set(index, cfr_from_u64(0));
+      leaf_set[index] = 0;
+    }
+  }
+  // override_range with the default (pmtree-ft) build's behaviour: empty `indices` allowed
+  // (pm_tree_adapter.rs:320-356, validation override_range_validation.rs:20-65)
+  void override_range(size_t start, const std::vector<CFr>& leaves, std::vector<size_t> indices) {
+    const size_t cap = tree.capacity();
+    for (size_t i : indices)
+      if (i >= cap) throw Error("Invalid indices");
+    std::sort(indices.begin(), indices.end());
+    indices.erase(std::unique(indices.begin(), indices.end()), indices.end());
+    size_t end = 0;
+    bool have_end = !leaves.empty();
+    if (have_end) {
+      end = start + leaves.size();
+      if (end < start || end > cap) throw Error("set_range got too many leaves");
+    }
+    if (!indices.empty() && have_end && (indices[0] > start || indices[0] >= end)) throw Error("Invalid indices");
+    if (leaves.empty() && indices.empty()) throw Error("Leaf index out of bounds");
+    if (indices.empty()) {
+      if (leaves.size() == 1) set(start, leaves[0]); else set_range(start, leaves);
+      return;
+    }
+    if (leaves.empty()) {
+      if (indices.size() == 1) {
+        del(indices[0]);
+        return;
+      }
+      // remove_indices (pm_tree_adapter.rs:417-435): the whole span [first, last] is reset
+      size_t s = indices.front(), e = indices.back() + 1;
+      set_range(s, std::vector<CFr>(e - s, cfr_from_u64(0)));
+      for (size_t i = s; i < e; i++) leaf_set[i] = 0;
+      return;
+    }
+    // remove_indices_and_set_leaves (pm_tree_adapter.rs:437-480); the merged buffer is written at `start`
+    // (SURVEY Appendix C.1), exactly as the reference does
+    size_t min_index = indices[0];
+    std::vector<CFr> vals(end - min_index, cfr_from_u64(0));
+    for (size_t i = min_index; i < start; i++)
+      if (!std::binary_search(indices.begin(), indices.end(), i)) vals[i - min_index] = get(i);
+    for (size_t i = 0; i < leaves.size(); i++) vals[start - min_index + i] = leaves[i];
+    if (start + vals.size() > cap) throw Error("set_range got too many leaves");
+    set_range(start, vals);
+    for (size_t i : indices) leaf_set[i] = 0;
+    for (size_t i = start; i < end - min_index && i < cap; i++) leaf_set[i] = 1;
+  }
+};
+
+namespace {
+
+void validate_witness(const FFI_RLNWitnessInput& w) {  // witness.rs:78-108
+  if (cfr_is_zero(w.user_message_limit)) throw Error("User message limit cannot be zero");
+  if (w.path_elements.size() != w.identity_path_index.size())
+    throw Error("Merkle proof length mismatch: expected " + std::to_string(w.path_elements.size()) + ", got " +
+                std::to_string(w.identity_path_index.size()));
+  if (cfr_cmp(w.message_id, w.user_message_limit) >= 0)
+    throw Error("Message id (" + cfr_dec(w.message_id) + ") is not within user_message_limit (" +
+                cfr_dec(w.user_message_limit) + ")");
+}
+
+// inputs_for_witness_calculation + populate_inputs (witness.rs:832-881, iden3calc.rs:122-181)
+void fill_inputs(const Prover& P, const FFI_RLNWitnessInput& w, uint8_t* buf) {
+  const Graph& g = P.graph();
+  memset(buf, 0, (size_t)g.inputs_size * 32);
+  buf[0] = 1;
+  auto put = [&](const char* name, const CFr* vals, size_t count) {
+    auto it = g.input_mapping.find(name);
+    if (it == g.input_mapping.end()) throw Error(std::string("Error calculating witness: missing input ") + name);
+    if (it->second.second != count)
+      throw Error(std::string("Error calculating witness: invalid input length for ") + name + ": expected " +
+                  std::to_string(it->second.second) + ", got " + std::to_string(count));
+    memcpy(buf + (size_t)it->second.first * 32, vals, count * 32);
+  };
+  put("identitySecret", &w.identity_secret, 1);
+  put("userMessageLimit", &w.user_message_limit, 1);
+  put("messageId", &w.message_id, 1);
+  put("pathElements", w.path_elements.data(), w.path_elements.size());
+  std::vector<CFr> idx;
+  for (uint8_t b : w.identity_path_index) idx.push_back(cfr_from_u64(b));
+  put("identityPathIndex", idx.data(), idx.size());
+  put("x", &w.x, 1);
+  put("externalNullifier", &w.external_nullifier, 1);
+}
+
+void check_against_graph(const Prover& P, const FFI_RLNWitnessInput& w) {  // proof.rs:644-700
+  size_t d = P.graph().tree_depth;
+  if (w.path_elements.size() != d)
+    throw Error("The field path_elements has length " + std::to_string(w.path_elements.size()) +
+                ", but the field tree_depth has length " + std::to_string(d));
+  if (w.identity_path_index.size() != d)
+    throw Error("The field identity_path_index has length " + std::to_string(w.identity_path_index.size()) +
+                ", but the field tree_depth has length " + std::to_string(d));
+  if (P.graph().max_out != 1) throw Error("Witness message mode SingleV1 does not match graph mode MultiV1");
+}
+
+// generate_rln_proof for a slice of witnesses (public.rs:624-631)
+void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CFr* rs, FFI_RLNProof** out) {
+  Prover& P = *rln.prover;
+  const size_t ni = P.inputs_per_proof();
+  for (size_t i = 0; i < n; i++) check_against_graph(P, *ws[i]);
+  size_t done = 0;
+  std::vector<FFI_RLNProof*> made;
+  try {
+    while (done < n) {
+      size_t m = std::min(n - done, P.capacity());
+      std::vector<uint8_t> inputs(m * ni * 32), rsb(m * 64);
+      for (size_t i = 0; i < m; i++) {
+        fill_inputs(P, *ws[done + i], inputs.data() + i * ni * 32);
+        CFr r = rs ? rs[2 * (done + i)] : random_fr();      // proof.rs:743-745
+        CFr s = rs ? rs[2 * (done + i) + 1] : random_fr();
+        memcpy(rsb.data() + i * 64, r.le, 32);
+        memcpy(rsb.data() + i * 64 + 32, s.le, 32);
+      }
+      std::vector<ProofOut> po(m);
+      P.prove(m, inputs.data(), rsb.data(), po.data());
+      for (size_t i = 0; i < m; i++) {
+        if (po[i].error) throw Error("Error calculating witness: graph evaluation failed (code " +
+                                     std::to_string(po[i].error) + ")");
+        std::unique_ptr<FFI_RLNProof> pr(new FFI_RLNProof);
+        memcpy(pr->proof, po[i].compressed, 128);
+        memcpy(pr->values.y.le, po[i].values[0], 32);
+        memcpy(pr->values.root.le, po[i].values[1], 32);
+        memcpy(pr->values.nullifier.le, po[i].values[2], 32);
+        memcpy(pr->values.x.le, po[i].values[3], 32);
+        memcpy(pr->values.external_nullifier.le, po[i].values[4], 32);
+        made.push_back(pr.release());
+      }
+      done += m;
+    }
+  } catch (...) {
+    for (auto* p : made) delete p;
+    throw;
+  }
+  for (size_t i = 0; i < n; i++) out[i] = made[i];
+}
+
+bool verify_zk(FFI_RLN& rln, const FFI_RLNProof& pr) {  // verify_zk_proof (proof.rs:856-894)
+  G1Affine A, C;
+  G2Affine B;
+  if (!g1_decompress(pr.proof, &A) || !g2_decompress(pr.proof + 32, &B) || !g1_decompress(pr.proof + 96, &C))
+    return false;
+  auto F = [](const CFr& v) {
+    uint32_t c[8];
+    memcpy(c, v.le, 32);
+    return Fr::from_canonical(c);
+  };
+  std::vector<Fr> in = {F(pr.values.y), F(pr.values.root), F(pr.values.nullifier), F(pr.values.x),
+                        F(pr.values.external_nullifier)};
+  return groth16_verify(rln.prover->zkey(), A, B, C, in);
+}
+
+std::vector<uint8_t> values_bytes(const FFI_RLNProofValues& v, bool be) {  // proof.rs:192-236 / :239-283
+  std::vector<uint8_t> b;
+  b.push_back(0x00);
+  put_fr(b, v.root, be);
+  put_fr(b, v.external_nullifier, be);
+  put_fr(b, v.x, be);
+  put_fr(b, v.y, be);
+  put_fr(b, v.nullifier, be);
+  return b;
+}
+FFI_RLNProofValues values_from(Cursor& c) {  // proof.rs:285-411
+  c.need(1);
+  uint8_t ver = c.d[c.o++];
+  if (ver == 0x01) throw Error("multi message-id proof values are not supported by this backend");
+  if (ver != 0x00) {
+    char buf[8];
+    snprintf(buf, sizeof buf, "%#04x", ver);
+    throw Error(std::string("Unknown message mode version byte: ") + buf);
+  }
+  FFI_RLNProofValues v;
+  v.root = c.fr();
+  v.external_nullifier = c.fr();
+  v.x = c.fr();
+  v.y = c.fr();
+  v.nullifier = c.fr();
+  return v;
+}
+bool g2_in_subgroup(const G2Affine& p) {  // [r]P == 0 (ark-serialize Validate::Yes)
+  return scalar_mul(p, FrParams::MOD).is_inf();
+}
+FFI_RLNProof* proof_from_bytes(const Vec_uint8_t* bytes, bool be) {  // proof.rs:455-530
+  if (!bytes || bytes->len == 0) throw Error("Expected to read 1 bytes but read 0 bytes");
+  const uint8_t* d = bytes->ptr;
+  if (d[0] > 1) {
+    char buf[8];
+    snprintf(buf, sizeof buf, "%#04x", d[0]);
+    throw Error(std::string("Unknown message mode version byte: ") + buf);
+  }
+  if (bytes->len < 129)
+    throw Error("Expected to read 129 bytes but read " + std::to_string(bytes->len) + " bytes");
+  std::unique_ptr<FFI_RLNProof> pr(new FFI_RLNProof);
+  memcpy(pr->proof, d + 1, 128);
+  G1Affine A, C;
+  G2Affine B;
+  if (!g1_decompress(pr->proof, &A) || !g2_decompress(pr->proof + 32, &B) || !g1_decompress(pr->proof + 96, &C) ||
+      !g2_in_subgroup(B))
+    throw Error("Proof serialization error: the input buffer contained invalid data");
+  Cursor c{d, bytes->len, 129, be};
+  pr->values = values_from(c);
+  if (c.o != bytes->len)
+    throw Error("Expected to read " + std::to_string(c.o) + " bytes but read " + std::to_string(bytes->len) + " bytes");
+  return pr.release();
+}
+std::vector<uint8_t> witness_bytes(const FFI_RLNWitnessInput& w, bool be) {  // witness.rs:369-468
+  std::vector<uint8_t> b;
+  b.push_back(0x00);
+  put_fr(b, w.identity_secret, be);
+  put_fr(b, w.user_message_limit, be);
+  put_fr(b, w.message_id, be);
+  put_u64(b, w.path_elements.size(), be);
+  for (auto& e : w.path_elements) put_fr(b, e, be);
+  put_u64(b, w.identity_path_index.size(), be);
+  b.insert(b.end(), w.identity_path_index.begin(), w.identity_path_index.end());
+  put_fr(b, w.x, be);
+  put_fr(b, w.external_nullifier, be);
+  return b;
+}
+FFI_RLNWitnessInput* witness_from_bytes(const Vec_uint8_t* bytes, bool be) {  // witness.rs:470-620
+  if (!bytes || bytes->len == 0) throw Error("Expected to read 1 bytes but read 0 bytes");
+  Cursor c{bytes->ptr, bytes->len, 0, be};
+  uint8_t ver = c.d[c.o++];
+  if (ver == 0x01) throw Error("multi message-id witnesses are not supported by this backend");
+  if (ver != 0x00) {
+    char buf[8];
+    snprintf(buf, sizeof buf, "%#04x", ver);
+    throw Error(std::string("Unknown message mode version byte: ") + buf);
+  }
+  std::unique_ptr<FFI_RLNWitnessInput> w(new FFI_RLNWitnessInput);
+  w->identity_secret = c.fr();
+  w->user_message_limit = c.fr();
+  w->message_id = c.fr();
+  w->path_elements = c.vec_fr();
+  w->identity_path_index = c.vec_u8();
+  w->x = c.fr();
+  w->external_nullifier = c.fr();
+  if (c.o != bytes->len)
+    throw Error("Expected to read " + std::to_string(c.o) + " bytes but read " + std::to_string(bytes->len) + " bytes");
+  validate_witness(*w);
+  return w.release();
+}
+
+template <class ResT, class F>
+ResT guard_ptr(F&& f) {
+  try {
+    return ResT{f(), no_err()};
+  } catch (const std::exception& e) {
+    return ResT{nullptr, make_str(e.what())};
+  }
+}
+template <class F>
+CBoolResult_t guard_bool(F&& f) {
+  try {
+    return CBoolResult_t{f(), no_err()};
+  } catch (const std::exception& e) {
+    return CBoolResult_t{false, make_str(e.what())};
+  }
+}
+template <class F>
+CResult_Vec_uint8_Vec_uint8_t guard_bytes(F&& f) {
+  try {
+    return {make_bytes(f()), no_err()};
+  } catch (const std::exception& e) {
+    return {Vec_uint8_t{nullptr, 0, 0}, make_str(e.what())};
+  }
+}
+
+FFI_RLN* rln_create(size_t depth, const std::vector<uint8_t>& zkey, const std::vector<uint8_t>& graph) {
+  require_gpu();
+  std::unique_ptr<FFI_RLN> r(new FFI_RLN);
+  ProverConfig cfg;
+  const char* mb = getenv("RLNAMD_MAX_BATCH");
+  cfg.max_batch = mb && *mb ? (size_t)atoll(mb) : 64;
+  r->prover.reset(new Prover(zkey.data(), zkey.size(), graph.data(), graph.size(), cfg));
+  if (r->prover->graph().tree_depth != depth)  // graph_from_raw expected depth (circuit/mod.rs:163-179)
+    throw Error("Graph error: tree depth mismatch: expected " + std::to_string(depth) + ", got " +
+                std::to_string(r->prover->graph().tree_depth));
+  r->new_tree(depth);
+  return r.release();
+}
+
+}  // namespace
+
+extern "C" {
+
+// ================================================================================ RLN object
+CResult_FFI_RLN_ptr_Vec_uint8_t ffi_rln_new(size_t tree_depth, const char* config_path) {
+  (void)config_path;  // tree config only selects the sled/pmtree persistence, out of scope
+  return guard_ptr<CResult_FFI_RLN_ptr_Vec_uint8_t>([&]() -> FFI_RLN_t* {
+    // RLN::new always loads the embedded depth-20 circuit (public.rs:110-128, circuit/mod.rs:29-42);
+    // the tree is built with the requested depth.
+    std::string dir = resource_dir(20);
+    auto zkey = read_file(dir + "/rln_final.arkzkey");
+    auto graph = read_file(dir + "/graph.bin");
+    require_gpu();
+    std::unique_ptr<FFI_RLN> r(new FFI_RLN);
+    ProverConfig cfg;
+    const char* mb = getenv("RLNAMD_MAX_BATCH");
+    cfg.max_batch = mb && *mb ? (size_t)atoll(mb) : 64;
+    r->prover.reset(new Prover(zkey.data(), zkey.size(), graph.data(), graph.size(), cfg));
+    r->new_tree(tree_depth);
+    return (FFI_RLN_t*)r.release();
+  });
+}
+CResult_FFI_RLN_ptr_Vec_uint8_t ffi_rln_new_with_params(size_t tree_depth, const Vec_uint8_t* zkey_data,
+                                                        const Vec_uint8_t* graph_data, const char* config_path) {
+  (void)config_path;
+  return guard_ptr<CResult_FFI_RLN_ptr_Vec_uint8_t>([&]() -> FFI_RLN_t* {
+    if (!zkey_data || !graph_data) throw Error("ZKey error: Empty zkey bytes");
+    std::vector<uint8_t> z(zkey_data->ptr, zkey_data->ptr + zkey_data->len);
+    std::vector<uint8_t> g(graph_data->ptr, graph_data->ptr + graph_data->len);
+    return (FFI_RLN_t*)rln_create(tree_depth, z, g);
+  });
+}
+void ffi_rln_free(FFI_RLN_t* rln) { delete (FFI_RLN*)rln; }
+size_t ffi_rln_get_tree_depth(FFI_RLN_t* const* rln) { return ((FFI_RLN*)*rln)->tree.depth; }
+size_t ffi_rln_get_max_out(FFI_RLN_t* const* rln) { return ((FFI_RLN*)*rln)->prover->graph().max_out; }
+
+// ================================================================================ proofs
+CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_generate_rln_proof(FFI_RLN_t* const* rln,
+                                                            FFI_RLNWitnessInput_t* const* witness) {
+  return guard_ptr<CResult_FFI_RLNProof_ptr_Vec_uint8_t>([&]() -> FFI_RLNProof_t* {
+    FFI_RLNProof* out = nullptr;
+    FFI_RLNWitnessInput* w = (FFI_RLNWitnessInput*)*witness;
+    prove_many(*(FFI_RLN*)*rln, &w, 1, nullptr, &out);
+    return (FFI_RLNProof_t*)out;
+  });
+}
+CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_generate_rln_proof_with_rs(FFI_RLN_t* const* rln,
+                                                                    FFI_RLNWitnessInput_t* const* witness,
+                                                                    const CFr_t* r, const CFr_t* s) {
+  return guard_ptr<CResult_FFI_RLNProof_ptr_Vec_uint8_t>([&]() -> FFI_RLNProof_t* {
+    FFI_RLNProof* out = nullptr;
+    FFI_RLNWitnessInput* w = (FFI_RLNWitnessInput*)*witness;
+    CFr rs[2] = {R(r), R(s)};
+    prove_many(*(FFI_RLN*)*rln, &w, 1, rs, &out);
+    return (FFI_RLNProof_t*)out;
+  });
+}
+CBoolResult_t ffi_generate_rln_proofs_batch(FFI_RLN_t* const* rln, FFI_RLNWitnessInput_t* const* witnesses, size_t n,
+                                            const CFr_t* rs, FFI_RLNProof_t** out) {
+  return guard_bool([&]() {
+    prove_many(*(FFI_RLN*)*rln, (FFI_RLNWitnessInput* const*)witnesses, n, (const CFr*)rs, (FFI_RLNProof**)out);
+    return true;
+  });
+}
+CBoolResult_t ffi_verify_rln_proof(FFI_RLN_t* const* rln, FFI_RLNProof_t* const* proof, const CFr_t* x) {
+  return guard_bool([&]() {  // public.rs:725-745: proof -> root -> signal, first failure is an error
+    FFI_RLN& r = *(FFI_RLN*)*rln;
+    const FFI_RLNProof& pr = *(FFI_RLNProof*)*proof;
+    if (!verify_zk(r, pr)) throw Error("Verification error: Invalid proof provided");
+    CFr root;
+    r.tree.get_node_host(0, root.le);
+    if (cfr_cmp(root, pr.values.root) != 0) throw Error("Verification error: Expected one of the provided roots");
+    if (cfr_cmp(R(x), pr.values.x) != 0) throw Error("Verification error: Signal value does not match");
+    return true;
+  });
+}
+CBoolResult_t ffi_verify_with_roots(FFI_RLN_t* const* rln, FFI_RLNProof_t* const* proof, const Vec_CFr_t* roots,
+                                    const CFr_t* x) {
+  return guard_bool([&]() {  // public.rs:750-771
+    FFI_RLN& r = *(FFI_RLN*)*rln;
+    const FFI_RLNProof& pr = *(FFI_RLNProof*)*proof;
+    if (!verify_zk(r, pr)) throw Error("Verification error: Invalid proof provided");
+    if (roots && roots->len) {
+      bool found = false;
+      for (size_t i = 0; i < roots->len; i++) found |= cfr_cmp(((const CFr*)roots->ptr)[i], pr.values.root) == 0;
+      if (!found) throw Error("Verification error: Expected one of the provided roots");
+    }
+    if (cfr_cmp(R(x), pr.values.x) != 0) throw Error("Verification error: Signal value does not match");
+    return true;
+  });
+}
+FFI_RLNProofValues_t* ffi_rln_proof_get_values(FFI_RLNProof_t* const* proof) {
+  return (FFI_RLNProofValues_t*)new FFI_RLNProofValues(((FFI_RLNProof*)*proof)->values);
+}
+uint8_t ffi_rln_proof_get_version_byte(FFI_RLNProof_t* const*) { return 0x00; }
+static std::vector<uint8_t> proof_bytes(const FFI_RLNProof& pr, bool be) {  // proof.rs:413-449
+  std::vector<uint8_t> b;
+  b.push_back(0x00);
+  b.insert(b.end(), pr.proof, pr.proof + 128);
+  auto v = values_bytes(pr.values, be);
+  b.insert(b.end(), v.begin(), v.end());
+  return b;
+}
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_proof_to_bytes_le(FFI_RLNProof_t* const* proof) {
+  return guard_bytes([&]() { return proof_bytes(*(FFI_RLNProof*)*proof, false); });
+}
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_proof_to_bytes_be(FFI_RLNProof_t* const* proof) {
+  return guard_bytes([&]() { return proof_bytes(*(FFI_RLNProof*)*proof, true); });
+}
+CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_bytes_le_to_rln_proof(const Vec_uint8_t* bytes) {
+  return guard_ptr<CResult_FFI_RLNProof_ptr_Vec_uint8_t>(
+      [&]() -> FFI_RLNProof_t* { return (FFI_RLNProof_t*)proof_from_bytes(bytes, false); });
+}
+CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_bytes_be_to_rln_proof(const Vec_uint8_t* bytes) {
+  return guard_ptr<CResult_FFI_RLNProof_ptr_Vec_uint8_t>(
+      [&]() -> FFI_RLNProof_t* { return (FFI_RLNProof_t*)proof_from_bytes(bytes, true); });
+}
+void ffi_rln_proof_free(FFI_RLNProof_t* proof) { delete (FFI_RLNProof*)proof; }
+
+// ================================================================================ witness input
+CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t ffi_rln_witness_input_new_single(
+    const CFr_t* identity_secret, const CFr_t* user_message_limit, const CFr_t* message_id,
+    const Vec_CFr_t* path_elements, const Vec_uint8_t* identity_path_index, const CFr_t* x,
+    const CFr_t* external_nullifier) {
+  return guard_ptr<CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t>([&]() -> FFI_RLNWitnessInput_t* {
+    std::unique_ptr<FFI_RLNWitnessInput> w(new FFI_RLNWitnessInput);
+    w->identity_secret = R(identity_secret);
+    w->user_message_limit = R(user_message_limit);
+    w->message_id = R(message_id);
+    w->path_elements.assign((const CFr*)path_elements->ptr, (const CFr*)path_elements->ptr + path_elements->len);
+    w->identity_path_index.assign(identity_path_index->ptr, identity_path_index->ptr + identity_path_index->len);
+    w->x = R(x);
+    w->external_nullifier = R(external_nullifier);
+    validate_witness(*w);
+    return (FFI_RLNWitnessInput_t*)w.release();
+  });
+}
+#define W(w) (*(FFI_RLNWitnessInput*)*(w))
+uint8_t ffi_rln_witness_input_get_version_byte(FFI_RLNWitnessInput_t* const*) { return 0x00; }
+CFr_t* ffi_rln_witness_input_get_identity_secret(FFI_RLNWitnessInput_t* const* w) { return box_cfr(W(w).identity_secret); }
+CFr_t* ffi_rln_witness_input_get_user_message_limit(FFI_RLNWitnessInput_t* const* w) { return box_cfr(W(w).user_message_limit); }
+CFr_t* ffi_rln_witness_input_get_message_id(FFI_RLNWitnessInput_t* const* w) { return box_cfr(W(w).message_id); }
+Vec_CFr_t ffi_rln_witness_input_get_path_elements(FFI_RLNWitnessInput_t* const* w) { return make_vec_cfr(W(w).path_elements); }
+Vec_uint8_t ffi_rln_witness_input_get_identity_path_index(FFI_RLNWitnessInput_t* const* w) { return make_bytes(W(w).identity_path_index); }
+CFr_t* ffi_rln_witness_input_get_x(FFI_RLNWitnessInput_t* const* w) { return box_cfr(W(w).x); }
+CFr_t* ffi_rln_witness_input_get_external_nullifier(FFI_RLNWitnessInput_t* const* w) { return box_cfr(W(w).external_nullifier); }
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_witness_to_bytes_le(FFI_RLNWitnessInput_t* const* w) {
+  return guard_bytes([&]() { return witness_bytes(W(w), false); });
+}
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_witness_to_bytes_be(FFI_RLNWitnessInput_t* const* w) {
+  return guard_bytes([&]() { return witness_bytes(W(w), true); });
+}
+CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t ffi_bytes_le_to_rln_witness(const Vec_uint8_t* b) {
+  return guard_ptr<CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t>(
+      [&]() -> FFI_RLNWitnessInput_t* { return (FFI_RLNWitnessInput_t*)witness_from_bytes(b, false); });
+}
+CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t ffi_bytes_be_to_rln_witness(const Vec_uint8_t* b) {
+  return guard_ptr<CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t>(
+      [&]() -> FFI_RLNWitnessInput_t* { return (FFI_RLNWitnessInput_t*)witness_from_bytes(b, true); });
+}
+void ffi_rln_witness_input_free(FFI_RLNWitnessInput_t* w) { delete (FFI_RLNWitnessInput*)w; }
+
+// ================================================================================ proof values
+#define PV(p) (*(FFI_RLNProofValues*)*(p))
+CFr_t* ffi_rln_proof_values_get_root(FFI_RLNProofValues_t* const* pv) { return box_cfr(PV(pv).root); }
+CFr_t* ffi_rln_proof_values_get_x(FFI_RLNProofValues_t* const* pv) { return box_cfr(PV(pv).x); }
+CFr_t* ffi_rln_proof_values_get_external_nullifier(FFI_RLNProofValues_t* const* pv) { return box_cfr(PV(pv).external_nullifier); }
+CResult_CFr_ptr_Vec_uint8_t ffi_rln_proof_values_get_y(FFI_RLNProofValues_t* const* pv) { return {box_cfr(PV(pv).y), no_err()}; }
+CResult_CFr_ptr_Vec_uint8_t ffi_rln_proof_values_get_nullifier(FFI_RLNProofValues_t* const* pv) { return {box_cfr(PV(pv).nullifier), no_err()}; }
+uint8_t ffi_rln_proof_values_get_version_byte(FFI_RLNProofValues_t* const*) { return 0x00; }
+Vec_uint8_t ffi_rln_proof_values_to_bytes_le(FFI_RLNProofValues_t* const* pv) { return make_bytes(values_bytes(PV(pv), false)); }
+Vec_uint8_t ffi_rln_proof_values_to_bytes_be(FFI_RLNProofValues_t* const* pv) { return make_bytes(values_bytes(PV(pv), true)); }
+static FFI_RLNProofValues* pv_from(const Vec_uint8_t* b, bool be) {
+  if (!b || b->len == 0) throw Error("Expected to read 1 bytes but read 0 bytes");
+  Cursor c{b->ptr, b->len, 0, be};
+  std::unique_ptr<FFI_RLNProofValues> v(new FFI_RLNProofValues(values_from(c)));
+  return v.release();
+}
+CResult_FFI_RLNProofValues_ptr_Vec_uint8_t ffi_bytes_le_to_rln_proof_values(const Vec_uint8_t* b) {
+  return guard_ptr<CResult_FFI_RLNProofValues_ptr_Vec_uint8_t>(
+      [&]() -> FFI_RLNProofValues_t* { return (FFI_RLNProofValues_t*)pv_from(b, false); });
+}
+CResult_FFI_RLNProofValues_ptr_Vec_uint8_t ffi_bytes_be_to_rln_proof_values(const Vec_uint8_t* b) {
+  return guard_ptr<CResult_FFI_RLNProofValues_ptr_Vec_uint8_t>(
+      [&]() -> FFI_RLNProofValues_t* { return (FFI_RLNProofValues_t*)pv_from(b, true); });
+}
+void ffi_rln_proof_values_free(FFI_RLNProofValues_t* pv) { delete (FFI_RLNProofValues*)pv; }
+
+// ================================================================================ tree
+#define RLNM(r) (*(FFI_RLN*)*(r))
+static std::vector<CFr> vec_of(const Vec_CFr_t* v) {
+  return std::vector<CFr>((const CFr*)v->ptr, (const CFr*)v->ptr + v->len);
+}
+CBoolResult_t ffi_set_tree(FFI_RLN_t** rln, size_t tree_depth) {
+  return guard_bool([&]() { RLNM(rln).new_tree(tree_depth); return true; });
+}
+CBoolResult_t ffi_delete_leaf(FFI_RLN_t** rln, size_t index) {
+  return guard_bool([&]() { RLNM(rln).del(index); return true; });
+}
+CBoolResult_t ffi_set_leaf(FFI_RLN_t** rln, size_t index, const CFr_t* leaf) {
+  return guard_bool([&]() { RLNM(rln).set(index, R(leaf)); return true; });
+}
+CResult_CFr_ptr_Vec_uint8_t ffi_get_leaf(FFI_RLN_t* const* rln, size_t index) {
+  return guard_ptr<CResult_CFr_ptr_Vec_uint8_t>([&]() { return box_cfr(RLNM(rln).get(index)); });
+}
+size_t ffi_leaves_set(FFI_RLN_t* const* rln) { return RLNM(rln).next_index; }
+CBoolResult_t ffi_set_next_leaf(FFI_RLN_t** rln, const CFr_t* leaf) {
+  return guard_bool([&]() { RLNM(rln).set(RLNM(rln).next_index, R(leaf)); return true; });  // update_next :271-274
+}
+CBoolResult_t ffi_set_leaves_from(FFI_RLN_t** rln, size_t index, const Vec_CFr_t* leaves) {
+  return guard_bool([&]() { RLNM(rln).override_range(index, vec_of(leaves), {}); return true; });  // public.rs:364-368
+}
+CBoolResult_t ffi_init_tree_with_leaves(FFI_RLN_t** rln, const Vec_CFr_t* leaves) {
+  return guard_bool([&]() {  // public.rs:376-379
+    FFI_RLN& r = RLNM(rln);
+    r.new_tree(r.tree.depth);
+    r.override_range(0, vec_of(leaves), {});
+    return true;
+  });
+}
+CBoolResult_t ffi_atomic_operation(FFI_RLN_t** rln, size_t index, const Vec_CFr_t* leaves, const Vec_size_t* indices) {
+  return guard_bool([&]() {
+    RLNM(rln).override_range(index, vec_of(leaves), std::vector<size_t>(indices->ptr, indices->ptr + indices->len));
+    return true;
+  });
+}
+CBoolResult_t ffi_seq_atomic_operation(FFI_RLN_t** rln, const Vec_CFr_t* leaves, const Vec_uint8_t* indices) {
+  return guard_bool([&]() {  // ffi_tree.rs:170-187
+    std::vector<size_t> idx(indices->ptr, indices->ptr + indices->len);
+    RLNM(rln).override_range(RLNM(rln).next_index, vec_of(leaves), idx);
+    return true;
+  });
+}
+CFr_t* ffi_get_root(FFI_RLN_t* const* rln) {
+  CFr r;
+  memset(r.le, 0, 32);
+  try {
+    RLNM(rln).tree.get_node_host(0, r.le);
+  } catch (...) {
+  }
+  return box_cfr(r);
+}
+CResult_FFI_MerkleProof_ptr_Vec_uint8_t ffi_get_merkle_proof(FFI_RLN_t* const* rln, size_t index) {
+  return guard_ptr<CResult_FFI_MerkleProof_ptr_Vec_uint8_t>([&]() -> FFI_MerkleProof_t* {
+    FFI_RLN& r = RLNM(rln);
+    if (index >= r.tree.capacity()) throw Error("Leaf index out of bounds");
+    size_t d = r.tree.depth;
+    std::vector<CFr> elems(d);
+    std::vector<uint8_t> bits(d);
+    r.tree.proof_host(index, (uint8_t*)elems.data(), bits.data());
+    FFI_MerkleProof_t* mp = (FFI_MerkleProof_t*)malloc(sizeof(FFI_MerkleProof_t));
+    mp->path_elements = make_vec_cfr(elems);
+    mp->path_index = make_bytes(bits);
+    return mp;
+  });
+}
+void ffi_merkle_proof_free(FFI_MerkleProof_t* proof) {
+  if (!proof) return;
+  free(proof->path_elements.ptr);
+  free(proof->path_index.ptr);
+  free(proof);
+}
+CBoolResult_t ffi_set_metadata(FFI_RLN_t** rln, const Vec_uint8_t* metadata) {
+  return guard_bool([&]() { RLNM(rln).metadata.assign(metadata->ptr, metadata->ptr + metadata->len); return true; });
+}
+CResult_Vec_uint8_Vec_uint8_t ffi_get_metadata(FFI_RLN_t* const* rln) {
+  return guard_bytes([&]() { return RLNM(rln).metadata; });
+}
+CBoolResult_t ffi_flush(FFI_RLN_t** rln) {
+  (void)rln;
+  return CBoolResult_t{true, no_err()};  // nothing buffered: the tree lives in HBM
+}
+
+// ================================================================================ CFr / Vec helpers
+CFr_t* ffi_cfr_zero(void) { return box_cfr(cfr_from_u64(0)); }
+CFr_t* ffi_cfr_one(void) { return box_cfr(cfr_from_u64(1)); }
+CResult_Vec_uint8_Vec_uint8_t ffi_cfr_to_bytes_le(const CFr_t* cfr) {
+  return guard_bytes([&]() { return std::vector<uint8_t>(R(cfr).le, R(cfr).le + 32); });
+}
+CResult_Vec_uint8_Vec_uint8_t ffi_cfr_to_bytes_be(const CFr_t* cfr) {
+  return guard_bytes([&]() {
+    std::vector<uint8_t> b(32);
+    be32(R(cfr).le, b.data());
+    return b;
+  });
+}
+static CFr cfr_from_bytes(const Vec_uint8_t* bytes, bool be) {
+  if (!bytes) throw Error("Input data too short: expected at least 32 bytes, got 0 bytes");
+  Cursor c{bytes->ptr, bytes->len, 0, be};
+  return c.fr();
+}
+CResult_CFr_ptr_Vec_uint8_t ffi_bytes_le_to_cfr(const Vec_uint8_t* bytes) {
+  return guard_ptr<CResult_CFr_ptr_Vec_uint8_t>([&]() { return box_cfr(cfr_from_bytes(bytes, false)); });
+}
+CResult_CFr_ptr_Vec_uint8_t ffi_bytes_be_to_cfr(const Vec_uint8_t* bytes) {
+  return guard_ptr<CResult_CFr_ptr_Vec_uint8_t>([&]() { return box_cfr(cfr_from_bytes(bytes, true)); });
+}
+CFr_t* ffi_uint_to_cfr(uint32_t value) { return box_cfr(cfr_from_u64(value)); }
+Vec_uint8_t ffi_cfr_debug(const CFr_t* cfr) { return make_str(cfr ? cfr_dec(R(cfr)) : "None"); }
+void ffi_cfr_free(CFr_t* cfr) { free(cfr); }
+
+Vec_CFr_t ffi_vec_cfr_new(size_t capacity) {
+  size_t cap = capacity ? capacity : 1;
+  return {(CFr_t*)malloc(cap * sizeof(CFr)), 0, cap};
+}
+Vec_CFr_t ffi_vec_cfr_from_cfr(const CFr_t* cfr) { return make_vec_cfr({R(cfr)}); }
+void ffi_vec_cfr_push(Vec_CFr_t* v, const CFr_t* cfr) {
+  if (v->len == v->cap || !v->ptr) {
+    size_t cap = v->cap ? v->cap * 2 : 4;
+    v->ptr = (CFr_t*)realloc(v->ptr, cap * sizeof(CFr));
+    v->cap = cap;
+  }
+  ((CFr*)v->ptr)[v->len++] = R(cfr);
+}
+size_t ffi_vec_cfr_len(const Vec_CFr_t* v) { return v->len; }
+const CFr_t* ffi_vec_cfr_get(const Vec_CFr_t* v, size_t i) { return i < v->len ? (const CFr_t*)((const CFr*)v->ptr + i) : nullptr; }
+static std::vector<uint8_t> vec_cfr_bytes(const Vec_CFr_t* v, bool be) {  // utils.rs:123-156
+  std::vector<uint8_t> b;
+  put_u64(b, v->len, be);
+  for (size_t i = 0; i < v->len; i++) put_fr(b, ((const CFr*)v->ptr)[i], be);
+  return b;
+}
+CResult_Vec_uint8_Vec_uint8_t ffi_vec_cfr_to_bytes_le(const Vec_CFr_t* v) { return guard_bytes([&]() { return vec_cfr_bytes(v, false); }); }
+CResult_Vec_uint8_Vec_uint8_t ffi_vec_cfr_to_bytes_be(const Vec_CFr_t* v) { return guard_bytes([&]() { return vec_cfr_bytes(v, true); }); }
+static CResult_Vec_CFr_Vec_uint8_t vec_cfr_from(const Vec_uint8_t* bytes, bool be) {
+  try {
+    Cursor c{bytes->ptr, bytes->len, 0, be};
+    return {make_vec_cfr(c.vec_fr()), no_err()};
+  } catch (const std::exception& e) {
+    return {Vec_CFr_t{nullptr, 0, 0}, make_str(e.what())};
+  }
+}
+CResult_Vec_CFr_Vec_uint8_t ffi_bytes_le_to_vec_cfr(const Vec_uint8_t* bytes) { return vec_cfr_from(bytes, false); }
+CResult_Vec_CFr_Vec_uint8_t ffi_bytes_be_to_vec_cfr(const Vec_uint8_t* bytes) { return vec_cfr_from(bytes, true); }
+Vec_uint8_t ffi_vec_cfr_debug(const Vec_CFr_t* v) {
+  if (!v) return make_str("None");
+  std::string s = "[";
+  for (size_t i = 0; i < v->len; i++) s += (i ? ", " : "") + cfr_dec(((const CFr*)v->ptr)[i]);
+  return make_str(s + "]");
+}
+void ffi_vec_cfr_free(Vec_CFr_t v) { free(v.ptr); }
+
+static std::vector<uint8_t> vec_u8_bytes(const Vec_uint8_t* v, bool be) {  // utils.rs:158-190
+  std::vector<uint8_t> b;
+  put_u64(b, v->len, be);
+  b.insert(b.end(), v->ptr, v->ptr + v->len);
+  return b;
+}
+CResult_Vec_uint8_Vec_uint8_t ffi_vec_u8_to_bytes_le(const Vec_uint8_t* v) { return guard_bytes([&]() { return vec_u8_bytes(v, false); }); }
+CResult_Vec_uint8_Vec_uint8_t ffi_vec_u8_to_bytes_be(const Vec_uint8_t* v) { return guard_bytes([&]() { return vec_u8_bytes(v, true); }); }
+CResult_Vec_uint8_Vec_uint8_t ffi_bytes_le_to_vec_u8(const Vec_uint8_t* bytes) {
+  return guard_bytes([&]() { Cursor c{bytes->ptr, bytes->len, 0, false}; return c.vec_u8(); });
+}
+CResult_Vec_uint8_Vec_uint8_t ffi_bytes_be_to_vec_u8(const Vec_uint8_t* bytes) {
+  return guard_bytes([&]() { Cursor c{bytes->ptr, bytes->len, 0, true}; return c.vec_u8(); });
+}
+Vec_uint8_t ffi_vec_u8_debug(const Vec_uint8_t* v) {
+  if (!v) return make_str("None");
+  std::string s = "[";
+  char buf[8];
+  for (size_t i = 0; i < v->len; i++) {
+    snprintf(buf, sizeof buf, "%x", v->ptr[i]);
+    s += (i ? ", " : "") + std::string(buf);
+  }
+  return make_str(s + "]");
+}
+void ffi_vec_u8_free(Vec_uint8_t v) { free(v.ptr); }
+
+CFr_t* ffi_hash_to_field_le(const Vec_uint8_t* input) {
+  CFr r;
+  hash_to_field_le(input->ptr, input->len, r.le);
+  return box_cfr(r);
+}
+CFr_t* ffi_hash_to_field_be(const Vec_uint8_t* input) {
+  CFr r;
+  hash_to_field_be(input->ptr, input->len, r.le);
+  return box_cfr(r);
+}
+CFr_t* ffi_poseidon_hash_pair(const CFr_t* a, const CFr_t* b) {
+  CFr in[2] = {R(a), R(b)}, out;
+  memset(out.le, 0, 32);
+  (void)rlnamd_poseidon_hash((const uint8_t*)in, 1, 2, out.le);  // one-lane launch of the batch kernel
+  return box_cfr(out);
+}
+Vec_CFr_t ffi_key_gen(void) {  // keygen (protocol/keygen.rs:18-30): random secret, commitment = H(secret)
+  CFr secret = random_fr(), commitment;
+  memset(commitment.le, 0, 32);
+  (void)rlnamd_poseidon_hash(secret.le, 1, 1, commitment.le);
+  return make_vec_cfr({secret, commitment});
+}
+void ffi_c_string_free(Vec_uint8_t s) { free(s.ptr); }
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+// Dense Poseidon Merkle tree resident in HBM.
+//
+// Device-side counterpart of FullMerkleTree (/root/reference/utils/src/merkle_tree/full_merkle_tree.rs):
+// same heap layout (node i has children 2i+1, 2i+2; leaves at 2^d - 1 + idx; :20-40,336-358), same
+// level-by-level rehash of the touched parent range (update_hashes :360-399), same proof shape
+// (bottom-up siblings + index bits, bit = 1 when the node is a right child, :288-304,420-439).
+// Nodes are kept as Montgomery residues in HBM (2^(d+1) - 1 x 32 B: 64 MiB at depth 20).
+#pragma once
+#include <vector>
+
+#include "common.h"
+#include "field.h"
+
+namespace rlnamd {
+
+struct MerkleTreeDev {
+  int depth = 0;
+  DevBuf<Fr> nodes;
+  std::vector<Fr> zero_hashes;  // [level] Montgomery, level 0 = root ... depth = leaf
+  hipStream_t stream = 0;
+
+  void init(int depth_, const uint8_t default_leaf_le[32]);  // FullMerkleTree::new :82-115
+  size_t capacity() const { return (size_t)1 << depth; }
+  size_t num_nodes() const { return ((size_t)2 << depth) - 1; }
+
+  // write `n` canonical LE leaves starting at leaf index `start`, then rehash (set_range :197-223).
+  void set_range_host(size_t start, const uint8_t* leaves_le, size_t n);
+  void set_range_device(size_t start, const uint8_t* d_leaves_le, size_t n);
+  // leaves i -> Fr(first + i): synthetic fill generated on the device (bench / config 3), then rehash
+  void fill_sequential_device(size_t start, size_t n, uint64_t first);
+  void rehash(size_t lo_node, size_t hi_node);  // update_hashes :360-399
+
+  void get_node_host(size_t node, uint8_t out_le[32]);
+  // one proof -> host (elems: depth*32 B canonical LE bottom-up, bits: depth bytes)
+  void proof_host(size_t leaf, uint8_t* elems_le, uint8_t* bits);
+  // `count` proofs for leaves [first, first+count) written to device buffers
+  // d_elems: [count][depth][32] canonical LE, d_bits: [count][depth]
+  void proofs_device(size_t first, size_t count, uint8_t* d_elems, uint8_t* d_bits);
+  // recompute the root from each emitted proof + its leaf on the device (compute_root_from :441-446);
+  // returns the number of proofs whose root differs from the tree root.
+  size_t verify_proofs_device(size_t first, size_t count, const uint8_t* d_elems, const uint8_t* d_bits);
+};
+
+}  // namespace rlnamd

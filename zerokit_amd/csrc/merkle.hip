@@ -1,0 +1,189 @@
+#include "merkle.h"
+
+#include <string.h>
+
+#include "poseidon.h"
+
+namespace rlnamd {
+
+// parents [first, first+count): nodes[p] = H(nodes[2p+1], nodes[2p+2])   (hash_parent, :373-376)
+__global__ void __launch_bounds__(256) k_hash_parents(Fr* __restrict__ nodes, size_t first, size_t count,
+                                                      PoseidonView pv) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  size_t p = first + i;
+  Fr in[2] = {nodes[2 * p + 1], nodes[2 * p + 2]};
+  nodes[p] = poseidon_hash_dev<3>(in, pv);
+}
+
+// zero_hashes[depth] = default leaf; zero_hashes[l] = H(z[l+1], z[l+1])  -- single lane, init only
+__global__ void k_zero_hashes(Fr* zh, int depth, PoseidonView pv) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int l = depth - 1; l >= 0; l--) {
+    Fr in[2] = {zh[l + 1], zh[l + 1]};
+    zh[l] = poseidon_hash_dev<3>(in, pv);
+  }
+}
+
+// nodes of level l (2^l of them starting at 2^l - 1) <- zero_hashes[l]
+__global__ void __launch_bounds__(256) k_fill_levels(Fr* __restrict__ nodes, const Fr* __restrict__ zh, int depth,
+                                                     size_t total) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int level = 63 - __clzll((unsigned long long)(i + 1));
+  nodes[i] = zh[level];
+}
+
+__global__ void __launch_bounds__(256) k_set_leaves(Fr* __restrict__ nodes, size_t first_node,
+                                                    const uint32_t* __restrict__ leaves_le, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  nodes[first_node + i] = Fr::from_canonical(leaves_le + i * 8);
+}
+
+__global__ void __launch_bounds__(256) k_fill_seq(Fr* __restrict__ nodes, size_t first_node, size_t n,
+                                                  uint64_t first) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t v = first + i;
+  uint32_t c[8] = {(uint32_t)v, (uint32_t)(v >> 32), 0, 0, 0, 0, 0, 0};
+  nodes[first_node + i] = Fr::from_canonical(c);
+}
+
+// one lane per (proof, level): coalesced 32-byte stores of the sibling in canonical form
+__global__ void __launch_bounds__(256) k_proofs(const Fr* __restrict__ nodes, int depth, size_t first, size_t count,
+                                                uint32_t* __restrict__ elems, uint8_t* __restrict__ bits) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count * (size_t)depth) return;
+  size_t pi = t / depth;
+  int lvl = (int)(t % depth);  // 0 = leaf level
+  size_t node = (((size_t)1 << depth) - 1 + first + pi);
+  // ancestor of the leaf at height lvl: ((node + 1) >> lvl) - 1
+  size_t cur = ((node + 1) >> lvl) - 1;
+  bool right = (cur & 1) == 0;  // even heap index == right child (:296-300)
+  size_t sib = right ? cur - 1 : cur + 1;
+  nodes[sib].to_canonical(elems + t * 8);
+  bits[t] = right ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) k_verify_proofs(const Fr* __restrict__ nodes, int depth, size_t first,
+                                                       size_t count, const uint32_t* __restrict__ elems,
+                                                       const uint8_t* __restrict__ bits, PoseidonView pv,
+                                                       unsigned long long* __restrict__ bad) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  Fr h = nodes[((size_t)1 << depth) - 1 + first + i];
+  for (int l = 0; l < depth; l++) {
+    Fr s = Fr::from_canonical(elems + (i * depth + l) * 8);
+    Fr in[2];
+    if (bits[i * depth + l]) {
+      in[0] = s;
+      in[1] = h;
+    } else {
+      in[0] = h;
+      in[1] = s;
+    }
+    h = poseidon_hash_dev<3>(in, pv);
+  }
+  if (h != nodes[0]) atomicAdd(bad, 1ULL);
+}
+
+void MerkleTreeDev::init(int depth_, const uint8_t default_leaf_le[32]) {
+  require_gpu();
+  if (depth_ < 0 || depth_ > 30) throw Error("InvalidDepth: tree depth must be in [0, 30] for the HBM-resident tree");
+  depth = depth_;
+  nodes.alloc(num_nodes());
+  PoseidonView pv = poseidon_view(3);
+  DevBuf<Fr> zh(depth + 1);
+  uint32_t c[8];
+  memcpy(c, default_leaf_le, 32);
+  Fr leaf = Fr::from_canonical(c);
+  RLN_HIP(hipMemcpyAsync(zh.p + depth, &leaf, sizeof(Fr), hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(k_zero_hashes, dim3(1), dim3(64), 0, stream, zh.p, depth, pv);
+  size_t total = num_nodes();
+  hipLaunchKernelGGL(k_fill_levels, dim3(div_up(total, 256)), dim3(256), 0, stream, nodes.p, zh.p, depth, total);
+  RLN_HIP(hipGetLastError());
+  zero_hashes.resize(depth + 1);
+  RLN_HIP(hipMemcpyAsync(zero_hashes.data(), zh.p, (depth + 1) * sizeof(Fr), hipMemcpyDeviceToHost, stream));
+  RLN_HIP(hipStreamSynchronize(stream));
+}
+
+void MerkleTreeDev::rehash(size_t lo, size_t hi) {
+  PoseidonView pv = poseidon_view(3);
+  while (lo > 0) {
+    lo = ((lo + 1) >> 1) - 1;
+    hi = ((hi + 1) >> 1) - 1;
+    size_t cnt = hi - lo + 1;
+    hipLaunchKernelGGL(k_hash_parents, dim3(div_up(cnt, 256)), dim3(256), 0, stream, nodes.p, lo, cnt, pv);
+  }
+  RLN_HIP(hipGetLastError());
+}
+
+void MerkleTreeDev::set_range_device(size_t start, const uint8_t* d_leaves_le, size_t n) {
+  if (start + n > capacity() || start + n < start) throw Error("TooManySet");
+  if (n == 0) return;
+  size_t first = capacity() - 1 + start;
+  hipLaunchKernelGGL(k_set_leaves, dim3(div_up(n, 256)), dim3(256), 0, stream, nodes.p, first,
+                     (const uint32_t*)d_leaves_le, n);
+  rehash(first, first + n - 1);
+}
+
+void MerkleTreeDev::set_range_host(size_t start, const uint8_t* leaves_le, size_t n) {
+  if (start + n > capacity() || start + n < start) throw Error("TooManySet");
+  if (n == 0) return;
+  DevBuf<uint8_t> tmp(n * 32);
+  RLN_HIP(hipMemcpyAsync(tmp.p, leaves_le, n * 32, hipMemcpyHostToDevice, stream));
+  set_range_device(start, tmp.p, n);
+  RLN_HIP(hipStreamSynchronize(stream));
+}
+
+void MerkleTreeDev::fill_sequential_device(size_t start, size_t n, uint64_t first_value) {
+  if (start + n > capacity()) throw Error("TooManySet");
+  if (n == 0) return;
+  size_t first = capacity() - 1 + start;
+  hipLaunchKernelGGL(k_fill_seq, dim3(div_up(n, 256)), dim3(256), 0, stream, nodes.p, first, n, first_value);
+  rehash(first, first + n - 1);
+}
+
+void MerkleTreeDev::get_node_host(size_t node, uint8_t out_le[32]) {
+  if (node >= num_nodes()) throw Error("InvalidLeaf");
+  Fr v;
+  RLN_HIP(hipMemcpyAsync(&v, nodes.p + node, sizeof(Fr), hipMemcpyDeviceToHost, stream));
+  RLN_HIP(hipStreamSynchronize(stream));
+  uint32_t c[8];
+  v.to_canonical(c);
+  memcpy(out_le, c, 32);
+}
+
+void MerkleTreeDev::proofs_device(size_t first, size_t count, uint8_t* d_elems, uint8_t* d_bits) {
+  if (first + count > capacity()) throw Error("InvalidLeaf");
+  if (count == 0 || depth == 0) return;
+  size_t total = count * (size_t)depth;
+  hipLaunchKernelGGL(k_proofs, dim3(div_up(total, 256)), dim3(256), 0, stream, nodes.p, depth, first, count,
+                     (uint32_t*)d_elems, d_bits);
+  RLN_HIP(hipGetLastError());
+}
+
+void MerkleTreeDev::proof_host(size_t leaf, uint8_t* elems_le, uint8_t* bits) {
+  if (leaf >= capacity()) throw Error("InvalidLeaf");
+  if (depth == 0) return;
+  DevBuf<uint8_t> e((size_t)depth * 32), b(depth);
+  proofs_device(leaf, 1, e.p, b.p);
+  RLN_HIP(hipMemcpyAsync(elems_le, e.p, (size_t)depth * 32, hipMemcpyDeviceToHost, stream));
+  RLN_HIP(hipMemcpyAsync(bits, b.p, depth, hipMemcpyDeviceToHost, stream));
+  RLN_HIP(hipStreamSynchronize(stream));
+}
+
+size_t MerkleTreeDev::verify_proofs_device(size_t first, size_t count, const uint8_t* d_elems, const uint8_t* d_bits) {
+  if (count == 0) return 0;
+  DevBuf<unsigned long long> bad(1);
+  RLN_HIP(hipMemsetAsync(bad.p, 0, sizeof(unsigned long long), stream));
+  hipLaunchKernelGGL(k_verify_proofs, dim3(div_up(count, 256)), dim3(256), 0, stream, nodes.p, depth, first, count,
+                     (const uint32_t*)d_elems, d_bits, poseidon_view(3), bad.p);
+  unsigned long long h = 0;
+  RLN_HIP(hipMemcpyAsync(&h, bad.p, sizeof(h), hipMemcpyDeviceToHost, stream));
+  RLN_HIP(hipStreamSynchronize(stream));
+  return (size_t)h;
+}
+
+}  // namespace rlnamd

@@ -1,0 +1,89 @@
+// Poseidon over BN254 Fr, bit-identical to the reference's un-optimised form
+// (/root/reference/utils/src/poseidon/poseidon_hash.rs:97-135: per round add t constants, x^5 on all lanes
+// (full) or lane 0 (partial), dense t x t MDS; output state[0]) with the Grain-LFSR constants of
+// poseidon_constants.rs:15-261 and the (t, R_F, R_P) table of rln/src/hashers.rs:14-23.
+#pragma once
+#include <vector>
+
+#include "common.h"
+#include "field.h"
+
+namespace rlnamd {
+
+constexpr int POSEIDON_MAX_T = 4;  // RLN uses t = 2, 3, 4 (1, 2, 3 inputs)
+
+struct PoseidonParams {
+  int t = 0, rf = 0, rp = 0;
+  std::vector<Fr> ark;  // (rf+rp)*t, Montgomery
+  std::vector<Fr> mds;  // t*t row-major, Montgomery
+};
+
+// host: derive the constants exactly as find_poseidon_ark_and_mds does (poseidon_constants.rs:207-261)
+PoseidonParams poseidon_derive_params(int t);
+
+// device-resident constant tables for t = 2..4
+struct PoseidonDev {
+  int rf[POSEIDON_MAX_T + 1] = {0}, rp[POSEIDON_MAX_T + 1] = {0};
+  DevBuf<Fr> ark[POSEIDON_MAX_T + 1];
+  DevBuf<Fr> mds[POSEIDON_MAX_T + 1];
+  void init();
+  bool ready = false;
+};
+PoseidonDev& poseidon_dev();  // lazily initialised singleton (per process == per GPU)
+
+// device pointers view handed to kernels
+struct PoseidonView {
+  const Fr* ark;
+  const Fr* mds;
+  int rf, rp;
+};
+PoseidonView poseidon_view(int t);
+
+#if defined(__HIPCC__)
+// One hash on one lane.  `in` are Montgomery residues.
+template <int T, bool FULL>
+__device__ __forceinline__ void poseidon_round_dev(Fr* st, const Fr* __restrict__ ark, const Fr* __restrict__ mds) {
+#pragma unroll
+  for (int j = 0; j < T; j++) st[j] = st[j] + ark[j];
+#pragma unroll
+  for (int j = 0; j < (FULL ? T : 1); j++) {
+    Fr x2 = st[j].sqr();
+    st[j] = x2.sqr() * st[j];
+  }
+  Fr nx[T];
+#pragma unroll
+  for (int i = 0; i < T; i++) {
+    Fr acc = mds[i * T] * st[0];
+#pragma unroll
+    for (int j = 1; j < T; j++) acc = acc + mds[i * T + j] * st[j];
+    nx[i] = acc;
+  }
+#pragma unroll
+  for (int j = 0; j < T; j++) st[j] = nx[j];
+}
+
+// One hash on one lane.  `in` are Montgomery residues.  Rounds run as three loops (first R_F/2 full,
+// R_P partial, last R_F/2 full) so the state stays in registers with no per-round branch.
+template <int T>
+__device__ __forceinline__ Fr poseidon_hash_dev(const Fr* in, const PoseidonView& pv) {
+  Fr st[T];
+  st[0] = Fr::zero();
+#pragma unroll
+  for (int j = 1; j < T; j++) st[j] = in[j - 1];
+  const int half = pv.rf / 2;
+  const Fr* ark = pv.ark;
+#pragma unroll 1
+  for (int r = 0; r < half; r++, ark += T) poseidon_round_dev<T, true>(st, ark, pv.mds);
+#pragma unroll 1
+  for (int r = 0; r < pv.rp; r++, ark += T) poseidon_round_dev<T, false>(st, ark, pv.mds);
+#pragma unroll 1
+  for (int r = 0; r < half; r++, ark += T) poseidon_round_dev<T, true>(st, ark, pv.mds);
+  return st[0];
+}
+#endif
+
+// Batched hash: `n` hashes of `arity` inputs each.  in/out are canonical 32-byte LE on the device
+// (in: [n][arity][32], out: [n][32]).
+void poseidon_hash_batch_device(const uint8_t* d_in, size_t n, int arity, uint8_t* d_out, hipStream_t s);
+
+}  // namespace rlnamd

@@ -1,0 +1,87 @@
+// Batched RLN Groth16 prover resident on one MI355X.
+//
+// Device-side replacement for the path below generate_zk_proof_with_rs
+// (/root/reference/rln/src/protocol/proof.rs:753-777):
+//   calc_witness            (circuit/iden3calc.rs:20-60, iden3calc/graph.rs:246-272)  -> k_witness
+//   CircomReduction         (circuit/qap.rs:30-98)                                     -> k_matvec, k_ntt_pass, k_hquot
+//   create_proof_with_...   (ark-groth16 0.5.0; restated in partial_proof.rs:182-274)  -> k_recode, k_msm_*, k_finalize
+//   proof_values_from_witness (protocol/witness.rs:759-828)                            -> k_proof_values
+//
+// Data layout (everything "batch-lane"): every per-proof quantity is stored [index][proof] with 32-byte
+// elements, so the 64 lanes of a wavefront are 64 different proofs executing the same straight-line work
+// on the same index: all loads/stores are 2 KiB-contiguous per wave, table rows / twiddles / matrix
+// coefficients are wave-uniform, and no kernel needs LDS transposes or cross-lane traffic until the final
+// per-proof reduction.
+//
+// MSM: the bases are fixed by the zkey, so Pippenger's bucket phase is replaced by a fixed-base comb table
+// held in HBM: for every base P_k and every c-bit window j the table stores d * 2^(c j) * P_k for
+// d = 1..2^(c-1) in affine form (signed digits).  A proof's MSM is then  sum_k sum_j +-T[k][j][|d_kj|]:
+// mixed additions only, no bucket reduction, no data-dependent writes.  288 GB of HBM is what makes the
+// table affordable (c = 8: 10 GB; c = 12: 90 GB).
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "curve.h"
+#include "zkey.h"
+
+namespace rlnamd {
+
+constexpr int PROVER_STAGES = 8;
+extern const char* const kProverStageNames[PROVER_STAGES];
+
+struct ProverConfig {
+  int window_bits = 0;      // 0 = take RLNAMD_WINDOW_BITS or the default (8)
+  size_t max_batch = 1024;  // workspace capacity in proofs (rounded up to a multiple of 64)
+};
+
+struct ProofOut {            // one proof, host side
+  uint8_t compressed[128];   // ark-serialize compressed Proof{a,b,c}
+  uint8_t coords[256];       // affine A.x A.y | B.x.c0 B.x.c1 B.y.c0 B.y.c1 | C.x C.y  (canonical LE)
+  uint8_t values[5][32];     // y, root, nullifier, x, external_nullifier (verifier order, proof.rs:863-869)
+  uint32_t error;            // 0 ok; otherwise witness-graph evaluation failed for this proof
+};
+
+class Prover {
+ public:
+  Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_t graph_len, ProverConfig cfg);
+  ~Prover();
+
+  const Zkey& zkey() const { return zk_; }
+  const Graph& graph() const { return graph_; }
+  size_t capacity() const { return B_; }
+  int window_bits() const { return c_; }
+  int windows() const { return W_; }
+  size_t inputs_per_proof() const { return graph_.inputs_size; }
+  size_t table_bytes() const;
+
+  // Host inputs: `inputs` = n x inputs_size canonical 32-byte LE values (the witness-graph inputs buffer,
+  // slot 0 = 1, iden3calc.rs:122-181); rs = n x 2 x 32 bytes (r, s).  Copies to the device.
+  void upload(size_t n, const uint8_t* inputs, const uint8_t* rs);
+  // Runs the whole pipeline on the resident inputs (async on the prover stream, then synchronises).
+  void run(size_t n);
+  void download(size_t n, ProofOut* out);
+  // convenience
+  void prove(size_t n, const uint8_t* inputs, const uint8_t* rs, ProofOut* out) {
+    upload(n, inputs, rs);
+    run(n);
+    download(n, out);
+  }
+  // stage times of the last run() in ms (HIP events on the prover stream)
+  void stage_ms(float out[PROVER_STAGES]) const;
+  // debug / parity taps (host copies, canonical LE): witness signals and h for proof p of the last run
+  void fetch_witness(size_t p, std::vector<uint8_t>* w_le);
+  void fetch_h(size_t p, std::vector<uint8_t>* h_le);
+
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> d_;
+  Zkey zk_;
+  Graph graph_;
+  size_t B_ = 0;
+  int c_ = 8, W_ = 32;
+};
+
+}  // namespace rlnamd

@@ -1,0 +1,997 @@
+#define RLN_NOINLINE_MUL 1
+#include "prover.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "poseidon.h"
+
+namespace rlnamd {
+
+const char* const kProverStageNames[PROVER_STAGES] = {"witness", "matvec", "ntt",      "recode",
+                                                      "msm_g1",  "msm_g2", "finalize", "values"};
+
+// =====================================================================================================
+// 256-bit integer helpers on canonical limbs (witness-graph ops that are not field ops)
+// =====================================================================================================
+struct U256 {
+  uint32_t v[8];
+};
+__device__ __forceinline__ bool u_is_zero(const U256& a) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o |= a.v[i];
+  return o == 0;
+}
+__device__ __forceinline__ int u_cmp(const U256& a, const U256& b) {  // -1, 0, 1
+  for (int i = 7; i >= 0; i--) {
+    if (a.v[i] != b.v[i]) return a.v[i] > b.v[i] ? 1 : -1;
+  }
+  return 0;
+}
+__device__ __forceinline__ U256 u_from_limbs(const uint32_t* p) {
+  U256 r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = p[i];
+  return r;
+}
+__device__ __forceinline__ U256 u_sub(const U256& a, const U256& b) {
+  U256 r;
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t s = (uint64_t)a.v[i] - b.v[i] - borrow;
+    r.v[i] = (uint32_t)s;
+    borrow = (uint32_t)(s >> 63);
+  }
+  return r;
+}
+__device__ U256 u_shr(const U256& a, unsigned n) {  // n < 256
+  U256 r;
+  unsigned w = n >> 5, b = n & 31;
+  for (int i = 0; i < 8; i++) {
+    uint32_t lo = (i + w < 8) ? a.v[i + w] : 0;
+    uint32_t hi = (i + w + 1 < 8) ? a.v[i + w + 1] : 0;
+    r.v[i] = b ? ((lo >> b) | (hi << (32 - b))) : lo;
+  }
+  return r;
+}
+__device__ U256 u_shl(const U256& a, unsigned n) {  // n < 256, bits above 256 dropped (ark BigInt <<)
+  U256 r;
+  unsigned w = n >> 5, b = n & 31;
+  for (int i = 7; i >= 0; i--) {
+    uint32_t hi = (i >= (int)w) ? a.v[i - w] : 0;
+    uint32_t lo = (i >= (int)w + 1) ? a.v[i - w - 1] : 0;
+    r.v[i] = b ? ((hi << b) | (lo >> (32 - b))) : hi;
+  }
+  return r;
+}
+// a / b and a % b by shift-subtract (b != 0)
+__device__ void u_divmod(const U256& a, const U256& b, U256* q, U256* rem) {
+  U256 Q, Rm;
+  for (int i = 0; i < 8; i++) Q.v[i] = Rm.v[i] = 0;
+  for (int bit = 255; bit >= 0; bit--) {
+    uint32_t top = Rm.v[7] >> 31;
+    Rm = u_shl(Rm, 1);
+    Rm.v[0] |= (a.v[bit >> 5] >> (bit & 31)) & 1;
+    if (top || u_cmp(Rm, b) >= 0) {
+      Rm = u_sub(Rm, b);
+      Q.v[bit >> 5] |= 1u << (bit & 31);
+    }
+  }
+  *q = Q;
+  *rem = Rm;
+}
+
+enum WitnessErr : uint32_t { WERR_NONE = 0, WERR_INPUT_RANGE = 1, WERR_SHIFT = 2, WERR_BITOP = 3, WERR_UNO_ID = 4 };
+
+// Every operation that is not Mul/Add/Sub/Neg/TernCond/Const/Input: iden3calc/graph.rs:72-143, 314-466.
+__device__ __noinline__ Fr witness_slow_op(uint32_t op, Fr fa, Fr fb, uint32_t* err) {
+  U256 a, b, m, half;
+  fa.to_canonical(a.v);
+  fb.to_canonical(b.v);
+  m = u_from_limbs(FrParams::MOD);
+  half = u_from_limbs(FrParams::HALF);
+  auto boolean = [](bool x) { return x ? Fr::one() : Fr::zero(); };
+  switch (op) {
+    case G_DIV:
+      return fb.is_zero() ? Fr::zero() : fa * fb.inv();
+    case G_POW:
+      return fa.pow(b.v);
+    case G_IDIV:
+    case G_MOD: {
+      if (u_is_zero(b)) return Fr::zero();
+      U256 q, r;
+      u_divmod(a, b, &q, &r);
+      return Fr::from_canonical(op == G_IDIV ? q.v : r.v);
+    }
+    case G_EQ:
+      return boolean(u_cmp(a, b) == 0);
+    case G_NEQ:
+      return boolean(u_cmp(a, b) != 0);
+    case G_LT:
+    case G_GT:
+    case G_LEQ:
+    case G_GEQ: {  // values above M/2 are negative (graph.rs:410-466)
+      bool an = u_cmp(a, half) > 0, bn = u_cmp(b, half) > 0;
+      int c = u_cmp(a, b);
+      bool res;
+      if (an == bn)
+        res = op == G_LT ? c < 0 : op == G_GT ? c > 0 : op == G_LEQ ? c <= 0 : c >= 0;
+      else
+        res = (op == G_LT || op == G_LEQ) ? an : bn;
+      return boolean(res);
+    }
+    case G_LAND:
+      return boolean(!u_is_zero(a) && !u_is_zero(b));
+    case G_LOR:
+      return boolean(!u_is_zero(a) || !u_is_zero(b));
+    case G_SHL: {  // graph.rs:314-326
+      if (u_is_zero(b)) return fa;
+      U256 lim = {{254, 0, 0, 0, 0, 0, 0, 0}};
+      if (u_cmp(b, lim) >= 0) return Fr::zero();
+      U256 r = u_shl(a, b.v[0]);
+      if (u_cmp(r, m) >= 0) {
+        *err = WERR_SHIFT;
+        return Fr::zero();
+      }
+      return Fr::from_canonical(r.v);
+    }
+    case G_SHR: {  // graph.rs:328-363
+      if (u_is_zero(b)) return fa;
+      U256 lim = {{254, 0, 0, 0, 0, 0, 0, 0}};
+      if (u_cmp(b, lim) >= 0) return Fr::zero();
+      U256 r = u_shr(a, b.v[0] & 0xFF);
+      return Fr::from_canonical(r.v);
+    }
+    case G_BOR:
+    case G_BAND:
+    case G_BXOR: {  // graph.rs:365-408: one subtraction when d > MODULUS, then from_bigint
+      U256 d;
+      for (int i = 0; i < 8; i++)
+        d.v[i] = op == G_BOR ? (a.v[i] | b.v[i]) : op == G_BAND ? (a.v[i] & b.v[i]) : (a.v[i] ^ b.v[i]);
+      if (u_cmp(d, m) > 0) d = u_sub(d, m);
+      if (u_cmp(d, m) >= 0) {
+        *err = WERR_BITOP;
+        return Fr::zero();
+      }
+      return Fr::from_canonical(d.v);
+    }
+    case G_ID:
+      *err = WERR_UNO_ID;  // "uno operator Id not implemented for Montgomery" (graph.rs:201-204)
+      return Fr::zero();
+    default:
+      return Fr::zero();
+  }
+}
+
+// =====================================================================================================
+// 1. witness: one lane per proof interprets the straight-line graph (graph.rs:246-272)
+// =====================================================================================================
+__global__ void __launch_bounds__(64) k_witness(const GNode* __restrict__ nodes, uint32_t n_nodes,
+                                                const Fr* __restrict__ consts, const uint32_t* __restrict__ inputs,
+                                                uint32_t n_inputs, Fr* __restrict__ V, uint32_t* __restrict__ err,
+                                                uint32_t B, uint32_t nb) {
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= nb) return;
+  uint32_t e = WERR_NONE;
+  Fr last = Fr::zero();
+#pragma unroll 1
+  for (uint32_t n = 0; n < n_nodes; n++) {
+    GNode nd = nodes[n];
+    Fr v;
+    if (nd.op == G_INPUT) {
+      const uint32_t* src = inputs + ((size_t)p * n_inputs + nd.a) * 8;
+      if (limbs_geq(src, FrParams::MOD)) e = e ? e : WERR_INPUT_RANGE;  // u256_to_fr fails (graph.rs:42-45)
+      v = Fr::from_canonical(src);
+    } else if (nd.op == G_CONST) {
+      v = consts[nd.a];
+    } else {
+      // operand forwarding: chains (x^5 s-boxes, MDS sums) read the value produced one node earlier
+      Fr va = (nd.a + 1 == n) ? last : V[(size_t)nd.a * B + p];
+      if (nd.op == G_NEG) {
+        v = va.neg();
+      } else if (nd.op == G_ID) {
+        v = witness_slow_op(G_ID, va, va, &e);
+      } else {
+        Fr vb = (nd.b + 1 == n) ? last : V[(size_t)nd.b * B + p];
+        if (nd.op == G_MUL)
+          v = va * vb;
+        else if (nd.op == G_ADD)
+          v = va + vb;
+        else if (nd.op == G_SUB)
+          v = va - vb;
+        else if (nd.op == G_TERN) {
+          Fr vc = V[(size_t)nd.c * B + p];
+          v = va.is_zero() ? vc : vb;  // graph.rs:214-224
+        } else {
+          uint32_t e2 = 0;
+          v = witness_slow_op(nd.op, va, vb, &e2);
+          if (e2 && !e) e = e2;
+        }
+      }
+    }
+    V[(size_t)n * B + p] = v;
+    last = v;
+  }
+  err[p] = e;
+}
+
+// =====================================================================================================
+// 2. a = A.w, b = B.w, c = a o b on the padded domain (qap.rs:40-67)
+// =====================================================================================================
+struct CsrView {
+  const uint32_t* ptr;
+  const uint32_t* col;  // already mapped to graph node ids
+  const Fr* coef;
+};
+__global__ void __launch_bounds__(256) k_matvec(CsrView A, CsrView Bm, const Fr* __restrict__ V,
+                                                const uint32_t* __restrict__ sig2node, uint32_t nc, uint32_t ni,
+                                                uint32_t n, Fr* __restrict__ abc, uint32_t B, uint32_t nb) {
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  uint32_t row = blockIdx.y * blockDim.y + threadIdx.y;
+  if (p >= nb || row >= n) return;
+  Fr a = Fr::zero(), b = Fr::zero();
+  if (row < nc) {
+    for (uint32_t k = A.ptr[row]; k < A.ptr[row + 1]; k++) a = a + A.coef[k] * V[(size_t)A.col[k] * B + p];
+    for (uint32_t k = Bm.ptr[row]; k < Bm.ptr[row + 1]; k++) b = b + Bm.coef[k] * V[(size_t)Bm.col[k] * B + p];
+  } else if (row < nc + ni) {
+    a = V[(size_t)sig2node[row - nc] * B + p];  // a[nc..nc+ni] = w[0..ni] (qap.rs:54-58)
+  }
+  size_t o = (size_t)row * B + p;
+  abc[o] = a;
+  abc[(size_t)n * B + o] = b;
+  abc[2 * (size_t)n * B + o] = (row < nc) ? a * b : Fr::zero();
+}
+
+// =====================================================================================================
+// 3. radix-2^K register-blocked NTT passes over [index][proof] data (ark-poly Radix2EvaluationDomain
+//    fft/ifft semantics; call sites qap.rs:69-90).  DIF takes natural order to bit-reversed, DIT takes
+//    bit-reversed back to natural, so iNTT(DIF) -> coset scale -> NTT(DIT) needs no reordering pass.
+// =====================================================================================================
+template <int K, bool DIF>
+__global__ void __launch_bounds__(256) k_ntt_pass(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0,
+                                                  const Fr* __restrict__ scale, uint32_t B, uint32_t nb) {
+  constexpr int R = 1 << K;
+  const uint32_t n = 1u << logn;
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  uint32_t g = blockIdx.y * blockDim.y + threadIdx.y;
+  if (p >= nb || g >= (n >> K)) return;
+  Fr* x = data + (size_t)blockIdx.z * n * B + p;
+  uint32_t stride, base;
+  if (DIF) {
+    stride = n >> (s0 + K);  // h_last
+    uint32_t blk = g / stride, lo = g % stride;
+    base = blk * (n >> s0) + lo;
+  } else {
+    stride = 1u << s0;  // h_first
+    uint32_t blk = g / stride, lo = g % stride;
+    base = blk * (stride << K) + lo;
+  }
+  const uint32_t lo = g % stride;
+  Fr e[R];
+#pragma unroll
+  for (int m = 0; m < R; m++) e[m] = x[(size_t)(base + m * stride) * B];
+#pragma unroll
+  for (int t = 0; t < K; t++) {
+    const int half = DIF ? (R >> (t + 1)) : (1 << t);
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+      if (m & half) continue;
+      uint32_t j = (uint32_t)(m & (half - 1)) * stride + lo;
+      uint32_t ti = DIF ? (j << (s0 + t)) : (j << (logn - 1 - (s0 + t)));
+      Fr w = tw[ti];
+      if (DIF) {
+        Fr u = e[m], v = e[m + half];
+        e[m] = u + v;
+        e[m + half] = (u - v) * w;
+      } else {
+        Fr u = e[m], v = e[m + half] * w;
+        e[m] = u + v;
+        e[m + half] = u - v;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < R; m++) {
+    uint32_t pos = base + m * stride;
+    Fr o = e[m];
+    if (scale) o = o * scale[pos];
+    x[(size_t)pos * B] = o;
+  }
+}
+
+// h = a o b - c  (qap.rs:84-95), written over the `a` vector
+__global__ void __launch_bounds__(256) k_hquot(Fr* __restrict__ abc, uint32_t n, uint32_t B, uint32_t nb) {
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  uint32_t i = blockIdx.y * blockDim.y + threadIdx.y;
+  if (p >= nb || i >= n) return;
+  size_t o = (size_t)i * B + p;
+  abc[o] = abc[o] * abc[(size_t)n * B + o] - abc[2 * (size_t)n * B + o];
+}
+
+// =====================================================================================================
+// 4. scalars -> signed c-bit digits, layout [scalar][window][proof] (int16)
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ V, const uint32_t* __restrict__ sig2node,
+                                                uint32_t ns, const Fr* __restrict__ H, uint32_t n,
+                                                const uint32_t* __restrict__ rs, int c, int W,
+                                                int16_t* __restrict__ digits, uint32_t B, uint32_t nb) {
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  uint32_t sid = blockIdx.y * blockDim.y + threadIdx.y;
+  if (p >= nb || sid >= ns + n + 3) return;
+  Fr x;
+  if (sid < ns) {
+    x = V[(size_t)sig2node[sid] * B + p];
+  } else if (sid < ns + n) {
+    x = H[(size_t)(sid - ns) * B + p];
+  } else {
+    Fr r = Fr::from_canonical(rs + (size_t)p * 16);
+    Fr s = Fr::from_canonical(rs + (size_t)p * 16 + 8);
+    uint32_t which = sid - ns - n;  // 0: r, 1: s, 2: -(r s)
+    x = which == 0 ? r : which == 1 ? s : (r * s).neg();
+  }
+  uint32_t l[8];
+  x.to_canonical(l);
+  const uint32_t mask = (1u << c) - 1, E = 1u << (c - 1);
+  uint32_t carry = 0;
+  int16_t* out = digits + (size_t)sid * W * B + p;
+#pragma unroll 1
+  for (int j = 0; j < W; j++) {
+    uint32_t raw = (l[0] & mask) + carry;
+#pragma unroll
+    for (int i = 0; i < 7; i++) l[i] = (l[i] >> c) | (l[i + 1] << (32 - c));
+    l[7] >>= c;
+    int d;
+    if (raw > E) {
+      d = (int)raw - (int)(mask + 1);
+      carry = 1;
+    } else {
+      d = (int)raw;
+      carry = 0;
+    }
+    out[(size_t)j * B] = (int16_t)d;
+  }
+}
+
+// =====================================================================================================
+// 5. table-driven MSM: acc += +-T[point][window][|digit|-1]
+// =====================================================================================================
+struct ChunkDesc {
+  uint32_t pt_begin, pt_end;  // compact point range
+};
+
+template <class F>
+__global__ void __launch_bounds__(64) k_msm(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ sid,
+                                            const ChunkDesc* __restrict__ chunks, uint32_t nchunks,
+                                            const int16_t* __restrict__ digits, XYZZ<F>* __restrict__ part, int c,
+                                            int W, uint32_t B, uint32_t pgroups) {
+  // XCD-aware decode: hardware places block L on XCD L % 8; all proof groups of one chunk share the same
+  // table rows, so they are given consecutive slots on ONE XCD and meet in that XCD's L2.
+  uint32_t L = blockIdx.x;
+  uint32_t xcd = L & 7, q = L >> 3;
+  uint32_t chunk = (q / pgroups) * 8 + xcd, pg = q % pgroups;
+  if (chunk >= nchunks) return;
+  uint32_t p = pg * 64 + threadIdx.x;  // padded lanes run on zero digits
+  ChunkDesc cd = chunks[chunk];
+  XYZZ<F> acc = XYZZ<F>::inf();
+  const int cs = c - 1;
+#pragma unroll 1
+  for (uint32_t k = cd.pt_begin; k < cd.pt_end; k++) {
+    const int16_t* dg = digits + (size_t)sid[k] * W * B + p;
+    const Affine<F>* row = table + (((size_t)k * W) << cs);
+#pragma unroll 1
+    for (int j = 0; j < W; j++) {
+      int d = dg[(size_t)j * B];
+      if (d != 0) {
+        uint32_t e = (uint32_t)(d < 0 ? -d : d) - 1;
+        Affine<F> pt = row[((size_t)j << cs) + e];
+        if (d < 0) pt.y = pt.y.neg();
+        acc.madd(pt);
+      }
+    }
+  }
+  part[(size_t)chunk * B + p] = acc;
+}
+
+// sums[seg][p] = sum over the segment's chunks
+template <class F>
+__global__ void __launch_bounds__(64) k_msm_reduce(const XYZZ<F>* __restrict__ part, const uint32_t* __restrict__ seg_first,
+                                                   uint32_t nseg, XYZZ<F>* __restrict__ sums, uint32_t B, uint32_t nb) {
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  uint32_t seg = blockIdx.y;
+  if (p >= nb || seg >= nseg) return;
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (uint32_t ch = seg_first[seg]; ch < seg_first[seg + 1]; ch++) acc.add(part[(size_t)ch * B + p]);
+  sums[(size_t)seg * B + p] = acc;
+}
+
+// one-time comb table: row (k, j) = { d * 2^(c j) * P_k : d = 1..2^(c-1) } in affine form.
+// Built by doubling the known prefix (multiples 1..m -> m+1..2m are "T[i] + T[m]" and one doubling) with
+// one shared inversion per level (Montgomery's trick; prefix products parked in `scratch`).
+template <class F>
+__global__ void __launch_bounds__(64) k_table_build(const Affine<F>* __restrict__ pts, uint32_t npts, int c, int W,
+                                                    Affine<F>* __restrict__ table, F* __restrict__ scratch) {
+  size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (t >= (size_t)npts * W) return;
+  uint32_t k = (uint32_t)(t / W), j = (uint32_t)(t % W);
+  const uint32_t E = 1u << (c - 1);
+  XYZZ<F> b = XYZZ<F>::from_affine(pts[k]);
+  for (uint32_t i = 0; i < (uint32_t)c * j; i++) b = b.dbl();
+  Affine<F> base = b.to_affine();
+  Affine<F>* row = table + (t << (c - 1));
+  F* pre = scratch + t * (E / 2 ? E / 2 : 1);
+  row[0] = base;
+  for (uint32_t m = 1; m < E; m <<= 1) {
+    const Affine<F> Pm = row[m - 1];
+    F run = F::one();
+    for (uint32_t i = 1; i <= m; i++) {
+      F den = (i < m) ? (row[i - 1].x - Pm.x) : Pm.y.dbl();
+      pre[i - 1] = run;
+      run = run * den;
+    }
+    F inv = run.inv();
+    for (uint32_t i = m; i >= 1; i--) {
+      F den, lam, x3, y3;
+      if (i < m) {
+        Affine<F> Pi = row[i - 1];
+        den = Pi.x - Pm.x;
+        F di = inv * pre[i - 1];
+        lam = (Pi.y - Pm.y) * di;
+        x3 = lam.sqr() - Pi.x - Pm.x;
+        y3 = lam * (Pi.x - x3) - Pi.y;
+      } else {
+        den = Pm.y.dbl();
+        F di = inv * pre[i - 1];
+        F x2 = Pm.x.sqr();
+        lam = (x2.dbl() + x2) * di;
+        x3 = lam.sqr() - Pm.x.dbl();
+        y3 = lam * (Pm.x - x3) - Pm.y;
+      }
+      inv = inv * den;
+      row[m + i - 1] = {x3, y3};
+    }
+  }
+}
+
+// =====================================================================================================
+// 6. finalize: A, B affine; C = s*A + r*B1 + (L + H - rs*delta) ; compressed encoding
+//    (partial_proof.rs:232-273; the alpha/beta/delta/query[0] terms are folded into the MSM segments)
+// =====================================================================================================
+__device__ __forceinline__ bool fq_is_neg_dev(const Fq& y) {
+  uint32_t c[8];
+  y.to_canonical(c);
+  return limbs_gt(c, FqParams::HALF);
+}
+__device__ __forceinline__ void store_fq(uint32_t* dst, const Fq& x) { x.to_canonical(dst); }
+
+__global__ void __launch_bounds__(64) k_finalize(const G1XYZZ* __restrict__ sums1, const G2XYZZ* __restrict__ sums2,
+                                                 const uint32_t* __restrict__ rs, uint32_t* __restrict__ coords,
+                                                 uint8_t* __restrict__ comp, uint32_t B, uint32_t nb) {
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= nb) return;
+  G1Affine A = sums1[p].to_affine();
+  G1Affine B1 = sums1[(size_t)B + p].to_affine();
+  G1XYZZ Cacc = sums1[2 * (size_t)B + p];
+  G2Affine B2 = sums2[p].to_affine();
+  const uint32_t* r = rs + (size_t)p * 16;
+  const uint32_t* s = r + 8;
+  Cacc.add(scalar_mul(A, s));
+  bool r_zero = true;
+  for (int i = 0; i < 8; i++) r_zero &= r[i] == 0;
+  if (!r_zero) Cacc.add(scalar_mul(B1, r));  // g1_b = 0 when r == 0 (partial_proof.rs:242-248)
+  G1Affine C = Cacc.to_affine();
+  uint32_t* o = coords + (size_t)p * 64;
+  store_fq(o, A.x);
+  store_fq(o + 8, A.y);
+  store_fq(o + 16, B2.x.c0);
+  store_fq(o + 24, B2.x.c1);
+  store_fq(o + 32, B2.y.c0);
+  store_fq(o + 40, B2.y.c1);
+  store_fq(o + 48, C.x);
+  store_fq(o + 56, C.y);
+  // ark-serialize compressed Proof{a,b,c}: x with flags in the top byte (0x80: y > -y, 0x40: infinity)
+  uint32_t w[32];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    w[i] = o[i];
+    w[8 + i] = o[16 + i];
+    w[16 + i] = o[24 + i];
+    w[24 + i] = o[48 + i];
+  }
+  if (A.is_inf()) w[7] |= 0x40000000u; else if (fq_is_neg_dev(A.y)) w[7] |= 0x80000000u;
+  if (B2.is_inf()) w[23] |= 0x40000000u;
+  else if (B2.y.c1.is_zero() ? fq_is_neg_dev(B2.y.c0) : fq_is_neg_dev(B2.y.c1)) w[23] |= 0x80000000u;
+  if (C.is_inf()) w[31] |= 0x40000000u; else if (fq_is_neg_dev(C.y)) w[31] |= 0x80000000u;
+  uint32_t* cw = (uint32_t*)(comp + (size_t)p * 128);
+#pragma unroll
+  for (int i = 0; i < 32; i++) cw[i] = w[i];
+}
+
+// =====================================================================================================
+// 7. proof values by the Poseidon formulae (witness.rs:759-828): root, a1, y, nullifier
+// =====================================================================================================
+struct InputSlots {
+  uint32_t secret, limit, msg_id, path, path_idx, x, ext, depth;
+};
+__global__ void __launch_bounds__(64) k_proof_values(const uint32_t* __restrict__ inputs, uint32_t n_inputs,
+                                                     InputSlots sl, PoseidonView p2, PoseidonView p3, PoseidonView p4,
+                                                     uint32_t* __restrict__ values, uint32_t nb) {
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= nb) return;
+  const uint32_t* in = inputs + (size_t)p * n_inputs * 8;
+  auto ld = [&](uint32_t slot) { return Fr::from_canonical(in + (size_t)slot * 8); };
+  Fr secret = ld(sl.secret), limit = ld(sl.limit), msg = ld(sl.msg_id), x = ld(sl.x), ext = ld(sl.ext);
+  Fr h1[1] = {secret};
+  Fr idc = poseidon_hash_dev<2>(h1, p2);
+  Fr h2[2] = {idc, limit};
+  Fr root = poseidon_hash_dev<3>(h2, p3);
+#pragma unroll 1
+  for (uint32_t i = 0; i < sl.depth; i++) {
+    Fr e = ld(sl.path + i);
+    const uint32_t* bi = in + (size_t)(sl.path_idx + i) * 8;
+    uint32_t nz = 0;
+    for (int q = 0; q < 8; q++) nz |= bi[q];
+    if (nz == 0) {
+      h2[0] = root;
+      h2[1] = e;
+    } else {
+      h2[0] = e;
+      h2[1] = root;
+    }
+    root = poseidon_hash_dev<3>(h2, p3);
+  }
+  Fr h3[3] = {secret, ext, msg};
+  Fr a1 = poseidon_hash_dev<4>(h3, p4);
+  Fr y = secret + x * a1;
+  h1[0] = a1;
+  Fr nullifier = poseidon_hash_dev<2>(h1, p2);
+  uint32_t* o = values + (size_t)p * 40;
+  y.to_canonical(o);
+  root.to_canonical(o + 8);
+  nullifier.to_canonical(o + 16);
+  x.to_canonical(o + 24);
+  ext.to_canonical(o + 32);
+}
+
+// gathers for the parity taps
+__global__ void k_gather_col(const Fr* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t count, uint32_t B,
+                             uint32_t p, uint32_t* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  uint32_t row = idx ? idx[i] : i;
+  src[(size_t)row * B + p].to_canonical(out + (size_t)i * 8);
+}
+
+// =====================================================================================================
+// host side
+// =====================================================================================================
+struct Prover::Impl {
+  hipStream_t stream = nullptr, stream2 = nullptr;
+  hipEvent_t ev[PROVER_STAGES + 1];
+  hipEvent_t ev_fork, ev_join;
+  float ms[PROVER_STAGES] = {0};
+
+  uint32_t N = 0, NS = 0, NI = 0, nc = 0, ni = 0, n = 0;
+  int logn = 0;
+  DevBuf<GNode> nodes;
+  DevBuf<Fr> consts;
+  DevBuf<uint32_t> sig2node;
+  DevBuf<uint32_t> a_ptr, a_col, b_ptr, b_col;
+  DevBuf<Fr> a_coef, b_coef;
+  DevBuf<Fr> tw_f, tw_i, coset;
+  // MSM
+  DevBuf<G1Affine> t1;
+  DevBuf<G2Affine> t2;
+  DevBuf<uint32_t> sid1, sid2;
+  DevBuf<ChunkDesc> chunks1, chunks2;
+  DevBuf<uint32_t> segfirst1, segfirst2;
+  uint32_t nchunks1 = 0, nchunks2 = 0, npts1 = 0, npts2 = 0;
+  InputSlots slots{};
+  // workspace
+  DevBuf<uint32_t> inputs, rs, err, coords, values;
+  DevBuf<uint8_t> comp;
+  DevBuf<Fr> V, abc;
+  DevBuf<int16_t> digits;
+  DevBuf<G1XYZZ> part1, sums1;
+  DevBuf<G2XYZZ> part2, sums2;
+  bool have_run = false;
+};
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+static uint32_t bitrev(uint32_t x, int bits) {
+  uint32_t r = 0;
+  for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+  return r;
+}
+
+template <class F>
+static void build_table(const std::vector<Affine<F>>& pts, int c, int W, DevBuf<Affine<F>>& table, hipStream_t s) {
+  size_t npts = pts.size();
+  size_t E = (size_t)1 << (c - 1);
+  table.alloc(npts * W * E);
+  DevBuf<Affine<F>> d_pts(npts);
+  d_pts.upload(pts.data(), npts, s);
+  // scratch is half a table; build in slabs of points so it never exceeds ~4 GiB
+  size_t per_pt = (size_t)W * std::max<size_t>(E / 2, 1) * sizeof(F);
+  size_t slab = std::max<size_t>(1, ((size_t)4 << 30) / per_pt);
+  slab = std::min(slab, npts);
+  DevBuf<F> scratch(slab * W * std::max<size_t>(E / 2, 1));
+  for (size_t k0 = 0; k0 < npts; k0 += slab) {
+    size_t cnt = std::min(slab, npts - k0);
+    size_t threads = cnt * W;
+    hipLaunchKernelGGL(k_table_build<F>, dim3(div_up(threads, 64)), dim3(64), 0, s, d_pts.p + k0, (uint32_t)cnt, c, W,
+                       table.p + k0 * W * E, scratch.p);
+    RLN_HIP(hipGetLastError());
+  }
+  RLN_HIP(hipStreamSynchronize(s));
+}
+
+Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_t graph_len, ProverConfig cfg)
+    : d_(new Impl) {
+  require_gpu();
+  zk_ = parse_arkzkey(zkey, zkey_len);
+  graph_ = parse_graph(graph, graph_len);
+  Impl& D = *d_;
+  c_ = cfg.window_bits > 0 ? cfg.window_bits : env_int("RLNAMD_WINDOW_BITS", 8);
+  if (c_ < 2 || c_ > 14) throw Error("window bits must be in [2, 14]");
+  W_ = (255 + c_ - 1) / c_;
+  B_ = ((cfg.max_batch ? cfg.max_batch : 1) + 63) / 64 * 64;
+
+  // ---- consistency between zkey and graph (what arkworks asserts inside the prover)
+  D.N = (uint32_t)graph_.nodes.size();
+  D.NS = (uint32_t)graph_.signals.size();
+  D.NI = graph_.inputs_size;
+  D.nc = (uint32_t)zk_.num_constraints;
+  D.ni = (uint32_t)zk_.num_instance_variables;
+  if (zk_.a_query.size() != D.NS || zk_.b_g1_query.size() != D.NS || zk_.b_g2_query.size() != D.NS)
+    throw Error("zkey/graph mismatch: query length != number of witness signals");
+  if (zk_.gamma_abc_g1.size() != D.ni || zk_.l_query.size() + D.ni != D.NS)
+    throw Error("MalformedVerifyingKey: instance/aux split does not match the witness length");
+  uint32_t dom = 1;
+  D.logn = 0;
+  while (dom < D.nc + D.ni) {
+    dom <<= 1;
+    D.logn++;
+  }
+  D.n = dom;
+  if (D.logn < 1 || D.logn > 27) throw Error("PolynomialDegreeTooLarge");
+  if (zk_.h_query.size() < D.n) throw Error("zkey h_query shorter than the evaluation domain");
+
+  RLN_HIP(hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking));
+  RLN_HIP(hipStreamCreateWithFlags(&D.stream2, hipStreamNonBlocking));
+  for (auto& e : D.ev) RLN_HIP(hipEventCreate(&e));
+  RLN_HIP(hipEventCreateWithFlags(&D.ev_fork, hipEventDisableTiming));
+  RLN_HIP(hipEventCreateWithFlags(&D.ev_join, hipEventDisableTiming));
+  hipStream_t s = D.stream;
+
+  // ---- graph program
+  D.nodes.alloc(D.N);
+  D.nodes.upload(graph_.nodes.data(), D.N, s);
+  D.consts.alloc(std::max<size_t>(graph_.constants.size(), 1));
+  if (!graph_.constants.empty()) D.consts.upload(graph_.constants.data(), graph_.constants.size(), s);
+  D.sig2node.alloc(D.NS);
+  D.sig2node.upload(graph_.signals.data(), D.NS, s);
+
+  // ---- matrices as CSR over graph node ids
+  auto csr = [&](const std::vector<SparseRow>& m, DevBuf<uint32_t>& ptr, DevBuf<uint32_t>& col, DevBuf<Fr>& coef) {
+    std::vector<uint32_t> hp(D.nc + 1, 0), hc;
+    std::vector<Fr> hv;
+    for (uint32_t r = 0; r < D.nc; r++) {
+      for (size_t k = 0; k < m[r].col.size(); k++) {
+        hc.push_back(graph_.signals[m[r].col[k]]);
+        hv.push_back(m[r].coeff[k]);
+      }
+      hp[r + 1] = (uint32_t)hc.size();
+    }
+    ptr.alloc(hp.size());
+    ptr.upload(hp.data(), hp.size(), s);
+    col.alloc(std::max<size_t>(hc.size(), 1));
+    coef.alloc(std::max<size_t>(hv.size(), 1));
+    if (!hc.empty()) {
+      col.upload(hc.data(), hc.size(), s);
+      coef.upload(hv.data(), hv.size(), s);
+    }
+    RLN_HIP(hipStreamSynchronize(s));
+  };
+  csr(zk_.a, D.a_ptr, D.a_col, D.a_coef);
+  csr(zk_.b, D.b_ptr, D.b_col, D.b_coef);
+
+  // ---- NTT tables: w = W^(2^(28-logn)), g = root of the doubled domain, coset[pos] = g^bitrev(pos) / n
+  {
+    Fr root28 = Fr::from_canonical(FR_ROOT_2_28);
+    Fr g = root28;
+    for (int i = 0; i < 28 - (D.logn + 1); i++) g = g.sqr();  // order 2n
+    Fr w = g.sqr();                                           // order n
+    Fr wi = w.inv();
+    std::vector<Fr> tf(D.n / 2), ti(D.n / 2), cs(D.n);
+    Fr a = Fr::one(), b = Fr::one();
+    for (uint32_t k = 0; k < D.n / 2; k++) {
+      tf[k] = a;
+      ti[k] = b;
+      a = a * w;
+      b = b * wi;
+    }
+    Fr ninv = Fr::from_u32(D.n).inv();
+    std::vector<Fr> gp(D.n);
+    Fr acc = ninv;
+    for (uint32_t i = 0; i < D.n; i++) {
+      gp[i] = acc;
+      acc = acc * g;
+    }
+    for (uint32_t pos = 0; pos < D.n; pos++) cs[pos] = gp[bitrev(pos, D.logn)];
+    D.tw_f.alloc(tf.size());
+    D.tw_i.alloc(ti.size());
+    D.coset.alloc(cs.size());
+    D.tw_f.upload(tf.data(), tf.size(), s);
+    D.tw_i.upload(ti.data(), ti.size(), s);
+    D.coset.upload(cs.data(), cs.size(), s);
+    RLN_HIP(hipStreamSynchronize(s));
+  }
+
+  // ---- MSM segments.  Scalar ids: [0, NS) witness, [NS, NS+n) h, then r, s, -(r s).
+  const uint32_t SID_R = D.NS + D.n, SID_S = SID_R + 1, SID_NRS = SID_R + 2;
+  const uint32_t chunk_pts = (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK", 32));
+  {
+    std::vector<G1Affine> pts;
+    std::vector<uint32_t> sids, segfirst;
+    std::vector<ChunkDesc> chunks;
+    auto begin_seg = [&]() { segfirst.push_back((uint32_t)chunks.size()); return (uint32_t)pts.size(); };
+    auto end_seg = [&](uint32_t first) {
+      for (uint32_t k = first; k < pts.size(); k += chunk_pts)
+        chunks.push_back({k, (uint32_t)std::min<size_t>(k + chunk_pts, pts.size())});
+    };
+    auto push = [&](const G1Affine& P, uint32_t sid) {
+      if (P.is_inf()) return;
+      pts.push_back(P);
+      sids.push_back(sid);
+    };
+    // A = alpha + sum_i w_i A_i + r delta      (w_0 = 1 carries a_query[0] and alpha)
+    uint32_t f = begin_seg();
+    for (uint32_t i = 0; i < D.NS; i++) push(zk_.a_query[i], i);
+    push(zk_.alpha_g1, 0);
+    push(zk_.delta_g1, SID_R);
+    end_seg(f);
+    // B1 = beta + sum_i w_i B_i + s delta
+    f = begin_seg();
+    for (uint32_t i = 0; i < D.NS; i++) push(zk_.b_g1_query[i], i);
+    push(zk_.beta_g1, 0);
+    push(zk_.delta_g1, SID_S);
+    end_seg(f);
+    // Cpart = sum_j w_(ni+j) L_j + sum_k h_k H_k - (r s) delta
+    f = begin_seg();
+    for (uint32_t j = 0; j < zk_.l_query.size(); j++) push(zk_.l_query[j], D.ni + j);
+    for (uint32_t k = 0; k < D.n; k++) push(zk_.h_query[k], D.NS + k);
+    push(zk_.delta_g1, SID_NRS);
+    end_seg(f);
+    segfirst.push_back((uint32_t)chunks.size());
+    D.npts1 = (uint32_t)pts.size();
+    D.nchunks1 = (uint32_t)chunks.size();
+    D.sid1.alloc(sids.size());
+    D.sid1.upload(sids.data(), sids.size(), s);
+    D.chunks1.alloc(chunks.size());
+    D.chunks1.upload(chunks.data(), chunks.size(), s);
+    D.segfirst1.alloc(segfirst.size());
+    D.segfirst1.upload(segfirst.data(), segfirst.size(), s);
+    RLN_HIP(hipStreamSynchronize(s));
+    build_table<Fq>(pts, c_, W_, D.t1, s);
+  }
+  {
+    const uint32_t chunk2 = (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_G2", 16));
+    std::vector<G2Affine> pts;
+    std::vector<uint32_t> sids, segfirst;
+    std::vector<ChunkDesc> chunks;
+    auto push = [&](const G2Affine& P, uint32_t sid) {
+      if (P.is_inf()) return;
+      pts.push_back(P);
+      sids.push_back(sid);
+    };
+    segfirst.push_back(0);
+    for (uint32_t i = 0; i < D.NS; i++) push(zk_.b_g2_query[i], i);
+    push(zk_.beta_g2, 0);
+    push(zk_.delta_g2, SID_S);
+    for (uint32_t k = 0; k < pts.size(); k += chunk2)
+      chunks.push_back({k, (uint32_t)std::min<size_t>(k + chunk2, pts.size())});
+    segfirst.push_back((uint32_t)chunks.size());
+    D.npts2 = (uint32_t)pts.size();
+    D.nchunks2 = (uint32_t)chunks.size();
+    D.sid2.alloc(sids.size());
+    D.sid2.upload(sids.data(), sids.size(), s);
+    D.chunks2.alloc(chunks.size());
+    D.chunks2.upload(chunks.data(), chunks.size(), s);
+    D.segfirst2.alloc(segfirst.size());
+    D.segfirst2.upload(segfirst.data(), segfirst.size(), s);
+    RLN_HIP(hipStreamSynchronize(s));
+    build_table<Fq2>(pts, c_, W_, D.t2, s);
+  }
+
+  // ---- named input slots for the proof-values kernel (single message-id circuit, witness.rs:832-881)
+  auto slot = [&](const char* name, uint32_t want_len) -> uint32_t {
+    auto it = graph_.input_mapping.find(name);
+    if (it == graph_.input_mapping.end()) throw Error(std::string("MissingInput: ") + name);
+    if (want_len && it->second.second != want_len)
+      throw Error(std::string("InvalidInputLength: ") + name);
+    return it->second.first;
+  };
+  D.slots.depth = graph_.tree_depth;
+  D.slots.secret = slot("identitySecret", 1);
+  D.slots.limit = slot("userMessageLimit", 1);
+  D.slots.msg_id = slot("messageId", 0);
+  D.slots.path = slot("pathElements", graph_.tree_depth);
+  D.slots.path_idx = slot("identityPathIndex", graph_.tree_depth);
+  D.slots.x = slot("x", 1);
+  D.slots.ext = slot("externalNullifier", 1);
+  poseidon_dev();
+
+  // ---- workspace
+  const size_t B = B_;
+  D.inputs.alloc(B * D.NI * 8);
+  D.rs.alloc(B * 16);
+  D.err.alloc(B);
+  D.coords.alloc(B * 64);
+  D.values.alloc(B * 40);
+  D.comp.alloc(B * 128);
+  D.V.alloc((size_t)D.N * B);
+  D.abc.alloc(3 * (size_t)D.n * B);
+  D.digits.alloc((size_t)(D.NS + D.n + 3) * W_ * B);
+  D.part1.alloc((size_t)D.nchunks1 * B);
+  D.sums1.alloc(3 * B);
+  D.part2.alloc((size_t)D.nchunks2 * B);
+  D.sums2.alloc(B);
+  RLN_HIP(hipMemsetAsync(D.inputs.p, 0, D.inputs.bytes(), s));
+  RLN_HIP(hipMemsetAsync(D.rs.p, 0, D.rs.bytes(), s));
+  RLN_HIP(hipMemsetAsync(D.digits.p, 0, D.digits.bytes(), s));
+  RLN_HIP(hipStreamSynchronize(s));
+}
+
+Prover::~Prover() {
+  if (!d_) return;
+  Impl& D = *d_;
+  if (D.stream) (void)hipStreamSynchronize(D.stream);
+  if (D.stream2) (void)hipStreamSynchronize(D.stream2);
+  for (auto& e : D.ev) (void)hipEventDestroy(e);
+  (void)hipEventDestroy(D.ev_fork);
+  (void)hipEventDestroy(D.ev_join);
+  if (D.stream) (void)hipStreamDestroy(D.stream);
+  if (D.stream2) (void)hipStreamDestroy(D.stream2);
+}
+
+size_t Prover::table_bytes() const { return d_->t1.bytes() + d_->t2.bytes(); }
+
+void Prover::upload(size_t n, const uint8_t* inputs, const uint8_t* rs) {
+  if (n > B_) throw Error("batch larger than the prover workspace (max_batch)");
+  Impl& D = *d_;
+  RLN_HIP(hipMemcpyAsync(D.inputs.p, inputs, n * D.NI * 32, hipMemcpyHostToDevice, D.stream));
+  RLN_HIP(hipMemcpyAsync(D.rs.p, rs, n * 64, hipMemcpyHostToDevice, D.stream));
+  RLN_HIP(hipStreamSynchronize(D.stream));
+}
+
+template <bool DIF>
+static void launch_ntt(Fr* data, const Fr* tw, int logn, const Fr* final_scale, uint32_t B, uint32_t nb,
+                       hipStream_t s) {
+  int s0 = 0;
+  while (s0 < logn) {
+    int rem = logn - s0;
+    int K = rem > 4 ? 3 : rem;  // 13 -> 3,3,3,4
+    uint32_t groups = (1u << logn) >> K;
+    dim3 block(64, 4), grid(div_up(nb, 64), div_up(groups, 4), 3);
+    const Fr* sc = (s0 + K == logn) ? final_scale : nullptr;
+    switch (K) {
+      case 1: hipLaunchKernelGGL((k_ntt_pass<1, DIF>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb); break;
+      case 2: hipLaunchKernelGGL((k_ntt_pass<2, DIF>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb); break;
+      case 3: hipLaunchKernelGGL((k_ntt_pass<3, DIF>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb); break;
+      default: hipLaunchKernelGGL((k_ntt_pass<4, DIF>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb); break;
+    }
+    RLN_HIP(hipGetLastError());
+    s0 += K;
+  }
+}
+
+void Prover::run(size_t n) {
+  if (n == 0) return;
+  if (n > B_) throw Error("batch larger than the prover workspace (max_batch)");
+  Impl& D = *d_;
+  hipStream_t s = D.stream;
+  const uint32_t B = (uint32_t)B_, nb = (uint32_t)n;
+  const uint32_t pg = div_up(nb, 64);
+  const uint32_t nbp = pg * 64;  // padded lanes compute on zeroed inputs; results ignored
+  int st = 0;
+  RLN_HIP(hipEventRecord(D.ev[st++], s));
+  // values (Poseidon formulae) run beside the main pipeline on the second stream
+  RLN_HIP(hipEventRecord(D.ev_fork, s));
+  RLN_HIP(hipStreamWaitEvent(D.stream2, D.ev_fork, 0));
+  hipLaunchKernelGGL(k_proof_values, dim3(pg), dim3(64), 0, D.stream2, D.inputs.p, D.NI, D.slots, poseidon_view(2),
+                     poseidon_view(3), poseidon_view(4), D.values.p, nbp);
+  RLN_HIP(hipEventRecord(D.ev_join, D.stream2));
+
+  hipLaunchKernelGGL(k_witness, dim3(pg), dim3(64), 0, s, D.nodes.p, D.N, D.consts.p, D.inputs.p, D.NI, D.V.p,
+                     D.err.p, B, nbp);
+  RLN_HIP(hipEventRecord(D.ev[st++], s));
+  {
+    CsrView A{D.a_ptr.p, D.a_col.p, D.a_coef.p}, Bm{D.b_ptr.p, D.b_col.p, D.b_coef.p};
+    hipLaunchKernelGGL(k_matvec, dim3(pg, div_up(D.n, 4)), dim3(64, 4), 0, s, A, Bm, D.V.p, D.sig2node.p, D.nc, D.ni,
+                       D.n, D.abc.p, B, nbp);
+  }
+  RLN_HIP(hipEventRecord(D.ev[st++], s));
+  launch_ntt<true>(D.abc.p, D.tw_i.p, D.logn, D.coset.p, B, nbp, s);   // iNTT (DIF) + g^i / n
+  launch_ntt<false>(D.abc.p, D.tw_f.p, D.logn, nullptr, B, nbp, s);    // NTT (DIT)
+  hipLaunchKernelGGL(k_hquot, dim3(pg, div_up(D.n, 4)), dim3(64, 4), 0, s, D.abc.p, D.n, B, nbp);
+  RLN_HIP(hipEventRecord(D.ev[st++], s));
+  hipLaunchKernelGGL(k_recode, dim3(pg, div_up(D.NS + D.n + 3, 4)), dim3(64, 4), 0, s, D.V.p, D.sig2node.p, D.NS,
+                     D.abc.p, D.n, D.rs.p, c_, W_, D.digits.p, B, nbp);
+  RLN_HIP(hipEventRecord(D.ev[st++], s));
+  {
+    uint32_t blocks = div_up(D.nchunks1, 8) * 8 * pg;
+    hipLaunchKernelGGL(k_msm<Fq>, dim3(blocks), dim3(64), 0, s, D.t1.p, D.sid1.p, D.chunks1.p, D.nchunks1,
+                       D.digits.p, D.part1.p, c_, W_, B, pg);
+  }
+  RLN_HIP(hipEventRecord(D.ev[st++], s));
+  {
+    uint32_t blocks = div_up(D.nchunks2, 8) * 8 * pg;
+    hipLaunchKernelGGL(k_msm<Fq2>, dim3(blocks), dim3(64), 0, s, D.t2.p, D.sid2.p, D.chunks2.p, D.nchunks2,
+                       D.digits.p, D.part2.p, c_, W_, B, pg);
+  }
+  RLN_HIP(hipEventRecord(D.ev[st++], s));
+  hipLaunchKernelGGL(k_msm_reduce<Fq>, dim3(pg, 3), dim3(64), 0, s, D.part1.p, D.segfirst1.p, 3u, D.sums1.p, B, nbp);
+  hipLaunchKernelGGL(k_msm_reduce<Fq2>, dim3(pg, 1), dim3(64), 0, s, D.part2.p, D.segfirst2.p, 1u, D.sums2.p, B, nbp);
+  hipLaunchKernelGGL(k_finalize, dim3(pg), dim3(64), 0, s, D.sums1.p, D.sums2.p, D.rs.p, D.coords.p, D.comp.p, B, nbp);
+  RLN_HIP(hipGetLastError());
+  RLN_HIP(hipEventRecord(D.ev[st++], s));
+  RLN_HIP(hipStreamWaitEvent(s, D.ev_join, 0));
+  RLN_HIP(hipEventRecord(D.ev[st++], s));
+  RLN_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < PROVER_STAGES; i++) RLN_HIP(hipEventElapsedTime(&D.ms[i], D.ev[i], D.ev[i + 1]));
+  D.have_run = true;
+}
+
+void Prover::stage_ms(float out[PROVER_STAGES]) const {
+  for (int i = 0; i < PROVER_STAGES; i++) out[i] = d_->ms[i];
+}
+
+void Prover::download(size_t n, ProofOut* out) {
+  if (n > B_) throw Error("batch larger than the prover workspace (max_batch)");
+  Impl& D = *d_;
+  std::vector<uint8_t> comp(n * 128);
+  std::vector<uint32_t> coords(n * 64), values(n * 40), err(n);
+  RLN_HIP(hipMemcpyAsync(comp.data(), D.comp.p, n * 128, hipMemcpyDeviceToHost, D.stream));
+  RLN_HIP(hipMemcpyAsync(coords.data(), D.coords.p, n * 256, hipMemcpyDeviceToHost, D.stream));
+  RLN_HIP(hipMemcpyAsync(values.data(), D.values.p, n * 160, hipMemcpyDeviceToHost, D.stream));
+  RLN_HIP(hipMemcpyAsync(err.data(), D.err.p, n * 4, hipMemcpyDeviceToHost, D.stream));
+  RLN_HIP(hipStreamSynchronize(D.stream));
+  for (size_t i = 0; i < n; i++) {
+    memcpy(out[i].compressed, comp.data() + i * 128, 128);
+    memcpy(out[i].coords, coords.data() + i * 64, 256);
+    memcpy(out[i].values, values.data() + i * 40, 160);
+    out[i].error = err[i];
+  }
+}
+
+void Prover::fetch_witness(size_t p, std::vector<uint8_t>* w_le) {
+  Impl& D = *d_;
+  if (!D.have_run || p >= B_) throw Error("no resident run to read from");
+  DevBuf<uint32_t> tmp((size_t)D.NS * 8);
+  hipLaunchKernelGGL(k_gather_col, dim3(div_up(D.NS, 256)), dim3(256), 0, D.stream, D.V.p, D.sig2node.p, D.NS,
+                     (uint32_t)B_, (uint32_t)p, tmp.p);
+  w_le->resize((size_t)D.NS * 32);
+  RLN_HIP(hipMemcpyAsync(w_le->data(), tmp.p, w_le->size(), hipMemcpyDeviceToHost, D.stream));
+  RLN_HIP(hipStreamSynchronize(D.stream));
+}
+
+void Prover::fetch_h(size_t p, std::vector<uint8_t>* h_le) {
+  Impl& D = *d_;
+  if (!D.have_run || p >= B_) throw Error("no resident run to read from");
+  DevBuf<uint32_t> tmp((size_t)D.n * 8);
+  hipLaunchKernelGGL(k_gather_col, dim3(div_up(D.n, 256)), dim3(256), 0, D.stream, D.abc.p, (const uint32_t*)nullptr,
+                     D.n, (uint32_t)B_, (uint32_t)p, tmp.p);
+  h_le->resize((size_t)D.n * 32);
+  RLN_HIP(hipMemcpyAsync(h_le->data(), tmp.p, h_le->size(), hipMemcpyDeviceToHost, D.stream));
+  RLN_HIP(hipStreamSynchronize(D.stream));
+}
+
+}  // namespace rlnamd
