@@ -1,0 +1,135 @@
+"""ORACLE (test infrastructure): ctypes binding of oracle/c/liboracle.so, the C restatement of the reference's
+CPU proving path.  Used by tests/ (parity at batch sizes the Python oracle cannot reach), smoke() and
+bench.py's cpu_baseline leg -- never by the product."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+_RES = os.path.join(_HERE, "..", "..", "zerokit_amd", "resources")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = os.path.join(_HERE, "rln_oracle.c")
+        if not os.path.exists(_SO) or os.path.getmtime(src) > os.path.getmtime(_SO):
+            subprocess.check_call(["make", "-C", _HERE])
+        L = C.CDLL(_SO)
+        L.oracle_load.restype = C.c_void_p
+        L.oracle_load.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        for f in ("oracle_num_inputs", "oracle_num_signals", "oracle_domain"):
+            getattr(L, f).restype = C.c_size_t
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.oracle_poseidon.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p]
+        L.oracle_prove.restype = C.c_int
+        L.oracle_prove.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p] + [C.c_char_p] * 5
+        L.oracle_prove_many.restype = C.c_double
+        L.oracle_prove_many.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_char_p,
+                                        C.POINTER(C.c_int)]
+        L.oracle_tree_root.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_char_p]
+        _lib = L
+    return _lib
+
+
+def _b(x):
+    return int(x).to_bytes(32, "little")
+
+
+class Circuit:
+    def __init__(self, depth=20):
+        d = os.path.join(_RES, "tree_depth_%d" % depth)
+        z = open(os.path.join(d, "rln_final.arkzkey"), "rb").read()
+        g = open(os.path.join(d, "graph.bin"), "rb").read()
+        self.h = lib().oracle_load(z, len(z), g, len(g))
+        if not self.h:
+            raise RuntimeError("oracle_load failed")
+        self.n_inputs = lib().oracle_num_inputs(self.h)
+        self.n_signals = lib().oracle_num_signals(self.h)
+        self.domain = lib().oracle_domain(self.h)
+
+    # slots of the shipped single-message graphs (graph.bin metadata; asserted in tests/test_oracle_c.py)
+    SLOTS = dict(x=1, external_nullifier=2, identity_secret=3, user_message_limit=4, message_id=5, path_elements=6)
+
+    def pack(self, w):
+        depth = len(w["path_elements"])
+        buf = bytearray(self.n_inputs * 32)
+        buf[0] = 1
+
+        def put(slot, v):
+            buf[slot * 32:(slot + 1) * 32] = _b(v)
+        put(1, w["x"])
+        put(2, w["external_nullifier"])
+        put(3, w["identity_secret"])
+        put(4, w["user_message_limit"])
+        put(5, w["message_id"])
+        for i, e in enumerate(w["path_elements"]):
+            put(6 + i, e)
+        for i, e in enumerate(w["identity_path_index"]):
+            put(6 + depth + i, e)
+        return bytes(buf)
+
+    def prove(self, w, r, s, want_witness=False, want_h=False):
+        proof = C.create_string_buffer(128)
+        coords = C.create_string_buffer(256)
+        values = C.create_string_buffer(160)
+        wit = C.create_string_buffer(32 * self.n_signals) if want_witness else None
+        hb = C.create_string_buffer(32 * self.domain) if want_h else None
+        rc = lib().oracle_prove(self.h, self.pack(w), _b(r) + _b(s), proof, coords, values, wit, hb)
+        if rc:
+            raise RuntimeError("oracle_prove rc=%d" % rc)
+        out = dict(proof=proof.raw,
+                   coords=[int.from_bytes(coords.raw[32 * i:32 * i + 32], "little") for i in range(8)],
+                   public_inputs=[int.from_bytes(values.raw[32 * i:32 * i + 32], "little") for i in range(5)])
+        if wit is not None:
+            out["witness"] = [int.from_bytes(wit.raw[32 * i:32 * i + 32], "little") for i in range(self.n_signals)]
+        if hb is not None:
+            out["h"] = [int.from_bytes(hb.raw[32 * i:32 * i + 32], "little") for i in range(self.domain)]
+        return out
+
+    def prove_many(self, ws, rs, threads=None):
+        """-> (seconds, [proof128], [public_inputs])"""
+        n = len(ws)
+        threads = threads or os.cpu_count() or 1
+        inputs = b"".join(self.pack(w) for w in ws)
+        rsb = b"".join(_b(r) + _b(s) for r, s in rs)
+        proofs = C.create_string_buffer(128 * n)
+        values = C.create_string_buffer(160 * n)
+        rc = C.c_int(0)
+        secs = lib().oracle_prove_many(self.h, inputs, rsb, n, threads, proofs, values, C.byref(rc))
+        if rc.value:
+            raise RuntimeError("oracle_prove_many rc=%d" % rc.value)
+        pub = [[int.from_bytes(values.raw[160 * i + 32 * k:160 * i + 32 * k + 32], "little") for k in range(5)]
+               for i in range(n)]
+        return secs, [proofs.raw[128 * i:128 * (i + 1)] for i in range(n)], pub
+
+
+def poseidon_batch(rows):
+    arity = len(rows[0])
+    buf = b"".join(_b(v) for r in rows for v in r)
+    out = C.create_string_buffer(32 * len(rows))
+    lib().oracle_poseidon(buf, len(rows), arity, out)
+    return [int.from_bytes(out.raw[32 * i:32 * i + 32], "little") for i in range(len(rows))]
+
+
+def tree_root(depth, leaves):
+    out = C.create_string_buffer(32)
+    lib().oracle_tree_root(depth, b"".join(_b(v) for v in leaves), len(leaves), out)
+    return int.from_bytes(out.raw, "little")
+
+
+def time_baseline(ws, rs, target_seconds=12.0):
+    """bench.py cpu_baseline: one proof per host thread on every core, bounded sample."""
+    c = Circuit(20)
+    cores = os.cpu_count() or 1
+    t1, _, _ = c.prove_many(ws[:1], rs[:1], threads=1)      # single-thread latency
+    n = max(cores, min(len(ws), int(target_seconds / max(t1, 1e-3)) * cores // 1))
+    n = min(n, len(ws), max(cores, int(target_seconds * cores / max(t1, 1e-3))))
+    secs, _, _ = c.prove_many(ws[:n], rs[:n], threads=cores)
+    return {"value": round(n / secs, 3), "unit": "proofs/s", "cores": cores, "kind": "port",
+            "single_thread_ms_per_proof": round(t1 * 1e3, 2),
+            "sample": "%d proofs of the same config-2 witnesses, one proof per thread on %d threads "
+                      "(oracle/c: arkworks-equivalent CPU path restated in C, 4x64-bit Montgomery, Pippenger MSM)"
+                      % (n, cores)}

@@ -1,0 +1,574 @@
+/* ORACLE -- test infrastructure, NOT product code.
+ *
+ * CPU restatement, in plain C, of the reference's RLN proving path for the depth-20 single-message circuit.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+ * (zerokit_amd/) never links or calls it.
+ *
+ * What it restates (reference file:line under /root/reference):
+ *   field arithmetic        ark-ff 0.5.0 Fp256<MontBackend<.., 4>> (third party, Cargo.lock): 4 x 64-bit
+ *                           Montgomery limbs, the representation arkworks itself uses
+ *   G1/G2 arithmetic        ark-ec 0.5.0 short_weierstrass Jacobian formulas (third party)
+ *   MSM                     ark-ec 0.5.0 VariableBaseMSM::msm_bigint = windowed Pippenger; call sites
+ *                           rln/src/partial_proof.rs:98-104,255-256
+ *   NTT                     ark-poly 0.5.0 Radix2EvaluationDomain fft/ifft; call sites rln/src/circuit/qap.rs:69-90
+ *   QAP witness map         rln/src/circuit/qap.rs:30-98
+ *   Groth16 assembly        rln/src/partial_proof.rs:182-274 (== ark-groth16 create_proof_with_reduction_and_matrices,
+ *                           rln/tests/partial_proof.rs:110-180)
+ *   witness graph           rln/src/circuit/iden3calc/{storage.rs:265-302, proto.rs:7-117, graph.rs:72-143,246-272,314-466}
+ *   arkzkey parser          rln/src/circuit/mod.rs:256-305
+ *   Poseidon                utils/src/poseidon/poseidon_hash.rs:97-135, poseidon_constants.rs:15-261, rln/src/hashers.rs:14-23
+ *   proof values            rln/src/protocol/witness.rs:759-828
+ *   compressed proof        ark-serialize 0.5.0 (flags 0x80 / 0x40 in the top byte)
+ *
+ * Pinning: tests/test_oracle_c.py checks this file against the Python oracle (oracle/pyref, itself pinned
+ * to the reference's Poseidon / tree / snarkjs-proof KATs by tests/test_oracle_kats.py) and against the
+ * committed golden vectors.  Proof BYTES have no golden in the reference ("parity unpinned" for bytes);
+ * they are pinned by uniqueness: A, B are closed forms and C is the unique solution of the pairing check.
+ */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+typedef unsigned __int128 u128;
+typedef uint64_t u64;
+
+/* ------------------------------------------------------------------------------------------ fields */
+typedef struct { u64 v[4]; } fe;                       /* Montgomery residue */
+typedef struct { u64 p[4], r1[4], r2[4], inv; } field; /* modulus, R mod p, R^2 mod p, -p^-1 mod 2^64 */
+
+static const field FR = {{0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL},
+                         {0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL},
+                         {0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL},
+                         0xc2e1f593efffffffULL};
+static const field FQ = {{0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL},
+                         {0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x666ea36f7879462cULL, 0x0e0a77c19a07df2fULL},
+                         {0xf32cfc5b538afa89ULL, 0xb5e71911d44501fbULL, 0x47ab1eff0a417ff6ULL, 0x06d89f71cab8351fULL},
+                         0x87d20782e4866389ULL};
+
+static inline int ge4(const u64 a[4], const u64 b[4]) {
+  for (int i = 3; i >= 0; i--) { if (a[i] != b[i]) return a[i] > b[i]; }
+  return 1;
+}
+static inline void sub4(u64 r[4], const u64 a[4], const u64 b[4]) {
+  u128 br = 0;
+  for (int i = 0; i < 4; i++) { u128 t = (u128)a[i] - b[i] - (u64)br; r[i] = (u64)t; br = (t >> 64) & 1; }
+}
+static inline int fe_is_zero(const fe* a) { return (a->v[0] | a->v[1] | a->v[2] | a->v[3]) == 0; }
+static inline int fe_eq(const fe* a, const fe* b) { return memcmp(a, b, sizeof(fe)) == 0; }
+static inline void fe_add(const field* F, fe* r, const fe* a, const fe* b) {
+  u128 c = 0; u64 t[4];
+  for (int i = 0; i < 4; i++) { c += (u128)a->v[i] + b->v[i]; t[i] = (u64)c; c >>= 64; }
+  if (ge4(t, F->p)) sub4(t, t, F->p);
+  memcpy(r->v, t, 32);
+}
+static inline void fe_sub(const field* F, fe* r, const fe* a, const fe* b) {
+  u64 t[4]; u128 br = 0;
+  for (int i = 0; i < 4; i++) { u128 x = (u128)a->v[i] - b->v[i] - (u64)br; t[i] = (u64)x; br = (x >> 64) & 1; }
+  if (br) { u128 c = 0; for (int i = 0; i < 4; i++) { c += (u128)t[i] + F->p[i]; t[i] = (u64)c; c >>= 64; } }
+  memcpy(r->v, t, 32);
+}
+static inline void fe_neg(const field* F, fe* r, const fe* a) {
+  if (fe_is_zero(a)) { *r = *a; return; }
+  fe z = {{0, 0, 0, 0}}; fe_sub(F, r, &z, a);
+}
+static inline void fe_dbl(const field* F, fe* r, const fe* a) { fe_add(F, r, a, a); }
+/* CIOS Montgomery product */
+static inline void fe_mul(const field* F, fe* r, const fe* a, const fe* b) {
+  u64 t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) { c += (u128)a->v[j] * b->v[i] + t[j]; t[j] = (u64)c; c >>= 64; }
+    c += t[4]; t[4] = (u64)c; t[5] = (u64)(c >> 64);
+    u64 m = t[0] * F->inv;
+    c = ((u128)m * F->p[0] + t[0]) >> 64;
+    for (int j = 1; j < 4; j++) { c += (u128)m * F->p[j] + t[j]; t[j - 1] = (u64)c; c >>= 64; }
+    c += t[4]; t[3] = (u64)c; t[4] = t[5] + (u64)(c >> 64);
+  }
+  if (t[4] || ge4(t, F->p)) sub4(t, t, F->p);
+  memcpy(r->v, t, 32);
+}
+static inline void fe_sqr(const field* F, fe* r, const fe* a) { fe_mul(F, r, a, a); }
+static void fe_from_u64x4(const field* F, fe* r, const u64 c[4]) { fe x; memcpy(x.v, c, 32); fe r2; memcpy(r2.v, F->r2, 32); fe_mul(F, r, &x, &r2); }
+static void fe_to_u64x4(const field* F, u64 c[4], const fe* a) { fe one = {{1, 0, 0, 0}}, t; fe_mul(F, &t, a, &one); memcpy(c, t.v, 32); }
+static void fe_from_bytes(const field* F, fe* r, const uint8_t* le) { u64 c[4]; memcpy(c, le, 32); fe_from_u64x4(F, r, c); }
+static void fe_to_bytes(const field* F, uint8_t* le, const fe* a) { u64 c[4]; fe_to_u64x4(F, c, a); memcpy(le, c, 32); }
+static void fe_one(const field* F, fe* r) { memcpy(r->v, F->r1, 32); }
+static void fe_set_u64(const field* F, fe* r, u64 x) { u64 c[4] = {x, 0, 0, 0}; fe_from_u64x4(F, r, c); }
+static void fe_pow(const field* F, fe* r, const fe* a, const u64 e[4]) {
+  fe acc; fe_one(F, &acc);
+  for (int i = 255; i >= 0; i--) { fe_sqr(F, &acc, &acc); if ((e[i >> 6] >> (i & 63)) & 1) fe_mul(F, &acc, &acc, a); }
+  *r = acc;
+}
+static void fe_inv(const field* F, fe* r, const fe* a) {
+  u64 e[4]; u64 two[4] = {2, 0, 0, 0}; sub4(e, F->p, two); fe_pow(F, r, a, e);
+}
+
+/* Fq2 = Fq[u]/(u^2+1) */
+typedef struct { fe c0, c1; } fe2;
+static inline void f2_add(fe2* r, const fe2* a, const fe2* b) { fe_add(&FQ, &r->c0, &a->c0, &b->c0); fe_add(&FQ, &r->c1, &a->c1, &b->c1); }
+static inline void f2_sub(fe2* r, const fe2* a, const fe2* b) { fe_sub(&FQ, &r->c0, &a->c0, &b->c0); fe_sub(&FQ, &r->c1, &a->c1, &b->c1); }
+static inline void f2_neg(fe2* r, const fe2* a) { fe_neg(&FQ, &r->c0, &a->c0); fe_neg(&FQ, &r->c1, &a->c1); }
+static inline void f2_mul(fe2* r, const fe2* a, const fe2* b) {
+  fe v0, v1, s, t;
+  fe_mul(&FQ, &v0, &a->c0, &b->c0); fe_mul(&FQ, &v1, &a->c1, &b->c1);
+  fe_add(&FQ, &s, &a->c0, &a->c1); fe_add(&FQ, &t, &b->c0, &b->c1); fe_mul(&FQ, &s, &s, &t);
+  fe_sub(&FQ, &r->c0, &v0, &v1); fe_sub(&FQ, &s, &s, &v0); fe_sub(&FQ, &r->c1, &s, &v1);
+}
+static inline void f2_sqr(fe2* r, const fe2* a) { f2_mul(r, a, a); }
+static inline int f2_is_zero(const fe2* a) { return fe_is_zero(&a->c0) && fe_is_zero(&a->c1); }
+static inline int f2_eq(const fe2* a, const fe2* b) { return fe_eq(&a->c0, &b->c0) && fe_eq(&a->c1, &b->c1); }
+static void f2_inv(fe2* r, const fe2* a) {
+  fe n, t; fe_sqr(&FQ, &n, &a->c0); fe_sqr(&FQ, &t, &a->c1); fe_add(&FQ, &n, &n, &t); fe_inv(&FQ, &n, &n);
+  fe_mul(&FQ, &r->c0, &a->c0, &n); fe_mul(&FQ, &t, &a->c1, &n); fe_neg(&FQ, &r->c1, &t);
+}
+
+/* ------------------------------------------------------------------------------------------ curves
+ * One generic Jacobian implementation over an "element" of 1 (G1) or 2 (G2) base-field limbs groups. */
+#define DEF_CURVE(NAME, EL, ADD, SUB, MUL, SQR, NEG, ISZ, EQ, INV, ONE)                                   \
+  typedef struct { EL x, y; int inf; } NAME##_aff;                                                          \
+  typedef struct { EL X, Y, Z; } NAME##_jac; /* Z == 0 : infinity */                                       \
+  static void NAME##_jac_inf(NAME##_jac* r) { memset(r, 0, sizeof(*r)); ONE(&r->X); ONE(&r->Y); }           \
+  static int NAME##_jac_is_inf(const NAME##_jac* p) { return ISZ(&p->Z); }                                  \
+  static void NAME##_dbl(NAME##_jac* r, const NAME##_jac* p) {                                              \
+    if (ISZ(&p->Z)) { *r = *p; return; }                                                                    \
+    EL A, B, C, D, E, F, t, X3, Y3, Z3;                                                                     \
+    SQR(&A, &p->X); SQR(&B, &p->Y); SQR(&C, &B);                                                            \
+    ADD(&t, &p->X, &B); SQR(&t, &t); SUB(&t, &t, &A); SUB(&t, &t, &C); ADD(&D, &t, &t);                     \
+    ADD(&E, &A, &A); ADD(&E, &E, &A); SQR(&F, &E);                                                          \
+    ADD(&t, &D, &D); SUB(&X3, &F, &t);                                                                      \
+    ADD(&C, &C, &C); ADD(&C, &C, &C); ADD(&C, &C, &C);                                                      \
+    SUB(&t, &D, &X3); MUL(&t, &E, &t); SUB(&Y3, &t, &C);                                                    \
+    MUL(&Z3, &p->Y, &p->Z); ADD(&Z3, &Z3, &Z3);                                                             \
+    r->X = X3; r->Y = Y3; r->Z = Z3;                                                                        \
+  }                                                                                                         \
+  static void NAME##_add_mixed(NAME##_jac* r, const NAME##_jac* p, const NAME##_aff* q) {                   \
+    if (q->inf) { *r = *p; return; }                                                                        \
+    if (ISZ(&p->Z)) { r->X = q->x; r->Y = q->y; ONE(&r->Z); return; }                                       \
+    EL Z1Z1, U2, S2, H, HH, HHH, rr, V, t, X3, Y3, Z3;                                                      \
+    SQR(&Z1Z1, &p->Z); MUL(&U2, &q->x, &Z1Z1); MUL(&S2, &q->y, &p->Z); MUL(&S2, &S2, &Z1Z1);              \
+    if (EQ(&U2, &p->X)) { if (EQ(&S2, &p->Y)) { NAME##_dbl(r, p); } else { NAME##_jac_inf(r); } return; }   \
+    SUB(&H, &U2, &p->X); SQR(&HH, &H); MUL(&HHH, &H, &HH); SUB(&rr, &S2, &p->Y); MUL(&V, &p->X, &HH);      \
+    SQR(&X3, &rr); SUB(&X3, &X3, &HHH); ADD(&t, &V, &V); SUB(&X3, &X3, &t);                                 \
+    SUB(&t, &V, &X3); MUL(&Y3, &rr, &t); MUL(&t, &p->Y, &HHH); SUB(&Y3, &Y3, &t);                           \
+    MUL(&Z3, &p->Z, &H);                                                                                    \
+    r->X = X3; r->Y = Y3; r->Z = Z3;                                                                        \
+  }                                                                                                         \
+  static void NAME##_add(NAME##_jac* r, const NAME##_jac* p, const NAME##_jac* q) {                         \
+    if (ISZ(&p->Z)) { *r = *q; return; }                                                                    \
+    if (ISZ(&q->Z)) { *r = *p; return; }                                                                    \
+    EL Z1Z1, Z2Z2, U1, U2, S1, S2, H, HH, HHH, rr, V, t, X3, Y3, Z3;                                        \
+    SQR(&Z1Z1, &p->Z); SQR(&Z2Z2, &q->Z); MUL(&U1, &p->X, &Z2Z2); MUL(&U2, &q->X, &Z1Z1);                 \
+    MUL(&S1, &p->Y, &q->Z); MUL(&S1, &S1, &Z2Z2); MUL(&S2, &q->Y, &p->Z); MUL(&S2, &S2, &Z1Z1);            \
+    if (EQ(&U1, &U2)) { if (EQ(&S1, &S2)) { NAME##_dbl(r, p); } else { NAME##_jac_inf(r); } return; }       \
+    SUB(&H, &U2, &U1); SQR(&HH, &H); MUL(&HHH, &H, &HH); SUB(&rr, &S2, &S1); MUL(&V, &U1, &HH);            \
+    SQR(&X3, &rr); SUB(&X3, &X3, &HHH); ADD(&t, &V, &V); SUB(&X3, &X3, &t);                                 \
+    SUB(&t, &V, &X3); MUL(&Y3, &rr, &t); MUL(&t, &S1, &HHH); SUB(&Y3, &Y3, &t);                             \
+    MUL(&Z3, &p->Z, &q->Z); MUL(&Z3, &Z3, &H);                                                              \
+    r->X = X3; r->Y = Y3; r->Z = Z3;                                                                        \
+  }                                                                                                         \
+  static void NAME##_to_aff(NAME##_aff* r, const NAME##_jac* p) {                                           \
+    if (ISZ(&p->Z)) { memset(r, 0, sizeof(*r)); r->inf = 1; return; }                                       \
+    EL zi, zi2; INV(&zi, &p->Z); SQR(&zi2, &zi); MUL(&r->x, &p->X, &zi2); MUL(&zi2, &zi2, &zi);             \
+    MUL(&r->y, &p->Y, &zi2); r->inf = 0;                                                                    \
+  }                                                                                                         \
+  static void NAME##_mul(NAME##_jac* r, const NAME##_aff* p, const u64 k[4]) {                              \
+    NAME##_jac acc; NAME##_jac_inf(&acc);                                                                   \
+    for (int i = 255; i >= 0; i--) { NAME##_dbl(&acc, &acc); if ((k[i >> 6] >> (i & 63)) & 1) NAME##_add_mixed(&acc, &acc, p); } \
+    *r = acc;                                                                                               \
+  }                                                                                                         \
+  /* windowed Pippenger over canonical 256-bit scalars (msm_bigint) */                                      \
+  static void NAME##_msm(NAME##_jac* out, const NAME##_aff* pts, const u64 (*sc)[4], size_t n) {            \
+    int c = 0; { size_t m = n; while (m > 1) { m >>= 1; c++; } c = n < 32 ? 3 : c * 69 / 100 + 2; } /* ark-ec: ln(n) + 2 */ \
+    int nw = (254 + c - 1) / c; size_t nb = ((size_t)1 << c) - 1;                                           \
+    NAME##_jac* buckets = (NAME##_jac*)malloc(nb * sizeof(NAME##_jac));                                     \
+    NAME##_jac total; NAME##_jac_inf(&total);                                                               \
+    for (int w = nw - 1; w >= 0; w--) {                                                                     \
+      for (int k = 0; k < c; k++) NAME##_dbl(&total, &total);                                               \
+      for (size_t b = 0; b < nb; b++) NAME##_jac_inf(&buckets[b]);                                          \
+      int bit = w * c;                                                                                      \
+      for (size_t i = 0; i < n; i++) {                                                                      \
+        if (pts[i].inf) continue;                                                                           \
+        u64 lo = sc[i][bit >> 6] >> (bit & 63);                                                             \
+        if ((bit & 63) + c > 64 && (bit >> 6) < 3) lo |= sc[i][(bit >> 6) + 1] << (64 - (bit & 63));        \
+        u64 d = lo & (((u64)1 << c) - 1);                                                                   \
+        if (d) NAME##_add_mixed(&buckets[d - 1], &buckets[d - 1], &pts[i]);                                 \
+      }                                                                                                     \
+      NAME##_jac run, ws; NAME##_jac_inf(&run); NAME##_jac_inf(&ws);                                        \
+      for (size_t b = nb; b-- > 0;) { NAME##_add(&run, &run, &buckets[b]); NAME##_add(&ws, &ws, &run); }    \
+      NAME##_add(&total, &total, &ws);                                                                      \
+    }                                                                                                       \
+    free(buckets); *out = total;                                                                            \
+  }
+
+#define FQ_ADD(r, a, b) fe_add(&FQ, r, a, b)
+#define FQ_SUB(r, a, b) fe_sub(&FQ, r, a, b)
+#define FQ_MUL(r, a, b) fe_mul(&FQ, r, a, b)
+#define FQ_SQR(r, a) fe_sqr(&FQ, r, a)
+#define FQ_NEG(r, a) fe_neg(&FQ, r, a)
+#define FQ_INV(r, a) fe_inv(&FQ, r, a)
+#define FQ_ONE(r) fe_one(&FQ, r)
+static void f2_one(fe2* r) { fe_one(&FQ, &r->c0); memset(&r->c1, 0, sizeof(fe)); }
+DEF_CURVE(g1, fe, FQ_ADD, FQ_SUB, FQ_MUL, FQ_SQR, FQ_NEG, fe_is_zero, fe_eq, FQ_INV, FQ_ONE)
+DEF_CURVE(g2, fe2, f2_add, f2_sub, f2_mul, f2_sqr, f2_neg, f2_is_zero, f2_eq, f2_inv, f2_one)
+
+/* ------------------------------------------------------------------------------------------ Poseidon */
+typedef struct { int t, rf, rp; fe* ark; fe* mds; } pparams;
+static pparams PP[5]; /* index t = 2..4 */
+static int pp_ready = 0;
+typedef struct { uint8_t st[80]; int head; } grain;
+static int grain_update(grain* g) {
+  int h = g->head;
+  int b = g->st[(h + 62) % 80] ^ g->st[(h + 51) % 80] ^ g->st[(h + 38) % 80] ^ g->st[(h + 23) % 80] ^ g->st[(h + 13) % 80] ^ g->st[h];
+  g->st[h] = (uint8_t)b; g->head = (h + 1) % 80; return b;
+}
+static void grain_put(grain* g, int lo, int hi, u64 v) { for (int i = hi; i >= lo; i--) { g->st[i] = v & 1; v >>= 1; } }
+static void grain_value(grain* g, u64 out[4]) { /* 254 bits, first generated bit most significant */
+  memset(out, 0, 32);
+  for (int k = 253; k >= 0; k--) {
+    int b = grain_update(g);
+    while (!b) { grain_update(g); b = grain_update(g); }
+    if (grain_update(g)) out[k >> 6] |= (u64)1 << (k & 63);
+  }
+}
+static void poseidon_init(void) {
+  if (pp_ready) return;
+  static const int tab[3][3] = {{2, 8, 56}, {3, 8, 57}, {4, 8, 56}}; /* hashers.rs:14-23, skip_matrices = 0 */
+  for (int q = 0; q < 3; q++) {
+    int t = tab[q][0], rf = tab[q][1], rp = tab[q][2];
+    grain g; memset(&g, 0, sizeof g);
+    g.st[1] = 1; grain_put(&g, 6, 17, 254); grain_put(&g, 18, 29, t); grain_put(&g, 30, 39, rf); grain_put(&g, 40, 49, rp);
+    for (int i = 50; i < 80; i++) g.st[i] = 1;
+    for (int i = 0; i < 160; i++) grain_update(&g);
+    pparams* P = &PP[t]; P->t = t; P->rf = rf; P->rp = rp;
+    P->ark = (fe*)malloc(sizeof(fe) * (rf + rp) * t); P->mds = (fe*)malloc(sizeof(fe) * t * t);
+    for (int i = 0; i < (rf + rp) * t; i++) { u64 v[4]; do { grain_value(&g, v); } while (ge4(v, FR.p)); fe_from_u64x4(&FR, &P->ark[i], v); }
+    fe xs[4], ys[4];
+    for (int i = 0; i < t; i++) { u64 v[4]; grain_value(&g, v); if (ge4(v, FR.p)) sub4(v, v, FR.p); fe_from_u64x4(&FR, &xs[i], v); }
+    for (int i = 0; i < t; i++) { u64 v[4]; grain_value(&g, v); if (ge4(v, FR.p)) sub4(v, v, FR.p); fe_from_u64x4(&FR, &ys[i], v); }
+    for (int i = 0; i < t; i++) for (int j = 0; j < t; j++) { fe s; fe_add(&FR, &s, &xs[i], &ys[j]); fe_inv(&FR, &P->mds[i * t + j], &s); }
+  }
+  pp_ready = 1;
+}
+static void poseidon(fe* out, const fe* in, int arity) { /* poseidon_hash.rs:97-135 */
+  int t = arity + 1; const pparams* P = &PP[t];
+  fe st[4], nx[4]; memset(&st[0], 0, sizeof(fe));
+  for (int j = 1; j < t; j++) st[j] = in[j - 1];
+  for (int r = 0; r < P->rf + P->rp; r++) {
+    for (int j = 0; j < t; j++) fe_add(&FR, &st[j], &st[j], &P->ark[r * t + j]);
+    int full = r < P->rf / 2 || r >= P->rf / 2 + P->rp;
+    for (int j = 0; j < (full ? t : 1); j++) { fe x2, x4; fe_sqr(&FR, &x2, &st[j]); fe_sqr(&FR, &x4, &x2); fe_mul(&FR, &st[j], &x4, &st[j]); }
+    for (int i = 0; i < t; i++) { fe acc; memset(&acc, 0, sizeof acc); for (int j = 0; j < t; j++) { fe m; fe_mul(&FR, &m, &P->mds[i * t + j], &st[j]); fe_add(&FR, &acc, &acc, &m); } nx[i] = acc; }
+    for (int j = 0; j < t; j++) st[j] = nx[j];
+  }
+  *out = st[0];
+}
+
+/* ------------------------------------------------------------------------------------------ circuit */
+typedef struct { uint32_t op, a, b, c; } gnode; /* op: 0 input, 1 const, 2+duo (proto.rs:88-110), 22 neg, 23 id, 24 tern */
+typedef struct {
+  /* zkey */
+  g1_aff alpha1, beta1, delta1; g2_aff beta2, gamma2, delta2;
+  g1_aff *ic, *aq, *b1q, *hq, *lq; g2_aff* b2q;
+  size_t n_ic, n_aq, n_b1, n_b2, n_h, n_l;
+  u64 n_inst, n_wit, n_cons;
+  size_t* a_ptr; uint32_t* a_col; fe* a_val; size_t* b_ptr; uint32_t* b_col; fe* b_val;
+  /* graph */
+  gnode* nodes; size_t n_nodes; fe* consts; uint32_t* signals; size_t n_signals; size_t n_inputs;
+  uint32_t off_secret, off_limit, off_msg, off_path, off_idx, off_x, off_ext, depth;
+  /* ntt */
+  int logn; size_t n; fe *tw, *twi, *coset; fe ninv;
+} circuit;
+
+static const uint8_t* rd_g1(const uint8_t* p, g1_aff* o) {
+  uint8_t yb[32]; memcpy(yb, p + 32, 32); int fl = yb[31] & 0xC0; yb[31] &= 0x3F;
+  o->inf = (fl & 0x40) != 0;
+  if (o->inf) { memset(&o->x, 0, sizeof(fe)); memset(&o->y, 0, sizeof(fe)); } else { fe_from_bytes(&FQ, &o->x, p); fe_from_bytes(&FQ, &o->y, yb); }
+  return p + 64;
+}
+static const uint8_t* rd_g2(const uint8_t* p, g2_aff* o) {
+  uint8_t yb[32]; memcpy(yb, p + 96, 32); int fl = yb[31] & 0xC0; yb[31] &= 0x3F;
+  o->inf = (fl & 0x40) != 0;
+  if (o->inf) { memset(&o->x, 0, sizeof(fe2)); memset(&o->y, 0, sizeof(fe2)); }
+  else { fe_from_bytes(&FQ, &o->x.c0, p); fe_from_bytes(&FQ, &o->x.c1, p + 32); fe_from_bytes(&FQ, &o->y.c0, p + 64); fe_from_bytes(&FQ, &o->y.c1, yb); }
+  return p + 128;
+}
+static u64 rd_u64(const uint8_t** p) { u64 v; memcpy(&v, *p, 8); *p += 8; return v; }
+static u64 rd_varint(const uint8_t** p) { u64 v = 0; int s = 0; for (;;) { uint8_t c = *(*p)++; v |= (u64)(c & 0x7F) << s; if (!(c & 0x80)) return v; s += 7; } }
+
+static int parse_zkey(circuit* C, const uint8_t* d, size_t len) { /* circuit/mod.rs:256-305 */
+  const uint8_t* p = d; (void)len;
+  p = rd_g1(p, &C->alpha1); p = rd_g2(p, &C->beta2); p = rd_g2(p, &C->gamma2); p = rd_g2(p, &C->delta2);
+#define VEC1(arr, cnt) do { cnt = rd_u64(&p); arr = (g1_aff*)malloc(sizeof(g1_aff) * (cnt ? cnt : 1)); for (size_t i = 0; i < cnt; i++) p = rd_g1(p, &arr[i]); } while (0)
+  VEC1(C->ic, C->n_ic);
+  p = rd_g1(p, &C->beta1); p = rd_g1(p, &C->delta1);
+  VEC1(C->aq, C->n_aq); VEC1(C->b1q, C->n_b1);
+  C->n_b2 = rd_u64(&p); C->b2q = (g2_aff*)malloc(sizeof(g2_aff) * C->n_b2); for (size_t i = 0; i < C->n_b2; i++) p = rd_g2(p, &C->b2q[i]);
+  VEC1(C->hq, C->n_h); VEC1(C->lq, C->n_l);
+  C->n_inst = rd_u64(&p); C->n_wit = rd_u64(&p); C->n_cons = rd_u64(&p);
+  u64 annz = rd_u64(&p), bnnz = rd_u64(&p); (void)rd_u64(&p);
+  for (int m = 0; m < 3; m++) {
+    u64 rows = rd_u64(&p);
+    size_t* ptr = (size_t*)malloc(sizeof(size_t) * (rows + 1)); u64 cap = m == 0 ? annz : m == 1 ? bnnz : 1;
+    uint32_t* col = (uint32_t*)malloc(sizeof(uint32_t) * (cap ? cap : 1)); fe* val = (fe*)malloc(sizeof(fe) * (cap ? cap : 1));
+    size_t k = 0; ptr[0] = 0;
+    for (u64 r = 0; r < rows; r++) {
+      u64 e = rd_u64(&p);
+      for (u64 j = 0; j < e; j++) { if (k >= cap) return -1; fe_from_bytes(&FR, &val[k], p); p += 32; col[k] = (uint32_t)rd_u64(&p); k++; }
+      ptr[r + 1] = k;
+    }
+    if (m == 0) { C->a_ptr = ptr; C->a_col = col; C->a_val = val; } else if (m == 1) { C->b_ptr = ptr; C->b_col = col; C->b_val = val; } else { free(ptr); free(col); free(val); }
+  }
+  return (size_t)(p - d) == len ? 0 : -2;
+}
+
+static void pb_skip(const uint8_t** p, int wt) { if (wt == 0) rd_varint(p); else if (wt == 2) { u64 l = rd_varint(p); *p += l; } else if (wt == 1) *p += 8; else *p += 4; }
+static int parse_graph(circuit* C, const uint8_t* d, size_t len) { /* storage.rs:265-302 */
+  if (len < 22 || memcmp(d, "wtns.graph.001", 14) != 0) return -1;
+  const uint8_t* p = d + 14; u64 nn = rd_u64(&p);
+  C->nodes = (gnode*)calloc(nn, sizeof(gnode)); C->consts = (fe*)malloc(sizeof(fe) * nn); C->n_nodes = nn;
+  size_t nconst = 0;
+  for (u64 i = 0; i < nn; i++) {
+    u64 ml = rd_varint(&p); const uint8_t* e = p + ml;
+    while (p < e) {
+      u64 key = rd_varint(&p); int tag = (int)(key >> 3), wt = (int)(key & 7);
+      if (wt != 2 || tag < 1 || tag > 5) { pb_skip(&p, wt); continue; }
+      u64 bl = rd_varint(&p); const uint8_t* be = p + bl; uint32_t f[5] = {0, 0, 0, 0, 0};
+      if (tag == 2) {
+        uint8_t raw[32]; memset(raw, 0, 32);
+        while (p < be) { u64 k2 = rd_varint(&p); if ((k2 >> 3) == 1 && (k2 & 7) == 2) { u64 l2 = rd_varint(&p); const uint8_t* e2 = p + l2;
+            while (p < e2) { u64 k3 = rd_varint(&p); if ((k3 >> 3) == 1 && (k3 & 7) == 2) { u64 l3 = rd_varint(&p); memcpy(raw, p, l3 > 32 ? 32 : l3); p += l3; } else pb_skip(&p, (int)(k3 & 7)); } }
+          else pb_skip(&p, (int)(k2 & 7)); }
+        u64 v[4]; memcpy(v, raw, 32); while (ge4(v, FR.p)) sub4(v, v, FR.p);
+        fe_from_u64x4(&FR, &C->consts[nconst], v); C->nodes[i].op = 1; C->nodes[i].a = (uint32_t)nconst++;
+      } else {
+        while (p < be) { u64 k2 = rd_varint(&p); int t2 = (int)(k2 >> 3); if ((k2 & 7) == 0 && t2 >= 1 && t2 <= 4) f[t2] = (uint32_t)rd_varint(&p); else pb_skip(&p, (int)(k2 & 7)); }
+        if (tag == 1) { C->nodes[i].op = 0; C->nodes[i].a = f[1]; }
+        else if (tag == 3) { C->nodes[i].op = f[1] == 0 ? 22 : 23; C->nodes[i].a = f[2]; }
+        else if (tag == 4) { C->nodes[i].op = 2 + f[1]; C->nodes[i].a = f[2]; C->nodes[i].b = f[3]; }
+        else { C->nodes[i].op = 24; C->nodes[i].a = f[2]; C->nodes[i].b = f[3]; C->nodes[i].c = f[4]; }
+      }
+      p = be;
+    }
+    p = e;
+  }
+  u64 ml = rd_varint(&p); const uint8_t* e = p + ml;
+  C->signals = (uint32_t*)malloc(sizeof(uint32_t) * nn); C->n_signals = 0;
+  while (p < e) {
+    u64 key = rd_varint(&p); int tag = (int)(key >> 3), wt = (int)(key & 7);
+    if (tag == 1 && wt == 2) { u64 l = rd_varint(&p); const uint8_t* pe = p + l; while (p < pe) C->signals[C->n_signals++] = (uint32_t)rd_varint(&p); }
+    else if (tag == 1 && wt == 0) C->signals[C->n_signals++] = (uint32_t)rd_varint(&p);
+    else if (tag == 2 && wt == 2) {
+      u64 l = rd_varint(&p); const uint8_t* ee = p + l; char name[64] = {0}; uint32_t off = 0, ln = 0;
+      while (p < ee) { u64 k2 = rd_varint(&p);
+        if ((k2 >> 3) == 1 && (k2 & 7) == 2) { u64 sl = rd_varint(&p); memcpy(name, p, sl < 63 ? sl : 63); p += sl; }
+        else if ((k2 >> 3) == 2 && (k2 & 7) == 2) { u64 sl = rd_varint(&p); const uint8_t* se = p + sl; while (p < se) { u64 k3 = rd_varint(&p); u64 v = rd_varint(&p); if ((k3 >> 3) == 1) off = (uint32_t)v; else if ((k3 >> 3) == 2) ln = (uint32_t)v; } }
+        else pb_skip(&p, (int)(k2 & 7)); }
+      if (!strcmp(name, "identitySecret")) C->off_secret = off; else if (!strcmp(name, "userMessageLimit")) C->off_limit = off;
+      else if (!strcmp(name, "messageId")) C->off_msg = off; else if (!strcmp(name, "pathElements")) { C->off_path = off; C->depth = ln; }
+      else if (!strcmp(name, "identityPathIndex")) C->off_idx = off; else if (!strcmp(name, "x")) C->off_x = off;
+      else if (!strcmp(name, "externalNullifier")) C->off_ext = off;
+    } else pb_skip(&p, wt);
+  }
+  uint32_t mx = 0; int started = 0;
+  for (size_t i = 0; i < C->n_nodes; i++) { if (C->nodes[i].op == 0) { if (C->nodes[i].a > mx) mx = C->nodes[i].a; started = 1; } else if (started) break; }
+  C->n_inputs = mx + 1;
+  return 0;
+}
+
+static void u256_shr(u64 r[4], const u64 a[4], unsigned n) {
+  unsigned w = n >> 6, b = n & 63;
+  for (int i = 0; i < 4; i++) { u64 lo = i + w < 4 ? a[i + w] : 0, hi = i + w + 1 < 4 ? a[i + w + 1] : 0; r[i] = b ? (lo >> b) | (hi << (64 - b)) : lo; }
+}
+static int gt4(const u64 a[4], const u64 b[4]) { for (int i = 3; i >= 0; i--) if (a[i] != b[i]) return a[i] > b[i]; return 0; }
+
+/* graph.rs:246-272; ops the RLN circuits use (others -> error code) */
+static int eval_graph(const circuit* C, const uint8_t* inputs_le, fe* vals, fe* out) {
+  for (size_t n = 0; n < C->n_nodes; n++) {
+    const gnode* nd = &C->nodes[n]; fe* v = &vals[n];
+    switch (nd->op) {
+      case 0: { u64 c[4]; memcpy(c, inputs_le + 32 * (size_t)nd->a, 32); if (ge4(c, FR.p)) return -1; fe_from_u64x4(&FR, v, c); break; }
+      case 1: *v = C->consts[nd->a]; break;
+      case 2: fe_mul(&FR, v, &vals[nd->a], &vals[nd->b]); break;
+      case 4: fe_add(&FR, v, &vals[nd->a], &vals[nd->b]); break;
+      case 5: fe_sub(&FR, v, &vals[nd->a], &vals[nd->b]); break;
+      case 3: if (fe_is_zero(&vals[nd->b])) memset(v, 0, sizeof *v); else { fe i; fe_inv(&FR, &i, &vals[nd->b]); fe_mul(&FR, v, &vals[nd->a], &i); } break;
+      case 9: if (fe_eq(&vals[nd->a], &vals[nd->b])) fe_one(&FR, v); else memset(v, 0, sizeof *v); break;
+      case 10: if (!fe_eq(&vals[nd->a], &vals[nd->b])) fe_one(&FR, v); else memset(v, 0, sizeof *v); break;
+      case 18: { /* Shr graph.rs:328-363 */
+        u64 a[4], b[4], r[4]; fe_to_u64x4(&FR, a, &vals[nd->a]); fe_to_u64x4(&FR, b, &vals[nd->b]);
+        if (!(b[0] | b[1] | b[2] | b[3])) { *v = vals[nd->a]; break; }
+        if (b[1] | b[2] | b[3] || b[0] >= 254) { memset(v, 0, sizeof *v); break; }
+        u256_shr(r, a, (unsigned)b[0]); fe_from_u64x4(&FR, v, r); break; }
+      case 20: { /* Band graph.rs:365-380 */
+        u64 a[4], b[4], r[4]; fe_to_u64x4(&FR, a, &vals[nd->a]); fe_to_u64x4(&FR, b, &vals[nd->b]);
+        for (int i = 0; i < 4; i++) r[i] = a[i] & b[i];
+        if (gt4(r, FR.p)) sub4(r, r, FR.p);
+        if (ge4(r, FR.p)) return -3;
+        fe_from_u64x4(&FR, v, r); break; }
+      case 22: fe_neg(&FR, v, &vals[nd->a]); break;
+      case 24: *v = fe_is_zero(&vals[nd->a]) ? vals[nd->c] : vals[nd->b]; break;
+      default: return -2;
+    }
+  }
+  for (size_t i = 0; i < C->n_signals; i++) out[i] = vals[C->signals[i]];
+  return 0;
+}
+
+static void bitrev_perm(fe* a, size_t n) {
+  for (size_t i = 1, j = 0; i < n; i++) { size_t bit = n >> 1; for (; j & bit; bit >>= 1) j ^= bit; j ^= bit; if (i < j) { fe t = a[i]; a[i] = a[j]; a[j] = t; } }
+}
+static void ntt(const circuit* C, fe* a, int inverse) { /* out[i] = sum a[j] w^(ij) */
+  size_t n = C->n; const fe* tw = inverse ? C->twi : C->tw;
+  bitrev_perm(a, n);
+  for (size_t len = 2; len <= n; len <<= 1) {
+    size_t half = len >> 1, step = n / len;
+    for (size_t s = 0; s < n; s += len)
+      for (size_t k = 0; k < half; k++) { fe u = a[s + k], v; fe_mul(&FR, &v, &a[s + k + half], &tw[k * step]); fe_add(&FR, &a[s + k], &u, &v); fe_sub(&FR, &a[s + k + half], &u, &v); }
+  }
+  if (inverse) for (size_t i = 0; i < n; i++) fe_mul(&FR, &a[i], &a[i], &C->ninv);
+}
+static void ntt_init(circuit* C) {
+  size_t need = C->n_cons + C->n_inst; C->n = 1; C->logn = 0; while (C->n < need) { C->n <<= 1; C->logn++; }
+  u64 wc[4] = {0x9bd61b6e725b19f0ULL, 0x402d111e41112ed4ULL, 0x00e0a7eb8ef62abcULL, 0x2a3c09f0a58a7e85ULL}; /* 5^((r-1)/2^28) */
+  fe g; fe_from_u64x4(&FR, &g, wc);
+  for (int i = 0; i < 28 - (C->logn + 1); i++) fe_sqr(&FR, &g, &g);
+  fe w, wi; fe_sqr(&FR, &w, &g); fe_inv(&FR, &wi, &w);
+  C->tw = (fe*)malloc(sizeof(fe) * C->n / 2); C->twi = (fe*)malloc(sizeof(fe) * C->n / 2); C->coset = (fe*)malloc(sizeof(fe) * C->n);
+  fe a, b; fe_one(&FR, &a); fe_one(&FR, &b);
+  for (size_t k = 0; k < C->n / 2; k++) { C->tw[k] = a; C->twi[k] = b; fe_mul(&FR, &a, &a, &w); fe_mul(&FR, &b, &b, &wi); }
+  fe_one(&FR, &a); for (size_t i = 0; i < C->n; i++) { C->coset[i] = a; fe_mul(&FR, &a, &a, &g); }
+  fe nn; fe_set_u64(&FR, &nn, C->n); fe_inv(&FR, &C->ninv, &nn);
+}
+
+static void g1_compress(const g1_aff* p, uint8_t out[32]) {
+  if (p->inf) { memset(out, 0, 32); out[31] = 0x40; return; }
+  fe_to_bytes(&FQ, out, &p->x); u64 y[4], h[4] = {0x9e10460b6c3e7ea3ULL, 0xcbc0b548b438e546ULL, 0xdc2822db40c0ac2eULL, 0x183227397098d014ULL};
+  fe_to_u64x4(&FQ, y, &p->y); if (gt4(y, h)) out[31] |= 0x80;
+}
+static void g2_compress(const g2_aff* p, uint8_t out[64]) {
+  if (p->inf) { memset(out, 0, 64); out[63] = 0x40; return; }
+  fe_to_bytes(&FQ, out, &p->x.c0); fe_to_bytes(&FQ, out + 32, &p->x.c1);
+  u64 y[4], h[4] = {0x9e10460b6c3e7ea3ULL, 0xcbc0b548b438e546ULL, 0xdc2822db40c0ac2eULL, 0x183227397098d014ULL};
+  fe_to_u64x4(&FQ, y, fe_is_zero(&p->y.c1) ? &p->y.c0 : &p->y.c1); if (gt4(y, h)) out[63] |= 0x80;
+}
+
+/* ------------------------------------------------------------------------------------------ public API */
+void* oracle_load(const uint8_t* zkey, size_t zlen, const uint8_t* graph, size_t glen) {
+  poseidon_init();
+  circuit* C = (circuit*)calloc(1, sizeof(circuit));
+  if (parse_zkey(C, zkey, zlen) != 0 || parse_graph(C, graph, glen) != 0) { free(C); return NULL; }
+  ntt_init(C);
+  return C;
+}
+size_t oracle_num_inputs(void* h) { return ((circuit*)h)->n_inputs; }
+size_t oracle_num_signals(void* h) { return ((circuit*)h)->n_signals; }
+size_t oracle_domain(void* h) { return ((circuit*)h)->n; }
+
+void oracle_poseidon(const uint8_t* in_le, size_t n, int arity, uint8_t* out_le) {
+  poseidon_init();
+  for (size_t i = 0; i < n; i++) { fe x[3], h; for (int j = 0; j < arity; j++) fe_from_bytes(&FR, &x[j], in_le + 32 * (i * arity + j)); poseidon(&h, x, arity); fe_to_bytes(&FR, out_le + 32 * i, &h); }
+}
+
+/* proof_values_from_witness (witness.rs:759-828) -> y, root, nullifier, x, ext */
+static void proof_values(const circuit* C, const uint8_t* in, uint8_t* out160) {
+  fe secret, limit, msg, x, ext, idc, root, a1, y, nul, t[3];
+  fe_from_bytes(&FR, &secret, in + 32 * C->off_secret); fe_from_bytes(&FR, &limit, in + 32 * C->off_limit);
+  fe_from_bytes(&FR, &msg, in + 32 * C->off_msg); fe_from_bytes(&FR, &x, in + 32 * C->off_x); fe_from_bytes(&FR, &ext, in + 32 * C->off_ext);
+  poseidon(&idc, &secret, 1); t[0] = idc; t[1] = limit; poseidon(&root, t, 2);
+  for (uint32_t i = 0; i < C->depth; i++) {
+    fe e; fe_from_bytes(&FR, &e, in + 32 * (C->off_path + i));
+    const uint8_t* b = in + 32 * (C->off_idx + i); int nz = 0; for (int k = 0; k < 32; k++) nz |= b[k];
+    if (!nz) { t[0] = root; t[1] = e; } else { t[0] = e; t[1] = root; }
+    poseidon(&root, t, 2);
+  }
+  t[0] = secret; t[1] = ext; t[2] = msg; poseidon(&a1, t, 3);
+  fe_mul(&FR, &y, &x, &a1); fe_add(&FR, &y, &y, &secret); poseidon(&nul, &a1, 1);
+  fe_to_bytes(&FR, out160, &y); fe_to_bytes(&FR, out160 + 32, &root); fe_to_bytes(&FR, out160 + 64, &nul);
+  fe_to_bytes(&FR, out160 + 96, &x); fe_to_bytes(&FR, out160 + 128, &ext);
+}
+
+/* One proof.  inputs: n_inputs x 32 B (slot 0 = 1); rs: r|s; outputs optional. Returns 0 on success. */
+int oracle_prove(void* hnd, const uint8_t* inputs_le, const uint8_t* rs_le, uint8_t* proof128, uint8_t* coords256,
+                 uint8_t* values160, uint8_t* witness_le, uint8_t* h_le) {
+  const circuit* C = (const circuit*)hnd;
+  size_t ns = C->n_signals, n = C->n, nc = C->n_cons, ni = C->n_inst;
+  fe* vals = (fe*)malloc(sizeof(fe) * C->n_nodes); fe* w = (fe*)malloc(sizeof(fe) * ns);
+  int rc = eval_graph(C, inputs_le, vals, w); free(vals);
+  if (rc) { free(w); return rc; }
+  if (witness_le) for (size_t i = 0; i < ns; i++) fe_to_bytes(&FR, witness_le + 32 * i, &w[i]);
+  /* qap.rs:30-98 */
+  fe* a = (fe*)calloc(n, sizeof(fe)); fe* b = (fe*)calloc(n, sizeof(fe)); fe* c = (fe*)calloc(n, sizeof(fe));
+  for (size_t r = 0; r < nc; r++) {
+    fe acc; memset(&acc, 0, sizeof acc);
+    for (size_t k = C->a_ptr[r]; k < C->a_ptr[r + 1]; k++) { fe m; fe_mul(&FR, &m, &C->a_val[k], &w[C->a_col[k]]); fe_add(&FR, &acc, &acc, &m); }
+    a[r] = acc; memset(&acc, 0, sizeof acc);
+    for (size_t k = C->b_ptr[r]; k < C->b_ptr[r + 1]; k++) { fe m; fe_mul(&FR, &m, &C->b_val[k], &w[C->b_col[k]]); fe_add(&FR, &acc, &acc, &m); }
+    b[r] = acc; fe_mul(&FR, &c[r], &a[r], &b[r]);
+  }
+  for (size_t i = 0; i < ni; i++) a[nc + i] = w[i];
+  fe* v3[3] = {a, b, c};
+  for (int q = 0; q < 3; q++) { ntt(C, v3[q], 1); for (size_t i = 0; i < n; i++) fe_mul(&FR, &v3[q][i], &v3[q][i], &C->coset[i]); ntt(C, v3[q], 0); }
+  for (size_t i = 0; i < n; i++) { fe t; fe_mul(&FR, &t, &a[i], &b[i]); fe_sub(&FR, &a[i], &t, &c[i]); } /* h in a */
+  if (h_le) for (size_t i = 0; i < n; i++) fe_to_bytes(&FR, h_le + 32 * i, &a[i]);
+  /* partial_proof.rs:182-274 */
+  u64(*ws)[4] = (u64(*)[4])malloc(sizeof(u64[4]) * ns); u64(*hs)[4] = (u64(*)[4])malloc(sizeof(u64[4]) * n);
+  for (size_t i = 0; i < ns; i++) fe_to_u64x4(&FR, ws[i], &w[i]);
+  for (size_t i = 0; i < n; i++) fe_to_u64x4(&FR, hs[i], &a[i]);
+  u64 r[4], s[4], rsv[4]; memcpy(r, rs_le, 32); memcpy(s, rs_le + 32, 32);
+  { fe fr, fs, frs; fe_from_u64x4(&FR, &fr, r); fe_from_u64x4(&FR, &fs, s); fe_mul(&FR, &frs, &fr, &fs); fe_to_u64x4(&FR, rsv, &frs); }
+  g1_jac ga, gb1, gc, t1; g2_jac gb2, t2;
+  g1_msm(&ga, C->aq + 1, (const u64(*)[4])(ws + 1), ns - 1);
+  g1_add_mixed(&ga, &ga, &C->alpha1); g1_add_mixed(&ga, &ga, &C->aq[0]); g1_mul(&t1, &C->delta1, r); g1_add(&ga, &ga, &t1);
+  int rz = !(r[0] | r[1] | r[2] | r[3]);
+  if (!rz) { g1_msm(&gb1, C->b1q + 1, (const u64(*)[4])(ws + 1), ns - 1); g1_add_mixed(&gb1, &gb1, &C->beta1); g1_add_mixed(&gb1, &gb1, &C->b1q[0]); g1_mul(&t1, &C->delta1, s); g1_add(&gb1, &gb1, &t1); }
+  else g1_jac_inf(&gb1);
+  g2_msm(&gb2, C->b2q + 1, (const u64(*)[4])(ws + 1), ns - 1);
+  g2_add_mixed(&gb2, &gb2, &C->beta2); g2_add_mixed(&gb2, &gb2, &C->b2q[0]); g2_mul(&t2, &C->delta2, s); g2_add(&gb2, &gb2, &t2);
+  g1_jac lacc, hacc; g1_msm(&lacc, C->lq, (const u64(*)[4])(ws + ni), C->n_l); g1_msm(&hacc, C->hq, (const u64(*)[4])hs, n);
+  g1_aff A, B1; g2_aff B2; g1_to_aff(&A, &ga); g1_to_aff(&B1, &gb1); g2_to_aff(&B2, &gb2);
+  g1_mul(&gc, &A, s); g1_mul(&t1, &B1, r); g1_add(&gc, &gc, &t1);
+  g1_mul(&t1, &C->delta1, rsv); fe_neg(&FQ, &t1.Y, &t1.Y); g1_add(&gc, &gc, &t1);
+  g1_add(&gc, &gc, &lacc); g1_add(&gc, &gc, &hacc);
+  g1_aff Cc; g1_to_aff(&Cc, &gc);
+  if (proof128) { g1_compress(&A, proof128); g2_compress(&B2, proof128 + 32); g1_compress(&Cc, proof128 + 96); }
+  if (coords256) { fe_to_bytes(&FQ, coords256, &A.x); fe_to_bytes(&FQ, coords256 + 32, &A.y); fe_to_bytes(&FQ, coords256 + 64, &B2.x.c0); fe_to_bytes(&FQ, coords256 + 96, &B2.x.c1);
+    fe_to_bytes(&FQ, coords256 + 128, &B2.y.c0); fe_to_bytes(&FQ, coords256 + 160, &B2.y.c1); fe_to_bytes(&FQ, coords256 + 192, &Cc.x); fe_to_bytes(&FQ, coords256 + 224, &Cc.y); }
+  if (values160) proof_values(C, inputs_le, values160);
+  free(w); free(a); free(b); free(c); free(ws); free(hs);
+  return 0;
+}
+
+typedef struct { void* h; const uint8_t *in, *rs; uint8_t *proofs, *values; size_t n, next; pthread_mutex_t* mu; int rc; } job;
+static void* worker(void* arg) {
+  job* J = (job*)arg; size_t ni = oracle_num_inputs(J->h);
+  for (;;) {
+    pthread_mutex_lock(J->mu); size_t i = J->next++; pthread_mutex_unlock(J->mu);
+    if (i >= J->n) break;
+    int rc = oracle_prove(J->h, J->in + i * ni * 32, J->rs + i * 64, J->proofs ? J->proofs + i * 128 : NULL, NULL, J->values ? J->values + i * 160 : NULL, NULL, NULL);
+    if (rc) J->rc = rc;
+  }
+  return NULL;
+}
+/* n proofs, one proof per host thread (the deployment mode rln/README.md:324-332 recommends); returns seconds */
+double oracle_prove_many(void* h, const uint8_t* inputs, const uint8_t* rs, size_t n, int threads, uint8_t* proofs, uint8_t* values, int* rc_out) {
+  pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER; job J = {h, inputs, rs, proofs, values, n, 0, &mu, 0};
+  struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
+  for (int i = 0; i < threads; i++) pthread_create(&th[i], NULL, worker, &J);
+  for (int i = 0; i < threads; i++) pthread_join(th[i], NULL);
+  clock_gettime(CLOCK_MONOTONIC, &t1); free(th);
+  if (rc_out) *rc_out = J.rc;
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+/* dense Poseidon tree: leaves (n x 32 B) at [0, n) of a depth-d tree with default leaf 0; root + optional nodes */
+void oracle_tree_root(int depth, const uint8_t* leaves_le, size_t n, uint8_t root_le[32]) {
+  poseidon_init();
+  size_t cap = (size_t)1 << depth; fe* lvl = (fe*)calloc(cap, sizeof(fe));
+  for (size_t i = 0; i < n && i < cap; i++) fe_from_bytes(&FR, &lvl[i], leaves_le + 32 * i);
+  for (size_t w = cap; w > 1; w >>= 1) for (size_t i = 0; i < w / 2; i++) { fe in[2] = {lvl[2 * i], lvl[2 * i + 1]}; poseidon(&lvl[i], in, 2); }
+  fe_to_bytes(&FR, root_le, &lvl[0]); free(lvl);
+}
