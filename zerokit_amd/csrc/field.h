@@ -55,6 +55,26 @@ struct Fp {
 
   // r = t - MOD if t >= MOD else t   (t < 2*MOD)
   static RLN_HD void reduce_once(uint32_t* t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t d[8], keep;
+    asm("v_sub_co_u32 %0, vcc, %9, %17\n\t"
+        "v_subb_co_u32 %1, vcc, %10, %18, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %11, %19, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %12, %20, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %13, %21, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %14, %22, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %15, %23, vcc\n\t"
+        "v_subb_co_u32 %7, vcc, %16, %24, vcc\n\t"
+        "v_subb_co_u32 %8, vcc, 0, 0, vcc"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]),
+          "=&v"(keep)
+        : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7]), "v"(P::MOD[0]),
+          "v"(P::MOD[1]), "v"(P::MOD[2]), "v"(P::MOD[3]), "v"(P::MOD[4]), "v"(P::MOD[5]), "v"(P::MOD[6]),
+          "v"(P::MOD[7])
+        : "vcc");
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = keep ? t[i] : d[i];
+#else
     uint32_t d[8];
     uint32_t borrow = 0;
 #pragma unroll
@@ -65,9 +85,46 @@ struct Fp {
     }
 #pragma unroll
     for (int i = 0; i < 8; i++) t[i] = borrow ? t[i] : d[i];
+#endif
   }
 
   friend RLN_HD Fp operator+(const Fp& a, const Fp& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // one carry chain for a+b, one borrow chain for (a+b)-p, then a select: 24 full-rate VALU ops
+    Fp r, d;
+    asm("v_add_co_u32 %0, vcc, %8, %16\n\t"
+        "v_addc_co_u32 %1, vcc, %9, %17, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %10, %18, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %11, %19, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, %12, %20, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, %13, %21, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %14, %22, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, %15, %23, vcc"
+        : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]),
+          "=&v"(r.v[7])
+        : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+          "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7])
+        : "vcc");
+    uint32_t keep;  // all-ones when r < p (borrow out of the subtraction)
+    asm("v_sub_co_u32 %0, vcc, %9, %17\n\t"
+        "v_subb_co_u32 %1, vcc, %10, %18, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %11, %19, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %12, %20, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %13, %21, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %14, %22, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %15, %23, vcc\n\t"
+        "v_subb_co_u32 %7, vcc, %16, %24, vcc\n\t"
+        "v_subb_co_u32 %8, vcc, 0, 0, vcc"
+        : "=&v"(d.v[0]), "=&v"(d.v[1]), "=&v"(d.v[2]), "=&v"(d.v[3]), "=&v"(d.v[4]), "=&v"(d.v[5]), "=&v"(d.v[6]),
+          "=&v"(d.v[7]), "=&v"(keep)
+        : "v"(r.v[0]), "v"(r.v[1]), "v"(r.v[2]), "v"(r.v[3]), "v"(r.v[4]), "v"(r.v[5]), "v"(r.v[6]), "v"(r.v[7]),
+          "v"(P::MOD[0]), "v"(P::MOD[1]), "v"(P::MOD[2]), "v"(P::MOD[3]), "v"(P::MOD[4]), "v"(P::MOD[5]),
+          "v"(P::MOD[6]), "v"(P::MOD[7])
+        : "vcc");
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = keep ? r.v[i] : d.v[i];
+    return r;
+#else
     Fp r;
     uint32_t c = 0;
 #pragma unroll
@@ -78,8 +135,43 @@ struct Fp {
     }
     reduce_once(r.v);  // a,b < MOD < 2^254 so no carry out of limb 7
     return r;
+#endif
   }
   friend RLN_HD Fp operator-(const Fp& a, const Fp& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    Fp r;
+    uint32_t borrow;  // all-ones when a < b
+    asm("v_sub_co_u32 %0, vcc, %9, %17\n\t"
+        "v_subb_co_u32 %1, vcc, %10, %18, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %11, %19, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %12, %20, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %13, %21, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %14, %22, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %15, %23, vcc\n\t"
+        "v_subb_co_u32 %7, vcc, %16, %24, vcc\n\t"
+        "v_subb_co_u32 %8, vcc, 0, 0, vcc"
+        : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]),
+          "=&v"(r.v[7]), "=&v"(borrow)
+        : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+          "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7])
+        : "vcc");
+    uint32_t m[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) m[i] = P::MOD[i] & borrow;
+    asm("v_add_co_u32 %0, vcc, %0, %8\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %2, %10, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %3, %11, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, %4, %12, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, %5, %13, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %6, %14, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, %7, %15, vcc"
+        : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]), "+v"(r.v[4]), "+v"(r.v[5]), "+v"(r.v[6]),
+          "+v"(r.v[7])
+        : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7])
+        : "vcc");
+    return r;
+#else
     Fp r;
     uint32_t borrow = 0;
 #pragma unroll
@@ -96,12 +188,114 @@ struct Fp {
       c = (uint32_t)(s >> 32);
     }
     return r;
+#endif
   }
   RLN_HD Fp neg() const { return is_zero() ? *this : (zero() - *this); }
   RLN_HD Fp dbl() const { return *this + *this; }
 
-  // Montgomery product a*b*R^-1 mod p.  Operand-scanning CIOS, multiply and reduce interleaved so each
-  // inner step is two v_mad_u64_u32 with 32-bit carries; "no-carry" form (top word fits, MOD < 2^254).
+  // Montgomery product a*b*R^-1 mod p.
+  //
+  // Device: product-scanning (column-wise) form.  Each column accumulates its a_i*b_j and m_i*p_j terms in
+  // a 64-bit register pair with v_mad_u64_u32, whose carry-out is counted into a third word by one
+  // v_addc_co_u32: two instructions per 32x32 product, no per-product zero-extension or 64-bit adds
+  // (the operand-scanning C form costs ~6).  The modulus limbs ride in SGPRs (wave-uniform).
+  // Host: operand-scanning CIOS in portable C (same value, used by tests and one-time table setup).
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "mont_mac.inc"
+  static __device__ __forceinline__ Fp mont_mul(const Fp& a, const Fp& b) {
+    uint32_t m[8], t[8];
+    uint64_t acc = 0;
+    uint32_t top = 0;
+    macv1(acc, top, a.v[0], b.v[0]);
+    m[0] = (uint32_t)acc * P::INV32;
+    macs1(acc, top, m[0], P::MOD[0]);
+    acc = (acc >> 32) | ((uint64_t)top << 32);
+    top = 0;
+    macv2(acc, top, a.v[0], b.v[1], a.v[1], b.v[0]);
+    macs1(acc, top, m[0], P::MOD[1]);
+    m[1] = (uint32_t)acc * P::INV32;
+    macs1(acc, top, m[1], P::MOD[0]);
+    acc = (acc >> 32) | ((uint64_t)top << 32);
+    top = 0;
+    macv3(acc, top, a.v[0], b.v[2], a.v[1], b.v[1], a.v[2], b.v[0]);
+    macs2(acc, top, m[0], P::MOD[2], m[1], P::MOD[1]);
+    m[2] = (uint32_t)acc * P::INV32;
+    macs1(acc, top, m[2], P::MOD[0]);
+    acc = (acc >> 32) | ((uint64_t)top << 32);
+    top = 0;
+    macv4(acc, top, a.v[0], b.v[3], a.v[1], b.v[2], a.v[2], b.v[1], a.v[3], b.v[0]);
+    macs3(acc, top, m[0], P::MOD[3], m[1], P::MOD[2], m[2], P::MOD[1]);
+    m[3] = (uint32_t)acc * P::INV32;
+    macs1(acc, top, m[3], P::MOD[0]);
+    acc = (acc >> 32) | ((uint64_t)top << 32);
+    top = 0;
+    macv5(acc, top, a.v[0], b.v[4], a.v[1], b.v[3], a.v[2], b.v[2], a.v[3], b.v[1], a.v[4], b.v[0]);
+    macs4(acc, top, m[0], P::MOD[4], m[1], P::MOD[3], m[2], P::MOD[2], m[3], P::MOD[1]);
+    m[4] = (uint32_t)acc * P::INV32;
+    macs1(acc, top, m[4], P::MOD[0]);
+    acc = (acc >> 32) | ((uint64_t)top << 32);
+    top = 0;
+    macv6(acc, top, a.v[0], b.v[5], a.v[1], b.v[4], a.v[2], b.v[3], a.v[3], b.v[2], a.v[4], b.v[1], a.v[5], b.v[0]);
+    macs5(acc, top, m[0], P::MOD[5], m[1], P::MOD[4], m[2], P::MOD[3], m[3], P::MOD[2], m[4], P::MOD[1]);
+    m[5] = (uint32_t)acc * P::INV32;
+    macs1(acc, top, m[5], P::MOD[0]);
+    acc = (acc >> 32) | ((uint64_t)top << 32);
+    top = 0;
+    macv7(acc, top, a.v[0], b.v[6], a.v[1], b.v[5], a.v[2], b.v[4], a.v[3], b.v[3], a.v[4], b.v[2], a.v[5], b.v[1], a.v[6], b.v[0]);
+    macs6(acc, top, m[0], P::MOD[6], m[1], P::MOD[5], m[2], P::MOD[4], m[3], P::MOD[3], m[4], P::MOD[2], m[5], P::MOD[1]);
+    m[6] = (uint32_t)acc * P::INV32;
+    macs1(acc, top, m[6], P::MOD[0]);
+    acc = (acc >> 32) | ((uint64_t)top << 32);
+    top = 0;
+    macv8(acc, top, a.v[0], b.v[7], a.v[1], b.v[6], a.v[2], b.v[5], a.v[3], b.v[4], a.v[4], b.v[3], a.v[5], b.v[2], a.v[6], b.v[1], a.v[7], b.v[0]);
+    macs7(acc, top, m[0], P::MOD[7], m[1], P::MOD[6], m[2], P::MOD[5], m[3], P::MOD[4], m[4], P::MOD[3], m[5], P::MOD[2], m[6], P::MOD[1]);
+    m[7] = (uint32_t)acc * P::INV32;
+    macs1(acc, top, m[7], P::MOD[0]);
+    acc = (acc >> 32) | ((uint64_t)top << 32);
+    top = 0;
+    macv7(acc, top, a.v[1], b.v[7], a.v[2], b.v[6], a.v[3], b.v[5], a.v[4], b.v[4], a.v[5], b.v[3], a.v[6], b.v[2], a.v[7], b.v[1]);
+    macs7(acc, top, m[1], P::MOD[7], m[2], P::MOD[6], m[3], P::MOD[5], m[4], P::MOD[4], m[5], P::MOD[3], m[6], P::MOD[2], m[7], P::MOD[1]);
+    t[0] = (uint32_t)acc;
+    acc = (acc >> 32) | ((uint64_t)top << 32);
+    top = 0;
+    macv6(acc, top, a.v[2], b.v[7], a.v[3], b.v[6], a.v[4], b.v[5], a.v[5], b.v[4], a.v[6], b.v[3], a.v[7], b.v[2]);
+    macs6(acc, top, m[2], P::MOD[7], m[3], P::MOD[6], m[4], P::MOD[5], m[5], P::MOD[4], m[6], P::MOD[3], m[7], P::MOD[2]);
+    t[1] = (uint32_t)acc;
+    acc = (acc >> 32) | ((uint64_t)top << 32);
+    top = 0;
+    macv5(acc, top, a.v[3], b.v[7], a.v[4], b.v[6], a.v[5], b.v[5], a.v[6], b.v[4], a.v[7], b.v[3]);
+    macs5(acc, top, m[3], P::MOD[7], m[4], P::MOD[6], m[5], P::MOD[5], m[6], P::MOD[4], m[7], P::MOD[3]);
+    t[2] = (uint32_t)acc;
+    acc = (acc >> 32) | ((uint64_t)top << 32);
+    top = 0;
+    macv4(acc, top, a.v[4], b.v[7], a.v[5], b.v[6], a.v[6], b.v[5], a.v[7], b.v[4]);
+    macs4(acc, top, m[4], P::MOD[7], m[5], P::MOD[6], m[6], P::MOD[5], m[7], P::MOD[4]);
+    t[3] = (uint32_t)acc;
+    acc = (acc >> 32) | ((uint64_t)top << 32);
+    top = 0;
+    macv3(acc, top, a.v[5], b.v[7], a.v[6], b.v[6], a.v[7], b.v[5]);
+    macs3(acc, top, m[5], P::MOD[7], m[6], P::MOD[6], m[7], P::MOD[5]);
+    t[4] = (uint32_t)acc;
+    acc = (acc >> 32) | ((uint64_t)top << 32);
+    top = 0;
+    macv2(acc, top, a.v[6], b.v[7], a.v[7], b.v[6]);
+    macs2(acc, top, m[6], P::MOD[7], m[7], P::MOD[6]);
+    t[5] = (uint32_t)acc;
+    acc = (acc >> 32) | ((uint64_t)top << 32);
+    top = 0;
+    macv1(acc, top, a.v[7], b.v[7]);
+    macs1(acc, top, m[7], P::MOD[7]);
+    t[6] = (uint32_t)acc;
+    acc = (acc >> 32) | ((uint64_t)top << 32);
+    top = 0;
+    t[7] = (uint32_t)acc;
+    reduce_once(t);
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = t[i];
+    return r;
+  }
+#else
   static RLN_HD Fp mont_mul(const Fp& a, const Fp& b) {
     uint32_t t[8];
 #pragma unroll
@@ -129,6 +323,7 @@ struct Fp {
     for (int i = 0; i < 8; i++) r.v[i] = t[i];
     return r;
   }
+#endif
 #if defined(__HIP_DEVICE_COMPILE__) && defined(RLN_NOINLINE_MUL)
   // Out-of-line multiply: one 3 KB body shared by every call site keeps point-arithmetic kernels
   // (a G2 mixed add is 30 base-field products) inside the instruction cache.  Operands travel in VGPRs.
