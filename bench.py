@@ -105,7 +105,8 @@ def main():
 
     B = args.batch
     t0 = time.time()
-    prover = BatchProver(max_batch=B)
+    wbits = int(os.environ.get("RLNAMD_WINDOW_BITS", "13"))   # 153 GiB of fixed-base tables: sized for 288 GB HBM
+    prover = BatchProver(max_batch=B, window_bits=wbits)
     init_s = time.time() - t0
     ws, rs = config2_witnesses(B, seed=0xC0FFEE + rank)   # every rank proves a different shard
     inputs = prover.pack_inputs(ws)
@@ -116,15 +117,13 @@ def main():
         if world > 1:
             dist.barrier()
 
-    stage_sum = {}
     for _ in range(args.warmup):
         prover.run(n)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        prover.run(n)
-        for k, v in prover.stage_ms().items():
-            stage_sum[k] = stage_sum.get(k, 0.0) + v
+        prover.run_async(n)      # batches pipeline on the device; each ends with proofs in pinned host memory
+    prover.sync()
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -139,7 +138,7 @@ def main():
 
     if rank == 0:
         steps = max(args.steps, 1)
-        stage_ms = {k: v / steps for k, v in stage_sum.items()}
+        stage_ms = prover.stage_ms()   # HIP-event spans of the last batch (overlapped with its neighbours)
         proofs = world * B * args.steps
         value = proofs / elapsed
         msm_ms = stage_ms.get("msm_g1", 0.0)

@@ -82,6 +82,11 @@ int rlnamd_prover_input_slot(rlnamd_prover* p, const char* name, uint32_t* offse
 /* inputs: n * inputs_size * 32 bytes (slot 0 must hold 1); rs: n * 64 bytes (r then s). */
 int rlnamd_prover_upload(rlnamd_prover* p, size_t n, const uint8_t* inputs_le, const uint8_t* rs_le);
 int rlnamd_prover_run(rlnamd_prover* p, size_t n);      /* inputs already resident; blocks until done */
+/* Enqueue only: consecutive batches overlap on the device (front end of batch k+1 and back end of batch
+ * k-1 beside the MSM of batch k); each batch ends with its proofs copied to pinned host memory.
+ * rlnamd_prover_sync drains the pipeline; download / stage_ms refer to the last enqueued batch. */
+int rlnamd_prover_run_async(rlnamd_prover* p, size_t n);
+int rlnamd_prover_sync(rlnamd_prover* p);
 /* proofs: n*128 (ark-serialize compressed Proof), coords: n*256 (affine A|B|C) or NULL,
  * values: n*160 (y, root, nullifier, x, external_nullifier) or NULL, errors: n*4 or NULL */
 int rlnamd_prover_download(rlnamd_prover* p, size_t n, uint8_t* proofs, uint8_t* coords, uint8_t* values,

@@ -120,13 +120,31 @@ def tree_root(depth, leaves):
     return int.from_bytes(out.raw, "little")
 
 
+def usable_cores():
+    """host threads this process may really use: affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def time_baseline(ws, rs, target_seconds=12.0):
-    """bench.py cpu_baseline: one proof per host thread on every core, bounded sample."""
+    """bench.py cpu_baseline: one proof per host thread on every usable core, bounded sample."""
     c = Circuit(20)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     t1, _, _ = c.prove_many(ws[:1], rs[:1], threads=1)      # single-thread latency
-    n = max(cores, min(len(ws), int(target_seconds / max(t1, 1e-3)) * cores // 1))
-    n = min(n, len(ws), max(cores, int(target_seconds * cores / max(t1, 1e-3))))
+    n = min(len(ws), max(cores, int(target_seconds * cores / max(t1, 1e-3))))
     secs, _, _ = c.prove_many(ws[:n], rs[:n], threads=cores)
     return {"value": round(n / secs, 3), "unit": "proofs/s", "cores": cores, "kind": "port",
             "single_thread_ms_per_proof": round(t1 * 1e3, 2),

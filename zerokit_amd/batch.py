@@ -80,6 +80,13 @@ class BatchProver:
     def run(self, n):
         check(lib().rlnamd_prover_run(self._h, n))
 
+    def run_async(self, n):
+        """enqueue only; consecutive batches pipeline on the device (see Prover::run_async)"""
+        check(lib().rlnamd_prover_run_async(self._h, n))
+
+    def sync(self):
+        check(lib().rlnamd_prover_sync(self._h))
+
     def download(self, n):
         proofs = C.create_string_buffer(128 * n)
         coords = C.create_string_buffer(256 * n)

@@ -234,6 +234,16 @@ int rlnamd_prover_run(rlnamd_prover* p, size_t n) {
   p->p->run(n);
   RLN_CATCH
 }
+int rlnamd_prover_run_async(rlnamd_prover* p, size_t n) {
+  RLN_TRY
+  p->p->run_async(n);
+  RLN_CATCH
+}
+int rlnamd_prover_sync(rlnamd_prover* p) {
+  RLN_TRY
+  p->p->sync();
+  RLN_CATCH
+}
 int rlnamd_prover_download(rlnamd_prover* p, size_t n, uint8_t* proofs, uint8_t* coords, uint8_t* values,
                            uint32_t* errors) {
   RLN_TRY

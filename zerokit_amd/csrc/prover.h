@@ -60,8 +60,13 @@ class Prover {
   // Host inputs: `inputs` = n x inputs_size canonical 32-byte LE values (the witness-graph inputs buffer,
   // slot 0 = 1, iden3calc.rs:122-181); rs = n x 2 x 32 bytes (r, s).  Copies to the device.
   void upload(size_t n, const uint8_t* inputs, const uint8_t* rs);
-  // Runs the whole pipeline on the resident inputs (async on the prover stream, then synchronises).
+  // Runs the whole pipeline on the resident inputs and waits for it.
   void run(size_t n);
+  // Same, but only enqueues: consecutive calls overlap (batch k+1's witness/NTT front end and batch k-1's
+  // finalize back end run beside batch k's MSM on separate HIP streams; two workspace slots).  Every
+  // batch ends with its proofs + values copied to pinned host memory.  sync() drains the pipeline.
+  void run_async(size_t n);
+  void sync();
   void download(size_t n, ProofOut* out);
   // convenience
   void prove(size_t n, const uint8_t* inputs, const uint8_t* rs, ProofOut* out) {

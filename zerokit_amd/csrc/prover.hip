@@ -396,16 +396,18 @@ __global__ void __launch_bounds__(64) k_msm(const Affine<F>* __restrict__ table,
   part[(size_t)chunk * B + p] = acc;
 }
 
-// sums[seg][p] = sum over the segment's chunks
+// dst[r][p] = sum of src[i][p] over ranges[r] -- used twice (chunks -> groups -> segments) so the
+// per-proof reduction is a two-level tree instead of one long serial chain
 template <class F>
-__global__ void __launch_bounds__(64) k_msm_reduce(const XYZZ<F>* __restrict__ part, const uint32_t* __restrict__ seg_first,
-                                                   uint32_t nseg, XYZZ<F>* __restrict__ sums, uint32_t B, uint32_t nb) {
+__global__ void __launch_bounds__(64) k_sum_ranges(const XYZZ<F>* __restrict__ src, const ChunkDesc* __restrict__ ranges,
+                                                   uint32_t nranges, XYZZ<F>* __restrict__ dst, uint32_t B, uint32_t nb) {
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
-  uint32_t seg = blockIdx.y;
-  if (p >= nb || seg >= nseg) return;
+  uint32_t r = blockIdx.y;
+  if (p >= nb || r >= nranges) return;
+  ChunkDesc cd = ranges[r];
   XYZZ<F> acc = XYZZ<F>::inf();
-  for (uint32_t ch = seg_first[seg]; ch < seg_first[seg + 1]; ch++) acc.add(part[(size_t)ch * B + p]);
-  sums[(size_t)seg * B + p] = acc;
+  for (uint32_t i = cd.pt_begin; i < cd.pt_end; i++) acc.add(src[(size_t)i * B + p]);
+  dst[(size_t)r * B + p] = acc;
 }
 
 // one-time comb table: row (k, j) = { d * 2^(c j) * P_k : d = 1..2^(c-1) } in affine form.
@@ -467,22 +469,67 @@ __device__ __forceinline__ bool fq_is_neg_dev(const Fq& y) {
 }
 __device__ __forceinline__ void store_fq(uint32_t* dst, const Fq& x) { x.to_canonical(dst); }
 
-__global__ void __launch_bounds__(64) k_finalize(const G1XYZZ* __restrict__ sums1, const G2XYZZ* __restrict__ sums2,
-                                                 const uint32_t* __restrict__ rs, uint32_t* __restrict__ coords,
-                                                 uint8_t* __restrict__ comp, uint32_t B, uint32_t nb) {
+// F1: the three MSM sums that become proof elements go to affine form in parallel (one inversion each)
+__global__ void __launch_bounds__(64) k_fin_affine(const G1XYZZ* __restrict__ sums1, const G2XYZZ* __restrict__ sums2,
+                                                   G1Affine* __restrict__ affA, G1Affine* __restrict__ affB1,
+                                                   G2Affine* __restrict__ affB2, uint32_t B, uint32_t nb) {
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
   if (p >= nb) return;
-  G1Affine A = sums1[p].to_affine();
-  G1Affine B1 = sums1[(size_t)B + p].to_affine();
+  if (blockIdx.y == 0)
+    affA[p] = sums1[p].to_affine();
+  else if (blockIdx.y == 1)
+    affB1[p] = sums1[(size_t)B + p].to_affine();
+  else
+    affB2[p] = sums2[p].to_affine();
+}
+
+// F2: the two variable-base products s*A and r*B1 (partial_proof.rs:257-260), one lane each, fixed 4-bit
+// windows over a 15-entry table parked in HBM: 252 doublings + 63 additions instead of a bit-serial
+// double-and-add whose lanes diverge on every scalar bit.
+__global__ void __launch_bounds__(64) k_fin_smul(const G1Affine* __restrict__ affA, const G1Affine* __restrict__ affB1,
+                                                 const uint32_t* __restrict__ rs, G1XYZZ* __restrict__ tbl,
+                                                 G1XYZZ* __restrict__ prod, uint32_t B, uint32_t nb) {
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= nb) return;
+  const uint32_t task = blockIdx.y;  // 0: s*A, 1: r*B1
+  const G1Affine P = task == 0 ? affA[p] : affB1[p];
+  const uint32_t* k = rs + (size_t)p * 16 + (task == 0 ? 8 : 0);
+  G1XYZZ* T = tbl + (size_t)task * 16 * B + p;  // T[d] at T[d * B]
+  G1XYZZ cur = G1XYZZ::from_affine(P);
+  T[(size_t)1 * B] = cur;
+#pragma unroll 1
+  for (int d = 2; d < 16; d++) {
+    cur.madd(P);
+    T[(size_t)d * B] = cur;
+  }
+  G1XYZZ acc = G1XYZZ::inf();
+#pragma unroll 1
+  for (int w = 63; w >= 0; w--) {
+    if (w != 63) {
+      acc = acc.dbl();
+      acc = acc.dbl();
+      acc = acc.dbl();
+      acc = acc.dbl();
+    }
+    uint32_t d = (k[w >> 3] >> ((w & 7) * 4)) & 15;
+    if (d) acc.add(T[(size_t)d * B]);
+  }
+  prod[(size_t)task * B + p] = acc;  // r == 0 gives infinity, matching g1_b = 0 (partial_proof.rs:242-248)
+}
+
+// F3: C = s*A + r*B1 + (L + H - rs*delta); canonical coordinates and the compressed encoding
+__global__ void __launch_bounds__(64) k_fin_out(const G1XYZZ* __restrict__ sums1, const G1XYZZ* __restrict__ prod,
+                                                const G1Affine* __restrict__ affA, const G2Affine* __restrict__ affB2,
+                                                uint32_t* __restrict__ coords, uint8_t* __restrict__ comp, uint32_t B,
+                                                uint32_t nb) {
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= nb) return;
   G1XYZZ Cacc = sums1[2 * (size_t)B + p];
-  G2Affine B2 = sums2[p].to_affine();
-  const uint32_t* r = rs + (size_t)p * 16;
-  const uint32_t* s = r + 8;
-  Cacc.add(scalar_mul(A, s));
-  bool r_zero = true;
-  for (int i = 0; i < 8; i++) r_zero &= r[i] == 0;
-  if (!r_zero) Cacc.add(scalar_mul(B1, r));  // g1_b = 0 when r == 0 (partial_proof.rs:242-248)
+  Cacc.add(prod[p]);
+  Cacc.add(prod[(size_t)B + p]);
   G1Affine C = Cacc.to_affine();
+  G1Affine A = affA[p];
+  G2Affine B2 = affB2[p];
   uint32_t* o = coords + (size_t)p * 64;
   store_fq(o, A.x);
   store_fq(o + 8, A.y);
@@ -568,10 +615,29 @@ __global__ void k_gather_col(const Fr* __restrict__ src, const uint32_t* __restr
 // =====================================================================================================
 // host side
 // =====================================================================================================
+// Everything one in-flight batch owns.  Two slots let batch k+1 run its latency-bound front end (witness
+// interpreter, NTT) and batch k-1 its back end (reduction, finalize) on their own streams while batch k
+// keeps the chip busy with the MSM.
+struct Slot {
+  DevBuf<uint32_t> err, coords, values;
+  DevBuf<uint8_t> comp;
+  DevBuf<Fr> V, abc;
+  DevBuf<int16_t> digits;
+  DevBuf<G1XYZZ> part1, grp1, sums1, prod, tbl;
+  DevBuf<G2XYZZ> part2, grp2, sums2;
+  DevBuf<G1Affine> affA, affB1;
+  DevBuf<G2Affine> affB2;
+  uint8_t* h_comp = nullptr;    // pinned: every run ends with the proofs + values copied to the host
+  uint32_t* h_values = nullptr;
+  uint32_t* h_err = nullptr;
+  hipEvent_t evA = nullptr, evB = nullptr, evC = nullptr;
+  hipEvent_t t[11];  // timing marks
+  bool used = false;
+  size_t n = 0;
+};
+
 struct Prover::Impl {
-  hipStream_t stream = nullptr, stream2 = nullptr;
-  hipEvent_t ev[PROVER_STAGES + 1];
-  hipEvent_t ev_fork, ev_join;
+  hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;
   float ms[PROVER_STAGES] = {0};
 
   uint32_t N = 0, NS = 0, NI = 0, nc = 0, ni = 0, n = 0;
@@ -587,17 +653,20 @@ struct Prover::Impl {
   DevBuf<G2Affine> t2;
   DevBuf<uint32_t> sid1, sid2;
   DevBuf<ChunkDesc> chunks1, chunks2;
-  DevBuf<uint32_t> segfirst1, segfirst2;
-  uint32_t nchunks1 = 0, nchunks2 = 0, npts1 = 0, npts2 = 0;
+  DevBuf<ChunkDesc> groups1, groups2, segs1, segs2;  // two-level reduction ranges
+  uint32_t nchunks1 = 0, nchunks2 = 0, npts1 = 0, npts2 = 0, ngroups1 = 0, ngroups2 = 0;
   InputSlots slots{};
-  // workspace
-  DevBuf<uint32_t> inputs, rs, err, coords, values;
-  DevBuf<uint8_t> comp;
-  DevBuf<Fr> V, abc;
-  DevBuf<int16_t> digits;
-  DevBuf<G1XYZZ> part1, sums1;
-  DevBuf<G2XYZZ> part2, sums2;
-  bool have_run = false;
+  // resident inputs (shared by both slots; upload() drains the pipeline first)
+  DevBuf<uint32_t> inputs, rs;
+  Slot slot[2];
+  int cur = 0;
+  Slot* last = nullptr;
+
+  void sync_all() {
+    RLN_HIP(hipStreamSynchronize(sA));
+    RLN_HIP(hipStreamSynchronize(sB));
+    RLN_HIP(hipStreamSynchronize(sC));
+  }
 };
 
 static int env_int(const char* name, int dflt) {
@@ -609,6 +678,18 @@ static uint32_t bitrev(uint32_t x, int bits) {
   uint32_t r = 0;
   for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
   return r;
+}
+
+// chunks of one segment -> groups of <= 16 chunks -> the segment
+static void make_reduce_ranges(const std::vector<uint32_t>& segfirst, std::vector<ChunkDesc>& groups,
+                               std::vector<ChunkDesc>& segs) {
+  const uint32_t G = 16;
+  for (size_t sgi = 0; sgi + 1 < segfirst.size(); sgi++) {
+    uint32_t g0 = (uint32_t)groups.size();
+    for (uint32_t c = segfirst[sgi]; c < segfirst[sgi + 1]; c += G)
+      groups.push_back({c, std::min(c + G, segfirst[sgi + 1])});
+    segs.push_back({g0, (uint32_t)groups.size()});
+  }
 }
 
 template <class F>
@@ -664,12 +745,16 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   if (D.logn < 1 || D.logn > 27) throw Error("PolynomialDegreeTooLarge");
   if (zk_.h_query.size() < D.n) throw Error("zkey h_query shorter than the evaluation domain");
 
-  RLN_HIP(hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking));
-  RLN_HIP(hipStreamCreateWithFlags(&D.stream2, hipStreamNonBlocking));
-  for (auto& e : D.ev) RLN_HIP(hipEventCreate(&e));
-  RLN_HIP(hipEventCreateWithFlags(&D.ev_fork, hipEventDisableTiming));
-  RLN_HIP(hipEventCreateWithFlags(&D.ev_join, hipEventDisableTiming));
-  hipStream_t s = D.stream;
+  {
+    // the short latency-bound stages get the high-priority queues so their few waves are dispatched ahead
+    // of the MSM's thousands of workgroups
+    int lo = 0, hi = 0;
+    RLN_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    RLN_HIP(hipStreamCreateWithPriority(&D.sA, hipStreamNonBlocking, hi));
+    RLN_HIP(hipStreamCreateWithPriority(&D.sB, hipStreamNonBlocking, lo));
+    RLN_HIP(hipStreamCreateWithPriority(&D.sC, hipStreamNonBlocking, hi));
+  }
+  hipStream_t s = D.sB;
 
   // ---- graph program
   D.nodes.alloc(D.N);
@@ -777,8 +862,13 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     D.sid1.upload(sids.data(), sids.size(), s);
     D.chunks1.alloc(chunks.size());
     D.chunks1.upload(chunks.data(), chunks.size(), s);
-    D.segfirst1.alloc(segfirst.size());
-    D.segfirst1.upload(segfirst.data(), segfirst.size(), s);
+    std::vector<ChunkDesc> groups, segs;
+    make_reduce_ranges(segfirst, groups, segs);
+    D.ngroups1 = (uint32_t)groups.size();
+    D.groups1.alloc(groups.size());
+    D.groups1.upload(groups.data(), groups.size(), s);
+    D.segs1.alloc(segs.size());
+    D.segs1.upload(segs.data(), segs.size(), s);
     RLN_HIP(hipStreamSynchronize(s));
     build_table<Fq>(pts, c_, W_, D.t1, s);
   }
@@ -805,8 +895,13 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     D.sid2.upload(sids.data(), sids.size(), s);
     D.chunks2.alloc(chunks.size());
     D.chunks2.upload(chunks.data(), chunks.size(), s);
-    D.segfirst2.alloc(segfirst.size());
-    D.segfirst2.upload(segfirst.data(), segfirst.size(), s);
+    std::vector<ChunkDesc> groups, segs;
+    make_reduce_ranges(segfirst, groups, segs);
+    D.ngroups2 = (uint32_t)groups.size();
+    D.groups2.alloc(groups.size());
+    D.groups2.upload(groups.data(), groups.size(), s);
+    D.segs2.alloc(segs.size());
+    D.segs2.upload(segs.data(), segs.size(), s);
     RLN_HIP(hipStreamSynchronize(s));
     build_table<Fq2>(pts, c_, W_, D.t2, s);
   }
@@ -833,33 +928,54 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   const size_t B = B_;
   D.inputs.alloc(B * D.NI * 8);
   D.rs.alloc(B * 16);
-  D.err.alloc(B);
-  D.coords.alloc(B * 64);
-  D.values.alloc(B * 40);
-  D.comp.alloc(B * 128);
-  D.V.alloc((size_t)D.N * B);
-  D.abc.alloc(3 * (size_t)D.n * B);
-  D.digits.alloc((size_t)(D.NS + D.n + 3) * W_ * B);
-  D.part1.alloc((size_t)D.nchunks1 * B);
-  D.sums1.alloc(3 * B);
-  D.part2.alloc((size_t)D.nchunks2 * B);
-  D.sums2.alloc(B);
   RLN_HIP(hipMemsetAsync(D.inputs.p, 0, D.inputs.bytes(), s));
   RLN_HIP(hipMemsetAsync(D.rs.p, 0, D.rs.bytes(), s));
-  RLN_HIP(hipMemsetAsync(D.digits.p, 0, D.digits.bytes(), s));
+  for (Slot& S : D.slot) {
+    S.err.alloc(B);
+    S.coords.alloc(B * 64);
+    S.values.alloc(B * 40);
+    S.comp.alloc(B * 128);
+    S.V.alloc((size_t)D.N * B);
+    S.abc.alloc(3 * (size_t)D.n * B);
+    S.digits.alloc((size_t)(D.NS + D.n + 3) * W_ * B);
+    S.part1.alloc((size_t)D.nchunks1 * B);
+    S.grp1.alloc((size_t)D.ngroups1 * B);
+    S.sums1.alloc(3 * B);
+    S.part2.alloc((size_t)D.nchunks2 * B);
+    S.grp2.alloc((size_t)D.ngroups2 * B);
+    S.sums2.alloc(B);
+    S.prod.alloc(2 * B);
+    S.tbl.alloc(2 * 16 * B);
+    S.affA.alloc(B);
+    S.affB1.alloc(B);
+    S.affB2.alloc(B);
+    RLN_HIP(hipHostMalloc((void**)&S.h_comp, B * 128, hipHostMallocDefault));
+    RLN_HIP(hipHostMalloc((void**)&S.h_values, B * 160, hipHostMallocDefault));
+    RLN_HIP(hipHostMalloc((void**)&S.h_err, B * 4, hipHostMallocDefault));
+    RLN_HIP(hipEventCreateWithFlags(&S.evA, hipEventDisableTiming));
+    RLN_HIP(hipEventCreateWithFlags(&S.evB, hipEventDisableTiming));
+    RLN_HIP(hipEventCreateWithFlags(&S.evC, hipEventDisableTiming));
+    for (auto& e : S.t) RLN_HIP(hipEventCreate(&e));
+    RLN_HIP(hipMemsetAsync(S.digits.p, 0, S.digits.bytes(), s));
+  }
   RLN_HIP(hipStreamSynchronize(s));
 }
 
 Prover::~Prover() {
   if (!d_) return;
   Impl& D = *d_;
-  if (D.stream) (void)hipStreamSynchronize(D.stream);
-  if (D.stream2) (void)hipStreamSynchronize(D.stream2);
-  for (auto& e : D.ev) (void)hipEventDestroy(e);
-  (void)hipEventDestroy(D.ev_fork);
-  (void)hipEventDestroy(D.ev_join);
-  if (D.stream) (void)hipStreamDestroy(D.stream);
-  if (D.stream2) (void)hipStreamDestroy(D.stream2);
+  for (hipStream_t st : {D.sA, D.sB, D.sC})
+    if (st) (void)hipStreamSynchronize(st);
+  for (Slot& S : D.slot) {
+    if (S.h_comp) (void)hipHostFree(S.h_comp);
+    if (S.h_values) (void)hipHostFree(S.h_values);
+    if (S.h_err) (void)hipHostFree(S.h_err);
+    for (hipEvent_t e : {S.evA, S.evB, S.evC})
+      if (e) (void)hipEventDestroy(e);
+    for (auto& e : S.t) (void)hipEventDestroy(e);
+  }
+  for (hipStream_t st : {D.sA, D.sB, D.sC})
+    if (st) (void)hipStreamDestroy(st);
 }
 
 size_t Prover::table_bytes() const { return d_->t1.bytes() + d_->t2.bytes(); }
@@ -867,9 +983,10 @@ size_t Prover::table_bytes() const { return d_->t1.bytes() + d_->t2.bytes(); }
 void Prover::upload(size_t n, const uint8_t* inputs, const uint8_t* rs) {
   if (n > B_) throw Error("batch larger than the prover workspace (max_batch)");
   Impl& D = *d_;
-  RLN_HIP(hipMemcpyAsync(D.inputs.p, inputs, n * D.NI * 32, hipMemcpyHostToDevice, D.stream));
-  RLN_HIP(hipMemcpyAsync(D.rs.p, rs, n * 64, hipMemcpyHostToDevice, D.stream));
-  RLN_HIP(hipStreamSynchronize(D.stream));
+  D.sync_all();  // in-flight batches still read the resident inputs
+  RLN_HIP(hipMemcpyAsync(D.inputs.p, inputs, n * D.NI * 32, hipMemcpyHostToDevice, D.sA));
+  RLN_HIP(hipMemcpyAsync(D.rs.p, rs, n * 64, hipMemcpyHostToDevice, D.sA));
+  RLN_HIP(hipStreamSynchronize(D.sA));
 }
 
 template <bool DIF>
@@ -893,61 +1010,95 @@ static void launch_ntt(Fr* data, const Fr* tw, int logn, const Fr* final_scale, 
   }
 }
 
-void Prover::run(size_t n) {
+// Enqueue one batch; returns as soon as the work is queued.  Stage A (stream sA): proof values, witness,
+// matvec, NTTs.  Stage B (sB): digit recoding and the two MSMs.  Stage C (sC): two-level reduction, the
+// three finalize kernels, D2H of proofs + values into pinned memory.  Consecutive batches alternate slots.
+void Prover::run_async(size_t n) {
   if (n == 0) return;
   if (n > B_) throw Error("batch larger than the prover workspace (max_batch)");
   Impl& D = *d_;
-  hipStream_t s = D.stream;
+  Slot& S = D.slot[D.cur];
+  D.cur ^= 1;
   const uint32_t B = (uint32_t)B_, nb = (uint32_t)n;
   const uint32_t pg = div_up(nb, 64);
-  const uint32_t nbp = pg * 64;  // padded lanes compute on zeroed inputs; results ignored
-  int st = 0;
-  RLN_HIP(hipEventRecord(D.ev[st++], s));
-  // values (Poseidon formulae) run beside the main pipeline on the second stream
-  RLN_HIP(hipEventRecord(D.ev_fork, s));
-  RLN_HIP(hipStreamWaitEvent(D.stream2, D.ev_fork, 0));
-  hipLaunchKernelGGL(k_proof_values, dim3(pg), dim3(64), 0, D.stream2, D.inputs.p, D.NI, D.slots, poseidon_view(2),
-                     poseidon_view(3), poseidon_view(4), D.values.p, nbp);
-  RLN_HIP(hipEventRecord(D.ev_join, D.stream2));
-
-  hipLaunchKernelGGL(k_witness, dim3(pg), dim3(64), 0, s, D.nodes.p, D.N, D.consts.p, D.inputs.p, D.NI, D.V.p,
-                     D.err.p, B, nbp);
-  RLN_HIP(hipEventRecord(D.ev[st++], s));
+  const uint32_t nbp = pg * 64;  // padded lanes compute on stale / zero inputs; results ignored
+  // ---------------- stage A
+  if (S.used) RLN_HIP(hipStreamWaitEvent(D.sA, S.evC, 0));  // slot free again
+  RLN_HIP(hipEventRecord(S.t[0], D.sA));
+  hipLaunchKernelGGL(k_proof_values, dim3(pg), dim3(64), 0, D.sA, D.inputs.p, D.NI, D.slots, poseidon_view(2),
+                     poseidon_view(3), poseidon_view(4), S.values.p, nbp);
+  RLN_HIP(hipEventRecord(S.t[1], D.sA));
+  hipLaunchKernelGGL(k_witness, dim3(pg), dim3(64), 0, D.sA, D.nodes.p, D.N, D.consts.p, D.inputs.p, D.NI, S.V.p,
+                     S.err.p, B, nbp);
+  RLN_HIP(hipEventRecord(S.t[2], D.sA));
   {
     CsrView A{D.a_ptr.p, D.a_col.p, D.a_coef.p}, Bm{D.b_ptr.p, D.b_col.p, D.b_coef.p};
-    hipLaunchKernelGGL(k_matvec, dim3(pg, div_up(D.n, 4)), dim3(64, 4), 0, s, A, Bm, D.V.p, D.sig2node.p, D.nc, D.ni,
-                       D.n, D.abc.p, B, nbp);
+    hipLaunchKernelGGL(k_matvec, dim3(pg, div_up(D.n, 4)), dim3(64, 4), 0, D.sA, A, Bm, S.V.p, D.sig2node.p, D.nc,
+                       D.ni, D.n, S.abc.p, B, nbp);
   }
-  RLN_HIP(hipEventRecord(D.ev[st++], s));
-  launch_ntt<true>(D.abc.p, D.tw_i.p, D.logn, D.coset.p, B, nbp, s);   // iNTT (DIF) + g^i / n
-  launch_ntt<false>(D.abc.p, D.tw_f.p, D.logn, nullptr, B, nbp, s);    // NTT (DIT)
-  hipLaunchKernelGGL(k_hquot, dim3(pg, div_up(D.n, 4)), dim3(64, 4), 0, s, D.abc.p, D.n, B, nbp);
-  RLN_HIP(hipEventRecord(D.ev[st++], s));
-  hipLaunchKernelGGL(k_recode, dim3(pg, div_up(D.NS + D.n + 3, 4)), dim3(64, 4), 0, s, D.V.p, D.sig2node.p, D.NS,
-                     D.abc.p, D.n, D.rs.p, c_, W_, D.digits.p, B, nbp);
-  RLN_HIP(hipEventRecord(D.ev[st++], s));
+  RLN_HIP(hipEventRecord(S.t[3], D.sA));
+  launch_ntt<true>(S.abc.p, D.tw_i.p, D.logn, D.coset.p, B, nbp, D.sA);  // iNTT (DIF) + g^i / n
+  launch_ntt<false>(S.abc.p, D.tw_f.p, D.logn, nullptr, B, nbp, D.sA);   // NTT (DIT)
+  hipLaunchKernelGGL(k_hquot, dim3(pg, div_up(D.n, 4)), dim3(64, 4), 0, D.sA, S.abc.p, D.n, B, nbp);
+  RLN_HIP(hipEventRecord(S.t[4], D.sA));
+  RLN_HIP(hipEventRecord(S.evA, D.sA));
+  // ---------------- stage B
+  RLN_HIP(hipStreamWaitEvent(D.sB, S.evA, 0));
+  RLN_HIP(hipEventRecord(S.t[5], D.sB));
+  hipLaunchKernelGGL(k_recode, dim3(pg, div_up(D.NS + D.n + 3, 4)), dim3(64, 4), 0, D.sB, S.V.p, D.sig2node.p, D.NS,
+                     S.abc.p, D.n, D.rs.p, c_, W_, S.digits.p, B, nbp);
+  RLN_HIP(hipEventRecord(S.t[6], D.sB));
   {
     uint32_t blocks = div_up(D.nchunks1, 8) * 8 * pg;
-    hipLaunchKernelGGL(k_msm<Fq>, dim3(blocks), dim3(64), 0, s, D.t1.p, D.sid1.p, D.chunks1.p, D.nchunks1,
-                       D.digits.p, D.part1.p, c_, W_, B, pg);
+    hipLaunchKernelGGL(k_msm<Fq>, dim3(blocks), dim3(64), 0, D.sB, D.t1.p, D.sid1.p, D.chunks1.p, D.nchunks1,
+                       S.digits.p, S.part1.p, c_, W_, B, pg);
   }
-  RLN_HIP(hipEventRecord(D.ev[st++], s));
+  RLN_HIP(hipEventRecord(S.t[7], D.sB));
   {
     uint32_t blocks = div_up(D.nchunks2, 8) * 8 * pg;
-    hipLaunchKernelGGL(k_msm<Fq2>, dim3(blocks), dim3(64), 0, s, D.t2.p, D.sid2.p, D.chunks2.p, D.nchunks2,
-                       D.digits.p, D.part2.p, c_, W_, B, pg);
+    hipLaunchKernelGGL(k_msm<Fq2>, dim3(blocks), dim3(64), 0, D.sB, D.t2.p, D.sid2.p, D.chunks2.p, D.nchunks2,
+                       S.digits.p, S.part2.p, c_, W_, B, pg);
   }
-  RLN_HIP(hipEventRecord(D.ev[st++], s));
-  hipLaunchKernelGGL(k_msm_reduce<Fq>, dim3(pg, 3), dim3(64), 0, s, D.part1.p, D.segfirst1.p, 3u, D.sums1.p, B, nbp);
-  hipLaunchKernelGGL(k_msm_reduce<Fq2>, dim3(pg, 1), dim3(64), 0, s, D.part2.p, D.segfirst2.p, 1u, D.sums2.p, B, nbp);
-  hipLaunchKernelGGL(k_finalize, dim3(pg), dim3(64), 0, s, D.sums1.p, D.sums2.p, D.rs.p, D.coords.p, D.comp.p, B, nbp);
+  RLN_HIP(hipEventRecord(S.t[8], D.sB));
+  RLN_HIP(hipEventRecord(S.evB, D.sB));
+  // ---------------- stage C
+  RLN_HIP(hipStreamWaitEvent(D.sC, S.evB, 0));
+  RLN_HIP(hipEventRecord(S.t[9], D.sC));
+  hipLaunchKernelGGL(k_sum_ranges<Fq>, dim3(pg, D.ngroups1), dim3(64), 0, D.sC, S.part1.p, D.groups1.p, D.ngroups1,
+                     S.grp1.p, B, nbp);
+  hipLaunchKernelGGL(k_sum_ranges<Fq2>, dim3(pg, D.ngroups2), dim3(64), 0, D.sC, S.part2.p, D.groups2.p, D.ngroups2,
+                     S.grp2.p, B, nbp);
+  hipLaunchKernelGGL(k_sum_ranges<Fq>, dim3(pg, 3), dim3(64), 0, D.sC, S.grp1.p, D.segs1.p, 3u, S.sums1.p, B, nbp);
+  hipLaunchKernelGGL(k_sum_ranges<Fq2>, dim3(pg, 1), dim3(64), 0, D.sC, S.grp2.p, D.segs2.p, 1u, S.sums2.p, B, nbp);
+  hipLaunchKernelGGL(k_fin_affine, dim3(pg, 3), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
+                     S.affB2.p, B, nbp);
+  hipLaunchKernelGGL(k_fin_smul, dim3(pg, 2), dim3(64), 0, D.sC, S.affA.p, S.affB1.p, D.rs.p, S.tbl.p, S.prod.p, B, nbp);
+  hipLaunchKernelGGL(k_fin_out, dim3(pg), dim3(64), 0, D.sC, S.sums1.p, S.prod.p, S.affA.p, S.affB2.p, S.coords.p,
+                     S.comp.p, B, nbp);
   RLN_HIP(hipGetLastError());
-  RLN_HIP(hipEventRecord(D.ev[st++], s));
-  RLN_HIP(hipStreamWaitEvent(s, D.ev_join, 0));
-  RLN_HIP(hipEventRecord(D.ev[st++], s));
-  RLN_HIP(hipStreamSynchronize(s));
-  for (int i = 0; i < PROVER_STAGES; i++) RLN_HIP(hipEventElapsedTime(&D.ms[i], D.ev[i], D.ev[i + 1]));
-  D.have_run = true;
+  RLN_HIP(hipMemcpyAsync(S.h_comp, S.comp.p, n * 128, hipMemcpyDeviceToHost, D.sC));
+  RLN_HIP(hipMemcpyAsync(S.h_values, S.values.p, n * 160, hipMemcpyDeviceToHost, D.sC));
+  RLN_HIP(hipMemcpyAsync(S.h_err, S.err.p, n * 4, hipMemcpyDeviceToHost, D.sC));
+  RLN_HIP(hipEventRecord(S.t[10], D.sC));
+  RLN_HIP(hipEventRecord(S.evC, D.sC));
+  S.used = true;
+  S.n = n;
+  D.last = &S;
+}
+
+void Prover::sync() {
+  Impl& D = *d_;
+  D.sync_all();
+  if (D.last) {
+    Slot& S = *D.last;
+    const int pairs[PROVER_STAGES][2] = {{1, 2}, {2, 3}, {3, 4}, {5, 6}, {6, 7}, {7, 8}, {9, 10}, {0, 1}};
+    for (int i = 0; i < PROVER_STAGES; i++) RLN_HIP(hipEventElapsedTime(&D.ms[i], S.t[pairs[i][0]], S.t[pairs[i][1]]));
+  }
+}
+
+void Prover::run(size_t n) {
+  run_async(n);
+  sync();
 }
 
 void Prover::stage_ms(float out[PROVER_STAGES]) const {
@@ -957,41 +1108,42 @@ void Prover::stage_ms(float out[PROVER_STAGES]) const {
 void Prover::download(size_t n, ProofOut* out) {
   if (n > B_) throw Error("batch larger than the prover workspace (max_batch)");
   Impl& D = *d_;
-  std::vector<uint8_t> comp(n * 128);
-  std::vector<uint32_t> coords(n * 64), values(n * 40), err(n);
-  RLN_HIP(hipMemcpyAsync(comp.data(), D.comp.p, n * 128, hipMemcpyDeviceToHost, D.stream));
-  RLN_HIP(hipMemcpyAsync(coords.data(), D.coords.p, n * 256, hipMemcpyDeviceToHost, D.stream));
-  RLN_HIP(hipMemcpyAsync(values.data(), D.values.p, n * 160, hipMemcpyDeviceToHost, D.stream));
-  RLN_HIP(hipMemcpyAsync(err.data(), D.err.p, n * 4, hipMemcpyDeviceToHost, D.stream));
-  RLN_HIP(hipStreamSynchronize(D.stream));
+  sync();
+  if (!D.last) throw Error("no resident run to read from");
+  Slot& S = *D.last;
+  std::vector<uint32_t> coords(n * 64);
+  RLN_HIP(hipMemcpyAsync(coords.data(), S.coords.p, n * 256, hipMemcpyDeviceToHost, D.sC));
+  RLN_HIP(hipStreamSynchronize(D.sC));
   for (size_t i = 0; i < n; i++) {
-    memcpy(out[i].compressed, comp.data() + i * 128, 128);
+    memcpy(out[i].compressed, S.h_comp + i * 128, 128);
     memcpy(out[i].coords, coords.data() + i * 64, 256);
-    memcpy(out[i].values, values.data() + i * 40, 160);
-    out[i].error = err[i];
+    memcpy(out[i].values, S.h_values + i * 40, 160);
+    out[i].error = S.h_err[i];
   }
 }
 
 void Prover::fetch_witness(size_t p, std::vector<uint8_t>* w_le) {
   Impl& D = *d_;
-  if (!D.have_run || p >= B_) throw Error("no resident run to read from");
+  sync();
+  if (!D.last || p >= B_) throw Error("no resident run to read from");
   DevBuf<uint32_t> tmp((size_t)D.NS * 8);
-  hipLaunchKernelGGL(k_gather_col, dim3(div_up(D.NS, 256)), dim3(256), 0, D.stream, D.V.p, D.sig2node.p, D.NS,
+  hipLaunchKernelGGL(k_gather_col, dim3(div_up(D.NS, 256)), dim3(256), 0, D.sC, D.last->V.p, D.sig2node.p, D.NS,
                      (uint32_t)B_, (uint32_t)p, tmp.p);
   w_le->resize((size_t)D.NS * 32);
-  RLN_HIP(hipMemcpyAsync(w_le->data(), tmp.p, w_le->size(), hipMemcpyDeviceToHost, D.stream));
-  RLN_HIP(hipStreamSynchronize(D.stream));
+  RLN_HIP(hipMemcpyAsync(w_le->data(), tmp.p, w_le->size(), hipMemcpyDeviceToHost, D.sC));
+  RLN_HIP(hipStreamSynchronize(D.sC));
 }
 
 void Prover::fetch_h(size_t p, std::vector<uint8_t>* h_le) {
   Impl& D = *d_;
-  if (!D.have_run || p >= B_) throw Error("no resident run to read from");
+  sync();
+  if (!D.last || p >= B_) throw Error("no resident run to read from");
   DevBuf<uint32_t> tmp((size_t)D.n * 8);
-  hipLaunchKernelGGL(k_gather_col, dim3(div_up(D.n, 256)), dim3(256), 0, D.stream, D.abc.p, (const uint32_t*)nullptr,
+  hipLaunchKernelGGL(k_gather_col, dim3(div_up(D.n, 256)), dim3(256), 0, D.sC, D.last->abc.p, (const uint32_t*)nullptr,
                      D.n, (uint32_t)B_, (uint32_t)p, tmp.p);
   h_le->resize((size_t)D.n * 32);
-  RLN_HIP(hipMemcpyAsync(h_le->data(), tmp.p, h_le->size(), hipMemcpyDeviceToHost, D.stream));
-  RLN_HIP(hipStreamSynchronize(D.stream));
+  RLN_HIP(hipMemcpyAsync(h_le->data(), tmp.p, h_le->size(), hipMemcpyDeviceToHost, D.sC));
+  RLN_HIP(hipStreamSynchronize(D.sC));
 }
 
 }  // namespace rlnamd
