@@ -143,6 +143,13 @@ def main():
         value = proofs / elapsed
         msm_ms = stage_ms.get("msm_g1", 0.0)
         achieved = (MSM_G1_BYTES_PER_PROOF * B) / (msm_ms * 1e-3) / 1e9 if msm_ms > 0 else 0.0
+        traffic = None   # HBM bytes per launch of the dominant kernel, from the committed PMC passes
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_k_msm_g1.json")))
+            if B == 1024 and int(prover.info.window_bits) == 13:
+                traffic = round(pm["traffic_bytes_per_launch"] / 1e9, 3)
+        except Exception:  # noqa: BLE001
+            pass
         line = {
             "metric": "RLN Groth16 proofs/sec (BN254, h=20)",
             "value": round(value, 2),
@@ -165,8 +172,11 @@ def main():
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "kernel": "k_msm<Fq> (G1 fixed-base table MSM)",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
-                         "note": "integer-ALU bound (256-bit modular multiply); see DESIGN.md"},
+                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
+                         "traffic_unit": "GB per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r1_pmc_k_msm_g1.json)",
+                         "launch_ms": round(msm_ms, 3),
+                         "note": "integer-ALU bound (256-bit modular multiply): 11 G mixed-add/s ~ 91% of the "
+                                 "measured 135 G Fq-mul/s multiplier ceiling; see DESIGN.md section 4"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ws, rs)

@@ -1024,9 +1024,6 @@ void Prover::run_async(size_t n) {
   const uint32_t nbp = pg * 64;  // padded lanes compute on stale / zero inputs; results ignored
   // ---------------- stage A
   if (S.used) RLN_HIP(hipStreamWaitEvent(D.sA, S.evC, 0));  // slot free again
-  RLN_HIP(hipEventRecord(S.t[0], D.sA));
-  hipLaunchKernelGGL(k_proof_values, dim3(pg), dim3(64), 0, D.sA, D.inputs.p, D.NI, D.slots, poseidon_view(2),
-                     poseidon_view(3), poseidon_view(4), S.values.p, nbp);
   RLN_HIP(hipEventRecord(S.t[1], D.sA));
   hipLaunchKernelGGL(k_witness, dim3(pg), dim3(64), 0, D.sA, D.nodes.p, D.N, D.consts.p, D.inputs.p, D.NI, S.V.p,
                      S.err.p, B, nbp);
@@ -1062,6 +1059,11 @@ void Prover::run_async(size_t n) {
   RLN_HIP(hipEventRecord(S.t[8], D.sB));
   RLN_HIP(hipEventRecord(S.evB, D.sB));
   // ---------------- stage C
+  // proof values (Poseidon chain, latency-bound, depends on the inputs only): the back-end stream has slack
+  if (S.used) RLN_HIP(hipStreamWaitEvent(D.sC, S.evC, 0));
+  RLN_HIP(hipEventRecord(S.t[0], D.sC));
+  hipLaunchKernelGGL(k_proof_values, dim3(pg), dim3(64), 0, D.sC, D.inputs.p, D.NI, D.slots, poseidon_view(2),
+                     poseidon_view(3), poseidon_view(4), S.values.p, nbp);
   RLN_HIP(hipStreamWaitEvent(D.sC, S.evB, 0));
   RLN_HIP(hipEventRecord(S.t[9], D.sC));
   hipLaunchKernelGGL(k_sum_ranges<Fq>, dim3(pg, D.ngroups1), dim3(64), 0, D.sC, S.part1.p, D.groups1.p, D.ngroups1,
@@ -1091,7 +1093,7 @@ void Prover::sync() {
   D.sync_all();
   if (D.last) {
     Slot& S = *D.last;
-    const int pairs[PROVER_STAGES][2] = {{1, 2}, {2, 3}, {3, 4}, {5, 6}, {6, 7}, {7, 8}, {9, 10}, {0, 1}};
+    const int pairs[PROVER_STAGES][2] = {{1, 2}, {2, 3}, {3, 4}, {5, 6}, {6, 7}, {7, 8}, {9, 10}, {0, 9}};
     for (int i = 0; i < PROVER_STAGES; i++) RLN_HIP(hipEventElapsedTime(&D.ms[i], S.t[pairs[i][0]], S.t[pairs[i][1]]));
   }
 }
