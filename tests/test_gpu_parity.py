@@ -125,6 +125,30 @@ def test_tree_config3_small_and_checksum():
         assert dev.proof(i) == ref.proof(i)
 
 
+def test_tree_config3_full_size_properties():
+    """BASELINE config 3 at full size (2^20 leaves i+1, 2^20 paths): every emitted path recomputes the root on
+    the device (compute_root_from, full_merkle_tree.rs:441-446); root equals the C oracle's; sampled paths
+    equal a host recomputation from the oracle's Poseidon; an update of one leaf moves exactly its path."""
+    from oracle.c import binding as ob
+    from zerokit_amd.batch import PoseidonTree
+    depth = 20
+    t = PoseidonTree(depth)
+    res = t.bench(1 << depth, first_value=1, verify=True)
+    assert res["bad"] == 0
+    root = t.root()
+    assert root == ob.tree_root(depth, list(range(1, (1 << depth) + 1)))
+    for leaf in (0, 1, 524287, 524288, (1 << depth) - 1):
+        elems, bits = t.proof(leaf)
+        assert bits == [(leaf >> k) & 1 for k in range(depth)]
+        h = leaf + 1
+        for e, b in zip(elems, bits):
+            h = ob.poseidon_batch([[e, h] if b else [h, e]])[0]
+        assert h == root
+    before = t.proof(12345)
+    t.set(777777, 42)
+    assert t.root() != root and t.proof(12345)[0][:5] == before[0][:5] and t.get(777777) == 42
+
+
 # ------------------------------------------------------------------------------------------ prover
 def test_witness_and_h_vs_golden(prover):
     cases = _cases()["cases"]

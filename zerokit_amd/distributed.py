@@ -1,0 +1,56 @@
+"""Multi-GPU sharding for the proving path: independent proofs shard by index, one process per
+GPU, every rank holds a full replica of the fixed-base tables, no data-path collective.  The only exchange is
+returning the 128-byte proofs + public values to the caller, done here with one all_gather over
+torch.distributed (backend "nccl" == RCCL on the GPU box, "gloo" in the CPU tests)."""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, world):
+    """contiguous shards, sizes differ by at most one: [(lo, hi)] * world (BASELINE config 4: 65 536 -> 8 x 8 192)"""
+    base, extra = divmod(n, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def prove_sharded(prove_fn, witnesses, rs, group=None, device="cpu"):
+    """Every rank calls this with the FULL witness list; rank r proves witnesses[lo_r:hi_r] with
+    prove_fn(ws, rs) -> list of dict(proof=128 bytes, public_inputs=[5 ints]) and all ranks receive the
+    complete, index-ordered result list."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    bounds = shard_bounds(len(witnesses), world)
+    lo, hi = bounds[rank]
+    local = prove_fn(witnesses[lo:hi], rs[lo:hi]) if hi > lo else []
+    if world == 1:
+        return local
+    width = max(h - l for l, h in bounds)
+    rec = 128 + 5 * 32
+    buf = torch.zeros((width, rec), dtype=torch.uint8)
+    for i, o in enumerate(local):
+        row = o["proof"] + b"".join(int(v).to_bytes(32, "little") for v in o["public_inputs"])
+        buf[i] = torch.frombuffer(bytearray(row), dtype=torch.uint8)
+    buf = buf.to(device)
+    gathered = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(gathered, buf, group=group)
+    out = []
+    for r, (l, h) in enumerate(bounds):
+        g = gathered[r].cpu().numpy()
+        for i in range(h - l):
+            row = g[i].tobytes()
+            out.append(dict(proof=row[:128],
+                            public_inputs=[int.from_bytes(row[128 + 32 * k:160 + 32 * k], "little") for k in range(5)]))
+    return out
+
+
+def max_over_ranks(seconds, device="cpu", group=None):
+    """the bench's timing rule: the step time of the job is the slowest rank's"""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
