@@ -100,6 +100,56 @@ def merkle_main(args):
                            "unit": "GB/s", "frac": round(path_bytes / (p * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}}))
 
 
+def msm_main(args):
+    """BASELINE config 5: one 2^24-point G1 MSM split by point index over the ranks (1 rank = whole MSM on one
+    GPU), one RCCL all_gather of the per-window sums, local fold.  Side measurement, one JSON line on rank 0."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    from zerokit_amd import lib
+    from zerokit_amd._native import check
+    from zerokit_amd.batch import MsmG1
+    from zerokit_amd.distributed import all_gather_bytes, shard_bounds
+    check(lib().rlnamd_set_device(local_rank))
+    n_total = 1 << int(os.environ.get("RLNAMD_MSM_LOG2", "24"))
+    lo, hi = shard_bounds(n_total, world)[rank]
+    m = MsmG1(hi - lo)
+    m.generate(0xC0FFEE, lo, hi - lo)          # bases + scalars resident in HBM, not timed
+    times, stage = [], {}
+    for it in range(args.warmup + max(args.steps, 1)):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        blob, stage = m.run_windows()
+        blobs = all_gather_bytes(blob, device="cuda")
+        res = m.combine(blobs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if it >= args.warmup:
+            times.append(dt)
+    if rank == 0:
+        ok = res == MsmG1.expected(0xC0FFEE, 0, n_total)
+        ms = sum(times) / len(times) * 1e3
+        gbps = n_total * 96 / (ms * 1e-3) / 1e9
+        print(json.dumps({"metric": "single 2^%d-point BN254 G1 MSM (config 5)" % (n_total.bit_length() - 1),
+                          "ms": round(ms, 3), "n_gpus": world, "correct": bool(ok), "stage_ms_rank0": stage,
+                          "roofline": {"bound": "hbm", "achieved": round(gbps, 2), "peak": HBM_PEAK_GBPS * world,
+                                       "unit": "GB/s", "frac": round(gbps / (HBM_PEAK_GBPS * world), 5)}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,11 +157,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("RLNAMD_BENCH_BATCH", "1024")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="proofs", choices=["proofs", "merkle"],
+    ap.add_argument("--workload", default="proofs", choices=["proofs", "merkle", "msm"],
                     help="proofs = BASELINE metric (default); merkle = config 3 side measurement (not the bench line)")
     args = ap.parse_args()
     if args.workload == "merkle":
         return merkle_main(args)
+    if args.workload == "msm":
+        return msm_main(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

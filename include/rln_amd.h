@@ -111,6 +111,25 @@ int rlnamd_parse_resources(const uint8_t* zkey, size_t zkey_len, const uint8_t* 
 int rlnamd_proof_compress(const uint8_t coords_le[256], uint8_t proof[128]);
 int rlnamd_proof_decompress(const uint8_t proof[128], uint8_t coords_le[256]);
 
+/* ---- variable-base G1 MSM (BASELINE config 5) ------------------------------------------------------------
+ * Replaces VariableBaseMSM::msm_bigint (ark-ec 0.5.0; call sites rln/src/partial_proof.rs:98-104,255-256)
+ * for large n with bases that are not fixed.  Multi-GPU: every rank runs rlnamd_msm_run on its slice of the
+ * points, the window sums (rlnamd_msm_window_sums_bytes() bytes per rank) are all-gathered, and
+ * rlnamd_msm_combine adds them and folds the windows. */
+typedef struct rlnamd_msm rlnamd_msm;
+int rlnamd_msm_new(size_t capacity, rlnamd_msm** out);
+void rlnamd_msm_free(rlnamd_msm* m);
+/* points: n x (x || y) canonical LE affine, all-zero = infinity; scalars: n x 32 bytes canonical LE */
+int rlnamd_msm_set(rlnamd_msm* m, const uint8_t* points_xy_le, const uint8_t* scalars_le, size_t n);
+/* synthetic config-5 workload generated in HBM: P_i = k_i G, scalars s_i, SplitMix64(seed) at index first+i */
+int rlnamd_msm_generate(rlnamd_msm* m, uint64_t seed, uint64_t first_index, size_t n);
+/* its closed form (sum k_i s_i mod r) G, host side, scalar arithmetic only */
+int rlnamd_msm_expected(uint64_t seed, uint64_t first_index, size_t n, uint8_t out_xy_le[64]);
+size_t rlnamd_msm_window_sums_bytes(void);
+/* ms[0] digits + counting sort, ms[1] bucket accumulation, ms[2] bucket reduction */
+int rlnamd_msm_run(rlnamd_msm* m, uint8_t* window_sums, float ms[3]);
+int rlnamd_msm_combine(rlnamd_msm* m, const uint8_t* window_sums, size_t contributors, uint8_t out_xy_le[64]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,3 +64,47 @@ def test_two_rank_sharded_proving_matches_single_process():
     _, ref_proofs, ref_pub = ob.Circuit(20).prove_many(ws, rs, threads=4)
     assert proofs == ref_proofs and pubs == ref_pub
     assert slowest == 2.0
+
+
+class _FakeMsm:
+    """stands in for MsmG1 on CPU: 'window sums' are 16 integers (sum of k_i s_i digits would be EC points on
+    the GPU); combine is the same add-then-Horner fold, over the integers"""
+
+    def generate(self, seed, first, n):
+        self.vals = [(seed + first + i) % 1009 for i in range(n)]
+
+    def run_windows(self):
+        w = [sum(v >> (3 * k) & 7 for v in self.vals) for k in range(16)]
+        return b"".join(x.to_bytes(8, "little") for x in w), {}
+
+    def combine(self, blobs):
+        tot = 0
+        for k in reversed(range(16)):
+            tot = tot * 8 + sum(int.from_bytes(b[8 * k:8 * k + 8], "little") for b in blobs)
+        return tot
+
+
+def _msm_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from zerokit_amd.distributed import msm_sharded
+    res, _ = msm_sharded(_FakeMsm(), 5, 1000)
+    if rank == 1:
+        q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_msm_gather_and_fold():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_msm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == sum((5 + i) % 1009 for i in range(1000))

@@ -263,3 +263,45 @@ def test_ffi_round_trip_like_reference_tests():
     a.delete_leaf(500)                                    # >= next_index: no-op
     a.set_tree(20)
     assert a.get_root() == RLN(20).get_root() and a.leaves_set() == 0
+
+
+# ------------------------------------------------------------------------------------------ variable-base MSM
+def test_msm_g1_vs_oracle_small_and_edge_cases():
+    """msm_bigint semantics on small inputs: random points/scalars vs the Python oracle, plus the edge cases
+    (empty, zero scalars, infinity bases, repeated and opposite points, maximal scalar)."""
+    from oracle.pyref.bn254 import G1, G1_GEN
+    from zerokit_amd.batch import MsmG1
+    rnd = random.Random(21)
+    m = MsmG1(4096)
+    pts = [G1.mul(G1_GEN, rnd.randrange(1, R)) for _ in range(40)]
+    sc = [rnd.randrange(R) for _ in range(40)]
+    assert m.msm(pts, sc) == G1.msm_naive(pts, sc)
+    assert m.msm([], []) is None
+    assert m.msm(pts[:3], [0, 0, 0]) is None
+    assert m.msm([None, pts[0]], [5, 7]) == G1.mul(pts[0], 7)
+    assert m.msm([pts[0]] * 5, [1, 2, 3, 4, 5]) == G1.mul(pts[0], 15)
+    assert m.msm([pts[0], G1.neg(pts[0])], [9, 9]) is None
+    assert m.msm([pts[1]], [R - 1]) == G1.neg(pts[1])
+    assert m.msm([pts[2], pts[3]], [0x8000, 0xFFFF8000FFFF]) == G1.msm_naive([pts[2], pts[3]], [0x8000, 0xFFFF8000FFFF])
+    big = [pts[i % 40] for i in range(3000)]
+    bsc = [rnd.randrange(R) for _ in range(3000)]
+    assert m.msm(big, bsc) == G1.msm(big, bsc, c=8)
+
+
+def test_msm_g1_generated_closed_form_and_split():
+    """config-5 workload at 2^16 points: result equals the scalar-side closed form (sum k_i s_i) G; splitting
+    the points into 4 slices (the per-GPU shards) and combining their window sums gives the same point
+    (linearity), as the 8-GPU all-gather does."""
+    from zerokit_amd.batch import MsmG1
+    n, seed = 1 << 16, 0xC0FFEE
+    m = MsmG1(n)
+    m.generate(seed, 0, n)
+    blob, ms = m.run_windows()
+    want = MsmG1.expected(seed, 0, n)
+    assert m.combine([blob]) == want
+    blobs = []
+    q = n // 4
+    for r in range(4):
+        m.generate(seed, r * q, q)
+        blobs.append(m.run_windows()[0])
+    assert m.combine(blobs) == want

@@ -97,6 +97,14 @@ SIGNATURES = {
     "rlnamd_parse_resources": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "rlnamd_proof_compress": (C.c_int, [C.c_char_p, C.c_char_p]),
     "rlnamd_proof_decompress": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "rlnamd_msm_new": (C.c_int, [C.c_size_t, PP]),
+    "rlnamd_msm_free": (None, [P]),
+    "rlnamd_msm_set": (C.c_int, [P, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "rlnamd_msm_generate": (C.c_int, [P, C.c_uint64, C.c_uint64, C.c_size_t]),
+    "rlnamd_msm_expected": (C.c_int, [C.c_uint64, C.c_uint64, C.c_size_t, C.c_char_p]),
+    "rlnamd_msm_window_sums_bytes": (C.c_size_t, []),
+    "rlnamd_msm_run": (C.c_int, [P, C.c_char_p, C.POINTER(C.c_float)]),
+    "rlnamd_msm_combine": (C.c_int, [P, C.c_char_p, C.c_size_t, C.c_char_p]),
     # ---- rln.h
     "ffi_rln_new": (CResultPtr, [C.c_size_t, C.c_char_p]),
     "ffi_rln_new_with_params": (CResultPtr, [C.c_size_t, C.POINTER(VecU8), C.POINTER(VecU8), C.c_char_p]),

@@ -197,3 +197,55 @@ class PoseidonTree:
         bad = C.c_size_t()
         check(lib().rlnamd_tree_bench(self._h, n_leaves, first_value, 1 if verify else 0, ms, C.byref(bad)))
         return dict(build_ms=float(ms[0]), proofs_ms=float(ms[1]), bad=int(bad.value))
+
+
+class MsmG1:
+    """Variable-base G1 MSM (VariableBaseMSM::msm_bigint, ark-ec 0.5.0; BASELINE config 5)."""
+
+    def __init__(self, capacity):
+        self._h = C.c_void_p()
+        check(lib().rlnamd_msm_new(capacity, C.byref(self._h)))
+        self.ws_bytes = int(lib().rlnamd_msm_window_sums_bytes())
+
+    def close(self):
+        if self._h:
+            lib().rlnamd_msm_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set(self, points, scalars):
+        """points: list of (x, y) ints or None for infinity"""
+        pb = b"".join((_b(0) + _b(0)) if p is None else (_b(p[0]) + _b(p[1])) for p in points)
+        check(lib().rlnamd_msm_set(self._h, pb, b"".join(_b(s) for s in scalars), len(points)))
+
+    def generate(self, seed, first_index, n):
+        check(lib().rlnamd_msm_generate(self._h, seed, first_index, n))
+
+    @staticmethod
+    def expected(seed, first_index, n):
+        out = C.create_string_buffer(64)
+        check(lib().rlnamd_msm_expected(seed, first_index, n, out))
+        return int.from_bytes(out.raw[:32], "little"), int.from_bytes(out.raw[32:], "little")
+
+    def run_windows(self):
+        """-> (window-sum blob to all-gather, stage ms dict)"""
+        buf = C.create_string_buffer(self.ws_bytes)
+        ms = (C.c_float * 3)()
+        check(lib().rlnamd_msm_run(self._h, buf, ms))
+        return buf.raw, dict(sort_ms=float(ms[0]), bucket_acc_ms=float(ms[1]), bucket_reduce_ms=float(ms[2]))
+
+    def combine(self, blobs):
+        out = C.create_string_buffer(64)
+        check(lib().rlnamd_msm_combine(self._h, b"".join(blobs), len(blobs), out))
+        x, y = int.from_bytes(out.raw[:32], "little"), int.from_bytes(out.raw[32:], "little")
+        return None if x == 0 and y == 0 else (x, y)
+
+    def msm(self, points, scalars):
+        self.set(points, scalars)
+        blob, _ = self.run_windows()
+        return self.combine([blob])

@@ -9,6 +9,7 @@
 #include "common.h"
 #include "keccak.h"
 #include "merkle.h"
+#include "msm.h"
 #include "pairing.h"
 #include "poseidon.h"
 #include "prover.h"
@@ -282,6 +283,44 @@ int rlnamd_prover_fetch_h(rlnamd_prover* p, size_t index, uint8_t* out_le) {
 int rlnamd_verify(rlnamd_prover* p, const uint8_t proof[128], const uint8_t values_le[160], int* ok) {
   RLN_TRY
   verify_common(p->p->zkey(), proof, values_le, ok);
+  RLN_CATCH
+}
+
+struct rlnamd_msm {
+  std::unique_ptr<MsmG1> m;
+};
+int rlnamd_msm_new(size_t capacity, rlnamd_msm** out) {
+  RLN_TRY
+  std::unique_ptr<rlnamd_msm> h(new rlnamd_msm);
+  h->m.reset(new MsmG1(capacity ? capacity : 1));
+  *out = h.release();
+  RLN_CATCH
+}
+void rlnamd_msm_free(rlnamd_msm* m) { delete m; }
+int rlnamd_msm_set(rlnamd_msm* m, const uint8_t* points_xy_le, const uint8_t* scalars_le, size_t n) {
+  RLN_TRY
+  m->m->set_host(points_xy_le, scalars_le, n);
+  RLN_CATCH
+}
+int rlnamd_msm_generate(rlnamd_msm* m, uint64_t seed, uint64_t first_index, size_t n) {
+  RLN_TRY
+  m->m->generate(seed, first_index, n);
+  RLN_CATCH
+}
+int rlnamd_msm_expected(uint64_t seed, uint64_t first_index, size_t n, uint8_t out_xy_le[64]) {
+  RLN_TRY
+  MsmG1::expected_generated(seed, first_index, n, out_xy_le);
+  RLN_CATCH
+}
+size_t rlnamd_msm_window_sums_bytes(void) { return MsmG1::window_sums_bytes(); }
+int rlnamd_msm_run(rlnamd_msm* m, uint8_t* window_sums, float ms[3]) {
+  RLN_TRY
+  m->m->run_windows(window_sums, ms);
+  RLN_CATCH
+}
+int rlnamd_msm_combine(rlnamd_msm* m, const uint8_t* window_sums, size_t contributors, uint8_t out_xy_le[64]) {
+  RLN_TRY
+  m->m->combine(window_sums, contributors, out_xy_le);
   RLN_CATCH
 }
 

@@ -1,0 +1,30 @@
+// Variable-base G1 MSM (large n, bases not known in advance): see msm.hip.
+#pragma once
+#include <stdint.h>
+
+#include <memory>
+
+namespace rlnamd {
+
+class MsmG1 {
+ public:
+  explicit MsmG1(size_t capacity);
+  ~MsmG1();
+  // points: n x (x || y) canonical LE, (0,0) = infinity; scalars: n x 32 canonical LE
+  void set_host(const uint8_t* points_xy_le, const uint8_t* scalars_le, size_t n);
+  // synthetic workload generated in HBM: P_i = k_i G, s_i from SplitMix64(seed) at global index first_index + i
+  void generate(uint64_t seed, uint64_t first_index, size_t n);
+  static void expected_generated(uint64_t seed, uint64_t first_index, size_t n, uint8_t out_xy_le[64]);
+  // Pippenger up to one point per window; `window_sums_out` receives window_sums_bytes() bytes.
+  // ms[0] = digits + counting sort, ms[1] = bucket accumulation, ms[2] = bucket reduction (HIP events)
+  void run_windows(uint8_t* window_sums_out, float ms[3]);
+  // adds the window sums of `contributors` devices and folds the windows (Horner); affine canonical result
+  void combine(const uint8_t* window_sums, size_t contributors, uint8_t out_xy_le[64]);
+  static size_t window_sums_bytes();
+
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> d_;
+};
+
+}  // namespace rlnamd

@@ -1,0 +1,348 @@
+// Variable-base G1 MSM for large n (BASELINE config 5: one 2^24-point MSM, split across GPUs by point index).
+//
+// Replaces ark-ec 0.5.0 `VariableBaseMSM::msm_bigint` (third party; call sites
+// /root/reference/rln/src/partial_proof.rs:98-104,255-256) for the case the fixed-base tables of prover.hip
+// do not cover: bases that are not known in advance.  Classic Pippenger, laid out for a GPU:
+//   1. k_digits      signed 16-bit digits of every scalar (16 windows), histogram of bucket sizes (atomics)
+//   2. k_scan        exclusive prefix sum of the 16 x 2^15 bucket counts
+//   3. k_scatter     counting sort: point indices grouped by (window, bucket)
+//   4. k_bucket_acc  one lane per bucket: mixed additions of its points           <- the ALU-heavy kernel
+//   5. k_bucket_red  per (window, 32-bucket chunk): running-sum trick -> sum and weighted sum
+//      k_chunk_fix   weighted sum + chunk_base * sum
+//      k_sum_ranges  two-level tree over the chunks -> one point per window
+//   6. k_combine     adds the per-window sums of all contributing devices and runs Horner over the windows
+// Multi-GPU: every rank runs 1-5 on its slice of the points; the 16 window sums (2 KB) are
+// exchanged with one all-gather and step 6 runs on every rank.  RCCL has no elliptic-curve reduce op, so the
+// "all-reduce of bucket partials" is realised as gather + local add.
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+#include "curve.h"
+#include "msm.h"
+
+namespace rlnamd {
+
+constexpr int MSM_C = 16;
+constexpr int MSM_W = 16;                 // ceil(255 / 16)
+constexpr uint32_t MSM_NB = 1u << 15;     // buckets per window (signed digits)
+constexpr uint32_t MSM_CHUNK = 32;        // buckets per reduction chunk
+constexpr uint32_t MSM_NCH = MSM_NB / MSM_CHUNK;
+
+struct Range {
+  uint32_t begin, end;
+};
+
+__device__ __forceinline__ uint64_t splitmix_at(uint64_t seed, uint64_t j) {
+  uint64_t z = seed + (j + 1) * 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+static uint64_t splitmix_at_host(uint64_t seed, uint64_t j) {
+  uint64_t z = seed + (j + 1) * 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+// synthetic workload: P_i = k_i * G, scalar s_i; k_i, s_i 253-bit values of the stream
+__global__ void __launch_bounds__(64) k_gen(uint64_t seed, uint64_t first, uint32_t n, G1Affine* __restrict__ pts,
+                                            uint32_t* __restrict__ scal) {
+  uint32_t t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= n) return;
+  uint64_t i = first + t;
+  uint32_t k[8], s[8];
+  for (int q = 0; q < 4; q++) {
+    uint64_t a = splitmix_at(seed, 8 * i + q), b = splitmix_at(seed, 8 * i + 4 + q);
+    k[2 * q] = (uint32_t)a;
+    k[2 * q + 1] = (uint32_t)(a >> 32);
+    s[2 * q] = (uint32_t)b;
+    s[2 * q + 1] = (uint32_t)(b >> 32);
+  }
+  k[7] &= 0x1FFFFFFFu;  // < 2^253 < r
+  s[7] &= 0x1FFFFFFFu;
+  G1Affine g{Fq::from_u32(1), Fq::from_u32(2)};
+  pts[t] = scalar_mul(g, k).to_affine();
+  for (int q = 0; q < 8; q++) scal[(size_t)t * 8 + q] = s[q];
+}
+
+__global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scal, uint32_t n, int32_t* __restrict__ dig,
+                                                uint32_t* __restrict__ count) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t l[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) l[q] = scal[(size_t)i * 8 + q];
+  uint32_t carry = 0;
+#pragma unroll
+  for (int w = 0; w < MSM_W; w++) {
+    uint32_t raw = ((l[w >> 1] >> ((w & 1) * 16)) & 0xFFFFu) + carry;
+    int d;
+    if (raw > MSM_NB) {
+      d = (int)raw - 65536;
+      carry = 1;
+    } else {
+      d = (int)raw;
+      carry = 0;
+    }
+    dig[(size_t)w * n + i] = d;
+    if (d != 0) atomicAdd(&count[(uint32_t)w * MSM_NB + (uint32_t)(d < 0 ? -d : d) - 1], 1u);
+  }
+}
+
+// exclusive scan of `m` counters by one 1024-lane block (m = 524 288: 512 per lane)
+__global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ count, uint32_t m, uint32_t* __restrict__ offs) {
+  __shared__ uint32_t part[1024];
+  uint32_t t = threadIdx.x, per = (m + 1023) / 1024;
+  uint32_t lo = t * per, hi = lo + per < m ? lo + per : m;
+  uint32_t s = 0;
+  for (uint32_t i = lo; i < hi; i++) s += count[i];
+  part[t] = s;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = t ? part[t - 1] : 0;
+  for (uint32_t i = lo; i < hi; i++) {
+    offs[i] = run;
+    run += count[i];
+  }
+  if (t == 1023) offs[m] = part[1023];
+}
+
+__global__ void __launch_bounds__(256) k_scatter(const int32_t* __restrict__ dig, uint32_t n, const uint32_t* __restrict__ offs,
+                                                 uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  uint32_t w = blockIdx.y;
+  if (i >= n) return;
+  int d = dig[(size_t)w * n + i];
+  if (d == 0) return;
+  uint32_t key = w * MSM_NB + (uint32_t)(d < 0 ? -d : d) - 1;
+  uint32_t pos = offs[key] + atomicAdd(&cursor[key], 1u);
+  sorted[pos] = i | (d < 0 ? 0x80000000u : 0u);
+}
+
+__global__ void __launch_bounds__(64) k_bucket_acc(const G1Affine* __restrict__ pts, const uint32_t* __restrict__ offs,
+                                                   const uint32_t* __restrict__ sorted, G1XYZZ* __restrict__ buckets,
+                                                   uint32_t nkeys) {
+  uint32_t key = blockIdx.x * 64 + threadIdx.x;
+  if (key >= nkeys) return;
+  G1XYZZ acc = G1XYZZ::inf();
+  for (uint32_t j = offs[key]; j < offs[key + 1]; j++) {
+    uint32_t v = sorted[j];
+    G1Affine p = pts[v & 0x7FFFFFFFu];
+    if (v & 0x80000000u) p.y = p.y.neg();
+    acc.madd(p);
+  }
+  buckets[key] = acc;
+}
+
+// chunk [lo, lo+32) of one window: S = sum B_b, T = sum (b - lo + 1) B_b by the running-sum trick
+__global__ void __launch_bounds__(64) k_bucket_red(const G1XYZZ* __restrict__ buckets, G1XYZZ* __restrict__ chunkS,
+                                                   G1XYZZ* __restrict__ chunkT, uint32_t nchunks) {
+  uint32_t ch = blockIdx.x * 64 + threadIdx.x;
+  if (ch >= nchunks) return;
+  const G1XYZZ* b = buckets + (size_t)ch * MSM_CHUNK;
+  G1XYZZ run = G1XYZZ::inf(), wsum = G1XYZZ::inf();
+  for (int k = MSM_CHUNK - 1; k >= 0; k--) {
+    run.add(b[k]);
+    wsum.add(run);
+  }
+  chunkS[ch] = run;
+  chunkT[ch] = wsum;
+}
+
+// X = T + lo * S with lo = 32 * (chunk index within its window): bucket b holds digit value b + 1
+__global__ void __launch_bounds__(64) k_chunk_fix(const G1XYZZ* __restrict__ chunkS, G1XYZZ* __restrict__ chunkT,
+                                                  uint32_t nchunks) {
+  uint32_t ch = blockIdx.x * 64 + threadIdx.x;
+  if (ch >= nchunks) return;
+  uint32_t lo = (ch % MSM_NCH) * MSM_CHUNK;
+  G1XYZZ S = chunkS[ch], acc = G1XYZZ::inf();
+  for (int bit = 14; bit >= 0; bit--) {
+    acc = acc.dbl();
+    if ((lo >> bit) & 1) acc.add(S);
+  }
+  G1XYZZ T = chunkT[ch];
+  T.add(acc);
+  chunkT[ch] = T;
+}
+
+__global__ void __launch_bounds__(64) k_range_sum(const G1XYZZ* __restrict__ src, const Range* __restrict__ ranges,
+                                                  uint32_t nr, G1XYZZ* __restrict__ dst) {
+  uint32_t r = blockIdx.x * 64 + threadIdx.x;
+  if (r >= nr) return;
+  G1XYZZ acc = G1XYZZ::inf();
+  for (uint32_t i = ranges[r].begin; i < ranges[r].end; i++) acc.add(src[i]);
+  dst[r] = acc;
+}
+
+// window sums of `k` contributors ([k][W]) -> sum per window -> Horner over the windows -> affine
+__global__ void k_combine(const G1XYZZ* __restrict__ wsums, uint32_t k, uint32_t* __restrict__ out_xy) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  G1XYZZ total = G1XYZZ::inf();
+  for (int w = MSM_W - 1; w >= 0; w--) {
+    for (int d = 0; d < MSM_C; d++) total = total.dbl();
+    for (uint32_t r = 0; r < k; r++) total.add(wsums[(size_t)r * MSM_W + w]);
+  }
+  G1Affine a = total.to_affine();
+  a.x.to_canonical(out_xy);
+  a.y.to_canonical(out_xy + 8);
+}
+
+struct MsmG1::Impl {
+  hipStream_t s = nullptr;
+  size_t cap = 0, n = 0;
+  DevBuf<G1Affine> pts;
+  DevBuf<uint32_t> scal, count, offs, cursor, sorted;
+  DevBuf<int32_t> dig;
+  DevBuf<G1XYZZ> buckets, chunkS, chunkT, grp, wsum;
+  DevBuf<Range> r1, r2;
+  hipEvent_t e[4];
+};
+
+MsmG1::MsmG1(size_t capacity) : d_(new Impl) {
+  require_gpu();
+  Impl& D = *d_;
+  D.cap = capacity;
+  RLN_HIP(hipStreamCreateWithFlags(&D.s, hipStreamNonBlocking));
+  for (auto& e : D.e) RLN_HIP(hipEventCreate(&e));
+  const uint32_t nkeys = MSM_W * MSM_NB, nch = MSM_W * MSM_NCH;
+  D.pts.alloc(capacity);
+  D.scal.alloc(capacity * 8);
+  D.dig.alloc(capacity * MSM_W);
+  D.sorted.alloc(capacity * MSM_W);
+  D.count.alloc(nkeys);
+  D.offs.alloc(nkeys + 1);
+  D.cursor.alloc(nkeys);
+  D.buckets.alloc(nkeys);
+  D.chunkS.alloc(nch);
+  D.chunkT.alloc(nch);
+  // per window: 1024 chunks -> 32 groups of 32 -> 1
+  std::vector<Range> r1, r2;
+  for (uint32_t w = 0; w < MSM_W; w++) {
+    for (uint32_t g = 0; g < MSM_NCH / 32; g++) r1.push_back({w * MSM_NCH + g * 32, w * MSM_NCH + g * 32 + 32});
+    r2.push_back({w * (MSM_NCH / 32), (w + 1) * (MSM_NCH / 32)});
+  }
+  D.r1.alloc(r1.size());
+  D.r2.alloc(r2.size());
+  D.r1.upload(r1.data(), r1.size(), D.s);
+  D.r2.upload(r2.data(), r2.size(), D.s);
+  D.grp.alloc(r1.size());
+  D.wsum.alloc(MSM_W);
+  RLN_HIP(hipStreamSynchronize(D.s));
+}
+
+MsmG1::~MsmG1() {
+  if (!d_) return;
+  if (d_->s) {
+    (void)hipStreamSynchronize(d_->s);
+    (void)hipStreamDestroy(d_->s);
+  }
+  for (auto& e : d_->e) (void)hipEventDestroy(e);
+}
+
+void MsmG1::set_host(const uint8_t* points_xy_le, const uint8_t* scalars_le, size_t n) {
+  Impl& D = *d_;
+  if (n > D.cap) throw Error("MSM larger than the workspace");
+  std::vector<G1Affine> p(n);
+  for (size_t i = 0; i < n; i++) {
+    uint32_t x[8], y[8];
+    memcpy(x, points_xy_le + 64 * i, 32);
+    memcpy(y, points_xy_le + 64 * i + 32, 32);
+    if (limbs_geq(x, FqParams::MOD) || limbs_geq(y, FqParams::MOD)) throw Error("Non-canonical field element");
+    p[i] = {Fq::from_canonical(x), Fq::from_canonical(y)};  // (0,0) encodes infinity
+  }
+  for (size_t i = 0; i < n; i++) {
+    uint32_t s[8];
+    memcpy(s, scalars_le + 32 * i, 32);
+    if (limbs_geq(s, FrParams::MOD)) throw Error("Non-canonical field element: value is not in [0, r-1]");
+  }
+  RLN_HIP(hipMemcpyAsync(D.pts.p, p.data(), n * sizeof(G1Affine), hipMemcpyHostToDevice, D.s));
+  RLN_HIP(hipMemcpyAsync(D.scal.p, scalars_le, n * 32, hipMemcpyHostToDevice, D.s));
+  RLN_HIP(hipStreamSynchronize(D.s));
+  D.n = n;
+}
+
+void MsmG1::generate(uint64_t seed, uint64_t first_index, size_t n) {
+  Impl& D = *d_;
+  if (n > D.cap) throw Error("MSM larger than the workspace");
+  hipLaunchKernelGGL(k_gen, dim3(div_up(n, 64)), dim3(64), 0, D.s, seed, first_index, (uint32_t)n, D.pts.p, D.scal.p);
+  RLN_HIP(hipGetLastError());
+  RLN_HIP(hipStreamSynchronize(D.s));
+  D.n = n;
+}
+
+// closed form of the synthetic workload: (sum k_i s_i mod r) * G, computed on the host (scalar side only)
+void MsmG1::expected_generated(uint64_t seed, uint64_t first_index, size_t n, uint8_t out_xy_le[64]) {
+  Fr acc = Fr::zero();
+  for (uint64_t i = first_index; i < first_index + n; i++) {
+    uint32_t k[8], s[8];
+    for (int q = 0; q < 4; q++) {
+      uint64_t a = splitmix_at_host(seed, 8 * i + q), b = splitmix_at_host(seed, 8 * i + 4 + q);
+      k[2 * q] = (uint32_t)a;
+      k[2 * q + 1] = (uint32_t)(a >> 32);
+      s[2 * q] = (uint32_t)b;
+      s[2 * q + 1] = (uint32_t)(b >> 32);
+    }
+    k[7] &= 0x1FFFFFFFu;
+    s[7] &= 0x1FFFFFFFu;
+    acc = acc + Fr::from_canonical(k) * Fr::from_canonical(s);
+  }
+  uint32_t e[8];
+  acc.to_canonical(e);
+  G1Affine g{Fq::from_u32(1), Fq::from_u32(2)};
+  G1Affine r = scalar_mul(g, e).to_affine();
+  uint32_t c[8];
+  r.x.to_canonical(c);
+  memcpy(out_xy_le, c, 32);
+  r.y.to_canonical(c);
+  memcpy(out_xy_le + 32, c, 32);
+}
+
+void MsmG1::run_windows(uint8_t* window_sums_out, float ms[3]) {
+  Impl& D = *d_;
+  const uint32_t n = (uint32_t)D.n, nkeys = MSM_W * MSM_NB, nch = MSM_W * MSM_NCH;
+  hipStream_t s = D.s;
+  RLN_HIP(hipEventRecord(D.e[0], s));
+  RLN_HIP(hipMemsetAsync(D.count.p, 0, D.count.bytes(), s));
+  RLN_HIP(hipMemsetAsync(D.cursor.p, 0, D.cursor.bytes(), s));
+  if (n) {
+    hipLaunchKernelGGL(k_digits, dim3(div_up(n, 256)), dim3(256), 0, s, D.scal.p, n, D.dig.p, D.count.p);
+  }
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, D.count.p, nkeys, D.offs.p);
+  if (n) hipLaunchKernelGGL(k_scatter, dim3(div_up(n, 256), MSM_W), dim3(256), 0, s, D.dig.p, n, D.offs.p, D.cursor.p, D.sorted.p);
+  RLN_HIP(hipEventRecord(D.e[1], s));
+  hipLaunchKernelGGL(k_bucket_acc, dim3(div_up(nkeys, 64)), dim3(64), 0, s, D.pts.p, D.offs.p, D.sorted.p, D.buckets.p, nkeys);
+  RLN_HIP(hipEventRecord(D.e[2], s));
+  hipLaunchKernelGGL(k_bucket_red, dim3(div_up(nch, 64)), dim3(64), 0, s, D.buckets.p, D.chunkS.p, D.chunkT.p, nch);
+  hipLaunchKernelGGL(k_chunk_fix, dim3(div_up(nch, 64)), dim3(64), 0, s, D.chunkS.p, D.chunkT.p, nch);
+  hipLaunchKernelGGL(k_range_sum, dim3(div_up(D.r1.n, 64)), dim3(64), 0, s, D.chunkT.p, D.r1.p, (uint32_t)D.r1.n, D.grp.p);
+  hipLaunchKernelGGL(k_range_sum, dim3(1), dim3(64), 0, s, D.grp.p, D.r2.p, (uint32_t)D.r2.n, D.wsum.p);
+  RLN_HIP(hipGetLastError());
+  RLN_HIP(hipEventRecord(D.e[3], s));
+  RLN_HIP(hipMemcpyAsync(window_sums_out, D.wsum.p, MSM_W * sizeof(G1XYZZ), hipMemcpyDeviceToHost, s));
+  RLN_HIP(hipStreamSynchronize(s));
+  if (ms)
+    for (int i = 0; i < 3; i++) RLN_HIP(hipEventElapsedTime(&ms[i], D.e[i], D.e[i + 1]));
+}
+
+void MsmG1::combine(const uint8_t* window_sums, size_t contributors, uint8_t out_xy_le[64]) {
+  Impl& D = *d_;
+  DevBuf<G1XYZZ> in(contributors * MSM_W);
+  DevBuf<uint32_t> out(16);
+  RLN_HIP(hipMemcpyAsync(in.p, window_sums, contributors * MSM_W * sizeof(G1XYZZ), hipMemcpyHostToDevice, D.s));
+  hipLaunchKernelGGL(k_combine, dim3(1), dim3(64), 0, D.s, in.p, (uint32_t)contributors, out.p);
+  RLN_HIP(hipGetLastError());
+  RLN_HIP(hipMemcpyAsync(out_xy_le, out.p, 64, hipMemcpyDeviceToHost, D.s));
+  RLN_HIP(hipStreamSynchronize(D.s));
+}
+
+size_t MsmG1::window_sums_bytes() { return MSM_W * sizeof(G1XYZZ); }
+
+}  // namespace rlnamd

@@ -54,3 +54,26 @@ def max_over_ranks(seconds, device="cpu", group=None):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+def msm_sharded(msm, seed, n_total, group=None, device="cpu"):
+    """BASELINE config 5: one n_total-point MSM split by point index across the ranks.  Every rank runs
+    Pippenger on its slice (`msm` is a zerokit_amd.batch.MsmG1 holding the slice workspace), the per-window sums
+    (2 KiB per rank) are exchanged with ONE all_gather -- RCCL over xGMI on the GPU box -- and every rank folds
+    them locally (RCCL has no elliptic-curve reduce op: gather + local add)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_bounds(n_total, world)[rank]
+    msm.generate(seed, lo, hi - lo)
+    blob, ms = msm.run_windows()
+    blobs = all_gather_bytes(blob, group=group, device=device)
+    return msm.combine(blobs), ms
+
+
+def all_gather_bytes(blob, group=None, device="cpu"):
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [blob]
+    t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, t, group=group)
+    return [o.cpu().numpy().tobytes() for o in out]
