@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librln.so")
+LIB_PATH = os.environ.get("RLNAMD_LIB") or os.path.join(_HERE, "lib", "librln.so")
 
 
 class NativeMissing(RuntimeError):
