@@ -21,6 +21,18 @@ struct Affine {
   RLN_HD Affine neg() const { return {x, y.neg()}; }
 };
 
+// a*b - c*d; for prime fields the two products share one Montgomery reduction on the device
+template <class P>
+RLN_HD Fp<P> fused_sub(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& d) {
+  return Fp<P>::dot2_sub(a, b, c, d);
+}
+// Fq2: both components of a*b - c*d are 4-term dot products over Fq (4 p^2 < p 2^256): 8 products, 2 reductions
+RLN_HD Fq2 fused_sub(const Fq2& a, const Fq2& b, const Fq2& c, const Fq2& d) {
+  Fq nc0 = c.c0.neg(), nc1 = c.c1.neg();
+  return {Fq::dot4(a.c0, b.c0, a.c1.neg(), b.c1, nc0, d.c0, c.c1, d.c1),
+          Fq::dot4(a.c0, b.c1, a.c1, b.c0, nc0, d.c1, nc1, d.c0)};
+}
+
 template <class F>
 struct XYZZ {
   F X, Y, ZZ, ZZZ;
@@ -83,7 +95,7 @@ struct XYZZ {
     F PPP = P * PP;
     F Q = X * PP;
     F X3 = R.sqr() - PPP - Q.dbl();
-    Y = R * (Q - X3) - Y * PPP;
+    Y = fused_sub(R, Q - X3, Y, PPP);  // R (Q - X3) - Y PPP, one reduction
     X = X3;
     ZZ = ZZ * PP;
     ZZZ = ZZZ * PPP;
@@ -112,7 +124,7 @@ struct XYZZ {
     F PPP = P * PP;
     F Q = U1 * PP;
     F X3 = R.sqr() - PPP - Q.dbl();
-    Y = R * (Q - X3) - S1 * PPP;
+    Y = fused_sub(R, Q - X3, S1, PPP);
     X = X3;
     ZZ = ZZ * o.ZZ * PP;
     ZZZ = ZZZ * o.ZZZ * PPP;

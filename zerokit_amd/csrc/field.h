@@ -202,99 +202,7 @@ struct Fp {
   // Host: operand-scanning CIOS in portable C (same value, used by tests and one-time table setup).
 #if defined(__HIP_DEVICE_COMPILE__)
 #include "mont_mac.inc"
-  static __device__ __forceinline__ Fp mont_mul(const Fp& a, const Fp& b) {
-    uint32_t m[8], t[8];
-    uint64_t acc = 0;
-    uint32_t top = 0;
-    macv1(acc, top, a.v[0], b.v[0]);
-    m[0] = (uint32_t)acc * P::INV32;
-    macs1(acc, top, m[0], P::MOD[0]);
-    acc = (acc >> 32) | ((uint64_t)top << 32);
-    top = 0;
-    macv2(acc, top, a.v[0], b.v[1], a.v[1], b.v[0]);
-    macs1(acc, top, m[0], P::MOD[1]);
-    m[1] = (uint32_t)acc * P::INV32;
-    macs1(acc, top, m[1], P::MOD[0]);
-    acc = (acc >> 32) | ((uint64_t)top << 32);
-    top = 0;
-    macv3(acc, top, a.v[0], b.v[2], a.v[1], b.v[1], a.v[2], b.v[0]);
-    macs2(acc, top, m[0], P::MOD[2], m[1], P::MOD[1]);
-    m[2] = (uint32_t)acc * P::INV32;
-    macs1(acc, top, m[2], P::MOD[0]);
-    acc = (acc >> 32) | ((uint64_t)top << 32);
-    top = 0;
-    macv4(acc, top, a.v[0], b.v[3], a.v[1], b.v[2], a.v[2], b.v[1], a.v[3], b.v[0]);
-    macs3(acc, top, m[0], P::MOD[3], m[1], P::MOD[2], m[2], P::MOD[1]);
-    m[3] = (uint32_t)acc * P::INV32;
-    macs1(acc, top, m[3], P::MOD[0]);
-    acc = (acc >> 32) | ((uint64_t)top << 32);
-    top = 0;
-    macv5(acc, top, a.v[0], b.v[4], a.v[1], b.v[3], a.v[2], b.v[2], a.v[3], b.v[1], a.v[4], b.v[0]);
-    macs4(acc, top, m[0], P::MOD[4], m[1], P::MOD[3], m[2], P::MOD[2], m[3], P::MOD[1]);
-    m[4] = (uint32_t)acc * P::INV32;
-    macs1(acc, top, m[4], P::MOD[0]);
-    acc = (acc >> 32) | ((uint64_t)top << 32);
-    top = 0;
-    macv6(acc, top, a.v[0], b.v[5], a.v[1], b.v[4], a.v[2], b.v[3], a.v[3], b.v[2], a.v[4], b.v[1], a.v[5], b.v[0]);
-    macs5(acc, top, m[0], P::MOD[5], m[1], P::MOD[4], m[2], P::MOD[3], m[3], P::MOD[2], m[4], P::MOD[1]);
-    m[5] = (uint32_t)acc * P::INV32;
-    macs1(acc, top, m[5], P::MOD[0]);
-    acc = (acc >> 32) | ((uint64_t)top << 32);
-    top = 0;
-    macv7(acc, top, a.v[0], b.v[6], a.v[1], b.v[5], a.v[2], b.v[4], a.v[3], b.v[3], a.v[4], b.v[2], a.v[5], b.v[1], a.v[6], b.v[0]);
-    macs6(acc, top, m[0], P::MOD[6], m[1], P::MOD[5], m[2], P::MOD[4], m[3], P::MOD[3], m[4], P::MOD[2], m[5], P::MOD[1]);
-    m[6] = (uint32_t)acc * P::INV32;
-    macs1(acc, top, m[6], P::MOD[0]);
-    acc = (acc >> 32) | ((uint64_t)top << 32);
-    top = 0;
-    macv8(acc, top, a.v[0], b.v[7], a.v[1], b.v[6], a.v[2], b.v[5], a.v[3], b.v[4], a.v[4], b.v[3], a.v[5], b.v[2], a.v[6], b.v[1], a.v[7], b.v[0]);
-    macs7(acc, top, m[0], P::MOD[7], m[1], P::MOD[6], m[2], P::MOD[5], m[3], P::MOD[4], m[4], P::MOD[3], m[5], P::MOD[2], m[6], P::MOD[1]);
-    m[7] = (uint32_t)acc * P::INV32;
-    macs1(acc, top, m[7], P::MOD[0]);
-    acc = (acc >> 32) | ((uint64_t)top << 32);
-    top = 0;
-    macv7(acc, top, a.v[1], b.v[7], a.v[2], b.v[6], a.v[3], b.v[5], a.v[4], b.v[4], a.v[5], b.v[3], a.v[6], b.v[2], a.v[7], b.v[1]);
-    macs7(acc, top, m[1], P::MOD[7], m[2], P::MOD[6], m[3], P::MOD[5], m[4], P::MOD[4], m[5], P::MOD[3], m[6], P::MOD[2], m[7], P::MOD[1]);
-    t[0] = (uint32_t)acc;
-    acc = (acc >> 32) | ((uint64_t)top << 32);
-    top = 0;
-    macv6(acc, top, a.v[2], b.v[7], a.v[3], b.v[6], a.v[4], b.v[5], a.v[5], b.v[4], a.v[6], b.v[3], a.v[7], b.v[2]);
-    macs6(acc, top, m[2], P::MOD[7], m[3], P::MOD[6], m[4], P::MOD[5], m[5], P::MOD[4], m[6], P::MOD[3], m[7], P::MOD[2]);
-    t[1] = (uint32_t)acc;
-    acc = (acc >> 32) | ((uint64_t)top << 32);
-    top = 0;
-    macv5(acc, top, a.v[3], b.v[7], a.v[4], b.v[6], a.v[5], b.v[5], a.v[6], b.v[4], a.v[7], b.v[3]);
-    macs5(acc, top, m[3], P::MOD[7], m[4], P::MOD[6], m[5], P::MOD[5], m[6], P::MOD[4], m[7], P::MOD[3]);
-    t[2] = (uint32_t)acc;
-    acc = (acc >> 32) | ((uint64_t)top << 32);
-    top = 0;
-    macv4(acc, top, a.v[4], b.v[7], a.v[5], b.v[6], a.v[6], b.v[5], a.v[7], b.v[4]);
-    macs4(acc, top, m[4], P::MOD[7], m[5], P::MOD[6], m[6], P::MOD[5], m[7], P::MOD[4]);
-    t[3] = (uint32_t)acc;
-    acc = (acc >> 32) | ((uint64_t)top << 32);
-    top = 0;
-    macv3(acc, top, a.v[5], b.v[7], a.v[6], b.v[6], a.v[7], b.v[5]);
-    macs3(acc, top, m[5], P::MOD[7], m[6], P::MOD[6], m[7], P::MOD[5]);
-    t[4] = (uint32_t)acc;
-    acc = (acc >> 32) | ((uint64_t)top << 32);
-    top = 0;
-    macv2(acc, top, a.v[6], b.v[7], a.v[7], b.v[6]);
-    macs2(acc, top, m[6], P::MOD[7], m[7], P::MOD[6]);
-    t[5] = (uint32_t)acc;
-    acc = (acc >> 32) | ((uint64_t)top << 32);
-    top = 0;
-    macv1(acc, top, a.v[7], b.v[7]);
-    macs1(acc, top, m[7], P::MOD[7]);
-    t[6] = (uint32_t)acc;
-    acc = (acc >> 32) | ((uint64_t)top << 32);
-    top = 0;
-    t[7] = (uint32_t)acc;
-    reduce_once(t);
-    Fp r;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = t[i];
-    return r;
-  }
+  static __device__ __forceinline__ Fp mont_mul(const Fp& a, const Fp& b) { return mont_dot1(a, b); }
 #else
   static RLN_HD Fp mont_mul(const Fp& a, const Fp& b) {
     uint32_t t[8];
@@ -337,6 +245,32 @@ struct Fp {
 #endif
   }
   RLN_HD Fp sqr() const { return (*this) * (*this); }
+
+  // a*b + c*d (and 3-, 4-term forms) with ONE Montgomery reduction on the device; plain sums on the host.
+  static RLN_HD Fp dot2(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RLN_NOINLINE_MUL)
+    return mont_dot2(a, b, c, d);
+#else
+    return a * b + c * d;
+#endif
+  }
+  static RLN_HD Fp dot3(const Fp& a0, const Fp& b0, const Fp& a1, const Fp& b1, const Fp& a2, const Fp& b2) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RLN_NOINLINE_MUL)
+    return mont_dot3(a0, b0, a1, b1, a2, b2);
+#else
+    return a0 * b0 + a1 * b1 + a2 * b2;
+#endif
+  }
+  static RLN_HD Fp dot4(const Fp& a0, const Fp& b0, const Fp& a1, const Fp& b1, const Fp& a2, const Fp& b2,
+                        const Fp& a3, const Fp& b3) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RLN_NOINLINE_MUL)
+    return mont_dot4(a0, b0, a1, b1, a2, b2, a3, b3);
+#else
+    return a0 * b0 + a1 * b1 + a2 * b2 + a3 * b3;
+#endif
+  }
+  // a*b - c*d
+  static RLN_HD Fp dot2_sub(const Fp& a, const Fp& b, const Fp& c, const Fp& d) { return dot2(a, b, c.neg(), d); }
 
   // canonical little-endian limbs <-> Montgomery
   static RLN_HD Fp from_canonical(const uint32_t* c) {
@@ -402,12 +336,18 @@ struct Fq2 {
   friend RLN_HD Fq2 operator-(const Fq2& a, const Fq2& b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
   RLN_HD Fq2 neg() const { return {c0.neg(), c1.neg()}; }
   RLN_HD Fq2 dbl() const { return {c0.dbl(), c1.dbl()}; }
-  // Karatsuba: 3 base multiplications
+  // Device: c0 = REDC(a0 b0 + (-a1) b1), c1 = REDC(a0 b1 + a1 b0): 4 products but only 2 reductions and no
+  // Karatsuba additions (3 full multiplications = 3 products + 3 reductions + 5 add/sub).
+  // Host: Karatsuba, 3 base multiplications.
   friend RLN_HD Fq2 operator*(const Fq2& a, const Fq2& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RLN_NOINLINE_MUL)
+    return {Fq::dot2(a.c0, b.c0, a.c1.neg(), b.c1), Fq::dot2(a.c0, b.c1, a.c1, b.c0)};
+#else
     Fq v0 = a.c0 * b.c0;
     Fq v1 = a.c1 * b.c1;
     Fq s = (a.c0 + a.c1) * (b.c0 + b.c1);
     return {v0 - v1, s - v0 - v1};
+#endif
   }
   RLN_HD Fq2 sqr() const {
     Fq p = c0 * c1;

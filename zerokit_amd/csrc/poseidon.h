@@ -50,13 +50,17 @@ __device__ __forceinline__ void poseidon_round_dev(Fr* st, const Fr* __restrict_
     Fr x2 = st[j].sqr();
     st[j] = x2.sqr() * st[j];
   }
+  // each MDS row is one fused dot product: T products, one Montgomery reduction
   Fr nx[T];
 #pragma unroll
   for (int i = 0; i < T; i++) {
-    Fr acc = mds[i * T] * st[0];
-#pragma unroll
-    for (int j = 1; j < T; j++) acc = acc + mds[i * T + j] * st[j];
-    nx[i] = acc;
+    const Fr* row = mds + i * T;
+    if constexpr (T == 2)
+      nx[i] = Fr::dot2(row[0], st[0], row[1], st[1]);
+    else if constexpr (T == 3)
+      nx[i] = Fr::dot3(row[0], st[0], row[1], st[1], row[2], st[2]);
+    else
+      nx[i] = Fr::dot4(row[0], st[0], row[1], st[1], row[2], st[2], row[3], st[3]);
   }
 #pragma unroll
   for (int j = 0; j < T; j++) st[j] = nx[j];

@@ -752,9 +752,11 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     // of the MSM's thousands of workgroups
     int lo = 0, hi = 0;
     RLN_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    RLN_HIP(hipStreamCreateWithPriority(&D.sA, hipStreamNonBlocking, hi));
-    RLN_HIP(hipStreamCreateWithPriority(&D.sB, hipStreamNonBlocking, lo));
-    RLN_HIP(hipStreamCreateWithPriority(&D.sC, hipStreamNonBlocking, hi));
+    const char* pe = getenv("RLNAMD_PRIO");  // experiment knob: three chars h/l for streams A, B, C
+    auto pick = [&](int i, int dflt) { return (pe && strlen(pe) == 3) ? (pe[i] == 'h' ? hi : lo) : dflt; };
+    RLN_HIP(hipStreamCreateWithPriority(&D.sA, hipStreamNonBlocking, pick(0, hi)));
+    RLN_HIP(hipStreamCreateWithPriority(&D.sB, hipStreamNonBlocking, pick(1, lo)));
+    RLN_HIP(hipStreamCreateWithPriority(&D.sC, hipStreamNonBlocking, pick(2, hi)));
   }
   hipStream_t s = D.sB;
 
@@ -824,7 +826,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
 
   // ---- MSM segments.  Scalar ids: [0, NS) witness, [NS, NS+n) h, then r, s, -(r s).
   const uint32_t SID_R = D.NS + D.n, SID_S = SID_R + 1, SID_NRS = SID_R + 2;
-  const uint32_t chunk_pts = (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK", 32));
+  const uint32_t chunk_pts = (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK", 8));
   {
     std::vector<G1Affine> pts;
     std::vector<uint32_t> sids, segfirst;
@@ -875,7 +877,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     build_table<Fq>(pts, c_, W_, D.t1, s);
   }
   {
-    const uint32_t chunk2 = (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_G2", 16));
+    const uint32_t chunk2 = (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_G2", 4));
     std::vector<G2Affine> pts;
     std::vector<uint32_t> sids, segfirst;
     std::vector<ChunkDesc> chunks;
