@@ -96,6 +96,13 @@ const char* rlnamd_prover_stage_name(int i);
 /* parity taps of the last run: full witness (num_signals*32) / h (domain_size*32) of proof `index` */
 int rlnamd_prover_fetch_witness(rlnamd_prover* p, size_t index, uint8_t* out_le);
 int rlnamd_prover_fetch_h(rlnamd_prover* p, size_t index, uint8_t* out_le);
+/* Public signals (the circuit outputs/inputs w[1..num_instance)) of the first n proofs of the last run, read
+ * from the witness: n * num_public * 32 bytes.  Circuit-generic (multi message-id: ys, root, nullifiers, x,
+ * external_nullifier, selector_used -- the verifier order of protocol/proof.rs:870-885). */
+size_t rlnamd_prover_num_public(rlnamd_prover* p);
+int rlnamd_prover_download_public(rlnamd_prover* p, size_t n, uint8_t* out_le);
+/* generic-arity verification: n_values public inputs */
+int rlnamd_verify_public(rlnamd_prover* p, const uint8_t proof[128], const uint8_t* values_le, size_t n_values, int* ok);
 /* verify_zk_proof (protocol/proof.rs:856-894) on the host CPU, as in the reference.
  * values: y, root, nullifier, x, external_nullifier.  *ok = 1 valid, 0 invalid. */
 int rlnamd_verify(rlnamd_prover* p, const uint8_t proof[128], const uint8_t values_le[160], int* ok);

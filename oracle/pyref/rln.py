@@ -14,8 +14,8 @@ from .poseidon import poseidon
 RES = os.path.join(os.path.dirname(__file__), "..", "..", "zerokit_amd", "resources")
 
 
-def load_circuit(depth=20):
-    d = os.path.join(RES, "tree_depth_%d" % depth)
+def load_circuit(depth=20, multi=False):
+    d = os.path.join(RES, "tree_depth_%d%s" % (depth, "_multi_max_out_4" if multi else ""))
     zk = arkzkey.parse(open(os.path.join(d, "rln_final.arkzkey"), "rb").read())
     g = wtns_graph.parse(open(os.path.join(d, "graph.bin"), "rb").read())
     return zk, g
@@ -166,3 +166,16 @@ class FullMerkleTree:
                 bits.append(1)
             i = ((i + 1) >> 1) - 1
         return elems, bits
+
+
+def proof_values_multi(secret, limit, message_ids, selector_used, path_elements, path_index, x, ext):
+    """witness.rs:777-802 -> public inputs in the verifier order of proof.rs:870-885:
+    ys..., root, nullifiers..., x, external_nullifier, selector_used..."""
+    root = compute_tree_root(secret, limit, path_elements, path_index)
+    ys, nulls = [], []
+    for mid, sel in zip(message_ids, selector_used):
+        a1 = poseidon([secret, ext, mid])
+        s = 1 if sel else 0
+        ys.append((secret + x * a1) % R * s % R)
+        nulls.append(poseidon([a1]) * s % R)
+    return ys + [root] + nulls + [x, ext] + [1 if b else 0 for b in selector_used]

@@ -305,3 +305,31 @@ def test_msm_g1_generated_closed_form_and_split():
         m.generate(seed, r * q, q)
         blobs.append(m.run_windows()[0])
     assert m.combine(blobs) == want
+
+
+# ------------------------------------------------------------------------------------------ other circuits
+def test_other_circuits_depth10_and_multi_message_id():
+    """The prover is circuit-generic: the shipped depth-10 single circuit and the depth-20 multi-message-id
+    (max_out 4) circuit (extra graph ops Neq / Div / TernCond / Neg; 16 public inputs in the order of
+    proof.rs:870-885) reproduce the oracle's witness digest, public signals and proof bytes, and verify."""
+    from zerokit_amd.batch import BatchProver
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "rln_other_circuits.json")))["cases"]
+    for c in cases:
+        p = BatchProver(max_batch=64, depth=c["depth"], multi=c["multi"])
+        named = {k: [int(v) for v in vs] for k, vs in c["inputs"].items()}
+        n = p.upload(p.pack_named_inputs([named, named]), [(int(c["r"]), int(c["s"])), (1, 2)])
+        p.run(n)
+        out = p.download(n)
+        assert out[0]["error"] == 0
+        pub = p.download_public(n)
+        assert [str(v) for v in pub[0]] == c["public"], c["name"]
+        assert _digest(p.fetch_witness(0)) == c["witness_sha256"], c["name"]
+        assert out[0]["proof"].hex() == c["proof_compressed"], c["name"]
+        assert p.verify_public(out[0]["proof"], pub[0]) and p.verify_public(out[1]["proof"], pub[1])
+        assert out[1]["proof"] != out[0]["proof"] and pub[1] == pub[0]
+        bad = list(pub[0])
+        bad[-1] ^= 1
+        assert not p.verify_public(out[0]["proof"], bad)
+        if not c["multi"]:
+            assert out[0]["public_inputs"] == pub[0]          # Poseidon-formula values == witness outputs
+        p.close()

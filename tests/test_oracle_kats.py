@@ -171,3 +171,17 @@ def test_prove_appendix_d_vector(circuit20):
         "34966d01384d39783d9a793104998a150e4aa0c536dec8f60690b9e12c40598627c322f73f7324f33c569cd274f11aa1"
         "e9d8237c7b58b201c946e56ce4777ac0dc154929c5688c36f4ace4a2f2a126ab")
     assert groth16.verify(zk, proof, full[1:6])
+
+
+def test_multi_message_id_circuit_internal_oracle():
+    """depth-20 multi-message-id circuit (max_out 4): witness outputs equal the formulae of
+    protocol/witness.rs:777-802 in the verifier order of proof.rs:870-885."""
+    zk, g = rln.load_circuit(20, multi=True)
+    assert (zk.num_instance_variables, zk.num_constraints, len(g.nodes), g.max_out) == (16, 7390, 29254, 4)
+    sel = [0, 1, 1, 1]
+    w = dict(identitySecret=[987654321], userMessageLimit=[10], messageId=[0, 4, 5, 9], selectorUsed=sel,
+             pathElements=[3 * i + 2 for i in range(20)], identityPathIndex=[(i >> 1) & 1 for i in range(20)],
+             x=[77], externalNullifier=[88])
+    full = wtns_graph.calc_witness(g, w)
+    assert full[1:16] == rln.proof_values_multi(987654321, 10, w["messageId"], sel, w["pathElements"],
+                                                w["identityPathIndex"], 77, 88)

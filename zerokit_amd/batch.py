@@ -8,8 +8,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 STAGES = 8
 
 
-def resource_paths(depth=20):
-    d = os.path.join(_HERE, "resources", "tree_depth_%d" % depth)
+def resource_paths(depth=20, multi=False):
+    d = os.path.join(_HERE, "resources", "tree_depth_%d%s" % (depth, "_multi_max_out_4" if multi else ""))
     return os.path.join(d, "rln_final.arkzkey"), os.path.join(d, "graph.bin")
 
 
@@ -21,9 +21,9 @@ class BatchProver:
     """n x generate_zk_proof_with_rs (/root/reference/rln/src/protocol/proof.rs:753-777) +
     proof_values_from_witness (protocol/witness.rs:759-804) in one device batch."""
 
-    def __init__(self, zkey: bytes = None, graph: bytes = None, max_batch=1024, window_bits=0, depth=20):
+    def __init__(self, zkey: bytes = None, graph: bytes = None, max_batch=1024, window_bits=0, depth=20, multi=False):
         if zkey is None or graph is None:
-            zp, gp = resource_paths(depth)
+            zp, gp = resource_paths(depth, multi)
             zkey, graph = open(zp, "rb").read(), open(gp, "rb").read()
         self._h = C.c_void_p()
         check(lib().rlnamd_prover_new(zkey, len(zkey), graph, len(graph), max_batch, window_bits, C.byref(self._h)))
@@ -33,10 +33,11 @@ class BatchProver:
         self.inputs_size = int(info.inputs_size)
         self.slots = {}
         for name in ("identitySecret", "userMessageLimit", "messageId", "pathElements", "identityPathIndex", "x",
-                     "externalNullifier"):
+                     "externalNullifier", "selectorUsed"):
             off, ln = C.c_uint32(), C.c_uint32()
-            check(lib().rlnamd_prover_input_slot(self._h, name.encode(), C.byref(off), C.byref(ln)))
-            self.slots[name] = (off.value, ln.value)
+            if lib().rlnamd_prover_input_slot(self._h, name.encode(), C.byref(off), C.byref(ln)) == 0:
+                self.slots[name] = (off.value, ln.value)
+        self.num_public = int(lib().rlnamd_prover_num_public(self._h))
 
     def close(self):
         if self._h:
@@ -56,14 +57,33 @@ class BatchProver:
         out = bytearray(len(witnesses) * self.inputs_size * 32)
         names = {"identitySecret": "identity_secret", "userMessageLimit": "user_message_limit",
                  "messageId": "message_id", "pathElements": "path_elements",
-                 "identityPathIndex": "identity_path_index", "x": "x", "externalNullifier": "external_nullifier"}
+                 "identityPathIndex": "identity_path_index", "x": "x", "externalNullifier": "external_nullifier",
+                 "selectorUsed": "selector_used"}
         for i, w in enumerate(witnesses):
             base = i * self.inputs_size * 32
             out[base] = 1
             for sig, key in names.items():
+                if sig not in self.slots:
+                    continue
                 off, ln = self.slots[sig]
                 v = w[key]
                 vals = list(v) if isinstance(v, (list, tuple)) else [v]
+                if len(vals) != ln:
+                    raise RLNError("invalid input length for %s: expected %d, got %d" % (sig, ln, len(vals)))
+                for k, x in enumerate(vals):
+                    out[base + (off + k) * 32: base + (off + k + 1) * 32] = _b(x)
+        return bytes(out)
+
+    def pack_named_inputs(self, named):
+        """named: list of {graph signal name: [ints]} (any circuit): the populate_inputs of iden3calc.rs:122-146"""
+        out = bytearray(len(named) * self.inputs_size * 32)
+        for i, w in enumerate(named):
+            base = i * self.inputs_size * 32
+            out[base] = 1
+            for sig, vals in w.items():
+                if sig not in self.slots:
+                    raise RLNError("MissingInput: " + sig)
+                off, ln = self.slots[sig]
                 if len(vals) != ln:
                     raise RLNError("invalid input length for %s: expected %d, got %d" % (sig, ln, len(vals)))
                 for k, x in enumerate(vals):
@@ -110,6 +130,20 @@ class BatchProver:
         n = self.upload(self.pack_inputs(witnesses), rs)
         self.run(n)
         return self.download(n)
+
+    def download_public(self, n):
+        """public signals w[1..] of the first n proofs of the last run, from the witness (circuit-generic)"""
+        buf = C.create_string_buffer(32 * self.num_public * n)
+        check(lib().rlnamd_prover_download_public(self._h, n, buf))
+        k = self.num_public
+        return [[int.from_bytes(buf.raw[32 * (i * k + j):32 * (i * k + j + 1)], "little") for j in range(k)]
+                for i in range(n)]
+
+    def verify_public(self, proof: bytes, public_inputs):
+        ok = C.c_int()
+        check(lib().rlnamd_verify_public(self._h, proof, b"".join(_b(v) for v in public_inputs), len(public_inputs),
+                                         C.byref(ok)))
+        return bool(ok.value)
 
     def stage_ms(self):
         ms = (C.c_float * STAGES)()

@@ -44,7 +44,7 @@ struct rlnamd_prover {
   std::unique_ptr<Prover> p;
 };
 
-static void verify_common(const Zkey& zk, const uint8_t proof[128], const uint8_t values_le[160], int* ok);
+static void verify_common(const Zkey& zk, const uint8_t proof[128], const uint8_t* values_le, int* ok, size_t nv = 5);
 
 extern "C" {
 
@@ -324,20 +324,34 @@ int rlnamd_msm_combine(rlnamd_msm* m, const uint8_t* window_sums, size_t contrib
   RLN_CATCH
 }
 
-static void verify_common(const Zkey& zk, const uint8_t proof[128], const uint8_t values_le[160], int* ok) {
+static void verify_common(const Zkey& zk, const uint8_t proof[128], const uint8_t* values_le, int* ok, size_t nv) {
   G1Affine A, C;
   G2Affine B;
   *ok = 0;
   if (!g1_decompress(proof, &A) || !g2_decompress(proof + 32, &B) || !g1_decompress(proof + 96, &C))
     throw Error("Proof serialization error: the input buffer contained invalid data");
   std::vector<Fr> in;
-  for (int i = 0; i < 5; i++) {
+  for (size_t i = 0; i < nv; i++) {
     uint32_t c[8];
     memcpy(c, values_le + 32 * i, 32);
     if (limbs_geq(c, FrParams::MOD)) throw Error("Non-canonical field element: value is not in [0, r-1]");
     in.push_back(Fr::from_canonical(c));
   }
   *ok = groth16_verify(zk, A, B, C, in) ? 1 : 0;
+}
+
+size_t rlnamd_prover_num_public(rlnamd_prover* p) { return p->p->num_public(); }
+int rlnamd_prover_download_public(rlnamd_prover* p, size_t n, uint8_t* out_le) {
+  RLN_TRY
+  std::vector<uint8_t> v;
+  p->p->fetch_public(n, &v);
+  memcpy(out_le, v.data(), v.size());
+  RLN_CATCH
+}
+int rlnamd_verify_public(rlnamd_prover* p, const uint8_t proof[128], const uint8_t* values_le, size_t n_values, int* ok) {
+  RLN_TRY
+  verify_common(p->p->zkey(), proof, values_le, ok, n_values);
+  RLN_CATCH
 }
 
 int rlnamd_verify_with_zkey(const uint8_t* zkey, size_t zkey_len, const uint8_t proof[128],

@@ -77,6 +77,9 @@ class Prover {
   // stage times of the last run() in ms (HIP events on the prover stream)
   void stage_ms(float out[PROVER_STAGES]) const;
   // debug / parity taps (host copies, canonical LE): witness signals and h for proof p of the last run
+  // public signals w[1..num_instance) of the first n proofs of the last run, n x (num_instance-1) x 32 bytes
+  void fetch_public(size_t n, std::vector<uint8_t>* out_le);
+  size_t num_public() const { return (size_t)zk_.num_instance_variables - 1; }
   void fetch_witness(size_t p, std::vector<uint8_t>* w_le);
   void fetch_h(size_t p, std::vector<uint8_t>* h_le);
 

@@ -605,6 +605,16 @@ __global__ void __launch_bounds__(64) k_proof_values(const uint32_t* __restrict_
   ext.to_canonical(o + 32);
 }
 
+// public signals w[1..npub] of every proof straight from the witness (the circuit's own outputs; for the
+// single-message circuit they equal k_proof_values' y, root, nullifier, x, external_nullifier)
+__global__ void __launch_bounds__(256) k_public_signals(const Fr* __restrict__ V, const uint32_t* __restrict__ sig2node,
+                                                        uint32_t npub, uint32_t B, uint32_t nb, uint32_t* __restrict__ out) {
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  uint32_t k = blockIdx.y * blockDim.y + threadIdx.y;
+  if (p >= nb || k >= npub) return;
+  V[(size_t)sig2node[1 + k] * B + p].to_canonical(out + ((size_t)p * npub + k) * 8);
+}
+
 // gathers for the parity taps
 __global__ void k_gather_col(const Fr* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t count, uint32_t B,
                              uint32_t p, uint32_t* __restrict__ out) {
@@ -658,6 +668,7 @@ struct Prover::Impl {
   DevBuf<ChunkDesc> groups1, groups2, segs1, segs2;  // two-level reduction ranges
   uint32_t nchunks1 = 0, nchunks2 = 0, npts1 = 0, npts2 = 0, ngroups1 = 0, ngroups2 = 0;
   InputSlots slots{};
+  bool have_values_kernel = false;
   // resident inputs (shared by both slots; upload() drains the pipeline first)
   DevBuf<uint32_t> inputs, rs;
   Slot slot[2];
@@ -910,22 +921,24 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     build_table<Fq2>(pts, c_, W_, D.t2, s);
   }
 
-  // ---- named input slots for the proof-values kernel (single message-id circuit, witness.rs:832-881)
-  auto slot = [&](const char* name, uint32_t want_len) -> uint32_t {
-    auto it = graph_.input_mapping.find(name);
-    if (it == graph_.input_mapping.end()) throw Error(std::string("MissingInput: ") + name);
-    if (want_len && it->second.second != want_len)
-      throw Error(std::string("InvalidInputLength: ") + name);
-    return it->second.first;
-  };
-  D.slots.depth = graph_.tree_depth;
-  D.slots.secret = slot("identitySecret", 1);
-  D.slots.limit = slot("userMessageLimit", 1);
-  D.slots.msg_id = slot("messageId", 0);
-  D.slots.path = slot("pathElements", graph_.tree_depth);
-  D.slots.path_idx = slot("identityPathIndex", graph_.tree_depth);
-  D.slots.x = slot("x", 1);
-  D.slots.ext = slot("externalNullifier", 1);
+  // ---- named input slots for the proof-values kernel (single message-id circuit, witness.rs:832-881);
+  //      other circuits (multi message-id) take their public values from the witness instead
+  D.have_values_kernel = false;
+  {
+    auto find = [&](const char* name, uint32_t want_len, uint32_t* off) {
+      auto it = graph_.input_mapping.find(name);
+      if (it == graph_.input_mapping.end() || it->second.second != want_len) return false;
+      *off = it->second.first;
+      return true;
+    };
+    D.slots.depth = graph_.tree_depth;
+    bool ok = graph_.max_out == 1 && D.ni == 6;
+    ok = ok && find("identitySecret", 1, &D.slots.secret) && find("userMessageLimit", 1, &D.slots.limit) &&
+         find("messageId", 1, &D.slots.msg_id) && find("pathElements", graph_.tree_depth, &D.slots.path) &&
+         find("identityPathIndex", graph_.tree_depth, &D.slots.path_idx) && find("x", 1, &D.slots.x) &&
+         find("externalNullifier", 1, &D.slots.ext);
+    D.have_values_kernel = ok;
+  }
   poseidon_dev();
 
   // ---- workspace
@@ -1066,8 +1079,9 @@ void Prover::run_async(size_t n) {
   // proof values (Poseidon chain, latency-bound, depends on the inputs only): the back-end stream has slack
   if (S.used) RLN_HIP(hipStreamWaitEvent(D.sC, S.evC, 0));
   RLN_HIP(hipEventRecord(S.t[0], D.sC));
-  hipLaunchKernelGGL(k_proof_values, dim3(pg), dim3(64), 0, D.sC, D.inputs.p, D.NI, D.slots, poseidon_view(2),
-                     poseidon_view(3), poseidon_view(4), S.values.p, nbp);
+  if (D.have_values_kernel)
+    hipLaunchKernelGGL(k_proof_values, dim3(pg), dim3(64), 0, D.sC, D.inputs.p, D.NI, D.slots, poseidon_view(2),
+                       poseidon_view(3), poseidon_view(4), S.values.p, nbp);
   RLN_HIP(hipStreamWaitEvent(D.sC, S.evB, 0));
   RLN_HIP(hipEventRecord(S.t[9], D.sC));
   hipLaunchKernelGGL(k_sum_ranges<Fq>, dim3(pg, D.ngroups1), dim3(64), 0, D.sC, S.part1.p, D.groups1.p, D.ngroups1,
@@ -1126,6 +1140,19 @@ void Prover::download(size_t n, ProofOut* out) {
     memcpy(out[i].values, S.h_values + i * 40, 160);
     out[i].error = S.h_err[i];
   }
+}
+
+void Prover::fetch_public(size_t n, std::vector<uint8_t>* out_le) {
+  Impl& D = *d_;
+  sync();
+  if (!D.last || n > B_) throw Error("no resident run to read from");
+  const uint32_t npub = D.ni - 1;
+  DevBuf<uint32_t> tmp(n * npub * 8);
+  hipLaunchKernelGGL(k_public_signals, dim3(div_up(n, 64), div_up(npub, 4)), dim3(64, 4), 0, D.sC, D.last->V.p,
+                     D.sig2node.p, npub, (uint32_t)B_, (uint32_t)n, tmp.p);
+  out_le->resize(n * npub * 32);
+  RLN_HIP(hipMemcpyAsync(out_le->data(), tmp.p, out_le->size(), hipMemcpyDeviceToHost, D.sC));
+  RLN_HIP(hipStreamSynchronize(D.sC));
 }
 
 void Prover::fetch_witness(size_t p, std::vector<uint8_t>* w_le) {
