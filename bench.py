@@ -172,8 +172,10 @@ def main():
     import torch  # plumbing only: device selection, barrier, max-reduce
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # under torchrun the RCCL group is always created
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     from zerokit_amd import lib
@@ -194,7 +196,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -206,7 +208,7 @@ def main():
     prover.sync()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -262,7 +264,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(ws, rs)
         print(json.dumps(line))
     prover.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     if not ok:
         sys.exit(3)
