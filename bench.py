@@ -153,8 +153,8 @@ def msm_main(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("RLNAMD_BENCH_BATCH", "1024")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="proofs", choices=["proofs", "merkle", "msm"],
@@ -176,7 +176,7 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from zerokit_amd import lib
     from zerokit_amd._native import check
