@@ -199,6 +199,51 @@ def test_batch_vs_python_oracle_random(prover):
         assert rln.public_inputs(rln.proof_values_from_witness(wi)) == out[i]["public_inputs"]
 
 
+def test_full_size_batch_1024_bit_exact_vs_c_oracle():
+    """BASELINE config 2 at full size: all 1024 proofs of the bench workload are bit-identical to the C oracle
+    (proof bytes and public values), pipelined twice to cover both workspace slots, and a sample verifies."""
+    from oracle.c import binding as ob
+    from oracle.pyref import workload
+    from zerokit_amd.batch import BatchProver
+    n = 1024
+    ws, rs = workload.config2_witnesses(n)
+    p = BatchProver(max_batch=n)
+    p.upload(p.pack_inputs(ws), rs)
+    p.run_async(n)
+    p.run_async(n)          # second slot; must reproduce the same bytes
+    p.run_async(n)
+    out = p.download(n)
+    _, ref_proofs, ref_pub = ob.Circuit(20).prove_many(ws, rs)
+    assert all(o["error"] == 0 for o in out)
+    assert [o["proof"] for o in out] == ref_proofs
+    assert [o["public_inputs"] for o in out] == ref_pub
+    assert p.download_public(n) == ref_pub
+    for i in (0, 63, 64, 511, 1023):
+        assert p.verify(out[i]["proof"], out[i]["public_inputs"])
+    p.close()
+
+
+def test_edge_case_witnesses_vs_c_oracle(prover):
+    """boundary values of every input: zero / r-1 field elements, message_id = limit - 1, all-ones path index,
+    r = 0 (g1_b = 0 branch), s = 0, r = s = r_mod - 1"""
+    from oracle.c import binding as ob
+    base = dict(identity_secret=R - 1, user_message_limit=R - 1, message_id=R - 2, path_elements=[R - 1] * 20,
+                identity_path_index=[1] * 20, x=R - 1, external_nullifier=R - 1)
+    zero = dict(identity_secret=0, user_message_limit=1, message_id=0, path_elements=[0] * 20,
+                identity_path_index=[0] * 20, x=0, external_nullifier=0)
+    mixed = dict(identity_secret=1, user_message_limit=2, message_id=1, path_elements=[i for i in range(20)],
+                 identity_path_index=[i & 1 for i in range(20)], x=1 << 253, external_nullifier=(1 << 128) - 1)
+    ws = [base, zero, mixed, base, zero]
+    rs = [(1, 1), (0, 5), (7, 0), (R - 1, R - 1), (0, 0)]
+    out = prover.prove(ws, rs)
+    c = ob.Circuit(20)
+    for o, w, (r, s) in zip(out, ws, rs):
+        ref = c.prove(w, r, s)
+        assert o["error"] == 0
+        assert o["proof"] == ref["proof"] and o["public_inputs"] == ref["public_inputs"]
+        assert prover.verify(o["proof"], o["public_inputs"])
+
+
 def test_batch_is_order_and_size_independent(prover):
     """the same witness gives the same proof alone, in a batch, and at a different lane"""
     from oracle.pyref import workload
