@@ -1,0 +1,162 @@
+"""The reference's own FFI tests (rln/tests/ffi.rs) replayed through the zerokit C ABI of this backend
+(include/rln.h via zerokit_amd.public).  Needs the GPU: every tree update and proof runs HIP kernels."""
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+NO_OF_LEAVES = 64  # the reference uses 256; smaller keeps one-by-one insertion quick
+
+
+def _leaves(seed=1):
+    rnd = random.Random(seed)
+    return [rnd.randrange(R) for _ in range(NO_OF_LEAVES)]
+
+
+@pytest.fixture(scope="module")
+def rln():
+    from zerokit_amd.public import RLN
+    return RLN(20)
+
+
+def test_merkle_operations_ffi(rln):
+    """rln/tests/ffi.rs:119-196: single / next / batch insertion agree; deleting everything restores the
+    empty root"""
+    leaves = _leaves()
+    rln.set_tree(20)
+    root_empty = rln.get_root()
+    for i, l in enumerate(leaves):
+        rln.set_leaf(i, l)
+    root_single = rln.get_root()
+    rln.set_tree(20)
+    for l in leaves:
+        rln.set_next_leaf(l)
+    assert rln.get_root() == root_single
+    rln.set_tree(20)
+    rln.init_tree_with_leaves(leaves)
+    assert rln.get_root() == root_single
+    for i in range(NO_OF_LEAVES):
+        rln.delete_leaf(i)
+    assert rln.get_root() == root_empty
+    assert rln.leaves_set() == NO_OF_LEAVES          # delete never lowers next_index
+
+
+def test_leaf_setting_with_index_ffi(rln):
+    """ffi.rs:199-262"""
+    leaves = _leaves(2)
+    rln.set_tree(20)
+    assert rln.leaves_set() == 0
+    set_index = 23
+    rln.init_tree_with_leaves(leaves)
+    root_init = rln.get_root()
+    rln.init_tree_with_leaves(leaves[:set_index])
+    rln.set_leaves_from(set_index, leaves[set_index:])
+    assert rln.get_root() == root_init
+    rln.set_tree(20)
+    for l in leaves:
+        rln.set_next_leaf(l)
+    assert rln.get_root() == root_init
+
+
+def test_atomic_operation_ffi(rln):
+    """ffi.rs:265-295: deleting and re-setting the same last leaf is a no-op"""
+    leaves = _leaves(3)
+    rln.init_tree_with_leaves(leaves)
+    root = rln.get_root()
+    last = NO_OF_LEAVES - 1
+    rln.atomic_operation(last, [leaves[-1]], [last])
+    assert rln.get_root() == root
+    # delete two, add two (public.rs atomic_operation doc): indices before `start` are reset
+    rln.atomic_operation(last + 1, [7, 8], [last - 1, last])
+    assert rln.get_leaf(last + 1) == 7 and rln.get_leaf(last + 2) == 8 and rln.leaves_set() == last + 3
+
+
+def test_set_leaves_bad_index_ffi(rln):
+    """ffi.rs:298-322: a range that does not fit leaves the tree untouched"""
+    from zerokit_amd.public import RLNError
+    rln.set_tree(20)
+    root_empty = rln.get_root()
+    with pytest.raises(RLNError, match="too many leaves"):
+        rln.set_leaves_from((1 << 20) - 5, _leaves(4))
+    assert rln.get_root() == root_empty
+
+
+def test_rln_out_of_bounds_ffi(rln):
+    """ffi.rs:1070-1173"""
+    from zerokit_amd.public import RLNError
+    rln.set_tree(20)
+    cap = 1 << 20
+    for idx in (cap + 10, cap):
+        with pytest.raises(RLNError):
+            rln.set_leaf(idx, 123)
+        with pytest.raises(RLNError):
+            rln.get_merkle_proof(idx)
+        with pytest.raises(RLNError):
+            rln.get_leaf(idx)
+        with pytest.raises(RLNError):
+            rln.delete_leaf(idx)
+    with pytest.raises(RLNError):
+        rln.set_leaves_from(cap + 10, [1, 2])
+    with pytest.raises(RLNError):
+        rln.atomic_operation(cap + 10, [1], [cap + 10])
+    with pytest.raises(RLNError):
+        rln.atomic_operation(0, [1], [cap + 10])
+    with pytest.raises(RLNError):
+        rln.atomic_operation(0, [1, 2], [1])             # delete index after `start`
+    with pytest.raises(RLNError):
+        rln.atomic_operation((1 << 64) - 1, [1], [0])     # start + len overflows
+    rln.set_tree(4)
+    with pytest.raises(RLNError):
+        rln.init_tree_with_leaves(list(range(1, 18)))     # 17 leaves into 16 slots
+    for _ in range(16):
+        rln.set_next_leaf(3)
+    with pytest.raises(RLNError):
+        rln.set_next_leaf(3)                              # tree full
+    rln.set_tree(20)
+
+
+def test_get_leaf_and_metadata_ffi(rln):
+    """ffi.rs:763-860"""
+    rln.set_tree(20)
+    idx = 0xABCDE
+    rln.set_leaf(idx, 424242)
+    assert rln.get_leaf(idx) == 424242
+    assert rln.get_metadata() == b""
+    rln.set_metadata(bytes(range(10)))
+    assert rln.get_metadata() == bytes(range(10))
+
+
+def test_rln_invalid_witness_input_ffi():
+    """ffi.rs:986-1067: constructor validation errors surface as CResult.err strings"""
+    from zerokit_amd.public import RLNError, RLNWitnessInput
+    with pytest.raises(RLNError, match="cannot be zero"):
+        RLNWitnessInput(1, 0, 0, [0] * 20, [0] * 20, 1, 1)
+    with pytest.raises(RLNError, match="length mismatch"):
+        RLNWitnessInput(1, 5, 0, [0] * 20, [0] * 19, 1, 1)
+    with pytest.raises(RLNError, match="not within user_message_limit"):
+        RLNWitnessInput(1, 5, 5, [0] * 20, [0] * 20, 1, 1)
+
+
+def test_depth10_rln_object_with_params():
+    """ffi_rln_new_with_params (ffi.rs:425-470 pattern) with the shipped depth-10 resources"""
+    from zerokit_amd import hashers
+    from zerokit_amd.batch import resource_paths
+    from zerokit_amd.public import RLN, RLNError, RLNWitnessInput
+    zp, gp = resource_paths(10)
+    z, g = open(zp, "rb").read(), open(gp, "rb").read()
+    rln = RLN.new_with_params(10, z, g)
+    with pytest.raises(RLNError, match="depth"):
+        RLN.new_with_params(20, z, g)                     # graph_from_raw expected-depth check
+    with pytest.raises(RLNError):
+        RLN.new_with_params(10, b"", g)
+    secret = 99
+    rc = hashers.poseidon_hash_pair(hashers.poseidon_hash([secret]), 10)
+    rln.set_leaf(5, rc)
+    elems, bits = rln.get_merkle_proof(5)
+    assert len(elems) == 10 and bits == [1, 0, 1, 0, 0, 0, 0, 0, 0, 0]
+    w = RLNWitnessInput(secret, 10, 3, elems, bits, 1234, 5678)
+    p = rln.generate_rln_proof(w)
+    assert rln.verify_rln_proof(p, 1234)
+    assert p.values.root == rln.get_root()

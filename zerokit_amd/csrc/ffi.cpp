@@ -245,7 +245,8 @@ struct FFI_RLN {
     tree.get_node_host(tree.capacity() - 1 + index, r.le);
     return r;
   }
-  void del(size_t index) {  // :271-285
+  void del(size_t index) {  // :271-285; out-of-capacity indices are an error (rln/tests/ffi.rs:1087-1089)
+    if (index >= tree.capacity()) throw Error("Leaf index out of bounds");
     if (index < next_index) {
       set(index, cfr_from_u64(0));
       leaf_set[index] = 0;
