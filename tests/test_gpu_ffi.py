@@ -68,9 +68,13 @@ def test_atomic_operation_ffi(rln):
     last = NO_OF_LEAVES - 1
     rln.atomic_operation(last, [leaves[-1]], [last])
     assert rln.get_root() == root
-    # delete two, add two (public.rs atomic_operation doc): indices before `start` are reset
+    # Mixed delete + set with delete indices BEFORE `start`: the reference writes its merged buffer
+    # [default x (start - min_index) | new leaves] AT `start`, not at min_index (SURVEY Appendix C.1,
+    # full_merkle_tree.rs:251-268 / pm_tree_adapter.rs:460-473); the old leaves are only flagged empty.
     rln.atomic_operation(last + 1, [7, 8], [last - 1, last])
-    assert rln.get_leaf(last + 1) == 7 and rln.get_leaf(last + 2) == 8 and rln.leaves_set() == last + 3
+    assert [rln.get_leaf(last + k) for k in (1, 2, 3, 4)] == [0, 0, 7, 8]
+    assert rln.get_leaf(last) == leaves[-1] and rln.get_leaf(last - 1) == leaves[-2]
+    assert rln.leaves_set() == last + 5
 
 
 def test_set_leaves_bad_index_ffi(rln):
