@@ -233,8 +233,9 @@ __global__ void __launch_bounds__(256) k_matvec(CsrView A, CsrView Bm, const Fr*
                                                 const uint32_t* __restrict__ sig2node, uint32_t nc, uint32_t ni,
                                                 uint32_t n, Fr* __restrict__ abc, uint32_t B, uint32_t nb) {
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
-  uint32_t row = blockIdx.y * blockDim.y + threadIdx.y;
-  if (p >= nb || row >= n) return;
+  uint32_t row = __builtin_amdgcn_readfirstlane(blockIdx.y * blockDim.y + threadIdx.y);  // wave-uniform
+  if (row >= n) return;
+  if (p >= nb) return;
   Fr a = Fr::zero(), b = Fr::zero();
   if (row < nc) {
     for (uint32_t k = A.ptr[row]; k < A.ptr[row + 1]; k++) a = a + A.coef[k] * V[(size_t)A.col[k] * B + p];
@@ -253,14 +254,18 @@ __global__ void __launch_bounds__(256) k_matvec(CsrView A, CsrView Bm, const Fr*
 //    fft/ifft semantics; call sites qap.rs:69-90).  DIF takes natural order to bit-reversed, DIT takes
 //    bit-reversed back to natural, so iNTT(DIF) -> coset scale -> NTT(DIT) needs no reordering pass.
 // =====================================================================================================
+#ifndef RLN_NTT_WAVES
+#define RLN_NTT_WAVES 1
+#endif
 template <int K, bool DIF>
-__global__ void __launch_bounds__(256) k_ntt_pass(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0,
+__global__ void __launch_bounds__(256, RLN_NTT_WAVES) k_ntt_pass(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0,
                                                   const Fr* __restrict__ scale, uint32_t B, uint32_t nb) {
   constexpr int R = 1 << K;
   const uint32_t n = 1u << logn;
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
-  uint32_t g = blockIdx.y * blockDim.y + threadIdx.y;
-  if (p >= nb || g >= (n >> K)) return;
+  uint32_t g = __builtin_amdgcn_readfirstlane(blockIdx.y * blockDim.y + threadIdx.y);  // one group per wave
+  if (g >= (n >> K)) return;
+  if (p >= nb) return;
   Fr* x = data + (size_t)blockIdx.z * n * B + p;
   uint32_t stride, base;
   if (DIF) {
@@ -284,7 +289,9 @@ __global__ void __launch_bounds__(256) k_ntt_pass(Fr* __restrict__ data, const F
       if (m & half) continue;
       uint32_t j = (uint32_t)(m & (half - 1)) * stride + lo;
       uint32_t ti = DIF ? (j << (s0 + t)) : (j << (logn - 1 - (s0 + t)));
-      Fr w = tw[ti];
+      // the twiddle index is the same for all 64 lanes (lanes = proofs): force the scalar path so the
+      // twiddle rides in SGPRs instead of eight VGPRs per butterfly
+      Fr w = tw[__builtin_amdgcn_readfirstlane(ti)];
       if (DIF) {
         Fr u = e[m], v = e[m + half];
         e[m] = u + v;
@@ -300,7 +307,7 @@ __global__ void __launch_bounds__(256) k_ntt_pass(Fr* __restrict__ data, const F
   for (int m = 0; m < R; m++) {
     uint32_t pos = base + m * stride;
     Fr o = e[m];
-    if (scale) o = o * scale[pos];
+    if (scale) o = o * scale[__builtin_amdgcn_readfirstlane(pos)];
     x[(size_t)pos * B] = o;
   }
 }
@@ -1012,7 +1019,9 @@ static void launch_ntt(Fr* data, const Fr* tw, int logn, const Fr* final_scale, 
   int s0 = 0;
   while (s0 < logn) {
     int rem = logn - s0;
-    int K = rem > 4 ? 3 : rem;  // 13 -> 3,3,3,4
+    static const int maxk = env_int("RLNAMD_NTT_MAXK", 3);
+    int K = rem > maxk ? 3 : rem;  // 13 -> 3,3,3,3,1 (a 16-point block spills; measured 6.7 -> 5.0 ms)
+    if (K > maxk) K = maxk;
     uint32_t groups = (1u << logn) >> K;
     dim3 block(64, 4), grid(div_up(nb, 64), div_up(groups, 4), 3);
     const Fr* sc = (s0 + K == logn) ? final_scale : nullptr;
