@@ -5,8 +5,21 @@ import ctypes as C
 import os
 import subprocess
 
+import hashlib
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liboracle.so")
+
+
+def _cpu_tag():
+    """-march=native objects must not travel between machines: one library per CPU model"""
+    try:
+        model = next(l for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        model = "unknown"
+    return hashlib.sha1(model.encode()).hexdigest()[:10]
+
+
+_SO = os.path.join(_HERE, "liboracle_%s.so" % _cpu_tag())
 _RES = os.path.join(_HERE, "..", "..", "zerokit_amd", "resources")
 _lib = None
 
@@ -16,7 +29,8 @@ def lib():
     if _lib is None:
         src = os.path.join(_HERE, "rln_oracle.c")
         if not os.path.exists(_SO) or os.path.getmtime(src) > os.path.getmtime(_SO):
-            subprocess.check_call(["make", "-C", _HERE])
+            subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+                                   "-pthread", src, "-o", _SO])
         L = C.CDLL(_SO)
         L.oracle_load.restype = C.c_void_p
         L.oracle_load.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
