@@ -96,6 +96,21 @@ const char* rlnamd_prover_stage_name(int i);
 /* parity taps of the last run: full witness (num_signals*32) / h (domain_size*32) of proof `index` */
 int rlnamd_prover_fetch_witness(rlnamd_prover* p, size_t index, uint8_t* out_le);
 int rlnamd_prover_fetch_h(rlnamd_prover* p, size_t index, uint8_t* out_le);
+/* ---- partial proofs (generate_partial_zk_proof / finish_zk_proof_with_rs, protocol/proof.rs:783-849;
+ * Groth16Partial, partial_proof.rs:108-274).  mode: 0 full proof, 1 partial (inputs hold only identitySecret,
+ * userMessageLimit, pathElements, identityPathIndex; other slots zero), 2 finish (full inputs + r, s + the
+ * partial points given with rlnamd_prover_upload_partial).  A partial proof is four points per proof as
+ * canonical LE affine coordinates [pi_a x,y | rho x,y | pi_b x.c0,x.c1,y.c0,y.c1 | pi_c x,y] = 320 bytes;
+ * rlnamd_prover_known_mask returns, per witness signal, whether the partial witness fixes it
+ * (PartialProof::mask is this vector without entry 0). */
+#define RLNAMD_MODE_FULL 0
+#define RLNAMD_MODE_PARTIAL 1
+#define RLNAMD_MODE_FINISH 2
+int rlnamd_prover_run_mode(rlnamd_prover* p, size_t n, int mode);
+int rlnamd_prover_run_async_mode(rlnamd_prover* p, size_t n, int mode);
+int rlnamd_prover_upload_partial(rlnamd_prover* p, size_t n, const uint8_t* coords320);
+int rlnamd_prover_download_partial(rlnamd_prover* p, size_t n, uint8_t* coords320);
+int rlnamd_prover_known_mask(rlnamd_prover* p, uint8_t* out_num_signals);
 /* Public signals (the circuit outputs/inputs w[1..num_instance)) of the first n proofs of the last run, read
  * from the witness: n * num_public * 32 bytes.  Circuit-generic (multi message-id: ys, root, nullifiers, x,
  * external_nullifier, selector_used -- the verifier order of protocol/proof.rs:870-885). */

@@ -136,3 +136,63 @@ def verify(zk, proof, public_inputs):
     ic = G1.to_affine(ic)
     return pairing_product_is_one([
         (A, B), (G1.neg(zk.alpha_g1), zk.beta_g2), (G1.neg(ic), zk.gamma_g2), (G1.neg(C), zk.delta_g2)])
+
+
+def known_mask(graph, unknown_inputs=("messageId", "selectorUsed", "x", "externalNullifier")):
+    """evaluate_partial knownness (iden3calc/graph.rs:274-312) per witness signal for the partial witness of
+    protocol/witness.rs:887-937"""
+    unk = set()
+    for name in unknown_inputs:
+        if name in graph.input_mapping:
+            off, ln = graph.input_mapping[name]
+            unk.update(range(off, off + ln))
+    known = []
+    for n in graph.nodes:
+        k = n[0]
+        if k == "Const":
+            known.append(True)
+        elif k == "Input":
+            known.append(n[1] not in unk)
+        elif k == "Duo":
+            known.append(known[n[2]] and known[n[3]])
+        elif k == "Uno":
+            known.append(known[n[2]])
+        else:
+            known.append(known[n[2]] and known[n[3]] and known[n[4]])
+    return [known[s] for s in graph.signals]
+
+
+def prove_partial(zk, w, mask):
+    """create_partial_proof_from_assignment (partial_proof.rs:108-179); mask/w indexed by witness signal
+    (entry 0 = the constant 1).  -> (pi_a, rho, pi_b, pi_c) affine"""
+    ni = len(zk.gamma_abc_g1)
+    idx = [i for i in range(1, len(w)) if mask[i]]
+    a = G1.msm([zk.a_query[i] for i in idx], [w[i] for i in idx])
+    b1 = G1.msm([zk.b_g1_query[i] for i in idx], [w[i] for i in idx])
+    b2 = G2.msm([zk.b_g2_query[i] for i in idx], [w[i] for i in idx])
+    lidx = [i for i in idx if i >= ni]
+    lc = G1.msm([zk.l_query[i - ni] for i in lidx], [w[i] for i in lidx])
+    pi_a = G1.to_affine(_sum(G1, [zk.alpha_g1, zk.a_query[0], a]))
+    rho = G1.to_affine(_sum(G1, [zk.beta_g1, zk.b_g1_query[0], b1]))
+    pi_b = G2.to_affine(_sum(G2, [zk.beta_g2, zk.b_g2_query[0], b2]))
+    return pi_a, rho, pi_b, lc
+
+
+def finish_partial(zk, partial, w, mask, r, s):
+    """finish_partial_proof_with_assignment (partial_proof.rs:182-274) -> (A, B, C)"""
+    ni = len(zk.gamma_abc_g1)
+    pi_a, rho, pi_b, pi_c = partial
+    h = witness_map(zk, w)
+    idx = [i for i in range(1, len(w)) if not mask[i]]
+    a = G1.msm([zk.a_query[i] for i in idx], [w[i] for i in idx])
+    b1 = G1.msm([zk.b_g1_query[i] for i in idx], [w[i] for i in idx])
+    b2 = G2.msm([zk.b_g2_query[i] for i in idx], [w[i] for i in idx])
+    lidx = [i for i in idx if i >= ni]
+    l_rem = G1.msm([zk.l_query[i - ni] for i in lidx], [w[i] for i in lidx])
+    g_a = G1.to_affine(_sum(G1, [pi_a, a, G1.mul(zk.delta_g1, r)]))
+    g1_b = G1.to_affine(_sum(G1, [rho, b1, G1.mul(zk.delta_g1, s)])) if r % R else None
+    g2_b = G2.to_affine(_sum(G2, [pi_b, b2, G2.mul(zk.delta_g2, s)]))
+    h_acc = G1.msm(zk.h_query, h)
+    g_c = G1.to_affine(_sum(G1, [G1.mul(g_a, s), G1.mul(g1_b, r), G1.neg(G1.mul(zk.delta_g1, r * s % R)),
+                                 pi_c, l_rem, h_acc]))
+    return g_a, g2_b, g_c

@@ -380,3 +380,40 @@ def test_other_circuits_depth10_and_multi_message_id():
         if not c["multi"]:
             assert out[0]["public_inputs"] == pub[0]          # Poseidon-formula values == witness outputs
         p.close()
+
+
+# ------------------------------------------------------------------------------------------ partial proofs
+def test_partial_proof_then_finish_equals_full(prover):
+    """generate_partial_zk_proof + finish_zk_proof_with_rs == generate_zk_proof_with_rs
+    (rln/tests/protocol.rs:222-248, here for a batch and against the oracle):
+    the mask equals the oracle's evaluate_partial knownness, the four partial points equal the oracle's,
+    and finishing with (r, s) reproduces the full proof bytes and the golden vector."""
+    from oracle.pyref import groth16, rln, wtns_graph
+    cases = _cases()["cases"][:3]
+    ws = [_w(c) for c in cases]
+    rs = [(int(c["r"]), int(c["s"])) for c in cases]
+    zk, g = rln.load_circuit(20)
+    mask = groth16.known_mask(g)
+    assert prover.known_mask() == [1 if m else 0 for m in mask]
+    pws = [dict(identity_secret=w["identity_secret"], user_message_limit=w["user_message_limit"],
+                path_elements=w["path_elements"], identity_path_index=w["identity_path_index"]) for w in ws]
+    partials = prover.prove_partial(pws)
+    # oracle partial for the first witness
+    w0 = ws[0]
+    full = wtns_graph.calc_witness(g, rln.WitnessInput(w0["identity_secret"], w0["user_message_limit"],
+                                                       w0["message_id"], w0["path_elements"],
+                                                       w0["identity_path_index"], w0["x"],
+                                                       w0["external_nullifier"]).named_inputs())
+    pa, rho, pb, pc = groth16.prove_partial(zk, full, mask)
+    want = b"".join(v.to_bytes(32, "little") for v in (pa[0], pa[1], rho[0], rho[1], pb[0][0], pb[0][1], pb[1][0],
+                                                        pb[1][1], pc[0], pc[1]))
+    assert partials[0] == want
+    out = prover.finish(ws, rs, partials)
+    full_out = prover.prove(ws, rs)
+    for o, f, c in zip(out, full_out, cases):
+        assert o["proof"] == f["proof"] == bytes.fromhex(c["proof_compressed"])
+        assert o["public_inputs"] == f["public_inputs"]
+    # the partial proof is message-independent: reuse it for a different message of the same member
+    w_new = dict(ws[1], x=ws[1]["x"] ^ 1, message_id=2, external_nullifier=7)
+    o = prover.finish([w_new], [(5, 6)], [partials[1]])[0]
+    assert o["proof"] == prover.prove([w_new], [(5, 6)])[0]["proof"] and prover.verify(o["proof"], o["public_inputs"])

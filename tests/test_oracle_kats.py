@@ -185,3 +185,15 @@ def test_multi_message_id_circuit_internal_oracle():
     full = wtns_graph.calc_witness(g, w)
     assert full[1:16] == rln.proof_values_multi(987654321, 10, w["messageId"], sel, w["pathElements"],
                                                 w["identityPathIndex"], 77, 88)
+
+
+@pytest.mark.slow
+def test_partial_then_finish_equals_full_proof(circuit20):
+    """rln/tests/protocol.rs:222-248: partial + finish == full proof for r = 44, s = 77"""
+    zk, g = circuit20
+    mask = groth16.known_mask(g)
+    assert sum(mask) == 5339 and mask[0] and not mask[1] and mask[2]      # root is known, y is not
+    w = rln.WitnessInput(12345, 100, 1, [0] * 20, [0] * 20, 42, 100)
+    full = wtns_graph.calc_witness(g, w.named_inputs())
+    part = groth16.prove_partial(zk, full, mask)
+    assert groth16.finish_partial(zk, part, full, mask, 44, 77) == groth16.prove(zk, full, 44, 77)

@@ -87,6 +87,11 @@ SIGNATURES = {
     "rlnamd_prover_run": (C.c_int, [P, C.c_size_t]),
     "rlnamd_prover_run_async": (C.c_int, [P, C.c_size_t]),
     "rlnamd_prover_sync": (C.c_int, [P]),
+    "rlnamd_prover_run_mode": (C.c_int, [P, C.c_size_t, C.c_int]),
+    "rlnamd_prover_run_async_mode": (C.c_int, [P, C.c_size_t, C.c_int]),
+    "rlnamd_prover_upload_partial": (C.c_int, [P, C.c_size_t, C.c_char_p]),
+    "rlnamd_prover_download_partial": (C.c_int, [P, C.c_size_t, C.c_char_p]),
+    "rlnamd_prover_known_mask": (C.c_int, [P, C.c_char_p]),
     "rlnamd_prover_download": (C.c_int, [P, C.c_size_t, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint32)]),
     "rlnamd_prover_stage_ms": (C.c_int, [P, C.POINTER(C.c_float)]),
     "rlnamd_prover_stage_name": (C.c_char_p, [C.c_int]),

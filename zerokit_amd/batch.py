@@ -131,6 +131,35 @@ class BatchProver:
         self.run(n)
         return self.download(n)
 
+    # ---- partial proofs (protocol/proof.rs:783-849)
+    def known_mask(self):
+        buf = C.create_string_buffer(int(self.info.num_signals))
+        check(lib().rlnamd_prover_known_mask(self._h, buf))
+        return list(buf.raw)
+
+    def prove_partial(self, partial_witnesses):
+        """partial_witnesses: dicts with identity_secret, user_message_limit, path_elements,
+        identity_path_index.  -> list of 320-byte partial proofs (pi_a | rho | pi_b | pi_c, affine LE)."""
+        full = [dict(w, message_id=0, x=0, external_nullifier=0) for w in partial_witnesses]
+        n = self.upload(self.pack_inputs(full), [(0, 0)] * len(full))
+        check(lib().rlnamd_prover_run_mode(self._h, n, 1))
+        buf = C.create_string_buffer(320 * n)
+        check(lib().rlnamd_prover_download_partial(self._h, n, buf))
+        return [buf.raw[320 * i:320 * (i + 1)] for i in range(n)]
+
+    def upload_partial(self, partials):
+        check(lib().rlnamd_prover_upload_partial(self._h, len(partials), b"".join(partials)))
+
+    def finish(self, witnesses, rs, partials):
+        """finish_zk_proof_with_rs for a batch: only the message-dependent rows + h + blinding are walked"""
+        n = self.upload(self.pack_inputs(witnesses), rs)
+        self.upload_partial(partials)
+        check(lib().rlnamd_prover_run_mode(self._h, n, 2))
+        return self.download(n)
+
+    def run_async_mode(self, n, mode):
+        check(lib().rlnamd_prover_run_async_mode(self._h, n, mode))
+
     def download_public(self, n):
         """public signals w[1..] of the first n proofs of the last run, from the witness (circuit-generic)"""
         buf = C.create_string_buffer(32 * self.num_public * n)

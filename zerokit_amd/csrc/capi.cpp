@@ -245,6 +245,32 @@ int rlnamd_prover_sync(rlnamd_prover* p) {
   p->p->sync();
   RLN_CATCH
 }
+int rlnamd_prover_run_mode(rlnamd_prover* p, size_t n, int mode) {
+  RLN_TRY
+  p->p->run(n, mode);
+  RLN_CATCH
+}
+int rlnamd_prover_run_async_mode(rlnamd_prover* p, size_t n, int mode) {
+  RLN_TRY
+  p->p->run_async(n, mode);
+  RLN_CATCH
+}
+int rlnamd_prover_upload_partial(rlnamd_prover* p, size_t n, const uint8_t* coords320) {
+  RLN_TRY
+  p->p->upload_partial(n, coords320);
+  RLN_CATCH
+}
+int rlnamd_prover_download_partial(rlnamd_prover* p, size_t n, uint8_t* coords320) {
+  RLN_TRY
+  p->p->download_partial(n, coords320);
+  RLN_CATCH
+}
+int rlnamd_prover_known_mask(rlnamd_prover* p, uint8_t* out) {
+  RLN_TRY
+  const std::vector<uint8_t>& m = p->p->known_mask();
+  memcpy(out, m.data(), m.size());
+  RLN_CATCH
+}
 int rlnamd_prover_download(rlnamd_prover* p, size_t n, uint8_t* proofs, uint8_t* coords, uint8_t* values,
                            uint32_t* errors) {
   RLN_TRY

@@ -30,6 +30,9 @@
 namespace rlnamd {
 
 constexpr int PROVER_STAGES = 8;
+// Walks over the fixed-base tables (partial_proof.rs:108-274): the whole proof, the part fixed by a partial
+// witness (secret, limit, Merkle path), or the remainder given the partial points.
+enum ProveMode { PROVE_FULL = 0, PROVE_PARTIAL = 1, PROVE_FINISH = 2 };
 extern const char* const kProverStageNames[PROVER_STAGES];
 
 struct ProverConfig {
@@ -61,12 +64,21 @@ class Prover {
   // slot 0 = 1, iden3calc.rs:122-181); rs = n x 2 x 32 bytes (r, s).  Copies to the device.
   void upload(size_t n, const uint8_t* inputs, const uint8_t* rs);
   // Runs the whole pipeline on the resident inputs and waits for it.
-  void run(size_t n);
+  void run(size_t n, int mode = PROVE_FULL);
   // Same, but only enqueues: consecutive calls overlap (batch k+1's witness/NTT front end and batch k-1's
   // finalize back end run beside batch k's MSM on separate HIP streams; two workspace slots).  Every
   // batch ends with its proofs + values copied to pinned host memory.  sync() drains the pipeline.
-  void run_async(size_t n);
+  void run_async(size_t n, int mode = PROVE_FULL);
   void sync();
+  // Partial proofs.  PROVE_PARTIAL: inputs carry only the partial witness (unknown slots zero); the result is
+  // four points per proof, canonical affine [pi_a x,y | rho x,y | pi_b x.c0,x.c1,y.c0,y.c1 | pi_c x,y] = 320 B
+  // (create_partial_proof_from_assignment, partial_proof.rs:108-179).  PROVE_FINISH: full inputs + (r, s) +
+  // the partial points uploaded with upload_partial (finish_partial_proof_with_assignment, :182-274).
+  void upload_partial(size_t n, const uint8_t* coords320);
+  void download_partial(size_t n, uint8_t* coords320);
+  // per witness signal (length = number of signals): 1 when fixed by the partial witness (PartialProof::mask
+  // is this vector without its first entry)
+  const std::vector<uint8_t>& known_mask() const;
   void download(size_t n, ProofOut* out);
   // convenience
   void prove(size_t n, const uint8_t* inputs, const uint8_t* rs, ProofOut* out) {

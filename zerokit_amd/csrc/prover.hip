@@ -374,9 +374,9 @@ struct ChunkDesc {
 
 template <class F>
 __global__ void __launch_bounds__(64) k_msm(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ sid,
-                                            const ChunkDesc* __restrict__ chunks, uint32_t nchunks,
-                                            const int16_t* __restrict__ digits, XYZZ<F>* __restrict__ part, int c,
-                                            int W, uint32_t B, uint32_t pgroups) {
+                                            const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks,
+                                            uint32_t nchunks, const int16_t* __restrict__ digits,
+                                            XYZZ<F>* __restrict__ part, int c, int W, uint32_t B, uint32_t pgroups) {
   // XCD-aware decode: hardware places block L on XCD L % 8; all proof groups of one chunk share the same
   // table rows, so they are given consecutive slots on ONE XCD and meet in that XCD's L2.
   uint32_t L = blockIdx.x;
@@ -388,7 +388,8 @@ __global__ void __launch_bounds__(64) k_msm(const Affine<F>* __restrict__ table,
   XYZZ<F> acc = XYZZ<F>::inf();
   const int cs = c - 1;
 #pragma unroll 1
-  for (uint32_t k = cd.pt_begin; k < cd.pt_end; k++) {
+  for (uint32_t i = cd.pt_begin; i < cd.pt_end; i++) {
+    const uint32_t k = rows[i];  // table row; the walk (full / partial / finish) is a list of rows
     const int16_t* dg = digits + (size_t)sid[k] * W * B + p;
     const Affine<F>* row = table + (((size_t)k * W) << cs);
 #pragma unroll 1
@@ -477,6 +478,48 @@ __device__ __forceinline__ bool fq_is_neg_dev(const Fq& y) {
   return limbs_gt(c, FqParams::HALF);
 }
 __device__ __forceinline__ void store_fq(uint32_t* dst, const Fq& x) { x.to_canonical(dst); }
+
+// Partial proofs (partial_proof.rs:108-179, 182-274).  k_partial_out: the four sums of the "known" walk leave as
+// canonical affine coordinates [pi_a | rho | pi_b | pi_c] (320 B).  k_add_partial: the same four points, given
+// back with the full witness, are added to the sums of the "unknown + H + blinding" walk before finalize.
+__global__ void __launch_bounds__(64) k_partial_out(const G1XYZZ* __restrict__ sums1, const G2XYZZ* __restrict__ sums2,
+                                                    uint32_t* __restrict__ out, uint32_t B, uint32_t nb) {
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= nb) return;
+  uint32_t* o = out + (size_t)p * 80;
+  const uint32_t t = blockIdx.y;  // 0 pi_a, 1 rho, 2 pi_c, 3 pi_b
+  if (t < 3) {
+    G1Affine a = sums1[(size_t)t * B + p].to_affine();
+    uint32_t* d = o + (t == 0 ? 0 : t == 1 ? 16 : 64);
+    a.x.to_canonical(d);
+    a.y.to_canonical(d + 8);
+  } else {
+    G2Affine b = sums2[p].to_affine();
+    b.x.c0.to_canonical(o + 32);
+    b.x.c1.to_canonical(o + 40);
+    b.y.c0.to_canonical(o + 48);
+    b.y.c1.to_canonical(o + 56);
+  }
+}
+__global__ void __launch_bounds__(64) k_add_partial(G1XYZZ* __restrict__ sums1, G2XYZZ* __restrict__ sums2,
+                                                    const uint32_t* __restrict__ pp, uint32_t B, uint32_t nb) {
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= nb) return;
+  const uint32_t* o = pp + (size_t)p * 80;
+  const uint32_t t = blockIdx.y;
+  if (t < 3) {
+    const uint32_t* d = o + (t == 0 ? 0 : t == 1 ? 16 : 64);
+    G1Affine a{Fq::from_canonical(d), Fq::from_canonical(d + 8)};
+    G1XYZZ acc = sums1[(size_t)t * B + p];
+    acc.madd(a);
+    sums1[(size_t)t * B + p] = acc;
+  } else {
+    G2Affine b{{Fq::from_canonical(o + 32), Fq::from_canonical(o + 40)}, {Fq::from_canonical(o + 48), Fq::from_canonical(o + 56)}};
+    G2XYZZ acc = sums2[p];
+    acc.madd(b);
+    sums2[p] = acc;
+  }
+}
 
 // F1: the three MSM sums that become proof elements go to affine form in parallel (one inversion each)
 __global__ void __launch_bounds__(64) k_fin_affine(const G1XYZZ* __restrict__ sums1, const G2XYZZ* __restrict__ sums2,
@@ -646,6 +689,9 @@ struct Slot {
   DevBuf<G2XYZZ> part2, grp2, sums2;
   DevBuf<G1Affine> affA, affB1;
   DevBuf<G2Affine> affB2;
+  DevBuf<uint32_t> pp_out;       // partial mode output, 320 B per proof
+  uint32_t* h_pp = nullptr;
+  int mode = 0;
   uint8_t* h_comp = nullptr;    // pinned: every run ends with the proofs + values copied to the host
   uint32_t* h_values = nullptr;
   uint32_t* h_err = nullptr;
@@ -671,9 +717,17 @@ struct Prover::Impl {
   DevBuf<G1Affine> t1;
   DevBuf<G2Affine> t2;
   DevBuf<uint32_t> sid1, sid2;
-  DevBuf<ChunkDesc> chunks1, chunks2;
-  DevBuf<ChunkDesc> groups1, groups2, segs1, segs2;  // two-level reduction ranges
-  uint32_t nchunks1 = 0, nchunks2 = 0, npts1 = 0, npts2 = 0, ngroups1 = 0, ngroups2 = 0;
+  // a walk = a list of table rows cut into chunks, plus the two-level reduction ranges; one per mode
+  struct Plan {
+    DevBuf<uint32_t> rows;
+    DevBuf<ChunkDesc> chunks, groups, segs;
+    uint32_t nchunks = 0, ngroups = 0, nseg = 0;
+  };
+  Plan plan1[3], plan2[3];  // [PROVE_FULL, PROVE_PARTIAL, PROVE_FINISH]
+  uint32_t max_chunks1 = 0, max_chunks2 = 0, max_groups1 = 0, max_groups2 = 0;
+  uint32_t npts1 = 0, npts2 = 0;
+  std::vector<uint8_t> known;  // per witness signal: computable from the partial witness (evaluate_partial)
+  DevBuf<uint32_t> pp_in;      // resident partial-proof points for finish mode, 320 B per proof
   InputSlots slots{};
   bool have_values_kernel = false;
   // resident inputs (shared by both slots; upload() drains the pipeline first)
@@ -842,89 +896,116 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     RLN_HIP(hipStreamSynchronize(s));
   }
 
+  // ---- which witness signals are fixed by the partial witness (evaluate_partial, graph.rs:274-312): a node
+  //      is known iff all its operands are; the unknown inputs are the per-message ones
+  //      (inputs_for_partial_witness_calculation, witness.rs:887-937)
+  {
+    std::vector<uint8_t> in_known(D.NI, 1), node_known(D.N, 0);
+    for (const char* name : {"messageId", "selectorUsed", "x", "externalNullifier"}) {
+      auto it = graph_.input_mapping.find(name);
+      if (it == graph_.input_mapping.end()) continue;
+      for (uint32_t k = 0; k < it->second.second; k++) in_known[it->second.first + k] = 0;
+    }
+    for (uint32_t i = 0; i < D.N; i++) {
+      const GNode& nd = graph_.nodes[i];
+      bool k;
+      if (nd.op == G_INPUT) k = in_known[nd.a];
+      else if (nd.op == G_CONST) k = true;
+      else if (nd.op == G_NEG || nd.op == G_ID) k = node_known[nd.a];
+      else if (nd.op == G_TERN) k = node_known[nd.a] && node_known[nd.b] && node_known[nd.c];
+      else k = node_known[nd.a] && node_known[nd.b];
+      node_known[i] = k;
+    }
+    D.known.resize(D.NS);
+    for (uint32_t i = 0; i < D.NS; i++) D.known[i] = node_known[graph_.signals[i]];
+  }
+
   // ---- MSM segments.  Scalar ids: [0, NS) witness, [NS, NS+n) h, then r, s, -(r s).
+  //      Every table row belongs to one output segment; the three walks are subsets of the rows:
+  //      full = all, partial = rows whose scalar is a known witness signal (incl. w_0 = 1, which carries
+  //      alpha / beta / query[0]), finish = the rest (unknown signals, h, blinding terms).
   const uint32_t SID_R = D.NS + D.n, SID_S = SID_R + 1, SID_NRS = SID_R + 2;
-  const uint32_t chunk_pts = (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK", 8));
+  auto make_plans = [&](const std::vector<uint32_t>& sids, const std::vector<uint32_t>& row_seg, uint32_t nseg,
+                        uint32_t chunk_pts, Impl::Plan* plans, uint32_t* max_chunks, uint32_t* max_groups) {
+    for (int mode = 0; mode < 3; mode++) {
+      std::vector<uint32_t> rows, segfirst;
+      std::vector<ChunkDesc> chunks;
+      for (uint32_t sg = 0; sg < nseg; sg++) {
+        segfirst.push_back((uint32_t)chunks.size());
+        uint32_t first = (uint32_t)rows.size();
+        for (uint32_t k = 0; k < sids.size(); k++) {
+          if (row_seg[k] != sg) continue;
+          bool is_known = sids[k] < D.NS && D.known[sids[k]];
+          if (mode == PROVE_FULL || (mode == PROVE_PARTIAL) == is_known) rows.push_back(k);
+        }
+        for (uint32_t k = first; k < rows.size(); k += chunk_pts)
+          chunks.push_back({k, (uint32_t)std::min<size_t>(k + chunk_pts, rows.size())});
+      }
+      segfirst.push_back((uint32_t)chunks.size());
+      std::vector<ChunkDesc> groups, segs;
+      make_reduce_ranges(segfirst, groups, segs);
+      Impl::Plan& P = plans[mode];
+      P.nchunks = (uint32_t)chunks.size();
+      P.ngroups = (uint32_t)groups.size();
+      P.nseg = nseg;
+      P.rows.alloc(std::max<size_t>(rows.size(), 1));
+      P.chunks.alloc(std::max<size_t>(chunks.size(), 1));
+      P.groups.alloc(std::max<size_t>(groups.size(), 1));
+      P.segs.alloc(segs.size());
+      if (!rows.empty()) P.rows.upload(rows.data(), rows.size(), s);
+      if (!chunks.empty()) P.chunks.upload(chunks.data(), chunks.size(), s);
+      if (!groups.empty()) P.groups.upload(groups.data(), groups.size(), s);
+      P.segs.upload(segs.data(), segs.size(), s);
+      RLN_HIP(hipStreamSynchronize(s));
+      *max_chunks = std::max(*max_chunks, P.nchunks);
+      *max_groups = std::max(*max_groups, P.ngroups);
+    }
+  };
   {
     std::vector<G1Affine> pts;
-    std::vector<uint32_t> sids, segfirst;
-    std::vector<ChunkDesc> chunks;
-    auto begin_seg = [&]() { segfirst.push_back((uint32_t)chunks.size()); return (uint32_t)pts.size(); };
-    auto end_seg = [&](uint32_t first) {
-      for (uint32_t k = first; k < pts.size(); k += chunk_pts)
-        chunks.push_back({k, (uint32_t)std::min<size_t>(k + chunk_pts, pts.size())});
-    };
-    auto push = [&](const G1Affine& P, uint32_t sid) {
+    std::vector<uint32_t> sids, row_seg;
+    auto push = [&](const G1Affine& P, uint32_t sid, uint32_t seg) {
       if (P.is_inf()) return;
       pts.push_back(P);
       sids.push_back(sid);
+      row_seg.push_back(seg);
     };
-    // A = alpha + sum_i w_i A_i + r delta      (w_0 = 1 carries a_query[0] and alpha)
-    uint32_t f = begin_seg();
-    for (uint32_t i = 0; i < D.NS; i++) push(zk_.a_query[i], i);
-    push(zk_.alpha_g1, 0);
-    push(zk_.delta_g1, SID_R);
-    end_seg(f);
-    // B1 = beta + sum_i w_i B_i + s delta
-    f = begin_seg();
-    for (uint32_t i = 0; i < D.NS; i++) push(zk_.b_g1_query[i], i);
-    push(zk_.beta_g1, 0);
-    push(zk_.delta_g1, SID_S);
-    end_seg(f);
-    // Cpart = sum_j w_(ni+j) L_j + sum_k h_k H_k - (r s) delta
-    f = begin_seg();
-    for (uint32_t j = 0; j < zk_.l_query.size(); j++) push(zk_.l_query[j], D.ni + j);
-    for (uint32_t k = 0; k < D.n; k++) push(zk_.h_query[k], D.NS + k);
-    push(zk_.delta_g1, SID_NRS);
-    end_seg(f);
-    segfirst.push_back((uint32_t)chunks.size());
+    // seg 0: A = alpha + sum_i w_i A_i + r delta      (w_0 = 1 carries a_query[0] and alpha)
+    for (uint32_t i = 0; i < D.NS; i++) push(zk_.a_query[i], i, 0);
+    push(zk_.alpha_g1, 0, 0);
+    push(zk_.delta_g1, SID_R, 0);
+    // seg 1: B1 = beta + sum_i w_i B_i + s delta
+    for (uint32_t i = 0; i < D.NS; i++) push(zk_.b_g1_query[i], i, 1);
+    push(zk_.beta_g1, 0, 1);
+    push(zk_.delta_g1, SID_S, 1);
+    // seg 2: Cpart = sum_j w_(ni+j) L_j + sum_k h_k H_k - (r s) delta
+    for (uint32_t j = 0; j < zk_.l_query.size(); j++) push(zk_.l_query[j], D.ni + j, 2);
+    for (uint32_t k = 0; k < D.n; k++) push(zk_.h_query[k], D.NS + k, 2);
+    push(zk_.delta_g1, SID_NRS, 2);
     D.npts1 = (uint32_t)pts.size();
-    D.nchunks1 = (uint32_t)chunks.size();
     D.sid1.alloc(sids.size());
     D.sid1.upload(sids.data(), sids.size(), s);
-    D.chunks1.alloc(chunks.size());
-    D.chunks1.upload(chunks.data(), chunks.size(), s);
-    std::vector<ChunkDesc> groups, segs;
-    make_reduce_ranges(segfirst, groups, segs);
-    D.ngroups1 = (uint32_t)groups.size();
-    D.groups1.alloc(groups.size());
-    D.groups1.upload(groups.data(), groups.size(), s);
-    D.segs1.alloc(segs.size());
-    D.segs1.upload(segs.data(), segs.size(), s);
-    RLN_HIP(hipStreamSynchronize(s));
+    make_plans(sids, row_seg, 3, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK", 8)), D.plan1, &D.max_chunks1,
+               &D.max_groups1);
     build_table<Fq>(pts, c_, W_, D.t1, s);
   }
   {
-    const uint32_t chunk2 = (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_G2", 4));
     std::vector<G2Affine> pts;
-    std::vector<uint32_t> sids, segfirst;
-    std::vector<ChunkDesc> chunks;
+    std::vector<uint32_t> sids, row_seg;
     auto push = [&](const G2Affine& P, uint32_t sid) {
       if (P.is_inf()) return;
       pts.push_back(P);
       sids.push_back(sid);
+      row_seg.push_back(0);
     };
-    segfirst.push_back(0);
     for (uint32_t i = 0; i < D.NS; i++) push(zk_.b_g2_query[i], i);
     push(zk_.beta_g2, 0);
     push(zk_.delta_g2, SID_S);
-    for (uint32_t k = 0; k < pts.size(); k += chunk2)
-      chunks.push_back({k, (uint32_t)std::min<size_t>(k + chunk2, pts.size())});
-    segfirst.push_back((uint32_t)chunks.size());
     D.npts2 = (uint32_t)pts.size();
-    D.nchunks2 = (uint32_t)chunks.size();
     D.sid2.alloc(sids.size());
     D.sid2.upload(sids.data(), sids.size(), s);
-    D.chunks2.alloc(chunks.size());
-    D.chunks2.upload(chunks.data(), chunks.size(), s);
-    std::vector<ChunkDesc> groups, segs;
-    make_reduce_ranges(segfirst, groups, segs);
-    D.ngroups2 = (uint32_t)groups.size();
-    D.groups2.alloc(groups.size());
-    D.groups2.upload(groups.data(), groups.size(), s);
-    D.segs2.alloc(segs.size());
-    D.segs2.upload(segs.data(), segs.size(), s);
-    RLN_HIP(hipStreamSynchronize(s));
+    make_plans(sids, row_seg, 1, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_G2", 4)), D.plan2, &D.max_chunks2,
+               &D.max_groups2);
     build_table<Fq2>(pts, c_, W_, D.t2, s);
   }
 
@@ -952,6 +1033,8 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   const size_t B = B_;
   D.inputs.alloc(B * D.NI * 8);
   D.rs.alloc(B * 16);
+  D.pp_in.alloc(B * 80);
+  RLN_HIP(hipMemsetAsync(D.pp_in.p, 0, D.pp_in.bytes(), s));
   RLN_HIP(hipMemsetAsync(D.inputs.p, 0, D.inputs.bytes(), s));
   RLN_HIP(hipMemsetAsync(D.rs.p, 0, D.rs.bytes(), s));
   for (Slot& S : D.slot) {
@@ -962,17 +1045,19 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     S.V.alloc((size_t)D.N * B);
     S.abc.alloc(3 * (size_t)D.n * B);
     S.digits.alloc((size_t)(D.NS + D.n + 3) * W_ * B);
-    S.part1.alloc((size_t)D.nchunks1 * B);
-    S.grp1.alloc((size_t)D.ngroups1 * B);
+    S.part1.alloc((size_t)D.max_chunks1 * B);
+    S.grp1.alloc((size_t)D.max_groups1 * B);
     S.sums1.alloc(3 * B);
-    S.part2.alloc((size_t)D.nchunks2 * B);
-    S.grp2.alloc((size_t)D.ngroups2 * B);
+    S.part2.alloc((size_t)D.max_chunks2 * B);
+    S.grp2.alloc((size_t)D.max_groups2 * B);
     S.sums2.alloc(B);
     S.prod.alloc(2 * B);
     S.tbl.alloc(2 * 16 * B);
     S.affA.alloc(B);
     S.affB1.alloc(B);
     S.affB2.alloc(B);
+    S.pp_out.alloc(B * 80);
+    RLN_HIP(hipHostMalloc((void**)&S.h_pp, B * 320, hipHostMallocDefault));
     RLN_HIP(hipHostMalloc((void**)&S.h_comp, B * 128, hipHostMallocDefault));
     RLN_HIP(hipHostMalloc((void**)&S.h_values, B * 160, hipHostMallocDefault));
     RLN_HIP(hipHostMalloc((void**)&S.h_err, B * 4, hipHostMallocDefault));
@@ -991,6 +1076,7 @@ Prover::~Prover() {
   for (hipStream_t st : {D.sA, D.sB, D.sC})
     if (st) (void)hipStreamSynchronize(st);
   for (Slot& S : D.slot) {
+    if (S.h_pp) (void)hipHostFree(S.h_pp);
     if (S.h_comp) (void)hipHostFree(S.h_comp);
     if (S.h_values) (void)hipHostFree(S.h_values);
     if (S.h_err) (void)hipHostFree(S.h_err);
@@ -1039,11 +1125,15 @@ static void launch_ntt(Fr* data, const Fr* tw, int logn, const Fr* final_scale, 
 // Enqueue one batch; returns as soon as the work is queued.  Stage A (stream sA): proof values, witness,
 // matvec, NTTs.  Stage B (sB): digit recoding and the two MSMs.  Stage C (sC): two-level reduction, the
 // three finalize kernels, D2H of proofs + values into pinned memory.  Consecutive batches alternate slots.
-void Prover::run_async(size_t n) {
+void Prover::run_async(size_t n, int mode) {
   if (n == 0) return;
   if (n > B_) throw Error("batch larger than the prover workspace (max_batch)");
+  if (mode < PROVE_FULL || mode > PROVE_FINISH) throw Error("unknown prover mode");
   Impl& D = *d_;
+  const Impl::Plan& P1 = D.plan1[mode];
+  const Impl::Plan& P2 = D.plan2[mode];
   Slot& S = D.slot[D.cur];
+  S.mode = mode;
   D.cur ^= 1;
   const uint32_t B = (uint32_t)B_, nb = (uint32_t)n;
   const uint32_t pg = div_up(nb, 64);
@@ -1054,15 +1144,17 @@ void Prover::run_async(size_t n) {
   hipLaunchKernelGGL(k_witness, dim3(pg), dim3(64), 0, D.sA, D.nodes.p, D.N, D.consts.p, D.inputs.p, D.NI, S.V.p,
                      S.err.p, B, nbp);
   RLN_HIP(hipEventRecord(S.t[2], D.sA));
-  {
+  if (mode != PROVE_PARTIAL) {  // the quotient h depends on the whole witness: not part of a partial proof
     CsrView A{D.a_ptr.p, D.a_col.p, D.a_coef.p}, Bm{D.b_ptr.p, D.b_col.p, D.b_coef.p};
     hipLaunchKernelGGL(k_matvec, dim3(pg, div_up(D.n, 4)), dim3(64, 4), 0, D.sA, A, Bm, S.V.p, D.sig2node.p, D.nc,
                        D.ni, D.n, S.abc.p, B, nbp);
   }
   RLN_HIP(hipEventRecord(S.t[3], D.sA));
-  launch_ntt<true>(S.abc.p, D.tw_i.p, D.logn, D.coset.p, B, nbp, D.sA);  // iNTT (DIF) + g^i / n
-  launch_ntt<false>(S.abc.p, D.tw_f.p, D.logn, nullptr, B, nbp, D.sA);   // NTT (DIT)
-  hipLaunchKernelGGL(k_hquot, dim3(pg, div_up(D.n, 4)), dim3(64, 4), 0, D.sA, S.abc.p, D.n, B, nbp);
+  if (mode != PROVE_PARTIAL) {
+    launch_ntt<true>(S.abc.p, D.tw_i.p, D.logn, D.coset.p, B, nbp, D.sA);  // iNTT (DIF) + g^i / n
+    launch_ntt<false>(S.abc.p, D.tw_f.p, D.logn, nullptr, B, nbp, D.sA);   // NTT (DIT)
+    hipLaunchKernelGGL(k_hquot, dim3(pg, div_up(D.n, 4)), dim3(64, 4), 0, D.sA, S.abc.p, D.n, B, nbp);
+  }
   RLN_HIP(hipEventRecord(S.t[4], D.sA));
   RLN_HIP(hipEventRecord(S.evA, D.sA));
   // ---------------- stage B
@@ -1071,16 +1163,16 @@ void Prover::run_async(size_t n) {
   hipLaunchKernelGGL(k_recode, dim3(pg, div_up(D.NS + D.n + 3, 4)), dim3(64, 4), 0, D.sB, S.V.p, D.sig2node.p, D.NS,
                      S.abc.p, D.n, D.rs.p, c_, W_, S.digits.p, B, nbp);
   RLN_HIP(hipEventRecord(S.t[6], D.sB));
-  {
-    uint32_t blocks = div_up(D.nchunks1, 8) * 8 * pg;
-    hipLaunchKernelGGL(k_msm<Fq>, dim3(blocks), dim3(64), 0, D.sB, D.t1.p, D.sid1.p, D.chunks1.p, D.nchunks1,
-                       S.digits.p, S.part1.p, c_, W_, B, pg);
+  if (P1.nchunks) {
+    uint32_t blocks = div_up(P1.nchunks, 8) * 8 * pg;
+    hipLaunchKernelGGL(k_msm<Fq>, dim3(blocks), dim3(64), 0, D.sB, D.t1.p, D.sid1.p, P1.rows.p, P1.chunks.p,
+                       P1.nchunks, S.digits.p, S.part1.p, c_, W_, B, pg);
   }
   RLN_HIP(hipEventRecord(S.t[7], D.sB));
-  {
-    uint32_t blocks = div_up(D.nchunks2, 8) * 8 * pg;
-    hipLaunchKernelGGL(k_msm<Fq2>, dim3(blocks), dim3(64), 0, D.sB, D.t2.p, D.sid2.p, D.chunks2.p, D.nchunks2,
-                       S.digits.p, S.part2.p, c_, W_, B, pg);
+  if (P2.nchunks) {
+    uint32_t blocks = div_up(P2.nchunks, 8) * 8 * pg;
+    hipLaunchKernelGGL(k_msm<Fq2>, dim3(blocks), dim3(64), 0, D.sB, D.t2.p, D.sid2.p, P2.rows.p, P2.chunks.p,
+                       P2.nchunks, S.digits.p, S.part2.p, c_, W_, B, pg);
   }
   RLN_HIP(hipEventRecord(S.t[8], D.sB));
   RLN_HIP(hipEventRecord(S.evB, D.sB));
@@ -1093,20 +1185,31 @@ void Prover::run_async(size_t n) {
                        poseidon_view(3), poseidon_view(4), S.values.p, nbp);
   RLN_HIP(hipStreamWaitEvent(D.sC, S.evB, 0));
   RLN_HIP(hipEventRecord(S.t[9], D.sC));
-  hipLaunchKernelGGL(k_sum_ranges<Fq>, dim3(pg, D.ngroups1), dim3(64), 0, D.sC, S.part1.p, D.groups1.p, D.ngroups1,
-                     S.grp1.p, B, nbp);
-  hipLaunchKernelGGL(k_sum_ranges<Fq2>, dim3(pg, D.ngroups2), dim3(64), 0, D.sC, S.part2.p, D.groups2.p, D.ngroups2,
-                     S.grp2.p, B, nbp);
-  hipLaunchKernelGGL(k_sum_ranges<Fq>, dim3(pg, 3), dim3(64), 0, D.sC, S.grp1.p, D.segs1.p, 3u, S.sums1.p, B, nbp);
-  hipLaunchKernelGGL(k_sum_ranges<Fq2>, dim3(pg, 1), dim3(64), 0, D.sC, S.grp2.p, D.segs2.p, 1u, S.sums2.p, B, nbp);
-  hipLaunchKernelGGL(k_fin_affine, dim3(pg, 3), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
-                     S.affB2.p, B, nbp);
-  hipLaunchKernelGGL(k_fin_smul, dim3(pg, 2), dim3(64), 0, D.sC, S.affA.p, S.affB1.p, D.rs.p, S.tbl.p, S.prod.p, B, nbp);
-  hipLaunchKernelGGL(k_fin_out, dim3(pg), dim3(64), 0, D.sC, S.sums1.p, S.prod.p, S.affA.p, S.affB2.p, S.coords.p,
-                     S.comp.p, B, nbp);
-  RLN_HIP(hipGetLastError());
-  RLN_HIP(hipMemcpyAsync(S.h_comp, S.comp.p, n * 128, hipMemcpyDeviceToHost, D.sC));
-  RLN_HIP(hipMemcpyAsync(S.h_values, S.values.p, n * 160, hipMemcpyDeviceToHost, D.sC));
+  if (P1.ngroups)
+    hipLaunchKernelGGL(k_sum_ranges<Fq>, dim3(pg, P1.ngroups), dim3(64), 0, D.sC, S.part1.p, P1.groups.p, P1.ngroups,
+                       S.grp1.p, B, nbp);
+  if (P2.ngroups)
+    hipLaunchKernelGGL(k_sum_ranges<Fq2>, dim3(pg, P2.ngroups), dim3(64), 0, D.sC, S.part2.p, P2.groups.p, P2.ngroups,
+                       S.grp2.p, B, nbp);
+  hipLaunchKernelGGL(k_sum_ranges<Fq>, dim3(pg, 3), dim3(64), 0, D.sC, S.grp1.p, P1.segs.p, 3u, S.sums1.p, B, nbp);
+  hipLaunchKernelGGL(k_sum_ranges<Fq2>, dim3(pg, 1), dim3(64), 0, D.sC, S.grp2.p, P2.segs.p, 1u, S.sums2.p, B, nbp);
+  if (mode == PROVE_PARTIAL) {
+    hipLaunchKernelGGL(k_partial_out, dim3(pg, 4), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, S.pp_out.p, B, nbp);
+    RLN_HIP(hipGetLastError());
+    RLN_HIP(hipMemcpyAsync(S.h_pp, S.pp_out.p, n * 320, hipMemcpyDeviceToHost, D.sC));
+  } else {
+    if (mode == PROVE_FINISH)
+      hipLaunchKernelGGL(k_add_partial, dim3(pg, 4), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, D.pp_in.p, B, nbp);
+    hipLaunchKernelGGL(k_fin_affine, dim3(pg, 3), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
+                       S.affB2.p, B, nbp);
+    hipLaunchKernelGGL(k_fin_smul, dim3(pg, 2), dim3(64), 0, D.sC, S.affA.p, S.affB1.p, D.rs.p, S.tbl.p, S.prod.p, B,
+                       nbp);
+    hipLaunchKernelGGL(k_fin_out, dim3(pg), dim3(64), 0, D.sC, S.sums1.p, S.prod.p, S.affA.p, S.affB2.p, S.coords.p,
+                       S.comp.p, B, nbp);
+    RLN_HIP(hipGetLastError());
+    RLN_HIP(hipMemcpyAsync(S.h_comp, S.comp.p, n * 128, hipMemcpyDeviceToHost, D.sC));
+    RLN_HIP(hipMemcpyAsync(S.h_values, S.values.p, n * 160, hipMemcpyDeviceToHost, D.sC));
+  }
   RLN_HIP(hipMemcpyAsync(S.h_err, S.err.p, n * 4, hipMemcpyDeviceToHost, D.sC));
   RLN_HIP(hipEventRecord(S.t[10], D.sC));
   RLN_HIP(hipEventRecord(S.evC, D.sC));
@@ -1125,10 +1228,27 @@ void Prover::sync() {
   }
 }
 
-void Prover::run(size_t n) {
-  run_async(n);
+void Prover::run(size_t n, int mode) {
+  run_async(n, mode);
   sync();
 }
+
+void Prover::upload_partial(size_t n, const uint8_t* coords320) {
+  if (n > B_) throw Error("batch larger than the prover workspace (max_batch)");
+  Impl& D = *d_;
+  D.sync_all();
+  RLN_HIP(hipMemcpyAsync(D.pp_in.p, coords320, n * 320, hipMemcpyHostToDevice, D.sA));
+  RLN_HIP(hipStreamSynchronize(D.sA));
+}
+
+void Prover::download_partial(size_t n, uint8_t* coords320) {
+  Impl& D = *d_;
+  sync();
+  if (!D.last || D.last->mode != PROVE_PARTIAL || n > D.last->n) throw Error("the last run was not a partial-proof run");
+  memcpy(coords320, D.last->h_pp, n * 320);
+}
+
+const std::vector<uint8_t>& Prover::known_mask() const { return d_->known; }
 
 void Prover::stage_ms(float out[PROVER_STAGES]) const {
   for (int i = 0; i < PROVER_STAGES; i++) out[i] = d_->ms[i];
