@@ -13,8 +13,8 @@
  *  - CFr is opaque; elements of a Vec_CFr_t are contiguous CFr values reachable through ffi_vec_cfr_get
  *    (ffi_utils.rs:183-185).  In this implementation a CFr is the 32-byte little-endian canonical value.
  *
- * Scope: single message-id circuit, in-memory tree.  Not exported: the ffi_rln_v3_* mirror,
- * partial proofs, multi message-id witnesses, seeded keygen and the sled/pmtree persistence (§8f "next").
+ * Scope: single message-id circuit, in-memory tree, full and partial proofs.  Not exported: the
+ * ffi_rln_v3_* mirror, multi message-id witness types, seeded keygen and the sled/pmtree persistence (§8f).
  * Extensions that the reference lacks are marked EXT (deterministic blinding, batch).
  */
 #ifndef RLN_H
@@ -33,6 +33,8 @@ typedef struct FFI_RLN FFI_RLN_t;                         /* ffi_rln.rs:16-18 */
 typedef struct FFI_RLNProof FFI_RLNProof_t;               /* ffi_rln.rs:153-155 */
 typedef struct FFI_RLNWitnessInput FFI_RLNWitnessInput_t; /* ffi_rln.rs:322-324 */
 typedef struct FFI_RLNProofValues FFI_RLNProofValues_t;   /* ffi_rln.rs:714-716 */
+typedef struct FFI_RLNPartialWitnessInput FFI_RLNPartialWitnessInput_t; /* ffi_rln.rs:562-564 */
+typedef struct FFI_RLNPartialProof FFI_RLNPartialProof_t; /* ffi_rln.rs:239-241 */
 
 typedef struct Vec_uint8 { uint8_t* ptr; size_t len; size_t cap; } Vec_uint8_t;
 typedef struct Vec_CFr { CFr_t* ptr; size_t len; size_t cap; } Vec_CFr_t;
@@ -46,6 +48,8 @@ typedef struct { FFI_RLNProof_t* ok; Vec_uint8_t err; } CResult_FFI_RLNProof_ptr
 typedef struct { FFI_RLNWitnessInput_t* ok; Vec_uint8_t err; } CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t;
 typedef struct { FFI_RLNProofValues_t* ok; Vec_uint8_t err; } CResult_FFI_RLNProofValues_ptr_Vec_uint8_t;
 typedef struct { FFI_MerkleProof_t* ok; Vec_uint8_t err; } CResult_FFI_MerkleProof_ptr_Vec_uint8_t;
+typedef struct { FFI_RLNPartialWitnessInput_t* ok; Vec_uint8_t err; } CResult_FFI_RLNPartialWitnessInput_ptr_Vec_uint8_t;
+typedef struct { FFI_RLNPartialProof_t* ok; Vec_uint8_t err; } CResult_FFI_RLNPartialProof_ptr_Vec_uint8_t;
 typedef struct { CFr_t* ok; Vec_uint8_t err; } CResult_CFr_ptr_Vec_uint8_t;
 typedef struct { Vec_CFr_t ok; Vec_uint8_t err; } CResult_Vec_CFr_Vec_uint8_t;
 typedef struct { Vec_uint8_t ok; Vec_uint8_t err; } CResult_Vec_uint8_Vec_uint8_t;
@@ -100,6 +104,28 @@ CResult_Vec_uint8_Vec_uint8_t ffi_rln_witness_to_bytes_be(FFI_RLNWitnessInput_t*
 CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t ffi_bytes_le_to_rln_witness(const Vec_uint8_t* b); /* ffi_rln.rs:509 */
 CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t ffi_bytes_be_to_rln_witness(const Vec_uint8_t* b); /* ffi_rln.rs:525 */
 void ffi_rln_witness_input_free(FFI_RLNWitnessInput_t* w);                                     /* ffi_rln.rs:557 */
+
+/* ---- partial proofs (proof split: precompute the member-dependent part, finish per message) ----------- */
+CResult_FFI_RLNPartialWitnessInput_ptr_Vec_uint8_t ffi_rln_partial_witness_input_new(
+    const CFr_t* identity_secret, const CFr_t* user_message_limit, const Vec_CFr_t* path_elements,
+    const Vec_uint8_t* identity_path_index);                                                    /* ffi_rln.rs:567-592 */
+FFI_RLNPartialWitnessInput_t* ffi_rln_witness_to_partial_witness(FFI_RLNWitnessInput_t* const* w); /* ffi_rln.rs:636 */
+void ffi_rln_partial_witness_input_free(FFI_RLNPartialWitnessInput_t* w);                       /* ffi_rln.rs:708 */
+CResult_FFI_RLNPartialProof_ptr_Vec_uint8_t ffi_generate_partial_zk_proof(
+    FFI_RLN_t* const* rln, FFI_RLNPartialWitnessInput_t* const* partial_witness);               /* ffi_rln.rs:922-936 */
+CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_finish_rln_proof(FFI_RLN_t* const* rln, FFI_RLNPartialProof_t* const* partial,
+                                                          FFI_RLNWitnessInput_t* const* witness); /* ffi_rln.rs:939-960 */
+/* EXT: finish_zk_proof_with_rs (protocol/proof.rs:821-849) */
+CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_finish_rln_proof_with_rs(FFI_RLN_t* const* rln,
+                                                                  FFI_RLNPartialProof_t* const* partial,
+                                                                  FFI_RLNWitnessInput_t* const* witness,
+                                                                  const CFr_t* r, const CFr_t* s);
+uint8_t ffi_rln_partial_proof_get_version_byte(FFI_RLNPartialProof_t* const* partial);          /* ffi_rln.rs:245 */
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_partial_proof_to_bytes_le(FFI_RLNPartialProof_t* const* partial); /* ffi_rln.rs:252 */
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_partial_proof_to_bytes_be(FFI_RLNPartialProof_t* const* partial); /* ffi_rln.rs:289 */
+CResult_FFI_RLNPartialProof_ptr_Vec_uint8_t ffi_bytes_le_to_rln_partial_proof(const Vec_uint8_t* bytes); /* ffi_rln.rs:268 */
+CResult_FFI_RLNPartialProof_ptr_Vec_uint8_t ffi_bytes_be_to_rln_partial_proof(const Vec_uint8_t* bytes); /* ffi_rln.rs:305 */
+void ffi_rln_partial_proof_free(FFI_RLNPartialProof_t* partial);                                /* ffi_rln.rs:284 */
 
 /* ---- proof values ---------------------------------------------------------------------------------- */
 CFr_t* ffi_rln_proof_values_get_root(FFI_RLNProofValues_t* const* pv);                         /* ffi_rln.rs:719 */

@@ -164,3 +164,35 @@ def test_depth10_rln_object_with_params():
     p = rln.generate_rln_proof(w)
     assert rln.verify_rln_proof(p, 1234)
     assert p.values.root == rln.get_root()
+
+
+def test_partial_and_finish_proof_ffi():
+    """rln/tests/ffi.rs:1176-1291 + :1294-1393: partial proof, finish, serialisation round trip (6 011 bytes,
+    SURVEY Appendix B), and partial + finish == full for fixed (r, s) (protocol.rs:222-248)"""
+    from zerokit_amd import hashers
+    from zerokit_amd.public import RLN, RLNError, RLNPartialProof, RLNPartialWitnessInput, RLNWitnessInput
+    rln = RLN(20)
+    secret = hashers.hash_to_field_le(b"partial-member")
+    rc = hashers.poseidon_hash_pair(hashers.poseidon_hash([secret]), 100)
+    rln.set_leaf(7, rc)
+    elems, bits = rln.get_merkle_proof(7)
+    pw = RLNPartialWitnessInput(secret, 100, elems, bits)
+    pp = rln.generate_partial_zk_proof(pw)
+    raw = pp.to_bytes_le()
+    assert len(raw) == 6011 and raw[0] == 0 and raw[1:9] == (5843).to_bytes(8, "little")
+    pp2 = RLNPartialProof.from_bytes_le(raw)
+    assert pp2.to_bytes_le() == raw
+    with pytest.raises(RLNError):
+        RLNPartialProof.from_bytes_le(raw[:-1])
+    for msg_id, x in ((1, 111), (2, 222)):                 # one partial proof, many messages
+        w = RLNWitnessInput(secret, 100, msg_id, elems, bits, x, 999)
+        p_fin = rln.finish_rln_proof_with_rs(pp2, w, 44, 77)
+        p_full = rln.generate_rln_proof_with_rs(w, 44, 77)
+        assert p_fin.to_bytes_le() == p_full.to_bytes_le()
+        assert rln.verify_rln_proof(rln.finish_rln_proof(pp, w), x)
+    pw2 = RLNPartialWitnessInput.from_witness(w)
+    assert rln.generate_partial_zk_proof(pw2).to_bytes_le() == raw
+    with pytest.raises(RLNError, match="cannot be zero"):
+        RLNPartialWitnessInput(secret, 0, elems, bits)
+    with pytest.raises(RLNError, match="path_elements"):
+        rln.generate_partial_zk_proof(RLNPartialWitnessInput(secret, 100, elems[:10], bits[:10]))

@@ -145,6 +145,18 @@ SIGNATURES = {
     "ffi_bytes_le_to_rln_witness": (CResultPtr, [C.POINTER(VecU8)]),
     "ffi_bytes_be_to_rln_witness": (CResultPtr, [C.POINTER(VecU8)]),
     "ffi_rln_witness_input_free": (None, [P]),
+    "ffi_rln_partial_witness_input_new": (CResultPtr, [CFRP, CFRP, C.POINTER(VecCFr), C.POINTER(VecU8)]),
+    "ffi_rln_witness_to_partial_witness": (P, [PP]),
+    "ffi_rln_partial_witness_input_free": (None, [P]),
+    "ffi_generate_partial_zk_proof": (CResultPtr, [PP, PP]),
+    "ffi_finish_rln_proof": (CResultPtr, [PP, PP, PP]),
+    "ffi_finish_rln_proof_with_rs": (CResultPtr, [PP, PP, PP, CFRP, CFRP]),
+    "ffi_rln_partial_proof_get_version_byte": (C.c_uint8, [PP]),
+    "ffi_rln_partial_proof_to_bytes_le": (CResultVecU8, [PP]),
+    "ffi_rln_partial_proof_to_bytes_be": (CResultVecU8, [PP]),
+    "ffi_bytes_le_to_rln_partial_proof": (CResultPtr, [C.POINTER(VecU8)]),
+    "ffi_bytes_be_to_rln_partial_proof": (CResultPtr, [C.POINTER(VecU8)]),
+    "ffi_rln_partial_proof_free": (None, [P]),
     "ffi_rln_proof_values_get_root": (CFRP, [PP]),
     "ffi_rln_proof_values_get_x": (CFRP, [PP]),
     "ffi_rln_proof_values_get_external_nullifier": (CFRP, [PP]),

@@ -212,6 +212,16 @@ struct FFI_RLNProof {
   FFI_RLNProofValues values;
 };
 
+struct FFI_RLNPartialWitnessInput {  // RLNPartialWitnessInput (protocol/witness.rs:62-73)
+  CFr identity_secret, user_message_limit;
+  std::vector<CFr> path_elements;
+  std::vector<uint8_t> identity_path_index;
+};
+struct FFI_RLNPartialProof {  // PartialProof (partial_proof.rs:31-43): mask + four points (affine, canonical LE)
+  std::vector<uint8_t> mask;  // per assignment entry (witness signals 1..)
+  uint8_t coords[320];        // pi_a | rho | pi_b | pi_c
+};
+
 struct FFI_RLN {
   std::unique_ptr<Prover> prover;
   MerkleTreeDev tree;
@@ -385,6 +395,124 @@ void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CF
   for (size_t i = 0; i < n; i++) out[i] = made[i];
 }
 
+bool g2_in_subgroup(const G2Affine& p) {  // [r]P == 0 (ark-serialize Validate::Yes)
+  return scalar_mul(p, FrParams::MOD).is_inf();
+}
+void fill_outputs(const ProofOut& po, FFI_RLNProof* pr) {
+  memcpy(pr->proof, po.compressed, 128);
+  memcpy(pr->values.y.le, po.values[0], 32);
+  memcpy(pr->values.root.le, po.values[1], 32);
+  memcpy(pr->values.nullifier.le, po.values[2], 32);
+  memcpy(pr->values.x.le, po.values[3], 32);
+  memcpy(pr->values.external_nullifier.le, po.values[4], 32);
+}
+
+// generate_partial_zk_proof (proof.rs:783-803)
+FFI_RLNPartialProof* prove_partial(FFI_RLN& rln, const FFI_RLNPartialWitnessInput& pw) {
+  Prover& P = *rln.prover;
+  size_t d = P.graph().tree_depth;
+  if (pw.path_elements.size() != d)
+    throw Error("The field path_elements has length " + std::to_string(pw.path_elements.size()) +
+                ", but the field tree_depth has length " + std::to_string(d));
+  FFI_RLNWitnessInput w;
+  w.identity_secret = pw.identity_secret;
+  w.user_message_limit = pw.user_message_limit;
+  w.message_id = cfr_from_u64(0);
+  w.path_elements = pw.path_elements;
+  w.identity_path_index = pw.identity_path_index;
+  w.x = cfr_from_u64(0);
+  w.external_nullifier = cfr_from_u64(0);
+  std::vector<uint8_t> inputs(P.inputs_per_proof() * 32), rs(64, 0);
+  fill_inputs(P, w, inputs.data());
+  P.upload(1, inputs.data(), rs.data());
+  P.run(1, PROVE_PARTIAL);
+  std::unique_ptr<FFI_RLNPartialProof> pp(new FFI_RLNPartialProof);
+  P.download_partial(1, pp->coords);
+  const std::vector<uint8_t>& known = P.known_mask();
+  pp->mask.assign(known.begin() + 1, known.end());
+  return pp.release();
+}
+
+// finish_zk_proof_with_rs (proof.rs:821-849) + proof values
+FFI_RLNProof* finish_proof(FFI_RLN& rln, const FFI_RLNPartialProof& pp, const FFI_RLNWitnessInput& w, const CFr& r,
+                           const CFr& s) {
+  Prover& P = *rln.prover;
+  check_against_graph(P, w);
+  const std::vector<uint8_t>& known = P.known_mask();
+  if (pp.mask.size() + 1 != known.size() || !std::equal(pp.mask.begin(), pp.mask.end(), known.begin() + 1))
+    throw Error("Error producing proof: the partial proof's mask does not match this circuit (malformed verifying key)");
+  std::vector<uint8_t> inputs(P.inputs_per_proof() * 32), rs(64);
+  fill_inputs(P, w, inputs.data());
+  memcpy(rs.data(), r.le, 32);
+  memcpy(rs.data() + 32, s.le, 32);
+  P.upload(1, inputs.data(), rs.data());
+  P.upload_partial(1, pp.coords);
+  P.run(1, PROVE_FINISH);
+  ProofOut po;
+  P.download(1, &po);
+  if (po.error) throw Error("Error calculating witness: graph evaluation failed (code " + std::to_string(po.error) + ")");
+  std::unique_ptr<FFI_RLNProof> pr(new FFI_RLNProof);
+  fill_outputs(po, pr.get());
+  return pr.release();
+}
+
+std::vector<uint8_t> partial_proof_bytes(const FFI_RLNPartialProof& pp) {  // proof.rs:535-547 (always LE)
+  std::vector<uint8_t> b;
+  b.push_back(0x00);
+  put_u64(b, pp.mask.size(), false);
+  b.insert(b.end(), pp.mask.begin(), pp.mask.end());
+  auto fq = [&](int k) {
+    uint32_t c[8];
+    memcpy(c, pp.coords + 32 * k, 32);
+    return Fq::from_canonical(c);
+  };
+  uint8_t buf[64];
+  g1_compress(G1Affine{fq(0), fq(1)}, buf);
+  b.insert(b.end(), buf, buf + 32);
+  g1_compress(G1Affine{fq(2), fq(3)}, buf);
+  b.insert(b.end(), buf, buf + 32);
+  g2_compress(G2Affine{{fq(4), fq(5)}, {fq(6), fq(7)}}, buf);
+  b.insert(b.end(), buf, buf + 64);
+  g1_compress(G1Affine{fq(8), fq(9)}, buf);
+  b.insert(b.end(), buf, buf + 32);
+  return b;
+}
+FFI_RLNPartialProof* partial_proof_from_bytes(const Vec_uint8_t* bytes) {  // proof.rs:552-572
+  if (!bytes || bytes->len == 0) throw Error("Expected to read 1 bytes but read 0 bytes");
+  const uint8_t* d = bytes->ptr;
+  if (d[0] > 1) {
+    char buf[8];
+    snprintf(buf, sizeof buf, "%#04x", d[0]);
+    throw Error(std::string("Unknown message mode version byte: ") + buf);
+  }
+  Cursor c{d, bytes->len, 1, false};
+  uint64_t k = c.len();
+  if (k > bytes->len) c.need((size_t)-1 - c.o);
+  c.need((size_t)k + 160);
+  std::unique_ptr<FFI_RLNPartialProof> pp(new FFI_RLNPartialProof);
+  pp->mask.assign(d + c.o, d + c.o + k);
+  for (uint8_t m : pp->mask)
+    if (m > 1) throw Error("Proof serialization error: the input buffer contained invalid data");
+  c.o += k;
+  G1Affine a, rho, pc;
+  G2Affine pb;
+  if (!g1_decompress(d + c.o, &a) || !g1_decompress(d + c.o + 32, &rho) || !g2_decompress(d + c.o + 64, &pb) ||
+      !g1_decompress(d + c.o + 128, &pc) || !g2_in_subgroup(pb))
+    throw Error("Proof serialization error: the input buffer contained invalid data");
+  c.o += 160;
+  if (c.o != bytes->len)
+    throw Error("Expected to read " + std::to_string(c.o) + " bytes but read " + std::to_string(bytes->len) + " bytes");
+  auto st = [&](int k2, const Fq& v) {
+    uint32_t w[8];
+    v.to_canonical(w);
+    memcpy(pp->coords + 32 * k2, w, 32);
+  };
+  st(0, a.x); st(1, a.y); st(2, rho.x); st(3, rho.y);
+  st(4, pb.x.c0); st(5, pb.x.c1); st(6, pb.y.c0); st(7, pb.y.c1);
+  st(8, pc.x); st(9, pc.y);
+  return pp.release();
+}
+
 bool verify_zk(FFI_RLN& rln, const FFI_RLNProof& pr) {  // verify_zk_proof (proof.rs:856-894)
   G1Affine A, C;
   G2Affine B;
@@ -426,9 +554,6 @@ FFI_RLNProofValues values_from(Cursor& c) {  // proof.rs:285-411
   v.y = c.fr();
   v.nullifier = c.fr();
   return v;
-}
-bool g2_in_subgroup(const G2Affine& p) {  // [r]P == 0 (ark-serialize Validate::Yes)
-  return scalar_mul(p, FrParams::MOD).is_inf();
 }
 FFI_RLNProof* proof_from_bytes(const Vec_uint8_t* bytes, bool be) {  // proof.rs:455-530
   if (!bytes || bytes->len == 0) throw Error("Expected to read 1 bytes but read 0 bytes");
@@ -649,6 +774,72 @@ CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_bytes_be_to_rln_proof(const Vec_uint8_t
       [&]() -> FFI_RLNProof_t* { return (FFI_RLNProof_t*)proof_from_bytes(bytes, true); });
 }
 void ffi_rln_proof_free(FFI_RLNProof_t* proof) { delete (FFI_RLNProof*)proof; }
+
+// ================================================================================ partial proofs
+CResult_FFI_RLNPartialWitnessInput_ptr_Vec_uint8_t ffi_rln_partial_witness_input_new(
+    const CFr_t* identity_secret, const CFr_t* user_message_limit, const Vec_CFr_t* path_elements,
+    const Vec_uint8_t* identity_path_index) {
+  return guard_ptr<CResult_FFI_RLNPartialWitnessInput_ptr_Vec_uint8_t>([&]() -> FFI_RLNPartialWitnessInput_t* {
+    std::unique_ptr<FFI_RLNPartialWitnessInput> w(new FFI_RLNPartialWitnessInput);
+    w->identity_secret = R(identity_secret);
+    w->user_message_limit = R(user_message_limit);
+    w->path_elements.assign((const CFr*)path_elements->ptr, (const CFr*)path_elements->ptr + path_elements->len);
+    w->identity_path_index.assign(identity_path_index->ptr, identity_path_index->ptr + identity_path_index->len);
+    if (cfr_is_zero(w->user_message_limit)) throw Error("User message limit cannot be zero");  // witness.rs:253-270
+    if (w->path_elements.size() != w->identity_path_index.size())
+      throw Error("Merkle proof length mismatch: expected " + std::to_string(w->path_elements.size()) + ", got " +
+                  std::to_string(w->identity_path_index.size()));
+    return (FFI_RLNPartialWitnessInput_t*)w.release();
+  });
+}
+FFI_RLNPartialWitnessInput_t* ffi_rln_witness_to_partial_witness(FFI_RLNWitnessInput_t* const* w) {
+  const FFI_RLNWitnessInput& f = *(FFI_RLNWitnessInput*)*w;
+  FFI_RLNPartialWitnessInput* p = new FFI_RLNPartialWitnessInput;
+  p->identity_secret = f.identity_secret;
+  p->user_message_limit = f.user_message_limit;
+  p->path_elements = f.path_elements;
+  p->identity_path_index = f.identity_path_index;
+  return (FFI_RLNPartialWitnessInput_t*)p;
+}
+void ffi_rln_partial_witness_input_free(FFI_RLNPartialWitnessInput_t* w) { delete (FFI_RLNPartialWitnessInput*)w; }
+CResult_FFI_RLNPartialProof_ptr_Vec_uint8_t ffi_generate_partial_zk_proof(
+    FFI_RLN_t* const* rln, FFI_RLNPartialWitnessInput_t* const* partial_witness) {
+  return guard_ptr<CResult_FFI_RLNPartialProof_ptr_Vec_uint8_t>([&]() -> FFI_RLNPartialProof_t* {
+    return (FFI_RLNPartialProof_t*)prove_partial(*(FFI_RLN*)*rln, *(FFI_RLNPartialWitnessInput*)*partial_witness);
+  });
+}
+CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_finish_rln_proof(FFI_RLN_t* const* rln, FFI_RLNPartialProof_t* const* partial,
+                                                          FFI_RLNWitnessInput_t* const* witness) {
+  return guard_ptr<CResult_FFI_RLNProof_ptr_Vec_uint8_t>([&]() -> FFI_RLNProof_t* {
+    return (FFI_RLNProof_t*)finish_proof(*(FFI_RLN*)*rln, *(FFI_RLNPartialProof*)*partial,
+                                         *(FFI_RLNWitnessInput*)*witness, random_fr(), random_fr());
+  });
+}
+CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_finish_rln_proof_with_rs(FFI_RLN_t* const* rln,
+                                                                  FFI_RLNPartialProof_t* const* partial,
+                                                                  FFI_RLNWitnessInput_t* const* witness,
+                                                                  const CFr_t* r, const CFr_t* s) {
+  return guard_ptr<CResult_FFI_RLNProof_ptr_Vec_uint8_t>([&]() -> FFI_RLNProof_t* {
+    return (FFI_RLNProof_t*)finish_proof(*(FFI_RLN*)*rln, *(FFI_RLNPartialProof*)*partial,
+                                         *(FFI_RLNWitnessInput*)*witness, R(r), R(s));
+  });
+}
+uint8_t ffi_rln_partial_proof_get_version_byte(FFI_RLNPartialProof_t* const*) { return 0x00; }
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_partial_proof_to_bytes_le(FFI_RLNPartialProof_t* const* partial) {
+  return guard_bytes([&]() { return partial_proof_bytes(*(FFI_RLNPartialProof*)*partial); });
+}
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_partial_proof_to_bytes_be(FFI_RLNPartialProof_t* const* partial) {
+  return guard_bytes([&]() { return partial_proof_bytes(*(FFI_RLNPartialProof*)*partial); });  // always LE
+}
+CResult_FFI_RLNPartialProof_ptr_Vec_uint8_t ffi_bytes_le_to_rln_partial_proof(const Vec_uint8_t* bytes) {
+  return guard_ptr<CResult_FFI_RLNPartialProof_ptr_Vec_uint8_t>(
+      [&]() -> FFI_RLNPartialProof_t* { return (FFI_RLNPartialProof_t*)partial_proof_from_bytes(bytes); });
+}
+CResult_FFI_RLNPartialProof_ptr_Vec_uint8_t ffi_bytes_be_to_rln_partial_proof(const Vec_uint8_t* bytes) {
+  return guard_ptr<CResult_FFI_RLNPartialProof_ptr_Vec_uint8_t>(
+      [&]() -> FFI_RLNPartialProof_t* { return (FFI_RLNPartialProof_t*)partial_proof_from_bytes(bytes); });
+}
+void ffi_rln_partial_proof_free(FFI_RLNPartialProof_t* partial) { delete (FFI_RLNPartialProof*)partial; }
 
 // ================================================================================ witness input
 CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t ffi_rln_witness_input_new_single(

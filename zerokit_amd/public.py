@@ -176,6 +176,46 @@ class RLNProof:
         return cls(_ok_ptr(lib().ffi_bytes_be_to_rln_proof(C.byref(v))))
 
 
+class RLNPartialWitnessInput:
+    """RLNPartialWitnessInput::new (protocol/witness.rs:253-270)"""
+
+    def __init__(self, identity_secret, user_message_limit, path_elements, identity_path_index, _handle=None):
+        if _handle is not None:
+            self._h = _handle
+            return
+        pe, _k1 = _vec_cfr(path_elements)
+        pi, _k2 = _vec_u8(bytes(identity_path_index))
+        self._h = _ok_ptr(lib().ffi_rln_partial_witness_input_new(
+            C.byref(_cfr(identity_secret)), C.byref(_cfr(user_message_limit)), C.byref(pe), C.byref(pi)))
+
+    @classmethod
+    def from_witness(cls, w: RLNWitnessInput):
+        return cls(0, 0, [], [], _handle=C.c_void_p(lib().ffi_rln_witness_to_partial_witness(C.byref(w._h))))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().ffi_rln_partial_witness_input_free(self._h)
+            self._h = None
+
+
+class RLNPartialProof:
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().ffi_rln_partial_proof_free(self._h)
+            self._h = None
+
+    def to_bytes_le(self):
+        return _take_bytes(lib().ffi_rln_partial_proof_to_bytes_le(C.byref(self._h)))
+
+    @classmethod
+    def from_bytes_le(cls, b):
+        v, _k = _vec_u8(b)
+        return cls(_ok_ptr(lib().ffi_bytes_le_to_rln_partial_proof(C.byref(v))))
+
+
 class RLN:
     """rln::public::RLN.  `RLN(tree_depth)` == RLN::new(tree_depth, "") (public.rs:110-128);
     `RLN.new_with_params(depth, zkey, graph)` == RLN::new_with_params (public.rs:166-196)."""
@@ -269,6 +309,21 @@ class RLN:
             rsp = flat.ptr
         _ok_bool(lib().ffi_generate_rln_proofs_batch(C.byref(self._h), hs, n, rsp, outs))
         return [RLNProof(C.c_void_p(outs[i])) for i in range(n)]
+
+    def generate_partial_zk_proof(self, partial_witness: RLNPartialWitnessInput) -> RLNPartialProof:
+        """public.rs:651-658"""
+        return RLNPartialProof(_ok_ptr(lib().ffi_generate_partial_zk_proof(C.byref(self._h),
+                                                                           C.byref(partial_witness._h))))
+
+    def finish_rln_proof(self, partial: RLNPartialProof, witness: RLNWitnessInput) -> RLNProof:
+        """public.rs:674-683"""
+        return RLNProof(_ok_ptr(lib().ffi_finish_rln_proof(C.byref(self._h), C.byref(partial._h),
+                                                           C.byref(witness._h))))
+
+    def finish_rln_proof_with_rs(self, partial: RLNPartialProof, witness: RLNWitnessInput, r, s) -> RLNProof:
+        return RLNProof(_ok_ptr(lib().ffi_finish_rln_proof_with_rs(C.byref(self._h), C.byref(partial._h),
+                                                                   C.byref(witness._h), C.byref(_cfr(r)),
+                                                                   C.byref(_cfr(s)))))
 
     def verify_rln_proof(self, proof: RLNProof, x) -> bool:
         return _ok_bool(lib().ffi_verify_rln_proof(C.byref(self._h), C.byref(proof._h), C.byref(_cfr(x))))
