@@ -167,7 +167,7 @@ def test_depth10_rln_object_with_params():
 
 
 def test_partial_and_finish_proof_ffi():
-    """rln/tests/ffi.rs:1176-1291 + :1294-1393: partial proof, finish, serialisation round trip (6 011 bytes,
+    """rln/tests/ffi.rs:1176-1291 + :1294-1393: partial proof, finish, serialisation round trip (6 011 bytes + version byte,
     SURVEY Appendix B), and partial + finish == full for fixed (r, s) (protocol.rs:222-248)"""
     from zerokit_amd import hashers
     from zerokit_amd.public import RLN, RLNError, RLNPartialProof, RLNPartialWitnessInput, RLNWitnessInput
@@ -179,7 +179,7 @@ def test_partial_and_finish_proof_ffi():
     pw = RLNPartialWitnessInput(secret, 100, elems, bits)
     pp = rln.generate_partial_zk_proof(pw)
     raw = pp.to_bytes_le()
-    assert len(raw) == 6011 and raw[0] == 0 and raw[1:9] == (5843).to_bytes(8, "little")
+    assert len(raw) == 6012 and raw[0] == 0 and raw[1:9] == (5843).to_bytes(8, "little")
     pp2 = RLNPartialProof.from_bytes_le(raw)
     assert pp2.to_bytes_le() == raw
     with pytest.raises(RLNError):
