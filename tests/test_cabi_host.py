@@ -205,3 +205,19 @@ def test_witness_and_proof_wire_formats():
         RLNProof.from_bytes_le(b"\x07" + raw[1:])
     with pytest.raises(RLNError, match="invalid data"):
         RLNProof.from_bytes_le(raw[:1] + b"\x04" + bytes(31) + raw[33:])  # x = 4 is not on the curve
+
+
+def test_header_compiles_as_c_and_program_fails_loudly_without_gpu(tmp_path):
+    """include/rln.h is plain C: a C caller (tests/host/ffi_smoke.c) builds against it with gcc -Wall and links
+    -lrln; without a device ffi_rln_new returns the error string instead of a handle (no CPU fallback)."""
+    import subprocess
+    if lib().rlnamd_device_count() > 0:
+        pytest.skip("GPU present")
+    exe = str(tmp_path / "ffi_smoke")
+    libdir = os.path.join(ROOT, "zerokit_amd", "lib")
+    res = subprocess.run(["gcc", "-Wall", "-Wextra", "-Werror", "-std=c11", "-I", os.path.join(ROOT, "include"),
+                          os.path.join(ROOT, "tests", "host", "ffi_smoke.c"), "-L", libdir, "-lrln",
+                          "-Wl,-rpath," + libdir, "-o", exe], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 2 and "no HIP device" in out.stderr

@@ -196,3 +196,19 @@ def test_partial_and_finish_proof_ffi():
         RLNPartialWitnessInput(secret, 0, elems, bits)
     with pytest.raises(RLNError, match="path_elements"):
         rln.generate_partial_zk_proof(RLNPartialWitnessInput(secret, 100, elems[:10], bits[:10]))
+
+
+def test_c_program_links_and_proves(tmp_path):
+    """A plain C program compiled against include/rln.h and linked with -lrln (the drop-in situation of
+    rln/ffi_c_examples/): creates the object, registers a member, proves, serialises, verifies."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "ffi_smoke")
+    libdir = os.path.join(root, "zerokit_amd", "lib")
+    subprocess.check_call(["gcc", "-Wall", "-std=c11", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "host", "ffi_smoke.c"), "-L", libdir, "-lrln",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "C harness: OK" in out.stdout
