@@ -13,8 +13,8 @@
  *  - CFr is opaque; elements of a Vec_CFr_t are contiguous CFr values reachable through ffi_vec_cfr_get
  *    (ffi_utils.rs:183-185).  In this implementation a CFr is the 32-byte little-endian canonical value.
  *
- * Scope: single message-id circuit, in-memory tree, full and partial proofs.  Not exported: the
- * ffi_rln_v3_* mirror, multi message-id witness types, seeded keygen and the sled/pmtree persistence (§8f).
+ * Scope: single and multi message-id circuits, in-memory tree, full and partial proofs.  Not
+ * exported: the ffi_rln_v3_* mirror and the sled/pmtree persistence (§8f).
  * Extensions that the reference lacks are marked EXT (deterministic blinding, batch).
  */
 #ifndef RLN_H
@@ -39,6 +39,8 @@ typedef struct FFI_RLNPartialProof FFI_RLNPartialProof_t; /* ffi_rln.rs:239-241 
 typedef struct Vec_uint8 { uint8_t* ptr; size_t len; size_t cap; } Vec_uint8_t;
 typedef struct Vec_CFr { CFr_t* ptr; size_t len; size_t cap; } Vec_CFr_t;
 typedef struct Vec_size { size_t* ptr; size_t len; size_t cap; } Vec_size_t;
+typedef struct Vec_bool { bool* ptr; size_t len; size_t cap; } Vec_bool_t;
+typedef struct Vec_String { Vec_uint8_t* ptr; size_t len; size_t cap; } Vec_String_t; /* repr_c::Vec<repr_c::String> */
 
 typedef struct CBoolResult { bool ok; Vec_uint8_t err; } CBoolResult_t;                  /* ffi_utils.rs:24-29 */
 typedef struct FFI_MerkleProof { Vec_CFr_t path_elements; Vec_uint8_t path_index; } FFI_MerkleProof_t; /* ffi_tree.rs:13-18 */
@@ -53,6 +55,7 @@ typedef struct { FFI_RLNPartialProof_t* ok; Vec_uint8_t err; } CResult_FFI_RLNPa
 typedef struct { CFr_t* ok; Vec_uint8_t err; } CResult_CFr_ptr_Vec_uint8_t;
 typedef struct { Vec_CFr_t ok; Vec_uint8_t err; } CResult_Vec_CFr_Vec_uint8_t;
 typedef struct { Vec_uint8_t ok; Vec_uint8_t err; } CResult_Vec_uint8_Vec_uint8_t;
+typedef struct { Vec_bool_t ok; Vec_uint8_t err; } CResult_Vec_bool_Vec_uint8_t;
 
 /* ---- RLN object ------------------------------------------------------------------------------------ */
 CResult_FFI_RLN_ptr_Vec_uint8_t ffi_rln_new(size_t tree_depth, const char* config_path);      /* ffi_rln.rs:24-57 */
@@ -69,6 +72,15 @@ CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_generate_rln_proof(FFI_RLN_t* const* rl
 CBoolResult_t ffi_verify_rln_proof(FFI_RLN_t* const* rln, FFI_RLNProof_t* const* proof, const CFr_t* x); /* :966-984 */
 CBoolResult_t ffi_verify_with_roots(FFI_RLN_t* const* rln, FFI_RLNProof_t* const* proof, const Vec_CFr_t* roots,
                                     const CFr_t* x);                                          /* ffi_rln.rs:987-1010 */
+/* proof from an externally calculated witness (decimal strings, one per witness signal) */
+CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_generate_rln_proof_with_witness(FFI_RLN_t* const* rln,
+                                                                         const Vec_String_t* calculated_witness,
+                                                                         FFI_RLNWitnessInput_t* const* witness); /* ffi_rln.rs:875-920 */
+/* slashing (protocol/slashing.rs:12-100) */
+CResult_CFr_ptr_Vec_uint8_t ffi_compute_id_secret(const CFr_t* share1_x, const CFr_t* share1_y, const CFr_t* share2_x,
+                                                  const CFr_t* share2_y);                       /* ffi_rln.rs:1015 */
+CResult_CFr_ptr_Vec_uint8_t ffi_recover_id_secret(FFI_RLNProofValues_t* const* proof_values_1,
+                                                  FFI_RLNProofValues_t* const* proof_values_2); /* ffi_rln.rs:1036 */
 /* EXT: generate_zk_proof_with_rs (protocol/proof.rs:753-777) -- explicit blinding scalars r, s */
 CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_generate_rln_proof_with_rs(FFI_RLN_t* const* rln,
                                                                     FFI_RLNWitnessInput_t* const* witness,
@@ -91,6 +103,13 @@ CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t ffi_rln_witness_input_new_single(
     const CFr_t* identity_secret, const CFr_t* user_message_limit, const CFr_t* message_id,
     const Vec_CFr_t* path_elements, const Vec_uint8_t* identity_path_index, const CFr_t* x,
     const CFr_t* external_nullifier);                                                          /* ffi_rln.rs:327-358 */
+CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t ffi_rln_witness_input_new_multi(
+    const CFr_t* identity_secret, const CFr_t* user_message_limit, const Vec_CFr_t* message_ids,
+    const Vec_CFr_t* path_elements, const Vec_uint8_t* identity_path_index, const CFr_t* x,
+    const CFr_t* external_nullifier, const Vec_bool_t* selector_used);                          /* ffi_rln.rs:361-396 */
+Vec_CFr_t ffi_rln_witness_input_get_message_ids(FFI_RLNWitnessInput_t* const* w);              /* ffi_rln.rs:425 */
+Vec_bool_t ffi_rln_witness_input_get_selector_used(FFI_RLNWitnessInput_t* const* w);           /* ffi_rln.rs:470 */
+void ffi_vec_bool_free(Vec_bool_t v);
 uint8_t ffi_rln_witness_input_get_version_byte(FFI_RLNWitnessInput_t* const* w);               /* ffi_rln.rs:399 */
 CFr_t* ffi_rln_witness_input_get_identity_secret(FFI_RLNWitnessInput_t* const* w);             /* ffi_rln.rs:404 */
 CFr_t* ffi_rln_witness_input_get_user_message_limit(FFI_RLNWitnessInput_t* const* w);          /* ffi_rln.rs:411 */
@@ -103,6 +122,7 @@ CResult_Vec_uint8_Vec_uint8_t ffi_rln_witness_to_bytes_le(FFI_RLNWitnessInput_t*
 CResult_Vec_uint8_Vec_uint8_t ffi_rln_witness_to_bytes_be(FFI_RLNWitnessInput_t* const* w);    /* ffi_rln.rs:493 */
 CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t ffi_bytes_le_to_rln_witness(const Vec_uint8_t* b); /* ffi_rln.rs:509 */
 CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t ffi_bytes_be_to_rln_witness(const Vec_uint8_t* b); /* ffi_rln.rs:525 */
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_witness_to_bigint_json(FFI_RLNWitnessInput_t* const* w); /* ffi_rln.rs:541 */
 void ffi_rln_witness_input_free(FFI_RLNWitnessInput_t* w);                                     /* ffi_rln.rs:557 */
 
 /* ---- partial proofs (proof split: precompute the member-dependent part, finish per message) ----------- */
@@ -110,6 +130,15 @@ CResult_FFI_RLNPartialWitnessInput_ptr_Vec_uint8_t ffi_rln_partial_witness_input
     const CFr_t* identity_secret, const CFr_t* user_message_limit, const Vec_CFr_t* path_elements,
     const Vec_uint8_t* identity_path_index);                                                    /* ffi_rln.rs:567-592 */
 FFI_RLNPartialWitnessInput_t* ffi_rln_witness_to_partial_witness(FFI_RLNWitnessInput_t* const* w); /* ffi_rln.rs:636 */
+uint8_t ffi_rln_partial_witness_input_get_version_byte(FFI_RLNPartialWitnessInput_t* const* w);  /* ffi_rln.rs:595 */
+CFr_t* ffi_rln_partial_witness_input_get_identity_secret(FFI_RLNPartialWitnessInput_t* const* w); /* ffi_rln.rs:602 */
+CFr_t* ffi_rln_partial_witness_input_get_user_message_limit(FFI_RLNPartialWitnessInput_t* const* w); /* :609 */
+Vec_CFr_t ffi_rln_partial_witness_input_get_path_elements(FFI_RLNPartialWitnessInput_t* const* w); /* :616 */
+Vec_uint8_t ffi_rln_partial_witness_input_get_identity_path_index(FFI_RLNPartialWitnessInput_t* const* w); /* :629 */
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_partial_witness_to_bytes_le(FFI_RLNPartialWitnessInput_t* const* w); /* :644 */
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_partial_witness_to_bytes_be(FFI_RLNPartialWitnessInput_t* const* w); /* :660 */
+CResult_FFI_RLNPartialWitnessInput_ptr_Vec_uint8_t ffi_bytes_le_to_rln_partial_witness(const Vec_uint8_t* b); /* :676 */
+CResult_FFI_RLNPartialWitnessInput_ptr_Vec_uint8_t ffi_bytes_be_to_rln_partial_witness(const Vec_uint8_t* b); /* :692 */
 void ffi_rln_partial_witness_input_free(FFI_RLNPartialWitnessInput_t* w);                       /* ffi_rln.rs:708 */
 CResult_FFI_RLNPartialProof_ptr_Vec_uint8_t ffi_generate_partial_zk_proof(
     FFI_RLN_t* const* rln, FFI_RLNPartialWitnessInput_t* const* partial_witness);               /* ffi_rln.rs:922-936 */
@@ -133,6 +162,9 @@ CFr_t* ffi_rln_proof_values_get_x(FFI_RLNProofValues_t* const* pv);             
 CFr_t* ffi_rln_proof_values_get_external_nullifier(FFI_RLNProofValues_t* const* pv);           /* ffi_rln.rs:729 */
 CResult_CFr_ptr_Vec_uint8_t ffi_rln_proof_values_get_y(FFI_RLNProofValues_t* const* pv);       /* ffi_rln.rs:736 */
 CResult_CFr_ptr_Vec_uint8_t ffi_rln_proof_values_get_nullifier(FFI_RLNProofValues_t* const* pv); /* ffi_rln.rs:746 */
+CResult_Vec_bool_Vec_uint8_t ffi_rln_proof_values_get_selector_used(FFI_RLNProofValues_t* const* pv); /* ffi_rln.rs:756 */
+CResult_Vec_CFr_Vec_uint8_t ffi_rln_proof_values_get_ys(FFI_RLNProofValues_t* const* pv);      /* ffi_rln.rs:766 */
+CResult_Vec_CFr_Vec_uint8_t ffi_rln_proof_values_get_nullifiers(FFI_RLNProofValues_t* const* pv); /* ffi_rln.rs:782 */
 uint8_t ffi_rln_proof_values_get_version_byte(FFI_RLNProofValues_t* const* pv);                /* ffi_rln.rs:798 */
 Vec_uint8_t ffi_rln_proof_values_to_bytes_le(FFI_RLNProofValues_t* const* pv);                 /* ffi_rln.rs:803 */
 Vec_uint8_t ffi_rln_proof_values_to_bytes_be(FFI_RLNProofValues_t* const* pv);                 /* ffi_rln.rs:808 */
@@ -191,6 +223,9 @@ CFr_t* ffi_hash_to_field_le(const Vec_uint8_t* input);                          
 CFr_t* ffi_hash_to_field_be(const Vec_uint8_t* input);                                         /* ffi_utils.rs:354 */
 CFr_t* ffi_poseidon_hash_pair(const CFr_t* a, const CFr_t* b);                                 /* ffi_utils.rs:359 */
 Vec_CFr_t ffi_key_gen(void);                                                                   /* ffi_utils.rs:366 */
+Vec_CFr_t ffi_seeded_key_gen(const Vec_uint8_t* seed);                                         /* ffi_utils.rs:372 */
+Vec_CFr_t ffi_extended_key_gen(void);                                                          /* ffi_utils.rs:380 */
+Vec_CFr_t ffi_seeded_extended_key_gen(const Vec_uint8_t* seed);                                /* ffi_utils.rs:392 */
 void ffi_c_string_free(Vec_uint8_t s);                                                         /* ffi_utils.rs:407 */
 
 #ifdef __cplusplus

@@ -111,6 +111,9 @@ int rlnamd_prover_run_async_mode(rlnamd_prover* p, size_t n, int mode);
 int rlnamd_prover_upload_partial(rlnamd_prover* p, size_t n, const uint8_t* coords320);
 int rlnamd_prover_download_partial(rlnamd_prover* p, size_t n, uint8_t* coords320);
 int rlnamd_prover_known_mask(rlnamd_prover* p, uint8_t* out_num_signals);
+/* Externally calculated witnesses (n x num_signals x 32 canonical LE) for the NEXT full run of n proofs; they
+ * replace the witness-graph interpreter's output (generate_zk_proof_with_witness, protocol/proof.rs:705-732). */
+int rlnamd_prover_upload_witness(rlnamd_prover* p, size_t n, const uint8_t* witness_le);
 /* Public signals (the circuit outputs/inputs w[1..num_instance)) of the first n proofs of the last run, read
  * from the witness: n * num_public * 32 bytes.  Circuit-generic (multi message-id: ys, root, nullifiers, x,
  * external_nullifier, selector_used -- the verifier order of protocol/proof.rs:870-885). */

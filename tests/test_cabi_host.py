@@ -221,3 +221,97 @@ def test_header_compiles_as_c_and_program_fails_loudly_without_gpu(tmp_path):
     assert res.returncode == 0, res.stderr
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 2 and "no HIP device" in out.stderr
+
+
+def test_multi_message_witness_validation_and_wire_format():
+    """rln/tests/public.rs:1528-1676 (validation rules) + the 0x01 wire layout of protocol/witness.rs:402-432"""
+    from zerokit_amd.public import RLNError, RLNWitnessInput
+    pe, pi = list(range(100, 120)), [i & 1 for i in range(20)]
+    mk = lambda limit, ids, sel: RLNWitnessInput.new_multi(7, limit, ids, pe, pi, 11, 13, sel)
+    with pytest.raises(RLNError, match="at least one message_id"):
+        mk(10, [], [])
+    with pytest.raises(RLNError, match="message_ids has length 2, but the field selector_used has length 1"):
+        mk(10, [0, 1], [True])
+    with pytest.raises(RLNError, match=r"Message id \(10\) is not within user_message_limit \(10\)"):
+        mk(10, [0, 10], [True, True])
+    mk(10, [0, 10], [True, False])  # inactive slot above the limit is fine
+    with pytest.raises(RLNError, match="cannot be zero"):
+        mk(0, [0], [True])
+    with pytest.raises(RLNError, match="Duplicate message ID"):
+        mk(10, [5, 5, 1, 2], [True, True, False, False])
+    mk(10, [0, 0, 1, 2], [False, False, True, True])  # duplicates only matter when active
+    with pytest.raises(RLNError, match="At least one selector_used"):
+        mk(10, [0, 1, 2, 3], [False] * 4)
+    w = mk(10, [0, 1, 2, 3], [True, True, False, False])
+    assert w.version_byte == 1 and w.message_ids == [0, 1, 2, 3] and w.selector_used == [True, True, False, False]
+    le, be = w.to_bytes_le(), w.to_bytes_be()
+    # 1 + secret + limit + (8 + 20*32) + (8 + 20) + x + ext + (8 + 4*32) + (8 + 4)
+    assert len(le) == len(be) == 1 + 64 + 648 + 28 + 64 + 136 + 12 and le[0] == 1
+    tail = (4).to_bytes(8, "little") + b"\x01\x01\x00\x00"
+    assert le.endswith(tail) and be.endswith((4).to_bytes(8, "big") + b"\x01\x01\x00\x00")
+    w2 = RLNWitnessInput.from_bytes_le(le)
+    assert w2.version_byte == 1 and w2.to_bytes_be() == be and RLNWitnessInput.from_bytes_be(be).to_bytes_le() == le
+    with pytest.raises(RLNError, match="Non-canonical bool"):
+        RLNWitnessInput.from_bytes_le(le[:-1] + b"\x02")
+    with pytest.raises(RLNError, match="version byte"):
+        RLNWitnessInput.from_bytes_le(b"\x02" + le[1:])
+    # the witness-calculator JSON: keys sorted, compact, decimal strings (serde_json default map)
+    j = json.loads(w.to_bigint_json())
+    assert list(j) == sorted(j) and j["messageId"] == ["0", "1", "2", "3"] and j["selectorUsed"] == ["1", "1", "0", "0"]
+    assert j["pathElements"] == [str(v) for v in pe] and j["identityPathIndex"] == [str(v) for v in pi]
+    assert " " not in w.to_bigint_json()
+    single = RLNWitnessInput(7, 10, 3, pe, pi, 11, 13)
+    js = json.loads(single.to_bigint_json())
+    assert js["messageId"] == "3" and "selectorUsed" not in js and js["identitySecret"] == "7"
+
+
+def test_partial_witness_wire_format():
+    """protocol/witness.rs:631-760"""
+    from zerokit_amd.public import RLNError, RLNPartialWitnessInput
+    pe, pi = list(range(1, 21)), [1] * 20
+    p = RLNPartialWitnessInput(5, 9, pe, pi)
+    le, be = p.to_bytes_le(), p.to_bytes_be()
+    assert len(le) == 1 + 64 + 8 + 640 + 8 + 20 and le[0] == 0
+    q = RLNPartialWitnessInput.from_bytes_le(le)
+    assert (q.identity_secret, q.user_message_limit, q.path_elements, q.identity_path_index) == (5, 9, pe, pi)
+    assert RLNPartialWitnessInput.from_bytes_be(be).to_bytes_le() == le
+    with pytest.raises(RLNError, match="Expected to read"):
+        RLNPartialWitnessInput.from_bytes_le(le + b"\0")
+    with pytest.raises(RLNError, match="cannot be zero"):
+        RLNPartialWitnessInput.from_bytes_le(le[:33] + bytes(32) + le[65:])
+
+
+def test_slashing_host_math_and_multi_proof_values_bytes():
+    """protocol/slashing.rs:12-100 and the MultiV1 proof-values layout (protocol/proof.rs:205-236)"""
+    from oracle.pyref.bn254 import R
+    from oracle.pyref.keygen import compute_id_secret as o_secret
+    from zerokit_amd.public import RLNError, RLNProofValues, compute_id_secret, recover_id_secret
+    a0, a1 = 123456789, 987654321987654321
+    sh = lambda x: (x, (a0 + x * a1) % R)
+    assert compute_id_secret(sh(5), sh(R - 3)) == a0 == o_secret(sh(5), sh(R - 3))
+    with pytest.raises(RLNError, match="division by zero"):
+        compute_id_secret(sh(5), sh(5))
+
+    def multi_bytes(root, ext, x, ys, nulls, sel, order="little"):
+        f = lambda v: int(v).to_bytes(32, order)
+        n8 = lambda k: k.to_bytes(8, order)
+        return (b"\x01" + f(root) + f(ext) + f(x) + n8(len(ys)) + b"".join(map(f, ys)) + n8(len(nulls)) +
+                b"".join(map(f, nulls)) + n8(len(sel)) + bytes(sel))
+
+    x1, x2 = 1111, 2222
+    v1 = RLNProofValues.from_bytes_le(multi_bytes(9, 77, x1, [0, sh(x1)[1], 5, 0], [0, 42, 43, 0], [0, 1, 1, 0]))
+    v2 = RLNProofValues.from_bytes_le(multi_bytes(9, 77, x2, [sh(x2)[1], 0, 0, 6], [42, 0, 0, 99], [1, 0, 0, 1]))
+    assert v1.version_byte == 1 and v1.ys[1] == sh(x1)[1] and v1.selector_used == [False, True, True, False]
+    assert v1.to_bytes_le() == multi_bytes(9, 77, x1, [0, sh(x1)[1], 5, 0], [0, 42, 43, 0], [0, 1, 1, 0])
+    assert v1.to_bytes_be() == multi_bytes(9, 77, x1, [0, sh(x1)[1], 5, 0], [0, 42, 43, 0], [0, 1, 1, 0], "big")
+    assert recover_id_secret(v1, v2) == a0  # slot 1 of v1 and slot 0 of v2 share nullifier 42
+    v3 = RLNProofValues.from_bytes_le(multi_bytes(9, 77, x2, [1, 2, 3, 4], [42, 1, 2, 3], [0, 1, 1, 1]))
+    with pytest.raises(RLNError, match="No matching nullifier"):
+        recover_id_secret(v1, v3)  # 42 sits in an inactive slot
+    v4 = RLNProofValues.from_bytes_le(multi_bytes(9, 78, x2, [1, 2, 3, 4], [42, 1, 2, 3], [1, 1, 1, 1]))
+    with pytest.raises(RLNError, match="External nullifiers mismatch: 77 != 78"):
+        recover_id_secret(v1, v4)
+    with pytest.raises(RLNError, match="does not exist on the `MultiV1` variant"):
+        v1.y
+    with pytest.raises(RLNError, match="ys has length 2, but the field nullifiers has length 1"):
+        RLNProofValues.from_bytes_le(multi_bytes(9, 77, 1, [1, 2], [3], [1, 0]))

@@ -212,3 +212,130 @@ def test_c_program_links_and_proves(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "C harness: OK" in out.stdout
+
+
+def _multi_rln():
+    from zerokit_amd.batch import resource_paths
+    from zerokit_amd.public import RLN
+    zp, gp = resource_paths(20, multi=True)
+    return RLN.new_with_params(20, open(zp, "rb").read(), open(gp, "rb").read())
+
+
+def test_multi_message_rln_proof_ffi():
+    """rln/tests/public.rs:1672-1737 through the C ABI, plus the committed golden of the max_out = 4 circuit:
+    same inputs and (r, s) -> the oracle's compressed proof and public signals"""
+    import json
+    import os
+    from zerokit_amd.public import RLNError, RLNProof, RLNWitnessInput
+    rln = _multi_rln()
+    assert rln.max_out() == 4
+    case = [c for c in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rln_other_circuits.json")))
+            ["cases"] if c["multi"]][0]
+    i = {k: [int(t) for t in v] for k, v in case["inputs"].items()}
+    w = RLNWitnessInput.new_multi(i["identitySecret"][0], i["userMessageLimit"][0], i["messageId"], i["pathElements"],
+                                  i["identityPathIndex"], i["x"][0], i["externalNullifier"][0],
+                                  [bool(b) for b in i["selectorUsed"]])
+    p = rln.generate_rln_proof_with_rs(w, int(case["r"]), int(case["s"]))
+    raw = p.to_bytes_le()
+    assert raw[0] == 1 and raw[1:129].hex() == case["proof_compressed"]
+    v = p.values
+    pub = [int(t) for t in case["public"]]
+    assert v.ys + [v.root] + v.nullifiers + [v.x, v.external_nullifier] + [int(b) for b in v.selector_used] == pub
+    assert v.ys[1] == 0 and v.ys[3] == 0 and v.nullifiers[1] == 0 and v.ys[0] != 0 and v.nullifiers[2] != 0
+    assert rln.verify_with_roots(p, i["x"][0], [])
+    q = RLNProof.from_bytes_le(raw)
+    assert q.to_bytes_le() == raw and RLNProof.from_bytes_be(p.to_bytes_be()).to_bytes_le() == raw
+    assert rln.verify_with_roots(q, i["x"][0], [v.root])
+    # a tampered output no longer verifies; a single-message witness is refused by the multi circuit and back
+    bad = bytearray(raw)
+    bad[129 + 1 + 96 + 8] ^= 1                      # first byte of ys[0]
+    with pytest.raises(RLNError, match="Invalid proof"):
+        rln.verify_with_roots(RLNProof.from_bytes_le(bytes(bad)), i["x"][0], [])
+    single = RLNWitnessInput(i["identitySecret"][0], 100, 3, i["pathElements"], i["identityPathIndex"], 5, 6)
+    with pytest.raises(RLNError):
+        rln.generate_rln_proof(single)
+    from zerokit_amd.public import RLN
+    with pytest.raises(RLNError):
+        RLN(20).generate_rln_proof(w)
+    with pytest.raises(RLNError, match="max_out|length"):
+        rln.generate_rln_proof(RLNWitnessInput.new_multi(1, 100, [0, 1], i["pathElements"], i["identityPathIndex"],
+                                                         5, 6, [True, True]))
+
+
+def test_multi_message_recover_id_secret_ffi():
+    """rln/tests/public.rs:1739-1828"""
+    import random
+    from zerokit_amd import hashers
+    from zerokit_amd.public import RLNError, RLNWitnessInput, recover_id_secret
+    rln = _multi_rln()
+    rnd = random.Random(5)
+    pe, pi = [rnd.randrange(R) for _ in range(20)], [rnd.randrange(2) for _ in range(20)]
+    ext = hashers.poseidon_hash_pair(hashers.hash_to_field_le(b"test-epoch"), hashers.hash_to_field_le(b"test-rln-identifier"))
+    secret, other = rnd.randrange(R), rnd.randrange(R)
+    mk = lambda s, x, sel: RLNWitnessInput.new_multi(s, 10, [0, 1, 2, 3], pe, pi, x, ext, sel)
+    sel = [True, True, False, False]
+    proofs = rln.generate_rln_proofs_batch([mk(secret, 111, sel), mk(secret, 222, sel), mk(other, 333, sel)])
+    v1, v2, v3 = (p.values for p in proofs)
+    assert recover_id_secret(v1, v2) == secret
+    with pytest.raises(RLNError, match="No matching nullifier"):
+        recover_id_secret(v1, v3)
+    # single-message slashing (rln/tests/ffi.rs:640-760 pattern) on the default circuit
+    from zerokit_amd.public import RLN
+    r1 = RLN(20)
+    ws = [RLNWitnessInput(secret, 10, 1, pe, pi, x, ext) for x in (111, 222)]
+    a, b = (p.values for p in r1.generate_rln_proofs_batch(ws))
+    assert recover_id_secret(a, b) == secret
+    with pytest.raises(RLNError, match="No matching nullifier"):
+        recover_id_secret(a, v1)                  # cross-mode pairs are not matched (slashing.rs:97-98)
+
+
+def test_generate_rln_proof_with_witness_ffi():
+    """ffi_generate_rln_proof_with_witness (ffi_rln.rs:875-920): the proof is built from an externally calculated
+    witness (here: this backend's own witness tap, as decimal strings with one entry sent as its negative)"""
+    from zerokit_amd import hashers
+    from zerokit_amd.batch import BatchProver
+    from zerokit_amd.public import RLN, RLNError, RLNWitnessInput
+    rln = RLN(20)
+    secret = 4242
+    rln.set_leaf(3, hashers.poseidon_hash_pair(hashers.poseidon_hash([secret]), 50))
+    elems, bits = rln.get_merkle_proof(3)
+    w = RLNWitnessInput(secret, 50, 7, elems, bits, 1357, 2468)
+    full = rln.generate_rln_proof(w)
+    bp = BatchProver(max_batch=64, window_bits=8)
+    bp.prove([dict(identity_secret=secret, user_message_limit=50, message_id=7, path_elements=elems,
+                   identity_path_index=bits, x=1357, external_nullifier=2468)], [(1, 2)])
+    calc = bp.fetch_witness(0)
+    assert calc[0] == 1 and len(calc) == 5844
+    strs = [str(v) for v in calc]
+    strs[10] = "-" + str(R - calc[10]) if calc[10] else "0"      # negative entries are reduced mod r
+    p = rln.generate_rln_proof_with_witness(strs, w)
+    assert rln.verify_rln_proof(p, 1357)
+    assert p.to_bytes_le()[129:] == full.to_bytes_le()[129:]       # same proof values
+    wrong = list(calc)
+    wrong[100] = (wrong[100] + 1) % R
+    with pytest.raises(RLNError, match="Invalid proof"):
+        rln.verify_rln_proof(rln.generate_rln_proof_with_witness(wrong, w), 1357)
+    with pytest.raises(RLNError, match="Failed to parse witness"):
+        rln.generate_rln_proof_with_witness(["12x"] + strs[1:], w)
+    with pytest.raises(RLNError, match="malformed"):
+        rln.generate_rln_proof_with_witness(strs[:-1], w)
+
+
+def test_seeded_keygen_ffi():
+    """rln/tests/ffi_utils.rs:8-66 and rln/tests/protocol.rs:463-540"""
+    from zerokit_amd import hashers
+    from zerokit_amd.public import extended_keygen, extended_seeded_keygen, seeded_keygen
+    s, c = seeded_keygen(bytes(range(10)))
+    assert s == 0x766ce6c7e7a01bdf5b3f257616f603918c30946fa23480f2859c597817e6716
+    assert c == 0xbf16d2b5c0d6f9d9d561e05bfca16a81b4b873bb063508fae360d8c74cef51f
+    s, c = seeded_keygen(b"A seed phrase example")
+    assert s == 0x20df38f3f00496f19fe7c6535492543b21798ed7cb91aebe4af8012db884eda3
+    assert c == 0x1223a78a5d66043a7f9863e14507dc80720a5602b2a894923e5b5147d5a9c325
+    t, n, s, c = extended_seeded_keygen(bytes(range(10)))
+    assert t == 0x766ce6c7e7a01bdf5b3f257616f603918c30946fa23480f2859c597817e6716
+    assert n == 0x1f18714c7bc83b5bca9e89d404cf6f2f585bc4c0f7ed8b53742b7e2b298f50b4
+    assert s == 0x2aca62aaa7abaf3686fff2caf00f55ab9462dc12db5b5d4bcf3994e671f8e521
+    assert c == 0x68b66aa0a8320d2e56842581553285393188714c48f9b17acd198b4f1734c5c
+    assert extended_seeded_keygen(b"seed") == extended_seeded_keygen(b"seed") != extended_seeded_keygen(b"seed2")
+    t, n, s, c = extended_keygen()
+    assert s == hashers.poseidon_hash_pair(t, n) and c == hashers.poseidon_hash([s])

@@ -197,3 +197,19 @@ def test_partial_then_finish_equals_full_proof(circuit20):
     full = wtns_graph.calc_witness(g, w.named_inputs())
     part = groth16.prove_partial(zk, full, mask)
     assert groth16.finish_partial(zk, part, full, mask, 44, 77) == groth16.prove(zk, full, 44, 77)
+
+
+def test_seeded_keygen_kats():
+    """rln/tests/protocol.rs:463-517 and rln/tests/ffi_utils.rs:8-66 (ChaCha20Rng + Fr::rand + Poseidon)"""
+    from oracle.pyref import keygen
+    s, c = keygen.seeded_keygen(b"A seed phrase example")
+    assert s == 0x20df38f3f00496f19fe7c6535492543b21798ed7cb91aebe4af8012db884eda3
+    assert c == 0x1223a78a5d66043a7f9863e14507dc80720a5602b2a894923e5b5147d5a9c325
+    s, c = keygen.seeded_keygen(bytes(range(10)))
+    assert s == 0x766ce6c7e7a01bdf5b3f257616f603918c30946fa23480f2859c597817e6716
+    assert c == 0xbf16d2b5c0d6f9d9d561e05bfca16a81b4b873bb063508fae360d8c74cef51f
+    t, n, s, c = keygen.extended_seeded_keygen(bytes(range(10)))
+    assert t == 0x766ce6c7e7a01bdf5b3f257616f603918c30946fa23480f2859c597817e6716
+    assert n == 0x1f18714c7bc83b5bca9e89d404cf6f2f585bc4c0f7ed8b53742b7e2b298f50b4
+    assert s == 0x2aca62aaa7abaf3686fff2caf00f55ab9462dc12db5b5d4bcf3994e671f8e521
+    assert c == 0x68b66aa0a8320d2e56842581553285393188714c48f9b17acd198b4f1734c5c

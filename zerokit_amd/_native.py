@@ -29,6 +29,18 @@ class VecSize(C.Structure):
     _fields_ = [("ptr", C.POINTER(C.c_size_t)), ("len", C.c_size_t), ("cap", C.c_size_t)]
 
 
+class VecBool(C.Structure):
+    _fields_ = [("ptr", C.POINTER(C.c_bool)), ("len", C.c_size_t), ("cap", C.c_size_t)]
+
+
+class CResultVecBool(C.Structure):
+    _fields_ = [("ok", VecBool), ("err", VecU8)]
+
+
+class VecString(C.Structure):  # repr_c::Vec<repr_c::String>
+    _fields_ = [("ptr", C.POINTER(VecU8)), ("len", C.c_size_t), ("cap", C.c_size_t)]
+
+
 class CBoolResult(C.Structure):
     _fields_ = [("ok", C.c_bool), ("err", VecU8)]
 
@@ -91,6 +103,7 @@ SIGNATURES = {
     "rlnamd_prover_run_async_mode": (C.c_int, [P, C.c_size_t, C.c_int]),
     "rlnamd_prover_upload_partial": (C.c_int, [P, C.c_size_t, C.c_char_p]),
     "rlnamd_prover_download_partial": (C.c_int, [P, C.c_size_t, C.c_char_p]),
+    "rlnamd_prover_upload_witness": (C.c_int, [P, C.c_size_t, C.c_char_p]),
     "rlnamd_prover_known_mask": (C.c_int, [P, C.c_char_p]),
     "rlnamd_prover_download": (C.c_int, [P, C.c_size_t, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint32)]),
     "rlnamd_prover_stage_ms": (C.c_int, [P, C.POINTER(C.c_float)]),
@@ -132,6 +145,11 @@ SIGNATURES = {
     "ffi_bytes_be_to_rln_proof": (CResultPtr, [C.POINTER(VecU8)]),
     "ffi_rln_proof_free": (None, [P]),
     "ffi_rln_witness_input_new_single": (CResultPtr, [CFRP, CFRP, CFRP, C.POINTER(VecCFr), C.POINTER(VecU8), CFRP, CFRP]),
+    "ffi_rln_witness_input_new_multi": (CResultPtr, [CFRP, CFRP, C.POINTER(VecCFr), C.POINTER(VecCFr),
+                                                     C.POINTER(VecU8), CFRP, CFRP, C.POINTER(VecBool)]),
+    "ffi_rln_witness_input_get_message_ids": (VecCFr, [PP]),
+    "ffi_rln_witness_input_get_selector_used": (VecBool, [PP]),
+    "ffi_vec_bool_free": (None, [VecBool]),
     "ffi_rln_witness_input_get_version_byte": (C.c_uint8, [PP]),
     "ffi_rln_witness_input_get_identity_secret": (CFRP, [PP]),
     "ffi_rln_witness_input_get_user_message_limit": (CFRP, [PP]),
@@ -144,10 +162,26 @@ SIGNATURES = {
     "ffi_rln_witness_to_bytes_be": (CResultVecU8, [PP]),
     "ffi_bytes_le_to_rln_witness": (CResultPtr, [C.POINTER(VecU8)]),
     "ffi_bytes_be_to_rln_witness": (CResultPtr, [C.POINTER(VecU8)]),
+    "ffi_rln_witness_to_bigint_json": (CResultVecU8, [PP]),
     "ffi_rln_witness_input_free": (None, [P]),
     "ffi_rln_partial_witness_input_new": (CResultPtr, [CFRP, CFRP, C.POINTER(VecCFr), C.POINTER(VecU8)]),
     "ffi_rln_witness_to_partial_witness": (P, [PP]),
+    "ffi_rln_partial_witness_input_get_version_byte": (C.c_uint8, [PP]),
+    "ffi_rln_partial_witness_input_get_identity_secret": (CFRP, [PP]),
+    "ffi_rln_partial_witness_input_get_user_message_limit": (CFRP, [PP]),
+    "ffi_rln_partial_witness_input_get_path_elements": (VecCFr, [PP]),
+    "ffi_rln_partial_witness_input_get_identity_path_index": (VecU8, [PP]),
+    "ffi_rln_partial_witness_to_bytes_le": (CResultVecU8, [PP]),
+    "ffi_rln_partial_witness_to_bytes_be": (CResultVecU8, [PP]),
+    "ffi_bytes_le_to_rln_partial_witness": (CResultPtr, [C.POINTER(VecU8)]),
+    "ffi_bytes_be_to_rln_partial_witness": (CResultPtr, [C.POINTER(VecU8)]),
     "ffi_rln_partial_witness_input_free": (None, [P]),
+    "ffi_generate_rln_proof_with_witness": (CResultPtr, [PP, C.POINTER(VecString), PP]),
+    "ffi_compute_id_secret": (CResultPtr, [CFRP, CFRP, CFRP, CFRP]),
+    "ffi_recover_id_secret": (CResultPtr, [PP, PP]),
+    "ffi_seeded_key_gen": (VecCFr, [C.POINTER(VecU8)]),
+    "ffi_extended_key_gen": (VecCFr, []),
+    "ffi_seeded_extended_key_gen": (VecCFr, [C.POINTER(VecU8)]),
     "ffi_generate_partial_zk_proof": (CResultPtr, [PP, PP]),
     "ffi_finish_rln_proof": (CResultPtr, [PP, PP, PP]),
     "ffi_finish_rln_proof_with_rs": (CResultPtr, [PP, PP, PP, CFRP, CFRP]),
@@ -162,6 +196,9 @@ SIGNATURES = {
     "ffi_rln_proof_values_get_external_nullifier": (CFRP, [PP]),
     "ffi_rln_proof_values_get_y": (CResultPtr, [PP]),
     "ffi_rln_proof_values_get_nullifier": (CResultPtr, [PP]),
+    "ffi_rln_proof_values_get_ys": (CResultVecCFr, [PP]),
+    "ffi_rln_proof_values_get_nullifiers": (CResultVecCFr, [PP]),
+    "ffi_rln_proof_values_get_selector_used": (CResultVecBool, [PP]),
     "ffi_rln_proof_values_get_version_byte": (C.c_uint8, [PP]),
     "ffi_rln_proof_values_to_bytes_le": (VecU8, [PP]),
     "ffi_rln_proof_values_to_bytes_be": (VecU8, [PP]),

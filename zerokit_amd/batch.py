@@ -150,6 +150,14 @@ class BatchProver:
     def upload_partial(self, partials):
         check(lib().rlnamd_prover_upload_partial(self._h, len(partials), b"".join(partials)))
 
+    def prove_with_witness(self, witnesses, rs, calculated):
+        """generate_zk_proof_with_witness for a batch: `calculated` = per proof the full witness (ints)"""
+        n = self.upload(self.pack_inputs(witnesses), rs)
+        blob = b"".join(int(v).to_bytes(32, "little") for w in calculated for v in w)
+        check(lib().rlnamd_prover_upload_witness(self._h, n, blob))
+        check(lib().rlnamd_prover_run_mode(self._h, n, 0))
+        return self.download(n)
+
     def finish(self, witnesses, rs, partials):
         """finish_zk_proof_with_rs for a batch: only the message-dependent rows + h + blinding are walked"""
         n = self.upload(self.pack_inputs(witnesses), rs)

@@ -260,6 +260,11 @@ int rlnamd_prover_upload_partial(rlnamd_prover* p, size_t n, const uint8_t* coor
   p->p->upload_partial(n, coords320);
   RLN_CATCH
 }
+int rlnamd_prover_upload_witness(rlnamd_prover* p, size_t n, const uint8_t* witness_le) {
+  RLN_TRY
+  p->p->upload_witness(n, witness_le);
+  RLN_CATCH
+}
 int rlnamd_prover_download_partial(rlnamd_prover* p, size_t n, uint8_t* coords320) {
   RLN_TRY
   p->p->download_partial(n, coords320);

@@ -195,17 +195,158 @@ CFr random_fr() {
   return r;
 }
 
+
+Fr to_fr(const CFr& v) {
+  uint32_t c[8];
+  memcpy(c, v.le, 32);
+  return Fr::from_canonical(c);
+}
+CFr from_fr(const Fr& f) {
+  CFr r;
+  uint32_t c[8];
+  f.to_canonical(c);
+  memcpy(r.le, c, 32);
+  return r;
+}
+
+// ChaCha20Rng::from_seed (rand_chacha 0.3.1, pinned in Cargo.lock): 20 rounds, 64-bit block counter from 0,
+// stream id 0; the output is the keystream read as little-endian words.
+struct ChaCha20Rng {
+  uint32_t key[8];
+  uint64_t counter = 0;
+  uint8_t buf[64];
+  size_t pos = 64;
+  explicit ChaCha20Rng(const uint8_t seed[32]) { memcpy(key, seed, 32); }
+  static uint32_t rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+  void block() {
+    uint32_t st[16] = {0x61707865, 0x3320646e, 0x79622d32, 0x6b206574};
+    memcpy(st + 4, key, 32);
+    st[12] = (uint32_t)counter;
+    st[13] = (uint32_t)(counter >> 32);
+    st[14] = st[15] = 0;
+    uint32_t x[16];
+    memcpy(x, st, 64);
+    auto qr = [&](int a, int b, int c, int d) {
+      x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16);
+      x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12);
+      x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);
+      x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
+    };
+    for (int i = 0; i < 10; i++) {
+      qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+      qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
+    }
+    for (int i = 0; i < 16; i++) {
+      uint32_t w = x[i] + st[i];
+      memcpy(buf + 4 * i, &w, 4);
+    }
+    counter++;
+    pos = 0;
+  }
+  void fill(uint8_t* out, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+      if (pos == 64) block();
+      out[i] = buf[pos++];
+    }
+  }
+  // <Fr as UniformRand>::rand (ark-ff 0.5.0 fields/models/fp/mod.rs): four u64 limbs, top two bits shaved,
+  // rejected while >= r; the accepted limbs ARE the Montgomery representation, so the value is raw / 2^256.
+  CFr next_fr() {
+    for (;;) {
+      uint8_t raw[32];
+      fill(raw, 32);
+      raw[31] &= 0x3F;
+      if (!is_canonical(raw)) continue;
+      CFr c;
+      memcpy(c.le, raw, 32);
+      uint32_t one[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+      Fr m;  // the Montgomery form of 1/R is the plain integer 1
+      memcpy(m.v, one, 32);
+      return from_fr(to_fr(c) * m);
+    }
+  }
+};
+ChaCha20Rng seeded_rng(const Vec_uint8_t* seed) {  // keygen.rs:50-58: the seed is keccak256 of the signal
+  uint8_t h[32];
+  keccak256(seed ? seed->ptr : nullptr, seed ? seed->len : 0, h);
+  return ChaCha20Rng(h);
+}
+CFr poseidon_host_call(const std::vector<CFr>& in) {  // one-lane launch of the batch kernel
+  CFr out;
+  memset(out.le, 0, 32);
+  if (rlnamd_poseidon_hash((const uint8_t*)in.data(), 1, in.size(), out.le) != 0)
+    throw Error(std::string("poseidon: ") + rlnamd_last_error());
+  return out;
+}
+
+// compute_id_secret (protocol/slashing.rs:12-36)
+CFr compute_id_secret(const CFr& x1, const CFr& y1, const CFr& x2, const CFr& y2) {
+  Fr dx = to_fr(x1) - to_fr(x2);
+  if (dx.is_zero()) throw Error("Cannot recover secret: division by zero (shares have the same x value)");
+  Fr a1 = (to_fr(y1) - to_fr(y2)) * dx.inv();
+  return from_fr(to_fr(y1) - to_fr(x1) * a1);
+}
+
+// BigInt::from_str + calculated_witness_to_field_elements (protocol/proof.rs:593-614): decimal, optional sign,
+// reduced mod r; negative values map to r - |w|
+CFr parse_bigint_fr(const uint8_t* p, size_t n) {
+  size_t i = 0;
+  bool neg = false;
+  if (i < n && (p[i] == '+' || p[i] == '-')) neg = p[i++] == '-';
+  if (i >= n) throw Error("Failed to parse witness: cannot parse integer from empty string");
+  if (p[i] == '_') throw Error("Failed to parse witness: invalid digit found in string");
+  Fr acc = Fr::zero(), ten = to_fr(cfr_from_u64(10));
+  bool over = false;  // |w| > r is only an error for negative values
+  std::vector<uint8_t> digits;
+  for (; i < n; i++) {
+    if (p[i] == '_') continue;
+    if (p[i] < '0' || p[i] > '9') throw Error("Failed to parse witness: invalid digit found in string");
+    acc = acc * ten + to_fr(cfr_from_u64(p[i] - '0'));
+    digits.push_back(p[i] - '0');
+  }
+  if (neg) {
+    // compare |w| with r through its decimal length / value (r has 77 digits)
+    static const char* RDEC = "21888242871839275222246405745257275088548364400416034343698204186575808495617";
+    size_t lead = 0;
+    while (lead + 1 < digits.size() && digits[lead] == 0) lead++;
+    size_t len = digits.size() - lead;
+    if (len > 77) over = true;
+    else if (len == 77)
+      for (size_t k = 0; k < 77; k++) {
+        int d = digits[lead + k], r = RDEC[k] - '0';
+        if (d != r) {
+          over = d > r;
+          break;
+        }
+      }
+    if (over) throw Error("Cannot convert bigint to biguint: negative value below -r");
+    acc = Fr::zero() - acc;
+  }
+  return from_fr(acc);
+}
+
+std::string json_str_array(const std::vector<std::string>& v) {
+  std::string s = "[";
+  for (size_t i = 0; i < v.size(); i++) s += (i ? ",\"" : "\"") + v[i] + "\"";
+  return s + "]";
+}
 }  // namespace
 
 // -------------------------------------------------------------------------------------- object model
-struct FFI_RLNWitnessInput {  // RLNWitnessInput (protocol/witness.rs:44-58), SingleV1 only
+struct FFI_RLNWitnessInput {  // RLNWitnessInput (protocol/witness.rs:44-58): SingleV1 or MultiV1
   CFr identity_secret, user_message_limit, message_id;
   std::vector<CFr> path_elements;
   std::vector<uint8_t> identity_path_index;
   CFr x, external_nullifier;
+  bool multi = false;
+  std::vector<CFr> message_ids;        // MultiV1
+  std::vector<uint8_t> selector_used;  // MultiV1, 0/1
 };
-struct FFI_RLNProofValues {  // RLNProofValues (protocol/proof.rs), SingleV1
+struct FFI_RLNProofValues {  // RLNProofValues (protocol/proof.rs:40-110): SingleV1 {y, nullifier} or MultiV1
   CFr root, x, external_nullifier, y, nullifier;
+  bool multi = false;
+  std::vector<CFr> ys, nullifiers;
+  std::vector<uint8_t> selector_used;
 };
 struct FFI_RLNProof {
   uint8_t proof[128];
@@ -314,9 +455,29 @@ void validate_witness(const FFI_RLNWitnessInput& w) {  // witness.rs:78-108
   if (w.path_elements.size() != w.identity_path_index.size())
     throw Error("Merkle proof length mismatch: expected " + std::to_string(w.path_elements.size()) + ", got " +
                 std::to_string(w.identity_path_index.size()));
-  if (cfr_cmp(w.message_id, w.user_message_limit) >= 0)
-    throw Error("Message id (" + cfr_dec(w.message_id) + ") is not within user_message_limit (" +
-                cfr_dec(w.user_message_limit) + ")");
+  if (!w.multi) {
+    if (cfr_cmp(w.message_id, w.user_message_limit) >= 0)
+      throw Error("Message id (" + cfr_dec(w.message_id) + ") is not within user_message_limit (" +
+                  cfr_dec(w.user_message_limit) + ")");
+    return;
+  }
+  if (w.message_ids.empty()) throw Error("The field message_ids must contain at least one message_id");
+  if (w.selector_used.size() != w.message_ids.size())
+    throw Error("The field message_ids has length " + std::to_string(w.message_ids.size()) +
+                ", but the field selector_used has length " + std::to_string(w.selector_used.size()));
+  bool any = false;
+  for (uint8_t b : w.selector_used) any |= b != 0;
+  if (!any) throw Error("At least one selector_used value must be true");
+  for (size_t i = 0; i < w.message_ids.size(); i++) {
+    if (!w.selector_used[i]) continue;
+    for (size_t j = 0; j < i; j++)
+      if (w.selector_used[j] && cfr_cmp(w.message_ids[i], w.message_ids[j]) == 0)
+        throw Error("Duplicate message ID found in message_ids");
+  }
+  for (size_t i = 0; i < w.message_ids.size(); i++)
+    if (w.selector_used[i] && cfr_cmp(w.message_ids[i], w.user_message_limit) >= 0)
+      throw Error("Message id (" + cfr_dec(w.message_ids[i]) + ") is not within user_message_limit (" +
+                  cfr_dec(w.user_message_limit) + ")");
 }
 
 // inputs_for_witness_calculation + populate_inputs (witness.rs:832-881, iden3calc.rs:122-181)
@@ -334,7 +495,14 @@ void fill_inputs(const Prover& P, const FFI_RLNWitnessInput& w, uint8_t* buf) {
   };
   put("identitySecret", &w.identity_secret, 1);
   put("userMessageLimit", &w.user_message_limit, 1);
-  put("messageId", &w.message_id, 1);
+  if (w.multi) {
+    put("messageId", w.message_ids.data(), w.message_ids.size());
+    std::vector<CFr> sel;
+    for (uint8_t b : w.selector_used) sel.push_back(cfr_from_u64(b ? 1 : 0));
+    put("selectorUsed", sel.data(), sel.size());
+  } else {
+    put("messageId", &w.message_id, 1);
+  }
   put("pathElements", w.path_elements.data(), w.path_elements.size());
   std::vector<CFr> idx;
   for (uint8_t b : w.identity_path_index) idx.push_back(cfr_from_u64(b));
@@ -351,7 +519,46 @@ void check_against_graph(const Prover& P, const FFI_RLNWitnessInput& w) {  // pr
   if (w.identity_path_index.size() != d)
     throw Error("The field identity_path_index has length " + std::to_string(w.identity_path_index.size()) +
                 ", but the field tree_depth has length " + std::to_string(d));
-  if (P.graph().max_out != 1) throw Error("Witness message mode SingleV1 does not match graph mode MultiV1");
+  const bool graph_multi = P.graph().input_mapping.count("selectorUsed") != 0;  // mode.rs:145-157
+  if (w.multi != graph_multi)
+    throw Error(std::string("Witness message mode ") + (w.multi ? "MultiV1" : "SingleV1") +
+                " does not match graph mode " + (graph_multi ? "MultiV1" : "SingleV1"));
+  if (w.multi) {
+    size_t mo = P.graph().max_out;
+    if (w.message_ids.size() != mo)
+      throw Error("The field message_ids has length " + std::to_string(w.message_ids.size()) +
+                  ", but the field max_out has length " + std::to_string(mo));
+    if (w.selector_used.size() != mo)
+      throw Error("The field selector_used has length " + std::to_string(w.selector_used.size()) +
+                  ", but the field max_out has length " + std::to_string(mo));
+  }
+}
+
+void fill_outputs(const ProofOut& po, FFI_RLNProof* pr) {
+  memcpy(pr->proof, po.compressed, 128);
+  memcpy(pr->values.y.le, po.values[0], 32);
+  memcpy(pr->values.root.le, po.values[1], 32);
+  memcpy(pr->values.nullifier.le, po.values[2], 32);
+  memcpy(pr->values.x.le, po.values[3], 32);
+  memcpy(pr->values.external_nullifier.le, po.values[4], 32);
+}
+// multi message-id public signals [ys | root | nullifiers | x | ext | selector_used] -> proof values
+void values_from_public(const uint8_t* pub, size_t mo, FFI_RLNProofValues* v) {
+  auto at = [&](size_t k) {
+    CFr c;
+    memcpy(c.le, pub + 32 * k, 32);
+    return c;
+  };
+  v->multi = true;
+  v->ys.clear();
+  v->nullifiers.clear();
+  v->selector_used.clear();
+  for (size_t k = 0; k < mo; k++) v->ys.push_back(at(k));
+  v->root = at(mo);
+  for (size_t k = 0; k < mo; k++) v->nullifiers.push_back(at(mo + 1 + k));
+  v->x = at(2 * mo + 1);
+  v->external_nullifier = at(2 * mo + 2);
+  for (size_t k = 0; k < mo; k++) v->selector_used.push_back(cfr_is_zero(at(2 * mo + 3 + k)) ? 0 : 1);
 }
 
 // generate_rln_proof for a slice of witnesses (public.rs:624-631)
@@ -359,6 +566,7 @@ void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CF
   Prover& P = *rln.prover;
   const size_t ni = P.inputs_per_proof();
   for (size_t i = 0; i < n; i++) check_against_graph(P, *ws[i]);
+  const bool multi = n > 0 && ws[0]->multi;
   size_t done = 0;
   std::vector<FFI_RLNProof*> made;
   try {
@@ -374,16 +582,14 @@ void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CF
       }
       std::vector<ProofOut> po(m);
       P.prove(m, inputs.data(), rsb.data(), po.data());
+      std::vector<uint8_t> pub;
+      if (multi) P.fetch_public(m, &pub);  // ys, root, nullifiers, x, ext, selectors (witness.rs:777-802)
       for (size_t i = 0; i < m; i++) {
         if (po[i].error) throw Error("Error calculating witness: graph evaluation failed (code " +
                                      std::to_string(po[i].error) + ")");
         std::unique_ptr<FFI_RLNProof> pr(new FFI_RLNProof);
-        memcpy(pr->proof, po[i].compressed, 128);
-        memcpy(pr->values.y.le, po[i].values[0], 32);
-        memcpy(pr->values.root.le, po[i].values[1], 32);
-        memcpy(pr->values.nullifier.le, po[i].values[2], 32);
-        memcpy(pr->values.x.le, po[i].values[3], 32);
-        memcpy(pr->values.external_nullifier.le, po[i].values[4], 32);
+        fill_outputs(po[i], pr.get());
+        if (multi) values_from_public(pub.data() + i * P.num_public() * 32, P.graph().max_out, &pr->values);
         made.push_back(pr.release());
       }
       done += m;
@@ -395,16 +601,43 @@ void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CF
   for (size_t i = 0; i < n; i++) out[i] = made[i];
 }
 
+// generate_rln_proof_with_witness (public.rs:643-658): the Groth16 proof is made from the supplied witness;
+// the proof values come from the witness input (single: the values kernel over the inputs; multi: the public
+// signals, identical for any witness that satisfies the circuit).
+FFI_RLNProof* prove_with_witness(FFI_RLN& rln, const Vec_String_t* calc, const FFI_RLNWitnessInput& w) {
+  Prover& P = *rln.prover;
+  std::vector<uint8_t> given;
+  given.reserve((calc ? calc->len : 0) * 32);
+  for (size_t i = 0; calc && i < calc->len; i++) {
+    CFr v = parse_bigint_fr(calc->ptr[i].ptr, calc->ptr[i].len);
+    given.insert(given.end(), v.le, v.le + 32);
+  }
+  check_against_graph(P, w);
+  if (given.size() / 32 != P.num_signals())  // SynthesisError::MalformedVerifyingKey in ark-groth16
+    throw Error("Error producing proof: malformed verifying key (witness has " + std::to_string(given.size() / 32) +
+                " entries, the circuit " + std::to_string(P.num_signals()) + ")");
+  std::vector<uint8_t> inputs(P.inputs_per_proof() * 32), rs(64);
+  fill_inputs(P, w, inputs.data());
+  CFr r = random_fr(), sb = random_fr();
+  memcpy(rs.data(), r.le, 32);
+  memcpy(rs.data() + 32, sb.le, 32);
+  P.upload(1, inputs.data(), rs.data());
+  P.upload_witness(1, given.data());
+  P.run(1, PROVE_FULL);
+  ProofOut po;
+  P.download(1, &po);
+  std::unique_ptr<FFI_RLNProof> pr(new FFI_RLNProof);
+  fill_outputs(po, pr.get());
+  if (w.multi) {
+    std::vector<uint8_t> pub;
+    P.fetch_public(1, &pub);
+    values_from_public(pub.data(), P.graph().max_out, &pr->values);
+  }
+  return pr.release();
+}
+
 bool g2_in_subgroup(const G2Affine& p) {  // [r]P == 0 (ark-serialize Validate::Yes)
   return scalar_mul(p, FrParams::MOD).is_inf();
-}
-void fill_outputs(const ProofOut& po, FFI_RLNProof* pr) {
-  memcpy(pr->proof, po.compressed, 128);
-  memcpy(pr->values.y.le, po.values[0], 32);
-  memcpy(pr->values.root.le, po.values[1], 32);
-  memcpy(pr->values.nullifier.le, po.values[2], 32);
-  memcpy(pr->values.x.le, po.values[3], 32);
-  memcpy(pr->values.external_nullifier.le, po.values[4], 32);
 }
 
 // generate_partial_zk_proof (proof.rs:783-803)
@@ -453,6 +686,11 @@ FFI_RLNProof* finish_proof(FFI_RLN& rln, const FFI_RLNPartialProof& pp, const FF
   if (po.error) throw Error("Error calculating witness: graph evaluation failed (code " + std::to_string(po.error) + ")");
   std::unique_ptr<FFI_RLNProof> pr(new FFI_RLNProof);
   fill_outputs(po, pr.get());
+  if (w.multi) {
+    std::vector<uint8_t> pub;
+    P.fetch_public(1, &pub);
+    values_from_public(pub.data(), P.graph().max_out, &pr->values);
+  }
   return pr.release();
 }
 
@@ -523,26 +761,61 @@ bool verify_zk(FFI_RLN& rln, const FFI_RLNProof& pr) {  // verify_zk_proof (proo
     memcpy(c, v.le, 32);
     return Fr::from_canonical(c);
   };
-  std::vector<Fr> in = {F(pr.values.y), F(pr.values.root), F(pr.values.nullifier), F(pr.values.x),
-                        F(pr.values.external_nullifier)};
+  std::vector<Fr> in;  // proof.rs:863-885
+  const FFI_RLNProofValues& v = pr.values;
+  if (!v.multi) {
+    in = {F(v.y), F(v.root), F(v.nullifier), F(v.x), F(v.external_nullifier)};
+  } else {
+    for (auto& y : v.ys) in.push_back(F(y));
+    in.push_back(F(v.root));
+    for (auto& nl : v.nullifiers) in.push_back(F(nl));
+    in.push_back(F(v.x));
+    in.push_back(F(v.external_nullifier));
+    for (uint8_t b : v.selector_used) in.push_back(F(cfr_from_u64(b ? 1 : 0)));
+  }
+  if (in.size() + 1 != rln.prover->zkey().gamma_abc_g1.size())
+    throw Error("Error producing proof: malformed verifying key (public input count does not match the circuit)");
   return groth16_verify(rln.prover->zkey(), A, B, C, in);
 }
 
+void put_vec_fr(std::vector<uint8_t>& b, const std::vector<CFr>& v, bool be) {  // utils.rs:123-156
+  put_u64(b, v.size(), be);
+  for (auto& e : v) put_fr(b, e, be);
+}
+void put_vec_bool(std::vector<uint8_t>& b, const std::vector<uint8_t>& v, bool be) {  // utils.rs: vec_bool_to_bytes
+  put_u64(b, v.size(), be);
+  for (uint8_t x : v) b.push_back(x ? 1 : 0);
+}
+std::vector<uint8_t> read_vec_bool(Cursor& c) {
+  std::vector<uint8_t> raw = c.vec_u8();
+  for (uint8_t x : raw)
+    if (x > 1) {
+      char buf[8];
+      snprintf(buf, sizeof buf, "%#04x", x);
+      throw Error(std::string("Non-canonical bool byte: expected 0x00 or 0x01, got ") + buf);
+    }
+  return raw;
+}
 std::vector<uint8_t> values_bytes(const FFI_RLNProofValues& v, bool be) {  // proof.rs:192-236 / :239-283
   std::vector<uint8_t> b;
-  b.push_back(0x00);
+  b.push_back(v.multi ? 0x01 : 0x00);
   put_fr(b, v.root, be);
   put_fr(b, v.external_nullifier, be);
   put_fr(b, v.x, be);
-  put_fr(b, v.y, be);
-  put_fr(b, v.nullifier, be);
+  if (!v.multi) {
+    put_fr(b, v.y, be);
+    put_fr(b, v.nullifier, be);
+  } else {
+    put_vec_fr(b, v.ys, be);
+    put_vec_fr(b, v.nullifiers, be);
+    put_vec_bool(b, v.selector_used, be);
+  }
   return b;
 }
 FFI_RLNProofValues values_from(Cursor& c) {  // proof.rs:285-411
   c.need(1);
   uint8_t ver = c.d[c.o++];
-  if (ver == 0x01) throw Error("multi message-id proof values are not supported by this backend");
-  if (ver != 0x00) {
+  if (ver > 0x01) {
     char buf[8];
     snprintf(buf, sizeof buf, "%#04x", ver);
     throw Error(std::string("Unknown message mode version byte: ") + buf);
@@ -551,8 +824,21 @@ FFI_RLNProofValues values_from(Cursor& c) {  // proof.rs:285-411
   v.root = c.fr();
   v.external_nullifier = c.fr();
   v.x = c.fr();
-  v.y = c.fr();
-  v.nullifier = c.fr();
+  if (ver == 0x00) {
+    v.y = c.fr();
+    v.nullifier = c.fr();
+  } else {
+    v.multi = true;
+    v.ys = c.vec_fr();
+    v.nullifiers = c.vec_fr();
+    v.selector_used = read_vec_bool(c);
+    if (v.selector_used.size() != v.ys.size())
+      throw Error("The field ys has length " + std::to_string(v.ys.size()) + ", but the field selector_used has length " +
+                  std::to_string(v.selector_used.size()));
+    if (v.nullifiers.size() != v.ys.size())
+      throw Error("The field ys has length " + std::to_string(v.ys.size()) + ", but the field nullifiers has length " +
+                  std::to_string(v.nullifiers.size()));
+  }
   return v;
 }
 FFI_RLNProof* proof_from_bytes(const Vec_uint8_t* bytes, bool be) {  // proof.rs:455-530
@@ -578,41 +864,84 @@ FFI_RLNProof* proof_from_bytes(const Vec_uint8_t* bytes, bool be) {  // proof.rs
     throw Error("Expected to read " + std::to_string(c.o) + " bytes but read " + std::to_string(bytes->len) + " bytes");
   return pr.release();
 }
-std::vector<uint8_t> witness_bytes(const FFI_RLNWitnessInput& w, bool be) {  // witness.rs:369-468
+std::vector<uint8_t> witness_bytes(const FFI_RLNWitnessInput& w, bool be) {  // witness.rs:369-468, mode.rs:27-35
   std::vector<uint8_t> b;
-  b.push_back(0x00);
+  b.push_back(w.multi ? 0x01 : 0x00);
   put_fr(b, w.identity_secret, be);
   put_fr(b, w.user_message_limit, be);
-  put_fr(b, w.message_id, be);
-  put_u64(b, w.path_elements.size(), be);
-  for (auto& e : w.path_elements) put_fr(b, e, be);
+  if (!w.multi) put_fr(b, w.message_id, be);
+  put_vec_fr(b, w.path_elements, be);
   put_u64(b, w.identity_path_index.size(), be);
   b.insert(b.end(), w.identity_path_index.begin(), w.identity_path_index.end());
   put_fr(b, w.x, be);
   put_fr(b, w.external_nullifier, be);
+  if (w.multi) {
+    put_vec_fr(b, w.message_ids, be);
+    put_vec_bool(b, w.selector_used, be);
+  }
   return b;
 }
 FFI_RLNWitnessInput* witness_from_bytes(const Vec_uint8_t* bytes, bool be) {  // witness.rs:470-620
   if (!bytes || bytes->len == 0) throw Error("Expected to read 1 bytes but read 0 bytes");
   Cursor c{bytes->ptr, bytes->len, 0, be};
   uint8_t ver = c.d[c.o++];
-  if (ver == 0x01) throw Error("multi message-id witnesses are not supported by this backend");
-  if (ver != 0x00) {
+  if (ver > 0x01) {
     char buf[8];
     snprintf(buf, sizeof buf, "%#04x", ver);
     throw Error(std::string("Unknown message mode version byte: ") + buf);
   }
   std::unique_ptr<FFI_RLNWitnessInput> w(new FFI_RLNWitnessInput);
+  w->multi = ver == 0x01;
   w->identity_secret = c.fr();
   w->user_message_limit = c.fr();
-  w->message_id = c.fr();
+  if (!w->multi) w->message_id = c.fr();
   w->path_elements = c.vec_fr();
   w->identity_path_index = c.vec_u8();
   w->x = c.fr();
   w->external_nullifier = c.fr();
+  if (w->multi) {
+    w->message_ids = c.vec_fr();
+    w->selector_used = read_vec_bool(c);
+  }
   if (c.o != bytes->len)
     throw Error("Expected to read " + std::to_string(c.o) + " bytes but read " + std::to_string(bytes->len) + " bytes");
   validate_witness(*w);
+  return w.release();
+}
+
+void validate_partial_witness(const FFI_RLNPartialWitnessInput& w) {  // witness.rs:253-270
+  if (cfr_is_zero(w.user_message_limit)) throw Error("User message limit cannot be zero");
+  if (w.path_elements.size() != w.identity_path_index.size())
+    throw Error("Merkle proof length mismatch: expected " + std::to_string(w.path_elements.size()) + ", got " +
+                std::to_string(w.identity_path_index.size()));
+}
+std::vector<uint8_t> partial_witness_bytes(const FFI_RLNPartialWitnessInput& w, bool be) {  // witness.rs:631-676
+  std::vector<uint8_t> b;
+  b.push_back(0x00);
+  put_fr(b, w.identity_secret, be);
+  put_fr(b, w.user_message_limit, be);
+  put_vec_fr(b, w.path_elements, be);
+  put_u64(b, w.identity_path_index.size(), be);
+  b.insert(b.end(), w.identity_path_index.begin(), w.identity_path_index.end());
+  return b;
+}
+FFI_RLNPartialWitnessInput* partial_witness_from_bytes(const Vec_uint8_t* bytes, bool be) {  // witness.rs:679-760
+  if (!bytes || bytes->len == 0) throw Error("Expected to read 1 bytes but read 0 bytes");
+  Cursor c{bytes->ptr, bytes->len, 0, be};
+  uint8_t ver = c.d[c.o++];
+  if (ver > 0x01) {
+    char buf[8];
+    snprintf(buf, sizeof buf, "%#04x", ver);
+    throw Error(std::string("Unknown message mode version byte: ") + buf);
+  }
+  std::unique_ptr<FFI_RLNPartialWitnessInput> w(new FFI_RLNPartialWitnessInput);
+  w->identity_secret = c.fr();
+  w->user_message_limit = c.fr();
+  w->path_elements = c.vec_fr();
+  w->identity_path_index = c.vec_u8();
+  if (c.o != bytes->len)
+    throw Error("Expected to read " + std::to_string(c.o) + " bytes but read " + std::to_string(bytes->len) + " bytes");
+  validate_partial_witness(*w);
   return w.release();
 }
 
@@ -750,10 +1079,10 @@ CBoolResult_t ffi_verify_with_roots(FFI_RLN_t* const* rln, FFI_RLNProof_t* const
 FFI_RLNProofValues_t* ffi_rln_proof_get_values(FFI_RLNProof_t* const* proof) {
   return (FFI_RLNProofValues_t*)new FFI_RLNProofValues(((FFI_RLNProof*)*proof)->values);
 }
-uint8_t ffi_rln_proof_get_version_byte(FFI_RLNProof_t* const*) { return 0x00; }
+uint8_t ffi_rln_proof_get_version_byte(FFI_RLNProof_t* const* p) { return ((FFI_RLNProof*)*p)->values.multi ? 0x01 : 0x00; }
 static std::vector<uint8_t> proof_bytes(const FFI_RLNProof& pr, bool be) {  // proof.rs:413-449
   std::vector<uint8_t> b;
-  b.push_back(0x00);
+  b.push_back(pr.values.multi ? 0x01 : 0x00);
   b.insert(b.end(), pr.proof, pr.proof + 128);
   auto v = values_bytes(pr.values, be);
   b.insert(b.end(), v.begin(), v.end());
@@ -785,10 +1114,7 @@ CResult_FFI_RLNPartialWitnessInput_ptr_Vec_uint8_t ffi_rln_partial_witness_input
     w->user_message_limit = R(user_message_limit);
     w->path_elements.assign((const CFr*)path_elements->ptr, (const CFr*)path_elements->ptr + path_elements->len);
     w->identity_path_index.assign(identity_path_index->ptr, identity_path_index->ptr + identity_path_index->len);
-    if (cfr_is_zero(w->user_message_limit)) throw Error("User message limit cannot be zero");  // witness.rs:253-270
-    if (w->path_elements.size() != w->identity_path_index.size())
-      throw Error("Merkle proof length mismatch: expected " + std::to_string(w->path_elements.size()) + ", got " +
-                  std::to_string(w->identity_path_index.size()));
+    validate_partial_witness(*w);
     return (FFI_RLNPartialWitnessInput_t*)w.release();
   });
 }
@@ -802,6 +1128,34 @@ FFI_RLNPartialWitnessInput_t* ffi_rln_witness_to_partial_witness(FFI_RLNWitnessI
   return (FFI_RLNPartialWitnessInput_t*)p;
 }
 void ffi_rln_partial_witness_input_free(FFI_RLNPartialWitnessInput_t* w) { delete (FFI_RLNPartialWitnessInput*)w; }
+#define PW(w) (*(FFI_RLNPartialWitnessInput*)*(w))
+uint8_t ffi_rln_partial_witness_input_get_version_byte(FFI_RLNPartialWitnessInput_t* const*) { return 0x00; }
+CFr_t* ffi_rln_partial_witness_input_get_identity_secret(FFI_RLNPartialWitnessInput_t* const* w) {
+  return box_cfr(PW(w).identity_secret);
+}
+CFr_t* ffi_rln_partial_witness_input_get_user_message_limit(FFI_RLNPartialWitnessInput_t* const* w) {
+  return box_cfr(PW(w).user_message_limit);
+}
+Vec_CFr_t ffi_rln_partial_witness_input_get_path_elements(FFI_RLNPartialWitnessInput_t* const* w) {
+  return make_vec_cfr(PW(w).path_elements);
+}
+Vec_uint8_t ffi_rln_partial_witness_input_get_identity_path_index(FFI_RLNPartialWitnessInput_t* const* w) {
+  return make_bytes(PW(w).identity_path_index);
+}
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_partial_witness_to_bytes_le(FFI_RLNPartialWitnessInput_t* const* w) {
+  return guard_bytes([&]() { return partial_witness_bytes(PW(w), false); });
+}
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_partial_witness_to_bytes_be(FFI_RLNPartialWitnessInput_t* const* w) {
+  return guard_bytes([&]() { return partial_witness_bytes(PW(w), true); });
+}
+CResult_FFI_RLNPartialWitnessInput_ptr_Vec_uint8_t ffi_bytes_le_to_rln_partial_witness(const Vec_uint8_t* b) {
+  return guard_ptr<CResult_FFI_RLNPartialWitnessInput_ptr_Vec_uint8_t>(
+      [&]() -> FFI_RLNPartialWitnessInput_t* { return (FFI_RLNPartialWitnessInput_t*)partial_witness_from_bytes(b, false); });
+}
+CResult_FFI_RLNPartialWitnessInput_ptr_Vec_uint8_t ffi_bytes_be_to_rln_partial_witness(const Vec_uint8_t* b) {
+  return guard_ptr<CResult_FFI_RLNPartialWitnessInput_ptr_Vec_uint8_t>(
+      [&]() -> FFI_RLNPartialWitnessInput_t* { return (FFI_RLNPartialWitnessInput_t*)partial_witness_from_bytes(b, true); });
+}
 CResult_FFI_RLNPartialProof_ptr_Vec_uint8_t ffi_generate_partial_zk_proof(
     FFI_RLN_t* const* rln, FFI_RLNPartialWitnessInput_t* const* partial_witness) {
   return guard_ptr<CResult_FFI_RLNPartialProof_ptr_Vec_uint8_t>([&]() -> FFI_RLNPartialProof_t* {
@@ -859,8 +1213,36 @@ CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t ffi_rln_witness_input_new_single(
     return (FFI_RLNWitnessInput_t*)w.release();
   });
 }
+CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t ffi_rln_witness_input_new_multi(
+    const CFr_t* identity_secret, const CFr_t* user_message_limit, const Vec_CFr_t* message_ids,
+    const Vec_CFr_t* path_elements, const Vec_uint8_t* identity_path_index, const CFr_t* x,
+    const CFr_t* external_nullifier, const Vec_bool_t* selector_used) {
+  return guard_ptr<CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t>([&]() -> FFI_RLNWitnessInput_t* {
+    std::unique_ptr<FFI_RLNWitnessInput> w(new FFI_RLNWitnessInput);
+    w->multi = true;
+    w->identity_secret = R(identity_secret);
+    w->user_message_limit = R(user_message_limit);
+    w->message_id = cfr_from_u64(0);
+    w->message_ids.assign((const CFr*)message_ids->ptr, (const CFr*)message_ids->ptr + message_ids->len);
+    w->path_elements.assign((const CFr*)path_elements->ptr, (const CFr*)path_elements->ptr + path_elements->len);
+    w->identity_path_index.assign(identity_path_index->ptr, identity_path_index->ptr + identity_path_index->len);
+    w->x = R(x);
+    w->external_nullifier = R(external_nullifier);
+    for (size_t i = 0; i < selector_used->len; i++) w->selector_used.push_back(selector_used->ptr[i] ? 1 : 0);
+    validate_witness(*w);
+    return (FFI_RLNWitnessInput_t*)w.release();
+  });
+}
 #define W(w) (*(FFI_RLNWitnessInput*)*(w))
-uint8_t ffi_rln_witness_input_get_version_byte(FFI_RLNWitnessInput_t* const*) { return 0x00; }
+static Vec_bool_t make_vec_bool(const std::vector<uint8_t>& v) {
+  bool* p = (bool*)malloc(v.size() ? v.size() : 1);
+  for (size_t i = 0; i < v.size(); i++) p[i] = v[i] != 0;
+  return {p, v.size(), v.size() ? v.size() : 1};
+}
+Vec_CFr_t ffi_rln_witness_input_get_message_ids(FFI_RLNWitnessInput_t* const* w) { return make_vec_cfr(W(w).message_ids); }
+Vec_bool_t ffi_rln_witness_input_get_selector_used(FFI_RLNWitnessInput_t* const* w) { return make_vec_bool(W(w).selector_used); }
+void ffi_vec_bool_free(Vec_bool_t v) { free(v.ptr); }
+uint8_t ffi_rln_witness_input_get_version_byte(FFI_RLNWitnessInput_t* const* w) { return W(w).multi ? 0x01 : 0x00; }
 CFr_t* ffi_rln_witness_input_get_identity_secret(FFI_RLNWitnessInput_t* const* w) { return box_cfr(W(w).identity_secret); }
 CFr_t* ffi_rln_witness_input_get_user_message_limit(FFI_RLNWitnessInput_t* const* w) { return box_cfr(W(w).user_message_limit); }
 CFr_t* ffi_rln_witness_input_get_message_id(FFI_RLNWitnessInput_t* const* w) { return box_cfr(W(w).message_id); }
@@ -889,9 +1271,30 @@ void ffi_rln_witness_input_free(FFI_RLNWitnessInput_t* w) { delete (FFI_RLNWitne
 CFr_t* ffi_rln_proof_values_get_root(FFI_RLNProofValues_t* const* pv) { return box_cfr(PV(pv).root); }
 CFr_t* ffi_rln_proof_values_get_x(FFI_RLNProofValues_t* const* pv) { return box_cfr(PV(pv).x); }
 CFr_t* ffi_rln_proof_values_get_external_nullifier(FFI_RLNProofValues_t* const* pv) { return box_cfr(PV(pv).external_nullifier); }
-CResult_CFr_ptr_Vec_uint8_t ffi_rln_proof_values_get_y(FFI_RLNProofValues_t* const* pv) { return {box_cfr(PV(pv).y), no_err()}; }
-CResult_CFr_ptr_Vec_uint8_t ffi_rln_proof_values_get_nullifier(FFI_RLNProofValues_t* const* pv) { return {box_cfr(PV(pv).nullifier), no_err()}; }
-uint8_t ffi_rln_proof_values_get_version_byte(FFI_RLNProofValues_t* const*) { return 0x00; }
+// wrong-variant getters return an error string (the V3 behaviour, ffi_rln_v3.rs:705-718; V1 panics)
+CResult_CFr_ptr_Vec_uint8_t ffi_rln_proof_values_get_y(FFI_RLNProofValues_t* const* pv) {
+  if (PV(pv).multi) return {nullptr, make_str("Field `y` does not exist on the `MultiV1` variant")};
+  return {box_cfr(PV(pv).y), no_err()};
+}
+CResult_CFr_ptr_Vec_uint8_t ffi_rln_proof_values_get_nullifier(FFI_RLNProofValues_t* const* pv) {
+  if (PV(pv).multi) return {nullptr, make_str("Field `nullifier` does not exist on the `MultiV1` variant")};
+  return {box_cfr(PV(pv).nullifier), no_err()};
+}
+CResult_Vec_CFr_Vec_uint8_t ffi_rln_proof_values_get_ys(FFI_RLNProofValues_t* const* pv) {
+  if (!PV(pv).multi) return {Vec_CFr_t{nullptr, 0, 0}, make_str("Field `ys` does not exist on the `SingleV1` variant")};
+  return {make_vec_cfr(PV(pv).ys), no_err()};
+}
+CResult_Vec_CFr_Vec_uint8_t ffi_rln_proof_values_get_nullifiers(FFI_RLNProofValues_t* const* pv) {
+  if (!PV(pv).multi)
+    return {Vec_CFr_t{nullptr, 0, 0}, make_str("Field `nullifiers` does not exist on the `SingleV1` variant")};
+  return {make_vec_cfr(PV(pv).nullifiers), no_err()};
+}
+CResult_Vec_bool_Vec_uint8_t ffi_rln_proof_values_get_selector_used(FFI_RLNProofValues_t* const* pv) {
+  if (!PV(pv).multi)
+    return {Vec_bool_t{nullptr, 0, 0}, make_str("Field `selector_used` does not exist on the `SingleV1` variant")};
+  return {make_vec_bool(PV(pv).selector_used), no_err()};
+}
+uint8_t ffi_rln_proof_values_get_version_byte(FFI_RLNProofValues_t* const* pv) { return PV(pv).multi ? 0x01 : 0x00; }
 Vec_uint8_t ffi_rln_proof_values_to_bytes_le(FFI_RLNProofValues_t* const* pv) { return make_bytes(values_bytes(PV(pv), false)); }
 Vec_uint8_t ffi_rln_proof_values_to_bytes_be(FFI_RLNProofValues_t* const* pv) { return make_bytes(values_bytes(PV(pv), true)); }
 static FFI_RLNProofValues* pv_from(const Vec_uint8_t* b, bool be) {
@@ -1111,6 +1514,69 @@ Vec_CFr_t ffi_key_gen(void) {  // keygen (protocol/keygen.rs:18-30): random secr
   memset(commitment.le, 0, 32);
   (void)rlnamd_poseidon_hash(secret.le, 1, 1, commitment.le);
   return make_vec_cfr({secret, commitment});
+}
+Vec_CFr_t ffi_seeded_key_gen(const Vec_uint8_t* seed) {  // seeded_keygen (protocol/keygen.rs:50-65)
+  ChaCha20Rng rng = seeded_rng(seed);
+  CFr secret = rng.next_fr();
+  return make_vec_cfr({secret, poseidon_host_call({secret})});
+}
+static Vec_CFr_t extended_identity(const CFr& trapdoor, const CFr& nullifier) {  // keygen.rs:31-45
+  CFr secret = poseidon_host_call({trapdoor, nullifier});
+  return make_vec_cfr({trapdoor, nullifier, secret, poseidon_host_call({secret})});
+}
+Vec_CFr_t ffi_extended_key_gen(void) { return extended_identity(random_fr(), random_fr()); }
+Vec_CFr_t ffi_seeded_extended_key_gen(const Vec_uint8_t* seed) {  // extended_seeded_keygen (keygen.rs:72-94)
+  ChaCha20Rng rng = seeded_rng(seed);
+  CFr trapdoor = rng.next_fr();
+  CFr nullifier = rng.next_fr();
+  return extended_identity(trapdoor, nullifier);
+}
+
+CResult_CFr_ptr_Vec_uint8_t ffi_compute_id_secret(const CFr_t* share1_x, const CFr_t* share1_y, const CFr_t* share2_x,
+                                                  const CFr_t* share2_y) {
+  return guard_ptr<CResult_CFr_ptr_Vec_uint8_t>(
+      [&]() -> CFr_t* { return box_cfr(compute_id_secret(R(share1_x), R(share1_y), R(share2_x), R(share2_y))); });
+}
+CResult_CFr_ptr_Vec_uint8_t ffi_recover_id_secret(FFI_RLNProofValues_t* const* pv1, FFI_RLNProofValues_t* const* pv2) {
+  return guard_ptr<CResult_CFr_ptr_Vec_uint8_t>([&]() -> CFr_t* {  // recover_id_secret (slashing.rs:43-100)
+    const FFI_RLNProofValues &a = PV(pv1), &b = PV(pv2);
+    if (cfr_cmp(a.external_nullifier, b.external_nullifier) != 0)
+      throw Error("External nullifiers mismatch: " + cfr_dec(a.external_nullifier) + " != " +
+                  cfr_dec(b.external_nullifier));
+    if (!a.multi && !b.multi) return box_cfr(compute_id_secret(a.x, a.y, b.x, b.y));
+    if (a.multi && b.multi)
+      for (size_t i = 0; i < a.nullifiers.size(); i++) {
+        if (!a.selector_used[i]) continue;
+        for (size_t j = 0; j < b.nullifiers.size(); j++)
+          if (b.selector_used[j] && cfr_cmp(a.nullifiers[i], b.nullifiers[j]) == 0)
+            return box_cfr(compute_id_secret(a.x, a.ys[i], b.x, b.ys[j]));
+      }
+    throw Error("No matching nullifier found across the provided proof values");
+  });
+}
+
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_witness_to_bigint_json(FFI_RLNWitnessInput_t* const* wp) {
+  // rln_witness_to_bigint_json (witness.rs:317-366); serde_json's default map is a BTreeMap: keys sorted, compact
+  const FFI_RLNWitnessInput& w = W(wp);
+  std::vector<std::string> pe, pi, ids, sel;
+  for (auto& e : w.path_elements) pe.push_back(cfr_dec(e));
+  for (uint8_t b : w.identity_path_index) pi.push_back(std::to_string((unsigned)b));
+  for (auto& e : w.message_ids) ids.push_back(cfr_dec(e));
+  for (uint8_t b : w.selector_used) sel.push_back(b ? "1" : "0");
+  std::string j = "{\"externalNullifier\":\"" + cfr_dec(w.external_nullifier) + "\",\"identityPathIndex\":" +
+                  json_str_array(pi) + ",\"identitySecret\":\"" + cfr_dec(w.identity_secret) + "\",\"messageId\":" +
+                  (w.multi ? json_str_array(ids) : "\"" + cfr_dec(w.message_id) + "\"") + ",\"pathElements\":" +
+                  json_str_array(pe) + (w.multi ? ",\"selectorUsed\":" + json_str_array(sel) : "") +
+                  ",\"userMessageLimit\":\"" + cfr_dec(w.user_message_limit) + "\",\"x\":\"" + cfr_dec(w.x) + "\"}";
+  return {make_str(j), no_err()};
+}
+
+CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_generate_rln_proof_with_witness(FFI_RLN_t* const* rln,
+                                                                         const Vec_String_t* calculated_witness,
+                                                                         FFI_RLNWitnessInput_t* const* witness) {
+  return guard_ptr<CResult_FFI_RLNProof_ptr_Vec_uint8_t>([&]() -> FFI_RLNProof_t* {
+    return (FFI_RLNProof_t*)prove_with_witness(*(FFI_RLN*)*rln, calculated_witness, W(witness));
+  });
 }
 void ffi_c_string_free(Vec_uint8_t s) { free(s.ptr); }
 

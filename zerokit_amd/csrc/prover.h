@@ -64,6 +64,10 @@ class Prover {
   // slot 0 = 1, iden3calc.rs:122-181); rs = n x 2 x 32 bytes (r, s).  Copies to the device.
   void upload(size_t n, const uint8_t* inputs, const uint8_t* rs);
   // Runs the whole pipeline on the resident inputs and waits for it.
+  // Externally calculated witnesses (n x num_signals canonical LE) for the NEXT run(n, PROVE_FULL): they replace
+  // the graph interpreter's output (generate_zk_proof_with_witness, protocol/proof.rs:705-732).
+  void upload_witness(size_t n, const uint8_t* w_le);
+  size_t num_signals() const { return graph_.signals.size(); }
   void run(size_t n, int mode = PROVE_FULL);
   // Same, but only enqueues: consecutive calls overlap (batch k+1's witness/NTT front end and batch k-1's
   // finalize back end run beside batch k's MSM on separate HIP streams; two workspace slots).  Every

@@ -674,6 +674,17 @@ __global__ void k_gather_col(const Fr* __restrict__ src, const uint32_t* __restr
   src[(size_t)row * B + p].to_canonical(out + (size_t)i * 8);
 }
 
+// generate_zk_proof_with_witness (protocol/proof.rs:705-732): an externally calculated witness replaces the
+// graph interpreter's.  given = [proof][signal] canonical LE; each signal is stored at the node it aliases.
+__global__ void k_scatter_witness(const uint32_t* __restrict__ given, const uint32_t* __restrict__ sig2node,
+                                  uint32_t NS, Fr* __restrict__ V, uint32_t* __restrict__ err, uint32_t B, uint32_t nb) {
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  uint32_t j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (p >= nb || j >= NS) return;
+  V[(size_t)sig2node[j] * B + p] = Fr::from_canonical(given + ((size_t)p * NS + j) * 8);
+  if (j == 0) err[p] = WERR_NONE;
+}
+
 // =====================================================================================================
 // host side
 // =====================================================================================================
@@ -728,6 +739,8 @@ struct Prover::Impl {
   uint32_t npts1 = 0, npts2 = 0;
   std::vector<uint8_t> known;  // per witness signal: computable from the partial witness (evaluate_partial)
   DevBuf<uint32_t> pp_in;      // resident partial-proof points for finish mode, 320 B per proof
+  DevBuf<uint32_t> wgiven;     // externally calculated witnesses for the next run (upload_witness), else empty
+  size_t wgiven_n = 0;
   InputSlots slots{};
   bool have_values_kernel = false;
   // resident inputs (shared by both slots; upload() drains the pipeline first)
@@ -1099,6 +1112,17 @@ void Prover::upload(size_t n, const uint8_t* inputs, const uint8_t* rs) {
   RLN_HIP(hipStreamSynchronize(D.sA));
 }
 
+void Prover::upload_witness(size_t n, const uint8_t* w_le) {
+  if (n > B_) throw Error("batch larger than the prover workspace (max_batch)");
+  Impl& D = *d_;
+  D.sync_all();
+  size_t words = n * (size_t)D.NS * 8;
+  if (D.wgiven.n < words) D.wgiven.alloc(words);
+  RLN_HIP(hipMemcpyAsync(D.wgiven.p, w_le, words * 4, hipMemcpyHostToDevice, D.sA));
+  RLN_HIP(hipStreamSynchronize(D.sA));
+  D.wgiven_n = n;
+}
+
 template <bool DIF>
 static void launch_ntt(Fr* data, const Fr* tw, int logn, const Fr* final_scale, uint32_t B, uint32_t nb,
                        hipStream_t s) {
@@ -1143,6 +1167,12 @@ void Prover::run_async(size_t n, int mode) {
   RLN_HIP(hipEventRecord(S.t[1], D.sA));
   hipLaunchKernelGGL(k_witness, dim3(pg), dim3(64), 0, D.sA, D.nodes.p, D.N, D.consts.p, D.inputs.p, D.NI, S.V.p,
                      S.err.p, B, nbp);
+  if (D.wgiven_n) {
+    if (D.wgiven_n != n || mode != PROVE_FULL) throw Error("upload_witness: the next run must be a full proof of the same batch");
+    hipLaunchKernelGGL(k_scatter_witness, dim3(pg, div_up(D.NS, 4)), dim3(64, 4), 0, D.sA, D.wgiven.p, D.sig2node.p,
+                       D.NS, S.V.p, S.err.p, B, nb);
+    D.wgiven_n = 0;
+  }
   RLN_HIP(hipEventRecord(S.t[2], D.sA));
   if (mode != PROVE_PARTIAL) {  // the quotient h depends on the whole witness: not part of a partial proof
     CsrView A{D.a_ptr.p, D.a_col.p, D.a_coef.p}, Bm{D.b_ptr.p, D.b_col.p, D.b_coef.p};

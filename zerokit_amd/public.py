@@ -4,7 +4,7 @@ errors are RLNError carrying the string the ABI returned (the reference stringif
 rln/src/ffi/ffi_rln.rs:52-55)."""
 import ctypes as C
 
-from ._native import (CFr, CResultPtr, MerkleProof, RLNError, VecCFr, VecSize, VecU8, lib)
+from ._native import (CFr, CResultPtr, MerkleProof, RLNError, VecBool, VecCFr, VecSize, VecString, VecU8, lib)
 
 
 def _cfr(x: int) -> CFr:
@@ -33,6 +33,23 @@ def _vec_cfr(vals):
 def _vec_u8(b: bytes):
     arr = (C.c_uint8 * max(len(b), 1)).from_buffer_copy(bytes(b) if len(b) else b"\0")
     return VecU8(C.cast(arr, C.POINTER(C.c_uint8)), len(b), len(b)), arr
+
+
+def _vec_bool(vals):
+    arr = (C.c_bool * max(len(vals), 1))(*[bool(v) for v in vals])
+    return VecBool(C.cast(arr, C.POINTER(C.c_bool)), len(vals), len(vals)), arr
+
+
+def _take_vec_cfr(v: VecCFr):
+    out = [int.from_bytes(bytes(v.ptr[i].le), "little") for i in range(v.len)]
+    lib().ffi_vec_cfr_free(v)
+    return out
+
+
+def _take_vec_bool(v: VecBool):
+    out = [bool(v.ptr[i]) for i in range(v.len)]
+    lib().ffi_vec_bool_free(v)
+    return out
 
 
 def _err(v: VecU8) -> str:
@@ -76,10 +93,38 @@ class RLNWitnessInput:
             C.byref(_cfr(identity_secret)), C.byref(_cfr(user_message_limit)), C.byref(_cfr(message_id)),
             C.byref(pe), C.byref(pi), C.byref(_cfr(x)), C.byref(_cfr(external_nullifier))))
 
+    @classmethod
+    def new_multi(cls, identity_secret, user_message_limit, message_ids, path_elements, identity_path_index, x,
+                  external_nullifier, selector_used):
+        """RLNWitnessInput::new_multi (protocol/witness.rs:117-180)"""
+        mi, _k0 = _vec_cfr(message_ids)
+        pe, _k1 = _vec_cfr(path_elements)
+        pi, _k2 = _vec_u8(bytes(identity_path_index))
+        su, _k3 = _vec_bool(selector_used)
+        return cls(0, 0, 0, [], [], 0, 0, _handle=_ok_ptr(lib().ffi_rln_witness_input_new_multi(
+            C.byref(_cfr(identity_secret)), C.byref(_cfr(user_message_limit)), C.byref(mi), C.byref(pe),
+            C.byref(pi), C.byref(_cfr(x)), C.byref(_cfr(external_nullifier)), C.byref(su))))
+
     def __del__(self):
         if getattr(self, "_h", None):
             lib().ffi_rln_witness_input_free(self._h)
             self._h = None
+
+    @property
+    def version_byte(self):
+        return lib().ffi_rln_witness_input_get_version_byte(C.byref(self._h))
+
+    def to_bigint_json(self) -> str:
+        """rln_witness_to_bigint_json (protocol/witness.rs:317-366)"""
+        return _take_bytes(lib().ffi_rln_witness_to_bigint_json(C.byref(self._h))).decode()
+
+    @property
+    def message_ids(self):
+        return _take_vec_cfr(lib().ffi_rln_witness_input_get_message_ids(C.byref(self._h)))
+
+    @property
+    def selector_used(self):
+        return _take_vec_bool(lib().ffi_rln_witness_input_get_selector_used(C.byref(self._h)))
 
     def to_bytes_le(self):
         return _take_bytes(lib().ffi_rln_witness_to_bytes_le(C.byref(self._h)))
@@ -118,6 +163,16 @@ class RLNProofValues:
             lib().ffi_rln_proof_values_free(self._h)
             self._h = None
 
+    @classmethod
+    def from_bytes_le(cls, b):
+        v, _k = _vec_u8(b)
+        return cls(_ok_ptr(lib().ffi_bytes_le_to_rln_proof_values(C.byref(v))))
+
+    @classmethod
+    def from_bytes_be(cls, b):
+        v, _k = _vec_u8(b)
+        return cls(_ok_ptr(lib().ffi_bytes_be_to_rln_proof_values(C.byref(v))))
+
     root = property(lambda s: _take_cfr(lib().ffi_rln_proof_values_get_root(C.byref(s._h))))
     x = property(lambda s: _take_cfr(lib().ffi_rln_proof_values_get_x(C.byref(s._h))))
     external_nullifier = property(
@@ -132,6 +187,20 @@ class RLNProofValues:
     def nullifier(self):
         r = lib().ffi_rln_proof_values_get_nullifier(C.byref(self._h))
         return _take_cfr(C.cast(_ok_ptr(r), C.POINTER(CFr)))
+
+    @property
+    def version_byte(self):
+        return lib().ffi_rln_proof_values_get_version_byte(C.byref(self._h))
+
+    def _vec(self, fn, take):
+        r = fn(C.byref(self._h))
+        if r.err.ptr:
+            raise RLNError(_err(r.err))
+        return take(r.ok)
+
+    ys = property(lambda s: s._vec(lib().ffi_rln_proof_values_get_ys, _take_vec_cfr))
+    nullifiers = property(lambda s: s._vec(lib().ffi_rln_proof_values_get_nullifiers, _take_vec_cfr))
+    selector_used = property(lambda s: s._vec(lib().ffi_rln_proof_values_get_selector_used, _take_vec_bool))
 
     def to_bytes_le(self):
         v = lib().ffi_rln_proof_values_to_bytes_le(C.byref(self._h))
@@ -188,6 +257,36 @@ class RLNPartialWitnessInput:
         self._h = _ok_ptr(lib().ffi_rln_partial_witness_input_new(
             C.byref(_cfr(identity_secret)), C.byref(_cfr(user_message_limit)), C.byref(pe), C.byref(pi)))
 
+    def to_bytes_le(self):
+        return _take_bytes(lib().ffi_rln_partial_witness_to_bytes_le(C.byref(self._h)))
+
+    def to_bytes_be(self):
+        return _take_bytes(lib().ffi_rln_partial_witness_to_bytes_be(C.byref(self._h)))
+
+    @classmethod
+    def from_bytes_le(cls, b):
+        v, _k = _vec_u8(b)
+        return cls(0, 0, [], [], _handle=_ok_ptr(lib().ffi_bytes_le_to_rln_partial_witness(C.byref(v))))
+
+    @classmethod
+    def from_bytes_be(cls, b):
+        v, _k = _vec_u8(b)
+        return cls(0, 0, [], [], _handle=_ok_ptr(lib().ffi_bytes_be_to_rln_partial_witness(C.byref(v))))
+
+    identity_secret = property(
+        lambda s: _take_cfr(lib().ffi_rln_partial_witness_input_get_identity_secret(C.byref(s._h))))
+    user_message_limit = property(
+        lambda s: _take_cfr(lib().ffi_rln_partial_witness_input_get_user_message_limit(C.byref(s._h))))
+    path_elements = property(
+        lambda s: _take_vec_cfr(lib().ffi_rln_partial_witness_input_get_path_elements(C.byref(s._h))))
+
+    @property
+    def identity_path_index(self):
+        v = lib().ffi_rln_partial_witness_input_get_identity_path_index(C.byref(self._h))
+        b = C.string_at(v.ptr, v.len)
+        lib().ffi_vec_u8_free(v)
+        return list(b)
+
     @classmethod
     def from_witness(cls, w: RLNWitnessInput):
         return cls(0, 0, [], [], _handle=C.c_void_p(lib().ffi_rln_witness_to_partial_witness(C.byref(w._h))))
@@ -236,6 +335,13 @@ class RLN:
             self._h = None
 
     # ---- Merkle-tree APIs (public.rs:298-593)
+    def tree_depth(self):
+        return int(lib().ffi_rln_get_tree_depth(C.byref(self._h)))
+
+    def max_out(self):
+        """message slots of the loaded circuit (1 for the single message-id circuit)"""
+        return int(lib().ffi_rln_get_max_out(C.byref(self._h)))
+
     def set_tree(self, tree_depth):
         _ok_bool(lib().ffi_set_tree(C.byref(self._h), tree_depth))
 
@@ -310,6 +416,19 @@ class RLN:
         _ok_bool(lib().ffi_generate_rln_proofs_batch(C.byref(self._h), hs, n, rsp, outs))
         return [RLNProof(C.c_void_p(outs[i])) for i in range(n)]
 
+    def generate_rln_proof_with_witness(self, calculated_witness, witness: RLNWitnessInput) -> RLNProof:
+        """public.rs:643-658: calculated_witness = the full witness as ints (or decimal strings)"""
+        strs = [str(v).encode() for v in calculated_witness]
+        arr = (VecU8 * max(len(strs), 1))()
+        keep = []
+        for i, b in enumerate(strs):
+            buf = (C.c_uint8 * max(len(b), 1)).from_buffer_copy(b or b"\0")
+            keep.append(buf)
+            arr[i] = VecU8(C.cast(buf, C.POINTER(C.c_uint8)), len(b), len(b))
+        vs = VecString(C.cast(arr, C.POINTER(VecU8)), len(strs), len(strs))
+        return RLNProof(_ok_ptr(lib().ffi_generate_rln_proof_with_witness(C.byref(self._h), C.byref(vs),
+                                                                          C.byref(witness._h))))
+
     def generate_partial_zk_proof(self, partial_witness: RLNPartialWitnessInput) -> RLNPartialProof:
         """public.rs:651-658"""
         return RLNPartialProof(_ok_ptr(lib().ffi_generate_partial_zk_proof(C.byref(self._h),
@@ -332,3 +451,33 @@ class RLN:
         v, _k = _vec_cfr(roots)
         return _ok_bool(lib().ffi_verify_with_roots(C.byref(self._h), C.byref(proof._h), C.byref(v),
                                                     C.byref(_cfr(x))))
+
+
+def compute_id_secret(share1, share2) -> int:
+    """protocol/slashing.rs:12-36: shares are (x, y) pairs"""
+    r = lib().ffi_compute_id_secret(C.byref(_cfr(share1[0])), C.byref(_cfr(share1[1])), C.byref(_cfr(share2[0])),
+                                    C.byref(_cfr(share2[1])))
+    return _take_cfr(C.cast(_ok_ptr(r), C.POINTER(CFr)))
+
+
+def recover_id_secret(values_1: RLNProofValues, values_2: RLNProofValues) -> int:
+    """protocol/slashing.rs:43-100"""
+    r = lib().ffi_recover_id_secret(C.byref(values_1._h), C.byref(values_2._h))
+    return _take_cfr(C.cast(_ok_ptr(r), C.POINTER(CFr)))
+
+
+def seeded_keygen(seed: bytes):
+    """protocol/keygen.rs:50-65 -> (identity_secret, id_commitment)"""
+    v, _k = _vec_u8(seed)
+    return tuple(_take_vec_cfr(lib().ffi_seeded_key_gen(C.byref(v))))
+
+
+def extended_keygen():
+    """protocol/keygen.rs:31-45 -> (trapdoor, nullifier, identity_secret, id_commitment)"""
+    return tuple(_take_vec_cfr(lib().ffi_extended_key_gen()))
+
+
+def extended_seeded_keygen(seed: bytes):
+    """protocol/keygen.rs:72-94"""
+    v, _k = _vec_u8(seed)
+    return tuple(_take_vec_cfr(lib().ffi_seeded_extended_key_gen(C.byref(v))))
