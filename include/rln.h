@@ -14,7 +14,7 @@
  *    (ffi_utils.rs:183-185).  In this implementation a CFr is the 32-byte little-endian canonical value.
  *
  * Scope: single and multi message-id circuits, in-memory tree, full and partial proofs.  Not
- * exported: the ffi_rln_v3_* mirror and the sled/pmtree persistence (§8f).
+ * kept: the sled/pmtree on-disk persistence (§8f rank 4); the ffi_rln_v3_* mirror is at the end of this file.
  * Extensions that the reference lacks are marked EXT (deterministic blinding, batch).
  */
 #ifndef RLN_H
@@ -227,6 +227,109 @@ Vec_CFr_t ffi_seeded_key_gen(const Vec_uint8_t* seed);                          
 Vec_CFr_t ffi_extended_key_gen(void);                                                          /* ffi_utils.rs:380 */
 Vec_CFr_t ffi_seeded_extended_key_gen(const Vec_uint8_t* seed);                                /* ffi_utils.rs:392 */
 void ffi_c_string_free(Vec_uint8_t s);                                                         /* ffi_utils.rs:407 */
+
+/* ==== V3 mirror (rln/src/ffi/ffi_rln_v3.rs:323-1609) -- what rln/ffi_c_examples and rln/ffi_nim_examples call.
+ * Same objects as above behind V3 names; differences: stateless / tree-flavour constructors, V3 error texts
+ * (rln/src/error.rs:104-208), ffi_rln_v3_verify returning plain `false` on a signal mismatch, and the V3 wire
+ * formats (protocol/serialize.rs): enum tag 0/1, values ordered y|root|nullifier|x|ext, proofs without a leading
+ * version byte, "mixed" = LE proof + BE values; deserialisers accept trailing bytes.  All three tree flavours map
+ * to the one device-resident tree; the pm-tree variant keeps no on-disk state. */
+typedef struct FFI_RLNV3 FFI_RLNV3_t;                                   /* ffi_rln_v3.rs:310-312 */
+typedef struct FFI_RLNV3WitnessInput FFI_RLNV3WitnessInput_t;           /* ffi_rln_v3.rs:612-614 */
+typedef struct FFI_RLNV3PartialWitnessInput FFI_RLNV3PartialWitnessInput_t; /* ffi_rln_v3.rs:864-866 */
+typedef struct FFI_RLNV3Proof FFI_RLNV3Proof_t;                         /* ffi_rln_v3.rs:1011-1013 */
+typedef struct FFI_RLNV3PartialProof FFI_RLNV3PartialProof_t;           /* ffi_rln_v3.rs:1095-1097 */
+typedef struct FFI_RLNV3ProofValues FFI_RLNV3ProofValues_t;             /* ffi_rln_v3.rs:1139-1141 */
+typedef struct FFI_RLNV3MerkleProof { Vec_CFr_t path_elements; Vec_uint8_t path_index; } FFI_RLNV3MerkleProof_t; /* :1363-1368 */
+typedef struct { FFI_RLNV3_t* ok; Vec_uint8_t err; } CResult_FFI_RLNV3_ptr_Vec_uint8_t;
+typedef struct { FFI_RLNV3WitnessInput_t* ok; Vec_uint8_t err; } CResult_FFI_RLNV3WitnessInput_ptr_Vec_uint8_t;
+typedef struct { FFI_RLNV3PartialWitnessInput_t* ok; Vec_uint8_t err; } CResult_FFI_RLNV3PartialWitnessInput_ptr_Vec_uint8_t;
+typedef struct { FFI_RLNV3Proof_t* ok; Vec_uint8_t err; } CResult_FFI_RLNV3Proof_ptr_Vec_uint8_t;
+typedef struct { FFI_RLNV3PartialProof_t* ok; Vec_uint8_t err; } CResult_FFI_RLNV3PartialProof_ptr_Vec_uint8_t;
+typedef struct { FFI_RLNV3ProofValues_t* ok; Vec_uint8_t err; } CResult_FFI_RLNV3ProofValues_ptr_Vec_uint8_t;
+typedef struct { FFI_RLNV3MerkleProof_t* ok; Vec_uint8_t err; } CResult_FFI_RLNV3MerkleProof_ptr_Vec_uint8_t;
+
+FFI_RLNV3_t* ffi_rln_v3_new_stateless_default(void); /* ffi_rln_v3.rs:324 */
+CResult_FFI_RLNV3_ptr_Vec_uint8_t ffi_rln_v3_new_stateless(const Vec_uint8_t* zkey_data, const Vec_uint8_t* graph_data); /* ffi_rln_v3.rs:330 */
+FFI_RLNV3_t* ffi_rln_v3_new_with_full_merkle_tree_default(void); /* ffi_rln_v3.rs:350 */
+CResult_FFI_RLNV3_ptr_Vec_uint8_t ffi_rln_v3_new_with_full_merkle_tree(size_t tree_depth, const Vec_uint8_t* zkey_data, const Vec_uint8_t* graph_data); /* ffi_rln_v3.rs:357 */
+FFI_RLNV3_t* ffi_rln_v3_new_with_optimal_merkle_tree_default(void); /* ffi_rln_v3.rs:391 */
+CResult_FFI_RLNV3_ptr_Vec_uint8_t ffi_rln_v3_new_with_optimal_merkle_tree(size_t tree_depth, const Vec_uint8_t* zkey_data, const Vec_uint8_t* graph_data); /* ffi_rln_v3.rs:399 */
+FFI_RLNV3_t* ffi_rln_v3_new_with_pm_tree_default(void); /* ffi_rln_v3.rs:433 */
+CResult_FFI_RLNV3_ptr_Vec_uint8_t ffi_rln_v3_new_with_pm_tree(size_t tree_depth, const Vec_uint8_t* zkey_data, const Vec_uint8_t* graph_data, const char* config_path); /* ffi_rln_v3.rs:440 */
+void ffi_rln_v3_free(FFI_RLNV3_t* rln); /* ffi_rln_v3.rs:606 */
+CResult_FFI_RLNV3Proof_ptr_Vec_uint8_t ffi_rln_v3_generate_proof(FFI_RLNV3_t* const* rln, FFI_RLNV3WitnessInput_t* const* witness); /* ffi_rln_v3.rs:507 */
+CResult_FFI_RLNV3Proof_ptr_Vec_uint8_t ffi_rln_v3_generate_proof_with_rs(FFI_RLNV3_t* const* rln, FFI_RLNV3WitnessInput_t* const* witness, const CFr_t* r, const CFr_t* s); /* EXT */
+CBoolResult_t ffi_rln_v3_verify(FFI_RLNV3_t* const* rln, FFI_RLNV3Proof_t* const* proof, const CFr_t* x); /* ffi_rln_v3.rs:524 */
+CBoolResult_t ffi_rln_v3_verify_with_roots(FFI_RLNV3_t* const* rln, FFI_RLNV3Proof_t* const* proof, const Vec_CFr_t* roots, const CFr_t* x); /* ffi_rln_v3.rs:548 */
+CResult_FFI_RLNV3PartialProof_ptr_Vec_uint8_t ffi_rln_v3_generate_partial_proof( FFI_RLNV3_t* const* rln, FFI_RLNV3PartialWitnessInput_t* const* partial_witness); /* ffi_rln_v3.rs:571 */
+CResult_FFI_RLNV3Proof_ptr_Vec_uint8_t ffi_rln_v3_finish_proof(FFI_RLNV3_t* const* rln, FFI_RLNV3PartialProof_t* const* partial, FFI_RLNV3WitnessInput_t* const* witness); /* ffi_rln_v3.rs:588 */
+CResult_FFI_RLNV3WitnessInput_ptr_Vec_uint8_t ffi_rln_v3_witness_input_new_single( const CFr_t* identity_secret, const CFr_t* user_message_limit, const CFr_t* message_id, const Vec_CFr_t* path_elements, const Vec_uint8_t* identity_path_index, const CFr_t* x, const CFr_t* external_nullifier); /* ffi_rln_v3.rs:617 */
+CResult_FFI_RLNV3WitnessInput_ptr_Vec_uint8_t ffi_rln_v3_witness_input_new_multi( const CFr_t* identity_secret, const CFr_t* user_message_limit, const Vec_CFr_t* message_ids, const Vec_CFr_t* path_elements, const Vec_uint8_t* identity_path_index, const CFr_t* x, const CFr_t* external_nullifier, const Vec_bool_t* selector_used); /* ffi_rln_v3.rs:652 */
+CFr_t* ffi_rln_v3_witness_input_get_identity_secret(FFI_RLNV3WitnessInput_t* const* w); /* ffi_rln_v3.rs:691 */
+CFr_t* ffi_rln_v3_witness_input_get_user_message_limit(FFI_RLNV3WitnessInput_t* const* w); /* ffi_rln_v3.rs:698 */
+CResult_CFr_ptr_Vec_uint8_t ffi_rln_v3_witness_input_get_message_id(FFI_RLNV3WitnessInput_t* const* w); /* ffi_rln_v3.rs:705 */
+CResult_Vec_CFr_Vec_uint8_t ffi_rln_v3_witness_input_get_message_ids(FFI_RLNV3WitnessInput_t* const* w); /* ffi_rln_v3.rs:721 */
+Vec_CFr_t ffi_rln_v3_witness_input_get_path_elements(FFI_RLNV3WitnessInput_t* const* w); /* ffi_rln_v3.rs:742 */
+Vec_uint8_t ffi_rln_v3_witness_input_get_identity_path_index(FFI_RLNV3WitnessInput_t* const* w); /* ffi_rln_v3.rs:755 */
+CFr_t* ffi_rln_v3_witness_input_get_x(FFI_RLNV3WitnessInput_t* const* w); /* ffi_rln_v3.rs:762 */
+CFr_t* ffi_rln_v3_witness_input_get_external_nullifier(FFI_RLNV3WitnessInput_t* const* w); /* ffi_rln_v3.rs:769 */
+CResult_Vec_bool_Vec_uint8_t ffi_rln_v3_witness_input_get_selector_used(FFI_RLNV3WitnessInput_t* const* w); /* ffi_rln_v3.rs:776 */
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_v3_witness_to_bytes_le(FFI_RLNV3WitnessInput_t* const* w); /* ffi_rln_v3.rs:792 */
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_v3_witness_to_bytes_be(FFI_RLNV3WitnessInput_t* const* w); /* ffi_rln_v3.rs:809 */
+CResult_FFI_RLNV3WitnessInput_ptr_Vec_uint8_t ffi_bytes_le_to_rln_v3_witness(const Vec_uint8_t* bytes); /* ffi_rln_v3.rs:826 */
+CResult_FFI_RLNV3WitnessInput_ptr_Vec_uint8_t ffi_bytes_be_to_rln_v3_witness(const Vec_uint8_t* bytes); /* ffi_rln_v3.rs:842 */
+void ffi_rln_v3_witness_input_free(FFI_RLNV3WitnessInput_t* w); /* ffi_rln_v3.rs:858 */
+CResult_FFI_RLNV3PartialWitnessInput_ptr_Vec_uint8_t ffi_rln_v3_partial_witness_input_new( const CFr_t* identity_secret, const CFr_t* user_message_limit, const Vec_CFr_t* path_elements, const Vec_uint8_t* identity_path_index); /* ffi_rln_v3.rs:869 */
+CFr_t* ffi_rln_v3_partial_witness_input_get_identity_secret(FFI_RLNV3PartialWitnessInput_t* const* w); /* ffi_rln_v3.rs:897 */
+CFr_t* ffi_rln_v3_partial_witness_input_get_user_message_limit(FFI_RLNV3PartialWitnessInput_t* const* w); /* ffi_rln_v3.rs:904 */
+Vec_CFr_t ffi_rln_v3_partial_witness_input_get_path_elements(FFI_RLNV3PartialWitnessInput_t* const* w); /* ffi_rln_v3.rs:911 */
+Vec_uint8_t ffi_rln_v3_partial_witness_input_get_identity_path_index(FFI_RLNV3PartialWitnessInput_t* const* w); /* ffi_rln_v3.rs:924 */
+FFI_RLNV3PartialWitnessInput_t* ffi_rln_v3_witness_to_partial_witness(FFI_RLNV3WitnessInput_t* const* w); /* ffi_rln_v3.rs:931 */
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_v3_partial_witness_to_bytes_le(FFI_RLNV3PartialWitnessInput_t* const* w); /* ffi_rln_v3.rs:939 */
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_v3_partial_witness_to_bytes_be(FFI_RLNV3PartialWitnessInput_t* const* w); /* ffi_rln_v3.rs:956 */
+CResult_FFI_RLNV3PartialWitnessInput_ptr_Vec_uint8_t ffi_bytes_le_to_rln_v3_partial_witness(const Vec_uint8_t* bytes); /* ffi_rln_v3.rs:973 */
+CResult_FFI_RLNV3PartialWitnessInput_ptr_Vec_uint8_t ffi_bytes_be_to_rln_v3_partial_witness(const Vec_uint8_t* bytes); /* ffi_rln_v3.rs:989 */
+void ffi_rln_v3_partial_witness_input_free(FFI_RLNV3PartialWitnessInput_t* w); /* ffi_rln_v3.rs:1005 */
+FFI_RLNV3ProofValues_t* ffi_rln_v3_proof_get_values(FFI_RLNV3Proof_t* const* proof); /* ffi_rln_v3.rs:1016 */
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_v3_proof_to_bytes_le(FFI_RLNV3Proof_t* const* proof); /* ffi_rln_v3.rs:1023 */
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_v3_proof_to_bytes_mixed(FFI_RLNV3Proof_t* const* proof); /* ffi_rln_v3.rs:1040 */
+CResult_FFI_RLNV3Proof_ptr_Vec_uint8_t ffi_bytes_le_to_rln_v3_proof(const Vec_uint8_t* bytes); /* ffi_rln_v3.rs:1057 */
+CResult_FFI_RLNV3Proof_ptr_Vec_uint8_t ffi_bytes_mixed_to_rln_v3_proof(const Vec_uint8_t* bytes); /* ffi_rln_v3.rs:1073 */
+void ffi_rln_v3_proof_free(FFI_RLNV3Proof_t* proof); /* ffi_rln_v3.rs:1089 */
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_v3_partial_proof_to_bytes_le(FFI_RLNV3PartialProof_t* const* partial); /* ffi_rln_v3.rs:1100 */
+CResult_FFI_RLNV3PartialProof_ptr_Vec_uint8_t ffi_bytes_le_to_rln_v3_partial_proof(const Vec_uint8_t* bytes); /* ffi_rln_v3.rs:1117 */
+void ffi_rln_v3_partial_proof_free(FFI_RLNV3PartialProof_t* partial); /* ffi_rln_v3.rs:1133 */
+CFr_t* ffi_rln_v3_proof_values_get_root(FFI_RLNV3ProofValues_t* const* pv); /* ffi_rln_v3.rs:1144 */
+CFr_t* ffi_rln_v3_proof_values_get_x(FFI_RLNV3ProofValues_t* const* pv); /* ffi_rln_v3.rs:1151 */
+CFr_t* ffi_rln_v3_proof_values_get_external_nullifier(FFI_RLNV3ProofValues_t* const* pv); /* ffi_rln_v3.rs:1156 */
+CResult_CFr_ptr_Vec_uint8_t ffi_rln_v3_proof_values_get_y(FFI_RLNV3ProofValues_t* const* pv); /* ffi_rln_v3.rs:1163 */
+CResult_CFr_ptr_Vec_uint8_t ffi_rln_v3_proof_values_get_nullifier(FFI_RLNV3ProofValues_t* const* pv); /* ffi_rln_v3.rs:1179 */
+CResult_Vec_bool_Vec_uint8_t ffi_rln_v3_proof_values_get_selector_used(FFI_RLNV3ProofValues_t* const* pv); /* ffi_rln_v3.rs:1195 */
+CResult_Vec_CFr_Vec_uint8_t ffi_rln_v3_proof_values_get_ys(FFI_RLNV3ProofValues_t* const* pv); /* ffi_rln_v3.rs:1211 */
+CResult_Vec_CFr_Vec_uint8_t ffi_rln_v3_proof_values_get_nullifiers(FFI_RLNV3ProofValues_t* const* pv); /* ffi_rln_v3.rs:1232 */
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_v3_proof_values_to_bytes_le(FFI_RLNV3ProofValues_t* const* pv); /* ffi_rln_v3.rs:1253 */
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_v3_proof_values_to_bytes_be(FFI_RLNV3ProofValues_t* const* pv); /* ffi_rln_v3.rs:1270 */
+CResult_FFI_RLNV3ProofValues_ptr_Vec_uint8_t ffi_bytes_le_to_rln_v3_proof_values(const Vec_uint8_t* bytes); /* ffi_rln_v3.rs:1287 */
+CResult_FFI_RLNV3ProofValues_ptr_Vec_uint8_t ffi_bytes_be_to_rln_v3_proof_values(const Vec_uint8_t* bytes); /* ffi_rln_v3.rs:1303 */
+void ffi_rln_v3_proof_values_free(FFI_RLNV3ProofValues_t* pv); /* ffi_rln_v3.rs:1319 */
+CResult_CFr_ptr_Vec_uint8_t ffi_rln_v3_compute_id_secret(const CFr_t* share1_x, const CFr_t* share1_y, const CFr_t* share2_x, const CFr_t* share2_y); /* ffi_rln_v3.rs:1324 */
+CResult_CFr_ptr_Vec_uint8_t ffi_rln_v3_recover_id_secret(FFI_RLNV3ProofValues_t* const* pv1, FFI_RLNV3ProofValues_t* const* pv2); /* ffi_rln_v3.rs:1345 */
+void ffi_rln_v3_merkle_proof_free(FFI_RLNV3MerkleProof_t* proof); /* ffi_rln_v3.rs:1371 */
+CBoolResult_t ffi_rln_v3_delete_leaf(FFI_RLNV3_t** rln, size_t index); /* ffi_rln_v3.rs:1376 */
+CBoolResult_t ffi_rln_v3_set_leaf(FFI_RLNV3_t** rln, size_t index, const CFr_t* leaf); /* ffi_rln_v3.rs:1390 */
+CResult_CFr_ptr_Vec_uint8_t ffi_rln_v3_get_leaf(FFI_RLNV3_t* const* rln, size_t index); /* ffi_rln_v3.rs:1408 */
+size_t ffi_rln_v3_leaves_set(FFI_RLNV3_t* const* rln); /* ffi_rln_v3.rs:1425 */
+CBoolResult_t ffi_rln_v3_set_next_leaf(FFI_RLNV3_t** rln, const CFr_t* leaf); /* ffi_rln_v3.rs:1430 */
+CBoolResult_t ffi_rln_v3_set_leaves_from(FFI_RLNV3_t** rln, size_t index, const Vec_CFr_t* leaves); /* ffi_rln_v3.rs:1444 */
+CBoolResult_t ffi_rln_v3_init_tree_with_leaves(FFI_RLNV3_t** rln, const Vec_CFr_t* leaves); /* ffi_rln_v3.rs:1463 */
+CBoolResult_t ffi_rln_v3_atomic_operation(FFI_RLNV3_t** rln, size_t index, const Vec_CFr_t* leaves, const Vec_size_t* indices); /* ffi_rln_v3.rs:1481 */
+CBoolResult_t ffi_rln_v3_seq_atomic_operation(FFI_RLNV3_t** rln, const Vec_CFr_t* leaves, const Vec_uint8_t* indices); /* ffi_rln_v3.rs:1502 */
+CFr_t* ffi_rln_v3_get_root(FFI_RLNV3_t* const* rln); /* ffi_rln_v3.rs:1531 */
+CResult_FFI_RLNV3MerkleProof_ptr_Vec_uint8_t ffi_rln_v3_get_merkle_proof(FFI_RLNV3_t* const* rln, size_t index); /* ffi_rln_v3.rs:1537 */
+CBoolResult_t ffi_rln_v3_set_metadata(FFI_RLNV3_t** rln, const Vec_uint8_t* metadata); /* ffi_rln_v3.rs:1565 */
+CResult_Vec_uint8_Vec_uint8_t ffi_rln_v3_get_metadata(FFI_RLNV3_t* const* rln); /* ffi_rln_v3.rs:1582 */
+CBoolResult_t ffi_rln_v3_flush(FFI_RLNV3_t** rln); /* ffi_rln_v3.rs:1598 */
 
 #ifdef __cplusplus
 }

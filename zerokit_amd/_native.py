@@ -251,6 +251,88 @@ SIGNATURES = {
     "ffi_hash_to_field_be": (CFRP, [C.POINTER(VecU8)]),
     "ffi_poseidon_hash_pair": (CFRP, [CFRP, CFRP]),
     "ffi_key_gen": (VecCFr, []),
+    # ---- V3 mirror (include/rln.h, ffi_rln_v3.rs:323-1609)
+    "ffi_rln_v3_new_stateless_default": (P, []),
+    "ffi_rln_v3_new_stateless": (CResultPtr, [C.POINTER(VecU8), C.POINTER(VecU8)]),
+    "ffi_rln_v3_new_with_full_merkle_tree_default": (P, []),
+    "ffi_rln_v3_new_with_full_merkle_tree": (CResultPtr, [C.c_size_t, C.POINTER(VecU8), C.POINTER(VecU8)]),
+    "ffi_rln_v3_new_with_optimal_merkle_tree_default": (P, []),
+    "ffi_rln_v3_new_with_optimal_merkle_tree": (CResultPtr, [C.c_size_t, C.POINTER(VecU8), C.POINTER(VecU8)]),
+    "ffi_rln_v3_new_with_pm_tree_default": (P, []),
+    "ffi_rln_v3_new_with_pm_tree": (CResultPtr, [C.c_size_t, C.POINTER(VecU8), C.POINTER(VecU8), C.c_char_p]),
+    "ffi_rln_v3_free": (None, [P]),
+    "ffi_rln_v3_generate_proof": (CResultPtr, [PP, PP]),
+    "ffi_rln_v3_generate_proof_with_rs": (CResultPtr, [PP, PP, CFRP, CFRP]),
+    "ffi_rln_v3_verify": (CBoolResult, [PP, PP, CFRP]),
+    "ffi_rln_v3_verify_with_roots": (CBoolResult, [PP, PP, C.POINTER(VecCFr), CFRP]),
+    "ffi_rln_v3_generate_partial_proof": (CResultPtr, [PP, PP]),
+    "ffi_rln_v3_finish_proof": (CResultPtr, [PP, PP, PP]),
+    "ffi_rln_v3_witness_input_new_single": (CResultPtr, [CFRP, CFRP, CFRP, C.POINTER(VecCFr), C.POINTER(VecU8), CFRP, CFRP]),
+    "ffi_rln_v3_witness_input_new_multi": (CResultPtr, [CFRP, CFRP, C.POINTER(VecCFr), C.POINTER(VecCFr), C.POINTER(VecU8), CFRP, CFRP, C.POINTER(VecBool)]),
+    "ffi_rln_v3_witness_input_get_identity_secret": (CFRP, [PP]),
+    "ffi_rln_v3_witness_input_get_user_message_limit": (CFRP, [PP]),
+    "ffi_rln_v3_witness_input_get_message_id": (CResultPtr, [PP]),
+    "ffi_rln_v3_witness_input_get_message_ids": (CResultVecCFr, [PP]),
+    "ffi_rln_v3_witness_input_get_path_elements": (VecCFr, [PP]),
+    "ffi_rln_v3_witness_input_get_identity_path_index": (VecU8, [PP]),
+    "ffi_rln_v3_witness_input_get_x": (CFRP, [PP]),
+    "ffi_rln_v3_witness_input_get_external_nullifier": (CFRP, [PP]),
+    "ffi_rln_v3_witness_input_get_selector_used": (CResultVecBool, [PP]),
+    "ffi_rln_v3_witness_to_bytes_le": (CResultVecU8, [PP]),
+    "ffi_rln_v3_witness_to_bytes_be": (CResultVecU8, [PP]),
+    "ffi_bytes_le_to_rln_v3_witness": (CResultPtr, [C.POINTER(VecU8)]),
+    "ffi_bytes_be_to_rln_v3_witness": (CResultPtr, [C.POINTER(VecU8)]),
+    "ffi_rln_v3_witness_input_free": (None, [P]),
+    "ffi_rln_v3_partial_witness_input_new": (CResultPtr, [CFRP, CFRP, C.POINTER(VecCFr), C.POINTER(VecU8)]),
+    "ffi_rln_v3_partial_witness_input_get_identity_secret": (CFRP, [PP]),
+    "ffi_rln_v3_partial_witness_input_get_user_message_limit": (CFRP, [PP]),
+    "ffi_rln_v3_partial_witness_input_get_path_elements": (VecCFr, [PP]),
+    "ffi_rln_v3_partial_witness_input_get_identity_path_index": (VecU8, [PP]),
+    "ffi_rln_v3_witness_to_partial_witness": (P, [PP]),
+    "ffi_rln_v3_partial_witness_to_bytes_le": (CResultVecU8, [PP]),
+    "ffi_rln_v3_partial_witness_to_bytes_be": (CResultVecU8, [PP]),
+    "ffi_bytes_le_to_rln_v3_partial_witness": (CResultPtr, [C.POINTER(VecU8)]),
+    "ffi_bytes_be_to_rln_v3_partial_witness": (CResultPtr, [C.POINTER(VecU8)]),
+    "ffi_rln_v3_partial_witness_input_free": (None, [P]),
+    "ffi_rln_v3_proof_get_values": (P, [PP]),
+    "ffi_rln_v3_proof_to_bytes_le": (CResultVecU8, [PP]),
+    "ffi_rln_v3_proof_to_bytes_mixed": (CResultVecU8, [PP]),
+    "ffi_bytes_le_to_rln_v3_proof": (CResultPtr, [C.POINTER(VecU8)]),
+    "ffi_bytes_mixed_to_rln_v3_proof": (CResultPtr, [C.POINTER(VecU8)]),
+    "ffi_rln_v3_proof_free": (None, [P]),
+    "ffi_rln_v3_partial_proof_to_bytes_le": (CResultVecU8, [PP]),
+    "ffi_bytes_le_to_rln_v3_partial_proof": (CResultPtr, [C.POINTER(VecU8)]),
+    "ffi_rln_v3_partial_proof_free": (None, [P]),
+    "ffi_rln_v3_proof_values_get_root": (CFRP, [PP]),
+    "ffi_rln_v3_proof_values_get_x": (CFRP, [PP]),
+    "ffi_rln_v3_proof_values_get_external_nullifier": (CFRP, [PP]),
+    "ffi_rln_v3_proof_values_get_y": (CResultPtr, [PP]),
+    "ffi_rln_v3_proof_values_get_nullifier": (CResultPtr, [PP]),
+    "ffi_rln_v3_proof_values_get_selector_used": (CResultVecBool, [PP]),
+    "ffi_rln_v3_proof_values_get_ys": (CResultVecCFr, [PP]),
+    "ffi_rln_v3_proof_values_get_nullifiers": (CResultVecCFr, [PP]),
+    "ffi_rln_v3_proof_values_to_bytes_le": (CResultVecU8, [PP]),
+    "ffi_rln_v3_proof_values_to_bytes_be": (CResultVecU8, [PP]),
+    "ffi_bytes_le_to_rln_v3_proof_values": (CResultPtr, [C.POINTER(VecU8)]),
+    "ffi_bytes_be_to_rln_v3_proof_values": (CResultPtr, [C.POINTER(VecU8)]),
+    "ffi_rln_v3_proof_values_free": (None, [P]),
+    "ffi_rln_v3_compute_id_secret": (CResultPtr, [CFRP, CFRP, CFRP, CFRP]),
+    "ffi_rln_v3_recover_id_secret": (CResultPtr, [PP, PP]),
+    "ffi_rln_v3_merkle_proof_free": (None, [P]),
+    "ffi_rln_v3_delete_leaf": (CBoolResult, [PP, C.c_size_t]),
+    "ffi_rln_v3_set_leaf": (CBoolResult, [PP, C.c_size_t, CFRP]),
+    "ffi_rln_v3_get_leaf": (CResultPtr, [PP, C.c_size_t]),
+    "ffi_rln_v3_leaves_set": (C.c_size_t, [PP]),
+    "ffi_rln_v3_set_next_leaf": (CBoolResult, [PP, CFRP]),
+    "ffi_rln_v3_set_leaves_from": (CBoolResult, [PP, C.c_size_t, C.POINTER(VecCFr)]),
+    "ffi_rln_v3_init_tree_with_leaves": (CBoolResult, [PP, C.POINTER(VecCFr)]),
+    "ffi_rln_v3_atomic_operation": (CBoolResult, [PP, C.c_size_t, C.POINTER(VecCFr), C.POINTER(VecSize)]),
+    "ffi_rln_v3_seq_atomic_operation": (CBoolResult, [PP, C.POINTER(VecCFr), C.POINTER(VecU8)]),
+    "ffi_rln_v3_get_root": (CFRP, [PP]),
+    "ffi_rln_v3_get_merkle_proof": (CResultPtr, [PP, C.c_size_t]),
+    "ffi_rln_v3_set_metadata": (CBoolResult, [PP, C.POINTER(VecU8)]),
+    "ffi_rln_v3_get_metadata": (CResultVecU8, [PP]),
+    "ffi_rln_v3_flush": (CBoolResult, [PP]),
     "ffi_c_string_free": (None, [VecU8]),
 }
 

@@ -366,6 +366,7 @@ struct FFI_RLNPartialProof {  // PartialProof (partial_proof.rs:31-43): mask + f
 struct FFI_RLN {
   std::unique_ptr<Prover> prover;
   MerkleTreeDev tree;
+  bool stateless = false;  // V3 only (RLNV3<Stateless, _>): no tree, tree calls return an error
   size_t next_index = 0;
   std::vector<uint8_t> leaf_set;  // cached_leaves_indices
   std::vector<uint8_t> metadata;
@@ -1581,3 +1582,5 @@ CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_generate_rln_proof_with_witness(FFI_RLN
 void ffi_c_string_free(Vec_uint8_t s) { free(s.ptr); }
 
 }  // extern "C"
+
+#include "ffi_v3.inc"
