@@ -706,14 +706,15 @@ struct Slot {
   uint8_t* h_comp = nullptr;    // pinned: every run ends with the proofs + values copied to the host
   uint32_t* h_values = nullptr;
   uint32_t* h_err = nullptr;
-  hipEvent_t evA = nullptr, evB = nullptr, evC = nullptr;
-  hipEvent_t t[11];  // timing marks
+  hipEvent_t evA = nullptr, evB = nullptr, evB2 = nullptr, evR = nullptr, evC = nullptr;
+  hipEvent_t t[12];  // timing marks
   bool used = false;
   size_t n = 0;
 };
 
 struct Prover::Impl {
-  hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;
+  hipStream_t sA = nullptr, sB = nullptr, sB2 = nullptr, sC = nullptr;
+  bool split_msm = false;  // G2 walk on its own stream: its workgroups fill the G1 kernel's tail (RLNAMD_MSM_SPLIT)
   float ms[PROVER_STAGES] = {0};
 
   uint32_t N = 0, NS = 0, NI = 0, nc = 0, ni = 0, n = 0;
@@ -752,6 +753,7 @@ struct Prover::Impl {
   void sync_all() {
     RLN_HIP(hipStreamSynchronize(sA));
     RLN_HIP(hipStreamSynchronize(sB));
+    RLN_HIP(hipStreamSynchronize(sB2));
     RLN_HIP(hipStreamSynchronize(sC));
   }
 };
@@ -841,7 +843,9 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     auto pick = [&](int i, int dflt) { return (pe && strlen(pe) == 3) ? (pe[i] == 'h' ? hi : lo) : dflt; };
     RLN_HIP(hipStreamCreateWithPriority(&D.sA, hipStreamNonBlocking, pick(0, hi)));
     RLN_HIP(hipStreamCreateWithPriority(&D.sB, hipStreamNonBlocking, pick(1, lo)));
+    RLN_HIP(hipStreamCreateWithPriority(&D.sB2, hipStreamNonBlocking, pick(1, lo)));
     RLN_HIP(hipStreamCreateWithPriority(&D.sC, hipStreamNonBlocking, pick(2, hi)));
+    D.split_msm = env_int("RLNAMD_MSM_SPLIT", 0) != 0;  // measured +1 % only; off keeps per-kernel timings clean
   }
   hipStream_t s = D.sB;
 
@@ -1076,6 +1080,8 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     RLN_HIP(hipHostMalloc((void**)&S.h_err, B * 4, hipHostMallocDefault));
     RLN_HIP(hipEventCreateWithFlags(&S.evA, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evB, hipEventDisableTiming));
+    RLN_HIP(hipEventCreateWithFlags(&S.evB2, hipEventDisableTiming));
+    RLN_HIP(hipEventCreateWithFlags(&S.evR, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evC, hipEventDisableTiming));
     for (auto& e : S.t) RLN_HIP(hipEventCreate(&e));
     RLN_HIP(hipMemsetAsync(S.digits.p, 0, S.digits.bytes(), s));
@@ -1086,18 +1092,18 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
 Prover::~Prover() {
   if (!d_) return;
   Impl& D = *d_;
-  for (hipStream_t st : {D.sA, D.sB, D.sC})
+  for (hipStream_t st : {D.sA, D.sB, D.sB2, D.sC})
     if (st) (void)hipStreamSynchronize(st);
   for (Slot& S : D.slot) {
     if (S.h_pp) (void)hipHostFree(S.h_pp);
     if (S.h_comp) (void)hipHostFree(S.h_comp);
     if (S.h_values) (void)hipHostFree(S.h_values);
     if (S.h_err) (void)hipHostFree(S.h_err);
-    for (hipEvent_t e : {S.evA, S.evB, S.evC})
+    for (hipEvent_t e : {S.evA, S.evB, S.evB2, S.evR, S.evC})
       if (e) (void)hipEventDestroy(e);
     for (auto& e : S.t) (void)hipEventDestroy(e);
   }
-  for (hipStream_t st : {D.sA, D.sB, D.sC})
+  for (hipStream_t st : {D.sA, D.sB, D.sB2, D.sC})
     if (st) (void)hipStreamDestroy(st);
 }
 
@@ -1193,19 +1199,26 @@ void Prover::run_async(size_t n, int mode) {
   hipLaunchKernelGGL(k_recode, dim3(pg, div_up(D.NS + D.n + 3, 4)), dim3(64, 4), 0, D.sB, S.V.p, D.sig2node.p, D.NS,
                      S.abc.p, D.n, D.rs.p, c_, W_, S.digits.p, B, nbp);
   RLN_HIP(hipEventRecord(S.t[6], D.sB));
+  hipStream_t s2 = D.split_msm ? D.sB2 : D.sB;
+  if (D.split_msm) {
+    RLN_HIP(hipEventRecord(S.evR, D.sB));
+    RLN_HIP(hipStreamWaitEvent(D.sB2, S.evR, 0));
+  }
   if (P1.nchunks) {
     uint32_t blocks = div_up(P1.nchunks, 8) * 8 * pg;
     hipLaunchKernelGGL(k_msm<Fq>, dim3(blocks), dim3(64), 0, D.sB, D.t1.p, D.sid1.p, P1.rows.p, P1.chunks.p,
                        P1.nchunks, S.digits.p, S.part1.p, c_, W_, B, pg);
   }
   RLN_HIP(hipEventRecord(S.t[7], D.sB));
+  RLN_HIP(hipEventRecord(S.t[11], s2));
   if (P2.nchunks) {
     uint32_t blocks = div_up(P2.nchunks, 8) * 8 * pg;
-    hipLaunchKernelGGL(k_msm<Fq2>, dim3(blocks), dim3(64), 0, D.sB, D.t2.p, D.sid2.p, P2.rows.p, P2.chunks.p,
+    hipLaunchKernelGGL(k_msm<Fq2>, dim3(blocks), dim3(64), 0, s2, D.t2.p, D.sid2.p, P2.rows.p, P2.chunks.p,
                        P2.nchunks, S.digits.p, S.part2.p, c_, W_, B, pg);
   }
-  RLN_HIP(hipEventRecord(S.t[8], D.sB));
+  RLN_HIP(hipEventRecord(S.t[8], s2));
   RLN_HIP(hipEventRecord(S.evB, D.sB));
+  if (D.split_msm) RLN_HIP(hipEventRecord(S.evB2, D.sB2));
   // ---------------- stage C
   // proof values (Poseidon chain, latency-bound, depends on the inputs only): the back-end stream has slack
   if (S.used) RLN_HIP(hipStreamWaitEvent(D.sC, S.evC, 0));
@@ -1214,6 +1227,7 @@ void Prover::run_async(size_t n, int mode) {
     hipLaunchKernelGGL(k_proof_values, dim3(pg), dim3(64), 0, D.sC, D.inputs.p, D.NI, D.slots, poseidon_view(2),
                        poseidon_view(3), poseidon_view(4), S.values.p, nbp);
   RLN_HIP(hipStreamWaitEvent(D.sC, S.evB, 0));
+  if (D.split_msm) RLN_HIP(hipStreamWaitEvent(D.sC, S.evB2, 0));
   RLN_HIP(hipEventRecord(S.t[9], D.sC));
   if (P1.ngroups)
     hipLaunchKernelGGL(k_sum_ranges<Fq>, dim3(pg, P1.ngroups), dim3(64), 0, D.sC, S.part1.p, P1.groups.p, P1.ngroups,
@@ -1253,7 +1267,7 @@ void Prover::sync() {
   D.sync_all();
   if (D.last) {
     Slot& S = *D.last;
-    const int pairs[PROVER_STAGES][2] = {{1, 2}, {2, 3}, {3, 4}, {5, 6}, {6, 7}, {7, 8}, {9, 10}, {0, 9}};
+    const int pairs[PROVER_STAGES][2] = {{1, 2}, {2, 3}, {3, 4}, {5, 6}, {6, 7}, {11, 8}, {9, 10}, {0, 9}};
     for (int i = 0; i < PROVER_STAGES; i++) RLN_HIP(hipEventElapsedTime(&D.ms[i], S.t[pairs[i][0]], S.t[pairs[i][1]]));
   }
 }
