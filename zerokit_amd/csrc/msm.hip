@@ -29,6 +29,10 @@ constexpr int MSM_W = 16;                 // ceil(255 / 16)
 constexpr uint32_t MSM_NB = 1u << 15;     // buckets per window (signed digits)
 constexpr uint32_t MSM_CHUNK = 32;        // buckets per reduction chunk
 constexpr uint32_t MSM_NCH = MSM_NB / MSM_CHUNK;
+// A bucket larger than MSM_SEG points is cut into segments walked by separate lanes: the top window of a
+// 254-bit scalar has 13-14 significant bits, so its buckets hold 4-8x the average and one lane per bucket would
+// leave the kernel waiting for 64 long waves (measured: 37 ms for 21 ms worth of additions).
+constexpr uint32_t MSM_SEG = 640;
 
 struct Range {
   uint32_t begin, end;
@@ -68,8 +72,10 @@ __global__ void __launch_bounds__(64) k_gen(uint64_t seed, uint64_t first, uint3
   for (int q = 0; q < 8; q++) scal[(size_t)t * 8 + q] = s[q];
 }
 
-__global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scal, uint32_t n, int32_t* __restrict__ dig,
-                                                uint32_t* __restrict__ count) {
+// Signed 16-bit digits, packed (sign << 15) | (|d| - 1); 0xFFFF marks a zero digit (|d| - 1 = 32767 never carries
+// a sign: the most negative digit is -32767).  Coalesced [window][point] stores, no atomics.
+constexpr uint16_t DIG_ZERO = 0xFFFFu;
+__global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scal, uint32_t n, uint16_t* __restrict__ dig) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   uint32_t l[8];
@@ -79,16 +85,69 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
 #pragma unroll
   for (int w = 0; w < MSM_W; w++) {
     uint32_t raw = ((l[w >> 1] >> ((w & 1) * 16)) & 0xFFFFu) + carry;
-    int d;
+    uint32_t mag, sign;
     if (raw > MSM_NB) {
-      d = (int)raw - 65536;
+      mag = 65536u - raw;
+      sign = 1;
       carry = 1;
     } else {
-      d = (int)raw;
+      mag = raw;
+      sign = 0;
       carry = 0;
     }
-    dig[(size_t)w * n + i] = d;
-    if (d != 0) atomicAdd(&count[(uint32_t)w * MSM_NB + (uint32_t)(d < 0 ? -d : d) - 1], 1u);
+    dig[(size_t)w * n + i] = mag ? (uint16_t)((sign << 15) | (mag - 1)) : DIG_ZERO;
+  }
+}
+
+// Counting sort by (window, bucket) with the 2^15 counters of one window held in LDS (128 KiB of the CU's 160):
+// workgroup (tile, window) histograms its slice of the points with LDS atomics and stores the 32 768 counts; after the
+// prefix sums the same workgroup shape replays the slice, taking slots from LDS cursors preset to its global bases.
+// 268 M global atomics per pass (9.8 + 11.9 ms measured) become LDS atomics plus plain stores.
+constexpr uint32_t MSM_TILES = 16;
+__global__ void __launch_bounds__(1024) k_hist(const uint16_t* __restrict__ dig, uint32_t n, uint32_t tile_len,
+                                               uint32_t* __restrict__ hist) {
+  extern __shared__ uint32_t bins[];
+  const uint32_t t = blockIdx.x, w = blockIdx.y;
+  for (uint32_t b = threadIdx.x; b < MSM_NB; b += 1024) bins[b] = 0;
+  __syncthreads();
+  uint32_t lo = t * tile_len, hi = lo + tile_len < n ? lo + tile_len : n;
+  const uint16_t* d = dig + (size_t)w * n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+    uint16_t v = d[i];
+    if (v != DIG_ZERO) atomicAdd(&bins[v & 0x7FFFu], 1u);
+  }
+  __syncthreads();
+  uint32_t* out = hist + ((size_t)w * MSM_TILES + t) * MSM_NB;
+  for (uint32_t b = threadIdx.x; b < MSM_NB; b += 1024) out[b] = bins[b];
+}
+// per key: tile counts -> exclusive prefix over the tiles (in place) and the bucket total
+__global__ void __launch_bounds__(256) k_tile_prefix(uint32_t* __restrict__ hist, uint32_t* __restrict__ count) {
+  uint32_t key = blockIdx.x * 256 + threadIdx.x;
+  if (key >= MSM_W * MSM_NB) return;
+  uint32_t w = key / MSM_NB, b = key % MSM_NB, run = 0;
+  for (uint32_t t = 0; t < MSM_TILES; t++) {
+    uint32_t* h = hist + ((size_t)w * MSM_TILES + t) * MSM_NB + b;
+    uint32_t v = *h;
+    *h = run;
+    run += v;
+  }
+  count[key] = run;
+}
+__global__ void __launch_bounds__(1024) k_scatter(const uint16_t* __restrict__ dig, uint32_t n, uint32_t tile_len,
+                                                  const uint32_t* __restrict__ offs, const uint32_t* __restrict__ hist,
+                                                  uint32_t* __restrict__ sorted) {
+  extern __shared__ uint32_t bins[];
+  const uint32_t t = blockIdx.x, w = blockIdx.y;
+  const uint32_t* base = hist + ((size_t)w * MSM_TILES + t) * MSM_NB;
+  for (uint32_t b = threadIdx.x; b < MSM_NB; b += 1024) bins[b] = offs[w * MSM_NB + b] + base[b];
+  __syncthreads();
+  uint32_t lo = t * tile_len, hi = lo + tile_len < n ? lo + tile_len : n;
+  const uint16_t* d = dig + (size_t)w * n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+    uint16_t v = d[i];
+    if (v == DIG_ZERO) continue;
+    uint32_t pos = atomicAdd(&bins[v & 0x7FFFu], 1u);
+    sorted[pos] = i | ((uint32_t)(v >> 15) << 31);
   }
 }
 
@@ -115,30 +174,72 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ coun
   if (t == 1023) offs[m] = part[1023];
 }
 
-__global__ void __launch_bounds__(256) k_scatter(const int32_t* __restrict__ dig, uint32_t n, const uint32_t* __restrict__ offs,
-                                                 uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
-  uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  uint32_t w = blockIdx.y;
-  if (i >= n) return;
-  int d = dig[(size_t)w * n + i];
-  if (d == 0) return;
-  uint32_t key = w * MSM_NB + (uint32_t)(d < 0 ? -d : d) - 1;
-  uint32_t pos = offs[key] + atomicAdd(&cursor[key], 1u);
-  sorted[pos] = i | (d < 0 ? 0x80000000u : 0u);
+// software-pipelined: the index two steps ahead and the point one step ahead are in flight during an addition
+__device__ __forceinline__ G1XYZZ bucket_walk(const G1Affine* __restrict__ pts, const uint32_t* __restrict__ sorted,
+                                              uint32_t lo, uint32_t hi) {
+  G1XYZZ acc = G1XYZZ::inf();
+  if (lo >= hi) return acc;
+  uint32_t v = sorted[lo];
+  uint32_t vn = lo + 1 < hi ? sorted[lo + 1] : 0;
+  G1Affine p = pts[v & 0x7FFFFFFFu];
+  for (uint32_t j = lo; j < hi; j++) {
+    G1Affine cur = p;
+    uint32_t cv = v;
+    v = vn;
+    if (j + 1 < hi) p = pts[v & 0x7FFFFFFFu];
+    if (j + 2 < hi) vn = sorted[j + 2];
+    if (cv & 0x80000000u) cur.y = cur.y.neg();
+    acc.madd(cur);
+  }
+  return acc;
 }
 
+// One launch walks everything: the first `xblocks` workgroups take the extra segments of oversized buckets (most exit
+// at once: the task count is only known on the device), the rest take segment 0 of every bucket.  Keeping the few
+// hundred long extra waves inside the big launch hides them; as a launch of their own they ran 4.3 ms at one wave/SIMD.
 __global__ void __launch_bounds__(64) k_bucket_acc(const G1Affine* __restrict__ pts, const uint32_t* __restrict__ offs,
                                                    const uint32_t* __restrict__ sorted, G1XYZZ* __restrict__ buckets,
-                                                   uint32_t nkeys) {
+                                                   uint32_t nkeys, uint32_t xblocks, const uint32_t* __restrict__ ntasks,
+                                                   const uint2* __restrict__ tasks, G1XYZZ* __restrict__ partial) {
+  if (blockIdx.x < xblocks) {
+    uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= *ntasks) return;
+    uint2 tk = tasks[t];
+    uint32_t lo = offs[tk.x] + tk.y * MSM_SEG, hi = offs[tk.x + 1];
+    if (hi - lo > MSM_SEG) hi = lo + MSM_SEG;
+    partial[t] = bucket_walk(pts, sorted, lo, hi);
+    return;
+  }
+  uint32_t key = (blockIdx.x - xblocks) * 64 + threadIdx.x;
+  if (key >= nkeys) return;
+  uint32_t lo = offs[key], hi = offs[key + 1];
+  if (hi - lo > MSM_SEG) hi = lo + MSM_SEG;
+  buckets[key] = bucket_walk(pts, sorted, lo, hi);
+}
+
+// segments 1.. of the oversized buckets: task list built with one atomic per such bucket (contiguous per bucket)
+__global__ void __launch_bounds__(256) k_plan_extra(const uint32_t* __restrict__ offs, uint32_t nkeys,
+                                                    uint32_t* __restrict__ ntasks, uint2* __restrict__ tasks,
+                                                    uint2* __restrict__ xinfo) {
+  uint32_t key = blockIdx.x * 256 + threadIdx.x;
+  if (key >= nkeys) return;
+  uint32_t cnt = offs[key + 1] - offs[key];
+  uint32_t extra = cnt > MSM_SEG ? (cnt - 1) / MSM_SEG : 0;
+  uint32_t base = 0;
+  if (extra) {
+    base = atomicAdd(ntasks, extra);
+    for (uint32_t q = 0; q < extra; q++) tasks[base + q] = make_uint2(key, q + 1);
+  }
+  xinfo[key] = make_uint2(base, extra);
+}
+__global__ void __launch_bounds__(64) k_fold_extra(const uint2* __restrict__ xinfo, const G1XYZZ* __restrict__ partial,
+                                                   G1XYZZ* __restrict__ buckets, uint32_t nkeys) {
   uint32_t key = blockIdx.x * 64 + threadIdx.x;
   if (key >= nkeys) return;
-  G1XYZZ acc = G1XYZZ::inf();
-  for (uint32_t j = offs[key]; j < offs[key + 1]; j++) {
-    uint32_t v = sorted[j];
-    G1Affine p = pts[v & 0x7FFFFFFFu];
-    if (v & 0x80000000u) p.y = p.y.neg();
-    acc.madd(p);
-  }
+  uint2 xi = xinfo[key];
+  if (!xi.y) return;
+  G1XYZZ acc = buckets[key];
+  for (uint32_t q = 0; q < xi.y; q++) acc.add(partial[xi.x + q]);
   buckets[key] = acc;
 }
 
@@ -199,9 +300,13 @@ struct MsmG1::Impl {
   hipStream_t s = nullptr;
   size_t cap = 0, n = 0;
   DevBuf<G1Affine> pts;
-  DevBuf<uint32_t> scal, count, offs, cursor, sorted;
-  DevBuf<int32_t> dig;
-  DevBuf<G1XYZZ> buckets, chunkS, chunkT, grp, wsum;
+  DevBuf<uint32_t> scal, count, offs, sorted;
+  DevBuf<uint16_t> dig;
+  DevBuf<uint32_t> hist;
+  DevBuf<G1XYZZ> buckets, chunkS, chunkT, grp, wsum, partial;
+  DevBuf<uint32_t> ntasks;
+  DevBuf<uint2> tasks, xinfo;
+  size_t max_tasks = 0;
   DevBuf<Range> r1, r2;
   hipEvent_t e[4];
 };
@@ -212,6 +317,8 @@ MsmG1::MsmG1(size_t capacity) : d_(new Impl) {
   D.cap = capacity;
   RLN_HIP(hipStreamCreateWithFlags(&D.s, hipStreamNonBlocking));
   for (auto& e : D.e) RLN_HIP(hipEventCreate(&e));
+  RLN_HIP(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, MSM_NB * 4));
+  RLN_HIP(hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, MSM_NB * 4));
   const uint32_t nkeys = MSM_W * MSM_NB, nch = MSM_W * MSM_NCH;
   D.pts.alloc(capacity);
   D.scal.alloc(capacity * 8);
@@ -219,8 +326,13 @@ MsmG1::MsmG1(size_t capacity) : d_(new Impl) {
   D.sorted.alloc(capacity * MSM_W);
   D.count.alloc(nkeys);
   D.offs.alloc(nkeys + 1);
-  D.cursor.alloc(nkeys);
+  D.hist.alloc((size_t)nkeys * MSM_TILES);
   D.buckets.alloc(nkeys);
+  D.max_tasks = capacity * MSM_W / MSM_SEG + 1;
+  D.ntasks.alloc(1);
+  D.tasks.alloc(D.max_tasks);
+  D.xinfo.alloc(nkeys);
+  D.partial.alloc(D.max_tasks);
   D.chunkS.alloc(nch);
   D.chunkT.alloc(nch);
   // per window: 1024 chunks -> 32 groups of 32 -> 1
@@ -310,15 +422,21 @@ void MsmG1::run_windows(uint8_t* window_sums_out, float ms[3]) {
   const uint32_t n = (uint32_t)D.n, nkeys = MSM_W * MSM_NB, nch = MSM_W * MSM_NCH;
   hipStream_t s = D.s;
   RLN_HIP(hipEventRecord(D.e[0], s));
-  RLN_HIP(hipMemsetAsync(D.count.p, 0, D.count.bytes(), s));
-  RLN_HIP(hipMemsetAsync(D.cursor.p, 0, D.cursor.bytes(), s));
-  if (n) {
-    hipLaunchKernelGGL(k_digits, dim3(div_up(n, 256)), dim3(256), 0, s, D.scal.p, n, D.dig.p, D.count.p);
-  }
+  const uint32_t tile_len = div_up(n ? n : 1, MSM_TILES);
+  const size_t lds = MSM_NB * sizeof(uint32_t);
+  if (n) hipLaunchKernelGGL(k_digits, dim3(div_up(n, 256)), dim3(256), 0, s, D.scal.p, n, D.dig.p);
+  hipLaunchKernelGGL(k_hist, dim3(MSM_TILES, MSM_W), dim3(1024), lds, s, D.dig.p, n, tile_len, D.hist.p);
+  hipLaunchKernelGGL(k_tile_prefix, dim3(div_up(nkeys, 256)), dim3(256), 0, s, D.hist.p, D.count.p);
   hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, D.count.p, nkeys, D.offs.p);
-  if (n) hipLaunchKernelGGL(k_scatter, dim3(div_up(n, 256), MSM_W), dim3(256), 0, s, D.dig.p, n, D.offs.p, D.cursor.p, D.sorted.p);
+  hipLaunchKernelGGL(k_scatter, dim3(MSM_TILES, MSM_W), dim3(1024), lds, s, D.dig.p, n, tile_len, D.offs.p, D.hist.p,
+                     D.sorted.p);
   RLN_HIP(hipEventRecord(D.e[1], s));
-  hipLaunchKernelGGL(k_bucket_acc, dim3(div_up(nkeys, 64)), dim3(64), 0, s, D.pts.p, D.offs.p, D.sorted.p, D.buckets.p, nkeys);
+  RLN_HIP(hipMemsetAsync(D.ntasks.p, 0, 4, s));
+  hipLaunchKernelGGL(k_plan_extra, dim3(div_up(nkeys, 256)), dim3(256), 0, s, D.offs.p, nkeys, D.ntasks.p, D.tasks.p, D.xinfo.p);
+  const uint32_t xblocks = div_up(D.max_tasks, 64);
+  hipLaunchKernelGGL(k_bucket_acc, dim3(xblocks + div_up(nkeys, 64)), dim3(64), 0, s, D.pts.p, D.offs.p, D.sorted.p,
+                     D.buckets.p, nkeys, xblocks, D.ntasks.p, D.tasks.p, D.partial.p);
+  hipLaunchKernelGGL(k_fold_extra, dim3(div_up(nkeys, 64)), dim3(64), 0, s, D.xinfo.p, D.partial.p, D.buckets.p, nkeys);
   RLN_HIP(hipEventRecord(D.e[2], s));
   hipLaunchKernelGGL(k_bucket_red, dim3(div_up(nch, 64)), dim3(64), 0, s, D.buckets.p, D.chunkS.p, D.chunkT.p, nch);
   hipLaunchKernelGGL(k_chunk_fix, dim3(div_up(nch, 64)), dim3(64), 0, s, D.chunkS.p, D.chunkT.p, nch);
