@@ -29,10 +29,6 @@ constexpr int MSM_W = 16;                 // ceil(255 / 16)
 constexpr uint32_t MSM_NB = 1u << 15;     // buckets per window (signed digits)
 constexpr uint32_t MSM_CHUNK = 32;        // buckets per reduction chunk
 constexpr uint32_t MSM_NCH = MSM_NB / MSM_CHUNK;
-// A bucket larger than MSM_SEG points is cut into segments walked by separate lanes: the top window of a
-// 254-bit scalar has 13-14 significant bits, so its buckets hold 4-8x the average and one lane per bucket would
-// leave the kernel waiting for 64 long waves (measured: 37 ms for 21 ms worth of additions).
-constexpr uint32_t MSM_SEG = 640;
 
 struct Range {
   uint32_t begin, end;
@@ -174,72 +170,64 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ coun
   if (t == 1023) offs[m] = part[1023];
 }
 
-// software-pipelined: the index two steps ahead and the point one step ahead are in flight during an addition
-__device__ __forceinline__ G1XYZZ bucket_walk(const G1Affine* __restrict__ pts, const uint32_t* __restrict__ sorted,
-                                              uint32_t lo, uint32_t hi) {
+// Bucket accumulation over equal SLICES of the sorted list instead of one lane per bucket: bucket sizes are
+// Poisson(512) (a wave waits for its largest, +11 %) and the top window of a 254-bit scalar has 4-8x larger buckets
+// (a 64-wave tail: 37 ms for 21 ms of additions).  Lane s walks entries [s*L, (s+1)*L) -- exactly L additions -- and
+// flushes at every bucket boundary it crosses: a bucket lying inside the slice goes straight to buckets[], the part of
+// a bucket that began in an earlier slice to head[s], the part of one that continues into the next slice to tail[s];
+// k_slice_fix then forms bucket = tail[s0] + head[s0+1] + ... + head[s1].  The next index is loaded during an addition
+// (prefetching the point as well costs 16 VGPRs and the fourth wave per SIMD: slower).
+constexpr uint32_t MSM_SLICE = 512;
+__global__ void __launch_bounds__(64) k_slice_acc(const G1Affine* __restrict__ pts, const uint32_t* __restrict__ offs,
+                                                  const uint32_t* __restrict__ sorted, uint32_t nkeys,
+                                                  G1XYZZ* __restrict__ buckets, G1XYZZ* __restrict__ head,
+                                                  G1XYZZ* __restrict__ tail) {
+  const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+  const uint32_t total = offs[nkeys];
+  const uint64_t lo64 = (uint64_t)s * MSM_SLICE;
+  if (lo64 >= total) return;
+  const uint32_t lo = (uint32_t)lo64, hi = total - lo > MSM_SLICE ? lo + MSM_SLICE : total;
+  // first key whose range ends after lo (skips empty buckets)
+  uint32_t a = 0, b = nkeys - 1;
+  while (a < b) {
+    uint32_t m = (a + b) >> 1;
+    if (offs[m + 1] > lo) b = m; else a = m + 1;
+  }
+  uint32_t key = a, kend = offs[key + 1];
+  bool from_before = offs[key] < lo;
   G1XYZZ acc = G1XYZZ::inf();
-  if (lo >= hi) return acc;
   uint32_t v = sorted[lo];
-  uint32_t vn = lo + 1 < hi ? sorted[lo + 1] : 0;
-  G1Affine p = pts[v & 0x7FFFFFFFu];
   for (uint32_t j = lo; j < hi; j++) {
-    G1Affine cur = p;
+    if (j == kend) {  // bucket `key` ends inside this slice
+      if (from_before) head[s] = acc; else buckets[key] = acc;
+      acc = G1XYZZ::inf();
+      from_before = false;
+      do kend = offs[++key + 1]; while (kend == j);
+    }
+    G1Affine cur = pts[v & 0x7FFFFFFFu];
     uint32_t cv = v;
-    v = vn;
-    if (j + 1 < hi) p = pts[v & 0x7FFFFFFFu];
-    if (j + 2 < hi) vn = sorted[j + 2];
+    if (j + 1 < hi) v = sorted[j + 1];
     if (cv & 0x80000000u) cur.y = cur.y.neg();
     acc.madd(cur);
   }
-  return acc;
+  if (from_before) head[s] = acc;          // started earlier (and may run on: the fix-up adds the later heads)
+  else if (kend > hi) tail[s] = acc;       // started here, continues in the next slice
+  else buckets[key] = acc;                 // ends exactly at the slice end
 }
-
-// One launch walks everything: the first `xblocks` workgroups take the extra segments of oversized buckets (most exit
-// at once: the task count is only known on the device), the rest take segment 0 of every bucket.  Keeping the few
-// hundred long extra waves inside the big launch hides them; as a launch of their own they ran 4.3 ms at one wave/SIMD.
-__global__ void __launch_bounds__(64) k_bucket_acc(const G1Affine* __restrict__ pts, const uint32_t* __restrict__ offs,
-                                                   const uint32_t* __restrict__ sorted, G1XYZZ* __restrict__ buckets,
-                                                   uint32_t nkeys, uint32_t xblocks, const uint32_t* __restrict__ ntasks,
-                                                   const uint2* __restrict__ tasks, G1XYZZ* __restrict__ partial) {
-  if (blockIdx.x < xblocks) {
-    uint32_t t = blockIdx.x * 64 + threadIdx.x;
-    if (t >= *ntasks) return;
-    uint2 tk = tasks[t];
-    uint32_t lo = offs[tk.x] + tk.y * MSM_SEG, hi = offs[tk.x + 1];
-    if (hi - lo > MSM_SEG) hi = lo + MSM_SEG;
-    partial[t] = bucket_walk(pts, sorted, lo, hi);
-    return;
-  }
-  uint32_t key = (blockIdx.x - xblocks) * 64 + threadIdx.x;
-  if (key >= nkeys) return;
-  uint32_t lo = offs[key], hi = offs[key + 1];
-  if (hi - lo > MSM_SEG) hi = lo + MSM_SEG;
-  buckets[key] = bucket_walk(pts, sorted, lo, hi);
-}
-
-// segments 1.. of the oversized buckets: task list built with one atomic per such bucket (contiguous per bucket)
-__global__ void __launch_bounds__(256) k_plan_extra(const uint32_t* __restrict__ offs, uint32_t nkeys,
-                                                    uint32_t* __restrict__ ntasks, uint2* __restrict__ tasks,
-                                                    uint2* __restrict__ xinfo) {
-  uint32_t key = blockIdx.x * 256 + threadIdx.x;
-  if (key >= nkeys) return;
-  uint32_t cnt = offs[key + 1] - offs[key];
-  uint32_t extra = cnt > MSM_SEG ? (cnt - 1) / MSM_SEG : 0;
-  uint32_t base = 0;
-  if (extra) {
-    base = atomicAdd(ntasks, extra);
-    for (uint32_t q = 0; q < extra; q++) tasks[base + q] = make_uint2(key, q + 1);
-  }
-  xinfo[key] = make_uint2(base, extra);
-}
-__global__ void __launch_bounds__(64) k_fold_extra(const uint2* __restrict__ xinfo, const G1XYZZ* __restrict__ partial,
-                                                   G1XYZZ* __restrict__ buckets, uint32_t nkeys) {
+__global__ void __launch_bounds__(64) k_slice_fix(const uint32_t* __restrict__ offs, uint32_t nkeys,
+                                                  const G1XYZZ* __restrict__ head, const G1XYZZ* __restrict__ tail,
+                                                  G1XYZZ* __restrict__ buckets) {
   uint32_t key = blockIdx.x * 64 + threadIdx.x;
   if (key >= nkeys) return;
-  uint2 xi = xinfo[key];
-  if (!xi.y) return;
-  G1XYZZ acc = buckets[key];
-  for (uint32_t q = 0; q < xi.y; q++) acc.add(partial[xi.x + q]);
+  uint32_t start = offs[key], end = offs[key + 1];
+  if (start == end) {
+    buckets[key] = G1XYZZ::inf();
+    return;
+  }
+  uint32_t s0 = start / MSM_SLICE, s1 = (end - 1) / MSM_SLICE;
+  if (s0 == s1) return;  // written by its slice
+  G1XYZZ acc = tail[s0];  // slice s0 saw it start (from_before == false) and run past its end
+  for (uint32_t s = s0 + 1; s <= s1; s++) acc.add(head[s]);
   buckets[key] = acc;
 }
 
@@ -303,10 +291,8 @@ struct MsmG1::Impl {
   DevBuf<uint32_t> scal, count, offs, sorted;
   DevBuf<uint16_t> dig;
   DevBuf<uint32_t> hist;
-  DevBuf<G1XYZZ> buckets, chunkS, chunkT, grp, wsum, partial;
-  DevBuf<uint32_t> ntasks;
-  DevBuf<uint2> tasks, xinfo;
-  size_t max_tasks = 0;
+  DevBuf<G1XYZZ> buckets, chunkS, chunkT, grp, wsum, head, tail;
+  size_t max_slices = 0;
   DevBuf<Range> r1, r2;
   hipEvent_t e[4];
 };
@@ -328,11 +314,9 @@ MsmG1::MsmG1(size_t capacity) : d_(new Impl) {
   D.offs.alloc(nkeys + 1);
   D.hist.alloc((size_t)nkeys * MSM_TILES);
   D.buckets.alloc(nkeys);
-  D.max_tasks = capacity * MSM_W / MSM_SEG + 1;
-  D.ntasks.alloc(1);
-  D.tasks.alloc(D.max_tasks);
-  D.xinfo.alloc(nkeys);
-  D.partial.alloc(D.max_tasks);
+  D.max_slices = capacity * MSM_W / MSM_SLICE + 1;
+  D.head.alloc(D.max_slices);
+  D.tail.alloc(D.max_slices);
   D.chunkS.alloc(nch);
   D.chunkT.alloc(nch);
   // per window: 1024 chunks -> 32 groups of 32 -> 1
@@ -431,12 +415,11 @@ void MsmG1::run_windows(uint8_t* window_sums_out, float ms[3]) {
   hipLaunchKernelGGL(k_scatter, dim3(MSM_TILES, MSM_W), dim3(1024), lds, s, D.dig.p, n, tile_len, D.offs.p, D.hist.p,
                      D.sorted.p);
   RLN_HIP(hipEventRecord(D.e[1], s));
-  RLN_HIP(hipMemsetAsync(D.ntasks.p, 0, 4, s));
-  hipLaunchKernelGGL(k_plan_extra, dim3(div_up(nkeys, 256)), dim3(256), 0, s, D.offs.p, nkeys, D.ntasks.p, D.tasks.p, D.xinfo.p);
-  const uint32_t xblocks = div_up(D.max_tasks, 64);
-  hipLaunchKernelGGL(k_bucket_acc, dim3(xblocks + div_up(nkeys, 64)), dim3(64), 0, s, D.pts.p, D.offs.p, D.sorted.p,
-                     D.buckets.p, nkeys, xblocks, D.ntasks.p, D.tasks.p, D.partial.p);
-  hipLaunchKernelGGL(k_fold_extra, dim3(div_up(nkeys, 64)), dim3(64), 0, s, D.xinfo.p, D.partial.p, D.buckets.p, nkeys);
+  const uint32_t nslices = div_up((size_t)n * MSM_W, MSM_SLICE);
+  if (nslices)
+    hipLaunchKernelGGL(k_slice_acc, dim3(div_up(nslices, 64)), dim3(64), 0, s, D.pts.p, D.offs.p, D.sorted.p, nkeys,
+                       D.buckets.p, D.head.p, D.tail.p);
+  hipLaunchKernelGGL(k_slice_fix, dim3(div_up(nkeys, 64)), dim3(64), 0, s, D.offs.p, nkeys, D.head.p, D.tail.p, D.buckets.p);
   RLN_HIP(hipEventRecord(D.e[2], s));
   hipLaunchKernelGGL(k_bucket_red, dim3(div_up(nch, 64)), dim3(64), 0, s, D.buckets.p, D.chunkS.p, D.chunkT.p, nch);
   hipLaunchKernelGGL(k_chunk_fix, dim3(div_up(nch, 64)), dim3(64), 0, s, D.chunkS.p, D.chunkT.p, nch);
