@@ -1,0 +1,296 @@
+// fq29.h -- BN254 Fq in 9 x 29-bit unsaturated limbs (Montgomery radix R' = 2^261), device only.
+//
+// Why a second representation: on gfx950 the 8 x 32-bit product-scanning multiply of field.h spends one v_addc per
+// v_mad_u64_u32 to capture the carry out of the 64-bit column sum (128 mad + 131 addc + moves + the conditional
+// subtraction = ~375 instructions, 134 G mul/s measured).  With 29-bit limbs a column of 9 products (2^58 each)
+// plus the reduction terms stays below 2^64, so the accumulate needs no carry capture, and the 7 spare bits of
+// 9 x 29 = 261 > 254 remove the final conditional subtraction: ~235 instructions, 173 G mul/s measured
+// (tools/microbench29.hip).  The fixed-base MSM (prover.hip k_msm29) walks its tables and keeps its accumulators in
+// this form; everything outside that kernel stays in the 8 x 32 form of field.h, bit-exact by construction
+// (values are the same residues mod q; only their integer representatives differ).
+//
+// Representation classes (value = sum v[j] 2^(29 j), congruent to x 2^261 mod q):
+//   N      limbs v[0..7] < 2^29, v[8] = the rest ("normalised"); the integer may be any multiple-of-q offset
+//   lazy   limbs < 2^30 (one borrow-free subtraction K - b or one addition of two N values)
+// mul/dot2 accept N x N, N x lazy (column bound: 9 (2^58 + 2^59 + 2^58) < 2^64) and return N with value
+// < q + a b / 2^261 (q / 2^261 = 0.0059: inputs up to 10 q keep the output below 1.7 q).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "curve.h"
+#include "fq29_constants.h"
+
+namespace rlnamd {
+
+struct Fq29 {
+  uint32_t v[9];
+
+  static constexpr uint32_t M = (1u << 29) - 1;
+
+  static __device__ __forceinline__ Fq29 from_const(const uint32_t (&c)[9]) {
+    Fq29 r;
+#pragma unroll
+    for (int j = 0; j < 9; j++) r.v[j] = c[j];
+    return r;
+  }
+  static __device__ __forceinline__ Fq29 zero() {
+    Fq29 r;
+#pragma unroll
+    for (int j = 0; j < 9; j++) r.v[j] = 0;
+    return r;
+  }
+  __device__ __forceinline__ bool limbs_all_zero() const {
+    uint32_t o = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) o |= v[j];
+    return o == 0;
+  }
+  __device__ __forceinline__ void normalize() {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      v[j + 1] += v[j] >> 29;
+      v[j] &= M;
+    }
+  }
+
+  // REDC(sum of N products): t accumulates columns; one limb is retired per round
+  template <int NP>
+  static __device__ __forceinline__ Fq29 redc_dot(const Fq29* const (&a)[NP], const Fq29* const (&b)[NP]) {
+    uint64_t t[10];
+#pragma unroll
+    for (int j = 0; j < 10; j++) t[j] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+#pragma unroll
+      for (int k = 0; k < NP; k++) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) t[j] += (uint64_t)a[k]->v[j] * b[k]->v[i];
+      }
+      uint32_t m = ((uint32_t)t[0] * Fq29C::INV) & M;
+#pragma unroll
+      for (int j = 0; j < 9; j++) t[j] += (uint64_t)m * Fq29C::P[j];
+      uint64_t carry = t[0] >> 29;
+#pragma unroll
+      for (int j = 0; j < 9; j++) t[j] = t[j + 1];
+      t[0] += carry;
+      t[9] = 0;
+    }
+    Fq29 r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      r.v[j] = (uint32_t)t[j] & M;
+      t[j + 1] += t[j] >> 29;
+    }
+    r.v[8] = (uint32_t)t[8];
+    return r;
+  }
+  static __device__ __forceinline__ Fq29 mul(const Fq29& a, const Fq29& b) {
+    const Fq29* const aa[1] = {&a};
+    const Fq29* const bb[1] = {&b};
+    return redc_dot<1>(aa, bb);
+  }
+  // a0 b0 + a1 b1 with one reduction
+  static __device__ __forceinline__ Fq29 dot2(const Fq29& a0, const Fq29& b0, const Fq29& a1, const Fq29& b1) {
+    const Fq29* const aa[2] = {&a0, &a1};
+    const Fq29* const bb[2] = {&b0, &b1};
+    return redc_dot<2>(aa, bb);
+  }
+  // K - b limb by limb: no borrows because every limb of the biased constant K dominates a normalised limb
+  static __device__ __forceinline__ Fq29 neg_lazy(const uint32_t (&K)[9], const Fq29& b) {
+    Fq29 r;
+#pragma unroll
+    for (int j = 0; j < 9; j++) r.v[j] = K[j] - b.v[j];
+    return r;
+  }
+  // a + K - b, normalised
+  static __device__ __forceinline__ Fq29 sub(const Fq29& a, const uint32_t (&K)[9], const Fq29& b) {
+    Fq29 r;
+#pragma unroll
+    for (int j = 0; j < 9; j++) r.v[j] = a.v[j] + K[j] - b.v[j];
+    r.normalize();
+    return r;
+  }
+
+  // exact: is the (normalised) value one of 0, q, 2q, ..., 7q ?
+  __device__ __forceinline__ bool is_zero_mod_q() const {
+    bool hit = false;
+#pragma unroll
+    for (int k = 0; k < 8; k++) hit |= v[0] == Fq29C::KP[k][0];
+    if (!hit) return false;  // the low limb filters all but 8 / 2^29 of the values
+    for (int k = 0; k < 8; k++) {
+      bool eq = true;
+      for (int j = 0; j < 9; j++) eq &= v[j] == Fq29C::KP[k][j];
+      if (eq) return true;
+    }
+    return false;
+  }
+
+  // ---- conversions to / from the 8 x 32 Montgomery form of field.h (same residue, radix 2^256)
+  static __device__ __forceinline__ Fq29 from_fq(const Fq& a) {
+    Fq29 u;  // the integer a.v (= x 2^256 mod q, canonical) cut into 29-bit limbs
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      const int bit = 29 * j, w = bit >> 5, s = bit & 31;
+      uint64_t lo = a.v[w], hi = w + 1 < 8 ? a.v[w + 1] : 0;
+      u.v[j] = (uint32_t)(((lo | (hi << 32)) >> s) & M);
+    }
+    return mul(u, from_const(Fq29C::FROM_FQ));  // x 2^256 2^266 / 2^261 = x 2^261
+  }
+  __device__ __forceinline__ Fq to_fq() const {
+    Fq29 t = mul(*this, from_const(Fq29C::TO_FQ));  // x 2^256 + (0 or 1) q, limbs normalised
+    // exact reduction into [0, q): subtract q when t >= q
+    uint32_t d[9];
+    int64_t borrow = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      int64_t x = (int64_t)t.v[j] - (int64_t)Fq29C::P[j] + borrow;
+      d[j] = (uint32_t)x & (j < 8 ? M : 0xFFFFFFFFu);
+      borrow = x >> (j < 8 ? 29 : 63);
+    }
+    const bool ge = borrow == 0;
+    uint32_t r[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) r[j] = ge ? d[j] : t.v[j];
+    Fq o;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+      // bits [32 w, 32 w + 32) of sum r[j] 2^(29 j)
+      const int j0 = (32 * w) / 29, s = 32 * w - 29 * j0;
+      uint64_t acc = (uint64_t)r[j0] >> s;
+      acc |= (uint64_t)r[j0 + 1] << (29 - s);
+      if (j0 + 2 < 9) acc |= (uint64_t)r[j0 + 2] << (58 - s);
+      o.v[w] = (uint32_t)acc;
+    }
+    return o;
+  }
+};
+
+// Table entry: the two coordinates as 256-bit integers (the Montgomery-2^261 residues, fully reduced), 64 bytes so an
+// entry never straddles a cache line; never the point at infinity (dropped when the table is built).
+struct G1Affine29 {
+  uint32_t x[8], y[8];
+};
+__device__ __forceinline__ Fq29 unpack29(const uint32_t (&w)[8]) {
+  Fq29 u;
+#pragma unroll
+  for (int j = 0; j < 9; j++) {
+    const int bit = 29 * j, k = bit >> 5, s = bit & 31;
+    uint64_t lo = w[k], hi = k + 1 < 8 ? w[k + 1] : 0;
+    u.v[j] = (uint32_t)(((lo | (hi << 32)) >> s) & Fq29::M);
+  }
+  return u;
+}
+// exact reduction of a normalised value < 2 q into [0, q), packed as 8 x 32
+__device__ __forceinline__ void pack29_reduced(const Fq29& t, uint32_t (&o)[8]) {
+  uint32_t d[9];
+  int64_t borrow = 0;
+#pragma unroll
+  for (int j = 0; j < 9; j++) {
+    int64_t x = (int64_t)t.v[j] - (int64_t)Fq29C::P[j] + borrow;
+    d[j] = (uint32_t)x & (j < 8 ? Fq29::M : 0xFFFFFFFFu);
+    borrow = x >> (j < 8 ? 29 : 63);
+  }
+  const bool ge = borrow == 0;
+  uint32_t r[9];
+#pragma unroll
+  for (int j = 0; j < 9; j++) r[j] = ge ? d[j] : t.v[j];
+#pragma unroll
+  for (int w = 0; w < 8; w++) {
+    const int j0 = (32 * w) / 29, s = 32 * w - 29 * j0;
+    uint64_t acc = (uint64_t)r[j0] >> s;
+    acc |= (uint64_t)r[j0 + 1] << (29 - s);
+    if (j0 + 2 < 9) acc |= (uint64_t)r[j0 + 2] << (58 - s);
+    o[w] = (uint32_t)acc;
+  }
+}
+__device__ __forceinline__ G1Affine29 to_table29(const G1Affine& a) {
+  G1Affine29 e;
+  pack29_reduced(Fq29::from_fq(a.x), e.x);
+  pack29_reduced(Fq29::from_fq(a.y), e.y);
+  return e;
+}
+
+// XYZZ accumulator over Fq29.  Invariants between additions: X, Y, ZZ, ZZZ normalised; X < 5.2 q, Y < 2.1 q,
+// ZZ, ZZZ < 1.7 q; infinity <=> ZZ has all limbs zero (a finite point never has ZZ = 0 mod q, and mul never returns
+// the all-zero limb pattern for non-zero operands... it can only return 0 for a zero product).
+struct G1Acc29 {
+  Fq29 X, Y, ZZ, ZZZ;
+
+  static __device__ __forceinline__ G1Acc29 inf() { return {Fq29::zero(), Fq29::zero(), Fq29::zero(), Fq29::zero()}; }
+  __device__ __forceinline__ bool is_inf() const { return ZZ.limbs_all_zero(); }
+
+  __device__ __forceinline__ G1XYZZ to_xyzz() const {
+    if (is_inf()) return G1XYZZ::inf();
+    return {X.to_fq(), Y.to_fq(), ZZ.to_fq(), ZZZ.to_fq()};
+  }
+  static __device__ __forceinline__ G1Acc29 from_xyzz(const G1XYZZ& p) {
+    if (p.is_inf()) return inf();
+    return {Fq29::from_fq(p.X), Fq29::from_fq(p.Y), Fq29::from_fq(p.ZZ), Fq29::from_fq(p.ZZZ)};
+  }
+
+  // 2 (x, py) for an affine point (mdbl-2008-s-1); py normalised, < 2 q
+  static __device__ __forceinline__ G1Acc29 dbl_affine(const Fq29& x, const Fq29& py) {
+    Fq29 U;
+#pragma unroll
+    for (int j = 0; j < 9; j++) U.v[j] = 2 * py.v[j];          // lazy, < 4 q
+    Fq29 V = Fq29::mul(U, U);
+    Fq29 W = Fq29::mul(U, V);
+    Fq29 S = Fq29::mul(x, V);
+    Fq29 x2 = Fq29::mul(x, x);
+    Fq29 Mm;
+#pragma unroll
+    for (int j = 0; j < 9; j++) Mm.v[j] = 3 * x2.v[j];
+    Mm.normalize();                                              // < 3.3 q
+    Fq29 M2 = Fq29::mul(Mm, Mm);
+    Fq29 X3;
+#pragma unroll
+    for (int j = 0; j < 9; j++) X3.v[j] = M2.v[j] + Fq29C::K4T[j] - 2 * S.v[j];
+    X3.normalize();                                              // < 5.1 q
+    Fq29 D = Fq29::sub(S, Fq29C::K6, X3);
+    Fq29 nY = Fq29::neg_lazy(Fq29C::K4, py);
+    return {X3, Fq29::dot2(Mm, D, nY, W), V, W};
+  }
+
+  // this += (x, +-y)   madd-2008-s in the lazy representation (bounds: header comment).  Statement order keeps few
+  // values alive at a time; the equal-x case (doubling / cancellation) stays in this representation too, so the
+  // rare path does not raise the kernel's register count.
+  __device__ __forceinline__ void madd(const G1Affine29& e, bool negate) {
+    const Fq29 px = unpack29(e.x);
+    Fq29 py = unpack29(e.y);
+    if (negate) py = Fq29::neg_lazy(Fq29C::K2, py);    // lazy, value < 2 q (table y is canonical, < q)
+    if (is_inf()) {
+      X = px;
+      Y = py;
+      Y.normalize();
+      ZZ = Fq29::from_const(Fq29C::ONE);
+      ZZZ = ZZ;
+      return;
+    }
+    Fq29 P = Fq29::sub(Fq29::mul(px, ZZ), Fq29C::K6, X);    // U2 - X   in (0.8 q, 7.2 q)
+    Fq29 R = Fq29::sub(Fq29::mul(py, ZZZ), Fq29C::K4, Y);   // S2 - Y   in (1.9 q, 5.2 q)
+    if (P.is_zero_mod_q()) {                                // same x
+      if (R.is_zero_mod_q()) {
+        py.normalize();
+        *this = dbl_affine(px, py);
+      } else {
+        *this = inf();
+      }
+      return;
+    }
+    Fq29 PP = Fq29::mul(P, P);                        // < 1.4 q
+    ZZ = Fq29::mul(ZZ, PP);
+    Fq29 Q = Fq29::mul(X, PP);                        // < 1.1 q
+    Fq29 PPP = Fq29::mul(P, PP);                      // < 1.1 q
+    ZZZ = Fq29::mul(ZZZ, PPP);
+    Fq29 R2 = Fq29::mul(R, R);                        // < 1.2 q
+#pragma unroll
+    for (int j = 0; j < 9; j++) X.v[j] = R2.v[j] + Fq29C::K4T[j] - (PPP.v[j] + 2 * Q.v[j]);
+    X.normalize();                                    // X3 in (0.7 q, 5.2 q)
+    Fq29 D = Fq29::sub(Q, Fq29C::K6, X);              // Q - X3 < 7.1 q
+    Fq29 nY = Fq29::neg_lazy(Fq29C::K4, Y);           // lazy, < 4 q
+    Y = Fq29::dot2(R, D, nY, PPP);                    // R (Q - X3) - Y PPP  < 1.3 q
+  }
+};
+
+}  // namespace rlnamd
