@@ -170,6 +170,12 @@ struct Fq29 {
 // entry never straddles a cache line; never the point at infinity (dropped when the table is built).
 struct G1Affine29 {
   uint32_t x[8], y[8];
+  __device__ __forceinline__ bool is_inf() const {  // (0, 0), as Affine<F>::inf(); never present in the prover tables
+    uint32_t o = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o |= x[j] | y[j];
+    return o == 0;
+  }
 };
 __device__ __forceinline__ Fq29 unpack29(const uint32_t (&w)[8]) {
   Fq29 u;

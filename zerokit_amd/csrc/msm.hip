@@ -20,6 +20,7 @@
 
 #include "common.h"
 #include "curve.h"
+#include "fq29.h"
 #include "msm.h"
 
 namespace rlnamd {
@@ -177,8 +178,13 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ coun
 // a bucket that began in an earlier slice to head[s], the part of one that continues into the next slice to tail[s];
 // k_slice_fix then forms bucket = tail[s0] + head[s0+1] + ... + head[s1].  The next index is loaded during an addition
 // (prefetching the point as well costs 16 VGPRs and the fourth wave per SIMD: slower).
-constexpr uint32_t MSM_SLICE = 512;
-__global__ void __launch_bounds__(64) k_slice_acc(const G1Affine* __restrict__ pts, const uint32_t* __restrict__ offs,
+constexpr uint32_t MSM_SLICE = 256;
+// the bases in the packed 9 x 29-bit-limb form the accumulator works in (fq29.h): one pass per MSM, 0.3 ms at 2^24
+__global__ void __launch_bounds__(256) k_pts_to29(const G1Affine* __restrict__ src, G1Affine29* __restrict__ dst, uint32_t n) {
+  uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t < n) dst[t] = to_table29(src[t]);
+}
+__global__ void __launch_bounds__(64) k_slice_acc(const G1Affine29* __restrict__ pts, const uint32_t* __restrict__ offs,
                                                   const uint32_t* __restrict__ sorted, uint32_t nkeys,
                                                   G1XYZZ* __restrict__ buckets, G1XYZZ* __restrict__ head,
                                                   G1XYZZ* __restrict__ tail) {
@@ -195,24 +201,24 @@ __global__ void __launch_bounds__(64) k_slice_acc(const G1Affine* __restrict__ p
   }
   uint32_t key = a, kend = offs[key + 1];
   bool from_before = offs[key] < lo;
-  G1XYZZ acc = G1XYZZ::inf();
+  G1Acc29 acc = G1Acc29::inf();
   uint32_t v = sorted[lo];
   for (uint32_t j = lo; j < hi; j++) {
     if (j == kend) {  // bucket `key` ends inside this slice
-      if (from_before) head[s] = acc; else buckets[key] = acc;
-      acc = G1XYZZ::inf();
+      if (from_before) head[s] = acc.to_xyzz(); else buckets[key] = acc.to_xyzz();
+      acc = G1Acc29::inf();
       from_before = false;
       do kend = offs[++key + 1]; while (kend == j);
     }
-    G1Affine cur = pts[v & 0x7FFFFFFFu];
+    G1Affine29 cur = pts[v & 0x7FFFFFFFu];
     uint32_t cv = v;
     if (j + 1 < hi) v = sorted[j + 1];
-    if (cv & 0x80000000u) cur.y = cur.y.neg();
-    acc.madd(cur);
+    if (!cur.is_inf()) acc.madd(cur, (cv & 0x80000000u) != 0);
   }
-  if (from_before) head[s] = acc;          // started earlier (and may run on: the fix-up adds the later heads)
-  else if (kend > hi) tail[s] = acc;       // started here, continues in the next slice
-  else buckets[key] = acc;                 // ends exactly at the slice end
+  G1XYZZ out = acc.to_xyzz();
+  if (from_before) head[s] = out;          // started earlier (and may run on: the fix-up adds the later heads)
+  else if (kend > hi) tail[s] = out;       // started here, continues in the next slice
+  else buckets[key] = out;                 // ends exactly at the slice end
 }
 __global__ void __launch_bounds__(64) k_slice_fix(const uint32_t* __restrict__ offs, uint32_t nkeys,
                                                   const G1XYZZ* __restrict__ head, const G1XYZZ* __restrict__ tail,
@@ -288,6 +294,7 @@ struct MsmG1::Impl {
   hipStream_t s = nullptr;
   size_t cap = 0, n = 0;
   DevBuf<G1Affine> pts;
+  DevBuf<G1Affine29> pts29;
   DevBuf<uint32_t> scal, count, offs, sorted;
   DevBuf<uint16_t> dig;
   DevBuf<uint32_t> hist;
@@ -307,6 +314,7 @@ MsmG1::MsmG1(size_t capacity) : d_(new Impl) {
   RLN_HIP(hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, MSM_NB * 4));
   const uint32_t nkeys = MSM_W * MSM_NB, nch = MSM_W * MSM_NCH;
   D.pts.alloc(capacity);
+  D.pts29.alloc(capacity);
   D.scal.alloc(capacity * 8);
   D.dig.alloc(capacity * MSM_W);
   D.sorted.alloc(capacity * MSM_W);
@@ -408,6 +416,7 @@ void MsmG1::run_windows(uint8_t* window_sums_out, float ms[3]) {
   RLN_HIP(hipEventRecord(D.e[0], s));
   const uint32_t tile_len = div_up(n ? n : 1, MSM_TILES);
   const size_t lds = MSM_NB * sizeof(uint32_t);
+  if (n) hipLaunchKernelGGL(k_pts_to29, dim3(div_up(n, 256)), dim3(256), 0, s, D.pts.p, D.pts29.p, n);
   if (n) hipLaunchKernelGGL(k_digits, dim3(div_up(n, 256)), dim3(256), 0, s, D.scal.p, n, D.dig.p);
   hipLaunchKernelGGL(k_hist, dim3(MSM_TILES, MSM_W), dim3(1024), lds, s, D.dig.p, n, tile_len, D.hist.p);
   hipLaunchKernelGGL(k_tile_prefix, dim3(div_up(nkeys, 256)), dim3(256), 0, s, D.hist.p, D.count.p);
@@ -417,7 +426,7 @@ void MsmG1::run_windows(uint8_t* window_sums_out, float ms[3]) {
   RLN_HIP(hipEventRecord(D.e[1], s));
   const uint32_t nslices = div_up((size_t)n * MSM_W, MSM_SLICE);
   if (nslices)
-    hipLaunchKernelGGL(k_slice_acc, dim3(div_up(nslices, 64)), dim3(64), 0, s, D.pts.p, D.offs.p, D.sorted.p, nkeys,
+    hipLaunchKernelGGL(k_slice_acc, dim3(div_up(nslices, 64)), dim3(64), 0, s, D.pts29.p, D.offs.p, D.sorted.p, nkeys,
                        D.buckets.p, D.head.p, D.tail.p);
   hipLaunchKernelGGL(k_slice_fix, dim3(div_up(nkeys, 64)), dim3(64), 0, s, D.offs.p, nkeys, D.head.p, D.tail.p, D.buckets.p);
   RLN_HIP(hipEventRecord(D.e[2], s));
