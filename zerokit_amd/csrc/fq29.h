@@ -96,6 +96,14 @@ struct Fq29 {
     const Fq29* const bb[2] = {&b0, &b1};
     return redc_dot<2>(aa, bb);
   }
+  // sum of four products with one reduction; at most two of the eight operands may be lazy (limbs < 2^30):
+  // 9 (2 2^59 + 2 2^58 + 2^58) = 15.75 2^60 < 2^64
+  static __device__ __forceinline__ Fq29 dot4(const Fq29& a0, const Fq29& b0, const Fq29& a1, const Fq29& b1,
+                                              const Fq29& a2, const Fq29& b2, const Fq29& a3, const Fq29& b3) {
+    const Fq29* const aa[4] = {&a0, &a1, &a2, &a3};
+    const Fq29* const bb[4] = {&b0, &b1, &b2, &b3};
+    return redc_dot<4>(aa, bb);
+  }
   // K - b limb by limb: no borrows because every limb of the biased constant K dominates a normalised limb
   static __device__ __forceinline__ Fq29 neg_lazy(const uint32_t (&K)[9], const Fq29& b) {
     Fq29 r;
@@ -296,6 +304,148 @@ struct G1Acc29 {
     Fq29 D = Fq29::sub(Q, Fq29C::K6, X);              // Q - X3 < 7.1 q
     Fq29 nY = Fq29::neg_lazy(Fq29C::K4, Y);           // lazy, < 4 q
     Y = Fq29::dot2(R, D, nY, PPP);                    // R (Q - X3) - Y PPP  < 1.3 q
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// G2: Fq2 = Fq[u]/(u^2 + 1) over Fq29.  Same lazy bounds as G1, component-wise.
+struct Fq2_29 {
+  Fq29 c0, c1;
+  static __device__ __forceinline__ Fq2_29 mul(const Fq2_29& a, const Fq2_29& b) {  // a, b normalised
+    Fq29 n1 = Fq29::neg_lazy(Fq29C::K8, a.c1);   // a.c1 < 7.9 q
+    return {Fq29::dot2(a.c0, b.c0, n1, b.c1), Fq29::dot2(a.c0, b.c1, a.c1, b.c0)};
+  }
+  static __device__ __forceinline__ Fq2_29 sqr(const Fq2_29& a) {                   // (a0 + a1)(a0 - a1), 2 a0 a1
+    Fq29 s, d, t;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      s.v[j] = a.c0.v[j] + a.c1.v[j];   // lazy
+      t.v[j] = 2 * a.c0.v[j];           // lazy
+    }
+    d = Fq29::sub(a.c0, Fq29C::K8, a.c1);
+    return {Fq29::mul(s, d), Fq29::mul(t, a.c1)};
+  }
+  static __device__ __forceinline__ Fq2_29 sub(const Fq2_29& a, const uint32_t (&K)[9], const Fq2_29& b) {
+    return {Fq29::sub(a.c0, K, b.c0), Fq29::sub(a.c1, K, b.c1)};
+  }
+  __device__ __forceinline__ bool is_zero_mod_q() const { return c0.is_zero_mod_q() && c1.is_zero_mod_q(); }
+  static __device__ __forceinline__ Fq2_29 from_fq2(const Fq2& a) { return {Fq29::from_fq(a.c0), Fq29::from_fq(a.c1)}; }
+  __device__ __forceinline__ Fq2 to_fq2() const { return {c0.to_fq(), c1.to_fq()}; }
+};
+
+struct G2Affine29 {  // 128 bytes: x.c0, x.c1, y.c0, y.c1 packed as in G1Affine29
+  uint32_t x0[8], x1[8], y0[8], y1[8];
+};
+__device__ __forceinline__ G2Affine29 to_table29(const G2Affine& a) {
+  G2Affine29 e;
+  pack29_reduced(Fq29::from_fq(a.x.c0), e.x0);
+  pack29_reduced(Fq29::from_fq(a.x.c1), e.x1);
+  pack29_reduced(Fq29::from_fq(a.y.c0), e.y0);
+  pack29_reduced(Fq29::from_fq(a.y.c1), e.y1);
+  return e;
+}
+
+// Bounds as in G1Acc29 (X < 5.2 q, Y < 2.1 q, ZZ, ZZZ < 1.7 q per component); products of two Fq2 values add two
+// base products per component, which the 0.0059 factor absorbs (e.g. P P: 2 * 7.2^2 * 0.0059 + 1 < 1.7).
+struct G2Acc29 {
+  Fq2_29 X, Y, ZZ, ZZZ;
+  static __device__ __forceinline__ G2Acc29 inf() {
+    Fq2_29 z{Fq29::zero(), Fq29::zero()};
+    return {z, z, z, z};
+  }
+  __device__ __forceinline__ bool is_inf() const { return ZZ.c0.limbs_all_zero() && ZZ.c1.limbs_all_zero(); }
+  __device__ __forceinline__ G2XYZZ to_xyzz() const {
+    if (is_inf()) return G2XYZZ::inf();
+    return {X.to_fq2(), Y.to_fq2(), ZZ.to_fq2(), ZZZ.to_fq2()};
+  }
+  static __device__ __forceinline__ G2Acc29 from_xyzz(const G2XYZZ& p) {
+    if (p.is_inf()) return inf();
+    return {Fq2_29::from_fq2(p.X), Fq2_29::from_fq2(p.Y), Fq2_29::from_fq2(p.ZZ), Fq2_29::from_fq2(p.ZZZ)};
+  }
+
+  // 2 (x, y), y normalised < 2 q per component (mdbl-2008-s-1)
+  static __device__ __forceinline__ G2Acc29 dbl_affine(const Fq2_29& x, const Fq2_29& y) {
+    Fq2_29 U;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      U.c0.v[j] = 2 * y.c0.v[j];
+      U.c1.v[j] = 2 * y.c1.v[j];
+    }
+    U.c0.normalize();
+    U.c1.normalize();                           // < 4 q
+    Fq2_29 V = Fq2_29::sqr(U);
+    Fq2_29 W = Fq2_29::mul(U, V);
+    Fq2_29 S = Fq2_29::mul(x, V);
+    Fq2_29 x2 = Fq2_29::sqr(x);
+    Fq2_29 Mm;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      Mm.c0.v[j] = 3 * x2.c0.v[j];
+      Mm.c1.v[j] = 3 * x2.c1.v[j];
+    }
+    Mm.c0.normalize();
+    Mm.c1.normalize();                          // < 3.1 q
+    Fq2_29 M2 = Fq2_29::sqr(Mm);
+    Fq2_29 X3;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      X3.c0.v[j] = M2.c0.v[j] + Fq29C::K4T[j] - 2 * S.c0.v[j];
+      X3.c1.v[j] = M2.c1.v[j] + Fq29C::K4T[j] - 2 * S.c1.v[j];
+    }
+    X3.c0.normalize();
+    X3.c1.normalize();                          // < 5.5 q
+    Fq2_29 D = Fq2_29::sub(S, Fq29C::K6, X3);
+    Fq29 nM1 = Fq29::neg_lazy(Fq29C::K8, Mm.c1);
+    Fq29 ny0 = Fq29::neg_lazy(Fq29C::K4, y.c0);
+    Fq29 ny1 = Fq29::neg_lazy(Fq29C::K4, y.c1);
+    Fq29 y0 = Fq29::dot4(Mm.c0, D.c0, nM1, D.c1, W.c0, ny0, W.c1, y.c1);   // M D - W y
+    Fq29 y1 = Fq29::dot4(Mm.c0, D.c1, Mm.c1, D.c0, W.c0, ny1, W.c1, ny0);
+    return {X3, {y0, y1}, V, W};
+  }
+
+  __device__ __forceinline__ void madd(const G2Affine29& e, bool negate) {
+    const Fq2_29 px{unpack29(e.x0), unpack29(e.x1)};
+    Fq2_29 py{unpack29(e.y0), unpack29(e.y1)};
+    if (negate) {
+      py.c0 = Fq29::neg_lazy(Fq29C::K2, py.c0);
+      py.c1 = Fq29::neg_lazy(Fq29C::K2, py.c1);
+      py.c0.normalize();
+      py.c1.normalize();
+    }
+    if (is_inf()) {
+      X = px;
+      Y = py;
+      ZZ = {Fq29::from_const(Fq29C::ONE), Fq29::zero()};
+      ZZZ = ZZ;
+      return;
+    }
+    Fq2_29 P = Fq2_29::sub(Fq2_29::mul(px, ZZ), Fq29C::K6, X);
+    Fq2_29 R = Fq2_29::sub(Fq2_29::mul(py, ZZZ), Fq29C::K4, Y);
+    if (P.is_zero_mod_q()) {  // same x: doubling or cancellation (rare), kept in this form: no extra registers
+      if (R.is_zero_mod_q()) *this = dbl_affine(px, py); else *this = inf();
+      return;
+    }
+    Fq2_29 PP = Fq2_29::sqr(P);
+    ZZ = Fq2_29::mul(ZZ, PP);
+    Fq2_29 Q = Fq2_29::mul(X, PP);
+    Fq2_29 PPP = Fq2_29::mul(P, PP);
+    ZZZ = Fq2_29::mul(ZZZ, PPP);
+    Fq2_29 R2 = Fq2_29::sqr(R);
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      X.c0.v[j] = R2.c0.v[j] + Fq29C::K4T[j] - (PPP.c0.v[j] + 2 * Q.c0.v[j]);
+      X.c1.v[j] = R2.c1.v[j] + Fq29C::K4T[j] - (PPP.c1.v[j] + 2 * Q.c1.v[j]);
+    }
+    X.c0.normalize();
+    X.c1.normalize();
+    Fq2_29 D = Fq2_29::sub(Q, Fq29C::K6, X);
+    // Y3 = R D - Y PPP, four base products per component, one reduction each
+    Fq29 nR1 = Fq29::neg_lazy(Fq29C::K8, R.c1);
+    Fq29 nY0 = Fq29::neg_lazy(Fq29C::K4, Y.c0);
+    Fq29 nY1 = Fq29::neg_lazy(Fq29C::K4, Y.c1);
+    Fq29 y0 = Fq29::dot4(R.c0, D.c0, nR1, D.c1, nY0, PPP.c0, Y.c1, PPP.c1);
+    Fq29 y1 = Fq29::dot4(R.c0, D.c1, R.c1, D.c0, nY0, PPP.c1, nY1, PPP.c0);
+    Y = {y0, y1};
   }
 };
 

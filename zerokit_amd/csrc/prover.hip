@@ -177,6 +177,7 @@ __global__ void __launch_bounds__(64) k_witness(const GNode* __restrict__ nodes,
                                                 const Fr* __restrict__ consts, const uint32_t* __restrict__ inputs,
                                                 uint32_t n_inputs, Fr* __restrict__ V, uint32_t* __restrict__ err,
                                                 uint32_t B, uint32_t nb) {
+  __builtin_amdgcn_s_setprio(3);  // few, latency-bound waves: issue ahead of the MSM waves sharing the SIMD
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
   if (p >= nb) return;
   uint32_t e = WERR_NONE;
@@ -409,23 +410,24 @@ __global__ void __launch_bounds__(64) k_msm(const Affine<F>* __restrict__ table,
 
 // The same walk for G1 in the 9 x 29-bit form of fq29.h (tables and accumulator): 16.0 G mixed additions/s against
 // 12.6 G in the 8 x 32 form (tools/microbench29.hip).  Partial sums leave in the common XYZZ<Fq> form.
-__global__ void __launch_bounds__(64) k_msm29(const G1Affine29* __restrict__ table, const uint32_t* __restrict__ sid,
+template <class Acc, class Entry, class Out, int WAVES>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_msm29(const Entry* __restrict__ table, const uint32_t* __restrict__ sid,
                                               const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks,
                                               uint32_t nchunks, const int16_t* __restrict__ digits,
-                                              G1XYZZ* __restrict__ part, int c, int W, uint32_t B, uint32_t pgroups) {
+                                              Out* __restrict__ part, int c, int W, uint32_t B, uint32_t pgroups) {
   uint32_t L = blockIdx.x;
   uint32_t xcd = L & 7, q = L >> 3;
   uint32_t chunk = (q / pgroups) * 8 + xcd, pg = q % pgroups;
   if (chunk >= nchunks) return;
   uint32_t p = pg * 64 + threadIdx.x;
   ChunkDesc cd = chunks[chunk];
-  G1Acc29 acc = G1Acc29::inf();
+  Acc acc = Acc::inf();
   const int cs = c - 1;
 #pragma unroll 1
   for (uint32_t i = cd.pt_begin; i < cd.pt_end; i++) {
     const uint32_t k = rows[i];
     const int16_t* dg = digits + (size_t)sid[k] * W * B + p;
-    const G1Affine29* row = table + (((size_t)k * W) << cs);
+    const Entry* row = table + (((size_t)k * W) << cs);
 #pragma unroll 1
     for (int j = 0; j < W; j++) {  // (touching the next entry ahead of the addition was measured: 3 % slower)
       int d = dg[(size_t)j * B];
@@ -437,11 +439,11 @@ __global__ void __launch_bounds__(64) k_msm29(const G1Affine29* __restrict__ tab
   }
   part[(size_t)chunk * B + p] = acc.to_xyzz();
 }
-__global__ void __launch_bounds__(256) k_table_to29(const G1Affine* __restrict__ src, G1Affine29* __restrict__ dst, size_t n) {
+template <class A, class E>
+__global__ void __launch_bounds__(256) k_table_to29(const A* __restrict__ src, E* __restrict__ dst, size_t n) {
   size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n) return;
-  G1Affine a = src[t];
-  dst[t] = to_table29(a);
+  dst[t] = to_table29(src[t]);
 }
 
 // dst[r][p] = sum of src[i][p] over ranges[r] -- used twice (chunks -> groups -> segments) so the
@@ -449,6 +451,7 @@ __global__ void __launch_bounds__(256) k_table_to29(const G1Affine* __restrict__
 template <class F>
 __global__ void __launch_bounds__(64) k_sum_ranges(const XYZZ<F>* __restrict__ src, const ChunkDesc* __restrict__ ranges,
                                                    uint32_t nranges, XYZZ<F>* __restrict__ dst, uint32_t B, uint32_t nb) {
+  __builtin_amdgcn_s_setprio(3);  // few, latency-bound waves: issue ahead of the MSM waves sharing the SIMD
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
   uint32_t r = blockIdx.y;
   if (p >= nb || r >= nranges) return;
@@ -563,6 +566,7 @@ __global__ void __launch_bounds__(64) k_add_partial(G1XYZZ* __restrict__ sums1, 
 __global__ void __launch_bounds__(64) k_fin_affine(const G1XYZZ* __restrict__ sums1, const G2XYZZ* __restrict__ sums2,
                                                    G1Affine* __restrict__ affA, G1Affine* __restrict__ affB1,
                                                    G2Affine* __restrict__ affB2, uint32_t B, uint32_t nb) {
+  __builtin_amdgcn_s_setprio(3);  // few, latency-bound waves: issue ahead of the MSM waves sharing the SIMD
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
   if (p >= nb) return;
   if (blockIdx.y == 0)
@@ -579,6 +583,7 @@ __global__ void __launch_bounds__(64) k_fin_affine(const G1XYZZ* __restrict__ su
 __global__ void __launch_bounds__(64) k_fin_smul(const G1Affine* __restrict__ affA, const G1Affine* __restrict__ affB1,
                                                  const uint32_t* __restrict__ rs, G1XYZZ* __restrict__ tbl,
                                                  G1XYZZ* __restrict__ prod, uint32_t B, uint32_t nb) {
+  __builtin_amdgcn_s_setprio(3);  // few, latency-bound waves: issue ahead of the MSM waves sharing the SIMD
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
   if (p >= nb) return;
   const uint32_t task = blockIdx.y;  // 0: s*A, 1: r*B1
@@ -612,6 +617,7 @@ __global__ void __launch_bounds__(64) k_fin_out(const G1XYZZ* __restrict__ sums1
                                                 const G1Affine* __restrict__ affA, const G2Affine* __restrict__ affB2,
                                                 uint32_t* __restrict__ coords, uint8_t* __restrict__ comp, uint32_t B,
                                                 uint32_t nb) {
+  __builtin_amdgcn_s_setprio(3);  // few, latency-bound waves: issue ahead of the MSM waves sharing the SIMD
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
   if (p >= nb) return;
   G1XYZZ Cacc = sums1[2 * (size_t)B + p];
@@ -656,6 +662,7 @@ struct InputSlots {
 __global__ void __launch_bounds__(64) k_proof_values(const uint32_t* __restrict__ inputs, uint32_t n_inputs,
                                                      InputSlots sl, PoseidonView p2, PoseidonView p3, PoseidonView p4,
                                                      uint32_t* __restrict__ values, uint32_t nb) {
+  __builtin_amdgcn_s_setprio(3);  // few, latency-bound waves: issue ahead of the MSM waves sharing the SIMD
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
   if (p >= nb) return;
   const uint32_t* in = inputs + (size_t)p * n_inputs * 8;
@@ -751,7 +758,8 @@ struct Slot {
 };
 
 struct Prover::Impl {
-  hipStream_t sA = nullptr, sB = nullptr, sB2 = nullptr, sC = nullptr;
+  hipStream_t sA = nullptr, sA2 = nullptr, sB = nullptr, sB2 = nullptr, sC = nullptr;
+  uint32_t seq = 0;  // batches enqueued: consecutive front ends alternate between sA and sA2
   bool split_msm = false;  // G2 walk on its own stream: its workgroups fill the G1 kernel's tail (RLNAMD_MSM_SPLIT)
   float ms[PROVER_STAGES] = {0};
 
@@ -767,6 +775,8 @@ struct Prover::Impl {
   DevBuf<G1Affine> t1;
   DevBuf<G1Affine29> t1_29;  // G1 table in the 9 x 29-bit form (default; RLNAMD_FQ29=0 keeps the 8 x 32 walk)
   bool use29 = true;
+  DevBuf<G2Affine29> t2_29;
+  bool use29_g2 = true;
   DevBuf<G2Affine> t2;
   DevBuf<uint32_t> sid1, sid2;
   // a walk = a list of table rows cut into chunks, plus the two-level reduction ranges; one per mode
@@ -786,12 +796,14 @@ struct Prover::Impl {
   bool have_values_kernel = false;
   // resident inputs (shared by both slots; upload() drains the pipeline first)
   DevBuf<uint32_t> inputs, rs;
-  Slot slot[2];
+  static constexpr int NSLOT = 2;  // a third slot + a second front-end stream was measured: no gain (the chip is busy)
+  Slot slot[NSLOT];
   int cur = 0;
   Slot* last = nullptr;
 
   void sync_all() {
     RLN_HIP(hipStreamSynchronize(sA));
+    RLN_HIP(hipStreamSynchronize(sA2));
     RLN_HIP(hipStreamSynchronize(sB));
     RLN_HIP(hipStreamSynchronize(sB2));
     RLN_HIP(hipStreamSynchronize(sC));
@@ -845,24 +857,25 @@ static void build_table(const std::vector<Affine<F>>& pts, int c, int W, DevBuf<
 
 // G1 table in the 9 x 29 form: slabs are built in the 8 x 32 form (k_table_build reads its own rows back) and
 // converted into place
-static void build_table29(const std::vector<G1Affine>& pts, int c, int W, DevBuf<G1Affine29>& table, hipStream_t s) {
+template <class F, class Entry>
+static void build_table29(const std::vector<Affine<F>>& pts, int c, int W, DevBuf<Entry>& table, hipStream_t s) {
   size_t npts = pts.size();
   size_t E = (size_t)1 << (c - 1);
   table.alloc(npts * W * E);
-  DevBuf<G1Affine> d_pts(npts);
+  DevBuf<Affine<F>> d_pts(npts);
   d_pts.upload(pts.data(), npts, s);
-  size_t per_pt = (size_t)W * std::max<size_t>(E / 2, 1) * sizeof(Fq);
+  size_t per_pt = (size_t)W * std::max<size_t>(E / 2, 1) * sizeof(F);
   size_t slab = std::max<size_t>(1, ((size_t)4 << 30) / per_pt);
   slab = std::min(slab, npts);
-  DevBuf<Fq> scratch(slab * W * std::max<size_t>(E / 2, 1));
-  DevBuf<G1Affine> tmp(slab * W * E);
+  DevBuf<F> scratch(slab * W * std::max<size_t>(E / 2, 1));
+  DevBuf<Affine<F>> tmp(slab * W * E);
   for (size_t k0 = 0; k0 < npts; k0 += slab) {
     size_t cnt = std::min(slab, npts - k0);
     size_t threads = cnt * W;
-    hipLaunchKernelGGL(k_table_build<Fq>, dim3(div_up(threads, 64)), dim3(64), 0, s, d_pts.p + k0, (uint32_t)cnt, c, W,
+    hipLaunchKernelGGL(k_table_build<F>, dim3(div_up(threads, 64)), dim3(64), 0, s, d_pts.p + k0, (uint32_t)cnt, c, W,
                        tmp.p, scratch.p);
-    hipLaunchKernelGGL(k_table_to29, dim3(div_up(threads * E, 256)), dim3(256), 0, s, tmp.p, table.p + k0 * W * E,
-                       threads * E);
+    hipLaunchKernelGGL((k_table_to29<Affine<F>, Entry>), dim3(div_up(threads * E, 256)), dim3(256), 0, s, tmp.p,
+                       table.p + k0 * W * E, threads * E);
     RLN_HIP(hipGetLastError());
   }
   RLN_HIP(hipStreamSynchronize(s));
@@ -907,10 +920,12 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     const char* pe = getenv("RLNAMD_PRIO");  // experiment knob: three chars h/l for streams A, B, C
     auto pick = [&](int i, int dflt) { return (pe && strlen(pe) == 3) ? (pe[i] == 'h' ? hi : lo) : dflt; };
     RLN_HIP(hipStreamCreateWithPriority(&D.sA, hipStreamNonBlocking, pick(0, hi)));
+    RLN_HIP(hipStreamCreateWithPriority(&D.sA2, hipStreamNonBlocking, pick(0, hi)));
     RLN_HIP(hipStreamCreateWithPriority(&D.sB, hipStreamNonBlocking, pick(1, lo)));
     RLN_HIP(hipStreamCreateWithPriority(&D.sB2, hipStreamNonBlocking, pick(1, lo)));
     RLN_HIP(hipStreamCreateWithPriority(&D.sC, hipStreamNonBlocking, pick(2, hi)));
     D.use29 = env_int("RLNAMD_FQ29", 1) != 0;
+    D.use29_g2 = env_int("RLNAMD_FQ29_G2", D.use29 ? 1 : 0) != 0;
     D.split_msm = env_int("RLNAMD_MSM_SPLIT", 0) != 0;  // measured +1 % only; off keeps per-kernel timings clean
   }
   hipStream_t s = D.sB;
@@ -1070,7 +1085,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     D.sid1.upload(sids.data(), sids.size(), s);
     make_plans(sids, row_seg, 3, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK", 8)), D.plan1, &D.max_chunks1,
                &D.max_groups1);
-    if (D.use29) build_table29(pts, c_, W_, D.t1_29, s); else build_table<Fq>(pts, c_, W_, D.t1, s);
+    if (D.use29) build_table29<Fq, G1Affine29>(pts, c_, W_, D.t1_29, s); else build_table<Fq>(pts, c_, W_, D.t1, s);
   }
   {
     std::vector<G2Affine> pts;
@@ -1089,7 +1104,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     D.sid2.upload(sids.data(), sids.size(), s);
     make_plans(sids, row_seg, 1, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_G2", 4)), D.plan2, &D.max_chunks2,
                &D.max_groups2);
-    build_table<Fq2>(pts, c_, W_, D.t2, s);
+    if (D.use29_g2) build_table29<Fq2, G2Affine29>(pts, c_, W_, D.t2_29, s); else build_table<Fq2>(pts, c_, W_, D.t2, s);
   }
 
   // ---- named input slots for the proof-values kernel (single message-id circuit, witness.rs:832-881);
@@ -1158,7 +1173,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
 Prover::~Prover() {
   if (!d_) return;
   Impl& D = *d_;
-  for (hipStream_t st : {D.sA, D.sB, D.sB2, D.sC})
+  for (hipStream_t st : {D.sA, D.sA2, D.sB, D.sB2, D.sC})
     if (st) (void)hipStreamSynchronize(st);
   for (Slot& S : D.slot) {
     if (S.h_pp) (void)hipHostFree(S.h_pp);
@@ -1169,11 +1184,11 @@ Prover::~Prover() {
       if (e) (void)hipEventDestroy(e);
     for (auto& e : S.t) (void)hipEventDestroy(e);
   }
-  for (hipStream_t st : {D.sA, D.sB, D.sB2, D.sC})
+  for (hipStream_t st : {D.sA, D.sA2, D.sB, D.sB2, D.sC})
     if (st) (void)hipStreamDestroy(st);
 }
 
-size_t Prover::table_bytes() const { return d_->t1.bytes() + d_->t1_29.bytes() + d_->t2.bytes(); }
+size_t Prover::table_bytes() const { return d_->t1.bytes() + d_->t1_29.bytes() + d_->t2.bytes() + d_->t2_29.bytes(); }
 
 void Prover::upload(size_t n, const uint8_t* inputs, const uint8_t* rs) {
   if (n > B_) throw Error("batch larger than the prover workspace (max_batch)");
@@ -1230,35 +1245,38 @@ void Prover::run_async(size_t n, int mode) {
   const Impl::Plan& P2 = D.plan2[mode];
   Slot& S = D.slot[D.cur];
   S.mode = mode;
-  D.cur ^= 1;
+  D.cur = (D.cur + 1) % Impl::NSLOT;
+  // the front end is latency-bound (16 waves of the graph interpreter per 1024 proofs, then NTT passes squeezed in
+  // beside the MSM): two of them in flight on their own streams keep it off the critical path
+  hipStream_t sA = (Impl::NSLOT > 2 && (D.seq++ & 1)) ? D.sA2 : D.sA;
   const uint32_t B = (uint32_t)B_, nb = (uint32_t)n;
   const uint32_t pg = div_up(nb, 64);
   const uint32_t nbp = pg * 64;  // padded lanes compute on stale / zero inputs; results ignored
   // ---------------- stage A
-  if (S.used) RLN_HIP(hipStreamWaitEvent(D.sA, S.evC, 0));  // slot free again
-  RLN_HIP(hipEventRecord(S.t[1], D.sA));
-  hipLaunchKernelGGL(k_witness, dim3(pg), dim3(64), 0, D.sA, D.nodes.p, D.N, D.consts.p, D.inputs.p, D.NI, S.V.p,
+  if (S.used) RLN_HIP(hipStreamWaitEvent(sA, S.evC, 0));  // slot free again
+  RLN_HIP(hipEventRecord(S.t[1], sA));
+  hipLaunchKernelGGL(k_witness, dim3(pg), dim3(64), 0, sA, D.nodes.p, D.N, D.consts.p, D.inputs.p, D.NI, S.V.p,
                      S.err.p, B, nbp);
   if (D.wgiven_n) {
     if (D.wgiven_n != n || mode != PROVE_FULL) throw Error("upload_witness: the next run must be a full proof of the same batch");
-    hipLaunchKernelGGL(k_scatter_witness, dim3(pg, div_up(D.NS, 4)), dim3(64, 4), 0, D.sA, D.wgiven.p, D.sig2node.p,
+    hipLaunchKernelGGL(k_scatter_witness, dim3(pg, div_up(D.NS, 4)), dim3(64, 4), 0, sA, D.wgiven.p, D.sig2node.p,
                        D.NS, S.V.p, S.err.p, B, nb);
     D.wgiven_n = 0;
   }
-  RLN_HIP(hipEventRecord(S.t[2], D.sA));
+  RLN_HIP(hipEventRecord(S.t[2], sA));
   if (mode != PROVE_PARTIAL) {  // the quotient h depends on the whole witness: not part of a partial proof
     CsrView A{D.a_ptr.p, D.a_col.p, D.a_coef.p}, Bm{D.b_ptr.p, D.b_col.p, D.b_coef.p};
-    hipLaunchKernelGGL(k_matvec, dim3(pg, div_up(D.n, 4)), dim3(64, 4), 0, D.sA, A, Bm, S.V.p, D.sig2node.p, D.nc,
+    hipLaunchKernelGGL(k_matvec, dim3(pg, div_up(D.n, 4)), dim3(64, 4), 0, sA, A, Bm, S.V.p, D.sig2node.p, D.nc,
                        D.ni, D.n, S.abc.p, B, nbp);
   }
-  RLN_HIP(hipEventRecord(S.t[3], D.sA));
+  RLN_HIP(hipEventRecord(S.t[3], sA));
   if (mode != PROVE_PARTIAL) {
-    launch_ntt<true>(S.abc.p, D.tw_i.p, D.logn, D.coset.p, B, nbp, D.sA);  // iNTT (DIF) + g^i / n
-    launch_ntt<false>(S.abc.p, D.tw_f.p, D.logn, nullptr, B, nbp, D.sA);   // NTT (DIT)
-    hipLaunchKernelGGL(k_hquot, dim3(pg, div_up(D.n, 4)), dim3(64, 4), 0, D.sA, S.abc.p, D.n, B, nbp);
+    launch_ntt<true>(S.abc.p, D.tw_i.p, D.logn, D.coset.p, B, nbp, sA);  // iNTT (DIF) + g^i / n
+    launch_ntt<false>(S.abc.p, D.tw_f.p, D.logn, nullptr, B, nbp, sA);   // NTT (DIT)
+    hipLaunchKernelGGL(k_hquot, dim3(pg, div_up(D.n, 4)), dim3(64, 4), 0, sA, S.abc.p, D.n, B, nbp);
   }
-  RLN_HIP(hipEventRecord(S.t[4], D.sA));
-  RLN_HIP(hipEventRecord(S.evA, D.sA));
+  RLN_HIP(hipEventRecord(S.t[4], sA));
+  RLN_HIP(hipEventRecord(S.evA, sA));
   // ---------------- stage B
   RLN_HIP(hipStreamWaitEvent(D.sB, S.evA, 0));
   RLN_HIP(hipEventRecord(S.t[5], D.sB));
@@ -1273,7 +1291,7 @@ void Prover::run_async(size_t n, int mode) {
   if (P1.nchunks) {
     uint32_t blocks = div_up(P1.nchunks, 8) * 8 * pg;
     if (D.use29)
-      hipLaunchKernelGGL(k_msm29, dim3(blocks), dim3(64), 0, D.sB, D.t1_29.p, D.sid1.p, P1.rows.p, P1.chunks.p,
+      hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(blocks), dim3(64), 0, D.sB, D.t1_29.p, D.sid1.p, P1.rows.p, P1.chunks.p,
                          P1.nchunks, S.digits.p, S.part1.p, c_, W_, B, pg);
     else
       hipLaunchKernelGGL(k_msm<Fq>, dim3(blocks), dim3(64), 0, D.sB, D.t1.p, D.sid1.p, P1.rows.p, P1.chunks.p,
@@ -1283,8 +1301,12 @@ void Prover::run_async(size_t n, int mode) {
   RLN_HIP(hipEventRecord(S.t[11], s2));
   if (P2.nchunks) {
     uint32_t blocks = div_up(P2.nchunks, 8) * 8 * pg;
-    hipLaunchKernelGGL(k_msm<Fq2>, dim3(blocks), dim3(64), 0, s2, D.t2.p, D.sid2.p, P2.rows.p, P2.chunks.p,
-                       P2.nchunks, S.digits.p, S.part2.p, c_, W_, B, pg);
+    if (D.use29_g2)
+      hipLaunchKernelGGL((k_msm29<G2Acc29, G2Affine29, G2XYZZ, 2>), dim3(blocks), dim3(64), 0, s2, D.t2_29.p, D.sid2.p,
+                         P2.rows.p, P2.chunks.p, P2.nchunks, S.digits.p, S.part2.p, c_, W_, B, pg);
+    else
+      hipLaunchKernelGGL(k_msm<Fq2>, dim3(blocks), dim3(64), 0, s2, D.t2.p, D.sid2.p, P2.rows.p, P2.chunks.p,
+                         P2.nchunks, S.digits.p, S.part2.p, c_, W_, B, pg);
   }
   RLN_HIP(hipEventRecord(S.t[8], s2));
   RLN_HIP(hipEventRecord(S.evB, D.sB));
