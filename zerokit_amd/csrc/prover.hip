@@ -751,8 +751,8 @@ struct Slot {
   uint8_t* h_comp = nullptr;    // pinned: every run ends with the proofs + values copied to the host
   uint32_t* h_values = nullptr;
   uint32_t* h_err = nullptr;
-  hipEvent_t evA = nullptr, evB = nullptr, evB2 = nullptr, evR = nullptr, evC = nullptr;
-  hipEvent_t t[12];  // timing marks
+  hipEvent_t evA = nullptr, evB = nullptr, evB2 = nullptr, evR = nullptr, evC = nullptr, evW = nullptr;
+  hipEvent_t t[13] = {};  // timing marks
   bool used = false;
   size_t n = 0;
 };
@@ -796,8 +796,10 @@ struct Prover::Impl {
   bool have_values_kernel = false;
   // resident inputs (shared by both slots; upload() drains the pipeline first)
   DevBuf<uint32_t> inputs, rs;
-  static constexpr int NSLOT = 2;  // a third slot + a second front-end stream was measured: no gain (the chip is busy)
+  static constexpr int NSLOT = 4;
   Slot slot[NSLOT];
+  int nslot = 4, nstreamA = 2;  // RLNAMD_SLOTS / RLNAMD_ASTREAMS
+  uint32_t msm_lds = 0;         // RLNAMD_MSM_WAVES (waves per SIMD the G1 walk may occupy; 0 = no cap)
   int cur = 0;
   Slot* last = nullptr;
 
@@ -924,6 +926,12 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     RLN_HIP(hipStreamCreateWithPriority(&D.sB, hipStreamNonBlocking, pick(1, lo)));
     RLN_HIP(hipStreamCreateWithPriority(&D.sB2, hipStreamNonBlocking, pick(1, lo)));
     RLN_HIP(hipStreamCreateWithPriority(&D.sC, hipStreamNonBlocking, pick(2, hi)));
+    D.nslot = std::min(std::max(env_int("RLNAMD_SLOTS", 4), 2), (int)Impl::NSLOT);
+    {
+      int mw = env_int("RLNAMD_MSM_WAVES", 0);
+      D.msm_lds = mw > 0 ? (uint32_t)(160 * 1024 / (4 * mw)) & ~255u : 0;
+    }
+    D.nstreamA = env_int("RLNAMD_ASTREAMS", 2);
     D.use29 = env_int("RLNAMD_FQ29", 1) != 0;
     D.use29_g2 = env_int("RLNAMD_FQ29_G2", D.use29 ? 1 : 0) != 0;
     D.split_msm = env_int("RLNAMD_MSM_SPLIT", 0) != 0;  // measured +1 % only; off keeps per-kernel timings clean
@@ -1135,7 +1143,8 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   RLN_HIP(hipMemsetAsync(D.pp_in.p, 0, D.pp_in.bytes(), s));
   RLN_HIP(hipMemsetAsync(D.inputs.p, 0, D.inputs.bytes(), s));
   RLN_HIP(hipMemsetAsync(D.rs.p, 0, D.rs.bytes(), s));
-  for (Slot& S : D.slot) {
+  for (int si = 0; si < D.nslot; si++) {
+    Slot& S = D.slot[si];
     S.err.alloc(B);
     S.coords.alloc(B * 64);
     S.values.alloc(B * 40);
@@ -1163,6 +1172,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     RLN_HIP(hipEventCreateWithFlags(&S.evB, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evB2, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evR, hipEventDisableTiming));
+    RLN_HIP(hipEventCreateWithFlags(&S.evW, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evC, hipEventDisableTiming));
     for (auto& e : S.t) RLN_HIP(hipEventCreate(&e));
     RLN_HIP(hipMemsetAsync(S.digits.p, 0, S.digits.bytes(), s));
@@ -1180,9 +1190,10 @@ Prover::~Prover() {
     if (S.h_comp) (void)hipHostFree(S.h_comp);
     if (S.h_values) (void)hipHostFree(S.h_values);
     if (S.h_err) (void)hipHostFree(S.h_err);
-    for (hipEvent_t e : {S.evA, S.evB, S.evB2, S.evR, S.evC})
+    for (hipEvent_t e : {S.evA, S.evB, S.evB2, S.evR, S.evC, S.evW})
       if (e) (void)hipEventDestroy(e);
-    for (auto& e : S.t) (void)hipEventDestroy(e);
+    for (auto& e : S.t)
+      if (e) (void)hipEventDestroy(e);
   }
   for (hipStream_t st : {D.sA, D.sA2, D.sB, D.sB2, D.sC})
     if (st) (void)hipStreamDestroy(st);
@@ -1220,7 +1231,10 @@ static void launch_ntt(Fr* data, const Fr* tw, int logn, const Fr* final_scale, 
     int K = rem > maxk ? 3 : rem;  // 13 -> 3,3,3,3,1 (a 16-point block spills; measured 6.7 -> 5.0 ms)
     if (K > maxk) K = maxk;
     uint32_t groups = (1u << logn) >> K;
-    dim3 block(64, 4), grid(div_up(nb, 64), div_up(groups, 4), 3);
+    // one wave per workgroup: a 4-wave workgroup needs four free wave slots on one CU at the same moment, which the
+    // single-wave MSM workgroups streaming through the chip never leave (measured: mat-vec 0.6 -> 32 ms, NTT 5 -> 19 ms)
+    static const int wpb = env_int("RLNAMD_NTT_WPB", 1);
+    dim3 block(64, wpb), grid(div_up(nb, 64), div_up(groups, wpb), 3);
     const Fr* sc = (s0 + K == logn) ? final_scale : nullptr;
     switch (K) {
       case 1: hipLaunchKernelGGL((k_ntt_pass<1, DIF>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb); break;
@@ -1245,10 +1259,12 @@ void Prover::run_async(size_t n, int mode) {
   const Impl::Plan& P2 = D.plan2[mode];
   Slot& S = D.slot[D.cur];
   S.mode = mode;
-  D.cur = (D.cur + 1) % Impl::NSLOT;
-  // the front end is latency-bound (16 waves of the graph interpreter per 1024 proofs, then NTT passes squeezed in
-  // beside the MSM): two of them in flight on their own streams keep it off the critical path
-  hipStream_t sA = (Impl::NSLOT > 2 && (D.seq++ & 1)) ? D.sA2 : D.sA;
+  D.cur = (D.cur + 1) % D.nslot;
+  // Front end in two pipeline stages on their own streams: A1 = graph interpreter (16 latency-bound waves per 1024
+  // proofs, ~28 ms), A2 = mat-vec + NTTs + quotient (throughput kernels squeezed in beside the MSM, ~25 ms contended).
+  // Chained on one stream they were the critical path (54 ms against 49 ms of MSM).
+  hipStream_t sA = D.sA;
+  hipStream_t sA2 = D.nstreamA > 1 ? D.sA2 : D.sA;
   const uint32_t B = (uint32_t)B_, nb = (uint32_t)n;
   const uint32_t pg = div_up(nb, 64);
   const uint32_t nbp = pg * 64;  // padded lanes compute on stale / zero inputs; results ignored
@@ -1264,23 +1280,28 @@ void Prover::run_async(size_t n, int mode) {
     D.wgiven_n = 0;
   }
   RLN_HIP(hipEventRecord(S.t[2], sA));
+  if (sA2 != sA) {
+    RLN_HIP(hipEventRecord(S.evW, sA));
+    RLN_HIP(hipStreamWaitEvent(sA2, S.evW, 0));
+  }
+  RLN_HIP(hipEventRecord(S.t[12], sA2));
   if (mode != PROVE_PARTIAL) {  // the quotient h depends on the whole witness: not part of a partial proof
     CsrView A{D.a_ptr.p, D.a_col.p, D.a_coef.p}, Bm{D.b_ptr.p, D.b_col.p, D.b_coef.p};
-    hipLaunchKernelGGL(k_matvec, dim3(pg, div_up(D.n, 4)), dim3(64, 4), 0, sA, A, Bm, S.V.p, D.sig2node.p, D.nc,
+    hipLaunchKernelGGL(k_matvec, dim3(pg, D.n), dim3(64, 1), 0, sA2, A, Bm, S.V.p, D.sig2node.p, D.nc,
                        D.ni, D.n, S.abc.p, B, nbp);
   }
-  RLN_HIP(hipEventRecord(S.t[3], sA));
+  RLN_HIP(hipEventRecord(S.t[3], sA2));
   if (mode != PROVE_PARTIAL) {
-    launch_ntt<true>(S.abc.p, D.tw_i.p, D.logn, D.coset.p, B, nbp, sA);  // iNTT (DIF) + g^i / n
-    launch_ntt<false>(S.abc.p, D.tw_f.p, D.logn, nullptr, B, nbp, sA);   // NTT (DIT)
-    hipLaunchKernelGGL(k_hquot, dim3(pg, div_up(D.n, 4)), dim3(64, 4), 0, sA, S.abc.p, D.n, B, nbp);
+    launch_ntt<true>(S.abc.p, D.tw_i.p, D.logn, D.coset.p, B, nbp, sA2);  // iNTT (DIF) + g^i / n
+    launch_ntt<false>(S.abc.p, D.tw_f.p, D.logn, nullptr, B, nbp, sA2);   // NTT (DIT)
+    hipLaunchKernelGGL(k_hquot, dim3(pg, D.n), dim3(64, 1), 0, sA2, S.abc.p, D.n, B, nbp);
   }
-  RLN_HIP(hipEventRecord(S.t[4], sA));
-  RLN_HIP(hipEventRecord(S.evA, sA));
+  RLN_HIP(hipEventRecord(S.t[4], sA2));
+  RLN_HIP(hipEventRecord(S.evA, sA2));
   // ---------------- stage B
   RLN_HIP(hipStreamWaitEvent(D.sB, S.evA, 0));
   RLN_HIP(hipEventRecord(S.t[5], D.sB));
-  hipLaunchKernelGGL(k_recode, dim3(pg, div_up(D.NS + D.n + 3, 4)), dim3(64, 4), 0, D.sB, S.V.p, D.sig2node.p, D.NS,
+  hipLaunchKernelGGL(k_recode, dim3(pg, D.NS + D.n + 3), dim3(64, 1), 0, D.sB, S.V.p, D.sig2node.p, D.NS,
                      S.abc.p, D.n, D.rs.p, c_, W_, S.digits.p, B, nbp);
   RLN_HIP(hipEventRecord(S.t[6], D.sB));
   hipStream_t s2 = D.split_msm ? D.sB2 : D.sB;
@@ -1291,7 +1312,9 @@ void Prover::run_async(size_t n, int mode) {
   if (P1.nchunks) {
     uint32_t blocks = div_up(P1.nchunks, 8) * 8 * pg;
     if (D.use29)
-      hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(blocks), dim3(64), 0, D.sB, D.t1_29.p, D.sid1.p, P1.rows.p, P1.chunks.p,
+      // dynamic LDS that the kernel never touches caps it at D.msm_waves waves per SIMD: at 4 x 128 VGPRs the
+      // register file is full and the front end's NTT / mat-vec workgroups wait for an MSM workgroup (~1 ms) to retire
+      hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(blocks), dim3(64), D.msm_lds, D.sB, D.t1_29.p, D.sid1.p, P1.rows.p, P1.chunks.p,
                          P1.nchunks, S.digits.p, S.part1.p, c_, W_, B, pg);
     else
       hipLaunchKernelGGL(k_msm<Fq>, dim3(blocks), dim3(64), 0, D.sB, D.t1.p, D.sid1.p, P1.rows.p, P1.chunks.p,
@@ -1359,7 +1382,7 @@ void Prover::sync() {
   D.sync_all();
   if (D.last) {
     Slot& S = *D.last;
-    const int pairs[PROVER_STAGES][2] = {{1, 2}, {2, 3}, {3, 4}, {5, 6}, {6, 7}, {11, 8}, {9, 10}, {0, 9}};
+    const int pairs[PROVER_STAGES][2] = {{1, 2}, {12, 3}, {3, 4}, {5, 6}, {6, 7}, {11, 8}, {9, 10}, {0, 9}};
     for (int i = 0; i < PROVER_STAGES; i++) RLN_HIP(hipEventElapsedTime(&D.ms[i], S.t[pairs[i][0]], S.t[pairs[i][1]]));
   }
 }
