@@ -256,7 +256,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32x8 (256-bit Montgomery integers, BN254 Fr/Fq)",
+            "dtype": "u32 limbs (256-bit Montgomery integers, BN254 Fr/Fq; 8x32 and 9x29 forms)",
             "data": "synthetic (SplitMix64 0xC0FFEE witnesses, shipped depth-20 arkzkey + graph)",
             "config": {"workload": "config 2: batch of %d independent RLN proofs per GPU, tree_height=20, "
                                    "inputs resident in HBM" % B,
@@ -265,13 +265,15 @@ def main():
                        "device": name.value.decode(), "init_s": round(init_s, 2), "verified": bool(ok)},
             "achieved_GBps_whole_proof": round(value * BYTES_PER_PROOF / 1e9, 3),
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
-            "roofline": {"bound": "hbm", "kernel": "k_msm<Fq> (G1 fixed-base table MSM)",
+            "roofline": {"bound": "hbm", "kernel": "k_msm29<G1> (G1 fixed-base table MSM, 9 x 29-bit limbs)",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
                          "traffic_unit": "GB per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r1_pmc_k_msm_g1.json)",
                          "launch_ms": round(msm_ms, 3),
-                         "note": "integer-ALU bound (256-bit modular multiply): 11 G mixed-add/s ~ 91% of the "
-                                 "measured 135 G Fq-mul/s multiplier ceiling; see DESIGN.md section 4"},
+                         "madd_per_s": round(473500 * B / (msm_ms * 1e-3) / 1e9, 2) if msm_ms > 0 else None,
+                         "note": "integer-multiplier bound, not HBM bound: G mixed additions/s in madd_per_s against "
+                                 "17.0 G/s = 31.6 T v_mad_u64_u32/s (measured peak) / 1860 mads per addition; "
+                                 "see DESIGN.md section 4"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ws, rs)
