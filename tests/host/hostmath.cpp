@@ -3,7 +3,15 @@
 // Test infrastructure only: nothing in the product links this.
 #include <string.h>
 
+#include <stdexcept>
+#include <string>
 #include "curve.h"
+namespace rlnamd {
+struct Error : std::runtime_error {  // common.h's Error without the HIP headers
+  explicit Error(const std::string& m) : std::runtime_error(m) {}
+};
+}  // namespace rlnamd
+#include "pairing.h"
 using namespace rlnamd;
 
 template <class F> static F ld(const uint8_t* p) { uint32_t c[8]; memcpy(c, p, 32); return F::from_canonical(c); }
@@ -12,6 +20,23 @@ static Fq2 ld2(const uint8_t* p) { return {ld<Fq>(p), ld<Fq>(p + 32)}; }
 static void st2(uint8_t* p, const Fq2& x) { st(p, x.c0); st(p + 32, x.c1); }
 
 extern "C" {
+// structured final exponentiation against the definition (square-and-multiply over (q^12 - 1) / r) on an arbitrary
+// Fq12 element, plus the Fq12 inverse; returns a bit mask of the checks that hold (7 = all)
+int hm_final_exp_check(uint32_t seed) {
+  Fq12 f;
+  for (int k = 0; k < 6; k++) f.c[k] = {Fq::from_u32(seed + 3 * k + 1), Fq::from_u32(seed * 7 + k + 2)};
+  int ok = 0;
+  Fq12 fi = f12_inv(f);
+  if (f12_mul(f, fi).is_one()) ok |= 1;
+  Fq12 slow = final_exponentiation_generic(f), fast = final_exponentiation(f);
+  bool eq = true;
+  for (int k = 0; k < 6; k++) eq &= slow.c[k] == fast.c[k];
+  if (eq) ok |= 2;
+  // the result lies in the order-r subgroup: frob(x) has the same order and x^(q^6) = x^-1
+  if (f12_mul(fast, f12_conj(fast)).is_one()) ok |= 4;
+  return ok;
+}
+
 // op: 0 add 1 sub 2 mul 3 inv 4 neg 5 sqr ; field: 0 Fr 1 Fq
 void hm_fp_op(int field, int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
   if (field == 0) {

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def L():
     so = os.path.join(ROOT, "tests", "host", "libhostmath.so")
     src = os.path.join(ROOT, "tests", "host", "hostmath.cpp")
-    hdrs = [os.path.join(ROOT, "zerokit_amd", "csrc", h) for h in ("field.h", "curve.h")]
+    hdrs = [os.path.join(ROOT, "zerokit_amd", "csrc", h) for h in ("field.h", "curve.h", "pairing.h")]
     if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I",
                                os.path.join(ROOT, "zerokit_amd", "csrc"), src, "-o", so])
@@ -117,3 +117,10 @@ def test_g2_group_law(L):
         assert g2i(out.raw) == G2.add(P, P)
         L.hm_g2_mul(g2b(P), b(k2), out)
         assert g2i(out.raw) == G2.mul(P, k2)
+
+
+def test_structured_final_exponentiation_equals_definition(L):
+    """pairing.h: (q^6-1)(q^2+1) + the u-chain for the hard part == f^((q^12-1)/r) by square-and-multiply; Fq12
+    inverse through Fq6; result in the cyclotomic subgroup"""
+    for seed in (1, 12345, 99991):
+        assert L.hm_final_exp_check(seed) == 7

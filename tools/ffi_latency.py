@@ -1,0 +1,18 @@
+import time, sys
+sys.path.insert(0,'/root/repo')
+from zerokit_amd.public import RLN, RLNWitnessInput
+from zerokit_amd import hashers
+rln = RLN(20)
+secret = 1234567
+rln.set_leaf(3, hashers.poseidon_hash_pair(hashers.poseidon_hash([secret]), 100))
+elems, bits = rln.get_merkle_proof(3)
+ws = [RLNWitnessInput(secret, 100, i % 100, elems, bits, 1000 + i, 777) for i in range(64)]
+p = rln.generate_rln_proof(ws[0])
+for n in (1, 1, 1):
+    t = time.perf_counter(); p = rln.generate_rln_proof(ws[1]); dt = time.perf_counter() - t
+    print("single proof latency ms", round(dt * 1e3, 2))
+t = time.perf_counter(); ok = rln.verify_rln_proof(p, 1001); print("verify ms", round((time.perf_counter() - t) * 1e3, 2), ok)
+for n in (8, 64):
+    t = time.perf_counter(); ps = rln.generate_rln_proofs_batch(ws[:n]); dt = time.perf_counter() - t
+    print("batch", n, "ms", round(dt * 1e3, 2), "per proof", round(dt * 1e3 / n, 3))
+t = time.perf_counter(); rln.set_leaf(5, 99); r = rln.get_root(); print("set_leaf+root ms", round((time.perf_counter() - t) * 1e3, 3))

@@ -9,6 +9,7 @@
 #include <algorithm>
 
 #include "fq29.h"
+#include "pairing.h"
 #include "poseidon.h"
 
 namespace rlnamd {
@@ -888,6 +889,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   require_gpu();
   zk_ = parse_arkzkey(zkey, zkey_len);
   graph_ = parse_graph(graph, graph_len);
+  (void)prepared(zk_);  // verifier precomputation now, so concurrent verify calls only read it
   Impl& D = *d_;
   c_ = cfg.window_bits > 0 ? cfg.window_bits : env_int("RLNAMD_WINDOW_BITS", 8);
   if (c_ < 2 || c_ > 14) throw Error("window bits must be in [2, 14]");

@@ -9,6 +9,7 @@
 
 #include <map>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "curve.h"
@@ -28,6 +29,8 @@ struct Zkey {
   uint64_t num_instance_variables = 0, num_witness_variables = 0, num_constraints = 0;
   uint64_t a_nnz = 0, b_nnz = 0, c_nnz = 0;
   std::vector<SparseRow> a, b, c;
+  // verifier-side precomputation (pairing.h: prepare_vk), built on first use; copies of a key share it
+  mutable std::shared_ptr<const void> prepared_vk;
 };
 // throws Error("...") on malformed input (ZKeyReadError in the reference, circuit/error.rs)
 Zkey parse_arkzkey(const uint8_t* data, size_t len);
