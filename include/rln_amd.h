@@ -144,6 +144,11 @@ int rlnamd_proof_decompress(const uint8_t proof[128], uint8_t coords_le[256]);
 typedef struct rlnamd_msm rlnamd_msm;
 int rlnamd_msm_new(size_t capacity, rlnamd_msm** out);
 void rlnamd_msm_free(rlnamd_msm* m);
+/* Device self-test: the 9 x 29-bit-limb group law the MSM walks use (csrc/fq29.h) against the 8 x 32-bit one on
+ * `threads` pseudo-random walks of `iters` signed additions each (doublings, cancellations, restarts from infinity
+ * included).  group 1 = G1, 2 = G2 (g2_gen_xy_le = generator x.c0 | x.c1 | y.c0 | y.c1, canonical LE; NULL for G1).
+ * *mismatches = number of walks whose affine results differ (0 expected). */
+int rlnamd_selftest_fq29(int group, uint32_t threads, uint32_t iters, const uint8_t* g2_gen_xy_le, uint32_t* mismatches);
 /* points: n x (x || y) canonical LE affine, all-zero = infinity; scalars: n x 32 bytes canonical LE */
 int rlnamd_msm_set(rlnamd_msm* m, const uint8_t* points_xy_le, const uint8_t* scalars_le, size_t n);
 /* synthetic config-5 workload generated in HBM: P_i = k_i G, scalars s_i, SplitMix64(seed) at index first+i */

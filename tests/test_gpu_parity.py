@@ -417,3 +417,19 @@ def test_partial_proof_then_finish_equals_full(prover):
     w_new = dict(ws[1], x=ws[1]["x"] ^ 1, message_id=2, external_nullifier=7)
     o = prover.finish([w_new], [(5, 6)], [partials[1]])[0]
     assert o["proof"] == prover.prove([w_new], [(5, 6)])[0]["proof"] and prover.verify(o["proof"], o["public_inputs"])
+
+
+def test_fq29_group_law_matches_the_8x32_group_law_on_device():
+    """csrc/fq29.h (9 x 29-bit unsaturated limbs, the form both fixed-base walks and the Pippenger buckets use)
+    against curve.h on 16 384 pseudo-random walks of 96 signed additions each, with repeated points (doubling),
+    point / negation pairs (cancellation) and restarts from infinity: bit-identical affine results, G1 and G2"""
+    import ctypes as C
+    from oracle.pyref.bn254 import G2_GEN
+    from zerokit_amd._native import lib, check
+    bad = C.c_uint32(123)
+    check(lib().rlnamd_selftest_fq29(1, 16384, 96, None, C.byref(bad)))
+    assert bad.value == 0
+    g2 = b"".join(int(v).to_bytes(32, "little") for v in (G2_GEN[0][0], G2_GEN[0][1], G2_GEN[1][0], G2_GEN[1][1]))
+    bad = C.c_uint32(123)
+    check(lib().rlnamd_selftest_fq29(2, 4096, 48, g2, C.byref(bad)))
+    assert bad.value == 0

@@ -328,6 +328,11 @@ int rlnamd_msm_new(size_t capacity, rlnamd_msm** out) {
   RLN_CATCH
 }
 void rlnamd_msm_free(rlnamd_msm* m) { delete m; }
+int rlnamd_selftest_fq29(int group, uint32_t threads, uint32_t iters, const uint8_t* g2_gen_xy_le, uint32_t* mismatches) {
+  RLN_TRY
+  *mismatches = selftest_fq29(group, threads, iters, g2_gen_xy_le);
+  RLN_CATCH
+}
 int rlnamd_msm_set(rlnamd_msm* m, const uint8_t* points_xy_le, const uint8_t* scalars_le, size_t n) {
   RLN_TRY
   m->m->set_host(points_xy_le, scalars_le, n);

@@ -27,4 +27,8 @@ class MsmG1 {
   std::unique_ptr<Impl> d_;
 };
 
+// device self-test of the 9 x 29-bit group law against the 8 x 32-bit one (msm.hip); group 1 = G1, 2 = G2 (pass the
+// G2 generator as x.c0 | x.c1 | y.c0 | y.c1, canonical LE); returns the number of mismatching walks
+uint32_t selftest_fq29(int group, uint32_t threads, uint32_t iters, const uint8_t* g2_gen_xy_le);
+
 }  // namespace rlnamd

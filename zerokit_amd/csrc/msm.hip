@@ -290,6 +290,89 @@ __global__ void k_combine(const G1XYZZ* __restrict__ wsums, uint32_t k, uint32_t
   a.y.to_canonical(out_xy + 8);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Self-test of the 9 x 29-bit group law (fq29.h) against the 8 x 32-bit one (curve.h) on the device: every thread
+// walks the same pseudo-random sequence of signed table points with both accumulators, including a repeated point
+// (doubling), a point followed by its negation (cancellation) and additions onto infinity.  Used by
+// rlnamd_selftest_fq29 (tests/test_gpu_parity.py); `bad` counts threads whose affine results differ.
+template <class Aff, class XY, class Aff29, class Acc29>
+__global__ void __launch_bounds__(64) k_selftest29(const Aff* __restrict__ pts, const Aff29* __restrict__ pts29,
+                                                   uint32_t npts, uint32_t iters, uint32_t* __restrict__ bad) {
+  uint32_t t = blockIdx.x * 64 + threadIdx.x;
+  XY a = XY::inf();
+  Acc29 b = Acc29::inf();
+  uint32_t st = t * 2654435761u + 12345u;
+  for (uint32_t i = 0; i < iters; i++) {
+    st = st * 1664525u + 1013904223u;
+    uint32_t k = (st >> 8) % npts;
+    bool neg = (st >> 7) & 1;
+    if (i % 7 == 3) k = (t + i) % npts;            // then again at i % 7 == 4: same point twice
+    if (i % 7 == 4) { k = (t + i - 1) % npts; neg = (t >> 1) & 1; }
+    if (i % 11 == 5 && (t & 3) == 0) { a = XY::inf(); b = Acc29::inf(); }   // restart from infinity
+    Aff p = pts[k];
+    if (neg) p.y = p.y.neg();
+    a.madd(p);
+    b.madd(pts29[k], neg);
+    if (i % 13 == 7) {                              // a point and its negation back to back: cancels to the previous sum
+      Aff q = pts[(k + 1) % npts];
+      a.madd(q);
+      b.madd(pts29[(k + 1) % npts], false);
+      q.y = q.y.neg();
+      a.madd(q);
+      b.madd(pts29[(k + 1) % npts], true);
+    }
+  }
+  XY c = b.to_xyzz();
+  Aff x = a.to_affine(), y = c.to_affine();
+  if (!(x.x == y.x) || !(x.y == y.y)) atomicAdd(bad, 1u);
+}
+template <class Aff, class Aff29>
+__global__ void k_selftest_conv(const Aff* __restrict__ src, Aff29* __restrict__ dst, uint32_t n) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) dst[t] = to_table29(src[t]);
+}
+template <class F>
+__global__ void k_selftest_points(Affine<F> g, Affine<F>* __restrict__ out, uint32_t n) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  uint32_t k[8] = {t * 2654435761u + 1u, t ^ 0x9e3779b9u, t + 17u, 0, 0, 0, 0, 0};
+  out[t] = scalar_mul(g, k).to_affine();
+}
+
+// returns the number of mismatching threads (0 = the two representations agree); group 1 = G1, 2 = G2
+uint32_t selftest_fq29(int group, uint32_t threads, uint32_t iters, const uint8_t* g2_gen_xy_le) {
+  require_gpu();
+  const uint32_t NP = 1024;
+  DevBuf<uint32_t> bad(1);
+  RLN_HIP(hipMemset(bad.p, 0, 4));
+  threads = (threads + 63) / 64 * 64;
+  if (group == 1) {
+    DevBuf<G1Affine> p(NP);
+    DevBuf<G1Affine29> p29(NP);
+    G1Affine g{Fq::from_u32(1), Fq::from_u32(2)};
+    hipLaunchKernelGGL(k_selftest_points<Fq>, dim3(NP / 64), dim3(64), 0, 0, g, p.p, NP);
+    hipLaunchKernelGGL((k_selftest_conv<G1Affine, G1Affine29>), dim3(NP / 64), dim3(64), 0, 0, p.p, p29.p, NP);
+    hipLaunchKernelGGL((k_selftest29<G1Affine, G1XYZZ, G1Affine29, G1Acc29>), dim3(threads / 64), dim3(64), 0, 0, p.p,
+                       p29.p, NP, iters, bad.p);
+  } else {
+    G2Affine g;
+    uint32_t c[4][8];
+    memcpy(c, g2_gen_xy_le, 128);
+    g.x = {Fq::from_canonical(c[0]), Fq::from_canonical(c[1])};
+    g.y = {Fq::from_canonical(c[2]), Fq::from_canonical(c[3])};
+    DevBuf<G2Affine> p(NP);
+    DevBuf<G2Affine29> p29(NP);
+    hipLaunchKernelGGL(k_selftest_points<Fq2>, dim3(NP / 64), dim3(64), 0, 0, g, p.p, NP);
+    hipLaunchKernelGGL((k_selftest_conv<G2Affine, G2Affine29>), dim3(NP / 64), dim3(64), 0, 0, p.p, p29.p, NP);
+    hipLaunchKernelGGL((k_selftest29<G2Affine, G2XYZZ, G2Affine29, G2Acc29>), dim3(threads / 64), dim3(64), 0, 0, p.p,
+                       p29.p, NP, iters, bad.p);
+  }
+  RLN_HIP(hipGetLastError());
+  uint32_t h = 0;
+  RLN_HIP(hipMemcpy(&h, bad.p, 4, hipMemcpyDeviceToHost));
+  return h;
+}
+
 struct MsmG1::Impl {
   hipStream_t s = nullptr;
   size_t cap = 0, n = 0;
