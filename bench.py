@@ -24,6 +24,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before torch / HIP initialise: see zerokit_amd/csrc/common.cpp
 
 R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 MASK = (1 << 64) - 1

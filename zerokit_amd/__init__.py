@@ -7,6 +7,12 @@ Host-side mirror (Python over ctypes) of the reference's operator interface for 
   zerokit_amd.batch.PoseidonTree<-> utils FullMerkleTree       (utils/src/merkle_tree/full_merkle_tree.rs)
 All compute goes through zerokit_amd/lib/librln.so (HIP kernels for gfx950); nothing here computes.
 """
+import os as _os
+
+# seven HIP streams are kept busy by the prover; ROCclr's default of 4 hardware queues makes streams share a queue and
+# serialise (see csrc/common.cpp).  Read at HIP runtime initialisation, so set before torch / HIP is first used.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from ._native import LIB_PATH, NativeMissing, RLNError, lib  # noqa: F401
 
 __all__ = ["lib", "LIB_PATH", "NativeMissing", "RLNError"]

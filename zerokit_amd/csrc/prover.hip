@@ -752,14 +752,16 @@ struct Slot {
   uint8_t* h_comp = nullptr;    // pinned: every run ends with the proofs + values copied to the host
   uint32_t* h_values = nullptr;
   uint32_t* h_err = nullptr;
-  hipEvent_t evA = nullptr, evB = nullptr, evB2 = nullptr, evR = nullptr, evC = nullptr, evW = nullptr;
-  hipEvent_t t[13] = {};  // timing marks
+  hipEvent_t evA = nullptr, evB = nullptr, evB2 = nullptr, evR = nullptr, evC = nullptr, evW = nullptr, evV = nullptr;
+  hipEvent_t t[14] = {};  // timing marks
   bool used = false;
   size_t n = 0;
 };
 
 struct Prover::Impl {
-  hipStream_t sA = nullptr, sA2 = nullptr, sB = nullptr, sB2 = nullptr, sC = nullptr;
+  hipStream_t sA = nullptr, sAb = nullptr, sA2 = nullptr, sB = nullptr, sB2 = nullptr, sC = nullptr;
+  hipStream_t sV[2] = {nullptr, nullptr};  // proof values (24 chained Poseidon hashes per proof, latency-bound)
+  int wstreams = 2;  // graph interpreters in flight (RLNAMD_WSTREAMS): 16 latency-bound waves each
   uint32_t seq = 0;  // batches enqueued: consecutive front ends alternate between sA and sA2
   bool split_msm = false;  // G2 walk on its own stream: its workgroups fill the G1 kernel's tail (RLNAMD_MSM_SPLIT)
   float ms[PROVER_STAGES] = {0};
@@ -797,18 +799,21 @@ struct Prover::Impl {
   bool have_values_kernel = false;
   // resident inputs (shared by both slots; upload() drains the pipeline first)
   DevBuf<uint32_t> inputs, rs;
-  static constexpr int NSLOT = 4;
+  static constexpr int NSLOT = 6;
   Slot slot[NSLOT];
-  int nslot = 4, nstreamA = 2;  // RLNAMD_SLOTS / RLNAMD_ASTREAMS
+  int nslot = 5, nstreamA = 2;  // RLNAMD_SLOTS / RLNAMD_ASTREAMS
   uint32_t msm_lds = 0;         // RLNAMD_MSM_WAVES (waves per SIMD the G1 walk may occupy; 0 = no cap)
   int cur = 0;
   Slot* last = nullptr;
 
   void sync_all() {
     RLN_HIP(hipStreamSynchronize(sA));
+    RLN_HIP(hipStreamSynchronize(sAb));
+    RLN_HIP(hipStreamSynchronize(sV[0]));
+    RLN_HIP(hipStreamSynchronize(sV[1]));
     RLN_HIP(hipStreamSynchronize(sA2));
     RLN_HIP(hipStreamSynchronize(sB));
-    RLN_HIP(hipStreamSynchronize(sB2));
+    if (sB2) RLN_HIP(hipStreamSynchronize(sB2));
     RLN_HIP(hipStreamSynchronize(sC));
   }
 };
@@ -925,10 +930,12 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     auto pick = [&](int i, int dflt) { return (pe && strlen(pe) == 3) ? (pe[i] == 'h' ? hi : lo) : dflt; };
     RLN_HIP(hipStreamCreateWithPriority(&D.sA, hipStreamNonBlocking, pick(0, hi)));
     RLN_HIP(hipStreamCreateWithPriority(&D.sA2, hipStreamNonBlocking, pick(0, hi)));
+    RLN_HIP(hipStreamCreateWithPriority(&D.sAb, hipStreamNonBlocking, pick(0, hi)));
+    for (auto& v : D.sV) RLN_HIP(hipStreamCreateWithPriority(&v, hipStreamNonBlocking, pick(2, hi)));
+    D.wstreams = env_int("RLNAMD_WSTREAMS", 2);
     RLN_HIP(hipStreamCreateWithPriority(&D.sB, hipStreamNonBlocking, pick(1, lo)));
-    RLN_HIP(hipStreamCreateWithPriority(&D.sB2, hipStreamNonBlocking, pick(1, lo)));
     RLN_HIP(hipStreamCreateWithPriority(&D.sC, hipStreamNonBlocking, pick(2, hi)));
-    D.nslot = std::min(std::max(env_int("RLNAMD_SLOTS", 4), 2), (int)Impl::NSLOT);
+    D.nslot = std::min(std::max(env_int("RLNAMD_SLOTS", 5), 2), (int)Impl::NSLOT);
     {
       int mw = env_int("RLNAMD_MSM_WAVES", 0);
       D.msm_lds = mw > 0 ? (uint32_t)(160 * 1024 / (4 * mw)) & ~255u : 0;
@@ -937,6 +944,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     D.use29 = env_int("RLNAMD_FQ29", 1) != 0;
     D.use29_g2 = env_int("RLNAMD_FQ29_G2", D.use29 ? 1 : 0) != 0;
     D.split_msm = env_int("RLNAMD_MSM_SPLIT", 0) != 0;  // measured +1 % only; off keeps per-kernel timings clean
+    if (D.split_msm) RLN_HIP(hipStreamCreateWithPriority(&D.sB2, hipStreamNonBlocking, pick(1, lo)));
   }
   hipStream_t s = D.sB;
 
@@ -1175,6 +1183,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     RLN_HIP(hipEventCreateWithFlags(&S.evB2, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evR, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evW, hipEventDisableTiming));
+    RLN_HIP(hipEventCreateWithFlags(&S.evV, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evC, hipEventDisableTiming));
     for (auto& e : S.t) RLN_HIP(hipEventCreate(&e));
     RLN_HIP(hipMemsetAsync(S.digits.p, 0, S.digits.bytes(), s));
@@ -1185,19 +1194,19 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
 Prover::~Prover() {
   if (!d_) return;
   Impl& D = *d_;
-  for (hipStream_t st : {D.sA, D.sA2, D.sB, D.sB2, D.sC})
+  for (hipStream_t st : {D.sA, D.sAb, D.sA2, D.sB, D.sB2, D.sC, D.sV[0], D.sV[1]})
     if (st) (void)hipStreamSynchronize(st);
   for (Slot& S : D.slot) {
     if (S.h_pp) (void)hipHostFree(S.h_pp);
     if (S.h_comp) (void)hipHostFree(S.h_comp);
     if (S.h_values) (void)hipHostFree(S.h_values);
     if (S.h_err) (void)hipHostFree(S.h_err);
-    for (hipEvent_t e : {S.evA, S.evB, S.evB2, S.evR, S.evC, S.evW})
+    for (hipEvent_t e : {S.evA, S.evB, S.evB2, S.evR, S.evC, S.evW, S.evV})
       if (e) (void)hipEventDestroy(e);
     for (auto& e : S.t)
       if (e) (void)hipEventDestroy(e);
   }
-  for (hipStream_t st : {D.sA, D.sA2, D.sB, D.sB2, D.sC})
+  for (hipStream_t st : {D.sA, D.sAb, D.sA2, D.sB, D.sB2, D.sC, D.sV[0], D.sV[1]})
     if (st) (void)hipStreamDestroy(st);
 }
 
@@ -1265,8 +1274,9 @@ void Prover::run_async(size_t n, int mode) {
   // Front end in two pipeline stages on their own streams: A1 = graph interpreter (16 latency-bound waves per 1024
   // proofs, ~28 ms), A2 = mat-vec + NTTs + quotient (throughput kernels squeezed in beside the MSM, ~25 ms contended).
   // Chained on one stream they were the critical path (54 ms against 49 ms of MSM).
-  hipStream_t sA = D.sA;
-  hipStream_t sA2 = D.nstreamA > 1 ? D.sA2 : D.sA;
+  const uint32_t sq = D.seq++;
+  hipStream_t sA = (D.nstreamA > 1 && D.wstreams > 1 && (sq & 1)) ? D.sAb : D.sA;
+  hipStream_t sA2 = D.nstreamA > 1 ? D.sA2 : sA;
   const uint32_t B = (uint32_t)B_, nb = (uint32_t)n;
   const uint32_t pg = div_up(nb, 64);
   const uint32_t nbp = pg * 64;  // padded lanes compute on stale / zero inputs; results ignored
@@ -1338,11 +1348,18 @@ void Prover::run_async(size_t n, int mode) {
   if (D.split_msm) RLN_HIP(hipEventRecord(S.evB2, D.sB2));
   // ---------------- stage C
   // proof values (Poseidon chain, latency-bound, depends on the inputs only): the back-end stream has slack
-  if (S.used) RLN_HIP(hipStreamWaitEvent(D.sC, S.evC, 0));
-  RLN_HIP(hipEventRecord(S.t[0], D.sC));
+  hipStream_t sV = D.sV[sq & 1];
+  if (S.used) {
+    RLN_HIP(hipStreamWaitEvent(D.sC, S.evC, 0));
+    RLN_HIP(hipStreamWaitEvent(sV, S.evC, 0));
+  }
+  RLN_HIP(hipEventRecord(S.t[0], sV));
   if (D.have_values_kernel)
-    hipLaunchKernelGGL(k_proof_values, dim3(pg), dim3(64), 0, D.sC, D.inputs.p, D.NI, D.slots, poseidon_view(2),
+    hipLaunchKernelGGL(k_proof_values, dim3(pg), dim3(64), 0, sV, D.inputs.p, D.NI, D.slots, poseidon_view(2),
                        poseidon_view(3), poseidon_view(4), S.values.p, nbp);
+  RLN_HIP(hipEventRecord(S.t[13], sV));
+  RLN_HIP(hipEventRecord(S.evV, sV));
+  RLN_HIP(hipStreamWaitEvent(D.sC, S.evV, 0));
   RLN_HIP(hipStreamWaitEvent(D.sC, S.evB, 0));
   if (D.split_msm) RLN_HIP(hipStreamWaitEvent(D.sC, S.evB2, 0));
   RLN_HIP(hipEventRecord(S.t[9], D.sC));
@@ -1384,7 +1401,7 @@ void Prover::sync() {
   D.sync_all();
   if (D.last) {
     Slot& S = *D.last;
-    const int pairs[PROVER_STAGES][2] = {{1, 2}, {12, 3}, {3, 4}, {5, 6}, {6, 7}, {11, 8}, {9, 10}, {0, 9}};
+    const int pairs[PROVER_STAGES][2] = {{1, 2}, {12, 3}, {3, 4}, {5, 6}, {6, 7}, {11, 8}, {9, 10}, {0, 13}};
     for (int i = 0; i < PROVER_STAGES; i++) RLN_HIP(hipEventElapsedTime(&D.ms[i], S.t[pairs[i][0]], S.t[pairs[i][1]]));
   }
 }
