@@ -23,19 +23,20 @@
 
 namespace rlnamd {
 
-struct Fq29 {
+template <class C, class Mont>
+struct F29 {
   uint32_t v[9];
 
   static constexpr uint32_t M = (1u << 29) - 1;
 
-  static __device__ __forceinline__ Fq29 from_const(const uint32_t (&c)[9]) {
-    Fq29 r;
+  static __device__ __forceinline__ F29 from_const(const uint32_t (&c)[9]) {
+    F29 r;
 #pragma unroll
     for (int j = 0; j < 9; j++) r.v[j] = c[j];
     return r;
   }
-  static __device__ __forceinline__ Fq29 zero() {
-    Fq29 r;
+  static __device__ __forceinline__ F29 zero() {
+    F29 r;
 #pragma unroll
     for (int j = 0; j < 9; j++) r.v[j] = 0;
     return r;
@@ -56,7 +57,7 @@ struct Fq29 {
 
   // REDC(sum of N products): t accumulates columns; one limb is retired per round
   template <int NP>
-  static __device__ __forceinline__ Fq29 redc_dot(const Fq29* const (&a)[NP], const Fq29* const (&b)[NP]) {
+  static __device__ __forceinline__ F29 redc_dot(const F29* const (&a)[NP], const F29* const (&b)[NP]) {
     uint64_t t[10];
 #pragma unroll
     for (int j = 0; j < 10; j++) t[j] = 0;
@@ -67,16 +68,16 @@ struct Fq29 {
 #pragma unroll
         for (int j = 0; j < 9; j++) t[j] += (uint64_t)a[k]->v[j] * b[k]->v[i];
       }
-      uint32_t m = ((uint32_t)t[0] * Fq29C::INV) & M;
+      uint32_t m = ((uint32_t)t[0] * C::INV) & M;
 #pragma unroll
-      for (int j = 0; j < 9; j++) t[j] += (uint64_t)m * Fq29C::P[j];
+      for (int j = 0; j < 9; j++) t[j] += (uint64_t)m * C::P[j];
       uint64_t carry = t[0] >> 29;
 #pragma unroll
       for (int j = 0; j < 9; j++) t[j] = t[j + 1];
       t[0] += carry;
       t[9] = 0;
     }
-    Fq29 r;
+    F29 r;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       r.v[j] = (uint32_t)t[j] & M;
@@ -85,35 +86,41 @@ struct Fq29 {
     r.v[8] = (uint32_t)t[8];
     return r;
   }
-  static __device__ __forceinline__ Fq29 mul(const Fq29& a, const Fq29& b) {
-    const Fq29* const aa[1] = {&a};
-    const Fq29* const bb[1] = {&b};
+  static __device__ __forceinline__ F29 mul(const F29& a, const F29& b) {
+    const F29* const aa[1] = {&a};
+    const F29* const bb[1] = {&b};
     return redc_dot<1>(aa, bb);
   }
   // a0 b0 + a1 b1 with one reduction
-  static __device__ __forceinline__ Fq29 dot2(const Fq29& a0, const Fq29& b0, const Fq29& a1, const Fq29& b1) {
-    const Fq29* const aa[2] = {&a0, &a1};
-    const Fq29* const bb[2] = {&b0, &b1};
+  static __device__ __forceinline__ F29 dot2(const F29& a0, const F29& b0, const F29& a1, const F29& b1) {
+    const F29* const aa[2] = {&a0, &a1};
+    const F29* const bb[2] = {&b0, &b1};
     return redc_dot<2>(aa, bb);
+  }
+  static __device__ __forceinline__ F29 dot3(const F29& a0, const F29& b0, const F29& a1, const F29& b1, const F29& a2,
+                                             const F29& b2) {  // at most two lazy operands (see dot4)
+    const F29* const aa[3] = {&a0, &a1, &a2};
+    const F29* const bb[3] = {&b0, &b1, &b2};
+    return redc_dot<3>(aa, bb);
   }
   // sum of four products with one reduction; at most two of the eight operands may be lazy (limbs < 2^30):
   // 9 (2 2^59 + 2 2^58 + 2^58) = 15.75 2^60 < 2^64
-  static __device__ __forceinline__ Fq29 dot4(const Fq29& a0, const Fq29& b0, const Fq29& a1, const Fq29& b1,
-                                              const Fq29& a2, const Fq29& b2, const Fq29& a3, const Fq29& b3) {
-    const Fq29* const aa[4] = {&a0, &a1, &a2, &a3};
-    const Fq29* const bb[4] = {&b0, &b1, &b2, &b3};
+  static __device__ __forceinline__ F29 dot4(const F29& a0, const F29& b0, const F29& a1, const F29& b1,
+                                              const F29& a2, const F29& b2, const F29& a3, const F29& b3) {
+    const F29* const aa[4] = {&a0, &a1, &a2, &a3};
+    const F29* const bb[4] = {&b0, &b1, &b2, &b3};
     return redc_dot<4>(aa, bb);
   }
   // K - b limb by limb: no borrows because every limb of the biased constant K dominates a normalised limb
-  static __device__ __forceinline__ Fq29 neg_lazy(const uint32_t (&K)[9], const Fq29& b) {
-    Fq29 r;
+  static __device__ __forceinline__ F29 neg_lazy(const uint32_t (&K)[9], const F29& b) {
+    F29 r;
 #pragma unroll
     for (int j = 0; j < 9; j++) r.v[j] = K[j] - b.v[j];
     return r;
   }
   // a + K - b, normalised
-  static __device__ __forceinline__ Fq29 sub(const Fq29& a, const uint32_t (&K)[9], const Fq29& b) {
-    Fq29 r;
+  static __device__ __forceinline__ F29 sub(const F29& a, const uint32_t (&K)[9], const F29& b) {
+    F29 r;
 #pragma unroll
     for (int j = 0; j < 9; j++) r.v[j] = a.v[j] + K[j] - b.v[j];
     r.normalize();
@@ -124,35 +131,35 @@ struct Fq29 {
   __device__ __forceinline__ bool is_zero_mod_q() const {
     bool hit = false;
 #pragma unroll
-    for (int k = 0; k < 8; k++) hit |= v[0] == Fq29C::KP[k][0];
+    for (int k = 0; k < 8; k++) hit |= v[0] == C::KP[k][0];
     if (!hit) return false;  // the low limb filters all but 8 / 2^29 of the values
     for (int k = 0; k < 8; k++) {
       bool eq = true;
-      for (int j = 0; j < 9; j++) eq &= v[j] == Fq29C::KP[k][j];
+      for (int j = 0; j < 9; j++) eq &= v[j] == C::KP[k][j];
       if (eq) return true;
     }
     return false;
   }
 
   // ---- conversions to / from the 8 x 32 Montgomery form of field.h (same residue, radix 2^256)
-  static __device__ __forceinline__ Fq29 from_fq(const Fq& a) {
-    Fq29 u;  // the integer a.v (= x 2^256 mod q, canonical) cut into 29-bit limbs
+  static __device__ __forceinline__ F29 from_fq(const Mont& a) {
+    F29 u;  // the integer a.v (= x 2^256 mod q, canonical) cut into 29-bit limbs
 #pragma unroll
     for (int j = 0; j < 9; j++) {
       const int bit = 29 * j, w = bit >> 5, s = bit & 31;
       uint64_t lo = a.v[w], hi = w + 1 < 8 ? a.v[w + 1] : 0;
       u.v[j] = (uint32_t)(((lo | (hi << 32)) >> s) & M);
     }
-    return mul(u, from_const(Fq29C::FROM_FQ));  // x 2^256 2^266 / 2^261 = x 2^261
+    return mul(u, from_const(C::FROM_FQ));  // x 2^256 2^266 / 2^261 = x 2^261
   }
-  __device__ __forceinline__ Fq to_fq() const {
-    Fq29 t = mul(*this, from_const(Fq29C::TO_FQ));  // x 2^256 + (0 or 1) q, limbs normalised
+  __device__ __forceinline__ Mont to_fq() const {
+    F29 t = mul(*this, from_const(C::TO_FQ));  // x 2^256 + (0 or 1) q, limbs normalised
     // exact reduction into [0, q): subtract q when t >= q
     uint32_t d[9];
     int64_t borrow = 0;
 #pragma unroll
     for (int j = 0; j < 9; j++) {
-      int64_t x = (int64_t)t.v[j] - (int64_t)Fq29C::P[j] + borrow;
+      int64_t x = (int64_t)t.v[j] - (int64_t)C::P[j] + borrow;
       d[j] = (uint32_t)x & (j < 8 ? M : 0xFFFFFFFFu);
       borrow = x >> (j < 8 ? 29 : 63);
     }
@@ -160,7 +167,7 @@ struct Fq29 {
     uint32_t r[9];
 #pragma unroll
     for (int j = 0; j < 9; j++) r[j] = ge ? d[j] : t.v[j];
-    Fq o;
+    Mont o;
 #pragma unroll
     for (int w = 0; w < 8; w++) {
       // bits [32 w, 32 w + 32) of sum r[j] 2^(29 j)
@@ -173,6 +180,9 @@ struct Fq29 {
     return o;
   }
 };
+
+using Fq29 = F29<Fq29C, Fq>;
+using Fr29 = F29<Fr29C, Fr>;  // same limb form for the scalar field (Poseidon): r / 2^261 = q / 2^261 to 4 digits
 
 // Table entry: the two coordinates as 256-bit integers (the Montgomery-2^261 residues, fully reduced), 64 bytes so an
 // entry never straddles a cache line; never the point at infinity (dropped when the table is built).

@@ -86,6 +86,15 @@ PoseidonParams poseidon_derive_params(int t) {
   return P;
 }
 
+__global__ void k_fr_to29(const Fr* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  Fr29 v = Fr29::from_fq(src[t]);
+  v.normalize();
+#pragma unroll
+  for (int k = 0; k < 9; k++) dst[t * 9 + k] = v.v[k];
+}
+
 void PoseidonDev::init() {
   if (ready) return;
   require_gpu();
@@ -97,6 +106,11 @@ void PoseidonDev::init() {
     mds[t].alloc(P.mds.size());
     RLN_HIP(hipMemcpy(ark[t].p, P.ark.data(), P.ark.size() * sizeof(Fr), hipMemcpyHostToDevice));
     RLN_HIP(hipMemcpy(mds[t].p, P.mds.data(), P.mds.size() * sizeof(Fr), hipMemcpyHostToDevice));
+    ark29[t].alloc(P.ark.size() * 9);
+    mds29[t].alloc(P.mds.size() * 9);
+    hipLaunchKernelGGL(k_fr_to29, dim3(div_up(P.ark.size(), 64)), dim3(64), 0, 0, ark[t].p, ark29[t].p, (uint32_t)P.ark.size());
+    hipLaunchKernelGGL(k_fr_to29, dim3(div_up(P.mds.size(), 64)), dim3(64), 0, 0, mds[t].p, mds29[t].p, (uint32_t)P.mds.size());
+    RLN_HIP(hipDeviceSynchronize());
   }
   ready = true;
 }
@@ -110,7 +124,7 @@ PoseidonDev& poseidon_dev() {
 PoseidonView poseidon_view(int t) {
   if (t < 2 || t > POSEIDON_MAX_T) throw Error("unsupported Poseidon width t=" + std::to_string(t));
   PoseidonDev& d = poseidon_dev();
-  return {d.ark[t].p, d.mds[t].p, d.rf[t], d.rp[t]};
+  return {d.ark[t].p, d.mds[t].p, d.rf[t], d.rp[t], d.ark29[t].p, d.mds29[t].p};
 }
 
 template <int T>
