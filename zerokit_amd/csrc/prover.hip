@@ -174,12 +174,36 @@ __device__ __noinline__ Fr witness_slow_op(uint32_t op, Fr fa, Fr fb, uint32_t* 
 // =====================================================================================================
 // 1. witness: one lane per proof interprets the straight-line graph (graph.rs:246-272)
 // =====================================================================================================
+// Operand encoding of the device program (built once on the host, Prover::Prover): the top two bits of a / b / c say
+// where the value lives -- RING: produced at most 63 nodes earlier, read from the LDS ring; CONST: index into the
+// constant table, a wave-uniform scalar load; FAR: anything else, read from the value array in HBM.  In the shipped
+// circuits every operand is a constant (23 %), the previous node (33 %, forwarded in registers) or within the last 16
+// nodes; only the 124 reads of input nodes go to HBM.  The ring is 64 slots x 64 lanes x 32 B = 128 KiB of LDS -- one
+// wave per CU is all this kernel ever has (16 waves per 1024 proofs).
+constexpr uint32_t OPK_RING = 0u << 30, OPK_CONST = 1u << 30, OPK_FAR = 2u << 30, OPK_MASK = 3u << 30;
+constexpr uint32_t WIT_RING = 64;
+__device__ __forceinline__ Fr ring_load(const uint32_t* ring, uint32_t node, uint32_t lane) {
+  Fr r;
+  const uint32_t* s = ring + (node % WIT_RING) * 8 * 64 + lane;
+#pragma unroll
+  for (int k = 0; k < 8; k++) r.v[k] = s[k * 64];
+  return r;
+}
+__device__ __forceinline__ Fr operand_load(uint32_t enc, const uint32_t* ring, const Fr* __restrict__ consts,
+                                           const Fr* __restrict__ V, uint32_t B, uint32_t p, uint32_t lane) {
+  uint32_t kind = enc & OPK_MASK, id = enc & ~OPK_MASK;
+  if (kind == OPK_RING) return ring_load(ring, id, lane);
+  if (kind == OPK_CONST) return consts[id];
+  return V[(size_t)id * B + p];
+}
 __global__ void __launch_bounds__(64) k_witness(const GNode* __restrict__ nodes, uint32_t n_nodes,
                                                 const Fr* __restrict__ consts, const uint32_t* __restrict__ inputs,
                                                 uint32_t n_inputs, Fr* __restrict__ V, uint32_t* __restrict__ err,
                                                 uint32_t B, uint32_t nb) {
+  extern __shared__ uint32_t ring[];
   __builtin_amdgcn_s_setprio(3);  // few, latency-bound waves: issue ahead of the MSM waves sharing the SIMD
-  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  const uint32_t lane = threadIdx.x;
+  uint32_t p = blockIdx.x * 64 + lane;
   if (p >= nb) return;
   uint32_t e = WERR_NONE;
   Fr last = Fr::zero();
@@ -195,13 +219,13 @@ __global__ void __launch_bounds__(64) k_witness(const GNode* __restrict__ nodes,
       v = consts[nd.a];
     } else {
       // operand forwarding: chains (x^5 s-boxes, MDS sums) read the value produced one node earlier
-      Fr va = (nd.a + 1 == n) ? last : V[(size_t)nd.a * B + p];
+      Fr va = (nd.a == (OPK_RING | (n - 1))) ? last : operand_load(nd.a, ring, consts, V, B, p, lane);
       if (nd.op == G_NEG) {
         v = va.neg();
       } else if (nd.op == G_ID) {
         v = witness_slow_op(G_ID, va, va, &e);
       } else {
-        Fr vb = (nd.b + 1 == n) ? last : V[(size_t)nd.b * B + p];
+        Fr vb = (nd.b == (OPK_RING | (n - 1))) ? last : operand_load(nd.b, ring, consts, V, B, p, lane);
         if (nd.op == G_MUL)
           v = va * vb;
         else if (nd.op == G_ADD)
@@ -209,7 +233,7 @@ __global__ void __launch_bounds__(64) k_witness(const GNode* __restrict__ nodes,
         else if (nd.op == G_SUB)
           v = va - vb;
         else if (nd.op == G_TERN) {
-          Fr vc = V[(size_t)nd.c * B + p];
+          Fr vc = operand_load(nd.c, ring, consts, V, B, p, lane);
           v = va.is_zero() ? vc : vb;  // graph.rs:214-224
         } else {
           uint32_t e2 = 0;
@@ -219,6 +243,9 @@ __global__ void __launch_bounds__(64) k_witness(const GNode* __restrict__ nodes,
       }
     }
     V[(size_t)n * B + p] = v;
+    uint32_t* slot = ring + (n % WIT_RING) * 8 * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 8; k++) slot[k * 64] = v.v[k];
     last = v;
   }
   err[p] = e;
@@ -950,7 +977,26 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
 
   // ---- graph program
   D.nodes.alloc(D.N);
-  D.nodes.upload(graph_.nodes.data(), D.N, s);
+  {
+    // device program: operands tagged with where the interpreter finds them (k_witness)
+    std::vector<GNode> prog(graph_.nodes);
+    auto enc = [&](uint32_t n, uint32_t o) -> uint32_t {
+      if (o >= n) throw Error("Graph error: node operand refers forward");
+      if (graph_.nodes[o].op == G_CONST) return OPK_CONST | graph_.nodes[o].a;
+      if (n - o < WIT_RING) return OPK_RING | o;
+      return OPK_FAR | o;
+    };
+    for (uint32_t n = 0; n < D.N; n++) {
+      GNode& g = prog[n];
+      if (g.op == G_INPUT || g.op == G_CONST) continue;
+      g.a = enc(n, g.a);
+      if (g.op != G_NEG && g.op != G_ID) g.b = enc(n, g.b);
+      if (g.op == G_TERN) g.c = enc(n, g.c);
+    }
+    D.nodes.upload(prog.data(), D.N, s);
+    RLN_HIP(hipStreamSynchronize(s));
+  }
+  RLN_HIP(hipFuncSetAttribute((const void*)k_witness, hipFuncAttributeMaxDynamicSharedMemorySize, WIT_RING * 8 * 64 * 4));
   D.consts.alloc(std::max<size_t>(graph_.constants.size(), 1));
   if (!graph_.constants.empty()) D.consts.upload(graph_.constants.data(), graph_.constants.size(), s);
   D.sig2node.alloc(D.NS);
@@ -1283,7 +1329,7 @@ void Prover::run_async(size_t n, int mode) {
   // ---------------- stage A
   if (S.used) RLN_HIP(hipStreamWaitEvent(sA, S.evC, 0));  // slot free again
   RLN_HIP(hipEventRecord(S.t[1], sA));
-  hipLaunchKernelGGL(k_witness, dim3(pg), dim3(64), 0, sA, D.nodes.p, D.N, D.consts.p, D.inputs.p, D.NI, S.V.p,
+  hipLaunchKernelGGL(k_witness, dim3(pg), dim3(64), WIT_RING * 8 * 64 * 4, sA, D.nodes.p, D.N, D.consts.p, D.inputs.p, D.NI, S.V.p,
                      S.err.p, B, nbp);
   if (D.wgiven_n) {
     if (D.wgiven_n != n || mode != PROVE_FULL) throw Error("upload_witness: the next run must be a full proof of the same batch");
