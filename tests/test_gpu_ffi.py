@@ -339,3 +339,34 @@ def test_seeded_keygen_ffi():
     assert extended_seeded_keygen(b"seed") == extended_seeded_keygen(b"seed") != extended_seeded_keygen(b"seed2")
     t, n, s, c = extended_keygen()
     assert s == hashers.poseidon_hash_pair(t, n) and c == hashers.poseidon_hash([s])
+
+
+def test_concurrent_proving_on_one_object():
+    """generate_rln_proof takes &self in the reference (public.rs:624) and may be called from several threads: four
+    threads share one RLN object; every proof must verify and carry its own x"""
+    import threading
+    from zerokit_amd import hashers
+    from zerokit_amd.public import RLN, RLNWitnessInput
+    rln = RLN(20)
+    secret = 271828
+    rln.set_leaf(9, hashers.poseidon_hash_pair(hashers.poseidon_hash([secret]), 50))
+    elems, bits = rln.get_merkle_proof(9)
+    results, errors = {}, []
+
+    def work(tid):
+        try:
+            for k in range(3):
+                x = 1000 * tid + k + 1
+                p = rln.generate_rln_proof(RLNWitnessInput(secret, 50, (tid * 3 + k) % 50, elems, bits, x, 4242))
+                results[(tid, k)] = (x, p)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors and len(results) == 12
+    for x, p in results.values():
+        assert p.values.x == x and rln.verify_rln_proof(p, x)

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <fstream>
 #include <memory>
+#include <mutex>
 #include <random>
 #include <string>
 #include <vector>
@@ -364,6 +365,9 @@ struct FFI_RLNPartialProof {  // PartialProof (partial_proof.rs:31-43): mask + f
 };
 
 struct FFI_RLN {
+  // generate / verify take &self in the reference and may be called from several threads (SURVEY section 8b,
+  // "Threading"); the prover owns one set of device workspaces, so proving calls on one object take turns
+  std::mutex prove_mu;
   std::unique_ptr<Prover> prover;
   MerkleTreeDev tree;
   bool stateless = false;  // V3 only (RLNV3<Stateless, _>): no tree, tree calls return an error
@@ -564,6 +568,7 @@ void values_from_public(const uint8_t* pub, size_t mo, FFI_RLNProofValues* v) {
 
 // generate_rln_proof for a slice of witnesses (public.rs:624-631)
 void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CFr* rs, FFI_RLNProof** out) {
+  std::lock_guard<std::mutex> guard(rln.prove_mu);
   Prover& P = *rln.prover;
   const size_t ni = P.inputs_per_proof();
   for (size_t i = 0; i < n; i++) check_against_graph(P, *ws[i]);
@@ -606,6 +611,7 @@ void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CF
 // the proof values come from the witness input (single: the values kernel over the inputs; multi: the public
 // signals, identical for any witness that satisfies the circuit).
 FFI_RLNProof* prove_with_witness(FFI_RLN& rln, const Vec_String_t* calc, const FFI_RLNWitnessInput& w) {
+  std::lock_guard<std::mutex> guard(rln.prove_mu);
   Prover& P = *rln.prover;
   std::vector<uint8_t> given;
   given.reserve((calc ? calc->len : 0) * 32);
@@ -643,6 +649,7 @@ bool g2_in_subgroup(const G2Affine& p) {  // [r]P == 0 (ark-serialize Validate::
 
 // generate_partial_zk_proof (proof.rs:783-803)
 FFI_RLNPartialProof* prove_partial(FFI_RLN& rln, const FFI_RLNPartialWitnessInput& pw) {
+  std::lock_guard<std::mutex> guard(rln.prove_mu);
   Prover& P = *rln.prover;
   size_t d = P.graph().tree_depth;
   if (pw.path_elements.size() != d)
@@ -670,6 +677,7 @@ FFI_RLNPartialProof* prove_partial(FFI_RLN& rln, const FFI_RLNPartialWitnessInpu
 // finish_zk_proof_with_rs (proof.rs:821-849) + proof values
 FFI_RLNProof* finish_proof(FFI_RLN& rln, const FFI_RLNPartialProof& pp, const FFI_RLNWitnessInput& w, const CFr& r,
                            const CFr& s) {
+  std::lock_guard<std::mutex> guard(rln.prove_mu);
   Prover& P = *rln.prover;
   check_against_graph(P, w);
   const std::vector<uint8_t>& known = P.known_mask();
