@@ -3,10 +3,11 @@
 // Replaces ark-ec 0.5.0 `VariableBaseMSM::msm_bigint` (third party; call sites
 // /root/reference/rln/src/partial_proof.rs:98-104,255-256) for the case the fixed-base tables of prover.hip
 // do not cover: bases that are not known in advance.  Classic Pippenger, laid out for a GPU:
-//   1. k_digits      signed 16-bit digits of every scalar (16 windows), histogram of bucket sizes (atomics)
-//   2. k_scan        exclusive prefix sum of the 16 x 2^15 bucket counts
-//   3. k_scatter     counting sort: point indices grouped by (window, bucket)
-//   4. k_bucket_acc  one lane per bucket: mixed additions of its points           <- the ALU-heavy kernel
+//   1. k_digits      signed 16-bit digits of every scalar (16 windows), packed uint16
+//   2. k_hist / k_tile_prefix / k_scan_*   per-(window, tile) bucket counts in LDS, prefix sums -> bucket offsets
+//   3. k_part1 / k_part2   two-level counting sort: point indices grouped by (window, bucket)
+//   4. k_slice_acc / k_slice_fix   equal slices of the sorted list, one per lane: mixed additions in the 9 x 29-bit
+//                    limb form (fq29.h), pieces of a bucket joined afterwards     <- the multiplier-bound kernel
 //   5. k_bucket_red  per (window, 32-bucket chunk): running-sum trick -> sum and weighted sum
 //      k_chunk_fix   weighted sum + chunk_base * sum
 //      k_sum_ranges  two-level tree over the chunks -> one point per window
@@ -14,6 +15,7 @@
 // Multi-GPU: every rank runs 1-5 on its slice of the points; the 16 window sums (2 KB) are
 // exchanged with one all-gather and step 6 runs on every rank.  RCCL has no elliptic-curve reduce op, so the
 // "all-reduce of bucket partials" is realised as gather + local add.
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -148,13 +150,68 @@ __global__ void __launch_bounds__(1024) k_scatter(const uint16_t* __restrict__ d
   }
 }
 
-// exclusive scan of `m` counters by one 1024-lane block (m = 524 288: 512 per lane)
-__global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ count, uint32_t m, uint32_t* __restrict__ offs) {
+// Two-level placement (used when n <= 2^24, so that index + 6 bucket bits + sign fit one word).  Scattering straight
+// into 32 768 buckets per window leaves ~1 GiB of partly written cache lines in flight (7.0 ms for 1 GiB of output);
+// here a workgroup first appends its points to 512 coarse partitions of 64 buckets -- 512 open lines per workgroup,
+// each filled front to back -- and a second pass places every partition (~128 KiB) into its buckets through LDS.
+constexpr uint32_t MSM_PARTS = 512, MSM_PART_NB = MSM_NB / MSM_PARTS;  // 64 buckets per partition
+constexpr uint32_t MSM_PART_CAP = 32768;                               // entries of a partition that fit LDS (128 KiB)
+__global__ void __launch_bounds__(1024) k_part1(const uint16_t* __restrict__ dig, uint32_t n, uint32_t tile_len,
+                                                const uint32_t* __restrict__ offs, const uint32_t* __restrict__ hist,
+                                                uint32_t* __restrict__ tmp) {
+  __shared__ uint32_t cur[MSM_PARTS];
+  const uint32_t t = blockIdx.x, w = blockIdx.y;
+  if (threadIdx.x < MSM_PARTS) {
+    const uint32_t P = threadIdx.x;
+    const uint32_t* h = hist + ((size_t)w * MSM_TILES + t) * MSM_NB + P * MSM_PART_NB;  // counts of the earlier tiles
+    uint32_t sum = 0;
+    for (uint32_t b = 0; b < MSM_PART_NB; b++) sum += h[b];
+    cur[P] = offs[w * MSM_NB + P * MSM_PART_NB] + sum;
+  }
+  __syncthreads();
+  uint32_t lo = t * tile_len, hi = lo + tile_len < n ? lo + tile_len : n;
+  const uint16_t* d = dig + (size_t)w * n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+    uint32_t v = d[i];
+    if (v == DIG_ZERO) continue;
+    uint32_t b = v & 0x7FFFu;
+    uint32_t pos = atomicAdd(&cur[b / MSM_PART_NB], 1u);
+    tmp[pos] = i | ((b % MSM_PART_NB) << 24) | ((v >> 15) << 31);
+  }
+}
+// A partition that fits LDS is placed there (positions relative to the partition start) and streamed out coalesced;
+// larger ones (the top window of 254-bit scalars: 4x the average) are placed directly in global memory.
+__global__ void __launch_bounds__(1024) k_part2(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ offs,
+                                                uint32_t* __restrict__ sorted) {
+  extern __shared__ uint32_t lds[];  // [MSM_PART_CAP] staged output
+  __shared__ uint32_t cur[MSM_PART_NB];
+  const uint32_t P = blockIdx.x, w = blockIdx.y;
+  const uint32_t k0 = w * MSM_NB + P * MSM_PART_NB;
+  const uint32_t lo = offs[k0], hi = offs[k0 + MSM_PART_NB], len = hi - lo;
+  const bool staged = len <= MSM_PART_CAP;
+  if (threadIdx.x < MSM_PART_NB) cur[threadIdx.x] = offs[k0 + threadIdx.x] - (staged ? lo : 0);
+  __syncthreads();
+  for (uint32_t e = lo + threadIdx.x; e < hi; e += 1024) {
+    uint32_t x = tmp[e];
+    uint32_t pos = atomicAdd(&cur[(x >> 24) & (MSM_PART_NB - 1)], 1u);
+    uint32_t val = x & 0x80FFFFFFu;
+    if (staged) lds[pos] = val; else sorted[pos] = val;
+  }
+  if (!staged) return;
+  __syncthreads();
+  for (uint32_t e = threadIdx.x; e < len; e += 1024) sorted[lo + e] = lds[e];
+}
+
+// exclusive scan of the 16 x 2^15 bucket counts in two steps: one workgroup per window scans its 32 768 counters
+// (32 per lane) and records the window total; a second launch adds the totals of the earlier windows.
+// (One 1024-lane workgroup over all 524 288 counters took 0.75 ms.)
+__global__ void __launch_bounds__(1024) k_scan_window(const uint32_t* __restrict__ count, uint32_t* __restrict__ offs,
+                                                      uint32_t* __restrict__ wtotal) {
   __shared__ uint32_t part[1024];
-  uint32_t t = threadIdx.x, per = (m + 1023) / 1024;
-  uint32_t lo = t * per, hi = lo + per < m ? lo + per : m;
+  const uint32_t t = threadIdx.x, w = blockIdx.x, per = MSM_NB / 1024;
+  const uint32_t* c = count + (size_t)w * MSM_NB + t * per;
   uint32_t s = 0;
-  for (uint32_t i = lo; i < hi; i++) s += count[i];
+  for (uint32_t i = 0; i < per; i++) s += c[i];
   part[t] = s;
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -164,11 +221,19 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ coun
     __syncthreads();
   }
   uint32_t run = t ? part[t - 1] : 0;
-  for (uint32_t i = lo; i < hi; i++) {
-    offs[i] = run;
-    run += count[i];
+  uint32_t* o = offs + (size_t)w * MSM_NB + t * per;
+  for (uint32_t i = 0; i < per; i++) {
+    o[i] = run;
+    run += c[i];
   }
-  if (t == 1023) offs[m] = part[1023];
+  if (t == 1023) wtotal[w] = part[1023];
+}
+__global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ offs, const uint32_t* __restrict__ wtotal) {
+  uint32_t key = blockIdx.x * 256 + threadIdx.x;
+  if (key > MSM_W * MSM_NB) return;
+  uint32_t w = key / MSM_NB, base = 0;
+  for (uint32_t k = 0; k < w && k < MSM_W; k++) base += wtotal[k];
+  if (key == MSM_W * MSM_NB) offs[key] = base; else offs[key] += base;
 }
 
 // Bucket accumulation over equal SLICES of the sorted list instead of one lane per bucket: bucket sizes are
@@ -373,12 +438,17 @@ uint32_t selftest_fq29(int group, uint32_t threads, uint32_t iters, const uint8_
   return h;
 }
 
+static bool env_two_level() {
+  static const bool on = !(getenv("RLNAMD_MSM_SORT2") && getenv("RLNAMD_MSM_SORT2")[0] == '0');
+  return on;
+}
+
 struct MsmG1::Impl {
   hipStream_t s = nullptr;
   size_t cap = 0, n = 0;
   DevBuf<G1Affine> pts;
   DevBuf<G1Affine29> pts29;
-  DevBuf<uint32_t> scal, count, offs, sorted;
+  DevBuf<uint32_t> scal, count, offs, sorted, tmp, wtotal;
   DevBuf<uint16_t> dig;
   DevBuf<uint32_t> hist;
   DevBuf<G1XYZZ> buckets, chunkS, chunkT, grp, wsum, head, tail;
@@ -394,6 +464,7 @@ MsmG1::MsmG1(size_t capacity) : d_(new Impl) {
   RLN_HIP(hipStreamCreateWithFlags(&D.s, hipStreamNonBlocking));
   for (auto& e : D.e) RLN_HIP(hipEventCreate(&e));
   RLN_HIP(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, MSM_NB * 4));
+  RLN_HIP(hipFuncSetAttribute((const void*)k_part2, hipFuncAttributeMaxDynamicSharedMemorySize, MSM_PART_CAP * 4));
   RLN_HIP(hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, MSM_NB * 4));
   const uint32_t nkeys = MSM_W * MSM_NB, nch = MSM_W * MSM_NCH;
   D.pts.alloc(capacity);
@@ -401,7 +472,9 @@ MsmG1::MsmG1(size_t capacity) : d_(new Impl) {
   D.scal.alloc(capacity * 8);
   D.dig.alloc(capacity * MSM_W);
   D.sorted.alloc(capacity * MSM_W);
+  if (capacity <= (1u << 24)) D.tmp.alloc(capacity * MSM_W);
   D.count.alloc(nkeys);
+  D.wtotal.alloc(MSM_W);
   D.offs.alloc(nkeys + 1);
   D.hist.alloc((size_t)nkeys * MSM_TILES);
   D.buckets.alloc(nkeys);
@@ -503,9 +576,15 @@ void MsmG1::run_windows(uint8_t* window_sums_out, float ms[3]) {
   if (n) hipLaunchKernelGGL(k_digits, dim3(div_up(n, 256)), dim3(256), 0, s, D.scal.p, n, D.dig.p);
   hipLaunchKernelGGL(k_hist, dim3(MSM_TILES, MSM_W), dim3(1024), lds, s, D.dig.p, n, tile_len, D.hist.p);
   hipLaunchKernelGGL(k_tile_prefix, dim3(div_up(nkeys, 256)), dim3(256), 0, s, D.hist.p, D.count.p);
-  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, D.count.p, nkeys, D.offs.p);
-  hipLaunchKernelGGL(k_scatter, dim3(MSM_TILES, MSM_W), dim3(1024), lds, s, D.dig.p, n, tile_len, D.offs.p, D.hist.p,
-                     D.sorted.p);
+  hipLaunchKernelGGL(k_scan_window, dim3(MSM_W), dim3(1024), 0, s, D.count.p, D.offs.p, D.wtotal.p);
+  hipLaunchKernelGGL(k_scan_add, dim3(div_up(nkeys + 1, 256)), dim3(256), 0, s, D.offs.p, D.wtotal.p);
+  if (D.tmp.p && env_two_level()) {
+    hipLaunchKernelGGL(k_part1, dim3(MSM_TILES, MSM_W), dim3(1024), 0, s, D.dig.p, n, tile_len, D.offs.p, D.hist.p, D.tmp.p);
+    hipLaunchKernelGGL(k_part2, dim3(MSM_PARTS, MSM_W), dim3(1024), MSM_PART_CAP * 4, s, D.tmp.p, D.offs.p, D.sorted.p);
+  } else {
+    hipLaunchKernelGGL(k_scatter, dim3(MSM_TILES, MSM_W), dim3(1024), lds, s, D.dig.p, n, tile_len, D.offs.p, D.hist.p,
+                       D.sorted.p);
+  }
   RLN_HIP(hipEventRecord(D.e[1], s));
   const uint32_t nslices = div_up((size_t)n * MSM_W, MSM_SLICE);
   if (nslices)
