@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ offs, c
 // a bucket that began in an earlier slice to head[s], the part of one that continues into the next slice to tail[s];
 // k_slice_fix then forms bucket = tail[s0] + head[s0+1] + ... + head[s1].  The next index is loaded during an addition
 // (prefetching the point as well costs 16 VGPRs and the fourth wave per SIMD: slower).
-constexpr uint32_t MSM_SLICE = 256;
+constexpr uint32_t MSM_SLICE = 128;
 // the bases in the packed 9 x 29-bit-limb form the accumulator works in (fq29.h): one pass per MSM, 0.3 ms at 2^24
 __global__ void __launch_bounds__(256) k_pts_to29(const G1Affine* __restrict__ src, G1Affine29* __restrict__ dst, uint32_t n) {
   uint32_t t = blockIdx.x * 256 + threadIdx.x;
