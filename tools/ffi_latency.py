@@ -1,3 +1,5 @@
+"""Latency of the zerokit FFI calls a nwaku-style caller makes one at a time (needs the GPU): single proof, verify,
+small batches, one leaf update.  Run: python tools/ffi_latency.py"""
 import time, sys
 sys.path.insert(0,'/root/repo')
 from zerokit_amd.public import RLN, RLNWitnessInput
