@@ -17,9 +17,9 @@ constexpr uint32_t M29 = (1u << 29) - 1;
 struct P29 { uint32_t p[9]; uint32_t inv; };   // modulus limbs, -p^-1 mod 2^29
 __constant__ P29 c_p29;
 
-struct F29 {
+struct L29 {
   uint32_t v[9];
-  static __device__ __forceinline__ F29 mul(const F29& a, const F29& b) {
+  static __device__ __forceinline__ L29 mul(const L29& a, const L29& b) {
     uint32_t p[9];
 #pragma unroll
     for (int j = 0; j < 9; j++) p[j] = __builtin_amdgcn_readfirstlane(c_p29.p[j]);
@@ -40,7 +40,7 @@ struct F29 {
       t[0] += carry;
       t[9] = 0;
     }
-    F29 r;
+    L29 r;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       r.v[j] = (uint32_t)t[j] & M29;
@@ -49,8 +49,8 @@ struct F29 {
     r.v[8] = (uint32_t)t[8];
     return r;
   }
-  static __device__ __forceinline__ F29 add_lazy(const F29& a, const F29& b) {
-    F29 r;
+  static __device__ __forceinline__ L29 add_lazy(const L29& a, const L29& b) {
+    L29 r;
 #pragma unroll
     for (int j = 0; j < 9; j++) r.v[j] = a.v[j] + b.v[j];
     return r;
@@ -64,12 +64,12 @@ struct F29 {
   }
 };
 
-template <int ITER> __global__ void __launch_bounds__(256) k_mul29(F29* out, const F29* in) {
+template <int ITER> __global__ void __launch_bounds__(256) k_mul29(L29* out, const L29* in) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  F29 x = in[t], y = in[t + 1];
+  L29 x = in[t], y = in[t + 1];
 #pragma unroll 1
-  for (int i = 0; i < ITER; i++) { x = F29::mul(x, y); y = F29::mul(y, x); }
-  out[t] = F29::add_lazy(x, y);
+  for (int i = 0; i < ITER; i++) { x = L29::mul(x, y); y = L29::mul(y, x); }
+  out[t] = L29::add_lazy(x, y);
 }
 template <int ITER> __global__ void __launch_bounds__(256) k_fqmul(Fq* out, const Fq* in) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -150,10 +150,10 @@ int main() {
   const int BLOCKS = 256 * 16, T = 256, N = BLOCKS * T; constexpr int MI = 512;
   // correctness on a few values: mul(a, b) == a*b*2^-261 mod p, checked on the host with python-free 128-bit loops is long;
   // instead check the algebraic identity mul(mul(a,b),c) == mul(a,mul(b,c)) and mul(a, R mod p) == a on device results.
-  std::vector<F29> h(N + 1);
+  std::vector<L29> h(N + 1);
   for (int i = 0; i <= N; i++) for (int k = 0; k < 9; k++) h[i].v[k] = (uint32_t)(i * 2654435761u + k * 40503u + 12345u) & (k == 8 ? 0x1FFFFF : M29);
-  F29 *din, *dout; CK(hipMalloc(&din, (N + 1) * sizeof(F29))); CK(hipMalloc(&dout, N * sizeof(F29)));
-  CK(hipMemcpy(din, h.data(), (N + 1) * sizeof(F29), hipMemcpyHostToDevice));
+  L29 *din, *dout; CK(hipMalloc(&din, (N + 1) * sizeof(L29))); CK(hipMalloc(&dout, N * sizeof(L29)));
+  CK(hipMemcpy(din, h.data(), (N + 1) * sizeof(L29), hipMemcpyHostToDevice));
   float ms = time_kernel([&] { hipLaunchKernelGGL(k_mul29<MI>, dim3(BLOCKS), dim3(T), 0, 0, dout, din); });
   printf("Fq 9x29 mont mul   : %8.3f ms  %8.2f Gmul/s\n", ms, (double)N * MI * 2 / ms / 1e6);
   std::vector<Fq> g(N + 1);
@@ -162,6 +162,11 @@ int main() {
   CK(hipMemcpy(ein, g.data(), (N + 1) * sizeof(Fq), hipMemcpyHostToDevice));
   ms = time_kernel([&] { hipLaunchKernelGGL(k_fqmul<MI>, dim3(BLOCKS), dim3(T), 0, 0, eout, ein); });
   printf("Fq 8x32 mont mul   : %8.3f ms  %8.2f Gmul/s\n", ms, (double)N * MI * 2 / ms / 1e6);
+  // latency of one dependent product when a single wave has the SIMD to itself (the graph interpreter's situation)
+  ms = time_kernel([&] { hipLaunchKernelGGL(k_mul29<MI>, dim3(1), dim3(64), 0, 0, dout, din); });
+  printf("single wave 9x29   : %8.3f us per dependent product\n", ms * 1e3 / (MI * 2));
+  ms = time_kernel([&] { hipLaunchKernelGGL(k_fqmul<MI>, dim3(1), dim3(64), 0, 0, eout, ein); });
+  printf("single wave 8x32   : %8.3f us per dependent product\n", ms * 1e3 / (MI * 2));
   {
     const int NP = 512;
     std::vector<G1Affine> pts(NP);

@@ -181,7 +181,9 @@ __device__ __noinline__ Fr witness_slow_op(uint32_t op, Fr fa, Fr fb, uint32_t* 
 // nodes; only the 124 reads of input nodes go to HBM.  The ring is 64 slots x 64 lanes x 32 B = 128 KiB of LDS -- one
 // wave per CU is all this kernel ever has (16 waves per 1024 proofs).
 constexpr uint32_t OPK_RING = 0u << 30, OPK_CONST = 1u << 30, OPK_FAR = 2u << 30, OPK_MASK = 3u << 30;
-constexpr uint32_t WIT_RING = 64;
+constexpr uint32_t G_STORE = 1u << 31;  // flag on GNode.op: this node's value must reach HBM (witness signal, input, far operand)
+constexpr uint32_t WIT_RING = 32;        // node values kept in LDS (64 KiB)
+constexpr uint32_t WIT_LDS_CONSTS = 2048;  // constants kept in LDS (64 KiB)
 __device__ __forceinline__ Fr ring_load(const uint32_t* ring, uint32_t node, uint32_t lane) {
   Fr r;
   const uint32_t* s = ring + (node % WIT_RING) * 8 * 64 + lane;
@@ -193,23 +195,42 @@ __device__ __forceinline__ Fr operand_load(uint32_t enc, const uint32_t* ring, c
                                            const Fr* __restrict__ V, uint32_t B, uint32_t p, uint32_t lane) {
   uint32_t kind = enc & OPK_MASK, id = enc & ~OPK_MASK;
   if (kind == OPK_RING) return ring_load(ring, id, lane);
-  if (kind == OPK_CONST) return consts[id];
+  if (kind == OPK_CONST) {
+    if (id >= WIT_LDS_CONSTS) return consts[id];
+    Fr r;
+    const uint32_t* c = ring + WIT_RING * 8 * 64 + id * 8;  // broadcast read: every lane the same address
+#pragma unroll
+    for (int k = 0; k < 8; k++) r.v[k] = c[k];
+    return r;
+  }
   return V[(size_t)id * B + p];
 }
 __global__ void __launch_bounds__(64) k_witness(const GNode* __restrict__ nodes, uint32_t n_nodes,
-                                                const Fr* __restrict__ consts, const uint32_t* __restrict__ inputs,
-                                                uint32_t n_inputs, Fr* __restrict__ V, uint32_t* __restrict__ err,
-                                                uint32_t B, uint32_t nb) {
-  extern __shared__ uint32_t ring[];
+                                                const Fr* __restrict__ consts, uint32_t n_consts,
+                                                const uint32_t* __restrict__ inputs, uint32_t n_inputs,
+                                                Fr* __restrict__ V, uint32_t* __restrict__ err, uint32_t B, uint32_t nb) {
+  extern __shared__ uint32_t ring[];  // [WIT_RING][8][64] node values, then [WIT_LDS_CONSTS][8] constants
   __builtin_amdgcn_s_setprio(3);  // few, latency-bound waves: issue ahead of the MSM waves sharing the SIMD
   const uint32_t lane = threadIdx.x;
   uint32_t p = blockIdx.x * 64 + lane;
   if (p >= nb) return;
   uint32_t e = WERR_NONE;
   Fr last = Fr::zero();
+  {
+    uint32_t* lc = ring + WIT_RING * 8 * 64;
+    const uint32_t* gc = (const uint32_t*)consts;
+    const uint32_t words = (n_consts < WIT_LDS_CONSTS ? n_consts : WIT_LDS_CONSTS) * 8;
+    for (uint32_t i = lane; i < words; i += 64) lc[i] = gc[i];
+    __syncthreads();
+  }
+  GNode ahead = nodes[0];
 #pragma unroll 1
   for (uint32_t n = 0; n < n_nodes; n++) {
-    GNode nd = nodes[n];
+    // the descriptor of the next node is fetched while this one executes (scalar load)
+    GNode nd = ahead;
+    if (n + 1 < n_nodes) ahead = nodes[n + 1];
+    const bool store = (nd.op & G_STORE) != 0;
+    nd.op &= ~G_STORE;
     Fr v;
     if (nd.op == G_INPUT) {
       const uint32_t* src = inputs + ((size_t)p * n_inputs + nd.a) * 8;
@@ -219,6 +240,7 @@ __global__ void __launch_bounds__(64) k_witness(const GNode* __restrict__ nodes,
       v = consts[nd.a];
     } else {
       // operand forwarding: chains (x^5 s-boxes, MDS sums) read the value produced one node earlier
+      // (reading the NEXT node's LDS operands ahead of time was tried: 33 ms instead of 19.5 -- register pressure)
       Fr va = (nd.a == (OPK_RING | (n - 1))) ? last : operand_load(nd.a, ring, consts, V, B, p, lane);
       if (nd.op == G_NEG) {
         v = va.neg();
@@ -242,7 +264,8 @@ __global__ void __launch_bounds__(64) k_witness(const GNode* __restrict__ nodes,
         }
       }
     }
-    V[(size_t)n * B + p] = v;
+    // only ~6 000 of the 23 414 node values are read outside this kernel (190 MB instead of 767 MB per batch)
+    if (store) V[(size_t)n * B + p] = v;
     uint32_t* slot = ring + (n % WIT_RING) * 8 * 64 + lane;
 #pragma unroll
     for (int k = 0; k < 8; k++) slot[k * 64] = v.v[k];
@@ -986,17 +1009,30 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
       if (n - o < WIT_RING) return OPK_RING | o;
       return OPK_FAR | o;
     };
+    std::vector<uint8_t> store(D.N, 0);
+    for (uint32_t sgn : graph_.signals) store[sgn] = 1;
     for (uint32_t n = 0; n < D.N; n++) {
       GNode& g = prog[n];
+      if (g.op == G_INPUT) store[n] = 1;
       if (g.op == G_INPUT || g.op == G_CONST) continue;
-      g.a = enc(n, g.a);
-      if (g.op != G_NEG && g.op != G_ID) g.b = enc(n, g.b);
-      if (g.op == G_TERN) g.c = enc(n, g.c);
+      const uint32_t oa = g.a, ob = g.b, oc = g.c;
+      g.a = enc(n, oa);
+      if ((g.a & OPK_MASK) == OPK_FAR) store[oa] = 1;
+      if (g.op != G_NEG && g.op != G_ID) {
+        g.b = enc(n, ob);
+        if ((g.b & OPK_MASK) == OPK_FAR) store[ob] = 1;
+      }
+      if (g.op == G_TERN) {
+        g.c = enc(n, oc);
+        if ((g.c & OPK_MASK) == OPK_FAR) store[oc] = 1;
+      }
     }
+    for (uint32_t n = 0; n < D.N; n++)
+      if (store[n]) prog[n].op |= G_STORE;
     D.nodes.upload(prog.data(), D.N, s);
     RLN_HIP(hipStreamSynchronize(s));
   }
-  RLN_HIP(hipFuncSetAttribute((const void*)k_witness, hipFuncAttributeMaxDynamicSharedMemorySize, WIT_RING * 8 * 64 * 4));
+  RLN_HIP(hipFuncSetAttribute((const void*)k_witness, hipFuncAttributeMaxDynamicSharedMemorySize, WIT_RING * 8 * 64 * 4 + WIT_LDS_CONSTS * 32));
   D.consts.alloc(std::max<size_t>(graph_.constants.size(), 1));
   if (!graph_.constants.empty()) D.consts.upload(graph_.constants.data(), graph_.constants.size(), s);
   D.sig2node.alloc(D.NS);
@@ -1329,7 +1365,8 @@ void Prover::run_async(size_t n, int mode) {
   // ---------------- stage A
   if (S.used) RLN_HIP(hipStreamWaitEvent(sA, S.evC, 0));  // slot free again
   RLN_HIP(hipEventRecord(S.t[1], sA));
-  hipLaunchKernelGGL(k_witness, dim3(pg), dim3(64), WIT_RING * 8 * 64 * 4, sA, D.nodes.p, D.N, D.consts.p, D.inputs.p, D.NI, S.V.p,
+  hipLaunchKernelGGL(k_witness, dim3(pg), dim3(64), WIT_RING * 8 * 64 * 4 + WIT_LDS_CONSTS * 32, sA, D.nodes.p, D.N, D.consts.p,
+                     (uint32_t)graph_.constants.size(), D.inputs.p, D.NI, S.V.p,
                      S.err.p, B, nbp);
   if (D.wgiven_n) {
     if (D.wgiven_n != n || mode != PROVE_FULL) throw Error("upload_witness: the next run must be a full proof of the same batch");
