@@ -330,6 +330,11 @@ def test_msm_g1_vs_oracle_small_and_edge_cases():
     assert m.msm([pts[0], G1.neg(pts[0])], [9, 9]) is None
     assert m.msm([pts[1]], [R - 1]) == G1.neg(pts[1])
     assert m.msm([pts[2], pts[3]], [0x8000, 0xFFFF8000FFFF]) == G1.msm_naive([pts[2], pts[3]], [0x8000, 0xFFFF8000FFFF])
+    # the same base with the same scalar lands in the same bucket of every window: the accumulator meets its own point
+    # (doubling) and its negation (cancellation) inside the 9 x 29-bit group law
+    assert m.msm([pts[4]] * 300, [7] * 300) == G1.mul(pts[4], 2100)
+    assert m.msm([pts[5], G1.neg(pts[5]), pts[5], pts[6]] * 2, [R - 3] * 8) == \
+        G1.msm_naive([pts[5], pts[6]], [2 * (R - 3) % R, 2 * (R - 3) % R])
     big = [pts[i % 40] for i in range(3000)]
     bsc = [rnd.randrange(R) for _ in range(3000)]
     assert m.msm(big, bsc) == G1.msm(big, bsc, c=8)
