@@ -91,6 +91,37 @@ struct F29 {
     const F29* const bb[1] = {&b};
     return redc_dot<1>(aa, bb);
   }
+  // REDC(a^2): row i adds a_i^2 into column 2 i and (2 a_i) a_l, l > i, into column i + l -- 45 products instead of
+  // 81.  Column i is complete when round i retires it (its terms come from rows k <= i / 2).  The column sums are the
+  // same integers as in mul(a, a), so the bounds of mul hold; a may be N or lazy.
+  static __device__ __forceinline__ F29 sqr(const F29& a) {
+    uint64_t t[10];
+#pragma unroll
+    for (int j = 0; j < 10; j++) t[j] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      t[i] += (uint64_t)a.v[i] * a.v[i];
+      const uint32_t d = 2 * a.v[i];
+#pragma unroll
+      for (int l = i + 1; l < 9; l++) t[l] += (uint64_t)d * a.v[l];
+      uint32_t m = ((uint32_t)t[0] * C::INV) & M;
+#pragma unroll
+      for (int j = 0; j < 9; j++) t[j] += (uint64_t)m * C::P[j];
+      uint64_t carry = t[0] >> 29;
+#pragma unroll
+      for (int j = 0; j < 9; j++) t[j] = t[j + 1];
+      t[0] += carry;
+      t[9] = 0;
+    }
+    F29 r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      r.v[j] = (uint32_t)t[j] & M;
+      t[j + 1] += t[j] >> 29;
+    }
+    r.v[8] = (uint32_t)t[8];
+    return r;
+  }
   // a0 b0 + a1 b1 with one reduction
   static __device__ __forceinline__ F29 dot2(const F29& a0, const F29& b0, const F29& a1, const F29& b1) {
     const F29* const aa[2] = {&a0, &a1};
@@ -258,15 +289,15 @@ struct G1Acc29 {
     Fq29 U;
 #pragma unroll
     for (int j = 0; j < 9; j++) U.v[j] = 2 * py.v[j];          // lazy, < 4 q
-    Fq29 V = Fq29::mul(U, U);
+    Fq29 V = Fq29::sqr(U);
     Fq29 W = Fq29::mul(U, V);
     Fq29 S = Fq29::mul(x, V);
-    Fq29 x2 = Fq29::mul(x, x);
+    Fq29 x2 = Fq29::sqr(x);
     Fq29 Mm;
 #pragma unroll
     for (int j = 0; j < 9; j++) Mm.v[j] = 3 * x2.v[j];
     Mm.normalize();                                              // < 3.3 q
-    Fq29 M2 = Fq29::mul(Mm, Mm);
+    Fq29 M2 = Fq29::sqr(Mm);
     Fq29 X3;
 #pragma unroll
     for (int j = 0; j < 9; j++) X3.v[j] = M2.v[j] + Fq29C::K4T[j] - 2 * S.v[j];
@@ -302,12 +333,12 @@ struct G1Acc29 {
       }
       return;
     }
-    Fq29 PP = Fq29::mul(P, P);                        // < 1.4 q
+    Fq29 PP = Fq29::sqr(P);                           // < 1.4 q
     ZZ = Fq29::mul(ZZ, PP);
     Fq29 Q = Fq29::mul(X, PP);                        // < 1.1 q
     Fq29 PPP = Fq29::mul(P, PP);                      // < 1.1 q
     ZZZ = Fq29::mul(ZZZ, PPP);
-    Fq29 R2 = Fq29::mul(R, R);                        // < 1.2 q
+    Fq29 R2 = Fq29::sqr(R);                           // < 1.2 q
 #pragma unroll
     for (int j = 0; j < 9; j++) X.v[j] = R2.v[j] + Fq29C::K4T[j] - (PPP.v[j] + 2 * Q.v[j]);
     X.normalize();                                    // X3 in (0.7 q, 5.2 q)

@@ -105,8 +105,8 @@ __device__ __forceinline__ void poseidon_round29(Fr29* st, const uint32_t* __res
 #pragma unroll
   for (int j = 0; j < T; j++) {
     if (FULL || j == 0) {
-      Fr29 x2 = Fr29::mul(st[j], st[j]);
-      Fr29 x4 = Fr29::mul(x2, x2);
+      Fr29 x2 = Fr29::sqr(st[j]);
+      Fr29 x4 = Fr29::sqr(x2);
       st[j] = Fr29::mul(x4, st[j]);
     } else if (T == 4) {
       st[j].normalize();  // a 4-term dot product takes at most two lazy operands
