@@ -438,3 +438,22 @@ def test_fq29_group_law_matches_the_8x32_group_law_on_device():
     bad = C.c_uint32(123)
     check(lib().rlnamd_selftest_fq29(2, 4096, 48, g2, C.byref(bad)))
     assert bad.value == 0
+
+
+def test_mixed_window_schedules_give_the_same_proofs():
+    """The comb tables may use (c + 1)-bit windows for the first few windows (window_bits = c + 100 * wide, 19
+    instead of 20 windows at c = 13 in bench.py).  Group elements are canonical, so every schedule must return the
+    golden proof bytes; partial + finish walks share the tables and must agree too."""
+    from zerokit_amd.batch import BatchProver
+    cases = _cases()["cases"]
+    ws, rs = [_w(c) for c in cases], [(int(c["r"]), int(c["s"])) for c in cases]
+    for wb, windows in ((708, 31), (309, 28), (1010, 25)):   # 7x9+24x8 = 255, 3x10+25x9 = 255, 10x11+15x10 = 260 bits
+        p = BatchProver(max_batch=64, window_bits=wb)
+        try:
+            assert int(p.info.windows) == windows
+            out = p.prove(ws, rs)
+            for o, c in zip(out, cases):
+                assert o["proof"].hex() == c["proof_compressed"], (wb, c["name"])
+                assert p.verify(o["proof"], o["public_inputs"])
+        finally:
+            p.close()

@@ -374,12 +374,25 @@ __global__ void __launch_bounds__(256) k_hquot(Fr* __restrict__ abc, uint32_t n,
   abc[o] = abc[o] * abc[(size_t)n * B + o] - abc[2 * (size_t)n * B + o];
 }
 
+// Window schedule of the comb tables.  Window j covers cw[j] scalar bits starting at bit bo[j]; its table row holds
+// the 2^(cw[j]-1) multiples d 2^bo[j] P (signed digits) at entry offset ro[j] inside the point's block of `stride`
+// entries.  Uniform widths (c, c, ...) are the classical comb; with 288 GB of HBM the first `wide` windows take one
+// more bit so that W drops from 20 to 19 at c = 13 (8 x 14 + 11 x 13 = 255 bits, table x 1.35).  Passed by value:
+// the kernels index it with wave-uniform j (scalar loads from the kernarg segment).
+struct WinSched {
+  int W;
+  uint32_t stride;
+  uint8_t cw[32];
+  uint16_t bo[32];
+  uint32_t ro[32];
+};
+
 // =====================================================================================================
-// 4. scalars -> signed c-bit digits, layout [scalar][window][proof] (int16)
+// 4. scalars -> signed digits (window j: cw[j] bits), layout [scalar][window][proof] (int16)
 // =====================================================================================================
 __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ V, const uint32_t* __restrict__ sig2node,
                                                 uint32_t ns, const Fr* __restrict__ H, uint32_t n,
-                                                const uint32_t* __restrict__ rs, int c, int W,
+                                                const uint32_t* __restrict__ rs, WinSched ws,
                                                 int16_t* __restrict__ digits, uint32_t B, uint32_t nb) {
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
   uint32_t sid = blockIdx.y * blockDim.y + threadIdx.y;
@@ -397,11 +410,13 @@ __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ V, const 
   }
   uint32_t l[8];
   x.to_canonical(l);
-  const uint32_t mask = (1u << c) - 1, E = 1u << (c - 1);
+  const int W = ws.W;
   uint32_t carry = 0;
   int16_t* out = digits + (size_t)sid * W * B + p;
 #pragma unroll 1
   for (int j = 0; j < W; j++) {
+    const int c = ws.cw[j];
+    const uint32_t mask = (1u << c) - 1, E = 1u << (c - 1);
     uint32_t raw = (l[0] & mask) + carry;
 #pragma unroll
     for (int i = 0; i < 7; i++) l[i] = (l[i] >> c) | (l[i + 1] << (32 - c));
@@ -429,7 +444,7 @@ template <class F>
 __global__ void __launch_bounds__(64) k_msm(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ sid,
                                             const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks,
                                             uint32_t nchunks, const int16_t* __restrict__ digits,
-                                            XYZZ<F>* __restrict__ part, int c, int W, uint32_t B, uint32_t pgroups) {
+                                            XYZZ<F>* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups) {
   // XCD-aware decode: hardware places block L on XCD L % 8; all proof groups of one chunk share the same
   // table rows, so they are given consecutive slots on ONE XCD and meet in that XCD's L2.
   uint32_t L = blockIdx.x;
@@ -439,18 +454,18 @@ __global__ void __launch_bounds__(64) k_msm(const Affine<F>* __restrict__ table,
   uint32_t p = pg * 64 + threadIdx.x;  // padded lanes run on zero digits
   ChunkDesc cd = chunks[chunk];
   XYZZ<F> acc = XYZZ<F>::inf();
-  const int cs = c - 1;
+  const int W = ws.W;
 #pragma unroll 1
   for (uint32_t i = cd.pt_begin; i < cd.pt_end; i++) {
     const uint32_t k = rows[i];  // table row; the walk (full / partial / finish) is a list of rows
     const int16_t* dg = digits + (size_t)sid[k] * W * B + p;
-    const Affine<F>* row = table + (((size_t)k * W) << cs);
+    const Affine<F>* row = table + (size_t)k * ws.stride;
 #pragma unroll 1
     for (int j = 0; j < W; j++) {
       int d = dg[(size_t)j * B];
       if (d != 0) {
         uint32_t e = (uint32_t)(d < 0 ? -d : d) - 1;
-        Affine<F> pt = row[((size_t)j << cs) + e];
+        Affine<F> pt = row[ws.ro[j] + e];
         if (d < 0) pt.y = pt.y.neg();
         acc.madd(pt);
       }
@@ -465,7 +480,7 @@ template <class Acc, class Entry, class Out, int WAVES>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_msm29(const Entry* __restrict__ table, const uint32_t* __restrict__ sid,
                                               const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks,
                                               uint32_t nchunks, const int16_t* __restrict__ digits,
-                                              Out* __restrict__ part, int c, int W, uint32_t B, uint32_t pgroups) {
+                                              Out* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups) {
   uint32_t L = blockIdx.x;
   uint32_t xcd = L & 7, q = L >> 3;
   uint32_t chunk = (q / pgroups) * 8 + xcd, pg = q % pgroups;
@@ -473,18 +488,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 
   uint32_t p = pg * 64 + threadIdx.x;
   ChunkDesc cd = chunks[chunk];
   Acc acc = Acc::inf();
-  const int cs = c - 1;
+  const int W = ws.W;
 #pragma unroll 1
   for (uint32_t i = cd.pt_begin; i < cd.pt_end; i++) {
     const uint32_t k = rows[i];
     const int16_t* dg = digits + (size_t)sid[k] * W * B + p;
-    const Entry* row = table + (((size_t)k * W) << cs);
+    const Entry* row = table + (size_t)k * ws.stride;
 #pragma unroll 1
     for (int j = 0; j < W; j++) {  // (touching the next entry ahead of the addition was measured: 3 % slower)
       int d = dg[(size_t)j * B];
       if (d != 0) {
         uint32_t e = (uint32_t)(d < 0 ? -d : d) - 1;
-        acc.madd(row[((size_t)j << cs) + e], d < 0);
+        acc.madd(row[ws.ro[j] + e], d < 0);
       }
     }
   }
@@ -516,17 +531,19 @@ __global__ void __launch_bounds__(64) k_sum_ranges(const XYZZ<F>* __restrict__ s
 // Built by doubling the known prefix (multiples 1..m -> m+1..2m are "T[i] + T[m]" and one doubling) with
 // one shared inversion per level (Montgomery's trick; prefix products parked in `scratch`).
 template <class F>
-__global__ void __launch_bounds__(64) k_table_build(const Affine<F>* __restrict__ pts, uint32_t npts, int c, int W,
+__global__ void __launch_bounds__(64) k_table_build(const Affine<F>* __restrict__ pts, uint32_t npts, WinSched ws,
                                                     Affine<F>* __restrict__ table, F* __restrict__ scratch) {
+  const uint32_t W = (uint32_t)ws.W;
   size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
   if (t >= (size_t)npts * W) return;
   uint32_t k = (uint32_t)(t / W), j = (uint32_t)(t % W);
-  const uint32_t E = 1u << (c - 1);
+  const uint32_t E = 1u << (ws.cw[j] - 1);
   XYZZ<F> b = XYZZ<F>::from_affine(pts[k]);
-  for (uint32_t i = 0; i < (uint32_t)c * j; i++) b = b.dbl();
+  for (uint32_t i = 0; i < (uint32_t)ws.bo[j]; i++) b = b.dbl();
   Affine<F> base = b.to_affine();
-  Affine<F>* row = table + (t << (c - 1));
-  F* pre = scratch + t * (E / 2 ? E / 2 : 1);
+  const size_t off = (size_t)k * ws.stride + ws.ro[j];  // even: every row has >= 2 entries (cw >= 2)
+  Affine<F>* row = table + off;
+  F* pre = scratch + off / 2;
   row[0] = base;
   for (uint32_t m = 1; m < E; m <<= 1) {
     const Affine<F> Pm = row[m - 1];
@@ -852,6 +869,7 @@ struct Prover::Impl {
   static constexpr int NSLOT = 6;
   Slot slot[NSLOT];
   int nslot = 5, nstreamA = 2;  // RLNAMD_SLOTS / RLNAMD_ASTREAMS
+  WinSched ws{};                // window schedule of both comb tables
   uint32_t msm_lds = 0;         // RLNAMD_MSM_WAVES (waves per SIMD the G1 walk may occupy; 0 = no cap)
   int cur = 0;
   Slot* last = nullptr;
@@ -892,22 +910,22 @@ static void make_reduce_ranges(const std::vector<uint32_t>& segfirst, std::vecto
 }
 
 template <class F>
-static void build_table(const std::vector<Affine<F>>& pts, int c, int W, DevBuf<Affine<F>>& table, hipStream_t s) {
+static void build_table(const std::vector<Affine<F>>& pts, const WinSched& ws, DevBuf<Affine<F>>& table, hipStream_t s) {
   size_t npts = pts.size();
-  size_t E = (size_t)1 << (c - 1);
-  table.alloc(npts * W * E);
+  const size_t stride = ws.stride;
+  table.alloc(npts * stride);
   DevBuf<Affine<F>> d_pts(npts);
   d_pts.upload(pts.data(), npts, s);
   // scratch is half a table; build in slabs of points so it never exceeds ~4 GiB
-  size_t per_pt = (size_t)W * std::max<size_t>(E / 2, 1) * sizeof(F);
+  size_t per_pt = stride / 2 * sizeof(F);
   size_t slab = std::max<size_t>(1, ((size_t)4 << 30) / per_pt);
   slab = std::min(slab, npts);
-  DevBuf<F> scratch(slab * W * std::max<size_t>(E / 2, 1));
+  DevBuf<F> scratch(slab * stride / 2);
   for (size_t k0 = 0; k0 < npts; k0 += slab) {
     size_t cnt = std::min(slab, npts - k0);
-    size_t threads = cnt * W;
-    hipLaunchKernelGGL(k_table_build<F>, dim3(div_up(threads, 64)), dim3(64), 0, s, d_pts.p + k0, (uint32_t)cnt, c, W,
-                       table.p + k0 * W * E, scratch.p);
+    size_t threads = cnt * ws.W;
+    hipLaunchKernelGGL(k_table_build<F>, dim3(div_up(threads, 64)), dim3(64), 0, s, d_pts.p + k0, (uint32_t)cnt, ws,
+                       table.p + k0 * stride, scratch.p);
     RLN_HIP(hipGetLastError());
   }
   RLN_HIP(hipStreamSynchronize(s));
@@ -916,27 +934,48 @@ static void build_table(const std::vector<Affine<F>>& pts, int c, int W, DevBuf<
 // G1 table in the 9 x 29 form: slabs are built in the 8 x 32 form (k_table_build reads its own rows back) and
 // converted into place
 template <class F, class Entry>
-static void build_table29(const std::vector<Affine<F>>& pts, int c, int W, DevBuf<Entry>& table, hipStream_t s) {
+static void build_table29(const std::vector<Affine<F>>& pts, const WinSched& ws, DevBuf<Entry>& table, hipStream_t s) {
   size_t npts = pts.size();
-  size_t E = (size_t)1 << (c - 1);
-  table.alloc(npts * W * E);
+  const size_t stride = ws.stride;
+  table.alloc(npts * stride);
   DevBuf<Affine<F>> d_pts(npts);
   d_pts.upload(pts.data(), npts, s);
-  size_t per_pt = (size_t)W * std::max<size_t>(E / 2, 1) * sizeof(F);
+  size_t per_pt = stride / 2 * sizeof(F);
   size_t slab = std::max<size_t>(1, ((size_t)4 << 30) / per_pt);
   slab = std::min(slab, npts);
-  DevBuf<F> scratch(slab * W * std::max<size_t>(E / 2, 1));
-  DevBuf<Affine<F>> tmp(slab * W * E);
+  DevBuf<F> scratch(slab * stride / 2);
+  DevBuf<Affine<F>> tmp(slab * stride);
   for (size_t k0 = 0; k0 < npts; k0 += slab) {
     size_t cnt = std::min(slab, npts - k0);
-    size_t threads = cnt * W;
-    hipLaunchKernelGGL(k_table_build<F>, dim3(div_up(threads, 64)), dim3(64), 0, s, d_pts.p + k0, (uint32_t)cnt, c, W,
+    size_t threads = cnt * ws.W;
+    hipLaunchKernelGGL(k_table_build<F>, dim3(div_up(threads, 64)), dim3(64), 0, s, d_pts.p + k0, (uint32_t)cnt, ws,
                        tmp.p, scratch.p);
-    hipLaunchKernelGGL((k_table_to29<Affine<F>, Entry>), dim3(div_up(threads * E, 256)), dim3(256), 0, s, tmp.p,
-                       table.p + k0 * W * E, threads * E);
+    hipLaunchKernelGGL((k_table_to29<Affine<F>, Entry>), dim3(div_up(cnt * stride, 256)), dim3(256), 0, s, tmp.p,
+                       table.p + k0 * stride, cnt * stride);
     RLN_HIP(hipGetLastError());
   }
   RLN_HIP(hipStreamSynchronize(s));
+}
+
+// c-bit windows, the first `wide` of them one bit wider; W = the fewest windows that cover 255 bits (254-bit scalars
+// plus the carry of the signed recoding)
+static WinSched make_sched(int c, int wide) {
+  WinSched ws{};
+  int W = (255 - wide + c - 1) / c;
+  if (wide > W) throw Error("more wide windows than windows");
+  if (W > 32) throw Error("window bits too small: more than 32 windows");
+  ws.W = W;
+  uint32_t bit = 0, off = 0;
+  for (int j = 0; j < W; j++) {
+    int cw = c + (j < wide ? 1 : 0);
+    ws.cw[j] = (uint8_t)cw;
+    ws.bo[j] = (uint16_t)bit;
+    ws.ro[j] = off;
+    bit += cw;
+    off += 1u << (cw - 1);
+  }
+  ws.stride = off;
+  return ws;
 }
 
 Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_t graph_len, ProverConfig cfg)
@@ -946,9 +985,13 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   graph_ = parse_graph(graph, graph_len);
   (void)prepared(zk_);  // verifier precomputation now, so concurrent verify calls only read it
   Impl& D = *d_;
-  c_ = cfg.window_bits > 0 ? cfg.window_bits : env_int("RLNAMD_WINDOW_BITS", 8);
-  if (c_ < 2 || c_ > 14) throw Error("window bits must be in [2, 14]");
-  W_ = (255 + c_ - 1) / c_;
+  // window_bits = c + 100 * wide: c-bit windows, the first `wide` of them (c + 1)-bit (see WinSched)
+  const int wb = cfg.window_bits > 0 ? cfg.window_bits : env_int("RLNAMD_WINDOW_BITS", 8);
+  c_ = wb % 100;
+  const int wide = wb >= 100 ? wb / 100 : env_int("RLNAMD_WINDOW_WIDE", 0);
+  if (c_ < 2 || c_ > 14 || wide < 0) throw Error("window bits must be in [2, 14]");
+  D.ws = make_sched(c_, wide);
+  W_ = D.ws.W;
   B_ = ((cfg.max_batch ? cfg.max_batch : 1) + 63) / 64 * 64;
 
   // ---- consistency between zkey and graph (what arkworks asserts inside the prover)
@@ -1185,7 +1228,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     D.sid1.upload(sids.data(), sids.size(), s);
     make_plans(sids, row_seg, 3, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK", 8)), D.plan1, &D.max_chunks1,
                &D.max_groups1);
-    if (D.use29) build_table29<Fq, G1Affine29>(pts, c_, W_, D.t1_29, s); else build_table<Fq>(pts, c_, W_, D.t1, s);
+    if (D.use29) build_table29<Fq, G1Affine29>(pts, D.ws, D.t1_29, s); else build_table<Fq>(pts, D.ws, D.t1, s);
   }
   {
     std::vector<G2Affine> pts;
@@ -1204,7 +1247,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     D.sid2.upload(sids.data(), sids.size(), s);
     make_plans(sids, row_seg, 1, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_G2", 4)), D.plan2, &D.max_chunks2,
                &D.max_groups2);
-    if (D.use29_g2) build_table29<Fq2, G2Affine29>(pts, c_, W_, D.t2_29, s); else build_table<Fq2>(pts, c_, W_, D.t2, s);
+    if (D.use29_g2) build_table29<Fq2, G2Affine29>(pts, D.ws, D.t2_29, s); else build_table<Fq2>(pts, D.ws, D.t2, s);
   }
 
   // ---- named input slots for the proof-values kernel (single message-id circuit, witness.rs:832-881);
@@ -1397,7 +1440,7 @@ void Prover::run_async(size_t n, int mode) {
   RLN_HIP(hipStreamWaitEvent(D.sB, S.evA, 0));
   RLN_HIP(hipEventRecord(S.t[5], D.sB));
   hipLaunchKernelGGL(k_recode, dim3(pg, D.NS + D.n + 3), dim3(64, 1), 0, D.sB, S.V.p, D.sig2node.p, D.NS,
-                     S.abc.p, D.n, D.rs.p, c_, W_, S.digits.p, B, nbp);
+                     S.abc.p, D.n, D.rs.p, D.ws, S.digits.p, B, nbp);
   RLN_HIP(hipEventRecord(S.t[6], D.sB));
   hipStream_t s2 = D.split_msm ? D.sB2 : D.sB;
   if (D.split_msm) {
@@ -1410,10 +1453,10 @@ void Prover::run_async(size_t n, int mode) {
       // dynamic LDS that the kernel never touches caps it at D.msm_waves waves per SIMD: at 4 x 128 VGPRs the
       // register file is full and the front end's NTT / mat-vec workgroups wait for an MSM workgroup (~1 ms) to retire
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(blocks), dim3(64), D.msm_lds, D.sB, D.t1_29.p, D.sid1.p, P1.rows.p, P1.chunks.p,
-                         P1.nchunks, S.digits.p, S.part1.p, c_, W_, B, pg);
+                         P1.nchunks, S.digits.p, S.part1.p, D.ws, B, pg);
     else
       hipLaunchKernelGGL(k_msm<Fq>, dim3(blocks), dim3(64), 0, D.sB, D.t1.p, D.sid1.p, P1.rows.p, P1.chunks.p,
-                         P1.nchunks, S.digits.p, S.part1.p, c_, W_, B, pg);
+                         P1.nchunks, S.digits.p, S.part1.p, D.ws, B, pg);
   }
   RLN_HIP(hipEventRecord(S.t[7], D.sB));
   RLN_HIP(hipEventRecord(S.t[11], s2));
@@ -1421,10 +1464,10 @@ void Prover::run_async(size_t n, int mode) {
     uint32_t blocks = div_up(P2.nchunks, 8) * 8 * pg;
     if (D.use29_g2)
       hipLaunchKernelGGL((k_msm29<G2Acc29, G2Affine29, G2XYZZ, 2>), dim3(blocks), dim3(64), 0, s2, D.t2_29.p, D.sid2.p,
-                         P2.rows.p, P2.chunks.p, P2.nchunks, S.digits.p, S.part2.p, c_, W_, B, pg);
+                         P2.rows.p, P2.chunks.p, P2.nchunks, S.digits.p, S.part2.p, D.ws, B, pg);
     else
       hipLaunchKernelGGL(k_msm<Fq2>, dim3(blocks), dim3(64), 0, s2, D.t2.p, D.sid2.p, P2.rows.p, P2.chunks.p,
-                         P2.nchunks, S.digits.p, S.part2.p, c_, W_, B, pg);
+                         P2.nchunks, S.digits.p, S.part2.p, D.ws, B, pg);
   }
   RLN_HIP(hipEventRecord(S.t[8], s2));
   RLN_HIP(hipEventRecord(S.evB, D.sB));
