@@ -34,7 +34,7 @@ int rlnamd_device_name(char* buf, size_t cap);
 
 /* ---- hashing ----------------------------------------------------------------------------------------
  * Batched Poseidon: poseidon_hash / poseidon_hash_pair (rln/src/hashers.rs:32-54) over n independent
- * inputs.  inputs: n * arity * 32 bytes, out: n * 32 bytes (host memory). arity in {1,2,3}. */
+ * inputs.  inputs: n * arity * 32 bytes, out: n * 32 bytes (host memory). arity 1..8 (t = 2..9). */
 int rlnamd_poseidon_hash(const uint8_t* inputs_le, size_t n, size_t arity, uint8_t* out_le);
 /* hash_to_field_le / _be (rln/src/hashers.rs:73-93): Keccak-256 then reduction mod r.  Host only. */
 int rlnamd_hash_to_field_le(const uint8_t* data, size_t len, uint8_t out_le[32]);

@@ -50,14 +50,16 @@ def test_poseidon_kats_and_random_vs_oracle():
     assert hashers.poseidon_hash_pair(0, 1) == \
         12583541437132735734108669866114103169564651237895298778035846191048104863326
     rnd = random.Random(7)
-    for arity in (1, 2, 3):
-        rows = [[rnd.randrange(R) for _ in range(arity)] for _ in range(300)]
+    for arity in range(1, 9):     # every width of rln/src/hashers.rs:14-23 (t = 2..9)
+        rows = [[rnd.randrange(R) for _ in range(arity)] for _ in range(300 if arity <= 3 else 70)]
         rows[0] = [0] * arity
         rows[1] = [R - 1] * arity
         got = hashers.poseidon_hash_batch(rows)
         assert got == [poseidon(r) for r in rows]
-    with pytest.raises(Exception):
-        hashers.poseidon_hash([1, 2, 3, 4])  # no parameters on this path for t = 5
+    with pytest.raises(Exception, match="No parameters found for input length 9"):
+        hashers.poseidon_hash(list(range(9)))     # utils/src/poseidon/error.rs:5
+    with pytest.raises(Exception, match="Empty input provided"):
+        hashers.poseidon_hash([])
     with pytest.raises(Exception, match="Non-canonical"):
         hashers.poseidon_hash([R])
 

@@ -80,7 +80,9 @@ int rlnamd_device_name(char* buf, size_t cap) {
 int rlnamd_poseidon_hash(const uint8_t* inputs_le, size_t n, size_t arity, uint8_t* out_le) {
   RLN_TRY
   require_gpu();
-  if (arity < 1 || arity > 3) throw Error("Input length must be valid with supported round parameters");
+  // PoseidonError texts of utils/src/poseidon/error.rs:4-8; widths t = 2..9 (rln/src/hashers.rs:14-23)
+  if (arity == 0) throw Error("Empty input provided");
+  if (arity > 8) throw Error("No parameters found for input length " + std::to_string(arity));
   if (n == 0) return RLNAMD_OK;
   for (size_t i = 0; i < n * arity; i++) {
     uint32_t tmp[8];

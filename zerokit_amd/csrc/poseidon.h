@@ -13,7 +13,7 @@
 
 namespace rlnamd {
 
-constexpr int POSEIDON_MAX_T = 4;  // RLN uses t = 2, 3, 4 (1, 2, 3 inputs)
+constexpr int POSEIDON_MAX_T = 9;  // every width of rln/src/hashers.rs:14-23; RLN itself uses t = 2, 3, 4
 
 struct PoseidonParams {
   int t = 0, rf = 0, rp = 0;
@@ -24,7 +24,7 @@ struct PoseidonParams {
 // host: derive the constants exactly as find_poseidon_ark_and_mds does (poseidon_constants.rs:207-261)
 PoseidonParams poseidon_derive_params(int t);
 
-// device-resident constant tables for t = 2..4
+// device-resident constant tables for t = 2..9
 struct PoseidonDev {
   int rf[POSEIDON_MAX_T + 1] = {0}, rp[POSEIDON_MAX_T + 1] = {0};
   DevBuf<Fr> ark[POSEIDON_MAX_T + 1];
@@ -49,6 +49,7 @@ PoseidonView poseidon_view(int t);
 // One hash on one lane.  `in` are Montgomery residues.
 template <int T, bool FULL>
 __device__ __forceinline__ void poseidon_round_dev(Fr* st, const Fr* __restrict__ ark, const Fr* __restrict__ mds) {
+  static_assert(T >= 2 && T <= 4, "the 8 x 32 form is kept for t = 2..4 only");
 #pragma unroll
   for (int j = 0; j < T; j++) st[j] = st[j] + ark[j];
 #pragma unroll
@@ -95,6 +96,20 @@ __device__ __forceinline__ Fr poseidon_hash_dev_8x32(const Fr* in, const Poseido
 // product).  Bounds: state entries leave a round normalised and < 1.1 r; "+ ark" makes them lazy (limbs < 2^30,
 // < 2.1 r); x^2 = lazy x lazy (9 (2^60 + 2^58) < 2^64), x^5 = x^4 x; an MDS row is one T-term dot product with at most
 // two lazy operands (T = 4 normalises the pass-through entries of a partial round first).
+// sum of N products of normalised operands with one reduction, N <= 5: 9 (5 2^58 + 2^58) < 2^64 per column
+template <int N>
+__device__ __forceinline__ Fr29 poseidon_dotn29(const Fr29* a, const Fr29* b) {
+  static_assert(N >= 1 && N <= 5, "column sums must stay below 2^64");
+  const Fr29* aa[N];
+  const Fr29* bb[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    aa[k] = a + k;
+    bb[k] = b + k;
+  }
+  return Fr29::redc_dot<N>(aa, bb);
+}
+
 template <int T, bool FULL>
 __device__ __forceinline__ void poseidon_round29(Fr29* st, const uint32_t* __restrict__ ark, const uint32_t* __restrict__ mds) {
 #pragma unroll
@@ -108,8 +123,8 @@ __device__ __forceinline__ void poseidon_round29(Fr29* st, const uint32_t* __res
       Fr29 x2 = Fr29::sqr(st[j]);
       Fr29 x4 = Fr29::sqr(x2);
       st[j] = Fr29::mul(x4, st[j]);
-    } else if (T == 4) {
-      st[j].normalize();  // a 4-term dot product takes at most two lazy operands
+    } else if (T >= 4) {
+      st[j].normalize();  // a 4-term dot product takes at most two lazy operands, the wider ones none
     }
   }
   Fr29 nx[T];
@@ -125,8 +140,17 @@ __device__ __forceinline__ void poseidon_round29(Fr29* st, const uint32_t* __res
       nx[i] = Fr29::dot2(m[0], st[0], m[1], st[1]);
     else if constexpr (T == 3)
       nx[i] = Fr29::dot3(m[0], st[0], m[1], st[1], m[2], st[2]);
-    else
+    else if constexpr (T == 4)
       nx[i] = Fr29::dot4(m[0], st[0], m[1], st[1], m[2], st[2], m[3], st[3]);
+    else if constexpr (T == 5)
+      nx[i] = poseidon_dotn29<5>(m, st);
+    else {  // t = 6..9: two groups, each reduced once; the sum (< 2.2 r, limbs < 2^30) is normalised
+      nx[i] = poseidon_dotn29<5>(m, st);
+      const Fr29 hi = poseidon_dotn29<T - 5>(m + 5, st + 5);
+#pragma unroll
+      for (int k = 0; k < 9; k++) nx[i].v[k] += hi.v[k];
+      nx[i].normalize();
+    }
   }
 #pragma unroll
   for (int j = 0; j < T; j++) st[j] = nx[j];

@@ -149,6 +149,11 @@ void poseidon_hash_batch_device(const uint8_t* d_in, size_t n, int arity, uint8_
     case 1: hipLaunchKernelGGL(k_poseidon_batch<2>, grid, block, 0, s, in, n, out, pv); break;
     case 2: hipLaunchKernelGGL(k_poseidon_batch<3>, grid, block, 0, s, in, n, out, pv); break;
     case 3: hipLaunchKernelGGL(k_poseidon_batch<4>, grid, block, 0, s, in, n, out, pv); break;
+    case 4: hipLaunchKernelGGL(k_poseidon_batch<5>, grid, block, 0, s, in, n, out, pv); break;
+    case 5: hipLaunchKernelGGL(k_poseidon_batch<6>, grid, block, 0, s, in, n, out, pv); break;
+    case 6: hipLaunchKernelGGL(k_poseidon_batch<7>, grid, block, 0, s, in, n, out, pv); break;
+    case 7: hipLaunchKernelGGL(k_poseidon_batch<8>, grid, block, 0, s, in, n, out, pv); break;
+    case 8: hipLaunchKernelGGL(k_poseidon_batch<9>, grid, block, 0, s, in, n, out, pv); break;
     default: throw Error("unsupported Poseidon arity " + std::to_string(arity));
   }
   RLN_HIP(hipGetLastError());

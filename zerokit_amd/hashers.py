@@ -11,7 +11,7 @@ def _b(x: int) -> bytes:
 
 
 def poseidon_hash(inputs):
-    """poseidon_hash (hashers.rs:32-36): one hash of 1..3 field elements, on the GPU."""
+    """poseidon_hash (hashers.rs:32-36): one hash of 1..8 field elements, on the GPU."""
     return poseidon_hash_batch([list(inputs)])[0]
 
 
@@ -26,7 +26,7 @@ def poseidon_hash_batch(rows):
         return []
     arity = len(rows[0])
     if arity == 0:
-        raise ValueError("EmptyInput")
+        raise ValueError("Empty input provided")   # PoseidonError::EmptyInput
     buf = b"".join(_b(v) for row in rows for v in row)
     out = C.create_string_buffer(32 * len(rows))
     check(lib().rlnamd_poseidon_hash(buf, len(rows), arity, out))
