@@ -370,3 +370,62 @@ def test_concurrent_proving_on_one_object():
     assert not errors and len(results) == 12
     for x, p in results.values():
         assert p.values.x == x and rln.verify_rln_proof(p, x)
+
+
+def test_persistent_tree_config(tmp_path):
+    """PmTreeConfig (pm_tree_adapter.rs:71-176) through ffi_rln_new's config file: a non-temporary tree with a path
+    comes back after the object is dropped (leaves, next index, root, metadata); flush writes without dropping;
+    set_tree replaces it by a temporary tree; the config errors carry the reference's texts."""
+    import json
+    from zerokit_amd.public import RLN
+    store = tmp_path / "tree_db"
+    cfg = tmp_path / "cfg.json"
+    cfg.write_text(json.dumps({"path": str(store), "temporary": False, "cache_capacity": 1 << 20,
+                               "flush_every_ms": 500, "mode": "HighThroughput", "use_compression": False}))
+    leaves = _leaves(11)
+    r = RLN(20, str(cfg))
+    assert r.leaves_set() == 0
+    r.set_leaves_from(0, leaves)
+    r.delete_leaf(5)
+    r.set_metadata(b"block 1234567")
+    root, n = r.get_root(), r.leaves_set()
+    r.flush()
+    assert (store / "rlnamd_tree.bin").exists()
+    r.set_leaf(NO_OF_LEAVES + 3, 77)          # after the flush: written when the object is dropped
+    root2 = r.get_root()
+    assert root2 != root and r.leaves_set() == NO_OF_LEAVES + 4
+    r.close()
+
+    r = RLN(20, str(cfg))
+    assert r.get_root() == root2 and r.leaves_set() == NO_OF_LEAVES + 4
+    assert r.get_metadata() == b"block 1234567"
+    assert r.get_leaf(4) == leaves[4] and r.get_leaf(5) == 0 and r.get_leaf(NO_OF_LEAVES + 3) == 77
+    elems, bits = r.get_merkle_proof(4)
+    assert len(elems) == 20 and bits[:3] == [0, 0, 1]
+    r.set_next_leaf(9)                         # continues at the stored next index
+    assert r.get_leaf(NO_OF_LEAVES + 4) == 9
+    r.set_tree(20)                             # PoseidonTree::default: the stored tree is left as it was flushed
+    r.set_leaf(0, 1)
+    r.close()
+    r = RLN(20, str(cfg))
+    assert r.leaves_set() == NO_OF_LEAVES + 5 and r.get_leaf(NO_OF_LEAVES + 4) == 9 and r.get_leaf(0) == leaves[0]
+    r.close()
+
+    with pytest.raises(Exception, match="Tree depth"):          # stored depth 20 != requested depth
+        RLN(10, str(cfg))
+    bad = tmp_path / "bad.json"
+    bad.write_text(json.dumps({"temporary": False}))
+    with pytest.raises(Exception, match="Configuration error: Error while creating pmtree config: missing path"):
+        RLN(20, str(bad))
+    bad.write_text(json.dumps({"temporary": True, "path": str(store)}))
+    with pytest.raises(Exception, match="path already exists"):
+        RLN(20, str(bad))
+    bad.write_text("{not json")
+    with pytest.raises(Exception, match="Error while reading pmtree config"):
+        RLN(20, str(bad))
+    bad.write_text(json.dumps({"path": str(tmp_path / "t2"), "temporary": False, "tree_depth": 16}))
+    with pytest.raises(Exception, match="Tree depth"):          # config depth != requested depth
+        RLN(20, str(bad))
+    # a missing config file is the default (temporary) tree, as `.unwrap_or_default()` in ffi_rln.rs:45
+    r = RLN(20, str(tmp_path / "does_not_exist.json"))
+    assert r.leaves_set() == 0

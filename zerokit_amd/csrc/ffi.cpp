@@ -6,10 +6,13 @@
 // run on the host.
 #include "../../include/rln.h"
 
+#include <ctype.h>
 #include <dlfcn.h>
+#include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <fstream>
@@ -364,6 +367,103 @@ struct FFI_RLNPartialProof {  // PartialProof (partial_proof.rs:31-43): mask + f
   uint8_t coords[320];        // pi_a | rho | pi_b | pi_c
 };
 
+// ---- tree persistence --------------------------------------------------------------------------------------------
+// The reference keeps the default (pmtree-ft) tree in a sled database under `path` (pm_tree_adapter.rs:71-176,
+// 191-239).  sled's on-disk format belongs to a third-party crate (sled 0.34.7) that is not in the tree, so the state is
+// kept in ONE snapshot file of our own, `<path>/rlnamd_tree.bin`: the same config keys and lifecycle (load when
+// present, otherwise start empty; written by ffi_flush and when the object is freed), not readable by sled.  The
+// tree itself stays in HBM; a snapshot holds depth, next_index, the metadata bytes and the leaves below next_index.
+struct TreeConfig {
+  std::string path;
+  bool has_path = false;
+  bool temporary = true;   // DEFAULT_TEMPORARY (pm_tree_adapter.rs:67)
+  long tree_depth = -1;
+  bool persistent() const { return !temporary && has_path; }
+};
+
+// flat JSON object with string / number / bool / null values (PmTreeConfig::from_str, pm_tree_adapter.rs:139-176)
+TreeConfig parse_tree_config(const std::string& js) {
+  TreeConfig c;
+  size_t i = 0;
+  auto bad = [&](const char* what) -> Error {
+    return Error(std::string("Configuration error: Error while reading pmtree config: ") + what + " at column " +
+                 std::to_string(i));
+  };
+  auto ws = [&]() { while (i < js.size() && isspace((unsigned char)js[i])) i++; };
+  auto str = [&]() {
+    std::string o;
+    if (js[i] != '"') throw bad("expected a string");
+    for (i++; i < js.size() && js[i] != '"'; i++) {
+      if (js[i] == '\\' && i + 1 < js.size()) {
+        char e = js[++i];
+        o += e == 'n' ? '\n' : e == 't' ? '\t' : e;
+      } else {
+        o += js[i];
+      }
+    }
+    if (i >= js.size()) throw bad("unterminated string");
+    i++;
+    return o;
+  };
+  ws();
+  if (i >= js.size() || js[i] != '{') throw bad("expected value");
+  i++;
+  ws();
+  while (i < js.size() && js[i] != '}') {
+    std::string key = str();
+    ws();
+    if (i >= js.size() || js[i] != ':') throw bad("expected `:`");
+    i++;
+    ws();
+    if (i >= js.size()) throw bad("EOF while parsing a value");
+    if (js[i] == '"') {
+      std::string v = str();
+      if (key == "path") { c.path = v; c.has_path = true; }
+    } else if (!js.compare(i, 4, "true") || !js.compare(i, 5, "false")) {
+      bool v = js[i] == 't';
+      i += v ? 4 : 5;
+      if (key == "temporary") c.temporary = v;
+    } else if (!js.compare(i, 4, "null")) {
+      i += 4;
+    } else if (isdigit((unsigned char)js[i]) || js[i] == '-') {
+      size_t j = i;
+      while (j < js.size() && (isdigit((unsigned char)js[j]) || strchr("+-.eE", js[j]))) j++;
+      if (key == "tree_depth") c.tree_depth = atol(js.substr(i, j - i).c_str());
+      i = j;
+    } else {
+      throw bad("expected value");
+    }
+    ws();
+    if (i < js.size() && js[i] == ',') { i++; ws(); }
+    else if (i < js.size() && js[i] != '}') throw bad("expected `,` or `}`");
+  }
+  if (i >= js.size()) throw bad("EOF while parsing an object");
+  // resolve_path (pm_tree_adapter.rs:93-100)
+  if (!c.temporary && !c.has_path) throw Error("Configuration error: Error while creating pmtree config: missing path");
+  struct stat st;
+  if (c.temporary && c.has_path && stat(c.path.c_str(), &st) == 0)
+    throw Error("Configuration error: Error while creating pmtree config: path already exists");
+  return c;
+}
+
+// the config_path argument of ffi_rln_new*: a JSON file; unreadable / missing / oversized file == "" == defaults
+// (ffi_rln.rs:28-45: `.unwrap_or_default()`)
+TreeConfig tree_config_from_file(const char* config_path) {
+  std::string js;
+  if (config_path && *config_path) {
+    FILE* f = fopen(config_path, "rb");
+    if (f) {
+      char buf[4096];
+      size_t n;
+      while ((n = fread(buf, 1, sizeof buf, f)) > 0 && js.size() <= (1u << 20)) js.append(buf, n);
+      fclose(f);
+      if (js.size() > (1u << 20)) js.clear();  // MAX_CONFIG_SIZE
+    }
+  }
+  if (js.empty()) return TreeConfig();
+  return parse_tree_config(js);
+}
+
 struct FFI_RLN {
   // generate / verify take &self in the reference and may be called from several threads (SURVEY section 8b,
   // "Threading"); the prover owns one set of device workspaces, so proving calls on one object take turns
@@ -374,6 +474,14 @@ struct FFI_RLN {
   size_t next_index = 0;
   std::vector<uint8_t> leaf_set;  // cached_leaves_indices
   std::vector<uint8_t> metadata;
+  std::string store;              // snapshot file of a persistent tree ("" = temporary tree)
+
+  ~FFI_RLN() {
+    try {
+      flush();  // sled flushes when the database is dropped
+    } catch (...) {
+    }
+  }
 
   void new_tree(size_t depth) {  // PoseidonTree::default(depth) (public.rs:298-303)
     if (depth >= 64) throw Error("Tree depth exceeds maximum allowed (must be < 64)");
@@ -382,6 +490,61 @@ struct FFI_RLN {
     tree.init((int)depth, zero);
     next_index = 0;
     leaf_set.assign((size_t)1 << depth, 0);
+    metadata.clear();
+  }
+  // PmTree::new (pm_tree_adapter.rs:191-239): depth check against the config, load the stored tree when there is
+  // one (its depth must match), else start empty; cached_leaves_indices rebuilt from the leaves below next_index
+  void open_tree(size_t depth, const TreeConfig& cfg) {
+    if (cfg.tree_depth >= 0 && (size_t)cfg.tree_depth != depth)
+      throw Error("Merkle tree error: Tree depth exceeds maximum allowed (must be < 64)");  // InvalidDepth
+    store.clear();
+    new_tree(depth);
+    if (!cfg.persistent()) return;
+    if (mkdir(cfg.path.c_str(), 0777) != 0 && errno != EEXIST)
+      throw Error("Merkle tree error: cannot create " + cfg.path + ": " + strerror(errno));
+    std::string file = cfg.path + "/rlnamd_tree.bin";
+    FILE* f = fopen(file.c_str(), "rb");
+    if (f) {
+      struct { char magic[8]; uint64_t depth, next, meta_len; } h;
+      std::vector<uint8_t> meta, leaves;
+      bool ok = fread(&h, sizeof h, 1, f) == 1 && !memcmp(h.magic, "RLNAMDT1", 8) && h.depth < 64 &&
+                h.next <= ((uint64_t)1 << h.depth) && h.meta_len <= (1u << 30);
+      if (ok) {
+        meta.resize(h.meta_len);
+        leaves.resize(h.next * 32);
+        ok = (meta.empty() || fread(meta.data(), meta.size(), 1, f) == 1) &&
+             (leaves.empty() || fread(leaves.data(), leaves.size(), 1, f) == 1);
+      }
+      fclose(f);
+      if (!ok) throw Error("Merkle tree error: " + file + " is not a tree snapshot of this library");
+      if (h.depth != depth) throw Error("Merkle tree error: Tree depth exceeds maximum allowed (must be < 64)");
+      if (h.next) {
+        tree.set_range_host(0, leaves.data(), h.next);
+        static const uint8_t zero[32] = {0};
+        for (size_t i = 0; i < h.next; i++) leaf_set[i] = memcmp(leaves.data() + 32 * i, zero, 32) != 0;
+      }
+      next_index = h.next;
+      metadata = meta;
+    }
+    store = file;
+  }
+  void flush() {  // written to a sibling file, then renamed over the snapshot
+    if (store.empty()) return;
+    std::vector<uint8_t> leaves(next_index * 32);
+    if (next_index) tree.get_leaves_host(0, next_index, leaves.data());
+    struct { char magic[8]; uint64_t depth, next, meta_len; } h;
+    memcpy(h.magic, "RLNAMDT1", 8);
+    h.depth = (uint64_t)tree.depth;
+    h.next = next_index;
+    h.meta_len = metadata.size();
+    std::string tmp = store + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) throw Error("Merkle tree error: cannot write " + tmp + ": " + strerror(errno));
+    bool ok = fwrite(&h, sizeof h, 1, f) == 1 && (metadata.empty() || fwrite(metadata.data(), metadata.size(), 1, f) == 1) &&
+              (leaves.empty() || fwrite(leaves.data(), leaves.size(), 1, f) == 1);
+    ok = fclose(f) == 0 && ok;
+    if (!ok || rename(tmp.c_str(), store.c_str()) != 0)
+      throw Error("Merkle tree error: cannot write " + store + ": " + strerror(errno));
   }
   void set_range(size_t start, const std::vector<CFr>& leaves) {  // full_merkle_tree.rs:197-223
     if (start + leaves.size() > tree.capacity() || start + leaves.size() < start)
@@ -979,7 +1142,8 @@ CResult_Vec_uint8_Vec_uint8_t guard_bytes(F&& f) {
   }
 }
 
-FFI_RLN* rln_create(size_t depth, const std::vector<uint8_t>& zkey, const std::vector<uint8_t>& graph) {
+FFI_RLN* rln_create(size_t depth, const std::vector<uint8_t>& zkey, const std::vector<uint8_t>& graph,
+                    const TreeConfig& tcfg = TreeConfig()) {
   require_gpu();
   std::unique_ptr<FFI_RLN> r(new FFI_RLN);
   ProverConfig cfg;
@@ -989,7 +1153,7 @@ FFI_RLN* rln_create(size_t depth, const std::vector<uint8_t>& zkey, const std::v
   if (r->prover->graph().tree_depth != depth)  // graph_from_raw expected depth (circuit/mod.rs:163-179)
     throw Error("Graph error: tree depth mismatch: expected " + std::to_string(depth) + ", got " +
                 std::to_string(r->prover->graph().tree_depth));
-  r->new_tree(depth);
+  r->open_tree(depth, tcfg);
   return r.release();
 }
 
@@ -999,8 +1163,8 @@ extern "C" {
 
 // ================================================================================ RLN object
 CResult_FFI_RLN_ptr_Vec_uint8_t ffi_rln_new(size_t tree_depth, const char* config_path) {
-  (void)config_path;  // tree config only selects the sled/pmtree persistence, out of scope
   return guard_ptr<CResult_FFI_RLN_ptr_Vec_uint8_t>([&]() -> FFI_RLN_t* {
+    TreeConfig tcfg = tree_config_from_file(config_path);  // RLN::new: the config is parsed first (public.rs:113)
     // RLN::new always loads the embedded depth-20 circuit (public.rs:110-128, circuit/mod.rs:29-42);
     // the tree is built with the requested depth.
     std::string dir = resource_dir(20);
@@ -1012,18 +1176,17 @@ CResult_FFI_RLN_ptr_Vec_uint8_t ffi_rln_new(size_t tree_depth, const char* confi
     const char* mb = getenv("RLNAMD_MAX_BATCH");
     cfg.max_batch = mb && *mb ? (size_t)atoll(mb) : 64;
     r->prover.reset(new Prover(zkey.data(), zkey.size(), graph.data(), graph.size(), cfg));
-    r->new_tree(tree_depth);
+    r->open_tree(tree_depth, tcfg);
     return (FFI_RLN_t*)r.release();
   });
 }
 CResult_FFI_RLN_ptr_Vec_uint8_t ffi_rln_new_with_params(size_t tree_depth, const Vec_uint8_t* zkey_data,
                                                         const Vec_uint8_t* graph_data, const char* config_path) {
-  (void)config_path;
   return guard_ptr<CResult_FFI_RLN_ptr_Vec_uint8_t>([&]() -> FFI_RLN_t* {
     if (!zkey_data || !graph_data) throw Error("ZKey error: Empty zkey bytes");
     std::vector<uint8_t> z(zkey_data->ptr, zkey_data->ptr + zkey_data->len);
     std::vector<uint8_t> g(graph_data->ptr, graph_data->ptr + graph_data->len);
-    return (FFI_RLN_t*)rln_create(tree_depth, z, g);
+    return (FFI_RLN_t*)rln_create(tree_depth, z, g, tree_config_from_file(config_path));
   });
 }
 void ffi_rln_free(FFI_RLN_t* rln) { delete (FFI_RLN*)rln; }
@@ -1328,7 +1491,13 @@ static std::vector<CFr> vec_of(const Vec_CFr_t* v) {
   return std::vector<CFr>((const CFr*)v->ptr, (const CFr*)v->ptr + v->len);
 }
 CBoolResult_t ffi_set_tree(FFI_RLN_t** rln, size_t tree_depth) {
-  return guard_bool([&]() { RLNM(rln).new_tree(tree_depth); return true; });
+  return guard_bool([&]() {  // PoseidonTree::default(depth): the stored tree is dropped (flushed), the new one is temporary
+    FFI_RLN& r = RLNM(rln);
+    r.flush();
+    r.store.clear();
+    r.new_tree(tree_depth);
+    return true;
+  });
 }
 CBoolResult_t ffi_delete_leaf(FFI_RLN_t** rln, size_t index) {
   return guard_bool([&]() { RLNM(rln).del(index); return true; });
@@ -1349,6 +1518,8 @@ CBoolResult_t ffi_set_leaves_from(FFI_RLN_t** rln, size_t index, const Vec_CFr_t
 CBoolResult_t ffi_init_tree_with_leaves(FFI_RLN_t** rln, const Vec_CFr_t* leaves) {
   return guard_bool([&]() {  // public.rs:376-379
     FFI_RLN& r = RLNM(rln);
+    r.flush();  // set_tree(depth) then set_leaves_from (public.rs:376-379): a default, temporary tree
+    r.store.clear();
     r.new_tree(r.tree.depth);
     r.override_range(0, vec_of(leaves), {});
     return true;
@@ -1402,9 +1573,8 @@ CBoolResult_t ffi_set_metadata(FFI_RLN_t** rln, const Vec_uint8_t* metadata) {
 CResult_Vec_uint8_Vec_uint8_t ffi_get_metadata(FFI_RLN_t* const* rln) {
   return guard_bytes([&]() { return RLNM(rln).metadata; });
 }
-CBoolResult_t ffi_flush(FFI_RLN_t** rln) {
-  (void)rln;
-  return CBoolResult_t{true, no_err()};  // nothing buffered: the tree lives in HBM
+CBoolResult_t ffi_flush(FFI_RLN_t** rln) {  // temporary trees: nothing to do, the tree lives in HBM
+  return guard_bool([&]() { RLNM(rln).flush(); return true; });
 }
 
 // ================================================================================ CFr / Vec helpers

@@ -31,6 +31,8 @@ struct MerkleTreeDev {
   void rehash(size_t lo_node, size_t hi_node);  // update_hashes :360-399
 
   void get_node_host(size_t node, uint8_t out_le[32]);
+  // leaves [first, first + n) as canonical 32-byte LE values (tree snapshots)
+  void get_leaves_host(size_t first, size_t n, uint8_t* out_le);
   // one proof -> host (elems: depth*32 B canonical LE bottom-up, bits: depth bytes)
   void proof_host(size_t leaf, uint8_t* elems_le, uint8_t* bits);
   // `count` proofs for leaves [first, first+count) written to device buffers

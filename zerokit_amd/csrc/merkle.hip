@@ -2,6 +2,8 @@
 
 #include <string.h>
 
+#include <vector>
+
 #include "poseidon.h"
 
 namespace rlnamd {
@@ -153,6 +155,19 @@ void MerkleTreeDev::get_node_host(size_t node, uint8_t out_le[32]) {
   uint32_t c[8];
   v.to_canonical(c);
   memcpy(out_le, c, 32);
+}
+
+void MerkleTreeDev::get_leaves_host(size_t first, size_t n, uint8_t* out_le) {
+  if (first + n > capacity() || first + n < first) throw Error("InvalidLeaf");
+  if (n == 0) return;
+  std::vector<Fr> v(n);
+  RLN_HIP(hipMemcpyAsync(v.data(), nodes.p + (capacity() - 1 + first), n * sizeof(Fr), hipMemcpyDeviceToHost, stream));
+  RLN_HIP(hipStreamSynchronize(stream));
+  for (size_t i = 0; i < n; i++) {
+    uint32_t c[8];
+    v[i].to_canonical(c);
+    memcpy(out_le + 32 * i, c, 32);
+  }
 }
 
 void MerkleTreeDev::proofs_device(size_t first, size_t count, uint8_t* d_elems, uint8_t* d_bits) {

@@ -316,7 +316,8 @@ class RLNPartialProof:
 
 
 class RLN:
-    """rln::public::RLN.  `RLN(tree_depth)` == RLN::new(tree_depth, "") (public.rs:110-128);
+    """rln::public::RLN.  `RLN(tree_depth)` == RLN::new(tree_depth, "") (public.rs:110-128); `tree_config` is what
+    ffi_rln_new takes: the PATH of a JSON file with the PmTreeConfig keys (ffi_rln.rs:24-57);
     `RLN.new_with_params(depth, zkey, graph)` == RLN::new_with_params (public.rs:166-196)."""
 
     def __init__(self, tree_depth=20, tree_config="", _handle=None):
@@ -394,6 +395,14 @@ class RLN:
 
     def get_metadata(self):
         return _take_bytes(lib().ffi_get_metadata(C.byref(self._h)))
+
+    def flush(self):
+        """ffi_flush (ffi_tree.rs): writes a persistent tree's snapshot; nothing to do for a temporary tree"""
+        _ok_bool(lib().ffi_flush(C.byref(self._h)))
+
+    def close(self):
+        """drop the object now (a persistent tree is flushed, as sled does when the database is dropped)"""
+        self.__del__()
 
     # ---- zkSNARK APIs (public.rs:595-771)
     def generate_rln_proof(self, witness: RLNWitnessInput) -> RLNProof:
