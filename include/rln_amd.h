@@ -148,6 +148,11 @@ void rlnamd_msm_free(rlnamd_msm* m);
  * `threads` pseudo-random walks of `iters` signed additions each (doublings, cancellations, restarts from infinity
  * included).  group 1 = G1, 2 = G2 (g2_gen_xy_le = generator x.c0 | x.c1 | y.c0 | y.c1, canonical LE; NULL for G1).
  * *mismatches = number of walks whose affine results differ (0 expected). */
+/* Parameter self-check, host only (no device, not a hashing path): derives the Poseidon parameters for `arity`
+ * inputs (Grain LFSR, utils/src/poseidon/poseidon_constants.rs:207-261) and evaluates ONE hash twice on the host --
+ * with the reference's dense rounds (poseidon_hash.rs:97-135) and with the equivalent sparse partial rounds the device
+ * kernels use -- so the CPU test suite can compare both with the oracle. */
+int rlnamd_poseidon_params_check(const uint8_t* inputs_le, size_t arity, uint8_t out_dense_le[32], uint8_t out_sparse_le[32]);
 int rlnamd_selftest_fq29(int group, uint32_t threads, uint32_t iters, const uint8_t* g2_gen_xy_le, uint32_t* mismatches);
 /* points: n x (x || y) canonical LE affine, all-zero = infinity; scalars: n x 32 bytes canonical LE */
 int rlnamd_msm_set(rlnamd_msm* m, const uint8_t* points_xy_le, const uint8_t* scalars_le, size_t n);

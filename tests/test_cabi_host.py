@@ -315,3 +315,28 @@ def test_slashing_host_math_and_multi_proof_values_bytes():
         v1.y
     with pytest.raises(RLNError, match="ys has length 2, but the field nullifiers has length 1"):
         RLNProofValues.from_bytes_le(multi_bytes(9, 77, 1, [1, 2], [3], [1, 0]))
+
+
+def test_poseidon_parameter_derivation_dense_and_sparse_forms():
+    """The library's own Grain-LFSR derivation, checked on the host for every width t = 2..9: the dense rounds of
+    the reference (poseidon_hash.rs:97-135) and the equivalent sparse partial rounds the device kernels use must
+    both give the oracle's hash (reference KATs: utils/tests/poseidon_hash_test.rs:21-130).  No device involved."""
+    import ctypes as C
+    import random
+    from oracle.pyref.poseidon import poseidon
+    from zerokit_amd import lib
+    from zerokit_amd._native import check
+    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    rnd = random.Random(5)
+    for arity in range(1, 9):
+        for row in ([0] * arity, [R - 1] * arity, [rnd.randrange(R) for _ in range(arity)]):
+            buf = b"".join(v.to_bytes(32, "little") for v in row)
+            d, s = C.create_string_buffer(32), C.create_string_buffer(32)
+            check(lib().rlnamd_poseidon_params_check(buf, arity, d, s))
+            want = poseidon(row)
+            assert int.from_bytes(d.raw, "little") == want, ("dense", arity)
+            assert int.from_bytes(s.raw, "little") == want, ("sparse", arity)
+    d, s = C.create_string_buffer(32), C.create_string_buffer(32)
+    assert lib().rlnamd_poseidon_params_check((1).to_bytes(32, "little") + (2).to_bytes(32, "little"), 2, d, s) == 0
+    assert int.from_bytes(s.raw, "little") == \
+        7853200120776062878684798364095072458815029376092732009249414926327459813530   # circomlib's published vector for poseidon([1, 2]) (not from the reference tree)

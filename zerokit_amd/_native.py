@@ -119,6 +119,7 @@ SIGNATURES = {
     "rlnamd_proof_compress": (C.c_int, [C.c_char_p, C.c_char_p]),
     "rlnamd_proof_decompress": (C.c_int, [C.c_char_p, C.c_char_p]),
     "rlnamd_msm_new": (C.c_int, [C.c_size_t, PP]),
+    "rlnamd_poseidon_params_check": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p]),
     "rlnamd_selftest_fq29": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_char_p, C.POINTER(C.c_uint32)]),
     "rlnamd_msm_free": (None, [P]),
     "rlnamd_msm_set": (C.c_int, [P, C.c_char_p, C.c_char_p, C.c_size_t]),

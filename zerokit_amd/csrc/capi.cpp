@@ -330,6 +330,27 @@ int rlnamd_msm_new(size_t capacity, rlnamd_msm** out) {
   RLN_CATCH
 }
 void rlnamd_msm_free(rlnamd_msm* m) { delete m; }
+int rlnamd_poseidon_params_check(const uint8_t* inputs_le, size_t arity, uint8_t out_dense_le[32], uint8_t out_sparse_le[32]) {
+  RLN_TRY
+  if (arity == 0) throw Error("Empty input provided");
+  if (arity > 8) throw Error("No parameters found for input length " + std::to_string(arity));
+  PoseidonParams P = poseidon_derive_params((int)arity + 1);
+  std::vector<Fr> in(arity);
+  for (size_t i = 0; i < arity; i++) {
+    uint32_t tmp[8];
+    memcpy(tmp, inputs_le + 32 * i, 32);
+    if (limbs_geq(tmp, FrParams::MOD)) throw Error("Non-canonical field element: value is not in [0, r-1]");
+    in[i] = Fr::from_canonical(tmp);
+  }
+  Fr d, sp;
+  poseidon_params_eval_host(P, in.data(), &d, &sp);
+  uint32_t c[8];
+  d.to_canonical(c);
+  memcpy(out_dense_le, c, 32);
+  sp.to_canonical(c);
+  memcpy(out_sparse_le, c, 32);
+  RLN_CATCH
+}
 int rlnamd_selftest_fq29(int group, uint32_t threads, uint32_t iters, const uint8_t* g2_gen_xy_le, uint32_t* mismatches) {
   RLN_TRY
   *mismatches = selftest_fq29(group, threads, iters, g2_gen_xy_le);

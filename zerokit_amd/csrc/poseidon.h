@@ -2,6 +2,17 @@
 // (/root/reference/utils/src/poseidon/poseidon_hash.rs:97-135: per round add t constants, x^5 on all lanes
 // (full) or lane 0 (partial), dense t x t MDS; output state[0]) with the Grain-LFSR constants of
 // poseidon_constants.rs:15-261 and the (t, R_F, R_P) table of rln/src/hashers.rs:14-23.
+//
+// The device kernels evaluate the SAME function with the partial rounds in an equivalent sparse form (field
+// arithmetic is exact, so the output bits cannot change; every KAT and the random parity tests run through it):
+//   * constants: in a partial round only lane 0 passes the S-box, so the constants of the other lanes commute with it
+//     and are pushed forward through M into the next round's constants: k_r = c_r + v_(r-1), v_r = M (0, k_r[1..]);
+//     round r adds k_r[0] to lane 0 only and v_(R_P) joins the constants of the first full round that follows;
+//   * matrices: M_r = M A_(r-1) (A_0 = I) is factored as A_r B_r with A_r = [[1, 0], [0, Mhat_r]] and
+//     B_r = [[m00, v^T], [Mhat_r^-1 w, I]]; A_r leaves lane 0 alone, so it commutes with the next S-box and is merged
+//     into M_(r+1).  Round r is then  x0 <- (x0 + k_r[0])^5;  (x0, x^) <- (row0_r . x,  x^ + u_r x0):
+//     2 t - 1 products instead of t^2; after the last partial round the state takes the leftover A_(R_P) once.
+// poseidon_derive_params computes (k, row0, u, A) on the host from the Grain constants.
 #pragma once
 #include <vector>
 
@@ -19,10 +30,15 @@ struct PoseidonParams {
   int t = 0, rf = 0, rp = 0;
   std::vector<Fr> ark;  // (rf+rp)*t, Montgomery
   std::vector<Fr> mds;  // t*t row-major, Montgomery
+  // sparse form of the partial rounds (header comment): per round k0[r], row0[r][t], u[r][t-1]; leftover matrix
+  // a_fin (t-1 x t-1, row-major); ark2 = constants of the last rf/2 full rounds with v_(R_P) added to the first
+  std::vector<Fr> k0, row0, u, a_fin, ark2;
 };
 
 // host: derive the constants exactly as find_poseidon_ark_and_mds does (poseidon_constants.rs:207-261)
 PoseidonParams poseidon_derive_params(int t);
+// host: one hash with the dense rounds of the reference and one with the sparse partial rounds (parameter self-check)
+void poseidon_params_eval_host(const PoseidonParams& P, const Fr* in, Fr* out_dense, Fr* out_sparse);
 
 // device-resident constant tables for t = 2..9
 struct PoseidonDev {
@@ -30,6 +46,9 @@ struct PoseidonDev {
   DevBuf<Fr> ark[POSEIDON_MAX_T + 1];
   DevBuf<Fr> mds[POSEIDON_MAX_T + 1];
   DevBuf<uint32_t> ark29[POSEIDON_MAX_T + 1], mds29[POSEIDON_MAX_T + 1];  // the same constants as Fr29 (9 words each)
+  DevBuf<uint32_t> opt29[POSEIDON_MAX_T + 1];  // k0 | row0 | u | a_fin | ark2 as Fr29
+  size_t off_k0[POSEIDON_MAX_T + 1] = {0}, off_row0[POSEIDON_MAX_T + 1] = {0}, off_u[POSEIDON_MAX_T + 1] = {0},
+         off_afin[POSEIDON_MAX_T + 1] = {0}, off_ark2[POSEIDON_MAX_T + 1] = {0};
   void init();
   bool ready = false;
 };
@@ -42,6 +61,7 @@ struct PoseidonView {
   int rf, rp;
   const uint32_t* ark29;  // Fr29 images of ark / mds (fq29.h), 9 words per element
   const uint32_t* mds29;
+  const uint32_t *k0, *row0, *u, *a_fin, *ark2;  // sparse partial rounds (Fr29)
 };
 PoseidonView poseidon_view(int t);
 
@@ -155,6 +175,49 @@ __device__ __forceinline__ void poseidon_round29(Fr29* st, const uint32_t* __res
 #pragma unroll
   for (int j = 0; j < T; j++) st[j] = nx[j];
 }
+// sum_j c[j] x[j], c = N constants at `c` (9 words each), any T <= 9; x normalised
+template <int T>
+__device__ __forceinline__ Fr29 poseidon_row29(const uint32_t* __restrict__ c, const Fr29* x) {
+  Fr29 m[T];
+#pragma unroll
+  for (int j = 0; j < T; j++) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) m[j].v[k] = c[j * 9 + k];
+  }
+  if constexpr (T <= 5) {
+    return poseidon_dotn29<T>(m, x);
+  } else {
+    Fr29 lo = poseidon_dotn29<5>(m, x);
+    const Fr29 hi = poseidon_dotn29<T - 5>(m + 5, x + 5);
+#pragma unroll
+    for (int k = 0; k < 9; k++) lo.v[k] += hi.v[k];
+    lo.normalize();
+    return lo;
+  }
+}
+// One partial round in the sparse form: x0 <- (x0 + k)^5; x0' = row0 . x; x_i += u_i x0.  All entries stay normalised;
+// lanes 1.. accumulate one product (< 1.1 r) per round, < 72 r after 64 rounds, inside the 261-bit range (169 r).
+template <int T>
+__device__ __forceinline__ void poseidon_partial29(Fr29* st, const uint32_t* __restrict__ k0,
+                                                   const uint32_t* __restrict__ row0, const uint32_t* __restrict__ u) {
+#pragma unroll
+  for (int k = 0; k < 9; k++) st[0].v[k] += k0[k];
+  const Fr29 x2 = Fr29::sqr(st[0]);
+  const Fr29 x4 = Fr29::sqr(x2);
+  st[0] = Fr29::mul(x4, st[0]);
+  const Fr29 n0 = poseidon_row29<T>(row0, st);
+#pragma unroll
+  for (int i = 1; i < T; i++) {
+    Fr29 ui;
+#pragma unroll
+    for (int k = 0; k < 9; k++) ui.v[k] = u[(i - 1) * 9 + k];
+    const Fr29 p = Fr29::mul(ui, st[0]);
+#pragma unroll
+    for (int k = 0; k < 9; k++) st[i].v[k] += p.v[k];
+    st[i].normalize();
+  }
+  st[0] = n0;
+}
 template <int T>
 __device__ __forceinline__ Fr poseidon_hash_dev(const Fr* in, const PoseidonView& pv) {
   Fr29 st[T];
@@ -165,8 +228,17 @@ __device__ __forceinline__ Fr poseidon_hash_dev(const Fr* in, const PoseidonView
   const uint32_t* ark = pv.ark29;
 #pragma unroll 1
   for (int r = 0; r < half; r++, ark += T * 9) poseidon_round29<T, true>(st, ark, pv.mds29);
+  const uint32_t *k0 = pv.k0, *row0 = pv.row0, *u = pv.u;
 #pragma unroll 1
-  for (int r = 0; r < pv.rp; r++, ark += T * 9) poseidon_round29<T, false>(st, ark, pv.mds29);
+  for (int r = 0; r < pv.rp; r++, k0 += 9, row0 += T * 9, u += (T - 1) * 9) poseidon_partial29<T>(st, k0, row0, u);
+  {  // leftover A_(R_P) on lanes 1..T-1
+    Fr29 nx[T];
+#pragma unroll
+    for (int i = 1; i < T; i++) nx[i] = poseidon_row29<T - 1>(pv.a_fin + (i - 1) * (T - 1) * 9, st + 1);
+#pragma unroll
+    for (int i = 1; i < T; i++) st[i] = nx[i];
+  }
+  ark = pv.ark2;
 #pragma unroll 1
   for (int r = 0; r < half; r++, ark += T * 9) poseidon_round29<T, true>(st, ark, pv.mds29);
   return st[0].to_fq();

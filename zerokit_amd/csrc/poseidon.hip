@@ -64,6 +64,85 @@ const int kRoundParams[][4] = {{2, 8, 56, 0}, {3, 8, 57, 0}, {4, 8, 56, 0}, {5, 
                                {6, 8, 60, 0}, {7, 8, 63, 0}, {8, 8, 64, 0}, {9, 8, 63, 0}};
 }  // namespace
 
+// n x n inverse over Fr (Gauss-Jordan); the blocks Mhat_r of an MDS-derived matrix are invertible
+static std::vector<Fr> mat_inv(std::vector<Fr> a, int n) {
+  std::vector<Fr> b((size_t)n * n, Fr::zero());
+  for (int i = 0; i < n; i++) b[i * n + i] = Fr::one();
+  for (int c = 0; c < n; c++) {
+    int p = c;
+    while (p < n && a[p * n + c].is_zero()) p++;
+    if (p == n) throw Error("Poseidon: singular block in the sparse round derivation");
+    for (int j = 0; j < n; j++) {
+      std::swap(a[c * n + j], a[p * n + j]);
+      std::swap(b[c * n + j], b[p * n + j]);
+    }
+    const Fr iv = a[c * n + c].inv();
+    for (int j = 0; j < n; j++) {
+      a[c * n + j] = a[c * n + j] * iv;
+      b[c * n + j] = b[c * n + j] * iv;
+    }
+    for (int r = 0; r < n; r++) {
+      if (r == c || a[r * n + c].is_zero()) continue;
+      const Fr f = a[r * n + c];
+      for (int j = 0; j < n; j++) {
+        a[r * n + j] = a[r * n + j] - f * a[c * n + j];
+        b[r * n + j] = b[r * n + j] - f * b[c * n + j];
+      }
+    }
+  }
+  return b;
+}
+
+// the equivalent sparse form of the partial rounds (poseidon.h header comment)
+static void derive_sparse_rounds(PoseidonParams& P) {
+  const int t = P.t, half = P.rf / 2, n = t - 1;
+  const std::vector<Fr>& M = P.mds;
+  // constants pushed forward
+  std::vector<Fr> v(t, Fr::zero());
+  for (int r = 0; r < P.rp; r++) {
+    const Fr* c = P.ark.data() + (size_t)(half + r) * t;
+    std::vector<Fr> k(t);
+    for (int j = 0; j < t; j++) k[j] = c[j] + v[j];
+    P.k0.push_back(k[0]);
+    for (int i = 0; i < t; i++) {
+      Fr acc = Fr::zero();
+      for (int j = 1; j < t; j++) acc = acc + M[i * t + j] * k[j];
+      v[i] = acc;
+    }
+  }
+  P.ark2.assign(P.ark.begin() + (size_t)(half + P.rp) * t, P.ark.end());
+  for (int j = 0; j < t; j++) P.ark2[j] = P.ark2[j] + v[j];
+  // matrices: M_r = M A_(r-1) = A_r B_r
+  std::vector<Fr> A((size_t)t * t, Fr::zero());
+  for (int i = 0; i < t; i++) A[i * t + i] = Fr::one();
+  for (int r = 0; r < P.rp; r++) {
+    std::vector<Fr> Mr((size_t)t * t, Fr::zero());
+    for (int i = 0; i < t; i++)
+      for (int j = 0; j < t; j++) {
+        Fr acc = Fr::zero();
+        for (int l = 0; l < t; l++) acc = acc + M[i * t + l] * A[l * t + j];
+        Mr[i * t + j] = acc;
+      }
+    std::vector<Fr> hat((size_t)n * n), w(n);
+    for (int i = 0; i < n; i++) {
+      w[i] = Mr[(i + 1) * t];
+      for (int j = 0; j < n; j++) hat[i * n + j] = Mr[(i + 1) * t + j + 1];
+    }
+    for (int j = 0; j < t; j++) P.row0.push_back(Mr[j]);
+    const std::vector<Fr> hi = mat_inv(hat, n);
+    for (int i = 0; i < n; i++) {
+      Fr acc = Fr::zero();
+      for (int j = 0; j < n; j++) acc = acc + hi[i * n + j] * w[j];
+      P.u.push_back(acc);
+    }
+    std::fill(A.begin(), A.end(), Fr::zero());
+    A[0] = Fr::one();
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++) A[(i + 1) * t + j + 1] = hat[i * n + j];
+    if (r == P.rp - 1) P.a_fin = hat;
+  }
+}
+
 PoseidonParams poseidon_derive_params(int t) {
   const int* rp = nullptr;
   for (auto& p : kRoundParams)
@@ -83,7 +162,60 @@ PoseidonParams poseidon_derive_params(int t) {
   P.mds.resize(t * t);
   for (int i = 0; i < t; i++)
     for (int j = 0; j < t; j++) P.mds[i * t + j] = (xs[i] + ys[j]).inv();
+  derive_sparse_rounds(P);
   return P;
+}
+
+// Host evaluation of the parameter set in both forms (no device): the reference's dense rounds and the sparse
+// partial rounds the kernels use.  Only the parameter self-check (rlnamd_poseidon_params_check) calls it.
+void poseidon_params_eval_host(const PoseidonParams& P, const Fr* in, Fr* out_dense, Fr* out_sparse) {
+  const int t = P.t, half = P.rf / 2;
+  auto pow5 = [](const Fr& x) { Fr x2 = x.sqr(); return x2.sqr() * x; };
+  auto mix = [&](std::vector<Fr>& s) {
+    std::vector<Fr> n(t);
+    for (int i = 0; i < t; i++) {
+      Fr acc = Fr::zero();
+      for (int j = 0; j < t; j++) acc = acc + P.mds[i * t + j] * s[j];
+      n[i] = acc;
+    }
+    s = n;
+  };
+  std::vector<Fr> s(t, Fr::zero());
+  for (int j = 1; j < t; j++) s[j] = in[j - 1];
+  for (int r = 0; r < P.rf + P.rp; r++) {  // poseidon_hash.rs:117-133
+    for (int j = 0; j < t; j++) s[j] = s[j] + P.ark[(size_t)r * t + j];
+    const bool full = r < half || r >= half + P.rp;
+    for (int j = 0; j < (full ? t : 1); j++) s[j] = pow5(s[j]);
+    mix(s);
+  }
+  *out_dense = s[0];
+  std::fill(s.begin(), s.end(), Fr::zero());
+  for (int j = 1; j < t; j++) s[j] = in[j - 1];
+  for (int r = 0; r < half; r++) {
+    for (int j = 0; j < t; j++) s[j] = pow5(s[j] + P.ark[(size_t)r * t + j]);
+    mix(s);
+  }
+  for (int r = 0; r < P.rp; r++) {
+    const Fr x0 = pow5(s[0] + P.k0[r]);
+    Fr n0 = P.row0[(size_t)r * t] * x0;
+    for (int j = 1; j < t; j++) n0 = n0 + P.row0[(size_t)r * t + j] * s[j];
+    for (int j = 1; j < t; j++) s[j] = s[j] + P.u[(size_t)r * (t - 1) + j - 1] * x0;
+    s[0] = n0;
+  }
+  {
+    std::vector<Fr> n(t);
+    for (int i = 1; i < t; i++) {
+      Fr acc = Fr::zero();
+      for (int j = 1; j < t; j++) acc = acc + P.a_fin[(size_t)(i - 1) * (t - 1) + j - 1] * s[j];
+      n[i] = acc;
+    }
+    for (int i = 1; i < t; i++) s[i] = n[i];
+  }
+  for (int r = 0; r < half; r++) {
+    for (int j = 0; j < t; j++) s[j] = pow5(s[j] + P.ark2[(size_t)r * t + j]);
+    mix(s);
+  }
+  *out_sparse = s[0];
 }
 
 __global__ void k_fr_to29(const Fr* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n) {
@@ -110,6 +242,17 @@ void PoseidonDev::init() {
     mds29[t].alloc(P.mds.size() * 9);
     hipLaunchKernelGGL(k_fr_to29, dim3(div_up(P.ark.size(), 64)), dim3(64), 0, 0, ark[t].p, ark29[t].p, (uint32_t)P.ark.size());
     hipLaunchKernelGGL(k_fr_to29, dim3(div_up(P.mds.size(), 64)), dim3(64), 0, 0, mds[t].p, mds29[t].p, (uint32_t)P.mds.size());
+    // sparse partial rounds: k0 | row0 | u | a_fin | ark2
+    std::vector<Fr> all;
+    off_k0[t] = all.size(); all.insert(all.end(), P.k0.begin(), P.k0.end());
+    off_row0[t] = all.size(); all.insert(all.end(), P.row0.begin(), P.row0.end());
+    off_u[t] = all.size(); all.insert(all.end(), P.u.begin(), P.u.end());
+    off_afin[t] = all.size(); all.insert(all.end(), P.a_fin.begin(), P.a_fin.end());
+    off_ark2[t] = all.size(); all.insert(all.end(), P.ark2.begin(), P.ark2.end());
+    DevBuf<Fr> tmp(all.size());
+    RLN_HIP(hipMemcpy(tmp.p, all.data(), all.size() * sizeof(Fr), hipMemcpyHostToDevice));
+    opt29[t].alloc(all.size() * 9);
+    hipLaunchKernelGGL(k_fr_to29, dim3(div_up(all.size(), 64)), dim3(64), 0, 0, tmp.p, opt29[t].p, (uint32_t)all.size());
     RLN_HIP(hipDeviceSynchronize());
   }
   ready = true;
@@ -124,7 +267,9 @@ PoseidonDev& poseidon_dev() {
 PoseidonView poseidon_view(int t) {
   if (t < 2 || t > POSEIDON_MAX_T) throw Error("unsupported Poseidon width t=" + std::to_string(t));
   PoseidonDev& d = poseidon_dev();
-  return {d.ark[t].p, d.mds[t].p, d.rf[t], d.rp[t], d.ark29[t].p, d.mds29[t].p};
+  const uint32_t* o = d.opt29[t].p;
+  return {d.ark[t].p, d.mds[t].p, d.rf[t], d.rp[t], d.ark29[t].p, d.mds29[t].p, o + 9 * d.off_k0[t], o + 9 * d.off_row0[t],
+          o + 9 * d.off_u[t], o + 9 * d.off_afin[t], o + 9 * d.off_ark2[t]};
 }
 
 template <int T>
