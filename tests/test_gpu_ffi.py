@@ -375,7 +375,9 @@ def test_concurrent_proving_on_one_object():
 def test_persistent_tree_config(tmp_path):
     """PmTreeConfig (pm_tree_adapter.rs:71-176) through ffi_rln_new's config file: a non-temporary tree with a path
     comes back after the object is dropped (leaves, next index, root, metadata); flush writes without dropping;
-    set_tree replaces it by a temporary tree; the config errors carry the reference's texts."""
+    set_tree replaces it by a temporary tree; the config errors carry the reference's texts.  Same flows as
+    rln/tests/pm_tree.rs:58-83 (config from JSON + reopen), :110-130 (persistence incl. metadata), :133-149 (depth
+    mismatch on reload), :152-170 (deleted leaf stays empty after reload), :435-468 (multiple reopen)."""
     import json
     from zerokit_amd.public import RLN
     store = tmp_path / "tree_db"
