@@ -820,7 +820,7 @@ struct Slot {
   uint32_t* h_values = nullptr;
   uint32_t* h_err = nullptr;
   hipEvent_t evA = nullptr, evB = nullptr, evB2 = nullptr, evR = nullptr, evC = nullptr, evW = nullptr, evV = nullptr;
-  hipEvent_t t[14] = {};  // timing marks
+  hipEvent_t t[15] = {};  // timing marks
   bool used = false;
   size_t n = 0;
 };
@@ -830,7 +830,7 @@ struct Prover::Impl {
   hipStream_t sV[2] = {nullptr, nullptr};  // proof values (24 chained Poseidon hashes per proof, latency-bound)
   int wstreams = 2;  // graph interpreters in flight (RLNAMD_WSTREAMS): 16 latency-bound waves each
   uint32_t seq = 0;  // batches enqueued: consecutive front ends alternate between sA and sA2
-  bool split_msm = false;  // G2 walk on its own stream: its workgroups fill the G1 kernel's tail (RLNAMD_MSM_SPLIT)
+  bool split_msm = true;   // G2 walk on its own stream: its workgroups fill the G1 kernel's tail (RLNAMD_MSM_SPLIT)
   float ms[PROVER_STAGES] = {0};
 
   uint32_t N = 0, NS = 0, NI = 0, nc = 0, ni = 0, n = 0;
@@ -870,6 +870,7 @@ struct Prover::Impl {
   Slot slot[NSLOT];
   int nslot = 5, nstreamA = 2;  // RLNAMD_SLOTS / RLNAMD_ASTREAMS
   WinSched ws{};                // window schedule of both comb tables
+  bool recode_front = true;     // RLNAMD_RECODE_FRONT
   uint32_t msm_lds = 0;         // RLNAMD_MSM_WAVES (waves per SIMD the G1 walk may occupy; 0 = no cap)
   int cur = 0;
   Slot* last = nullptr;
@@ -1036,7 +1037,10 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     D.nstreamA = env_int("RLNAMD_ASTREAMS", 2);
     D.use29 = env_int("RLNAMD_FQ29", 1) != 0;
     D.use29_g2 = env_int("RLNAMD_FQ29_G2", D.use29 ? 1 : 0) != 0;
-    D.split_msm = env_int("RLNAMD_MSM_SPLIT", 0) != 0;  // measured +1 % only; off keeps per-kernel timings clean
+    D.recode_front = env_int("RLNAMD_RECODE_FRONT", 1) != 0;
+    // the G1 walk is ~12 rounds of 2.8 ms workgroups: on one stream its last round leaves SIMDs idle until the G2
+    // walk may start; on two streams the walks of neighbouring batches fill each other's tails (+3.3 - 3.7 % measured)
+    D.split_msm = env_int("RLNAMD_MSM_SPLIT", 1) != 0;
     if (D.split_msm) RLN_HIP(hipStreamCreateWithPriority(&D.sB2, hipStreamNonBlocking, pick(1, lo)));
   }
   hipStream_t s = D.sB;
@@ -1435,13 +1439,23 @@ void Prover::run_async(size_t n, int mode) {
     hipLaunchKernelGGL(k_hquot, dim3(pg, D.n), dim3(64, 1), 0, sA2, S.abc.p, D.n, B, nbp);
   }
   RLN_HIP(hipEventRecord(S.t[4], sA2));
-  RLN_HIP(hipEventRecord(S.evA, sA2));
-  // ---------------- stage B
-  RLN_HIP(hipStreamWaitEvent(D.sB, S.evA, 0));
-  RLN_HIP(hipEventRecord(S.t[5], D.sB));
-  hipLaunchKernelGGL(k_recode, dim3(pg, D.NS + D.n + 3), dim3(64, 1), 0, D.sB, S.V.p, D.sig2node.p, D.NS,
+  // digit recoding either closes the front end (the MSM stream then carries nothing but the two table walks) or
+  // opens the MSM stage (RLNAMD_RECODE_FRONT=0)
+  hipStream_t sR = D.recode_front ? sA2 : D.sB;
+  if (!D.recode_front) {
+    RLN_HIP(hipEventRecord(S.evA, sA2));
+    RLN_HIP(hipStreamWaitEvent(D.sB, S.evA, 0));
+  }
+  RLN_HIP(hipEventRecord(S.t[5], sR));
+  hipLaunchKernelGGL(k_recode, dim3(pg, D.NS + D.n + 3), dim3(64, 1), 0, sR, S.V.p, D.sig2node.p, D.NS,
                      S.abc.p, D.n, D.rs.p, D.ws, S.digits.p, B, nbp);
-  RLN_HIP(hipEventRecord(S.t[6], D.sB));
+  RLN_HIP(hipEventRecord(S.t[6], sR));
+  // ---------------- stage B
+  if (D.recode_front) {
+    RLN_HIP(hipEventRecord(S.evA, sA2));
+    RLN_HIP(hipStreamWaitEvent(D.sB, S.evA, 0));
+  }
+  RLN_HIP(hipEventRecord(S.t[14], D.sB));
   hipStream_t s2 = D.split_msm ? D.sB2 : D.sB;
   if (D.split_msm) {
     RLN_HIP(hipEventRecord(S.evR, D.sB));
@@ -1527,7 +1541,7 @@ void Prover::sync() {
   D.sync_all();
   if (D.last) {
     Slot& S = *D.last;
-    const int pairs[PROVER_STAGES][2] = {{1, 2}, {12, 3}, {3, 4}, {5, 6}, {6, 7}, {11, 8}, {9, 10}, {0, 13}};
+    const int pairs[PROVER_STAGES][2] = {{1, 2}, {12, 3}, {3, 4}, {5, 6}, {14, 7}, {11, 8}, {9, 10}, {0, 13}};
     for (int i = 0; i < PROVER_STAGES; i++) RLN_HIP(hipEventElapsedTime(&D.ms[i], S.t[pairs[i][0]], S.t[pairs[i][1]]));
   }
 }
