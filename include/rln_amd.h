@@ -84,7 +84,8 @@ int rlnamd_prover_upload(rlnamd_prover* p, size_t n, const uint8_t* inputs_le, c
 int rlnamd_prover_run(rlnamd_prover* p, size_t n);      /* inputs already resident; blocks until done */
 /* Enqueue only: consecutive batches overlap on the device (front end of batch k+1 and back end of batch
  * k-1 beside the MSM of batch k); each batch ends with its proofs copied to pinned host memory.
- * rlnamd_prover_sync drains the pipeline; download / stage_ms refer to the last enqueued batch. */
+ * rlnamd_prover_sync drains the pipeline; download refers to the last enqueued batch, stage_ms to the mean over the
+ * batches still held in the workspace slots (the last <= 5 launches of the same kind). */
 int rlnamd_prover_run_async(rlnamd_prover* p, size_t n);
 int rlnamd_prover_sync(rlnamd_prover* p);
 /* proofs: n*128 (ark-serialize compressed Proof), coords: n*256 (affine A|B|C) or NULL,

@@ -74,6 +74,7 @@ class Prover {
   // batch ends with its proofs + values copied to pinned host memory.  sync() drains the pipeline.
   void run_async(size_t n, int mode = PROVE_FULL);
   void sync();
+  void sync_measure(bool last_only);
   // Partial proofs.  PROVE_PARTIAL: inputs carry only the partial witness (unknown slots zero); the result is
   // four points per proof, canonical affine [pi_a x,y | rho x,y | pi_b x.c0,x.c1,y.c0,y.c1 | pi_c x,y] = 320 B
   // (create_partial_proof_from_assignment, partial_proof.rs:108-179).  PROVE_FINISH: full inputs + (r, s) +
@@ -90,7 +91,8 @@ class Prover {
     run(n);
     download(n, out);
   }
-  // stage times of the last run() in ms (HIP events on the prover stream)
+  // stage spans in ms (HIP events on the stage's own stream), averaged over the batches still held in the workspace
+  // slots (the last <= 5 launches of the same kind); after run() of a single batch: that batch alone
   void stage_ms(float out[PROVER_STAGES]) const;
   // debug / parity taps (host copies, canonical LE): witness signals and h for proof p of the last run
   // public signals w[1..num_instance) of the first n proofs of the last run, n x (num_instance-1) x 32 bytes

@@ -1536,19 +1536,35 @@ void Prover::run_async(size_t n, int mode) {
   D.last = &S;
 }
 
-void Prover::sync() {
+void Prover::sync() { sync_measure(false); }
+
+void Prover::sync_measure(bool last_only) {
   Impl& D = *d_;
   D.sync_all();
   if (D.last) {
-    Slot& S = *D.last;
+    // stage spans, averaged over the batches still held in the workspace slots (the last <= nslot launches of the
+    // same kind): in the pipeline a span includes whatever shared the chip with it
     const int pairs[PROVER_STAGES][2] = {{1, 2}, {12, 3}, {3, 4}, {5, 6}, {14, 7}, {11, 8}, {9, 10}, {0, 13}};
-    for (int i = 0; i < PROVER_STAGES; i++) RLN_HIP(hipEventElapsedTime(&D.ms[i], S.t[pairs[i][0]], S.t[pairs[i][1]]));
+    float acc[PROVER_STAGES] = {0};
+    int cnt = 0;
+    for (int k = 0; k < D.nslot; k++) {
+      Slot& S = D.slot[k];
+      if (!S.used || S.mode != D.last->mode || S.n != D.last->n || (last_only && &S != D.last)) continue;
+      for (int i = 0; i < PROVER_STAGES; i++) {
+        float ms = 0;
+        RLN_HIP(hipEventElapsedTime(&ms, S.t[pairs[i][0]], S.t[pairs[i][1]]));
+        acc[i] += ms;
+      }
+      cnt++;
+    }
+    for (int i = 0; i < PROVER_STAGES; i++) D.ms[i] = cnt ? acc[i] / cnt : 0.f;
   }
 }
 
 void Prover::run(size_t n, int mode) {
+  sync();  // nothing else in flight: the stage spans of this batch are those of the stages by themselves
   run_async(n, mode);
-  sync();
+  sync_measure(true);
 }
 
 void Prover::upload_partial(size_t n, const uint8_t* coords320) {
