@@ -342,7 +342,12 @@ struct G1Acc29 {
 #pragma unroll
     for (int j = 0; j < 9; j++) X.v[j] = R2.v[j] + Fq29C::K4T[j] - (PPP.v[j] + 2 * Q.v[j]);
     X.normalize();                                    // X3 in (0.7 q, 5.2 q)
-    Fq29 D = Fq29::sub(Q, Fq29C::K6, X);              // Q - X3 < 7.1 q
+    // Q - X3 < 7.1 q, left un-normalised: limbs < 2^29 + 2^30.  In the dot product below its partner R is normalised,
+    // nY is lazy (< 2^30) and PPP normalised: a column is at most 9 (2^29 (2^29 + 2^30) + 2^30 2^29 + 2^58) =
+    // 54 2^58 < 2^64, so the 24-instruction carry chain of a normalisation is not needed here
+    Fq29 D;
+#pragma unroll
+    for (int j = 0; j < 9; j++) D.v[j] = Q.v[j] + Fq29C::K6[j] - X.v[j];
     Fq29 nY = Fq29::neg_lazy(Fq29C::K4, Y);           // lazy, < 4 q
     Y = Fq29::dot2(R, D, nY, PPP);                    // R (Q - X3) - Y PPP  < 1.3 q
   }
