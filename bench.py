@@ -11,7 +11,11 @@ scaling); timing = barrier + sync on both sides, max over ranks.
 
 Extra objects on the same line:
   roofline     -- dominant kernel (G1 table MSM): algorithmic MSM operand bytes per launch / its mean launch
-                  time from HIP events on the prover stream, against the 8 TB/s HBM peak.
+                  time (HIP events on the kernel's own stream, last five launches of the timed region: the walks
+                  of neighbouring batches overlap on two streams, so this span includes sharing the SIMDs;
+                  launch_ms_alone = the same launch with nothing else in flight, measured after the timed
+                  region), against the 8 TB/s HBM peak.  Defaults: K = 50 steps, W = 2 warm-up steps, comb
+                  tables on the 19-window schedule (207 GiB; smaller tables are tried if that does not fit).
   cpu_baseline -- the oracle's C restatement of the arkworks CPU path (oracle/c, kind "port") timed on a
                   bounded sample of the same witnesses on the host cores (rank 0, N = 1 only).
 """
