@@ -173,43 +173,58 @@ struct F29 {
   }
 
   // ---- conversions to / from the 8 x 32 Montgomery form of field.h (same residue, radix 2^256)
-  static __device__ __forceinline__ F29 from_fq(const Mont& a) {
-    F29 u;  // the integer a.v (= x 2^256 mod q, canonical) cut into 29-bit limbs
-#pragma unroll
-    for (int j = 0; j < 9; j++) {
-      const int bit = 29 * j, w = bit >> 5, s = bit & 31;
-      uint64_t lo = a.v[w], hi = w + 1 < 8 ? a.v[w + 1] : 0;
-      u.v[j] = (uint32_t)(((lo | (hi << 32)) >> s) & M);
-    }
-    return mul(u, from_const(C::FROM_FQ));  // x 2^256 2^266 / 2^261 = x 2^261
+  // the 256-bit integer of an 8 x 32 value cut into 29-bit limbs (no arithmetic)
+  static __device__ __forceinline__ F29 slice(const Mont& a) {
+    // written out limb by limb: an index computed from a loop variable kept callers' arrays of Mont values in scratch
+    // memory (the NTT pass's eight-element block)
+    const uint32_t a0 = a.v[0], a1 = a.v[1], a2 = a.v[2], a3 = a.v[3], a4 = a.v[4], a5 = a.v[5], a6 = a.v[6], a7 = a.v[7];
+    F29 u;
+    u.v[0] = a0 & M;
+    u.v[1] = ((a0 >> 29) | (a1 << 3)) & M;
+    u.v[2] = ((a1 >> 26) | (a2 << 6)) & M;
+    u.v[3] = ((a2 >> 23) | (a3 << 9)) & M;
+    u.v[4] = ((a3 >> 20) | (a4 << 12)) & M;
+    u.v[5] = ((a4 >> 17) | (a5 << 15)) & M;
+    u.v[6] = ((a5 >> 14) | (a6 << 18)) & M;
+    u.v[7] = ((a6 >> 11) | (a7 << 21)) & M;
+    u.v[8] = a7 >> 8;
+    return u;
   }
-  __device__ __forceinline__ Mont to_fq() const {
-    F29 t = mul(*this, from_const(C::TO_FQ));  // x 2^256 + (0 or 1) q, limbs normalised
-    // exact reduction into [0, q): subtract q when t >= q
+  // exact reduction of a normalised value < 2 q into [0, q), as 8 x 32 words
+  __device__ __forceinline__ Mont pack_reduced() const {
     uint32_t d[9];
     int64_t borrow = 0;
 #pragma unroll
     for (int j = 0; j < 9; j++) {
-      int64_t x = (int64_t)t.v[j] - (int64_t)C::P[j] + borrow;
+      int64_t x = (int64_t)v[j] - (int64_t)C::P[j] + borrow;
       d[j] = (uint32_t)x & (j < 8 ? M : 0xFFFFFFFFu);
       borrow = x >> (j < 8 ? 29 : 63);
     }
     const bool ge = borrow == 0;
-    uint32_t r[9];
-#pragma unroll
-    for (int j = 0; j < 9; j++) r[j] = ge ? d[j] : t.v[j];
-    Mont o;
-#pragma unroll
-    for (int w = 0; w < 8; w++) {
-      // bits [32 w, 32 w + 32) of sum r[j] 2^(29 j)
-      const int j0 = (32 * w) / 29, s = 32 * w - 29 * j0;
-      uint64_t acc = (uint64_t)r[j0] >> s;
-      acc |= (uint64_t)r[j0 + 1] << (29 - s);
-      if (j0 + 2 < 9) acc |= (uint64_t)r[j0 + 2] << (58 - s);
-      o.v[w] = (uint32_t)acc;
-    }
+    const uint32_t r0 = ge ? d[0] : v[0], r1 = ge ? d[1] : v[1], r2 = ge ? d[2] : v[2], r3 = ge ? d[3] : v[3],
+                   r4 = ge ? d[4] : v[4], r5 = ge ? d[5] : v[5], r6 = ge ? d[6] : v[6], r7 = ge ? d[7] : v[7],
+                   r8 = ge ? d[8] : v[8];
+    Mont o;  // bits [32 w, 32 w + 32) of sum r_j 2^(29 j), written out word by word (see slice)
+    o.v[0] = r0 | (r1 << 29);
+    o.v[1] = (r1 >> 3) | (r2 << 26);
+    o.v[2] = (r2 >> 6) | (r3 << 23);
+    o.v[3] = (r3 >> 9) | (r4 << 20);
+    o.v[4] = (r4 >> 12) | (r5 << 17);
+    o.v[5] = (r5 >> 15) | (r6 << 14);
+    o.v[6] = (r6 >> 18) | (r7 << 11);
+    o.v[7] = (r7 >> 21) | (r8 << 8);
     return o;
   }
+  static __device__ __forceinline__ F29 from_fq(const Mont& a) {
+    return mul(slice(a), from_const(C::FROM_FQ));  // x 2^256 2^266 / 2^261 = x 2^261
+  }
+  __device__ __forceinline__ Mont to_fq() const {
+    return mul(*this, from_const(C::TO_FQ)).pack_reduced();  // x 2^256 + (0 or 1) q, limbs normalised
+  }
+  // a w for an 8 x 32 Montgomery value a (a 2^256, canonical) and a constant held in this form (w 2^261): the 8 x 32
+  // integer re-sliced into 29-bit limbs times w 2^261, divided by 2^261, is (a w) 2^256 + (0 or 1) q -- the product in
+  // the 8 x 32 form without a conversion multiplication (~290 instead of ~375 instructions per product)
+  static __device__ __forceinline__ Mont mul_mont(const Mont& a, const F29& w29) { return mul(slice(a), w29).pack_reduced(); }
 };
 
 using Fq29 = F29<Fq29C, Fq>;

@@ -310,9 +310,31 @@ __global__ void __launch_bounds__(256) k_matvec(CsrView A, CsrView Bm, const Fr*
 #ifndef RLN_NTT_WAVES
 #define RLN_NTT_WAVES 1
 #endif
-template <int K, bool DIF>
-__global__ void __launch_bounds__(256, RLN_NTT_WAVES) k_ntt_pass(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0,
-                                                  const Fr* __restrict__ scale, uint32_t B, uint32_t nb) {
+__device__ __forceinline__ Fr29 load_fr29(const uint32_t* __restrict__ p) {
+  Fr29 w;
+#pragma unroll
+  for (int k = 0; k < 9; k++) w.v[k] = p[k];
+  return w;
+}
+// constants for Fr29::mul_mont: the Fr29 image (x 2^261, normalised) of 8 x 32 Montgomery values
+__global__ void __launch_bounds__(256) k_consts_to29(const Fr* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  Fr29 v = Fr29::from_fq(src[t]);
+  v.normalize();
+#pragma unroll
+  for (int k = 0; k < 9; k++) dst[(size_t)t * 9 + k] = v.v[k];
+}
+// M29: twiddles as Fr29 constants and Fr29::mul_mont products; otherwise 8 x 32 twiddles and products (RLNAMD_NTT29=0)
+template <int K, bool DIF, bool M29>
+__global__ void __launch_bounds__(256, RLN_NTT_WAVES) k_ntt_pass(Fr* __restrict__ data, const uint32_t* __restrict__ tw, int logn, int s0,
+                                                  const uint32_t* __restrict__ scale, uint32_t B, uint32_t nb) {
+  auto tmul = [&](const Fr& a, const uint32_t* __restrict__ tab, uint32_t idx) -> Fr {
+    if constexpr (M29)
+      return Fr29::mul_mont(a, load_fr29(tab + 9 * (size_t)idx));
+    else
+      return a * reinterpret_cast<const Fr*>(tab)[idx];
+  };
   constexpr int R = 1 << K;
   const uint32_t n = 1u << logn;
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
@@ -343,14 +365,15 @@ __global__ void __launch_bounds__(256, RLN_NTT_WAVES) k_ntt_pass(Fr* __restrict_
       uint32_t j = (uint32_t)(m & (half - 1)) * stride + lo;
       uint32_t ti = DIF ? (j << (s0 + t)) : (j << (logn - 1 - (s0 + t)));
       // the twiddle index is the same for all 64 lanes (lanes = proofs): force the scalar path so the
-      // twiddle rides in SGPRs instead of eight VGPRs per butterfly
-      Fr w = tw[__builtin_amdgcn_readfirstlane(ti)];
+      // twiddle rides in SGPRs instead of VGPRs.  Twiddles are held as Fr29 constants (w 2^261, 9 words): the
+      // product with an 8 x 32 value needs no conversion (Fr29::mul_mont, ~290 instead of ~375 instructions)
+      const uint32_t tix = __builtin_amdgcn_readfirstlane(ti);
       if (DIF) {
         Fr u = e[m], v = e[m + half];
         e[m] = u + v;
-        e[m + half] = (u - v) * w;
+        e[m + half] = tmul(u - v, tw, tix);
       } else {
-        Fr u = e[m], v = e[m + half] * w;
+        Fr u = e[m], v = tmul(e[m + half], tw, tix);
         e[m] = u + v;
         e[m + half] = u - v;
       }
@@ -360,7 +383,7 @@ __global__ void __launch_bounds__(256, RLN_NTT_WAVES) k_ntt_pass(Fr* __restrict_
   for (int m = 0; m < R; m++) {
     uint32_t pos = base + m * stride;
     Fr o = e[m];
-    if (scale) o = o * scale[__builtin_amdgcn_readfirstlane(pos)];
+    if (scale) o = tmul(o, scale, __builtin_amdgcn_readfirstlane(pos));
     x[(size_t)pos * B] = o;
   }
 }
@@ -841,6 +864,7 @@ struct Prover::Impl {
   DevBuf<uint32_t> a_ptr, a_col, b_ptr, b_col;
   DevBuf<Fr> a_coef, b_coef;
   DevBuf<Fr> tw_f, tw_i, coset;
+  DevBuf<uint32_t> tw_f29, tw_i29, coset29;  // the same constants as Fr29 (9 words each) for Fr29::mul_mont
   // MSM
   DevBuf<G1Affine> t1;
   DevBuf<G1Affine29> t1_29;  // G1 table in the 9 x 29-bit form (default; RLNAMD_FQ29=0 keeps the 8 x 32 walk)
@@ -871,6 +895,7 @@ struct Prover::Impl {
   int nslot = 5, nstreamA = 2;  // RLNAMD_SLOTS / RLNAMD_ASTREAMS
   WinSched ws{};                // window schedule of both comb tables
   bool recode_front = true;     // RLNAMD_RECODE_FRONT
+  bool ntt29 = false;           // RLNAMD_NTT29: NTT products through Fr29::mul_mont (measured: no gain, see launch site)
   uint32_t msm_lds = 0;         // RLNAMD_MSM_WAVES (waves per SIMD the G1 walk may occupy; 0 = no cap)
   int cur = 0;
   Slot* last = nullptr;
@@ -1038,6 +1063,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     D.use29 = env_int("RLNAMD_FQ29", 1) != 0;
     D.use29_g2 = env_int("RLNAMD_FQ29_G2", D.use29 ? 1 : 0) != 0;
     D.recode_front = env_int("RLNAMD_RECODE_FRONT", 1) != 0;
+    D.ntt29 = env_int("RLNAMD_NTT29", 0) != 0;
     // the G1 walk is ~12 rounds of 2.8 ms workgroups: on one stream its last round leaves SIMDs idle until the G2
     // walk may start; on two streams the walks of neighbouring batches fill each other's tails (+3.3 - 3.7 % measured)
     D.split_msm = env_int("RLNAMD_MSM_SPLIT", 1) != 0;
@@ -1138,6 +1164,13 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     D.tw_f.upload(tf.data(), tf.size(), s);
     D.tw_i.upload(ti.data(), ti.size(), s);
     D.coset.upload(cs.data(), cs.size(), s);
+    D.tw_f29.alloc(tf.size() * 9);
+    D.tw_i29.alloc(ti.size() * 9);
+    D.coset29.alloc(cs.size() * 9);
+    hipLaunchKernelGGL(k_consts_to29, dim3(div_up(tf.size(), 256)), dim3(256), 0, s, D.tw_f.p, D.tw_f29.p, (uint32_t)tf.size());
+    hipLaunchKernelGGL(k_consts_to29, dim3(div_up(ti.size(), 256)), dim3(256), 0, s, D.tw_i.p, D.tw_i29.p, (uint32_t)ti.size());
+    hipLaunchKernelGGL(k_consts_to29, dim3(div_up(cs.size(), 256)), dim3(256), 0, s, D.coset.p, D.coset29.p, (uint32_t)cs.size());
+    RLN_HIP(hipGetLastError());
     RLN_HIP(hipStreamSynchronize(s));
   }
 
@@ -1361,8 +1394,8 @@ void Prover::upload_witness(size_t n, const uint8_t* w_le) {
   D.wgiven_n = n;
 }
 
-template <bool DIF>
-static void launch_ntt(Fr* data, const Fr* tw, int logn, const Fr* final_scale, uint32_t B, uint32_t nb,
+template <bool DIF, bool M29>
+static void launch_ntt(Fr* data, const uint32_t* tw, int logn, const uint32_t* final_scale, uint32_t B, uint32_t nb,
                        hipStream_t s) {
   int s0 = 0;
   while (s0 < logn) {
@@ -1375,12 +1408,12 @@ static void launch_ntt(Fr* data, const Fr* tw, int logn, const Fr* final_scale, 
     // single-wave MSM workgroups streaming through the chip never leave (measured: mat-vec 0.6 -> 32 ms, NTT 5 -> 19 ms)
     static const int wpb = env_int("RLNAMD_NTT_WPB", 1);
     dim3 block(64, wpb), grid(div_up(nb, 64), div_up(groups, wpb), 3);
-    const Fr* sc = (s0 + K == logn) ? final_scale : nullptr;
+    const uint32_t* sc = (s0 + K == logn) ? final_scale : nullptr;
     switch (K) {
-      case 1: hipLaunchKernelGGL((k_ntt_pass<1, DIF>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb); break;
-      case 2: hipLaunchKernelGGL((k_ntt_pass<2, DIF>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb); break;
-      case 3: hipLaunchKernelGGL((k_ntt_pass<3, DIF>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb); break;
-      default: hipLaunchKernelGGL((k_ntt_pass<4, DIF>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb); break;
+      case 1: hipLaunchKernelGGL((k_ntt_pass<1, DIF, M29>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb); break;
+      case 2: hipLaunchKernelGGL((k_ntt_pass<2, DIF, M29>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb); break;
+      case 3: hipLaunchKernelGGL((k_ntt_pass<3, DIF, M29>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb); break;
+      default: hipLaunchKernelGGL((k_ntt_pass<4, DIF, M29>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb); break;
     }
     RLN_HIP(hipGetLastError());
     s0 += K;
@@ -1434,8 +1467,16 @@ void Prover::run_async(size_t n, int mode) {
   }
   RLN_HIP(hipEventRecord(S.t[3], sA2));
   if (mode != PROVE_PARTIAL) {
-    launch_ntt<true>(S.abc.p, D.tw_i.p, D.logn, D.coset.p, B, nbp, sA2);  // iNTT (DIF) + g^i / n
-    launch_ntt<false>(S.abc.p, D.tw_f.p, D.logn, nullptr, B, nbp, sA2);   // NTT (DIT)
+    // Twiddle products through Fr29::mul_mont need ~290 instead of ~375 instructions, but same-box A/B runs gave
+    // 20.21 / 20.26 k against 20.30 / 20.24 k proofs/s: beside the table walks the passes are bound by HBM and by
+    // waiting for SIMD slots, not by their instruction count.  Kept selectable (RLNAMD_NTT29=1), off by default.
+    if (D.ntt29) {
+      launch_ntt<true, true>(S.abc.p, D.tw_i29.p, D.logn, D.coset29.p, B, nbp, sA2);  // iNTT (DIF) + g^i / n
+      launch_ntt<false, true>(S.abc.p, D.tw_f29.p, D.logn, nullptr, B, nbp, sA2);     // NTT (DIT)
+    } else {
+      launch_ntt<true, false>(S.abc.p, (const uint32_t*)D.tw_i.p, D.logn, (const uint32_t*)D.coset.p, B, nbp, sA2);
+      launch_ntt<false, false>(S.abc.p, (const uint32_t*)D.tw_f.p, D.logn, nullptr, B, nbp, sA2);
+    }
     hipLaunchKernelGGL(k_hquot, dim3(pg, D.n), dim3(64, 1), 0, sA2, S.abc.p, D.n, B, nbp);
   }
   RLN_HIP(hipEventRecord(S.t[4], sA2));
