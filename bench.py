@@ -296,6 +296,10 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
                          "traffic_unit": "GB per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r1_pmc_k_msm_g1.json)",
                          "launch_ms": round(msm_ms, 3), "launch_ms_alone": round(g1_alone_ms, 3),
+                         # what the table-walk algorithm itself must read: one 64-byte entry per mixed addition
+                         "table_walk_gb_per_launch": round(23675 * int(prover.info.windows) * B * 64 / 1e9, 3),
+                         "table_walk_GBps_alone": round(23675 * int(prover.info.windows) * B * 64 / (g1_alone_ms * 1e-3) / 1e9, 1)
+                         if g1_alone_ms > 0 else None,
                          "madd_per_s": round(23675 * int(prover.info.windows) * B / (msm_ms * 1e-3) / 1e9, 2) if msm_ms > 0 else None,
                          "madd_per_s_alone": round(23675 * int(prover.info.windows) * B / (g1_alone_ms * 1e-3) / 1e9, 2)
                          if g1_alone_ms > 0 else None,
