@@ -69,6 +69,24 @@ k_walk(const G1Affine29* __restrict__ table, size_t rows_total, const int16_t* _
         }
       }
     }
+  } else if (MODE == 5) {  // as MODE 0 with non-temporal (streaming) loads of the entry: it is never reused
+#pragma unroll 1
+    for (uint32_t j = 0; j < steps; j++) {
+      int d = dg[(size_t)j * B];
+      if (d != 0) {
+        uint32_t e = (uint32_t)(d < 0 ? -d : d) - 1;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* src = reinterpret_cast<const u32x4*>(base + ((size_t)j << cs) + e);
+        G1Affine29 en;
+        u32x4 q0 = __builtin_nontemporal_load(src), q1 = __builtin_nontemporal_load(src + 1),
+              q2 = __builtin_nontemporal_load(src + 2), q3 = __builtin_nontemporal_load(src + 3);
+        en.x[0] = q0.x; en.x[1] = q0.y; en.x[2] = q0.z; en.x[3] = q0.w;
+        en.x[4] = q1.x; en.x[5] = q1.y; en.x[6] = q1.z; en.x[7] = q1.w;
+        en.y[0] = q2.x; en.y[1] = q2.y; en.y[2] = q2.z; en.y[3] = q2.w;
+        en.y[4] = q3.x; en.y[5] = q3.y; en.y[6] = q3.z; en.y[7] = q3.w;
+        acc.madd(en, d < 0);
+      }
+    }
   } else if (MODE == 3) {
     int dn = dg[0];
 #pragma unroll 1
@@ -165,6 +183,8 @@ int main(int argc, char** argv) {
   RUN(3, 4, "next digit loaded ahead of the addition (4 waves)");
   RUN(4, 4, "next entry in registers, digit two ahead (4 waves)");
   RUN(4, 3, "next entry in registers, digit two ahead (3 waves)");
+  RUN(5, 4, "non-temporal entry loads (4 waves)");
+  RUN(0, 4, "walk as k_msm29 again (4 waves/SIMD)");
   RUN(0, 3, "walk as k_msm29 (3 waves/SIMD)");
   RUN(3, 3, "next digit ahead (3 waves)");
   CK(hipDeviceSynchronize());
