@@ -102,6 +102,20 @@ k_walk(const G1Affine29* __restrict__ table, size_t rows_total, const int16_t* _
       }
     }
     out[(size_t)(chunk * pgroups + pg) * 64 + threadIdx.x] = acc2.to_xyzz();
+  } else if (MODE == 7) {  // control for MODE 6: two accumulators, but their entries come from different rows
+    G1Acc29 acc2 = G1Acc29::inf();
+#pragma unroll 1
+    for (uint32_t j = 0; j < steps / 2; j++) {
+      int d = dg[(size_t)j * B];
+      if (d != 0) {
+        uint32_t e = (uint32_t)(d < 0 ? -d : d) - 1;
+        const G1Affine29 e0 = base[((size_t)j << cs) + e];
+        const G1Affine29 e1 = base[((size_t)(j + steps / 2) << cs) + (e ^ 0x155)];
+        acc.madd(e0, d < 0);
+        acc2.madd(e1, d < 0);
+      }
+    }
+    out[(size_t)(chunk * pgroups + pg) * 64 + threadIdx.x] = acc2.to_xyzz();
   } else if (MODE == 3) {
     int dn = dg[0];
 #pragma unroll 1
@@ -198,6 +212,8 @@ int main(int argc, char** argv) {
   RUN(3, 4, "next digit loaded ahead of the addition (4 waves)");
   RUN(4, 4, "next entry in registers, digit two ahead (4 waves)");
   RUN(4, 3, "next entry in registers, digit two ahead (3 waves)");
+  RUN(0, 2, "walk as k_msm29 (2 waves/SIMD)");
+  RUN(7, 2, "two accumulators, two separate 64-byte entries per step (2 waves)");
   RUN(6, 3, "two accumulators, one 128-byte line per two additions (3 waves)");
   RUN(6, 2, "two accumulators, one 128-byte line per two additions (2 waves)");
   RUN(5, 4, "non-temporal entry loads (4 waves)");
