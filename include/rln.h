@@ -221,6 +221,8 @@ Vec_uint8_t ffi_vec_u8_debug(const Vec_uint8_t* v);                             
 void ffi_vec_u8_free(Vec_uint8_t v);                                                           /* ffi_utils.rs:343 */
 CFr_t* ffi_hash_to_field_le(const Vec_uint8_t* input);                                         /* ffi_utils.rs:349 */
 CFr_t* ffi_hash_to_field_be(const Vec_uint8_t* input);                                         /* ffi_utils.rs:354 */
+/* The five functions below have no error channel in the reference ABI.  A device failure (no GPU, out of memory)
+ * is reported on stderr and by a NULL pointer / an empty vector {NULL, 0, 0} -- never by a zero "result". */
 CFr_t* ffi_poseidon_hash_pair(const CFr_t* a, const CFr_t* b);                                 /* ffi_utils.rs:359 */
 Vec_CFr_t ffi_key_gen(void);                                                                   /* ffi_utils.rs:366 */
 Vec_CFr_t ffi_seeded_key_gen(const Vec_uint8_t* seed);                                         /* ffi_utils.rs:372 */

@@ -340,3 +340,52 @@ def test_poseidon_parameter_derivation_dense_and_sparse_forms():
     assert lib().rlnamd_poseidon_params_check((1).to_bytes(32, "little") + (2).to_bytes(32, "little"), 2, d, s) == 0
     assert int.from_bytes(s.raw, "little") == \
         7853200120776062878684798364095072458815029376092732009249414926327459813530   # circomlib's published vector for poseidon([1, 2]) (not from the reference tree)
+
+
+def test_verifier_rejects_g2_point_outside_the_order_r_subgroup():
+    """ark-serialize Validate::Yes (the reference's proof deserialiser, protocol/proof.rs:434-449 ->
+    Proof::deserialize_compressed) checks [r]B == 0; the twist has a large cofactor, so an x picked at random
+    gives a curve point outside G2 with overwhelming probability.  Every entry that takes raw proof bytes must
+    refuse it as a serialisation error, not feed it to the pairing."""
+    from oracle.pyref.bn254 import G2, R
+    v = _vec("config1_bench_witness")
+    good = bytes.fromhex(v["proof_compressed"])
+    public = [int(x) for x in v["public_inputs"]]
+    found = None
+    for k in range(1, 200):
+        cand = bytearray(good[32:96])
+        cand[0:8] = k.to_bytes(8, "little")          # perturb x.c0
+        try:
+            B = o_zkey.g2_decompress(bytes(cand))
+        except ValueError:                            # x^3 + b' is not a square for this x
+            continue
+        if B is None or not G2.on_curve(B):
+            continue
+        if G2.mul(B, R) is not None:                  # on the curve, not in the r-torsion
+            found = bytes(cand)
+            break
+    assert found is not None
+    z = open(os.path.join(RES, "rln_final.arkzkey"), "rb").read()
+    ok = C.c_int(-1)
+    rc = lib().rlnamd_verify_with_zkey(z, len(z), good[:32] + found + good[96:], b"".join(
+        x.to_bytes(32, "little") for x in public), C.byref(ok))
+    assert rc != 0 and ok.value == 0
+    assert "Proof serialization error" in _native.last_error()
+    assert _verify(good, public)                      # the untouched proof still verifies
+
+
+def test_python_mirrors_refuse_non_canonical_integers():
+    """CFr values of the C ABI are canonical by construction (ffi_bytes_*_to_cfr); the Python mirrors write the
+    bytes directly, so they apply the same rule instead of letting x + r pass the host-side comparisons."""
+    from zerokit_amd import batch, public
+    for bad in (hashers.R, hashers.R + 5, 1 << 255, -1):
+        with pytest.raises(_native.RLNError, match="Non-canonical field element"):
+            public._cfr(bad)
+        with pytest.raises(_native.RLNError, match="Non-canonical field element"):
+            public._vec_cfr([1, bad])
+        with pytest.raises(_native.RLNError, match="Non-canonical field element"):
+            batch._b(bad)
+    assert bytes(public._cfr(hashers.R - 1).le) == (hashers.R - 1).to_bytes(32, "little")
+    assert batch._b(batch._Q - 1, batch._Q) == (batch._Q - 1).to_bytes(32, "little")
+    with pytest.raises(_native.RLNError):
+        batch._b(batch._Q, batch._Q)

@@ -13,8 +13,17 @@ def resource_paths(depth=20, multi=False):
     return os.path.join(d, "rln_final.arkzkey"), os.path.join(d, "graph.bin")
 
 
-def _b(x: int) -> bytes:
-    return int(x).to_bytes(32, "little")
+_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+_Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+
+
+def _b(x: int, modulus: int = _R) -> bytes:
+    """canonical 32-byte LE form; values outside [0, modulus) are refused (the kernels would silently see a
+    different residue from the one the host-side checks compared)"""
+    x = int(x)
+    if not 0 <= x < modulus:
+        raise RLNError("Non-canonical field element: value is not in [0, %s-1]" % ("r" if modulus == _R else "q"))
+    return x.to_bytes(32, "little")
 
 
 class BatchProver:
@@ -291,7 +300,7 @@ class MsmG1:
 
     def set(self, points, scalars):
         """points: list of (x, y) ints or None for infinity"""
-        pb = b"".join((_b(0) + _b(0)) if p is None else (_b(p[0]) + _b(p[1])) for p in points)
+        pb = b"".join((_b(0) + _b(0)) if p is None else (_b(p[0], _Q) + _b(p[1], _Q)) for p in points)
         check(lib().rlnamd_msm_set(self._h, pb, b"".join(_b(s) for s in scalars), len(points)))
 
     def generate(self, seed, first_index, n):

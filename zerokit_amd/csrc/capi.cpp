@@ -387,7 +387,9 @@ static void verify_common(const Zkey& zk, const uint8_t proof[128], const uint8_
   G1Affine A, C;
   G2Affine B;
   *ok = 0;
-  if (!g1_decompress(proof, &A) || !g2_decompress(proof + 32, &B) || !g1_decompress(proof + 96, &C))
+  // Validate::Yes of the reference's proof deserialiser: on the curve AND, for G2, in the order-r subgroup
+  if (!g1_decompress(proof, &A) || !g2_decompress(proof + 32, &B) || !g1_decompress(proof + 96, &C) ||
+      !g2_in_subgroup(B))
     throw Error("Proof serialization error: the input buffer contained invalid data");
   std::vector<Fr> in;
   for (size_t i = 0; i < nv; i++) {

@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/random.h>
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -180,25 +181,28 @@ std::string resource_dir(size_t depth) {
   return base + "/tree_depth_" + std::to_string(depth);
 }
 
+// Uniform in [0, r) by rejection: 32 fresh bytes from the kernel's CSPRNG, masked to 254 bits, redrawn as a whole
+// while >= r (the loop of <Fr as UniformRand>::rand, ark-ff 0.5.0; the reference calls it with thread_rng,
+// protocol/proof.rs:743-745, protocol/keygen.rs).  r / 2^254 = 0.756, so 1.32 draws on average.
 CFr random_fr() {
-  static thread_local std::random_device rd;
-  uint8_t b[32];
-  for (int i = 0; i < 8; i++) {
-    uint32_t w = rd();
-    memcpy(b + 4 * i, &w, 4);
-  }
-  b[31] &= 0x3F;  // 254 bits, then reject
   CFr r;
   for (;;) {
-    if (is_canonical(b)) break;
-    uint32_t w = rd();
-    memcpy(b, &w, 4);
-    b[31] = (uint8_t)((b[31] + 1) & 0x1F);
+    uint8_t b[32];
+    size_t got = 0;
+    while (got < sizeof b) {
+      ssize_t k = getrandom(b + got, sizeof b - got, 0);
+      if (k < 0) {
+        if (errno == EINTR) continue;
+        throw Error(std::string("getrandom failed: ") + strerror(errno));
+      }
+      got += (size_t)k;
+    }
+    b[31] &= 0x3F;
+    if (!is_canonical(b)) continue;
+    memcpy(r.le, b, 32);
+    return r;
   }
-  memcpy(r.le, b, 32);
-  return r;
 }
-
 
 Fr to_fr(const CFr& v) {
   uint32_t c[8];
@@ -282,6 +286,20 @@ CFr poseidon_host_call(const std::vector<CFr>& in) {  // one-lane launch of the 
     throw Error(std::string("poseidon: ") + rlnamd_last_error());
   return out;
 }
+
+// entry points without an error channel: see the keygen block of the extern "C" section
+template <class T, class F>
+T no_channel(const char* who, T failed, F&& f) noexcept {
+  try {
+    return f();
+  } catch (const std::exception& e) {
+    fprintf(stderr, "librln: %s: %s\n", who, e.what());
+  } catch (...) {
+    fprintf(stderr, "librln: %s: unknown error\n", who);
+  }
+  return failed;
+}
+const Vec_CFr_t kNoVecCFr = {nullptr, 0, 0};
 
 // compute_id_secret (protocol/slashing.rs:12-36)
 CFr compute_id_secret(const CFr& x1, const CFr& y1, const CFr& x2, const CFr& y2) {
@@ -483,14 +501,27 @@ struct FFI_RLN {
     }
   }
 
-  void new_tree(size_t depth) {  // PoseidonTree::default(depth) (public.rs:298-303)
-    if (depth >= 64) throw Error("Tree depth exceeds maximum allowed (must be < 64)");
+  // PoseidonTree::default(depth) (public.rs:298-303).  `self.tree = PoseidonTree::default(d)?` leaves the old tree
+  // in place when the constructor fails, so the new tree is built beside the old one and swapped in -- together with
+  // next_index, leaf_set and metadata -- only once init has succeeded (bad depth, hipMalloc failure: nothing changes).
+  void new_tree(size_t depth) {
+    if (depth >= 64) throw Error("Merkle tree error: Tree depth exceeds maximum allowed (must be < 64)");  // InvalidDepth
+    if (depth > 30)  // the dense HBM-resident tree holds 2^(depth+1) - 1 nodes of 32 B: depth 30 is 64 GiB
+      throw Error("Merkle tree error: Tree depth exceeds maximum allowed (must be <= 30 for the HBM-resident tree)");
     uint8_t zero[32] = {0};
-    tree = MerkleTreeDev();
-    tree.init((int)depth, zero);
+    MerkleTreeDev fresh;
+    fresh.init((int)depth, zero);
+    std::vector<uint8_t> fresh_set((size_t)1 << depth, 0);
+    tree = std::move(fresh);
+    leaf_set.swap(fresh_set);
     next_index = 0;
-    leaf_set.assign((size_t)1 << depth, 0);
     metadata.clear();
+  }
+  // ffi_set_tree / ffi_init_tree_with_leaves: the stored tree is flushed and replaced by a default (temporary) one
+  void replace_with_default_tree(size_t depth) {
+    flush();
+    new_tree(depth);  // throws before anything is dropped
+    store.clear();
   }
   // PmTree::new (pm_tree_adapter.rs:191-239): depth check against the config, load the stored tree when there is
   // one (its depth must match), else start empty; cached_leaves_indices rebuilt from the leaves below next_index
@@ -804,10 +835,6 @@ FFI_RLNProof* prove_with_witness(FFI_RLN& rln, const Vec_String_t* calc, const F
     values_from_public(pub.data(), P.graph().max_out, &pr->values);
   }
   return pr.release();
-}
-
-bool g2_in_subgroup(const G2Affine& p) {  // [r]P == 0 (ark-serialize Validate::Yes)
-  return scalar_mul(p, FrParams::MOD).is_inf();
 }
 
 // generate_partial_zk_proof (proof.rs:783-803)
@@ -1492,10 +1519,7 @@ static std::vector<CFr> vec_of(const Vec_CFr_t* v) {
 }
 CBoolResult_t ffi_set_tree(FFI_RLN_t** rln, size_t tree_depth) {
   return guard_bool([&]() {  // PoseidonTree::default(depth): the stored tree is dropped (flushed), the new one is temporary
-    FFI_RLN& r = RLNM(rln);
-    r.flush();
-    r.store.clear();
-    r.new_tree(tree_depth);
+    RLNM(rln).replace_with_default_tree(tree_depth);
     return true;
   });
 }
@@ -1518,9 +1542,7 @@ CBoolResult_t ffi_set_leaves_from(FFI_RLN_t** rln, size_t index, const Vec_CFr_t
 CBoolResult_t ffi_init_tree_with_leaves(FFI_RLN_t** rln, const Vec_CFr_t* leaves) {
   return guard_bool([&]() {  // public.rs:376-379
     FFI_RLN& r = RLNM(rln);
-    r.flush();  // set_tree(depth) then set_leaves_from (public.rs:376-379): a default, temporary tree
-    r.store.clear();
-    r.new_tree(r.tree.depth);
+    r.replace_with_default_tree(r.tree.depth);  // set_tree(depth) then set_leaves_from (public.rs:376-379)
     r.override_range(0, vec_of(leaves), {});
     return true;
   });
@@ -1682,33 +1704,41 @@ CFr_t* ffi_hash_to_field_be(const Vec_uint8_t* input) {
   hash_to_field_be(input->ptr, input->len, r.le);
   return box_cfr(r);
 }
+// The hash / keygen entry points below return bare values in the reference (ffi_utils.rs:359-392: no CResult), so a
+// device failure (no GPU, out of memory, lost device) has no error channel.  It must not look like a result: the
+// functions print the error and return NULL / an empty Vec (ptr NULL, len 0), as the *_default constructors do, and
+// no exception leaves the extern "C" boundary.
 CFr_t* ffi_poseidon_hash_pair(const CFr_t* a, const CFr_t* b) {
-  CFr in[2] = {R(a), R(b)}, out;
-  memset(out.le, 0, 32);
-  (void)rlnamd_poseidon_hash((const uint8_t*)in, 1, 2, out.le);  // one-lane launch of the batch kernel
-  return box_cfr(out);
+  return no_channel("ffi_poseidon_hash_pair", (CFr_t*)nullptr,
+                    [&]() { return box_cfr(poseidon_host_call({R(a), R(b)})); });
 }
 Vec_CFr_t ffi_key_gen(void) {  // keygen (protocol/keygen.rs:18-30): random secret, commitment = H(secret)
-  CFr secret = random_fr(), commitment;
-  memset(commitment.le, 0, 32);
-  (void)rlnamd_poseidon_hash(secret.le, 1, 1, commitment.le);
-  return make_vec_cfr({secret, commitment});
+  return no_channel("ffi_key_gen", kNoVecCFr, [&]() {
+    CFr secret = random_fr();
+    return make_vec_cfr({secret, poseidon_host_call({secret})});
+  });
 }
 Vec_CFr_t ffi_seeded_key_gen(const Vec_uint8_t* seed) {  // seeded_keygen (protocol/keygen.rs:50-65)
-  ChaCha20Rng rng = seeded_rng(seed);
-  CFr secret = rng.next_fr();
-  return make_vec_cfr({secret, poseidon_host_call({secret})});
+  return no_channel("ffi_seeded_key_gen", kNoVecCFr, [&]() {
+    ChaCha20Rng rng = seeded_rng(seed);
+    CFr secret = rng.next_fr();
+    return make_vec_cfr({secret, poseidon_host_call({secret})});
+  });
 }
 static Vec_CFr_t extended_identity(const CFr& trapdoor, const CFr& nullifier) {  // keygen.rs:31-45
   CFr secret = poseidon_host_call({trapdoor, nullifier});
   return make_vec_cfr({trapdoor, nullifier, secret, poseidon_host_call({secret})});
 }
-Vec_CFr_t ffi_extended_key_gen(void) { return extended_identity(random_fr(), random_fr()); }
+Vec_CFr_t ffi_extended_key_gen(void) {
+  return no_channel("ffi_extended_key_gen", kNoVecCFr, [&]() { return extended_identity(random_fr(), random_fr()); });
+}
 Vec_CFr_t ffi_seeded_extended_key_gen(const Vec_uint8_t* seed) {  // extended_seeded_keygen (keygen.rs:72-94)
-  ChaCha20Rng rng = seeded_rng(seed);
-  CFr trapdoor = rng.next_fr();
-  CFr nullifier = rng.next_fr();
-  return extended_identity(trapdoor, nullifier);
+  return no_channel("ffi_seeded_extended_key_gen", kNoVecCFr, [&]() {
+    ChaCha20Rng rng = seeded_rng(seed);
+    CFr trapdoor = rng.next_fr();
+    CFr nullifier = rng.next_fr();
+    return extended_identity(trapdoor, nullifier);
+  });
 }
 
 CResult_CFr_ptr_Vec_uint8_t ffi_compute_id_secret(const CFr_t* share1_x, const CFr_t* share1_y, const CFr_t* share2_x,

@@ -1638,10 +1638,22 @@ void Prover::download(size_t n, ProofOut* out) {
   std::vector<uint32_t> coords(n * 64);
   RLN_HIP(hipMemcpyAsync(coords.data(), S.coords.p, n * 256, hipMemcpyDeviceToHost, D.sC));
   RLN_HIP(hipStreamSynchronize(D.sC));
+  // Without the proof-values kernel (a single message-id circuit whose graph does not carry the shipped input
+  // names) the five values are the circuit's own public outputs w[1..6] = y, root, nullifier, x, ext -- the same
+  // numbers for every satisfying witness (witness.rs:759-804).  Other shapes (multi message-id) are read by the
+  // caller through fetch_public; their `values` are zero here, never stale.
+  std::vector<uint8_t> pub;
+  const bool from_public = !D.have_values_kernel && D.ni == 6;
+  if (from_public) fetch_public(n, &pub);
   for (size_t i = 0; i < n; i++) {
     memcpy(out[i].compressed, S.h_comp + i * 128, 128);
     memcpy(out[i].coords, coords.data() + i * 64, 256);
-    memcpy(out[i].values, S.h_values + i * 40, 160);
+    if (D.have_values_kernel)
+      memcpy(out[i].values, S.h_values + i * 40, 160);
+    else if (from_public)
+      memcpy(out[i].values, pub.data() + i * 160, 160);
+    else
+      memset(out[i].values, 0, 160);
     out[i].error = S.h_err[i];
   }
 }

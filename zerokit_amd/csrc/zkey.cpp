@@ -459,4 +459,6 @@ bool g2_decompress(const uint8_t in[64], G2Affine* out) {
   return true;
 }
 
+bool g2_in_subgroup(const G2Affine& p) { return scalar_mul(p, FrParams::MOD).is_inf(); }
+
 }  // namespace rlnamd

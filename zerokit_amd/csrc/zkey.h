@@ -60,5 +60,9 @@ void g1_compress(const G1Affine& p, uint8_t out[32]);
 void g2_compress(const G2Affine& p, uint8_t out[64]);
 bool g1_decompress(const uint8_t in[32], G1Affine* out);   // false: x not on curve / non-canonical
 bool g2_decompress(const uint8_t in[64], G2Affine* out);
+// [r]P == 0: membership in the order-r subgroup of the twist (cofactor != 1 on G2).  ark-serialize Validate::Yes
+// performs this check on every deserialised proof (protocol/proof.rs:413-449 -> Proof::deserialize_compressed);
+// every entry that accepts proof bytes from outside calls it.  G1 has cofactor 1: on-curve is enough there.
+bool g2_in_subgroup(const G2Affine& p);
 
 }  // namespace rlnamd

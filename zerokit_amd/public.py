@@ -7,9 +7,21 @@ import ctypes as C
 from ._native import (CFr, CResultPtr, MerkleProof, RLNError, VecBool, VecCFr, VecSize, VecString, VecU8, lib)
 
 
+_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def _canonical(x) -> bytes:
+    """A CFr of the C ABI only ever holds a canonical value (ffi_bytes_*_to_cfr rejects anything else, and
+    validate_witness / the duplicate-id checks compare raw bytes), so the Python side enforces the same rule."""
+    x = int(x)
+    if not 0 <= x < _R:
+        raise RLNError("Non-canonical field element: value is not in [0, r-1]")
+    return x.to_bytes(32, "little")
+
+
 def _cfr(x: int) -> CFr:
     c = CFr()
-    C.memmove(c.le, int(x).to_bytes(32, "little"), 32)
+    C.memmove(c.le, _canonical(x), 32)
     return c
 
 
@@ -26,7 +38,7 @@ def _take_cfr(p) -> int:
 def _vec_cfr(vals):
     arr = (CFr * max(len(vals), 1))()
     for i, v in enumerate(vals):
-        C.memmove(arr[i].le, int(v).to_bytes(32, "little"), 32)
+        C.memmove(arr[i].le, _canonical(v), 32)
     return VecCFr(C.cast(arr, C.POINTER(CFr)), len(vals), len(vals)), arr
 
 
