@@ -197,11 +197,12 @@ def main():
 
     B = args.batch
     t0 = time.time()
-    # 813 = 13-bit windows, the first 8 of them 14-bit: 19 windows instead of 20 for 207 GiB of fixed-base tables
-    # (sized for 288 GB of HBM); RLNAMD_WINDOW_BITS=13 gives the uniform 20 x 13 schedule (153 GiB)
-    wbits = int(os.environ.get("RLNAMD_WINDOW_BITS", "813"))
+    # GLV comb schedule g1 + 10000 * g2 over the 127-bit scalar halves: 114 = 15 + 8 x 14 bits (9 windows, 18 additions
+    # per G1 point), 715 = 7 x 16 + 15 bits (8 windows, 16 additions per G2 point): 228 GiB of fixed-base tables, sized for
+    # 288 GB of HBM.  Smaller tables are tried if that does not fit (RLNAMD_GLV=0 + 813: the round-1 19-window walk).
+    wbits = int(os.environ.get("RLNAMD_WINDOW_BITS", "7150114"))
     prover = None
-    for wb in dict.fromkeys([wbits, 13, 12, 10]):       # a box with less free HBM still runs: smaller tables
+    for wb in dict.fromkeys([wbits, 114, 13, 12, 10]):   # a box with less free HBM still runs: smaller tables
         try:
             prover = BatchProver(max_batch=B, window_bits=wb)
             break
@@ -266,7 +267,8 @@ def main():
         traffic = None   # HBM bytes per launch of the dominant kernel, from the committed PMC passes
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_k_msm_g1.json")))
-            if B == 1024 and int(prover.info.window_bits) == 13 and int(prover.info.windows) == 19:
+            if B == 1024 and int(prover.info.window_bits) == pm.get("window_bits") and \
+                    int(prover.info.windows) == pm.get("windows"):
                 traffic = round(pm["traffic_bytes_per_launch"] / 1e9, 3)
         except Exception:  # noqa: BLE001
             pass
@@ -287,7 +289,10 @@ def main():
             "config": {"workload": "config 2: batch of %d independent RLN proofs per GPU, tree_height=20, "
                                    "inputs resident in HBM" % B,
                        "batch_per_gpu": B, "parallelism": "proof-sharded x%d, no collective" % world,
-                       "window_bits": int(prover.info.window_bits), "windows": int(prover.info.windows), "table_gib": round(prover.info.table_bytes / 2**30, 2),
+                       "glv": bool(prover.info.glv),
+                       "window_bits": int(prover.info.window_bits), "windows": int(prover.info.windows),
+                       "window_bits_g2": int(prover.info.window_bits_g2), "windows_g2": int(prover.info.windows_g2),
+                       "table_gib": round(prover.info.table_bytes / 2**30, 2),
                        "device": name.value.decode(), "init_s": round(init_s, 2), "verified": bool(ok)},
             "achieved_GBps_whole_proof": round(value * BYTES_PER_PROOF / 1e9, 3),
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
@@ -297,11 +302,11 @@ def main():
                          "traffic_unit": "GB per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r1_pmc_k_msm_g1.json)",
                          "launch_ms": round(msm_ms, 3), "launch_ms_alone": round(g1_alone_ms, 3),
                          # what the table-walk algorithm itself must read: one 64-byte entry per mixed addition
-                         "table_walk_gb_per_launch": round(23675 * int(prover.info.windows) * B * 64 / 1e9, 3),
-                         "table_walk_GBps_alone": round(23675 * int(prover.info.windows) * B * 64 / (g1_alone_ms * 1e-3) / 1e9, 1)
+                         "table_walk_gb_per_launch": round(int(prover.info.g1_rows) * int(prover.info.windows) * B * 64 / 1e9, 3),
+                         "table_walk_GBps_alone": round(int(prover.info.g1_rows) * int(prover.info.windows) * B * 64 / (g1_alone_ms * 1e-3) / 1e9, 1)
                          if g1_alone_ms > 0 else None,
-                         "madd_per_s": round(23675 * int(prover.info.windows) * B / (msm_ms * 1e-3) / 1e9, 2) if msm_ms > 0 else None,
-                         "madd_per_s_alone": round(23675 * int(prover.info.windows) * B / (g1_alone_ms * 1e-3) / 1e9, 2)
+                         "madd_per_s": round(int(prover.info.g1_rows) * int(prover.info.windows) * B / (msm_ms * 1e-3) / 1e9, 2) if msm_ms > 0 else None,
+                         "madd_per_s_alone": round(int(prover.info.g1_rows) * int(prover.info.windows) * B / (g1_alone_ms * 1e-3) / 1e9, 2)
                          if g1_alone_ms > 0 else None,
                          "note": "launch_ms = mean HIP-event span of the last five launches of the timed region, on the "
                                  "kernel's stream; the G1 and G2 walks of neighbouring batches run on two streams and share "

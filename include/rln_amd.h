@@ -63,7 +63,8 @@ int rlnamd_tree_bench(rlnamd_tree* t, size_t n_leaves, uint64_t first_value, int
  * (protocol/witness.rs:759-804) for n independent proofs at once. */
 typedef struct rlnamd_prover rlnamd_prover;
 /* zkey/graph: the bytes of rln_final.arkzkey and graph.bin (circuit/mod.rs:140-203).
- * max_batch: workspace capacity; window_bits: 0 = default / RLNAMD_WINDOW_BITS. */
+ * max_batch: workspace capacity; window_bits: 0 = default / RLNAMD_WINDOW_BITS, else g1 + 10000 * g2 with each
+ * spec = c + 100 * wide (c-bit windows, the first `wide` one bit wider; g2 = 0: same as g1). */
 int rlnamd_prover_new(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_t graph_len,
                       size_t max_batch, int window_bits, rlnamd_prover** out);
 void rlnamd_prover_free(rlnamd_prover* p);
@@ -74,7 +75,11 @@ typedef struct {
   uint64_t tree_depth, max_out;
   uint64_t capacity;         /* max batch */
   uint64_t table_bytes;      /* HBM held by the fixed-base tables */
-  int32_t window_bits, windows;
+  int32_t window_bits, windows;       /* G1 comb: narrow window width; table additions per G1 point and proof */
+  int32_t window_bits_g2, windows_g2; /* the same for the G2 comb */
+  int32_t glv;                        /* 1: scalars are split k1 + lambda k2 and the combs cover 127 bits */
+  int32_t reserved;
+  uint64_t g1_rows, g2_rows;          /* finite points of the G1 / G2 walk (table rows) */
 } rlnamd_prover_info;
 int rlnamd_prover_get_info(rlnamd_prover* p, rlnamd_prover_info* info);
 /* offset/len of a named input signal in the inputs buffer (iden3calc.rs:122-146); returns RLNAMD_ERR if absent */

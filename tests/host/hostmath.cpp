@@ -12,6 +12,7 @@ struct Error : std::runtime_error {  // common.h's Error without the HIP headers
 };
 }  // namespace rlnamd
 #include "pairing.h"
+#include "glv.h"
 using namespace rlnamd;
 
 template <class F> static F ld(const uint8_t* p) { uint32_t c[8]; memcpy(c, p, 32); return F::from_canonical(c); }
@@ -86,5 +87,26 @@ void hm_g2_mul(const uint8_t* a, const uint8_t* k, uint8_t* out) {
   uint32_t kk[8];
   memcpy(kk, k, 32);
   stg2(out, scalar_mul(ldg2(a), kk).to_affine());
+}
+// GLV split (glv.h): out = k1 (16 B LE) | neg1 (1 B) | k2 (16 B LE) | neg2 (1 B)
+void hm_glv_split(const uint8_t* k, uint8_t* out) {
+  uint32_t kk[8], k1[4], k2[4], n1, n2;
+  memcpy(kk, k, 32);
+  glv_split(kk, k1, &n1, k2, &n2);
+  memcpy(out, k1, 16);
+  out[16] = (uint8_t)n1;
+  memcpy(out + 17, k2, 16);
+  out[33] = (uint8_t)n2;
+}
+// the endomorphism itself on affine points: (beta x, y) with the constants the kernels use
+void hm_glv_phi_g1(const uint8_t* a, uint8_t* out) {
+  G1Affine p = ldg1(a);
+  if (!p.is_inf()) p.x = p.x * Fq::from_canonical(GlvParams::BETA_G1);
+  stg1(out, p);
+}
+void hm_glv_phi_g2(const uint8_t* a, uint8_t* out) {
+  G2Affine p = ldg2(a);
+  if (!p.is_inf()) p.x = p.x.mul_fq(Fq::from_canonical(GlvParams::BETA_G2));
+  stg2(out, p);
 }
 }

@@ -442,23 +442,60 @@ def test_fq29_group_law_matches_the_8x32_group_law_on_device():
     assert bad.value == 0
 
 
-def test_mixed_window_schedules_give_the_same_proofs():
-    """The comb tables may use (c + 1)-bit windows for the first few windows (window_bits = c + 100 * wide, 19
-    instead of 20 windows at c = 13 in bench.py).  Group elements are canonical, so every schedule must return the
-    golden proof bytes; partial + finish walks share the tables and must agree too."""
+def _golden_batch(p, cases, ws, rs, tag):
+    out = p.prove(ws, rs)
+    for o, c in zip(out, cases):
+        assert o["proof"].hex() == c["proof_compressed"], (tag, c["name"])
+        assert p.verify(o["proof"], o["public_inputs"])
+
+
+def test_mixed_window_schedules_give_the_same_proofs(monkeypatch):
+    """The comb tables may use (c + 1)-bit windows for the first few windows and different schedules for G1 and G2
+    (window_bits = g1 + 10000 * g2, spec = c + 100 * wide), over the 127-bit halves of the GLV split or -- RLNAMD_GLV=0
+    -- over the whole 254-bit scalar.  Group elements are canonical, so every schedule must return the golden proof
+    bytes."""
     from zerokit_amd.batch import BatchProver
     cases = _cases()["cases"]
     ws, rs = [_w(c) for c in cases], [(int(c["r"]), int(c["s"])) for c in cases]
-    for wb, windows in ((708, 31), (309, 28), (1010, 25)):   # 7x9+24x8 = 255, 3x10+25x9 = 255, 10x11+15x10 = 260 bits
+    # GLV: 7x9+8x8 = 127 bits -> 2 x 15 additions; G1 3x10+11x9 = 129, G2 3x11+10x10 = 133; 10x11+1x10 = 120+..: 12 windows
+    for wb, w1, w2 in ((708, 30, 30), (3100309, 28, 26), (1010, 24, 24)):
         p = BatchProver(max_batch=64, window_bits=wb)
         try:
-            assert int(p.info.windows) == windows
-            out = p.prove(ws, rs)
-            for o, c in zip(out, cases):
-                assert o["proof"].hex() == c["proof_compressed"], (wb, c["name"])
-                assert p.verify(o["proof"], o["public_inputs"])
+            assert int(p.info.glv) == 1 and int(p.info.windows) == w1 and int(p.info.windows_g2) == w2
+            _golden_batch(p, cases, ws, rs, wb)
         finally:
             p.close()
+    monkeypatch.setenv("RLNAMD_GLV", "0")
+    for wb, w1 in ((708, 31), (1010, 25)):   # 7x9+24x8 = 255, 10x11+15x10 = 260 bits
+        p = BatchProver(max_batch=64, window_bits=wb)
+        try:
+            assert int(p.info.glv) == 0 and int(p.info.windows) == w1 and int(p.info.windows_g2) == w1
+            _golden_batch(p, cases, ws, rs, wb)
+        finally:
+            p.close()
+
+
+def test_bench_schedule_gives_the_golden_proofs():
+    """bench.py's comb schedule (G1: 15 + 8 x 14 bits, G2: 7 x 16 + 15 bits over the GLV halves; 228 GiB of tables):
+    the 16-bit windows produce digits at both ends of the int16 range.  Golden proof bytes, and partial + finish
+    (which walk subsets of the same tables) must give the full proof."""
+    from zerokit_amd.batch import BatchProver
+    cases = _cases()["cases"]
+    ws, rs = [_w(c) for c in cases], [(int(c["r"]), int(c["s"])) for c in cases]
+    try:
+        p = BatchProver(max_batch=64, window_bits=7150114)
+    except Exception as e:  # noqa: BLE001
+        pytest.skip("not enough free HBM for the bench tables: %s" % e)
+    try:
+        assert int(p.info.windows) == 18 and int(p.info.windows_g2) == 16
+        _golden_batch(p, cases, ws, rs, "bench")
+        partial = p.prove_partial([{k: w[k] for k in ("identity_secret", "user_message_limit", "path_elements",
+                                                       "identity_path_index")} for w in ws])
+        fin = p.finish(ws, rs, partial)
+        for o, c in zip(fin, cases):
+            assert o["proof"].hex() == c["proof_compressed"], c["name"]
+    finally:
+        p.close()
 
 
 def test_ntt_products_in_the_9x29_form_give_the_same_h(monkeypatch):

@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def L():
     so = os.path.join(ROOT, "tests", "host", "libhostmath.so")
     src = os.path.join(ROOT, "tests", "host", "hostmath.cpp")
-    hdrs = [os.path.join(ROOT, "zerokit_amd", "csrc", h) for h in ("field.h", "curve.h", "pairing.h")]
+    hdrs = [os.path.join(ROOT, "zerokit_amd", "csrc", h) for h in ("field.h", "curve.h", "pairing.h", "glv.h",
+                                                                     "glv_constants.h")]
     if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I",
                                os.path.join(ROOT, "zerokit_amd", "csrc"), src, "-o", so])
@@ -124,3 +125,44 @@ def test_structured_final_exponentiation_equals_definition(L):
     inverse through Fq6; result in the cyclotomic subgroup"""
     for seed in (1, 12345, 99991):
         assert L.hm_final_exp_check(seed) == 7
+
+
+def _glv_constants():
+    import re
+    txt = open(os.path.join(ROOT, "zerokit_amd", "csrc", "glv_constants.h")).read()
+    out = {}
+    for name, body in re.findall(r"(\w+)\[\d+\]\s*=\s*\{([^}]*)\}", txt):
+        out[name] = sum(int(w.strip().rstrip("u"), 16) << (32 * k) for k, w in enumerate(body.split(",")))
+    return out
+
+
+def test_glv_split_and_endomorphism(L):
+    """k = +-k1 + lambda (+-k2) mod r with both halves below 2^126 (what lets the comb tables stop at 127 bits), and
+    (beta x, y) = [lambda](x, y) on G1 and G2 for the committed constants."""
+    c = _glv_constants()
+    lam = c["LAMBDA"]
+    assert (lam * lam + lam + 1) % R == 0 and pow(c["BETA_G1"], 3, Q) == 1 and pow(c["BETA_G2"], 3, Q) == 1
+    assert c["A1"] * c["B2"] + c["A2"] * c["B1ABS"] == R
+    rnd = random.Random(11)
+    worst = 0
+    ks = [0, 1, 2, R - 1, R - 2, R // 2, (R + 1) // 2, lam, R - lam, lam - 1, c["A2"], c["B1ABS"], R - c["A2"]]
+    ks += [rnd.randrange(R) for _ in range(20000)]
+    ks += [(rnd.randrange(1 << 40) * c["B1ABS"] + rnd.randrange(1 << 20)) % R for _ in range(2000)]  # near rounding ties
+    for k in ks:
+        out = ctypes.create_string_buffer(34)
+        L.hm_glv_split(b(k), out)
+        k1, n1 = int.from_bytes(out.raw[:16], "little"), out.raw[16]
+        k2, n2 = int.from_bytes(out.raw[17:33], "little"), out.raw[33]
+        assert ((-k1 if n1 else k1) + lam * (-k2 if n2 else k2) - k) % R == 0, k
+        worst = max(worst, k1, k2)
+    assert worst < 1 << 126
+    out = ctypes.create_string_buffer(64)
+    for kk in (1, 5, 0xDEADBEEF):
+        P = G1.mul(G1_GEN, kk)
+        L.hm_glv_phi_g1(g1b(P), out)
+        assert g1i(out.raw) == G1.mul(P, lam)
+    out = ctypes.create_string_buffer(128)
+    for kk in (1, 7, 0xC0FFEE):
+        T = G2.mul(G2_GEN, kk)
+        L.hm_glv_phi_g2(g2b(T), out)
+        assert g2i(out.raw) == G2.mul(T, lam)

@@ -64,7 +64,9 @@ class MerkleProof(C.Structure):
 class ProverInfo(C.Structure):
     _fields_ = [("inputs_size", C.c_uint64), ("num_signals", C.c_uint64), ("domain_size", C.c_uint64),
                 ("tree_depth", C.c_uint64), ("max_out", C.c_uint64), ("capacity", C.c_uint64),
-                ("table_bytes", C.c_uint64), ("window_bits", C.c_int32), ("windows", C.c_int32)]
+                ("table_bytes", C.c_uint64), ("window_bits", C.c_int32), ("windows", C.c_int32),
+                ("window_bits_g2", C.c_int32), ("windows_g2", C.c_int32), ("glv", C.c_int32), ("reserved", C.c_int32),
+                ("g1_rows", C.c_uint64), ("g2_rows", C.c_uint64)]
 
 
 P = C.c_void_p

@@ -216,6 +216,12 @@ int rlnamd_prover_get_info(rlnamd_prover* p, rlnamd_prover_info* info) {
   info->table_bytes = P.table_bytes();
   info->window_bits = P.window_bits();
   info->windows = P.windows();
+  info->window_bits_g2 = P.window_bits_g2();
+  info->windows_g2 = P.windows_g2();
+  info->glv = P.glv() ? 1 : 0;
+  info->reserved = 0;
+  info->g1_rows = P.g1_rows();
+  info->g2_rows = P.g2_rows();
   RLN_CATCH
 }
 int rlnamd_prover_input_slot(rlnamd_prover* p, const char* name, uint32_t* offset, uint32_t* len) {

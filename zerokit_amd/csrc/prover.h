@@ -36,7 +36,7 @@ enum ProveMode { PROVE_FULL = 0, PROVE_PARTIAL = 1, PROVE_FINISH = 2 };
 extern const char* const kProverStageNames[PROVER_STAGES];
 
 struct ProverConfig {
-  int window_bits = 0;      // 0 = take RLNAMD_WINDOW_BITS or the default (8)
+  int window_bits = 0;      // 0 = take RLNAMD_WINDOW_BITS or the default (8); g1 + 10000 * g2, spec = c + 100 * wide
   size_t max_batch = 1024;  // workspace capacity in proofs (rounded up to a multiple of 64)
 };
 
@@ -55,8 +55,13 @@ class Prover {
   const Zkey& zkey() const { return zk_; }
   const Graph& graph() const { return graph_; }
   size_t capacity() const { return B_; }
-  int window_bits() const { return c_; }
-  int windows() const { return W_; }
+  int window_bits() const { return c_; }      // G1 comb: narrow window width
+  int windows() const { return W_; }          // table additions per G1 point and proof (windows x GLV halves)
+  int window_bits_g2() const { return c2_; }
+  int windows_g2() const { return W2_; }
+  bool glv() const { return glv_; }
+  size_t g1_rows() const;                     // table rows (finite points) of the G1 / G2 walk
+  size_t g2_rows() const;
   size_t inputs_per_proof() const { return graph_.inputs_size; }
   size_t table_bytes() const;
 
@@ -107,7 +112,8 @@ class Prover {
   Zkey zk_;
   Graph graph_;
   size_t B_ = 0;
-  int c_ = 8, W_ = 32;
+  int c_ = 8, W_ = 32, c2_ = 8, W2_ = 32;
+  bool glv_ = true;
 };
 
 }  // namespace rlnamd

@@ -9,6 +9,7 @@
 #include <algorithm>
 
 #include "fq29.h"
+#include "glv.h"
 #include "pairing.h"
 #include "poseidon.h"
 
@@ -411,12 +412,41 @@ struct WinSched {
 };
 
 // =====================================================================================================
-// 4. scalars -> signed digits (window j: cw[j] bits), layout [scalar][window][proof] (int16)
+// 4. scalars -> signed digits (window j: cw[j] bits), layout [scalar][half][window][proof] (int16)
 // =====================================================================================================
+// Digits of the magnitude `l` (NL limbs, destroyed) under schedule ws; the scalar's sign flips every digit.  A window
+// of c bits yields d in [-2^(c-1), 2^(c-1)]; both ends select table entry 2^(c-1) - 1, but only one of them fits an
+// int16 at c = 16, so a window value of exactly 2^(c-1) goes to the end the sign leaves representable.
+template <int NL>
+__device__ __forceinline__ void emit_digits(uint32_t* l, bool neg, const WinSched& ws, int16_t* __restrict__ out, uint32_t B) {
+  uint32_t carry = 0;
+#pragma unroll 1
+  for (int j = 0; j < ws.W; j++) {
+    const int c = ws.cw[j];
+    const uint32_t mask = (c >= 32) ? 0xFFFFFFFFu : ((1u << c) - 1), E = 1u << (c - 1);
+    uint32_t raw = (l[0] & mask) + carry;
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) l[i] = (l[i] >> c) | (l[i + 1] << (32 - c));
+    l[NL - 1] >>= c;
+    int d;
+    if (raw > E || (raw == E && !neg)) {
+      d = (int)raw - (int)(mask + 1);
+      carry = 1;
+    } else {
+      d = (int)raw;
+      carry = 0;
+    }
+    out[(size_t)j * B] = (int16_t)(neg ? -d : d);
+  }
+}
+// Scalar ids: [0, ns) witness signals, [ns, ns + n) quotient coefficients h, then r, s, -(r s).  dig1 holds the G1
+// schedule for all of them; dig2 the G2 schedule for the ones the G2 walk uses (witness, r, s, -(r s): id - n).
+// nh = 2: every scalar is split as k1 + lambda k2 (glv.h) and both halves are recoded; nh = 1: the plain 254-bit walk.
 __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ V, const uint32_t* __restrict__ sig2node,
                                                 uint32_t ns, const Fr* __restrict__ H, uint32_t n,
-                                                const uint32_t* __restrict__ rs, WinSched ws,
-                                                int16_t* __restrict__ digits, uint32_t B, uint32_t nb) {
+                                                const uint32_t* __restrict__ rs, WinSched ws1, WinSched ws2, uint32_t nh,
+                                                int16_t* __restrict__ dig1, int16_t* __restrict__ dig2, uint32_t B,
+                                                uint32_t nb) {
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
   uint32_t sid = blockIdx.y * blockDim.y + threadIdx.y;
   if (p >= nb || sid >= ns + n + 3) return;
@@ -433,26 +463,29 @@ __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ V, const 
   }
   uint32_t l[8];
   x.to_canonical(l);
-  const int W = ws.W;
-  uint32_t carry = 0;
-  int16_t* out = digits + (size_t)sid * W * B + p;
-#pragma unroll 1
-  for (int j = 0; j < W; j++) {
-    const int c = ws.cw[j];
-    const uint32_t mask = (1u << c) - 1, E = 1u << (c - 1);
-    uint32_t raw = (l[0] & mask) + carry;
+  const bool g2 = sid < ns || sid >= ns + n;
+  const uint32_t sid2 = sid < ns ? sid : sid - n;
+  if (nh == 2) {
+    uint32_t k[2][4], neg[2];
+    glv_split(l, k[0], &neg[0], k[1], &neg[1]);
 #pragma unroll
-    for (int i = 0; i < 7; i++) l[i] = (l[i] >> c) | (l[i + 1] << (32 - c));
-    l[7] >>= c;
-    int d;
-    if (raw > E) {
-      d = (int)raw - (int)(mask + 1);
-      carry = 1;
-    } else {
-      d = (int)raw;
-      carry = 0;
+    for (int h = 0; h < 2; h++) {
+      uint32_t t[4];
+      if (g2) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[i] = k[h][i];
+        emit_digits<4>(t, neg[h] != 0, ws2, dig2 + ((size_t)sid2 * 2 + h) * ws2.W * B + p, B);
+      }
+      emit_digits<4>(k[h], neg[h] != 0, ws1, dig1 + ((size_t)sid * 2 + h) * ws1.W * B + p, B);
     }
-    out[(size_t)j * B] = (int16_t)d;
+  } else {
+    if (g2) {
+      uint32_t t[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) t[i] = l[i];
+      emit_digits<8>(t, false, ws2, dig2 + (size_t)sid2 * ws2.W * B + p, B);
+    }
+    emit_digits<8>(l, false, ws1, dig1 + (size_t)sid * ws1.W * B + p, B);
   }
 }
 
@@ -467,7 +500,8 @@ template <class F>
 __global__ void __launch_bounds__(64) k_msm(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ sid,
                                             const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks,
                                             uint32_t nchunks, const int16_t* __restrict__ digits,
-                                            XYZZ<F>* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups) {
+                                            XYZZ<F>* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups,
+                                            uint32_t nh) {
   // XCD-aware decode: hardware places block L on XCD L % 8; all proof groups of one chunk share the same
   // table rows, so they are given consecutive slots on ONE XCD and meet in that XCD's L2.
   uint32_t L = blockIdx.x;
@@ -480,8 +514,10 @@ __global__ void __launch_bounds__(64) k_msm(const Affine<F>* __restrict__ table,
   const int W = ws.W;
 #pragma unroll 1
   for (uint32_t i = cd.pt_begin; i < cd.pt_end; i++) {
-    const uint32_t k = rows[i];  // table row; the walk (full / partial / finish) is a list of rows
-    const int16_t* dg = digits + (size_t)sid[k] * W * B + p;
+    // table row; the walk (full / partial / finish) is a list of rows.  Bit 31: the row is walked with the digits of
+    // the scalar's second GLV half (the sum of those rows is mapped through phi afterwards, k_glv_fold)
+    const uint32_t kk = rows[i], k = kk & 0x7FFFFFFFu;
+    const int16_t* dg = digits + ((size_t)sid[k] * nh + (kk >> 31)) * W * B + p;
     const Affine<F>* row = table + (size_t)k * ws.stride;
 #pragma unroll 1
     for (int j = 0; j < W; j++) {
@@ -503,7 +539,8 @@ template <class Acc, class Entry, class Out, int WAVES>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_msm29(const Entry* __restrict__ table, const uint32_t* __restrict__ sid,
                                               const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks,
                                               uint32_t nchunks, const int16_t* __restrict__ digits,
-                                              Out* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups) {
+                                              Out* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups,
+                                              uint32_t nh) {
   uint32_t L = blockIdx.x;
   uint32_t xcd = L & 7, q = L >> 3;
   uint32_t chunk = (q / pgroups) * 8 + xcd, pg = q % pgroups;
@@ -514,8 +551,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 
   const int W = ws.W;
 #pragma unroll 1
   for (uint32_t i = cd.pt_begin; i < cd.pt_end; i++) {
-    const uint32_t k = rows[i];
-    const int16_t* dg = digits + (size_t)sid[k] * W * B + p;
+    const uint32_t kk = rows[i], k = kk & 0x7FFFFFFFu;  // bit 31: second GLV half (see k_msm)
+    const int16_t* dg = digits + ((size_t)sid[k] * nh + (kk >> 31)) * W * B + p;
     const Entry* row = table + (size_t)k * ws.stride;
 #pragma unroll 1
     for (int j = 0; j < W; j++) {  // (touching the next entry ahead of the addition was measured: 3 % slower)
@@ -548,6 +585,27 @@ __global__ void __launch_bounds__(64) k_sum_ranges(const XYZZ<F>* __restrict__ s
   XYZZ<F> acc = XYZZ<F>::inf();
   for (uint32_t i = cd.pt_begin; i < cd.pt_end; i++) acc.add(src[(size_t)i * B + p]);
   dst[(size_t)r * B + p] = acc;
+}
+
+// GLV: segment t holds sum k1_i P_i, segment nseg + t holds sum k2_i P_i; the result is the first plus phi of the
+// second, phi(X, Y, ZZ, ZZZ) = (beta X, Y, ZZ, ZZZ) (x = X / ZZ).  One Fq product per output point and proof.
+__global__ void __launch_bounds__(64) k_glv_fold(G1XYZZ* __restrict__ sums1, G2XYZZ* __restrict__ sums2, uint32_t nseg1,
+                                                 uint32_t B, uint32_t nb) {
+  __builtin_amdgcn_s_setprio(3);
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= nb) return;
+  const uint32_t t = blockIdx.y;
+  if (t < nseg1) {
+    G1XYZZ a = sums1[(size_t)t * B + p], b = sums1[(size_t)(nseg1 + t) * B + p];
+    b.X = b.X * Fq::from_canonical(GlvParams::BETA_G1);
+    a.add(b);
+    sums1[(size_t)t * B + p] = a;
+  } else {
+    G2XYZZ a = sums2[p], b = sums2[(size_t)B + p];
+    b.X = b.X.mul_fq(Fq::from_canonical(GlvParams::BETA_G2));
+    a.add(b);
+    sums2[p] = a;
+  }
 }
 
 // one-time comb table: row (k, j) = { d * 2^(c j) * P_k : d = 1..2^(c-1) } in affine form.
@@ -831,7 +889,7 @@ struct Slot {
   DevBuf<uint32_t> err, coords, values;
   DevBuf<uint8_t> comp;
   DevBuf<Fr> V, abc;
-  DevBuf<int16_t> digits;
+  DevBuf<int16_t> digits, digits2;  // signed window digits under the G1 / G2 schedule
   DevBuf<G1XYZZ> part1, grp1, sums1, prod, tbl;
   DevBuf<G2XYZZ> part2, grp2, sums2;
   DevBuf<G1Affine> affA, affB1;
@@ -893,7 +951,8 @@ struct Prover::Impl {
   static constexpr int NSLOT = 6;
   Slot slot[NSLOT];
   int nslot = 5, nstreamA = 2;  // RLNAMD_SLOTS / RLNAMD_ASTREAMS
-  WinSched ws{};                // window schedule of both comb tables
+  WinSched ws{}, ws2{};         // window schedules of the G1 and G2 comb tables
+  uint32_t nh = 2;              // halves per scalar: 2 = GLV split (k1 + lambda k2), 1 = plain 254-bit walk
   bool recode_front = true;     // RLNAMD_RECODE_FRONT
   bool ntt29 = false;           // RLNAMD_NTT29: NTT products through Fr29::mul_mont (measured: no gain, see launch site)
   uint32_t msm_lds = 0;         // RLNAMD_MSM_WAVES (waves per SIMD the G1 walk may occupy; 0 = no cap)
@@ -983,11 +1042,12 @@ static void build_table29(const std::vector<Affine<F>>& pts, const WinSched& ws,
   RLN_HIP(hipStreamSynchronize(s));
 }
 
-// c-bit windows, the first `wide` of them one bit wider; W = the fewest windows that cover 255 bits (254-bit scalars
-// plus the carry of the signed recoding)
-static WinSched make_sched(int c, int wide) {
+// c-bit windows, the first `wide` of them one bit wider; W = the fewest windows that cover `total` bits: 255 for the
+// plain walk (254-bit scalars plus the carry of the signed recoding), 127 for the halves of a GLV split (< 2^126)
+static WinSched make_sched(int c, int wide, int total) {
+  if (c < 2 || c > 16 || wide < 0 || c + (wide > 0 ? 1 : 0) > 16) throw Error("window bits must be in [2, 16]");
   WinSched ws{};
-  int W = (255 - wide + c - 1) / c;
+  int W = (total - wide + c - 1) / c;
   if (wide > W) throw Error("more wide windows than windows");
   if (W > 32) throw Error("window bits too small: more than 32 windows");
   ws.W = W;
@@ -1011,13 +1071,22 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   graph_ = parse_graph(graph, graph_len);
   (void)prepared(zk_);  // verifier precomputation now, so concurrent verify calls only read it
   Impl& D = *d_;
-  // window_bits = c + 100 * wide: c-bit windows, the first `wide` of them (c + 1)-bit (see WinSched)
+  // window_bits = g1 + 10000 * g2, each spec = c + 100 * wide: c-bit windows, the first `wide` of them (c + 1)-bit
+  // (see WinSched); g2 = 0: the G2 table takes the G1 schedule.  With the GLV split (default; RLNAMD_GLV=0 keeps the
+  // plain 254-bit walk) the windows cover the 127-bit halves: spec 114 = 15 + 8 x 14 bits, 9 windows, 18 additions
+  // per G1 point; spec 715 = 7 x 16 + 15 bits, 8 windows, 16 additions per G2 point.
   const int wb = cfg.window_bits > 0 ? cfg.window_bits : env_int("RLNAMD_WINDOW_BITS", 8);
-  c_ = wb % 100;
-  const int wide = wb >= 100 ? wb / 100 : env_int("RLNAMD_WINDOW_WIDE", 0);
-  if (c_ < 2 || c_ > 14 || wide < 0) throw Error("window bits must be in [2, 14]");
-  D.ws = make_sched(c_, wide);
-  W_ = D.ws.W;
+  const int spec1 = wb % 10000, spec2 = wb / 10000 ? wb / 10000 : spec1;
+  D.nh = env_int("RLNAMD_GLV", 1) != 0 ? 2 : 1;
+  const int total = D.nh == 2 ? GlvParams::HALF_BITS : 255;
+  c_ = spec1 % 100;
+  const int wide = spec1 >= 100 ? spec1 / 100 : env_int("RLNAMD_WINDOW_WIDE", 0);
+  D.ws = make_sched(c_, wide, total);
+  D.ws2 = make_sched(spec2 % 100, spec2 >= 100 ? spec2 / 100 : (wb / 10000 ? 0 : wide), total);
+  W_ = D.ws.W * D.nh;
+  c2_ = spec2 % 100;
+  W2_ = D.ws2.W * D.nh;
+  glv_ = D.nh == 2;
   B_ = ((cfg.max_batch ? cfg.max_batch : 1) + 63) / 64 * 64;
 
   // ---- consistency between zkey and graph (what arkworks asserts inside the prover)
@@ -1208,24 +1277,26 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     for (int mode = 0; mode < 3; mode++) {
       std::vector<uint32_t> rows, segfirst;
       std::vector<ChunkDesc> chunks;
-      for (uint32_t sg = 0; sg < nseg; sg++) {
-        segfirst.push_back((uint32_t)chunks.size());
-        uint32_t first = (uint32_t)rows.size();
-        for (uint32_t k = 0; k < sids.size(); k++) {
-          if (row_seg[k] != sg) continue;
-          bool is_known = sids[k] < D.NS && D.known[sids[k]];
-          if (mode == PROVE_FULL || (mode == PROVE_PARTIAL) == is_known) rows.push_back(k);
+      // reduction segment h * nseg + sg: the rows of output sg walked with GLV half h (bit 31 of the row entry)
+      for (uint32_t h = 0; h < D.nh; h++)
+        for (uint32_t sg = 0; sg < nseg; sg++) {
+          segfirst.push_back((uint32_t)chunks.size());
+          uint32_t first = (uint32_t)rows.size();
+          for (uint32_t k = 0; k < sids.size(); k++) {
+            if (row_seg[k] != sg) continue;
+            bool is_known = sids[k] < D.NS && D.known[sids[k]];
+            if (mode == PROVE_FULL || (mode == PROVE_PARTIAL) == is_known) rows.push_back(k | (h << 31));
+          }
+          for (uint32_t k = first; k < rows.size(); k += chunk_pts)
+            chunks.push_back({k, (uint32_t)std::min<size_t>(k + chunk_pts, rows.size())});
         }
-        for (uint32_t k = first; k < rows.size(); k += chunk_pts)
-          chunks.push_back({k, (uint32_t)std::min<size_t>(k + chunk_pts, rows.size())});
-      }
       segfirst.push_back((uint32_t)chunks.size());
       std::vector<ChunkDesc> groups, segs;
       make_reduce_ranges(segfirst, groups, segs);
       Impl::Plan& P = plans[mode];
       P.nchunks = (uint32_t)chunks.size();
       P.ngroups = (uint32_t)groups.size();
-      P.nseg = nseg;
+      P.nseg = nseg * D.nh;
       P.rows.alloc(std::max<size_t>(rows.size(), 1));
       P.chunks.alloc(std::max<size_t>(chunks.size(), 1));
       P.groups.alloc(std::max<size_t>(groups.size(), 1));
@@ -1263,8 +1334,9 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     D.npts1 = (uint32_t)pts.size();
     D.sid1.alloc(sids.size());
     D.sid1.upload(sids.data(), sids.size(), s);
-    make_plans(sids, row_seg, 3, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK", 8)), D.plan1, &D.max_chunks1,
-               &D.max_groups1);
+    // rows (x halves) per single-wave workgroup: ~150 additions each, as before the split (8 rows x 19 windows)
+    make_plans(sids, row_seg, 3, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK", D.nh == 2 ? 16 : 8)), D.plan1,
+               &D.max_chunks1, &D.max_groups1);
     if (D.use29) build_table29<Fq, G1Affine29>(pts, D.ws, D.t1_29, s); else build_table<Fq>(pts, D.ws, D.t1, s);
   }
   {
@@ -1280,11 +1352,15 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     push(zk_.beta_g2, 0);
     push(zk_.delta_g2, SID_S);
     D.npts2 = (uint32_t)pts.size();
-    D.sid2.alloc(sids.size());
-    D.sid2.upload(sids.data(), sids.size(), s);
-    make_plans(sids, row_seg, 1, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_G2", 4)), D.plan2, &D.max_chunks2,
-               &D.max_groups2);
-    if (D.use29_g2) build_table29<Fq2, G2Affine29>(pts, D.ws, D.t2_29, s); else build_table<Fq2>(pts, D.ws, D.t2, s);
+    // the G2 digit array holds the witness scalars and r, s, -(r s) only (k_recode): ids above the h block move down
+    std::vector<uint32_t> dsid(sids);
+    for (uint32_t& v : dsid)
+      if (v >= D.NS) v -= D.n;
+    D.sid2.alloc(dsid.size());
+    D.sid2.upload(dsid.data(), dsid.size(), s);
+    make_plans(sids, row_seg, 1, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_G2", D.nh == 2 ? 8 : 4)), D.plan2,
+               &D.max_chunks2, &D.max_groups2);
+    if (D.use29_g2) build_table29<Fq2, G2Affine29>(pts, D.ws2, D.t2_29, s); else build_table<Fq2>(pts, D.ws2, D.t2, s);
   }
 
   // ---- named input slots for the proof-values kernel (single message-id circuit, witness.rs:832-881);
@@ -1323,13 +1399,14 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     S.comp.alloc(B * 128);
     S.V.alloc((size_t)D.N * B);
     S.abc.alloc(3 * (size_t)D.n * B);
-    S.digits.alloc((size_t)(D.NS + D.n + 3) * W_ * B);
+    S.digits.alloc((size_t)(D.NS + D.n + 3) * D.nh * D.ws.W * B);
+    S.digits2.alloc((size_t)(D.NS + 3) * D.nh * D.ws2.W * B);
     S.part1.alloc((size_t)D.max_chunks1 * B);
     S.grp1.alloc((size_t)D.max_groups1 * B);
-    S.sums1.alloc(3 * B);
+    S.sums1.alloc(3 * D.nh * B);
     S.part2.alloc((size_t)D.max_chunks2 * B);
     S.grp2.alloc((size_t)D.max_groups2 * B);
-    S.sums2.alloc(B);
+    S.sums2.alloc(D.nh * B);
     S.prod.alloc(2 * B);
     S.tbl.alloc(2 * 16 * B);
     S.affA.alloc(B);
@@ -1349,6 +1426,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     RLN_HIP(hipEventCreateWithFlags(&S.evC, hipEventDisableTiming));
     for (auto& e : S.t) RLN_HIP(hipEventCreate(&e));
     RLN_HIP(hipMemsetAsync(S.digits.p, 0, S.digits.bytes(), s));
+    RLN_HIP(hipMemsetAsync(S.digits2.p, 0, S.digits2.bytes(), s));
   }
   RLN_HIP(hipStreamSynchronize(s));
 }
@@ -1373,6 +1451,8 @@ Prover::~Prover() {
 }
 
 size_t Prover::table_bytes() const { return d_->t1.bytes() + d_->t1_29.bytes() + d_->t2.bytes() + d_->t2_29.bytes(); }
+size_t Prover::g1_rows() const { return d_->npts1; }
+size_t Prover::g2_rows() const { return d_->npts2; }
 
 void Prover::upload(size_t n, const uint8_t* inputs, const uint8_t* rs) {
   if (n > B_) throw Error("batch larger than the prover workspace (max_batch)");
@@ -1489,7 +1569,7 @@ void Prover::run_async(size_t n, int mode) {
   }
   RLN_HIP(hipEventRecord(S.t[5], sR));
   hipLaunchKernelGGL(k_recode, dim3(pg, D.NS + D.n + 3), dim3(64, 1), 0, sR, S.V.p, D.sig2node.p, D.NS,
-                     S.abc.p, D.n, D.rs.p, D.ws, S.digits.p, B, nbp);
+                     S.abc.p, D.n, D.rs.p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nbp);
   RLN_HIP(hipEventRecord(S.t[6], sR));
   // ---------------- stage B
   if (D.recode_front) {
@@ -1508,10 +1588,10 @@ void Prover::run_async(size_t n, int mode) {
       // dynamic LDS that the kernel never touches caps it at D.msm_waves waves per SIMD: at 4 x 128 VGPRs the
       // register file is full and the front end's NTT / mat-vec workgroups wait for an MSM workgroup (~1 ms) to retire
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(blocks), dim3(64), D.msm_lds, D.sB, D.t1_29.p, D.sid1.p, P1.rows.p, P1.chunks.p,
-                         P1.nchunks, S.digits.p, S.part1.p, D.ws, B, pg);
+                         P1.nchunks, S.digits.p, S.part1.p, D.ws, B, pg, D.nh);
     else
       hipLaunchKernelGGL(k_msm<Fq>, dim3(blocks), dim3(64), 0, D.sB, D.t1.p, D.sid1.p, P1.rows.p, P1.chunks.p,
-                         P1.nchunks, S.digits.p, S.part1.p, D.ws, B, pg);
+                         P1.nchunks, S.digits.p, S.part1.p, D.ws, B, pg, D.nh);
   }
   RLN_HIP(hipEventRecord(S.t[7], D.sB));
   RLN_HIP(hipEventRecord(S.t[11], s2));
@@ -1519,10 +1599,10 @@ void Prover::run_async(size_t n, int mode) {
     uint32_t blocks = div_up(P2.nchunks, 8) * 8 * pg;
     if (D.use29_g2)
       hipLaunchKernelGGL((k_msm29<G2Acc29, G2Affine29, G2XYZZ, 2>), dim3(blocks), dim3(64), 0, s2, D.t2_29.p, D.sid2.p,
-                         P2.rows.p, P2.chunks.p, P2.nchunks, S.digits.p, S.part2.p, D.ws, B, pg);
+                         P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, pg, D.nh);
     else
       hipLaunchKernelGGL(k_msm<Fq2>, dim3(blocks), dim3(64), 0, s2, D.t2.p, D.sid2.p, P2.rows.p, P2.chunks.p,
-                         P2.nchunks, S.digits.p, S.part2.p, D.ws, B, pg);
+                         P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, pg, D.nh);
   }
   RLN_HIP(hipEventRecord(S.t[8], s2));
   RLN_HIP(hipEventRecord(S.evB, D.sB));
@@ -1550,8 +1630,10 @@ void Prover::run_async(size_t n, int mode) {
   if (P2.ngroups)
     hipLaunchKernelGGL(k_sum_ranges<Fq2>, dim3(pg, P2.ngroups), dim3(64), 0, D.sC, S.part2.p, P2.groups.p, P2.ngroups,
                        S.grp2.p, B, nbp);
-  hipLaunchKernelGGL(k_sum_ranges<Fq>, dim3(pg, 3), dim3(64), 0, D.sC, S.grp1.p, P1.segs.p, 3u, S.sums1.p, B, nbp);
-  hipLaunchKernelGGL(k_sum_ranges<Fq2>, dim3(pg, 1), dim3(64), 0, D.sC, S.grp2.p, P2.segs.p, 1u, S.sums2.p, B, nbp);
+  hipLaunchKernelGGL(k_sum_ranges<Fq>, dim3(pg, P1.nseg), dim3(64), 0, D.sC, S.grp1.p, P1.segs.p, P1.nseg, S.sums1.p, B, nbp);
+  hipLaunchKernelGGL(k_sum_ranges<Fq2>, dim3(pg, P2.nseg), dim3(64), 0, D.sC, S.grp2.p, P2.segs.p, P2.nseg, S.sums2.p, B, nbp);
+  if (D.nh == 2)  // sums of the second halves through phi, onto the first: afterwards sums1[0..3) / sums2[0] as without GLV
+    hipLaunchKernelGGL(k_glv_fold, dim3(pg, 4), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, 3u, B, nbp);
   if (mode == PROVE_PARTIAL) {
     hipLaunchKernelGGL(k_partial_out, dim3(pg, 4), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, S.pp_out.p, B, nbp);
     RLN_HIP(hipGetLastError());
