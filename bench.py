@@ -266,7 +266,7 @@ def main():
         achieved = (MSM_G1_BYTES_PER_PROOF * B) / (msm_ms * 1e-3) / 1e9 if msm_ms > 0 else 0.0
         traffic = None   # HBM bytes per launch of the dominant kernel, from the committed PMC passes
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_k_msm_g1.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_k_msm_g1.json")))
             if B == 1024 and int(prover.info.window_bits) == pm.get("window_bits") and \
                     int(prover.info.windows) == pm.get("windows"):
                 traffic = round(pm["traffic_bytes_per_launch"] / 1e9, 3)
@@ -299,7 +299,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_msm29<G1> (G1 fixed-base table MSM, 9 x 29-bit limbs)",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
-                         "traffic_unit": "GB per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r1_pmc_k_msm_g1.json)",
+                         "traffic_unit": "GB per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r2_pmc_k_msm_g1.json)",
                          "launch_ms": round(msm_ms, 3), "launch_ms_alone": round(g1_alone_ms, 3),
                          # what the table-walk algorithm itself must read: one 64-byte entry per mixed addition
                          "table_walk_gb_per_launch": round(int(prover.info.g1_rows) * int(prover.info.windows) * B * 64 / 1e9, 3),
