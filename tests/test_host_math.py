@@ -166,3 +166,22 @@ def test_glv_split_and_endomorphism(L):
         T = G2.mul(G2_GEN, kk)
         L.hm_glv_phi_g2(g2b(T), out)
         assert g2i(out.raw) == G2.mul(T, lam)
+
+
+def test_fq29_column_bounds_of_every_call_site():
+    """fq29.h accumulates 64-bit columns without carry capture; since round 2 most reductions run "wide" rounds (a
+    32-bit digit, no mask / 64-bit shift), which raises a column by up to 2^32 * sum(p[j]).  tools/check_fq29_bounds.py
+    replays every call site (G1 / G2 mixed addition and doubling, Fq2 products, Poseidon rounds, conversions) with all
+    limbs and digits at their maxima and fails on any column that reaches 2^64."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_fq29_bounds", os.path.join(ROOT, "tools", "check_fq29_bounds.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rows = mod.main(verbose=False)
+    assert len(rows) >= 25 and all(r[3] < 16.0 for r in rows)
+    assert max(r[3] for r in rows) > 15.0   # the G2 Y3 dot products sit at 15.53: the check is not vacuous
+    # the constants in the generated header are the ones the replay used
+    hdr = open(os.path.join(ROOT, "zerokit_amd", "csrc", "fq29_constants.h")).read()
+    f = mod.Field(mod.Q)
+    assert "INV32 = 0x%08xu" % ((-pow(f.P[0], -1, 1 << 32)) % (1 << 32)) in hdr
+    assert ("{" + ", ".join("0x%08xu" % l for l in f.K6) + "}") in hdr

@@ -55,9 +55,73 @@ struct F29 {
     }
   }
 
-  // REDC(sum of N products): t accumulates columns; one limb is retired per round
-  template <int NP>
-  static __device__ __forceinline__ F29 redc_dot(const F29* const (&a)[NP], const F29* const (&b)[NP]) {
+  // ---- Montgomery reduction rounds ------------------------------------------------------------------------------
+  // Opaque scalar constants: with an unknown multiplier the compiler keeps "x * c + t" as ONE v_mad_u64_u32 (it would
+  // turn x * 8 + t into a zero-extension, a 64-bit shift and a 64-bit add, and x * 1 + t into a zero-extension and an
+  // add).  s_mov_b32 is scalar work, off the VALU issue slots that bound the walks.
+  static __device__ __forceinline__ uint32_t sc8() {
+    uint32_t r;
+    asm("s_mov_b32 %0, 8" : "=s"(r));
+    return r;
+  }
+  static __device__ __forceinline__ uint32_t sc1() {
+    uint32_t r;
+    asm("s_mov_b32 %0, 1" : "=s"(r));
+    return r;
+  }
+  // One round retires column t[0] (weight 2^0) and renumbers t[1..9] to t[0..8].
+  //   masked: m = (t[0] INV) mod 2^29, t += m p, carry = t[0] >> 29            -- 4 instructions beside the 9 products
+  //   wide:   m' = (t[0] INV32) mod 2^32 with INV32 = -p[0]^-1 mod 2^32.  m' = m mod 2^29, so t[0] + m' p[0] is
+  //           0 mod 2^29 as before (the extra bits of m' only add a multiple of p 2^29), and it is 0 mod 2^32 as well,
+  //           so the carry t[0] / 2^29 is exactly 8 * hi32(t[0]): one multiply-add, no mask, no 64-bit shift
+  //           -- 2 instructions beside the 9 products.
+  // The price of the wide round is the column bound: m' p[j] < 2^32 p[j] instead of 2^29 p[j].  A column collects at
+  // most m' (p[0] + ... + p[8]) < 2^32 * 1.51 2^30 = 6.1 2^60 (Fq; Fr 6.8 2^60) from the reduction, which leaves
+  // 16 2^60 - 6.8 2^60 for the products: tools/check_fq29_bounds.py replays every call site of this file and of
+  // poseidon.h with all operand limbs at their class maximum and asserts that no column reaches 2^64.  The last round
+  // is always masked: an unmasked m_8 would add up to 7 p to the RESULT (the earlier rounds' excess is divided by
+  // 2^29 at least once: below 2^-26 p in total), and the bounds of the callers assume result < p + a b / 2^261.
+  template <bool WIDE>
+  static __device__ __forceinline__ void redc_round(uint64_t (&t)[10]) {
+    if (WIDE) {
+      const uint32_t m = (uint32_t)t[0] * C::INV32;
+#pragma unroll
+      for (int j = 0; j < 9; j++) t[j] += (uint64_t)m * C::P[j];
+      t[1] += (uint64_t)(uint32_t)(t[0] >> 32) * sc8();
+#pragma unroll
+      for (int j = 0; j < 9; j++) t[j] = t[j + 1];
+    } else {
+      const uint32_t m = ((uint32_t)t[0] * C::INV) & M;
+#pragma unroll
+      for (int j = 0; j < 9; j++) t[j] += (uint64_t)m * C::P[j];
+      const uint64_t carry = t[0] >> 29;
+#pragma unroll
+      for (int j = 0; j < 9; j++) t[j] = t[j + 1];
+      t[0] += carry;
+    }
+    t[9] = 0;
+  }
+  // carry chain over the nine result columns; `add` (limbs < 2^32, may be null) is added to the columns first, which
+  // saves the separate normalisation of "product + K - b" (24 instructions)
+  static __device__ __forceinline__ F29 finish(uint64_t (&t)[10], const F29* add) {
+    if (add) {
+#pragma unroll
+      for (int j = 0; j < 9; j++) t[j] += (uint64_t)add->v[j] * sc1();
+    }
+    F29 r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      r.v[j] = (uint32_t)t[j] & M;
+      t[j + 1] += t[j] >> 29;
+    }
+    r.v[8] = (uint32_t)t[8];
+    return r;
+  }
+
+  // REDC(sum of N products) [+ add]: t accumulates columns; one limb is retired per round
+  template <int NP, bool WIDE = false>
+  static __device__ __forceinline__ F29 redc_dot(const F29* const (&a)[NP], const F29* const (&b)[NP],
+                                                 const F29* add = nullptr) {
     uint64_t t[10];
 #pragma unroll
     for (int j = 0; j < 10; j++) t[j] = 0;
@@ -68,33 +132,26 @@ struct F29 {
 #pragma unroll
         for (int j = 0; j < 9; j++) t[j] += (uint64_t)a[k]->v[j] * b[k]->v[i];
       }
-      uint32_t m = ((uint32_t)t[0] * C::INV) & M;
-#pragma unroll
-      for (int j = 0; j < 9; j++) t[j] += (uint64_t)m * C::P[j];
-      uint64_t carry = t[0] >> 29;
-#pragma unroll
-      for (int j = 0; j < 9; j++) t[j] = t[j + 1];
-      t[0] += carry;
-      t[9] = 0;
+      if (i < 8) redc_round<WIDE>(t); else redc_round<false>(t);
     }
-    F29 r;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      r.v[j] = (uint32_t)t[j] & M;
-      t[j + 1] += t[j] >> 29;
-    }
-    r.v[8] = (uint32_t)t[8];
-    return r;
+    return finish(t, add);
   }
+  // wide rounds: N x N, N x lazy, lazy x lazy (check_fq29_bounds.py: "mul")
   static __device__ __forceinline__ F29 mul(const F29& a, const F29& b) {
     const F29* const aa[1] = {&a};
     const F29* const bb[1] = {&b};
-    return redc_dot<1>(aa, bb);
+    return redc_dot<1, true>(aa, bb);
   }
-  // REDC(a^2): row i adds a_i^2 into column 2 i and (2 a_i) a_l, l > i, into column i + l -- 45 products instead of
-  // 81.  Column i is complete when round i retires it (its terms come from rows k <= i / 2).  The column sums are the
-  // same integers as in mul(a, a), so the bounds of mul hold; a may be N or lazy.
-  static __device__ __forceinline__ F29 sqr(const F29& a) {
+  // a b / 2^261 + add, normalised (add: limbs < 2^32, e.g. K - x for a normalised x)
+  static __device__ __forceinline__ F29 mul_add(const F29& a, const F29& b, const F29& add) {
+    const F29* const aa[1] = {&a};
+    const F29* const bb[1] = {&b};
+    return redc_dot<1, true>(aa, bb, &add);
+  }
+  // REDC(a^2) [+ add]: row i adds a_i^2 into column 2 i and (2 a_i) a_l, l > i, into column i + l -- 45 products
+  // instead of 81.  Column i is complete when round i retires it (its terms come from rows k <= i / 2).  The column
+  // sums are the same integers as in mul(a, a), so the bounds of mul hold; a may be N or lazy.
+  static __device__ __forceinline__ F29 sqr_add(const F29& a, const F29* add) {
     uint64_t t[10];
 #pragma unroll
     for (int j = 0; j < 10; j++) t[j] = 0;
@@ -104,43 +161,40 @@ struct F29 {
       const uint32_t d = 2 * a.v[i];
 #pragma unroll
       for (int l = i + 1; l < 9; l++) t[l] += (uint64_t)d * a.v[l];
-      uint32_t m = ((uint32_t)t[0] * C::INV) & M;
-#pragma unroll
-      for (int j = 0; j < 9; j++) t[j] += (uint64_t)m * C::P[j];
-      uint64_t carry = t[0] >> 29;
-#pragma unroll
-      for (int j = 0; j < 9; j++) t[j] = t[j + 1];
-      t[0] += carry;
-      t[9] = 0;
+      if (i < 8) redc_round<true>(t); else redc_round<false>(t);
     }
-    F29 r;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      r.v[j] = (uint32_t)t[j] & M;
-      t[j + 1] += t[j] >> 29;
-    }
-    r.v[8] = (uint32_t)t[8];
-    return r;
+    return finish(t, add);
   }
-  // a0 b0 + a1 b1 with one reduction
+  static __device__ __forceinline__ F29 sqr(const F29& a) { return sqr_add(a, nullptr); }
+  // a0 b0 + a1 b1 with one reduction, wide rounds (check_fq29_bounds.py lists the operand classes of every caller)
   static __device__ __forceinline__ F29 dot2(const F29& a0, const F29& b0, const F29& a1, const F29& b1) {
     const F29* const aa[2] = {&a0, &a1};
     const F29* const bb[2] = {&b0, &b1};
-    return redc_dot<2>(aa, bb);
+    return redc_dot<2, true>(aa, bb);
   }
+  static __device__ __forceinline__ F29 dot2_add(const F29& a0, const F29& b0, const F29& a1, const F29& b1,
+                                                  const F29& add) {
+    const F29* const aa[2] = {&a0, &a1};
+    const F29* const bb[2] = {&b0, &b1};
+    return redc_dot<2, true>(aa, bb, &add);
+  }
+  // three / four products with one reduction.  WIDE rounds only where check_fq29_bounds.py has the call site: all
+  // operands normalised (dot3, dot4: Poseidon's MDS rows), or dot4 with two lazy operands K8 - x, K4 - x (G2's Y3:
+  // 15.53 2^60 of 16 2^60).  Masked rounds take at most two lazy operands (limbs < 2^30):
+  // 9 (2 2^59 + 2 2^58 + 2^58) = 15.75 2^60 < 2^64
+  template <bool WIDE = false>
   static __device__ __forceinline__ F29 dot3(const F29& a0, const F29& b0, const F29& a1, const F29& b1, const F29& a2,
-                                             const F29& b2) {  // at most two lazy operands (see dot4)
+                                             const F29& b2) {
     const F29* const aa[3] = {&a0, &a1, &a2};
     const F29* const bb[3] = {&b0, &b1, &b2};
-    return redc_dot<3>(aa, bb);
+    return redc_dot<3, WIDE>(aa, bb);
   }
-  // sum of four products with one reduction; at most two of the eight operands may be lazy (limbs < 2^30):
-  // 9 (2 2^59 + 2 2^58 + 2^58) = 15.75 2^60 < 2^64
+  template <bool WIDE = false>
   static __device__ __forceinline__ F29 dot4(const F29& a0, const F29& b0, const F29& a1, const F29& b1,
                                               const F29& a2, const F29& b2, const F29& a3, const F29& b3) {
     const F29* const aa[4] = {&a0, &a1, &a2, &a3};
     const F29* const bb[4] = {&b0, &b1, &b2, &b3};
-    return redc_dot<4>(aa, bb);
+    return redc_dot<4, WIDE>(aa, bb);
   }
   // K - b limb by limb: no borrows because every limb of the biased constant K dominates a normalised limb
   static __device__ __forceinline__ F29 neg_lazy(const uint32_t (&K)[9], const F29& b) {
@@ -160,10 +214,9 @@ struct F29 {
 
   // exact: is the (normalised) value one of 0, q, 2q, ..., 7q ?
   __device__ __forceinline__ bool is_zero_mod_q() const {
-    bool hit = false;
-#pragma unroll
-    for (int k = 0; k < 8; k++) hit |= v[0] == C::KP[k][0];
-    if (!hit) return false;  // the low limb filters all but 8 / 2^29 of the values
+    // the integer k q has low limb (k q) mod 2^29, so (v[0] q^-1) mod 2^29 = k: three instructions filter all but
+    // 8 / 2^29 of the values (eight compares of v[0] against the low limbs before)
+    if (((v[0] * C::QINV) & M) >= 8u) return false;
     for (int k = 0; k < 8; k++) {
       bool eq = true;
       for (int j = 0; j < 9; j++) eq &= v[j] == C::KP[k][j];
@@ -337,8 +390,11 @@ struct G1Acc29 {
       ZZZ = ZZ;
       return;
     }
-    Fq29 P = Fq29::sub(Fq29::mul(px, ZZ), Fq29C::K6, X);    // U2 - X   in (0.8 q, 7.2 q)
-    Fq29 R = Fq29::sub(Fq29::mul(py, ZZZ), Fq29C::K4, Y);   // S2 - Y   in (1.9 q, 5.2 q)
+    // "product + K - b" leaves the reduction's own carry chain normalised (Fq29::mul_add): no second normalisation
+    const Fq29 kX = Fq29::neg_lazy(Fq29C::K6, X);
+    const Fq29 nY = Fq29::neg_lazy(Fq29C::K4, Y);            // lazy, < 4 q; also the -Y of Y3 below
+    Fq29 P = Fq29::mul_add(px, ZZ, kX);                      // U2 - X   in (0.8 q, 7.2 q)
+    Fq29 R = Fq29::mul_add(py, ZZZ, nY);                     // S2 - Y   in (1.9 q, 5.2 q)
     if (P.is_zero_mod_q()) {                                // same x
       if (R.is_zero_mod_q()) {
         py.normalize();
@@ -353,17 +409,16 @@ struct G1Acc29 {
     Fq29 Q = Fq29::mul(X, PP);                        // < 1.1 q
     Fq29 PPP = Fq29::mul(P, PP);                      // < 1.1 q
     ZZZ = Fq29::mul(ZZZ, PPP);
-    Fq29 R2 = Fq29::sqr(R);                           // < 1.2 q
+    Fq29 kT;
 #pragma unroll
-    for (int j = 0; j < 9; j++) X.v[j] = R2.v[j] + Fq29C::K4T[j] - (PPP.v[j] + 2 * Q.v[j]);
-    X.normalize();                                    // X3 in (0.7 q, 5.2 q)
-    // Q - X3 < 7.1 q, left un-normalised: limbs < 2^29 + 2^30.  In the dot product below its partner R is normalised,
-    // nY is lazy (< 2^30) and PPP normalised: a column is at most 9 (2^29 (2^29 + 2^30) + 2^30 2^29 + 2^58) =
-    // 54 2^58 < 2^64, so the 24-instruction carry chain of a normalisation is not needed here
+    for (int j = 0; j < 9; j++) kT.v[j] = Fq29C::K4T[j] - (PPP.v[j] + 2 * Q.v[j]);   // limbs in (0, 2^31)
+    X = Fq29::sqr_add(R, &kT);                        // X3 = R^2 - PPP - 2 Q   in (0.7 q, 5.2 q)
+    // Q - X3 < 7.1 q, left un-normalised: limbs < 2^29 + K6[j].  In the dot product below its partner R is normalised,
+    // nY is lazy (K4[j] at most) and PPP normalised; with the wide rounds a column is at most
+    // 2^29 (sum_j (K6[j] + 2^29) + sum_j K4[j]) + 2^32 sum_j p[j] = 13.8 2^60 < 2^64 (check_fq29_bounds.py "g1.Y3")
     Fq29 D;
 #pragma unroll
     for (int j = 0; j < 9; j++) D.v[j] = Q.v[j] + Fq29C::K6[j] - X.v[j];
-    Fq29 nY = Fq29::neg_lazy(Fq29C::K4, Y);           // lazy, < 4 q
     Y = Fq29::dot2(R, D, nY, PPP);                    // R (Q - X3) - Y PPP  < 1.3 q
   }
 };
@@ -385,6 +440,24 @@ struct Fq2_29 {
     }
     d = Fq29::sub(a.c0, Fq29C::K8, a.c1);
     return {Fq29::mul(s, d), Fq29::mul(t, a.c1)};
+  }
+  // a b + add, add = (K - x.c0, K - x.c1) limb by limb: normalised by the reductions' own carry chains
+  static __device__ __forceinline__ Fq2_29 mul_add(const Fq2_29& a, const Fq2_29& b, const Fq2_29& add) {
+    Fq29 n1 = Fq29::neg_lazy(Fq29C::K8, a.c1);
+    return {Fq29::dot2_add(a.c0, b.c0, n1, b.c1, add.c0), Fq29::dot2_add(a.c0, b.c1, a.c1, b.c0, add.c1)};
+  }
+  static __device__ __forceinline__ Fq2_29 sqr_add(const Fq2_29& a, const Fq2_29& add) {
+    Fq29 s, d, t;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      s.v[j] = a.c0.v[j] + a.c1.v[j];   // lazy
+      t.v[j] = 2 * a.c0.v[j];           // lazy
+    }
+    d = Fq29::sub(a.c0, Fq29C::K8, a.c1);
+    return {Fq29::mul_add(s, d, add.c0), Fq29::mul_add(t, a.c1, add.c1)};
+  }
+  static __device__ __forceinline__ Fq2_29 neg_lazy(const uint32_t (&K)[9], const Fq2_29& b) {
+    return {Fq29::neg_lazy(K, b.c0), Fq29::neg_lazy(K, b.c1)};
   }
   static __device__ __forceinline__ Fq2_29 sub(const Fq2_29& a, const uint32_t (&K)[9], const Fq2_29& b) {
     return {Fq29::sub(a.c0, K, b.c0), Fq29::sub(a.c1, K, b.c1)};
@@ -459,8 +532,8 @@ struct G2Acc29 {
     Fq29 nM1 = Fq29::neg_lazy(Fq29C::K8, Mm.c1);
     Fq29 ny0 = Fq29::neg_lazy(Fq29C::K4, y.c0);
     Fq29 ny1 = Fq29::neg_lazy(Fq29C::K4, y.c1);
-    Fq29 y0 = Fq29::dot4(Mm.c0, D.c0, nM1, D.c1, W.c0, ny0, W.c1, y.c1);   // M D - W y
-    Fq29 y1 = Fq29::dot4(Mm.c0, D.c1, Mm.c1, D.c0, W.c0, ny1, W.c1, ny0);
+    Fq29 y0 = Fq29::dot4<true>(Mm.c0, D.c0, nM1, D.c1, W.c0, ny0, W.c1, y.c1);   // M D - W y
+    Fq29 y1 = Fq29::dot4<true>(Mm.c0, D.c1, Mm.c1, D.c0, W.c0, ny1, W.c1, ny0);
     return {X3, {y0, y1}, V, W};
   }
 
@@ -480,8 +553,10 @@ struct G2Acc29 {
       ZZZ = ZZ;
       return;
     }
-    Fq2_29 P = Fq2_29::sub(Fq2_29::mul(px, ZZ), Fq29C::K6, X);
-    Fq2_29 R = Fq2_29::sub(Fq2_29::mul(py, ZZZ), Fq29C::K4, Y);
+    const Fq2_29 kX = Fq2_29::neg_lazy(Fq29C::K6, X);
+    const Fq2_29 nY = Fq2_29::neg_lazy(Fq29C::K4, Y);      // also the -Y of Y3 below
+    Fq2_29 P = Fq2_29::mul_add(px, ZZ, kX);
+    Fq2_29 R = Fq2_29::mul_add(py, ZZZ, nY);
     if (P.is_zero_mod_q()) {  // same x: doubling or cancellation (rare), kept in this form: no extra registers
       if (R.is_zero_mod_q()) *this = dbl_affine(px, py); else *this = inf();
       return;
@@ -491,21 +566,20 @@ struct G2Acc29 {
     Fq2_29 Q = Fq2_29::mul(X, PP);
     Fq2_29 PPP = Fq2_29::mul(P, PP);
     ZZZ = Fq2_29::mul(ZZZ, PPP);
-    Fq2_29 R2 = Fq2_29::sqr(R);
+    Fq2_29 kT;
 #pragma unroll
     for (int j = 0; j < 9; j++) {
-      X.c0.v[j] = R2.c0.v[j] + Fq29C::K4T[j] - (PPP.c0.v[j] + 2 * Q.c0.v[j]);
-      X.c1.v[j] = R2.c1.v[j] + Fq29C::K4T[j] - (PPP.c1.v[j] + 2 * Q.c1.v[j]);
+      kT.c0.v[j] = Fq29C::K4T[j] - (PPP.c0.v[j] + 2 * Q.c0.v[j]);
+      kT.c1.v[j] = Fq29C::K4T[j] - (PPP.c1.v[j] + 2 * Q.c1.v[j]);
     }
-    X.c0.normalize();
-    X.c1.normalize();
+    X = Fq2_29::sqr_add(R, kT);                             // X3 = R^2 - PPP - 2 Q
     Fq2_29 D = Fq2_29::sub(Q, Fq29C::K6, X);
     // Y3 = R D - Y PPP, four base products per component, one reduction each
     Fq29 nR1 = Fq29::neg_lazy(Fq29C::K8, R.c1);
-    Fq29 nY0 = Fq29::neg_lazy(Fq29C::K4, Y.c0);
-    Fq29 nY1 = Fq29::neg_lazy(Fq29C::K4, Y.c1);
-    Fq29 y0 = Fq29::dot4(R.c0, D.c0, nR1, D.c1, nY0, PPP.c0, Y.c1, PPP.c1);
-    Fq29 y1 = Fq29::dot4(R.c0, D.c1, R.c1, D.c0, nY0, PPP.c1, nY1, PPP.c0);
+    const Fq29& nY0 = nY.c0;
+    const Fq29& nY1 = nY.c1;
+    Fq29 y0 = Fq29::dot4<true>(R.c0, D.c0, nR1, D.c1, nY0, PPP.c0, Y.c1, PPP.c1);
+    Fq29 y1 = Fq29::dot4<true>(R.c0, D.c1, R.c1, D.c0, nY0, PPP.c1, nY1, PPP.c0);
     Y = {y0, y1};
   }
 };

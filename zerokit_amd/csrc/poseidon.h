@@ -116,7 +116,8 @@ __device__ __forceinline__ Fr poseidon_hash_dev_8x32(const Fr* in, const Poseido
 // product).  Bounds: state entries leave a round normalised and < 1.1 r; "+ ark" makes them lazy (limbs < 2^30,
 // < 2.1 r); x^2 = lazy x lazy (9 (2^60 + 2^58) < 2^64), x^5 = x^4 x; an MDS row is one T-term dot product with at most
 // two lazy operands (T = 4 normalises the pass-through entries of a partial round first).
-// sum of N products of normalised operands with one reduction, N <= 5: 9 (5 2^58 + 2^58) < 2^64 per column
+// sum of N products of normalised operands with one reduction, N <= 5: 9 (5 2^58 + 2^58) < 2^64 per column; up to
+// four products take the wide reduction rounds of fq29.h (tools/check_fq29_bounds.py: 14.8 2^60 at N = 4)
 template <int N>
 __device__ __forceinline__ Fr29 poseidon_dotn29(const Fr29* a, const Fr29* b) {
   static_assert(N >= 1 && N <= 5, "column sums must stay below 2^64");
@@ -127,7 +128,7 @@ __device__ __forceinline__ Fr29 poseidon_dotn29(const Fr29* a, const Fr29* b) {
     aa[k] = a + k;
     bb[k] = b + k;
   }
-  return Fr29::redc_dot<N>(aa, bb);
+  return Fr29::redc_dot<N, (N <= 4)>(aa, bb);
 }
 
 template <int T, bool FULL>
@@ -159,9 +160,9 @@ __device__ __forceinline__ void poseidon_round29(Fr29* st, const uint32_t* __res
     if constexpr (T == 2)
       nx[i] = Fr29::dot2(m[0], st[0], m[1], st[1]);
     else if constexpr (T == 3)
-      nx[i] = Fr29::dot3(m[0], st[0], m[1], st[1], m[2], st[2]);
+      nx[i] = Fr29::dot3<FULL>(m[0], st[0], m[1], st[1], m[2], st[2]);   // FULL: every entry left the S-box normalised
     else if constexpr (T == 4)
-      nx[i] = Fr29::dot4(m[0], st[0], m[1], st[1], m[2], st[2], m[3], st[3]);
+      nx[i] = Fr29::dot4<true>(m[0], st[0], m[1], st[1], m[2], st[2], m[3], st[3]);   // all normalised (see above)
     else if constexpr (T == 5)
       nx[i] = poseidon_dotn29<5>(m, st);
     else {  // t = 6..9: two groups, each reduced once; the sum (< 2.2 r, limbs < 2^30) is normalised

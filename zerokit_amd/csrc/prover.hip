@@ -9,6 +9,7 @@
 #include <algorithm>
 
 #include "fq29.h"
+#include "walk29.h"
 #include "glv.h"
 #include "pairing.h"
 #include "poseidon.h"
@@ -398,19 +399,6 @@ __global__ void __launch_bounds__(256) k_hquot(Fr* __restrict__ abc, uint32_t n,
   abc[o] = abc[o] * abc[(size_t)n * B + o] - abc[2 * (size_t)n * B + o];
 }
 
-// Window schedule of the comb tables.  Window j covers cw[j] scalar bits starting at bit bo[j]; its table row holds
-// the 2^(cw[j]-1) multiples d 2^bo[j] P (signed digits) at entry offset ro[j] inside the point's block of `stride`
-// entries.  Uniform widths (c, c, ...) are the classical comb; with 288 GB of HBM the first `wide` windows take one
-// more bit so that W drops from 20 to 19 at c = 13 (8 x 14 + 11 x 13 = 255 bits, table x 1.35).  Passed by value:
-// the kernels index it with wave-uniform j (scalar loads from the kernarg segment).
-struct WinSched {
-  int W;
-  uint32_t stride;
-  uint8_t cw[32];
-  uint16_t bo[32];
-  uint32_t ro[32];
-};
-
 // =====================================================================================================
 // 4. scalars -> signed digits (window j: cw[j] bits), layout [scalar][half][window][proof] (int16)
 // =====================================================================================================
@@ -492,10 +480,6 @@ __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ V, const 
 // =====================================================================================================
 // 5. table-driven MSM: acc += +-T[point][window][|digit|-1]
 // =====================================================================================================
-struct ChunkDesc {
-  uint32_t pt_begin, pt_end;  // compact point range
-};
-
 template <class F>
 __global__ void __launch_bounds__(64) k_msm(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ sid,
                                             const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks,
@@ -533,38 +517,6 @@ __global__ void __launch_bounds__(64) k_msm(const Affine<F>* __restrict__ table,
   part[(size_t)chunk * B + p] = acc;
 }
 
-// The same walk for G1 in the 9 x 29-bit form of fq29.h (tables and accumulator): 16.0 G mixed additions/s against
-// 12.6 G in the 8 x 32 form (tools/microbench29.hip).  Partial sums leave in the common XYZZ<Fq> form.
-template <class Acc, class Entry, class Out, int WAVES>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_msm29(const Entry* __restrict__ table, const uint32_t* __restrict__ sid,
-                                              const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks,
-                                              uint32_t nchunks, const int16_t* __restrict__ digits,
-                                              Out* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups,
-                                              uint32_t nh) {
-  uint32_t L = blockIdx.x;
-  uint32_t xcd = L & 7, q = L >> 3;
-  uint32_t chunk = (q / pgroups) * 8 + xcd, pg = q % pgroups;
-  if (chunk >= nchunks) return;
-  uint32_t p = pg * 64 + threadIdx.x;
-  ChunkDesc cd = chunks[chunk];
-  Acc acc = Acc::inf();
-  const int W = ws.W;
-#pragma unroll 1
-  for (uint32_t i = cd.pt_begin; i < cd.pt_end; i++) {
-    const uint32_t kk = rows[i], k = kk & 0x7FFFFFFFu;  // bit 31: second GLV half (see k_msm)
-    const int16_t* dg = digits + ((size_t)sid[k] * nh + (kk >> 31)) * W * B + p;
-    const Entry* row = table + (size_t)k * ws.stride;
-#pragma unroll 1
-    for (int j = 0; j < W; j++) {  // (touching the next entry ahead of the addition was measured: 3 % slower)
-      int d = dg[(size_t)j * B];
-      if (d != 0) {
-        uint32_t e = (uint32_t)(d < 0 ? -d : d) - 1;
-        acc.madd(row[ws.ro[j] + e], d < 0);
-      }
-    }
-  }
-  part[(size_t)chunk * B + p] = acc.to_xyzz();
-}
 template <class A, class E>
 __global__ void __launch_bounds__(256) k_table_to29(const A* __restrict__ src, E* __restrict__ dst, size_t n) {
   size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -1,0 +1,62 @@
+// walk29.h -- the fixed-base table walk of the prover in the 9 x 29-bit limb form (fq29.h): window schedule, chunk
+// descriptor and the kernel itself.  A header of its own so that tools/asm_walk.hip can compile the two instantiations
+// alone (seconds instead of the three minutes of prover.hip) when the instruction count of the walk is being worked on.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fq29.h"
+
+namespace rlnamd {
+
+// Window schedule of the comb tables.  Window j covers cw[j] scalar bits starting at bit bo[j]; its table row holds
+// the 2^(cw[j]-1) multiples d 2^bo[j] P (signed digits) at entry offset ro[j] inside the point's block of `stride`
+// entries.  Uniform widths (c, c, ...) are the classical comb; with 288 GB of HBM the first `wide` windows take one
+// more bit so that W drops from 20 to 19 at c = 13 (8 x 14 + 11 x 13 = 255 bits, table x 1.35).  Passed by value:
+// the kernels index it with wave-uniform j (scalar loads from the kernarg segment).
+struct WinSched {
+  int W;
+  uint32_t stride;
+  uint8_t cw[32];
+  uint16_t bo[32];
+  uint32_t ro[32];
+};
+
+struct ChunkDesc {
+  uint32_t pt_begin, pt_end;  // compact point range
+};
+
+// The same walk for G1 in the 9 x 29-bit form of fq29.h (tables and accumulator): 16.0 G mixed additions/s against
+// 12.6 G in the 8 x 32 form (tools/microbench29.hip).  Partial sums leave in the common XYZZ<Fq> form.
+template <class Acc, class Entry, class Out, int WAVES>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_msm29(const Entry* __restrict__ table, const uint32_t* __restrict__ sid,
+                                              const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks,
+                                              uint32_t nchunks, const int16_t* __restrict__ digits,
+                                              Out* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups,
+                                              uint32_t nh) {
+  uint32_t L = blockIdx.x;
+  uint32_t xcd = L & 7, q = L >> 3;
+  uint32_t chunk = (q / pgroups) * 8 + xcd, pg = q % pgroups;
+  if (chunk >= nchunks) return;
+  uint32_t p = pg * 64 + threadIdx.x;
+  ChunkDesc cd = chunks[chunk];
+  Acc acc = Acc::inf();
+  const int W = ws.W;
+#pragma unroll 1
+  for (uint32_t i = cd.pt_begin; i < cd.pt_end; i++) {
+    const uint32_t kk = rows[i], k = kk & 0x7FFFFFFFu;  // bit 31: second GLV half (see k_msm)
+    const int16_t* dg = digits + ((size_t)sid[k] * nh + (kk >> 31)) * W * B + p;
+    const Entry* row = table + (size_t)k * ws.stride;
+#pragma unroll 1
+    for (int j = 0; j < W; j++) {  // (touching the next entry ahead of the addition was measured: 3 % slower)
+      int d = dg[(size_t)j * B];
+      if (d != 0) {
+        uint32_t e = (uint32_t)(d < 0 ? -d : d) - 1;
+        acc.madd(row[ws.ro[j] + e], d < 0);
+      }
+    }
+  }
+  part[(size_t)chunk * B + p] = acc.to_xyzz();
+}
+
+}  // namespace rlnamd
