@@ -81,6 +81,29 @@ def cpu_baseline(ws, rs, target_seconds=12.0):
         return {"error": str(e)}
 
 
+def valu_view(prover, B, alone_ms, clock_mhz):
+    """VALU side of the roofline for the G1 walk: instructions per launch from the committed PMC pass (they scale with
+    the number of additions), rate = instructions / duration of a launch with nothing else in flight"""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_walks.json")))["kernels"]["k_msm29<G1>"]
+        per_wave_add = pm["SQ_INSTS_VALU"] / (pm["lane_additions_per_launch"] / 64)
+    except Exception:  # noqa: BLE001
+        return None
+    adds = int(prover.info.g1_rows) * int(prover.info.windows) * B
+    insts = per_wave_add * adds / 64
+    if alone_ms <= 0:
+        return None
+    rate = insts / (alone_ms * 1e-3) / 1e9
+    peak_nominal = 1024 * 2.4e9 / 4 / 1e9
+    out = {"valu_insts_per_wave_addition": round(per_wave_add, 1), "valu_insts_per_launch_G": round(insts / 1e9, 3),
+           "achieved_Ginst_per_s": round(rate, 1), "peak_Ginst_per_s_at_2400MHz": round(peak_nominal, 1),
+           "frac_of_nominal_clock_peak": round(rate / peak_nominal, 4)}
+    if clock_mhz > 0:
+        out["clock_mhz"] = round(clock_mhz, 1)
+        out["frac_of_peak_at_measured_clock"] = round(rate / (1024 * clock_mhz * 1e6 / 4 / 1e9), 4)
+    return out
+
+
 def prover_alone_ms(prover):
     """msm_g1 span of the batch that just ran alone (run() = one batch, pipeline drained)"""
     return prover.stage_ms().get("msm_g1", 0.0)
@@ -231,6 +254,7 @@ def main():
     for _ in range(args.warmup):
         prover.run_async_mode(n, 2) if finish else prover.run(n)
     prover.sync()
+    prover.walk_clock_mhz()   # reset the clock tap: what follows is the timed region's clock
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -251,6 +275,7 @@ def main():
     ok = all(o["error"] == 0 for o in out) and prover.verify(out[0]["proof"], out[0]["public_inputs"]) and \
         prover.verify(out[-1]["proof"], out[-1]["public_inputs"])
 
+    clock_mhz = prover.walk_clock_mhz()   # mean shader clock under the two walks over the timed region
     stage_ms = prover.stage_ms()   # HIP-event spans, mean over the last five launches (overlapped with their neighbours)
     # the dominant kernel by itself: single batches with nothing else in flight (outside the timed region)
     alone = []
@@ -258,6 +283,7 @@ def main():
         prover.run(n)
         alone.append(prover_alone_ms(prover))
     g1_alone_ms = sorted(alone)[1] if not finish else 0.0
+    clock_alone_mhz = prover.walk_clock_mhz()
     if rank == 0:
         steps = max(args.steps, 1)
         proofs = world * B * args.steps
@@ -296,6 +322,10 @@ def main():
                        "device": name.value.decode(), "init_s": round(init_s, 2), "verified": bool(ok)},
             "achieved_GBps_whole_proof": round(value * BYTES_PER_PROOF / 1e9, 3),
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+            # the walks are VALU-issue bound: additions/s = SIMDs x 64 x clock / (4 x instructions per addition), so
+            # the clock the power management holds is part of the result (2.4 GHz nominal)
+            "shader_clock_mhz": {"timed_region": {k: round(v, 1) for k, v in clock_mhz.items()},
+                                 "walks_alone": {k: round(v, 1) for k, v in clock_alone_mhz.items()}},
             "roofline": {"bound": "hbm", "kernel": "k_msm29<G1> (G1 fixed-base table MSM, 9 x 29-bit limbs)",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
@@ -308,14 +338,21 @@ def main():
                          "madd_per_s": round(int(prover.info.g1_rows) * int(prover.info.windows) * B / (msm_ms * 1e-3) / 1e9, 2) if msm_ms > 0 else None,
                          "madd_per_s_alone": round(int(prover.info.g1_rows) * int(prover.info.windows) * B / (g1_alone_ms * 1e-3) / 1e9, 2)
                          if g1_alone_ms > 0 else None,
+                         # the bound that actually binds ("expect HBM-fraction << 1 and report VALU utilisation
+                         # alongside"): VALU wave-instructions of one launch (PMC SQ_INSTS_VALU, profiles/r2_pmc_walks.json)
+                         # over the launch by itself, against 1024 SIMDs x clock / 4 cycles per instruction
+                         "valu": valu_view(prover, B, g1_alone_ms, clock_alone_mhz.get("g1_walk", 0.0)),
                          "note": "launch_ms = mean HIP-event span of the last five launches of the timed region, on the "
                                  "kernel's stream; the G1 and G2 walks of neighbouring batches run on two streams and share "
                                  "the SIMDs, so the span includes that sharing (launch_ms_alone: the same launch with nothing "
-                                 "else in flight).  VALU-issue bound, not HBM bound: one mixed addition is ~2 300 VALU instructions "
-                                 "(1 467 v_mad_u64_u32) = 9.2 k SIMD cycles per wave-addition, measured identical with cached "
-                                 "and with HBM-resident table rows (tools/microbench_gather.hip); the chip then delivers "
-                                 "1024 SIMDs x 64 lanes x f / 9.2 k = 16.6 G additions/s at 2.4 GHz, 15.0 G/s at the 2.16 GHz "
-                                 "the power management holds while the 64-byte table gathers run; madd_per_s / madd_per_s_alone are G additions/s; "
+                                 "else in flight).  VALU-issue bound, not HBM bound: one mixed addition is ~2 020 VALU instructions "
+                                 "(1 467 v_mad_u64_u32 of the field products) and the SIMDs issue one per 4 cycles for the whole "
+                                 "launch (roofline.valu: fraction of the issue rate at the measured clock ~ 1); what is left is the "
+                                 "clock, which the power management holds near 1.85 - 1.95 GHz under this instruction mix plus "
+                                 "the table gathers (shader_clock_mhz; 2.4 GHz nominal).  madd_per_s / madd_per_s_alone are "
+                                 "G additions/s; traffic: FETCH_SIZE doubled as the guide prescribes for 128-byte requests "
+                                 "(calibrated on the G2 walk's 128-byte entries and on the NTT streams); the G1 walk's "
+                                 "64-byte gathers may be 64-byte requests, in which case the traffic is half of it; "
                                  "see DESIGN.md section 4"},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -99,6 +99,9 @@ int rlnamd_prover_download(rlnamd_prover* p, size_t n, uint8_t* proofs, uint8_t*
                            uint32_t* errors);
 int rlnamd_prover_stage_ms(rlnamd_prover* p, float ms[RLNAMD_PROVER_STAGES]);
 const char* rlnamd_prover_stage_name(int i);
+/* mean shader clock (MHz) under the G1 / G2 table walks since the previous call (the walks are VALU-issue bound: their
+ * rate is SIMDs x clock / instructions); drains the pipeline */
+int rlnamd_prover_walk_clock_mhz(rlnamd_prover* p, double mhz[2]);
 /* parity taps of the last run: full witness (num_signals*32) / h (domain_size*32) of proof `index` */
 int rlnamd_prover_fetch_witness(rlnamd_prover* p, size_t index, uint8_t* out_le);
 int rlnamd_prover_fetch_h(rlnamd_prover* p, size_t index, uint8_t* out_le);

@@ -109,6 +109,7 @@ SIGNATURES = {
     "rlnamd_prover_known_mask": (C.c_int, [P, C.c_char_p]),
     "rlnamd_prover_download": (C.c_int, [P, C.c_size_t, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint32)]),
     "rlnamd_prover_stage_ms": (C.c_int, [P, C.POINTER(C.c_float)]),
+    "rlnamd_prover_walk_clock_mhz": (C.c_int, [P, C.POINTER(C.c_double)]),
     "rlnamd_prover_stage_name": (C.c_char_p, [C.c_int]),
     "rlnamd_prover_fetch_witness": (C.c_int, [P, C.c_size_t, C.c_char_p]),
     "rlnamd_prover_fetch_h": (C.c_int, [P, C.c_size_t, C.c_char_p]),

@@ -196,6 +196,12 @@ class BatchProver:
         check(lib().rlnamd_prover_stage_ms(self._h, ms))
         return {lib().rlnamd_prover_stage_name(i).decode(): float(ms[i]) for i in range(STAGES)}
 
+    def walk_clock_mhz(self):
+        """mean shader clock under the G1 / G2 table walks since the previous call (drains the pipeline)"""
+        mhz = (C.c_double * 2)()
+        check(lib().rlnamd_prover_walk_clock_mhz(self._h, mhz))
+        return {"g1_walk": float(mhz[0]), "g2_walk": float(mhz[1])}
+
     def fetch_witness(self, index):
         n = int(self.info.num_signals)
         buf = C.create_string_buffer(32 * n)

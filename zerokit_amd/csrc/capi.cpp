@@ -302,6 +302,11 @@ int rlnamd_prover_stage_ms(rlnamd_prover* p, float ms[RLNAMD_PROVER_STAGES]) {
   p->p->stage_ms(ms);
   RLN_CATCH
 }
+int rlnamd_prover_walk_clock_mhz(rlnamd_prover* p, double mhz[2]) {
+  RLN_TRY
+  p->p->walk_clock_mhz(mhz);
+  RLN_CATCH
+}
 const char* rlnamd_prover_stage_name(int i) { return (i >= 0 && i < PROVER_STAGES) ? kProverStageNames[i] : ""; }
 
 int rlnamd_prover_fetch_witness(rlnamd_prover* p, size_t index, uint8_t* out_le) {

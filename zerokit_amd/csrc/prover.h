@@ -99,6 +99,9 @@ class Prover {
   // stage spans in ms (HIP events on the stage's own stream), averaged over the batches still held in the workspace
   // slots (the last <= 5 launches of the same kind); after run() of a single batch: that batch alone
   void stage_ms(float out[PROVER_STAGES]) const;
+  // mean shader clock (MHz) under the G1 / G2 table walks since the previous call (sampled workgroups: shader-clock
+  // cycles over 100 MHz wall ticks); drains the pipeline
+  void walk_clock_mhz(double out[2]);
   // debug / parity taps (host copies, canonical LE): witness signals and h for proof p of the last run
   // public signals w[1..num_instance) of the first n proofs of the last run, n x (num_instance-1) x 32 bytes
   void fetch_public(size_t n, std::vector<uint8_t>* out_le);

@@ -865,6 +865,7 @@ struct Prover::Impl {
   uint32_t seq = 0;  // batches enqueued: consecutive front ends alternate between sA and sA2
   bool split_msm = true;   // G2 walk on its own stream: its workgroups fill the G1 kernel's tail (RLNAMD_MSM_SPLIT)
   float ms[PROVER_STAGES] = {0};
+  DevBuf<unsigned long long> walk_clk;  // clock tap of the two walks: G1 cycles, G1 ticks, G2 cycles, G2 ticks
 
   uint32_t N = 0, NS = 0, NI = 0, nc = 0, ni = 0, n = 0;
   int logn = 0;
@@ -1088,6 +1089,8 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     // the G1 walk is ~12 rounds of 2.8 ms workgroups: on one stream its last round leaves SIMDs idle until the G2
     // walk may start; on two streams the walks of neighbouring batches fill each other's tails (+3.3 - 3.7 % measured)
     D.split_msm = env_int("RLNAMD_MSM_SPLIT", 1) != 0;
+    D.walk_clk.alloc(4);
+    RLN_HIP(hipMemset(D.walk_clk.p, 0, 4 * sizeof(unsigned long long)));
     if (D.split_msm) RLN_HIP(hipStreamCreateWithPriority(&D.sB2, hipStreamNonBlocking, pick(1, lo)));
   }
   hipStream_t s = D.sB;
@@ -1540,7 +1543,7 @@ void Prover::run_async(size_t n, int mode) {
       // dynamic LDS that the kernel never touches caps it at D.msm_waves waves per SIMD: at 4 x 128 VGPRs the
       // register file is full and the front end's NTT / mat-vec workgroups wait for an MSM workgroup (~1 ms) to retire
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(blocks), dim3(64), D.msm_lds, D.sB, D.t1_29.p, D.sid1.p, P1.rows.p, P1.chunks.p,
-                         P1.nchunks, S.digits.p, S.part1.p, D.ws, B, pg, D.nh);
+                         P1.nchunks, S.digits.p, S.part1.p, D.ws, B, pg, D.nh, D.walk_clk.p);
     else
       hipLaunchKernelGGL(k_msm<Fq>, dim3(blocks), dim3(64), 0, D.sB, D.t1.p, D.sid1.p, P1.rows.p, P1.chunks.p,
                          P1.nchunks, S.digits.p, S.part1.p, D.ws, B, pg, D.nh);
@@ -1551,7 +1554,8 @@ void Prover::run_async(size_t n, int mode) {
     uint32_t blocks = div_up(P2.nchunks, 8) * 8 * pg;
     if (D.use29_g2)
       hipLaunchKernelGGL((k_msm29<G2Acc29, G2Affine29, G2XYZZ, 2>), dim3(blocks), dim3(64), 0, s2, D.t2_29.p, D.sid2.p,
-                         P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, pg, D.nh);
+                         P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, pg, D.nh,
+                         D.walk_clk.p ? D.walk_clk.p + 2 : nullptr);
     else
       hipLaunchKernelGGL(k_msm<Fq2>, dim3(blocks), dim3(64), 0, s2, D.t2.p, D.sid2.p, P2.rows.p, P2.chunks.p,
                          P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, pg, D.nh);
@@ -1661,6 +1665,17 @@ const std::vector<uint8_t>& Prover::known_mask() const { return d_->known; }
 
 void Prover::stage_ms(float out[PROVER_STAGES]) const {
   for (int i = 0; i < PROVER_STAGES; i++) out[i] = d_->ms[i];
+}
+
+void Prover::walk_clock_mhz(double out[2]) {
+  Impl& D = *d_;
+  sync();
+  unsigned long long h[4] = {0, 0, 0, 0};
+  if (D.walk_clk.p) {
+    RLN_HIP(hipMemcpy(h, D.walk_clk.p, sizeof(h), hipMemcpyDeviceToHost));
+    RLN_HIP(hipMemset(D.walk_clk.p, 0, sizeof(h)));
+  }
+  for (int g = 0; g < 2; g++) out[g] = h[2 * g + 1] ? 100.0 * (double)h[2 * g] / (double)h[2 * g + 1] : 0.0;
 }
 
 void Prover::download(size_t n, ProofOut* out) {

@@ -33,7 +33,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 
                                               const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks,
                                               uint32_t nchunks, const int16_t* __restrict__ digits,
                                               Out* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups,
-                                              uint32_t nh) {
+                                              uint32_t nh, unsigned long long* __restrict__ clk) {
+  // clock tap (clk may be null): every 64th workgroup adds its shader-clock cycles and its 100 MHz wall ticks; their
+  // ratio is the clock the power management held under this kernel, which is what the issue-bound walk scales with
+  const unsigned long long c0 = clk ? clock64() : 0, w0 = clk ? wall_clock64() : 0;
   uint32_t L = blockIdx.x;
   uint32_t xcd = L & 7, q = L >> 3;
   uint32_t chunk = (q / pgroups) * 8 + xcd, pg = q % pgroups;
@@ -57,6 +60,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 
     }
   }
   part[(size_t)chunk * B + p] = acc.to_xyzz();
+  if (clk && threadIdx.x == 0 && (L & 63) == 0) {
+    atomicAdd(clk, clock64() - c0);
+    atomicAdd(clk + 1, wall_clock64() - w0);
+  }
 }
 
 }  // namespace rlnamd
