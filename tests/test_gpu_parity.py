@@ -389,6 +389,38 @@ def test_other_circuits_depth10_and_multi_message_id():
         p.close()
 
 
+def test_both_graph_interpreters_give_the_golden_witness(monkeypatch):
+    """The graph interpreter runs in the 9 x 29-bit limb form by default (k_witness29: static value bounds and G_RED
+    reductions chosen on the host, stored signals converted by k_v29_to_fr); RLNAMD_WIT29=0 keeps the 8 x 32 one.  Both
+    must reproduce the oracle's witness digests -- the depth-20 goldens, and the multi message-id circuit whose graph
+    carries the slow operations (Shr / Band / Neq / Div on canonical integers), TernCond and Neg."""
+    from zerokit_amd.batch import BatchProver
+    cases = _cases()["cases"]
+    other = [c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "rln_other_circuits.json")))["cases"]
+             if c["multi"]]
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RLNAMD_WIT29", flag)
+        p = BatchProver(max_batch=64)
+        try:
+            out = p.prove([_w(c) for c in cases], [(int(c["r"]), int(c["s"])) for c in cases])
+            for i, c in enumerate(cases):
+                assert out[i]["error"] == 0 and out[i]["proof"].hex() == c["proof_compressed"], (flag, c["name"])
+                assert _digest(p.fetch_witness(i)) == c["witness_sha256"], (flag, c["name"])
+        finally:
+            p.close()
+        for c in other:
+            p = BatchProver(max_batch=64, depth=c["depth"], multi=True)
+            try:
+                named = {k: [int(v) for v in vs] for k, vs in c["inputs"].items()}
+                n = p.upload(p.pack_named_inputs([named]), [(int(c["r"]), int(c["s"]))])
+                p.run(n)
+                out = p.download(n)
+                assert out[0]["error"] == 0 and out[0]["proof"].hex() == c["proof_compressed"], (flag, c["name"])
+                assert _digest(p.fetch_witness(0)) == c["witness_sha256"], (flag, c["name"])
+            finally:
+                p.close()
+
+
 # ------------------------------------------------------------------------------------------ partial proofs
 def test_partial_proof_then_finish_equals_full(prover):
     """generate_partial_zk_proof + finish_zk_proof_with_rs == generate_zk_proof_with_rs

@@ -276,6 +276,244 @@ __global__ void __launch_bounds__(64) k_witness(const GNode* __restrict__ nodes,
   err[p] = e;
 }
 
+// ---- The same interpreter with node values in the 9 x 29-bit form of fq29.h (default; RLNAMD_WIT29=0 keeps the one
+// above).  One wave per SIMD is all this kernel ever has, so its time is latency, and tools/microbench_lonewave.hip
+// shows what a lone wave pays on gfx950: ~12 cycles per LDS instruction issued (a 9 x ds_read_b32 operand is a 118-cycle
+// round trip, two of them 225), 25 - 70 cycles per uniform branch hop, ~5.7 cycles per dependent multiply-add.  The 8 x 32
+// interpreter spends two thirds of its 1 950 cycles per node on exactly that (profiled: an ADD node of 30 instructions
+// takes 1 250 - 1 750 cycles).  Hence:
+//   * values live in LDS as [slot][lane][12 words]: an operand is ds_read_b128 x 2 + ds_read_b32, conflict-free at
+//     the 48-byte lane stride; constants as [id][12 words] are the SAME address form with lane multiplier 0, so both
+//     operands of a node are read without a branch and share one round trip;
+//   * the descriptor is 16 bytes (one broadcast ds_read_b128, issued one node ahead, made wave-uniform when its turn
+//     comes); the program reaches LDS through coalesced vector loads, a chunk ahead (a scalar load in flight would turn
+//     every LDS wait into s_waitcnt lgkmcnt(0));
+//   * forwarding the previous node's value is a select, the rare sources (a value further back than the ring, a
+//     constant beyond the LDS table), the G_RED reduction and the slow operations hide behind ONE flag test;
+//   * a product is ~200 instructions against ~375 in the 8 x 32 form, and the ~6 000 witness signals leave in the limb
+//     form ([slot][proof][12 words], three 16-byte stores) for a throughput kernel to convert (k_v29_to_fr).
+//
+// Value discipline: every node value is normalised (limbs < 2^29) with a STATIC bound, computed on the host when the
+// device program is built (Prover::Prover): products < 1 + 0.006 a b (in units of r), sums a + b, differences
+// a + 8 (K8 - b, b < 7.9 r), inputs / constants / slow operations ~ 1.  A node whose bound would pass WIT29_BMAX
+// carries W29_RED: its value is multiplied by the Montgomery one (result < 1.1 r).  Every operand is therefore below
+// 7.5 r, inside what fq29.h's products (check_fq29_bounds.py: N(10)), K8 - b and the exact zero test (k r, k < 8) take.
+constexpr uint32_t W29_STORE = 1u << 8, W29_RED = 1u << 9, W29_RARE = 1u << 10,  // flags in descriptor word 0
+                   W29_FWDA = 1u << 11, W29_FWDB = 1u << 12;                     // operand a / b is the previous node
+constexpr uint32_t WIT29_RING = 32;          // node values kept in LDS: 32 x 64 x 48 B = 96 KiB
+constexpr uint32_t WIT29_LDS_CONSTS = 1024;  // constants kept in LDS: 48 KiB
+constexpr uint32_t WIT29_CH = 256;           // descriptors per program chunk: 64 lanes x 64 B; two chunks in LDS (8 KiB)
+constexpr uint32_t WIT29_LDS_BYTES = WIT29_RING * 64 * 48 + WIT29_LDS_CONSTS * 48 + 2 * WIT29_CH * 16;
+constexpr double WIT29_BMAX = 7.5;
+struct GNode29 {
+  uint32_t w0;       // op | flags | slot << 16 (slot: index into the compact array of stored values)
+  uint32_t a, b, c;  // operands as in GNode: OPK_RING | node, OPK_CONST | index, OPK_FAR | slot
+};
+// LDS byte address of an operand for this lane, without a branch (a uniform branch hop costs a lone wave 25 - 70
+// cycles): ring value (id % RING) * 64 * 48 + lane * 48, LDS constant RING * 64 * 48 + id * 48.  Only valid for the
+// operands of the fast path (ring or LDS constant); the rare path re-reads what else it needs.
+__device__ __forceinline__ uint32_t wit29_addr(uint32_t enc, uint32_t lane48) {
+  const uint32_t id = enc & ~OPK_MASK;
+  const uint32_t cm = 0u - ((enc >> 30) & 1u);   // all ones for OPK_CONST
+  const uint32_t ring_a = (id % WIT29_RING) * (64 * 48), const_a = WIT29_RING * 64 * 48 + id * 48;
+  return ((const_a & cm) | (ring_a & ~cm)) + (lane48 & ~cm);
+}
+__device__ __forceinline__ void wit29_read(Fr29& r, uint32_t addr, const uint32_t* ring) {
+  const char* a = (const char*)ring + addr;
+  const uint4 x = *(const uint4*)a, y = *(const uint4*)(a + 16);
+  r.v[0] = x.x; r.v[1] = x.y; r.v[2] = x.z; r.v[3] = x.w;
+  r.v[4] = y.x; r.v[5] = y.y; r.v[6] = y.z; r.v[7] = y.w;
+  r.v[8] = *(const uint32_t*)(a + 32);
+}
+struct Wit29Out {
+  Fr29 v;
+  uint32_t e;
+};
+// Everything that is not Mul / Add on ring / LDS-constant / forwarded operands.  Out of line and by value on purpose:
+// inlined, its slow operations (calls with stack arguments) made the compiler keep the hot path's operands in scratch.
+__device__ __noinline__ Wit29Out wit29_rare(uint32_t w0, uint32_t ea, uint32_t eb, uint32_t ec, uint32_t n, Fr29 va,
+                                            Fr29 vb, Fr29 last, const uint32_t* ring, uint32_t lane,
+                                            const uint32_t* __restrict__ consts29, const uint32_t* __restrict__ inputs,
+                                            uint32_t n_inputs, const uint4* __restrict__ V29, uint32_t B, uint32_t p) {
+  Wit29Out o;
+  o.e = WERR_NONE;
+  const uint32_t op = w0 & 0xFF;
+  auto src = [&](Fr29& r, uint32_t enc) {   // any source, from scratch
+    const uint32_t kind = enc >> 30, id = enc & ~OPK_MASK;
+    if (kind == (OPK_FAR >> 30)) {
+      const uint4* g = V29 + ((size_t)id * B + p) * 3;
+      const uint4 x = g[0], y = g[1], z = g[2];
+      r.v[0] = x.x; r.v[1] = x.y; r.v[2] = x.z; r.v[3] = x.w;
+      r.v[4] = y.x; r.v[5] = y.y; r.v[6] = y.z; r.v[7] = y.w;
+      r.v[8] = z.x;
+    } else if (kind == (OPK_CONST >> 30) && id >= WIT29_LDS_CONSTS) {
+      const uint32_t* c = consts29 + (size_t)id * 9;
+#pragma unroll
+      for (int k = 0; k < 9; k++) r.v[k] = c[k];
+    } else if (kind == (OPK_RING >> 30) && id + 1 == n) {
+      r = last;
+    } else {
+      wit29_read(r, wit29_addr(enc, lane * 48), ring);
+    }
+  };
+  Fr29 v;
+  if (op == G_CONST) {
+    src(v, OPK_CONST | ea);
+  } else if (op == G_INPUT) {
+    const uint32_t* in = inputs + ((size_t)p * n_inputs + ea) * 8;
+    if (limbs_geq(in, FrParams::MOD)) o.e = WERR_INPUT_RANGE;  // u256_to_fr fails (graph.rs:42-45)
+    Fr x;
+#pragma unroll
+    for (int k = 0; k < 8; k++) x.v[k] = in[k];
+    v = Fr29::mul(Fr29::slice(x), Fr29::from_const(Fr29C::FROM_CANON));
+  } else {
+    src(va, ea);
+    if (op != G_NEG && op != G_ID) src(vb, eb);
+    if (op == G_MUL) {
+      v = Fr29::mul(va, vb);
+    } else if (op == G_ADD) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) v.v[k] = va.v[k] + vb.v[k];
+      v.normalize();
+    } else if (op == G_SUB) {
+      v = Fr29::sub(va, Fr29C::K8, vb);
+    } else if (op == G_NEG) {
+      v = Fr29::neg_lazy(Fr29C::K8, va);
+      v.normalize();
+    } else if (op == G_ID) {
+      (void)witness_slow_op(G_ID, Fr::zero(), Fr::zero(), &o.e);
+      v = Fr29::zero();
+    } else if (op == G_TERN) {
+      Fr29 vc;
+      src(vc, ec);
+      const bool z = va.is_zero_mod_q();  // graph.rs:214-224
+#pragma unroll
+      for (int k = 0; k < 9; k++) v.v[k] = z ? vc.v[k] : vb.v[k];
+    } else {  // comparisons, shifts, bit operations, division ...: on canonical integers, in the 8 x 32 form
+      v = Fr29::from_fq(witness_slow_op(op, va.to_fq(), vb.to_fq(), &o.e));
+    }
+  }
+  if (w0 & W29_RED) v = Fr29::mul(v, Fr29::from_const(Fr29C::ONE));
+  o.v = v;
+  return o;
+}
+template <bool PROF>
+__global__ void __launch_bounds__(64) k_witness29(const GNode29* __restrict__ nodes, uint32_t n_nodes,
+                                                  const uint32_t* __restrict__ consts29, uint32_t n_consts,
+                                                  const uint32_t* __restrict__ inputs, uint32_t n_inputs,
+                                                  uint4* __restrict__ V29, uint32_t* __restrict__ err, uint32_t B,
+                                                  uint32_t nb, unsigned long long* __restrict__ prof) {
+  unsigned long long pc[4] = {0, 0, 0, 0}, pn[4] = {0, 0, 0, 0}, pw0 = 0, pc0 = 0;
+  if (PROF) { pc0 = clock64(); pw0 = wall_clock64(); }
+  // LDS: [WIT29_RING][64][12] node values, [WIT29_LDS_CONSTS][12] constants, [2 WIT29_CH][4] program words
+  extern __shared__ __attribute__((aligned(16))) uint32_t ring[];
+  __builtin_amdgcn_s_setprio(3);  // few, latency-bound waves: issue ahead of the MSM waves sharing the SIMD
+  const uint32_t lane = threadIdx.x, lane48 = lane * 48;
+  uint32_t p = blockIdx.x * 64 + lane;
+  if (p >= nb) return;
+  uint32_t e = WERR_NONE;
+  Fr29 last = Fr29::zero();
+  uint32_t* const lconsts = ring + WIT29_RING * 64 * 12;
+  uint32_t* const prog = lconsts + WIT29_LDS_CONSTS * 12;
+  {
+    const uint32_t nc = n_consts < WIT29_LDS_CONSTS ? n_consts : WIT29_LDS_CONSTS;
+    for (uint32_t i = lane; i < nc * 9; i += 64) lconsts[(i / 9) * 12 + i % 9] = consts29[i];
+  }
+  const uint4* const gsrc = (const uint4*)nodes;   // lane l of chunk k: descriptors [k CH + 4 l, + 4)
+  uint4 pf[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) pf[k] = gsrc[lane * 4 + k];
+#pragma unroll
+  for (int k = 0; k < 4; k++) ((uint4*)prog)[lane * 4 + k] = pf[k];
+#pragma unroll
+  for (int k = 0; k < 4; k++) pf[k] = gsrc[(size_t)WIT29_CH + lane * 4 + k];   // chunk 1
+  __syncthreads();
+  uint4 d_next = ((const uint4*)prog)[0];
+  const uint32_t n_chunks = (n_nodes + WIT29_CH - 1) / WIT29_CH;
+#pragma unroll 1
+  for (uint32_t ch = 0; ch < n_chunks; ch++) {
+    {   // chunk ch is in LDS; park chunk + 1, start loading chunk + 2
+#pragma unroll
+      for (int k = 0; k < 4; k++) ((uint4*)prog)[((ch + 1) & 1) * WIT29_CH + lane * 4 + k] = pf[k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) pf[k] = gsrc[(size_t)(ch + 2) * WIT29_CH + lane * 4 + k];
+    }
+    const uint32_t n_end = (ch + 1) * WIT29_CH < n_nodes ? (ch + 1) * WIT29_CH : n_nodes;
+#pragma unroll 1
+    for (uint32_t n = ch * WIT29_CH; n < n_end; n++) {
+      const uint32_t w0 = __builtin_amdgcn_readfirstlane(d_next.x), ea = __builtin_amdgcn_readfirstlane(d_next.y),
+                     eb = __builtin_amdgcn_readfirstlane(d_next.z), ec = __builtin_amdgcn_readfirstlane(d_next.w);
+      unsigned long long tn = 0;
+      if (PROF) tn = clock64();
+      // both operand reads go out before anything waits (other nodes read two harmless LDS addresses)
+      Fr29 va, vb, v;
+      wit29_read(va, wit29_addr(ea, lane48), ring);
+      wit29_read(vb, wit29_addr(eb, lane48), ring);
+      d_next = ((const uint4*)prog)[(n + 1) % (2 * WIT29_CH)];
+      const bool fa = (w0 & W29_FWDA) != 0, fb = (w0 & W29_FWDB) != 0;   // the previous node's value: from registers
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        va.v[k] = fa ? last.v[k] : va.v[k];
+        vb.v[k] = fb ? last.v[k] : vb.v[k];
+      }
+      // (the compiler sinks the second operand's reads below the flag test; pinning them above it with an empty asm was
+      // measured: 15.0 ms against 13.8 ms)
+      if (!(w0 & W29_RARE)) {
+        if ((w0 & 0xFF) == G_MUL) {
+          v = Fr29::mul(va, vb);
+        } else {  // G_ADD
+#pragma unroll
+          for (int k = 0; k < 9; k++) v.v[k] = va.v[k] + vb.v[k];
+          v.normalize();
+        }
+      } else {
+        const Wit29Out o = wit29_rare(w0, ea, eb, ec, n, va, vb, last, ring, lane, consts29, inputs, n_inputs, V29, B, p);
+        v = o.v;
+        if (o.e && !e) e = o.e;
+      }
+      {  // every value goes to the ring (three LDS instructions: cheaper than asking whether anybody reads it)
+        char* a = (char*)ring + (n % WIT29_RING) * 64 * 48 + lane48;
+        *(uint4*)a = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+        *(uint4*)(a + 16) = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+        *(uint32_t*)(a + 32) = v.v[8];
+      }
+      if (w0 & W29_STORE) {
+        uint4* g = V29 + ((size_t)(w0 >> 16) * B + p) * 3;
+        g[0] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+        g[1] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+        g[2] = make_uint4(v.v[8], 0, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < 9; k++) last.v[k] = v.v[k];
+      if (PROF) {
+        const uint32_t op = w0 & 0xFF;
+        const int cls = op == G_MUL ? 0 : op == G_ADD ? 1 : (op == G_CONST || op == G_INPUT) ? 2 : 3;
+        pc[cls] += clock64() - tn;
+        pn[cls]++;
+      }
+    }
+  }
+  err[p] = e;
+  if (PROF && blockIdx.x == 0 && lane == 0) {
+    for (int k = 0; k < 4; k++) { prof[k] = pc[k]; prof[4 + k] = pn[k]; }
+    prof[8] = clock64() - pc0;
+    prof[9] = wall_clock64() - pw0;
+  }
+}
+// stored node values of the Fr29 interpreter -> the 8 x 32 Montgomery values every later kernel reads (V[node][proof])
+__global__ void __launch_bounds__(64) k_v29_to_fr(const uint4* __restrict__ V29, const uint32_t* __restrict__ slot2node,
+                                                  uint32_t nslots, Fr* __restrict__ V, uint32_t B, uint32_t nb) {
+  const uint32_t p = blockIdx.x * 64 + threadIdx.x, sl = blockIdx.y;
+  if (p >= nb || sl >= nslots) return;
+  const uint4* g = V29 + ((size_t)sl * B + p) * 3;
+  const uint4 x = g[0], y = g[1], z = g[2];
+  Fr29 v;
+  v.v[0] = x.x; v.v[1] = x.y; v.v[2] = x.z; v.v[3] = x.w;
+  v.v[4] = y.x; v.v[5] = y.y; v.v[6] = y.z; v.v[7] = y.w;
+  v.v[8] = z.x;
+  V[(size_t)slot2node[sl] * B + p] = v.to_fq();
+}
+
 // =====================================================================================================
 // 2. a = A.w, b = B.w, c = a o b on the padded domain (qap.rs:40-67)
 // =====================================================================================================
@@ -841,6 +1079,7 @@ struct Slot {
   DevBuf<uint32_t> err, coords, values;
   DevBuf<uint8_t> comp;
   DevBuf<Fr> V, abc;
+  DevBuf<uint4> V29;              // Fr29 interpreter: stored node values, [slot][proof][12 words]
   DevBuf<int16_t> digits, digits2;  // signed window digits under the G1 / G2 schedule
   DevBuf<G1XYZZ> part1, grp1, sums1, prod, tbl;
   DevBuf<G2XYZZ> part2, grp2, sums2;
@@ -866,6 +1105,11 @@ struct Prover::Impl {
   bool split_msm = true;   // G2 walk on its own stream: its workgroups fill the G1 kernel's tail (RLNAMD_MSM_SPLIT)
   float ms[PROVER_STAGES] = {0};
   DevBuf<unsigned long long> walk_clk;  // clock tap of the two walks: G1 cycles, G1 ticks, G2 cycles, G2 ticks
+  bool wit29 = true;             // RLNAMD_WIT29: graph interpreter in the 9 x 29-bit form (k_witness29)
+  DevBuf<GNode29> nodes29;
+  DevBuf<unsigned long long> wit_prof;
+  DevBuf<uint32_t> consts29, slot2node;
+  uint32_t nstore29 = 0;
 
   uint32_t N = 0, NS = 0, NI = 0, nc = 0, ni = 0, n = 0;
   int logn = 0;
@@ -1132,6 +1376,103 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   RLN_HIP(hipFuncSetAttribute((const void*)k_witness, hipFuncAttributeMaxDynamicSharedMemorySize, WIT_RING * 8 * 64 * 4 + WIT_LDS_CONSTS * 32));
   D.consts.alloc(std::max<size_t>(graph_.constants.size(), 1));
   if (!graph_.constants.empty()) D.consts.upload(graph_.constants.data(), graph_.constants.size(), s);
+  D.wit29 = env_int("RLNAMD_WIT29", 1) != 0;
+  if (D.wit29) {
+    // The program of k_witness29: the same nodes; stored values (witness signals, inputs, operands further back than
+    // the LDS ring) live in a compact array indexed by `slot`; W29_RED where the static bound of a value (in units of r)
+    // would pass WIT29_BMAX (see k_witness29)
+    std::vector<uint8_t> store(D.N, 0);
+    for (uint32_t sgn : graph_.signals) store[sgn] = 1;
+    auto far = [&](uint32_t n, uint32_t o) { return graph_.nodes[o].op != G_CONST && n - o >= WIT29_RING; };
+    for (uint32_t n = 0; n < D.N; n++) {
+      const GNode& g = graph_.nodes[n];
+      if (g.op == G_INPUT) store[n] = 1;
+      if (g.op == G_INPUT || g.op == G_CONST) continue;
+      if (g.a >= n) throw Error("Graph error: node operand refers forward");
+      if (far(n, g.a)) store[g.a] = 1;
+      if (g.op != G_NEG && g.op != G_ID) {
+        if (g.b >= n) throw Error("Graph error: node operand refers forward");
+        if (far(n, g.b)) store[g.b] = 1;
+      }
+      if (g.op == G_TERN) {
+        if (g.c >= n) throw Error("Graph error: node operand refers forward");
+        if (far(n, g.c)) store[g.c] = 1;
+      }
+    }
+    std::vector<uint32_t> slot_of(D.N, 0), slot2node;
+    for (uint32_t n = 0; n < D.N; n++)
+      if (store[n]) {
+        slot_of[n] = (uint32_t)slot2node.size();
+        slot2node.push_back(n);
+      }
+    if (slot2node.size() >= 65536) throw Error("graph too large for the Fr29 interpreter (set RLNAMD_WIT29=0)");
+    std::vector<GNode29> prog(D.N);
+    std::vector<double> bnd(D.N, 1.01);
+    for (uint32_t n = 0; n < D.N; n++) {
+      const GNode& g = graph_.nodes[n];
+      GNode29 q{};
+      uint32_t flags = store[n] ? W29_STORE : 0;
+      q.a = g.a;   // G_INPUT: input index, G_CONST: constant index
+      double b = 1.01;  // inputs, constants, slow operations: a fresh product with a constant
+      // the fast path of the kernel is Mul / Add with both operands in LDS (ring or constant table) or forwarded
+      bool rare = g.op != G_MUL && g.op != G_ADD;
+      if (g.op != G_INPUT && g.op != G_CONST) {
+        auto enc = [&](uint32_t o) -> uint32_t {
+          if (graph_.nodes[o].op == G_CONST) {
+            if (graph_.nodes[o].a >= WIT29_LDS_CONSTS) rare = true;
+            return OPK_CONST | graph_.nodes[o].a;
+          }
+          if (n - o < WIT29_RING) return OPK_RING | o;
+          rare = true;
+          return OPK_FAR | slot_of[o];
+        };
+        if (g.a + 1 == n && graph_.nodes[g.a].op != G_CONST) flags |= W29_FWDA;
+        if (g.op != G_NEG && g.op != G_ID && g.b + 1 == n && graph_.nodes[g.b].op != G_CONST) flags |= W29_FWDB;
+        auto bo = [&](uint32_t o) { return graph_.nodes[o].op == G_CONST ? 1.01 : bnd[o]; };
+        q.a = enc(g.a);
+        const double ba = bo(g.a);
+        double bb = 0, bc = 0;
+        if (g.op != G_NEG && g.op != G_ID) {
+          q.b = enc(g.b);
+          bb = bo(g.b);
+        }
+        if (g.op == G_TERN) {
+          q.c = enc(g.c);
+          bc = bo(g.c);
+        }
+        if (g.op == G_MUL) b = 1.0 + 0.006 * ba * bb;
+        else if (g.op == G_ADD) b = ba + bb;
+        else if (g.op == G_SUB) b = ba + 8.0;
+        else if (g.op == G_NEG) b = 8.0;
+        else if (g.op == G_TERN) b = std::max(bb, bc);
+      }
+      if (b > WIT29_BMAX) {
+        flags |= W29_RED;
+        rare = true;
+        b = 1.0 + 0.006 * b;
+      }
+      if (rare) flags |= W29_RARE;
+      bnd[n] = b;
+      q.w0 = g.op | flags | (slot_of[n] << 16);
+      prog[n] = q;
+    }
+    D.nstore29 = (uint32_t)slot2node.size();
+    prog.resize(((size_t)D.N / WIT29_CH + 4) * WIT29_CH, GNode29{});   // the kernel prefetches two chunks past the end
+    D.nodes29.alloc(prog.size());
+    D.nodes29.upload(prog.data(), prog.size(), s);
+    D.slot2node.alloc(std::max<size_t>(slot2node.size(), 1));
+    if (!slot2node.empty()) D.slot2node.upload(slot2node.data(), slot2node.size(), s);
+    D.consts29.alloc(std::max<size_t>(graph_.constants.size(), 1) * 9);
+    if (!graph_.constants.empty())
+      hipLaunchKernelGGL(k_consts_to29, dim3(div_up(graph_.constants.size(), 256)), dim3(256), 0, s, D.consts.p,
+                         D.consts29.p, (uint32_t)graph_.constants.size());
+    RLN_HIP(hipGetLastError());
+    RLN_HIP(hipStreamSynchronize(s));
+    RLN_HIP(hipFuncSetAttribute((const void*)k_witness29<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                WIT29_LDS_BYTES));
+    RLN_HIP(hipFuncSetAttribute((const void*)k_witness29<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                WIT29_LDS_BYTES));
+  }
   D.sig2node.alloc(D.NS);
   D.sig2node.upload(graph_.signals.data(), D.NS, s);
 
@@ -1353,6 +1694,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     S.values.alloc(B * 40);
     S.comp.alloc(B * 128);
     S.V.alloc((size_t)D.N * B);
+    if (D.wit29) S.V29.alloc((size_t)D.nstore29 * 3 * B);
     S.abc.alloc(3 * (size_t)D.n * B);
     S.digits.alloc((size_t)(D.NS + D.n + 3) * D.nh * D.ws.W * B);
     S.digits2.alloc((size_t)(D.NS + 3) * D.nh * D.ws2.W * B);
@@ -1480,9 +1822,28 @@ void Prover::run_async(size_t n, int mode) {
   // ---------------- stage A
   if (S.used) RLN_HIP(hipStreamWaitEvent(sA, S.evC, 0));  // slot free again
   RLN_HIP(hipEventRecord(S.t[1], sA));
-  hipLaunchKernelGGL(k_witness, dim3(pg), dim3(64), WIT_RING * 8 * 64 * 4 + WIT_LDS_CONSTS * 32, sA, D.nodes.p, D.N, D.consts.p,
-                     (uint32_t)graph_.constants.size(), D.inputs.p, D.NI, S.V.p,
-                     S.err.p, B, nbp);
+  if (D.wit29) {
+    static const bool prof = env_int("RLNAMD_WIT_PROF", 0) != 0;   // diagnostic: cycles per node class, on stderr
+    if (prof) {
+      DevBuf<unsigned long long>& pb = D.wit_prof;
+      if (!pb.p) pb.alloc(16);
+      hipLaunchKernelGGL(k_witness29<true>, dim3(pg), dim3(64), WIT29_LDS_BYTES, sA, D.nodes29.p, D.N,
+                         D.consts29.p, (uint32_t)graph_.constants.size(), D.inputs.p, D.NI, S.V29.p, S.err.p, B, nbp, pb.p);
+      unsigned long long h[16];
+      RLN_HIP(hipStreamSynchronize(sA));
+      RLN_HIP(hipMemcpy(h, pb.p, sizeof(h), hipMemcpyDeviceToHost));
+      fprintf(stderr, "wit29 prof: mul %llu cyc / %llu, add %llu / %llu, const+input %llu / %llu, other %llu / %llu; total %llu cyc, %.3f ms, clock %.0f MHz\n",
+              h[0], h[4], h[1], h[5], h[2], h[6], h[3], h[7], h[8], h[9] / 1e5, h[9] ? 100.0 * h[8] / h[9] : 0.0);
+    } else
+    hipLaunchKernelGGL(k_witness29<false>, dim3(pg), dim3(64), WIT29_LDS_BYTES, sA, D.nodes29.p, D.N,
+                       D.consts29.p, (uint32_t)graph_.constants.size(), D.inputs.p, D.NI, S.V29.p, S.err.p, B, nbp, nullptr);
+    hipLaunchKernelGGL(k_v29_to_fr, dim3(pg, D.nstore29), dim3(64, 1), 0, sA, S.V29.p, D.slot2node.p, D.nstore29, S.V.p, B,
+                       nbp);
+  } else {
+    hipLaunchKernelGGL(k_witness, dim3(pg), dim3(64), WIT_RING * 8 * 64 * 4 + WIT_LDS_CONSTS * 32, sA, D.nodes.p, D.N, D.consts.p,
+                       (uint32_t)graph_.constants.size(), D.inputs.p, D.NI, S.V.p,
+                       S.err.p, B, nbp);
+  }
   if (D.wgiven_n) {
     if (D.wgiven_n != n || mode != PROVE_FULL) throw Error("upload_witness: the next run must be a full proof of the same batch");
     hipLaunchKernelGGL(k_scatter_witness, dim3(pg, div_up(D.NS, 4)), dim3(64, 4), 0, sA, D.wgiven.p, D.sig2node.p,
