@@ -1893,6 +1893,9 @@ void Prover::run_async(size_t n, int mode) {
     RLN_HIP(hipStreamWaitEvent(D.sB, S.evA, 0));
   }
   RLN_HIP(hipEventRecord(S.t[14], D.sB));
+  // below half a wave of proofs the walks run with lanes = chunks (walk29.h); RLNAMD_LANECHUNK overrides the threshold
+  static const uint32_t lanechunk_max = (uint32_t)env_int("RLNAMD_LANECHUNK", 24);
+  const bool lanechunk = nb <= lanechunk_max;
   hipStream_t s2 = D.split_msm ? D.sB2 : D.sB;
   if (D.split_msm) {
     RLN_HIP(hipEventRecord(S.evR, D.sB));
@@ -1900,7 +1903,11 @@ void Prover::run_async(size_t n, int mode) {
   }
   if (P1.nchunks) {
     uint32_t blocks = div_up(P1.nchunks, 8) * 8 * pg;
-    if (D.use29)
+    if (D.use29 && lanechunk)
+      hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>), dim3(div_up(P1.nchunks, 64), nb), dim3(64), 0, D.sB,
+                         D.t1_29.p, D.sid1.p, P1.rows.p, P1.chunks.p, P1.nchunks, S.digits.p, S.part1.p, D.ws, B, pg, D.nh,
+                         nullptr);
+    else if (D.use29)
       // dynamic LDS that the kernel never touches caps it at D.msm_waves waves per SIMD: at 4 x 128 VGPRs the
       // register file is full and the front end's NTT / mat-vec workgroups wait for an MSM workgroup (~1 ms) to retire
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(blocks), dim3(64), D.msm_lds, D.sB, D.t1_29.p, D.sid1.p, P1.rows.p, P1.chunks.p,
@@ -1913,7 +1920,11 @@ void Prover::run_async(size_t n, int mode) {
   RLN_HIP(hipEventRecord(S.t[11], s2));
   if (P2.nchunks) {
     uint32_t blocks = div_up(P2.nchunks, 8) * 8 * pg;
-    if (D.use29_g2)
+    if (D.use29_g2 && lanechunk)
+      hipLaunchKernelGGL((k_msm29<G2Acc29, G2Affine29, G2XYZZ, 1, true>), dim3(div_up(P2.nchunks, 64), nb), dim3(64), 0, s2,
+                         D.t2_29.p, D.sid2.p, P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, pg, D.nh,
+                         nullptr);
+    else if (D.use29_g2)
       hipLaunchKernelGGL((k_msm29<G2Acc29, G2Affine29, G2XYZZ, 2>), dim3(blocks), dim3(64), 0, s2, D.t2_29.p, D.sid2.p,
                          P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, pg, D.nh,
                          D.walk_clk.p ? D.walk_clk.p + 2 : nullptr);

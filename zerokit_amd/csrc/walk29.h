@@ -28,7 +28,13 @@ struct ChunkDesc {
 
 // The same walk for G1 in the 9 x 29-bit form of fq29.h (tables and accumulator): 16.0 G mixed additions/s against
 // 12.6 G in the 8 x 32 form (tools/microbench29.hip).  Partial sums leave in the common XYZZ<Fq> form.
-template <class Acc, class Entry, class Out, int WAVES>
+//
+// LANECHUNK (small batches): the 64 lanes of a wave are 64 CHUNKS of one proof instead of one chunk of 64 proofs.  A
+// proof's walk is issue-bound whatever the batch holds -- with lanes = proofs a single proof still issues every
+// instruction of its 2 960 + 962 chunk waves, 63 lanes idle (4.4 + 5.6 ms) -- so below half a wave of proofs the walk
+// runs transposed: 47 + 16 waves per proof, each alone on its SIMD.  Rows, scalar ids and table rows become per-lane
+// (vector) loads; the partial sums land where k_sum_ranges expects them.
+template <class Acc, class Entry, class Out, int WAVES, bool LANECHUNK = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_msm29(const Entry* __restrict__ table, const uint32_t* __restrict__ sid,
                                               const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks,
                                               uint32_t nchunks, const int16_t* __restrict__ digits,
@@ -38,13 +44,34 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 
   // ratio is the clock the power management held under this kernel, which is what the issue-bound walk scales with
   const unsigned long long c0 = clk ? clock64() : 0, w0 = clk ? wall_clock64() : 0;
   uint32_t L = blockIdx.x;
+  const int W = ws.W;
+  if (LANECHUNK) {
+    const uint32_t chunk = L * 64 + threadIdx.x, p = blockIdx.y;   // one proof per grid row
+    if (chunk >= nchunks) return;
+    const ChunkDesc cd = chunks[chunk];
+    Acc acc = Acc::inf();
+    for (uint32_t i = cd.pt_begin; i < cd.pt_end; i++) {
+      const uint32_t kk = rows[i], k = kk & 0x7FFFFFFFu;
+      const int16_t* dg = digits + ((size_t)sid[k] * nh + (kk >> 31)) * W * B + p;
+      const Entry* row = table + (size_t)k * ws.stride;
+#pragma unroll 1
+      for (int j = 0; j < W; j++) {
+        int d = dg[(size_t)j * B];
+        if (d != 0) {
+          uint32_t e = (uint32_t)(d < 0 ? -d : d) - 1;
+          acc.madd(row[ws.ro[j] + e], d < 0);
+        }
+      }
+    }
+    part[(size_t)chunk * B + p] = acc.to_xyzz();
+    return;
+  }
   uint32_t xcd = L & 7, q = L >> 3;
   uint32_t chunk = (q / pgroups) * 8 + xcd, pg = q % pgroups;
   if (chunk >= nchunks) return;
   uint32_t p = pg * 64 + threadIdx.x;
   ChunkDesc cd = chunks[chunk];
   Acc acc = Acc::inf();
-  const int W = ws.W;
 #pragma unroll 1
   for (uint32_t i = cd.pt_begin; i < cd.pt_end; i++) {
     const uint32_t kk = rows[i], k = kk & 0x7FFFFFFFu;  // bit 31: second GLV half (see k_msm)
