@@ -421,6 +421,36 @@ def test_both_graph_interpreters_give_the_golden_witness(monkeypatch):
                 p.close()
 
 
+def test_lane_chunk_walk_and_clock_tap(monkeypatch):
+    """Batches of at most RLNAMD_LANECHUNK (24) proofs walk the tables with lanes = chunks, larger ones with lanes =
+    proofs (walk29.h).  The same witnesses must give the same proof bytes either way -- alone, inside a batch that is
+    walked the other way, and with the threshold forced to 0 -- and the clock tap of the walk kernels must report a
+    plausible shader clock after a lanes = proofs run."""
+    from zerokit_amd.batch import BatchProver
+    cases = _cases()["cases"]
+    ws, rs = [_w(c) for c in cases], [(int(c["r"]), int(c["s"])) for c in cases]
+    p = BatchProver(max_batch=64)
+    try:
+        small = p.prove(ws[:2], rs[:2])                       # lanes = chunks
+        reps = 40 // len(ws) + 1
+        big = p.prove((ws * reps)[:40], (rs * reps)[:40])     # lanes = proofs
+        clk = p.walk_clock_mhz()
+        assert 500.0 < clk["g1_walk"] < 3000.0 and 500.0 < clk["g2_walk"] < 3000.0, clk
+        for i in range(2):
+            assert small[i]["proof"].hex() == cases[i]["proof_compressed"]
+        for i in range(40):
+            assert big[i]["proof"].hex() == cases[i % len(ws)]["proof_compressed"], i
+    finally:
+        p.close()
+    monkeypatch.setenv("RLNAMD_LANECHUNK", "0")
+    p = BatchProver(max_batch=64)
+    try:
+        out = p.prove(ws[:2], rs[:2])
+        assert [o["proof"].hex() for o in out] == [c["proof_compressed"] for c in cases[:2]]
+    finally:
+        p.close()
+
+
 # ------------------------------------------------------------------------------------------ partial proofs
 def test_partial_proof_then_finish_equals_full(prover):
     """generate_partial_zk_proof + finish_zk_proof_with_rs == generate_zk_proof_with_rs

@@ -1106,6 +1106,7 @@ struct Prover::Impl {
   float ms[PROVER_STAGES] = {0};
   DevBuf<unsigned long long> walk_clk;  // clock tap of the two walks: G1 cycles, G1 ticks, G2 cycles, G2 ticks
   bool wit29 = true;             // RLNAMD_WIT29: graph interpreter in the 9 x 29-bit form (k_witness29)
+  uint32_t lanechunk_max = 24;   // RLNAMD_LANECHUNK: largest batch walked with lanes = chunks
   DevBuf<GNode29> nodes29;
   DevBuf<unsigned long long> wit_prof;
   DevBuf<uint32_t> consts29, slot2node;
@@ -1377,6 +1378,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   D.consts.alloc(std::max<size_t>(graph_.constants.size(), 1));
   if (!graph_.constants.empty()) D.consts.upload(graph_.constants.data(), graph_.constants.size(), s);
   D.wit29 = env_int("RLNAMD_WIT29", 1) != 0;
+  D.lanechunk_max = (uint32_t)std::max(0, env_int("RLNAMD_LANECHUNK", 24));
   if (D.wit29) {
     // The program of k_witness29: the same nodes; stored values (witness signals, inputs, operands further back than
     // the LDS ring) live in a compact array indexed by `slot`; W29_RED where the static bound of a value (in units of r)
@@ -1894,8 +1896,7 @@ void Prover::run_async(size_t n, int mode) {
   }
   RLN_HIP(hipEventRecord(S.t[14], D.sB));
   // below half a wave of proofs the walks run with lanes = chunks (walk29.h); RLNAMD_LANECHUNK overrides the threshold
-  static const uint32_t lanechunk_max = (uint32_t)env_int("RLNAMD_LANECHUNK", 24);
-  const bool lanechunk = nb <= lanechunk_max;
+  const bool lanechunk = nb <= D.lanechunk_max;
   hipStream_t s2 = D.split_msm ? D.sB2 : D.sB;
   if (D.split_msm) {
     RLN_HIP(hipEventRecord(S.evR, D.sB));
