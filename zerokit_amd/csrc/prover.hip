@@ -288,8 +288,9 @@ __global__ void __launch_bounds__(64) k_witness(const GNode* __restrict__ nodes,
 //   * the descriptor is 16 bytes (one broadcast ds_read_b128, issued one node ahead, made wave-uniform when its turn
 //     comes); the program reaches LDS through coalesced vector loads, a chunk ahead (a scalar load in flight would turn
 //     every LDS wait into s_waitcnt lgkmcnt(0));
-//   * forwarding the previous node's value is a select, the rare sources (a value further back than the ring, a
-//     constant beyond the LDS table), the G_RED reduction and the slow operations hide behind ONE flag test;
+//   * no register forwarding (a node waits for an LDS read anyway; the previous node's value comes back from the ring);
+//     the rare sources (a value further back than the ring, a constant beyond the LDS table), the reduction flag and the
+//     slow operations hide behind ONE flag test, taken before any operand is read;
 //   * a product is ~200 instructions against ~375 in the 8 x 32 form, and the ~6 000 witness signals leave in the limb
 //     form ([slot][proof][12 words], three 16-byte stores) for a throughput kernel to convert (k_v29_to_fr).
 //
@@ -298,8 +299,7 @@ __global__ void __launch_bounds__(64) k_witness(const GNode* __restrict__ nodes,
 // a + 8 (K8 - b, b < 7.9 r), inputs / constants / slow operations ~ 1.  A node whose bound would pass WIT29_BMAX
 // carries W29_RED: its value is multiplied by the Montgomery one (result < 1.1 r).  Every operand is therefore below
 // 7.5 r, inside what fq29.h's products (check_fq29_bounds.py: N(10)), K8 - b and the exact zero test (k r, k < 8) take.
-constexpr uint32_t W29_STORE = 1u << 8, W29_RED = 1u << 9, W29_RARE = 1u << 10,  // flags in descriptor word 0
-                   W29_FWDA = 1u << 11, W29_FWDB = 1u << 12;                     // operand a / b is the previous node
+constexpr uint32_t W29_STORE = 1u << 8, W29_RED = 1u << 9, W29_RARE = 1u << 10;  // flags in descriptor word 0
 constexpr uint32_t WIT29_RING = 32;          // node values kept in LDS: 32 x 64 x 48 B = 96 KiB
 constexpr uint32_t WIT29_LDS_CONSTS = 1024;  // constants kept in LDS: 48 KiB
 constexpr uint32_t WIT29_CH = 256;           // descriptors per program chunk: 64 lanes x 64 B; two chunks in LDS (8 KiB)
@@ -331,8 +331,8 @@ struct Wit29Out {
 };
 // Everything that is not Mul / Add on ring / LDS-constant / forwarded operands.  Out of line and by value on purpose:
 // inlined, its slow operations (calls with stack arguments) made the compiler keep the hot path's operands in scratch.
-__device__ __noinline__ Wit29Out wit29_rare(uint32_t w0, uint32_t ea, uint32_t eb, uint32_t ec, uint32_t n, Fr29 va,
-                                            Fr29 vb, Fr29 last, const uint32_t* ring, uint32_t lane,
+__device__ __noinline__ Wit29Out wit29_rare(uint32_t w0, uint32_t ea, uint32_t eb, uint32_t ec, const uint32_t* ring,
+                                            uint32_t lane,
                                             const uint32_t* __restrict__ consts29, const uint32_t* __restrict__ inputs,
                                             uint32_t n_inputs, const uint4* __restrict__ V29, uint32_t B, uint32_t p) {
   Wit29Out o;
@@ -350,13 +350,11 @@ __device__ __noinline__ Wit29Out wit29_rare(uint32_t w0, uint32_t ea, uint32_t e
       const uint32_t* c = consts29 + (size_t)id * 9;
 #pragma unroll
       for (int k = 0; k < 9; k++) r.v[k] = c[k];
-    } else if (kind == (OPK_RING >> 30) && id + 1 == n) {
-      r = last;
     } else {
       wit29_read(r, wit29_addr(enc, lane * 48), ring);
     }
   };
-  Fr29 v;
+  Fr29 v, va, vb;
   if (op == G_CONST) {
     src(v, OPK_CONST | ea);
   } else if (op == G_INPUT) {
@@ -412,7 +410,6 @@ __global__ void __launch_bounds__(64) k_witness29(const GNode29* __restrict__ no
   uint32_t p = blockIdx.x * 64 + lane;
   if (p >= nb) return;
   uint32_t e = WERR_NONE;
-  Fr29 last = Fr29::zero();
   uint32_t* const lconsts = ring + WIT29_RING * 64 * 12;
   uint32_t* const prog = lconsts + WIT29_LDS_CONSTS * 12;
   {
@@ -445,20 +442,16 @@ __global__ void __launch_bounds__(64) k_witness29(const GNode29* __restrict__ no
                      eb = __builtin_amdgcn_readfirstlane(d_next.z), ec = __builtin_amdgcn_readfirstlane(d_next.w);
       unsigned long long tn = 0;
       if (PROF) tn = clock64();
-      // both operand reads go out before anything waits (other nodes read two harmless LDS addresses)
-      Fr29 va, vb, v;
-      wit29_read(va, wit29_addr(ea, lane48), ring);
-      wit29_read(vb, wit29_addr(eb, lane48), ring);
-      d_next = ((const uint4*)prog)[(n + 1) % (2 * WIT29_CH)];
-      const bool fa = (w0 & W29_FWDA) != 0, fb = (w0 & W29_FWDB) != 0;   // the previous node's value: from registers
-#pragma unroll
-      for (int k = 0; k < 9; k++) {
-        va.v[k] = fa ? last.v[k] : va.v[k];
-        vb.v[k] = fb ? last.v[k] : vb.v[k];
-      }
-      // (the compiler sinks the second operand's reads below the flag test; pinning them above it with an empty asm was
-      // measured: 15.0 ms against 13.8 ms)
+      Fr29 v;
       if (!(w0 & W29_RARE)) {
+        // Mul / Add on ring values and LDS constants: both operand reads and the next descriptor go out together and
+        // cost one LDS round trip.  The previous node's value is read back from the ring like any other (its write
+        // was issued a few instructions earlier and LDS is in order): forwarding it in registers cost 18 selects and
+        // saved nothing, because a node waits for at least one LDS read anyway.
+        Fr29 va, vb;
+        wit29_read(va, wit29_addr(ea, lane48), ring);
+        wit29_read(vb, wit29_addr(eb, lane48), ring);
+        d_next = ((const uint4*)prog)[(n + 1) % (2 * WIT29_CH)];
         if ((w0 & 0xFF) == G_MUL) {
           v = Fr29::mul(va, vb);
         } else {  // G_ADD
@@ -467,7 +460,8 @@ __global__ void __launch_bounds__(64) k_witness29(const GNode29* __restrict__ no
           v.normalize();
         }
       } else {
-        const Wit29Out o = wit29_rare(w0, ea, eb, ec, n, va, vb, last, ring, lane, consts29, inputs, n_inputs, V29, B, p);
+        d_next = ((const uint4*)prog)[(n + 1) % (2 * WIT29_CH)];
+        const Wit29Out o = wit29_rare(w0, ea, eb, ec, ring, lane, consts29, inputs, n_inputs, V29, B, p);
         v = o.v;
         if (o.e && !e) e = o.e;
       }
@@ -483,8 +477,6 @@ __global__ void __launch_bounds__(64) k_witness29(const GNode29* __restrict__ no
         g[1] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
         g[2] = make_uint4(v.v[8], 0, 0, 0);
       }
-#pragma unroll
-      for (int k = 0; k < 9; k++) last.v[k] = v.v[k];
       if (PROF) {
         const uint32_t op = w0 & 0xFF;
         const int cls = op == G_MUL ? 0 : op == G_ADD ? 1 : (op == G_CONST || op == G_INPUT) ? 2 : 3;
@@ -1428,8 +1420,6 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
           rare = true;
           return OPK_FAR | slot_of[o];
         };
-        if (g.a + 1 == n && graph_.nodes[g.a].op != G_CONST) flags |= W29_FWDA;
-        if (g.op != G_NEG && g.op != G_ID && g.b + 1 == n && graph_.nodes[g.b].op != G_CONST) flags |= W29_FWDB;
         auto bo = [&](uint32_t o) { return graph_.nodes[o].op == G_CONST ? 1.01 : bnd[o]; };
         q.a = enc(g.a);
         const double ba = bo(g.a);
