@@ -1388,11 +1388,14 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   if (!graph_.constants.empty()) D.consts.upload(graph_.constants.data(), graph_.constants.size(), s);
   D.wit29 = env_int("RLNAMD_WIT29", 1) != 0;
   D.lanechunk_max = (uint32_t)std::max(0, env_int("RLNAMD_LANECHUNK", 24));
+  std::vector<uint8_t> wit29_store;
+  std::vector<uint32_t> wit29_slot_of, wit29_slot2node;
   if (D.wit29) {
     // The program of k_witness29: the same nodes; stored values (witness signals, inputs, operands further back than
     // the LDS ring) live in a compact array indexed by `slot`; W29_RED where the static bound of a value (in units of r)
     // would pass WIT29_BMAX (see k_witness29)
-    std::vector<uint8_t> store(D.N, 0);
+    std::vector<uint8_t>& store = wit29_store;
+    store.assign(D.N, 0);
     for (uint32_t sgn : graph_.signals) store[sgn] = 1;
     auto far = [&](uint32_t n, uint32_t o) { return graph_.nodes[o].op != G_CONST && n - o >= WIT29_RING; };
     for (uint32_t n = 0; n < D.N; n++) {
@@ -1410,13 +1413,20 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
         if (far(n, g.c)) store[g.c] = 1;
       }
     }
-    std::vector<uint32_t> slot_of(D.N, 0), slot2node;
+    std::vector<uint32_t>& slot_of = wit29_slot_of;
+    std::vector<uint32_t>& slot2node = wit29_slot2node;
+    slot_of.assign(D.N, 0);
     for (uint32_t n = 0; n < D.N; n++)
       if (store[n]) {
         slot_of[n] = (uint32_t)slot2node.size();
         slot2node.push_back(n);
       }
-    if (slot2node.size() >= 65536) throw Error("graph too large for the Fr29 interpreter (set RLNAMD_WIT29=0)");
+    if (slot2node.size() >= 65536) D.wit29 = false;   // the descriptor has 16 bits for the slot: larger graphs keep k_witness
+  }
+  if (D.wit29) {
+    std::vector<uint8_t>& store = wit29_store;
+    std::vector<uint32_t>& slot_of = wit29_slot_of;
+    std::vector<uint32_t>& slot2node = wit29_slot2node;
     std::vector<GNode29> prog(D.N);
     std::vector<double> bnd(D.N, 1.01);
     for (uint32_t n = 0; n < D.N; n++) {
