@@ -35,6 +35,18 @@ int hm_final_exp_check(uint32_t seed) {
   if (eq) ok |= 2;
   // the result lies in the order-r subgroup: frob(x) has the same order and x^(q^6) = x^-1
   if (f12_mul(fast, f12_conj(fast)).is_one()) ok |= 4;
+  // tower arithmetic (Karatsuba product, complex squaring, sparse line product) against the schoolbook product
+  Fq12 g;
+  for (int k = 0; k < 6; k++) g.c[k] = {Fq::from_u32(seed * 11 + 5 * k + 3), Fq::from_u32(seed + 17 * k + 9)};
+  auto same = [](const Fq12& a, const Fq12& b) {
+    bool e = true;
+    for (int k = 0; k < 6; k++) e &= a.c[k] == b.c[k];
+    return e;
+  };
+  if (same(f12_mul(f, g), f12_mul_schoolbook(f, g)) && same(f12_sqr(f), f12_mul_schoolbook(f, f))) ok |= 8;
+  LineCoef lc{g.c[2], g.c[4]};
+  G1Affine P{Fq::from_u32(seed + 101), Fq::from_u32(seed * 3 + 7)};
+  if (same(f12_mul_line(f, P.y, lc.lam.mul_fq(P.x).neg(), lc.c), f12_mul_schoolbook(f, line_eval(lc, P)))) ok |= 16;
   return ok;
 }
 

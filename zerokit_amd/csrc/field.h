@@ -23,6 +23,10 @@
 
 namespace rlnamd {
 
+#if defined(RLN_COUNT_HOST_MUL)
+inline unsigned long long rln_host_mul_count = 0;
+#endif
+
 template <class P>
 struct Fp {
   uint32_t v[8];
@@ -204,31 +208,66 @@ struct Fp {
 #include "mont_mac.inc"
   static __device__ __forceinline__ Fp mont_mul(const Fp& a, const Fp& b) { return mont_dot1(a, b); }
 #else
+  // Host: CIOS on 4 x 64-bit limbs (the same Montgomery residues: 8 x 32 little-endian words ARE 4 x 64-bit words)
+  // with a 128-bit accumulator -- 32 wide products instead of 128 narrow ones.  The host side verifies proofs
+  // (pairing.h, ffi_verify_rln_proof), decompresses points and derives tables; ark-ff does the same with mulx / adx.
+  static constexpr uint64_t inv64() {   // -p^-1 mod 2^64 by Newton from -p^-1 mod 2^32
+    const uint64_t p0 = (uint64_t)P::MOD[0] | ((uint64_t)P::MOD[1] << 32);
+    uint64_t x = (uint64_t)(0u - P::INV32);   // p^-1 mod 2^32
+    x = x * (2 - p0 * x);                     // mod 2^64
+    return 0 - x;
+  }
   static RLN_HD Fp mont_mul(const Fp& a, const Fp& b) {
-    uint32_t t[8];
+    typedef unsigned __int128 u128;
+#if defined(RLN_COUNT_HOST_MUL)
+    rln_host_mul_count++;   // profiling builds of the host verifier (tests/host): products per stage
+#endif
+    uint64_t A[4], Bv[4], M[4], t[5] = {0, 0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < 8; i++) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const uint32_t bi = b.v[i];
-      uint64_t acc = (uint64_t)a.v[0] * bi + t[0];
-      const uint32_t m = (uint32_t)acc * P::INV32;
-      uint64_t red = (uint64_t)m * P::MOD[0] + (uint32_t)acc;
-      uint32_t c1 = (uint32_t)(acc >> 32), c2 = (uint32_t)(red >> 32);
-#pragma unroll
-      for (int j = 1; j < 8; j++) {
-        acc = (uint64_t)a.v[j] * bi + t[j] + c1;
-        c1 = (uint32_t)(acc >> 32);
-        red = (uint64_t)m * P::MOD[j] + (uint32_t)acc + c2;
-        c2 = (uint32_t)(red >> 32);
-        t[j - 1] = (uint32_t)red;
-      }
-      t[7] = c1 + c2;
+    for (int i = 0; i < 4; i++) {
+      A[i] = (uint64_t)a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32);
+      Bv[i] = (uint64_t)b.v[2 * i] | ((uint64_t)b.v[2 * i + 1] << 32);
+      M[i] = (uint64_t)P::MOD[2 * i] | ((uint64_t)P::MOD[2 * i + 1] << 32);
     }
-    reduce_once(t);
+    constexpr uint64_t INV = inv64();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      u128 c = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        c += (u128)A[j] * Bv[i] + t[j];
+        t[j] = (uint64_t)c;
+        c >>= 64;
+      }
+      c += t[4];
+      t[4] = (uint64_t)c;   // p < 2^254: no carry out of five words
+      const uint64_t m = t[0] * INV;
+      c = (u128)m * M[0] + t[0];
+      c >>= 64;
+#pragma unroll
+      for (int j = 1; j < 4; j++) {
+        c += (u128)m * M[j] + t[j];
+        t[j - 1] = (uint64_t)c;
+        c >>= 64;
+      }
+      c += t[4];
+      t[3] = (uint64_t)c;
+      t[4] = (uint64_t)(c >> 64);
+    }
+    uint64_t d[4], borrow = 0;   // t < 2 p: one conditional subtraction
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const u128 x = (u128)t[i] - M[i] - borrow;
+      d[i] = (uint64_t)x;
+      borrow = (uint64_t)(x >> 64) & 1;
+    }
     Fp r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = t[i];
+    for (int i = 0; i < 4; i++) {
+      const uint64_t w = borrow ? t[i] : d[i];
+      r.v[2 * i] = (uint32_t)w;
+      r.v[2 * i + 1] = (uint32_t)(w >> 32);
+    }
     return r;
   }
 #endif
@@ -303,12 +342,87 @@ struct Fp {
     }
     return r;
   }
-  // Fermat inverse; 0 -> 0
+  // Inverse; 0 -> 0.  Device: Fermat (straight-line, no divergence).  Host: binary extended Euclid on the stored
+  // integer x = a R (about 2 x 254 shift / subtract steps on four 64-bit words instead of 380 field products: the
+  // verifier's affine line steps, to_affine and the Fq12 inverse all end here), then x^-1 = a^-1 R^-1 is carried
+  // back to a^-1 R by two products with R^2.
   RLN_HD Fp inv() const {
+#if defined(__HIP_DEVICE_COMPILE__)
     uint32_t e[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) e[i] = P::PM2[i];
     return pow(e);
+#else
+    if (is_zero()) return zero();
+    typedef unsigned __int128 u128;
+    uint64_t u[4], w[4], x1[4] = {1, 0, 0, 0}, x2[4] = {0, 0, 0, 0}, M[4];
+    for (int i = 0; i < 4; i++) {
+      u[i] = (uint64_t)v[2 * i] | ((uint64_t)v[2 * i + 1] << 32);
+      M[i] = (uint64_t)P::MOD[2 * i] | ((uint64_t)P::MOD[2 * i + 1] << 32);
+      w[i] = M[i];
+    }
+    auto is_one = [](const uint64_t* a) { return a[0] == 1 && (a[1] | a[2] | a[3]) == 0; };
+    auto geq = [](const uint64_t* a, const uint64_t* b) {
+      for (int i = 3; i >= 0; i--)
+        if (a[i] != b[i]) return a[i] > b[i];
+      return true;
+    };
+    auto sub = [](uint64_t* a, const uint64_t* b) {   // a -= b, returns the borrow
+      uint64_t br = 0;
+      for (int i = 0; i < 4; i++) {
+        const u128 x = (u128)a[i] - b[i] - br;
+        a[i] = (uint64_t)x;
+        br = (uint64_t)(x >> 64) & 1;
+      }
+      return br;
+    };
+    auto add = [](uint64_t* a, const uint64_t* b) {   // a += b, returns the carry
+      uint64_t c = 0;
+      for (int i = 0; i < 4; i++) {
+        const u128 x = (u128)a[i] + b[i] + c;
+        a[i] = (uint64_t)x;
+        c = (uint64_t)(x >> 64);
+      }
+      return c;
+    };
+    auto shr1 = [](uint64_t* a, uint64_t top) {
+      for (int i = 0; i < 3; i++) a[i] = (a[i] >> 1) | (a[i + 1] << 63);
+      a[3] = (a[3] >> 1) | (top << 63);
+    };
+    auto halve = [&](uint64_t* a) {   // a / 2 mod p for a < p
+      uint64_t c = 0;
+      if (a[0] & 1) c = add(a, M);
+      shr1(a, c);
+    };
+    auto submod = [&](uint64_t* a, const uint64_t* b) {   // a - b mod p, a, b < p
+      if (sub(a, b)) add(a, M);
+    };
+    while (!is_one(u) && !is_one(w)) {
+      while (!(u[0] & 1)) {
+        shr1(u, 0);
+        halve(x1);
+      }
+      while (!(w[0] & 1)) {
+        shr1(w, 0);
+        halve(x2);
+      }
+      if (geq(u, w)) {
+        sub(u, w);
+        submod(x1, x2);
+      } else {
+        sub(w, u);
+        submod(x2, x1);
+      }
+    }
+    const uint64_t* res = is_one(u) ? x1 : x2;
+    Fp y, r2;
+    for (int i = 0; i < 4; i++) {
+      y.v[2 * i] = (uint32_t)res[i];
+      y.v[2 * i + 1] = (uint32_t)(res[i] >> 32);
+    }
+    for (int i = 0; i < 8; i++) r2.v[i] = P::R2[i];
+    return y * r2 * r2;
+#endif
   }
 };
 

@@ -459,6 +459,21 @@ bool g2_decompress(const uint8_t in[64], G2Affine* out) {
   return true;
 }
 
-bool g2_in_subgroup(const G2Affine& p) { return scalar_mul(p, FrParams::MOD).is_inf(); }
+// Membership in the order-r subgroup of the twist.  ark-ec's BN model (what `Validate::Yes` runs in the reference's
+// deserialisers) tests psi(P) == [6 u^2] P, psi the untwist-Frobenius-twist endomorphism (Dai, Lin, Zhao, Zhou,
+// "Fast subgroup membership testings for G1, G2 and GT on pairing-friendly curves", section 4.3): a 127-bit scalar
+// instead of the 254-bit [r] P == O -- the same verdict on every point of the twist (tests/test_host_math.py checks
+// both forms on subgroup and non-subgroup points).
+bool g2_in_subgroup(const G2Affine& p) {
+  if (p.is_inf()) return true;
+  static const uint32_t SIX_U2[8] = {0xe87cfd46u, 0xf83e9682u, 0xeeb859fbu, 0x6f4d8248u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u};   // 6 u^2, u = 4965661367192848881
+  auto fq2c = [](const uint32_t v[2][8]) { return Fq2{Fq::from_canonical(v[0]), Fq::from_canonical(v[1])}; };
+  static const Fq2 g12 = fq2c(FROB_G12), g13 = fq2c(FROB_G13);
+  const Fq2 px = p.x.conj() * g12, py = p.y.conj() * g13;   // psi(P)
+  const G2XYZZ k = scalar_mul(p, SIX_U2);
+  if (k.is_inf()) return false;
+  return k.X == px * k.ZZ && k.Y == py * k.ZZZ;
+}
+bool g2_in_subgroup_by_order(const G2Affine& p) { return scalar_mul(p, FrParams::MOD).is_inf(); }
 
 }  // namespace rlnamd

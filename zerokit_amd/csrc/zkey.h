@@ -63,6 +63,7 @@ bool g2_decompress(const uint8_t in[64], G2Affine* out);
 // [r]P == 0: membership in the order-r subgroup of the twist (cofactor != 1 on G2).  ark-serialize Validate::Yes
 // performs this check on every deserialised proof (protocol/proof.rs:413-449 -> Proof::deserialize_compressed);
 // every entry that accepts proof bytes from outside calls it.  G1 has cofactor 1: on-curve is enough there.
-bool g2_in_subgroup(const G2Affine& p);
+bool g2_in_subgroup(const G2Affine& p);            // psi(P) == [6 u^2] P
+bool g2_in_subgroup_by_order(const G2Affine& p);   // [r] P == O: the definition, kept as the cross-check of the tests
 
 }  // namespace rlnamd
