@@ -769,6 +769,29 @@ __global__ void __launch_bounds__(64) k_sum_ranges(const XYZZ<F>* __restrict__ s
   dst[(size_t)r * B + p] = acc;
 }
 
+// The same reduction for small batches, lanes = partial sums instead of lanes = proofs: with one proof in the batch
+// k_sum_ranges leaves 63 lanes idle and a G2 segment is a serial chain of 16 + 30 general additions (~ 2 ms); here the
+// 64 lanes of the wave of (proof, segment) each add their share of the segment's chunks and meet in a six-level tree
+// through LDS: 8 + 6 additions.
+template <class F>
+__global__ void __launch_bounds__(64) k_sum_tree(const XYZZ<F>* __restrict__ part, const ChunkDesc* __restrict__ segchunks,
+                                                 XYZZ<F>* __restrict__ dst, uint32_t B) {
+  __shared__ XYZZ<F> sh[64];
+  __builtin_amdgcn_s_setprio(3);
+  const uint32_t p = blockIdx.x, sgi = blockIdx.y, l = threadIdx.x;
+  const ChunkDesc cd = segchunks[sgi];
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (uint32_t i = cd.pt_begin + l; i < cd.pt_end; i += 64) acc.add(part[(size_t)i * B + p]);
+#pragma unroll 1
+  for (uint32_t stride = 32; stride >= 1; stride >>= 1) {
+    sh[l] = acc;
+    __syncthreads();
+    if (l < stride) acc.add(sh[l + stride]);
+    __syncthreads();
+  }
+  if (l == 0) dst[(size_t)sgi * B + p] = acc;
+}
+
 // GLV: segment t holds sum k1_i P_i, segment nseg + t holds sum k2_i P_i; the result is the first plus phi of the
 // second, phi(X, Y, ZZ, ZZZ) = (beta X, Y, ZZ, ZZZ) (x = X / ZZ).  One Fq product per output point and proof.
 __global__ void __launch_bounds__(64) k_glv_fold(G1XYZZ* __restrict__ sums1, G2XYZZ* __restrict__ sums2, uint32_t nseg1,
@@ -1141,7 +1164,7 @@ struct Prover::Impl {
   // a walk = a list of table rows cut into chunks, plus the two-level reduction ranges; one per mode
   struct Plan {
     DevBuf<uint32_t> rows;
-    DevBuf<ChunkDesc> chunks, groups, segs;
+    DevBuf<ChunkDesc> chunks, groups, segs, segchunks;   // segchunks: the chunk range of every segment (k_sum_tree)
     uint32_t nchunks = 0, ngroups = 0, nseg = 0;
   };
   Plan plan1[3], plan2[3];  // [PROVE_FULL, PROVE_PARTIAL, PROVE_FINISH]
@@ -1620,6 +1643,10 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
       if (!chunks.empty()) P.chunks.upload(chunks.data(), chunks.size(), s);
       if (!groups.empty()) P.groups.upload(groups.data(), groups.size(), s);
       P.segs.upload(segs.data(), segs.size(), s);
+      std::vector<ChunkDesc> segchunks;
+      for (size_t sgi = 0; sgi + 1 < segfirst.size(); sgi++) segchunks.push_back({segfirst[sgi], segfirst[sgi + 1]});
+      P.segchunks.alloc(segchunks.size());
+      P.segchunks.upload(segchunks.data(), segchunks.size(), s);
       RLN_HIP(hipStreamSynchronize(s));
       *max_chunks = std::max(*max_chunks, P.nchunks);
       *max_groups = std::max(*max_groups, P.ngroups);
@@ -1970,14 +1997,19 @@ void Prover::run_async(size_t n, int mode) {
   RLN_HIP(hipStreamWaitEvent(D.sC, S.evB, 0));
   if (D.split_msm) RLN_HIP(hipStreamWaitEvent(D.sC, S.evB2, 0));
   RLN_HIP(hipEventRecord(S.t[9], D.sC));
-  if (P1.ngroups)
-    hipLaunchKernelGGL(k_sum_ranges<Fq>, dim3(pg, P1.ngroups), dim3(64), 0, D.sC, S.part1.p, P1.groups.p, P1.ngroups,
-                       S.grp1.p, B, nbp);
-  if (P2.ngroups)
-    hipLaunchKernelGGL(k_sum_ranges<Fq2>, dim3(pg, P2.ngroups), dim3(64), 0, D.sC, S.part2.p, P2.groups.p, P2.ngroups,
-                       S.grp2.p, B, nbp);
-  hipLaunchKernelGGL(k_sum_ranges<Fq>, dim3(pg, P1.nseg), dim3(64), 0, D.sC, S.grp1.p, P1.segs.p, P1.nseg, S.sums1.p, B, nbp);
-  hipLaunchKernelGGL(k_sum_ranges<Fq2>, dim3(pg, P2.nseg), dim3(64), 0, D.sC, S.grp2.p, P2.segs.p, P2.nseg, S.sums2.p, B, nbp);
+  if (lanechunk) {   // small batch: lanes = partial sums (k_sum_tree)
+    hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, P1.nseg), dim3(64), 0, D.sC, S.part1.p, P1.segchunks.p, S.sums1.p, B);
+    hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(64), 0, D.sC, S.part2.p, P2.segchunks.p, S.sums2.p, B);
+  } else {
+    if (P1.ngroups)
+      hipLaunchKernelGGL(k_sum_ranges<Fq>, dim3(pg, P1.ngroups), dim3(64), 0, D.sC, S.part1.p, P1.groups.p, P1.ngroups,
+                         S.grp1.p, B, nbp);
+    if (P2.ngroups)
+      hipLaunchKernelGGL(k_sum_ranges<Fq2>, dim3(pg, P2.ngroups), dim3(64), 0, D.sC, S.part2.p, P2.groups.p, P2.ngroups,
+                         S.grp2.p, B, nbp);
+    hipLaunchKernelGGL(k_sum_ranges<Fq>, dim3(pg, P1.nseg), dim3(64), 0, D.sC, S.grp1.p, P1.segs.p, P1.nseg, S.sums1.p, B, nbp);
+    hipLaunchKernelGGL(k_sum_ranges<Fq2>, dim3(pg, P2.nseg), dim3(64), 0, D.sC, S.grp2.p, P2.segs.p, P2.nseg, S.sums2.p, B, nbp);
+  }
   if (D.nh == 2)  // sums of the second halves through phi, onto the first: afterwards sums1[0..3) / sums2[0] as without GLV
     hipLaunchKernelGGL(k_glv_fold, dim3(pg, 4), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, 3u, B, nbp);
   if (mode == PROVE_PARTIAL) {
