@@ -131,6 +131,7 @@ def main(verbose=True):
                 ("poseidon row (sparse partial round) dotn<4>", [(N, f.N(80))] * 4, True, None, False),
                 ("poseidon dotn<5> masked", [(N, f.N(80))] * 5, False, None, False),
                 ("poseidon mul(u_i, st[0])", [(N, N)], True, None, False),
+                ("witness interpreter a * b + c (mul_add, every value below 7.5 r)", [(N, N)], True, N, False),
             ]
         sites += [
             ("%s from_fq / to_fq / mul_mont  mul(N, const)" % name, [(N, limbs(f.p - 1))], True, None, False),

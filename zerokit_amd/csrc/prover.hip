@@ -300,6 +300,7 @@ __global__ void __launch_bounds__(64) k_witness(const GNode* __restrict__ nodes,
 // carries W29_RED: its value is multiplied by the Montgomery one (result < 1.1 r).  Every operand is therefore below
 // 7.5 r, inside what fq29.h's products (check_fq29_bounds.py: N(10)), K8 - b and the exact zero test (k r, k < 8) take.
 constexpr uint32_t W29_STORE = 1u << 8, W29_RED = 1u << 9, W29_RARE = 1u << 10;  // flags in descriptor word 0
+constexpr uint32_t W29_FMA = 25;             // program-only operation: a * b + c (an Add fused with its single-use product)
 constexpr uint32_t WIT29_RING = 32;          // node values kept in LDS: 32 x 64 x 48 B = 96 KiB
 constexpr uint32_t WIT29_LDS_CONSTS = 1024;  // constants kept in LDS: 48 KiB
 constexpr uint32_t WIT29_CH = 256;           // descriptors per program chunk: 64 lanes x 64 B; two chunks in LDS (8 KiB)
@@ -369,6 +370,10 @@ __device__ __noinline__ Wit29Out wit29_rare(uint32_t w0, uint32_t ea, uint32_t e
     if (op != G_NEG && op != G_ID) src(vb, eb);
     if (op == G_MUL) {
       v = Fr29::mul(va, vb);
+    } else if (op == W29_FMA) {
+      Fr29 vc;
+      src(vc, ec);
+      v = Fr29::mul_add(va, vb, vc);
     } else if (op == G_ADD) {
 #pragma unroll
       for (int k = 0; k < 9; k++) v.v[k] = va.v[k] + vb.v[k];
@@ -448,11 +453,14 @@ __global__ void __launch_bounds__(64) k_witness29(const GNode29* __restrict__ no
         // cost one LDS round trip.  The previous node's value is read back from the ring like any other (its write
         // was issued a few instructions earlier and LDS is in order): forwarding it in registers cost 18 selects and
         // saved nothing, because a node waits for at least one LDS read anyway.
-        Fr29 va, vb;
+        Fr29 va, vb, vc;
         wit29_read(va, wit29_addr(ea, lane48), ring);
         wit29_read(vb, wit29_addr(eb, lane48), ring);
+        wit29_read(vc, wit29_addr(ec, lane48), ring);   // the addend of a * b + c (a harmless ring slot otherwise)
         d_next = ((const uint4*)prog)[(n + 1) % (2 * WIT29_CH)];
-        if ((w0 & 0xFF) == G_MUL) {
+        if ((w0 & 0xFF) == W29_FMA) {
+          v = Fr29::mul_add(va, vb, vc);
+        } else if ((w0 & 0xFF) == G_MUL) {
           v = Fr29::mul(va, vb);
         } else {  // G_ADD
 #pragma unroll
@@ -479,7 +487,7 @@ __global__ void __launch_bounds__(64) k_witness29(const GNode29* __restrict__ no
       }
       if (PROF) {
         const uint32_t op = w0 & 0xFF;
-        const int cls = op == G_MUL ? 0 : op == G_ADD ? 1 : (op == G_CONST || op == G_INPUT) ? 2 : 3;
+        const int cls = (op == G_MUL || op == W29_FMA) ? 0 : op == G_ADD ? 1 : (op == G_CONST || op == G_INPUT) ? 2 : 3;
         pc[cls] += clock64() - tn;
         pn[cls]++;
       }
@@ -1142,7 +1150,7 @@ struct Prover::Impl {
   DevBuf<GNode29> nodes29;
   DevBuf<unsigned long long> wit_prof;
   DevBuf<uint32_t> consts29, slot2node;
-  uint32_t nstore29 = 0;
+  uint32_t nstore29 = 0, nprog29 = 0;   // stored values, program nodes (after fusion)
 
   uint32_t N = 0, NS = 0, NI = 0, nc = 0, ni = 0, n = 0;
   int logn = 0;
@@ -1411,82 +1419,115 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   if (!graph_.constants.empty()) D.consts.upload(graph_.constants.data(), graph_.constants.size(), s);
   D.wit29 = env_int("RLNAMD_WIT29", 1) != 0;
   D.lanechunk_max = (uint32_t)std::max(0, env_int("RLNAMD_LANECHUNK", 24));
-  std::vector<uint8_t> wit29_store;
-  std::vector<uint32_t> wit29_slot_of, wit29_slot2node;
+  std::vector<GNode29> wit29_prog;
+  std::vector<uint32_t> wit29_slot2node;
   if (D.wit29) {
-    // The program of k_witness29: the same nodes; stored values (witness signals, inputs, operands further back than
-    // the LDS ring) live in a compact array indexed by `slot`; W29_RED where the static bound of a value (in units of r)
-    // would pass WIT29_BMAX (see k_witness29)
-    std::vector<uint8_t>& store = wit29_store;
-    store.assign(D.N, 0);
-    for (uint32_t sgn : graph_.signals) store[sgn] = 1;
-    auto far = [&](uint32_t n, uint32_t o) { return graph_.nodes[o].op != G_CONST && n - o >= WIT29_RING; };
+    // The program of k_witness29.  (1) Fusion: an Add one of whose operands is a product used nowhere else (and is no
+    // witness signal) becomes ONE node, a * b + c (W29_FMA: the addend enters the product's final carry chain,
+    // Fr29::mul_add) -- in the shipped circuits every addition of a Poseidon round is of that kind, 23 414 nodes become
+    // ~15 000.  (2) Program order = node order without the fused products; the LDS ring is addressed by program
+    // index.  (3) Stored values (witness signals, inputs, operands further back than the ring) live in a compact array
+    // indexed by `slot`.  (4) W29_RED where the static bound of a value (in units of r) would pass WIT29_BMAX.
+    const uint32_t NONE = 0xFFFFFFFFu;
+    const std::vector<GNode>& G = graph_.nodes;
+    auto is_const = [&](uint32_t o) { return G[o].op == G_CONST; };
+    auto nops = [&](const GNode& g) {
+      return (g.op == G_INPUT || g.op == G_CONST) ? 0 : (g.op == G_NEG || g.op == G_ID) ? 1 : g.op == G_TERN ? 3 : 2;
+    };
+    std::vector<uint32_t> uses(D.N, 0);
     for (uint32_t n = 0; n < D.N; n++) {
-      const GNode& g = graph_.nodes[n];
-      if (g.op == G_INPUT) store[n] = 1;
-      if (g.op == G_INPUT || g.op == G_CONST) continue;
-      if (g.a >= n) throw Error("Graph error: node operand refers forward");
-      if (far(n, g.a)) store[g.a] = 1;
-      if (g.op != G_NEG && g.op != G_ID) {
-        if (g.b >= n) throw Error("Graph error: node operand refers forward");
-        if (far(n, g.b)) store[g.b] = 1;
-      }
-      if (g.op == G_TERN) {
-        if (g.c >= n) throw Error("Graph error: node operand refers forward");
-        if (far(n, g.c)) store[g.c] = 1;
+      const uint32_t o[3] = {G[n].a, G[n].b, G[n].c};
+      for (int k = 0; k < nops(G[n]); k++) {
+        if (o[k] >= n) throw Error("Graph error: node operand refers forward");
+        uses[o[k]]++;
       }
     }
-    std::vector<uint32_t>& slot_of = wit29_slot_of;
+    std::vector<uint8_t> is_signal(D.N, 0);
+    for (uint32_t sgn : graph_.signals) is_signal[sgn] = 1;
+    std::vector<uint32_t> fused_mul(D.N, NONE);   // for an Add: the product folded into it
+    std::vector<uint8_t> removed(D.N, 0);
+    const bool fuse = env_int("RLNAMD_WIT29_FUSE", 1) != 0;
+    for (uint32_t n = 0; fuse && n < D.N; n++) {
+      if (G[n].op != G_ADD) continue;
+      for (uint32_t m : {G[n].b, G[n].a}) {
+        if (G[m].op == G_MUL && uses[m] == 1 && !is_signal[m] && !removed[m] && G[n].a != G[n].b) {
+          fused_mul[n] = m;
+          removed[m] = 1;
+          break;
+        }
+      }
+    }
+    // program nodes: operands as ORIGINAL node ids
+    struct PNode { uint32_t op, node, src[3]; };
+    std::vector<PNode> P;
+    std::vector<uint32_t> pidx(D.N, NONE);
+    for (uint32_t n = 0; n < D.N; n++) {
+      if (removed[n]) continue;
+      PNode q{G[n].op, n, {G[n].a, G[n].b, G[n].c}};
+      if (fused_mul[n] != NONE) {
+        const uint32_t m = fused_mul[n];
+        q.op = W29_FMA;
+        q.src[0] = G[m].a;
+        q.src[1] = G[m].b;
+        q.src[2] = G[n].a == m ? G[n].b : G[n].a;
+      }
+      pidx[n] = (uint32_t)P.size();
+      P.push_back(q);
+    }
+    auto pn_ops = [&](const PNode& q) { return q.op == W29_FMA ? 3 : nops(GNode{q.op, 0, 0, 0}); };
+    std::vector<uint8_t> store(D.N, 0);
+    for (uint32_t n = 0; n < D.N; n++) store[n] = is_signal[n] || G[n].op == G_INPUT;
+    for (uint32_t i = 0; i < P.size(); i++)
+      for (int k = 0; k < pn_ops(P[i]); k++) {
+        const uint32_t o = P[i].src[k];
+        if (!is_const(o) && i - pidx[o] >= WIT29_RING) store[o] = 1;
+      }
+    std::vector<uint32_t> slot_of(D.N, 0);
     std::vector<uint32_t>& slot2node = wit29_slot2node;
-    slot_of.assign(D.N, 0);
     for (uint32_t n = 0; n < D.N; n++)
-      if (store[n]) {
+      if (store[n] && !removed[n]) {
         slot_of[n] = (uint32_t)slot2node.size();
         slot2node.push_back(n);
       }
     if (slot2node.size() >= 65536) D.wit29 = false;   // the descriptor has 16 bits for the slot: larger graphs keep k_witness
-  }
-  if (D.wit29) {
-    std::vector<uint8_t>& store = wit29_store;
-    std::vector<uint32_t>& slot_of = wit29_slot_of;
-    std::vector<uint32_t>& slot2node = wit29_slot2node;
-    std::vector<GNode29> prog(D.N);
+    std::vector<GNode29>& prog = wit29_prog;
+    prog.resize(P.size());
     std::vector<double> bnd(D.N, 1.01);
-    for (uint32_t n = 0; n < D.N; n++) {
-      const GNode& g = graph_.nodes[n];
-      GNode29 q{};
-      uint32_t flags = store[n] ? W29_STORE : 0;
-      q.a = g.a;   // G_INPUT: input index, G_CONST: constant index
+    for (uint32_t i = 0; D.wit29 && i < P.size(); i++) {
+      const PNode& q = P[i];
+      GNode29 d{};
+      uint32_t flags = store[q.node] ? W29_STORE : 0;
+      d.a = q.src[0];   // G_INPUT: input index, G_CONST: constant index
       double b = 1.01;  // inputs, constants, slow operations: a fresh product with a constant
-      // the fast path of the kernel is Mul / Add with both operands in LDS (ring or constant table) or forwarded
-      bool rare = g.op != G_MUL && g.op != G_ADD;
-      if (g.op != G_INPUT && g.op != G_CONST) {
+      // the fast path of the kernel: Mul / Add / a * b + c with every operand in LDS (ring or constant table)
+      bool rare = q.op != G_MUL && q.op != G_ADD && q.op != W29_FMA;
+      if (q.op != G_INPUT && q.op != G_CONST) {
         auto enc = [&](uint32_t o) -> uint32_t {
-          if (graph_.nodes[o].op == G_CONST) {
-            if (graph_.nodes[o].a >= WIT29_LDS_CONSTS) rare = true;
-            return OPK_CONST | graph_.nodes[o].a;
+          if (is_const(o)) {
+            if (G[o].a >= WIT29_LDS_CONSTS) rare = true;
+            return OPK_CONST | G[o].a;
           }
-          if (n - o < WIT29_RING) return OPK_RING | o;
+          if (i - pidx[o] < WIT29_RING) return OPK_RING | pidx[o];
           rare = true;
           return OPK_FAR | slot_of[o];
         };
-        auto bo = [&](uint32_t o) { return graph_.nodes[o].op == G_CONST ? 1.01 : bnd[o]; };
-        q.a = enc(g.a);
-        const double ba = bo(g.a);
-        double bb = 0, bc = 0;
-        if (g.op != G_NEG && g.op != G_ID) {
-          q.b = enc(g.b);
-          bb = bo(g.b);
+        auto bo = [&](uint32_t o) { return is_const(o) ? 1.01 : bnd[o]; };
+        const int k = pn_ops(q);
+        double bs[3] = {0, 0, 0};
+        uint32_t e[3] = {0, 0, 0};
+        for (int j = 0; j < k; j++) {
+          e[j] = enc(q.src[j]);
+          bs[j] = bo(q.src[j]);
         }
-        if (g.op == G_TERN) {
-          q.c = enc(g.c);
-          bc = bo(g.c);
-        }
-        if (g.op == G_MUL) b = 1.0 + 0.006 * ba * bb;
-        else if (g.op == G_ADD) b = ba + bb;
-        else if (g.op == G_SUB) b = ba + 8.0;
-        else if (g.op == G_NEG) b = 8.0;
-        else if (g.op == G_TERN) b = std::max(bb, bc);
+        d.a = e[0];
+        d.b = e[1];
+        d.c = e[2];
+        if (q.op == G_MUL) b = 1.0 + 0.006 * bs[0] * bs[1];
+        else if (q.op == W29_FMA) b = 1.0 + 0.006 * bs[0] * bs[1] + bs[2];
+        else if (q.op == G_ADD) b = bs[0] + bs[1];
+        else if (q.op == G_SUB) b = bs[0] + 8.0;
+        else if (q.op == G_NEG) b = 8.0;
+        else if (q.op == G_TERN) b = std::max(bs[1], bs[2]);
       }
       if (b > WIT29_BMAX) {
         flags |= W29_RED;
@@ -1494,12 +1535,17 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
         b = 1.0 + 0.006 * b;
       }
       if (rare) flags |= W29_RARE;
-      bnd[n] = b;
-      q.w0 = g.op | flags | (slot_of[n] << 16);
-      prog[n] = q;
+      bnd[q.node] = b;
+      d.w0 = q.op | flags | (slot_of[q.node] << 16);
+      prog[i] = d;
     }
+  }
+  if (D.wit29) {
+    std::vector<GNode29>& prog = wit29_prog;
+    std::vector<uint32_t>& slot2node = wit29_slot2node;
+    D.nprog29 = (uint32_t)prog.size();
     D.nstore29 = (uint32_t)slot2node.size();
-    prog.resize(((size_t)D.N / WIT29_CH + 4) * WIT29_CH, GNode29{});   // the kernel prefetches two chunks past the end
+    prog.resize(((size_t)D.nprog29 / WIT29_CH + 4) * WIT29_CH, GNode29{});   // the kernel prefetches two chunks past the end
     D.nodes29.alloc(prog.size());
     D.nodes29.upload(prog.data(), prog.size(), s);
     D.slot2node.alloc(std::max<size_t>(slot2node.size(), 1));
@@ -1873,7 +1919,7 @@ void Prover::run_async(size_t n, int mode) {
     if (prof) {
       DevBuf<unsigned long long>& pb = D.wit_prof;
       if (!pb.p) pb.alloc(16);
-      hipLaunchKernelGGL(k_witness29<true>, dim3(pg), dim3(64), WIT29_LDS_BYTES, sA, D.nodes29.p, D.N,
+      hipLaunchKernelGGL(k_witness29<true>, dim3(pg), dim3(64), WIT29_LDS_BYTES, sA, D.nodes29.p, D.nprog29,
                          D.consts29.p, (uint32_t)graph_.constants.size(), D.inputs.p, D.NI, S.V29.p, S.err.p, B, nbp, pb.p);
       unsigned long long h[16];
       RLN_HIP(hipStreamSynchronize(sA));
@@ -1881,7 +1927,7 @@ void Prover::run_async(size_t n, int mode) {
       fprintf(stderr, "wit29 prof: mul %llu cyc / %llu, add %llu / %llu, const+input %llu / %llu, other %llu / %llu; total %llu cyc, %.3f ms, clock %.0f MHz\n",
               h[0], h[4], h[1], h[5], h[2], h[6], h[3], h[7], h[8], h[9] / 1e5, h[9] ? 100.0 * h[8] / h[9] : 0.0);
     } else
-    hipLaunchKernelGGL(k_witness29<false>, dim3(pg), dim3(64), WIT29_LDS_BYTES, sA, D.nodes29.p, D.N,
+    hipLaunchKernelGGL(k_witness29<false>, dim3(pg), dim3(64), WIT29_LDS_BYTES, sA, D.nodes29.p, D.nprog29,
                        D.consts29.p, (uint32_t)graph_.constants.size(), D.inputs.p, D.NI, S.V29.p, S.err.p, B, nbp, nullptr);
     hipLaunchKernelGGL(k_v29_to_fr, dim3(pg, D.nstore29), dim3(64, 1), 0, sA, S.V29.p, D.slot2node.p, D.nstore29, S.V.p, B,
                        nbp);
