@@ -422,7 +422,7 @@ def test_both_graph_interpreters_give_the_golden_witness(monkeypatch):
 
 
 def test_lane_chunk_walk_and_clock_tap(monkeypatch):
-    """Batches of at most RLNAMD_LANECHUNK (24) proofs walk the tables with lanes = chunks, larger ones with lanes =
+    """Batches of at most RLNAMD_LANECHUNK (56) proofs walk the tables with lanes = chunks, larger ones with lanes =
     proofs (walk29.h).  The same witnesses must give the same proof bytes either way -- alone, inside a batch that is
     walked the other way, and with the threshold forced to 0 -- and the clock tap of the walk kernels must report a
     plausible shader clock after a lanes = proofs run."""
@@ -432,13 +432,13 @@ def test_lane_chunk_walk_and_clock_tap(monkeypatch):
     p = BatchProver(max_batch=64)
     try:
         small = p.prove(ws[:2], rs[:2])                       # lanes = chunks
-        reps = 40 // len(ws) + 1
-        big = p.prove((ws * reps)[:40], (rs * reps)[:40])     # lanes = proofs
+        reps = 64 // len(ws) + 1
+        big = p.prove((ws * reps)[:64], (rs * reps)[:64])     # lanes = proofs
         clk = p.walk_clock_mhz()
         assert 500.0 < clk["g1_walk"] < 3000.0 and 500.0 < clk["g2_walk"] < 3000.0, clk
         for i in range(2):
             assert small[i]["proof"].hex() == cases[i]["proof_compressed"]
-        for i in range(40):
+        for i in range(64):
             assert big[i]["proof"].hex() == cases[i % len(ws)]["proof_compressed"], i
     finally:
         p.close()

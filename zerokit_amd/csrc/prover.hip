@@ -1146,7 +1146,7 @@ struct Prover::Impl {
   float ms[PROVER_STAGES] = {0};
   DevBuf<unsigned long long> walk_clk;  // clock tap of the two walks: G1 cycles, G1 ticks, G2 cycles, G2 ticks
   bool wit29 = true;             // RLNAMD_WIT29: graph interpreter in the 9 x 29-bit form (k_witness29)
-  uint32_t lanechunk_max = 24;   // RLNAMD_LANECHUNK: largest batch walked with lanes = chunks
+  uint32_t lanechunk_max = 56;   // RLNAMD_LANECHUNK: largest batch walked with lanes = chunks
   DevBuf<GNode29> nodes29;
   DevBuf<unsigned long long> wit_prof;
   DevBuf<uint32_t> consts29, slot2node;
@@ -1418,7 +1418,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   D.consts.alloc(std::max<size_t>(graph_.constants.size(), 1));
   if (!graph_.constants.empty()) D.consts.upload(graph_.constants.data(), graph_.constants.size(), s);
   D.wit29 = env_int("RLNAMD_WIT29", 1) != 0;
-  D.lanechunk_max = (uint32_t)std::max(0, env_int("RLNAMD_LANECHUNK", 24));
+  D.lanechunk_max = (uint32_t)std::max(0, env_int("RLNAMD_LANECHUNK", 56));
   std::vector<GNode29> wit29_prog;
   std::vector<uint32_t> wit29_slot2node;
   if (D.wit29) {
