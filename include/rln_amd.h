@@ -133,6 +133,13 @@ int rlnamd_verify_public(rlnamd_prover* p, const uint8_t proof[128], const uint8
 /* verify_zk_proof (protocol/proof.rs:856-894) on the host CPU, as in the reference.
  * values: y, root, nullifier, x, external_nullifier.  *ok = 1 valid, 0 invalid. */
 int rlnamd_verify(rlnamd_prover* p, const uint8_t proof[128], const uint8_t values_le[160], int* ok);
+/* n independent verifications on `threads` host threads (0 = one per hardware thread): proofs n * 128 bytes, values
+ * n * n_values * 32 bytes, ok[i] = 1 valid, 0 invalid or malformed.  EXT: the reference verifies one proof per call
+ * (protocol/proof.rs:856-894); a relay node verifies every message it forwards. */
+int rlnamd_verify_many(rlnamd_prover* p, size_t n, const uint8_t* proofs, const uint8_t* values_le, size_t n_values,
+                       int threads, uint8_t* ok);
+int rlnamd_verify_many_with_zkey(const uint8_t* zkey, size_t zkey_len, size_t n, const uint8_t* proofs,
+                                 const uint8_t* values_le, size_t n_values, int threads, uint8_t* ok);
 /* same check straight from arkzkey bytes; needs no GPU (host parser + host pairing only) */
 int rlnamd_verify_with_zkey(const uint8_t* zkey, size_t zkey_len, const uint8_t proof[128],
                             const uint8_t values_le[160], int* ok);

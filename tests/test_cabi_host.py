@@ -110,6 +110,29 @@ def test_host_verifier_snarkjs_kat_and_goldens():
     assert not _verify(p[96:128] + p[32:96] + p[0:32], [int(x) for x in v["public_inputs"]])
 
 
+def test_verify_many_on_host_threads_matches_single_verification():
+    """rlnamd_verify_many_with_zkey (EXT, no GPU): the golden proofs, a changed public input, a malformed proof and a
+    non-canonical public input in one call; the verdicts do not depend on the thread count."""
+    from zerokit_amd.batch import verify_many_with_zkey
+    z = open(os.path.join(RES, "rln_final.arkzkey"), "rb").read()
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "rln_h20_vectors.json")))["cases"]
+    proofs = [bytes.fromhex(c["proof_compressed"]) for c in cases] * 3
+    pubs = [[int(v) for v in c["public_inputs"]] for c in cases] * 3
+    want = [True] * len(proofs)
+    pubs[1] = [pubs[1][0] ^ 1] + pubs[1][1:]
+    want[1] = False
+    proofs[2] = bytes([proofs[2][0] ^ 1]) + proofs[2][1:]
+    want[2] = False
+    proofs[4] = proofs[4][96:128] + proofs[4][32:96] + proofs[4][0:32]
+    want[4] = False
+    for threads in (1, 3, 0):
+        assert verify_many_with_zkey(z, proofs, pubs, threads=threads) == want, threads
+    assert verify_many_with_zkey(z, [], []) == []
+    for i, (pr, pi) in enumerate(zip(proofs, pubs)):
+        if i != 2:   # the malformed proof is an error for the single call (as ffi_verify_rln_proof), False here
+            assert _verify(pr, pi) == want[i]
+
+
 def test_point_compression_matches_oracle():
     for name in ("config1_bench_witness", "survey_appendix_d", "config2_1"):
         v = _vec(name)

@@ -18,3 +18,15 @@ for n in (8, 64):
     t = time.perf_counter(); ps = rln.generate_rln_proofs_batch(ws[:n]); dt = time.perf_counter() - t
     print("batch", n, "ms", round(dt * 1e3, 2), "per proof", round(dt * 1e3 / n, 3))
 t = time.perf_counter(); rln.set_leaf(5, 99); r = rln.get_root(); print("set_leaf+root ms", round((time.perf_counter() - t) * 1e3, 3))
+# host-side batch verification (rlnamd_verify_many_with_zkey: no GPU involved), golden proofs repeated
+import json, os
+from zerokit_amd.batch import verify_many_with_zkey
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+z = open(os.path.join(root, "zerokit_amd", "resources", "tree_depth_20", "rln_final.arkzkey"), "rb").read()
+cases = json.load(open(os.path.join(root, "tests", "golden", "rln_h20_vectors.json")))["cases"]
+reps = 512 // len(cases)
+proofs = [bytes.fromhex(c["proof_compressed"]) for c in cases] * reps
+pubs = [[int(v) for v in c["public_inputs"]] for c in cases] * reps
+for threads in (1, 0):
+    t = time.perf_counter(); ok = verify_many_with_zkey(z, proofs, pubs, threads=threads); dt = time.perf_counter() - t
+    print("verify_many", len(proofs), "proofs, threads", threads or os.cpu_count(), "->", round(len(proofs) / dt), "verifications/s", all(ok))

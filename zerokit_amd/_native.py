@@ -118,6 +118,9 @@ SIGNATURES = {
     "rlnamd_prover_download_public": (C.c_int, [P, C.c_size_t, C.c_char_p]),
     "rlnamd_verify_public": (C.c_int, [P, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
     "rlnamd_verify_with_zkey": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]),
+    "rlnamd_verify_many": (C.c_int, [P, C.c_size_t, C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_char_p]),
+    "rlnamd_verify_many_with_zkey": (C.c_int, [C.c_char_p, C.c_size_t, C.c_size_t, C.c_char_p, C.c_char_p, C.c_size_t,
+                                               C.c_int, C.c_char_p]),
     "rlnamd_parse_resources": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "rlnamd_proof_compress": (C.c_int, [C.c_char_p, C.c_char_p]),
     "rlnamd_proof_decompress": (C.c_int, [C.c_char_p, C.c_char_p]),

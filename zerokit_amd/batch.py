@@ -214,11 +214,35 @@ class BatchProver:
         check(lib().rlnamd_prover_fetch_h(self._h, index, buf))
         return [int.from_bytes(buf.raw[32 * i:32 * i + 32], "little") for i in range(n)]
 
+    def verify_many(self, proofs, public_inputs, threads=0):
+        """n independent verifications on host threads (rlnamd_verify_many); returns a list of bools"""
+        n = len(proofs)
+        if n == 0:
+            return []
+        nv = len(public_inputs[0])
+        ok = C.create_string_buffer(n)
+        check(lib().rlnamd_verify_many(self._h, n, b"".join(proofs), b"".join(_b(v) for pi in public_inputs for v in pi),
+                                       nv, threads, ok))
+        return [bool(x) for x in ok.raw]
+
     def verify(self, proof: bytes, public_inputs):
         """verify_zk_proof (protocol/proof.rs:856-894); public_inputs = [y, root, nullifier, x, ext]."""
         ok = C.c_int()
         check(lib().rlnamd_verify(self._h, proof, b"".join(_b(v) for v in public_inputs), C.byref(ok)))
         return bool(ok.value)
+
+
+def verify_many_with_zkey(zkey: bytes, proofs, public_inputs, threads=0):
+    """n independent Groth16 verifications on host threads, straight from arkzkey bytes (no GPU): proofs = list of
+    128-byte compressed proofs, public_inputs = list of equally long lists of ints.  Returns a list of bools."""
+    n = len(proofs)
+    if n == 0:
+        return []
+    nv = len(public_inputs[0])
+    ok = C.create_string_buffer(n)
+    check(lib().rlnamd_verify_many_with_zkey(zkey, len(zkey), n, b"".join(proofs),
+                                             b"".join(_b(v) for pi in public_inputs for v in pi), nv, threads, ok))
+    return [bool(x) for x in ok.raw]
 
 
 class PoseidonTree:

@@ -3,7 +3,9 @@
 
 #include <string.h>
 
+#include <atomic>
 #include <memory>
+#include <thread>
 #include <string>
 
 #include "common.h"
@@ -410,6 +412,46 @@ static void verify_common(const Zkey& zk, const uint8_t proof[128], const uint8_
     in.push_back(Fr::from_canonical(c));
   }
   *ok = groth16_verify(zk, A, B, C, in) ? 1 : 0;
+}
+
+// n independent verifications spread over host threads (verification stays on the CPU; a relay node
+// verifies every message it forwards).  ok[i] = 1 valid, 0 invalid or malformed.
+static void verify_many_common(const Zkey& zk, size_t n, const uint8_t* proofs, const uint8_t* values_le, size_t nv,
+                               int threads, uint8_t* ok) {
+  (void)prepared(zk);  // once, before the workers only read it
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t nt = threads > 0 ? (size_t)threads : (hw ? hw : 1);
+  nt = std::max<size_t>(1, std::min(nt, n));
+  std::atomic<size_t> next{0};
+  auto work = [&]() {
+    for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+      int v = 0;
+      try {
+        verify_common(zk, proofs + 128 * i, values_le + 32 * nv * i, &v, nv);
+      } catch (const std::exception&) {
+        v = 0;
+      }
+      ok[i] = (uint8_t)v;
+    }
+  };
+  std::vector<std::thread> pool;
+  for (size_t t = 1; t < nt; t++) pool.emplace_back(work);
+  work();
+  for (auto& t : pool) t.join();
+}
+int rlnamd_verify_many(rlnamd_prover* p, size_t n, const uint8_t* proofs, const uint8_t* values_le, size_t n_values,
+                       int threads, uint8_t* ok) {
+  RLN_TRY
+  verify_many_common(p->p->zkey(), n, proofs, values_le, n_values, threads, ok);
+  RLN_CATCH
+}
+int rlnamd_verify_many_with_zkey(const uint8_t* zkey, size_t zkey_len, size_t n, const uint8_t* proofs,
+                                 const uint8_t* values_le, size_t n_values, int threads, uint8_t* ok) {
+  RLN_TRY
+  Zkey zk = parse_arkzkey(zkey, zkey_len);
+  if (n_values + 1 != zk.gamma_abc_g1.size()) throw Error("MalformedVerifyingKey");
+  verify_many_common(zk, n, proofs, values_le, n_values, threads, ok);
+  RLN_CATCH
 }
 
 size_t rlnamd_prover_num_public(rlnamd_prover* p) { return p->p->num_public(); }
