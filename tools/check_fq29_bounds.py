@@ -130,7 +130,7 @@ def main(verbose=True):
                 ("poseidon dense partial round dot3 masked, two lazy", [(N, N), (N, lazy2), (N, lazy2)], False, None, False),
                 ("poseidon row (sparse partial round) dotn<4>", [(N, f.N(80))] * 4, True, None, False),
                 ("poseidon dotn<5> masked", [(N, f.N(80))] * 5, False, None, False),
-                ("poseidon mul(u_i, st[0])", [(N, N)], True, None, False),
+                ("poseidon mul_add(u_i, st[0], st[i])  (st[i] < 72 r)", [(N, N)], True, f.N(80), False),
                 ("witness interpreter a * b + c (mul_add, every value below 7.5 r)", [(N, N)], True, N, False),
             ]
         sites += [

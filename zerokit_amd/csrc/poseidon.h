@@ -212,10 +212,7 @@ __device__ __forceinline__ void poseidon_partial29(Fr29* st, const uint32_t* __r
     Fr29 ui;
 #pragma unroll
     for (int k = 0; k < 9; k++) ui.v[k] = u[(i - 1) * 9 + k];
-    const Fr29 p = Fr29::mul(ui, st[0]);
-#pragma unroll
-    for (int k = 0; k < 9; k++) st[i].v[k] += p.v[k];
-    st[i].normalize();
+    st[i] = Fr29::mul_add(ui, st[0], st[i]);   // the addend rides the product's own carry chain (no second normalisation)
   }
   st[0] = n0;
 }
@@ -319,12 +316,10 @@ __device__ __forceinline__ Fr poseidon_hash3_lanes(const Fr& in, const PoseidonV
     const Fr29 x5 = get(base);
     // slot 4: lane 0: p_0 = row0[0] x5; lanes 1, 2: u_i x5
     const Fr29 c = j == 0 ? cst(row0) : cst(u + (j - 1) * 9);
-    const Fr29 w = Fr29::mul(c, x5);
-    if (j != 0) {
-#pragma unroll
-      for (int q = 0; q < 9; q++) s.v[q] += w.v[q];
-      s.normalize();
-    }
+    Fr29 zero_or_s = s;
+    if (j == 0) zero_or_s = Fr29::zero();
+    const Fr29 w = Fr29::mul_add(c, x5, zero_or_s);   // lane 0: p_0; lanes 1, 2: s_i + u_i x
+    if (j != 0) s = w;
     __syncthreads();
     if (j != 0) put(t);   // p_i
     __syncthreads();
