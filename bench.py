@@ -1,26 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- RLN Groth16 proofs/s on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-A "step" is one pass of the proving hot path over one batch of synthetic witnesses: per GPU, BATCH
-(default 1024 = BASELINE config 2) independent depth-20 RLN proofs from the seeded config-2 generator
-(SplitMix64 0xC0FFEE; oracle/pyref/workload.py restates the generator, this file re-implements it so the
-product path never imports the oracle).  Inputs are uploaded to HBM before the timed region; the timed
-region is K calls of rlnamd_prover_run (witness -> QAP/NTT -> MSM -> finalize -> proof bytes in HBM).
-N > 1: one process per GPU (torchrun), every rank proves its own shard, no data-path collective (weak
-scaling); timing = barrier + sync on both sides, max over ranks.
+Timed region: H2D of fresh witness inputs -> witness graph -> QAP/NTT -> table MSMs -> finalize ->
+D2H of proofs + public values, through rlnamd_prover_submit / rlnamd_prover_collect (include/rln_amd.h).  The comb
+tables are resident (built before the timed region); the witness inputs are NOT: every step stages its inputs in pinned
+host memory and copies them to the device inside the timer, and every step's results are copied out and kept.
 
-Extra objects on the same line:
-  roofline     -- dominant kernel (G1 table MSM): algorithmic MSM operand bytes per launch / its mean launch
-                  time (HIP events on the kernel's own stream, last five launches of the timed region: the walks
-                  of neighbouring batches overlap on two streams, so this span includes sharing the SIMDs;
-                  launch_ms_alone = the same launch with nothing else in flight, measured after the timed
-                  region), against the 8 TB/s HBM peak.  Defaults: K = 50 steps, W = 2 warm-up steps, comb
-                  tables on the 19-window schedule (207 GiB; smaller tables are tried if that does not fit).
-  cpu_baseline -- the oracle's C restatement of the arkworks CPU path (oracle/c, kind "port") timed on a
-                  bounded sample of the same witnesses on the host cores (rank 0, N = 1 only).
+  N = 1   a step is one batch of BATCH = 1024 proofs (BASELINE config 2).  The K timed steps prove K DISTINCT batches
+          (witness indices 1024 k .. 1024 (k + 1) of the SplitMix64(0xC0FFEE) stream; the stream wraps after 64 batches),
+          all workspace slots in flight.
+  N > 1   BASELINE config 4: 65 536-index stream cut into contiguous shards, 8 192 per GPU; a step is one pass over the
+          rank's shard (8 chunks of 1024, uploaded again every step).  Two launch modes:
+            * under torchrun (WORLD_SIZE set; how the driver runs it): one process per GPU, barrier + device sync on
+              both sides of the timed region, max over ranks; torch.distributed is plumbing only.
+            * plain `python bench.py --gpus N`: ONE process drives N devices through rlnamd_pool (one host thread and
+              one prover replica per device).  Exits non-zero when fewer than N devices are visible -- it never runs a
+              smaller job silently.
+          No data-path collective for proofs (independent units).  The one collective of this code base, the
+          ncclAllGather of the config-5 MSM's window sums, is exercised after the timed region (config5 object;
+          `rccl_ranks` = size of the communicator created through the C ABI).
+
+Extra objects on the line: roofline (dominant kernel, both bounds: VALU issue -- the one that binds -- and the HBM view
+BASELINE.json asks for), cpu_baseline (oracle/c, kind "port", N = 1 only), config3 / config5 (the other single-GPU
+BASELINE configs, measured after the timed region with the prover released).
 """
 import argparse
+import collections
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -30,42 +37,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before torch / HIP initialise: see zerokit_amd/csrc/common.cpp
 
-R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
-MASK = (1 << 64) - 1
-# SURVEY.md §8(d): per-proof algorithmic bytes
+# SURVEY.md 8(d): per-proof algorithmic bytes
 BYTES_PER_PROOF = 7468404
 MSM_G1_BYTES_PER_PROOF = (5844 + 5844 + 8192 + 5838) * 96   # A, B1, H, L operands (point 64 B + scalar 32 B)
+CONFIG3_BYTES = 792723424
 HBM_PEAK_GBPS = 8000.0
+VALU_PEAK_GINST_NOMINAL = 1024 * 2.4e9 / 4 / 1e9            # 1024 SIMDs, one VALU instruction per 4 cycles, 2.4 GHz
+STREAM_WRAP = 64                                            # distinct batches kept in host memory
+SHARD = 8192                                                # config 4: proofs per GPU
 
 
-class SplitMix64:
-    def __init__(self, seed):
-        self.s = seed & MASK
-
-    def next(self):
-        self.s = (self.s + 0x9E3779B97F4A7C15) & MASK
-        z = self.s
-        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK
-        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK
-        return z ^ (z >> 31)
-
-    def fr(self):
-        v = 0
-        for i in range(4):
-            v |= self.next() << (64 * i)
-        return v % R
-
-
-def config2_witnesses(n, seed=0xC0FFEE, depth=20):
-    g = SplitMix64(seed)
-    ws, rs = [], []
-    for i in range(n):
-        ws.append(dict(identity_secret=g.fr(), user_message_limit=100, message_id=i % 100,
-                       path_elements=[g.fr() for _ in range(depth)],
-                       identity_path_index=[g.next() & 1 for _ in range(depth)], x=g.fr(),
-                       external_nullifier=g.fr()))
-        rs.append((g.fr(), g.fr()))
-    return ws, rs
+def walk_source_hash():
+    """identifies the code the table walks are compiled from; the PMC passes under profiles/ record it, and the VALU
+    view is only emitted when it matches (an instruction count belongs to one build)"""
+    h = hashlib.sha256()
+    for f in ("walk29.h", "fq29.h", "fq29_constants.h", "curve.h", "glv.h"):
+        h.update(open(os.path.join(ROOT, "zerokit_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(ws, rs, target_seconds=12.0):
@@ -81,61 +69,113 @@ def cpu_baseline(ws, rs, target_seconds=12.0):
         return {"error": str(e)}
 
 
-def valu_view(prover, B, alone_ms, clock_mhz):
-    """VALU side of the roofline for the G1 walk: instructions per launch from the committed PMC pass (they scale with
-    the number of additions), rate = instructions / duration of a launch with nothing else in flight"""
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_walks.json")))["kernels"]["k_msm29<G1>"]
-        per_wave_add = pm["SQ_INSTS_VALU"] / (pm["lane_additions_per_launch"] / 64)
-    except Exception:  # noqa: BLE001
+def load_pmc(info, B):
+    """the committed PMC passes of the walks, if they were taken on this schedule and this build of the walk"""
+    for name in ("r3_pmc_walks.json", "r2_pmc_walks.json"):
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:  # noqa: BLE001
+            continue
+        sched = pm.get("schedule")
+        if not sched or pm.get("walk_source_hash") != walk_source_hash():
+            continue
+        if (sched.get("window_bits"), sched.get("windows"), sched.get("window_bits_g2"), sched.get("windows_g2"),
+                sched.get("glv"), sched.get("batch")) != (int(info.window_bits), int(info.windows),
+                                                          int(info.window_bits_g2), int(info.windows_g2),
+                                                          int(info.glv), B):
+            continue
+        pm["_file"] = "profiles/" + name
+        return pm
+    return None
+
+
+def valu_view(pm, info, B, alone_ms, clock_mhz):
+    """VALU side of the roofline for the G1 walk: wave-instructions of one launch (PMC SQ_INSTS_VALU of the same build
+    and schedule) over the launch by itself, against 1024 SIMDs x clock / 4"""
+    if pm is None or alone_ms <= 0:
         return None
-    adds = int(prover.info.g1_rows) * int(prover.info.windows) * B
-    insts = per_wave_add * adds / 64
-    if alone_ms <= 0:
-        return None
+    k = pm["kernels"]["k_msm29<G1>"]
+    per_wave_add = k["SQ_INSTS_VALU"] / (k["lane_additions_per_launch"] / 64)
+    insts = per_wave_add * int(info.g1_rows) * int(info.windows) * B / 64
     rate = insts / (alone_ms * 1e-3) / 1e9
-    peak_nominal = 1024 * 2.4e9 / 4 / 1e9
-    out = {"valu_insts_per_wave_addition": round(per_wave_add, 1), "valu_insts_per_launch_G": round(insts / 1e9, 3),
-           "achieved_Ginst_per_s": round(rate, 1), "peak_Ginst_per_s_at_2400MHz": round(peak_nominal, 1),
-           "frac_of_nominal_clock_peak": round(rate / peak_nominal, 4)}
+    out = {"source": pm["_file"], "valu_insts_per_wave_addition": round(per_wave_add, 1),
+           "valu_insts_per_launch_G": round(insts / 1e9, 3), "achieved_Ginst_per_s": round(rate, 1),
+           "peak_Ginst_per_s_at_2400MHz": round(VALU_PEAK_GINST_NOMINAL, 1),
+           "frac_of_nominal_clock_peak": round(rate / VALU_PEAK_GINST_NOMINAL, 4)}
     if clock_mhz > 0:
         out["clock_mhz"] = round(clock_mhz, 1)
         out["frac_of_peak_at_measured_clock"] = round(rate / (1024 * clock_mhz * 1e6 / 4 / 1e9), 4)
     return out
 
 
-def prover_alone_ms(prover):
-    """msm_g1 span of the batch that just ran alone (run() = one batch, pipeline drained)"""
-    return prover.stage_ms().get("msm_g1", 0.0)
-
-
-def merkle_main(args):
-    """BASELINE config 3: build a 2^20-leaf Poseidon tree (leaves i+1 generated in HBM) and emit all 2^20
-    membership paths into HBM; algorithmic bytes 792 723 424.  Side measurement, one JSON line."""
+def measure_config3(steps=3):
+    """BASELINE config 3 on this GPU: 2^20-leaf build + 2^20 membership paths, every path recomputed on device"""
     from zerokit_amd.batch import PoseidonTree
     depth, n = 20, 1 << 20
     t = PoseidonTree(depth)
-    t.bench(n, 1, verify=False)   # warm-up
-    build, paths = [], []
-    for _ in range(max(args.steps, 1)):
-        r = t.bench(n, 1, verify=False)
-        build.append(r["build_ms"])
-        paths.append(r["proofs_ms"])
-    bad = t.bench(n, 1, verify=True)["bad"]
-    b, p = sum(build) / len(build), sum(paths) / len(paths)
+    try:
+        t.bench(n, 1, verify=False)
+        rs = [t.bench(n, 1, verify=False) for _ in range(steps)]
+        bad = t.bench(n, 1, verify=True)["bad"]
+    finally:
+        t.close()
+    b = sum(r["build_ms"] for r in rs) / len(rs)
+    p = sum(r["proofs_ms"] for r in rs) / len(rs)
     path_bytes = n * (depth * 32 + depth)
-    print(json.dumps({
-        "metric": "Poseidon Merkle: 2^20-leaf build + 2^20 membership paths (config 3)", "unit": "ms",
-        "build_ms": round(b, 3), "paths_ms": round(p, 3), "hashes_per_s": round((n - 1) / (b * 1e-3), 1),
-        "paths_failed_device_verification": bad,
-        "achieved_GBps_config3": round(792723424 / ((b + p) * 1e-3) / 1e9, 2),
-        "roofline_paths": {"bound": "hbm", "achieved": round(path_bytes / (p * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS,
-                           "unit": "GB/s", "frac": round(path_bytes / (p * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}}))
+    return {"workload": "config 3: 2^20-leaf Poseidon tree build + 2^20 membership paths", "build_ms": round(b, 3),
+            "paths_ms": round(p, 3), "hashes_per_s": round((n - 1) / (b * 1e-3), 1),
+            "achieved_GBps": round(CONFIG3_BYTES / ((b + p) * 1e-3) / 1e9, 2),
+            "correct": bad == 0, "paths_failed_device_verification": bad,
+            "roofline": {"bound": "hbm", "kernel": "k_proofs_canon (path emission)",
+                         "achieved": round(path_bytes / (p * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(path_bytes / (p * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}}
+
+
+def measure_config5(comm, rank, world, steps=3, log2n=24):
+    """BASELINE config 5: one 2^24-point G1 MSM split by point index over the ranks of `comm`; local Pippenger to the
+    window sums, ncclAllGather through the C ABI, local fold; compared with the scalar-side closed form"""
+    from zerokit_amd.batch import MsmG1
+    from zerokit_amd.distributed import shard_bounds
+    n_total = 1 << log2n
+    lo, hi = shard_bounds(n_total, world)[rank]
+    m = MsmG1(hi - lo)
+    try:
+        m.generate(0xC0FFEE, lo, hi - lo)
+        m.run_sharded(comm)
+        times, st = [], {}
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            res, st = m.run_sharded(comm)
+            times.append(time.perf_counter() - t0)
+    finally:
+        m.close()
+    ms = sum(times) / len(times) * 1e3
+    gbps = n_total * 96 / (ms * 1e-3) / 1e9
+    ok = res == MsmG1.expected(0xC0FFEE, 0, n_total) if rank == 0 else True
+    return {"workload": "config 5: single 2^%d-point BN254 G1 MSM, %d-way split, ncclAllGather of window sums"
+                        % (log2n, world),
+            "ms": round(ms, 3), "rccl_ranks": comm.ranks(), "correct": bool(ok),
+            "stage_ms_rank0": {k: round(v, 3) for k, v in st.items()},
+            "roofline": {"bound": "valu", "hbm_view": {"achieved": round(gbps, 2), "peak": HBM_PEAK_GBPS * world,
+                                                        "unit": "GB/s",
+                                                        "frac": round(gbps / (HBM_PEAK_GBPS * world), 5)}}}
+
+
+def merkle_main(args):
+    print(json.dumps(measure_config3(max(args.steps, 1))))
+
+
+def make_comm(rank, world, dist):
+    """an RCCL communicator created through the C ABI; the 128-byte id travels over torch.distributed (plumbing)"""
+    from zerokit_amd.batch import Comm
+    uid = [Comm.unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(uid, src=0)
+    return Comm.init_rank(uid[0], world, rank)
 
 
 def msm_main(args):
-    """BASELINE config 5: one 2^24-point G1 MSM split by point index over the ranks (1 rank = whole MSM on one
-    GPU), one RCCL all_gather of the per-window sums, local fold.  Side measurement, one JSON line on rank 0."""
+    """config 5 by itself (side measurement, one JSON line on rank 0)"""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,43 +184,79 @@ def msm_main(args):
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     from zerokit_amd import lib
     from zerokit_amd._native import check
-    from zerokit_amd.batch import MsmG1
-    from zerokit_amd.distributed import all_gather_bytes, shard_bounds
     check(lib().rlnamd_set_device(local_rank))
-    n_total = 1 << int(os.environ.get("RLNAMD_MSM_LOG2", "24"))
-    lo, hi = shard_bounds(n_total, world)[rank]
-    m = MsmG1(hi - lo)
-    m.generate(0xC0FFEE, lo, hi - lo)          # bases + scalars resident in HBM, not timed
-    times, stage = [], {}
-    for it in range(args.warmup + max(args.steps, 1)):
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        blob, stage = m.run_windows()
-        blobs = all_gather_bytes(blob, device="cuda")
-        res = m.combine(blobs)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        if it >= args.warmup:
-            times.append(dt)
+    comm = make_comm(rank, world, dist)
+    out = measure_config5(comm, rank, world, max(args.steps, 1), int(os.environ.get("RLNAMD_MSM_LOG2", "24")))
+    comm.close()
     if rank == 0:
-        ok = res == MsmG1.expected(0xC0FFEE, 0, n_total)
-        ms = sum(times) / len(times) * 1e3
-        gbps = n_total * 96 / (ms * 1e-3) / 1e9
-        print(json.dumps({"metric": "single 2^%d-point BN254 G1 MSM (config 5)" % (n_total.bit_length() - 1),
-                          "ms": round(ms, 3), "n_gpus": world, "correct": bool(ok), "stage_ms_rank0": stage,
-                          "roofline": {"bound": "hbm", "achieved": round(gbps, 2), "peak": HBM_PEAK_GBPS * world,
-                                       "unit": "GB/s", "frac": round(gbps / (HBM_PEAK_GBPS * world), 5)}}))
+        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def open_prover(B, factory):
+    """GLV comb schedule g1 + 10000 * g2 over the 127-bit scalar halves: 114 = 15 + 8 x 14 bits (9 windows, 18 additions
+    per G1 point), 715 = 7 x 16 + 15 bits (8 windows, 16 additions per G2 point): 228 GiB of fixed-base tables, sized for
+    288 GB of HBM.  Smaller tables are tried if that does not fit."""
+    wbits = int(os.environ.get("RLNAMD_WINDOW_BITS", "7150114"))
+    for wb in dict.fromkeys([wbits, 114, 13, 12, 10]):
+        try:
+            return factory(wb)
+        except Exception as e:  # noqa: BLE001
+            print("bench: window schedule %d not available (%s)" % (wb, e), file=sys.stderr)
+    raise SystemExit("bench: no table size fits this device")
+
+
+def pool_main(args):
+    """plain `python bench.py --gpus N` (no torchrun): one process, N devices, rlnamd_pool"""
+    from zerokit_amd import lib, workload
+    from zerokit_amd.batch import BatchProver, ProverPool
+    N = args.gpus
+    have = lib().rlnamd_device_count()
+    if have < N:
+        raise SystemExit("bench: --gpus %d but %d device(s) visible; refusing to run a smaller job" % (N, have))
+    B = args.batch
+    t0 = time.time()
+    pool = open_prover(B, lambda wb: ProverPool(devices=list(range(N)), max_batch=B, window_bits=wb))
+    init_s = time.time() - t0
+    # input slots come from the graph; any single prover knows them -- read them from a tiny one on device 0
+    probe = BatchProver(max_batch=64, window_bits=8)
+    slots, ni = dict(probe.slots), probe.inputs_size
+    probe.close()
+    n = SHARD * N
+    inputs, rsb = workload.config2_packed(slots, ni, 0, n)
+    for _ in range(args.warmup):
+        pool.prove_raw(inputs, rsb)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        proofs, values, errs = pool.prove_raw(inputs, rsb)
+    elapsed = time.perf_counter() - t0
+    idx = list(range(0, n, 509))
+    pub = [[int.from_bytes(values[160 * i + 32 * k:160 * i + 32 * k + 32], "little") for k in range(5)] for i in idx]
+    ok = not any(errs) and all(pool.verify_many([proofs[128 * i:128 * i + 128] for i in idx], pub))
+    value = n * args.steps / elapsed
+    name = C.create_string_buffer(128)
+    lib().rlnamd_device_name(name, 128)
+    print(json.dumps({
+        "metric": "RLN Groth16 proofs/sec (BN254, h=20)", "value": round(value, 2), "unit": "proofs/s", "n_gpus": N,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32 limbs (256-bit Montgomery integers, BN254 Fr/Fq; 8x32 and 9x29 forms)",
+        "data": "synthetic (SplitMix64 0xC0FFEE witnesses, shipped depth-20 arkzkey + graph)",
+        "config": {"workload": "config 4: %d proofs as %d contiguous shards of %d, one process driving %d devices "
+                               "through rlnamd_pool; H2D of inputs and D2H of proofs inside the timed region" % (n, N, SHARD, N),
+                   "batch_per_gpu": SHARD, "chunk": B, "parallelism": "proof-sharded x%d (rlnamd_pool), no collective" % N,
+                   "window_bits": int(pool.info.window_bits), "windows": int(pool.info.windows),
+                   "table_gib": round(pool.info.table_bytes / 2**30, 2), "device": name.value.decode(),
+                   "init_s": round(init_s, 2), "verified": bool(ok), "verified_sample": len(idx)},
+        "achieved_GBps_whole_proof": round(value * BYTES_PER_PROOF / 1e9, 3),
+        "replica_ms_last_step": [round(x, 2) for x in pool.last_ms()]}))
+    pool.close()
+    if not ok:
+        sys.exit(3)
 
 
 def main():
@@ -190,28 +266,34 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("RLNAMD_BENCH_BATCH", "1024")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-configs", action="store_true", help="skip the config3 / config5 objects")
     ap.add_argument("--workload", default="proofs", choices=["proofs", "merkle", "msm", "finish"],
-                    help="proofs = BASELINE metric (default); merkle = config 3 side measurement (not the bench line)")
+                    help="proofs = BASELINE metric (default); merkle / msm / finish = side measurements")
     args = ap.parse_args()
     if args.workload == "merkle":
         return merkle_main(args)
     if args.workload == "msm":
         return msm_main(args)
 
+    under_torchrun = "WORLD_SIZE" in os.environ
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if under_torchrun and world != args.gpus:
+        raise SystemExit("bench: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not under_torchrun and args.gpus > 1:
+        return pool_main(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
 
     import torch  # plumbing only: device selection, barrier, max-reduce
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    use_dist = world > 1 or "RANK" in os.environ          # under torchrun the RCCL group is always created
+    use_dist = under_torchrun                              # under torchrun the RCCL group is always created
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from zerokit_amd import lib
+    from zerokit_amd import lib, workload
     from zerokit_amd._native import check
     from zerokit_amd.batch import BatchProver
     check(lib().rlnamd_set_device(local_rank))
@@ -219,50 +301,59 @@ def main():
     lib().rlnamd_device_name(name, 128)
 
     B = args.batch
+    finish = args.workload == "finish"
     t0 = time.time()
-    # GLV comb schedule g1 + 10000 * g2 over the 127-bit scalar halves: 114 = 15 + 8 x 14 bits (9 windows, 18 additions
-    # per G1 point), 715 = 7 x 16 + 15 bits (8 windows, 16 additions per G2 point): 228 GiB of fixed-base tables, sized for
-    # 288 GB of HBM.  Smaller tables are tried if that does not fit (RLNAMD_GLV=0 + 813: the round-1 19-window walk).
-    wbits = int(os.environ.get("RLNAMD_WINDOW_BITS", "7150114"))
-    prover = None
-    for wb in dict.fromkeys([wbits, 114, 13, 12, 10]):   # a box with less free HBM still runs: smaller tables
-        try:
-            prover = BatchProver(max_batch=B, window_bits=wb)
-            break
-        except Exception as e:  # noqa: BLE001
-            print("bench: window schedule %d not available (%s)" % (wb, e), file=sys.stderr)
-    if prover is None:
-        raise SystemExit("bench: no table size fits this device")
+    prover = open_prover(B, lambda wb: BatchProver(max_batch=B, window_bits=wb))
     init_s = time.time() - t0
-    ws, rs = config2_witnesses(B, seed=0xC0FFEE + rank)   # every rank proves a different shard
-    inputs = prover.pack_inputs(ws)
-    n = prover.upload(inputs, rs)                          # resident in HBM before the timed region
+    nslots = prover.n_slots()
+
+    # ---- the witness stream of this rank, packed on the host before the timed region
+    if world == 1:
+        per_step = 1                                                   # batches per step
+        nbatches = min(max(args.steps, 1), STREAM_WRAP)
+        first = 0
+    else:
+        per_step = SHARD // B                                          # config 4: the rank's 8 192-proof shard
+        nbatches = per_step
+        first = SHARD * rank
+    batches = [workload.config2_packed(prover.slots, prover.inputs_size, first + B * k, B) for k in range(nbatches)]
+    partials = None
+    if finish:
+        # side measurement (SURVEY 8f-2): partial proofs of the members computed once, then only
+        # finish_zk_proof_with_rs per message (protocol/proof.rs:783-849)
+        partials = []
+        for k in range(nbatches):
+            ws, _ = workload.config2_range(first + B * k, B)
+            partials.append(prover.prove_partial([{q: w[q] for q in ("identity_secret", "user_message_limit",
+                                                                       "path_elements", "identity_path_index")} for w in ws]))
 
     def sync():
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
 
-    finish = args.workload == "finish"
-    if finish:
-        # side measurement (SURVEY §8f-2): partial proofs of the members computed once, then only
-        # finish_zk_proof_with_rs per message (protocol/proof.rs:783-849)
-        partials = prover.prove_partial([{k: w[k] for k in ("identity_secret", "user_message_limit", "path_elements",
-                                                             "identity_path_index")} for w in ws])
-        n = prover.upload(inputs, rs)
-        prover.upload_partial(partials)
-    for _ in range(args.warmup):
-        prover.run_async_mode(n, 2) if finish else prover.run(n)
+    results = {}                      # batch index -> (proofs, values, errors) of its LAST pass
+    inflight = collections.deque()
+
+    def pump(total_batches):
+        for j in range(total_batches):
+            k = j % nbatches
+            if len(inflight) == nslots:
+                t, kk = inflight.popleft()
+                results[kk] = prover.collect_raw(t, B)
+            t, _ = prover.submit(batches[k][0], batches[k][1], 2 if finish else 0, partials[k] if finish else None)
+            inflight.append((t, k))
+        while inflight:
+            t, kk = inflight.popleft()
+            results[kk] = prover.collect_raw(t, B)
+
+    pump(args.warmup * per_step)
     prover.sync()
-    prover.walk_clock_mhz()   # reset the clock tap: what follows is the timed region's clock
+    prover.walk_clock_mhz()           # reset the clock tap: what follows is the timed region's clock
+    results.clear()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        if finish:
-            prover.run_async_mode(n, 2)
-        else:
-            prover.run_async(n)  # batches pipeline on the device; each ends with proofs in pinned host memory
-    prover.sync()
+    pump(args.steps * per_step)       # H2D of every batch's inputs ... D2H of its proofs, all inside
     sync()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -270,34 +361,92 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # correctness spot check outside the timed region: first and last proof of the batch verify
-    out = prover.download(n)
-    ok = all(o["error"] == 0 for o in out) and prover.verify(out[0]["proof"], out[0]["public_inputs"]) and \
-        prover.verify(out[-1]["proof"], out[-1]["public_inputs"])
+    # ---- correctness outside the timed region: no error flags; first / last / middle proof of EVERY distinct batch
+    #      of the timed region verifies on the host (rlnamd_verify_many)
+    vp, vv = [], []
+    ok = len(results) == min(nbatches, args.steps * per_step) or args.steps == 0
+    for k, (proofs, values, errs) in sorted(results.items()):
+        ok = ok and not any(errs)
+        for i in (0, B // 2, B - 1):
+            vp.append(proofs[128 * i:128 * i + 128])
+            vv.append([int.from_bytes(values[160 * i + 32 * q:160 * i + 32 * q + 32], "little") for q in range(5)])
+    ok = bool(ok and (all(prover.verify_many(vp, vv)) if vp else True))
+    # distinct inputs give distinct proofs: the stream really was K different batches
+    distinct = len({r[0][:128] for r in results.values()}) == len(results)
 
     clock_mhz = prover.walk_clock_mhz()   # mean shader clock under the two walks over the timed region
-    stage_ms = prover.stage_ms()   # HIP-event spans, mean over the last five launches (overlapped with their neighbours)
+    stage_ms = prover.stage_ms()          # HIP-event spans, mean over the last five launches (overlapped with their neighbours)
     # the dominant kernel by itself: single batches with nothing else in flight (outside the timed region)
     alone = []
-    for _ in range(3):
-        prover.run(n)
-        alone.append(prover_alone_ms(prover))
-    g1_alone_ms = sorted(alone)[1] if not finish else 0.0
+    ws0, rs0 = workload.config2_range(first, B)
+    if not finish:
+        prover.upload(batches[0][0], rs0)
+        for _ in range(3):
+            prover.run(B)
+            alone.append(prover.stage_ms().get("msm_g1", 0.0))
+    g1_alone_ms = sorted(alone)[1] if alone else 0.0
     clock_alone_mhz = prover.walk_clock_mhz()
+    info = prover.info
+    g1_adds = int(info.g1_rows) * int(info.windows) * B
+    prover.close()
+
+    # ---- the other single-GPU BASELINE configs, with the prover's HBM released
+    side = {}
+    if not args.no_side_configs and not finish:
+        comm = None
+        try:
+            if world == 1:
+                side["config3"] = measure_config3()
+            comm = make_comm(rank, world, dist)
+            side["config5"] = measure_config5(comm, rank, world)
+        except Exception as e:  # noqa: BLE001
+            side["side_config_error"] = str(e)
+        finally:
+            if comm is not None:
+                comm.close()
+
     if rank == 0:
         steps = max(args.steps, 1)
-        proofs = world * B * args.steps
-        value = proofs / elapsed
+        proofs_total = world * B * per_step * args.steps
+        value = proofs_total / elapsed
         msm_ms = stage_ms.get("msm_g1", 0.0)
-        achieved = (MSM_G1_BYTES_PER_PROOF * B) / (msm_ms * 1e-3) / 1e9 if msm_ms > 0 else 0.0
-        traffic = None   # HBM bytes per launch of the dominant kernel, from the committed PMC passes
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_k_msm_g1.json")))
-            if B == 1024 and int(prover.info.window_bits) == pm.get("window_bits") and \
-                    int(prover.info.windows) == pm.get("windows"):
-                traffic = round(pm["traffic_bytes_per_launch"] / 1e9, 3)
-        except Exception:  # noqa: BLE001
-            pass
+        hbm_achieved = (MSM_G1_BYTES_PER_PROOF * B) / (msm_ms * 1e-3) / 1e9 if msm_ms > 0 else 0.0
+        pm = load_pmc(info, B)
+        valu = valu_view(pm, info, B, g1_alone_ms, clock_alone_mhz.get("g1_walk", 0.0))
+        traffic = round(pm["kernels"]["k_msm29<G1>"]["traffic_bytes_per_launch"] / 1e9, 3) \
+            if pm and "traffic_bytes_per_launch" in pm["kernels"]["k_msm29<G1>"] else None
+        # roofline of the dominant kernel.  The bound that binds is VALU issue ("integer-ALU bound ... report
+        # VALU utilisation alongside"): achieved = wave-instructions/s of the launch in the timed region, peak = 1024
+        # SIMDs x 2.4 GHz / 4.  The HBM view BASELINE.json asks for is kept beside it.
+        if valu:
+            insts = valu["valu_insts_per_launch_G"]
+            ach = insts / (msm_ms * 1e-3) if msm_ms > 0 else 0.0
+            roof = {"bound": "valu", "kernel": "k_msm29<G1> (G1 fixed-base table MSM, 9 x 29-bit limbs)",
+                    "achieved": round(ach, 1), "peak": round(VALU_PEAK_GINST_NOMINAL, 1), "unit": "Ginst/s",
+                    "frac": round(ach / VALU_PEAK_GINST_NOMINAL, 4), "traffic": traffic}
+        else:
+            roof = {"bound": "hbm", "kernel": "k_msm29<G1> (G1 fixed-base table MSM, 9 x 29-bit limbs)",
+                    "achieved": round(hbm_achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(hbm_achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
+                    "valu_view_omitted": "no PMC pass under profiles/ matches this schedule and this build of the walk "
+                                         "(walk_source_hash %s)" % walk_source_hash()}
+        roof.update({
+            "traffic_unit": "GB per launch (2*FETCH_SIZE + WRITE_SIZE, PMC pass of the same build)",
+            "launch_ms": round(msm_ms, 3), "launch_ms_alone": round(g1_alone_ms, 3),
+            "hbm_view": {"achieved": round(hbm_achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(hbm_achieved / HBM_PEAK_GBPS, 6),
+                         "algorithmic_bytes_per_launch": MSM_G1_BYTES_PER_PROOF * B,
+                         # what the table-walk algorithm itself reads: one 64-byte entry per mixed addition
+                         "table_walk_gb_per_launch": round(g1_adds * 64 / 1e9, 3),
+                         "table_walk_GBps_alone": round(g1_adds * 64 / (g1_alone_ms * 1e-3) / 1e9, 1) if g1_alone_ms > 0 else None},
+            "madd_per_s": round(g1_adds / (msm_ms * 1e-3) / 1e9, 2) if msm_ms > 0 else None,
+            "madd_per_s_alone": round(g1_adds / (g1_alone_ms * 1e-3) / 1e9, 2) if g1_alone_ms > 0 else None,
+            "valu": valu,
+            "note": "launch_ms = mean HIP-event span of the last five launches of the timed region on the kernel's own "
+                    "stream (it shares the SIMDs with the G2 walk of the neighbouring batch; launch_ms_alone: nothing else in "
+                    "flight).  VALU-issue bound: one mixed addition is ~2 000 VALU instructions and the SIMDs issue one per 4 "
+                    "cycles for the whole launch (valu.frac_of_peak_at_measured_clock ~ 1); what is left is the clock the "
+                    "power management holds under this instruction mix (shader_clock_mhz; 2.4 GHz nominal).  See DESIGN.md 4"})
         line = {
             "metric": "RLN Groth16 proofs/sec (BN254, h=20)" + (" -- finish_rln_proof from cached partial proofs "
                                                                  "(side measurement)" if finish else ""),
@@ -312,53 +461,34 @@ def main():
             "vs_baseline": None,
             "dtype": "u32 limbs (256-bit Montgomery integers, BN254 Fr/Fq; 8x32 and 9x29 forms)",
             "data": "synthetic (SplitMix64 0xC0FFEE witnesses, shipped depth-20 arkzkey + graph)",
-            "config": {"workload": "config 2: batch of %d independent RLN proofs per GPU, tree_height=20, "
-                                   "inputs resident in HBM" % B,
-                       "batch_per_gpu": B, "parallelism": "proof-sharded x%d, no collective" % world,
-                       "glv": bool(prover.info.glv),
-                       "window_bits": int(prover.info.window_bits), "windows": int(prover.info.windows),
-                       "window_bits_g2": int(prover.info.window_bits_g2), "windows_g2": int(prover.info.windows_g2),
-                       "table_gib": round(prover.info.table_bytes / 2**30, 2),
-                       "device": name.value.decode(), "init_s": round(init_s, 2), "verified": bool(ok)},
+            "config": {"workload": ("config 2: %d DISTINCT batches of %d independent RLN proofs, tree_height=20; H2D of the "
+                                    "witness inputs and D2H of proofs + values inside the timed region, %d workspace slots "
+                                    "in flight" % (nbatches, B, nslots)) if world == 1 else
+                                   ("config 4: %d proofs as %d contiguous shards of %d (one process per GPU), %d chunks of "
+                                    "%d per step uploaded again every step; H2D and D2H inside the timed region"
+                                    % (SHARD * world, world, SHARD, per_step, B)),
+                       "batch_per_gpu": B * per_step, "chunk": B,
+                       "parallelism": "proof-sharded x%d, no data-path collective" % world,
+                       "glv": bool(info.glv),
+                       "window_bits": int(info.window_bits), "windows": int(info.windows),
+                       "window_bits_g2": int(info.window_bits_g2), "windows_g2": int(info.windows_g2),
+                       "table_gib": round(info.table_bytes / 2**30, 2),
+                       "device": name.value.decode(), "init_s": round(init_s, 2), "verified": ok,
+                       "verified_proofs": len(vp), "distinct_batches_gave_distinct_proofs": bool(distinct)},
             "achieved_GBps_whole_proof": round(value * BYTES_PER_PROOF / 1e9, 3),
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             # the walks are VALU-issue bound: additions/s = SIMDs x 64 x clock / (4 x instructions per addition), so
             # the clock the power management holds is part of the result (2.4 GHz nominal)
             "shader_clock_mhz": {"timed_region": {k: round(v, 1) for k, v in clock_mhz.items()},
                                  "walks_alone": {k: round(v, 1) for k, v in clock_alone_mhz.items()}},
-            "roofline": {"bound": "hbm", "kernel": "k_msm29<G1> (G1 fixed-base table MSM, 9 x 29-bit limbs)",
-                         "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
-                         "traffic_unit": "GB per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r2_pmc_k_msm_g1.json)",
-                         "launch_ms": round(msm_ms, 3), "launch_ms_alone": round(g1_alone_ms, 3),
-                         # what the table-walk algorithm itself must read: one 64-byte entry per mixed addition
-                         "table_walk_gb_per_launch": round(int(prover.info.g1_rows) * int(prover.info.windows) * B * 64 / 1e9, 3),
-                         "table_walk_GBps_alone": round(int(prover.info.g1_rows) * int(prover.info.windows) * B * 64 / (g1_alone_ms * 1e-3) / 1e9, 1)
-                         if g1_alone_ms > 0 else None,
-                         "madd_per_s": round(int(prover.info.g1_rows) * int(prover.info.windows) * B / (msm_ms * 1e-3) / 1e9, 2) if msm_ms > 0 else None,
-                         "madd_per_s_alone": round(int(prover.info.g1_rows) * int(prover.info.windows) * B / (g1_alone_ms * 1e-3) / 1e9, 2)
-                         if g1_alone_ms > 0 else None,
-                         # the bound that actually binds ("expect HBM-fraction << 1 and report VALU utilisation
-                         # alongside"): VALU wave-instructions of one launch (PMC SQ_INSTS_VALU, profiles/r2_pmc_walks.json)
-                         # over the launch by itself, against 1024 SIMDs x clock / 4 cycles per instruction
-                         "valu": valu_view(prover, B, g1_alone_ms, clock_alone_mhz.get("g1_walk", 0.0)),
-                         "note": "launch_ms = mean HIP-event span of the last five launches of the timed region, on the "
-                                 "kernel's stream; the G1 and G2 walks of neighbouring batches run on two streams and share "
-                                 "the SIMDs, so the span includes that sharing (launch_ms_alone: the same launch with nothing "
-                                 "else in flight).  VALU-issue bound, not HBM bound: one mixed addition is ~2 020 VALU instructions "
-                                 "(1 467 v_mad_u64_u32 of the field products) and the SIMDs issue one per 4 cycles for the whole "
-                                 "launch (roofline.valu: fraction of the issue rate at the measured clock ~ 1); what is left is the "
-                                 "clock, which the power management holds near 1.85 - 1.95 GHz under this instruction mix plus "
-                                 "the table gathers (shader_clock_mhz; 2.4 GHz nominal).  madd_per_s / madd_per_s_alone are "
-                                 "G additions/s; traffic: FETCH_SIZE doubled as the guide prescribes for 128-byte requests "
-                                 "(calibrated on the G2 walk's 128-byte entries and on the NTT streams); the G1 walk's "
-                                 "64-byte gathers may be 64-byte requests, in which case the traffic is half of it; "
-                                 "see DESIGN.md section 4"},
+            "roofline": roof,
         }
+        line.update(side)
+        if "config5" in side:
+            line["rccl_ranks"] = side["config5"]["rccl_ranks"]
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(ws, rs)
+            line["cpu_baseline"] = cpu_baseline(ws0, rs0)
         print(json.dumps(line))
-    prover.close()
     if use_dist:
         dist.destroy_process_group()
     if not ok:

@@ -97,6 +97,24 @@ int rlnamd_prover_sync(rlnamd_prover* p);
  * values: n*160 (y, root, nullifier, x, external_nullifier) or NULL, errors: n*4 or NULL */
 int rlnamd_prover_download(rlnamd_prover* p, size_t n, uint8_t* proofs, uint8_t* coords, uint8_t* values,
                            uint32_t* errors);
+/* ---- streamed batches: the path of SURVEY 8(d)'s timed region, "H2D of witness inputs -> D2H of proofs".  The reference
+ * takes a fresh witness per call (rln/src/protocol/proof.rs:753-777, public.rs:624-631); rlnamd_prover_submit is n such
+ * calls at once: it stages the inputs (n * inputs_size * 32 bytes), rs (n * 64) and, in RLNAMD_MODE_FINISH, the partial
+ * points (n * 320, else NULL) in pinned memory owned by a workspace slot, copies them to that slot's own device buffers
+ * on the batch's front-end stream and enqueues the batch.  It returns at once with a ticket (> 0) unless all
+ * rlnamd_prover_slots() slots are in flight; consecutive submits of DIFFERENT batches overlap on the device exactly as
+ * run_async's do.  rlnamd_prover_collect waits for that batch only (any output pointer may be NULL; partial320 is the
+ * result of a RLNAMD_MODE_PARTIAL batch).  A ticket expires when its slot is reused, i.e. slots() submits later.
+ * rlnamd_prover_prove_stream = submit / collect over any n in chunks of `capacity`, results in index order. */
+int rlnamd_prover_slots(rlnamd_prover* p);
+int rlnamd_prover_submit(rlnamd_prover* p, size_t n, const uint8_t* inputs_le, const uint8_t* rs_le, int mode,
+                         const uint8_t* partial320, uint64_t* ticket);
+int rlnamd_prover_collect(rlnamd_prover* p, uint64_t ticket, size_t n, uint8_t* proofs, uint8_t* coords, uint8_t* values,
+                          uint32_t* errors, uint8_t* partial320);
+/* public signals w[1..num_instance) of a collected batch (n * num_public * 32 bytes), circuit-generic */
+int rlnamd_prover_collect_public(rlnamd_prover* p, uint64_t ticket, size_t n, uint8_t* out_le);
+int rlnamd_prover_prove_stream(rlnamd_prover* p, size_t n, const uint8_t* inputs_le, const uint8_t* rs_le,
+                               uint8_t* proofs, uint8_t* values, uint32_t* errors);
 int rlnamd_prover_stage_ms(rlnamd_prover* p, float ms[RLNAMD_PROVER_STAGES]);
 const char* rlnamd_prover_stage_name(int i);
 /* mean shader clock (MHz) under the G1 / G2 table walks since the previous call (the walks are VALU-issue bound: their
@@ -180,6 +198,49 @@ size_t rlnamd_msm_window_sums_bytes(void);
 /* ms[0] digits + counting sort, ms[1] bucket accumulation, ms[2] bucket reduction */
 int rlnamd_msm_run(rlnamd_msm* m, uint8_t* window_sums, float ms[3]);
 int rlnamd_msm_combine(rlnamd_msm* m, const uint8_t* window_sums, size_t contributors, uint8_t out_xy_le[64]);
+
+
+/* ---- multi-GPU (BASELINE configs 4 and 5) -----------------------------------------------------
+ * rlnamd_pool: one prover replica and one host thread per device of THIS process.  rlnamd_pool_prove cuts n proofs
+ * into contiguous index shards, one per replica (config 4: 65 536 proofs = 8 x 8 192), each replica streams its shard
+ * (rlnamd_prover_prove_stream) and writes its results at their index: proofs n * 128, values n * 160, errors n * 4
+ * (any may be NULL).  No data-path collective -- the proofs are independent (the reference's guidance is one worker per
+ * proof, rln/README.md:324-332).  devices = NULL / n_devices = 0: every visible device.  An ordinal may repeat (two
+ * replicas sharing one device, for tests on a 1-GPU box). */
+typedef struct rlnamd_pool rlnamd_pool;
+int rlnamd_pool_new(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_t graph_len, size_t max_batch,
+                    int window_bits, const int* devices, size_t n_devices, rlnamd_pool** out);
+void rlnamd_pool_free(rlnamd_pool* p);
+size_t rlnamd_pool_size(rlnamd_pool* p);
+int rlnamd_pool_device(rlnamd_pool* p, size_t replica);
+int rlnamd_pool_get_info(rlnamd_pool* p, rlnamd_prover_info* info);
+int rlnamd_pool_prove(rlnamd_pool* p, size_t n, const uint8_t* inputs_le, const uint8_t* rs_le, uint8_t* proofs,
+                      uint8_t* values, uint32_t* errors);
+int rlnamd_pool_last_ms(rlnamd_pool* p, float* ms_per_replica);   /* host wall time of each replica's last shard */
+int rlnamd_pool_verify_many(rlnamd_pool* p, size_t n, const uint8_t* proofs, const uint8_t* values_le, size_t n_values,
+                            int threads, uint8_t* ok);
+/* RCCL communicator for the one path with an exchange step, the config-5 MSM.  Multi-process (one process per GPU,
+ * e.g. under torchrun): rank 0 calls rlnamd_comm_unique_id, the 128 bytes reach the other ranks by any means, every
+ * rank calls rlnamd_comm_init_rank with its device current.  Single process: rlnamd_comm_init_all fills one
+ * communicator per listed device (ncclCommInitAll; ordinals must differ). */
+#define RLNAMD_COMM_ID_BYTES 128
+typedef struct rlnamd_comm rlnamd_comm;
+int rlnamd_comm_unique_id(uint8_t id[RLNAMD_COMM_ID_BYTES]);
+int rlnamd_comm_init_rank(const uint8_t id[RLNAMD_COMM_ID_BYTES], int nranks, int rank, rlnamd_comm** out);
+int rlnamd_comm_init_all(const int* devices, size_t n_devices, rlnamd_comm** out_array);
+void rlnamd_comm_free(rlnamd_comm* c);
+int rlnamd_comm_rank(rlnamd_comm* c);
+int rlnamd_comm_ranks(rlnamd_comm* c);
+/* The whole of config 5 on one rank: local Pippenger on this rank's points down to the 16 window sums, ONE
+ * ncclAllGather of 2 KiB per rank over xGMI on the MSM's own stream (RCCL has no elliptic-curve reduce op: the
+ * "all-reduce of bucket partials" is gather + local add), then the add + Horner fold on every rank.  Collective: every
+ * rank of the communicator calls it.  ms[0] digits + sort, ms[1] buckets, ms[2] all-gather, ms[3] combine (HIP events). */
+int rlnamd_msm_run_sharded(rlnamd_msm* m, rlnamd_comm* c, uint8_t out_xy_le[64], float ms[4]);
+/* the same for a caller that owns several devices in one process: a thread per device, generated points
+ * (rlnamd_msm_generate at the rank's index range), `repeats` timed runs; ms[0..3] = max over devices of the stage times
+ * of the last run, ms[4] = its wall time */
+int rlnamd_msm_generated_multi(const int* devices, size_t n_devices, uint64_t seed, size_t n_total, int repeats,
+                               uint8_t out_xy_le[64], float ms[5]);
 
 #ifdef __cplusplus
 }

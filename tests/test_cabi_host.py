@@ -412,3 +412,24 @@ def test_python_mirrors_refuse_non_canonical_integers():
     assert batch._b(batch._Q - 1, batch._Q) == (batch._Q - 1).to_bytes(32, "little")
     with pytest.raises(_native.RLNError):
         batch._b(batch._Q, batch._Q)
+
+
+def test_vectorised_workload_generator_matches_the_oracle_generator():
+    """zerokit_amd/workload.py (numpy, index ranges; used by bench.py and the size tests) against the sequential
+    restatement in oracle/pyref/workload.py, including a range that starts inside the stream and the packed form"""
+    from oracle.pyref import workload as o
+    from zerokit_amd import workload as w
+    ws, rs = o.config2_witnesses(150)
+    assert w.config2_range(0, 150) == (ws, rs)
+    assert w.config2_range(97, 53) == (ws[97:], rs[97:])
+    slots = {"identitySecret": (1, 1), "userMessageLimit": (2, 1), "messageId": (3, 1), "pathElements": (4, 20),
+             "identityPathIndex": (24, 20), "x": (44, 1), "externalNullifier": (45, 1)}
+    inp, rsb = w.config2_packed(slots, 46, 97, 53)
+    assert len(inp) == 53 * 46 * 32 and len(rsb) == 53 * 64
+    for i in (0, 52):
+        row = [int.from_bytes(inp[(46 * i + k) * 32:(46 * i + k + 1) * 32], "little") for k in range(46)]
+        wi = ws[97 + i]
+        assert row == [1, wi["identity_secret"], 100, wi["message_id"]] + wi["path_elements"] + \
+            wi["identity_path_index"] + [wi["x"], wi["external_nullifier"]]
+        assert (int.from_bytes(rsb[64 * i:64 * i + 32], "little"),
+                int.from_bytes(rsb[64 * i + 32:64 * i + 64], "little")) == rs[97 + i]

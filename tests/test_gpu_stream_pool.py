@@ -1,0 +1,269 @@
+"""GPU tests of the round-3 paths, all through the C ABI (include/rln_amd.h):
+
+  * streamed batches (rlnamd_prover_submit / _collect): SURVEY 8(d)'s timed region, a fresh witness batch per call as
+    in /root/reference/rln/src/protocol/proof.rs:753-777;
+  * BASELINE config 2 at full size on the BENCH table schedule and config 4's 8 192-proof shard through the streaming
+    API (skipped only when the device cannot hold the 228 GiB tables);
+  * rlnamd_pool (native multi-GPU dispatcher) against a single prover, including two replicas sharing one device;
+  * the RCCL path of config 5 in C (rlnamd_comm_*, rlnamd_msm_run_sharded) and the torch.distributed harness with the
+    REAL device objects in two processes sharing the device (backend gloo).
+Bit-exact everywhere: no tolerances."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH_SCHEDULE = 7150114        # bench.py's comb schedule: G1 15 + 8 x 14 bits, G2 7 x 16 + 15 bits, 228 GiB
+
+
+def _oracle(ws, rs):
+    from oracle.c import binding as ob
+    _, proofs, pub = ob.Circuit(20).prove_many(ws, rs)
+    return proofs, pub
+
+
+def _split(proofs, values, n):
+    return ([proofs[128 * i:128 * i + 128] for i in range(n)],
+            [[int.from_bytes(values[160 * i + 32 * k:160 * i + 32 * k + 32], "little") for k in range(5)]
+             for i in range(n)])
+
+
+@pytest.fixture(scope="module")
+def prover():
+    from zerokit_amd.batch import BatchProver
+    p = BatchProver(max_batch=256)
+    yield p
+    p.close()
+
+
+def test_three_distinct_batches_back_to_back_without_sync(prover):
+    """three DIFFERENT batches of different sizes enqueued back to back (no sync, no collect in between) come out
+    bit-identical to oracle/c; then a fourth batch reuses the first slot after a wrap"""
+    from zerokit_amd import workload
+    sizes = [(0, 200), (200, 130), (330, 70)]
+    packed = [workload.config2_packed(prover.slots, prover.inputs_size, f, n) for f, n in sizes]
+    tickets = [prover.submit(inp, rsb) for inp, rsb in packed]
+    assert [t for t, _ in tickets] == sorted(t for t, _ in tickets) and all(t > 0 for t, _ in tickets)
+    got = [prover.collect(t, n) for t, n in reversed(tickets)][::-1]   # collecting out of order is allowed
+    ws, rs = workload.config2_range(0, 400)
+    ref_proofs, ref_pub = _oracle(ws, rs)
+    for (f, n), out in zip(sizes, got):
+        assert all(o["error"] == 0 for o in out)
+        assert [o["proof"] for o in out] == ref_proofs[f:f + n]
+        assert [o["public_inputs"] for o in out] == ref_pub[f:f + n]
+    # wrap: more submits than slots; the expired ticket is refused, the live ones still match
+    nslots = prover.n_slots()
+    small = workload.config2_packed(prover.slots, prover.inputs_size, 0, 64)
+    ts = [prover.submit(*small)[0] for _ in range(nslots + 1)]
+    from zerokit_amd._native import RLNError
+    with pytest.raises(RLNError, match="expired"):
+        prover.collect(ts[0], 64)
+    out = prover.collect(ts[-1], 64)
+    assert [o["proof"] for o in out] == ref_proofs[:64]
+
+
+def test_prove_stream_ragged_sizes_match_resident_path(prover):
+    """rlnamd_prover_prove_stream over n that is not a multiple of the capacity (256): 256 + 256 + 88, and the empty
+    job; the same bytes as upload + run + download of the same witnesses"""
+    from zerokit_amd import workload
+    n = 600
+    inp, rsb = workload.config2_packed(prover.slots, prover.inputs_size, 1000, n)
+    proofs, values, errs = prover.prove_stream_raw(inp, rsb)
+    assert not any(errs) and len(errs) == n
+    ws, rs = workload.config2_range(1000, n)
+    for lo in (0, 256, 512):
+        cnt = min(256, n - lo)
+        ref = prover.prove(ws[lo:lo + cnt], rs[lo:lo + cnt])
+        assert [r["proof"] for r in ref] == [proofs[128 * i:128 * i + 128] for i in range(lo, lo + cnt)]
+        assert b"".join(v.to_bytes(32, "little") for r in ref for v in r["public_inputs"]) == \
+            values[160 * lo:160 * (lo + cnt)]
+    assert prover.prove_stream_raw(b"", b"") == (b"", b"", [])
+
+
+def test_streamed_partial_and_finish_match_full(prover):
+    """PROVE_PARTIAL and PROVE_FINISH through submit / collect: partial + finish == full proof for the same (r, s)"""
+    from zerokit_amd import workload
+    n = 70
+    ws, rs = workload.config2_range(5000, n)
+    inp, rsb = workload.config2_packed(prover.slots, prover.inputs_size, 5000, n)
+    zero = dict(message_id=0, x=0, external_nullifier=0)
+    pinp = prover.pack_inputs([dict(w, **zero) for w in ws])
+    t, _ = prover.submit(pinp, prover.pack_rs([(0, 0)] * n), mode=1)
+    partials = prover.collect_partial(t, n)
+    assert partials == prover.prove_partial([{k: w[k] for k in ("identity_secret", "user_message_limit",
+                                                                  "path_elements", "identity_path_index")} for w in ws])
+    t2, _ = prover.submit(inp, rsb, mode=2, partials=partials)
+    t3, _ = prover.submit(inp, rsb)
+    fin, full = prover.collect(t2, n), prover.collect(t3, n)
+    assert [o["proof"] for o in fin] == [o["proof"] for o in full]
+    assert [o["public_inputs"] for o in fin] == [o["public_inputs"] for o in full]
+
+
+# ---------------------------------------------------------------------------------------------------- pool
+def test_pool_of_one_and_two_replicas_on_one_device_equal_single_prover(prover):
+    """rlnamd_pool: a pool of one replica and a pool of two replicas sharing device 0 return, index for index, the
+    bytes of a single prover (ragged n = 301: shards of 128 + 173 proofs, chunks of 128)"""
+    from zerokit_amd import workload
+    from zerokit_amd.batch import ProverPool
+    n = 301
+    inp, rsb = workload.config2_packed(prover.slots, prover.inputs_size, 3000, n)
+    ref = prover.prove_stream_raw(inp, rsb)
+    for devices in ([0], [0, 0]):
+        pool = ProverPool(devices=devices, max_batch=128)
+        assert pool.size == len(devices) and pool.devices == devices
+        got = pool.prove_raw(inp, rsb)
+        got2 = pool.prove_raw(inp, rsb)            # a second job on the same replicas
+        assert got == ref and got2 == ref
+        assert pool.prove_raw(b"", b"") == (b"", b"", [])
+        gp, gv = _split(got[0], got[1], n)
+        assert all(pool.verify_many(gp[:8], gv[:8]))
+        pool.close()
+    from zerokit_amd._native import RLNError
+    with pytest.raises(RLNError, match="does not exist"):
+        ProverPool(devices=[0, 63], max_batch=64)
+
+
+# ---------------------------------------------------------------------------------------------------- RCCL in C
+def test_msm_run_sharded_single_rank_communicator_vs_closed_form():
+    """config 5 through the C ABI only: RCCL communicator of one rank (rlnamd_comm_init_rank), 2^18 generated points,
+    local Pippenger + ncclAllGather + fold == (sum k_i s_i) G; and the one-process multi-device entry with one device"""
+    import ctypes as C
+    from zerokit_amd import lib
+    from zerokit_amd._native import check
+    from zerokit_amd.batch import Comm, MsmG1
+    n = 1 << 18
+    comm = Comm.init_rank(Comm.unique_id(), 1, 0)
+    assert comm.ranks() == 1
+    m = MsmG1(n)
+    m.generate(0xC0FFEE, 0, n)
+    res, ms = m.run_sharded(comm)
+    assert res == MsmG1.expected(0xC0FFEE, 0, n)
+    assert set(ms) == {"sort_ms", "buckets_ms", "all_gather_ms", "combine_ms"} and ms["buckets_ms"] > 0
+    # same object, host-gather path: identical point
+    blob, _ = m.run_windows()
+    assert m.combine([blob]) == res
+    m.close()
+    comm.close()
+    out = C.create_string_buffer(64)
+    ms5 = (C.c_float * 5)()
+    devs = (C.c_int * 1)(0)
+    check(lib().rlnamd_msm_generated_multi(devs, 1, 0xC0FFEE, n, 2, out, ms5))
+    assert (int.from_bytes(out.raw[:32], "little"), int.from_bytes(out.raw[32:], "little")) == res
+
+
+# ------------------------------------------------------------------------------- two processes, one device
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, os.environ["RLN_ROOT"])
+import torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from zerokit_amd import workload
+from zerokit_amd.batch import BatchProver, MsmG1
+from zerokit_amd.distributed import msm_sharded, prove_sharded, shard_bounds
+n_total = 1 << 18
+lo, hi = shard_bounds(n_total, world)[rank]
+m = MsmG1(hi - lo)
+res, _ = msm_sharded(m, 0xC0FFEE, n_total)            # the REAL device MSM on this rank's slice + all_gather + fold
+m.close()
+p = BatchProver(max_batch=64)
+ws, rs = workload.config2_range(0, 37)                # ragged: shards of 19 and 18
+out = prove_sharded(p.prove, ws, rs)                  # the REAL device prover as prove_fn
+p.close()
+if rank == 0:
+    print("RESULT " + json.dumps({"msm": [str(res[0]), str(res[1])], "proofs": [o["proof"].hex() for o in out],
+                                  "pub": [[str(v) for v in o["public_inputs"]] for o in out]}))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_processes_sharing_the_device_msm_sharded_and_prove_sharded(prover):
+    """zerokit_amd.distributed with the product objects under world size 2: two processes share the one GPU
+    (backend gloo); msm_sharded(MsmG1) at 2^18 equals the closed form, prove_sharded(BatchProver.prove) equals a
+    single-process run"""
+    import json
+    from zerokit_amd import workload
+    from zerokit_amd.batch import MsmG1
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   RLN_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", _WORKER], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    line = next(l for l in outs[0][0].splitlines() if l.startswith("RESULT "))
+    got = json.loads(line[7:])
+    exp = MsmG1.expected(0xC0FFEE, 0, 1 << 18)
+    assert (int(got["msm"][0]), int(got["msm"][1])) == exp
+    ws, rs = workload.config2_range(0, 37)
+    ref = prover.prove(ws, rs)
+    assert got["proofs"] == [o["proof"].hex() for o in ref]
+    assert got["pub"] == [[str(v) for v in o["public_inputs"]] for o in ref]
+
+
+# ------------------------------------------------------------------- full sizes on the bench schedule (last: 228 GiB)
+@pytest.fixture(scope="module")
+def bench_prover():
+    from zerokit_amd._native import RLNError
+    from zerokit_amd.batch import BatchProver
+    try:
+        p = BatchProver(max_batch=1024, window_bits=BENCH_SCHEDULE)
+    except RLNError as e:
+        if "out of memory" in str(e).lower() or "hipErrorOutOfMemory" in str(e):
+            pytest.skip("the device cannot hold the 228 GiB bench tables: %s" % e)
+        raise
+    yield p
+    p.close()
+
+
+def test_config2_full_size_on_the_bench_schedule_vs_c_oracle(bench_prover):
+    """BASELINE config 2 exactly as bench.py runs it: 1 024 proofs on the 228 GiB GLV comb schedule (16-bit digits at
+    the int16 edge), streamed; every proof and every public value bit-identical to oracle/c"""
+    from zerokit_amd import workload
+    p = bench_prover
+    assert int(p.info.windows) == 18 and int(p.info.windows_g2) == 16 and int(p.info.glv) == 1
+    n = 1024
+    proofs, values, errs = p.prove_stream_raw(*workload.config2_packed(p.slots, p.inputs_size, 0, n))
+    assert not any(errs)
+    ws, rs = workload.config2_range(0, n)
+    ref_proofs, ref_pub = _oracle(ws, rs)
+    got_proofs, got_pub = _split(proofs, values, n)
+    assert got_proofs == ref_proofs
+    assert got_pub == ref_pub
+
+
+def test_config4_shard_8192_streamed_all_verified_sampled_vs_c_oracle(bench_prover):
+    """BASELINE config 4's per-GPU shard: witnesses 8 192 .. 16 384 of the 65 536-index stream (the shard of GPU 1)
+    through the streaming API on the bench schedule; all 8 192 verify (rlnamd_verify_many), 96 sampled indices are
+    byte-equal to oracle/c, and no two proofs coincide"""
+    from zerokit_amd import workload
+    p = bench_prover
+    first, n = 8192, 8192
+    proofs, values, errs = p.prove_stream_raw(*workload.config2_packed(p.slots, p.inputs_size, first, n))
+    assert not any(errs)
+    got_proofs, got_pub = _split(proofs, values, n)
+    assert all(p.verify_many(got_proofs, got_pub))
+    assert len(set(got_proofs)) == n
+    idx = sorted(set(list(range(0, n, 89)) + [1023, 1024, 8191]))
+    assert len(idx) >= 64
+    ws, rs = workload.config2_range(first, n)
+    ref_proofs, ref_pub = _oracle([ws[i] for i in idx], [rs[i] for i in idx])
+    assert [got_proofs[i] for i in idx] == ref_proofs
+    assert [got_pub[i] for i in idx] == ref_pub

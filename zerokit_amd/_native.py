@@ -134,6 +134,33 @@ SIGNATURES = {
     "rlnamd_msm_window_sums_bytes": (C.c_size_t, []),
     "rlnamd_msm_run": (C.c_int, [P, C.c_char_p, C.POINTER(C.c_float)]),
     "rlnamd_msm_combine": (C.c_int, [P, C.c_char_p, C.c_size_t, C.c_char_p]),
+    "rlnamd_prover_slots": (C.c_int, [P]),
+    "rlnamd_prover_submit": (C.c_int, [P, C.c_size_t, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p,
+                                      C.POINTER(C.c_uint64)]),
+    "rlnamd_prover_collect": (C.c_int, [P, C.c_uint64, C.c_size_t, C.c_char_p, C.c_char_p, C.c_char_p,
+                                       C.POINTER(C.c_uint32), C.c_char_p]),
+    "rlnamd_prover_collect_public": (C.c_int, [P, C.c_uint64, C.c_size_t, C.c_char_p]),
+    "rlnamd_prover_prove_stream": (C.c_int, [P, C.c_size_t, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
+                                            C.POINTER(C.c_uint32)]),
+    "rlnamd_pool_new": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_size_t, C.c_int,
+                                 C.POINTER(C.c_int), C.c_size_t, PP]),
+    "rlnamd_pool_free": (None, [P]),
+    "rlnamd_pool_size": (C.c_size_t, [P]),
+    "rlnamd_pool_device": (C.c_int, [P, C.c_size_t]),
+    "rlnamd_pool_get_info": (C.c_int, [P, C.POINTER(ProverInfo)]),
+    "rlnamd_pool_prove": (C.c_int, [P, C.c_size_t, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
+                                   C.POINTER(C.c_uint32)]),
+    "rlnamd_pool_last_ms": (C.c_int, [P, C.POINTER(C.c_float)]),
+    "rlnamd_pool_verify_many": (C.c_int, [P, C.c_size_t, C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_char_p]),
+    "rlnamd_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "rlnamd_comm_init_rank": (C.c_int, [C.c_char_p, C.c_int, C.c_int, PP]),
+    "rlnamd_comm_init_all": (C.c_int, [C.POINTER(C.c_int), C.c_size_t, PP]),
+    "rlnamd_comm_free": (None, [P]),
+    "rlnamd_comm_rank": (C.c_int, [P]),
+    "rlnamd_comm_ranks": (C.c_int, [P]),
+    "rlnamd_msm_run_sharded": (C.c_int, [P, P, C.c_char_p, C.POINTER(C.c_float)]),
+    "rlnamd_msm_generated_multi": (C.c_int, [C.POINTER(C.c_int), C.c_size_t, C.c_uint64, C.c_size_t, C.c_int,
+                                            C.c_char_p, C.POINTER(C.c_float)]),
     # ---- rln.h
     "ffi_rln_new": (CResultPtr, [C.c_size_t, C.c_char_p]),
     "ffi_rln_new_with_params": (CResultPtr, [C.c_size_t, C.POINTER(VecU8), C.POINTER(VecU8), C.c_char_p]),

@@ -26,6 +26,30 @@ def _b(x: int, modulus: int = _R) -> bytes:
     return x.to_bytes(32, "little")
 
 
+def _check_verify_shapes(proofs, public_inputs):
+    """the C entry points index proofs + 128 i and values + 32 nv i: refuse anything that is not exactly that shape"""
+    if len(proofs) != len(public_inputs):
+        raise RLNError("verify_many: %d proofs but %d public-input rows" % (len(proofs), len(public_inputs)))
+    nv = len(public_inputs[0])
+    for i, (p, row) in enumerate(zip(proofs, public_inputs)):
+        if len(p) != 128:
+            raise RLNError("verify_many: proof %d is %d bytes, expected 128" % (i, len(p)))
+        if len(row) != nv:
+            raise RLNError("verify_many: public-input row %d has %d entries, expected %d" % (i, len(row), nv))
+    return nv
+
+
+def _unpack_results(proofs, values, errs):
+    out = []
+    for i in range(len(errs)):
+        v = values[160 * i:160 * (i + 1)]
+        vals = [int.from_bytes(v[32 * k:32 * k + 32], "little") for k in range(5)]
+        out.append(dict(proof=proofs[128 * i:128 * (i + 1)],
+                        values=dict(y=vals[0], root=vals[1], nullifier=vals[2], x=vals[3], external_nullifier=vals[4]),
+                        public_inputs=vals, error=int(errs[i])))
+    return out
+
+
 class BatchProver:
     """n x generate_zk_proof_with_rs (/root/reference/rln/src/protocol/proof.rs:753-777) +
     proof_values_from_witness (protocol/witness.rs:759-804) in one device batch."""
@@ -140,6 +164,60 @@ class BatchProver:
         self.run(n)
         return self.download(n)
 
+    # ---- streamed batches (rlnamd_prover_submit / _collect): fresh inputs per batch, no pipeline drain
+    @staticmethod
+    def pack_rs(rs):
+        return b"".join(_b(r) + _b(s) for r, s in rs)
+
+    def n_slots(self):
+        """workspace slots = batches that can be in flight between submit and collect"""
+        return int(lib().rlnamd_prover_slots(self._h))
+
+    def submit(self, inputs: bytes, rsb: bytes, mode=0, partials=None):
+        """inputs = pack_inputs(...), rsb = pack_rs(...); returns (ticket, n).  Enqueue only."""
+        n = len(inputs) // (self.inputs_size * 32)
+        if len(inputs) != n * self.inputs_size * 32 or len(rsb) != 64 * n:
+            raise RLNError("submit: inputs / rs sizes do not match")
+        pp = None
+        if partials is not None:
+            pp = b"".join(partials)
+            if len(pp) != 320 * n:
+                raise RLNError("submit: one 320-byte partial proof per proof expected")
+        t = C.c_uint64()
+        check(lib().rlnamd_prover_submit(self._h, n, inputs, rsb, mode, pp, C.byref(t)))
+        return int(t.value), n
+
+    def collect_raw(self, ticket, n):
+        """waits for that batch only -> (proofs bytes n*128, values bytes n*160, errors list)"""
+        proofs = C.create_string_buffer(128 * n)
+        values = C.create_string_buffer(160 * n)
+        errs = (C.c_uint32 * n)()
+        check(lib().rlnamd_prover_collect(self._h, ticket, n, proofs, None, values, errs, None))
+        return proofs.raw, values.raw, list(errs)
+
+    def collect(self, ticket, n):
+        proofs, values, errs = self.collect_raw(ticket, n)
+        return _unpack_results(proofs, values, errs)
+
+    def collect_partial(self, ticket, n):
+        buf = C.create_string_buffer(320 * n)
+        check(lib().rlnamd_prover_collect(self._h, ticket, n, None, None, None, None, buf))
+        return [buf.raw[320 * i:320 * (i + 1)] for i in range(n)]
+
+    def prove_stream_raw(self, inputs: bytes, rsb: bytes):
+        """any n through rlnamd_prover_prove_stream (chunks of `capacity`, all slots in flight)"""
+        n = len(inputs) // (self.inputs_size * 32)
+        if len(inputs) != n * self.inputs_size * 32 or len(rsb) != 64 * n:
+            raise RLNError("prove_stream: inputs / rs sizes do not match")
+        proofs = C.create_string_buffer(128 * n)
+        values = C.create_string_buffer(160 * n)
+        errs = (C.c_uint32 * max(n, 1))()
+        check(lib().rlnamd_prover_prove_stream(self._h, n, inputs, rsb, proofs, values, errs))
+        return proofs.raw, values.raw, list(errs)[:n]
+
+    def prove_stream(self, witnesses, rs):
+        return _unpack_results(*self.prove_stream_raw(self.pack_inputs(witnesses), self.pack_rs(rs)))
+
     # ---- partial proofs (protocol/proof.rs:783-849)
     def known_mask(self):
         buf = C.create_string_buffer(int(self.info.num_signals))
@@ -219,7 +297,7 @@ class BatchProver:
         n = len(proofs)
         if n == 0:
             return []
-        nv = len(public_inputs[0])
+        nv = _check_verify_shapes(proofs, public_inputs)
         ok = C.create_string_buffer(n)
         check(lib().rlnamd_verify_many(self._h, n, b"".join(proofs), b"".join(_b(v) for pi in public_inputs for v in pi),
                                        nv, threads, ok))
@@ -238,11 +316,95 @@ def verify_many_with_zkey(zkey: bytes, proofs, public_inputs, threads=0):
     n = len(proofs)
     if n == 0:
         return []
-    nv = len(public_inputs[0])
+    nv = _check_verify_shapes(proofs, public_inputs)
     ok = C.create_string_buffer(n)
     check(lib().rlnamd_verify_many_with_zkey(zkey, len(zkey), n, b"".join(proofs),
                                              b"".join(_b(v) for pi in public_inputs for v in pi), nv, threads, ok))
     return [bool(x) for x in ok.raw]
+
+
+class ProverPool:
+    """rlnamd_pool: one prover replica + one host thread per device of this process; a job of n proofs is cut into
+    contiguous index shards (BASELINE config 4: 8 x 8 192) and every replica streams its shard."""
+
+    def __init__(self, devices=None, zkey: bytes = None, graph: bytes = None, max_batch=1024, window_bits=0, depth=20,
+                 multi=False):
+        if zkey is None or graph is None:
+            zp, gp = resource_paths(depth, multi)
+            zkey, graph = open(zp, "rb").read(), open(gp, "rb").read()
+        self._h = C.c_void_p()
+        devs = list(devices) if devices else []
+        arr = (C.c_int * max(len(devs), 1))(*devs)
+        check(lib().rlnamd_pool_new(zkey, len(zkey), graph, len(graph), max_batch, window_bits, arr if devs else None,
+                                    len(devs), C.byref(self._h)))
+        self.info = ProverInfo()
+        check(lib().rlnamd_pool_get_info(self._h, C.byref(self.info)))
+        self.inputs_size = int(self.info.inputs_size)
+        self.size = int(lib().rlnamd_pool_size(self._h))
+        self.devices = [int(lib().rlnamd_pool_device(self._h, i)) for i in range(self.size)]
+
+    def close(self):
+        if self._h:
+            lib().rlnamd_pool_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def prove_raw(self, inputs: bytes, rsb: bytes):
+        n = len(inputs) // (self.inputs_size * 32)
+        if len(inputs) != n * self.inputs_size * 32 or len(rsb) != 64 * n:
+            raise RLNError("pool: inputs / rs sizes do not match")
+        proofs = C.create_string_buffer(128 * n)
+        values = C.create_string_buffer(160 * n)
+        errs = (C.c_uint32 * max(n, 1))()
+        check(lib().rlnamd_pool_prove(self._h, n, inputs, rsb, proofs, values, errs))
+        return proofs.raw, values.raw, list(errs)[:n]
+
+    def last_ms(self):
+        ms = (C.c_float * self.size)()
+        check(lib().rlnamd_pool_last_ms(self._h, ms))
+        return [float(x) for x in ms]
+
+    def verify_many(self, proofs, public_inputs, threads=0):
+        n = len(proofs)
+        if n == 0:
+            return []
+        nv = _check_verify_shapes(proofs, public_inputs)
+        ok = C.create_string_buffer(n)
+        check(lib().rlnamd_pool_verify_many(self._h, n, b"".join(proofs),
+                                            b"".join(_b(v) for pi in public_inputs for v in pi), nv, threads, ok))
+        return [bool(x) for x in ok.raw]
+
+
+class Comm:
+    """rlnamd_comm: an RCCL communicator created through the C ABI (no torch type crosses it)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(lib().rlnamd_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def init_rank(cls, uid: bytes, nranks: int, rank: int):
+        h = C.c_void_p()
+        check(lib().rlnamd_comm_init_rank(uid, nranks, rank, C.byref(h)))
+        return cls(h)
+
+    def ranks(self):
+        return int(lib().rlnamd_comm_ranks(self._h))
+
+    def close(self):
+        if self._h:
+            lib().rlnamd_comm_free(self._h)
+            self._h = C.c_void_p()
 
 
 class PoseidonTree:
@@ -354,6 +516,15 @@ class MsmG1:
         check(lib().rlnamd_msm_combine(self._h, b"".join(blobs), len(blobs), out))
         x, y = int.from_bytes(out.raw[:32], "little"), int.from_bytes(out.raw[32:], "little")
         return None if x == 0 and y == 0 else (x, y)
+
+    def run_sharded(self, comm: "Comm"):
+        """config 5 on this rank of an RCCL communicator (collective): -> (point or None, stage ms dict)"""
+        out = C.create_string_buffer(64)
+        ms = (C.c_float * 4)()
+        check(lib().rlnamd_msm_run_sharded(self._h, comm._h, out, ms))
+        x, y = int.from_bytes(out.raw[:32], "little"), int.from_bytes(out.raw[32:], "little")
+        return (None if x == 0 and y == 0 else (x, y)), dict(sort_ms=float(ms[0]), buckets_ms=float(ms[1]),
+                                                              all_gather_ms=float(ms[2]), combine_ms=float(ms[3]))
 
     def msm(self, points, scalars):
         self.set(points, scalars)

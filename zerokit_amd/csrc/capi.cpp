@@ -3,7 +3,9 @@
 
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
+#include <system_error>
 #include <memory>
 #include <thread>
 #include <string>
@@ -15,6 +17,7 @@
 #include "pairing.h"
 #include "poseidon.h"
 #include "prover.h"
+#include "capi_util.h"
 
 using namespace rlnamd;
 
@@ -26,24 +29,9 @@ int fail(const std::exception& e) {
 }
 }  // namespace rlnamd
 
-#define RLN_TRY try {
-#define RLN_CATCH                        \
-  return RLNAMD_OK;                      \
-  }                                      \
-  catch (const std::exception& e) {      \
-    return rlnamd::fail(e);              \
-  }                                      \
-  catch (...) {                          \
-    rlnamd::g_last_error = "unknown error"; \
-    return RLNAMD_ERR;                   \
-  }
-
 struct rlnamd_tree {
   MerkleTreeDev t;
   DevBuf<uint8_t> bench_elems, bench_bits;
-};
-struct rlnamd_prover {
-  std::unique_ptr<Prover> p;
 };
 
 static void verify_common(const Zkey& zk, const uint8_t proof[128], const uint8_t* values_le, int* ok, size_t nv = 5);
@@ -206,7 +194,12 @@ void rlnamd_prover_free(rlnamd_prover* p) { delete p; }
 
 int rlnamd_prover_get_info(rlnamd_prover* p, rlnamd_prover_info* info) {
   RLN_TRY
-  const Prover& P = *p->p;
+  rlnamd::fill_prover_info(*p->p, info);
+  RLN_CATCH
+}
+}  // extern "C"
+namespace rlnamd {
+void fill_prover_info(const Prover& P, rlnamd_prover_info* info) {
   info->inputs_size = P.inputs_per_proof();
   info->num_signals = P.graph().signals.size();
   uint64_t dom = 1;
@@ -224,8 +217,9 @@ int rlnamd_prover_get_info(rlnamd_prover* p, rlnamd_prover_info* info) {
   info->reserved = 0;
   info->g1_rows = P.g1_rows();
   info->g2_rows = P.g2_rows();
-  RLN_CATCH
 }
+}  // namespace rlnamd
+extern "C" {
 int rlnamd_prover_input_slot(rlnamd_prover* p, const char* name, uint32_t* offset, uint32_t* len) {
   RLN_TRY
   auto& m = p->p->graph().input_mapping;
@@ -253,6 +247,32 @@ int rlnamd_prover_run_async(rlnamd_prover* p, size_t n) {
 int rlnamd_prover_sync(rlnamd_prover* p) {
   RLN_TRY
   p->p->sync();
+  RLN_CATCH
+}
+int rlnamd_prover_slots(rlnamd_prover* p) { return p->p->slots(); }
+int rlnamd_prover_submit(rlnamd_prover* p, size_t n, const uint8_t* inputs_le, const uint8_t* rs_le, int mode,
+                         const uint8_t* partial320, uint64_t* ticket) {
+  RLN_TRY
+  *ticket = p->p->submit(n, inputs_le, rs_le, mode, partial320);
+  RLN_CATCH
+}
+int rlnamd_prover_collect(rlnamd_prover* p, uint64_t ticket, size_t n, uint8_t* proofs, uint8_t* coords, uint8_t* values,
+                          uint32_t* errors, uint8_t* partial320) {
+  RLN_TRY
+  p->p->collect(ticket, n, proofs, values, errors, coords, partial320);
+  RLN_CATCH
+}
+int rlnamd_prover_collect_public(rlnamd_prover* p, uint64_t ticket, size_t n, uint8_t* out_le) {
+  RLN_TRY
+  std::vector<uint8_t> v;
+  p->p->collect_public(ticket, n, &v);
+  memcpy(out_le, v.data(), v.size());
+  RLN_CATCH
+}
+int rlnamd_prover_prove_stream(rlnamd_prover* p, size_t n, const uint8_t* inputs_le, const uint8_t* rs_le,
+                               uint8_t* proofs, uint8_t* values, uint32_t* errors) {
+  RLN_TRY
+  p->p->prove_stream(n, inputs_le, rs_le, proofs, values, errors);
   RLN_CATCH
 }
 int rlnamd_prover_run_mode(rlnamd_prover* p, size_t n, int mode) {
@@ -332,9 +352,6 @@ int rlnamd_verify(rlnamd_prover* p, const uint8_t proof[128], const uint8_t valu
   RLN_CATCH
 }
 
-struct rlnamd_msm {
-  std::unique_ptr<MsmG1> m;
-};
 int rlnamd_msm_new(size_t capacity, rlnamd_msm** out) {
   RLN_TRY
   std::unique_ptr<rlnamd_msm> h(new rlnamd_msm);
@@ -390,6 +407,12 @@ int rlnamd_msm_run(rlnamd_msm* m, uint8_t* window_sums, float ms[3]) {
   m->m->run_windows(window_sums, ms);
   RLN_CATCH
 }
+int rlnamd_msm_run_sharded(rlnamd_msm* m, rlnamd_comm* c, uint8_t out_xy_le[64], float ms[4]) {
+  RLN_TRY
+  if (!c) throw Error("rlnamd_msm_run_sharded: no communicator");
+  m->m->run_sharded(rlnamd_comm_handle(c), rlnamd_comm_size(c), out_xy_le, ms);
+  RLN_CATCH
+}
 int rlnamd_msm_combine(rlnamd_msm* m, const uint8_t* window_sums, size_t contributors, uint8_t out_xy_le[64]) {
   RLN_TRY
   m->m->combine(window_sums, contributors, out_xy_le);
@@ -416,12 +439,16 @@ static void verify_common(const Zkey& zk, const uint8_t proof[128], const uint8_
 
 // n independent verifications spread over host threads (verification stays on the CPU; a relay node
 // verifies every message it forwards).  ok[i] = 1 valid, 0 invalid or malformed.
-static void verify_many_common(const Zkey& zk, size_t n, const uint8_t* proofs, const uint8_t* values_le, size_t nv,
-                               int threads, uint8_t* ok) {
+}  // extern "C"
+namespace rlnamd {
+void verify_many_common(const Zkey& zk, size_t n, const uint8_t* proofs, const uint8_t* values_le, size_t nv,
+                        int threads, uint8_t* ok) {
+  if (nv + 1 != zk.gamma_abc_g1.size()) throw Error("MalformedVerifyingKey");
   (void)prepared(zk);  // once, before the workers only read it
   unsigned hw = std::thread::hardware_concurrency();
-  size_t nt = threads > 0 ? (size_t)threads : (hw ? hw : 1);
-  nt = std::max<size_t>(1, std::min(nt, n));
+  if (!hw) hw = 1;
+  size_t nt = threads > 0 ? (size_t)threads : hw;
+  nt = std::max<size_t>(1, std::min({nt, n, (size_t)4 * hw}));   // more threads than that only cost memory
   std::atomic<size_t> next{0};
   auto work = [&]() {
     for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
@@ -435,13 +462,23 @@ static void verify_many_common(const Zkey& zk, size_t n, const uint8_t* proofs, 
     }
   };
   std::vector<std::thread> pool;
-  for (size_t t = 1; t < nt; t++) pool.emplace_back(work);
+  pool.reserve(nt);
+  for (size_t t = 1; t < nt; t++) {
+    try {
+      pool.emplace_back(work);
+    } catch (const std::system_error&) {
+      break;  // no more threads to be had: the ones running (and this one) drain the queue
+    }
+  }
   work();
   for (auto& t : pool) t.join();
 }
+}  // namespace rlnamd
+extern "C" {
 int rlnamd_verify_many(rlnamd_prover* p, size_t n, const uint8_t* proofs, const uint8_t* values_le, size_t n_values,
                        int threads, uint8_t* ok) {
   RLN_TRY
+  if (n_values + 1 != p->p->zkey().gamma_abc_g1.size()) throw Error("MalformedVerifyingKey");
   verify_many_common(p->p->zkey(), n, proofs, values_le, n_values, threads, ok);
   RLN_CATCH
 }

@@ -21,8 +21,13 @@ class MsmG1 {
   // adds the window sums of `contributors` devices and folds the windows (Horner); affine canonical result
   void combine(const uint8_t* window_sums, size_t contributors, uint8_t out_xy_le[64]);
   static size_t window_sums_bytes();
+  // the whole of config 5 on one rank of an RCCL communicator (ncclComm_t passed as void*): windows, ncclAllGather of
+  // the window sums on the object's stream, local add + fold.  ms[0] digits + sort, ms[1] buckets (accumulate + reduce),
+  // ms[2] all-gather, ms[3] combine.  Collective: every rank of the communicator must call it.
+  void run_sharded(void* nccl_comm, int nranks, uint8_t out_xy_le[64], float ms[4]);
 
  private:
+  void enqueue_windows();
   struct Impl;
   std::unique_ptr<Impl> d_;
 };

@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <vector>
+#include <rccl/rccl.h>
 
 #include "common.h"
 #include "curve.h"
@@ -454,7 +455,9 @@ struct MsmG1::Impl {
   DevBuf<G1XYZZ> buckets, chunkS, chunkT, grp, wsum, head, tail;
   size_t max_slices = 0;
   DevBuf<Range> r1, r2;
-  hipEvent_t e[4];
+  DevBuf<G1XYZZ> gather;        // run_sharded: the window sums of every rank
+  DevBuf<uint32_t> result;
+  hipEvent_t e[6];
 };
 
 MsmG1::MsmG1(size_t capacity) : d_(new Impl) {
@@ -567,6 +570,41 @@ void MsmG1::expected_generated(uint64_t seed, uint64_t first_index, size_t n, ui
 
 void MsmG1::run_windows(uint8_t* window_sums_out, float ms[3]) {
   Impl& D = *d_;
+  enqueue_windows();
+  RLN_HIP(hipMemcpyAsync(window_sums_out, D.wsum.p, MSM_W * sizeof(G1XYZZ), hipMemcpyDeviceToHost, D.s));
+  RLN_HIP(hipStreamSynchronize(D.s));
+  if (ms)
+    for (int i = 0; i < 3; i++) RLN_HIP(hipEventElapsedTime(&ms[i], D.e[i], D.e[i + 1]));
+}
+
+// One MSM over the points of ALL ranks of an RCCL communicator (BASELINE config 5): every rank reduces its
+// slice to the 16 window sums, ONE ncclAllGather moves the 2 KiB blocks over xGMI (RCCL has no elliptic-curve reduce
+// op: "all-reduce of partials" = gather + local add), and every rank adds them and folds the windows.  Everything is
+// enqueued on the object's stream; the only host wait is the final copy of the 64-byte result.
+void MsmG1::run_sharded(void* nccl_comm, int nranks, uint8_t out_xy_le[64], float ms[4]) {
+  Impl& D = *d_;
+  if (nranks < 1) throw Error("run_sharded: empty communicator");
+  enqueue_windows();
+  if (D.gather.n < (size_t)nranks * MSM_W) D.gather.alloc((size_t)nranks * MSM_W);
+  if (!D.result.p) D.result.alloc(16);
+  ncclResult_t r = ncclAllGather(D.wsum.p, D.gather.p, MSM_W * sizeof(G1XYZZ), ncclUint8, (ncclComm_t)nccl_comm, D.s);
+  if (r != ncclSuccess) throw Error(std::string("RCCL error: ") + ncclGetErrorString(r) + " (ncclAllGather of the window sums)");
+  RLN_HIP(hipEventRecord(D.e[4], D.s));
+  hipLaunchKernelGGL(k_combine, dim3(1), dim3(64), 0, D.s, D.gather.p, (uint32_t)nranks, D.result.p);
+  RLN_HIP(hipGetLastError());
+  RLN_HIP(hipEventRecord(D.e[5], D.s));
+  RLN_HIP(hipMemcpyAsync(out_xy_le, D.result.p, 64, hipMemcpyDeviceToHost, D.s));
+  RLN_HIP(hipStreamSynchronize(D.s));
+  if (ms) {
+    RLN_HIP(hipEventElapsedTime(&ms[0], D.e[0], D.e[1]));
+    RLN_HIP(hipEventElapsedTime(&ms[1], D.e[1], D.e[3]));
+    RLN_HIP(hipEventElapsedTime(&ms[2], D.e[3], D.e[4]));
+    RLN_HIP(hipEventElapsedTime(&ms[3], D.e[4], D.e[5]));
+  }
+}
+
+void MsmG1::enqueue_windows() {
+  Impl& D = *d_;
   const uint32_t n = (uint32_t)D.n, nkeys = MSM_W * MSM_NB, nch = MSM_W * MSM_NCH;
   hipStream_t s = D.s;
   RLN_HIP(hipEventRecord(D.e[0], s));
@@ -598,10 +636,6 @@ void MsmG1::run_windows(uint8_t* window_sums_out, float ms[3]) {
   hipLaunchKernelGGL(k_range_sum, dim3(1), dim3(64), 0, s, D.grp.p, D.r2.p, (uint32_t)D.r2.n, D.wsum.p);
   RLN_HIP(hipGetLastError());
   RLN_HIP(hipEventRecord(D.e[3], s));
-  RLN_HIP(hipMemcpyAsync(window_sums_out, D.wsum.p, MSM_W * sizeof(G1XYZZ), hipMemcpyDeviceToHost, s));
-  RLN_HIP(hipStreamSynchronize(s));
-  if (ms)
-    for (int i = 0; i < 3; i++) RLN_HIP(hipEventElapsedTime(&ms[i], D.e[i], D.e[i + 1]));
 }
 
 void MsmG1::combine(const uint8_t* window_sums, size_t contributors, uint8_t out_xy_le[64]) {

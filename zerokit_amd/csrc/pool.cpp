@@ -1,0 +1,338 @@
+// Native multi-GPU side of include/rln_amd.h (BASELINE north_star: "batches of independent proofs, and
+// optionally a single large MSM, shard across the 8 GPUs of one node"):
+//
+//   rlnamd_pool  -- one Prover replica + one host thread per device (hipSetDevice is per-thread state).  A job of n
+//                   proofs is cut into contiguous index shards, one per replica (BASELINE config 4: 8 x 8 192), every
+//                   replica streams its shard through Prover::prove_stream (fresh inputs H2D, proofs D2H, chunks
+//                   overlapping on the device) and writes its results at their index.  No data-path collective: the
+//                   proofs are independent (the reference's guidance is one worker per proof, rln/README.md:324-332).
+//   rlnamd_comm  -- an RCCL communicator (multi-process: unique id + rank; single process: ncclCommInitAll) for the
+//                   one path that has an exchange step, the config-5 MSM: rlnamd_msm_run_sharded = local Pippenger to
+//                   16 window sums, ONE ncclAllGather of 2 KiB per rank over xGMI, local add + fold.
+#include <rccl/rccl.h>
+#include <string.h>
+
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "capi_util.h"
+#include "common.h"
+
+using namespace rlnamd;
+
+#define RLN_NCCL(expr)                                                                                       \
+  do {                                                                                                       \
+    ncclResult_t r_ = (expr);                                                                                \
+    if (r_ != ncclSuccess) throw Error(std::string("RCCL error: ") + ncclGetErrorString(r_) + " (" #expr ")"); \
+  } while (0)
+
+struct rlnamd_comm {
+  ncclComm_t comm = nullptr;
+  int nranks = 0, rank = 0, device = 0;
+};
+void* rlnamd_comm_handle(rlnamd_comm* c) { return (void*)c->comm; }
+int rlnamd_comm_size(rlnamd_comm* c) { return c->nranks; }
+
+namespace {
+
+struct Job {
+  size_t n = 0;
+  const uint8_t* inputs = nullptr;
+  const uint8_t* rs = nullptr;
+  uint8_t* proofs = nullptr;
+  uint8_t* values = nullptr;
+  uint32_t* errors = nullptr;
+};
+
+struct Replica {
+  int device = 0;
+  std::unique_ptr<Prover> prover;
+  std::thread th;
+  // the worker's mailbox
+  std::mutex mu;
+  std::condition_variable cv;
+  bool has_job = false, stop = false, ready = false;
+  Job job;
+  size_t lo = 0, hi = 0;
+  std::string error;   // of construction or of the last job
+  float last_ms = 0;   // wall time of the last shard on this replica
+};
+
+}  // namespace
+
+struct rlnamd_pool {
+  std::vector<std::unique_ptr<Replica>> rep;
+  std::mutex job_mu;          // one job at a time
+  std::mutex done_mu;
+  std::condition_variable done_cv;
+  size_t pending = 0;
+  size_t inputs_size = 0;
+
+  void worker(Replica* R, const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_t graph_len, ProverConfig cfg) {
+    try {
+      RLN_HIP(hipSetDevice(R->device));
+      R->prover.reset(new Prover(zkey, zkey_len, graph, graph_len, cfg));
+    } catch (const std::exception& e) {
+      R->error = e.what();
+    }
+    {
+      std::lock_guard<std::mutex> lk(done_mu);
+      R->ready = true;
+    }
+    done_cv.notify_all();
+    for (;;) {
+      std::unique_lock<std::mutex> lk(R->mu);
+      R->cv.wait(lk, [&] { return R->has_job || R->stop; });
+      if (R->stop) return;
+      Job j = R->job;
+      size_t lo = R->lo, hi = R->hi;
+      R->has_job = false;
+      lk.unlock();
+      R->error.clear();
+      try {
+        if (hi > lo) {
+          auto t0 = std::chrono::steady_clock::now();
+          const size_t nib = R->prover->inputs_per_proof() * 32;
+          R->prover->prove_stream(hi - lo, j.inputs + lo * nib, j.rs + lo * 64, j.proofs ? j.proofs + lo * 128 : nullptr,
+                                  j.values ? j.values + lo * 160 : nullptr, j.errors ? j.errors + lo : nullptr);
+          R->last_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+      } catch (const std::exception& e) {
+        R->error = e.what();
+      }
+      {
+        std::lock_guard<std::mutex> dl(done_mu);
+        pending--;
+      }
+      done_cv.notify_all();
+    }
+  }
+
+  ~rlnamd_pool() {
+    for (auto& R : rep) {
+      {
+        std::lock_guard<std::mutex> lk(R->mu);
+        R->stop = true;
+      }
+      R->cv.notify_all();
+    }
+    for (auto& R : rep)
+      if (R->th.joinable()) R->th.join();
+    // the Prover of a replica frees device memory: do it with its device current
+    for (auto& R : rep) {
+      (void)hipSetDevice(R->device);
+      R->prover.reset();
+    }
+  }
+};
+
+extern "C" {
+
+int rlnamd_pool_new(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_t graph_len, size_t max_batch,
+                    int window_bits, const int* devices, size_t n_devices, rlnamd_pool** out) {
+  RLN_TRY
+  require_gpu();
+  int have = 0;
+  RLN_HIP(hipGetDeviceCount(&have));
+  std::vector<int> devs;
+  if (!devices || n_devices == 0) {
+    for (int d = 0; d < have; d++) devs.push_back(d);   // every device of the node
+  } else {
+    devs.assign(devices, devices + n_devices);
+  }
+  for (int d : devs)
+    if (d < 0 || d >= have) throw Error("rlnamd_pool_new: device " + std::to_string(d) + " does not exist (" +
+                                        std::to_string(have) + " visible)");
+  int prev = 0;
+  RLN_HIP(hipGetDevice(&prev));
+  ProverConfig cfg;
+  cfg.max_batch = max_batch ? max_batch : 1024;
+  cfg.window_bits = window_bits;
+  std::unique_ptr<rlnamd_pool> P(new rlnamd_pool);
+  for (int d : devs) {
+    P->rep.emplace_back(new Replica);
+    P->rep.back()->device = d;
+  }
+  // the replicas build their tables in parallel (one thread per device; ~10 s for the 228 GiB schedule)
+  for (auto& R : P->rep) {
+    Replica* r = R.get();
+    rlnamd_pool* pp = P.get();
+    r->th = std::thread([pp, r, zkey, zkey_len, graph, graph_len, cfg] { pp->worker(r, zkey, zkey_len, graph, graph_len, cfg); });
+  }
+  {
+    std::unique_lock<std::mutex> lk(P->done_mu);
+    P->done_cv.wait(lk, [&] {
+      for (auto& R : P->rep)
+        if (!R->ready) return false;
+      return true;
+    });
+  }
+  (void)hipSetDevice(prev);
+  for (auto& R : P->rep)
+    if (!R->error.empty()) throw Error("rlnamd_pool_new: device " + std::to_string(R->device) + ": " + R->error);
+  P->inputs_size = P->rep[0]->prover->inputs_per_proof();
+  *out = P.release();
+  RLN_CATCH
+}
+
+void rlnamd_pool_free(rlnamd_pool* p) { delete p; }
+size_t rlnamd_pool_size(rlnamd_pool* p) { return p->rep.size(); }
+int rlnamd_pool_device(rlnamd_pool* p, size_t replica) { return replica < p->rep.size() ? p->rep[replica]->device : -1; }
+
+int rlnamd_pool_get_info(rlnamd_pool* p, rlnamd_prover_info* info) {
+  RLN_TRY
+  fill_prover_info(*p->rep[0]->prover, info);
+  RLN_CATCH
+}
+
+int rlnamd_pool_prove(rlnamd_pool* p, size_t n, const uint8_t* inputs_le, const uint8_t* rs_le, uint8_t* proofs,
+                      uint8_t* values, uint32_t* errors) {
+  RLN_TRY
+  if (n == 0) return RLNAMD_OK;
+  if (!inputs_le || !rs_le) throw Error("rlnamd_pool_prove: inputs and rs are required");
+  std::lock_guard<std::mutex> job_lk(p->job_mu);
+  const size_t N = p->rep.size();
+  {
+    std::lock_guard<std::mutex> dl(p->done_mu);
+    p->pending = N;
+  }
+  // contiguous shards by index, in units of whole waves (64 proofs) so that no replica pads more than the last one
+  const size_t waves = (n + 63) / 64;
+  for (size_t i = 0; i < N; i++) {
+    Replica& R = *p->rep[i];
+    size_t lo = std::min(n, (waves * i / N) * 64), hi = std::min(n, (waves * (i + 1) / N) * 64);
+    if (i + 1 == N) hi = n;
+    {
+      std::lock_guard<std::mutex> lk(R.mu);
+      R.job = Job{n, inputs_le, rs_le, proofs, values, errors};
+      R.lo = lo;
+      R.hi = hi;
+      R.has_job = true;
+    }
+    R.cv.notify_all();
+  }
+  {
+    std::unique_lock<std::mutex> lk(p->done_mu);
+    p->done_cv.wait(lk, [&] { return p->pending == 0; });
+  }
+  for (auto& R : p->rep)
+    if (!R->error.empty()) throw Error("rlnamd_pool_prove: device " + std::to_string(R->device) + ": " + R->error);
+  RLN_CATCH
+}
+
+int rlnamd_pool_last_ms(rlnamd_pool* p, float* ms_per_replica) {
+  for (size_t i = 0; i < p->rep.size(); i++) ms_per_replica[i] = p->rep[i]->last_ms;
+  return RLNAMD_OK;
+}
+
+/* verification stays on the host; any replica's zkey will do */
+int rlnamd_pool_verify_many(rlnamd_pool* p, size_t n, const uint8_t* proofs, const uint8_t* values_le, size_t n_values,
+                            int threads, uint8_t* ok) {
+  RLN_TRY
+  verify_many_common(p->rep[0]->prover->zkey(), n, proofs, values_le, n_values, threads, ok);
+  RLN_CATCH
+}
+
+// ------------------------------------------------------------------------------------------------ RCCL communicator
+int rlnamd_comm_unique_id(uint8_t id[RLNAMD_COMM_ID_BYTES]) {
+  RLN_TRY
+  require_gpu();
+  static_assert(sizeof(ncclUniqueId) == RLNAMD_COMM_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId u;
+  RLN_NCCL(ncclGetUniqueId(&u));
+  memcpy(id, &u, sizeof(u));
+  RLN_CATCH
+}
+
+int rlnamd_comm_init_rank(const uint8_t id[RLNAMD_COMM_ID_BYTES], int nranks, int rank, rlnamd_comm** out) {
+  RLN_TRY
+  require_gpu();
+  if (nranks < 1 || rank < 0 || rank >= nranks) throw Error("rlnamd_comm_init_rank: bad rank / size");
+  std::unique_ptr<rlnamd_comm> c(new rlnamd_comm);
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof(u));
+  RLN_HIP(hipGetDevice(&c->device));
+  RLN_NCCL(ncclCommInitRank(&c->comm, nranks, u, rank));
+  c->nranks = nranks;
+  c->rank = rank;
+  *out = c.release();
+  RLN_CATCH
+}
+
+int rlnamd_comm_init_all(const int* devices, size_t n_devices, rlnamd_comm** out_array) {
+  RLN_TRY
+  require_gpu();
+  if (!devices || n_devices == 0) throw Error("rlnamd_comm_init_all: no devices");
+  std::vector<ncclComm_t> comms(n_devices);
+  RLN_NCCL(ncclCommInitAll(comms.data(), (int)n_devices, devices));
+  for (size_t i = 0; i < n_devices; i++) {
+    rlnamd_comm* c = new rlnamd_comm;
+    c->comm = comms[i];
+    c->nranks = (int)n_devices;
+    c->rank = (int)i;
+    c->device = devices[i];
+    out_array[i] = c;
+  }
+  RLN_CATCH
+}
+
+void rlnamd_comm_free(rlnamd_comm* c) {
+  if (!c) return;
+  if (c->comm) (void)ncclCommDestroy(c->comm);
+  delete c;
+}
+int rlnamd_comm_rank(rlnamd_comm* c) { return c->rank; }
+int rlnamd_comm_ranks(rlnamd_comm* c) { return c->nranks; }
+
+// One MSM over n_total generated points sharded over the devices of THIS process: a thread per device, each with its
+// own MsmG1 on its slice and its rank of one communicator.  ms[0..3]: max over the devices of sort / buckets /
+// all-gather / combine; ms[4] = wall time of the slowest device including the host wait.
+int rlnamd_msm_generated_multi(const int* devices, size_t n_devices, uint64_t seed, size_t n_total, int repeats,
+                               uint8_t out_xy_le[64], float ms[5]) {
+  RLN_TRY
+  require_gpu();
+  if (!devices || n_devices == 0) throw Error("rlnamd_msm_generated_multi: no devices");
+  const size_t N = n_devices;
+  std::vector<rlnamd_comm*> comms(N, nullptr);
+  if (rlnamd_comm_init_all(devices, N, comms.data()) != RLNAMD_OK) throw Error(rlnamd_last_error());
+  std::vector<std::string> errs(N);
+  std::vector<std::array<float, 5>> t(N);
+  std::vector<std::array<uint8_t, 64>> res(N);
+  std::vector<std::thread> th;
+  for (size_t i = 0; i < N; i++)
+    th.emplace_back([&, i] {
+      try {
+        RLN_HIP(hipSetDevice(devices[i]));
+        size_t lo = n_total * i / N, hi = n_total * (i + 1) / N;
+        MsmG1 m(hi - lo ? hi - lo : 1);
+        m.generate(seed, lo, hi - lo);
+        for (int r = 0; r < std::max(1, repeats); r++) {
+          auto t0 = std::chrono::steady_clock::now();
+          m.run_sharded(comms[i]->comm, (int)N, res[i].data(), t[i].data());
+          t[i][4] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+      } catch (const std::exception& e) {
+        errs[i] = e.what();
+      }
+    });
+  for (auto& x : th) x.join();
+  for (auto* c : comms) rlnamd_comm_free(c);
+  for (size_t i = 0; i < N; i++)
+    if (!errs[i].empty()) throw Error("device " + std::to_string(devices[i]) + ": " + errs[i]);
+  for (size_t i = 1; i < N; i++)
+    if (memcmp(res[i].data(), res[0].data(), 64) != 0) throw Error("ranks disagree on the MSM result");
+  memcpy(out_xy_le, res[0].data(), 64);
+  if (ms)
+    for (int k = 0; k < 5; k++) {
+      ms[k] = 0;
+      for (size_t i = 0; i < N; i++) ms[k] = std::max(ms[k], t[i][k]);
+    }
+  RLN_CATCH
+}
+
+}  // extern "C"

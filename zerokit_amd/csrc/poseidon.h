@@ -52,7 +52,7 @@ struct PoseidonDev {
   void init();
   bool ready = false;
 };
-PoseidonDev& poseidon_dev();  // lazily initialised singleton (per process == per GPU)
+PoseidonDev& poseidon_dev();  // lazily initialised, one per device (the device current on the calling thread)
 
 // device pointers view handed to kernels
 struct PoseidonView {

@@ -1,5 +1,7 @@
 #include "poseidon.h"
 
+#include <mutex>
+
 #include <string.h>
 
 namespace rlnamd {
@@ -258,10 +260,17 @@ void PoseidonDev::init() {
   ready = true;
 }
 
+// one constant set per device: hipMalloc'ed memory belongs to the device that was current, and a process may drive
+// several (rlnamd_pool: one replica per GPU)
 PoseidonDev& poseidon_dev() {
-  static PoseidonDev d;
-  d.init();
-  return d;
+  static std::mutex mu;
+  static PoseidonDev per_device[64];
+  int dev = 0;
+  RLN_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) throw Error("device ordinal out of range");
+  std::lock_guard<std::mutex> lk(mu);
+  per_device[dev].init();
+  return per_device[dev];
 }
 
 PoseidonView poseidon_view(int t) {

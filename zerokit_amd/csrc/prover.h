@@ -80,6 +80,21 @@ class Prover {
   void run_async(size_t n, int mode = PROVE_FULL);
   void sync();
   void sync_measure(bool last_only);
+  // Streamed batches: submit() stages n fresh inputs (+ rs, + the partial points in finish mode) in the slot's pinned
+  // buffer, copies them to the slot's own device buffers on the batch's front-end stream and enqueues the batch; it
+  // returns a ticket (> 0) at once unless all slots() workspace slots are in flight (then it waits for the oldest).
+  // collect() waits for THAT batch only and copies its results out of pinned host memory (any pointer may be null;
+  // partial320 is the result of a PROVE_PARTIAL batch).  A ticket expires when its slot is reused, i.e. slots()
+  // submits later.  This is the path of SURVEY 8(d)'s timed region: H2D of witness inputs -> D2H of proofs.
+  uint64_t submit(size_t n, const uint8_t* inputs, const uint8_t* rs, int mode = PROVE_FULL,
+                  const uint8_t* partial320 = nullptr);
+  void collect(uint64_t ticket, size_t n, uint8_t* proofs, uint8_t* values, uint32_t* errors, uint8_t* coords = nullptr,
+               uint8_t* partial320 = nullptr);
+  void collect_public(uint64_t ticket, size_t n, std::vector<uint8_t>* out_le);
+  int slots() const;
+  // n proofs (any n) through submit / collect in chunks of <= capacity(), results in index order
+  void prove_stream(size_t n, const uint8_t* inputs, const uint8_t* rs, uint8_t* proofs, uint8_t* values,
+                    uint32_t* errors);
   // Partial proofs.  PROVE_PARTIAL: inputs carry only the partial witness (unknown slots zero); the result is
   // four points per proof, canonical affine [pi_a x,y | rho x,y | pi_b x.c0,x.c1,y.c0,y.c1 | pi_c x,y] = 320 B
   // (create_partial_proof_from_assignment, partial_proof.rs:108-179).  PROVE_FINISH: full inputs + (r, s) +
@@ -110,6 +125,8 @@ class Prover {
   void fetch_h(size_t p, std::vector<uint8_t>* h_le);
 
  private:
+  uint64_t enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint8_t* h_rs, const uint8_t* h_pp320);
+  void fetch_public_slot(void* slot, size_t n, std::vector<uint8_t>* out_le);
   struct Impl;
   std::unique_ptr<Impl> d_;
   Zkey zk_;

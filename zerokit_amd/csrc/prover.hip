@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <deque>
 
 #include "fq29.h"
 #include "walk29.h"
@@ -1128,6 +1129,12 @@ struct Slot {
   DevBuf<uint32_t> pp_out;       // partial mode output, 320 B per proof
   uint32_t* h_pp = nullptr;
   int mode = 0;
+  // streamed batches (Prover::submit): every slot owns its inputs, (r, s) and partial points plus the pinned staging
+  // buffer they are copied from, so a caller with a stream of distinct batches never drains the pipeline
+  DevBuf<uint32_t> inputs, rs, pp_in;
+  uint8_t* h_in = nullptr;      // pinned staging: inputs | rs | partial points
+  hipEvent_t evU = nullptr;     // H2D of this slot's inputs done
+  uint64_t ticket = 0;          // submit() ticket of the batch the slot holds (0: resident-input run)
   uint8_t* h_comp = nullptr;    // pinned: every run ends with the proofs + values copied to the host
   uint32_t* h_values = nullptr;
   uint32_t* h_err = nullptr;
@@ -1196,6 +1203,7 @@ struct Prover::Impl {
   uint32_t msm_lds = 0;         // RLNAMD_MSM_WAVES (waves per SIMD the G1 walk may occupy; 0 = no cap)
   int cur = 0;
   Slot* last = nullptr;
+  uint64_t tickets = 0;         // submit() tickets handed out
 
   void sync_all() {
     RLN_HIP(hipStreamSynchronize(sA));
@@ -1802,6 +1810,14 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     S.affB1.alloc(B);
     S.affB2.alloc(B);
     S.pp_out.alloc(B * 80);
+    S.inputs.alloc(B * D.NI * 8);
+    S.rs.alloc(B * 16);
+    S.pp_in.alloc(B * 80);
+    RLN_HIP(hipMemsetAsync(S.inputs.p, 0, S.inputs.bytes(), s));
+    RLN_HIP(hipMemsetAsync(S.rs.p, 0, S.rs.bytes(), s));
+    RLN_HIP(hipMemsetAsync(S.pp_in.p, 0, S.pp_in.bytes(), s));
+    RLN_HIP(hipHostMalloc((void**)&S.h_in, B * ((size_t)D.NI * 32 + 64 + 320), hipHostMallocDefault));
+    RLN_HIP(hipEventCreateWithFlags(&S.evU, hipEventDisableTiming));
     RLN_HIP(hipHostMalloc((void**)&S.h_pp, B * 320, hipHostMallocDefault));
     RLN_HIP(hipHostMalloc((void**)&S.h_comp, B * 128, hipHostMallocDefault));
     RLN_HIP(hipHostMalloc((void**)&S.h_values, B * 160, hipHostMallocDefault));
@@ -1827,6 +1843,8 @@ Prover::~Prover() {
     if (st) (void)hipStreamSynchronize(st);
   for (Slot& S : D.slot) {
     if (S.h_pp) (void)hipHostFree(S.h_pp);
+    if (S.h_in) (void)hipHostFree(S.h_in);
+    if (S.evU) (void)hipEventDestroy(S.evU);
     if (S.h_comp) (void)hipHostFree(S.h_comp);
     if (S.h_values) (void)hipHostFree(S.h_values);
     if (S.h_err) (void)hipHostFree(S.h_err);
@@ -1892,15 +1910,112 @@ static void launch_ntt(Fr* data, const uint32_t* tw, int logn, const uint32_t* f
 // Enqueue one batch; returns as soon as the work is queued.  Stage A (stream sA): proof values, witness,
 // matvec, NTTs.  Stage B (sB): digit recoding and the two MSMs.  Stage C (sC): two-level reduction, the
 // three finalize kernels, D2H of proofs + values into pinned memory.  Consecutive batches alternate slots.
-void Prover::run_async(size_t n, int mode) {
-  if (n == 0) return;
+void Prover::run_async(size_t n, int mode) { enqueue(n, mode, nullptr, nullptr, nullptr); }
+
+// Streamed batch ("H2D of witness inputs -> D2H of proofs"; the reference takes a fresh witness per call,
+// protocol/proof.rs:753-777): the inputs go through the slot's pinned staging buffer to the slot's own device buffers on
+// the front-end stream of this batch, so consecutive submits of DIFFERENT batches overlap like run_async's do.  Blocks
+// only when every workspace slot is in flight (then until the oldest batch has finished).
+uint64_t Prover::submit(size_t n, const uint8_t* inputs, const uint8_t* rs, int mode, const uint8_t* partial320) {
+  if (n == 0) throw Error("empty batch");
+  if (!inputs || !rs) throw Error("submit: inputs and rs are required");
+  if (mode == PROVE_FINISH && !partial320) throw Error("submit: finish mode needs the partial points");
+  return enqueue(n, mode, inputs, rs, partial320);
+}
+
+void Prover::collect(uint64_t ticket, size_t n, uint8_t* proofs, uint8_t* values, uint32_t* errors, uint8_t* coords,
+                     uint8_t* partial320) {
+  Impl& D = *d_;
+  Slot* Sp = nullptr;
+  for (int k = 0; k < D.nslot; k++)
+    if (D.slot[k].used && D.slot[k].ticket == ticket && ticket != 0) Sp = &D.slot[k];
+  if (!Sp) throw Error("collect: unknown or expired ticket (its workspace slot has been reused)");
+  Slot& S = *Sp;
+  if (n > S.n) throw Error("collect: more proofs requested than the batch holds");
+  RLN_HIP(hipEventSynchronize(S.evC));
+  if (S.mode == PROVE_PARTIAL) {
+    if (partial320) memcpy(partial320, S.h_pp, n * 320);
+  } else {
+    if (proofs) memcpy(proofs, S.h_comp, n * 128);
+    if (values) {
+      if (D.have_values_kernel)
+        memcpy(values, S.h_values, n * 160);
+      else if (D.ni == 6) {
+        std::vector<uint8_t> pub;
+        fetch_public_slot(&S, n, &pub);
+        memcpy(values, pub.data(), n * 160);
+      } else
+        memset(values, 0, n * 160);
+    }
+    if (coords) RLN_HIP(hipMemcpy(coords, S.coords.p, n * 256, hipMemcpyDeviceToHost));
+  }
+  if (errors) memcpy(errors, S.h_err, n * 4);
+}
+
+void Prover::collect_public(uint64_t ticket, size_t n, std::vector<uint8_t>* out_le) {
+  Impl& D = *d_;
+  for (int k = 0; k < D.nslot; k++)
+    if (D.slot[k].used && D.slot[k].ticket == ticket && ticket != 0) {
+      if (n > D.slot[k].n) throw Error("collect: more proofs requested than the batch holds");
+      RLN_HIP(hipEventSynchronize(D.slot[k].evC));
+      fetch_public_slot(&D.slot[k], n, out_le);
+      return;
+    }
+  throw Error("collect: unknown or expired ticket (its workspace slot has been reused)");
+}
+
+int Prover::slots() const { return d_->nslot; }
+
+// Any number of proofs through the streamed path: chunks of at most capacity() proofs, as many in flight as there are
+// workspace slots, results written in index order.  This is what a caller with more proofs than one workspace holds
+// gets instead of an upload / run / download loop that drains the pipeline after every chunk.
+void Prover::prove_stream(size_t n, const uint8_t* inputs, const uint8_t* rs, uint8_t* proofs, uint8_t* values,
+                          uint32_t* errors) {
+  Impl& D = *d_;
+  struct Pending { uint64_t ticket; size_t off, cnt; };
+  std::deque<Pending> q;
+  const size_t NIB = (size_t)D.NI * 32;
+  auto take = [&]() {
+    Pending f = q.front();
+    q.pop_front();
+    collect(f.ticket, f.cnt, proofs ? proofs + f.off * 128 : nullptr, values ? values + f.off * 160 : nullptr,
+            errors ? errors + f.off : nullptr);
+  };
+  try {
+    for (size_t off = 0; off < n; off += B_) {
+      size_t cnt = std::min(B_, n - off);
+      if ((int)q.size() == D.nslot) take();   // the slot the next submit reuses
+      q.push_back({submit(cnt, inputs + off * NIB, rs + off * 64), off, cnt});
+    }
+    while (!q.empty()) take();
+  } catch (...) {
+    D.sync_all();
+    throw;
+  }
+}
+
+uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint8_t* h_rs, const uint8_t* h_pp320) {
+  if (n == 0) return 0;
   if (n > B_) throw Error("batch larger than the prover workspace (max_batch)");
   if (mode < PROVE_FULL || mode > PROVE_FINISH) throw Error("unknown prover mode");
   Impl& D = *d_;
   const Impl::Plan& P1 = D.plan1[mode];
   const Impl::Plan& P2 = D.plan2[mode];
   Slot& S = D.slot[D.cur];
+  const bool streamed = h_inputs != nullptr;
+  if (streamed) {
+    if (D.wgiven_n) throw Error("upload_witness applies to the resident-input run that follows it, not to submit");
+    // the slot's previous batch must be finished before its staging buffer (and its result buffers) are reused
+    if (S.used) RLN_HIP(hipEventSynchronize(S.evC));
+    memcpy(S.h_in, h_inputs, n * (size_t)D.NI * 32);
+    memcpy(S.h_in + B_ * (size_t)D.NI * 32, h_rs, n * 64);
+    if (h_pp320) memcpy(S.h_in + B_ * ((size_t)D.NI * 32 + 64), h_pp320, n * 320);
+  }
+  const uint32_t* in_p = streamed ? S.inputs.p : D.inputs.p;
+  const uint32_t* rs_p = streamed ? S.rs.p : D.rs.p;
+  const uint32_t* pp_p = (streamed && h_pp320) ? S.pp_in.p : D.pp_in.p;
   S.mode = mode;
+  S.ticket = streamed ? ++D.tickets : 0;
   D.cur = (D.cur + 1) % D.nslot;
   // Front end in two pipeline stages on their own streams: A1 = graph interpreter (16 latency-bound waves per 1024
   // proofs, ~28 ms), A2 = mat-vec + NTTs + quotient (throughput kernels squeezed in beside the MSM, ~25 ms contended).
@@ -1913,6 +2028,13 @@ void Prover::run_async(size_t n, int mode) {
   const uint32_t nbp = pg * 64;  // padded lanes compute on stale / zero inputs; results ignored
   // ---------------- stage A
   if (S.used) RLN_HIP(hipStreamWaitEvent(sA, S.evC, 0));  // slot free again
+  if (streamed) {
+    RLN_HIP(hipMemcpyAsync(S.inputs.p, S.h_in, n * (size_t)D.NI * 32, hipMemcpyHostToDevice, sA));
+    RLN_HIP(hipMemcpyAsync(S.rs.p, S.h_in + B_ * (size_t)D.NI * 32, n * 64, hipMemcpyHostToDevice, sA));
+    if (h_pp320)
+      RLN_HIP(hipMemcpyAsync(S.pp_in.p, S.h_in + B_ * ((size_t)D.NI * 32 + 64), n * 320, hipMemcpyHostToDevice, sA));
+    RLN_HIP(hipEventRecord(S.evU, sA));
+  }
   RLN_HIP(hipEventRecord(S.t[1], sA));
   if (D.wit29) {
     static const bool prof = env_int("RLNAMD_WIT_PROF", 0) != 0;   // diagnostic: cycles per node class, on stderr
@@ -1920,7 +2042,7 @@ void Prover::run_async(size_t n, int mode) {
       DevBuf<unsigned long long>& pb = D.wit_prof;
       if (!pb.p) pb.alloc(16);
       hipLaunchKernelGGL(k_witness29<true>, dim3(pg), dim3(64), WIT29_LDS_BYTES, sA, D.nodes29.p, D.nprog29,
-                         D.consts29.p, (uint32_t)graph_.constants.size(), D.inputs.p, D.NI, S.V29.p, S.err.p, B, nbp, pb.p);
+                         D.consts29.p, (uint32_t)graph_.constants.size(), in_p, D.NI, S.V29.p, S.err.p, B, nbp, pb.p);
       unsigned long long h[16];
       RLN_HIP(hipStreamSynchronize(sA));
       RLN_HIP(hipMemcpy(h, pb.p, sizeof(h), hipMemcpyDeviceToHost));
@@ -1928,12 +2050,12 @@ void Prover::run_async(size_t n, int mode) {
               h[0], h[4], h[1], h[5], h[2], h[6], h[3], h[7], h[8], h[9] / 1e5, h[9] ? 100.0 * h[8] / h[9] : 0.0);
     } else
     hipLaunchKernelGGL(k_witness29<false>, dim3(pg), dim3(64), WIT29_LDS_BYTES, sA, D.nodes29.p, D.nprog29,
-                       D.consts29.p, (uint32_t)graph_.constants.size(), D.inputs.p, D.NI, S.V29.p, S.err.p, B, nbp, nullptr);
+                       D.consts29.p, (uint32_t)graph_.constants.size(), in_p, D.NI, S.V29.p, S.err.p, B, nbp, nullptr);
     hipLaunchKernelGGL(k_v29_to_fr, dim3(pg, D.nstore29), dim3(64, 1), 0, sA, S.V29.p, D.slot2node.p, D.nstore29, S.V.p, B,
                        nbp);
   } else {
     hipLaunchKernelGGL(k_witness, dim3(pg), dim3(64), WIT_RING * 8 * 64 * 4 + WIT_LDS_CONSTS * 32, sA, D.nodes.p, D.N, D.consts.p,
-                       (uint32_t)graph_.constants.size(), D.inputs.p, D.NI, S.V.p,
+                       (uint32_t)graph_.constants.size(), in_p, D.NI, S.V.p,
                        S.err.p, B, nbp);
   }
   if (D.wgiven_n) {
@@ -1977,7 +2099,7 @@ void Prover::run_async(size_t n, int mode) {
   }
   RLN_HIP(hipEventRecord(S.t[5], sR));
   hipLaunchKernelGGL(k_recode, dim3(pg, D.NS + D.n + 3), dim3(64, 1), 0, sR, S.V.p, D.sig2node.p, D.NS,
-                     S.abc.p, D.n, D.rs.p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nbp);
+                     S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nbp);
   RLN_HIP(hipEventRecord(S.t[6], sR));
   // ---------------- stage B
   if (D.recode_front) {
@@ -2033,9 +2155,10 @@ void Prover::run_async(size_t n, int mode) {
     RLN_HIP(hipStreamWaitEvent(D.sC, S.evC, 0));
     RLN_HIP(hipStreamWaitEvent(sV, S.evC, 0));
   }
+  if (streamed) RLN_HIP(hipStreamWaitEvent(sV, S.evU, 0));
   RLN_HIP(hipEventRecord(S.t[0], sV));
   if (D.have_values_kernel)
-    hipLaunchKernelGGL(k_proof_values, dim3(pg), dim3(64), 0, sV, D.inputs.p, D.NI, D.slots, poseidon_view(2),
+    hipLaunchKernelGGL(k_proof_values, dim3(pg), dim3(64), 0, sV, in_p, D.NI, D.slots, poseidon_view(2),
                        poseidon_view(3), poseidon_view(4), S.values.p, nbp);
   RLN_HIP(hipEventRecord(S.t[13], sV));
   RLN_HIP(hipEventRecord(S.evV, sV));
@@ -2064,10 +2187,10 @@ void Prover::run_async(size_t n, int mode) {
     RLN_HIP(hipMemcpyAsync(S.h_pp, S.pp_out.p, n * 320, hipMemcpyDeviceToHost, D.sC));
   } else {
     if (mode == PROVE_FINISH)
-      hipLaunchKernelGGL(k_add_partial, dim3(pg, 4), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, D.pp_in.p, B, nbp);
+      hipLaunchKernelGGL(k_add_partial, dim3(pg, 4), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, pp_p, B, nbp);
     hipLaunchKernelGGL(k_fin_affine, dim3(pg, 3), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
                        S.affB2.p, B, nbp);
-    hipLaunchKernelGGL(k_fin_smul, dim3(pg, 2), dim3(64), 0, D.sC, S.affA.p, S.affB1.p, D.rs.p, S.tbl.p, S.prod.p, B,
+    hipLaunchKernelGGL(k_fin_smul, dim3(pg, 2), dim3(64), 0, D.sC, S.affA.p, S.affB1.p, rs_p, S.tbl.p, S.prod.p, B,
                        nbp);
     hipLaunchKernelGGL(k_fin_out, dim3(pg), dim3(64), 0, D.sC, S.sums1.p, S.prod.p, S.affA.p, S.affB2.p, S.coords.p,
                        S.comp.p, B, nbp);
@@ -2081,6 +2204,7 @@ void Prover::run_async(size_t n, int mode) {
   S.used = true;
   S.n = n;
   D.last = &S;
+  return S.ticket;
 }
 
 void Prover::sync() { sync_measure(false); }
@@ -2179,9 +2303,16 @@ void Prover::fetch_public(size_t n, std::vector<uint8_t>* out_le) {
   Impl& D = *d_;
   sync();
   if (!D.last || n > B_) throw Error("no resident run to read from");
+  fetch_public_slot(D.last, n, out_le);
+}
+
+// the slot's batch must have finished (its evC passed); sC is in stream order behind it
+void Prover::fetch_public_slot(void* slot, size_t n, std::vector<uint8_t>* out_le) {
+  Impl& D = *d_;
+  Slot& S = *(Slot*)slot;
   const uint32_t npub = D.ni - 1;
   DevBuf<uint32_t> tmp(n * npub * 8);
-  hipLaunchKernelGGL(k_public_signals, dim3(div_up(n, 64), div_up(npub, 4)), dim3(64, 4), 0, D.sC, D.last->V.p,
+  hipLaunchKernelGGL(k_public_signals, dim3(div_up(n, 64), div_up(npub, 4)), dim3(64, 4), 0, D.sC, S.V.p,
                      D.sig2node.p, npub, (uint32_t)B_, (uint32_t)n, tmp.p);
   out_le->resize(n * npub * 32);
   RLN_HIP(hipMemcpyAsync(out_le->data(), tmp.p, out_le->size(), hipMemcpyDeviceToHost, D.sC));
