@@ -135,9 +135,8 @@ def measure_config5(comm, rank, world, steps=3, log2n=24):
     """BASELINE config 5: one 2^24-point G1 MSM split by point index over the ranks of `comm`; local Pippenger to the
     window sums, ncclAllGather through the C ABI, local fold; compared with the scalar-side closed form"""
     from zerokit_amd.batch import MsmG1
-    from zerokit_amd.distributed import shard_bounds
     n_total = 1 << log2n
-    lo, hi = shard_bounds(n_total, world)[rank]
+    lo, hi = n_total * rank // world, n_total * (rank + 1) // world     # contiguous slices by point index
     m = MsmG1(hi - lo)
     try:
         m.generate(0xC0FFEE, lo, hi - lo)
@@ -162,7 +161,7 @@ def measure_config5(comm, rank, world, steps=3, log2n=24):
 
 
 def merkle_main(args):
-    print(json.dumps(measure_config3(max(args.steps, 1))))
+    OUT.emit(measure_config3(max(args.steps, 1)))
 
 
 def make_comm(rank, world, dist):
@@ -179,20 +178,21 @@ def msm_main(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
-    import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    from zerokit_amd import lib
+    from zerokit_amd import lib        # before torch: see main()
     from zerokit_amd._native import check
     check(lib().rlnamd_set_device(local_rank))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     comm = make_comm(rank, world, dist)
     out = measure_config5(comm, rank, world, max(args.steps, 1), int(os.environ.get("RLNAMD_MSM_LOG2", "24")))
     comm.close()
     if rank == 0:
-        print(json.dumps(out))
+        OUT.emit(out)
     if world > 1:
         dist.destroy_process_group()
 
@@ -240,7 +240,7 @@ def pool_main(args):
     value = n * args.steps / elapsed
     name = C.create_string_buffer(128)
     lib().rlnamd_device_name(name, 128)
-    print(json.dumps({
+    OUT.emit({
         "metric": "RLN Groth16 proofs/sec (BN254, h=20)", "value": round(value, 2), "unit": "proofs/s", "n_gpus": N,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -253,13 +253,32 @@ def pool_main(args):
                    "table_gib": round(pool.info.table_bytes / 2**30, 2), "device": name.value.decode(),
                    "init_s": round(init_s, 2), "verified": bool(ok), "verified_sample": len(idx)},
         "achieved_GBps_whole_proof": round(value * BYTES_PER_PROOF / 1e9, 3),
-        "replica_ms_last_step": [round(x, 2) for x in pool.last_ms()]}))
+        "replica_ms_last_step": [round(x, 2) for x in pool.last_ms()]})
     pool.close()
     if not ok:
         sys.exit(3)
 
 
+class OneLineStdout:
+    """The contract is ONE JSON line on stdout.  Native libraries print there too (RCCL's version banner at communicator
+    creation), so file descriptor 1 points at stderr for the whole run and the line goes to the saved descriptor."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self.fd = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(self, obj):
+        sys.stdout.flush()
+        os.write(self.fd, (json.dumps(obj) + "\n").encode())
+
+
+OUT = None
+
+
 def main():
+    global OUT
+    OUT = OneLineStdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -284,19 +303,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
-    import torch  # plumbing only: device selection, barrier, max-reduce
-    import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    use_dist = under_torchrun                              # under torchrun the RCCL group is always created
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
+    # librln.so first: it then brings in the HIP runtime it was built for (/opt/rocm), and torch -- needed only under
+    # torchrun, for the barrier and the max over ranks -- binds to the same libamdhip64.so.7 instead of the older one
+    # bundled in its wheel.  A single-GPU run imports no torch at all.
     from zerokit_amd import lib, workload
     from zerokit_amd._native import check
     from zerokit_amd.batch import BatchProver
     check(lib().rlnamd_set_device(local_rank))
+    use_dist = under_torchrun                              # under torchrun the RCCL group is always created
+    torch = dist = None
+    if use_dist:
+        import torch  # plumbing only: barrier, max-reduce
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     name = C.create_string_buffer(128)
     lib().rlnamd_device_name(name, 128)
 
@@ -328,8 +350,9 @@ def main():
                                                                        "path_elements", "identity_path_index")} for w in ws]))
 
     def sync():
-        torch.cuda.synchronize()
+        prover.sync()                     # every stream of the prover drained (hipStreamSynchronize on each)
         if use_dist:
+            torch.cuda.synchronize()
             dist.barrier()
 
     results = {}                      # batch index -> (proofs, values, errors) of its LAST pass
@@ -348,7 +371,6 @@ def main():
             results[kk] = prover.collect_raw(t, B)
 
     pump(args.warmup * per_step)
-    prover.sync()
     prover.walk_clock_mhz()           # reset the clock tap: what follows is the timed region's clock
     results.clear()
     sync()
@@ -488,7 +510,7 @@ def main():
             line["rccl_ranks"] = side["config5"]["rccl_ranks"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ws0, rs0)
-        print(json.dumps(line))
+        OUT.emit(line)
     if use_dist:
         dist.destroy_process_group()
     if not ok:

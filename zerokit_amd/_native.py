@@ -1,7 +1,10 @@
 """ctypes bindings of the C ABI in include/rln.h + include/rln_amd.h (zerokit_amd/lib/librln.so).
 
-The library is the product; this file only declares signatures.  It is loaded with RTLD_GLOBAL after torch
-(when torch is present) so both share one HIP runtime (same SONAME libamdhip64.so.7)."""
+The library is the product; this file only declares signatures.  It is loaded with RTLD_GLOBAL so that it and torch
+(when a program uses both) share one HIP runtime -- whichever of the two is loaded first brings in its
+libamdhip64.so.7 and the other binds to it (same SONAME).  Load this library FIRST where throughput matters: the
+runtime bundled in the torch wheel (HIP 7.0) ran the streamed path 17 % slower than ROCm 7.2's in a same-box A/B
+(profiles/r3_rocprof_summary.md); bench.py does, and imports torch only under torchrun."""
 import ctypes as C
 import os
 

@@ -1110,6 +1110,15 @@ __global__ void k_scatter_witness(const uint32_t* __restrict__ given, const uint
   if (j == 0) err[p] = WERR_NONE;
 }
 
+// Streamed inputs: the batch's inputs, (r, s) and partial points move from the slot's pinned staging buffer to its device
+// buffers by a kernel on the batch's own front-end stream (the pinned pages are device-visible).  A hipMemcpyAsync
+// here goes through the runtime's copy path (SDMA / blit + cross-queue signalling), which with the HIP runtime torch
+// bundles (7.0) cost 8 ms per 1024-proof batch against 0 with ROCm 7.2's -- the same-box A/B is in profiles/r3_*.
+__global__ void __launch_bounds__(256) k_stage_in(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
+}
+
 // =====================================================================================================
 // host side
 // =====================================================================================================
@@ -2029,10 +2038,18 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // ---------------- stage A
   if (S.used) RLN_HIP(hipStreamWaitEvent(sA, S.evC, 0));  // slot free again
   if (streamed) {
-    RLN_HIP(hipMemcpyAsync(S.inputs.p, S.h_in, n * (size_t)D.NI * 32, hipMemcpyHostToDevice, sA));
-    RLN_HIP(hipMemcpyAsync(S.rs.p, S.h_in + B_ * (size_t)D.NI * 32, n * 64, hipMemcpyHostToDevice, sA));
-    if (h_pp320)
-      RLN_HIP(hipMemcpyAsync(S.pp_in.p, S.h_in + B_ * ((size_t)D.NI * 32 + 64), n * 320, hipMemcpyHostToDevice, sA));
+    static const bool h2d_kernel = env_int("RLNAMD_H2D_KERNEL", 1) != 0;
+    auto h2d = [&](void* dst, const uint8_t* src, size_t bytes) {   // sizes are multiples of 32
+      if (h2d_kernel)
+        hipLaunchKernelGGL(k_stage_in, dim3(div_up(bytes / 16, 256)), dim3(256), 0, sA, (const uint4*)src, (uint4*)dst,
+                           (uint32_t)(bytes / 16));
+      else
+        RLN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, sA));
+    };
+    h2d(S.inputs.p, S.h_in, n * (size_t)D.NI * 32);
+    h2d(S.rs.p, S.h_in + B_ * (size_t)D.NI * 32, n * 64);
+    if (h_pp320) h2d(S.pp_in.p, S.h_in + B_ * ((size_t)D.NI * 32 + 64), n * 320);
+    RLN_HIP(hipGetLastError());
     RLN_HIP(hipEventRecord(S.evU, sA));
   }
   RLN_HIP(hipEventRecord(S.t[1], sA));
