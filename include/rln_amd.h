@@ -82,6 +82,9 @@ typedef struct {
   uint64_t g1_rows, g2_rows;          /* finite points of the G1 / G2 walk (table rows) */
 } rlnamd_prover_info;
 int rlnamd_prover_get_info(rlnamd_prover* p, rlnamd_prover_info* info);
+/* the same for the prover behind an object of include/rln.h (FFI_RLN_t* / FFI_RLNV3_t*, passed as void*): shows how
+ * the "window_bits" / "max_batch" keys of the config_path JSON (or RLNAMD_WINDOW_BITS / RLNAMD_MAX_BATCH) sized it */
+int rlnamd_ffi_prover_info(const void* ffi_rln, rlnamd_prover_info* info);
 /* offset/len of a named input signal in the inputs buffer (iden3calc.rs:122-146); returns RLNAMD_ERR if absent */
 int rlnamd_prover_input_slot(rlnamd_prover* p, const char* name, uint32_t* offset, uint32_t* len);
 /* inputs: n * inputs_size * 32 bytes (slot 0 must hold 1); rs: n * 64 bytes (r then s). */

@@ -431,3 +431,62 @@ def test_persistent_tree_config(tmp_path):
     # a missing config file is the default (temporary) tree, as `.unwrap_or_default()` in ffi_rln.rs:45
     r = RLN(20, str(tmp_path / "does_not_exist.json"))
     assert r.leaves_set() == 0
+
+
+def test_config_path_sizes_the_prover_and_batch_streams_past_max_batch(tmp_path):
+    """the `window_bits` / `max_batch` keys of the config_path JSON (beside the PmTreeConfig keys of
+    pm_tree_adapter.rs:139-174, which stay honoured) size the prover behind ffi_rln_new, and
+    ffi_generate_rln_proofs_batch streams n > max_batch proofs through the workspace slots: 300 proofs with
+    max_batch 64 (4 full chunks + 44, more chunks than slots) equal the extension API's bytes and the golden (44, 77)
+    proof in position 0; the multi message-id circuit takes the same path"""
+    import json
+    import os
+    from zerokit_amd import workload
+    from zerokit_amd.batch import BatchProver, resource_paths
+    from zerokit_amd.public import RLN, RLNWitnessInput
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfgp = tmp_path / "cfg.json"
+    cfgp.write_text(json.dumps({"window_bits": 10, "max_batch": 64, "temporary": True, "cache_capacity": 1073741824}))
+    rln = RLN(20, tree_config=str(cfgp))
+    info = rln.prover_info()
+    assert int(info.capacity) == 64 and int(info.window_bits) == 10
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "rln_h20_vectors.json")))["cases"]
+    gold = next(c for c in cases if c["name"] == "survey_appendix_d")
+    gw = gold["witness"]
+    n = 300
+    ws, rs = workload.config2_range(40000, n)
+    ws[0] = dict(identity_secret=int(gw["identity_secret"]), user_message_limit=int(gw["user_message_limit"]),
+                 message_id=int(gw["message_id"]), path_elements=[int(t) for t in gw["path_elements"]],
+                 identity_path_index=[int(t) for t in gw["identity_path_index"]], x=int(gw["x"]),
+                 external_nullifier=int(gw["external_nullifier"]))
+    rs[0] = (int(gold["r"]), int(gold["s"]))
+    wi = [RLNWitnessInput(w["identity_secret"], w["user_message_limit"], w["message_id"], w["path_elements"],
+                          w["identity_path_index"], w["x"], w["external_nullifier"]) for w in ws]
+    proofs = rln.generate_rln_proofs_batch(wi, rs)
+    p = BatchProver(max_batch=128)
+    ref = p.prove_stream(ws, rs)
+    p.close()
+    got = [pr.to_bytes_le() for pr in proofs]
+    assert all(r["proof"] in g for r, g in zip(ref, got))
+    assert bytes.fromhex(gold["proof_compressed"]) in got[0]
+    for i in (0, 63, 64, 299):
+        v = proofs[i].values()
+        assert v.y == ref[i]["values"]["y"] and v.nullifier == ref[i]["values"]["nullifier"]
+        assert rln.verify_with_roots(proofs[i], ws[i]["x"], [])   # no roots given: the zk proof and x only
+    del proofs, rln
+    # multi message-id circuit through the same streaming path
+    zp, gp = resource_paths(20, multi=True)
+    z, g = open(zp, "rb").read(), open(gp, "rb").read()
+    cfgp.write_text(json.dumps({"max_batch": 64}))
+    m = RLN.new_with_params(20, z, g, tree_config=str(cfgp))
+    assert int(m.prover_info().capacity) == 64
+    mws = []
+    for i in range(150):
+        w = ws[i + 1]
+        mws.append(RLNWitnessInput.new_multi(w["identity_secret"], 100, [10 + i % 80, 3, 5, 7], w["path_elements"],
+                                             w["identity_path_index"], w["x"], w["external_nullifier"],
+                                             [True, i % 2 == 0, False, True]))
+    a = m.generate_rln_proofs_batch(mws, rs[:150])           # 64 + 64 + 22: streamed
+    b = [m.generate_rln_proofs_batch([mws[i]], [rs[i]])[0] for i in (0, 64, 149)]   # one at a time: resident path
+    for k, i in enumerate((0, 64, 149)):
+        assert a[i].to_bytes_le() == b[k].to_bytes_le()

@@ -137,6 +137,7 @@ SIGNATURES = {
     "rlnamd_msm_window_sums_bytes": (C.c_size_t, []),
     "rlnamd_msm_run": (C.c_int, [P, C.c_char_p, C.POINTER(C.c_float)]),
     "rlnamd_msm_combine": (C.c_int, [P, C.c_char_p, C.c_size_t, C.c_char_p]),
+    "rlnamd_ffi_prover_info": (C.c_int, [P, C.POINTER(ProverInfo)]),
     "rlnamd_prover_slots": (C.c_int, [P]),
     "rlnamd_prover_submit": (C.c_int, [P, C.c_size_t, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p,
                                       C.POINTER(C.c_uint64)]),

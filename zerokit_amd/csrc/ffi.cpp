@@ -18,12 +18,14 @@
 #include <algorithm>
 #include <fstream>
 #include <memory>
+#include <deque>
 #include <mutex>
 #include <random>
 #include <string>
 #include <vector>
 
 #include "../../include/rln_amd.h"
+#include "capi_util.h"
 #include "common.h"
 #include "keccak.h"
 #include "merkle.h"
@@ -396,7 +398,19 @@ struct TreeConfig {
   bool has_path = false;
   bool temporary = true;   // DEFAULT_TEMPORARY (pm_tree_adapter.rs:67)
   long tree_depth = -1;
+  // prover sizing, keys of THIS backend in the same JSON object (the reference's PmTreeConfig::from_str picks its keys
+  // out of a serde_json::Value and ignores the rest, so one config file serves both): "window_bits" = the comb schedule
+  // of rlnamd_prover_new (7150114 = the 228 GiB bench schedule), "max_batch" = workspace capacity in proofs.
+  // 0 / absent: RLNAMD_WINDOW_BITS / RLNAMD_MAX_BATCH, else the small defaults (c = 8 tables, 64 proofs).
+  long window_bits = 0, max_batch = 0;
   bool persistent() const { return !temporary && has_path; }
+  ProverConfig prover_config() const {
+    ProverConfig cfg;
+    const char* mb = getenv("RLNAMD_MAX_BATCH");
+    cfg.max_batch = max_batch > 0 ? (size_t)max_batch : (mb && *mb ? (size_t)atoll(mb) : 64);
+    cfg.window_bits = window_bits > 0 ? (int)window_bits : 0;   // 0: Prover takes RLNAMD_WINDOW_BITS or c = 8
+    return cfg;
+  }
 };
 
 // flat JSON object with string / number / bool / null values (PmTreeConfig::from_str, pm_tree_adapter.rs:139-176)
@@ -446,7 +460,10 @@ TreeConfig parse_tree_config(const std::string& js) {
     } else if (isdigit((unsigned char)js[i]) || js[i] == '-') {
       size_t j = i;
       while (j < js.size() && (isdigit((unsigned char)js[j]) || strchr("+-.eE", js[j]))) j++;
-      if (key == "tree_depth") c.tree_depth = atol(js.substr(i, j - i).c_str());
+      long num = atol(js.substr(i, j - i).c_str());
+      if (key == "tree_depth") c.tree_depth = num;
+      if (key == "window_bits") c.window_bits = num;
+      if (key == "max_batch") c.max_batch = num;
       i = j;
     } else {
       throw bad("expected value");
@@ -509,6 +526,17 @@ struct FFI_RLN {
     if (depth > 30)  // the dense HBM-resident tree holds 2^(depth+1) - 1 nodes of 32 B: depth 30 is 64 GiB
       throw Error("Merkle tree error: Tree depth exceeds maximum allowed (must be <= 30 for the HBM-resident tree)");
     uint8_t zero[32] = {0};
+    // The replacement is built beside the old tree so that a failure changes nothing -- unless the device cannot hold
+    // both (depth 28: 16 GiB each, next to up to 228 GiB of comb tables): then the old tree goes first and the reset is
+    // no longer atomic (a failure after this point leaves an empty depth-0 tree behind, reported by the error).
+    {
+      size_t free_b = 0, total_b = 0;
+      const size_t need = ((size_t)64 << depth) + ((size_t)1 << 26);   // 2^(depth+1) nodes of 32 B + slack
+      if (tree.depth > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < need) {
+        MerkleTreeDev empty;
+        tree = std::move(empty);
+      }
+    }
     MerkleTreeDev fresh;
     fresh.init((int)depth, zero);
     std::vector<uint8_t> fresh_set((size_t)1 << depth, 0);
@@ -767,32 +795,77 @@ void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CF
   const size_t ni = P.inputs_per_proof();
   for (size_t i = 0; i < n; i++) check_against_graph(P, *ws[i]);
   const bool multi = n > 0 && ws[0]->multi;
-  size_t done = 0;
   std::vector<FFI_RLNProof*> made;
+  const size_t npub = P.num_public(), mo = P.graph().max_out;
+  auto pack = [&](size_t off, size_t m, std::vector<uint8_t>& inputs, std::vector<uint8_t>& rsb) {
+    inputs.assign(m * ni * 32, 0);
+    rsb.resize(m * 64);
+    for (size_t i = 0; i < m; i++) {
+      fill_inputs(P, *ws[off + i], inputs.data() + i * ni * 32);
+      CFr r = rs ? rs[2 * (off + i)] : random_fr();      // proof.rs:743-745
+      CFr s = rs ? rs[2 * (off + i) + 1] : random_fr();
+      memcpy(rsb.data() + i * 64, r.le, 32);
+      memcpy(rsb.data() + i * 64 + 32, s.le, 32);
+    }
+  };
   try {
-    while (done < n) {
-      size_t m = std::min(n - done, P.capacity());
-      std::vector<uint8_t> inputs(m * ni * 32), rsb(m * 64);
-      for (size_t i = 0; i < m; i++) {
-        fill_inputs(P, *ws[done + i], inputs.data() + i * ni * 32);
-        CFr r = rs ? rs[2 * (done + i)] : random_fr();      // proof.rs:743-745
-        CFr s = rs ? rs[2 * (done + i) + 1] : random_fr();
-        memcpy(rsb.data() + i * 64, r.le, 32);
-        memcpy(rsb.data() + i * 64 + 32, s.le, 32);
-      }
-      std::vector<ProofOut> po(m);
-      P.prove(m, inputs.data(), rsb.data(), po.data());
+    if (n <= P.capacity()) {
+      // one batch: the latency path (a single proof walks with lanes = chunks, see Prover::run_async)
+      std::vector<uint8_t> inputs, rsb;
+      pack(0, n, inputs, rsb);
+      std::vector<ProofOut> po(n);
+      P.prove(n, inputs.data(), rsb.data(), po.data());
       std::vector<uint8_t> pub;
-      if (multi) P.fetch_public(m, &pub);  // ys, root, nullifiers, x, ext, selectors (witness.rs:777-802)
-      for (size_t i = 0; i < m; i++) {
+      if (multi) P.fetch_public(n, &pub);  // ys, root, nullifiers, x, ext, selectors (witness.rs:777-802)
+      for (size_t i = 0; i < n; i++) {
         if (po[i].error) throw Error("Error calculating witness: graph evaluation failed (code " +
                                      std::to_string(po[i].error) + ")");
         std::unique_ptr<FFI_RLNProof> pr(new FFI_RLNProof);
         fill_outputs(po[i], pr.get());
-        if (multi) values_from_public(pub.data() + i * P.num_public() * 32, P.graph().max_out, &pr->values);
+        if (multi) values_from_public(pub.data() + i * npub * 32, mo, &pr->values);
         made.push_back(pr.release());
       }
-      done += m;
+    } else {
+      // more proofs than one workspace holds: chunks of capacity() streamed through submit / collect, every workspace
+      // slot in flight -- the host packs chunk k + 1 while the device proves chunk k, nothing drains in between
+      struct Pending { uint64_t ticket; size_t m; };
+      std::deque<Pending> q;
+      std::vector<uint8_t> inputs, rsb, proofs, values, pub;
+      std::vector<uint32_t> errs;
+      auto take = [&]() {
+        Pending f = q.front();
+        q.pop_front();
+        proofs.resize(f.m * 128);
+        values.resize(f.m * 160);
+        errs.resize(f.m);
+        P.collect(f.ticket, f.m, proofs.data(), values.data(), errs.data());
+        if (multi) P.collect_public(f.ticket, f.m, &pub);
+        for (size_t i = 0; i < f.m; i++) {
+          if (errs[i]) throw Error("Error calculating witness: graph evaluation failed (code " + std::to_string(errs[i]) + ")");
+          std::unique_ptr<FFI_RLNProof> pr(new FFI_RLNProof);
+          memcpy(pr->proof, proofs.data() + 128 * i, 128);
+          const uint8_t* v = values.data() + 160 * i;
+          memcpy(pr->values.y.le, v, 32);
+          memcpy(pr->values.root.le, v + 32, 32);
+          memcpy(pr->values.nullifier.le, v + 64, 32);
+          memcpy(pr->values.x.le, v + 96, 32);
+          memcpy(pr->values.external_nullifier.le, v + 128, 32);
+          if (multi) values_from_public(pub.data() + i * npub * 32, mo, &pr->values);
+          made.push_back(pr.release());
+        }
+      };
+      try {
+        for (size_t off = 0; off < n; off += P.capacity()) {
+          size_t m = std::min(n - off, P.capacity());
+          pack(off, m, inputs, rsb);
+          if ((int)q.size() == P.slots()) take();
+          q.push_back({P.submit(m, inputs.data(), rsb.data()), m});
+        }
+        while (!q.empty()) take();
+      } catch (...) {
+        P.sync();   // nothing of this call stays in flight behind the error
+        throw;
+      }
     }
   } catch (...) {
     for (auto* p : made) delete p;
@@ -1173,10 +1246,7 @@ FFI_RLN* rln_create(size_t depth, const std::vector<uint8_t>& zkey, const std::v
                     const TreeConfig& tcfg = TreeConfig()) {
   require_gpu();
   std::unique_ptr<FFI_RLN> r(new FFI_RLN);
-  ProverConfig cfg;
-  const char* mb = getenv("RLNAMD_MAX_BATCH");
-  cfg.max_batch = mb && *mb ? (size_t)atoll(mb) : 64;
-  r->prover.reset(new Prover(zkey.data(), zkey.size(), graph.data(), graph.size(), cfg));
+  r->prover.reset(new Prover(zkey.data(), zkey.size(), graph.data(), graph.size(), tcfg.prover_config()));
   if (r->prover->graph().tree_depth != depth)  // graph_from_raw expected depth (circuit/mod.rs:163-179)
     throw Error("Graph error: tree depth mismatch: expected " + std::to_string(depth) + ", got " +
                 std::to_string(r->prover->graph().tree_depth));
@@ -1199,10 +1269,7 @@ CResult_FFI_RLN_ptr_Vec_uint8_t ffi_rln_new(size_t tree_depth, const char* confi
     auto graph = read_file(dir + "/graph.bin");
     require_gpu();
     std::unique_ptr<FFI_RLN> r(new FFI_RLN);
-    ProverConfig cfg;
-    const char* mb = getenv("RLNAMD_MAX_BATCH");
-    cfg.max_batch = mb && *mb ? (size_t)atoll(mb) : 64;
-    r->prover.reset(new Prover(zkey.data(), zkey.size(), graph.data(), graph.size(), cfg));
+    r->prover.reset(new Prover(zkey.data(), zkey.size(), graph.data(), graph.size(), tcfg.prover_config()));
     r->open_tree(tree_depth, tcfg);
     return (FFI_RLN_t*)r.release();
   });
@@ -1217,6 +1284,16 @@ CResult_FFI_RLN_ptr_Vec_uint8_t ffi_rln_new_with_params(size_t tree_depth, const
   });
 }
 void ffi_rln_free(FFI_RLN_t* rln) { delete (FFI_RLN*)rln; }
+// EXT (include/rln_amd.h): how the prover behind an FFI_RLN / FFI_RLNV3 object was sized (config_path keys, environment)
+int rlnamd_ffi_prover_info(const void* ffi_rln, rlnamd_prover_info* info) {
+  if (!ffi_rln || !info) return RLNAMD_ERR;
+  try {
+    rlnamd::fill_prover_info(*((const FFI_RLN*)ffi_rln)->prover, info);
+  } catch (...) {
+    return RLNAMD_ERR;
+  }
+  return RLNAMD_OK;
+}
 size_t ffi_rln_get_tree_depth(FFI_RLN_t* const* rln) { return ((FFI_RLN*)*rln)->tree.depth; }
 size_t ffi_rln_get_max_out(FFI_RLN_t* const* rln) { return ((FFI_RLN*)*rln)->prover->graph().max_out; }
 

@@ -130,6 +130,91 @@ __global__ void __launch_bounds__(256) k_proofs_canon(const uint4* __restrict__ 
   }
 }
 
+// Bulk emission, round 3.  k_proofs_canon's inner loop was gather -> store: every 16-byte store waited for an L2 round
+// trip, and with 32 waves per CU that caps the chip near 4 TB/s (0.19 ms for 692 MB; a fill reaches 6.8 TB/s).  A block
+// of PROOFS_PER_BLOCK consecutive proofs only needs ~170 distinct nodes (level l: the siblings of <= 64 >> l + 1
+// ancestors, a contiguous heap range), so they are converted to canonical form ONCE into LDS (no k_canon_nodes pass,
+// no 67 MB round trip through HBM) and the emission loop is LDS read -> 16-byte store: stores issue back to back, every
+// store instruction of a wave covers 1 KiB without gaps, and the path bits of the block (1 280 contiguous bytes) leave
+// as 16-byte stores instead of one byte per element.
+constexpr uint32_t PATHS_LDS_NODES = PROOFS_PER_BLOCK * 2 + 4 * 32;   // sum over levels of <= (63 >> l) + 4 nodes, depth <= 30
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+template <bool NT>
+__global__ void __launch_bounds__(256) k_proofs_lds(const Fr* __restrict__ nodes, uint32_t depth, uint32_t magic,
+                                                    size_t first, size_t count, u32x4_t* __restrict__ elems,
+                                                    uint8_t* __restrict__ bits, uint32_t bits_vec) {
+  __shared__ u32x4_t sh[PATHS_LDS_NODES * 2];
+  __shared__ uint32_t lvl_off[32];       // LDS slot of the first node kept for a level
+  __shared__ unsigned long long lvl_base[32];  // 1-based heap index of that node
+  const size_t p0 = (size_t)blockIdx.x * PROOFS_PER_BLOCK;
+  const uint32_t np = (uint32_t)(count - p0 < PROOFS_PER_BLOCK ? count - p0 : PROOFS_PER_BLOCK);
+  const size_t leaf1 = ((size_t)1 << depth) + first + p0;   // 1-based heap index of the block's first leaf
+  if (threadIdx.x < depth) {
+    // ancestors at height l: [leaf1 >> l, (leaf1 + np - 1) >> l]; their siblings: that range widened to even..odd
+    uint32_t off = 0;
+    for (uint32_t l = 0; l < threadIdx.x; l++) {
+      size_t lo = (leaf1 >> l) & ~(size_t)1, hi = ((leaf1 + np - 1) >> l) | 1;
+      off += (uint32_t)(hi - lo + 1);
+    }
+    lvl_off[threadIdx.x] = off;
+    lvl_base[threadIdx.x] = (leaf1 >> threadIdx.x) & ~(size_t)1;
+  }
+  __syncthreads();
+  {
+    const uint32_t last = depth - 1;
+    const uint32_t total = lvl_off[last] + (uint32_t)((((leaf1 + np - 1) >> last) | 1) - lvl_base[last] + 1);
+    for (uint32_t i = threadIdx.x; i < total; i += 256) {
+      uint32_t l = 0;
+      while (l + 1 < depth && lvl_off[l + 1] <= i) l++;
+      const size_t h1 = lvl_base[l] + (i - lvl_off[l]);   // 1-based heap index
+      uint32_t c[8];
+      nodes[h1 - 1].to_canonical(c);
+      sh[2 * i] = u32x4_t{c[0], c[1], c[2], c[3]};
+      sh[2 * i + 1] = u32x4_t{c[4], c[5], c[6], c[7]};
+    }
+  }
+  __syncthreads();
+  const uint32_t n2 = np * depth * 2;
+  const size_t out0 = p0 * depth;
+#pragma unroll 2
+  for (uint32_t e2 = threadIdx.x; e2 < n2; e2 += 256) {
+    const uint32_t e = e2 >> 1, half = e2 & 1;
+    const uint32_t pl = __umulhi(e, magic);
+    const uint32_t lvl = e - pl * depth;
+    const size_t cur1 = (leaf1 + pl) >> lvl;               // 1-based ancestor; its sibling is cur1 ^ 1
+    const uint32_t slot = lvl_off[lvl] + (uint32_t)((cur1 ^ 1) - lvl_base[lvl]);
+    if (NT)
+      __builtin_nontemporal_store(sh[2 * slot + half], &elems[(out0 << 1) + e2]);
+    else
+      elems[(out0 << 1) + e2] = sh[2 * slot + half];
+  }
+  // bits: bit = 1 when the node on the path is a right child, i.e. its 1-based heap index is odd (:296-300)
+  const uint32_t nb = np * depth;
+  if (bits_vec) {
+    for (uint32_t q = threadIdx.x; q * 16 < nb; q += 256) {
+      uint32_t w[4] = {0, 0, 0, 0};
+      for (uint32_t k = 0; k < 16; k++) {
+        const uint32_t e = q * 16 + k;
+        const uint32_t pl = __umulhi(e, magic);
+        const uint32_t lvl = e - pl * depth;
+        const uint32_t b = e < nb ? (uint32_t)(((leaf1 + pl) >> lvl) & 1) : 0u;
+        w[k >> 2] |= b << (8 * (k & 3));
+      }
+      if (q * 16 + 16 <= nb) {
+        *reinterpret_cast<uint4*>(bits + out0 + q * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+      } else {
+        for (uint32_t k = 0; q * 16 + k < nb; k++) bits[out0 + q * 16 + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+      }
+    }
+  } else {
+    for (uint32_t e = threadIdx.x; e < nb; e += 256) {
+      const uint32_t pl = __umulhi(e, magic);
+      const uint32_t lvl = e - pl * depth;
+      bits[out0 + e] = (uint8_t)(((leaf1 + pl) >> lvl) & 1);
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) k_verify_proofs(const Fr* __restrict__ nodes, int depth, size_t first,
                                                        size_t count, const uint32_t* __restrict__ elems,
                                                        const uint8_t* __restrict__ bits, PoseidonView pv,
@@ -243,7 +328,19 @@ void MerkleTreeDev::proofs_device(size_t first, size_t count, uint8_t* d_elems, 
   if (count == 0 || depth == 0) return;
   if ((uintptr_t)d_elems & 15) throw Error("proofs_device: the path-element buffer must be 16-byte aligned");
   size_t total = count * (size_t)depth;
-  if (total >= num_nodes()) {  // bulk: fewer conversions than path elements
+  static const int paths_mode = env_int_merkle("RLNAMD_PATHS", 2);   // 2 = k_proofs_lds, 1 = k_canon_nodes + k_proofs_canon
+  if (total >= num_nodes() && paths_mode == 2) {
+    // (p0 * depth) bytes into d_bits is a multiple of 16 for every block when the base is 16-byte aligned
+    const uint32_t bits_vec = (((uintptr_t)d_bits & 15) == 0 && (PROOFS_PER_BLOCK * (size_t)depth) % 16 == 0) ? 1u : 0u;
+    static const bool nt = env_int_merkle("RLNAMD_PATHS_NT", 1) != 0;
+    const uint32_t magic = (uint32_t)(0x100000000ull / (uint32_t)depth) + 1;
+    if (nt)
+      hipLaunchKernelGGL(k_proofs_lds<true>, dim3(div_up(count, PROOFS_PER_BLOCK)), dim3(256), 0, stream, nodes.p,
+                         (uint32_t)depth, magic, first, count, (u32x4_t*)d_elems, d_bits, bits_vec);
+    else
+      hipLaunchKernelGGL(k_proofs_lds<false>, dim3(div_up(count, PROOFS_PER_BLOCK)), dim3(256), 0, stream, nodes.p,
+                         (uint32_t)depth, magic, first, count, (u32x4_t*)d_elems, d_bits, bits_vec);
+  } else if (total >= num_nodes()) {  // bulk: fewer conversions than path elements
     if (canon.n != num_nodes() * 8) canon.alloc(num_nodes() * 8);
     hipLaunchKernelGGL(k_canon_nodes, dim3(div_up(num_nodes(), 256)), dim3(256), 0, stream, nodes.p, num_nodes(), canon.p);
     hipLaunchKernelGGL(k_proofs_canon, dim3(div_up(count, PROOFS_PER_BLOCK)), dim3(256), 0, stream, (const uint4*)canon.p,

@@ -347,6 +347,14 @@ class RLN:
             lib().ffi_rln_free(self._h)
             self._h = None
 
+    def prover_info(self):
+        """EXT: sizing of the prover behind this object (window schedule, max_batch, table bytes)"""
+        from ._native import ProverInfo
+        info = ProverInfo()
+        if lib().rlnamd_ffi_prover_info(self._h, C.byref(info)) != 0:
+            raise RLNError("no prover")
+        return info
+
     # ---- Merkle-tree APIs (public.rs:298-593)
     def tree_depth(self):
         return int(lib().ffi_rln_get_tree_depth(C.byref(self._h)))
