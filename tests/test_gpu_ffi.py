@@ -470,7 +470,7 @@ def test_config_path_sizes_the_prover_and_batch_streams_past_max_batch(tmp_path)
     assert all(r["proof"] in g for r, g in zip(ref, got))
     assert bytes.fromhex(gold["proof_compressed"]) in got[0]
     for i in (0, 63, 64, 299):
-        v = proofs[i].values()
+        v = proofs[i].values
         assert v.y == ref[i]["values"]["y"] and v.nullifier == ref[i]["values"]["nullifier"]
         assert rln.verify_with_roots(proofs[i], ws[i]["x"], [])   # no roots given: the zk proof and x only
     del proofs, rln
