@@ -14,6 +14,8 @@
 #include "glv.h"
 #include "pairing.h"
 #include "poseidon.h"
+#include "witness_ops.h"
+#include "witness_lanes.h"
 
 namespace rlnamd {
 
@@ -23,157 +25,6 @@ const char* const kProverStageNames[PROVER_STAGES] = {"witness", "matvec", "ntt"
 // =====================================================================================================
 // 256-bit integer helpers on canonical limbs (witness-graph ops that are not field ops)
 // =====================================================================================================
-struct U256 {
-  uint32_t v[8];
-};
-__device__ __forceinline__ bool u_is_zero(const U256& a) {
-  uint32_t o = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) o |= a.v[i];
-  return o == 0;
-}
-__device__ __forceinline__ int u_cmp(const U256& a, const U256& b) {  // -1, 0, 1
-  for (int i = 7; i >= 0; i--) {
-    if (a.v[i] != b.v[i]) return a.v[i] > b.v[i] ? 1 : -1;
-  }
-  return 0;
-}
-__device__ __forceinline__ U256 u_from_limbs(const uint32_t* p) {
-  U256 r;
-#pragma unroll
-  for (int i = 0; i < 8; i++) r.v[i] = p[i];
-  return r;
-}
-__device__ __forceinline__ U256 u_sub(const U256& a, const U256& b) {
-  U256 r;
-  uint32_t borrow = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    uint64_t s = (uint64_t)a.v[i] - b.v[i] - borrow;
-    r.v[i] = (uint32_t)s;
-    borrow = (uint32_t)(s >> 63);
-  }
-  return r;
-}
-__device__ U256 u_shr(const U256& a, unsigned n) {  // n < 256
-  U256 r;
-  unsigned w = n >> 5, b = n & 31;
-  for (int i = 0; i < 8; i++) {
-    uint32_t lo = (i + w < 8) ? a.v[i + w] : 0;
-    uint32_t hi = (i + w + 1 < 8) ? a.v[i + w + 1] : 0;
-    r.v[i] = b ? ((lo >> b) | (hi << (32 - b))) : lo;
-  }
-  return r;
-}
-__device__ U256 u_shl(const U256& a, unsigned n) {  // n < 256, bits above 256 dropped (ark BigInt <<)
-  U256 r;
-  unsigned w = n >> 5, b = n & 31;
-  for (int i = 7; i >= 0; i--) {
-    uint32_t hi = (i >= (int)w) ? a.v[i - w] : 0;
-    uint32_t lo = (i >= (int)w + 1) ? a.v[i - w - 1] : 0;
-    r.v[i] = b ? ((hi << b) | (lo >> (32 - b))) : hi;
-  }
-  return r;
-}
-// a / b and a % b by shift-subtract (b != 0)
-__device__ void u_divmod(const U256& a, const U256& b, U256* q, U256* rem) {
-  U256 Q, Rm;
-  for (int i = 0; i < 8; i++) Q.v[i] = Rm.v[i] = 0;
-  for (int bit = 255; bit >= 0; bit--) {
-    uint32_t top = Rm.v[7] >> 31;
-    Rm = u_shl(Rm, 1);
-    Rm.v[0] |= (a.v[bit >> 5] >> (bit & 31)) & 1;
-    if (top || u_cmp(Rm, b) >= 0) {
-      Rm = u_sub(Rm, b);
-      Q.v[bit >> 5] |= 1u << (bit & 31);
-    }
-  }
-  *q = Q;
-  *rem = Rm;
-}
-
-enum WitnessErr : uint32_t { WERR_NONE = 0, WERR_INPUT_RANGE = 1, WERR_SHIFT = 2, WERR_BITOP = 3, WERR_UNO_ID = 4 };
-
-// Every operation that is not Mul/Add/Sub/Neg/TernCond/Const/Input: iden3calc/graph.rs:72-143, 314-466.
-__device__ __noinline__ Fr witness_slow_op(uint32_t op, Fr fa, Fr fb, uint32_t* err) {
-  U256 a, b, m, half;
-  fa.to_canonical(a.v);
-  fb.to_canonical(b.v);
-  m = u_from_limbs(FrParams::MOD);
-  half = u_from_limbs(FrParams::HALF);
-  auto boolean = [](bool x) { return x ? Fr::one() : Fr::zero(); };
-  switch (op) {
-    case G_DIV:
-      return fb.is_zero() ? Fr::zero() : fa * fb.inv();
-    case G_POW:
-      return fa.pow(b.v);
-    case G_IDIV:
-    case G_MOD: {
-      if (u_is_zero(b)) return Fr::zero();
-      U256 q, r;
-      u_divmod(a, b, &q, &r);
-      return Fr::from_canonical(op == G_IDIV ? q.v : r.v);
-    }
-    case G_EQ:
-      return boolean(u_cmp(a, b) == 0);
-    case G_NEQ:
-      return boolean(u_cmp(a, b) != 0);
-    case G_LT:
-    case G_GT:
-    case G_LEQ:
-    case G_GEQ: {  // values above M/2 are negative (graph.rs:410-466)
-      bool an = u_cmp(a, half) > 0, bn = u_cmp(b, half) > 0;
-      int c = u_cmp(a, b);
-      bool res;
-      if (an == bn)
-        res = op == G_LT ? c < 0 : op == G_GT ? c > 0 : op == G_LEQ ? c <= 0 : c >= 0;
-      else
-        res = (op == G_LT || op == G_LEQ) ? an : bn;
-      return boolean(res);
-    }
-    case G_LAND:
-      return boolean(!u_is_zero(a) && !u_is_zero(b));
-    case G_LOR:
-      return boolean(!u_is_zero(a) || !u_is_zero(b));
-    case G_SHL: {  // graph.rs:314-326
-      if (u_is_zero(b)) return fa;
-      U256 lim = {{254, 0, 0, 0, 0, 0, 0, 0}};
-      if (u_cmp(b, lim) >= 0) return Fr::zero();
-      U256 r = u_shl(a, b.v[0]);
-      if (u_cmp(r, m) >= 0) {
-        *err = WERR_SHIFT;
-        return Fr::zero();
-      }
-      return Fr::from_canonical(r.v);
-    }
-    case G_SHR: {  // graph.rs:328-363
-      if (u_is_zero(b)) return fa;
-      U256 lim = {{254, 0, 0, 0, 0, 0, 0, 0}};
-      if (u_cmp(b, lim) >= 0) return Fr::zero();
-      U256 r = u_shr(a, b.v[0] & 0xFF);
-      return Fr::from_canonical(r.v);
-    }
-    case G_BOR:
-    case G_BAND:
-    case G_BXOR: {  // graph.rs:365-408: one subtraction when d > MODULUS, then from_bigint
-      U256 d;
-      for (int i = 0; i < 8; i++)
-        d.v[i] = op == G_BOR ? (a.v[i] | b.v[i]) : op == G_BAND ? (a.v[i] & b.v[i]) : (a.v[i] ^ b.v[i]);
-      if (u_cmp(d, m) > 0) d = u_sub(d, m);
-      if (u_cmp(d, m) >= 0) {
-        *err = WERR_BITOP;
-        return Fr::zero();
-      }
-      return Fr::from_canonical(d.v);
-    }
-    case G_ID:
-      *err = WERR_UNO_ID;  // "uno operator Id not implemented for Montgomery" (graph.rs:201-204)
-      return Fr::zero();
-    default:
-      return Fr::zero();
-  }
-}
-
 // =====================================================================================================
 // 1. witness: one lane per proof interprets the straight-line graph (graph.rs:246-272)
 // =====================================================================================================
@@ -567,7 +418,10 @@ __global__ void __launch_bounds__(256) k_consts_to29(const Fr* __restrict__ src,
   for (int k = 0; k < 9; k++) dst[(size_t)t * 9 + k] = v.v[k];
 }
 // M29: twiddles as Fr29 constants and Fr29::mul_mont products; otherwise 8 x 32 twiddles and products (RLNAMD_NTT29=0)
-template <int K, bool DIF, bool M29>
+// LG (small batches): lanes = groups of ONE proof (blockIdx.x = proof) instead of lanes = proofs -- a single proof then
+// fills its waves (3 072 eight-point blocks = 48 waves per pass) instead of running 3 072 waves with one useful lane each
+// (all ten passes of one proof 0.78 -> see profiles/r3); twiddle indices become per-lane values.
+template <int K, bool DIF, bool M29, bool LG = false>
 __global__ void __launch_bounds__(256, RLN_NTT_WAVES) k_ntt_pass(Fr* __restrict__ data, const uint32_t* __restrict__ tw, int logn, int s0,
                                                   const uint32_t* __restrict__ scale, uint32_t B, uint32_t nb) {
   auto tmul = [&](const Fr& a, const uint32_t* __restrict__ tab, uint32_t idx) -> Fr {
@@ -578,8 +432,10 @@ __global__ void __launch_bounds__(256, RLN_NTT_WAVES) k_ntt_pass(Fr* __restrict_
   };
   constexpr int R = 1 << K;
   const uint32_t n = 1u << logn;
-  uint32_t p = blockIdx.x * 64 + threadIdx.x;
-  uint32_t g = __builtin_amdgcn_readfirstlane(blockIdx.y * blockDim.y + threadIdx.y);  // one group per wave
+  auto uni = [](uint32_t v) -> uint32_t { return LG ? v : __builtin_amdgcn_readfirstlane(v); };
+  uint32_t p = LG ? blockIdx.x : blockIdx.x * 64 + threadIdx.x;
+  uint32_t g = LG ? blockIdx.y * 64 + threadIdx.x
+                  : __builtin_amdgcn_readfirstlane(blockIdx.y * blockDim.y + threadIdx.y);  // one group per wave
   if (g >= (n >> K)) return;
   if (p >= nb) return;
   Fr* x = data + (size_t)blockIdx.z * n * B + p;
@@ -608,7 +464,7 @@ __global__ void __launch_bounds__(256, RLN_NTT_WAVES) k_ntt_pass(Fr* __restrict_
       // the twiddle index is the same for all 64 lanes (lanes = proofs): force the scalar path so the
       // twiddle rides in SGPRs instead of VGPRs.  Twiddles are held as Fr29 constants (w 2^261, 9 words): the
       // product with an 8 x 32 value needs no conversion (Fr29::mul_mont, ~290 instead of ~375 instructions)
-      const uint32_t tix = __builtin_amdgcn_readfirstlane(ti);
+      const uint32_t tix = uni(ti);
       if (DIF) {
         Fr u = e[m], v = e[m + half];
         e[m] = u + v;
@@ -624,7 +480,7 @@ __global__ void __launch_bounds__(256, RLN_NTT_WAVES) k_ntt_pass(Fr* __restrict_
   for (int m = 0; m < R; m++) {
     uint32_t pos = base + m * stride;
     Fr o = e[m];
-    if (scale) o = tmul(o, scale, __builtin_amdgcn_readfirstlane(pos));
+    if (scale) o = tmul(o, scale, uni(pos));
     x[(size_t)pos * B] = o;
   }
 }
@@ -673,9 +529,18 @@ __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ V, const 
                                                 uint32_t ns, const Fr* __restrict__ H, uint32_t n,
                                                 const uint32_t* __restrict__ rs, WinSched ws1, WinSched ws2, uint32_t nh,
                                                 int16_t* __restrict__ dig1, int16_t* __restrict__ dig2, uint32_t B,
-                                                uint32_t nb) {
+                                                uint32_t nb, uint32_t part) {
+  // part 0: every scalar; 1: the witness scalars and r, s, -(r s) (all the G2 walk needs: it can start before the
+  // quotient h exists); 2: the coefficients of h only
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
   uint32_t sid = blockIdx.y * blockDim.y + threadIdx.y;
+  if (part == 1) {
+    if (sid >= ns + 3) return;
+    if (sid >= ns) sid += n;
+  } else if (part == 2) {
+    if (sid >= n) return;
+    sid += ns;
+  }
   if (p >= nb || sid >= ns + n + 3) return;
   Fr x;
   if (sid < ns) {
@@ -1166,6 +1031,7 @@ struct Prover::Impl {
   DevBuf<GNode29> nodes29;
   DevBuf<unsigned long long> wit_prof;
   DevBuf<uint32_t> consts29, slot2node;
+  WitLanes witlanes;             // lanes = independent nodes: the interpreter of batches walked with lanes = chunks
   uint32_t nstore29 = 0, nprog29 = 0;   // stored values, program nodes (after fusion)
 
   uint32_t N = 0, NS = 0, NI = 0, nc = 0, ni = 0, n = 0;
@@ -1189,7 +1055,8 @@ struct Prover::Impl {
   struct Plan {
     DevBuf<uint32_t> rows;
     DevBuf<ChunkDesc> chunks, groups, segs, segchunks;   // segchunks: the chunk range of every segment (k_sum_tree)
-    uint32_t nchunks = 0, ngroups = 0, nseg = 0;
+    DevBuf<uint32_t> early_ids, late_ids;   // chunk indices without / with rows that depend on the quotient h
+    uint32_t nchunks = 0, ngroups = 0, nseg = 0, n_early = 0, n_late = 0;
   };
   Plan plan1[3], plan2[3];  // [PROVE_FULL, PROVE_PARTIAL, PROVE_FINISH]
   uint32_t max_chunks1 = 0, max_chunks2 = 0, max_groups1 = 0, max_groups2 = 0;
@@ -1573,6 +1440,11 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
                          D.consts29.p, (uint32_t)graph_.constants.size());
     RLN_HIP(hipGetLastError());
     RLN_HIP(hipStreamSynchronize(s));
+    {   // the same stored values, produced by a wave per proof (witness_lanes.h) when a batch is below a wave of proofs
+      std::vector<uint32_t> store_slot(D.N, 0xFFFFFFFFu);
+      for (uint32_t i = 0; i < slot2node.size(); i++) store_slot[slot2node[i]] = i;
+      D.witlanes.build(graph_, store_slot, (uint32_t)slot2node.size(), s);   // V29 has one row more than stored values
+    }
     RLN_HIP(hipFuncSetAttribute((const void*)k_witness29<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 WIT29_LDS_BYTES));
     RLN_HIP(hipFuncSetAttribute((const void*)k_witness29<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1676,20 +1548,28 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   auto make_plans = [&](const std::vector<uint32_t>& sids, const std::vector<uint32_t>& row_seg, uint32_t nseg,
                         uint32_t chunk_pts, Impl::Plan* plans, uint32_t* max_chunks, uint32_t* max_groups) {
     for (int mode = 0; mode < 3; mode++) {
-      std::vector<uint32_t> rows, segfirst;
+      std::vector<uint32_t> rows, segfirst, early_ids, late_ids;
       std::vector<ChunkDesc> chunks;
       // reduction segment h * nseg + sg: the rows of output sg walked with GLV half h (bit 31 of the row entry)
       for (uint32_t h = 0; h < D.nh; h++)
         for (uint32_t sg = 0; sg < nseg; sg++) {
           segfirst.push_back((uint32_t)chunks.size());
-          uint32_t first = (uint32_t)rows.size();
-          for (uint32_t k = 0; k < sids.size(); k++) {
-            if (row_seg[k] != sg) continue;
-            bool is_known = sids[k] < D.NS && D.known[sids[k]];
-            if (mode == PROVE_FULL || (mode == PROVE_PARTIAL) == is_known) rows.push_back(k | (h << 31));
+          // rows whose scalar is a coefficient of h (G1 only: ids NS .. NS + n) come last and start a chunk of their
+          // own, so that a small batch can walk everything else while the NTTs still run (early_ids / late_ids)
+          for (int late = 0; late < 2; late++) {
+            uint32_t first = (uint32_t)rows.size();
+            for (uint32_t k = 0; k < sids.size(); k++) {
+              if (row_seg[k] != sg) continue;
+              const bool is_h = nseg == 3 && sids[k] >= D.NS && sids[k] < D.NS + D.n;
+              if ((int)is_h != late) continue;
+              bool is_known = sids[k] < D.NS && D.known[sids[k]];
+              if (mode == PROVE_FULL || (mode == PROVE_PARTIAL) == is_known) rows.push_back(k | (h << 31));
+            }
+            for (uint32_t k = first; k < rows.size(); k += chunk_pts) {
+              (late ? late_ids : early_ids).push_back((uint32_t)chunks.size());
+              chunks.push_back({k, (uint32_t)std::min<size_t>(k + chunk_pts, rows.size())});
+            }
           }
-          for (uint32_t k = first; k < rows.size(); k += chunk_pts)
-            chunks.push_back({k, (uint32_t)std::min<size_t>(k + chunk_pts, rows.size())});
         }
       segfirst.push_back((uint32_t)chunks.size());
       std::vector<ChunkDesc> groups, segs;
@@ -1710,6 +1590,12 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
       for (size_t sgi = 0; sgi + 1 < segfirst.size(); sgi++) segchunks.push_back({segfirst[sgi], segfirst[sgi + 1]});
       P.segchunks.alloc(segchunks.size());
       P.segchunks.upload(segchunks.data(), segchunks.size(), s);
+      P.n_early = (uint32_t)early_ids.size();
+      P.n_late = (uint32_t)late_ids.size();
+      P.early_ids.alloc(std::max<size_t>(early_ids.size(), 1));
+      P.late_ids.alloc(std::max<size_t>(late_ids.size(), 1));
+      if (!early_ids.empty()) P.early_ids.upload(early_ids.data(), early_ids.size(), s);
+      if (!late_ids.empty()) P.late_ids.upload(late_ids.data(), late_ids.size(), s);
       RLN_HIP(hipStreamSynchronize(s));
       *max_chunks = std::max(*max_chunks, P.nchunks);
       *max_groups = std::max(*max_groups, P.ngroups);
@@ -1803,7 +1689,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     S.values.alloc(B * 40);
     S.comp.alloc(B * 128);
     S.V.alloc((size_t)D.N * B);
-    if (D.wit29) S.V29.alloc((size_t)D.nstore29 * 3 * B);
+    if (D.wit29) S.V29.alloc(((size_t)D.nstore29 + 1) * 3 * B);   // + the trash row of k_witness_lanes
     S.abc.alloc(3 * (size_t)D.n * B);
     S.digits.alloc((size_t)(D.NS + D.n + 3) * D.nh * D.ws.W * B);
     S.digits2.alloc((size_t)(D.NS + 3) * D.nh * D.ws2.W * B);
@@ -1892,8 +1778,20 @@ void Prover::upload_witness(size_t n, const uint8_t* w_le) {
 
 template <bool DIF, bool M29>
 static void launch_ntt(Fr* data, const uint32_t* tw, int logn, const uint32_t* final_scale, uint32_t B, uint32_t nb,
-                       hipStream_t s) {
+                       hipStream_t s, bool lanes_are_groups = false) {
   int s0 = 0;
+  while (lanes_are_groups && s0 < logn) {   // small batch: blockIdx.x = proof, lanes = groups (radix-8 passes + a radix-2 tail)
+    const int rem = logn - s0, K = rem >= 3 ? 3 : 1;
+    const uint32_t groups = (1u << logn) >> K;
+    dim3 block(64, 1), grid(nb, div_up(groups, 64), 3);
+    const uint32_t* sc = (s0 + K == logn) ? final_scale : nullptr;
+    if (K == 3)
+      hipLaunchKernelGGL((k_ntt_pass<3, DIF, M29, true>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb);
+    else
+      hipLaunchKernelGGL((k_ntt_pass<1, DIF, M29, true>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb);
+    RLN_HIP(hipGetLastError());
+    s0 += K;
+  }
   while (s0 < logn) {
     int rem = logn - s0;
     static const int maxk = env_int("RLNAMD_NTT_MAXK", 3);
@@ -2031,8 +1929,14 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // Chained on one stream they were the critical path (54 ms against 49 ms of MSM).
   const uint32_t sq = D.seq++;
   hipStream_t sA = (D.nstreamA > 1 && D.wstreams > 1 && (sq & 1)) ? D.sAb : D.sA;
-  hipStream_t sA2 = D.nstreamA > 1 ? D.sA2 : sA;
   const uint32_t B = (uint32_t)B_, nb = (uint32_t)n;
+  // Small batches (latency, not throughput): the whole front end stays on ONE stream (every cross-stream event hop costs
+  // 0.1 - 0.15 ms), the digits of the witness scalars are recoded right behind the interpreter, and both walks start on
+  // everything that does not depend on the quotient h while mat-vec / NTTs still run; only the h rows of the G1 walk
+  // wait for them.
+  const bool early = nb <= D.lanechunk_max && D.use29 && D.use29_g2 && D.split_msm && D.recode_front &&
+                     mode != PROVE_PARTIAL && env_int("RLNAMD_EARLY_WALK", 1) != 0;
+  hipStream_t sA2 = (D.nstreamA > 1 && !early) ? D.sA2 : sA;
   const uint32_t pg = div_up(nb, 64);
   const uint32_t nbp = pg * 64;  // padded lanes compute on stale / zero inputs; results ignored
   // ---------------- stage A
@@ -2065,6 +1969,8 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
       RLN_HIP(hipMemcpy(h, pb.p, sizeof(h), hipMemcpyDeviceToHost));
       fprintf(stderr, "wit29 prof: mul %llu cyc / %llu, add %llu / %llu, const+input %llu / %llu, other %llu / %llu; total %llu cyc, %.3f ms, clock %.0f MHz\n",
               h[0], h[4], h[1], h[5], h[2], h[6], h[3], h[7], h[8], h[9] / 1e5, h[9] ? 100.0 * h[8] / h[9] : 0.0);
+    } else if (D.witlanes.ok && nb <= D.lanechunk_max) {
+      D.witlanes.launch(sA, D.consts29.p, in_p, D.NI, S.V29.p, S.err.p, B, nb);
     } else
     hipLaunchKernelGGL(k_witness29<false>, dim3(pg), dim3(64), WIT29_LDS_BYTES, sA, D.nodes29.p, D.nprog29,
                        D.consts29.p, (uint32_t)graph_.constants.size(), in_p, D.NI, S.V29.p, S.err.p, B, nbp, nullptr);
@@ -2080,6 +1986,22 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     hipLaunchKernelGGL(k_scatter_witness, dim3(pg, div_up(D.NS, 4)), dim3(64, 4), 0, sA, D.wgiven.p, D.sig2node.p,
                        D.NS, S.V.p, S.err.p, B, nb);
     D.wgiven_n = 0;
+  }
+  // Small batches (latency): the digits of the witness scalars and of r, s are recoded right behind the interpreter,
+  // so the G2 walk -- the longer of the two, and independent of the quotient h -- starts beside mat-vec / NTT instead
+  // of behind them; only h's digits wait for the NTTs.
+  const bool early_g2 = early;
+  if (early) {
+    hipLaunchKernelGGL(k_recode, dim3(pg, D.NS + 3), dim3(64, 1), 0, sA, S.V.p, D.sig2node.p, D.NS, S.abc.p, D.n, rs_p,
+                       D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nbp, 1u);
+    RLN_HIP(hipEventRecord(S.evW, sA));
+    RLN_HIP(hipStreamWaitEvent(D.sB, S.evW, 0));
+    RLN_HIP(hipStreamWaitEvent(D.sB2, S.evW, 0));
+    RLN_HIP(hipEventRecord(S.t[14], D.sB));
+    if (P1.n_early)
+      hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>), dim3(div_up(P1.n_early, 64), nb), dim3(64), 0,
+                         D.sB, D.t1_29.p, D.sid1.p, P1.rows.p, P1.chunks.p, P1.n_early, S.digits.p, S.part1.p, D.ws, B, pg,
+                         D.nh, nullptr, P1.early_ids.p);
   }
   RLN_HIP(hipEventRecord(S.t[2], sA));
   if (sA2 != sA) {
@@ -2101,8 +2023,9 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
       launch_ntt<true, true>(S.abc.p, D.tw_i29.p, D.logn, D.coset29.p, B, nbp, sA2);  // iNTT (DIF) + g^i / n
       launch_ntt<false, true>(S.abc.p, D.tw_f29.p, D.logn, nullptr, B, nbp, sA2);     // NTT (DIT)
     } else {
-      launch_ntt<true, false>(S.abc.p, (const uint32_t*)D.tw_i.p, D.logn, (const uint32_t*)D.coset.p, B, nbp, sA2);
-      launch_ntt<false, false>(S.abc.p, (const uint32_t*)D.tw_f.p, D.logn, nullptr, B, nbp, sA2);
+      const bool lg = nb <= D.lanechunk_max;   // below a wave of proofs: lanes = groups
+      launch_ntt<true, false>(S.abc.p, (const uint32_t*)D.tw_i.p, D.logn, (const uint32_t*)D.coset.p, B, lg ? nb : nbp, sA2, lg);
+      launch_ntt<false, false>(S.abc.p, (const uint32_t*)D.tw_f.p, D.logn, nullptr, B, lg ? nb : nbp, sA2, lg);
     }
     hipLaunchKernelGGL(k_hquot, dim3(pg, D.n), dim3(64, 1), 0, sA2, S.abc.p, D.n, B, nbp);
   }
@@ -2115,23 +2038,34 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     RLN_HIP(hipStreamWaitEvent(D.sB, S.evA, 0));
   }
   RLN_HIP(hipEventRecord(S.t[5], sR));
-  hipLaunchKernelGGL(k_recode, dim3(pg, D.NS + D.n + 3), dim3(64, 1), 0, sR, S.V.p, D.sig2node.p, D.NS,
-                     S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nbp);
+  if (early_g2)
+    hipLaunchKernelGGL(k_recode, dim3(pg, D.n), dim3(64, 1), 0, sR, S.V.p, D.sig2node.p, D.NS, S.abc.p, D.n, rs_p, D.ws,
+                       D.ws2, D.nh, S.digits.p, S.digits2.p, B, nbp, 2u);
+  else
+    hipLaunchKernelGGL(k_recode, dim3(pg, D.NS + D.n + 3), dim3(64, 1), 0, sR, S.V.p, D.sig2node.p, D.NS,
+                       S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nbp, 0u);
   RLN_HIP(hipEventRecord(S.t[6], sR));
   // ---------------- stage B
-  if (D.recode_front) {
+  if (D.recode_front && !early) {
     RLN_HIP(hipEventRecord(S.evA, sA2));
     RLN_HIP(hipStreamWaitEvent(D.sB, S.evA, 0));
   }
-  RLN_HIP(hipEventRecord(S.t[14], D.sB));
+  if (!early) RLN_HIP(hipEventRecord(S.t[14], D.sB));
   // below half a wave of proofs the walks run with lanes = chunks (walk29.h); RLNAMD_LANECHUNK overrides the threshold
   const bool lanechunk = nb <= D.lanechunk_max;
   hipStream_t s2 = D.split_msm ? D.sB2 : D.sB;
-  if (D.split_msm) {
+  if (D.split_msm && !early) {   // (early: sB2 already waits for the witness + part-1 digits, all the G2 walk reads)
     RLN_HIP(hipEventRecord(S.evR, D.sB));
     RLN_HIP(hipStreamWaitEvent(D.sB2, S.evR, 0));
   }
-  if (P1.nchunks) {
+  if (early) {   // the h rows, on the front-end stream itself (no event hop); everything else is already walking
+    if (P1.n_late)
+      hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>), dim3(div_up(P1.n_late, 64), nb), dim3(64), 0, sA,
+                         D.t1_29.p, D.sid1.p, P1.rows.p, P1.chunks.p, P1.n_late, S.digits.p, S.part1.p, D.ws, B, pg, D.nh,
+                         nullptr, P1.late_ids.p);
+    RLN_HIP(hipEventRecord(S.evR, sA));
+    RLN_HIP(hipStreamWaitEvent(D.sB, S.evR, 0));   // evB below then covers both launches
+  } else if (P1.nchunks) {
     uint32_t blocks = div_up(P1.nchunks, 8) * 8 * pg;
     if (D.use29 && lanechunk)
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>), dim3(div_up(P1.nchunks, 64), nb), dim3(64), 0, D.sB,

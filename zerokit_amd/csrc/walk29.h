@@ -39,15 +39,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 
                                               const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks,
                                               uint32_t nchunks, const int16_t* __restrict__ digits,
                                               Out* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups,
-                                              uint32_t nh, unsigned long long* __restrict__ clk) {
+                                              uint32_t nh, unsigned long long* __restrict__ clk,
+                                              const uint32_t* __restrict__ chunk_ids = nullptr) {
   // clock tap (clk may be null): every 64th workgroup adds its shader-clock cycles and its 100 MHz wall ticks; their
   // ratio is the clock the power management held under this kernel, which is what the issue-bound walk scales with
   const unsigned long long c0 = clk ? clock64() : 0, w0 = clk ? wall_clock64() : 0;
   uint32_t L = blockIdx.x;
   const int W = ws.W;
   if (LANECHUNK) {
-    const uint32_t chunk = L * 64 + threadIdx.x, p = blockIdx.y;   // one proof per grid row
-    if (chunk >= nchunks) return;
+    // chunk_ids (may be null): the launch covers a subset of the plan's chunks -- the rows that do not depend on the
+    // quotient h are walked while the NTTs still run, the h rows afterwards; partial sums land at their chunk's index
+    const uint32_t idx = L * 64 + threadIdx.x, p = blockIdx.y;   // one proof per grid row
+    if (idx >= nchunks) return;
+    const uint32_t chunk = chunk_ids ? chunk_ids[idx] : idx;
     const ChunkDesc cd = chunks[chunk];
     Acc acc = Acc::inf();
     for (uint32_t i = cd.pt_begin; i < cd.pt_end; i++) {

@@ -1,0 +1,31 @@
+// Witness-graph interpreter with lanes = independent nodes (witness_lanes.hip), for batches too small to fill a wave
+// with proofs.  k_witness29 runs one proof per LANE: a single proof issues every instruction of its ~15 000 node chain
+// with 63 lanes idle (11.1 ms on MI355X).  Here one proof owns a whole WAVE and the host cuts the graph
+// (/root/reference/rln/src/circuit/iden3calc/graph.rs:246-272 evaluates it node by node) into dependency steps: every
+// lane of a step evaluates a different node whose operands earlier steps produced, values live in LDS slots assigned
+// by the host from the liveness of the schedule.  The shipped depth-20 circuit has a multiplication depth of 5 736
+// against 13 972 products, and its additions ride along: ~7 000 steps instead of ~15 000 sequential nodes.
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "common.h"
+#include "zkey.h"
+
+namespace rlnamd {
+
+struct WitLanes {
+  bool ok = false;            // false: the graph does not fit this form (too many constants / live values): use k_witness29
+  uint32_t nsteps = 0, nfma = 0, nsqr = 0, nadd = 0, nmisc = 0, peak_slots = 0, n_consts = 0;
+  DevBuf<uint4> prog;         // [nsteps + padding][WL_W] micro-op descriptors
+  // store_slot[n]: index of node n in the compact array of stored values (V29), or 0xFFFFFFFF when it is not stored.
+  // d_consts29: the graph constants in the 9 x 29-bit Montgomery form, 9 words each (device memory).
+  // trash_slot: a row of V29 nobody reads (the kernel stores every value; values that are not kept go there).
+  void build(const Graph& g, const std::vector<uint32_t>& store_slot, uint32_t trash_slot, hipStream_t s);
+  // one wave per proof; V29 / err as for k_witness29: V29[(slot * B + proof) * 3 .. + 3), err[proof]
+  void launch(hipStream_t s, const uint32_t* d_consts29, const uint32_t* d_inputs, uint32_t n_inputs, uint4* V29,
+              uint32_t* err, uint32_t B, uint32_t nb) const;
+};
+
+}  // namespace rlnamd
