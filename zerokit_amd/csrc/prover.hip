@@ -647,17 +647,30 @@ __global__ void __launch_bounds__(64) k_sum_ranges(const XYZZ<F>* __restrict__ s
 // k_sum_ranges leaves 63 lanes idle and a G2 segment is a serial chain of 16 + 30 general additions (~ 2 ms); here the
 // 64 lanes of the wave of (proof, segment) each add their share of the segment's chunks and meet in a six-level tree
 // through LDS: 8 + 6 additions.
+// which segments / tasks a launch covers (grid.y = n): a small batch finishes s A and r B1 from the h-independent rows
+// while the h rows are still being walked, so the back-end kernels run twice on disjoint task lists
+struct TaskSel {
+  uint8_t id[8];
+};
+static TaskSel task_sel(std::initializer_list<uint32_t> ids) {
+  TaskSel t{};
+  uint32_t k = 0;
+  for (uint32_t v : ids) t.id[k++] = (uint8_t)v;
+  return t;
+}
 template <class F>
-__global__ void __launch_bounds__(64) k_sum_tree(const XYZZ<F>* __restrict__ part, const ChunkDesc* __restrict__ segchunks,
-                                                 XYZZ<F>* __restrict__ dst, uint32_t B) {
-  __shared__ XYZZ<F> sh[64];
+__global__ void __launch_bounds__(256) k_sum_tree(const XYZZ<F>* __restrict__ part, const ChunkDesc* __restrict__ segchunks,
+                                                  XYZZ<F>* __restrict__ dst, uint32_t B, uint32_t PB, TaskSel sel) {
+  // 256 lanes per (proof, segment): the short chunks of the small-batch plans leave ~1 500 partial sums per segment;
+  // six per lane and an eight-level tree cost what 64 lanes paid for the long chunks (part stride PB, result stride B)
+  __shared__ XYZZ<F> sh[256];
   __builtin_amdgcn_s_setprio(3);
-  const uint32_t p = blockIdx.x, sgi = blockIdx.y, l = threadIdx.x;
+  const uint32_t p = blockIdx.x, sgi = sel.id[blockIdx.y], l = threadIdx.x;
   const ChunkDesc cd = segchunks[sgi];
   XYZZ<F> acc = XYZZ<F>::inf();
-  for (uint32_t i = cd.pt_begin + l; i < cd.pt_end; i += 64) acc.add(part[(size_t)i * B + p]);
+  for (uint32_t i = cd.pt_begin + l; i < cd.pt_end; i += 256) acc.add(part[(size_t)i * PB + p]);
 #pragma unroll 1
-  for (uint32_t stride = 32; stride >= 1; stride >>= 1) {
+  for (uint32_t stride = 128; stride >= 1; stride >>= 1) {
     sh[l] = acc;
     __syncthreads();
     if (l < stride) acc.add(sh[l + stride]);
@@ -669,11 +682,11 @@ __global__ void __launch_bounds__(64) k_sum_tree(const XYZZ<F>* __restrict__ par
 // GLV: segment t holds sum k1_i P_i, segment nseg + t holds sum k2_i P_i; the result is the first plus phi of the
 // second, phi(X, Y, ZZ, ZZZ) = (beta X, Y, ZZ, ZZZ) (x = X / ZZ).  One Fq product per output point and proof.
 __global__ void __launch_bounds__(64) k_glv_fold(G1XYZZ* __restrict__ sums1, G2XYZZ* __restrict__ sums2, uint32_t nseg1,
-                                                 uint32_t B, uint32_t nb) {
+                                                 uint32_t B, uint32_t nb, TaskSel sel) {
   __builtin_amdgcn_s_setprio(3);
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
   if (p >= nb) return;
-  const uint32_t t = blockIdx.y;
+  const uint32_t t = sel.id[blockIdx.y];
   if (t < nseg1) {
     G1XYZZ a = sums1[(size_t)t * B + p], b = sums1[(size_t)(nseg1 + t) * B + p];
     b.X = b.X * Fq::from_canonical(GlvParams::BETA_G1);
@@ -793,13 +806,14 @@ __global__ void __launch_bounds__(64) k_add_partial(G1XYZZ* __restrict__ sums1, 
 // F1: the three MSM sums that become proof elements go to affine form in parallel (one inversion each)
 __global__ void __launch_bounds__(64) k_fin_affine(const G1XYZZ* __restrict__ sums1, const G2XYZZ* __restrict__ sums2,
                                                    G1Affine* __restrict__ affA, G1Affine* __restrict__ affB1,
-                                                   G2Affine* __restrict__ affB2, uint32_t B, uint32_t nb) {
+                                                   G2Affine* __restrict__ affB2, uint32_t B, uint32_t nb, TaskSel sel) {
   __builtin_amdgcn_s_setprio(3);  // few, latency-bound waves: issue ahead of the MSM waves sharing the SIMD
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
   if (p >= nb) return;
-  if (blockIdx.y == 0)
+  const uint32_t task = sel.id[blockIdx.y];
+  if (task == 0)
     affA[p] = sums1[p].to_affine();
-  else if (blockIdx.y == 1)
+  else if (task == 1)
     affB1[p] = sums1[(size_t)B + p].to_affine();
   else
     affB2[p] = sums2[p].to_affine();
@@ -1008,6 +1022,7 @@ struct Slot {
   DevBuf<uint32_t> inputs, rs, pp_in;
   uint8_t* h_in = nullptr;      // pinned staging: inputs | rs | partial points
   hipEvent_t evU = nullptr;     // H2D of this slot's inputs done
+  hipEvent_t evE = nullptr;     // small batches: the walk of the h-independent G1 rows done
   uint64_t ticket = 0;          // submit() ticket of the batch the slot holds (0: resident-input run)
   uint8_t* h_comp = nullptr;    // pinned: every run ends with the proofs + values copied to the host
   uint32_t* h_values = nullptr;
@@ -1059,6 +1074,10 @@ struct Prover::Impl {
     uint32_t nchunks = 0, ngroups = 0, nseg = 0, n_early = 0, n_late = 0;
   };
   Plan plan1[3], plan2[3];  // [PROVE_FULL, PROVE_PARTIAL, PROVE_FINISH]
+  // the same walks cut into shorter chunks for batches walked with lanes = chunks: a walk lasts as long as its longest
+  // chunk (a lane's serial chain of additions), and a handful of proofs cannot fill the chip anyway
+  Plan plan1s[3], plan2s[3];
+  uint32_t max_chunks1s = 0, max_chunks2s = 0, small_stride = 64;   // partial sums of a small batch: [chunk][64]
   uint32_t max_chunks1 = 0, max_chunks2 = 0, max_groups1 = 0, max_groups2 = 0;
   uint32_t npts1 = 0, npts2 = 0;
   std::vector<uint8_t> known;  // per witness signal: computable from the partial witness (evaluate_partial)
@@ -1628,6 +1647,11 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     // rows (x halves) per single-wave workgroup: ~150 additions each, as before the split (8 rows x 19 windows)
     make_plans(sids, row_seg, 3, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK", D.nh == 2 ? 16 : 8)), D.plan1,
                &D.max_chunks1, &D.max_groups1);
+    {
+      uint32_t unused = 0;
+      make_plans(sids, row_seg, 3, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_SMALL", 4)), D.plan1s, &D.max_chunks1s,
+                 &unused);
+    }
     if (D.use29) build_table29<Fq, G1Affine29>(pts, D.ws, D.t1_29, s); else build_table<Fq>(pts, D.ws, D.t1, s);
   }
   {
@@ -1651,6 +1675,11 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     D.sid2.upload(dsid.data(), dsid.size(), s);
     make_plans(sids, row_seg, 1, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_G2", D.nh == 2 ? 8 : 4)), D.plan2,
                &D.max_chunks2, &D.max_groups2);
+    {
+      uint32_t unused = 0;
+      make_plans(sids, row_seg, 1, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_G2_SMALL", 4)), D.plan2s, &D.max_chunks2s,
+                 &unused);
+    }
     if (D.use29_g2) build_table29<Fq2, G2Affine29>(pts, D.ws2, D.t2_29, s); else build_table<Fq2>(pts, D.ws2, D.t2, s);
   }
 
@@ -1693,10 +1722,10 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     S.abc.alloc(3 * (size_t)D.n * B);
     S.digits.alloc((size_t)(D.NS + D.n + 3) * D.nh * D.ws.W * B);
     S.digits2.alloc((size_t)(D.NS + 3) * D.nh * D.ws2.W * B);
-    S.part1.alloc((size_t)D.max_chunks1 * B);
+    S.part1.alloc(std::max((size_t)D.max_chunks1 * B, (size_t)D.max_chunks1s * D.small_stride));
     S.grp1.alloc((size_t)D.max_groups1 * B);
     S.sums1.alloc(3 * D.nh * B);
-    S.part2.alloc((size_t)D.max_chunks2 * B);
+    S.part2.alloc(std::max((size_t)D.max_chunks2 * B, (size_t)D.max_chunks2s * D.small_stride));
     S.grp2.alloc((size_t)D.max_groups2 * B);
     S.sums2.alloc(D.nh * B);
     S.prod.alloc(2 * B);
@@ -1713,6 +1742,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     RLN_HIP(hipMemsetAsync(S.pp_in.p, 0, S.pp_in.bytes(), s));
     RLN_HIP(hipHostMalloc((void**)&S.h_in, B * ((size_t)D.NI * 32 + 64 + 320), hipHostMallocDefault));
     RLN_HIP(hipEventCreateWithFlags(&S.evU, hipEventDisableTiming));
+    RLN_HIP(hipEventCreateWithFlags(&S.evE, hipEventDisableTiming));
     RLN_HIP(hipHostMalloc((void**)&S.h_pp, B * 320, hipHostMallocDefault));
     RLN_HIP(hipHostMalloc((void**)&S.h_comp, B * 128, hipHostMallocDefault));
     RLN_HIP(hipHostMalloc((void**)&S.h_values, B * 160, hipHostMallocDefault));
@@ -1740,6 +1770,7 @@ Prover::~Prover() {
     if (S.h_pp) (void)hipHostFree(S.h_pp);
     if (S.h_in) (void)hipHostFree(S.h_in);
     if (S.evU) (void)hipEventDestroy(S.evU);
+    if (S.evE) (void)hipEventDestroy(S.evE);
     if (S.h_comp) (void)hipHostFree(S.h_comp);
     if (S.h_values) (void)hipHostFree(S.h_values);
     if (S.h_err) (void)hipHostFree(S.h_err);
@@ -1906,8 +1937,10 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   if (n > B_) throw Error("batch larger than the prover workspace (max_batch)");
   if (mode < PROVE_FULL || mode > PROVE_FINISH) throw Error("unknown prover mode");
   Impl& D = *d_;
-  const Impl::Plan& P1 = D.plan1[mode];
-  const Impl::Plan& P2 = D.plan2[mode];
+  const bool small = n <= D.lanechunk_max && n <= D.small_stride && D.use29 && D.use29_g2;   // lanes = chunks
+  const Impl::Plan& P1 = small ? D.plan1s[mode] : D.plan1[mode];
+  const Impl::Plan& P2 = small ? D.plan2s[mode] : D.plan2[mode];
+  const uint32_t PB = small ? D.small_stride : (uint32_t)B_;   // stride of the partial-sum arrays
   Slot& S = D.slot[D.cur];
   const bool streamed = h_inputs != nullptr;
   if (streamed) {
@@ -2000,8 +2033,9 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     RLN_HIP(hipEventRecord(S.t[14], D.sB));
     if (P1.n_early)
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>), dim3(div_up(P1.n_early, 64), nb), dim3(64), 0,
-                         D.sB, D.t1_29.p, D.sid1.p, P1.rows.p, P1.chunks.p, P1.n_early, S.digits.p, S.part1.p, D.ws, B, pg,
+                         D.sB, D.t1_29.p, D.sid1.p, P1.rows.p, P1.chunks.p, P1.n_early, S.digits.p, S.part1.p, D.ws, B, PB,
                          D.nh, nullptr, P1.early_ids.p);
+    RLN_HIP(hipEventRecord(S.evE, D.sB));
   }
   RLN_HIP(hipEventRecord(S.t[2], sA));
   if (sA2 != sA) {
@@ -2061,7 +2095,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   if (early) {   // the h rows, on the front-end stream itself (no event hop); everything else is already walking
     if (P1.n_late)
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>), dim3(div_up(P1.n_late, 64), nb), dim3(64), 0, sA,
-                         D.t1_29.p, D.sid1.p, P1.rows.p, P1.chunks.p, P1.n_late, S.digits.p, S.part1.p, D.ws, B, pg, D.nh,
+                         D.t1_29.p, D.sid1.p, P1.rows.p, P1.chunks.p, P1.n_late, S.digits.p, S.part1.p, D.ws, B, PB, D.nh,
                          nullptr, P1.late_ids.p);
     RLN_HIP(hipEventRecord(S.evR, sA));
     RLN_HIP(hipStreamWaitEvent(D.sB, S.evR, 0));   // evB below then covers both launches
@@ -2069,7 +2103,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     uint32_t blocks = div_up(P1.nchunks, 8) * 8 * pg;
     if (D.use29 && lanechunk)
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>), dim3(div_up(P1.nchunks, 64), nb), dim3(64), 0, D.sB,
-                         D.t1_29.p, D.sid1.p, P1.rows.p, P1.chunks.p, P1.nchunks, S.digits.p, S.part1.p, D.ws, B, pg, D.nh,
+                         D.t1_29.p, D.sid1.p, P1.rows.p, P1.chunks.p, P1.nchunks, S.digits.p, S.part1.p, D.ws, B, PB, D.nh,
                          nullptr);
     else if (D.use29)
       // dynamic LDS that the kernel never touches caps it at D.msm_waves waves per SIMD: at 4 x 128 VGPRs the
@@ -2086,7 +2120,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     uint32_t blocks = div_up(P2.nchunks, 8) * 8 * pg;
     if (D.use29_g2 && lanechunk)
       hipLaunchKernelGGL((k_msm29<G2Acc29, G2Affine29, G2XYZZ, 1, true>), dim3(div_up(P2.nchunks, 64), nb), dim3(64), 0, s2,
-                         D.t2_29.p, D.sid2.p, P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, pg, D.nh,
+                         D.t2_29.p, D.sid2.p, P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, PB, D.nh,
                          nullptr);
     else if (D.use29_g2)
       hipLaunchKernelGGL((k_msm29<G2Acc29, G2Affine29, G2XYZZ, 2>), dim3(blocks), dim3(64), 0, s2, D.t2_29.p, D.sid2.p,
@@ -2113,13 +2147,45 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
                        poseidon_view(3), poseidon_view(4), S.values.p, nbp);
   RLN_HIP(hipEventRecord(S.t[13], sV));
   RLN_HIP(hipEventRecord(S.evV, sV));
-  RLN_HIP(hipStreamWaitEvent(D.sC, S.evV, 0));
-  RLN_HIP(hipStreamWaitEvent(D.sC, S.evB, 0));
-  if (D.split_msm) RLN_HIP(hipStreamWaitEvent(D.sC, S.evB2, 0));
-  RLN_HIP(hipEventRecord(S.t[9], D.sC));
-  if (lanechunk) {   // small batch: lanes = partial sums (k_sum_tree)
-    hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, P1.nseg), dim3(64), 0, D.sC, S.part1.p, P1.segchunks.p, S.sums1.p, B);
-    hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(64), 0, D.sC, S.part2.p, P2.segchunks.p, S.sums2.p, B);
+  // Small full proofs: A and B1 are sums over h-independent rows only, so their reduction, the two inversions and the two
+  // variable-base products s A, r B1 (the longest kernel of the back end) run on the idle sA2 as soon as the early G1
+  // walk is done -- beside the NTTs and the walk of the h rows, not behind them.  sums1 segments: h * 3 + {A, B1, C}.
+  const bool early_fin = early && mode == PROVE_FULL && D.nh == 2 && env_int("RLNAMD_EARLY_FIN", 1) != 0;
+  const TaskSel all6 = task_sel({0, 1, 2, 3, 4, 5}), all4 = task_sel({0, 1, 2, 3}), all3 = task_sel({0, 1, 2});
+  if (early_fin) {
+    RLN_HIP(hipStreamWaitEvent(D.sA2, S.evE, 0));   // sB: the early G1 walk
+    hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, 4), dim3(256), 0, D.sA2, S.part1.p, P1.segchunks.p, S.sums1.p, B,
+                       PB, task_sel({0, 1, 3, 4}));
+    hipLaunchKernelGGL(k_glv_fold, dim3(pg, 2), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({0, 1}));
+    hipLaunchKernelGGL(k_fin_affine, dim3(pg, 2), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
+                       S.affB2.p, B, nbp, task_sel({0, 1}));
+    hipLaunchKernelGGL(k_fin_smul, dim3(pg, 2), dim3(64), 0, D.sA2, S.affA.p, S.affB1.p, rs_p, S.tbl.p, S.prod.p, B, nbp);
+    RLN_HIP(hipGetLastError());
+    RLN_HIP(hipEventRecord(S.evA, D.sA2));
+    // sC in the order its inputs arrive: the G2 sum and inversion (behind the G2 walk only), then the C segment (behind
+    // the h rows), then k_fin_out (behind s A, r B1 and the proof values)
+    RLN_HIP(hipStreamWaitEvent(D.sC, S.evB2, 0));
+    RLN_HIP(hipEventRecord(S.t[9], D.sC));
+    hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(256), 0, D.sC, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, all6);
+    hipLaunchKernelGGL(k_glv_fold, dim3(pg, 1), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({3}));
+    hipLaunchKernelGGL(k_fin_affine, dim3(pg, 1), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
+                       S.affB2.p, B, nbp, task_sel({2}));
+    RLN_HIP(hipStreamWaitEvent(D.sC, S.evB, 0));
+    hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, 2), dim3(256), 0, D.sC, S.part1.p, P1.segchunks.p, S.sums1.p, B,
+                       PB, task_sel({2, 5}));
+    hipLaunchKernelGGL(k_glv_fold, dim3(pg, 1), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({2}));
+    RLN_HIP(hipStreamWaitEvent(D.sC, S.evA, 0));
+    RLN_HIP(hipStreamWaitEvent(D.sC, S.evV, 0));
+  } else {
+    RLN_HIP(hipStreamWaitEvent(D.sC, S.evV, 0));
+    RLN_HIP(hipStreamWaitEvent(D.sC, S.evB, 0));
+    if (D.split_msm) RLN_HIP(hipStreamWaitEvent(D.sC, S.evB2, 0));
+    RLN_HIP(hipEventRecord(S.t[9], D.sC));
+  }
+  if (early_fin) {
+  } else if (lanechunk) {   // small batch: lanes = partial sums (k_sum_tree)
+    hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, P1.nseg), dim3(256), 0, D.sC, S.part1.p, P1.segchunks.p, S.sums1.p, B, PB, all6);
+    hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(256), 0, D.sC, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, all6);
   } else {
     if (P1.ngroups)
       hipLaunchKernelGGL(k_sum_ranges<Fq>, dim3(pg, P1.ngroups), dim3(64), 0, D.sC, S.part1.p, P1.groups.p, P1.ngroups,
@@ -2130,8 +2196,9 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     hipLaunchKernelGGL(k_sum_ranges<Fq>, dim3(pg, P1.nseg), dim3(64), 0, D.sC, S.grp1.p, P1.segs.p, P1.nseg, S.sums1.p, B, nbp);
     hipLaunchKernelGGL(k_sum_ranges<Fq2>, dim3(pg, P2.nseg), dim3(64), 0, D.sC, S.grp2.p, P2.segs.p, P2.nseg, S.sums2.p, B, nbp);
   }
-  if (D.nh == 2)  // sums of the second halves through phi, onto the first: afterwards sums1[0..3) / sums2[0] as without GLV
-    hipLaunchKernelGGL(k_glv_fold, dim3(pg, 4), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, 3u, B, nbp);
+  if (early_fin) {
+  } else if (D.nh == 2)  // sums of the second halves through phi, onto the first: afterwards sums1[0..3) / sums2[0] as without GLV
+    hipLaunchKernelGGL(k_glv_fold, dim3(pg, 4), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, 3u, B, nbp, all4);
   if (mode == PROVE_PARTIAL) {
     hipLaunchKernelGGL(k_partial_out, dim3(pg, 4), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, S.pp_out.p, B, nbp);
     RLN_HIP(hipGetLastError());
@@ -2139,10 +2206,12 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   } else {
     if (mode == PROVE_FINISH)
       hipLaunchKernelGGL(k_add_partial, dim3(pg, 4), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, pp_p, B, nbp);
-    hipLaunchKernelGGL(k_fin_affine, dim3(pg, 3), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
-                       S.affB2.p, B, nbp);
-    hipLaunchKernelGGL(k_fin_smul, dim3(pg, 2), dim3(64), 0, D.sC, S.affA.p, S.affB1.p, rs_p, S.tbl.p, S.prod.p, B,
-                       nbp);
+    if (!early_fin) {
+      hipLaunchKernelGGL(k_fin_affine, dim3(pg, 3), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
+                         S.affB2.p, B, nbp, all3);
+      hipLaunchKernelGGL(k_fin_smul, dim3(pg, 2), dim3(64), 0, D.sC, S.affA.p, S.affB1.p, rs_p, S.tbl.p, S.prod.p, B,
+                         nbp);
+    }
     hipLaunchKernelGGL(k_fin_out, dim3(pg), dim3(64), 0, D.sC, S.sums1.p, S.prod.p, S.affA.p, S.affB2.p, S.coords.p,
                        S.comp.p, B, nbp);
     RLN_HIP(hipGetLastError());

@@ -33,7 +33,8 @@ struct ChunkDesc {
 // proof's walk is issue-bound whatever the batch holds -- with lanes = proofs a single proof still issues every
 // instruction of its 2 960 + 962 chunk waves, 63 lanes idle (4.4 + 5.6 ms) -- so below half a wave of proofs the walk
 // runs transposed: 47 + 16 waves per proof, each alone on its SIMD.  Rows, scalar ids and table rows become per-lane
-// (vector) loads; the partial sums land where k_sum_ranges expects them.
+// (vector) loads; the partial sums land at part[chunk * pgroups + proof] (the parameter is the stride of the
+// partial-sum array in this mode: the small-batch plans cut the walks into shorter chunks and keep [chunk][64]).
 template <class Acc, class Entry, class Out, int WAVES, bool LANECHUNK = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_msm29(const Entry* __restrict__ table, const uint32_t* __restrict__ sid,
                                               const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks,
@@ -67,7 +68,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 
         }
       }
     }
-    part[(size_t)chunk * B + p] = acc.to_xyzz();
+    part[(size_t)chunk * pgroups + p] = acc.to_xyzz();   // LANECHUNK: `pgroups` carries the stride of `part`
     return;
   }
   uint32_t xcd = L & 7, q = L >> 3;
