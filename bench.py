@@ -126,7 +126,7 @@ def measure_config3(steps=3):
             "paths_ms": round(p, 3), "hashes_per_s": round((n - 1) / (b * 1e-3), 1),
             "achieved_GBps": round(CONFIG3_BYTES / ((b + p) * 1e-3) / 1e9, 2),
             "correct": bad == 0, "paths_failed_device_verification": bad,
-            "roofline": {"bound": "hbm", "kernel": "k_proofs_canon (path emission)",
+            "roofline": {"bound": "hbm", "kernel": "k_proofs_lds (path emission)",
                          "achieved": round(path_bytes / (p * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(path_bytes / (p * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}}
 

@@ -993,8 +993,11 @@ __global__ void k_scatter_witness(const uint32_t* __restrict__ given, const uint
 // buffers by a kernel on the batch's own front-end stream (the pinned pages are device-visible).  A hipMemcpyAsync
 // here goes through the runtime's copy path (SDMA / blit + cross-queue signalling), which with the HIP runtime torch
 // bundles (7.0) cost 8 ms per 1024-proof batch against 0 with ROCm 7.2's -- the same-box A/B is in profiles/r3_*.
-__global__ void __launch_bounds__(256) k_stage_in(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16) {
-  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+// Single-wave workgroups: a 256-thread workgroup needs four free wave slots on one CU at the same instant, which the
+// single-wave MSM workgroups streaming through the chip rarely leave (rocprofv3: 3.0 ms on average, 26.7 ms at worst
+// for this 30 us copy when it was launched as 256-thread workgroups).
+__global__ void __launch_bounds__(64) k_stage_in(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16) {
+  uint32_t i = blockIdx.x * 64 + threadIdx.x;
   if (i < n16) dst[i] = src[i];
 }
 
@@ -1978,7 +1981,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     static const bool h2d_kernel = env_int("RLNAMD_H2D_KERNEL", 1) != 0;
     auto h2d = [&](void* dst, const uint8_t* src, size_t bytes) {   // sizes are multiples of 32
       if (h2d_kernel)
-        hipLaunchKernelGGL(k_stage_in, dim3(div_up(bytes / 16, 256)), dim3(256), 0, sA, (const uint4*)src, (uint4*)dst,
+        hipLaunchKernelGGL(k_stage_in, dim3(div_up(bytes / 16, 64)), dim3(64), 0, sA, (const uint4*)src, (uint4*)dst,
                            (uint32_t)(bytes / 16));
       else
         RLN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, sA));
