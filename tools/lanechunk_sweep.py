@@ -1,8 +1,9 @@
 import json, os, sys, time
-sys.path.insert(0, "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from zerokit_amd.batch import BatchProver
-sys.path.insert(0, "/root/repo/tests")
-cases = json.load(open("/root/repo/tests/golden/rln_h20_vectors.json"))["cases"]
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+cases = json.load(open(os.path.join(ROOT, "tests", "golden", "rln_h20_vectors.json")))["cases"]
 import test_gpu_parity as T
 ws = [T._w(c) for c in cases]; rs = [(int(c["r"]), int(c["s"])) for c in cases]
 p = BatchProver(max_batch=64)

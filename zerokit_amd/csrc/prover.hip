@@ -16,6 +16,7 @@
 #include "poseidon.h"
 #include "witness_ops.h"
 #include "witness_lanes.h"
+#include "fin29.h"
 
 namespace rlnamd {
 
@@ -1467,10 +1468,16 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
       for (uint32_t i = 0; i < slot2node.size(); i++) store_slot[slot2node[i]] = i;
       D.witlanes.build(graph_, store_slot, (uint32_t)slot2node.size(), s);   // V29 has one row more than stored values
     }
-    RLN_HIP(hipFuncSetAttribute((const void*)k_witness29<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                WIT29_LDS_BYTES));
-    RLN_HIP(hipFuncSetAttribute((const void*)k_witness29<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                WIT29_LDS_BYTES));
+    // 152 KiB of dynamic LDS: a device / partition with a smaller limit keeps the 8 x 32 interpreter (k_witness), the
+    // same fallback as for graphs with 65 536 or more stored values -- a resource limit must not fail the constructor
+    if (hipFuncSetAttribute((const void*)k_witness29<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            WIT29_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_witness29<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            WIT29_LDS_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      D.wit29 = false;
+      D.witlanes.ok = false;
+    }
   }
   D.sig2node.alloc(D.NS);
   D.sig2node.upload(graph_.signals.data(), D.NS, s);
@@ -2155,6 +2162,8 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // walk is done -- beside the NTTs and the walk of the h rows, not behind them.  sums1 segments: h * 3 + {A, B1, C}.
   const bool early_fin = early && mode == PROVE_FULL && D.nh == 2 && env_int("RLNAMD_EARLY_FIN", 1) != 0;
   const TaskSel all6 = task_sel({0, 1, 2, 3, 4, 5}), all4 = task_sel({0, 1, 2, 3}), all3 = task_sel({0, 1, 2});
+  // below a wave of proofs s A / r B1 are a lone lane's chain: NAF ladder in the 9 x 29 form (fin29.hip)
+  const bool fin29 = nb <= D.lanechunk_max && D.use29 && env_int("RLNAMD_FIN29", 1) != 0;
   if (early_fin) {
     RLN_HIP(hipStreamWaitEvent(D.sA2, S.evE, 0));   // sB: the early G1 walk
     hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, 4), dim3(256), 0, D.sA2, S.part1.p, P1.segchunks.p, S.sums1.p, B,
@@ -2162,7 +2171,10 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     hipLaunchKernelGGL(k_glv_fold, dim3(pg, 2), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({0, 1}));
     hipLaunchKernelGGL(k_fin_affine, dim3(pg, 2), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
                        S.affB2.p, B, nbp, task_sel({0, 1}));
-    hipLaunchKernelGGL(k_fin_smul, dim3(pg, 2), dim3(64), 0, D.sA2, S.affA.p, S.affB1.p, rs_p, S.tbl.p, S.prod.p, B, nbp);
+    if (fin29)
+      launch_fin_smul29(D.sA2, S.affA.p, S.affB1.p, rs_p, S.prod.p, B, nb);
+    else
+      hipLaunchKernelGGL(k_fin_smul, dim3(pg, 2), dim3(64), 0, D.sA2, S.affA.p, S.affB1.p, rs_p, S.tbl.p, S.prod.p, B, nbp);
     RLN_HIP(hipGetLastError());
     RLN_HIP(hipEventRecord(S.evA, D.sA2));
     // sC in the order its inputs arrive: the G2 sum and inversion (behind the G2 walk only), then the C segment (behind
@@ -2212,8 +2224,11 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     if (!early_fin) {
       hipLaunchKernelGGL(k_fin_affine, dim3(pg, 3), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
                          S.affB2.p, B, nbp, all3);
-      hipLaunchKernelGGL(k_fin_smul, dim3(pg, 2), dim3(64), 0, D.sC, S.affA.p, S.affB1.p, rs_p, S.tbl.p, S.prod.p, B,
-                         nbp);
+      if (fin29)
+        launch_fin_smul29(D.sC, S.affA.p, S.affB1.p, rs_p, S.prod.p, B, nb);
+      else
+        hipLaunchKernelGGL(k_fin_smul, dim3(pg, 2), dim3(64), 0, D.sC, S.affA.p, S.affB1.p, rs_p, S.tbl.p, S.prod.p, B,
+                           nbp);
     }
     hipLaunchKernelGGL(k_fin_out, dim3(pg), dim3(64), 0, D.sC, S.sums1.p, S.prod.p, S.affA.p, S.affB2.p, S.coords.p,
                        S.comp.p, B, nbp);

@@ -403,7 +403,11 @@ void WitLanes::build(const Graph& graph, const std::vector<uint32_t>& store_slot
   prog.alloc(img.size());
   prog.upload(img.data(), img.size(), s);
   RLN_HIP(hipStreamSynchronize(s));
-  RLN_HIP(hipFuncSetAttribute((const void*)k_witness_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, WL_LDS_BYTES));
+  if (hipFuncSetAttribute((const void*)k_witness_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, WL_LDS_BYTES) !=
+      hipSuccess) {   // a device with less LDS per workgroup: keep k_witness29
+    (void)hipGetLastError();
+    return;
+  }
   ok = true;
   if (env_int_wl("RLNAMD_WITLANES_INFO", 0))
     fprintf(stderr, "witness lanes: %u steps (%u fma, %u sqr, %u add, %u misc), peak %u live values, %u constants\n", nsteps,
