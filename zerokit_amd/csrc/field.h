@@ -342,19 +342,20 @@ struct Fp {
     }
     return r;
   }
-  // Inverse; 0 -> 0.  Device: Fermat (straight-line, no divergence).  Host: binary extended Euclid on the stored
-  // integer x = a R (about 2 x 254 shift / subtract steps on four 64-bit words instead of 380 field products: the
-  // verifier's affine line steps, to_affine and the Fq12 inverse all end here), then x^-1 = a^-1 R^-1 is carried
-  // back to a^-1 R by two products with R^2.
+  // Inverse; 0 -> 0.  Binary extended Euclid on the stored integer x = a R (about 2 x 254 shift / subtract steps on four
+  // 64-bit words instead of the 380 field products of a^(p-2): the verifier's affine line steps, to_affine and the Fq12
+  // inverse all end here), then x^-1 = a^-1 R^-1 is carried back to a^-1 R by two products with R^2.  Since round 3 the
+  // device takes the same route: an inversion is a lone dependent chain wherever it occurs (the three to_affine of a
+  // proof's back end, one per table-build level), ~20 k instructions instead of ~140 k -- 0.29 -> see profiles/r3 for one
+  // proof; lanes of a batch diverge inside the loop and still finish sooner.  -DRLN_DEVICE_FERMAT restores a^(p-2).
   RLN_HD Fp inv() const {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RLN_DEVICE_FERMAT)
     uint32_t e[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) e[i] = P::PM2[i];
     return pow(e);
 #else
     if (is_zero()) return zero();
-    typedef unsigned __int128 u128;
     uint64_t u[4], w[4], x1[4] = {1, 0, 0, 0}, x2[4] = {0, 0, 0, 0}, M[4];
     for (int i = 0; i < 4; i++) {
       u[i] = (uint64_t)v[2 * i] | ((uint64_t)v[2 * i + 1] << 32);
@@ -367,21 +368,23 @@ struct Fp {
         if (a[i] != b[i]) return a[i] > b[i];
       return true;
     };
-    auto sub = [](uint64_t* a, const uint64_t* b) {   // a -= b, returns the borrow
+    auto sub = [](uint64_t* a, const uint64_t* b) {   // a -= b, returns the borrow (no 128-bit type: device code too)
       uint64_t br = 0;
       for (int i = 0; i < 4; i++) {
-        const u128 x = (u128)a[i] - b[i] - br;
-        a[i] = (uint64_t)x;
-        br = (uint64_t)(x >> 64) & 1;
+        const uint64_t t = a[i] - b[i], b1 = a[i] < b[i] ? 1u : 0u;
+        const uint64_t t2 = t - br, b2 = t < br ? 1u : 0u;
+        a[i] = t2;
+        br = b1 | b2;
       }
       return br;
     };
     auto add = [](uint64_t* a, const uint64_t* b) {   // a += b, returns the carry
       uint64_t c = 0;
       for (int i = 0; i < 4; i++) {
-        const u128 x = (u128)a[i] + b[i] + c;
-        a[i] = (uint64_t)x;
-        c = (uint64_t)(x >> 64);
+        const uint64_t t = a[i] + b[i], c1 = t < a[i] ? 1u : 0u;
+        const uint64_t t2 = t + c, c2 = t2 < t ? 1u : 0u;
+        a[i] = t2;
+        c = c1 | c2;
       }
       return c;
     };
@@ -414,11 +417,12 @@ struct Fp {
         submod(x2, x1);
       }
     }
-    const uint64_t* res = is_one(u) ? x1 : x2;
+    const bool first = is_one(u);
     Fp y, r2;
     for (int i = 0; i < 4; i++) {
-      y.v[2 * i] = (uint32_t)res[i];
-      y.v[2 * i + 1] = (uint32_t)(res[i] >> 32);
+      const uint64_t res = first ? x1[i] : x2[i];   // (no pointer to the local arrays: they stay in registers)
+      y.v[2 * i] = (uint32_t)res;
+      y.v[2 * i + 1] = (uint32_t)(res >> 32);
     }
     for (int i = 0; i < 8; i++) r2.v[i] = P::R2[i];
     return y * r2 * r2;

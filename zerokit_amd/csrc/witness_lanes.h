@@ -17,7 +17,7 @@ namespace rlnamd {
 
 struct WitLanes {
   bool ok = false;            // false: the graph does not fit this form (too many constants / live values): use k_witness29
-  uint32_t nsteps = 0, nfma = 0, nsqr = 0, nadd = 0, nmisc = 0, peak_slots = 0, n_consts = 0;
+  uint32_t nsteps = 0, nrow = 0, nfma = 0, nsqr = 0, nadd = 0, nmisc = 0, peak_slots = 0, n_consts = 0;
   DevBuf<uint4> prog;         // [nsteps + padding][WL_W] micro-op descriptors
   // store_slot[n]: index of node n in the compact array of stored values (V29), or 0xFFFFFFFF when it is not stored.
   // d_consts29: the graph constants in the 9 x 29-bit Montgomery form, 9 words each (device memory).

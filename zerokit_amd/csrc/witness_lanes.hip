@@ -19,15 +19,17 @@
 
 namespace rlnamd {
 
-constexpr uint32_t WL_W = 32;                 // micro-ops per step (the widest ready set of the shipped circuits is 21)
+constexpr uint32_t WL_W = 64;                 // descriptors per step: one per lane (lane-form steps), 16 copies per row (row form)
+constexpr uint32_t WL_ROWS = 4;               // products per row-form step: one per DPP row of 16 lanes
 constexpr uint32_t WL_SLOTS = 3200;           // LDS value slots of 48 bytes: 150 KiB
 constexpr uint32_t WL_LDS_BYTES = WL_SLOTS * 48 + 64;
 constexpr uint32_t WL_PF = 8;                 // descriptors prefetched per lane (steps ahead)
 constexpr double WL_BMAX = 7.5;
-enum : uint32_t { WK_FMA = 0, WK_ADD = 1, WK_MISC = 2, WK_SQR = 3 };   // WK_SQR: every lane computes a * a + c
+enum : uint32_t { WK_FMA = 0, WK_ADD = 1, WK_MISC = 2, WK_SQR = 3, WK_ROW = 4 };   // 3 bits in the descriptor
+// WK_SQR: every lane computes a * a + c.  WK_ROW: a * b + c with ONE product per 16-lane DPP row, a limb per lane (below).
 enum : uint32_t { WO_NOP = 0, WO_COMPUTE = 1, WO_INPUT = 2, WO_RARE = 3 };   // MISC steps: what the lane does
 constexpr uint32_t WL_STORE = 1u << 8;
-// descriptor: x = lane op | WL_STORE | kind << 12 | graph op << 16;  y = dst | a << 16;  z = b | c << 16;  w = V29 slot
+// descriptor: x = lane op | WL_STORE | kind << 12 (3 bits) | graph op << 16;  y = dst | a << 16;  z = b | c << 16;  w = V29 slot
 //             (dst, a, b, c: LDS slots; WO_INPUT: a = index into the inputs buffer)
 
 __device__ __forceinline__ void wl_read(Fr29& r, const uint32_t* lds, uint32_t slot) {
@@ -74,6 +76,9 @@ __device__ __noinline__ WlOut wl_misc(uint32_t dx, uint32_t dy, uint32_t dz, con
     wl_read(va, lds, dy >> 16);
     wl_read(vb, lds, dz & 0xFFFF);
     wl_read(vc, lds, dz >> 16);
+    va.normalize();   // row-form results carry limbs up to 2^29 + 2: the exact zero test compares limb patterns
+    vb.normalize();
+    vc.normalize();
     if (gop == G_TERN) {
       const bool z = va.is_zero_mod_q();  // graph.rs:214-224
 #pragma unroll
@@ -86,6 +91,81 @@ __device__ __noinline__ WlOut wl_misc(uint32_t dx, uint32_t dy, uint32_t dz, con
   }
   o.v = v;
   return o;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row form of a * b + c (WK_ROW).  A lane-form step spends ~290 instructions of ONE wave on products that occupy two of
+// its 64 lanes on average.  Here a value's nine 29-bit limbs sit in lanes 0..8 of a 16-lane DPP row (a wave = four
+// products), and every lane computes ONE column of each partial product:
+//     T_c = sum_k a_k b_(c-k)          b_(c-k) = the neighbour's limb, fetched with v_mov_dpp row_shr:k
+//     T_(c+9) = sum_k a_k b_(c+9-k)    row_shl:(9-k);  a's limbs are row-uniform (every lane reads all nine from LDS)
+// The reduction is the separated (not interleaved) Montgomery form, because an interleaved round would need lane 0's
+// digit broadcast to its row nine times in a dependent chain:  n = T mod 2^261 as 29-bit limbs (one carry pass across the
+// lanes), m = n p' mod 2^261, U = m p, result = (T + U) / 2^261 + c.  The low 261 bits of T + U are an exact multiple of
+// 2^261; its quotient K (the carry into column 9) is read off the top three low columns:  W = S_8 + (S_7 >> 29) +
+// (S_6 >> 58) misses less than 3 units of the exact 2^29 K, so K = (W + 16) >> 29.  ~165 instructions per step.
+// Limbs: inputs "near-normalised" (< 2^29 + 4 below the top limb), columns < 9 (2^29.01)^2 + 9 2^29 2^30.1 < 2^63.3.
+// Values: m < 2^262 (lazy top limb), so the result is below a b / 2^261 + 2 r + c  -- the host's bounds use 2.4 r.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dppz(uint32_t v) {   // the neighbour's value; 0 where the source lane is outside the row
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+#define WL_SHR(k) (0x110 + (k))   // row_shr:k  lane i reads lane i - k
+#define WL_SHL(k) (0x100 + (k))   // row_shl:k  lane i reads lane i + k
+constexpr uint32_t WL_PINV[9] = {0x0fffffffu, 0x170fac9fu, 0x1a446cf0u, 0x0d0c9698u, 0x02391658u,
+                                 0x0c144c83u, 0x06cb8e6au, 0x03a1b068u, 0x1273f82fu};   // -r^-1 mod 2^261, 29-bit limbs
+// a 64-bit column -> its three 29-bit pieces, each delivered to the lane it belongs to
+__device__ __forceinline__ uint32_t wl_carry3(uint64_t x) {
+  constexpr uint32_t M = (1u << 29) - 1;
+  const uint32_t l = (uint32_t)x & M, mid = (uint32_t)(x >> 29) & M, h = (uint32_t)(x >> 58);
+  return l + dppz<WL_SHR(1)>(mid) + dppz<WL_SHR(2)>(h);
+}
+#define WL_MACS(lo, hi, cst, v)                                                                    \
+  lo = (uint64_t)cst[0] * v;                                                                        \
+  hi = 0;                                                                                           \
+  lo += (uint64_t)cst[1] * dppz<WL_SHR(1)>(v); hi += (uint64_t)cst[1] * dppz<WL_SHL(8)>(v);         \
+  lo += (uint64_t)cst[2] * dppz<WL_SHR(2)>(v); hi += (uint64_t)cst[2] * dppz<WL_SHL(7)>(v);         \
+  lo += (uint64_t)cst[3] * dppz<WL_SHR(3)>(v); hi += (uint64_t)cst[3] * dppz<WL_SHL(6)>(v);         \
+  lo += (uint64_t)cst[4] * dppz<WL_SHR(4)>(v); hi += (uint64_t)cst[4] * dppz<WL_SHL(5)>(v);         \
+  lo += (uint64_t)cst[5] * dppz<WL_SHR(5)>(v); hi += (uint64_t)cst[5] * dppz<WL_SHL(4)>(v);         \
+  lo += (uint64_t)cst[6] * dppz<WL_SHR(6)>(v); hi += (uint64_t)cst[6] * dppz<WL_SHL(3)>(v);         \
+  lo += (uint64_t)cst[7] * dppz<WL_SHR(7)>(v); hi += (uint64_t)cst[7] * dppz<WL_SHL(2)>(v);         \
+  lo += (uint64_t)cst[8] * dppz<WL_SHR(8)>(v); hi += (uint64_t)cst[8] * dppz<WL_SHL(1)>(v);
+// a: the nine limbs of the first factor (row-uniform); b, c: this lane's limb of the second factor and of the addend
+// (0 in lanes 9..15 of the row); j = lane & 15.  Returns this lane's limb of a b / 2^261 + c (valid in lanes 0..8).
+__device__ __forceinline__ uint32_t wl_row_mul_add(const uint32_t (&a)[9], uint32_t b, uint32_t c, uint32_t j) {
+  constexpr uint32_t M = (1u << 29) - 1;
+  uint64_t tlo, thi;
+  WL_MACS(tlo, thi, a, b)
+  const uint32_t n = wl_carry3(tlo);                      // T mod 2^261, limbs < 2^30 + 2^6 (lanes 0..8)
+  uint64_t u = (uint64_t)WL_PINV[0] * n;
+  u += (uint64_t)WL_PINV[1] * dppz<WL_SHR(1)>(n);
+  u += (uint64_t)WL_PINV[2] * dppz<WL_SHR(2)>(n);
+  u += (uint64_t)WL_PINV[3] * dppz<WL_SHR(3)>(n);
+  u += (uint64_t)WL_PINV[4] * dppz<WL_SHR(4)>(n);
+  u += (uint64_t)WL_PINV[5] * dppz<WL_SHR(5)>(n);
+  u += (uint64_t)WL_PINV[6] * dppz<WL_SHR(6)>(n);
+  u += (uint64_t)WL_PINV[7] * dppz<WL_SHR(7)>(n);
+  u += (uint64_t)WL_PINV[8] * dppz<WL_SHR(8)>(n);
+  uint32_t m = wl_carry3(u);                              // n p' mod 2^261 (what leaves lane 8 is dropped)
+  m = j < 9 ? m : 0;
+  uint64_t ulo, uhi;
+  WL_MACS(ulo, uhi, Fr29C::P, m)
+  const uint64_t slo = tlo + ulo;
+  uint64_t shi = thi + uhi;
+  // carry of the low half: exact in lane 8, moved to lane 0 of the high half
+  const uint64_t t1 = slo >> 29;
+  const uint32_t t2 = (uint32_t)(slo >> 58);
+  const uint64_t t1n = (uint64_t)dppz<WL_SHR(1)>((uint32_t)t1) | ((uint64_t)dppz<WL_SHR(1)>((uint32_t)(t1 >> 32)) << 32);
+  const uint64_t w = slo + t1n + dppz<WL_SHR(2)>(t2);
+  const uint64_t K = (w + 16) >> 29;
+  const uint64_t K0 = (uint64_t)dppz<WL_SHL(8)>((uint32_t)K) | ((uint64_t)dppz<WL_SHL(8)>((uint32_t)(K >> 32)) << 32);
+  shi += (j == 0 ? K0 : 0) + c;
+  // two carry passes: limbs 0..7 below 2^29 + 2, limb 8 keeps the rest
+  const uint32_t r1 = wl_carry3(shi);
+  const uint32_t keep = j < 8 ? (r1 & M) : r1, carry = j < 8 ? (r1 >> 29) : 0;
+  return keep + dppz<WL_SHR(1)>(carry);
 }
 
 __global__ void __launch_bounds__(64) k_witness_lanes(const uint4* __restrict__ prog, uint32_t nsteps,
@@ -105,7 +185,6 @@ __global__ void __launch_bounds__(64) k_witness_lanes(const uint4* __restrict__ 
     lds[WL_SLOTS * 12] = 0;   // error word
   }
   __syncthreads();
-  if (lane >= WL_W) return;   // the upper half of the wave has no micro-ops
   uint32_t e = WERR_NONE;
   uint4 d[WL_PF];
 #pragma unroll
@@ -116,8 +195,23 @@ __global__ void __launch_bounds__(64) k_witness_lanes(const uint4* __restrict__ 
     for (int k = 0; k < (int)WL_PF; k++) {
       const uint4 q = d[k];
       d[k] = prog[(size_t)(t0 + WL_PF + k) * WL_W + lane];   // the program is padded by WL_PF empty steps
-      const uint32_t kind = (__builtin_amdgcn_readfirstlane(q.x) >> 12) & 3;
+      const uint32_t kind = (__builtin_amdgcn_readfirstlane(q.x) >> 12) & 7;
       const uint32_t dst = q.y & 0xFFFF, sa = q.y >> 16, sb = q.z & 0xFFFF, sc = q.z >> 16;
+      if (__builtin_expect(kind == WK_ROW, 1)) {
+        // one product per 16-lane row; the row's descriptor is replicated over its lanes
+        const uint32_t j = lane & 15, jj = j < 9 ? j : 0;
+        Fr29 va;
+        wl_read(va, lds, sa);
+        uint32_t vb = lds[sb * 12 + jj], vc = lds[sc * 12 + jj];
+        vb = j < 9 ? vb : 0;
+        vc = j < 9 ? vc : 0;
+        const uint32_t r = wl_row_mul_add(va.v, vb, vc, j);
+        if (j < 9) {
+          lds[dst * 12 + j] = r;
+          if (q.x & WL_STORE) ((uint32_t*)(V29 + ((size_t)q.w * B + p) * 3))[j] = r;
+        }
+        continue;
+      }
       Fr29 v;
       // FMA steps fall through (a uniform branch hop costs a lone wave 25 - 70 cycles)
       if (__builtin_expect(kind == WK_FMA, 1)) {
@@ -224,9 +318,22 @@ void WitLanes::build(const Graph& graph, const std::vector<uint32_t>& store_slot
   uint32_t next_tmp = N;
   std::vector<double> tmp_bound;
   auto bnd = [&](uint32_t v) { return v < N ? bound[v] : tmp_bound[v - N]; };
-  nfma = nadd = nmisc = nsqr = 0;
+  nfma = nadd = nmisc = nsqr = nrow = 0;
+  // row form (one product per 16-lane row, wl_row_mul_add): at most WL_ROWS products per step, result < 2.05 r + ...
+  const bool rows = env_int_wl("RLNAMD_WITROWS", 1) != 0;
+  const double PB0 = rows ? 2.05 : 1.0;
+  const size_t fma_cap = rows ? WL_ROWS : WL_W;
+  // height = longest chain of nodes from a node to a sink: when a step cannot take every ready node, the ones the
+  // longest chains hang on go first
+  std::vector<uint32_t> height(N, 0);
+  for (uint32_t n = N; n-- > 0;) {
+    const uint32_t o[3] = {G[n].a, G[n].b, G[n].c};
+    for (int k = 0; k < nops(G[n]); k++) height[o[k]] = std::max(height[o[k]], height[n] + 1);
+  }
   while (!ready.empty() || !pending.empty()) {
-    std::sort(ready.begin(), ready.end());
+    std::sort(ready.begin(), ready.end(), [&](uint32_t x, uint32_t y) {
+      return height[x] != height[y] ? height[x] > height[y] : x < y;
+    });
     std::vector<MicroOp> ops;
     std::vector<uint32_t> produced, left;
     uint32_t kind;
@@ -251,17 +358,19 @@ void WitLanes::build(const Graph& graph, const std::vector<uint32_t>& store_slot
       for (uint32_t n : ready)
         if (G[n].op == G_ADD && bound[G[n].a] + bound[G[n].b] > WL_BMAX) force_fma = true;
       kind = (any_mul || force_fma) ? WK_FMA : WK_ADD;
+      const size_t cap = kind == WK_FMA ? fma_cap : (size_t)WL_W;
       if (kind == WK_FMA) {
-        if (pending.size() > WL_W / 2) return;   // not a graph this form is meant for
+        std::vector<Pending> later;
         for (const Pending& pd : pending) {   // reductions first: their consumers are waiting
+          if (ops.size() >= cap) { later.push_back(pd); continue; }
           ops.push_back(MicroOp{WO_COMPUTE, G_MUL, pd.node, {pd.raw, FIX + ONE, FIX + Z}, pd.node, 0});
           produced.push_back(pd.node);
-          bound[pd.node] = 1.0 + 0.006 * bnd(pd.raw);
+          bound[pd.node] = PB0 + 0.006 * bnd(pd.raw);
         }
-        pending.clear();
+        pending.swap(later);
       }
       for (uint32_t n : ready) {
-        if (ops.size() >= WL_W) { left.push_back(n); continue; }
+        if (ops.size() >= cap) { left.push_back(n); continue; }
         const GNode& g = G[n];
         if (kind == WK_ADD) {
           ops.push_back(MicroOp{WO_COMPUTE, G_ADD, n, {g.a, g.b, NONE}, n, 0});
@@ -278,13 +387,13 @@ void WitLanes::build(const Graph& graph, const std::vector<uint32_t>& store_slot
             const uint32_t u = users[n][0];
             if (G[u].op == G_ADD && G[u].a != G[u].b) {
               const uint32_t other = G[u].a == n ? G[u].b : G[u].a;
-              if (avail[other] && bound[other] + 1.0 + 0.006 * bound[g.a] * bound[g.b] <= WL_BMAX) { add = u; c = other; }
+              if (avail[other] && bound[other] + PB0 + 0.006 * bound[g.a] * bound[g.b] <= WL_BMAX) { add = u; c = other; }
             }
           }
           if (add != NONE) {
             m.node = m.dst = add;
             m.src[0] = g.a; m.src[1] = g.b; m.src[2] = c;
-            b = 1.0 + 0.006 * bound[g.a] * bound[g.b] + bound[c];
+            b = PB0 + 0.006 * bound[g.a] * bound[g.b] + bound[c];
             done[n] = 1;   // never materialised
             bound[add] = b;
             ops.push_back(m);
@@ -292,17 +401,17 @@ void WitLanes::build(const Graph& graph, const std::vector<uint32_t>& store_slot
             continue;
           }
           m.src[0] = g.a; m.src[1] = g.b; m.src[2] = FIX + Z;
-          b = 1.0 + 0.006 * bound[g.a] * bound[g.b];
+          b = PB0 + 0.006 * bound[g.a] * bound[g.b];
         } else if (g.op == G_ADD) {   // x * 1 + y, the larger bound as multiplicand
           const uint32_t x = bound[g.a] >= bound[g.b] ? g.a : g.b, y = x == g.a ? g.b : g.a;
           m.src[0] = x; m.src[1] = FIX + ONE; m.src[2] = y;
-          b = 1.0 + 0.006 * bound[x] + bound[y];
+          b = PB0 + 0.006 * bound[x] + bound[y];
         } else if (g.op == G_SUB) {   // a - b = b * (-1) + a
           m.src[0] = g.b; m.src[1] = FIX + MONE; m.src[2] = g.a;
-          b = 1.0 + 0.006 * bound[g.b] * 1.05 + bound[g.a];
+          b = PB0 + 0.006 * bound[g.b] * 1.05 + bound[g.a];
         } else {                      // G_NEG
           m.src[0] = g.a; m.src[1] = FIX + MONE; m.src[2] = FIX + Z;
-          b = 1.0 + 0.006 * bound[g.a] * 1.05;
+          b = PB0 + 0.006 * bound[g.a] * 1.05;
         }
         if (b > WL_BMAX) {            // leave the raw value in a temporary and reduce it in the next FMA step
           const uint32_t raw = next_tmp++;
@@ -318,7 +427,10 @@ void WitLanes::build(const Graph& graph, const std::vector<uint32_t>& store_slot
         produced.push_back(n);
       }
     }
-    if (kind == WK_FMA) {   // all products squarings (idle lanes compute ZERO * ZERO + ZERO: a square as well)?
+    if (kind == WK_FMA && rows) {
+      kind = WK_ROW;
+      nrow++;
+    } else if (kind == WK_FMA) {   // all products squarings (idle lanes compute ZERO * ZERO + ZERO: a square as well)?
       bool all_sq = !ops.empty();
       for (const MicroOp& m : ops) all_sq = all_sq && m.src[0] == m.src[1];
       if (all_sq) { kind = WK_SQR; nsqr++; }
@@ -389,11 +501,18 @@ void WitLanes::build(const Graph& graph, const std::vector<uint32_t>& store_slot
       }
       const uint32_t fa = m.lop == WO_INPUT ? m.imm : sa[3 * i];
       if (fa >= 65536) return;          // an input index that does not fit the descriptor: keep k_witness29
-      img[(size_t)t * WL_W + i] = make_uint4(x, sl | (fa << 16), sa[3 * i + 1] | (sa[3 * i + 2] << 16), w);
+      const uint4 desc = make_uint4(x, sl | (fa << 16), sa[3 * i + 1] | (sa[3 * i + 2] << 16), w);
+      if (step_kind[t] == WK_ROW) {     // the row's sixteen lanes all read the row's descriptor
+        for (uint32_t l = 0; l < 16; l++) img[(size_t)t * WL_W + 16 * i + l] = desc;
+      } else {
+        img[(size_t)t * WL_W + i] = desc;
+      }
     }
     // every descriptor of the step carries the kind (lane 0's is the one the kernel reads)
-    for (uint32_t i = (uint32_t)steps[t].size(); i < WL_W; i++) img[(size_t)t * WL_W + i].x = step_kind[t] << 12;
-    if (steps[t].empty()) img[(size_t)t * WL_W].x = step_kind[t] << 12;
+    {
+      const uint32_t used = step_kind[t] == WK_ROW ? 16 * (uint32_t)steps[t].size() : (uint32_t)steps[t].size();
+      for (uint32_t i = used; i < WL_W; i++) img[(size_t)t * WL_W + i].x = step_kind[t] << 12;
+    }
     for (uint32_t v : dies[t]) {
       free_slots.push_back(slot[v]);
       live--;
@@ -410,8 +529,8 @@ void WitLanes::build(const Graph& graph, const std::vector<uint32_t>& store_slot
   }
   ok = true;
   if (env_int_wl("RLNAMD_WITLANES_INFO", 0))
-    fprintf(stderr, "witness lanes: %u steps (%u fma, %u sqr, %u add, %u misc), peak %u live values, %u constants\n", nsteps,
-            nfma, nsqr, nadd, nmisc, peak_slots, n_consts);
+    fprintf(stderr, "witness lanes: %u steps (%u row, %u fma, %u sqr, %u add, %u misc), peak %u live values, %u constants\n",
+            nsteps, nrow, nfma, nsqr, nadd, nmisc, peak_slots, n_consts);
 }
 
 void WitLanes::launch(hipStream_t s, const uint32_t* d_consts29, const uint32_t* d_inputs, uint32_t n_inputs, uint4* V29,
