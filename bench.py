@@ -178,16 +178,16 @@ def msm_main(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    from zerokit_amd import lib        # before torch: see main()
-    from zerokit_amd._native import check
-    check(lib().rlnamd_set_device(local_rank))
     dist = None
-    if world > 1:
+    if world > 1:   # torch first: see main()
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    from zerokit_amd import lib
+    from zerokit_amd._native import check
+    check(lib().rlnamd_set_device(local_rank))
     comm = make_comm(rank, world, dist)
     out = measure_config5(comm, rank, world, max(args.steps, 1), int(os.environ.get("RLNAMD_MSM_LOG2", "24")))
     comm.close()
@@ -302,15 +302,18 @@ def main():
         return pool_main(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks for boxes with fewer devices than ranks (tools/gpu_r3_torchrun.sh): every rank on one device, gloo
+    # instead of RCCL (which refuses two ranks on one device); the driver never sets them
+    backend = os.environ.get("RLNAMD_BENCH_BACKEND", "nccl")
+    if "RLNAMD_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["RLNAMD_BENCH_DEVICE"])
 
-    # librln.so first: it then brings in the HIP runtime it was built for (/opt/rocm), and torch -- needed only under
-    # torchrun, for the barrier and the max over ranks -- binds to the same libamdhip64.so.7 instead of the older one
-    # bundled in its wheel.  A single-GPU run imports no torch at all.
-    from zerokit_amd import lib, workload
-    from zerokit_amd._native import check
-    from zerokit_amd.batch import BatchProver
-    check(lib().rlnamd_set_device(local_rank))
-    use_dist = under_torchrun                              # under torchrun the RCCL group is always created
+    # A single-GPU run imports no torch at all: librln.so brings in the HIP runtime it was built for (/opt/rocm).  Under
+    # torchrun torch is needed for the barrier and the max over ranks, and it goes FIRST: with librln.so (ROCm 7.2's
+    # libamdhip64 / librccl) loaded before a torch wheel built for ROCm 7.0 the process aborted at exit ("double free or
+    # corruption", tools/gpu_r3_torchrun.sh).  The streamed path no longer depends on which runtime it gets: the inputs
+    # are staged by a kernel, not by the copy path that was slow under the wheel's runtime (profiles/r3 section 1).
+    use_dist = under_torchrun                              # under torchrun the process group is always created
     torch = dist = None
     if use_dist:
         import torch  # plumbing only: barrier, max-reduce
@@ -318,7 +321,14 @@ def main():
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    from zerokit_amd import lib, workload
+    from zerokit_amd._native import check
+    from zerokit_amd.batch import BatchProver
+    check(lib().rlnamd_set_device(local_rank))
     name = C.create_string_buffer(128)
     lib().rlnamd_device_name(name, 128)
 
@@ -379,7 +389,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

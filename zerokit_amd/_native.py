@@ -2,9 +2,11 @@
 
 The library is the product; this file only declares signatures.  It is loaded with RTLD_GLOBAL so that it and torch
 (when a program uses both) share one HIP runtime -- whichever of the two is loaded first brings in its
-libamdhip64.so.7 and the other binds to it (same SONAME).  Load this library FIRST where throughput matters: the
-runtime bundled in the torch wheel (HIP 7.0) ran the streamed path 17 % slower than ROCm 7.2's in a same-box A/B
-(profiles/r3_rocprof_summary.md); bench.py does, and imports torch only under torchrun."""
+libamdhip64.so.7 and the other binds to it (same SONAME).  A program that uses both should import torch FIRST: with this
+library (ROCm 7.2's runtime and RCCL) loaded before a torch wheel built for ROCm 7.0 the process aborted at exit with a
+double free (tools/gpu_r3_torchrun.sh).  Throughput does not depend on the order since the streamed inputs are staged by a
+kernel instead of the copy path that was slow under the wheel's runtime (profiles/r3_rocprof_summary.md section 1);
+bench.py imports torch only under torchrun."""
 import ctypes as C
 import os
 
