@@ -1,0 +1,106 @@
+// Host emulator of the lanes = nodes witness interpreter: runs the micro-op program that zerokit_amd/csrc/witness_sched.cpp
+// emits (steps, LDS slot assignment, fusion, reductions) with the product's own host field arithmetic and graph
+// operations, so the CPU suite can check the SCHEDULE against the golden witness digests without a GPU.  The device
+// kernel differs only in how a value is represented (9 x 29-bit limbs, lazily reduced); residues mod r are the same.
+#include <stdint.h>
+#include <string.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "field.h"
+#include "witness_ops.h"
+#include "witness_sched.h"
+#include "zkey.h"
+
+using namespace rlnamd;
+
+static std::string g_err;
+
+extern "C" {
+const char* witsched_error() { return g_err.c_str(); }
+
+// graph: graph.bin bytes; inputs_le: inputs_size x 32 canonical LE (slot 0 = 1); rows: 0 lane form, 1 row form.
+// witness_out_le: num_signals x 32 canonical LE.  stats[0..7] = steps, row, fma, sqr, add, misc, peak live values, error flag
+int witsched_run(const uint8_t* graph, size_t len, const uint8_t* inputs_le, size_t inputs_size, int rows,
+                 uint8_t* witness_out_le, uint32_t* stats) {
+  try {
+    Graph g = parse_graph(graph, len);
+    if (inputs_size != g.inputs_size) throw std::runtime_error("inputs size mismatch");
+    const uint32_t N = (uint32_t)g.nodes.size(), NONE = 0xFFFFFFFFu;
+    // store every witness signal (and every input), as the prover does
+    std::vector<uint32_t> store_slot(N, NONE), slot2node;
+    for (uint32_t n = 0; n < N; n++) {
+      bool st = g.nodes[n].op == G_INPUT;
+      for (uint32_t s : g.signals) st = st || s == n;
+      if (st) { store_slot[n] = (uint32_t)slot2node.size(); slot2node.push_back(n); }
+    }
+    const uint32_t trash = (uint32_t)slot2node.size();
+    WlProgram P = wl_schedule(g, store_slot, trash, rows != 0);
+    if (!P.ok) throw std::runtime_error("graph does not fit the lanes form");
+    std::vector<Fr> lds(WL_SLOTS, Fr::zero()), stored(slot2node.size() + 1, Fr::zero());
+    const uint32_t nc = P.n_consts;
+    for (uint32_t i = 0; i < nc; i++) lds[i] = g.constants[i];
+    lds[nc] = Fr::zero();
+    lds[nc + 1] = Fr::one();
+    lds[nc + 2] = Fr::one().neg();
+    uint32_t err = 0;
+    for (uint32_t t = 0; t < P.nsteps + WL_PF; t++) {   // the kernel runs whole groups of WL_PF steps: padding included
+      const WlDesc* d = &P.img[(size_t)t * WL_W];
+      const uint32_t kind = (d[0].x >> 12) & 7;
+      // every lane reads its operands before any lane writes: two phases
+      std::vector<std::pair<uint32_t, Fr>> writes;
+      std::vector<std::pair<uint32_t, Fr>> stores;
+      const uint32_t lanes = WL_W, stride = kind == WK_ROW ? 16 : 1;
+      for (uint32_t l = 0; l < lanes; l += stride) {
+        const WlDesc& q = d[l];
+        if (((q.x >> 12) & 7) != kind) throw std::runtime_error("step kind differs between lanes");
+        const uint32_t dst = q.y & 0xFFFF, sa = q.y >> 16, sb = q.z & 0xFFFF, sc = q.z >> 16, lop = q.x & 0xFF,
+                       gop = (q.x >> 16) & 0xFF;
+        Fr v = Fr::zero();
+        if (kind == WK_FMA || kind == WK_ROW) {
+          v = lds[sa] * lds[sb] + lds[sc];
+        } else if (kind == WK_SQR) {
+          if (sa != sb) throw std::runtime_error("SQR step with a != b");
+          v = lds[sa] * lds[sa] + lds[sc];
+        } else if (kind == WK_ADD) {
+          v = lds[sa] + lds[sb];
+        } else if (lop == WO_INPUT) {
+          uint32_t c[8];
+          memcpy(c, inputs_le + (size_t)sa * 32, 32);
+          if (limbs_geq(c, FrParams::MOD)) err = WERR_INPUT_RANGE;
+          v = Fr::from_canonical(c);
+        } else if (lop == WO_RARE) {
+          if (gop == G_TERN) v = lds[sa].is_zero() ? lds[sc] : lds[sb];
+          else v = witness_slow_op(gop, lds[sa], lds[sb], &err);
+        }
+        if (kind == WK_ROW) {
+          for (uint32_t k = 1; k < 16; k++)
+            if (memcmp(&d[l + k], &q, sizeof(q)) != 0) throw std::runtime_error("row descriptor not replicated");
+        }
+        writes.push_back({dst, v});
+        if (q.x & WL_STORE) stores.push_back({q.w, v});
+      }
+      for (auto& w : writes) lds[w.first] = w.second;
+      for (auto& s : stores) {
+        if (s.first >= stored.size()) throw std::runtime_error("store slot out of range");
+        stored[s.first] = s.second;
+      }
+    }
+    for (size_t i = 0; i < g.signals.size(); i++) {
+      uint32_t c[8];
+      const uint32_t node = g.signals[i];
+      if (g.nodes[node].op == G_CONST) g.constants[g.nodes[node].a].to_canonical(c);
+      else stored[store_slot[node]].to_canonical(c);
+      memcpy(witness_out_le + 32 * i, c, 32);
+    }
+    stats[0] = P.nsteps; stats[1] = P.nrow; stats[2] = P.nfma; stats[3] = P.nsqr; stats[4] = P.nadd; stats[5] = P.nmisc;
+    stats[6] = P.peak_slots; stats[7] = err;
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return 1;
+  }
+}
+}

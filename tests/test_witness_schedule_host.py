@@ -1,0 +1,101 @@
+"""The host-side scheduler of the lanes = nodes witness interpreter (zerokit_amd/csrc/witness_sched.cpp) without a GPU:
+tests/host/witsched.cpp runs the emitted micro-op program -- dependency steps, LDS slot assignment from liveness, product /
+addition fusion, reductions, row replication -- with the product's own host field arithmetic and graph operations
+(/root/reference/rln/src/circuit/iden3calc/graph.rs:72-143, 246-272, 314-466), and the witness must hash to the committed
+golden digests on all three shipped circuits, in lane form and in row form."""
+import ctypes
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "zerokit_amd", "csrc")
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+@pytest.fixture(scope="module")
+def WS():
+    so = os.path.join(ROOT, "tests", "host", "libwitsched.so")
+    srcs = [os.path.join(ROOT, "tests", "host", "witsched.cpp"), os.path.join(CSRC, "witness_sched.cpp"),
+            os.path.join(CSRC, "zkey.cpp")]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("witness_sched.h", "witness_ops.h", "zkey.h", "field.h", "curve.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I",
+                               "/opt/rocm/include", "-I", CSRC] + srcs + ["-o", so])
+    lib = ctypes.CDLL(so)
+    lib.witsched_error.restype = ctypes.c_char_p
+    return lib
+
+
+def _run(lib, graph_bytes, named_inputs, rows):
+    from oracle.pyref import wtns_graph
+    g = wtns_graph.parse(graph_bytes)
+    size = g.inputs_size()
+    buf = bytearray(size * 32)
+    buf[0] = 1
+    for name, vals in named_inputs.items():
+        off, ln = g.input_mapping[name]
+        assert ln == len(vals)
+        for k, v in enumerate(vals):
+            buf[(off + k) * 32:(off + k + 1) * 32] = (int(v) % R).to_bytes(32, "little")
+    out = ctypes.create_string_buffer(32 * len(g.signals))
+    stats = (ctypes.c_uint32 * 8)()
+    rc = lib.witsched_run(graph_bytes, len(graph_bytes), bytes(buf), size, rows, out, stats)
+    assert rc == 0, lib.witsched_error().decode()
+    return hashlib.sha256(out.raw).hexdigest(), list(stats)
+
+
+def _graph(sub):
+    return open(os.path.join(ROOT, "zerokit_amd", "resources", sub, "graph.bin"), "rb").read()
+
+
+@pytest.mark.parametrize("rows", [0, 1])
+def test_schedule_reproduces_the_golden_witness_depth20(WS, rows):
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "rln_h20_vectors.json")))["cases"]
+    gb = _graph("tree_depth_20")
+    seen = None
+    for c in cases:
+        w = c["witness"]
+        named = {"identitySecret": [w["identity_secret"]], "userMessageLimit": [w["user_message_limit"]],
+                 "messageId": [w["message_id"]], "pathElements": w["path_elements"],
+                 "identityPathIndex": w["identity_path_index"], "x": [w["x"]],
+                 "externalNullifier": [w["external_nullifier"]]}
+        digest, st = _run(WS, gb, named, rows)
+        assert digest == c["witness_sha256"], c["name"]
+        assert st[7] == 0
+        seen = st
+    steps, nrow, nfma, nsqr, nadd, nmisc, peak, _ = seen
+    # the shipped circuit has 13 972 products at a multiplication depth of 5 736: the schedule must stay near that depth
+    assert 5736 <= steps < 8000 and peak < 200
+    if rows:
+        assert nrow > 7000 and nfma == 0 and nsqr == 0
+    else:
+        assert nrow == 0 and nfma + nsqr > 6500 and nsqr > 2000
+
+
+@pytest.mark.parametrize("rows", [0, 1])
+def test_schedule_reproduces_the_golden_witness_other_circuits(WS, rows):
+    for c in json.load(open(os.path.join(ROOT, "tests", "golden", "rln_other_circuits.json")))["cases"]:
+        sub = "tree_depth_%d%s" % (c["depth"], "_multi_max_out_4" if c["multi"] else "")
+        digest, st = _run(WS, _graph(sub), c["inputs"], rows)
+        assert digest == c["witness_sha256"], c["name"]
+        assert st[7] == 0
+
+
+def test_out_of_range_input_sets_the_error_flag(WS):
+    """an input >= r is an error of the graph evaluation (graph.rs:42-45: u256_to_fr fails), not a silent reduction"""
+    from oracle.pyref import wtns_graph
+    gb = _graph("tree_depth_10")
+    g = wtns_graph.parse(gb)
+    size = g.inputs_size()
+    buf = bytearray(size * 32)
+    buf[0] = 1
+    off, _ = g.input_mapping["x"]
+    buf[off * 32:(off + 1) * 32] = R.to_bytes(32, "little")     # x = r: not canonical
+    out = ctypes.create_string_buffer(32 * len(g.signals))
+    stats = (ctypes.c_uint32 * 8)()
+    assert WS.witsched_run(gb, len(gb), bytes(buf), size, 1, out, stats) == 0
+    assert stats[7] == 1

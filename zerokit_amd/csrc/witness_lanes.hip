@@ -8,6 +8,7 @@
 // reduces its multiplicands (result < r + a b / 2^261 + c), so an Add riding in an FMA step takes the operand with the
 // larger bound as multiplicand; when a result would still pass WL_BMAX it is followed by a reduction x * ONE + ZERO.
 #include "witness_lanes.h"
+#include "witness_sched.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -19,18 +20,7 @@
 
 namespace rlnamd {
 
-constexpr uint32_t WL_W = 64;                 // descriptors per step: one per lane (lane-form steps), 16 copies per row (row form)
-constexpr uint32_t WL_ROWS = 4;               // products per row-form step: one per DPP row of 16 lanes
-constexpr uint32_t WL_SLOTS = 3200;           // LDS value slots of 48 bytes: 150 KiB
 constexpr uint32_t WL_LDS_BYTES = WL_SLOTS * 48 + 64;
-constexpr uint32_t WL_PF = 8;                 // descriptors prefetched per lane (steps ahead)
-constexpr double WL_BMAX = 7.5;
-enum : uint32_t { WK_FMA = 0, WK_ADD = 1, WK_MISC = 2, WK_SQR = 3, WK_ROW = 4 };   // 3 bits in the descriptor
-// WK_SQR: every lane computes a * a + c.  WK_ROW: a * b + c with ONE product per 16-lane DPP row, a limb per lane (below).
-enum : uint32_t { WO_NOP = 0, WO_COMPUTE = 1, WO_INPUT = 2, WO_RARE = 3 };   // MISC steps: what the lane does
-constexpr uint32_t WL_STORE = 1u << 8;
-// descriptor: x = lane op | WL_STORE | kind << 12 (3 bits) | graph op << 16;  y = dst | a << 16;  z = b | c << 16;  w = V29 slot
-//             (dst, a, b, c: LDS slots; WO_INPUT: a = index into the inputs buffer)
 
 __device__ __forceinline__ void wl_read(Fr29& r, const uint32_t* lds, uint32_t slot) {
   const char* a = (const char*)lds + slot * 48;
@@ -249,278 +239,19 @@ __global__ void __launch_bounds__(64) k_witness_lanes(const uint4* __restrict__ 
 }
 
 // ======================================================================================================= host
-namespace {
-struct MicroOp {
-  uint32_t lop, gop, node;     // node: the graph node this micro-op defines (NONE for a raw value awaiting its reduction)
-  uint32_t src[3];             // value ids (NONE: unused; >= FIX: a fixed LDS slot)
-  uint32_t dst;                // value id
-  uint32_t imm;                // WO_INPUT: index into the inputs buffer
-};
-constexpr uint32_t NONE = 0xFFFFFFFFu;
-int env_int_wl(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
-}  // namespace
-
 void WitLanes::build(const Graph& graph, const std::vector<uint32_t>& store_slot, uint32_t trash_slot, hipStream_t s) {
   ok = false;
-  if (env_int_wl("RLNAMD_WITLANES", 1) == 0) return;
-  const std::vector<GNode>& G = graph.nodes;
-  const uint32_t N = (uint32_t)G.size();
-  n_consts = (uint32_t)graph.constants.size();
-  const uint32_t Z = n_consts, ONE = n_consts + 1, MONE = n_consts + 2, first_free = n_consts + 3;
-  const uint32_t DUMMY = WL_SLOTS - 1;
-  const uint32_t FIX = (1u << 30) + N;    // value ids >= FIX address a fixed LDS slot (ZERO / ONE / MINUS_ONE)
-  if (first_free + 64 >= DUMMY) return;   // the constants alone (nearly) fill the LDS
-  auto nops = [&](const GNode& g) {
-    return (g.op == G_INPUT || g.op == G_CONST) ? 0 : (g.op == G_NEG || g.op == G_ID) ? 1 : g.op == G_TERN ? 3 : 2;
-  };
-  std::vector<uint8_t> is_signal(N, 0);
-  for (uint32_t sg : graph.signals) is_signal[sg] = 1;
-  std::vector<std::vector<uint32_t>> users(N);
-  std::vector<uint32_t> uses(N, 0);
-  for (uint32_t n = 0; n < N; n++) {
-    const uint32_t o[3] = {G[n].a, G[n].b, G[n].c};
-    for (int k = 0; k < nops(G[n]); k++) {
-      if (o[k] >= n) throw Error("Graph error: node operand refers forward");
-      uses[o[k]]++;
-      if (users[o[k]].empty() || users[o[k]].back() != n) users[o[k]].push_back(n);
-    }
-  }
-  // Values: one per graph node (id = node) plus temporaries (raw results awaiting a reduction), ids >= N.
-  // avail[v]: produced (constants: always).  bound[v] in units of r.
-  std::vector<uint8_t> avail(N, 0), done(N, 0);
-  std::vector<double> bound(N, 1.01);
-  for (uint32_t n = 0; n < N; n++)
-    if (G[n].op == G_CONST) avail[n] = done[n] = 1;
-  std::vector<std::vector<MicroOp>> steps;
-  std::vector<uint32_t> step_kind;
-  std::vector<uint32_t> ready;
-  std::vector<uint8_t> in_ready(N, 0);
-  auto operands_avail = [&](uint32_t n) {
-    const uint32_t o[3] = {G[n].a, G[n].b, G[n].c};
-    for (int k = 0; k < nops(G[n]); k++)
-      if (!avail[o[k]]) return false;
-    return true;
-  };
-  for (uint32_t n = 0; n < N; n++)
-    if (G[n].op != G_CONST && operands_avail(n)) {
-      ready.push_back(n);
-      in_ready[n] = 1;
-    }
-  auto is_rare = [&](uint32_t n) {
-    const uint32_t op = G[n].op;
-    return !(op == G_MUL || op == G_ADD || op == G_SUB || op == G_NEG);
-  };
-  struct Pending { uint32_t node, raw; };   // a raw value that still needs x * ONE + ZERO to become `node`
-  std::vector<Pending> pending;
-  uint32_t next_tmp = N;
-  std::vector<double> tmp_bound;
-  auto bnd = [&](uint32_t v) { return v < N ? bound[v] : tmp_bound[v - N]; };
-  nfma = nadd = nmisc = nsqr = nrow = 0;
-  // row form (one product per 16-lane row, wl_row_mul_add): at most WL_ROWS products per step, result < 2.05 r + ...
-  const bool rows = env_int_wl("RLNAMD_WITROWS", 1) != 0;
-  const double PB0 = rows ? 2.05 : 1.0;
-  const size_t fma_cap = rows ? WL_ROWS : WL_W;
-  // height = longest chain of nodes from a node to a sink: when a step cannot take every ready node, the ones the
-  // longest chains hang on go first
-  std::vector<uint32_t> height(N, 0);
-  for (uint32_t n = N; n-- > 0;) {
-    const uint32_t o[3] = {G[n].a, G[n].b, G[n].c};
-    for (int k = 0; k < nops(G[n]); k++) height[o[k]] = std::max(height[o[k]], height[n] + 1);
-  }
-  while (!ready.empty() || !pending.empty()) {
-    std::sort(ready.begin(), ready.end(), [&](uint32_t x, uint32_t y) {
-      return height[x] != height[y] ? height[x] > height[y] : x < y;
-    });
-    std::vector<MicroOp> ops;
-    std::vector<uint32_t> produced, left;
-    uint32_t kind;
-    bool any_rare = false, any_mul = false;
-    for (uint32_t n : ready) {
-      any_rare |= is_rare(n);
-      any_mul |= G[n].op == G_MUL || G[n].op == G_SUB || G[n].op == G_NEG;
-    }
-    if (any_rare) {
-      kind = WK_MISC;
-      for (uint32_t n : ready) {
-        if (!is_rare(n) || ops.size() >= WL_W) { left.push_back(n); continue; }
-        MicroOp m{G[n].op == G_INPUT ? WO_INPUT : WO_RARE, G[n].op, n, {G[n].a, G[n].b, G[n].c}, n, G[n].a};
-        for (int k = nops(G[n]); k < 3; k++) m.src[k] = NONE;
-        ops.push_back(m);
-        produced.push_back(n);
-        bound[n] = G[n].op == G_TERN ? std::max(bound[G[n].b], bound[G[n].c]) : 1.01;
-      }
-    } else {
-      // an Add whose plain sum would pass the bound forces the product form for the whole step
-      bool force_fma = !pending.empty();
-      for (uint32_t n : ready)
-        if (G[n].op == G_ADD && bound[G[n].a] + bound[G[n].b] > WL_BMAX) force_fma = true;
-      kind = (any_mul || force_fma) ? WK_FMA : WK_ADD;
-      const size_t cap = kind == WK_FMA ? fma_cap : (size_t)WL_W;
-      if (kind == WK_FMA) {
-        std::vector<Pending> later;
-        for (const Pending& pd : pending) {   // reductions first: their consumers are waiting
-          if (ops.size() >= cap) { later.push_back(pd); continue; }
-          ops.push_back(MicroOp{WO_COMPUTE, G_MUL, pd.node, {pd.raw, FIX + ONE, FIX + Z}, pd.node, 0});
-          produced.push_back(pd.node);
-          bound[pd.node] = PB0 + 0.006 * bnd(pd.raw);
-        }
-        pending.swap(later);
-      }
-      for (uint32_t n : ready) {
-        if (ops.size() >= cap) { left.push_back(n); continue; }
-        const GNode& g = G[n];
-        if (kind == WK_ADD) {
-          ops.push_back(MicroOp{WO_COMPUTE, G_ADD, n, {g.a, g.b, NONE}, n, 0});
-          bound[n] = bound[g.a] + bound[g.b];
-          produced.push_back(n);
-          continue;
-        }
-        MicroOp m{WO_COMPUTE, g.op, n, {NONE, NONE, NONE}, n, 0};
-        double b;
-        if (g.op == G_MUL) {
-          // fuse with its only user when that is an Add of a value that is already there (a * b + c in one step)
-          uint32_t add = NONE, c = NONE;
-          if (uses[n] == 1 && !is_signal[n] && store_slot[n] == NONE) {
-            const uint32_t u = users[n][0];
-            if (G[u].op == G_ADD && G[u].a != G[u].b) {
-              const uint32_t other = G[u].a == n ? G[u].b : G[u].a;
-              if (avail[other] && bound[other] + PB0 + 0.006 * bound[g.a] * bound[g.b] <= WL_BMAX) { add = u; c = other; }
-            }
-          }
-          if (add != NONE) {
-            m.node = m.dst = add;
-            m.src[0] = g.a; m.src[1] = g.b; m.src[2] = c;
-            b = PB0 + 0.006 * bound[g.a] * bound[g.b] + bound[c];
-            done[n] = 1;   // never materialised
-            bound[add] = b;
-            ops.push_back(m);
-            produced.push_back(add);
-            continue;
-          }
-          m.src[0] = g.a; m.src[1] = g.b; m.src[2] = FIX + Z;
-          b = PB0 + 0.006 * bound[g.a] * bound[g.b];
-        } else if (g.op == G_ADD) {   // x * 1 + y, the larger bound as multiplicand
-          const uint32_t x = bound[g.a] >= bound[g.b] ? g.a : g.b, y = x == g.a ? g.b : g.a;
-          m.src[0] = x; m.src[1] = FIX + ONE; m.src[2] = y;
-          b = PB0 + 0.006 * bound[x] + bound[y];
-        } else if (g.op == G_SUB) {   // a - b = b * (-1) + a
-          m.src[0] = g.b; m.src[1] = FIX + MONE; m.src[2] = g.a;
-          b = PB0 + 0.006 * bound[g.b] * 1.05 + bound[g.a];
-        } else {                      // G_NEG
-          m.src[0] = g.a; m.src[1] = FIX + MONE; m.src[2] = FIX + Z;
-          b = PB0 + 0.006 * bound[g.a] * 1.05;
-        }
-        if (b > WL_BMAX) {            // leave the raw value in a temporary and reduce it in the next FMA step
-          const uint32_t raw = next_tmp++;
-          tmp_bound.push_back(b);
-          m.dst = raw;
-          m.node = NONE;
-          pending.push_back({n, raw});
-          ops.push_back(m);
-          continue;
-        }
-        bound[n] = b;
-        ops.push_back(m);
-        produced.push_back(n);
-      }
-    }
-    if (kind == WK_FMA && rows) {
-      kind = WK_ROW;
-      nrow++;
-    } else if (kind == WK_FMA) {   // all products squarings (idle lanes compute ZERO * ZERO + ZERO: a square as well)?
-      bool all_sq = !ops.empty();
-      for (const MicroOp& m : ops) all_sq = all_sq && m.src[0] == m.src[1];
-      if (all_sq) { kind = WK_SQR; nsqr++; }
-    }
-    if (kind == WK_FMA) nfma++; else if (kind == WK_ADD) nadd++; else if (kind == WK_MISC) nmisc++;
-    steps.push_back(ops);
-    step_kind.push_back(kind);
-    for (uint32_t n : ready) in_ready[n] = 0;
-    ready.swap(left);
-    for (uint32_t n : ready) in_ready[n] = 1;
-    for (uint32_t n : produced) { avail[n] = 1; done[n] = 1; }
-    for (uint32_t n : produced)
-      for (uint32_t u : users[n])
-        if (!done[u] && !in_ready[u] && operands_avail(u)) {
-          // a product already folded into its Add is done; an Add whose product was folded is produced by that step
-          ready.push_back(u);
-          in_ready[u] = 1;
-        }
-    // a node folded into an FMA (done, not avail) must not be scheduled again: drop it from `ready`
-    ready.erase(std::remove_if(ready.begin(), ready.end(), [&](uint32_t n) { return done[n]; }), ready.end());
-  }
-  for (uint32_t n = 0; n < N; n++)
-    if (!done[n]) throw Error("witness lanes: graph node left unscheduled");
-  // ---- LDS slots from the liveness of the schedule
-  const uint32_t nvals = next_tmp;
-  const uint32_t FIXB = FIX;
-  std::vector<uint32_t> last_use(nvals, 0), slot(nvals, NONE);
-  for (uint32_t t = 0; t < steps.size(); t++)
-    for (const MicroOp& m : steps[t])
-      for (int k = 0; k < 3; k++)
-        if (m.src[k] != NONE && m.src[k] < FIXB) last_use[m.src[k]] = t;
-  for (uint32_t n = 0; n < N; n++)
-    if (G[n].op == G_CONST) slot[n] = G[n].a;   // constants sit in their own slots
-  std::vector<uint32_t> free_slots;
-  for (uint32_t sl = DUMMY; sl-- > first_free;) free_slots.push_back(sl);
-  std::vector<std::vector<uint32_t>> dies(steps.size() + 1);
-  peak_slots = 0;
-  uint32_t live = 0;
-  // idle lanes and the padding steps (the kernel runs whole groups of WL_PF steps and prefetches one group further)
-  // compute ZERO * ZERO + ZERO into the dummy slot
-  std::vector<uint4> img((steps.size() + 2 * WL_PF) * (size_t)WL_W,
-                         make_uint4(0, DUMMY | (Z << 16), Z | (Z << 16), trash_slot));
-  auto slot_of_val = [&](uint32_t v) -> uint32_t {
-    if (v == NONE) return Z;
-    if (v >= FIXB) return v - FIXB;
-    if (slot[v] == NONE) throw Error("witness lanes: operand read before it was produced");
-    return slot[v];
-  };
-  for (uint32_t t = 0; t < steps.size(); t++) {
-    // operands first (their slots may be those of values that die here), then the results
-    std::vector<uint32_t> sa(steps[t].size() * 3);
-    for (size_t i = 0; i < steps[t].size(); i++)
-      for (int k = 0; k < 3; k++) sa[3 * i + k] = slot_of_val(steps[t][i].src[k]);
-    for (size_t i = 0; i < steps[t].size(); i++) {
-      const MicroOp& m = steps[t][i];
-      if (free_slots.empty()) return;   // more live values than LDS slots: keep k_witness29
-      const uint32_t sl = free_slots.back();
-      free_slots.pop_back();
-      slot[m.dst] = sl;
-      live++;
-      peak_slots = std::max(peak_slots, live);
-      // a value nobody reads (a signal that is only stored) dies at once
-      dies[std::max(last_use[m.dst], t)].push_back(m.dst);
-      uint32_t x = m.lop | (step_kind[t] << 12) | (m.gop << 16), w = trash_slot;
-      if (m.node != NONE && store_slot[m.node] != NONE) {
-        x |= WL_STORE;
-        w = store_slot[m.node];
-      }
-      const uint32_t fa = m.lop == WO_INPUT ? m.imm : sa[3 * i];
-      if (fa >= 65536) return;          // an input index that does not fit the descriptor: keep k_witness29
-      const uint4 desc = make_uint4(x, sl | (fa << 16), sa[3 * i + 1] | (sa[3 * i + 2] << 16), w);
-      if (step_kind[t] == WK_ROW) {     // the row's sixteen lanes all read the row's descriptor
-        for (uint32_t l = 0; l < 16; l++) img[(size_t)t * WL_W + 16 * i + l] = desc;
-      } else {
-        img[(size_t)t * WL_W + i] = desc;
-      }
-    }
-    // every descriptor of the step carries the kind (lane 0's is the one the kernel reads)
-    {
-      const uint32_t used = step_kind[t] == WK_ROW ? 16 * (uint32_t)steps[t].size() : (uint32_t)steps[t].size();
-      for (uint32_t i = used; i < WL_W; i++) img[(size_t)t * WL_W + i].x = step_kind[t] << 12;
-    }
-    for (uint32_t v : dies[t]) {
-      free_slots.push_back(slot[v]);
-      live--;
-    }
-  }
-  nsteps = (uint32_t)steps.size();
-  prog.alloc(img.size());
-  prog.upload(img.data(), img.size(), s);
+  const char* off = getenv("RLNAMD_WITLANES");
+  if (off && off[0] == '0') return;
+  const char* r = getenv("RLNAMD_WITROWS");
+  const bool rows = !(r && r[0] == '0');
+  WlProgram P = wl_schedule(graph, store_slot, trash_slot, rows);
+  nsteps = P.nsteps; nrow = P.nrow; nfma = P.nfma; nsqr = P.nsqr; nadd = P.nadd; nmisc = P.nmisc;
+  peak_slots = P.peak_slots; n_consts = P.n_consts;
+  if (!P.ok) return;
+  static_assert(sizeof(WlDesc) == sizeof(uint4), "descriptor size");
+  prog.alloc(P.img.size());
+  prog.upload(reinterpret_cast<const uint4*>(P.img.data()), P.img.size(), s);
   RLN_HIP(hipStreamSynchronize(s));
   if (hipFuncSetAttribute((const void*)k_witness_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, WL_LDS_BYTES) !=
       hipSuccess) {   // a device with less LDS per workgroup: keep k_witness29
@@ -528,7 +259,8 @@ void WitLanes::build(const Graph& graph, const std::vector<uint32_t>& store_slot
     return;
   }
   ok = true;
-  if (env_int_wl("RLNAMD_WITLANES_INFO", 0))
+  const char* info = getenv("RLNAMD_WITLANES_INFO");
+  if (info && info[0] == '1')
     fprintf(stderr, "witness lanes: %u steps (%u row, %u fma, %u sqr, %u add, %u misc), peak %u live values, %u constants\n",
             nsteps, nrow, nfma, nsqr, nadd, nmisc, peak_slots, n_consts);
 }

@@ -2,7 +2,14 @@
 // witness_lanes.hip: k_witness_lanes): 256-bit integer helpers and every operation of
 // /root/reference/rln/src/circuit/iden3calc/graph.rs:72-143, 314-466 that is not Mul / Add / Sub / Neg / TernCond.
 #pragma once
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#define RLN_WOP static __host__ __device__
+#define RLN_WOP_NOINLINE static __host__ __device__ __noinline__
+#else   // the CPU suite compiles the same operations into its host emulator of the interpreter (tests/host/witsched.cpp)
+#define RLN_WOP static inline
+#define RLN_WOP_NOINLINE static inline
+#endif
 #include <stdint.h>
 
 #include "curve.h"
@@ -13,25 +20,25 @@ namespace rlnamd {
 struct U256 {
   uint32_t v[8];
 };
-static __device__ __forceinline__ bool u_is_zero(const U256& a) {
+RLN_WOP bool u_is_zero(const U256& a) {
   uint32_t o = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) o |= a.v[i];
   return o == 0;
 }
-static __device__ __forceinline__ int u_cmp(const U256& a, const U256& b) {  // -1, 0, 1
+RLN_WOP int u_cmp(const U256& a, const U256& b) {  // -1, 0, 1
   for (int i = 7; i >= 0; i--) {
     if (a.v[i] != b.v[i]) return a.v[i] > b.v[i] ? 1 : -1;
   }
   return 0;
 }
-static __device__ __forceinline__ U256 u_from_limbs(const uint32_t* p) {
+RLN_WOP U256 u_from_limbs(const uint32_t* p) {
   U256 r;
 #pragma unroll
   for (int i = 0; i < 8; i++) r.v[i] = p[i];
   return r;
 }
-static __device__ __forceinline__ U256 u_sub(const U256& a, const U256& b) {
+RLN_WOP U256 u_sub(const U256& a, const U256& b) {
   U256 r;
   uint32_t borrow = 0;
 #pragma unroll
@@ -42,7 +49,7 @@ static __device__ __forceinline__ U256 u_sub(const U256& a, const U256& b) {
   }
   return r;
 }
-static __device__ U256 u_shr(const U256& a, unsigned n) {  // n < 256
+RLN_WOP U256 u_shr(const U256& a, unsigned n) {  // n < 256
   U256 r;
   unsigned w = n >> 5, b = n & 31;
   for (int i = 0; i < 8; i++) {
@@ -52,7 +59,7 @@ static __device__ U256 u_shr(const U256& a, unsigned n) {  // n < 256
   }
   return r;
 }
-static __device__ U256 u_shl(const U256& a, unsigned n) {  // n < 256, bits above 256 dropped (ark BigInt <<)
+RLN_WOP U256 u_shl(const U256& a, unsigned n) {  // n < 256, bits above 256 dropped (ark BigInt <<)
   U256 r;
   unsigned w = n >> 5, b = n & 31;
   for (int i = 7; i >= 0; i--) {
@@ -63,7 +70,7 @@ static __device__ U256 u_shl(const U256& a, unsigned n) {  // n < 256, bits abov
   return r;
 }
 // a / b and a % b by shift-subtract (b != 0)
-static __device__ void u_divmod(const U256& a, const U256& b, U256* q, U256* rem) {
+RLN_WOP void u_divmod(const U256& a, const U256& b, U256* q, U256* rem) {
   U256 Q, Rm;
   for (int i = 0; i < 8; i++) Q.v[i] = Rm.v[i] = 0;
   for (int bit = 255; bit >= 0; bit--) {
@@ -82,7 +89,7 @@ static __device__ void u_divmod(const U256& a, const U256& b, U256* q, U256* rem
 enum WitnessErr : uint32_t { WERR_NONE = 0, WERR_INPUT_RANGE = 1, WERR_SHIFT = 2, WERR_BITOP = 3, WERR_UNO_ID = 4 };
 
 // Every operation that is not Mul/Add/Sub/Neg/TernCond/Const/Input: iden3calc/graph.rs:72-143, 314-466.
-static __device__ __noinline__ Fr witness_slow_op(uint32_t op, Fr fa, Fr fb, uint32_t* err) {
+RLN_WOP_NOINLINE Fr witness_slow_op(uint32_t op, Fr fa, Fr fb, uint32_t* err) {
   U256 a, b, m, half;
   fa.to_canonical(a.v);
   fb.to_canonical(b.v);
