@@ -490,3 +490,40 @@ def test_config_path_sizes_the_prover_and_batch_streams_past_max_batch(tmp_path)
     b = [m.generate_rln_proofs_batch([mws[i]], [rs[i]])[0] for i in (0, 64, 149)]   # one at a time: resident path
     for k, i in enumerate((0, 64, 149)):
         assert a[i].to_bytes_le() == b[k].to_bytes_le()
+
+
+def test_config_devices_puts_a_pool_behind_the_ffi_object(tmp_path):
+    """`"devices": [0, 0]` in the config_path JSON: two prover replicas (here sharing device 0) behind one FFI_RLN;
+    ffi_generate_rln_proofs_batch shards 300 proofs over them by index (128 + 172, chunks of 64) and returns the bytes
+    a single prover gives; single proofs, the tree and verification keep working on the object"""
+    import json
+    from zerokit_amd import hashers, workload
+    from zerokit_amd.batch import BatchProver
+    from zerokit_amd.public import RLN, RLNWitnessInput
+    cfgp = tmp_path / "cfg.json"
+    cfgp.write_text(json.dumps({"devices": [0, 0], "max_batch": 64}))
+    rln = RLN(20, tree_config=str(cfgp))
+    assert int(rln.prover_info().capacity) == 64
+    n = 300
+    ws, rs = workload.config2_range(50000, n)
+    wi = [RLNWitnessInput(w["identity_secret"], w["user_message_limit"], w["message_id"], w["path_elements"],
+                          w["identity_path_index"], w["x"], w["external_nullifier"]) for w in ws]
+    proofs = rln.generate_rln_proofs_batch(wi, rs)
+    p = BatchProver(max_batch=128)
+    ref = p.prove_stream(ws, rs)
+    p.close()
+    got = [pr.to_bytes_le() for pr in proofs]
+    assert all(r["proof"] in g for r, g in zip(ref, got))
+    for i in (0, 127, 128, 299):
+        assert proofs[i].values.y == ref[i]["values"]["y"]
+        assert rln.verify_with_roots(proofs[i], ws[i]["x"], [])
+    # the ordinary calls on the same object
+    secret = 424242
+    rln.set_leaf(5, hashers.poseidon_hash_pair(hashers.poseidon_hash([secret]), 100))
+    elems, bits = rln.get_merkle_proof(5)
+    one = rln.generate_rln_proof(RLNWitnessInput(secret, 100, 7, elems, bits, 99, 1234))
+    assert rln.verify_rln_proof(one, 99)
+    # a device that does not exist is a configuration error, not a crash
+    cfgp.write_text(json.dumps({"devices": [0, 57]}))
+    with pytest.raises(Exception, match="does not exist"):
+        RLN(20, tree_config=str(cfgp))

@@ -37,5 +37,6 @@ struct rlnamd_msm {
   std::unique_ptr<rlnamd::MsmG1> m;
 };
 // pool.cpp
+rlnamd::Prover* rlnamd_pool_replica_prover(rlnamd_pool* p, size_t replica);   // owned by the pool
 void* rlnamd_comm_handle(rlnamd_comm* c);   // the ncclComm_t
 int rlnamd_comm_size(rlnamd_comm* c);

@@ -403,6 +403,11 @@ struct TreeConfig {
   // of rlnamd_prover_new (7150114 = the 228 GiB bench schedule), "max_batch" = workspace capacity in proofs.
   // 0 / absent: RLNAMD_WINDOW_BITS / RLNAMD_MAX_BATCH, else the small defaults (c = 8 tables, 64 proofs).
   long window_bits = 0, max_batch = 0;
+  // "devices": [0, 1, ...] -- two or more entries put an rlnamd_pool (a prover replica + a host thread per listed device)
+  // behind the object: ffi_generate_rln_proofs_batch then shards n > max_batch proofs over the devices by index
+  // (BASELINE config 4: 65 536 = 8 x 8 192).  Everything else -- single proofs, the tree, verification -- runs on the
+  // first listed device, which must be the calling thread's current device (device 0 unless the host chose otherwise).
+  std::vector<int> devices;
   bool persistent() const { return !temporary && has_path; }
   ProverConfig prover_config() const {
     ProverConfig cfg;
@@ -457,6 +462,22 @@ TreeConfig parse_tree_config(const std::string& js) {
       if (key == "temporary") c.temporary = v;
     } else if (!js.compare(i, 4, "null")) {
       i += 4;
+    } else if (js[i] == '[') {   // an array of integers ("devices"); other arrays are skipped
+      std::vector<int> vals;
+      i++;
+      for (;;) {
+        ws();
+        if (i >= js.size()) throw bad("EOF while parsing a list");
+        if (js[i] == ']') { i++; break; }
+        size_t j = i;
+        while (j < js.size() && (isdigit((unsigned char)js[j]) || js[j] == '-')) j++;
+        if (j == i) throw bad("expected value");
+        vals.push_back(atoi(js.substr(i, j - i).c_str()));
+        i = j;
+        ws();
+        if (i < js.size() && js[i] == ',') i++;
+      }
+      if (key == "devices") c.devices = vals;
     } else if (isdigit((unsigned char)js[i]) || js[i] == '-') {
       size_t j = i;
       while (j < js.size() && (isdigit((unsigned char)js[j]) || strchr("+-.eE", js[j]))) j++;
@@ -503,7 +524,19 @@ struct FFI_RLN {
   // generate / verify take &self in the reference and may be called from several threads (SURVEY section 8b,
   // "Threading"); the prover owns one set of device workspaces, so proving calls on one object take turns
   std::mutex prove_mu;
-  std::unique_ptr<Prover> prover;
+  std::shared_ptr<Prover> prover;   // owned, or replica 0 of `pool` (then the pool owns it)
+  rlnamd_pool* pool = nullptr;      // config "devices" with two or more entries: batch calls shard over the devices
+  void make_prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_t graph_len, const TreeConfig& tcfg) {
+    const ProverConfig cfg = tcfg.prover_config();
+    if (tcfg.devices.size() >= 2) {
+      if (rlnamd_pool_new(zkey, zkey_len, graph, graph_len, cfg.max_batch, cfg.window_bits, tcfg.devices.data(),
+                          tcfg.devices.size(), &pool) != RLNAMD_OK)
+        throw Error(std::string("Configuration error: devices: ") + rlnamd_last_error());
+      prover = std::shared_ptr<Prover>(rlnamd_pool_replica_prover(pool, 0), [](Prover*) {});
+    } else {
+      prover.reset(new Prover(zkey, zkey_len, graph, graph_len, cfg));
+    }
+  }
   MerkleTreeDev tree;
   bool stateless = false;  // V3 only (RLNV3<Stateless, _>): no tree, tree calls return an error
   size_t next_index = 0;
@@ -516,6 +549,8 @@ struct FFI_RLN {
       flush();  // sled flushes when the database is dropped
     } catch (...) {
     }
+    prover.reset();
+    if (pool) rlnamd_pool_free(pool);
   }
 
   // PoseidonTree::default(depth) (public.rs:298-303).  `self.tree = PoseidonTree::default(d)?` leaves the old tree
@@ -823,6 +858,25 @@ void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CF
         std::unique_ptr<FFI_RLNProof> pr(new FFI_RLNProof);
         fill_outputs(po[i], pr.get());
         if (multi) values_from_public(pub.data() + i * npub * 32, mo, &pr->values);
+        made.push_back(pr.release());
+      }
+    } else if (rln.pool && !multi) {
+      // several devices behind the object: contiguous index shards, one per replica, each streamed (rlnamd_pool_prove)
+      std::vector<uint8_t> inputs, rsb, proofs(n * 128), values(n * 160);
+      std::vector<uint32_t> errs(n);
+      pack(0, n, inputs, rsb);
+      if (rlnamd_pool_prove(rln.pool, n, inputs.data(), rsb.data(), proofs.data(), values.data(), errs.data()) != RLNAMD_OK)
+        throw Error(rlnamd_last_error());
+      for (size_t i = 0; i < n; i++) {
+        if (errs[i]) throw Error("Error calculating witness: graph evaluation failed (code " + std::to_string(errs[i]) + ")");
+        std::unique_ptr<FFI_RLNProof> pr(new FFI_RLNProof);
+        memcpy(pr->proof, proofs.data() + 128 * i, 128);
+        const uint8_t* v = values.data() + 160 * i;
+        memcpy(pr->values.y.le, v, 32);
+        memcpy(pr->values.root.le, v + 32, 32);
+        memcpy(pr->values.nullifier.le, v + 64, 32);
+        memcpy(pr->values.x.le, v + 96, 32);
+        memcpy(pr->values.external_nullifier.le, v + 128, 32);
         made.push_back(pr.release());
       }
     } else {
@@ -1246,7 +1300,7 @@ FFI_RLN* rln_create(size_t depth, const std::vector<uint8_t>& zkey, const std::v
                     const TreeConfig& tcfg = TreeConfig()) {
   require_gpu();
   std::unique_ptr<FFI_RLN> r(new FFI_RLN);
-  r->prover.reset(new Prover(zkey.data(), zkey.size(), graph.data(), graph.size(), tcfg.prover_config()));
+  r->make_prover(zkey.data(), zkey.size(), graph.data(), graph.size(), tcfg);
   if (r->prover->graph().tree_depth != depth)  // graph_from_raw expected depth (circuit/mod.rs:163-179)
     throw Error("Graph error: tree depth mismatch: expected " + std::to_string(depth) + ", got " +
                 std::to_string(r->prover->graph().tree_depth));
@@ -1269,7 +1323,7 @@ CResult_FFI_RLN_ptr_Vec_uint8_t ffi_rln_new(size_t tree_depth, const char* confi
     auto graph = read_file(dir + "/graph.bin");
     require_gpu();
     std::unique_ptr<FFI_RLN> r(new FFI_RLN);
-    r->prover.reset(new Prover(zkey.data(), zkey.size(), graph.data(), graph.size(), tcfg.prover_config()));
+    r->make_prover(zkey.data(), zkey.size(), graph.data(), graph.size(), tcfg);
     r->open_tree(tree_depth, tcfg);
     return (FFI_RLN_t*)r.release();
   });

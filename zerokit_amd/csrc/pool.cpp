@@ -36,6 +36,7 @@ struct rlnamd_comm {
   int nranks = 0, rank = 0, device = 0;
 };
 void* rlnamd_comm_handle(rlnamd_comm* c) { return (void*)c->comm; }
+rlnamd::Prover* rlnamd_pool_replica_prover(rlnamd_pool* p, size_t replica);
 int rlnamd_comm_size(rlnamd_comm* c) { return c->nranks; }
 
 namespace {
@@ -130,6 +131,10 @@ struct rlnamd_pool {
     }
   }
 };
+
+rlnamd::Prover* rlnamd_pool_replica_prover(rlnamd_pool* p, size_t replica) {
+  return replica < p->rep.size() ? p->rep[replica]->prover.get() : nullptr;
+}
 
 extern "C" {
 
