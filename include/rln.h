@@ -16,9 +16,10 @@
  * Scope: single and multi message-id circuits, full and partial proofs, the HBM-resident tree with the
  * PmTreeConfig semantics of config_path (path / temporary / tree_depth; a persistent tree is one snapshot file
  * <path>/rlnamd_tree.bin written by ffi_flush and when the object is freed -- not sled's on-disk format, which belongs
- * to a third-party crate).  The tree is dense: depth <= 30 (the reference's OptimalMerkleTree allows < 64); replacing a
- * tree (ffi_set_tree, ffi_init_tree_with_leaves) builds the new one beside the old when the device can hold both and
- * releases the old one first otherwise.  config_path may also carry "window_bits" and "max_batch" (prover sizing, see
+ * to a third-party crate).  Depth <= 30: the dense tree in HBM; depth 31 .. 63: a sparse tree (only written nodes are
+ * kept, hashes in device batches -- OptimalMerkleTree's semantics, utils/src/merkle_tree/optimal_merkle_tree.rs);
+ * depth >= 64 is the reference's InvalidDepth.  Replacing a dense tree (ffi_set_tree, ffi_init_tree_with_leaves) builds
+ * the new one beside the old when the device can hold both and releases the old one first otherwise.  config_path may also carry "window_bits" and "max_batch" (prover sizing, see
  * INTEGRATION.md).  The ffi_rln_v3_* mirror is at the end of this file.
  * Extensions that the reference lacks are marked EXT (deterministic blinding, batch: any n, streamed through the
  * workspace slots).

@@ -179,3 +179,42 @@ def proof_values_multi(secret, limit, message_ids, selector_used, path_elements,
         ys.append((secret + x * a1) % R * s % R)
         nulls.append(poseidon([a1]) * s % R)
     return ys + [root] + nulls + [x, ext] + [1 if b else 0 for b in selector_used]
+
+
+class SparseMerkleTree:
+    """ORACLE for deep trees: utils/src/merkle_tree/optimal_merkle_tree.rs:15-41, 120-200 restated -- only the nodes
+    that were written are kept ((level, index) -> value, level 0 = root), everything else is the cached hash of an
+    empty subtree of its level.  Roots / proofs agree with FullMerkleTree where both fit (checked in the CPU suite)."""
+
+    def __init__(self, depth, default_leaf=0, hash_pair=None):
+        self.h = hash_pair or (lambda a, b: poseidon([a, b]))
+        self.depth = depth
+        self.zero = [0] * (depth + 1)
+        self.zero[depth] = default_leaf
+        for lvl in range(depth - 1, -1, -1):
+            self.zero[lvl] = self.h(self.zero[lvl + 1], self.zero[lvl + 1])
+        self.nodes = {}
+
+    def node(self, lvl, idx):
+        return self.nodes.get((lvl, idx), self.zero[lvl])
+
+    def root(self):
+        return self.node(0, 0)
+
+    def get(self, leaf):
+        return self.node(self.depth, leaf)
+
+    def set(self, leaf, value):
+        self.nodes[(self.depth, leaf)] = value
+        idx = leaf
+        for lvl in range(self.depth, 0, -1):
+            idx >>= 1
+            self.nodes[(lvl - 1, idx)] = self.h(self.node(lvl, 2 * idx), self.node(lvl, 2 * idx + 1))
+
+    def proof(self, leaf):
+        elems, bits, idx = [], [], leaf
+        for lvl in range(self.depth, 0, -1):
+            elems.append(self.node(lvl, idx ^ 1))
+            bits.append(idx & 1)
+            idx >>= 1
+        return elems, bits

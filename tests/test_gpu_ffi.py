@@ -527,3 +527,59 @@ def test_config_devices_puts_a_pool_behind_the_ffi_object(tmp_path):
     cfgp.write_text(json.dumps({"devices": [0, 57]}))
     with pytest.raises(Exception, match="does not exist"):
         RLN(20, tree_config=str(cfgp))
+
+
+def test_deep_tree_depth_40_sparse():
+    """depths the dense HBM tree cannot hold (31 .. 63; the reference's OptimalMerkleTree allows < 64,
+    utils/src/merkle_tree/optimal_merkle_tree.rs:15-41) take the sparse host-indexed tree with device hashing: a depth-40
+    tree with leaves set far apart gives the oracle's root, leaves and paths; depth 64 stays an error"""
+    from oracle.pyref.rln import SparseMerkleTree
+    from zerokit_amd.public import RLN
+    d = 40
+    rln = RLN(20)
+    rln.set_tree(d)
+    assert rln.tree_depth() == d
+    o = SparseMerkleTree(d)
+    assert rln.get_root() == o.root()
+    rnd = random.Random(11)
+    idx = [0, 1, 2, (1 << 31) + 5, (1 << 39) + 123456789, (1 << 40) - 1, 77, (1 << 31) + 4]
+    for i in idx:
+        v = rnd.randrange(1, R)
+        rln.set_leaf(i, v)
+        o.set(i, v)
+        assert rln.get_root() == o.root()
+    rln.set_leaves_from(1000, [5, 6, 7, 8, 9])          # a range: one device batch per level
+    for k, v in enumerate([5, 6, 7, 8, 9]):
+        o.set(1000 + k, v)
+    assert rln.get_root() == o.root()
+    for i in (0, (1 << 39) + 123456789, (1 << 40) - 1, 1002, 12345):
+        elems, bits = rln.get_merkle_proof(i)
+        oe, ob = o.proof(i)
+        assert elems == oe and list(bits) == ob
+        assert rln.get_leaf(i) == o.get(i)
+    rln.delete_leaf(77)
+    o.set(77, 0)
+    assert rln.get_root() == o.root()
+    with pytest.raises(Exception, match="out of bounds|too many"):
+        rln.set_leaf(1 << 40, 1)
+    with pytest.raises(Exception, match="must be < 64"):
+        rln.set_tree(64)
+    rln.set_tree(20)                                     # back to the dense tree
+    assert rln.get_root() == SparseMerkleTree(20).root()
+
+
+def test_reference_tree_tests_and_kat_on_the_sparse_tree():
+    """the FFI tree tests of this file and of the V3 file (the reference's rln/tests/ffi.rs tree cases replayed) with the
+    sparse tree forced at every depth (RLNAMD_TREE_SPARSE_ABOVE=0): same roots, paths and errors as the dense HBM tree"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RLNAMD_TREE_SPARSE_ABOVE="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", os.path.join(root, "tests", "test_gpu_ffi.py"),
+                        os.path.join(root, "tests", "test_gpu_ffi_v3.py"), "-k",
+                        "(merkle_operations or leaf_setting or atomic_operation or bad_index or out_of_bounds or "
+                        "get_leaf_and_metadata or persistent_tree or stateful_tree or c_program_links) and not sparse"],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout

@@ -232,3 +232,21 @@ def test_seeded_keygen_kats():
     assert n == 0x1f18714c7bc83b5bca9e89d404cf6f2f585bc4c0f7ed8b53742b7e2b298f50b4
     assert s == 0x2aca62aaa7abaf3686fff2caf00f55ab9462dc12db5b5d4bcf3994e671f8e521
     assert c == 0x68b66aa0a8320d2e56842581553285393188714c48f9b17acd198b4f1734c5c
+
+
+def test_sparse_tree_oracle_agrees_with_the_full_tree_oracle():
+    """oracle/pyref SparseMerkleTree (the checker of the deep-tree GPU test) against FullMerkleTree, itself pinned to
+    the reference's depth-20 tree KAT above: same root and paths after the same updates"""
+    import random
+    from oracle.pyref.rln import FullMerkleTree, SparseMerkleTree
+    rnd = random.Random(5)
+    d = 7
+    full, sparse = FullMerkleTree(d), SparseMerkleTree(d)
+    assert full.root() == sparse.root()
+    for _ in range(40):
+        i, v = rnd.randrange(1 << d), rnd.randrange(1, 1 << 200)
+        full.set(i, v)
+        sparse.set(i, v)
+    assert full.root() == sparse.root()
+    for i in (0, 1, 77, 127):
+        assert tuple(full.proof(i)) == tuple(sparse.proof(i)) and full.get(i) == sparse.get(i)

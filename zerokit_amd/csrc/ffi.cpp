@@ -29,6 +29,7 @@
 #include "common.h"
 #include "keccak.h"
 #include "merkle.h"
+#include "tree_any.h"
 #include "pairing.h"
 #include "poseidon.h"
 #include "prover.h"
@@ -537,7 +538,7 @@ struct FFI_RLN {
       prover.reset(new Prover(zkey, zkey_len, graph, graph_len, cfg));
     }
   }
-  MerkleTreeDev tree;
+  TreeAny tree;   // dense in HBM up to depth 30, sparse (host-indexed, device-hashed) for 31 .. 63
   bool stateless = false;  // V3 only (RLNV3<Stateless, _>): no tree, tree calls return an error
   size_t next_index = 0;
   std::vector<uint8_t> leaf_set;  // cached_leaves_indices
@@ -558,23 +559,23 @@ struct FFI_RLN {
   // next_index, leaf_set and metadata -- only once init has succeeded (bad depth, hipMalloc failure: nothing changes).
   void new_tree(size_t depth) {
     if (depth >= 64) throw Error("Merkle tree error: Tree depth exceeds maximum allowed (must be < 64)");  // InvalidDepth
-    if (depth > 30)  // the dense HBM-resident tree holds 2^(depth+1) - 1 nodes of 32 B: depth 30 is 64 GiB
-      throw Error("Merkle tree error: Tree depth exceeds maximum allowed (must be <= 30 for the HBM-resident tree)");
     uint8_t zero[32] = {0};
     // The replacement is built beside the old tree so that a failure changes nothing -- unless the device cannot hold
-    // both (depth 28: 16 GiB each, next to up to 228 GiB of comb tables): then the old tree goes first and the reset is
-    // no longer atomic (a failure after this point leaves an empty depth-0 tree behind, reported by the error).
-    {
+    // both dense trees (depth 28: 16 GiB each, next to up to 228 GiB of comb tables): then the old tree goes first and
+    // the reset is no longer atomic (a failure after this point leaves an empty depth-0 tree behind, reported by the
+    // error).  Depths above 30 take the sparse tree (tree_any.h): nothing proportional to 2^depth is allocated.
+    if (depth <= (size_t)TreeAny::MAX_DENSE_DEPTH) {
       size_t free_b = 0, total_b = 0;
       const size_t need = ((size_t)64 << depth) + ((size_t)1 << 26);   // 2^(depth+1) nodes of 32 B + slack
-      if (tree.depth > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < need) {
-        MerkleTreeDev empty;
+      if (tree.depth > 0 && !tree.sparse && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < need) {
+        TreeAny empty;
         tree = std::move(empty);
       }
     }
-    MerkleTreeDev fresh;
+    TreeAny fresh;
     fresh.init((int)depth, zero);
-    std::vector<uint8_t> fresh_set((size_t)1 << depth, 0);
+    // cached_leaves_indices: one byte per leaf for the dense tree; the sparse tree keeps none (write-only bookkeeping)
+    std::vector<uint8_t> fresh_set(fresh.sparse ? 0 : (size_t)1 << depth, 0);
     tree = std::move(fresh);
     leaf_set.swap(fresh_set);
     next_index = 0;
@@ -615,7 +616,7 @@ struct FFI_RLN {
       if (h.next) {
         tree.set_range_host(0, leaves.data(), h.next);
         static const uint8_t zero[32] = {0};
-        for (size_t i = 0; i < h.next; i++) leaf_set[i] = memcmp(leaves.data() + 32 * i, zero, 32) != 0;
+        for (size_t i = 0; i < h.next && !leaf_set.empty(); i++) leaf_set[i] = memcmp(leaves.data() + 32 * i, zero, 32) != 0;
       }
       next_index = h.next;
       metadata = meta;
@@ -645,7 +646,7 @@ struct FFI_RLN {
       throw Error("set_range got too many leaves");
     if (leaves.empty()) return;
     tree.set_range_host(start, (const uint8_t*)leaves.data(), leaves.size());
-    for (size_t i = 0; i < leaves.size(); i++) leaf_set[start + i] = 1;
+    for (size_t i = 0; i < leaves.size() && !leaf_set.empty(); i++) leaf_set[start + i] = 1;
     next_index = std::max(next_index, start + leaves.size());
   }
   void set(size_t index, const CFr& leaf) {  // :141-147
@@ -662,7 +663,7 @@ struct FFI_RLN {
     if (index >= tree.capacity()) throw Error("Leaf index out of bounds");
     if (index < next_index) {
       set(index, cfr_from_u64(0));
-      leaf_set[index] = 0;
+      if (!leaf_set.empty()) leaf_set[index] = 0;
     }
   }
   // override_range with the default (pmtree-ft) build's behaviour: empty `indices` allowed
@@ -693,7 +694,7 @@ struct FFI_RLN {
       // remove_indices (pm_tree_adapter.rs:417-435): the whole span [first, last] is reset
       size_t s = indices.front(), e = indices.back() + 1;
       set_range(s, std::vector<CFr>(e - s, cfr_from_u64(0)));
-      for (size_t i = s; i < e; i++) leaf_set[i] = 0;
+      for (size_t i = s; i < e && !leaf_set.empty(); i++) leaf_set[i] = 0;
       return;
     }
     // remove_indices_and_set_leaves (pm_tree_adapter.rs:437-480); the merged buffer is written at `start`
@@ -705,8 +706,9 @@ struct FFI_RLN {
     for (size_t i = 0; i < leaves.size(); i++) vals[start - min_index + i] = leaves[i];
     if (start + vals.size() > cap) throw Error("set_range got too many leaves");
     set_range(start, vals);
-    for (size_t i : indices) leaf_set[i] = 0;
-    for (size_t i = start; i < end - min_index && i < cap; i++) leaf_set[i] = 1;
+    for (size_t i : indices)
+      if (!leaf_set.empty()) leaf_set[i] = 0;
+    for (size_t i = start; i < end - min_index && i < cap && !leaf_set.empty(); i++) leaf_set[i] = 1;
   }
 };
 

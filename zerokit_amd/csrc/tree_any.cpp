@@ -1,0 +1,131 @@
+#include "tree_any.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "common.h"
+#include "poseidon.h"
+
+namespace rlnamd {
+
+// n hashes of two inputs on the device (pairs: n x 64 bytes canonical LE -> out: n x 32)
+static void hash_pairs(const std::vector<uint8_t>& pairs, std::vector<uint8_t>& out) {
+  const size_t n = pairs.size() / 64;
+  out.resize(n * 32);
+  if (!n) return;
+  DevBuf<uint8_t> din(pairs.size()), dout(n * 32);
+  RLN_HIP(hipMemcpy(din.p, pairs.data(), pairs.size(), hipMemcpyHostToDevice));
+  poseidon_hash_batch_device(din.p, n, 2, dout.p, 0);
+  RLN_HIP(hipMemcpy(out.data(), dout.p, n * 32, hipMemcpyDeviceToHost));
+}
+
+void SparseTree::init(int depth, const uint8_t default_leaf_le[32]) {
+  require_gpu();
+  if (depth < 0 || depth >= 64) throw Error("InvalidDepth");
+  depth_ = depth;
+  lv_.assign(depth + 1, {});
+  zero_.assign(depth + 1, Node{});
+  memcpy(zero_[depth].data(), default_leaf_le, 32);
+  for (int l = depth - 1; l >= 0; l--) {   // cached_nodes (optimal_merkle_tree.rs:86-96): one hash per level
+    std::vector<uint8_t> in(64), out;
+    memcpy(in.data(), zero_[l + 1].data(), 32);
+    memcpy(in.data() + 32, zero_[l + 1].data(), 32);
+    hash_pairs(in, out);
+    memcpy(zero_[l].data(), out.data(), 32);
+  }
+}
+
+void SparseTree::node(int level, uint64_t index, uint8_t out_le[32]) const {
+  auto it = lv_[level].find(index);
+  memcpy(out_le, it == lv_[level].end() ? zero_[level].data() : it->second.data(), 32);
+}
+
+size_t SparseTree::stored_nodes() const {
+  size_t s = 0;
+  for (const auto& m : lv_) s += m.size();
+  return s;
+}
+
+void SparseTree::set_range(size_t start, const uint8_t* leaves_le, size_t n) {
+  if (!n) return;
+  std::vector<uint64_t> touched(n);
+  for (size_t i = 0; i < n; i++) {
+    Node v;
+    memcpy(v.data(), leaves_le + 32 * i, 32);
+    lv_[depth_][start + i] = v;
+    touched[i] = start + i;
+  }
+  // update_hashes (optimal_merkle_tree.rs:296-330): the parents of everything touched, level by level, each level one
+  // device batch
+  for (int l = depth_; l > 0; l--) {
+    std::vector<uint64_t> parents;
+    for (uint64_t t : touched)
+      if (parents.empty() || parents.back() != (t >> 1)) parents.push_back(t >> 1);   // touched is sorted
+    std::vector<uint8_t> in(parents.size() * 64), out;
+    for (size_t k = 0; k < parents.size(); k++) {
+      node(l, 2 * parents[k], in.data() + 64 * k);
+      node(l, 2 * parents[k] + 1, in.data() + 64 * k + 32);
+    }
+    hash_pairs(in, out);
+    for (size_t k = 0; k < parents.size(); k++) {
+      Node v;
+      memcpy(v.data(), out.data() + 32 * k, 32);
+      lv_[l - 1][parents[k]] = v;
+    }
+    touched.swap(parents);
+  }
+}
+
+void SparseTree::proof(size_t leaf, uint8_t* elems_le, uint8_t* bits) const {
+  uint64_t idx = leaf;
+  for (int l = depth_; l > 0; l--) {
+    const int k = depth_ - l;
+    node(l, idx ^ 1, elems_le + 32 * k);
+    bits[k] = (uint8_t)(idx & 1);   // odd index at its level == right child (full_merkle_tree.rs:296-300)
+    idx >>= 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+void TreeAny::init(int depth_, const uint8_t default_leaf_le[32]) {
+  if (depth_ < 0 || depth_ >= 64) throw Error("InvalidDepth");
+  // RLNAMD_TREE_SPARSE_ABOVE (tests): take the sparse tree above a smaller depth, so that the reference's tree tests and
+  // known answers at depth 20 run against it as well
+  static const int dense_max = [] {
+    const char* v = getenv("RLNAMD_TREE_SPARSE_ABOVE");
+    return (v && *v) ? std::min(atoi(v), MAX_DENSE_DEPTH) : MAX_DENSE_DEPTH;
+  }();
+  sparse = depth_ > dense_max;
+  if (sparse) {
+    sp.init(depth_, default_leaf_le);
+    dense = MerkleTreeDev();
+  } else {
+    dense.init(depth_, default_leaf_le);
+    sp = SparseTree();
+  }
+  depth = depth_;
+}
+
+void TreeAny::set_range_host(size_t start, const uint8_t* leaves_le, size_t n) {
+  if (sparse) sp.set_range(start, leaves_le, n); else dense.set_range_host(start, leaves_le, n);
+}
+
+void TreeAny::get_node_host(size_t node, uint8_t out_le[32]) {
+  if (!sparse) return dense.get_node_host(node, out_le);
+  if (node == 0) return sp.root(out_le);
+  if (node < capacity() - 1) throw Error("sparse tree: only the root and the leaves are addressed by heap index");
+  sp.leaf(node - (capacity() - 1), out_le);
+}
+
+void TreeAny::get_leaves_host(size_t first, size_t n, uint8_t* out_le) {
+  if (!sparse) return dense.get_leaves_host(first, n, out_le);
+  for (size_t i = 0; i < n; i++) sp.leaf(first + i, out_le + 32 * i);
+}
+
+void TreeAny::proof_host(size_t leaf, uint8_t* elems_le, uint8_t* bits) {
+  if (sparse) sp.proof(leaf, elems_le, bits); else dense.proof_host(leaf, elems_le, bits);
+}
+
+}  // namespace rlnamd
