@@ -433,3 +433,29 @@ def test_vectorised_workload_generator_matches_the_oracle_generator():
             wi["identity_path_index"] + [wi["x"], wi["external_nullifier"]]
         assert (int.from_bytes(rsb[64 * i:64 * i + 32], "little"),
                 int.from_bytes(rsb[64 * i + 32:64 * i + 64], "little")) == rs[97 + i]
+
+
+def test_config_path_is_parsed_before_any_device_is_needed(tmp_path):
+    """ffi_rln_new reads config_path first (RLN::new parses the config before anything else, public.rs:113): a malformed
+    file is the reference's configuration error on a box without a GPU too, and a well-formed one -- including this
+    backend's own keys window_bits / max_batch / devices beside the PmTreeConfig keys -- gets as far as the device check"""
+    import ctypes as C
+    from zerokit_amd import lib
+    from zerokit_amd._native import VecU8
+
+    def new(cfg_text):
+        p = tmp_path / "cfg.json"
+        p.write_text(cfg_text)
+        r = lib().ffi_rln_new(20, str(p).encode())
+        assert not r.ok
+        msg = C.string_at(r.err.ptr, r.err.len).decode()
+        lib().ffi_c_string_free(r.err)
+        return msg
+
+    assert "Error while reading pmtree config" in new('{"devices": [0, }')
+    assert "Error while reading pmtree config" in new('{"max_batch": }')
+    assert "missing path" in new('{"temporary": false}')
+    if lib().rlnamd_device_count() == 0:
+        for ok_cfg in ('{"window_bits": 7150114, "max_batch": 1024}', '{"devices": [0, 1, 2, 3], "temporary": true}',
+                       '{"cache_capacity": 1073741824, "flush_every_ms": 500, "mode": "HighThroughput", "use_compression": false}'):
+            assert "no HIP device" in new(ok_cfg)
