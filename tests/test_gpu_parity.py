@@ -422,23 +422,26 @@ def test_both_graph_interpreters_give_the_golden_witness(monkeypatch):
 
 
 def test_lane_chunk_walk_and_clock_tap(monkeypatch):
-    """Batches of at most RLNAMD_LANECHUNK (56) proofs walk the tables with lanes = chunks, larger ones with lanes =
-    proofs (walk29.h).  The same witnesses must give the same proof bytes either way -- alone, inside a batch that is
+    """Batches of at most RLNAMD_LANECHUNK (128) proofs take the small-batch shapes (lanes = chunks walks, walk29.h; a
+    wave per proof in the interpreter; early walks), larger ones the lanes = proofs pipeline.  The same witnesses must give the same proof bytes either way -- alone, inside a batch that is
     walked the other way, and with the threshold forced to 0 -- and the clock tap of the walk kernels must report a
     plausible shader clock after a lanes = proofs run."""
     from zerokit_amd.batch import BatchProver
     cases = _cases()["cases"]
     ws, rs = [_w(c) for c in cases], [(int(c["r"]), int(c["s"])) for c in cases]
-    p = BatchProver(max_batch=64)
+    p = BatchProver(max_batch=192)
     try:
         small = p.prove(ws[:2], rs[:2])                       # lanes = chunks
-        reps = 64 // len(ws) + 1
-        big = p.prove((ws * reps)[:64], (rs * reps)[:64])     # lanes = proofs
+        reps = 160 // len(ws) + 1
+        mid = p.prove((ws * reps)[:100], (rs * reps)[:100])   # still the small-batch shapes, two waves of proofs
+        big = p.prove((ws * reps)[:160], (rs * reps)[:160])   # lanes = proofs
         clk = p.walk_clock_mhz()
         assert 500.0 < clk["g1_walk"] < 3000.0 and 500.0 < clk["g2_walk"] < 3000.0, clk
         for i in range(2):
             assert small[i]["proof"].hex() == cases[i]["proof_compressed"]
-        for i in range(64):
+        for i in range(100):
+            assert mid[i]["proof"].hex() == cases[i % len(ws)]["proof_compressed"], i
+        for i in range(160):
             assert big[i]["proof"].hex() == cases[i % len(ws)]["proof_compressed"], i
     finally:
         p.close()

@@ -1,16 +1,29 @@
-import json, os, sys, time
+#!/usr/bin/env python3
+"""Latency of one batch of n proofs with the small-batch shapes (lanes = chunks walks, lanes = nodes interpreter, early
+walks ...) against the lanes = proofs pipeline: where is the crossover?  Run with RLNAMD_LANECHUNK=<threshold>
+(0 = never small).  Prints one JSON line."""
+import json
+import os
+import sys
+import time
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from zerokit_amd.batch import BatchProver
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-cases = json.load(open(os.path.join(ROOT, "tests", "golden", "rln_h20_vectors.json")))["cases"]
-import test_gpu_parity as T
-ws = [T._w(c) for c in cases]; rs = [(int(c["r"]), int(c["s"])) for c in cases]
-p = BatchProver(max_batch=64)
-for n in (8, 16, 24, 32, 48, 64):
-    W = (ws * 64)[:n]; R = (rs * 64)[:n]
-    p.prove(W, R)
-    t0 = time.perf_counter()
-    for _ in range(5): p.prove(W, R)
-    print("LANECHUNK=%s n=%2d  %.2f ms" % (os.environ.get("RLNAMD_LANECHUNK"), n, (time.perf_counter() - t0) / 5 * 1e3))
+from zerokit_amd import workload  # noqa: E402
+from zerokit_amd.batch import BatchProver  # noqa: E402
+
+p = BatchProver(max_batch=512)
+out = {"RLNAMD_LANECHUNK": os.environ.get("RLNAMD_LANECHUNK", "default")}
+for n in (1, 8, 32, 56, 64, 96, 128, 192, 256, 384, 512):
+    inp, rsb = workload.config2_packed(p.slots, p.inputs_size, 0, n)
+    t, _ = p.submit(inp, rsb)
+    p.collect_raw(t, n)
+    ts = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        t, _ = p.submit(inp, rsb)
+        p.collect_raw(t, n)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    out[n] = round(min(ts), 2)
+print(json.dumps(out))
 p.close()

@@ -1,0 +1,13 @@
+import json, os, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from zerokit_amd import workload
+from zerokit_amd.batch import BatchProver
+out = {"RLNAMD_LANECHUNK": os.environ.get("RLNAMD_LANECHUNK")}
+for mb in (64, 128, 256):
+    p = BatchProver(max_batch=mb)
+    inp, rsb = workload.config2_packed(p.slots, p.inputs_size, 0, 4096)
+    p.prove_stream_raw(inp[:p.inputs_size*32*mb*2], rsb[:64*mb*2])
+    t0 = time.perf_counter(); p.prove_stream_raw(inp, rsb); dt = time.perf_counter() - t0
+    out["max_batch_%d_proofs_per_s" % mb] = round(4096 / dt, 1)
+    p.close()
+print(json.dumps(out))

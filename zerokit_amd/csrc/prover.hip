@@ -1046,7 +1046,7 @@ struct Prover::Impl {
   float ms[PROVER_STAGES] = {0};
   DevBuf<unsigned long long> walk_clk;  // clock tap of the two walks: G1 cycles, G1 ticks, G2 cycles, G2 ticks
   bool wit29 = true;             // RLNAMD_WIT29: graph interpreter in the 9 x 29-bit form (k_witness29)
-  uint32_t lanechunk_max = 56;   // RLNAMD_LANECHUNK: largest batch walked with lanes = chunks
+  uint32_t lanechunk_max = 128;  // RLNAMD_LANECHUNK: largest batch that takes the small-batch shapes
   DevBuf<GNode29> nodes29;
   DevBuf<unsigned long long> wit_prof;
   DevBuf<uint32_t> consts29, slot2node;
@@ -1325,7 +1325,13 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   D.consts.alloc(std::max<size_t>(graph_.constants.size(), 1));
   if (!graph_.constants.empty()) D.consts.upload(graph_.constants.data(), graph_.constants.size(), s);
   D.wit29 = env_int("RLNAMD_WIT29", 1) != 0;
-  D.lanechunk_max = (uint32_t)std::max(0, env_int("RLNAMD_LANECHUNK", 56));
+  // Largest batch that takes the small-batch shapes (lanes = chunks walks, a wave per proof in the interpreter, early walks
+  // and back end).  tools/lanechunk_sweep.py / tools/midstream.py: one batch alone is faster that way up to ~450 proofs
+  // (64: 12.4 vs 23.2 ms, 128: 17.8 vs 27.4, 256: 28.4 vs 36.8), a STREAM of such batches up to ~150 (chunks of 64: 9.4 k
+  // vs 8.1 k proofs/s, 128: equal, 256: 10.1 k vs 12.1 k) -- 128 wins or ties on both.
+  D.lanechunk_max = (uint32_t)std::max(0, env_int("RLNAMD_LANECHUNK", 128));
+  // partial sums of a small batch: [chunk][stride]
+  D.small_stride = std::max<uint32_t>(64, (std::min<uint32_t>(D.lanechunk_max, (uint32_t)B_) + 63) / 64 * 64);
   std::vector<GNode29> wit29_prog;
   std::vector<uint32_t> wit29_slot2node;
   if (D.wit29) {
