@@ -216,16 +216,22 @@ def pool_main(args):
     from zerokit_amd.batch import BatchProver, ProverPool
     N = args.gpus
     have = lib().rlnamd_device_count()
-    if have < N:
+    devices = list(range(N))
+    if "RLNAMD_BENCH_POOL_DEVICES" in os.environ:   # test hook for 1-GPU boxes: replicas sharing a device ("0,0")
+        devices = [int(x) for x in os.environ["RLNAMD_BENCH_POOL_DEVICES"].split(",")]
+        if len(devices) != N:
+            raise SystemExit("bench: RLNAMD_BENCH_POOL_DEVICES must list --gpus devices")
+    elif have < N:
         raise SystemExit("bench: --gpus %d but %d device(s) visible; refusing to run a smaller job" % (N, have))
     B = args.batch
-    t0 = time.time()
-    pool = open_prover(B, lambda wb: ProverPool(devices=list(range(N)), max_batch=B, window_bits=wb))
-    init_s = time.time() - t0
-    # input slots come from the graph; any single prover knows them -- read them from a tiny one on device 0
+    # input slots come from the graph; any single prover knows them -- read them from a tiny one on device 0 BEFORE the
+    # pool's 228 GiB replicas exist
     probe = BatchProver(max_batch=64, window_bits=8)
     slots, ni = dict(probe.slots), probe.inputs_size
     probe.close()
+    t0 = time.time()
+    pool = open_prover(B, lambda wb: ProverPool(devices=devices, max_batch=B, window_bits=wb))
+    init_s = time.time() - t0
     n = SHARD * N
     inputs, rsb = workload.config2_packed(slots, ni, 0, n)
     for _ in range(args.warmup):

@@ -10,3 +10,7 @@ echo "rc=$?"; python3 -c "
 import json; d=json.loads(open('gpurun_out/r3t/n1.json').read()); print(d['value'], d['n_gpus'], d.get('rccl_ranks'), d['config5']['correct'], d['config3']['correct'])"
 # plain --gpus 2 without torchrun on a 1-GPU box must refuse
 python bench.py --gpus 2 --steps 1 --warmup 0; echo "rc=$? (non-zero expected)"
+# the one-process N-device path (rlnamd_pool) with two replicas sharing device 0
+RLNAMD_WINDOW_BITS=8 RLNAMD_BENCH_POOL_DEVICES=0,0 timeout 600 python bench.py --gpus 2 --steps 2 --warmup 1 > gpurun_out/r3t/pool2.json 2> gpurun_out/r3t/pool2.err
+echo "rc=$?"; python3 -c "
+import json; d=json.loads(open('gpurun_out/r3t/pool2.json').read()); print(d['value'], d['n_gpus'], d['ms_per_step'], d['config']['verified'], d['config']['verified_sample'], d['replica_ms_last_step'])"

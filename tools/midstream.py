@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Throughput of a STREAM of mid-size batches: 4 096 proofs through rlnamd_prover_prove_stream in chunks of max_batch =
+64 / 128 / 256 (c = 8 tables).  Run with RLNAMD_LANECHUNK=<threshold> to compare the small-batch shapes with the lanes =
+proofs pipeline (profiles/r3_rocprof_summary.md section 10).  Prints one JSON line."""
 import json, os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from zerokit_amd import workload
