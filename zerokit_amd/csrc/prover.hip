@@ -533,6 +533,7 @@ __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ V, const 
                                                 uint32_t nb, uint32_t part) {
   // part 0: every scalar; 1: the witness scalars and r, s, -(r s) (all the G2 walk needs: it can start before the
   // quotient h exists); 2: the coefficients of h only
+  // part 3 (small full proofs, fused plan): the products s w_i, r w_i and r s under the ids ns + n + 3 + ..., G1 only
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
   uint32_t sid = blockIdx.y * blockDim.y + threadIdx.y;
   if (part == 1) {
@@ -541,10 +542,22 @@ __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ V, const 
   } else if (part == 2) {
     if (sid >= n) return;
     sid += ns;
+  } else if (part == 3) {
+    if (sid >= 2 * ns + 1) return;
+    sid += ns + n + 3;
   }
-  if (p >= nb || sid >= ns + n + 3) return;
+  if (p >= nb || sid >= 3 * ns + n + 4) return;
   Fr x;
-  if (sid < ns) {
+  if (sid >= ns + n + 3) {
+    const uint32_t q = sid - (ns + n + 3);
+    const Fr r = Fr::from_canonical(rs + (size_t)p * 16), s = Fr::from_canonical(rs + (size_t)p * 16 + 8);
+    if (q < ns)
+      x = s * V[(size_t)sig2node[q] * B + p];
+    else if (q < 2 * ns)
+      x = r * V[(size_t)sig2node[q - ns] * B + p];
+    else
+      x = r * s;
+  } else if (sid < ns) {
     x = V[(size_t)sig2node[sid] * B + p];
   } else if (sid < ns + n) {
     x = H[(size_t)(sid - ns) * B + p];
@@ -556,7 +569,7 @@ __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ V, const 
   }
   uint32_t l[8];
   x.to_canonical(l);
-  const bool g2 = sid < ns || sid >= ns + n;
+  const bool g2 = sid < ns || (sid >= ns + n && sid < ns + n + 3);
   const uint32_t sid2 = sid < ns ? sid : sid - n;
   if (nh == 2) {
     uint32_t k[2][4], neg[2];
@@ -606,7 +619,7 @@ __global__ void __launch_bounds__(64) k_msm(const Affine<F>* __restrict__ table,
     // table row; the walk (full / partial / finish) is a list of rows.  Bit 31: the row is walked with the digits of
     // the scalar's second GLV half (the sum of those rows is mapped through phi afterwards, k_glv_fold)
     const uint32_t kk = rows[i], k = kk & 0x7FFFFFFFu;
-    const int16_t* dg = digits + ((size_t)sid[k] * nh + (kk >> 31)) * W * B + p;
+    const int16_t* dg = digits + ((size_t)sid[i] * nh + (kk >> 31)) * W * B + p;
     const Affine<F>* row = table + (size_t)k * ws.stride;
 #pragma unroll 1
     for (int j = 0; j < W; j++) {
@@ -1074,6 +1087,7 @@ struct Prover::Impl {
   struct Plan {
     DevBuf<uint32_t> rows;
     DevBuf<ChunkDesc> chunks, groups, segs, segchunks;   // segchunks: the chunk range of every segment (k_sum_tree)
+    DevBuf<uint32_t> rsid;                  // scalar id of every entry of `rows`
     DevBuf<uint32_t> early_ids, late_ids;   // chunk indices without / with rows that depend on the quotient h
     uint32_t nchunks = 0, ngroups = 0, nseg = 0, n_early = 0, n_late = 0;
   };
@@ -1081,6 +1095,7 @@ struct Prover::Impl {
   // the same walks cut into shorter chunks for batches walked with lanes = chunks: a walk lasts as long as its longest
   // chunk (a lane's serial chain of additions), and a handful of proofs cannot fill the chip anyway
   Plan plan1s[3], plan2s[3];
+  Plan plan1f[3];               // [PROVE_FULL] only: the fused small-batch plan (s A and r B1 as rows of the C segment)
   uint32_t max_chunks1s = 0, max_chunks2s = 0, small_stride = 64;   // partial sums of a small batch: [chunk][64]
   uint32_t max_chunks1 = 0, max_chunks2 = 0, max_groups1 = 0, max_groups2 = 0;
   uint32_t npts1 = 0, npts2 = 0;
@@ -1580,25 +1595,30 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   //      full = all, partial = rows whose scalar is a known witness signal (incl. w_0 = 1, which carries
   //      alpha / beta / query[0]), finish = the rest (unknown signals, h, blinding terms).
   const uint32_t SID_R = D.NS + D.n, SID_S = SID_R + 1, SID_NRS = SID_R + 2;
-  auto make_plans = [&](const std::vector<uint32_t>& sids, const std::vector<uint32_t>& row_seg, uint32_t nseg,
-                        uint32_t chunk_pts, Impl::Plan* plans, uint32_t* max_chunks, uint32_t* max_groups) {
+  // A walk = a list of (table row, scalar id, output segment) entries cut into chunks.  `dig_sid` = the id the digits
+  // of an entry live under (G2: the ids above the h block move down), `is_h` = the scalar is a coefficient of h.
+  struct VRow { uint32_t k, sid, dig_sid, seg; bool is_h; };
+  auto make_plans = [&](const std::vector<VRow>& vrows, uint32_t nseg, uint32_t chunk_pts, Impl::Plan* plans,
+                        uint32_t* max_chunks, uint32_t* max_groups, int only_mode) {
     for (int mode = 0; mode < 3; mode++) {
-      std::vector<uint32_t> rows, segfirst, early_ids, late_ids;
+      if (only_mode >= 0 && mode != only_mode) continue;
+      std::vector<uint32_t> rows, rsid, segfirst, early_ids, late_ids;
       std::vector<ChunkDesc> chunks;
       // reduction segment h * nseg + sg: the rows of output sg walked with GLV half h (bit 31 of the row entry)
       for (uint32_t h = 0; h < D.nh; h++)
         for (uint32_t sg = 0; sg < nseg; sg++) {
           segfirst.push_back((uint32_t)chunks.size());
-          // rows whose scalar is a coefficient of h (G1 only: ids NS .. NS + n) come last and start a chunk of their
-          // own, so that a small batch can walk everything else while the NTTs still run (early_ids / late_ids)
+          // rows whose scalar is a coefficient of h come last and start a chunk of their own, so that a small batch can
+          // walk everything else while the NTTs still run (early_ids / late_ids)
           for (int late = 0; late < 2; late++) {
             uint32_t first = (uint32_t)rows.size();
-            for (uint32_t k = 0; k < sids.size(); k++) {
-              if (row_seg[k] != sg) continue;
-              const bool is_h = nseg == 3 && sids[k] >= D.NS && sids[k] < D.NS + D.n;
-              if ((int)is_h != late) continue;
-              bool is_known = sids[k] < D.NS && D.known[sids[k]];
-              if (mode == PROVE_FULL || (mode == PROVE_PARTIAL) == is_known) rows.push_back(k | (h << 31));
+            for (const VRow& v : vrows) {
+              if (v.seg != sg || (int)v.is_h != late) continue;
+              bool is_known = v.sid < D.NS && D.known[v.sid];
+              if (mode == PROVE_FULL || (mode == PROVE_PARTIAL) == is_known) {
+                rows.push_back(v.k | (h << 31));
+                rsid.push_back(v.dig_sid);
+              }
             }
             for (uint32_t k = first; k < rows.size(); k += chunk_pts) {
               (late ? late_ids : early_ids).push_back((uint32_t)chunks.size());
@@ -1614,6 +1634,8 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
       P.ngroups = (uint32_t)groups.size();
       P.nseg = nseg * D.nh;
       P.rows.alloc(std::max<size_t>(rows.size(), 1));
+      P.rsid.alloc(std::max<size_t>(rsid.size(), 1));
+      if (!rsid.empty()) P.rsid.upload(rsid.data(), rsid.size(), s);
       P.chunks.alloc(std::max<size_t>(chunks.size(), 1));
       P.groups.alloc(std::max<size_t>(groups.size(), 1));
       P.segs.alloc(segs.size());
@@ -1660,13 +1682,42 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     D.npts1 = (uint32_t)pts.size();
     D.sid1.alloc(sids.size());
     D.sid1.upload(sids.data(), sids.size(), s);
+    std::vector<VRow> vrows;
+    for (uint32_t k = 0; k < sids.size(); k++)
+      vrows.push_back({k, sids[k], sids[k], row_seg[k], sids[k] >= D.NS && sids[k] < D.NS + D.n});
     // rows (x halves) per single-wave workgroup: ~150 additions each, as before the split (8 rows x 19 windows)
-    make_plans(sids, row_seg, 3, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK", D.nh == 2 ? 16 : 8)), D.plan1,
-               &D.max_chunks1, &D.max_groups1);
+    make_plans(vrows, 3, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK", D.nh == 2 ? 16 : 8)), D.plan1, &D.max_chunks1,
+               &D.max_groups1, -1);
     {
       uint32_t unused = 0;
-      make_plans(sids, row_seg, 3, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_SMALL", 4)), D.plan1s, &D.max_chunks1s,
-                 &unused);
+      make_plans(vrows, 3, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_SMALL", 4)), D.plan1s, &D.max_chunks1s, &unused, -1);
+    }
+    {
+      // Small full proofs, fused plan: s A + r B1 - r s delta = s alpha + r beta + r s delta + sum (s w_i) A_i + sum (r w_i) B1_i,
+      // so the two variable-base products of the back end (k_fin_smul: a lone lane's ladder of 127 doublings, the longest
+      // kernel behind the interpreter) become extra rows of the C segment -- the A and B1 rows walked a second time under
+      // the scalar ids of s w_i and r w_i (k_recode part 3) -- and the B1 segment is not walked at all.  More additions
+      // in total (+ 25 % G1 rows), which is why only batches below the small-batch threshold take this plan.
+      std::vector<VRow> f;
+      const uint32_t NX = D.NS + D.n + 3;   // first extra scalar id: s w_i at NX + i, r w_i at NX + NS + i, r s at NX + 2 NS
+      for (uint32_t k = 0; k < sids.size(); k++) {
+        const uint32_t sd = sids[k], sg = row_seg[k];
+        const bool is_h = sd >= D.NS && sd < D.NS + D.n;
+        if (sg == 0) {
+          f.push_back({k, sd, sd, 0, false});                                   // A itself is an output
+          if (sd < D.NS) f.push_back({k, sd, NX + sd, 2, false});               // (s w_i) A_i   (alpha carries sid 0: s alpha)
+          // delta with r (part of A) contributes s r delta to s A: counted once below
+        } else if (sg == 1) {
+          if (sd < D.NS) f.push_back({k, sd, NX + D.NS + sd, 2, false});        // (r w_i) B1_i  (beta carries sid 0: r beta)
+        } else if (sd == SID_NRS) {
+          f.push_back({k, sd, NX + 2 * D.NS, 2, false});                        // + r s delta instead of - r s delta
+        } else {
+          f.push_back({k, sd, sd, 2, is_h});                                    // L and H rows
+        }
+      }
+      uint32_t unused = 0;
+      make_plans(f, 3, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_SMALL", 4)), D.plan1f, &D.max_chunks1s, &unused,
+                 PROVE_FULL);
     }
     if (D.use29) build_table29<Fq, G1Affine29>(pts, D.ws, D.t1_29, s); else build_table<Fq>(pts, D.ws, D.t1, s);
   }
@@ -1689,12 +1740,13 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
       if (v >= D.NS) v -= D.n;
     D.sid2.alloc(dsid.size());
     D.sid2.upload(dsid.data(), dsid.size(), s);
-    make_plans(sids, row_seg, 1, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_G2", D.nh == 2 ? 8 : 4)), D.plan2,
-               &D.max_chunks2, &D.max_groups2);
+    std::vector<VRow> vrows;
+    for (uint32_t k = 0; k < sids.size(); k++) vrows.push_back({k, sids[k], dsid[k], 0u, false});
+    make_plans(vrows, 1, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_G2", D.nh == 2 ? 8 : 4)), D.plan2, &D.max_chunks2,
+               &D.max_groups2, -1);
     {
       uint32_t unused = 0;
-      make_plans(sids, row_seg, 1, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_G2_SMALL", 4)), D.plan2s, &D.max_chunks2s,
-                 &unused);
+      make_plans(vrows, 1, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_G2_SMALL", 4)), D.plan2s, &D.max_chunks2s, &unused, -1);
     }
     if (D.use29_g2) build_table29<Fq2, G2Affine29>(pts, D.ws2, D.t2_29, s); else build_table<Fq2>(pts, D.ws2, D.t2, s);
   }
@@ -1736,7 +1788,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     S.V.alloc((size_t)D.N * B);
     if (D.wit29) S.V29.alloc(((size_t)D.nstore29 + 1) * 3 * B);   // + the trash row of k_witness_lanes
     S.abc.alloc(3 * (size_t)D.n * B);
-    S.digits.alloc((size_t)(D.NS + D.n + 3) * D.nh * D.ws.W * B);
+    S.digits.alloc((size_t)(3 * D.NS + D.n + 4) * D.nh * D.ws.W * B);   // + s w_i, r w_i, r s of the fused small-batch plan
     S.digits2.alloc((size_t)(D.NS + 3) * D.nh * D.ws2.W * B);
     S.part1.alloc(std::max((size_t)D.max_chunks1 * B, (size_t)D.max_chunks1s * D.small_stride));
     S.grp1.alloc((size_t)D.max_groups1 * B);
@@ -1954,7 +2006,16 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   if (mode < PROVE_FULL || mode > PROVE_FINISH) throw Error("unknown prover mode");
   Impl& D = *d_;
   const bool small = n <= D.lanechunk_max && n <= D.small_stride && D.use29 && D.use29_g2;   // lanes = chunks
-  const Impl::Plan& P1 = small ? D.plan1s[mode] : D.plan1[mode];
+  // Small batches (latency, not throughput): the whole front end stays on ONE stream (every cross-stream event hop costs
+  // 0.1 - 0.15 ms), the digits of the witness scalars are recoded right behind the interpreter, and both walks start on
+  // everything that does not depend on the quotient h while mat-vec / NTTs still run; only the h rows of the G1 walk
+  // wait for them.
+  const bool early = n <= D.lanechunk_max && D.use29 && D.use29_g2 && D.split_msm && D.recode_front &&
+                     mode != PROVE_PARTIAL && env_int("RLNAMD_EARLY_WALK", 1) != 0;
+  // small full proofs: s A and r B1 are rows of the C segment (plan1f), no k_fin_smul
+  const bool fused = early && small && mode == PROVE_FULL && D.nh == 2 && env_int("RLNAMD_FUSED_SMUL", 1) != 0 &&
+                     env_int("RLNAMD_EARLY_FIN", 1) != 0;   // (its back end is the split one below)
+  const Impl::Plan& P1 = fused ? D.plan1f[PROVE_FULL] : small ? D.plan1s[mode] : D.plan1[mode];
   const Impl::Plan& P2 = small ? D.plan2s[mode] : D.plan2[mode];
   const uint32_t PB = small ? D.small_stride : (uint32_t)B_;   // stride of the partial-sum arrays
   Slot& S = D.slot[D.cur];
@@ -1979,12 +2040,6 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   const uint32_t sq = D.seq++;
   hipStream_t sA = (D.nstreamA > 1 && D.wstreams > 1 && (sq & 1)) ? D.sAb : D.sA;
   const uint32_t B = (uint32_t)B_, nb = (uint32_t)n;
-  // Small batches (latency, not throughput): the whole front end stays on ONE stream (every cross-stream event hop costs
-  // 0.1 - 0.15 ms), the digits of the witness scalars are recoded right behind the interpreter, and both walks start on
-  // everything that does not depend on the quotient h while mat-vec / NTTs still run; only the h rows of the G1 walk
-  // wait for them.
-  const bool early = nb <= D.lanechunk_max && D.use29 && D.use29_g2 && D.split_msm && D.recode_front &&
-                     mode != PROVE_PARTIAL && env_int("RLNAMD_EARLY_WALK", 1) != 0;
   hipStream_t sA2 = (D.nstreamA > 1 && !early) ? D.sA2 : sA;
   const uint32_t pg = div_up(nb, 64);
   const uint32_t nbp = pg * 64;  // padded lanes compute on stale / zero inputs; results ignored
@@ -2043,13 +2098,16 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   if (early) {
     hipLaunchKernelGGL(k_recode, dim3(pg, D.NS + 3), dim3(64, 1), 0, sA, S.V.p, D.sig2node.p, D.NS, S.abc.p, D.n, rs_p,
                        D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nbp, 1u);
+    if (fused)
+      hipLaunchKernelGGL(k_recode, dim3(pg, 2 * D.NS + 1), dim3(64, 1), 0, sA, S.V.p, D.sig2node.p, D.NS, S.abc.p, D.n,
+                         rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nbp, 3u);
     RLN_HIP(hipEventRecord(S.evW, sA));
     RLN_HIP(hipStreamWaitEvent(D.sB, S.evW, 0));
     RLN_HIP(hipStreamWaitEvent(D.sB2, S.evW, 0));
     RLN_HIP(hipEventRecord(S.t[14], D.sB));
     if (P1.n_early)
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>), dim3(div_up(P1.n_early, 64), nb), dim3(64), 0,
-                         D.sB, D.t1_29.p, D.sid1.p, P1.rows.p, P1.chunks.p, P1.n_early, S.digits.p, S.part1.p, D.ws, B, PB,
+                         D.sB, D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.n_early, S.digits.p, S.part1.p, D.ws, B, PB,
                          D.nh, nullptr, P1.early_ids.p);
     RLN_HIP(hipEventRecord(S.evE, D.sB));
   }
@@ -2111,7 +2169,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   if (early) {   // the h rows, on the front-end stream itself (no event hop); everything else is already walking
     if (P1.n_late)
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>), dim3(div_up(P1.n_late, 64), nb), dim3(64), 0, sA,
-                         D.t1_29.p, D.sid1.p, P1.rows.p, P1.chunks.p, P1.n_late, S.digits.p, S.part1.p, D.ws, B, PB, D.nh,
+                         D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.n_late, S.digits.p, S.part1.p, D.ws, B, PB, D.nh,
                          nullptr, P1.late_ids.p);
     RLN_HIP(hipEventRecord(S.evR, sA));
     RLN_HIP(hipStreamWaitEvent(D.sB, S.evR, 0));   // evB below then covers both launches
@@ -2119,15 +2177,15 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     uint32_t blocks = div_up(P1.nchunks, 8) * 8 * pg;
     if (D.use29 && lanechunk)
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>), dim3(div_up(P1.nchunks, 64), nb), dim3(64), 0, D.sB,
-                         D.t1_29.p, D.sid1.p, P1.rows.p, P1.chunks.p, P1.nchunks, S.digits.p, S.part1.p, D.ws, B, PB, D.nh,
+                         D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.nchunks, S.digits.p, S.part1.p, D.ws, B, PB, D.nh,
                          nullptr);
     else if (D.use29)
       // dynamic LDS that the kernel never touches caps it at D.msm_waves waves per SIMD: at 4 x 128 VGPRs the
       // register file is full and the front end's NTT / mat-vec workgroups wait for an MSM workgroup (~1 ms) to retire
-      hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(blocks), dim3(64), D.msm_lds, D.sB, D.t1_29.p, D.sid1.p, P1.rows.p, P1.chunks.p,
+      hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(blocks), dim3(64), D.msm_lds, D.sB, D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p,
                          P1.nchunks, S.digits.p, S.part1.p, D.ws, B, pg, D.nh, D.walk_clk.p);
     else
-      hipLaunchKernelGGL(k_msm<Fq>, dim3(blocks), dim3(64), 0, D.sB, D.t1.p, D.sid1.p, P1.rows.p, P1.chunks.p,
+      hipLaunchKernelGGL(k_msm<Fq>, dim3(blocks), dim3(64), 0, D.sB, D.t1.p, P1.rsid.p, P1.rows.p, P1.chunks.p,
                          P1.nchunks, S.digits.p, S.part1.p, D.ws, B, pg, D.nh);
   }
   RLN_HIP(hipEventRecord(S.t[7], D.sB));
@@ -2136,14 +2194,14 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     uint32_t blocks = div_up(P2.nchunks, 8) * 8 * pg;
     if (D.use29_g2 && lanechunk)
       hipLaunchKernelGGL((k_msm29<G2Acc29, G2Affine29, G2XYZZ, 1, true>), dim3(div_up(P2.nchunks, 64), nb), dim3(64), 0, s2,
-                         D.t2_29.p, D.sid2.p, P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, PB, D.nh,
+                         D.t2_29.p, P2.rsid.p, P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, PB, D.nh,
                          nullptr);
     else if (D.use29_g2)
-      hipLaunchKernelGGL((k_msm29<G2Acc29, G2Affine29, G2XYZZ, 2>), dim3(blocks), dim3(64), 0, s2, D.t2_29.p, D.sid2.p,
+      hipLaunchKernelGGL((k_msm29<G2Acc29, G2Affine29, G2XYZZ, 2>), dim3(blocks), dim3(64), 0, s2, D.t2_29.p, P2.rsid.p,
                          P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, pg, D.nh,
                          D.walk_clk.p ? D.walk_clk.p + 2 : nullptr);
     else
-      hipLaunchKernelGGL(k_msm<Fq2>, dim3(blocks), dim3(64), 0, s2, D.t2.p, D.sid2.p, P2.rows.p, P2.chunks.p,
+      hipLaunchKernelGGL(k_msm<Fq2>, dim3(blocks), dim3(64), 0, s2, D.t2.p, P2.rsid.p, P2.rows.p, P2.chunks.p,
                          P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, pg, D.nh);
   }
   RLN_HIP(hipEventRecord(S.t[8], s2));
@@ -2172,15 +2230,25 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   const bool fin29 = nb <= D.lanechunk_max && D.use29 && env_int("RLNAMD_FIN29", 1) != 0;
   if (early_fin) {
     RLN_HIP(hipStreamWaitEvent(D.sA2, S.evE, 0));   // sB: the early G1 walk
-    hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, 4), dim3(256), 0, D.sA2, S.part1.p, P1.segchunks.p, S.sums1.p, B,
-                       PB, task_sel({0, 1, 3, 4}));
-    hipLaunchKernelGGL(k_glv_fold, dim3(pg, 2), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({0, 1}));
-    hipLaunchKernelGGL(k_fin_affine, dim3(pg, 2), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
-                       S.affB2.p, B, nbp, task_sel({0, 1}));
-    if (fin29)
-      launch_fin_smul29(D.sA2, S.affA.p, S.affB1.p, rs_p, S.prod.p, B, nb);
-    else
-      hipLaunchKernelGGL(k_fin_smul, dim3(pg, 2), dim3(64), 0, D.sA2, S.affA.p, S.affB1.p, rs_p, S.tbl.p, S.prod.p, B, nbp);
+    if (fused) {
+      // fused plan: only A has to be reduced and inverted early; s A and r B1 are inside the C segment, B1 is never formed
+      hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, 2), dim3(256), 0, D.sA2, S.part1.p, P1.segchunks.p, S.sums1.p, B, PB,
+                         task_sel({0, 3}));
+      hipLaunchKernelGGL(k_glv_fold, dim3(pg, 1), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({0}));
+      hipLaunchKernelGGL(k_fin_affine, dim3(pg, 1), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
+                         S.affB2.p, B, nbp, task_sel({0}));
+      RLN_HIP(hipMemsetAsync(S.prod.p, 0, S.prod.bytes(), D.sA2));   // ZZ = 0: two points at infinity for k_fin_out
+    } else {
+      hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, 4), dim3(256), 0, D.sA2, S.part1.p, P1.segchunks.p, S.sums1.p, B,
+                         PB, task_sel({0, 1, 3, 4}));
+      hipLaunchKernelGGL(k_glv_fold, dim3(pg, 2), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({0, 1}));
+      hipLaunchKernelGGL(k_fin_affine, dim3(pg, 2), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
+                         S.affB2.p, B, nbp, task_sel({0, 1}));
+      if (fin29)
+        launch_fin_smul29(D.sA2, S.affA.p, S.affB1.p, rs_p, S.prod.p, B, nb);
+      else
+        hipLaunchKernelGGL(k_fin_smul, dim3(pg, 2), dim3(64), 0, D.sA2, S.affA.p, S.affB1.p, rs_p, S.tbl.p, S.prod.p, B, nbp);
+    }
     RLN_HIP(hipGetLastError());
     RLN_HIP(hipEventRecord(S.evA, D.sA2));
     // sC in the order its inputs arrive: the G2 sum and inversion (behind the G2 walk only), then the C segment (behind

@@ -35,6 +35,8 @@ struct ChunkDesc {
 // runs transposed: 47 + 16 waves per proof, each alone on its SIMD.  Rows, scalar ids and table rows become per-lane
 // (vector) loads; the partial sums land at part[chunk * pgroups + proof] (the parameter is the stride of the
 // partial-sum array in this mode: the small-batch plans cut the walks into shorter chunks and keep [chunk][64]).
+// `sid` is indexed by the position in `rows` (a plan may walk a table row with another scalar than the row's own: the
+// small-batch plan walks the A and B1 rows a second time with s w_i and r w_i, see Prover::Prover).
 template <class Acc, class Entry, class Out, int WAVES, bool LANECHUNK = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_msm29(const Entry* __restrict__ table, const uint32_t* __restrict__ sid,
                                               const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks,
@@ -57,7 +59,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 
     Acc acc = Acc::inf();
     for (uint32_t i = cd.pt_begin; i < cd.pt_end; i++) {
       const uint32_t kk = rows[i], k = kk & 0x7FFFFFFFu;
-      const int16_t* dg = digits + ((size_t)sid[k] * nh + (kk >> 31)) * W * B + p;
+      const int16_t* dg = digits + ((size_t)sid[i] * nh + (kk >> 31)) * W * B + p;
       const Entry* row = table + (size_t)k * ws.stride;
 #pragma unroll 1
       for (int j = 0; j < W; j++) {
@@ -80,7 +82,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 
 #pragma unroll 1
   for (uint32_t i = cd.pt_begin; i < cd.pt_end; i++) {
     const uint32_t kk = rows[i], k = kk & 0x7FFFFFFFu;  // bit 31: second GLV half (see k_msm)
-    const int16_t* dg = digits + ((size_t)sid[k] * nh + (kk >> 31)) * W * B + p;
+    const int16_t* dg = digits + ((size_t)sid[i] * nh + (kk >> 31)) * W * B + p;
     const Entry* row = table + (size_t)k * ws.stride;
 #pragma unroll 1
     for (int j = 0; j < W; j++) {  // (touching the next entry ahead of the addition was measured: 3 % slower)
