@@ -375,11 +375,15 @@ struct CsrView {
   const uint32_t* col;  // already mapped to graph node ids
   const Fr* coef;
 };
+// LG (small batches): lanes = rows of ONE proof (blockIdx.y) instead of lanes = proofs -- with lanes = proofs a single
+// proof launches 8 192 waves with one useful lane each, which also crowd the walks that run beside them
+template <bool LG>
 __global__ void __launch_bounds__(256) k_matvec(CsrView A, CsrView Bm, const Fr* __restrict__ V,
                                                 const uint32_t* __restrict__ sig2node, uint32_t nc, uint32_t ni,
                                                 uint32_t n, Fr* __restrict__ abc, uint32_t B, uint32_t nb) {
-  uint32_t p = blockIdx.x * 64 + threadIdx.x;
-  uint32_t row = __builtin_amdgcn_readfirstlane(blockIdx.y * blockDim.y + threadIdx.y);  // wave-uniform
+  uint32_t p = LG ? blockIdx.y : blockIdx.x * 64 + threadIdx.x;
+  uint32_t row = LG ? blockIdx.x * 64 + threadIdx.x
+                    : __builtin_amdgcn_readfirstlane(blockIdx.y * blockDim.y + threadIdx.y);  // wave-uniform
   if (row >= n) return;
   if (p >= nb) return;
   Fr a = Fr::zero(), b = Fr::zero();
@@ -487,9 +491,9 @@ __global__ void __launch_bounds__(256, RLN_NTT_WAVES) k_ntt_pass(Fr* __restrict_
 }
 
 // h = a o b - c  (qap.rs:84-95), written over the `a` vector
-__global__ void __launch_bounds__(256) k_hquot(Fr* __restrict__ abc, uint32_t n, uint32_t B, uint32_t nb) {
-  uint32_t p = blockIdx.x * 64 + threadIdx.x;
-  uint32_t i = blockIdx.y * blockDim.y + threadIdx.y;
+__global__ void __launch_bounds__(256) k_hquot(Fr* __restrict__ abc, uint32_t n, uint32_t B, uint32_t nb, uint32_t lg) {
+  uint32_t p = lg ? blockIdx.y : blockIdx.x * 64 + threadIdx.x;   // lg: lanes = coefficients of one proof
+  uint32_t i = lg ? blockIdx.x * 64 + threadIdx.x : blockIdx.y * blockDim.y + threadIdx.y;
   if (p >= nb || i >= n) return;
   size_t o = (size_t)i * B + p;
   abc[o] = abc[o] * abc[(size_t)n * B + o] - abc[2 * (size_t)n * B + o];
@@ -530,12 +534,12 @@ __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ V, const 
                                                 uint32_t ns, const Fr* __restrict__ H, uint32_t n,
                                                 const uint32_t* __restrict__ rs, WinSched ws1, WinSched ws2, uint32_t nh,
                                                 int16_t* __restrict__ dig1, int16_t* __restrict__ dig2, uint32_t B,
-                                                uint32_t nb, uint32_t part) {
+                                                uint32_t nb, uint32_t part, uint32_t lg) {
   // part 0: every scalar; 1: the witness scalars and r, s, -(r s) (all the G2 walk needs: it can start before the
   // quotient h exists); 2: the coefficients of h only
   // part 3 (small full proofs, fused plan): the products s w_i, r w_i and r s under the ids ns + n + 3 + ..., G1 only
-  uint32_t p = blockIdx.x * 64 + threadIdx.x;
-  uint32_t sid = blockIdx.y * blockDim.y + threadIdx.y;
+  uint32_t p = lg ? blockIdx.y : blockIdx.x * 64 + threadIdx.x;   // lg (small batches): lanes = scalars of one proof
+  uint32_t sid = lg ? blockIdx.x * 64 + threadIdx.x : blockIdx.y * blockDim.y + threadIdx.y;
   if (part == 1) {
     if (sid >= ns + 3) return;
     if (sid >= ns) sid += n;
@@ -2096,11 +2100,11 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // of behind them; only h's digits wait for the NTTs.
   const bool early_g2 = early;
   if (early) {
-    hipLaunchKernelGGL(k_recode, dim3(pg, D.NS + 3), dim3(64, 1), 0, sA, S.V.p, D.sig2node.p, D.NS, S.abc.p, D.n, rs_p,
-                       D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nbp, 1u);
+    hipLaunchKernelGGL(k_recode, dim3(div_up(D.NS + 3, 64), nb), dim3(64, 1), 0, sA, S.V.p, D.sig2node.p, D.NS, S.abc.p,
+                       D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nb, 1u, 1u);
     if (fused)
-      hipLaunchKernelGGL(k_recode, dim3(pg, 2 * D.NS + 1), dim3(64, 1), 0, sA, S.V.p, D.sig2node.p, D.NS, S.abc.p, D.n,
-                         rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nbp, 3u);
+      hipLaunchKernelGGL(k_recode, dim3(div_up(2 * D.NS + 1, 64), nb), dim3(64, 1), 0, sA, S.V.p, D.sig2node.p, D.NS,
+                         S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nb, 3u, 1u);
     RLN_HIP(hipEventRecord(S.evW, sA));
     RLN_HIP(hipStreamWaitEvent(D.sB, S.evW, 0));
     RLN_HIP(hipStreamWaitEvent(D.sB2, S.evW, 0));
@@ -2119,8 +2123,12 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   RLN_HIP(hipEventRecord(S.t[12], sA2));
   if (mode != PROVE_PARTIAL) {  // the quotient h depends on the whole witness: not part of a partial proof
     CsrView A{D.a_ptr.p, D.a_col.p, D.a_coef.p}, Bm{D.b_ptr.p, D.b_col.p, D.b_coef.p};
-    hipLaunchKernelGGL(k_matvec, dim3(pg, D.n), dim3(64, 1), 0, sA2, A, Bm, S.V.p, D.sig2node.p, D.nc,
-                       D.ni, D.n, S.abc.p, B, nbp);
+    if (nb <= D.lanechunk_max)
+      hipLaunchKernelGGL(k_matvec<true>, dim3(div_up(D.n, 64), nb), dim3(64, 1), 0, sA2, A, Bm, S.V.p, D.sig2node.p, D.nc,
+                         D.ni, D.n, S.abc.p, B, nb);
+    else
+      hipLaunchKernelGGL(k_matvec<false>, dim3(pg, D.n), dim3(64, 1), 0, sA2, A, Bm, S.V.p, D.sig2node.p, D.nc,
+                         D.ni, D.n, S.abc.p, B, nbp);
   }
   RLN_HIP(hipEventRecord(S.t[3], sA2));
   if (mode != PROVE_PARTIAL) {
@@ -2135,7 +2143,10 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
       launch_ntt<true, false>(S.abc.p, (const uint32_t*)D.tw_i.p, D.logn, (const uint32_t*)D.coset.p, B, lg ? nb : nbp, sA2, lg);
       launch_ntt<false, false>(S.abc.p, (const uint32_t*)D.tw_f.p, D.logn, nullptr, B, lg ? nb : nbp, sA2, lg);
     }
-    hipLaunchKernelGGL(k_hquot, dim3(pg, D.n), dim3(64, 1), 0, sA2, S.abc.p, D.n, B, nbp);
+    if (nb <= D.lanechunk_max)
+      hipLaunchKernelGGL(k_hquot, dim3(div_up(D.n, 64), nb), dim3(64, 1), 0, sA2, S.abc.p, D.n, B, nb, 1u);
+    else
+      hipLaunchKernelGGL(k_hquot, dim3(pg, D.n), dim3(64, 1), 0, sA2, S.abc.p, D.n, B, nbp, 0u);
   }
   RLN_HIP(hipEventRecord(S.t[4], sA2));
   // digit recoding either closes the front end (the MSM stream then carries nothing but the two table walks) or
@@ -2147,11 +2158,11 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   }
   RLN_HIP(hipEventRecord(S.t[5], sR));
   if (early_g2)
-    hipLaunchKernelGGL(k_recode, dim3(pg, D.n), dim3(64, 1), 0, sR, S.V.p, D.sig2node.p, D.NS, S.abc.p, D.n, rs_p, D.ws,
-                       D.ws2, D.nh, S.digits.p, S.digits2.p, B, nbp, 2u);
+    hipLaunchKernelGGL(k_recode, dim3(div_up(D.n, 64), nb), dim3(64, 1), 0, sR, S.V.p, D.sig2node.p, D.NS, S.abc.p, D.n,
+                       rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nb, 2u, 1u);
   else
     hipLaunchKernelGGL(k_recode, dim3(pg, D.NS + D.n + 3), dim3(64, 1), 0, sR, S.V.p, D.sig2node.p, D.NS,
-                       S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nbp, 0u);
+                       S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nbp, 0u, 0u);
   RLN_HIP(hipEventRecord(S.t[6], sR));
   // ---------------- stage B
   if (D.recode_front && !early) {
