@@ -1750,7 +1750,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
                &D.max_groups2, -1);
     {
       uint32_t unused = 0;
-      make_plans(vrows, 1, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_G2_SMALL", 4)), D.plan2s, &D.max_chunks2s, &unused, -1);
+      make_plans(vrows, 1, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_G2_SMALL", 2)), D.plan2s, &D.max_chunks2s, &unused, -1);
     }
     if (D.use29_g2) build_table29<Fq2, G2Affine29>(pts, D.ws2, D.t2_29, s); else build_table<Fq2>(pts, D.ws2, D.t2, s);
   }
