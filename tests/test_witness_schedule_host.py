@@ -69,11 +69,14 @@ def test_schedule_reproduces_the_golden_witness_depth20(WS, rows):
         seen = st
     steps, nrow, nfma, nsqr, nadd, nmisc, peak, _ = seen
     # the shipped circuit has 13 972 products at a multiplication depth of 5 736: the schedule must stay near that depth
-    assert 5736 <= steps < 8000 and peak < 200
+    # (7 300 steps with the sums in the circuit's source order; ~6 200 with the sums re-associated by arrival time)
+    print("schedule rows=%d: steps %d (row %d fma %d sqr %d add %d misc %d) peak slots %d"
+          % (rows, steps, nrow, nfma, nsqr, nadd, nmisc, peak))
+    assert 5736 <= steps < 6600 and peak < 200
     if rows:
-        assert nrow > 7000 and nfma == 0 and nsqr == 0
+        assert nrow > 5700 and nfma == 0 and nsqr == 0
     else:
-        assert nrow == 0 and nfma + nsqr > 6500 and nsqr > 2000
+        assert nrow == 0 and nfma + nsqr > 5700
 
 
 @pytest.mark.parametrize("rows", [0, 1])
