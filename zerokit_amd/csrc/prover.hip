@@ -987,6 +987,17 @@ __global__ void __launch_bounds__(256) k_public_signals(const Fr* __restrict__ V
   V[(size_t)sig2node[1 + k] * B + p].to_canonical(out + ((size_t)p * npub + k) * 8);
 }
 
+// Small batches: k_proof_values is a lone lane's chain of 24 Poseidon hashes (5.3 ms for one proof -- longer than the
+// whole rest of the proof once the interpreter runs in 2.9 ms), and the interpreter has just computed the same five
+// values as the circuit's outputs: take them from the witness (single-message circuit: w[1..5] = y, root, nullifier,
+// x, external_nullifier, the order of k_proof_values; rln.circom's public signals, protocol/proof.rs:37-52)
+__global__ void __launch_bounds__(64) k_values_from_witness(const Fr* __restrict__ V, const uint32_t* __restrict__ sig2node,
+                                                            uint32_t B, uint32_t nb, uint32_t* __restrict__ values) {
+  const uint32_t p = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
+  if (p >= nb) return;
+  V[(size_t)sig2node[1 + k] * B + p].to_canonical(values + (size_t)p * 40 + k * 8);
+}
+
 // gathers for the parity taps
 __global__ void k_gather_col(const Fr* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t count, uint32_t B,
                              uint32_t p, uint32_t* __restrict__ out) {
@@ -2227,7 +2238,11 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   }
   if (streamed) RLN_HIP(hipStreamWaitEvent(sV, S.evU, 0));
   RLN_HIP(hipEventRecord(S.t[0], sV));
-  if (D.have_values_kernel)
+  const bool values_w = early && D.have_values_kernel && D.ni == 6 && env_int("RLNAMD_VALUES_WITNESS", 1) != 0;
+  if (values_w) {   // small batches: the circuit's own outputs (see k_values_from_witness)
+    RLN_HIP(hipStreamWaitEvent(sV, S.evW, 0));   // sA: witness stored, digits recoded
+    hipLaunchKernelGGL(k_values_from_witness, dim3(pg, 5), dim3(64), 0, sV, S.V.p, D.sig2node.p, B, nbp, S.values.p);
+  } else if (D.have_values_kernel)
     hipLaunchKernelGGL(k_proof_values, dim3(pg), dim3(64), 0, sV, in_p, D.NI, D.slots, poseidon_view(2),
                        poseidon_view(3), poseidon_view(4), S.values.p, nbp);
   RLN_HIP(hipEventRecord(S.t[13], sV));

@@ -20,7 +20,9 @@
 
 namespace rlnamd {
 
-constexpr uint32_t WL_LDS_BYTES = WL_SLOTS * 48 + 64;
+constexpr uint32_t WL_STAGE = WL_SLOTS * 12 + 16;                       // word offset of the store staging area
+constexpr uint32_t WL_LDS_BYTES = WL_SLOTS * 48 + 64 + WL_PF * WL_ROWS * 48;   // slots, error word, staging
+static_assert(WL_PF * WL_ROWS == WL_W, "a staging entry per lane");
 
 __device__ __forceinline__ void wl_read(Fr29& r, const uint32_t* lds, uint32_t slot) {
   const char* a = (const char*)lds + slot * 48;
@@ -88,13 +90,13 @@ __device__ __noinline__ WlOut wl_misc(uint32_t dx, uint32_t dy, uint32_t dz, con
 // Row form of a * b + c (WK_ROW).  A lane-form step spends ~290 instructions of ONE wave on products that occupy two of
 // its 64 lanes on average.  Here a value's nine 29-bit limbs sit in lanes 0..8 of a 16-lane DPP row (a wave = four
 // products), and every lane computes ONE column of each partial product:
-//     T_c = sum_k a_k b_(c-k)          b_(c-k) = the neighbour's limb, fetched with v_mov_dpp row_shr:k
-//     T_(c+9) = sum_k a_k b_(c+9-k)    row_shl:(9-k);  a's limbs are row-uniform (every lane reads all nine from LDS)
+//     T_c = sum_k a_k b_(c-k)          b_(c-k) = the neighbour's limb, fetched with v_mov_dpp row_shr:k;
+//                                      a's limbs are row-uniform (every lane reads all nine from LDS)
 // The reduction is the separated (not interleaved) Montgomery form, because an interleaved round would need lane 0's
 // digit broadcast to its row nine times in a dependent chain:  n = T mod 2^261 as 29-bit limbs (one carry pass across the
 // lanes), m = n p' mod 2^261, U = m p, result = (T + U) / 2^261 + c.  The low 261 bits of T + U are an exact multiple of
 // 2^261; its quotient K (the carry into column 9) is read off the top three low columns:  W = S_8 + (S_7 >> 29) +
-// (S_6 >> 58) misses less than 3 units of the exact 2^29 K, so K = (W + 16) >> 29.  ~165 instructions per step.
+// (S_6 >> 58) misses less than 3 units of the exact 2^29 K, so K = (W + 16) >> 29.
 // Limbs: inputs "near-normalised" (< 2^29 + 4 below the top limb), columns < 9 (2^29.01)^2 + 9 2^29 2^30.1 < 2^63.3.
 // Values: m < 2^262 (lazy top limb), so the result is below a b / 2^261 + 2 r + c  -- the host's bounds use 2.4 r.
 template <int CTRL>
@@ -111,51 +113,134 @@ __device__ __forceinline__ uint32_t wl_carry3(uint64_t x) {
   const uint32_t l = (uint32_t)x & M, mid = (uint32_t)(x >> 29) & M, h = (uint32_t)(x >> 58);
   return l + dppz<WL_SHR(1)>(mid) + dppz<WL_SHR(2)>(h);
 }
-#define WL_MACS(lo, hi, cst, v)                                                                    \
-  lo = (uint64_t)cst[0] * v;                                                                        \
-  hi = 0;                                                                                           \
-  lo += (uint64_t)cst[1] * dppz<WL_SHR(1)>(v); hi += (uint64_t)cst[1] * dppz<WL_SHL(8)>(v);         \
-  lo += (uint64_t)cst[2] * dppz<WL_SHR(2)>(v); hi += (uint64_t)cst[2] * dppz<WL_SHL(7)>(v);         \
-  lo += (uint64_t)cst[3] * dppz<WL_SHR(3)>(v); hi += (uint64_t)cst[3] * dppz<WL_SHL(6)>(v);         \
-  lo += (uint64_t)cst[4] * dppz<WL_SHR(4)>(v); hi += (uint64_t)cst[4] * dppz<WL_SHL(5)>(v);         \
-  lo += (uint64_t)cst[5] * dppz<WL_SHR(5)>(v); hi += (uint64_t)cst[5] * dppz<WL_SHL(4)>(v);         \
-  lo += (uint64_t)cst[6] * dppz<WL_SHR(6)>(v); hi += (uint64_t)cst[6] * dppz<WL_SHL(3)>(v);         \
-  lo += (uint64_t)cst[7] * dppz<WL_SHR(7)>(v); hi += (uint64_t)cst[7] * dppz<WL_SHL(2)>(v);         \
-  lo += (uint64_t)cst[8] * dppz<WL_SHR(8)>(v); hi += (uint64_t)cst[8] * dppz<WL_SHL(1)>(v);
-// a: the nine limbs of the first factor (row-uniform); b, c: this lane's limb of the second factor and of the addend
-// (0 in lanes 9..15 of the row); j = lane & 15.  Returns this lane's limb of a b / 2^261 + c (valid in lanes 0..8).
-__device__ __forceinline__ uint32_t wl_row_mul_add(const uint32_t (&a)[9], uint32_t b, uint32_t c, uint32_t j) {
+// The 17 columns are spread over the row's SIXTEEN lanes: b is zero in lanes 9..15, so the row_shr fetches alone put
+// column c = 0..15 into lane c (lane c >= 9 sees b_(c-k) exactly where c - k <= 8); only column 16 = a_8 b_8 needs a
+// fetch of its own (lane 0, row_shl:8).  29 multiply-adds and 26 fetches (a second accumulator for the high columns in
+// lanes 0..8, the first version: 45 and 40 -- the same latency for the lone wave, more instructions issued).  The
+// result's limb i = column 9 + i: limbs 0..6 leave in lanes 9..15, limbs 7 and 8 (column 16 and the carries above it)
+// in lane 0, which closes the carry chain as a ring (row_ror).
+#define WL_ROR(k) (0x120 + (k))   // row_ror:k  lane i reads lane (i - k) mod 16
+// (two interleaved accumulators: a lone wave would otherwise wait out the latency of every multiply-add of the chain)
+#define WL_MACS16(acc, top, cst, v)                                                                 \
+  {                                                                                                 \
+    uint64_t e_ = (uint64_t)cst[0] * v;                                                             \
+    uint64_t o_ = (uint64_t)cst[1] * dppz<WL_SHR(1)>(v);                                            \
+    e_ += (uint64_t)cst[2] * dppz<WL_SHR(2)>(v);                                                    \
+    o_ += (uint64_t)cst[3] * dppz<WL_SHR(3)>(v);                                                    \
+    e_ += (uint64_t)cst[4] * dppz<WL_SHR(4)>(v);                                                    \
+    o_ += (uint64_t)cst[5] * dppz<WL_SHR(5)>(v);                                                    \
+    e_ += (uint64_t)cst[6] * dppz<WL_SHR(6)>(v);                                                    \
+    o_ += (uint64_t)cst[7] * dppz<WL_SHR(7)>(v);                                                    \
+    e_ += (uint64_t)cst[8] * dppz<WL_SHR(8)>(v);                                                    \
+    top = (uint64_t)cst[8] * dppz<WL_SHL(8)>(v);                                                    \
+    acc = e_ + o_;                                                                                  \
+  }
+// a: the first factor's nine limbs (row-uniform); b: this lane's limb of the second factor (0 in lanes 9..15);
+// cj: the addend's limb j - 9 in lanes 9..15 and limb 7 in lane 0; c8: the addend's limb 8 (read by lane 0).
+// Returns limb j - 9 of a b / 2^261 + c in lanes 9..15, limb 7 in lane 0 and limb 8 in lane 1.
+__device__ __forceinline__ uint32_t wl_row_mul_add16(const uint32_t (&a)[9], uint32_t b, uint32_t cj, uint32_t c8,
+                                                     uint32_t j) {
   constexpr uint32_t M = (1u << 29) - 1;
-  uint64_t tlo, thi;
-  WL_MACS(tlo, thi, a, b)
-  const uint32_t n = wl_carry3(tlo);                      // T mod 2^261, limbs < 2^30 + 2^6 (lanes 0..8)
+  uint64_t t, t16;
+  WL_MACS16(t, t16, a, b)
+  const uint32_t n = wl_carry3(t);                        // lanes 0..8: T mod 2^261 (lanes above: not read)
   uint64_t u = (uint64_t)WL_PINV[0] * n;
-  u += (uint64_t)WL_PINV[1] * dppz<WL_SHR(1)>(n);
+  uint64_t u1 = (uint64_t)WL_PINV[1] * dppz<WL_SHR(1)>(n);
   u += (uint64_t)WL_PINV[2] * dppz<WL_SHR(2)>(n);
-  u += (uint64_t)WL_PINV[3] * dppz<WL_SHR(3)>(n);
+  u1 += (uint64_t)WL_PINV[3] * dppz<WL_SHR(3)>(n);
   u += (uint64_t)WL_PINV[4] * dppz<WL_SHR(4)>(n);
-  u += (uint64_t)WL_PINV[5] * dppz<WL_SHR(5)>(n);
+  u1 += (uint64_t)WL_PINV[5] * dppz<WL_SHR(5)>(n);
   u += (uint64_t)WL_PINV[6] * dppz<WL_SHR(6)>(n);
-  u += (uint64_t)WL_PINV[7] * dppz<WL_SHR(7)>(n);
+  u1 += (uint64_t)WL_PINV[7] * dppz<WL_SHR(7)>(n);
   u += (uint64_t)WL_PINV[8] * dppz<WL_SHR(8)>(n);
-  uint32_t m = wl_carry3(u);                              // n p' mod 2^261 (what leaves lane 8 is dropped)
+  u += u1;
+  uint32_t m = wl_carry3(u);
   m = j < 9 ? m : 0;
-  uint64_t ulo, uhi;
-  WL_MACS(ulo, uhi, Fr29C::P, m)
-  const uint64_t slo = tlo + ulo;
-  uint64_t shi = thi + uhi;
-  // carry of the low half: exact in lane 8, moved to lane 0 of the high half
-  const uint64_t t1 = slo >> 29;
-  const uint32_t t2 = (uint32_t)(slo >> 58);
+  uint64_t U, U16;
+  WL_MACS16(U, U16, Fr29C::P, m)
+  const uint64_t s = t + U;                               // column j
+  const uint64_t s16 = t16 + U16;                         // lane 0: column 16
+  // carry of the low half: exact in lane 8, handed to column 9 next door
+  const uint64_t t1 = s >> 29;
+  const uint32_t t2 = (uint32_t)(s >> 58);
   const uint64_t t1n = (uint64_t)dppz<WL_SHR(1)>((uint32_t)t1) | ((uint64_t)dppz<WL_SHR(1)>((uint32_t)(t1 >> 32)) << 32);
-  const uint64_t w = slo + t1n + dppz<WL_SHR(2)>(t2);
+  const uint64_t w = s + t1n + dppz<WL_SHR(2)>(t2);
   const uint64_t K = (w + 16) >> 29;
-  const uint64_t K0 = (uint64_t)dppz<WL_SHL(8)>((uint32_t)K) | ((uint64_t)dppz<WL_SHL(8)>((uint32_t)(K >> 32)) << 32);
-  shi += (j == 0 ? K0 : 0) + c;
-  // two carry passes: limbs 0..7 below 2^29 + 2, limb 8 keeps the rest
-  const uint32_t r1 = wl_carry3(shi);
-  const uint32_t keep = j < 8 ? (r1 & M) : r1, carry = j < 8 ? (r1 >> 29) : 0;
-  return keep + dppz<WL_SHR(1)>(carry);
+  uint64_t K9 = (uint64_t)dppz<WL_SHR(1)>((uint32_t)K) | ((uint64_t)dppz<WL_SHR(1)>((uint32_t)(K >> 32)) << 32);
+  asm volatile("" : "+v"(K9));   // (as for top1 below: fetched with the whole row active)
+  // the ring of the high columns: lanes 9..15 = columns 9..15, lane 0 = column 16, lanes 1..8 hold zero
+  uint64_t y = s + (j == 9 ? K9 : 0);
+  y = j >= 9 ? y : (j == 0 ? s16 : 0);
+  y += cj;
+  const uint32_t l = (uint32_t)y & M, mid = (uint32_t)(y >> 29) & M, h = (uint32_t)(y >> 58);
+  const uint32_t h1 = dppz<WL_ROR(1)>(h);                 // lane 0: column 15's top piece, which belongs to column 17
+  const uint32_t r1 = l + dppz<WL_ROR(1)>(mid) + dppz<WL_ROR(2)>(h);
+  const uint32_t keep = r1 & M, carry = r1 >> 29;
+  const uint32_t r = keep + dppz<WL_ROR(1)>(carry);       // lane 9 receives lane 8's zero
+  const uint32_t top = (uint32_t)(y >> 29) + h1 + c8 + carry;   // lane 0: column 17 and whatever is above it
+  uint32_t top1 = dppz<WL_SHR(1)>(top);                         // limb 8 leaves in lane 1
+  // the fetch must run with the whole row active: without the pin the compiler sinks it into the j == 1 side of the
+  // select below (a branch), where lane 0 -- its source -- is switched off and the fetch returns 0
+  asm volatile("" : "+v"(top1));
+  return j == 1 ? top1 : r;
+}
+
+// The steps that are not row-form products (lane-form products when RLNAMD_WITROWS=0, plain additions, inputs and
+// the rare operations): out of line, so that the loop below is one compare and one branch away from its product.
+__device__ __noinline__ uint32_t wl_other_step(uint32_t kind, uint4 q, uint32_t* lds, const uint32_t* __restrict__ inputs,
+                                               uint32_t n_inputs, uint4* __restrict__ V29, uint32_t B, uint32_t p) {
+  const uint32_t dst = q.y & 0xFFFF, sa = q.y >> 16, sb = q.z & 0xFFFF, sc = q.z >> 16;
+  uint32_t e = WERR_NONE;
+  Fr29 v;
+  if (kind == WK_FMA) {
+    Fr29 va, vb, vc;
+    wl_read(va, lds, sa);
+    wl_read(vb, lds, sb);
+    wl_read(vc, lds, sc);
+    v = Fr29::mul_add(va, vb, vc);
+  } else if (kind == WK_SQR) {   // 45 products instead of 81: two of the three products of Poseidon's x^5
+    Fr29 va, vc;
+    wl_read(va, lds, sa);
+    wl_read(vc, lds, sc);
+    v = Fr29::sqr_add(va, &vc);
+  } else if (kind == WK_ADD) {
+    Fr29 va, vb;
+    wl_read(va, lds, sa);
+    wl_read(vb, lds, sb);
+#pragma unroll
+    for (int j = 0; j < 9; j++) v.v[j] = va.v[j] + vb.v[j];
+    v.normalize();
+  } else {
+    const WlOut o = wl_misc(q.x, q.y, q.z, lds, inputs, n_inputs, p);
+    v = o.v;
+    e = o.e;
+  }
+  wl_write(lds, dst, v);
+  if (q.x & WL_STORE) wl_store(V29, q.w, B, p, v);
+  return e;
+}
+
+// The wave is alone on its SIMD and every step reads what the step before wrote, so a step costs its latencies, not its
+// instruction count (PMC, one wave, 6 122 steps: 1 355 cycles per step = 580 VALU issue + 160 scalar + 55 branch +
+// 510 waiting at s_waitcnt).  The waiting was vmcnt(0) once per group of WL_PF steps: the prefetched descriptors were
+// loaded into fresh registers while the step still read the old ones, and copied at the end of the group -- which
+// drains every outstanding store (1 - 2 us each to HBM) of the steps just executed (vmcnt counts loads and stores in
+// order).  Hence
+//  * the descriptors of group g + 1 are all loaded at the START of group g (a second bank of registers): whatever the
+//    compiler's waits at the group boundary drain is a whole group (~6 us) old;
+//  * a row step does not store to V29: it leaves its result and the V29 slot in a staging entry in LDS, and the 64
+//    entries of a group are flushed together at the start of the next group, a lane per entry, three 16-byte stores.
+__device__ __forceinline__ void wl_flush(uint32_t* lds, uint4* __restrict__ V29, uint32_t B, uint32_t p, uint32_t lane) {
+  uint32_t* se = lds + WL_STAGE + lane * 12;
+  const uint4 a = *(const uint4*)se, b = *(const uint4*)(se + 4);
+  const uint32_t v8 = se[8], slot = se[9];
+  if (slot != 0xFFFFFFFFu) {
+    uint4* g = V29 + ((size_t)slot * B + p) * 3;
+    g[0] = a;
+    g[1] = b;
+    g[2] = make_uint4(v8, 0, 0, 0);
+    se[9] = 0xFFFFFFFFu;
+  }
 }
 
 __global__ void __launch_bounds__(64) k_witness_lanes(const uint4* __restrict__ prog, uint32_t nsteps,
@@ -174,65 +259,51 @@ __global__ void __launch_bounds__(64) k_witness_lanes(const uint4* __restrict__ 
     wl_write(lds, n_consts + 2, Fr29::mul(Fr29::neg_lazy(Fr29C::K8, one), one));   // -1, reduced
     lds[WL_SLOTS * 12] = 0;   // error word
   }
+  lds[WL_STAGE + lane * 12 + 9] = 0xFFFFFFFFu;   // staging entries: nothing to store
   __syncthreads();
   uint32_t e = WERR_NONE;
   uint4 d[WL_PF];
 #pragma unroll
   for (int k = 0; k < (int)WL_PF; k++) d[k] = prog[(size_t)k * WL_W + lane];
+  // a row's lanes: 0..8 read the second factor's limbs; the result's limbs 0..6 leave in lanes 9..15, limbs 7 and 8 in
+  // lanes 0 and 1; lane 2 carries the V29 slot into the staging entry (word 9: padding in the value slots)
+  const uint32_t j = lane & 15, row = lane >> 4;
+  const uint32_t jb = j < 9 ? j : 0, jc = j >= 9 ? j - 9 : 7 + j;
+  const bool writer = j >= 9 || j < 3;
 #pragma unroll 1
   for (uint32_t t0 = 0; t0 < nsteps; t0 += WL_PF) {
+    wl_flush(lds, V29, B, p, lane);
+    uint4 dn[WL_PF];   // the next group's descriptors, all issued here: a group old when the group ends
+#pragma unroll
+    for (int k = 0; k < (int)WL_PF; k++) dn[k] = prog[(size_t)(t0 + WL_PF + k) * WL_W + lane];   // (padded by 2 WL_PF steps)
 #pragma unroll
     for (int k = 0; k < (int)WL_PF; k++) {
       const uint4 q = d[k];
-      d[k] = prog[(size_t)(t0 + WL_PF + k) * WL_W + lane];   // the program is padded by WL_PF empty steps
       const uint32_t kind = (__builtin_amdgcn_readfirstlane(q.x) >> 12) & 7;
-      const uint32_t dst = q.y & 0xFFFF, sa = q.y >> 16, sb = q.z & 0xFFFF, sc = q.z >> 16;
       if (__builtin_expect(kind == WK_ROW, 1)) {
         // one product per 16-lane row; the row's descriptor is replicated over its lanes
-        const uint32_t j = lane & 15, jj = j < 9 ? j : 0;
+        const uint32_t dst = q.y & 0xFFFF, sa = q.y >> 16, sb = q.z & 0xFFFF, sc = q.z >> 16;
         Fr29 va;
         wl_read(va, lds, sa);
-        uint32_t vb = lds[sb * 12 + jj], vc = lds[sc * 12 + jj];
+        uint32_t vb = lds[sb * 12 + jb], vc = lds[sc * 12 + (j >= 9 ? jc : 7)];
+        const uint32_t c8 = lds[sc * 12 + 8];
         vb = j < 9 ? vb : 0;
-        vc = j < 9 ? vc : 0;
-        const uint32_t r = wl_row_mul_add(va.v, vb, vc, j);
-        if (j < 9) {
-          lds[dst * 12 + j] = r;
-          if (q.x & WL_STORE) ((uint32_t*)(V29 + ((size_t)q.w * B + p) * 3))[j] = r;
+        vc = (j >= 9 || j == 0) ? vc : 0;
+        uint32_t r = wl_row_mul_add16(va.v, vb, vc, c8, j);
+        r = j == 2 ? ((q.x & WL_STORE) ? q.w : 0xFFFFFFFFu) : r;
+        if (writer) {
+          lds[dst * 12 + jc] = r;
+          lds[WL_STAGE + (k * WL_ROWS + row) * 12 + jc] = r;
         }
-        continue;
-      }
-      Fr29 v;
-      // FMA steps fall through (a uniform branch hop costs a lone wave 25 - 70 cycles)
-      if (__builtin_expect(kind == WK_FMA, 1)) {
-        Fr29 va, vb, vc;
-        wl_read(va, lds, sa);
-        wl_read(vb, lds, sb);
-        wl_read(vc, lds, sc);
-        v = Fr29::mul_add(va, vb, vc);
-      } else if (kind == WK_SQR) {   // 45 products instead of 81: two of the three products of Poseidon's x^5
-        Fr29 va, vc;
-        wl_read(va, lds, sa);
-        wl_read(vc, lds, sc);
-        v = Fr29::sqr_add(va, &vc);
-      } else if (kind == WK_ADD) {
-        Fr29 va, vb;
-        wl_read(va, lds, sa);
-        wl_read(vb, lds, sb);
-#pragma unroll
-        for (int j = 0; j < 9; j++) v.v[j] = va.v[j] + vb.v[j];
-        v.normalize();
       } else {
-        const WlOut o = wl_misc(q.x, q.y, q.z, lds, inputs, n_inputs, p);
-        v = o.v;
-        if (o.e && !e) e = o.e;
+        const uint32_t e1 = wl_other_step(kind, q, lds, inputs, n_inputs, V29, B, p);
+        if (e1 && !e) e = e1;
       }
-      wl_write(lds, dst, v);
-      // (storing unconditionally into a trash row to save this branch was measured: 5.0 -> 5.4 ms; three 16-byte
-      // stores per lane and step cost a lone wave more than the skipped branch)
-      if (q.x & WL_STORE) wl_store(V29, q.w, B, p, v);
     }
+#pragma unroll
+    for (int k = 0; k < (int)WL_PF; k++) d[k] = dn[k];
   }
+  wl_flush(lds, V29, B, p, lane);
   if (e) atomicOr(&lds[WL_SLOTS * 12], e);
   __builtin_amdgcn_wave_barrier();   // one wave: LDS operations complete in program order
   if (lane == 0) err[p] = lds[WL_SLOTS * 12];

@@ -14,7 +14,7 @@ namespace rlnamd {
 constexpr uint32_t WL_W = 64;                 // descriptors per step: one per lane (lane-form steps), 16 copies per row (row form)
 constexpr uint32_t WL_ROWS = 4;               // products per row-form step: one per DPP row of 16 lanes
 constexpr uint32_t WL_SLOTS = 3200;           // LDS value slots of 48 bytes: 150 KiB
-constexpr uint32_t WL_PF = 8;                 // descriptors prefetched per lane (steps ahead)
+constexpr uint32_t WL_PF = 16;                // descriptors prefetched per lane (steps ahead)
 constexpr double WL_BMAX = 7.5;
 enum : uint32_t { WK_FMA = 0, WK_ADD = 1, WK_MISC = 2, WK_SQR = 3, WK_ROW = 4 };   // 3 bits in the descriptor
 // WK_SQR: every lane computes a * a + c.  WK_ROW: a * b + c with ONE product per 16-lane DPP row, a limb per lane.
