@@ -354,9 +354,11 @@ __global__ void __launch_bounds__(64) k_witness29(const GNode29* __restrict__ no
   }
 }
 // stored node values of the Fr29 interpreter -> the 8 x 32 Montgomery values every later kernel reads (V[node][proof])
+// lg (small batches): lanes = stored values of ONE proof (blockIdx.y) instead of lanes = proofs
 __global__ void __launch_bounds__(64) k_v29_to_fr(const uint4* __restrict__ V29, const uint32_t* __restrict__ slot2node,
-                                                  uint32_t nslots, Fr* __restrict__ V, uint32_t B, uint32_t nb) {
-  const uint32_t p = blockIdx.x * 64 + threadIdx.x, sl = blockIdx.y;
+                                                  uint32_t nslots, Fr* __restrict__ V, uint32_t B, uint32_t nb,
+                                                  uint32_t lg = 0) {
+  const uint32_t p = lg ? blockIdx.y : blockIdx.x * 64 + threadIdx.x, sl = lg ? blockIdx.x * 64 + threadIdx.x : blockIdx.y;
   if (p >= nb || sl >= nslots) return;
   const uint4* g = V29 + ((size_t)sl * B + p) * 3;
   const uint4 x = g[0], y = g[1], z = g[2];
@@ -377,17 +379,49 @@ struct CsrView {
 };
 // LG (small batches): lanes = rows of ONE proof (blockIdx.y) instead of lanes = proofs -- with lanes = proofs a single
 // proof launches 8 192 waves with one useful lane each, which also crowd the walks that run beside them
+// Long rows (LG): the circuit's matrices hold 2 entries in most rows and 60 + 60 in ninety of them (Poseidon's mix
+// layers), and a lane that walks 120 entries alone -- two dependent loads and a product each -- is the whole kernel
+// (0.40 ms for one proof).  Rows with more than MV_LONG entries in A or B are therefore taken out of the lanes = rows
+// part and given a wave each (blocks >= nshort): a lane per entry, then a shuffle tree of field additions (exact, so the
+// order of the sum does not matter).
+constexpr uint32_t MV_LONG = 8;
+__device__ __forceinline__ Fr fr_shfl_down(const Fr& x, int off) {
+  Fr r;
+#pragma unroll
+  for (int k = 0; k < 8; k++) r.v[k] = (uint32_t)__shfl_down((int)x.v[k], off, 64);
+  return r;
+}
 template <bool LG>
 __global__ void __launch_bounds__(256) k_matvec(CsrView A, CsrView Bm, const Fr* __restrict__ V,
                                                 const uint32_t* __restrict__ sig2node, uint32_t nc, uint32_t ni,
-                                                uint32_t n, Fr* __restrict__ abc, uint32_t B, uint32_t nb) {
+                                                uint32_t n, Fr* __restrict__ abc, uint32_t B, uint32_t nb,
+                                                const uint32_t* __restrict__ long_rows = nullptr, uint32_t nshort = 0) {
   uint32_t p = LG ? blockIdx.y : blockIdx.x * 64 + threadIdx.x;
+  if (LG && blockIdx.x >= nshort) {   // a wave per long row
+    const uint32_t row = long_rows[blockIdx.x - nshort], lane = threadIdx.x;
+    Fr a = Fr::zero(), b = Fr::zero();
+    for (uint32_t k = A.ptr[row] + lane; k < A.ptr[row + 1]; k += 64) a = a + A.coef[k] * V[(size_t)A.col[k] * B + p];
+    for (uint32_t k = Bm.ptr[row] + lane; k < Bm.ptr[row + 1]; k += 64) b = b + Bm.coef[k] * V[(size_t)Bm.col[k] * B + p];
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+      a = a + fr_shfl_down(a, off);
+      b = b + fr_shfl_down(b, off);
+    }
+    if (lane == 0) {
+      const size_t o = (size_t)row * B + p;
+      abc[o] = a;
+      abc[(size_t)n * B + o] = b;
+      abc[2 * (size_t)n * B + o] = a * b;
+    }
+    return;
+  }
   uint32_t row = LG ? blockIdx.x * 64 + threadIdx.x
                     : __builtin_amdgcn_readfirstlane(blockIdx.y * blockDim.y + threadIdx.y);  // wave-uniform
   if (row >= n) return;
   if (p >= nb) return;
   Fr a = Fr::zero(), b = Fr::zero();
   if (row < nc) {
+    if (LG && long_rows && (A.ptr[row + 1] - A.ptr[row] > MV_LONG || Bm.ptr[row + 1] - Bm.ptr[row] > MV_LONG)) return;
     for (uint32_t k = A.ptr[row]; k < A.ptr[row + 1]; k++) a = a + A.coef[k] * V[(size_t)A.col[k] * B + p];
     for (uint32_t k = Bm.ptr[row]; k < Bm.ptr[row + 1]; k++) b = b + Bm.coef[k] * V[(size_t)Bm.col[k] * B + p];
   } else if (row < nc + ni) {
@@ -1060,8 +1094,10 @@ struct Slot {
   uint32_t* h_values = nullptr;
   uint32_t* h_err = nullptr;
   hipEvent_t evA = nullptr, evB = nullptr, evB2 = nullptr, evR = nullptr, evC = nullptr, evW = nullptr, evV = nullptr;
+  hipEvent_t evX = nullptr;     // the witness is in V (before the small-batch recodes that follow it on the same stream)
   hipEvent_t t[15] = {};  // timing marks
   bool used = false;
+  bool marked = false;          // the timing marks t[] of the slot's batch were recorded
   size_t n = 0;
 };
 
@@ -1087,6 +1123,8 @@ struct Prover::Impl {
   DevBuf<Fr> consts;
   DevBuf<uint32_t> sig2node;
   DevBuf<uint32_t> a_ptr, a_col, b_ptr, b_col;
+  DevBuf<uint32_t> mv_long;       // rows with more than MV_LONG entries in A or B
+  uint32_t n_mv_long = 0;
   DevBuf<Fr> a_coef, b_coef;
   DevBuf<Fr> tw_f, tw_i, coset;
   DevBuf<uint32_t> tw_f29, tw_i29, coset29;  // the same constants as Fr29 (9 words each) for Fr29::mul_mont
@@ -1541,6 +1579,15 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   };
   csr(zk_.a, D.a_ptr, D.a_col, D.a_coef);
   csr(zk_.b, D.b_ptr, D.b_col, D.b_coef);
+  {   // rows the small-batch mat-vec gives a wave each (k_matvec)
+    std::vector<uint32_t> lr;
+    for (uint32_t r = 0; r < D.nc; r++)
+      if (zk_.a[r].col.size() > MV_LONG || zk_.b[r].col.size() > MV_LONG) lr.push_back(r);
+    D.n_mv_long = (uint32_t)lr.size();
+    D.mv_long.alloc(std::max<size_t>(lr.size(), 1));
+    if (!lr.empty()) D.mv_long.upload(lr.data(), lr.size(), s);
+    RLN_HIP(hipStreamSynchronize(s));
+  }
 
   // ---- NTT tables: w = W^(2^(28-logn)), g = root of the doubled domain, coset[pos] = g^bitrev(pos) / n
   {
@@ -1835,6 +1882,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     RLN_HIP(hipEventCreateWithFlags(&S.evB2, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evR, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evW, hipEventDisableTiming));
+    RLN_HIP(hipEventCreateWithFlags(&S.evX, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evV, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evC, hipEventDisableTiming));
     for (auto& e : S.t) RLN_HIP(hipEventCreate(&e));
@@ -1857,7 +1905,7 @@ Prover::~Prover() {
     if (S.h_comp) (void)hipHostFree(S.h_comp);
     if (S.h_values) (void)hipHostFree(S.h_values);
     if (S.h_err) (void)hipHostFree(S.h_err);
-    for (hipEvent_t e : {S.evA, S.evB, S.evB2, S.evR, S.evC, S.evW, S.evV})
+    for (hipEvent_t e : {S.evA, S.evB, S.evB2, S.evR, S.evC, S.evW, S.evV, S.evX})
       if (e) (void)hipEventDestroy(e);
     for (auto& e : S.t)
       if (e) (void)hipEventDestroy(e);
@@ -2075,7 +2123,16 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     RLN_HIP(hipGetLastError());
     RLN_HIP(hipEventRecord(S.evU, sA));
   }
-  RLN_HIP(hipEventRecord(S.t[1], sA));
+  // Timing marks (stage_ms): a timed event record is a barrier packet and a timestamp write on its stream -- three of
+  // them sit between the interpreter and the mat-vec of a single proof (~0.1 ms of its 5 ms).  Small batches record
+  // them only when asked to (RLNAMD_MARKS_SMALL=1; tools/single_latency.py); their stage_ms reads 0 otherwise.
+  const bool marks = nb > D.lanechunk_max || env_int("RLNAMD_MARKS_SMALL", 0) != 0;
+  S.marked = marks;
+#define MARK(i, stream)                                   \
+  do {                                                    \
+    if (marks) RLN_HIP(hipEventRecord(S.t[i], stream));   \
+  } while (0)
+  MARK(1, sA);
   if (D.wit29) {
     static const bool prof = env_int("RLNAMD_WIT_PROF", 0) != 0;   // diagnostic: cycles per node class, on stderr
     if (prof) {
@@ -2093,8 +2150,12 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     } else
     hipLaunchKernelGGL(k_witness29<false>, dim3(pg), dim3(64), WIT29_LDS_BYTES, sA, D.nodes29.p, D.nprog29,
                        D.consts29.p, (uint32_t)graph_.constants.size(), in_p, D.NI, S.V29.p, S.err.p, B, nbp, nullptr);
-    hipLaunchKernelGGL(k_v29_to_fr, dim3(pg, D.nstore29), dim3(64, 1), 0, sA, S.V29.p, D.slot2node.p, D.nstore29, S.V.p, B,
-                       nbp);
+    if (nb <= D.lanechunk_max)
+      hipLaunchKernelGGL(k_v29_to_fr, dim3(div_up(D.nstore29, 64), nb), dim3(64, 1), 0, sA, S.V29.p, D.slot2node.p,
+                         D.nstore29, S.V.p, B, nb, 1u);
+    else
+      hipLaunchKernelGGL(k_v29_to_fr, dim3(pg, D.nstore29), dim3(64, 1), 0, sA, S.V29.p, D.slot2node.p, D.nstore29, S.V.p,
+                         B, nbp);
   } else {
     hipLaunchKernelGGL(k_witness, dim3(pg), dim3(64), WIT_RING * 8 * 64 * 4 + WIT_LDS_CONSTS * 32, sA, D.nodes.p, D.N, D.consts.p,
                        (uint32_t)graph_.constants.size(), in_p, D.NI, S.V.p,
@@ -2110,38 +2171,37 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // so the G2 walk -- the longer of the two, and independent of the quotient h -- starts beside mat-vec / NTT instead
   // of behind them; only h's digits wait for the NTTs.
   const bool early_g2 = early;
+  RLN_HIP(hipEventRecord(S.evX, sA));   // mat-vec / NTT (sA2) need the witness, not the recodes below
   if (early) {
-    hipLaunchKernelGGL(k_recode, dim3(div_up(D.NS + 3, 64), nb), dim3(64, 1), 0, sA, S.V.p, D.sig2node.p, D.NS, S.abc.p,
-                       D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nb, 1u, 1u);
-    if (fused)
-      hipLaunchKernelGGL(k_recode, dim3(div_up(2 * D.NS + 1, 64), nb), dim3(64, 1), 0, sA, S.V.p, D.sig2node.p, D.NS,
-                         S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nb, 3u, 1u);
-    RLN_HIP(hipEventRecord(S.evW, sA));
-    RLN_HIP(hipStreamWaitEvent(D.sB, S.evW, 0));
+    // on the walks' own stream: mat-vec and the NTTs (sA) start at once, beside the recodes instead of behind them
+    RLN_HIP(hipStreamWaitEvent(D.sB, S.evX, 0));
+    hipLaunchKernelGGL(k_recode, dim3(div_up(D.NS + 3, 64), nb), dim3(64, 1), 0, D.sB, S.V.p, D.sig2node.p, D.NS,
+                       S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nb, 1u, 1u);
+    RLN_HIP(hipEventRecord(S.evW, D.sB));   // the G2 walk reads the first recode's digits only
     RLN_HIP(hipStreamWaitEvent(D.sB2, S.evW, 0));
-    RLN_HIP(hipEventRecord(S.t[14], D.sB));
+    if (fused)
+      hipLaunchKernelGGL(k_recode, dim3(div_up(2 * D.NS + 1, 64), nb), dim3(64, 1), 0, D.sB, S.V.p, D.sig2node.p, D.NS,
+                         S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nb, 3u, 1u);
+    MARK(14, D.sB);
     if (P1.n_early)
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>), dim3(div_up(P1.n_early, 64), nb), dim3(64), 0,
                          D.sB, D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.n_early, S.digits.p, S.part1.p, D.ws, B, PB,
                          D.nh, nullptr, P1.early_ids.p);
     RLN_HIP(hipEventRecord(S.evE, D.sB));
   }
-  RLN_HIP(hipEventRecord(S.t[2], sA));
-  if (sA2 != sA) {
-    RLN_HIP(hipEventRecord(S.evW, sA));
-    RLN_HIP(hipStreamWaitEvent(sA2, S.evW, 0));
-  }
-  RLN_HIP(hipEventRecord(S.t[12], sA2));
+  MARK(2, sA);
+  if (sA2 != sA) RLN_HIP(hipStreamWaitEvent(sA2, S.evX, 0));
+  MARK(12, sA2);
   if (mode != PROVE_PARTIAL) {  // the quotient h depends on the whole witness: not part of a partial proof
     CsrView A{D.a_ptr.p, D.a_col.p, D.a_coef.p}, Bm{D.b_ptr.p, D.b_col.p, D.b_coef.p};
     if (nb <= D.lanechunk_max)
-      hipLaunchKernelGGL(k_matvec<true>, dim3(div_up(D.n, 64), nb), dim3(64, 1), 0, sA2, A, Bm, S.V.p, D.sig2node.p, D.nc,
-                         D.ni, D.n, S.abc.p, B, nb);
+      hipLaunchKernelGGL(k_matvec<true>, dim3(div_up(D.n, 64) + D.n_mv_long, nb), dim3(64, 1), 0, sA2, A, Bm, S.V.p,
+                         D.sig2node.p, D.nc, D.ni, D.n, S.abc.p, B, nb, D.mv_long.p, div_up(D.n, 64));
     else
       hipLaunchKernelGGL(k_matvec<false>, dim3(pg, D.n), dim3(64, 1), 0, sA2, A, Bm, S.V.p, D.sig2node.p, D.nc,
                          D.ni, D.n, S.abc.p, B, nbp);
   }
-  RLN_HIP(hipEventRecord(S.t[3], sA2));
+  MARK(3, sA2);
   if (mode != PROVE_PARTIAL) {
     // Twiddle products through Fr29::mul_mont need ~290 instead of ~375 instructions, but same-box A/B runs gave
     // 20.21 / 20.26 k against 20.30 / 20.24 k proofs/s: beside the table walks the passes are bound by HBM and by
@@ -2159,7 +2219,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     else
       hipLaunchKernelGGL(k_hquot, dim3(pg, D.n), dim3(64, 1), 0, sA2, S.abc.p, D.n, B, nbp, 0u);
   }
-  RLN_HIP(hipEventRecord(S.t[4], sA2));
+  MARK(4, sA2);
   // digit recoding either closes the front end (the MSM stream then carries nothing but the two table walks) or
   // opens the MSM stage (RLNAMD_RECODE_FRONT=0)
   hipStream_t sR = D.recode_front ? sA2 : D.sB;
@@ -2167,20 +2227,20 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     RLN_HIP(hipEventRecord(S.evA, sA2));
     RLN_HIP(hipStreamWaitEvent(D.sB, S.evA, 0));
   }
-  RLN_HIP(hipEventRecord(S.t[5], sR));
+  MARK(5, sR);
   if (early_g2)
     hipLaunchKernelGGL(k_recode, dim3(div_up(D.n, 64), nb), dim3(64, 1), 0, sR, S.V.p, D.sig2node.p, D.NS, S.abc.p, D.n,
                        rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nb, 2u, 1u);
   else
     hipLaunchKernelGGL(k_recode, dim3(pg, D.NS + D.n + 3), dim3(64, 1), 0, sR, S.V.p, D.sig2node.p, D.NS,
                        S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nbp, 0u, 0u);
-  RLN_HIP(hipEventRecord(S.t[6], sR));
+  MARK(6, sR);
   // ---------------- stage B
   if (D.recode_front && !early) {
     RLN_HIP(hipEventRecord(S.evA, sA2));
     RLN_HIP(hipStreamWaitEvent(D.sB, S.evA, 0));
   }
-  if (!early) RLN_HIP(hipEventRecord(S.t[14], D.sB));
+  if (!early) MARK(14, D.sB);
   // below half a wave of proofs the walks run with lanes = chunks (walk29.h); RLNAMD_LANECHUNK overrides the threshold
   const bool lanechunk = nb <= D.lanechunk_max;
   hipStream_t s2 = D.split_msm ? D.sB2 : D.sB;
@@ -2210,8 +2270,8 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
       hipLaunchKernelGGL(k_msm<Fq>, dim3(blocks), dim3(64), 0, D.sB, D.t1.p, P1.rsid.p, P1.rows.p, P1.chunks.p,
                          P1.nchunks, S.digits.p, S.part1.p, D.ws, B, pg, D.nh);
   }
-  RLN_HIP(hipEventRecord(S.t[7], D.sB));
-  RLN_HIP(hipEventRecord(S.t[11], s2));
+  MARK(7, D.sB);
+  MARK(11, s2);
   if (P2.nchunks) {
     uint32_t blocks = div_up(P2.nchunks, 8) * 8 * pg;
     if (D.use29_g2 && lanechunk)
@@ -2226,7 +2286,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
       hipLaunchKernelGGL(k_msm<Fq2>, dim3(blocks), dim3(64), 0, s2, D.t2.p, P2.rsid.p, P2.rows.p, P2.chunks.p,
                          P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, pg, D.nh);
   }
-  RLN_HIP(hipEventRecord(S.t[8], s2));
+  MARK(8, s2);
   RLN_HIP(hipEventRecord(S.evB, D.sB));
   if (D.split_msm) RLN_HIP(hipEventRecord(S.evB2, D.sB2));
   // ---------------- stage C
@@ -2237,16 +2297,15 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     RLN_HIP(hipStreamWaitEvent(sV, S.evC, 0));
   }
   if (streamed) RLN_HIP(hipStreamWaitEvent(sV, S.evU, 0));
-  RLN_HIP(hipEventRecord(S.t[0], sV));
+  MARK(0, sV);
   const bool values_w = early && D.have_values_kernel && D.ni == 6 && env_int("RLNAMD_VALUES_WITNESS", 1) != 0;
   if (values_w) {   // small batches: the circuit's own outputs (see k_values_from_witness)
-    RLN_HIP(hipStreamWaitEvent(sV, S.evW, 0));   // sA: witness stored, digits recoded
+    RLN_HIP(hipStreamWaitEvent(sV, S.evX, 0));   // sA: witness stored
     hipLaunchKernelGGL(k_values_from_witness, dim3(pg, 5), dim3(64), 0, sV, S.V.p, D.sig2node.p, B, nbp, S.values.p);
   } else if (D.have_values_kernel)
     hipLaunchKernelGGL(k_proof_values, dim3(pg), dim3(64), 0, sV, in_p, D.NI, D.slots, poseidon_view(2),
                        poseidon_view(3), poseidon_view(4), S.values.p, nbp);
-  RLN_HIP(hipEventRecord(S.t[13], sV));
-  RLN_HIP(hipEventRecord(S.evV, sV));
+  MARK(13, sV);
   // Small full proofs: A and B1 are sums over h-independent rows only, so their reduction, the two inversions and the two
   // variable-base products s A, r B1 (the longest kernel of the back end) run on the idle sA2 as soon as the early G1
   // walk is done -- beside the NTTs and the walk of the h rows, not behind them.  sums1 segments: h * 3 + {A, B1, C}.
@@ -2277,14 +2336,15 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     }
     RLN_HIP(hipGetLastError());
     RLN_HIP(hipEventRecord(S.evA, D.sA2));
-    // sC in the order its inputs arrive: the G2 sum and inversion (behind the G2 walk only), then the C segment (behind
-    // the h rows), then k_fin_out (behind s A, r B1 and the proof values)
-    RLN_HIP(hipStreamWaitEvent(D.sC, S.evB2, 0));
-    RLN_HIP(hipEventRecord(S.t[9], D.sC));
-    hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(256), 0, D.sC, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, all6);
-    hipLaunchKernelGGL(k_glv_fold, dim3(pg, 1), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({3}));
-    hipLaunchKernelGGL(k_fin_affine, dim3(pg, 1), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
+    // The G2 sum and inversion (0.65 ms for one proof, behind the G2 walk only) on the values' stream, beside the C
+    // segment (sC, behind the h rows) instead of in front of it; k_fin_out waits for both, for s A, r B1 and the values.
+    RLN_HIP(hipStreamWaitEvent(sV, S.evB2, 0));
+    hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(256), 0, sV, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, all6);
+    hipLaunchKernelGGL(k_glv_fold, dim3(pg, 1), dim3(64), 0, sV, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({3}));
+    hipLaunchKernelGGL(k_fin_affine, dim3(pg, 1), dim3(64), 0, sV, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
                        S.affB2.p, B, nbp, task_sel({2}));
+    RLN_HIP(hipEventRecord(S.evV, sV));
+    MARK(9, D.sC);
     RLN_HIP(hipStreamWaitEvent(D.sC, S.evB, 0));
     hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, 2), dim3(256), 0, D.sC, S.part1.p, P1.segchunks.p, S.sums1.p, B,
                        PB, task_sel({2, 5}));
@@ -2292,10 +2352,11 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     RLN_HIP(hipStreamWaitEvent(D.sC, S.evA, 0));
     RLN_HIP(hipStreamWaitEvent(D.sC, S.evV, 0));
   } else {
+    RLN_HIP(hipEventRecord(S.evV, sV));
     RLN_HIP(hipStreamWaitEvent(D.sC, S.evV, 0));
     RLN_HIP(hipStreamWaitEvent(D.sC, S.evB, 0));
     if (D.split_msm) RLN_HIP(hipStreamWaitEvent(D.sC, S.evB2, 0));
-    RLN_HIP(hipEventRecord(S.t[9], D.sC));
+    MARK(9, D.sC);
   }
   if (early_fin) {
   } else if (lanechunk) {   // small batch: lanes = partial sums (k_sum_tree)
@@ -2337,7 +2398,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     RLN_HIP(hipMemcpyAsync(S.h_values, S.values.p, n * 160, hipMemcpyDeviceToHost, D.sC));
   }
   RLN_HIP(hipMemcpyAsync(S.h_err, S.err.p, n * 4, hipMemcpyDeviceToHost, D.sC));
-  RLN_HIP(hipEventRecord(S.t[10], D.sC));
+  MARK(10, D.sC);
   RLN_HIP(hipEventRecord(S.evC, D.sC));
   S.used = true;
   S.n = n;
@@ -2358,7 +2419,7 @@ void Prover::sync_measure(bool last_only) {
     int cnt = 0;
     for (int k = 0; k < D.nslot; k++) {
       Slot& S = D.slot[k];
-      if (!S.used || S.mode != D.last->mode || S.n != D.last->n || (last_only && &S != D.last)) continue;
+      if (!S.used || !S.marked || S.mode != D.last->mode || S.n != D.last->n || (last_only && &S != D.last)) continue;
       for (int i = 0; i < PROVER_STAGES; i++) {
         float ms = 0;
         RLN_HIP(hipEventElapsedTime(&ms, S.t[pairs[i][0]], S.t[pairs[i][1]]));
