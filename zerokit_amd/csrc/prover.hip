@@ -524,6 +524,81 @@ __global__ void __launch_bounds__(256, RLN_NTT_WAVES) k_ntt_pass(Fr* __restrict_
   }
 }
 
+// Small batches: nine levels in ONE kernel.  The 512 points {base + m stride} that nine consecutive levels close over
+// are one wave's work: three radix-8 sub-passes, eight points per lane, exchanged through 16 KB of LDS instead of
+// through HBM and two kernel boundaries (a lone proof's pass is all latency: 50 - 65 us for 6 us of arithmetic).  In the
+// set's local coordinates m = 0..511 the sub-passes are a 512-point transform's (local strides 64, 8, 1 for DIF and
+// 1, 8, 64 for DIT); their twiddles are the big transform's, indexed exactly as k_ntt_pass does for the pass
+// (s0 + 3 q, K = 3): global stride = stride * ls, lo = lo_set + lo_local * stride.  Same butterflies, same products, same
+// order per point: bit-identical to the passes it replaces.  Grid (proof, set, vector), one wave per workgroup.
+template <bool DIF>
+__global__ void __launch_bounds__(64) k_ntt_fused9(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0,
+                                                   const Fr* __restrict__ scale, uint32_t B, uint32_t nb) {
+  __shared__ Fr buf[512];
+  const uint32_t p = blockIdx.x, set = blockIdx.y, lane = threadIdx.x;
+  const uint32_t n = 1u << logn;
+  if (p >= nb) return;
+  Fr* x = data + (size_t)blockIdx.z * n * B + p;
+  uint32_t stride, base, lo;
+  if (DIF) {
+    stride = n >> (s0 + 9);
+    lo = set % stride;
+    base = (set / stride) * (n >> s0) + lo;
+  } else {
+    stride = 1u << s0;
+    lo = set % stride;
+    base = (set / stride) * (stride << 9) + lo;
+  }
+#pragma unroll 1
+  for (int q = 0; q < 3; q++) {
+    const uint32_t ls = DIF ? (64u >> (3 * q)) : (1u << (3 * q));
+    const uint32_t lo_l = lane % ls, base_l = (lane / ls) * (ls * 8) + lo_l;
+    const int s0q = s0 + 3 * q;
+    const uint32_t stride_q = stride * ls, lo_q = lo + lo_l * stride;
+    Fr e[8];
+    if (q == 0) {
+#pragma unroll
+      for (int m = 0; m < 8; m++) e[m] = x[(size_t)(base + (base_l + m * ls) * stride) * B];
+    } else {
+#pragma unroll
+      for (int m = 0; m < 8; m++) e[m] = buf[base_l + m * ls];
+    }
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const int half = DIF ? (8 >> (t + 1)) : (1 << t);
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        if (m & half) continue;
+        const uint32_t j = (uint32_t)(m & (half - 1)) * stride_q + lo_q;
+        const uint32_t ti = DIF ? (j << (s0q + t)) : (j << (logn - 1 - (s0q + t)));
+        if (DIF) {
+          const Fr u = e[m], v = e[m + half];
+          e[m] = u + v;
+          e[m + half] = (u - v) * tw[ti];
+        } else {
+          const Fr u = e[m], v = e[m + half] * tw[ti];
+          e[m] = u + v;
+          e[m + half] = u - v;
+        }
+      }
+    }
+    if (q == 2) {
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const uint32_t pos = base + (base_l + m * ls) * stride;
+        Fr o = e[m];
+        if (scale) o = o * scale[pos];
+        x[(size_t)pos * B] = o;
+      }
+    } else {
+      __syncthreads();   // (one wave: orders the reads above against the writes below)
+#pragma unroll
+      for (int m = 0; m < 8; m++) buf[base_l + m * ls] = e[m];
+      __syncthreads();
+    }
+  }
+}
+
 // h = a o b - c  (qap.rs:84-95), written over the `a` vector
 __global__ void __launch_bounds__(256) k_hquot(Fr* __restrict__ abc, uint32_t n, uint32_t B, uint32_t nb, uint32_t lg) {
   uint32_t p = lg ? blockIdx.y : blockIdx.x * 64 + threadIdx.x;   // lg: lanes = coefficients of one proof
@@ -1942,6 +2017,14 @@ template <bool DIF, bool M29>
 static void launch_ntt(Fr* data, const uint32_t* tw, int logn, const uint32_t* final_scale, uint32_t B, uint32_t nb,
                        hipStream_t s, bool lanes_are_groups = false) {
   int s0 = 0;
+  static const bool fuse9 = env_int("RLNAMD_NTT_FUSE9", 1) != 0;
+  if (lanes_are_groups && !M29 && fuse9 && logn >= 9) {   // nine levels in one kernel (k_ntt_fused9)
+    const Fr* sc = (9 == logn) ? reinterpret_cast<const Fr*>(final_scale) : nullptr;
+    hipLaunchKernelGGL((k_ntt_fused9<DIF>), dim3(nb, (1u << logn) >> 9, 3), dim3(64), 0, s, data,
+                       reinterpret_cast<const Fr*>(tw), logn, 0, sc, B, nb);
+    RLN_HIP(hipGetLastError());
+    s0 = 9;
+  }
   while (lanes_are_groups && s0 < logn) {   // small batch: blockIdx.x = proof, lanes = groups (radix-8 passes + a radix-2 tail)
     const int rem = logn - s0, K = rem >= 3 ? 3 : 1;
     const uint32_t groups = (1u << logn) >> K;
