@@ -2257,11 +2257,13 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   RLN_HIP(hipEventRecord(S.evX, sA));   // mat-vec / NTT (sA2) need the witness, not the recodes below
   if (early) {
     // on the walks' own stream: mat-vec and the NTTs (sA) start at once, beside the recodes instead of behind them
-    RLN_HIP(hipStreamWaitEvent(D.sB, S.evX, 0));
-    hipLaunchKernelGGL(k_recode, dim3(div_up(D.NS + 3, 64), nb), dim3(64, 1), 0, D.sB, S.V.p, D.sig2node.p, D.NS,
+    // The G2 chain (recode, walk, sum, inversion: 1.3 ms for one proof) is the longest thing behind the interpreter and
+    // every cross-stream hop costs it 50 - 100 us, so it runs on ONE stream (sB2); the G1 walk's stream takes the hop.
+    RLN_HIP(hipStreamWaitEvent(D.sB2, S.evX, 0));
+    hipLaunchKernelGGL(k_recode, dim3(div_up(D.NS + 3, 64), nb), dim3(64, 1), 0, D.sB2, S.V.p, D.sig2node.p, D.NS,
                        S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nb, 1u, 1u);
-    RLN_HIP(hipEventRecord(S.evW, D.sB));   // the G2 walk reads the first recode's digits only
-    RLN_HIP(hipStreamWaitEvent(D.sB2, S.evW, 0));
+    RLN_HIP(hipEventRecord(S.evW, D.sB2));
+    RLN_HIP(hipStreamWaitEvent(D.sB, S.evW, 0));
     if (fused)
       hipLaunchKernelGGL(k_recode, dim3(div_up(2 * D.NS + 1, 64), nb), dim3(64, 1), 0, D.sB, S.V.p, D.sig2node.p, D.NS,
                          S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nb, 3u, 1u);
@@ -2419,19 +2421,21 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     }
     RLN_HIP(hipGetLastError());
     RLN_HIP(hipEventRecord(S.evA, D.sA2));
-    // The G2 sum and inversion (0.65 ms for one proof, behind the G2 walk only) on the values' stream, beside the C
-    // segment (sC, behind the h rows) instead of in front of it; k_fin_out waits for both, for s A, r B1 and the values.
-    RLN_HIP(hipStreamWaitEvent(sV, S.evB2, 0));
-    hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(256), 0, sV, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, all6);
-    hipLaunchKernelGGL(k_glv_fold, dim3(pg, 1), dim3(64), 0, sV, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({3}));
-    hipLaunchKernelGGL(k_fin_affine, dim3(pg, 1), dim3(64), 0, sV, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
+    // The G2 sum and inversion (0.65 ms for one proof, behind the G2 walk only) beside the C segment (sC, behind the h
+    // rows) instead of in front of it; k_fin_out waits for both, for s A, r B1 and the values.
+    // (s2: the G2 walk's stream -- its back end follows it without a hop)
+    hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(256), 0, s2, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, all6);
+    hipLaunchKernelGGL(k_glv_fold, dim3(pg, 1), dim3(64), 0, s2, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({3}));
+    hipLaunchKernelGGL(k_fin_affine, dim3(pg, 1), dim3(64), 0, s2, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
                        S.affB2.p, B, nbp, task_sel({2}));
+    RLN_HIP(hipEventRecord(S.evB2, s2));
     RLN_HIP(hipEventRecord(S.evV, sV));
     MARK(9, D.sC);
     RLN_HIP(hipStreamWaitEvent(D.sC, S.evB, 0));
     hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, 2), dim3(256), 0, D.sC, S.part1.p, P1.segchunks.p, S.sums1.p, B,
                        PB, task_sel({2, 5}));
     hipLaunchKernelGGL(k_glv_fold, dim3(pg, 1), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({2}));
+    RLN_HIP(hipStreamWaitEvent(D.sC, S.evB2, 0));
     RLN_HIP(hipStreamWaitEvent(D.sC, S.evA, 0));
     RLN_HIP(hipStreamWaitEvent(D.sC, S.evV, 0));
   } else {
