@@ -2398,6 +2398,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   const TaskSel all6 = task_sel({0, 1, 2, 3, 4, 5}), all4 = task_sel({0, 1, 2, 3}), all3 = task_sel({0, 1, 2});
   // below a wave of proofs s A / r B1 are a lone lane's chain: NAF ladder in the 9 x 29 form (fin29.hip)
   const bool fin29 = nb <= D.lanechunk_max && D.use29 && env_int("RLNAMD_FIN29", 1) != 0;
+  hipStream_t sF = D.sC;   // the stream of k_fin_out and of the copies to the host
   if (early_fin) {
     RLN_HIP(hipStreamWaitEvent(D.sA2, S.evE, 0));   // sB: the early G1 walk
     if (fused) {
@@ -2430,14 +2431,18 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
                        S.affB2.p, B, nbp, task_sel({2}));
     RLN_HIP(hipEventRecord(S.evB2, s2));
     RLN_HIP(hipEventRecord(S.evV, sV));
-    MARK(9, D.sC);
-    RLN_HIP(hipStreamWaitEvent(D.sC, S.evB, 0));
-    hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, 2), dim3(256), 0, D.sC, S.part1.p, P1.segchunks.p, S.sums1.p, B,
+    // The C segment, k_fin_out and the copies home on the front-end stream itself, right behind the walk of the h rows:
+    // the chain interpreter -> NTT -> h -> walk -> sum -> output crosses no stream (each hop is 50 - 100 us).
+    sF = sA;
+    if (S.used) RLN_HIP(hipStreamWaitEvent(sF, S.evC, 0));
+    MARK(9, sF);
+    RLN_HIP(hipStreamWaitEvent(sF, S.evE, 0));   // the early G1 walk: the C segment's h-independent rows
+    hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, 2), dim3(256), 0, sF, S.part1.p, P1.segchunks.p, S.sums1.p, B,
                        PB, task_sel({2, 5}));
-    hipLaunchKernelGGL(k_glv_fold, dim3(pg, 1), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({2}));
-    RLN_HIP(hipStreamWaitEvent(D.sC, S.evB2, 0));
-    RLN_HIP(hipStreamWaitEvent(D.sC, S.evA, 0));
-    RLN_HIP(hipStreamWaitEvent(D.sC, S.evV, 0));
+    hipLaunchKernelGGL(k_glv_fold, dim3(pg, 1), dim3(64), 0, sF, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({2}));
+    RLN_HIP(hipStreamWaitEvent(sF, S.evB2, 0));
+    RLN_HIP(hipStreamWaitEvent(sF, S.evA, 0));
+    RLN_HIP(hipStreamWaitEvent(sF, S.evV, 0));
   } else {
     RLN_HIP(hipEventRecord(S.evV, sV));
     RLN_HIP(hipStreamWaitEvent(D.sC, S.evV, 0));
@@ -2478,15 +2483,15 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
         hipLaunchKernelGGL(k_fin_smul, dim3(pg, 2), dim3(64), 0, D.sC, S.affA.p, S.affB1.p, rs_p, S.tbl.p, S.prod.p, B,
                            nbp);
     }
-    hipLaunchKernelGGL(k_fin_out, dim3(pg), dim3(64), 0, D.sC, S.sums1.p, S.prod.p, S.affA.p, S.affB2.p, S.coords.p,
+    hipLaunchKernelGGL(k_fin_out, dim3(pg), dim3(64), 0, sF, S.sums1.p, S.prod.p, S.affA.p, S.affB2.p, S.coords.p,
                        S.comp.p, B, nbp);
     RLN_HIP(hipGetLastError());
-    RLN_HIP(hipMemcpyAsync(S.h_comp, S.comp.p, n * 128, hipMemcpyDeviceToHost, D.sC));
-    RLN_HIP(hipMemcpyAsync(S.h_values, S.values.p, n * 160, hipMemcpyDeviceToHost, D.sC));
+    RLN_HIP(hipMemcpyAsync(S.h_comp, S.comp.p, n * 128, hipMemcpyDeviceToHost, sF));
+    RLN_HIP(hipMemcpyAsync(S.h_values, S.values.p, n * 160, hipMemcpyDeviceToHost, sF));
   }
-  RLN_HIP(hipMemcpyAsync(S.h_err, S.err.p, n * 4, hipMemcpyDeviceToHost, D.sC));
-  MARK(10, D.sC);
-  RLN_HIP(hipEventRecord(S.evC, D.sC));
+  RLN_HIP(hipMemcpyAsync(S.h_err, S.err.p, n * 4, hipMemcpyDeviceToHost, sF));
+  MARK(10, sF);
+  RLN_HIP(hipEventRecord(S.evC, sF));
   S.used = true;
   S.n = n;
   D.last = &S;
