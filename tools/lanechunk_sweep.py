@@ -14,7 +14,7 @@ from zerokit_amd.batch import BatchProver  # noqa: E402
 
 p = BatchProver(max_batch=512)
 out = {"RLNAMD_LANECHUNK": os.environ.get("RLNAMD_LANECHUNK", "default")}
-for n in (1, 8, 32, 56, 64, 96, 128, 192, 256, 384, 512):
+for n in (1, 4, 8, 16, 32, 64, 128, 192, 256, 384, 512):
     inp, rsb = workload.config2_packed(p.slots, p.inputs_size, 0, n)
     t, _ = p.submit(inp, rsb)
     p.collect_raw(t, n)

@@ -12,16 +12,17 @@ from zerokit_amd import workload  # noqa: E402
 from zerokit_amd.batch import BatchProver  # noqa: E402
 
 p = BatchProver(max_batch=64)
-inp, rsb = workload.config2_packed(p.slots, p.inputs_size, 0, 1)
-_, rs = workload.config2_range(0, 1)
+N = int(os.environ.get("N", "1"))   # proofs per batch
+inp, rsb = workload.config2_packed(p.slots, p.inputs_size, 0, N)
+_, rs = workload.config2_range(0, N)
 out = {"upload": [], "run": [], "download": [], "submit_collect": [], "stage_ms": None}
 for _ in range(8):
     t0 = time.perf_counter()
     p.upload(inp, rs)
     t1 = time.perf_counter()
-    p.run(1)
+    p.run(N)
     t2 = time.perf_counter()
-    p.download(1)
+    p.download(N)
     t3 = time.perf_counter()
     out["upload"].append(round((t1 - t0) * 1e3, 3))
     out["run"].append(round((t2 - t1) * 1e3, 3))

@@ -1186,6 +1186,7 @@ struct Prover::Impl {
   DevBuf<unsigned long long> walk_clk;  // clock tap of the two walks: G1 cycles, G1 ticks, G2 cycles, G2 ticks
   bool wit29 = true;             // RLNAMD_WIT29: graph interpreter in the 9 x 29-bit form (k_witness29)
   uint32_t lanechunk_max = 128;  // RLNAMD_LANECHUNK: largest batch that takes the small-batch shapes
+  uint32_t witlanes_max = 256;   // RLNAMD_WITLANES_MAX: largest batch interpreted with lanes = nodes (a wave and 157 KB of LDS per proof)
   DevBuf<GNode29> nodes29;
   DevBuf<unsigned long long> wit_prof;
   DevBuf<uint32_t> consts29, slot2node;
@@ -1473,6 +1474,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   // (64: 12.4 vs 23.2 ms, 128: 17.8 vs 27.4, 256: 28.4 vs 36.8), a STREAM of such batches up to ~150 (chunks of 64: 9.4 k
   // vs 8.1 k proofs/s, 128: equal, 256: 10.1 k vs 12.1 k) -- 128 wins or ties on both.
   D.lanechunk_max = (uint32_t)std::max(0, env_int("RLNAMD_LANECHUNK", 128));
+  D.witlanes_max = (uint32_t)std::max(0, env_int("RLNAMD_WITLANES_MAX", 256));
   // partial sums of a small batch: [chunk][stride]
   D.small_stride = std::max<uint32_t>(64, (std::min<uint32_t>(D.lanechunk_max, (uint32_t)B_) + 63) / 64 * 64);
   std::vector<GNode29> wit29_prog;
@@ -2228,7 +2230,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
       RLN_HIP(hipMemcpy(h, pb.p, sizeof(h), hipMemcpyDeviceToHost));
       fprintf(stderr, "wit29 prof: mul %llu cyc / %llu, add %llu / %llu, const+input %llu / %llu, other %llu / %llu; total %llu cyc, %.3f ms, clock %.0f MHz\n",
               h[0], h[4], h[1], h[5], h[2], h[6], h[3], h[7], h[8], h[9] / 1e5, h[9] ? 100.0 * h[8] / h[9] : 0.0);
-    } else if (D.witlanes.ok && nb <= D.lanechunk_max) {
+    } else if (D.witlanes.ok && nb <= std::max(D.lanechunk_max, D.witlanes_max)) {
       D.witlanes.launch(sA, D.consts29.p, in_p, D.NI, S.V29.p, S.err.p, B, nb);
     } else
     hipLaunchKernelGGL(k_witness29<false>, dim3(pg), dim3(64), WIT29_LDS_BYTES, sA, D.nodes29.p, D.nprog29,
@@ -2383,7 +2385,9 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   }
   if (streamed) RLN_HIP(hipStreamWaitEvent(sV, S.evU, 0));
   MARK(0, sV);
-  const bool values_w = early && D.have_values_kernel && D.ni == 6 && env_int("RLNAMD_VALUES_WITNESS", 1) != 0;
+  // (whenever the batch is small enough for the lanes = nodes interpreter: the Poseidon chain alone is 5.3 ms)
+  const bool values_w = (early || (D.wit29 && D.witlanes.ok && nb <= D.witlanes_max)) && D.have_values_kernel && D.ni == 6 &&
+                        env_int("RLNAMD_VALUES_WITNESS", 1) != 0;
   if (values_w) {   // small batches: the circuit's own outputs (see k_values_from_witness)
     RLN_HIP(hipStreamWaitEvent(sV, S.evX, 0));   // sA: witness stored
     hipLaunchKernelGGL(k_values_from_witness, dim3(pg, 5), dim3(64), 0, sV, S.V.p, D.sig2node.p, B, nbp, S.values.p);
