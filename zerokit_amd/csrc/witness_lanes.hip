@@ -138,26 +138,28 @@ __device__ __forceinline__ uint32_t wl_carry3(uint64_t x) {
 // a: the first factor's nine limbs (row-uniform); b: this lane's limb of the second factor (0 in lanes 9..15);
 // cj: the addend's limb j - 9 in lanes 9..15 and limb 7 in lane 0; c8: the addend's limb 8 (read by lane 0).
 // Returns limb j - 9 of a b / 2^261 + c in lanes 9..15, limb 7 in lane 0 and limb 8 in lane 1.
+// PI, PP: -r^-1 mod 2^261 and r as 29-bit limbs, held in VECTOR registers by the caller (as literals they cost a scalar
+// move each per use: 18 of the step's ~31 scalar instructions, and the lone wave pays for every instruction it issues).
 __device__ __forceinline__ uint32_t wl_row_mul_add16(const uint32_t (&a)[9], uint32_t b, uint32_t cj, uint32_t c8,
-                                                     uint32_t j) {
+                                                     uint32_t j, const uint32_t (&PI)[9], const uint32_t (&PP)[9]) {
   constexpr uint32_t M = (1u << 29) - 1;
   uint64_t t, t16;
   WL_MACS16(t, t16, a, b)
   const uint32_t n = wl_carry3(t);                        // lanes 0..8: T mod 2^261 (lanes above: not read)
-  uint64_t u = (uint64_t)WL_PINV[0] * n;
-  uint64_t u1 = (uint64_t)WL_PINV[1] * dppz<WL_SHR(1)>(n);
-  u += (uint64_t)WL_PINV[2] * dppz<WL_SHR(2)>(n);
-  u1 += (uint64_t)WL_PINV[3] * dppz<WL_SHR(3)>(n);
-  u += (uint64_t)WL_PINV[4] * dppz<WL_SHR(4)>(n);
-  u1 += (uint64_t)WL_PINV[5] * dppz<WL_SHR(5)>(n);
-  u += (uint64_t)WL_PINV[6] * dppz<WL_SHR(6)>(n);
-  u1 += (uint64_t)WL_PINV[7] * dppz<WL_SHR(7)>(n);
-  u += (uint64_t)WL_PINV[8] * dppz<WL_SHR(8)>(n);
+  uint64_t u = (uint64_t)PI[0] * n;
+  uint64_t u1 = (uint64_t)PI[1] * dppz<WL_SHR(1)>(n);
+  u += (uint64_t)PI[2] * dppz<WL_SHR(2)>(n);
+  u1 += (uint64_t)PI[3] * dppz<WL_SHR(3)>(n);
+  u += (uint64_t)PI[4] * dppz<WL_SHR(4)>(n);
+  u1 += (uint64_t)PI[5] * dppz<WL_SHR(5)>(n);
+  u += (uint64_t)PI[6] * dppz<WL_SHR(6)>(n);
+  u1 += (uint64_t)PI[7] * dppz<WL_SHR(7)>(n);
+  u += (uint64_t)PI[8] * dppz<WL_SHR(8)>(n);
   u += u1;
   uint32_t m = wl_carry3(u);
   m = j < 9 ? m : 0;
   uint64_t U, U16;
-  WL_MACS16(U, U16, Fr29C::P, m)
+  WL_MACS16(U, U16, PP, m)
   const uint64_t s = t + U;                               // column j
   const uint64_t s16 = t16 + U16;                         // lane 0: column 16
   // carry of the low half: exact in lane 8, handed to column 9 next door
@@ -270,6 +272,13 @@ __global__ void __launch_bounds__(64) k_witness_lanes(const uint4* __restrict__ 
   const uint32_t j = lane & 15, row = lane >> 4;
   const uint32_t jb = j < 9 ? j : 0, jc = j >= 9 ? j - 9 : 7 + j;
   const bool writer = j >= 9 || j < 3;
+  uint32_t PI[9], PP[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    PI[k] = WL_PINV[k];
+    PP[k] = Fr29C::P[k];
+    asm volatile("" : "+v"(PI[k]), "+v"(PP[k]));
+  }
 #pragma unroll 1
   for (uint32_t t0 = 0; t0 < nsteps; t0 += WL_PF) {
     wl_flush(lds, V29, B, p, lane);
@@ -287,9 +296,10 @@ __global__ void __launch_bounds__(64) k_witness_lanes(const uint4* __restrict__ 
         wl_read(va, lds, sa);
         uint32_t vb = lds[sb * 12 + jb], vc = lds[sc * 12 + (j >= 9 ? jc : 7)];
         const uint32_t c8 = lds[sc * 12 + 8];
+        __builtin_amdgcn_sched_barrier(0);   // all six reads in flight before the first wait
         vb = j < 9 ? vb : 0;
         vc = (j >= 9 || j == 0) ? vc : 0;
-        uint32_t r = wl_row_mul_add16(va.v, vb, vc, c8, j);
+        uint32_t r = wl_row_mul_add16(va.v, vb, vc, c8, j, PI, PP);
         r = j == 2 ? ((q.x & WL_STORE) ? q.w : 0xFFFFFFFFu) : r;
         if (writer) {
           lds[dst * 12 + jc] = r;
