@@ -161,7 +161,8 @@ __device__ __forceinline__ uint32_t wl_row_mul_add16(const uint32_t (&a)[9], uin
   uint64_t U, U16;
   WL_MACS16(U, U16, PP, m)
   const uint64_t s = t + U;                               // column j
-  const uint64_t s16 = t16 + U16;                         // lane 0: column 16
+  uint64_t s16 = t16 + U16;                               // lane 0: column 16
+  asm volatile("" : "+v"(s16));   // computed by every lane: otherwise its two products sink into a lane-0-only branch
   // carry of the low half: exact in lane 8, handed to column 9 next door
   const uint64_t t1 = s >> 29;
   const uint32_t t2 = (uint32_t)(s >> 58);
@@ -272,6 +273,7 @@ __global__ void __launch_bounds__(64) k_witness_lanes(const uint4* __restrict__ 
   const uint32_t j = lane & 15, row = lane >> 4;
   const uint32_t jb = j < 9 ? j : 0, jc = j >= 9 ? j - 9 : 7 + j;
   const bool writer = j >= 9 || j < 3;
+  const uint32_t wj = writer ? jc : 10 + (j & 1);   // idle lanes: padding words 10, 11
   uint32_t PI[9], PP[9];
 #pragma unroll
   for (int k = 0; k < 9; k++) {
@@ -301,10 +303,10 @@ __global__ void __launch_bounds__(64) k_witness_lanes(const uint4* __restrict__ 
         vc = (j >= 9 || j == 0) ? vc : 0;
         uint32_t r = wl_row_mul_add16(va.v, vb, vc, c8, j, PI, PP);
         r = j == 2 ? ((q.x & WL_STORE) ? q.w : 0xFFFFFFFFu) : r;
-        if (writer) {
-          lds[dst * 12 + jc] = r;
-          lds[WL_STAGE + (k * WL_ROWS + row) * 12 + jc] = r;
-        }
+        // every lane writes (no exec-mask branch): the idle lanes 3..8 into the padding words of the dummy slot / of
+        // their staging entry
+        lds[(writer ? dst : WL_SLOTS - 1) * 12 + wj] = r;
+        lds[WL_STAGE + (k * WL_ROWS + row) * 12 + wj] = r;
       } else {
         const uint32_t e1 = wl_other_step(kind, q, lds, inputs, n_inputs, V29, B, p);
         if (e1 && !e) e = e1;
