@@ -287,29 +287,38 @@ __global__ void __launch_bounds__(64) k_witness_lanes(const uint4* __restrict__ 
     uint4 dn[WL_PF];   // the next group's descriptors, all issued here: a group old when the group ends
 #pragma unroll
     for (int k = 0; k < (int)WL_PF; k++) dn[k] = prog[(size_t)(t0 + WL_PF + k) * WL_W + lane];   // (padded by 2 WL_PF steps)
+    // one product per 16-lane row; the row's descriptor is replicated over its lanes
+    auto row_step = [&](const uint4& q, int k) {
+      const uint32_t dst = q.y & 0xFFFF, sa = q.y >> 16, sb = q.z & 0xFFFF, sc = q.z >> 16;
+      Fr29 va;
+      wl_read(va, lds, sa);
+      uint32_t vb = lds[sb * 12 + jb], vc = lds[sc * 12 + (j >= 9 ? jc : 7)];
+      const uint32_t c8 = lds[sc * 12 + 8];
+      __builtin_amdgcn_sched_barrier(0);   // all six reads in flight before the first wait
+      vb = j < 9 ? vb : 0;
+      vc = (j >= 9 || j == 0) ? vc : 0;
+      uint32_t r = wl_row_mul_add16(va.v, vb, vc, c8, j, PI, PP);
+      r = j == 2 ? ((q.x & WL_STORE) ? q.w : 0xFFFFFFFFu) : r;
+      // every lane writes (no exec-mask branch): the idle lanes 3..8 into the padding words of the dummy slot / of
+      // their staging entry
+      lds[(writer ? dst : WL_SLOTS - 1) * 12 + wj] = r;
+      lds[WL_STAGE + (k * WL_ROWS + row) * 12 + wj] = r;
+    };
+    // nine groups in ten hold nothing but row steps (the host marks them): no kind test, no branch between their steps
+    if (__builtin_expect((__builtin_amdgcn_readfirstlane(d[0].x) & WL_GROUP_ROWS) != 0, 1)) {
 #pragma unroll
-    for (int k = 0; k < (int)WL_PF; k++) {
-      const uint4 q = d[k];
-      const uint32_t kind = (__builtin_amdgcn_readfirstlane(q.x) >> 12) & 7;
-      if (__builtin_expect(kind == WK_ROW, 1)) {
-        // one product per 16-lane row; the row's descriptor is replicated over its lanes
-        const uint32_t dst = q.y & 0xFFFF, sa = q.y >> 16, sb = q.z & 0xFFFF, sc = q.z >> 16;
-        Fr29 va;
-        wl_read(va, lds, sa);
-        uint32_t vb = lds[sb * 12 + jb], vc = lds[sc * 12 + (j >= 9 ? jc : 7)];
-        const uint32_t c8 = lds[sc * 12 + 8];
-        __builtin_amdgcn_sched_barrier(0);   // all six reads in flight before the first wait
-        vb = j < 9 ? vb : 0;
-        vc = (j >= 9 || j == 0) ? vc : 0;
-        uint32_t r = wl_row_mul_add16(va.v, vb, vc, c8, j, PI, PP);
-        r = j == 2 ? ((q.x & WL_STORE) ? q.w : 0xFFFFFFFFu) : r;
-        // every lane writes (no exec-mask branch): the idle lanes 3..8 into the padding words of the dummy slot / of
-        // their staging entry
-        lds[(writer ? dst : WL_SLOTS - 1) * 12 + wj] = r;
-        lds[WL_STAGE + (k * WL_ROWS + row) * 12 + wj] = r;
-      } else {
-        const uint32_t e1 = wl_other_step(kind, q, lds, inputs, n_inputs, V29, B, p);
-        if (e1 && !e) e = e1;
+      for (int k = 0; k < (int)WL_PF; k++) row_step(d[k], k);
+    } else {
+#pragma unroll
+      for (int k = 0; k < (int)WL_PF; k++) {
+        const uint4 q = d[k];
+        const uint32_t kind = (__builtin_amdgcn_readfirstlane(q.x) >> 12) & 7;
+        if (kind == WK_ROW) {
+          row_step(q, k);
+        } else {
+          const uint32_t e1 = wl_other_step(kind, q, lds, inputs, n_inputs, V29, B, p);
+          if (e1 && !e) e = e1;
+        }
       }
     }
 #pragma unroll

@@ -386,7 +386,9 @@ static WlProgram wl_schedule_graph(const Graph& graph, const std::vector<uint32_
   // idle lanes and the padding steps (the kernel runs whole groups of WL_PF steps and prefetches one group further)
   // compute ZERO * ZERO + ZERO into the dummy slot
   std::vector<WlDesc>& img = R.img;
-  img.assign((steps.size() + 2 * WL_PF) * (size_t)WL_W, WlDesc{0, DUMMY | (Z << 16), Z | (Z << 16), trash_slot});
+  // (row form: the padding steps are row steps too, so that the last group can be a group of row steps)
+  img.assign((steps.size() + 2 * WL_PF) * (size_t)WL_W,
+             WlDesc{rows ? (WK_ROW << 12) : 0u, DUMMY | (Z << 16), Z | (Z << 16), trash_slot});
   auto slot_of_val = [&](uint32_t v) -> uint32_t {
     if (v == NONE) return Z;
     if (v >= FIXB) return v - FIXB;
@@ -433,6 +435,13 @@ static WlProgram wl_schedule_graph(const Graph& graph, const std::vector<uint32_
     }
   }
   nsteps = (uint32_t)steps.size();
+  // groups of WL_PF steps that hold row steps only: marked on their first step (every lane's copy)
+  for (size_t t0 = 0; t0 < steps.size(); t0 += WL_PF) {
+    bool all = true;
+    for (size_t t = t0; t < t0 + WL_PF; t++) all = all && (t >= steps.size() ? rows : step_kind[t] == WK_ROW);
+    if (all)
+      for (uint32_t l = 0; l < WL_W; l++) img[t0 * WL_W + l].x |= WL_GROUP_ROWS;
+  }
   R.ok = true;
   return R;
 }

@@ -20,7 +20,8 @@ enum : uint32_t { WK_FMA = 0, WK_ADD = 1, WK_MISC = 2, WK_SQR = 3, WK_ROW = 4 };
 // WK_SQR: every lane computes a * a + c.  WK_ROW: a * b + c with ONE product per 16-lane DPP row, a limb per lane.
 enum : uint32_t { WO_NOP = 0, WO_COMPUTE = 1, WO_INPUT = 2, WO_RARE = 3 };   // MISC steps: what the lane does
 constexpr uint32_t WL_STORE = 1u << 8;
-// descriptor: x = lane op | WL_STORE | kind << 12 (3 bits) | graph op << 16;  y = dst | a << 16;  z = b | c << 16;  w = V29 slot
+constexpr uint32_t WL_GROUP_ROWS = 1u << 15;   // on the first step of a group of WL_PF steps: every step of the group is a row step
+// descriptor: x = lane op | WL_STORE | kind << 12 (3 bits) | WL_GROUP_ROWS | graph op << 16;  y = dst | a << 16;  z = b | c << 16;  w = V29 slot
 //             (dst, a, b, c: LDS slots; WO_INPUT: a = index into the inputs buffer)
 struct WlDesc {
   uint32_t x, y, z, w;
