@@ -2217,6 +2217,14 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   do {                                                    \
     if (marks) RLN_HIP(hipEventRecord(S.t[i], stream));   \
   } while (0)
+  // The lanes = nodes interpreter (a wave and 157 KB of LDS per proof, ~25 x the instructions per proof of k_witness29,
+  // 2.0 ms against 11 ms): always below the small-batch threshold; up to witlanes_max only for a LONE batch -- in a stream
+  // of such batches it costs throughput (profiles/r3_rocprof_summary.md, section 10), and there the previous batch is still in flight.
+  // lone: nothing else in flight -- the batch may trade throughput for latency
+  static const int lone_force = env_int("RLNAMD_LONE", -1);   // -1: detect; 0 / 1: force (measurements)
+  const bool lone = lone_force >= 0 ? lone_force != 0 : (!D.last || hipEventQuery(D.last->evC) == hipSuccess);
+  (void)hipGetLastError();   // hipErrorNotReady is not an error here
+  const bool wl_used = D.wit29 && D.witlanes.ok && (nb <= D.lanechunk_max || (nb <= D.witlanes_max && lone));
   MARK(1, sA);
   if (D.wit29) {
     static const bool prof = env_int("RLNAMD_WIT_PROF", 0) != 0;   // diagnostic: cycles per node class, on stderr
@@ -2230,7 +2238,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
       RLN_HIP(hipMemcpy(h, pb.p, sizeof(h), hipMemcpyDeviceToHost));
       fprintf(stderr, "wit29 prof: mul %llu cyc / %llu, add %llu / %llu, const+input %llu / %llu, other %llu / %llu; total %llu cyc, %.3f ms, clock %.0f MHz\n",
               h[0], h[4], h[1], h[5], h[2], h[6], h[3], h[7], h[8], h[9] / 1e5, h[9] ? 100.0 * h[8] / h[9] : 0.0);
-    } else if (D.witlanes.ok && nb <= std::max(D.lanechunk_max, D.witlanes_max)) {
+    } else if (wl_used) {
       D.witlanes.launch(sA, D.consts29.p, in_p, D.NI, S.V29.p, S.err.p, B, nb);
     } else
     hipLaunchKernelGGL(k_witness29<false>, dim3(pg), dim3(64), WIT29_LDS_BYTES, sA, D.nodes29.p, D.nprog29,
@@ -2261,14 +2269,24 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     // on the walks' own stream: mat-vec and the NTTs (sA) start at once, beside the recodes instead of behind them
     // The G2 chain (recode, walk, sum, inversion: 1.3 ms for one proof) is the longest thing behind the interpreter and
     // every cross-stream hop costs it 50 - 100 us, so it runs on ONE stream (sB2); the G1 walk's stream takes the hop.
-    RLN_HIP(hipStreamWaitEvent(D.sB2, S.evX, 0));
-    hipLaunchKernelGGL(k_recode, dim3(div_up(D.NS + 3, 64), nb), dim3(64, 1), 0, D.sB2, S.V.p, D.sig2node.p, D.NS,
+    // (A lone batch; in a stream of batches the recodes stay on the front-end stream, where they do not queue behind the
+    // previous batch's walks.)
+    hipStream_t sR1 = lone ? D.sB2 : sA, sR3 = lone ? D.sB : sA;
+    if (lone) RLN_HIP(hipStreamWaitEvent(D.sB2, S.evX, 0));
+    hipLaunchKernelGGL(k_recode, dim3(div_up(D.NS + 3, 64), nb), dim3(64, 1), 0, sR1, S.V.p, D.sig2node.p, D.NS,
                        S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nb, 1u, 1u);
-    RLN_HIP(hipEventRecord(S.evW, D.sB2));
-    RLN_HIP(hipStreamWaitEvent(D.sB, S.evW, 0));
+    if (lone) {
+      RLN_HIP(hipEventRecord(S.evW, D.sB2));
+      RLN_HIP(hipStreamWaitEvent(D.sB, S.evW, 0));
+    }
     if (fused)
-      hipLaunchKernelGGL(k_recode, dim3(div_up(2 * D.NS + 1, 64), nb), dim3(64, 1), 0, D.sB, S.V.p, D.sig2node.p, D.NS,
+      hipLaunchKernelGGL(k_recode, dim3(div_up(2 * D.NS + 1, 64), nb), dim3(64, 1), 0, sR3, S.V.p, D.sig2node.p, D.NS,
                          S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nb, 3u, 1u);
+    if (!lone) {
+      RLN_HIP(hipEventRecord(S.evW, sA));
+      RLN_HIP(hipStreamWaitEvent(D.sB, S.evW, 0));
+      RLN_HIP(hipStreamWaitEvent(D.sB2, S.evW, 0));
+    }
     MARK(14, D.sB);
     if (P1.n_early)
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>), dim3(div_up(P1.n_early, 64), nb), dim3(64), 0,
@@ -2386,8 +2404,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   if (streamed) RLN_HIP(hipStreamWaitEvent(sV, S.evU, 0));
   MARK(0, sV);
   // (whenever the batch is small enough for the lanes = nodes interpreter: the Poseidon chain alone is 5.3 ms)
-  const bool values_w = (early || (D.wit29 && D.witlanes.ok && nb <= D.witlanes_max)) && D.have_values_kernel && D.ni == 6 &&
-                        env_int("RLNAMD_VALUES_WITNESS", 1) != 0;
+  const bool values_w = (early || wl_used) && D.have_values_kernel && D.ni == 6 && env_int("RLNAMD_VALUES_WITNESS", 1) != 0;
   if (values_w) {   // small batches: the circuit's own outputs (see k_values_from_witness)
     RLN_HIP(hipStreamWaitEvent(sV, S.evX, 0));   // sA: witness stored
     hipLaunchKernelGGL(k_values_from_witness, dim3(pg, 5), dim3(64), 0, sV, S.V.p, D.sig2node.p, B, nbp, S.values.p);
@@ -2428,19 +2445,29 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     RLN_HIP(hipEventRecord(S.evA, D.sA2));
     // The G2 sum and inversion (0.65 ms for one proof, behind the G2 walk only) beside the C segment (sC, behind the h
     // rows) instead of in front of it; k_fin_out waits for both, for s A, r B1 and the values.
-    // (s2: the G2 walk's stream -- its back end follows it without a hop)
-    hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(256), 0, s2, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, all6);
-    hipLaunchKernelGGL(k_glv_fold, dim3(pg, 1), dim3(64), 0, s2, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({3}));
-    hipLaunchKernelGGL(k_fin_affine, dim3(pg, 1), dim3(64), 0, s2, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
+    // (s2: the G2 walk's stream -- its back end follows it without a hop; in a stream of batches it goes to sC, where
+    // it does not hold up the next batch's G2 walk)
+    hipStream_t sG = lone ? s2 : D.sC;
+    if (!lone) RLN_HIP(hipStreamWaitEvent(D.sC, S.evB2, 0));
+    hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(256), 0, sG, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, all6);
+    hipLaunchKernelGGL(k_glv_fold, dim3(pg, 1), dim3(64), 0, sG, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({3}));
+    hipLaunchKernelGGL(k_fin_affine, dim3(pg, 1), dim3(64), 0, sG, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
                        S.affB2.p, B, nbp, task_sel({2}));
-    RLN_HIP(hipEventRecord(S.evB2, s2));
+    if (lone) RLN_HIP(hipEventRecord(S.evB2, s2));
     RLN_HIP(hipEventRecord(S.evV, sV));
     // The C segment, k_fin_out and the copies home on the front-end stream itself, right behind the walk of the h rows:
     // the chain interpreter -> NTT -> h -> walk -> sum -> output crosses no stream (each hop is 50 - 100 us).
-    sF = sA;
-    if (S.used) RLN_HIP(hipStreamWaitEvent(sF, S.evC, 0));
-    MARK(9, sF);
-    RLN_HIP(hipStreamWaitEvent(sF, S.evE, 0));   // the early G1 walk: the C segment's h-independent rows
+    // (Only for a lone batch: in a stream the front-end stream must be free for the batch after next -- there the C
+    // segment stays on sC, behind evB, which covers both G1 walks.)
+    if (lone) {
+      sF = sA;
+      if (S.used) RLN_HIP(hipStreamWaitEvent(sF, S.evC, 0));
+      MARK(9, sF);
+      RLN_HIP(hipStreamWaitEvent(sF, S.evE, 0));   // the early G1 walk: the C segment's h-independent rows
+    } else {
+      MARK(9, sF);
+      RLN_HIP(hipStreamWaitEvent(sF, S.evB, 0));
+    }
     hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, 2), dim3(256), 0, sF, S.part1.p, P1.segchunks.p, S.sums1.p, B,
                        PB, task_sel({2, 5}));
     hipLaunchKernelGGL(k_glv_fold, dim3(pg, 1), dim3(64), 0, sF, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({2}));
