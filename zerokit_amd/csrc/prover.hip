@@ -2153,6 +2153,11 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   if (n > B_) throw Error("batch larger than the prover workspace (max_batch)");
   if (mode < PROVE_FULL || mode > PROVE_FINISH) throw Error("unknown prover mode");
   Impl& D = *d_;
+  // lone: nothing else in flight -- the batch may trade throughput for latency (the fused plan's + 25 % G1 rows, the
+  // single-stream chains, the wave-per-proof interpreter above the small-batch threshold)
+  static const int lone_force = env_int("RLNAMD_LONE", -1);   // -1: detect; 0 / 1: force (measurements)
+  const bool lone = lone_force >= 0 ? lone_force != 0 : (!D.last || hipEventQuery(D.last->evC) == hipSuccess);
+  (void)hipGetLastError();   // hipErrorNotReady is not an error here
   const bool small = n <= D.lanechunk_max && n <= D.small_stride && D.use29 && D.use29_g2;   // lanes = chunks
   // Small batches (latency, not throughput): the whole front end stays on ONE stream (every cross-stream event hop costs
   // 0.1 - 0.15 ms), the digits of the witness scalars are recoded right behind the interpreter, and both walks start on
@@ -2161,7 +2166,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   const bool early = n <= D.lanechunk_max && D.use29 && D.use29_g2 && D.split_msm && D.recode_front &&
                      mode != PROVE_PARTIAL && env_int("RLNAMD_EARLY_WALK", 1) != 0;
   // small full proofs: s A and r B1 are rows of the C segment (plan1f), no k_fin_smul
-  const bool fused = early && small && mode == PROVE_FULL && D.nh == 2 && env_int("RLNAMD_FUSED_SMUL", 1) != 0 &&
+  const bool fused = lone && early && small && mode == PROVE_FULL && D.nh == 2 && env_int("RLNAMD_FUSED_SMUL", 1) != 0 &&
                      env_int("RLNAMD_EARLY_FIN", 1) != 0;   // (its back end is the split one below)
   const Impl::Plan& P1 = fused ? D.plan1f[PROVE_FULL] : small ? D.plan1s[mode] : D.plan1[mode];
   const Impl::Plan& P2 = small ? D.plan2s[mode] : D.plan2[mode];
@@ -2220,10 +2225,6 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // The lanes = nodes interpreter (a wave and 157 KB of LDS per proof, ~25 x the instructions per proof of k_witness29,
   // 2.0 ms against 11 ms): always below the small-batch threshold; up to witlanes_max only for a LONE batch -- in a stream
   // of such batches it costs throughput (profiles/r3_rocprof_summary.md, section 10), and there the previous batch is still in flight.
-  // lone: nothing else in flight -- the batch may trade throughput for latency
-  static const int lone_force = env_int("RLNAMD_LONE", -1);   // -1: detect; 0 / 1: force (measurements)
-  const bool lone = lone_force >= 0 ? lone_force != 0 : (!D.last || hipEventQuery(D.last->evC) == hipSuccess);
-  (void)hipGetLastError();   // hipErrorNotReady is not an error here
   const bool wl_used = D.wit29 && D.witlanes.ok && (nb <= D.lanechunk_max || (nb <= D.witlanes_max && lone));
   MARK(1, sA);
   if (D.wit29) {
