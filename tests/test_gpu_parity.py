@@ -454,6 +454,47 @@ def test_lane_chunk_walk_and_clock_tap(monkeypatch):
         p.close()
 
 
+@pytest.mark.parametrize("env", [
+    {"RLNAMD_LONE": "0"},             # as inside a stream of batches: plain small plan, back end on its own stream
+    {"RLNAMD_LONE": "1"},
+    {"RLNAMD_NTT_FUSE9": "0"},        # radix-8 passes only
+    {"RLNAMD_VALUES_WITNESS": "0"},   # proof values by the Poseidon chain instead of the circuit's public signals
+    {"RLNAMD_WL_REASSOC": "0"},       # the interpreter's schedule with the circuit's sums in source order
+    {"RLNAMD_WITROWS": "0"},          # lane-form products
+    {"RLNAMD_EARLY_FIN": "0", "RLNAMD_FUSED_SMUL": "0"},
+], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_small_batch_shape_variants_give_the_golden_bytes(monkeypatch, env):
+    """Every latency shape of the single-proof path has a switch that restores the shape it replaced (DESIGN section 4,
+    "Small batches"); each combination must give the golden proof bytes, public inputs and witness digest -- for one
+    proof and for a batch of five, also when the batch is NOT alone on the device (two batches back to back)."""
+    import hashlib
+    from zerokit_amd.batch import BatchProver
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cases = _cases()["cases"]
+    ws, rs = [_w(c) for c in cases], [(int(c["r"]), int(c["s"])) for c in cases]
+    p = BatchProver(max_batch=64)
+    try:
+        one = p.prove(ws[:1], rs[:1])[0]
+        assert one["proof"].hex() == cases[0]["proof_compressed"]
+        assert [str(v) for v in one["public_inputs"]] == cases[0]["public_inputs"]
+        full = p.fetch_witness(0)
+        assert hashlib.sha256(b"".join(v.to_bytes(32, "little") for v in full)).hexdigest() == cases[0]["witness_sha256"]
+        five = p.prove(ws[:5], rs[:5])
+        for i in range(5):
+            assert five[i]["proof"].hex() == cases[i]["proof_compressed"], i
+            assert [str(v) for v in five[i]["public_inputs"]] == cases[i]["public_inputs"], i
+        # two batches in flight: the second is enqueued while the first still runs
+        inp, rsb = p.pack_inputs(ws[:3]), p.pack_rs(rs[:3])
+        t1, _ = p.submit(inp, rsb)
+        t2, _ = p.submit(inp, rsb)
+        a, b = p.collect(t1, 3), p.collect(t2, 3)
+        for i in range(3):
+            assert a[i]["proof"].hex() == cases[i]["proof_compressed"] == b[i]["proof"].hex(), i
+    finally:
+        p.close()
+
+
 # ------------------------------------------------------------------------------------------ partial proofs
 def test_partial_proof_then_finish_equals_full(prover):
     """generate_partial_zk_proof + finish_zk_proof_with_rs == generate_zk_proof_with_rs

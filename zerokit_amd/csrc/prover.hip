@@ -2019,7 +2019,7 @@ template <bool DIF, bool M29>
 static void launch_ntt(Fr* data, const uint32_t* tw, int logn, const uint32_t* final_scale, uint32_t B, uint32_t nb,
                        hipStream_t s, bool lanes_are_groups = false) {
   int s0 = 0;
-  static const bool fuse9 = env_int("RLNAMD_NTT_FUSE9", 1) != 0;
+  const bool fuse9 = env_int("RLNAMD_NTT_FUSE9", 1) != 0;
   if (lanes_are_groups && !M29 && fuse9 && logn >= 9) {   // nine levels in one kernel (k_ntt_fused9)
     const Fr* sc = (9 == logn) ? reinterpret_cast<const Fr*>(final_scale) : nullptr;
     hipLaunchKernelGGL((k_ntt_fused9<DIF>), dim3(nb, (1u << logn) >> 9, 3), dim3(64), 0, s, data,
@@ -2155,7 +2155,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   Impl& D = *d_;
   // lone: nothing else in flight -- the batch may trade throughput for latency (the fused plan's + 25 % G1 rows, the
   // single-stream chains, the wave-per-proof interpreter above the small-batch threshold)
-  static const int lone_force = env_int("RLNAMD_LONE", -1);   // -1: detect; 0 / 1: force (measurements)
+  const int lone_force = env_int("RLNAMD_LONE", -1);   // -1: detect; 0 / 1: force (measurements, tests)
   const bool lone = lone_force >= 0 ? lone_force != 0 : (!D.last || hipEventQuery(D.last->evC) == hipSuccess);
   (void)hipGetLastError();   // hipErrorNotReady is not an error here
   const bool small = n <= D.lanechunk_max && n <= D.small_stride && D.use29 && D.use29_g2;   // lanes = chunks
