@@ -462,6 +462,7 @@ def test_lane_chunk_walk_and_clock_tap(monkeypatch):
     {"RLNAMD_WL_REASSOC": "0"},       # the interpreter's schedule with the circuit's sums in source order
     {"RLNAMD_WITROWS": "0"},          # lane-form products
     {"RLNAMD_EARLY_FIN": "0", "RLNAMD_FUSED_SMUL": "0"},
+    {"RLNAMD_LANECHUNK_WALK": "0"},   # the short-chunk plans walked with lanes = proofs (the shape of 49..128 proofs)
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_small_batch_shape_variants_give_the_golden_bytes(monkeypatch, env):
     """Every latency shape of the single-proof path has a switch that restores the shape it replaced (DESIGN section 4,

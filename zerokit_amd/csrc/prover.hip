@@ -1186,6 +1186,7 @@ struct Prover::Impl {
   DevBuf<unsigned long long> walk_clk;  // clock tap of the two walks: G1 cycles, G1 ticks, G2 cycles, G2 ticks
   bool wit29 = true;             // RLNAMD_WIT29: graph interpreter in the 9 x 29-bit form (k_witness29)
   uint32_t lanechunk_max = 128;  // RLNAMD_LANECHUNK: largest batch that takes the small-batch shapes
+  uint32_t lanechunk_walk_max = 48;  // RLNAMD_LANECHUNK_WALK: largest lone batch whose walks run with lanes = chunks
   uint32_t witlanes_max = 256;   // RLNAMD_WITLANES_MAX: largest batch interpreted with lanes = nodes (a wave and 157 KB of LDS per proof)
   DevBuf<GNode29> nodes29;
   DevBuf<unsigned long long> wit_prof;
@@ -1475,6 +1476,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   // vs 8.1 k proofs/s, 128: equal, 256: 10.1 k vs 12.1 k) -- 128 wins or ties on both.
   D.lanechunk_max = (uint32_t)std::max(0, env_int("RLNAMD_LANECHUNK", 128));
   D.witlanes_max = (uint32_t)std::max(0, env_int("RLNAMD_WITLANES_MAX", 256));
+  D.lanechunk_walk_max = (uint32_t)std::max(0, env_int("RLNAMD_LANECHUNK_WALK", 48));
   // partial sums of a small batch: [chunk][stride]
   D.small_stride = std::max<uint32_t>(64, (std::min<uint32_t>(D.lanechunk_max, (uint32_t)B_) + 63) / 64 * 64);
   std::vector<GNode29> wit29_prog;
@@ -2171,6 +2173,11 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   const Impl::Plan& P1 = fused ? D.plan1f[PROVE_FULL] : small ? D.plan1s[mode] : D.plan1[mode];
   const Impl::Plan& P2 = small ? D.plan2s[mode] : D.plan2[mode];
   const uint32_t PB = small ? D.small_stride : (uint32_t)B_;   // stride of the partial-sum arrays
+  // mid-size small batches: the short-chunk plans walked with lanes = proofs (walk29.h).  A lone batch: above 48 proofs
+  // (64: 11.3 -> 9.9 ms, 128: 18.1 -> 16.3 ms; 32: 6.9 ms against 8.4).  In a stream of batches the lanes = chunks form
+  // pays its scattered gathers in throughput much earlier (streams of 64 / 128-proof batches: 9.5 -> 10.8 k, 10.7 -> 11.9 k
+  // proofs/s), so there it stops at 16 proofs.
+  const bool walk_lp = small && early && (n > D.lanechunk_walk_max || (!lone && n >= 16));
   Slot& S = D.slot[D.cur];
   const bool streamed = h_inputs != nullptr;
   if (streamed) {
@@ -2289,7 +2296,11 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
       RLN_HIP(hipStreamWaitEvent(D.sB2, S.evW, 0));
     }
     MARK(14, D.sB);
-    if (P1.n_early)
+    if (P1.n_early && walk_lp)
+      hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(div_up(P1.n_early, 8) * 8 * pg), dim3(64), D.msm_lds,
+                         D.sB, D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.n_early, S.digits.p, S.part1.p, D.ws, B, pg,
+                         D.nh, nullptr, P1.early_ids.p, PB);
+    else if (P1.n_early)
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>), dim3(div_up(P1.n_early, 64), nb), dim3(64), 0,
                          D.sB, D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.n_early, S.digits.p, S.part1.p, D.ws, B, PB,
                          D.nh, nullptr, P1.early_ids.p);
@@ -2355,7 +2366,11 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     RLN_HIP(hipStreamWaitEvent(D.sB2, S.evR, 0));
   }
   if (early) {   // the h rows, on the front-end stream itself (no event hop); everything else is already walking
-    if (P1.n_late)
+    if (P1.n_late && walk_lp)
+      hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(div_up(P1.n_late, 8) * 8 * pg), dim3(64), D.msm_lds,
+                         sA, D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.n_late, S.digits.p, S.part1.p, D.ws, B, pg,
+                         D.nh, nullptr, P1.late_ids.p, PB);
+    else if (P1.n_late)
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>), dim3(div_up(P1.n_late, 64), nb), dim3(64), 0, sA,
                          D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.n_late, S.digits.p, S.part1.p, D.ws, B, PB, D.nh,
                          nullptr, P1.late_ids.p);
@@ -2380,7 +2395,10 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   MARK(11, s2);
   if (P2.nchunks) {
     uint32_t blocks = div_up(P2.nchunks, 8) * 8 * pg;
-    if (D.use29_g2 && lanechunk)
+    if (D.use29_g2 && walk_lp)
+      hipLaunchKernelGGL((k_msm29<G2Acc29, G2Affine29, G2XYZZ, 2>), dim3(blocks), dim3(64), 0, s2, D.t2_29.p, P2.rsid.p,
+                         P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, pg, D.nh, nullptr, nullptr, PB);
+    else if (D.use29_g2 && lanechunk)
       hipLaunchKernelGGL((k_msm29<G2Acc29, G2Affine29, G2XYZZ, 1, true>), dim3(div_up(P2.nchunks, 64), nb), dim3(64), 0, s2,
                          D.t2_29.p, P2.rsid.p, P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, PB, D.nh,
                          nullptr);

@@ -37,13 +37,17 @@ struct ChunkDesc {
 // partial-sum array in this mode: the small-batch plans cut the walks into shorter chunks and keep [chunk][64]).
 // `sid` is indexed by the position in `rows` (a plan may walk a table row with another scalar than the row's own: the
 // small-batch plan walks the A and B1 rows a second time with s w_i and r w_i, see Prover::Prover).
+// Between the two (RLNAMD_LANECHUNK_WALK < proofs <= RLNAMD_LANECHUNK): lanes = proofs over the small batches' SHORT chunks.
+// With lanes = chunks every lane of every wave gathers from its own table row -- 64 proofs are 5 900 + 1 900 waves of 64
+// scattered 72-byte reads per step over a 228 GiB table (6.9 ms for the G1 walk, TLB-bound); with lanes = proofs a wave
+// reads ONE row region and the short chunks still give 5 900 waves of 72 additions.
 template <class Acc, class Entry, class Out, int WAVES, bool LANECHUNK = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_msm29(const Entry* __restrict__ table, const uint32_t* __restrict__ sid,
                                               const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks,
                                               uint32_t nchunks, const int16_t* __restrict__ digits,
                                               Out* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups,
                                               uint32_t nh, unsigned long long* __restrict__ clk,
-                                              const uint32_t* __restrict__ chunk_ids = nullptr) {
+                                              const uint32_t* __restrict__ chunk_ids = nullptr, uint32_t pstride = 0) {
   // clock tap (clk may be null): every 64th workgroup adds its shader-clock cycles and its 100 MHz wall ticks; their
   // ratio is the clock the power management held under this kernel, which is what the issue-bound walk scales with
   const unsigned long long c0 = clk ? clock64() : 0, w0 = clk ? wall_clock64() : 0;
@@ -105,6 +109,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 
   uint32_t xcd = L & 7, q = L >> 3;
   uint32_t chunk = (q / pgroups) * 8 + xcd, pg = q % pgroups;
   if (chunk >= nchunks) return;
+  // chunk_ids / pstride (mid-size batches): the short-chunk plans of the small batches walked with lanes = proofs -- a
+  // subset of the plan's chunks per launch, partial sums at part[chunk * pstride + proof] (0: the batch stride B)
+  if (chunk_ids) chunk = chunk_ids[chunk];
   uint32_t p = pg * 64 + threadIdx.x;
   ChunkDesc cd = chunks[chunk];
   Acc acc = Acc::inf();
@@ -122,7 +129,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 
       }
     }
   }
-  part[(size_t)chunk * B + p] = acc.to_xyzz();
+  part[(size_t)chunk * (pstride ? pstride : B) + p] = acc.to_xyzz();
   if (clk && threadIdx.x == 0 && (L & 63) == 0) {
     atomicAdd(clk, clock64() - c0);
     atomicAdd(clk + 1, wall_clock64() - w0);
