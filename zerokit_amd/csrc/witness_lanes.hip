@@ -304,10 +304,41 @@ __global__ void __launch_bounds__(64) k_witness_lanes(const uint4* __restrict__ 
       lds[(writer ? dst : WL_SLOTS - 1) * 12 + wj] = r;
       lds[WL_STAGE + (k * WL_ROWS + row) * 12 + wj] = r;
     };
-    // nine groups in ten hold nothing but row steps (the host marks them): no kind test, no branch between their steps
+    // nine groups in ten hold nothing but row steps (the host marks them): no kind test, no branch between their steps,
+    // and the LDS addresses of step k + 1 are computed while step k's operand reads are in flight (eight instructions
+    // off the write -> read chain; the lone wave has nothing else to issue during that wait)
+    struct RowAddr {
+      uint32_t a, b, c, c8, w, meta;
+    };
+    auto row_addr = [&](const uint4& q) {
+      const uint32_t dst = q.y & 0xFFFF, sa = q.y >> 16, sb = q.z & 0xFFFF, sc = q.z >> 16;
+      return RowAddr{sa * 12, sb * 12 + jb, sc * 12 + (j >= 9 ? jc : 7), sc * 12 + 8, (writer ? dst : WL_SLOTS - 1) * 12 + wj,
+                     (q.x & WL_STORE) ? q.w : 0xFFFFFFFFu};
+    };
     if (__builtin_expect((__builtin_amdgcn_readfirstlane(d[0].x) & WL_GROUP_ROWS) != 0, 1)) {
+      RowAddr A = row_addr(d[0]);
 #pragma unroll
-      for (int k = 0; k < (int)WL_PF; k++) row_step(d[k], k);
+      for (int k = 0; k < (int)WL_PF; k++) {
+        Fr29 va;
+        {
+          const uint4 x = *(const uint4*)(lds + A.a), y = *(const uint4*)(lds + A.a + 4);
+          va.v[0] = x.x; va.v[1] = x.y; va.v[2] = x.z; va.v[3] = x.w;
+          va.v[4] = y.x; va.v[5] = y.y; va.v[6] = y.z; va.v[7] = y.w;
+          va.v[8] = lds[A.a + 8];
+        }
+        uint32_t vb = lds[A.b], vc = lds[A.c];
+        const uint32_t c8 = lds[A.c8];
+        __builtin_amdgcn_sched_barrier(0);   // all six reads in flight ...
+        const RowAddr An = row_addr(d[k + 1 < (int)WL_PF ? k + 1 : k]);
+        __builtin_amdgcn_sched_barrier(0);   // ... and the next step's addresses computed before the first wait
+        vb = j < 9 ? vb : 0;
+        vc = (j >= 9 || j == 0) ? vc : 0;
+        uint32_t r = wl_row_mul_add16(va.v, vb, vc, c8, j, PI, PP);
+        r = j == 2 ? A.meta : r;
+        lds[A.w] = r;
+        lds[WL_STAGE + (k * WL_ROWS + row) * 12 + wj] = r;
+        A = An;
+      }
     } else {
 #pragma unroll
       for (int k = 0; k < (int)WL_PF; k++) {
