@@ -785,22 +785,25 @@ static TaskSel task_sel(std::initializer_list<uint32_t> ids) {
   for (uint32_t v : ids) t.id[k++] = (uint8_t)v;
   return t;
 }
+constexpr uint32_t SUM_TREE_LANES = 512;
 template <class F>
-__global__ void __launch_bounds__(256) k_sum_tree(const XYZZ<F>* __restrict__ part, const ChunkDesc* __restrict__ segchunks,
+__global__ void __launch_bounds__(SUM_TREE_LANES) k_sum_tree(const XYZZ<F>* __restrict__ part, const ChunkDesc* __restrict__ segchunks,
                                                   XYZZ<F>* __restrict__ dst, uint32_t B, uint32_t PB, TaskSel sel) {
-  // 256 lanes per (proof, segment): the short chunks of the small-batch plans leave ~1 500 partial sums per segment;
-  // six per lane and an eight-level tree cost what 64 lanes paid for the long chunks (part stride PB, result stride B)
-  __shared__ XYZZ<F> sh[256];
+  // 512 lanes per (proof, segment): the short chunks of the small-batch plans leave ~2 000 partial sums per segment;
+  // four per lane and a nine-level tree (part stride PB, result stride B).  The additions are a dependent chain for the
+  // lone waves of a single proof (30 us each in Fq2), so the lane count is what sets the kernel's length: 256 lanes were
+  // 8 + 8 additions.  Only the upper half of a level passes through LDS.
+  __shared__ XYZZ<F> sh[SUM_TREE_LANES / 2];
   __builtin_amdgcn_s_setprio(3);
   const uint32_t p = blockIdx.x, sgi = sel.id[blockIdx.y], l = threadIdx.x;
   const ChunkDesc cd = segchunks[sgi];
   XYZZ<F> acc = XYZZ<F>::inf();
-  for (uint32_t i = cd.pt_begin + l; i < cd.pt_end; i += 256) acc.add(part[(size_t)i * PB + p]);
+  for (uint32_t i = cd.pt_begin + l; i < cd.pt_end; i += SUM_TREE_LANES) acc.add(part[(size_t)i * PB + p]);
 #pragma unroll 1
-  for (uint32_t stride = 128; stride >= 1; stride >>= 1) {
-    sh[l] = acc;
+  for (uint32_t stride = SUM_TREE_LANES / 2; stride >= 1; stride >>= 1) {
+    if (l >= stride && l < 2 * stride) sh[l - stride] = acc;
     __syncthreads();
-    if (l < stride) acc.add(sh[l + stride]);
+    if (l < stride) acc.add(sh[l]);
     __syncthreads();
   }
   if (l == 0) dst[(size_t)sgi * B + p] = acc;
@@ -2443,14 +2446,14 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     RLN_HIP(hipStreamWaitEvent(D.sA2, S.evE, 0));   // sB: the early G1 walk
     if (fused) {
       // fused plan: only A has to be reduced and inverted early; s A and r B1 are inside the C segment, B1 is never formed
-      hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, 2), dim3(256), 0, D.sA2, S.part1.p, P1.segchunks.p, S.sums1.p, B, PB,
+      hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, 2), dim3(SUM_TREE_LANES), 0, D.sA2, S.part1.p, P1.segchunks.p, S.sums1.p, B, PB,
                          task_sel({0, 3}));
       hipLaunchKernelGGL(k_glv_fold, dim3(pg, 1), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({0}));
       hipLaunchKernelGGL(k_fin_affine, dim3(pg, 1), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
                          S.affB2.p, B, nbp, task_sel({0}));
       RLN_HIP(hipMemsetAsync(S.prod.p, 0, S.prod.bytes(), D.sA2));   // ZZ = 0: two points at infinity for k_fin_out
     } else {
-      hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, 4), dim3(256), 0, D.sA2, S.part1.p, P1.segchunks.p, S.sums1.p, B,
+      hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, 4), dim3(SUM_TREE_LANES), 0, D.sA2, S.part1.p, P1.segchunks.p, S.sums1.p, B,
                          PB, task_sel({0, 1, 3, 4}));
       hipLaunchKernelGGL(k_glv_fold, dim3(pg, 2), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({0, 1}));
       hipLaunchKernelGGL(k_fin_affine, dim3(pg, 2), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
@@ -2468,7 +2471,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     // it does not hold up the next batch's G2 walk)
     hipStream_t sG = lone ? s2 : D.sC;
     if (!lone) RLN_HIP(hipStreamWaitEvent(D.sC, S.evB2, 0));
-    hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(256), 0, sG, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, all6);
+    hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(SUM_TREE_LANES), 0, sG, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, all6);
     hipLaunchKernelGGL(k_glv_fold, dim3(pg, 1), dim3(64), 0, sG, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({3}));
     hipLaunchKernelGGL(k_fin_affine, dim3(pg, 1), dim3(64), 0, sG, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
                        S.affB2.p, B, nbp, task_sel({2}));
@@ -2487,7 +2490,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
       MARK(9, sF);
       RLN_HIP(hipStreamWaitEvent(sF, S.evB, 0));
     }
-    hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, 2), dim3(256), 0, sF, S.part1.p, P1.segchunks.p, S.sums1.p, B,
+    hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, 2), dim3(SUM_TREE_LANES), 0, sF, S.part1.p, P1.segchunks.p, S.sums1.p, B,
                        PB, task_sel({2, 5}));
     hipLaunchKernelGGL(k_glv_fold, dim3(pg, 1), dim3(64), 0, sF, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({2}));
     RLN_HIP(hipStreamWaitEvent(sF, S.evB2, 0));
@@ -2502,8 +2505,8 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   }
   if (early_fin) {
   } else if (lanechunk) {   // small batch: lanes = partial sums (k_sum_tree)
-    hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, P1.nseg), dim3(256), 0, D.sC, S.part1.p, P1.segchunks.p, S.sums1.p, B, PB, all6);
-    hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(256), 0, D.sC, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, all6);
+    hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, P1.nseg), dim3(SUM_TREE_LANES), 0, D.sC, S.part1.p, P1.segchunks.p, S.sums1.p, B, PB, all6);
+    hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(SUM_TREE_LANES), 0, D.sC, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, all6);
   } else {
     if (P1.ngroups)
       hipLaunchKernelGGL(k_sum_ranges<Fq>, dim3(pg, P1.ngroups), dim3(64), 0, D.sC, S.part1.p, P1.groups.p, P1.ngroups,
