@@ -426,6 +426,22 @@ def main():
     clock_alone_mhz = prover.walk_clock_mhz()
     info = prover.info
     g1_adds = int(info.g1_rows) * int(info.windows) * B
+    # the other end of the same prover: ONE proof per call (what a caller of the reference does, rln/README.md:324-332),
+    # submit -> collect with nothing else in flight; outside the timed region, reported beside the headline
+    latency = None
+    if not finish and not args.no_side_configs and world == 1:
+        one = workload.config2_packed(prover.slots, prover.inputs_size, first, 1)
+        ts = []
+        for i in range(9):
+            t0 = time.perf_counter()
+            t, _ = prover.submit(*one)
+            pr, va, er = prover.collect_raw(t, 1)
+            if i >= 2:
+                ts.append((time.perf_counter() - t0) * 1e3)
+        same = bool(pr[:128] == results[0][0][:128] and not any(er)) if 0 in results else None
+        latency = {"ms_min": round(min(ts), 3), "ms_median": round(sorted(ts)[len(ts) // 2], 3), "calls": len(ts),
+                   "what": "one proof per call on the bench's prover (228 GiB tables): submit + collect, H2D and D2H included",
+                   "same_bytes_as_in_the_batch": same}
     prover.close()
 
     # ---- the other single-GPU BASELINE configs, with the prover's HBM released
@@ -522,6 +538,8 @@ def main():
             "roofline": roof,
         }
         line.update(side)
+        if latency is not None:
+            line["single_proof_latency"] = latency
         if "config5" in side:
             line["rccl_ranks"] = side["config5"]["rccl_ranks"]
         if world == 1 and not args.no_cpu_baseline:
