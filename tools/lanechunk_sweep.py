@@ -12,8 +12,8 @@ sys.path.insert(0, ROOT)
 from zerokit_amd import workload  # noqa: E402
 from zerokit_amd.batch import BatchProver  # noqa: E402
 
-p = BatchProver(max_batch=512)
-out = {"RLNAMD_LANECHUNK": os.environ.get("RLNAMD_LANECHUNK", "default")}
+p = BatchProver(max_batch=int(os.environ.get("MAXB", "512")), window_bits=int(os.environ.get("WBITS", "0")))   # WBITS=7150114: the throughput tables (228 GiB)
+out = {"RLNAMD_LANECHUNK": os.environ.get("RLNAMD_LANECHUNK", "default"), "table_gib": round(p.info.table_bytes / 2**30, 1)}
 for n in (1, 4, 8, 16, 32, 64, 128, 192, 256, 384, 512):
     inp, rsb = workload.config2_packed(p.slots, p.inputs_size, 0, n)
     t, _ = p.submit(inp, rsb)
