@@ -2171,7 +2171,9 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   const bool early = n <= D.lanechunk_max && D.use29 && D.use29_g2 && D.split_msm && D.recode_front &&
                      mode != PROVE_PARTIAL && env_int("RLNAMD_EARLY_WALK", 1) != 0;
   // small full proofs: s A and r B1 are rows of the C segment (plan1f), no k_fin_smul
-  const bool fused = lone && early && small && mode == PROVE_FULL && D.nh == 2 && env_int("RLNAMD_FUSED_SMUL", 1) != 0 &&
+  // (up to 96 proofs: above, the walks are issue-bound even for a lone batch and the extra rows cost more than the ladder
+  // they replace -- 128 proofs 16.6 -> 15.3 ms without them, 64 proofs 10.1 -> 10.3 ms)
+  const bool fused = lone && n <= 96 && early && small && mode == PROVE_FULL && D.nh == 2 && env_int("RLNAMD_FUSED_SMUL", 1) != 0 &&
                      env_int("RLNAMD_EARLY_FIN", 1) != 0;   // (its back end is the split one below)
   const Impl::Plan& P1 = fused ? D.plan1f[PROVE_FULL] : small ? D.plan1s[mode] : D.plan1[mode];
   const Impl::Plan& P2 = small ? D.plan2s[mode] : D.plan2[mode];
