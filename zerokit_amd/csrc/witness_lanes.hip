@@ -312,8 +312,10 @@ __global__ void __launch_bounds__(64) k_witness_lanes(const uint4* __restrict__ 
     };
     auto row_addr = [&](const uint4& q) {
       const uint32_t dst = q.y & 0xFFFF, sa = q.y >> 16, sb = q.z & 0xFFFF, sc = q.z >> 16;
-      return RowAddr{sa * 12, sb * 12 + jb, sc * 12 + (j >= 9 ? jc : 7), sc * 12 + 8, (writer ? dst : WL_SLOTS - 1) * 12 + wj,
-                     (q.x & WL_STORE) ? q.w : 0xFFFFFFFFu};
+      // lanes that must see 0 (b above limb 8, c outside the result's lanes) read a word of the ZERO slot: the masking
+      // happens here, in the address phase, instead of behind the reads
+      return RowAddr{sa * 12, j < 9 ? sb * 12 + j : n_consts * 12, (j >= 9 || j == 0) ? sc * 12 + (j >= 9 ? jc : 7) : n_consts * 12,
+                     sc * 12 + 8, (writer ? dst : WL_SLOTS - 1) * 12 + wj, (q.x & WL_STORE) ? q.w : 0xFFFFFFFFu};
     };
     if (__builtin_expect((__builtin_amdgcn_readfirstlane(d[0].x) & WL_GROUP_ROWS) != 0, 1)) {
       RowAddr A = row_addr(d[0]);
@@ -331,8 +333,6 @@ __global__ void __launch_bounds__(64) k_witness_lanes(const uint4* __restrict__ 
         __builtin_amdgcn_sched_barrier(0);   // all six reads in flight ...
         const RowAddr An = row_addr(d[k + 1 < (int)WL_PF ? k + 1 : k]);
         __builtin_amdgcn_sched_barrier(0);   // ... and the next step's addresses computed before the first wait
-        vb = j < 9 ? vb : 0;
-        vc = (j >= 9 || j == 0) ? vc : 0;
         uint32_t r = wl_row_mul_add16(va.v, vb, vc, c8, j, PI, PP);
         r = j == 2 ? A.meta : r;
         lds[A.w] = r;
