@@ -30,6 +30,7 @@ extern "C" {
 const char* rlnamd_last_error(void);
 int rlnamd_device_count(void);
 int rlnamd_set_device(int ordinal);
+int rlnamd_get_device(int* ordinal);   /* the calling thread's current device */
 int rlnamd_device_name(char* buf, size_t cap);
 
 /* ---- hashing ----------------------------------------------------------------------------------------
@@ -46,6 +47,9 @@ typedef struct rlnamd_tree rlnamd_tree;
 int rlnamd_tree_new(size_t depth, rlnamd_tree** out);                         /* ::default(depth) :74-80 */
 void rlnamd_tree_free(rlnamd_tree* t);
 int rlnamd_tree_set_range(rlnamd_tree* t, size_t start, const uint8_t* leaves_le, size_t n); /* :197-223 */
+/* k single-leaf writes (any order; a later entry for the same index wins) followed by ONE bottom-up pass over the union
+ * of their paths -- what k set() calls (:141-147, depth hashes each) leave behind, in one pass */
+int rlnamd_tree_set_leaves(rlnamd_tree* t, const uint64_t* indices, const uint8_t* leaves_le, size_t k);
 int rlnamd_tree_root(rlnamd_tree* t, uint8_t out_le[32]);                                    /* :137-139 */
 int rlnamd_tree_get_leaf(rlnamd_tree* t, size_t index, uint8_t out_le[32]);                  /* :149-154 */
 /* one proof: elems = depth*32 bytes bottom-up, bits = depth bytes (1 = node is a right child) :288-304 */
@@ -114,8 +118,16 @@ int rlnamd_prover_submit(rlnamd_prover* p, size_t n, const uint8_t* inputs_le, c
                          const uint8_t* partial320, uint64_t* ticket);
 int rlnamd_prover_collect(rlnamd_prover* p, uint64_t ticket, size_t n, uint8_t* proofs, uint8_t* coords, uint8_t* values,
                           uint32_t* errors, uint8_t* partial320);
-/* public signals w[1..num_instance) of a collected batch (n * num_public * 32 bytes), circuit-generic */
+/* public signals w[1..num_instance) of a finished batch (n * num_public * 32 bytes), circuit-generic.  Call it BEFORE
+ * rlnamd_prover_collect: collect ends the batch -- see the next comment. */
 int rlnamd_prover_collect_public(rlnamd_prover* p, uint64_t ticket, size_t n, uint8_t* out_le);
+/* Secrets do not outlive the batch.  The reference zeroises the identity secret wherever it holds it (IdSecret,
+ * rln/src/utils.rs:440-527) and the witness calculator's inputs (rln/src/circuit/iden3calc.rs:45-56).  Here
+ * rlnamd_prover_collect (and prove_stream, the pool, every ffi_* proving call) overwrites the batch's staged inputs --
+ * pinned host buffer and device copy -- its (r, s) and its witness values behind the copy-out; a later
+ * rlnamd_prover_collect_public of that ticket is an error.  The resident-input calls (upload / run / download, kept for
+ * the fetch_* parity taps) hold their data until rlnamd_prover_wipe or rlnamd_prover_free. */
+int rlnamd_prover_wipe(rlnamd_prover* p);
 int rlnamd_prover_prove_stream(rlnamd_prover* p, size_t n, const uint8_t* inputs_le, const uint8_t* rs_le,
                                uint8_t* proofs, uint8_t* values, uint32_t* errors);
 int rlnamd_prover_stage_ms(rlnamd_prover* p, float ms[RLNAMD_PROVER_STAGES]);
@@ -195,8 +207,14 @@ int rlnamd_selftest_fq29(int group, uint32_t threads, uint32_t iters, const uint
 int rlnamd_msm_set(rlnamd_msm* m, const uint8_t* points_xy_le, const uint8_t* scalars_le, size_t n);
 /* synthetic config-5 workload generated in HBM: P_i = k_i G, scalars s_i, SplitMix64(seed) at index first+i */
 int rlnamd_msm_generate(rlnamd_msm* m, uint64_t seed, uint64_t first_index, size_t n);
-/* its closed form (sum k_i s_i mod r) G, host side, scalar arithmetic only */
-int rlnamd_msm_expected(uint64_t seed, uint64_t first_index, size_t n, uint8_t out_xy_le[64]);
+/* distribution variants of the same workload: mode bit 0 = every scalar equals s_0 (all n points in ONE bucket per
+ * window), bit 1 = k_i = k_(i mod 4) (four distinct bases).  The library carries no expected value for its own
+ * workload: the closed form (sum k_i s_i mod r) G lives in the oracle (oracle/c: oracle_msm_expected). */
+#define RLNAMD_MSM_EQUAL_SCALARS 1u
+#define RLNAMD_MSM_FOUR_POINTS 2u
+int rlnamd_msm_generate_mode(rlnamd_msm* m, uint64_t seed, uint64_t first_index, size_t n, uint32_t mode);
+/* reads points [first, first + count) of the loaded / generated workload back (affine x || y, scalars; canonical LE) */
+int rlnamd_msm_fetch(rlnamd_msm* m, size_t first, size_t count, uint8_t* points_xy_le, uint8_t* scalars_le);
 size_t rlnamd_msm_window_sums_bytes(void);
 /* ms[0] digits + counting sort, ms[1] bucket accumulation, ms[2] bucket reduction */
 int rlnamd_msm_run(rlnamd_msm* m, uint8_t* window_sums, float ms[3]);
@@ -240,10 +258,10 @@ int rlnamd_comm_ranks(rlnamd_comm* c);
  * rank of the communicator calls it.  ms[0] digits + sort, ms[1] buckets, ms[2] all-gather, ms[3] combine (HIP events). */
 int rlnamd_msm_run_sharded(rlnamd_msm* m, rlnamd_comm* c, uint8_t out_xy_le[64], float ms[4]);
 /* the same for a caller that owns several devices in one process: a thread per device, generated points
- * (rlnamd_msm_generate at the rank's index range), `repeats` timed runs; ms[0..3] = max over devices of the stage times
+ * (rlnamd_msm_generate_mode at the rank's index range), `repeats` timed runs; ms[0..3] = max over devices of the stage times
  * of the last run, ms[4] = its wall time */
-int rlnamd_msm_generated_multi(const int* devices, size_t n_devices, uint64_t seed, size_t n_total, int repeats,
-                               uint8_t out_xy_le[64], float ms[5]);
+int rlnamd_msm_generated_multi(const int* devices, size_t n_devices, uint64_t seed, size_t n_total, uint32_t mode,
+                               int repeats, uint8_t out_xy_le[64], float ms[5]);
 
 #ifdef __cplusplus
 }

@@ -44,6 +44,23 @@ def lib():
         L.oracle_prove_many.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_char_p,
                                         C.POINTER(C.c_int)]
         L.oracle_tree_root.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_char_p]
+        L.oracle_msm_expected.restype = None
+        L.oracle_msm_expected.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_char_p]
+        L.oracle_msm_workload_item.restype = None
+        L.oracle_msm_workload_item.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_char_p, C.c_char_p]
+        L.oracle_msm_pippenger.restype = C.c_double
+        L.oracle_msm_pippenger.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, C.c_int, C.c_int, C.c_char_p,
+                                           C.POINTER(C.c_double)]
+        L.oracle_tree_new.restype = C.c_void_p
+        L.oracle_tree_new.argtypes = [C.c_int]
+        L.oracle_tree_free.argtypes = [C.c_void_p]
+        L.oracle_tree_set_range.restype = C.c_int
+        L.oracle_tree_set_range.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]
+        L.oracle_tree_get_root.argtypes = [C.c_void_p, C.c_char_p]
+        L.oracle_tree_proof.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_char_p]
+        L.oracle_tree_bench.restype = None
+        L.oracle_tree_bench.argtypes = [C.c_int, C.c_size_t, C.c_uint64, C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(C.c_double), C.c_char_p, C.c_char_p]
         _lib = L
     return _lib
 
@@ -132,6 +149,96 @@ def tree_root(depth, leaves):
     out = C.create_string_buffer(32)
     lib().oracle_tree_root(depth, b"".join(_b(v) for v in leaves), len(leaves), out)
     return int.from_bytes(out.raw, "little")
+
+
+def _xy(buf):
+    x, y = int.from_bytes(buf[:32], "little"), int.from_bytes(buf[32:64], "little")
+    return None if x == 0 and y == 0 else (x, y)
+
+
+# mode bits of the config-5 workload (rln_oracle.c "config 5"): the product's generator takes the same mask
+MSM_EQUAL_SCALARS = 1
+MSM_FOUR_POINTS = 2
+
+
+def msm_expected(seed, first, n, mode=0, threads=None):
+    """(sum k_i s_i mod r) G over the index range of the config-5 workload: the closed form the device MSM is
+    checked against at any size (2^24: ~1 s on 8 threads)"""
+    out = C.create_string_buffer(64)
+    lib().oracle_msm_expected(seed, first, n, mode, threads or usable_cores(), out)
+    return _xy(out.raw)
+
+
+def msm_workload_item(seed, i, mode=0):
+    """-> (point i of the workload as (x, y) or None, scalar i)"""
+    p, s = C.create_string_buffer(64), C.create_string_buffer(32)
+    lib().oracle_msm_workload_item(seed, i, mode, p, s)
+    return _xy(p.raw), int.from_bytes(s.raw, "little")
+
+
+def msm_pippenger(seed, first, n, mode=0, threads=None):
+    """msm_bigint's windowed Pippenger over the materialised workload -> (point, seconds of the MSM, seconds of the
+    untimed generation)"""
+    out, gen = C.create_string_buffer(64), C.c_double(0)
+    secs = lib().oracle_msm_pippenger(seed, first, n, mode, threads or usable_cores(), out, C.byref(gen))
+    return _xy(out.raw), secs, gen.value
+
+
+class Tree:
+    """FullMerkleTree restated in C (full_merkle_tree.rs): set_range / root / proof"""
+
+    def __init__(self, depth):
+        self.depth = depth
+        self.h = lib().oracle_tree_new(depth)
+
+    def close(self):
+        if self.h:
+            lib().oracle_tree_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_range(self, start, leaves, threads=1):
+        if lib().oracle_tree_set_range(self.h, start, b"".join(_b(v) for v in leaves), len(leaves), threads):
+            raise RuntimeError("oracle tree: range does not fit")
+
+    def set(self, index, leaf):
+        self.set_range(index, [leaf])
+
+    def root(self):
+        out = C.create_string_buffer(32)
+        lib().oracle_tree_get_root(self.h, out)
+        return int.from_bytes(out.raw, "little")
+
+    def proof(self, index):
+        e, b = C.create_string_buffer(32 * self.depth), C.create_string_buffer(max(self.depth, 1))
+        lib().oracle_tree_proof(self.h, index, e, b)
+        return ([int.from_bytes(e.raw[32 * i:32 * i + 32], "little") for i in range(self.depth)],
+                list(b.raw[:self.depth]))
+
+
+def tree_bench(depth, n, first_value=1, threads=None, singles=200, scattered=1000):
+    """CPU legs of config 3 and of the tree-mutation calls (see oracle_tree_bench)"""
+    out = (C.c_double * 4)()
+    root, root_after = C.create_string_buffer(32), C.create_string_buffer(32)
+    threads = threads or usable_cores()
+    lib().oracle_tree_bench(depth, n, first_value, threads, singles, scattered, out, root, root_after)
+    return dict(build_s=out[0], single_update_root_s=out[1], scattered_updates_root_s=out[2], paths_s=out[3],
+                root=int.from_bytes(root.raw, "little"), root_after_scattered=int.from_bytes(root_after.raw, "little"),
+                threads=threads, singles=singles, scattered=scattered)
+
+
+def scattered_updates(n, count, seed=0x5CA7, tag=0x5CA7000000000000):
+    """the (index, leaf) stream oracle_tree_bench applies in its scattered leg"""
+    M = (1 << 64) - 1
+
+    def sm(j):
+        z = (seed + (j + 1) * 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+    return [(sm(k) % n, tag + k) for k in range(count)]
 
 
 def usable_cores():

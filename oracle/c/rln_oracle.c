@@ -572,3 +572,237 @@ void oracle_tree_root(int depth, const uint8_t* leaves_le, size_t n, uint8_t roo
   for (size_t w = cap; w > 1; w >>= 1) for (size_t i = 0; i < w / 2; i++) { fe in[2] = {lvl[2 * i], lvl[2 * i + 1]}; poseidon(&lvl[i], in, 2); }
   fe_to_bytes(&FR, root_le, &lvl[0]); free(lvl);
 }
+
+/* ================================================================================================================
+ * Side configs of BASELINE.json (configs 3 and 5): closed forms and CPU baselines.  Test infrastructure as above.
+ * ================================================================================================================ */
+
+/* ------------------------------------------------------------------------------------------ config 5: one large MSM
+ * Workload: point i is P_i = k_i * G, its scalar is s_i, where k_i and
+ * s_i are the 253-bit values formed from words 8i..8i+3 and 8i+4..8i+7 of the SplitMix64(seed) stream (little-endian
+ * word order, top word masked to 61 bits).  Distribution variants (`mode`, a bit mask):
+ *   bit 0   every scalar equals s_0                 -> ONE bucket per window holds all n points
+ *   bit 1   k_i = k_(i mod 4)                       -> four distinct bases, every bucket meets its own point again
+ * What the reference computes on such an input is VariableBaseMSM::msm_bigint(bases, scalars) = sum s_i P_i
+ * (ark-ec 0.5.0; call sites rln/src/partial_proof.rs:98-104).  Because P_i = k_i G the same group element is
+ *   (sum_i k_i s_i mod r) * G
+ * which needs no curve arithmetic per point: this is the independent full-size check of the device MSM (the product
+ * carries no closed form of its own). */
+static inline u64 sm64_at(u64 seed, u64 j) {
+  u64 z = seed + (j + 1) * 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31);
+}
+static void msm_wl_k(u64 seed, u64 i, int mode, u64 k[4]) {
+  u64 j = (mode & 2) ? (i & 3) : i;
+  for (int q = 0; q < 4; q++) k[q] = sm64_at(seed, 8 * j + q);
+  k[3] &= 0x1FFFFFFFFFFFFFFFULL;
+}
+static void msm_wl_s(u64 seed, u64 i, int mode, u64 s[4]) {
+  u64 j = (mode & 1) ? 0 : i;
+  for (int q = 0; q < 4; q++) s[q] = sm64_at(seed, 8 * j + 4 + q);
+  s[3] &= 0x1FFFFFFFFFFFFFFFULL;
+}
+static const g1_aff* g1_generator(void) {
+  static g1_aff G; static int ready = 0;
+  if (!ready) { fe_set_u64(&FQ, &G.x, 1); fe_set_u64(&FQ, &G.y, 2); G.inf = 0; ready = 1; }
+  return &G;
+}
+typedef struct { u64 seed, lo, hi; int mode; fe acc; } cf_job;
+static void* cf_worker(void* a) {
+  cf_job* J = (cf_job*)a; fe acc; memset(&acc, 0, sizeof acc);
+  for (u64 i = J->lo; i < J->hi; i++) {
+    u64 k[4], s[4]; fe fk, fs, m; msm_wl_k(J->seed, i, J->mode, k); msm_wl_s(J->seed, i, J->mode, s);
+    fe_from_u64x4(&FR, &fk, k); fe_from_u64x4(&FR, &fs, s); fe_mul(&FR, &m, &fk, &fs); fe_add(&FR, &acc, &acc, &m);
+  }
+  J->acc = acc; return NULL;
+}
+/* (sum_{i in [first, first+n)} k_i s_i mod r) * G  ->  affine x | y, 32-byte little-endian each; (0, 0) = infinity */
+void oracle_msm_expected(u64 seed, u64 first, u64 n, int mode, int threads, uint8_t out_xy_le[64]) {
+  if (threads < 1) threads = 1;
+  if ((u64)threads > n) threads = n ? (int)n : 1;
+  cf_job* J = (cf_job*)calloc(threads, sizeof(cf_job)); pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
+  for (int t = 0; t < threads; t++) {
+    J[t].seed = seed; J[t].mode = mode; J[t].lo = first + n * t / threads; J[t].hi = first + n * (t + 1) / threads;
+    pthread_create(&th[t], NULL, cf_worker, &J[t]);
+  }
+  fe acc; memset(&acc, 0, sizeof acc);
+  for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); fe_add(&FR, &acc, &acc, &J[t].acc); }
+  free(J); free(th);
+  u64 e[4]; fe_to_u64x4(&FR, e, &acc);
+  g1_jac r; g1_mul(&r, g1_generator(), e); g1_aff a; g1_to_aff(&a, &r);
+  memset(out_xy_le, 0, 64);
+  if (!a.inf) { fe_to_bytes(&FQ, out_xy_le, &a.x); fe_to_bytes(&FQ, out_xy_le + 32, &a.y); }
+}
+/* the workload itself, for spot checks of the device generator: point i (affine x | y) and scalar i */
+void oracle_msm_workload_item(u64 seed, u64 i, int mode, uint8_t point_xy_le[64], uint8_t scalar_le[32]) {
+  u64 k[4], s[4]; msm_wl_k(seed, i, mode, k); msm_wl_s(seed, i, mode, s);
+  g1_jac r; g1_mul(&r, g1_generator(), k); g1_aff a; g1_to_aff(&a, &r);
+  memset(point_xy_le, 0, 64);
+  if (!a.inf) { fe_to_bytes(&FQ, point_xy_le, &a.x); fe_to_bytes(&FQ, point_xy_le + 32, &a.y); }
+  memcpy(scalar_le, s, 32);
+}
+
+/* CPU baseline of config 5: the points are materialised (fixed-base comb of G, batch-normalised -- untimed), then
+ * msm_bigint's windowed Pippenger runs over them with the windows spread over the host threads, which is how ark-ec's
+ * `parallel` feature spreads them (one rayon task per window, serial fold at the end). */
+typedef struct { const g1_aff* pts; const u64 (*sc)[4]; size_t n; int c, nw; g1_jac* wsum; int next; pthread_mutex_t mu; } pip_job;
+static void pip_window(const pip_job* J, int w, g1_jac* out) {
+  int c = J->c; size_t nb = ((size_t)1 << c) - 1;
+  g1_jac* buckets = (g1_jac*)malloc(nb * sizeof(g1_jac));
+  for (size_t b = 0; b < nb; b++) g1_jac_inf(&buckets[b]);
+  int bit = w * c;
+  for (size_t i = 0; i < J->n; i++) {
+    if (J->pts[i].inf) continue;
+    u64 lo = J->sc[i][bit >> 6] >> (bit & 63);
+    if ((bit & 63) + c > 64 && (bit >> 6) < 3) lo |= J->sc[i][(bit >> 6) + 1] << (64 - (bit & 63));
+    u64 d = lo & (((u64)1 << c) - 1);
+    if (d) g1_add_mixed(&buckets[d - 1], &buckets[d - 1], &J->pts[i]);
+  }
+  g1_jac run, ws; g1_jac_inf(&run); g1_jac_inf(&ws);
+  for (size_t b = nb; b-- > 0;) { g1_add(&run, &run, &buckets[b]); g1_add(&ws, &ws, &run); }
+  free(buckets); *out = ws;
+}
+static void* pip_worker(void* a) {
+  pip_job* J = (pip_job*)a;
+  for (;;) {
+    pthread_mutex_lock(&J->mu); int w = J->next++; pthread_mutex_unlock(&J->mu);
+    if (w >= J->nw) break;
+    pip_window(J, w, &J->wsum[w]);
+  }
+  return NULL;
+}
+typedef struct { u64 seed, first; size_t lo, hi; int mode; const g1_aff* comb; g1_aff* pts; u64 (*sc)[4]; } gen_job;
+static void* gen_worker(void* a) {
+  gen_job* J = (gen_job*)a; size_t m = J->hi - J->lo; if (!m) return NULL;
+  g1_jac* tmp = (g1_jac*)malloc(m * sizeof(g1_jac)); fe* pref = (fe*)malloc(m * sizeof(fe));
+  for (size_t t = 0; t < m; t++) {
+    u64 k[4]; msm_wl_k(J->seed, J->first + J->lo + t, J->mode, k); msm_wl_s(J->seed, J->first + J->lo + t, J->mode, J->sc[J->lo + t]);
+    g1_jac acc; g1_jac_inf(&acc);
+    for (int w = 0; w < 32; w++) { unsigned d = (unsigned)(k[w >> 3] >> ((w & 7) * 8)) & 255u; if (d) g1_add_mixed(&acc, &acc, &J->comb[w * 255 + d - 1]); }
+    tmp[t] = acc;
+  }
+  /* batch normalisation (Montgomery's trick) */
+  fe run; fe_one(&FQ, &run);
+  for (size_t t = 0; t < m; t++) { pref[t] = run; if (!fe_is_zero(&tmp[t].Z)) fe_mul(&FQ, &run, &run, &tmp[t].Z); }
+  fe inv; fe_inv(&FQ, &inv, &run);
+  for (size_t t = m; t-- > 0;) {
+    g1_aff* o = &J->pts[J->lo + t];
+    if (fe_is_zero(&tmp[t].Z)) { memset(o, 0, sizeof *o); o->inf = 1; continue; }
+    fe zi, zi2; fe_mul(&FQ, &zi, &inv, &pref[t]); fe_mul(&FQ, &inv, &inv, &tmp[t].Z);
+    fe_sqr(&FQ, &zi2, &zi); fe_mul(&FQ, &o->x, &tmp[t].X, &zi2); fe_mul(&FQ, &zi2, &zi2, &zi); fe_mul(&FQ, &o->y, &tmp[t].Y, &zi2); o->inf = 0;
+  }
+  free(tmp); free(pref); return NULL;
+}
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+/* returns the seconds of the Pippenger MSM alone; *gen_seconds = the untimed workload generation */
+double oracle_msm_pippenger(u64 seed, u64 first, size_t n, int mode, int threads, uint8_t out_xy_le[64], double* gen_seconds) {
+  if (threads < 1) threads = 1;
+  double t0 = now_s();
+  /* comb table of G: entry [w][d-1] = d * 2^(8w) * G */
+  g1_aff* comb = (g1_aff*)malloc(32 * 255 * sizeof(g1_aff));
+  g1_jac base; { g1_jac_inf(&base); g1_add_mixed(&base, &base, g1_generator()); }
+  for (int w = 0; w < 32; w++) {
+    g1_aff b; g1_to_aff(&b, &base); g1_jac e; g1_jac_inf(&e);
+    for (int d = 1; d <= 255; d++) { g1_add_mixed(&e, &e, &b); g1_to_aff(&comb[w * 255 + d - 1], &e); }
+    for (int k = 0; k < 8; k++) g1_dbl(&base, &base);
+  }
+  g1_aff* pts = (g1_aff*)malloc(n * sizeof(g1_aff)); u64(*sc)[4] = (u64(*)[4])malloc(n * sizeof(u64[4]));
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads); gen_job* G = (gen_job*)calloc(threads, sizeof(gen_job));
+  for (int t = 0; t < threads; t++) {
+    G[t] = (gen_job){seed, first, n * t / threads, n * (t + 1) / threads, mode, comb, pts, sc};
+    pthread_create(&th[t], NULL, gen_worker, &G[t]);
+  }
+  for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+  free(G); free(comb);
+  double t1 = now_s();
+  if (gen_seconds) *gen_seconds = t1 - t0;
+  /* ---- timed: msm_bigint */
+  pip_job J; J.pts = pts; J.sc = (const u64(*)[4])sc; J.n = n; J.next = 0; pthread_mutex_init(&J.mu, NULL);
+  { int c = 0; size_t m = n; while (m > 1) { m >>= 1; c++; } J.c = n < 32 ? 3 : c * 69 / 100 + 2; } /* ark-ec: ln(n) + 2 */
+  J.nw = (254 + J.c - 1) / J.c; J.wsum = (g1_jac*)malloc(J.nw * sizeof(g1_jac));
+  int nt = threads < J.nw ? threads : J.nw;
+  for (int t = 0; t < nt; t++) pthread_create(&th[t], NULL, pip_worker, &J);
+  for (int t = 0; t < nt; t++) pthread_join(th[t], NULL);
+  g1_jac total; g1_jac_inf(&total);
+  for (int w = J.nw - 1; w >= 0; w--) { for (int k = 0; k < J.c; k++) g1_dbl(&total, &total); g1_add(&total, &total, &J.wsum[w]); }
+  g1_aff a; g1_to_aff(&a, &total);
+  double t2 = now_s();
+  memset(out_xy_le, 0, 64);
+  if (!a.inf) { fe_to_bytes(&FQ, out_xy_le, &a.x); fe_to_bytes(&FQ, out_xy_le + 32, &a.y); }
+  free(J.wsum); free(th); free(pts); free(sc); pthread_mutex_destroy(&J.mu);
+  return t2 - t1;
+}
+
+/* ------------------------------------------------------------------------------------------ config 3: Merkle tree
+ * FullMerkleTree restated (utils/src/merkle_tree/full_merkle_tree.rs): flat node array, node i has children 2i+1 and
+ * 2i+2, leaves at capacity - 1 + index (:82-115); set_range writes the leaves and calls update_hashes, which recomputes
+ * the parents of the touched range level by level, in parallel when a level has many of them (:197-223, :360-399);
+ * set(index) is the one-leaf case: `depth` dependent hashes (:336-399). */
+typedef struct { int depth; size_t cap; fe* nodes; } otree;
+typedef struct { otree* T; size_t lo, hi; } lvl_job;
+static void* lvl_worker(void* a) {
+  lvl_job* J = (lvl_job*)a;
+  for (size_t p = J->lo; p < J->hi; p++) { fe in[2] = {J->T->nodes[2 * p + 1], J->T->nodes[2 * p + 2]}; poseidon(&J->T->nodes[p], in, 2); }
+  return NULL;
+}
+static void otree_update_hashes(otree* T, size_t start, size_t end, int threads) { /* inclusive node range on one level */
+  while (start > 0) {
+    size_t sp = ((start + 1) >> 1) - 1, ep = ((end + 1) >> 1) - 1, cnt = ep - sp + 1;
+    int nt = (threads > 1 && cnt >= 64) ? threads : 1; /* reference: MIN_PARALLEL_NODES = 8 on a rayon pool (merkle_tree.rs:18); threads are spawned per level here, so the cut is 64 */
+    if (nt == 1) { lvl_job J = {T, sp, ep + 1}; lvl_worker(&J); }
+    else {
+      pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * nt); lvl_job* J = (lvl_job*)malloc(sizeof(lvl_job) * nt);
+      for (int t = 0; t < nt; t++) { J[t] = (lvl_job){T, sp + cnt * t / nt, sp + cnt * (t + 1) / nt}; pthread_create(&th[t], NULL, lvl_worker, &J[t]); }
+      for (int t = 0; t < nt; t++) pthread_join(th[t], NULL);
+      free(th); free(J);
+    }
+    start = sp; end = ep;
+  }
+}
+void* oracle_tree_new(int depth) {
+  poseidon_init();
+  otree* T = (otree*)malloc(sizeof(otree)); T->depth = depth; T->cap = (size_t)1 << depth;
+  T->nodes = (fe*)calloc(2 * T->cap - 1, sizeof(fe));
+  /* ::new(depth, default_leaf = 0): every level holds the hash of two default children (:82-115) */
+  fe cur; memset(&cur, 0, sizeof cur);
+  for (int l = depth; l >= 0; l--) {
+    size_t lo = ((size_t)1 << l) - 1, n = (size_t)1 << l;
+    for (size_t i = 0; i < n; i++) T->nodes[lo + i] = cur;
+    fe in[2] = {cur, cur}; poseidon(&cur, in, 2);
+  }
+  return T;
+}
+void oracle_tree_free(void* h) { otree* T = (otree*)h; free(T->nodes); free(T); }
+int oracle_tree_set_range(void* h, size_t start, const uint8_t* leaves_le, size_t n, int threads) {
+  otree* T = (otree*)h; if (start + n > T->cap) return 1; if (!n) return 0;
+  size_t idx = T->cap - 1 + start;
+  for (size_t i = 0; i < n; i++) fe_from_bytes(&FR, &T->nodes[idx + i], leaves_le + 32 * i);
+  otree_update_hashes(T, idx, idx + n - 1, threads); return 0;
+}
+void oracle_tree_get_root(void* h, uint8_t root_le[32]) { fe_to_bytes(&FR, root_le, &((otree*)h)->nodes[0]); }
+void oracle_tree_proof(void* h, size_t leaf, uint8_t* elems_le, uint8_t* bits) { /* :288-304 */
+  otree* T = (otree*)h; size_t idx = T->cap - 1 + leaf; int k = 0;
+  while (idx > 0) { int right = !(idx & 1); fe_to_bytes(&FR, elems_le + 32 * k, &T->nodes[right ? idx - 1 : idx + 1]); bits[k++] = (uint8_t)right; idx = ((idx + 1) >> 1) - 1; }
+}
+/* CPU baseline of config 3 and of the tree-mutation calls: leaves i -> first_value + i (the product's config-3 workload).
+ * out[0] = seconds of the full build (set_range of n leaves, all threads), out[1] = seconds of ONE set(index) incl. the
+ * root read, averaged over `singles` calls, out[2] = seconds of `scattered` set() calls at pseudo-random indices followed
+ * by one root read (the reference pays depth hashes per call), out[3] = seconds of n membership proofs (path copies). */
+void oracle_tree_bench(int depth, size_t n, u64 first_value, int threads, int singles, int scattered, double out[4], uint8_t root_le[32],
+                       uint8_t root_after_le[32]) {
+  otree* T = (otree*)oracle_tree_new(depth);
+  uint8_t* leaves = (uint8_t*)calloc(n, 32);
+  for (size_t i = 0; i < n; i++) { u64 v = first_value + i; memcpy(leaves + 32 * i, &v, 8); }
+  double t0 = now_s(); oracle_tree_set_range(T, 0, leaves, n, threads); double t1 = now_s();
+  out[0] = t1 - t0; oracle_tree_get_root(T, root_le);
+  uint8_t* el = (uint8_t*)malloc(32 * depth); uint8_t* bits = (uint8_t*)malloc(depth);
+  t0 = now_s(); for (size_t i = 0; i < n; i++) oracle_tree_proof(T, i, el, bits); t1 = now_s(); out[3] = t1 - t0;
+  uint8_t leaf[32]; uint8_t r[32];
+  t0 = now_s();
+  for (int k = 0; k < singles; k++) { memset(leaf, 0, 32); u64 v = 0x5157000000000000ULL + k; memcpy(leaf, &v, 8); oracle_tree_set_range(T, (sm64_at(0x7EE, k) % n), leaf, 1, 1); oracle_tree_get_root(T, r); }
+  t1 = now_s(); out[1] = singles ? (t1 - t0) / singles : 0;
+  t0 = now_s();
+  for (int k = 0; k < scattered; k++) { memset(leaf, 0, 32); u64 v = 0x5CA7000000000000ULL + k; memcpy(leaf, &v, 8); oracle_tree_set_range(T, (sm64_at(0x5CA7, k) % n), leaf, 1, 1); }
+  oracle_tree_get_root(T, root_after_le); t1 = now_s(); out[2] = t1 - t0;
+  free(el); free(bits); free(leaves); oracle_tree_free(T);
+}

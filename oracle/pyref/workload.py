@@ -56,3 +56,32 @@ def config2_witnesses(n, seed=0xC0FFEE, depth=20):
         ws.append(w)
         rs.append((g.fr(), g.fr()))
     return ws, rs
+
+
+# ---------------------------------------------------------------------------------------------- config 5 workload
+def _sm64_at(seed, j):
+    z = (seed + (j + 1) * 0x9E3779B97F4A7C15) & MASK
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK
+    return z ^ (z >> 31)
+
+
+def msm_item(seed, i, mode=0):
+    """(k_i, s_i) of the config-5 workload: point i is k_i G, its scalar s_i; 253-bit values from words
+    8i..8i+3 / 8i+4..8i+7 of the SplitMix64 stream.  mode bit 0: every scalar is s_0; bit 1: k_i = k_(i mod 4)."""
+    j = (i & 3) if mode & 2 else i
+    k = sum(_sm64_at(seed, 8 * j + q) << (64 * q) for q in range(4)) & ((1 << 253) - 1)
+    j = 0 if mode & 1 else i
+    s = sum(_sm64_at(seed, 8 * j + 4 + q) << (64 * q) for q in range(4)) & ((1 << 253) - 1)
+    return k, s
+
+
+def msm_expected(seed, first, n, mode=0):
+    """msm_bigint(bases, scalars) on that workload (ark-ec 0.5.0; rln/src/partial_proof.rs:98-104) equals
+    (sum k_i s_i mod r) G -- Python ints; 2^18 terms take seconds"""
+    from .bn254 import G1, G1_GEN
+    acc = 0
+    for i in range(first, first + n):
+        k, s = msm_item(seed, i, mode)
+        acc = (acc + k * s) % R
+    return G1.mul(G1_GEN, acc) if acc else None

@@ -453,9 +453,15 @@ def test_config_path_is_parsed_before_any_device_is_needed(tmp_path):
         return msg
 
     assert "Error while reading pmtree config" in new('{"devices": [0, }')
+    # the devices list is read as strictly as serde_json reads a Vec: separators required, no trailing comma, no bare sign
+    for bad_list in ('[1 2]', '[1,]', '[-]', '[1,,2]', '["0"]', '[1.5]', '[0'):
+        assert "Error while reading pmtree config" in new('{"devices": %s}' % bad_list), bad_list
+    assert "negative device ordinal" in new('{"devices": [0, -1]}')
     assert "Error while reading pmtree config" in new('{"max_batch": }')
     assert "missing path" in new('{"temporary": false}')
     if lib().rlnamd_device_count() == 0:
         for ok_cfg in ('{"window_bits": 7150114, "max_batch": 1024}', '{"devices": [0, 1, 2, 3], "temporary": true}',
-                       '{"cache_capacity": 1073741824, "flush_every_ms": 500, "mode": "HighThroughput", "use_compression": false}'):
+                       '{"cache_capacity": 1073741824, "flush_every_ms": 500, "mode": "HighThroughput", "use_compression": false}',
+                       # unknown keys carry any JSON value (PmTreeConfig::from_str ignores them)
+                       '{"foo": ["a]", {"b": [1, 2]}], "bar": {"x": {"y": "}"}}, "devices": [0]}', '{"devices": []}'):
             assert "no HIP device" in new(ok_cfg)

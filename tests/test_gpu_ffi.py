@@ -529,6 +529,119 @@ def test_config_devices_puts_a_pool_behind_the_ffi_object(tmp_path):
         RLN(20, tree_config=str(cfgp))
 
 
+def test_deferred_tree_updates_with_reads_at_random_points_vs_oracle():
+    """ffi_set_leaf / ffi_set_next_leaf / ffi_delete_leaf only record the write; the first reader hashes the union of the
+    dirty paths in one pass (TreeAny::set_leaf).  A random stream of the mutation calls of rln/src/ffi/ffi_tree.rs with
+    reads (root, leaf, Merkle proof, leaves_set, a proof generated over the tree) at random points gives what
+    FullMerkleTree gives call by call (utils/src/merkle_tree/full_merkle_tree.rs:197-223,271-285,336-399), on the dense
+    depth-20 tree; rewrites of one index between two reads keep the last value; a burst of 3 000 writes between two reads
+    (every list kernel of the pass) and a range write over pending single writes included."""
+    from oracle.c import binding as ob
+    from zerokit_amd.public import RLN
+    rnd = random.Random(2024)
+    rln, o = RLN(20), ob.Tree(20)
+    nxt, written = 0, {}
+
+    def check_reads():
+        assert rln.get_root() == o.root()
+        i = rnd.choice(list(written) or [0])
+        assert rln.get_leaf(i) == written.get(i, 0)
+        elems, bits = rln.get_merkle_proof(i)
+        oe, obits = o.proof(i)
+        assert elems == oe and list(bits) == obits
+        assert rln.leaves_set() == nxt
+
+    assert rln.get_root() == o.root()
+    for step in range(400):
+        op = rnd.random()
+        if op < 0.45:
+            i, v = rnd.randrange(1 << 20) if rnd.random() < 0.7 else rnd.choice(list(written) or [3]), rnd.randrange(1, R)
+            rln.set_leaf(i, v)
+            o.set(i, v)
+            written[i] = v
+            nxt = max(nxt, i + 1)
+        elif op < 0.6:
+            v = rnd.randrange(1, R)
+            if nxt < (1 << 20):
+                rln.set_next_leaf(v)
+                o.set(nxt, v)
+                written[nxt] = v
+                nxt += 1
+        elif op < 0.7 and written:
+            i = rnd.choice(list(written))
+            rln.delete_leaf(i)
+            o.set(i, 0)
+            written[i] = 0
+        elif op < 0.75:
+            start, vals = rnd.randrange(1 << 19), [rnd.randrange(1, R) for _ in range(rnd.choice([2, 9, 64, 65, 300]))]
+            rln.set_leaves_from(start, vals)
+            o.set_range(start, vals)
+            for k, v in enumerate(vals):
+                written[start + k] = v
+            nxt = max(nxt, start + len(vals))
+        else:
+            check_reads()
+    check_reads()
+    # a burst: 3 000 scattered writes, two of them rewritten, then one read
+    burst = [(rnd.randrange(1 << 20), rnd.randrange(1, R)) for _ in range(3000)]
+    burst += [(burst[5][0], 777), (burst[6][0], 0)]
+    for i, v in burst:
+        rln.set_leaf(i, v)
+        o.set(i, v)
+        written[i] = v
+        nxt = max(nxt, i + 1)
+    check_reads()
+    # the witness of a proof is read from the tree after pending writes: the proof verifies against the oracle's root
+    from zerokit_amd import hashers
+    from zerokit_amd.public import RLNWitnessInput
+    secret = 987654321
+    rc = hashers.poseidon_hash_pair(hashers.poseidon_hash([secret]), 100)
+    rln.set_leaf(4242, rc)
+    o.set(4242, rc)
+    elems, bits = rln.get_merkle_proof(4242)
+    pr = rln.generate_rln_proof(RLNWitnessInput(secret, 100, 3, elems, bits, 11, 22))
+    assert pr.values.root == o.root() and rln.verify_rln_proof(pr, 11)
+    o.close()
+
+
+def test_current_device_is_unchanged_across_object_lifetime_and_devices_list_must_start_with_it(tmp_path):
+    """the calling thread's device is the same after ffi_rln_new / ffi_rln_free of an object with a device pool behind it
+    (~rlnamd_pool switches to each replica's device to free it, then back); a one-entry devices list is honoured; a list
+    that does not start with the current device is a configuration error"""
+    import ctypes as C
+    import json
+    from zerokit_amd import lib
+    from zerokit_amd._native import check
+    from zerokit_amd.public import RLN
+
+    def cur():
+        d = C.c_int(-1)
+        check(lib().rlnamd_get_device(C.byref(d)))
+        return d.value
+
+    before = cur()
+    cfgp = tmp_path / "cfg.json"
+    cfgp.write_text(json.dumps({"devices": [before, before], "max_batch": 64}))
+    r = RLN(20, tree_config=str(cfgp))
+    assert cur() == before
+    r.get_root()
+    del r
+    import gc
+    gc.collect()
+    assert cur() == before
+    cfgp.write_text(json.dumps({"devices": [before]}))
+    r = RLN(20, tree_config=str(cfgp))
+    assert r.get_root() == RLN(20).get_root()
+    del r
+    cfgp.write_text(json.dumps({"devices": [before + 1, before]}))
+    with pytest.raises(Exception, match="current device"):
+        RLN(20, tree_config=str(cfgp))
+    cfgp.write_text(json.dumps({"devices": []}))
+    with pytest.raises(Exception, match="empty list"):
+        RLN(20, tree_config=str(cfgp))
+    assert cur() == before
+
+
 def test_deep_tree_depth_40_sparse():
     """depths the dense HBM tree cannot hold (31 .. 63; the reference's OptimalMerkleTree allows < 64,
     utils/src/merkle_tree/optimal_merkle_tree.rs:15-41) take the sparse host-indexed tree with device hashing: a depth-40

@@ -314,6 +314,52 @@ def test_ffi_round_trip_like_reference_tests():
     assert a.get_root() == RLN(20).get_root() and a.leaves_set() == 0
 
 
+def test_tree_scattered_updates_one_pass_vs_oracle():
+    """rlnamd_tree_set_leaves: k single-leaf writes + ONE bottom-up pass over the union of their paths equals k set()
+    calls of FullMerkleTree (full_merkle_tree.rs:141-147,336-399) -- for k = 1 (the whole path in one launch), 21 / 84 /
+    85 / 86 (around the capacity of the single-workgroup tail), 1 000, 30 000 (more dirty parents than the three-lane
+    kernel takes) and on small depths (0, 1, 3); duplicates keep the last write; root, leaves and paths vs oracle/c"""
+    from oracle.c import binding as ob
+    from zerokit_amd.batch import PoseidonTree
+    rnd = random.Random(77)
+    for depth in (0, 1, 3):
+        t, o = PoseidonTree(depth), ob.Tree(depth)
+        ups = [(rnd.randrange(1 << depth), rnd.randrange(1, R)) for _ in range(5)]
+        t.set_leaves(ups)
+        for i, v in ups:
+            o.set(i, v)
+        assert t.root() == o.root()
+        t.close()
+        o.close()
+    depth = 20
+    t, o = PoseidonTree(depth), ob.Tree(depth)
+    t.fill_sequential(0, 1 << 14, 1)
+    o.set_range(0, list(range(1, (1 << 14) + 1)), threads=4)
+    assert t.root() == o.root()
+    for k in (1, 1, 21, 84, 85, 86, 1000, 30000):
+        ups = [(rnd.randrange(1 << depth), rnd.randrange(1, R)) for _ in range(k)]
+        if k >= 21:
+            ups += [(ups[0][0], 5), (ups[1][0], 0), (ups[0][0], 6)]      # rewrites: the last one wins
+        t.set_leaves(ups)
+        last = dict(ups)
+        for i, v in last.items():
+            o.set(i, v)
+        assert t.root() == o.root(), k
+        for i in list(last)[:3] + [0, (1 << depth) - 1]:
+            assert t.get(i) == last.get(i, t.get(i))
+            assert t.proof(i) == o.proof(i)
+    # neighbours: both children of one parent dirty, whole aligned blocks dirty
+    ups = [(i, 1000 + i) for i in range(4096, 4096 + 257)] + [(1 << 19, 1), ((1 << 19) + 1, 2)]
+    t.set_leaves(ups)
+    for i, v in ups:
+        o.set(i, v)
+    assert t.root() == o.root()
+    with pytest.raises(Exception):
+        t.set_leaves([(1 << depth, 1)])
+    t.close()
+    o.close()
+
+
 # ------------------------------------------------------------------------------------------ variable-base MSM
 def test_msm_g1_vs_oracle_small_and_edge_cases():
     """msm_bigint semantics on small inputs: random points/scalars vs the Python oracle, plus the edge cases
@@ -343,15 +389,21 @@ def test_msm_g1_vs_oracle_small_and_edge_cases():
 
 
 def test_msm_g1_generated_closed_form_and_split():
-    """config-5 workload at 2^16 points: result equals the scalar-side closed form (sum k_i s_i) G; splitting
-    the points into 4 slices (the per-GPU shards) and combining their window sums gives the same point
-    (linearity), as the 8-GPU all-gather does."""
+    """config-5 workload at 2^16 points: the generated points / scalars are the oracle's workload (spot check), the
+    result equals the ORACLE's closed form (sum k_i s_i) G (oracle/c and, independently, oracle/pyref), and splitting the
+    points into 4 slices (the per-GPU shards) and combining their window sums gives the same point (linearity), as the
+    8-GPU all-gather does."""
+    from oracle.c import binding as ob
+    from oracle.pyref import workload as owl
     from zerokit_amd.batch import MsmG1
     n, seed = 1 << 16, 0xC0FFEE
     m = MsmG1(n)
     m.generate(seed, 0, n)
+    for i in (0, 1, 63, 64, 4097, n - 1):
+        assert m.fetch(i, 1)[0] == ob.msm_workload_item(seed, i)
     blob, ms = m.run_windows()
-    want = MsmG1.expected(seed, 0, n)
+    want = ob.msm_expected(seed, 0, n)
+    assert want == owl.msm_expected(seed, 0, n)          # the two oracles agree (Python ints vs C limbs)
     assert m.combine([blob]) == want
     blobs = []
     q = n // 4
@@ -359,6 +411,54 @@ def test_msm_g1_generated_closed_form_and_split():
         m.generate(seed, r * q, q)
         blobs.append(m.run_windows()[0])
     assert m.combine(blobs) == want
+    m.close()
+
+
+def test_msm_g1_adversarial_distributions_vs_oracle():
+    """the size-dependent paths of the sort and of the bucket walk under skewed inputs, each against the oracle's closed
+    form AND (at 2^14) against the oracle's own Pippenger over the materialised points: every scalar equal (ONE bucket
+    per window holds all points -- a partition far above the LDS staging capacity, a bucket cut into thousands of slices
+    joined by the fix-up kernel), four distinct bases (a bucket keeps meeting a point it already holds), and both"""
+    from oracle.c import binding as ob
+    from zerokit_amd.batch import MsmG1
+    seed = 0xC0FFEE
+    n = 1 << 14
+    m = MsmG1(1 << 18)
+    for mode in (1, 2, 3):
+        m.generate(seed, 5, n, mode)
+        assert m.fetch(n - 1, 1)[0] == ob.msm_workload_item(seed, 5 + n - 1, mode)
+        got = m.combine([m.run_windows()[0]])
+        assert got == ob.msm_expected(seed, 5, n, mode), mode
+        assert got == ob.msm_pippenger(seed, 5, n, mode)[0], mode
+    n = 1 << 18
+    for mode in (1, 2, 3):
+        m.generate(seed, 0, n, mode)
+        assert m.combine([m.run_windows()[0]]) == ob.msm_expected(seed, 0, n, mode), mode
+    m.close()
+
+
+def test_msm_g1_config5_full_size_2_24_vs_oracle():
+    """BASELINE config 5 at FULL size: 2^24 generated points on one device against the oracle's closed form; the same
+    points as four 2^22 slices (the shards of a 4-way split) recombined from their window sums; and the all-equal-scalars
+    distribution at full size (16.7 M points in one bucket per window)."""
+    from oracle.c import binding as ob
+    from zerokit_amd.batch import MsmG1
+    n, seed = 1 << 24, 0xC0FFEE
+    want = ob.msm_expected(seed, 0, n)
+    m = MsmG1(n)
+    m.generate(seed, 0, n)
+    assert m.fetch(n - 1, 1)[0] == ob.msm_workload_item(seed, n - 1)
+    blob, ms = m.run_windows()
+    assert m.combine([blob]) == want
+    blobs, q = [], n // 4
+    for r in range(4):
+        m.generate(seed, r * q, q)
+        blobs.append(m.run_windows()[0])
+        assert m.combine(blobs[-1:]) == ob.msm_expected(seed, r * q, q)      # every shard by itself
+    assert m.combine(blobs) == want
+    m.generate(seed, 0, n, MsmG1.EQUAL_SCALARS)
+    assert m.combine([m.run_windows()[0]]) == ob.msm_expected(seed, 0, n, ob.MSM_EQUAL_SCALARS)
+    m.close()
 
 
 # ------------------------------------------------------------------------------------------ other circuits

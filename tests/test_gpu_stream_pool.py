@@ -105,6 +105,38 @@ def test_streamed_partial_and_finish_match_full(prover):
 
 
 # ---------------------------------------------------------------------------------------------------- pool
+def test_secrets_are_wiped_behind_collect_and_on_request(prover):
+    """the reference zeroises the identity secret and the witness calculator's inputs (rln/src/utils.rs:440-527,
+    rln/src/circuit/iden3calc.rs:45-56).  Here: after collect the slot's witness values read back as zeros and its
+    public signals are refused; the resident path keeps its witness for the parity taps until wipe(), then reads zeros;
+    proofs made after a wipe are unchanged"""
+    import ctypes as C
+    from zerokit_amd import lib, workload
+    from zerokit_amd._native import RLNError, check
+    ws, rs = workload.config2_range(300, 5)
+    ref = prover.prove(ws, rs)
+    w0 = prover.fetch_witness(0)
+    assert any(w0) and w0[0] == 1
+    prover.wipe()
+    assert not any(prover.fetch_witness(0)) and not any(prover.fetch_witness(4))
+    inp, rsb = prover.pack_inputs(ws), prover.pack_rs(rs)
+    t, n = prover.submit(inp, rsb)
+    got = prover.collect(t, n)
+    assert [g["proof"] for g in got] == [r["proof"] for r in ref]
+    assert not any(prover.fetch_witness(0))                     # the streamed batch's slot is the last run: wiped by collect
+    out = C.create_string_buffer(32 * 5 * 5)
+    assert lib().rlnamd_prover_collect_public(prover._h, t, 5, out) != 0
+    assert "wiped" in lib().rlnamd_last_error().decode()
+    # collect_public BEFORE collect is the supported order
+    t, n = prover.submit(inp, rsb)
+    check(lib().rlnamd_prover_collect_public(prover._h, t, 5, out))
+    pub0 = [int.from_bytes(out.raw[32 * k:32 * k + 32], "little") for k in range(5)]
+    assert pub0 == ref[0]["public_inputs"]
+    prover.collect(t, n)
+    assert prover.prove(ws, rs) == ref                          # nothing the next batch needs was wiped
+    assert any(prover.fetch_witness(0))
+
+
 def test_pool_of_one_and_two_replicas_on_one_device_equal_single_prover(prover):
     """rlnamd_pool: a pool of one replica and a pool of two replicas sharing device 0 return, index for index, the
     bytes of a single prover (ragged n = 301: shards of 128 + 173 proofs, chunks of 128)"""
@@ -131,8 +163,10 @@ def test_pool_of_one_and_two_replicas_on_one_device_equal_single_prover(prover):
 # ---------------------------------------------------------------------------------------------------- RCCL in C
 def test_msm_run_sharded_single_rank_communicator_vs_closed_form():
     """config 5 through the C ABI only: RCCL communicator of one rank (rlnamd_comm_init_rank), 2^18 generated points,
-    local Pippenger + ncclAllGather + fold == (sum k_i s_i) G; and the one-process multi-device entry with one device"""
+    local Pippenger + ncclAllGather + fold == the oracle's (sum k_i s_i) G; and the one-process multi-device entry with
+    one device"""
     import ctypes as C
+    from oracle.c import binding as ob
     from zerokit_amd import lib
     from zerokit_amd._native import check
     from zerokit_amd.batch import Comm, MsmG1
@@ -142,7 +176,7 @@ def test_msm_run_sharded_single_rank_communicator_vs_closed_form():
     m = MsmG1(n)
     m.generate(0xC0FFEE, 0, n)
     res, ms = m.run_sharded(comm)
-    assert res == MsmG1.expected(0xC0FFEE, 0, n)
+    assert res == ob.msm_expected(0xC0FFEE, 0, n)
     assert set(ms) == {"sort_ms", "buckets_ms", "all_gather_ms", "combine_ms"} and ms["buckets_ms"] > 0
     # same object, host-gather path: identical point
     blob, _ = m.run_windows()
@@ -152,7 +186,7 @@ def test_msm_run_sharded_single_rank_communicator_vs_closed_form():
     out = C.create_string_buffer(64)
     ms5 = (C.c_float * 5)()
     devs = (C.c_int * 1)(0)
-    check(lib().rlnamd_msm_generated_multi(devs, 1, 0xC0FFEE, n, 2, out, ms5))
+    check(lib().rlnamd_msm_generated_multi(devs, 1, 0xC0FFEE, n, 0, 2, out, ms5))
     assert (int.from_bytes(out.raw[:32], "little"), int.from_bytes(out.raw[32:], "little")) == res
 
 
@@ -210,7 +244,8 @@ def test_two_processes_sharing_the_device_msm_sharded_and_prove_sharded(prover):
         assert p.returncode == 0, se[-2000:]
     line = next(l for l in outs[0][0].splitlines() if l.startswith("RESULT "))
     got = json.loads(line[7:])
-    exp = MsmG1.expected(0xC0FFEE, 0, 1 << 18)
+    from oracle.c import binding as ob
+    exp = ob.msm_expected(0xC0FFEE, 0, 1 << 18)
     assert (int(got["msm"][0]), int(got["msm"][1])) == exp
     ws, rs = workload.config2_range(0, 37)
     ref = prover.prove(ws, rs)

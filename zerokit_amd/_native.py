@@ -85,6 +85,7 @@ SIGNATURES = {
     "rlnamd_last_error": (C.c_char_p, []),
     "rlnamd_device_count": (C.c_int, []),
     "rlnamd_set_device": (C.c_int, [C.c_int]),
+    "rlnamd_get_device": (C.c_int, [C.POINTER(C.c_int)]),
     "rlnamd_device_name": (C.c_int, [C.c_char_p, C.c_size_t]),
     "rlnamd_poseidon_hash": (C.c_int, [C.c_char_p, C.c_size_t, C.c_size_t, C.c_char_p]),
     "rlnamd_hash_to_field_le": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     "rlnamd_tree_new": (C.c_int, [C.c_size_t, PP]),
     "rlnamd_tree_free": (None, [P]),
     "rlnamd_tree_set_range": (C.c_int, [P, C.c_size_t, C.c_char_p, C.c_size_t]),
+    "rlnamd_tree_set_leaves": (C.c_int, [P, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]),
     "rlnamd_tree_root": (C.c_int, [P, C.c_char_p]),
     "rlnamd_tree_get_leaf": (C.c_int, [P, C.c_size_t, C.c_char_p]),
     "rlnamd_tree_proof": (C.c_int, [P, C.c_size_t, C.c_char_p, C.c_char_p]),
@@ -135,7 +137,8 @@ SIGNATURES = {
     "rlnamd_msm_free": (None, [P]),
     "rlnamd_msm_set": (C.c_int, [P, C.c_char_p, C.c_char_p, C.c_size_t]),
     "rlnamd_msm_generate": (C.c_int, [P, C.c_uint64, C.c_uint64, C.c_size_t]),
-    "rlnamd_msm_expected": (C.c_int, [C.c_uint64, C.c_uint64, C.c_size_t, C.c_char_p]),
+    "rlnamd_msm_generate_mode": (C.c_int, [P, C.c_uint64, C.c_uint64, C.c_size_t, C.c_uint32]),
+    "rlnamd_msm_fetch": (C.c_int, [P, C.c_size_t, C.c_size_t, C.c_char_p, C.c_char_p]),
     "rlnamd_msm_window_sums_bytes": (C.c_size_t, []),
     "rlnamd_msm_run": (C.c_int, [P, C.c_char_p, C.POINTER(C.c_float)]),
     "rlnamd_msm_combine": (C.c_int, [P, C.c_char_p, C.c_size_t, C.c_char_p]),
@@ -146,6 +149,7 @@ SIGNATURES = {
     "rlnamd_prover_collect": (C.c_int, [P, C.c_uint64, C.c_size_t, C.c_char_p, C.c_char_p, C.c_char_p,
                                        C.POINTER(C.c_uint32), C.c_char_p]),
     "rlnamd_prover_collect_public": (C.c_int, [P, C.c_uint64, C.c_size_t, C.c_char_p]),
+    "rlnamd_prover_wipe": (C.c_int, [P]),
     "rlnamd_prover_prove_stream": (C.c_int, [P, C.c_size_t, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
                                             C.POINTER(C.c_uint32)]),
     "rlnamd_pool_new": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_size_t, C.c_int,
@@ -165,7 +169,7 @@ SIGNATURES = {
     "rlnamd_comm_rank": (C.c_int, [P]),
     "rlnamd_comm_ranks": (C.c_int, [P]),
     "rlnamd_msm_run_sharded": (C.c_int, [P, P, C.c_char_p, C.POINTER(C.c_float)]),
-    "rlnamd_msm_generated_multi": (C.c_int, [C.POINTER(C.c_int), C.c_size_t, C.c_uint64, C.c_size_t, C.c_int,
+    "rlnamd_msm_generated_multi": (C.c_int, [C.POINTER(C.c_int), C.c_size_t, C.c_uint64, C.c_size_t, C.c_uint32, C.c_int,
                                             C.c_char_p, C.POINTER(C.c_float)]),
     # ---- rln.h
     "ffi_rln_new": (CResultPtr, [C.c_size_t, C.c_char_p]),

@@ -187,6 +187,10 @@ class BatchProver:
         check(lib().rlnamd_prover_submit(self._h, n, inputs, rsb, mode, pp, C.byref(t)))
         return int(t.value), n
 
+    def wipe(self):
+        """overwrite the resident inputs and the last run's witness values (the streamed calls do it by themselves)"""
+        check(lib().rlnamd_prover_wipe(self._h))
+
     def collect_raw(self, ticket, n):
         """waits for that batch only -> (proofs bytes n*128, values bytes n*160, errors list)"""
         proofs = C.create_string_buffer(128 * n)
@@ -433,6 +437,12 @@ class PoseidonTree:
     def set(self, index, leaf):
         self.set_range(index, [leaf])
 
+    def set_leaves(self, updates):
+        """[(index, leaf)] in any order, later entries win: ONE bottom-up pass over the union of the dirty paths"""
+        k = len(updates)
+        idx = (C.c_uint64 * max(k, 1))(*[int(i) for i, _ in updates])
+        check(lib().rlnamd_tree_set_leaves(self._h, idx, b"".join(_b(v) for _, v in updates), k))
+
     def root(self):
         out = C.create_string_buffer(32)
         check(lib().rlnamd_tree_root(self._h, out))
@@ -495,14 +505,22 @@ class MsmG1:
         pb = b"".join((_b(0) + _b(0)) if p is None else (_b(p[0], _Q) + _b(p[1], _Q)) for p in points)
         check(lib().rlnamd_msm_set(self._h, pb, b"".join(_b(s) for s in scalars), len(points)))
 
-    def generate(self, seed, first_index, n):
-        check(lib().rlnamd_msm_generate(self._h, seed, first_index, n))
+    EQUAL_SCALARS, FOUR_POINTS = 1, 2
 
-    @staticmethod
-    def expected(seed, first_index, n):
-        out = C.create_string_buffer(64)
-        check(lib().rlnamd_msm_expected(seed, first_index, n, out))
-        return int.from_bytes(out.raw[:32], "little"), int.from_bytes(out.raw[32:], "little")
+    def generate(self, seed, first_index, n, mode=0):
+        """config-5 workload in HBM (P_i = k_i G, s_i from the SplitMix64 stream); the expected sum is not ours to
+        state -- tests and bench.py take it from the oracle (oracle.c.binding.msm_expected)"""
+        check(lib().rlnamd_msm_generate_mode(self._h, seed, first_index, n, mode))
+
+    def fetch(self, first, count):
+        """-> [(point (x, y) or None, scalar)] of the loaded / generated workload"""
+        p, s = C.create_string_buffer(64 * count), C.create_string_buffer(32 * count)
+        check(lib().rlnamd_msm_fetch(self._h, first, count, p, s))
+        out = []
+        for i in range(count):
+            x, y = int.from_bytes(p.raw[64 * i:64 * i + 32], "little"), int.from_bytes(p.raw[64 * i + 32:64 * i + 64], "little")
+            out.append((None if x == 0 and y == 0 else (x, y), int.from_bytes(s.raw[32 * i:32 * i + 32], "little")))
+        return out
 
     def run_windows(self):
         """-> (window-sum blob to all-gather, stage ms dict)"""

@@ -52,6 +52,12 @@ int rlnamd_set_device(int ordinal) {
   RLN_CATCH
 }
 
+int rlnamd_get_device(int* ordinal) {
+  RLN_TRY
+  RLN_HIP(hipGetDevice(ordinal));
+  RLN_CATCH
+}
+
 int rlnamd_device_name(char* buf, size_t cap) {
   RLN_TRY
   require_gpu();
@@ -117,6 +123,29 @@ int rlnamd_tree_set_range(rlnamd_tree* t, size_t start, const uint8_t* leaves_le
     if (limbs_geq(tmp, FrParams::MOD)) throw Error("field element is not canonical (>= modulus)");
   }
   t->t.set_range_host(start, leaves_le, n);
+  RLN_CATCH
+}
+int rlnamd_tree_set_leaves(rlnamd_tree* t, const uint64_t* indices, const uint8_t* leaves_le, size_t k) {
+  RLN_TRY
+  // any order, later entries win: brought to the strictly increasing form the pass wants
+  std::vector<std::pair<uint64_t, size_t>> ord(k);
+  for (size_t i = 0; i < k; i++) {
+    uint32_t tmp[8];
+    memcpy(tmp, leaves_le + 32 * i, 32);
+    if (limbs_geq(tmp, FrParams::MOD)) throw Error("field element is not canonical (>= modulus)");
+    if (indices[i] >= t->t.capacity()) throw Error("TooManySet");
+    ord[i] = {indices[i], i};
+  }
+  std::stable_sort(ord.begin(), ord.end(), [](const std::pair<uint64_t, size_t>& a, const std::pair<uint64_t, size_t>& b) { return a.first < b.first; });
+  std::vector<uint64_t> idx;
+  std::vector<uint8_t> leaves;
+  for (size_t i = 0; i < k; i++) {
+    if (i + 1 < k && ord[i + 1].first == ord[i].first) continue;   // the last write to an index wins
+    idx.push_back(ord[i].first);
+    leaves.insert(leaves.end(), leaves_le + 32 * ord[i].second, leaves_le + 32 * ord[i].second + 32);
+  }
+  t->t.set_scattered(idx.data(), leaves.data(), idx.size());
+  RLN_HIP(hipStreamSynchronize(t->t.stream));
   RLN_CATCH
 }
 int rlnamd_tree_root(rlnamd_tree* t, uint8_t out_le[32]) {
@@ -331,6 +360,11 @@ int rlnamd_prover_walk_clock_mhz(rlnamd_prover* p, double mhz[2]) {
 }
 const char* rlnamd_prover_stage_name(int i) { return (i >= 0 && i < PROVER_STAGES) ? kProverStageNames[i] : ""; }
 
+int rlnamd_prover_wipe(rlnamd_prover* p) {
+  RLN_TRY
+  p->p->wipe(0);
+  RLN_CATCH
+}
 int rlnamd_prover_fetch_witness(rlnamd_prover* p, size_t index, uint8_t* out_le) {
   RLN_TRY
   std::vector<uint8_t> w;
@@ -396,9 +430,15 @@ int rlnamd_msm_generate(rlnamd_msm* m, uint64_t seed, uint64_t first_index, size
   m->m->generate(seed, first_index, n);
   RLN_CATCH
 }
-int rlnamd_msm_expected(uint64_t seed, uint64_t first_index, size_t n, uint8_t out_xy_le[64]) {
+int rlnamd_msm_generate_mode(rlnamd_msm* m, uint64_t seed, uint64_t first_index, size_t n, uint32_t mode) {
   RLN_TRY
-  MsmG1::expected_generated(seed, first_index, n, out_xy_le);
+  if (mode > 3) throw Error("rlnamd_msm_generate_mode: unknown mode bits");
+  m->m->generate(seed, first_index, n, mode);
+  RLN_CATCH
+}
+int rlnamd_msm_fetch(rlnamd_msm* m, size_t first, size_t count, uint8_t* points_xy_le, uint8_t* scalars_le) {
+  RLN_TRY
+  m->m->fetch(first, count, points_xy_le, scalars_le);
   RLN_CATCH
 }
 size_t rlnamd_msm_window_sums_bytes(void) { return MsmG1::window_sums_bytes(); }

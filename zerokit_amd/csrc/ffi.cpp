@@ -358,7 +358,18 @@ std::string json_str_array(const std::vector<std::string>& v) {
 }  // namespace
 
 // -------------------------------------------------------------------------------------- object model
+// the reference's IdSecret zeroises itself when dropped (rln/src/utils.rs:440-527: Zeroize + ZeroizeOnDrop); the stores
+// go through a volatile pointer so that they cannot be elided as dead
+static void secure_zero(void* p, size_t n) {
+  volatile uint8_t* v = (volatile uint8_t*)p;
+  for (size_t i = 0; i < n; i++) v[i] = 0;
+}
+struct ZeroOnExit {   // host staging copies of witness inputs / (r, s) / externally computed witnesses
+  std::vector<uint8_t>& v;
+  ~ZeroOnExit() { secure_zero(v.data(), v.size()); }
+};
 struct FFI_RLNWitnessInput {  // RLNWitnessInput (protocol/witness.rs:44-58): SingleV1 or MultiV1
+  ~FFI_RLNWitnessInput() { secure_zero(&identity_secret, sizeof identity_secret); }
   CFr identity_secret, user_message_limit, message_id;
   std::vector<CFr> path_elements;
   std::vector<uint8_t> identity_path_index;
@@ -379,6 +390,7 @@ struct FFI_RLNProof {
 };
 
 struct FFI_RLNPartialWitnessInput {  // RLNPartialWitnessInput (protocol/witness.rs:62-73)
+  ~FFI_RLNPartialWitnessInput() { secure_zero(&identity_secret, sizeof identity_secret); }
   CFr identity_secret, user_message_limit;
   std::vector<CFr> path_elements;
   std::vector<uint8_t> identity_path_index;
@@ -409,6 +421,7 @@ struct TreeConfig {
   // (BASELINE config 4: 65 536 = 8 x 8 192).  Everything else -- single proofs, the tree, verification -- runs on the
   // first listed device, which must be the calling thread's current device (device 0 unless the host chose otherwise).
   std::vector<int> devices;
+  bool has_devices = false;
   bool persistent() const { return !temporary && has_path; }
   ProverConfig prover_config() const {
     ProverConfig cfg;
@@ -463,22 +476,52 @@ TreeConfig parse_tree_config(const std::string& js) {
       if (key == "temporary") c.temporary = v;
     } else if (!js.compare(i, 4, "null")) {
       i += 4;
-    } else if (js[i] == '[') {   // an array of integers ("devices"); other arrays are skipped
+    } else if (js[i] == '[' && key == "devices") {
+      // strict, as serde_json would read a Vec<i32>: `[` (int (`,` int)*)? `]`, no trailing comma, no bare `-`
       std::vector<int> vals;
       i++;
-      for (;;) {
-        ws();
-        if (i >= js.size()) throw bad("EOF while parsing a list");
-        if (js[i] == ']') { i++; break; }
-        size_t j = i;
-        while (j < js.size() && (isdigit((unsigned char)js[j]) || js[j] == '-')) j++;
-        if (j == i) throw bad("expected value");
-        vals.push_back(atoi(js.substr(i, j - i).c_str()));
-        i = j;
-        ws();
-        if (i < js.size() && js[i] == ',') i++;
+      ws();
+      if (i < js.size() && js[i] == ']') {
+        i++;
+      } else {
+        for (;;) {
+          ws();
+          size_t j = i;
+          if (j < js.size() && js[j] == '-') j++;
+          size_t d0 = j;
+          while (j < js.size() && isdigit((unsigned char)js[j])) j++;
+          if (j == d0 || j - d0 > 9) throw bad("expected value");
+          vals.push_back(atoi(js.substr(i, j - i).c_str()));
+          i = j;
+          ws();
+          if (i >= js.size()) throw bad("EOF while parsing a list");
+          if (js[i] == ',') { i++; continue; }
+          if (js[i] == ']') { i++; break; }
+          throw bad("expected `,` or `]`");
+        }
       }
-      if (key == "devices") c.devices = vals;
+      for (int d : vals)
+        if (d < 0) throw Error("Configuration error: devices: negative device ordinal");
+      c.devices = vals;
+      c.has_devices = true;
+    } else if (js[i] == '[' || js[i] == '{') {
+      // any other array / object (a key this library does not know): skipped as a whole, like serde ignores unknown fields
+      int depth = 0;
+      bool in_str = false;
+      for (; i < js.size(); i++) {
+        const char ch = js[i];
+        if (in_str) {
+          if (ch == '\\') i++;
+          else if (ch == '"') in_str = false;
+          continue;
+        }
+        if (ch == '"') in_str = true;
+        else if (ch == '[' || ch == '{') depth++;
+        else if (ch == ']' || ch == '}') {
+          if (--depth == 0) { i++; break; }
+        }
+      }
+      if (depth != 0) throw bad("EOF while parsing a value");
     } else if (isdigit((unsigned char)js[i]) || js[i] == '-') {
       size_t j = i;
       while (j < js.size() && (isdigit((unsigned char)js[j]) || strchr("+-.eE", js[j]))) j++;
@@ -527,8 +570,20 @@ struct FFI_RLN {
   std::mutex prove_mu;
   std::shared_ptr<Prover> prover;   // owned, or replica 0 of `pool` (then the pool owns it)
   rlnamd_pool* pool = nullptr;      // config "devices" with two or more entries: batch calls shard over the devices
+  // The object lives on ONE device -- its tree, its prover (replica 0 of a pool) and every later call from the caller's
+  // thread use the CURRENT device -- so a "devices" list must start with the device that is current when the object is
+  // made; anything else would put the tree and the single proofs on another GPU than the one the list names.
+  int home_device = 0;
   void make_prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_t graph_len, const TreeConfig& tcfg) {
     const ProverConfig cfg = tcfg.prover_config();
+    if (hipGetDevice(&home_device) != hipSuccess) home_device = 0;
+    if (tcfg.has_devices) {
+      if (tcfg.devices.empty()) throw Error("Configuration error: devices: empty list");
+      if (tcfg.devices[0] != home_device)
+        throw Error("Configuration error: devices: the list starts with device " + std::to_string(tcfg.devices[0]) +
+                    " but the calling thread's current device is " + std::to_string(home_device) +
+                    " (the object's tree and single proofs live on the current device: make it current first)");
+    }
     if (tcfg.devices.size() >= 2) {
       if (rlnamd_pool_new(zkey, zkey_len, graph, graph_len, cfg.max_batch, cfg.window_bits, tcfg.devices.data(),
                           tcfg.devices.size(), &pool) != RLNAMD_OK)
@@ -649,9 +704,13 @@ struct FFI_RLN {
     for (size_t i = 0; i < leaves.size() && !leaf_set.empty(); i++) leaf_set[start + i] = 1;
     next_index = std::max(next_index, start + leaves.size());
   }
-  void set(size_t index, const CFr& leaf) {  // :141-147
+  // one leaf (:141-147).  The write is recorded and hashed by the first reader, together with every other write made
+  // until then (TreeAny::set_leaf): ONE pass over the union of the dirty paths instead of `depth` dependent hashes per call
+  void set(size_t index, const CFr& leaf) {
     if (index >= tree.capacity()) throw Error("set_range got too many leaves");
-    set_range(index, {leaf});
+    tree.set_leaf(index, leaf.le);
+    if (!leaf_set.empty()) leaf_set[index] = 1;
+    next_index = std::max(next_index, index + 1);
   }
   CFr get(size_t index) {
     if (index >= tree.capacity()) throw Error("Leaf index out of bounds");
@@ -825,6 +884,18 @@ void values_from_public(const uint8_t* pub, size_t mo, FFI_RLNProofValues* v) {
   for (size_t k = 0; k < mo; k++) v->selector_used.push_back(cfr_is_zero(at(2 * mo + 3 + k)) ? 0 : 1);
 }
 
+// Every resident-input run below ends with the prover's copies of the inputs and of the witness overwritten (the
+// reference zeroises the witness calculator's inputs buffer, circuit/iden3calc.rs:45-56), on the error paths as well.
+struct WipeResident {
+  Prover& P;
+  ~WipeResident() {
+    try {
+      P.wipe(0);
+    } catch (...) {
+    }
+  }
+};
+
 // generate_rln_proof for a slice of witnesses (public.rs:624-631)
 void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CFr* rs, FFI_RLNProof** out) {
   std::lock_guard<std::mutex> guard(rln.prove_mu);
@@ -849,6 +920,8 @@ void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CF
     if (n <= P.capacity()) {
       // one batch: the latency path (a single proof walks with lanes = chunks, see Prover::run_async)
       std::vector<uint8_t> inputs, rsb;
+      ZeroOnExit z1{inputs}, z2{rsb};
+      WipeResident wr{P};
       pack(0, n, inputs, rsb);
       std::vector<ProofOut> po(n);
       P.prove(n, inputs.data(), rsb.data(), po.data());
@@ -865,6 +938,7 @@ void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CF
     } else if (rln.pool && !multi) {
       // several devices behind the object: contiguous index shards, one per replica, each streamed (rlnamd_pool_prove)
       std::vector<uint8_t> inputs, rsb, proofs(n * 128), values(n * 160);
+      ZeroOnExit z1{inputs}, z2{rsb};
       std::vector<uint32_t> errs(n);
       pack(0, n, inputs, rsb);
       if (rlnamd_pool_prove(rln.pool, n, inputs.data(), rsb.data(), proofs.data(), values.data(), errs.data()) != RLNAMD_OK)
@@ -887,6 +961,7 @@ void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CF
       struct Pending { uint64_t ticket; size_t m; };
       std::deque<Pending> q;
       std::vector<uint8_t> inputs, rsb, proofs, values, pub;
+      ZeroOnExit z1{inputs}, z2{rsb};
       std::vector<uint32_t> errs;
       auto take = [&]() {
         Pending f = q.front();
@@ -894,8 +969,11 @@ void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CF
         proofs.resize(f.m * 128);
         values.resize(f.m * 160);
         errs.resize(f.m);
-        P.collect(f.ticket, f.m, proofs.data(), values.data(), errs.data());
-        if (multi) P.collect_public(f.ticket, f.m, &pub);
+        P.collect(f.ticket, f.m, proofs.data(), values.data(), errs.data(), nullptr, nullptr, !multi);
+        if (multi) {
+          P.collect_public(f.ticket, f.m, &pub);
+          P.wipe(f.ticket);
+        }
         for (size_t i = 0; i < f.m; i++) {
           if (errs[i]) throw Error("Error calculating witness: graph evaluation failed (code " + std::to_string(errs[i]) + ")");
           std::unique_ptr<FFI_RLNProof> pr(new FFI_RLNProof);
@@ -947,6 +1025,8 @@ FFI_RLNProof* prove_with_witness(FFI_RLN& rln, const Vec_String_t* calc, const F
     throw Error("Error producing proof: malformed verifying key (witness has " + std::to_string(given.size() / 32) +
                 " entries, the circuit " + std::to_string(P.num_signals()) + ")");
   std::vector<uint8_t> inputs(P.inputs_per_proof() * 32), rs(64);
+  ZeroOnExit z1{inputs}, z2{rs}, z3{given};
+  WipeResident wr{P};
   fill_inputs(P, w, inputs.data());
   CFr r = random_fr(), sb = random_fr();
   memcpy(rs.data(), r.le, 32);
@@ -983,6 +1063,8 @@ FFI_RLNPartialProof* prove_partial(FFI_RLN& rln, const FFI_RLNPartialWitnessInpu
   w.x = cfr_from_u64(0);
   w.external_nullifier = cfr_from_u64(0);
   std::vector<uint8_t> inputs(P.inputs_per_proof() * 32), rs(64, 0);
+  ZeroOnExit z1{inputs};
+  WipeResident wr{P};
   fill_inputs(P, w, inputs.data());
   P.upload(1, inputs.data(), rs.data());
   P.run(1, PROVE_PARTIAL);
@@ -1003,6 +1085,8 @@ FFI_RLNProof* finish_proof(FFI_RLN& rln, const FFI_RLNPartialProof& pp, const FF
   if (pp.mask.size() + 1 != known.size() || !std::equal(pp.mask.begin(), pp.mask.end(), known.begin() + 1))
     throw Error("Error producing proof: the partial proof's mask does not match this circuit (malformed verifying key)");
   std::vector<uint8_t> inputs(P.inputs_per_proof() * 32), rs(64);
+  ZeroOnExit z1{inputs}, z2{rs};
+  WipeResident wr{P};
   fill_inputs(P, w, inputs.data());
   memcpy(rs.data(), r.le, 32);
   memcpy(rs.data() + 32, s.le, 32);
@@ -1728,8 +1812,8 @@ CBoolResult_t ffi_set_metadata(FFI_RLN_t** rln, const Vec_uint8_t* metadata) {
 CResult_Vec_uint8_Vec_uint8_t ffi_get_metadata(FFI_RLN_t* const* rln) {
   return guard_bytes([&]() { return RLNM(rln).metadata; });
 }
-CBoolResult_t ffi_flush(FFI_RLN_t** rln) {  // temporary trees: nothing to do, the tree lives in HBM
-  return guard_bool([&]() { RLNM(rln).flush(); return true; });
+CBoolResult_t ffi_flush(FFI_RLN_t** rln) {  // deferred leaf writes are hashed now; persistent trees write their snapshot
+  return guard_bool([&]() { RLNM(rln).tree.flush_pending(); RLNM(rln).flush(); return true; });
 }
 
 // ================================================================================ CFr / Vec helpers
@@ -1758,7 +1842,10 @@ CResult_CFr_ptr_Vec_uint8_t ffi_bytes_be_to_cfr(const Vec_uint8_t* bytes) {
 }
 CFr_t* ffi_uint_to_cfr(uint32_t value) { return box_cfr(cfr_from_u64(value)); }
 Vec_uint8_t ffi_cfr_debug(const CFr_t* cfr) { return make_str(cfr ? cfr_dec(R(cfr)) : "None"); }
-void ffi_cfr_free(CFr_t* cfr) { free(cfr); }
+void ffi_cfr_free(CFr_t* cfr) {   // a CFr may be an identity secret (keygen): cleared before it goes back to the heap
+  if (cfr) secure_zero(cfr, sizeof(CFr));
+  free(cfr);
+}
 
 Vec_CFr_t ffi_vec_cfr_new(size_t capacity) {
   size_t cap = capacity ? capacity : 1;
@@ -1799,7 +1886,10 @@ Vec_uint8_t ffi_vec_cfr_debug(const Vec_CFr_t* v) {
   for (size_t i = 0; i < v->len; i++) s += (i ? ", " : "") + cfr_dec(((const CFr*)v->ptr)[i]);
   return make_str(s + "]");
 }
-void ffi_vec_cfr_free(Vec_CFr_t v) { free(v.ptr); }
+void ffi_vec_cfr_free(Vec_CFr_t v) {   // keygen hands the secrets out as a Vec<CFr>
+  if (v.ptr) secure_zero(v.ptr, v.len * sizeof(CFr));
+  free(v.ptr);
+}
 
 static std::vector<uint8_t> vec_u8_bytes(const Vec_uint8_t* v, bool be) {  // utils.rs:158-190
   std::vector<uint8_t> b;

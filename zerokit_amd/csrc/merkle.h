@@ -19,6 +19,17 @@ struct MerkleTreeDev {
   DevBuf<uint32_t> canon;  // bulk path emission: the nodes in canonical form, converted once per call (lazily allocated)
   std::vector<Fr> zero_hashes;  // [level] Montgomery, level 0 = root ... depth = leaf
   hipStream_t stream = 0;
+  // staging of set_scattered: leaf indices, dirty-node lists and leaves of one pass (pinned host + device copy)
+  DevBuf<uint32_t> scat_dev;
+  uint32_t* scat_host = nullptr;
+  size_t scat_cap = 0;
+
+  MerkleTreeDev() = default;
+  ~MerkleTreeDev();
+  MerkleTreeDev(MerkleTreeDev&&) noexcept;
+  MerkleTreeDev& operator=(MerkleTreeDev&&) noexcept;
+  MerkleTreeDev(const MerkleTreeDev&) = delete;
+  MerkleTreeDev& operator=(const MerkleTreeDev&) = delete;
 
   void init(int depth_, const uint8_t default_leaf_le[32]);  // FullMerkleTree::new :82-115
   size_t capacity() const { return (size_t)1 << depth; }
@@ -27,6 +38,9 @@ struct MerkleTreeDev {
   // write `n` canonical LE leaves starting at leaf index `start`, then rehash (set_range :197-223).
   void set_range_host(size_t start, const uint8_t* leaves_le, size_t n);
   void set_range_device(size_t start, const uint8_t* d_leaves_le, size_t n);
+  // k leaves at strictly increasing indices `idx`, then ONE bottom-up pass over the union of their paths (the parents of
+  // what changed, level by level; the top levels in a single launch).  Stream-ordered: returns without a host wait.
+  void set_scattered(const uint64_t* idx, const uint8_t* leaves_le, size_t k);
   // leaves i -> Fr(first + i): synthetic fill generated on the device (bench / config 3), then rehash
   void fill_sequential_device(size_t start, size_t n, uint64_t first);
   void rehash(size_t lo_node, size_t hi_node);  // update_hashes :360-399

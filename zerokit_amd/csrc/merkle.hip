@@ -39,6 +39,63 @@ __global__ void __launch_bounds__(64) k_hash_parents_l3(Fr* __restrict__ nodes, 
   if (active && j == 0) nodes[p] = h;
 }
 
+// ---- union of dirty paths (deferred single-leaf updates, MerkleTreeDev::set_scattered): a level is a LIST of parents
+__global__ void __launch_bounds__(256) k_scatter_leaves(Fr* __restrict__ nodes, size_t first_leaf_node,
+                                                        const uint32_t* __restrict__ idx, const uint32_t* __restrict__ leaves_le,
+                                                        uint32_t k) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= k) return;
+  nodes[first_leaf_node + idx[i]] = Fr::from_canonical(leaves_le + (size_t)i * 8);
+}
+__global__ void __launch_bounds__(256) k_hash_parents_list(Fr* __restrict__ nodes, const uint32_t* __restrict__ list,
+                                                           uint32_t count, PoseidonView pv) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  size_t p = list[i];
+  Fr in[2] = {nodes[2 * p + 1], nodes[2 * p + 2]};
+  nodes[p] = poseidon_hash_dev<3>(in, pv);
+}
+__global__ void __launch_bounds__(64) k_hash_parents_l3_list(Fr* __restrict__ nodes, const uint32_t* __restrict__ list,
+                                                             uint32_t count, PoseidonView pv) {
+  __shared__ __attribute__((aligned(16))) uint32_t sh[66 * 12];
+  const uint32_t lane = threadIdx.x, g = lane / 3, j = lane % 3;
+  const uint32_t i = blockIdx.x * 21 + g;
+  const bool active = lane < 63 && i < count;
+  const size_t p = active ? list[i] : 0;
+  Fr in = Fr::zero();
+  if (active && j != 0) in = nodes[2 * p + j];
+  const Fr h = poseidon_hash3_lanes(in, pv, sh);
+  if (active && j == 0) nodes[p] = h;
+}
+// The top of a dirty-path pass -- every level from `first` up to the root -- in ONE launch: a single update is 20
+// dependent hashes, and as 20 launches each paid its launch latency on top of the hash.  One workgroup of TAIL_WAVES
+// waves, 21 three-lane hashes per wave and step; a level's results reach the next level through HBM (the workgroup's
+// own CU: workgroup-scope visibility after the barrier).  levels[l] = [off[l], off[l + 1]) of `list`, bottom-up.
+constexpr uint32_t TAIL_WAVES = 4, TAIL_HASHES = 21 * TAIL_WAVES;
+struct LevelOffsets {
+  uint32_t off[34];
+};
+__global__ void __launch_bounds__(64 * TAIL_WAVES) k_hash_tail_list(Fr* __restrict__ nodes, const uint32_t* __restrict__ list,
+                                                                    LevelOffsets lo, int first, int nlevels, PoseidonView pv) {
+  __shared__ __attribute__((aligned(16))) uint32_t sh_all[TAIL_WAVES][66 * 12];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane / 3, j = lane % 3;
+  uint32_t* sh = sh_all[wave];
+  for (int l = first; l < nlevels; l++) {
+    const uint32_t b = lo.off[l], cnt = lo.off[l + 1] - b;
+    for (uint32_t i0 = 0; i0 < cnt; i0 += TAIL_HASHES) {
+      const uint32_t i = i0 + wave * 21 + g;
+      const bool active = lane < 63 && i < cnt;
+      const size_t p = active ? list[b + i] : 0;
+      Fr in = Fr::zero();
+      if (active && j != 0) in = nodes[2 * p + j];
+      const Fr h = poseidon_hash3_lanes(in, pv, sh);
+      if (active && j == 0) nodes[p] = h;
+    }
+    __threadfence();
+    __syncthreads();
+  }
+}
+
 // zero_hashes[depth] = default leaf; zero_hashes[l] = H(z[l+1], z[l+1])  -- single lane, init only
 __global__ void k_zero_hashes(Fr* zh, int depth, PoseidonView pv) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -290,6 +347,88 @@ void MerkleTreeDev::set_range_host(size_t start, const uint8_t* leaves_le, size_
   RLN_HIP(hipMemcpyAsync(tmp.p, leaves_le, n * 32, hipMemcpyHostToDevice, stream));
   set_range_device(start, tmp.p, n);
   RLN_HIP(hipStreamSynchronize(stream));
+}
+
+// One bottom-up pass over the UNION of the dirty paths of k scattered leaves: level by level only the parents of what
+// changed below are rehashed (update_hashes :360-399 applied to a set instead of a range).  k single-leaf updates cost
+// one ~depth-level pass instead of k of them.  idx: strictly increasing leaf indices; stream-ordered, no host wait.
+void MerkleTreeDev::set_scattered(const uint64_t* idx, const uint8_t* leaves_le, size_t k) {
+  if (k == 0) return;
+  if (k > 0xFFFFFFFFull) throw Error("TooManySet");
+  for (size_t i = 0; i < k; i++)
+    if (idx[i] >= capacity() || (i && idx[i] <= idx[i - 1])) throw Error("set_scattered: indices must be increasing and inside the tree");
+  // host side: the dirty node lists, bottom-up.  Heap indices fit 32 bits (depth <= 30).
+  LevelOffsets lo{};
+  std::vector<uint32_t> lists;
+  {
+    std::vector<uint64_t> cur(k);
+    for (size_t i = 0; i < k; i++) cur[i] = capacity() - 1 + idx[i];
+    for (int l = 0; l < depth; l++) {
+      lo.off[l] = (uint32_t)lists.size();
+      size_t m = 0;
+      for (size_t i = 0; i < cur.size(); i++) {
+        uint64_t p = (cur[i] - 1) >> 1;
+        if (m == 0 || cur[m - 1] != p) cur[m++] = p;
+      }
+      cur.resize(m);
+      for (uint64_t p : cur) lists.push_back((uint32_t)p);
+    }
+    lo.off[depth] = (uint32_t)lists.size();
+  }
+  // staging: [k leaf indices][lists][k x 32 B leaves], pinned; the previous pass may still be reading it
+  const size_t words = k + lists.size() + 8 * k;
+  RLN_HIP(hipStreamSynchronize(stream));
+  if (scat_cap < words) {
+    if (scat_host) (void)hipHostFree(scat_host);
+    scat_host = nullptr;
+    scat_cap = std::max<size_t>(words, 4096);
+    RLN_HIP(hipHostMalloc((void**)&scat_host, scat_cap * 4, hipHostMallocDefault));
+    scat_dev.alloc(scat_cap);
+  }
+  for (size_t i = 0; i < k; i++) scat_host[i] = (uint32_t)idx[i];
+  if (!lists.empty()) memcpy(scat_host + k, lists.data(), lists.size() * 4);
+  memcpy(scat_host + k + lists.size(), leaves_le, 32 * k);
+  RLN_HIP(hipMemcpyAsync(scat_dev.p, scat_host, words * 4, hipMemcpyHostToDevice, stream));
+  const uint32_t* d_idx = scat_dev.p;
+  const uint32_t* d_list = scat_dev.p + k;
+  const uint32_t* d_leaves = scat_dev.p + k + lists.size();
+  hipLaunchKernelGGL(k_scatter_leaves, dim3(div_up(k, 256)), dim3(256), 0, stream, nodes.p, capacity() - 1, d_idx, d_leaves,
+                     (uint32_t)k);
+  PoseidonView pv = poseidon_view(3);
+  int l = 0;
+  for (; l < depth; l++) {
+    const uint32_t cnt = lo.off[l + 1] - lo.off[l];
+    if (cnt <= TAIL_HASHES) break;   // counts only shrink towards the root: the rest is one launch
+    if (cnt <= 21 * 1024)
+      hipLaunchKernelGGL(k_hash_parents_l3_list, dim3(div_up(cnt, 21)), dim3(64), 0, stream, nodes.p, d_list + lo.off[l], cnt, pv);
+    else
+      hipLaunchKernelGGL(k_hash_parents_list, dim3(div_up(cnt, 256)), dim3(256), 0, stream, nodes.p, d_list + lo.off[l], cnt, pv);
+  }
+  if (l < depth)
+    hipLaunchKernelGGL(k_hash_tail_list, dim3(1), dim3(64 * TAIL_WAVES), 0, stream, nodes.p, d_list, lo, l, depth, pv);
+  RLN_HIP(hipGetLastError());
+}
+
+MerkleTreeDev::~MerkleTreeDev() {
+  if (scat_host) (void)hipHostFree(scat_host);
+}
+MerkleTreeDev::MerkleTreeDev(MerkleTreeDev&& o) noexcept { *this = std::move(o); }
+MerkleTreeDev& MerkleTreeDev::operator=(MerkleTreeDev&& o) noexcept {
+  if (this != &o) {
+    if (scat_host) (void)hipHostFree(scat_host);
+    depth = o.depth;
+    nodes = std::move(o.nodes);
+    canon = std::move(o.canon);
+    zero_hashes = std::move(o.zero_hashes);
+    stream = o.stream;
+    scat_dev = std::move(o.scat_dev);
+    scat_host = o.scat_host;
+    scat_cap = o.scat_cap;
+    o.scat_host = nullptr;
+    o.scat_cap = 0;
+    o.depth = 0;
+  }
+  return *this;
 }
 
 void MerkleTreeDev::fill_sequential_device(size_t start, size_t n, uint64_t first_value) {

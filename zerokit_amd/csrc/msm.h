@@ -13,8 +13,10 @@ class MsmG1 {
   // points: n x (x || y) canonical LE, (0,0) = infinity; scalars: n x 32 canonical LE
   void set_host(const uint8_t* points_xy_le, const uint8_t* scalars_le, size_t n);
   // synthetic workload generated in HBM: P_i = k_i G, s_i from SplitMix64(seed) at global index first_index + i
-  void generate(uint64_t seed, uint64_t first_index, size_t n);
-  static void expected_generated(uint64_t seed, uint64_t first_index, size_t n, uint8_t out_xy_le[64]);
+  // mode bit 0: every scalar is s_0; bit 1: k_i = k_(i mod 4).  The expected sum is the oracle's business, not ours.
+  void generate(uint64_t seed, uint64_t first_index, size_t n, uint32_t mode = 0);
+  // reads loaded / generated points [first, first + count) back: affine x || y and scalars, canonical LE
+  void fetch(size_t first, size_t count, uint8_t* points_xy_le, uint8_t* scalars_le);
   // Pippenger up to one point per window; `window_sums_out` receives window_sums_bytes() bytes.
   // ms[0] = digits + counting sort, ms[1] = bucket accumulation, ms[2] = bucket reduction (HIP events)
   void run_windows(uint8_t* window_sums_out, float ms[3]);

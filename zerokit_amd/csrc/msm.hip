@@ -44,22 +44,19 @@ __device__ __forceinline__ uint64_t splitmix_at(uint64_t seed, uint64_t j) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
   return z ^ (z >> 31);
 }
-static uint64_t splitmix_at_host(uint64_t seed, uint64_t j) {
-  uint64_t z = seed + (j + 1) * 0x9E3779B97F4A7C15ULL;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-  return z ^ (z >> 31);
-}
 
-// synthetic workload: P_i = k_i * G, scalar s_i; k_i, s_i 253-bit values of the stream
-__global__ void __launch_bounds__(64) k_gen(uint64_t seed, uint64_t first, uint32_t n, G1Affine* __restrict__ pts,
-                                            uint32_t* __restrict__ scal) {
+// synthetic workload: P_i = k_i * G, scalar s_i; k_i, s_i 253-bit values of the stream.
+// mode bit 0: every scalar is s_0 (one bucket per window receives every point); bit 1: k_i = k_(i mod 4) (four distinct
+// bases).  The expected result of a run is NOT computed here: tests and bench.py take it from the oracle.
+__global__ void __launch_bounds__(64) k_gen(uint64_t seed, uint64_t first, uint32_t n, uint32_t mode,
+                                            G1Affine* __restrict__ pts, uint32_t* __restrict__ scal) {
   uint32_t t = blockIdx.x * 64 + threadIdx.x;
   if (t >= n) return;
   uint64_t i = first + t;
+  const uint64_t ik = (mode & 2) ? (i & 3) : i, is = (mode & 1) ? 0 : i;
   uint32_t k[8], s[8];
   for (int q = 0; q < 4; q++) {
-    uint64_t a = splitmix_at(seed, 8 * i + q), b = splitmix_at(seed, 8 * i + 4 + q);
+    uint64_t a = splitmix_at(seed, 8 * ik + q), b = splitmix_at(seed, 8 * is + 4 + q);
     k[2 * q] = (uint32_t)a;
     k[2 * q + 1] = (uint32_t)(a >> 32);
     s[2 * q] = (uint32_t)b;
@@ -532,40 +529,28 @@ void MsmG1::set_host(const uint8_t* points_xy_le, const uint8_t* scalars_le, siz
   D.n = n;
 }
 
-void MsmG1::generate(uint64_t seed, uint64_t first_index, size_t n) {
+void MsmG1::generate(uint64_t seed, uint64_t first_index, size_t n, uint32_t mode) {
   Impl& D = *d_;
   if (n > D.cap) throw Error("MSM larger than the workspace");
-  hipLaunchKernelGGL(k_gen, dim3(div_up(n, 64)), dim3(64), 0, D.s, seed, first_index, (uint32_t)n, D.pts.p, D.scal.p);
+  hipLaunchKernelGGL(k_gen, dim3(div_up(n, 64)), dim3(64), 0, D.s, seed, first_index, (uint32_t)n, mode, D.pts.p, D.scal.p);
   RLN_HIP(hipGetLastError());
   RLN_HIP(hipStreamSynchronize(D.s));
   D.n = n;
 }
 
-// closed form of the synthetic workload: (sum k_i s_i mod r) * G, computed on the host (scalar side only)
-void MsmG1::expected_generated(uint64_t seed, uint64_t first_index, size_t n, uint8_t out_xy_le[64]) {
-  Fr acc = Fr::zero();
-  for (uint64_t i = first_index; i < first_index + n; i++) {
-    uint32_t k[8], s[8];
-    for (int q = 0; q < 4; q++) {
-      uint64_t a = splitmix_at_host(seed, 8 * i + q), b = splitmix_at_host(seed, 8 * i + 4 + q);
-      k[2 * q] = (uint32_t)a;
-      k[2 * q + 1] = (uint32_t)(a >> 32);
-      s[2 * q] = (uint32_t)b;
-      s[2 * q + 1] = (uint32_t)(b >> 32);
-    }
-    k[7] &= 0x1FFFFFFFu;
-    s[7] &= 0x1FFFFFFFu;
-    acc = acc + Fr::from_canonical(k) * Fr::from_canonical(s);
+void MsmG1::fetch(size_t first, size_t count, uint8_t* points_xy_le, uint8_t* scalars_le) {
+  Impl& D = *d_;
+  if (first + count > D.n) throw Error("MSM fetch: range outside the loaded points");
+  std::vector<G1Affine> p(count);
+  RLN_HIP(hipMemcpy(p.data(), D.pts.p + first, count * sizeof(G1Affine), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < count; i++) {
+    uint32_t c[8];
+    p[i].x.to_canonical(c);
+    memcpy(points_xy_le + 64 * i, c, 32);
+    p[i].y.to_canonical(c);
+    memcpy(points_xy_le + 64 * i + 32, c, 32);
   }
-  uint32_t e[8];
-  acc.to_canonical(e);
-  G1Affine g{Fq::from_u32(1), Fq::from_u32(2)};
-  G1Affine r = scalar_mul(g, e).to_affine();
-  uint32_t c[8];
-  r.x.to_canonical(c);
-  memcpy(out_xy_le, c, 32);
-  r.y.to_canonical(c);
-  memcpy(out_xy_le + 32, c, 32);
+  RLN_HIP(hipMemcpy(scalars_le, D.scal.p + first * 8, count * 32, hipMemcpyDeviceToHost));
 }
 
 void MsmG1::run_windows(uint8_t* window_sums_out, float ms[3]) {

@@ -80,6 +80,8 @@ struct rlnamd_pool {
       R->prover.reset(new Prover(zkey, zkey_len, graph, graph_len, cfg));
     } catch (const std::exception& e) {
       R->error = e.what();
+    } catch (...) {
+      R->error = "unknown exception while building the replica";
     }
     {
       std::lock_guard<std::mutex> lk(done_mu);
@@ -105,6 +107,8 @@ struct rlnamd_pool {
         }
       } catch (const std::exception& e) {
         R->error = e.what();
+      } catch (...) {
+        R->error = "unknown exception in the replica's worker";
       }
       {
         std::lock_guard<std::mutex> dl(done_mu);
@@ -124,11 +128,15 @@ struct rlnamd_pool {
     }
     for (auto& R : rep)
       if (R->th.joinable()) R->th.join();
-    // the Prover of a replica frees device memory: do it with its device current
+    // the Prover of a replica frees device memory: do it with its device current, and leave the CALLER's device as it
+    // was (hipSetDevice is per-thread state; the thread that frees an RLN object goes on using its own device)
+    int prev = -1;
+    (void)hipGetDevice(&prev);
     for (auto& R : rep) {
       (void)hipSetDevice(R->device);
       R->prover.reset();
     }
+    if (prev >= 0) (void)hipSetDevice(prev);
   }
 };
 
@@ -297,8 +305,8 @@ int rlnamd_comm_ranks(rlnamd_comm* c) { return c->nranks; }
 // One MSM over n_total generated points sharded over the devices of THIS process: a thread per device, each with its
 // own MsmG1 on its slice and its rank of one communicator.  ms[0..3]: max over the devices of sort / buckets /
 // all-gather / combine; ms[4] = wall time of the slowest device including the host wait.
-int rlnamd_msm_generated_multi(const int* devices, size_t n_devices, uint64_t seed, size_t n_total, int repeats,
-                               uint8_t out_xy_le[64], float ms[5]) {
+int rlnamd_msm_generated_multi(const int* devices, size_t n_devices, uint64_t seed, size_t n_total, uint32_t mode,
+                               int repeats, uint8_t out_xy_le[64], float ms[5]) {
   RLN_TRY
   require_gpu();
   if (!devices || n_devices == 0) throw Error("rlnamd_msm_generated_multi: no devices");
@@ -309,26 +317,64 @@ int rlnamd_msm_generated_multi(const int* devices, size_t n_devices, uint64_t se
   std::vector<std::array<float, 5>> t(N);
   std::vector<std::array<uint8_t, 64>> res(N);
   std::vector<std::thread> th;
+  // Two phases.  Setup (device, workspace, generated points) can fail on one rank only -- out of memory on one GPU --
+  // and a rank that never reaches its ncclAllGather leaves the others blocked in theirs for ever.  So every thread
+  // reports its setup, all meet at a host barrier, and the collective loop is entered only when every rank is ready.
+  std::mutex bmu;
+  std::condition_variable bcv;
+  size_t arrived = 0;
+  bool all_ok = true;
+  auto abort_all = [&] {
+    std::lock_guard<std::mutex> lk(bmu);
+    for (auto* c : comms)
+      if (c->comm) {
+        (void)ncclCommAbort(c->comm);
+        c->comm = nullptr;
+      }
+  };
   for (size_t i = 0; i < N; i++)
     th.emplace_back([&, i] {
+      std::unique_ptr<MsmG1> m;
+      std::string err;
       try {
         RLN_HIP(hipSetDevice(devices[i]));
         size_t lo = n_total * i / N, hi = n_total * (i + 1) / N;
-        MsmG1 m(hi - lo ? hi - lo : 1);
-        m.generate(seed, lo, hi - lo);
+        m.reset(new MsmG1(hi - lo ? hi - lo : 1));
+        m->generate(seed, lo, hi - lo, mode);
+      } catch (const std::exception& e) {
+        err = e.what();
+      } catch (...) {
+        err = "unknown exception during setup";
+      }
+      {
+        std::unique_lock<std::mutex> lk(bmu);
+        if (!err.empty()) all_ok = false;
+        if (++arrived == N) bcv.notify_all();
+        else bcv.wait(lk, [&] { return arrived == N; });
+        if (!all_ok) {
+          errs[i] = err;
+          return;
+        }
+      }
+      try {
         for (int r = 0; r < std::max(1, repeats); r++) {
           auto t0 = std::chrono::steady_clock::now();
-          m.run_sharded(comms[i]->comm, (int)N, res[i].data(), t[i].data());
+          m->run_sharded(comms[i]->comm, (int)N, res[i].data(), t[i].data());
           t[i][4] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
       } catch (const std::exception& e) {
         errs[i] = e.what();
+        abort_all();   // release the ranks blocked in the collective
+      } catch (...) {
+        errs[i] = "unknown exception in the collective phase";
+        abort_all();
       }
     });
   for (auto& x : th) x.join();
   for (auto* c : comms) rlnamd_comm_free(c);
   for (size_t i = 0; i < N; i++)
     if (!errs[i].empty()) throw Error("device " + std::to_string(devices[i]) + ": " + errs[i]);
+  if (!all_ok) throw Error("rlnamd_msm_generated_multi: setup failed");
   for (size_t i = 1; i < N; i++)
     if (memcmp(res[i].data(), res[0].data(), 64) != 0) throw Error("ranks disagree on the MSM result");
   memcpy(out_xy_le, res[0].data(), 64);

@@ -251,10 +251,10 @@ __device__ __forceinline__ Fr poseidon_hash_dev(const Fr* in, const PoseidonView
 //                  broadcast x = s_0'; slot 4  lane 0: p_0 = row0[0] x   lanes 1, 2: s_i += u_i x
 //                  lanes 1, 2 hand p_i to lane 0: s_0 = p_0 + p_1 + p_2                            4 product slots
 // instead of 9 + 6 and 7.5 on one lane: the same field operations (bit-identical output), 1.8 x less latency.
-// Call with all 64 lanes of a single-wave workgroup; lane l works for triple l / 3 (lane 63 idles); `sh` is 66 x 12
-// words of LDS.  `in`: the input of this lane (lanes 1 and 2 of the triple; ignored on lane 0); the hash is returned on lane 0.
+// Call with all 64 lanes of every wave of the workgroup (the waves meet at the same barriers: same trip counts); lane l of
+// a wave works for triple l / 3 (lane 63 idles); `sh` is 66 x 12 words of LDS PER WAVE.  `in`: the input of this lane (lanes 1 and 2 of the triple; ignored on lane 0); the hash is returned on lane 0.
 __device__ __forceinline__ Fr poseidon_hash3_lanes(const Fr& in, const PoseidonView& pv, uint32_t* sh) {
-  const uint32_t lane = threadIdx.x, j = lane % 3, base = lane - j;
+  const uint32_t lane = threadIdx.x & 63, j = lane % 3, base = lane - j;
   auto put = [&](const Fr29& x) {
     uint32_t* d = sh + lane * 12;
     *(uint4*)d = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);

@@ -88,8 +88,14 @@ class Prover {
   // submits later.  This is the path of SURVEY 8(d)'s timed region: H2D of witness inputs -> D2H of proofs.
   uint64_t submit(size_t n, const uint8_t* inputs, const uint8_t* rs, int mode = PROVE_FULL,
                   const uint8_t* partial320 = nullptr);
+  // wipe_after (default): the batch's inputs -- pinned staging and device copies -- its (r, s) and its witness values are
+  // overwritten behind the copy-out (the reference zeroises the identity secret and the witness calculator's inputs,
+  // rln/src/utils.rs:440-527, circuit/iden3calc.rs:45-56).  Pass false to read more of the batch (collect_public), then
+  // call wipe(ticket).
   void collect(uint64_t ticket, size_t n, uint8_t* proofs, uint8_t* values, uint32_t* errors, uint8_t* coords = nullptr,
-               uint8_t* partial320 = nullptr);
+               uint8_t* partial320 = nullptr, bool wipe_after = true);
+  // ticket 0: the resident-input path (upload / run / download keeps its data for the fetch_* taps until this is called)
+  void wipe(uint64_t ticket = 0);
   void collect_public(uint64_t ticket, size_t n, std::vector<uint8_t>* out_le);
   int slots() const;
   // n proofs (any n) through submit / collect in chunks of <= capacity(), results in index order

@@ -1142,6 +1142,22 @@ __global__ void __launch_bounds__(64) k_stage_in(const uint4* __restrict__ src, 
   if (i < n16) dst[i] = src[i];
 }
 
+// Zeroisation of what a finished batch leaves behind.  The reference zeroises the identity secret wherever it holds it
+// (IdSecret: Zeroize + ZeroizeOnDrop, rln/src/utils.rs:440-527) and the witness calculator's inputs buffer
+// (circuit/iden3calc.rs:45-56).  Here the secret sits in the inputs of the batch and in its witness values: columns
+// [0, n) of the stored rows of V (rows == nullptr: every row) and of V29.
+__global__ void __launch_bounds__(64) k_wipe_cols(Fr* __restrict__ V, const uint32_t* __restrict__ rows, uint32_t nrows,
+                                                  uint32_t B, uint32_t n) {
+  const uint32_t p = blockIdx.x * 64 + threadIdx.x, r = blockIdx.y;
+  if (p >= n || r >= nrows) return;
+  V[(size_t)(rows ? rows[r] : r) * B + p] = Fr::zero();
+}
+__global__ void __launch_bounds__(64) k_wipe_v29(uint4* __restrict__ V29, uint32_t nrows, uint32_t B, uint32_t n) {
+  const uint32_t j = blockIdx.x * 64 + threadIdx.x, r = blockIdx.y;
+  if (j >= 3 * n || r >= nrows) return;
+  V29[(size_t)r * B * 3 + j] = make_uint4(0, 0, 0, 0);
+}
+
 // =====================================================================================================
 // host side
 // =====================================================================================================
@@ -1176,6 +1192,7 @@ struct Slot {
   hipEvent_t t[15] = {};  // timing marks
   bool used = false;
   bool marked = false;          // the timing marks t[] of the slot's batch were recorded
+  bool wiped = false;           // the batch's inputs and witness values have been overwritten (Prover::wipe)
   size_t n = 0;
 };
 
@@ -1251,6 +1268,42 @@ struct Prover::Impl {
   int cur = 0;
   Slot* last = nullptr;
   uint64_t tickets = 0;         // submit() tickets handed out
+
+  // Overwrites what batch `S` knew about its witnesses (see k_wipe_cols): the slot's staged inputs (pinned host + device),
+  // its (r, s) and the witness values, on the back-end stream behind the batch's last reader; evC is recorded again, so
+  // whoever reuses the slot -- or reads the resident inputs next -- waits for the wipe as well.
+  size_t batch_cap = 0;   // = Prover::B_
+  void wipe_slot(Slot& S, bool resident) {
+    const size_t n = S.n ? S.n : batch_cap;
+    const size_t B = batch_cap;
+    if (!n) return;
+    RLN_HIP(hipStreamWaitEvent(sC, S.evC, 0));
+    if (resident) {
+      RLN_HIP(hipMemsetAsync(inputs.p, 0, std::min(inputs.bytes(), n * (size_t)NI * 32), sC));
+      RLN_HIP(hipMemsetAsync(rs.p, 0, std::min(rs.bytes(), n * 64), sC));
+      if (wgiven.p) RLN_HIP(hipMemsetAsync(wgiven.p, 0, wgiven.bytes(), sC));
+      wgiven_n = 0;
+    } else {
+      volatile uint8_t* h = S.h_in;   // volatile: the stores may not be elided (explicit_bzero semantics)
+      for (size_t i = 0; i < n * (size_t)NI * 32; i++) h[i] = 0;
+      for (size_t i = 0; i < n * 64; i++) h[B * (size_t)NI * 32 + i] = 0;
+      RLN_HIP(hipMemsetAsync(S.inputs.p, 0, n * (size_t)NI * 32, sC));
+      RLN_HIP(hipMemsetAsync(S.rs.p, 0, n * 64, sC));
+    }
+    const uint32_t pg = div_up(n, 64);
+    if (wit29 && S.V29.p) {
+      hipLaunchKernelGGL(k_wipe_cols, dim3(pg, nstore29), dim3(64), 0, sC, S.V.p, slot2node.p, nstore29, (uint32_t)B, (uint32_t)n);
+      hipLaunchKernelGGL(k_wipe_v29, dim3(div_up(3 * n, 64), nstore29 + 1), dim3(64), 0, sC, S.V29.p, nstore29 + 1, (uint32_t)B,
+                         (uint32_t)n);
+      // an externally supplied witness (upload_witness) was stored at the signal rows
+      hipLaunchKernelGGL(k_wipe_cols, dim3(pg, NS), dim3(64), 0, sC, S.V.p, sig2node.p, NS, (uint32_t)B, (uint32_t)n);
+    } else {
+      hipLaunchKernelGGL(k_wipe_cols, dim3(pg, N), dim3(64), 0, sC, S.V.p, (const uint32_t*)nullptr, N, (uint32_t)B, (uint32_t)n);
+    }
+    RLN_HIP(hipGetLastError());
+    RLN_HIP(hipEventRecord(S.evC, sC));
+    S.wiped = true;
+  }
 
   void sync_all() {
     RLN_HIP(hipStreamSynchronize(sA));
@@ -1381,6 +1434,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   W2_ = D.ws2.W * D.nh;
   glv_ = D.nh == 2;
   B_ = ((cfg.max_batch ? cfg.max_batch : 1) + 63) / 64 * 64;
+  D.batch_cap = B_;
 
   // ---- consistency between zkey and graph (what arkworks asserts inside the prover)
   D.N = (uint32_t)graph_.nodes.size();
@@ -1979,6 +2033,15 @@ Prover::~Prover() {
   Impl& D = *d_;
   for (hipStream_t st : {D.sA, D.sAb, D.sA2, D.sB, D.sB2, D.sC, D.sV[0], D.sV[1]})
     if (st) (void)hipStreamSynchronize(st);
+  // freed device memory is not cleared by the runtime: nothing secret-dependent goes back to the allocator
+  try {
+    if (D.sC) {
+      for (int k = 0; k < D.nslot; k++)
+        if (D.slot[k].used && !D.slot[k].wiped && D.slot[k].evC) D.wipe_slot(D.slot[k], D.slot[k].ticket == 0);
+      (void)hipStreamSynchronize(D.sC);
+    }
+  } catch (...) {
+  }
   for (Slot& S : D.slot) {
     if (S.h_pp) (void)hipHostFree(S.h_pp);
     if (S.h_in) (void)hipHostFree(S.h_in);
@@ -2083,7 +2146,7 @@ uint64_t Prover::submit(size_t n, const uint8_t* inputs, const uint8_t* rs, int 
 }
 
 void Prover::collect(uint64_t ticket, size_t n, uint8_t* proofs, uint8_t* values, uint32_t* errors, uint8_t* coords,
-                     uint8_t* partial320) {
+                     uint8_t* partial320, bool wipe_after) {
   Impl& D = *d_;
   Slot* Sp = nullptr;
   for (int k = 0; k < D.nslot; k++)
@@ -2109,6 +2172,28 @@ void Prover::collect(uint64_t ticket, size_t n, uint8_t* proofs, uint8_t* values
     if (coords) RLN_HIP(hipMemcpy(coords, S.coords.p, n * 256, hipMemcpyDeviceToHost));
   }
   if (errors) memcpy(errors, S.h_err, n * 4);
+  if (wipe_after && !S.wiped) D.wipe_slot(S, false);
+}
+
+// ticket 0: the resident-input run (upload / run / download): the shared input buffers and the last batch's witness.
+void Prover::wipe(uint64_t ticket) {
+  Impl& D = *d_;
+  if (ticket == 0) {
+    D.sync_all();
+    if (D.last) D.wipe_slot(*D.last, true);
+    else {
+      RLN_HIP(hipMemsetAsync(D.inputs.p, 0, D.inputs.bytes(), D.sC));
+      RLN_HIP(hipMemsetAsync(D.rs.p, 0, D.rs.bytes(), D.sC));
+    }
+    RLN_HIP(hipStreamSynchronize(D.sC));
+    return;
+  }
+  for (int k = 0; k < D.nslot; k++)
+    if (D.slot[k].used && D.slot[k].ticket == ticket) {
+      RLN_HIP(hipEventSynchronize(D.slot[k].evC));
+      if (!D.slot[k].wiped) D.wipe_slot(D.slot[k], false);
+      return;
+    }
 }
 
 void Prover::collect_public(uint64_t ticket, size_t n, std::vector<uint8_t>* out_le) {
@@ -2116,6 +2201,7 @@ void Prover::collect_public(uint64_t ticket, size_t n, std::vector<uint8_t>* out
   for (int k = 0; k < D.nslot; k++)
     if (D.slot[k].used && D.slot[k].ticket == ticket && ticket != 0) {
       if (n > D.slot[k].n) throw Error("collect: more proofs requested than the batch holds");
+      if (D.slot[k].wiped) throw Error("collect_public: the batch has been wiped (collect it with wipe_after = false first)");
       RLN_HIP(hipEventSynchronize(D.slot[k].evC));
       fetch_public_slot(&D.slot[k], n, out_le);
       return;
@@ -2148,6 +2234,9 @@ void Prover::prove_stream(size_t n, const uint8_t* inputs, const uint8_t* rs, ui
     }
     while (!q.empty()) take();
   } catch (...) {
+    D.sync_all();
+    for (int k = 0; k < D.nslot; k++)   // the error path leaves no witness behind either
+      if (D.slot[k].used && !D.slot[k].wiped) D.wipe_slot(D.slot[k], false);
     D.sync_all();
     throw;
   }
@@ -2548,6 +2637,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   MARK(10, sF);
   RLN_HIP(hipEventRecord(S.evC, sF));
   S.used = true;
+  S.wiped = false;
   S.n = n;
   D.last = &S;
   return S.ticket;

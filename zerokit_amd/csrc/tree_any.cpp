@@ -49,13 +49,19 @@ size_t SparseTree::stored_nodes() const {
 }
 
 void SparseTree::set_range(size_t start, const uint8_t* leaves_le, size_t n) {
+  std::vector<uint64_t> idx(n);
+  for (size_t i = 0; i < n; i++) idx[i] = start + i;
+  set_many(idx.data(), leaves_le, n);
+}
+
+void SparseTree::set_many(const uint64_t* idx, const uint8_t* leaves_le, size_t n) {
   if (!n) return;
   std::vector<uint64_t> touched(n);
   for (size_t i = 0; i < n; i++) {
     Node v;
     memcpy(v.data(), leaves_le + 32 * i, 32);
-    lv_[depth_][start + i] = v;
-    touched[i] = start + i;
+    lv_[depth_][idx[i]] = v;
+    touched[i] = idx[i];
   }
   // update_hashes (optimal_merkle_tree.rs:296-330): the parents of everything touched, level by level, each level one
   // device batch
@@ -106,13 +112,78 @@ void TreeAny::init(int depth_, const uint8_t default_leaf_le[32]) {
     sp = SparseTree();
   }
   depth = depth_;
+  pend.reset(new Pending);
+}
+
+size_t TreeAny::pending_writes() const {
+  if (!pend) return 0;
+  std::lock_guard<std::mutex> lk(pend->mu);
+  return pend->writes.size();
+}
+
+// caller holds pend->mu
+static void flush_locked(TreeAny& t) {
+  auto& w = t.pend->writes;
+  if (w.empty()) return;
+  std::vector<uint64_t> idx;
+  std::vector<uint8_t> leaves;
+  idx.reserve(w.size());
+  leaves.reserve(w.size() * 32);
+  for (const auto& kv : w) {
+    idx.push_back(kv.first);
+    leaves.insert(leaves.end(), kv.second.begin(), kv.second.end());
+  }
+  w.clear();   // a failing pass must not be replayed for ever; the error reaches the reader that triggered it
+  if (t.sparse) t.sp.set_many(idx.data(), leaves.data(), idx.size());
+  else t.dense.set_scattered(idx.data(), leaves.data(), idx.size());
+}
+
+void TreeAny::flush_pending() {
+  if (!pend) return;
+  std::lock_guard<std::mutex> lk(pend->mu);
+  flush_locked(*this);
+}
+
+void TreeAny::set_leaf(size_t index, const uint8_t leaf_le[32]) {
+  if (index >= capacity()) throw Error("TooManySet");
+  std::lock_guard<std::mutex> lk(pend->mu);
+  std::array<uint8_t, 32> v;
+  memcpy(v.data(), leaf_le, 32);
+  pend->writes[index] = v;
+  if (pend->writes.size() >= MAX_PENDING) flush_locked(*this);
 }
 
 void TreeAny::set_range_host(size_t start, const uint8_t* leaves_le, size_t n) {
+  if (start + n > capacity() || start + n < start) throw Error("TooManySet");
+  if (n == 0) return;
+  std::lock_guard<std::mutex> lk(pend->mu);
+  if (n <= DEFER_RANGE_MAX) {   // a short range is a handful of single writes
+    for (size_t i = 0; i < n; i++) {
+      std::array<uint8_t, 32> v;
+      memcpy(v.data(), leaves_le + 32 * i, 32);
+      pend->writes[start + i] = v;
+    }
+    if (pend->writes.size() >= MAX_PENDING) flush_locked(*this);
+    return;
+  }
+  // a bulk write: earlier single writes inside the range are overwritten by it, the others keep waiting (their paths
+  // and the range's meet only in nodes both passes recompute from the leaves below -- but the range pass would hash
+  // over leaves that are not written yet, so the pending ones go first)
+  flush_locked(*this);
   if (sparse) sp.set_range(start, leaves_le, n); else dense.set_range_host(start, leaves_le, n);
 }
 
 void TreeAny::get_node_host(size_t node, uint8_t out_le[32]) {
+  std::lock_guard<std::mutex> lk(pend->mu);
+  if (depth > 0 && node >= capacity() - 1) {   // a leaf: pending writes answer for themselves, the others are current
+    auto it = pend->writes.find(node - (capacity() - 1));
+    if (it != pend->writes.end()) {
+      memcpy(out_le, it->second.data(), 32);
+      return;
+    }
+  } else {
+    flush_locked(*this);
+  }
   if (!sparse) return dense.get_node_host(node, out_le);
   if (node == 0) return sp.root(out_le);
   if (node < capacity() - 1) throw Error("sparse tree: only the root and the leaves are addressed by heap index");
@@ -120,11 +191,15 @@ void TreeAny::get_node_host(size_t node, uint8_t out_le[32]) {
 }
 
 void TreeAny::get_leaves_host(size_t first, size_t n, uint8_t* out_le) {
+  std::lock_guard<std::mutex> lk(pend->mu);
+  flush_locked(*this);
   if (!sparse) return dense.get_leaves_host(first, n, out_le);
   for (size_t i = 0; i < n; i++) sp.leaf(first + i, out_le + 32 * i);
 }
 
 void TreeAny::proof_host(size_t leaf, uint8_t* elems_le, uint8_t* bits) {
+  std::lock_guard<std::mutex> lk(pend->mu);
+  flush_locked(*this);
   if (sparse) sp.proof(leaf, elems_le, bits); else dense.proof_host(leaf, elems_le, bits);
 }
 

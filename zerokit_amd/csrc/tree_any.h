@@ -8,6 +8,9 @@
 #include <stdint.h>
 
 #include <array>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 
@@ -20,6 +23,8 @@ class SparseTree {
   void init(int depth, const uint8_t default_leaf_le[32]);
   int depth() const { return depth_; }
   void set_range(size_t start, const uint8_t* leaves_le, size_t n);   // then update_hashes over the touched indices
+  // k leaves at strictly increasing indices, then ONE update_hashes pass over the union of the touched paths
+  void set_many(const uint64_t* idx, const uint8_t* leaves_le, size_t k);
   void root(uint8_t out_le[32]) const { node(0, 0, out_le); }
   void leaf(size_t index, uint8_t out_le[32]) const { node(depth_, index, out_le); }
   void proof(size_t leaf, uint8_t* elems_le, uint8_t* bits) const;     // bottom-up, bit = 1: the node is a right child
@@ -41,8 +46,25 @@ struct TreeAny {
   SparseTree sp;
   static constexpr int MAX_DENSE_DEPTH = 30;
 
+  // Deferred, coalesced single-leaf updates.  The reference pays `depth` hashes inside every set()
+  // (full_merkle_tree.rs:336-399) -- on a CPU core that is ~0.5 ms; a chain of 20 dependent hashes on a GPU is ~2 ms
+  // whatever is done to it.  So set_leaf() only records the write; the first READER of anything a write can change (root,
+  // proof, a bulk range write, a snapshot) runs ONE bottom-up pass over the union of the dirty paths: k updates between two
+  // reads cost one pass, not k.  A leaf read is answered from the pending writes.  Observable behaviour is the
+  // reference's: every read sees all earlier writes, later writes to an index win.
+  struct Pending {
+    std::mutex mu;                                        // readers (&self in the reference) may come from several threads
+    std::map<uint64_t, std::array<uint8_t, 32>> writes;   // ordered: the flush wants increasing indices
+  };
+  std::unique_ptr<Pending> pend{new Pending};
+  static constexpr size_t MAX_PENDING = (size_t)1 << 18;  // bounds host memory; a burst above it flushes early
+  static constexpr size_t DEFER_RANGE_MAX = 64;           // ranges up to this length ride in the pending set
+
   void init(int depth_, const uint8_t default_leaf_le[32]);
   size_t capacity() const { return (size_t)1 << depth; }
+  void set_leaf(size_t index, const uint8_t leaf_le[32]);   // deferred
+  void flush_pending();                                     // explicit (ffi_flush, snapshots); readers call it themselves
+  size_t pending_writes() const;
   void set_range_host(size_t start, const uint8_t* leaves_le, size_t n);
   // heap index as in MerkleTreeDev: 0 = root, capacity() - 1 + i = leaf i (the only two forms the FFI uses)
   void get_node_host(size_t node, uint8_t out_le[32]);
