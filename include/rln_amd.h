@@ -128,6 +128,9 @@ int rlnamd_prover_collect_public(rlnamd_prover* p, uint64_t ticket, size_t n, ui
  * rlnamd_prover_collect_public of that ticket is an error.  The resident-input calls (upload / run / download, kept for
  * the fetch_* parity taps) hold their data until rlnamd_prover_wipe or rlnamd_prover_free. */
 int rlnamd_prover_wipe(rlnamd_prover* p);
+/* the switches this prover was built with, "name=value ..." (ProverTuning, zerokit_amd/csrc/prover.h: every RLNAMD_*
+ * variable the prover reads is read once, at construction, and listed there) */
+int rlnamd_prover_describe(rlnamd_prover* p, char* buf, size_t cap);
 int rlnamd_prover_prove_stream(rlnamd_prover* p, size_t n, const uint8_t* inputs_le, const uint8_t* rs_le,
                                uint8_t* proofs, uint8_t* values, uint32_t* errors);
 int rlnamd_prover_stage_ms(rlnamd_prover* p, float ms[RLNAMD_PROVER_STAGES]);

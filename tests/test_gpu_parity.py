@@ -703,19 +703,3 @@ def test_bench_schedule_gives_the_golden_proofs():
             assert o["proof"].hex() == c["proof_compressed"], c["name"]
     finally:
         p.close()
-
-
-def test_ntt_products_in_the_9x29_form_give_the_same_h(monkeypatch):
-    """RLNAMD_NTT29=1 routes the NTT twiddle products through Fr29::mul_mont (8 x 32 value times a 9 x 29 constant,
-    no conversion multiplication).  Off by default (no measured gain); the quotient h and the proofs must not change."""
-    from zerokit_amd.batch import BatchProver
-    monkeypatch.setenv("RLNAMD_NTT29", "1")
-    cases = _cases()["cases"]
-    p = BatchProver(max_batch=64)
-    try:
-        out = p.prove([_w(c) for c in cases], [(int(c["r"]), int(c["s"])) for c in cases])
-        for i, (o, c) in enumerate(zip(out, cases)):
-            assert _digest(p.fetch_h(i)) == c["h_sha256"], c["name"]
-            assert o["proof"].hex() == c["proof_compressed"], c["name"]
-    finally:
-        p.close()

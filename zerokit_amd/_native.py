@@ -150,6 +150,7 @@ SIGNATURES = {
                                        C.POINTER(C.c_uint32), C.c_char_p]),
     "rlnamd_prover_collect_public": (C.c_int, [P, C.c_uint64, C.c_size_t, C.c_char_p]),
     "rlnamd_prover_wipe": (C.c_int, [P]),
+    "rlnamd_prover_describe": (C.c_int, [P, C.c_char_p, C.c_size_t]),
     "rlnamd_prover_prove_stream": (C.c_int, [P, C.c_size_t, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
                                             C.POINTER(C.c_uint32)]),
     "rlnamd_pool_new": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_size_t, C.c_int,

@@ -187,6 +187,12 @@ class BatchProver:
         check(lib().rlnamd_prover_submit(self._h, n, inputs, rsb, mode, pp, C.byref(t)))
         return int(t.value), n
 
+    def describe(self):
+        """the switches this prover was built with (ProverTuning)"""
+        buf = C.create_string_buffer(1024)
+        check(lib().rlnamd_prover_describe(self._h, buf, 1024))
+        return buf.value.decode()
+
     def wipe(self):
         """overwrite the resident inputs and the last run's witness values (the streamed calls do it by themselves)"""
         check(lib().rlnamd_prover_wipe(self._h))

@@ -360,6 +360,15 @@ int rlnamd_prover_walk_clock_mhz(rlnamd_prover* p, double mhz[2]) {
 }
 const char* rlnamd_prover_stage_name(int i) { return (i >= 0 && i < PROVER_STAGES) ? kProverStageNames[i] : ""; }
 
+int rlnamd_prover_describe(rlnamd_prover* p, char* buf, size_t cap) {
+  RLN_TRY
+  std::string d = p->p->tuning().describe();
+  if (cap) {
+    strncpy(buf, d.c_str(), cap - 1);
+    buf[cap - 1] = 0;
+  }
+  RLN_CATCH
+}
 int rlnamd_prover_wipe(rlnamd_prover* p) {
   RLN_TRY
   p->p->wipe(0);

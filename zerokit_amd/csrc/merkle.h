@@ -16,7 +16,6 @@ namespace rlnamd {
 struct MerkleTreeDev {
   int depth = 0;
   DevBuf<Fr> nodes;
-  DevBuf<uint32_t> canon;  // bulk path emission: the nodes in canonical form, converted once per call (lazily allocated)
   std::vector<Fr> zero_hashes;  // [level] Montgomery, level 0 = root ... depth = leaf
   hipStream_t stream = 0;
   // staging of set_scattered: leaf indices, dirty-node lists and leaves of one pass (pinned host + device copy)

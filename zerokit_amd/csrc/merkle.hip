@@ -10,11 +10,6 @@
 
 namespace rlnamd {
 
-static int env_int_merkle(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
-
 // parents [first, first+count): nodes[p] = H(nodes[2p+1], nodes[2p+2])   (hash_parent, :373-376)
 __global__ void __launch_bounds__(256) k_hash_parents(Fr* __restrict__ nodes, size_t first, size_t count,
                                                       PoseidonView pv) {
@@ -150,53 +145,17 @@ __global__ void __launch_bounds__(256) k_proofs(const Fr* __restrict__ nodes, in
   bits[t] = right ? 1 : 0;
 }
 
-// Bulk emission: a level-l sibling is shared by 2^l paths, so the nodes are brought to canonical form once
-// (k_canon_nodes, 2^(d+1) conversions instead of d 2^d) and the path kernel is a pure gather + 16-byte stores.
-__global__ void __launch_bounds__(256) k_canon_nodes(const Fr* __restrict__ nodes, size_t n, uint32_t* __restrict__ out) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t c[8];
-  nodes[i].to_canonical(c);
-  uint4* o = reinterpret_cast<uint4*>(out + i * 8);
-  o[0] = make_uint4(c[0], c[1], c[2], c[3]);
-  o[1] = make_uint4(c[4], c[5], c[6], c[7]);
-}
-// one lane per 16 bytes: lane pair (2 e, 2 e + 1) copies the two halves of path element e, so every store
-// instruction of a wave covers 1 KiB without gaps.  A workgroup takes PROOFS_PER_BLOCK consecutive proofs and splits
-// the element index by a multiply with magic = floor(2^32 / depth) + 1 (exact for e < 2^32 / depth) instead of a
-// 64-bit division per lane.  Measured 0.19 ms for 692 MB + 21 MB written (3.7 TB/s; a plain fill of the same size
-// reaches 6.8 TB/s, a copy 2 x 2.7 TB/s on this chip: tools/fill_bw.py).
 constexpr uint32_t PROOFS_PER_BLOCK = 64;
-__global__ void __launch_bounds__(256) k_proofs_canon(const uint4* __restrict__ canon, uint32_t depth, uint32_t magic,
-                                                      size_t first, size_t count, uint4* __restrict__ elems,
-                                                      uint8_t* __restrict__ bits) {
-  const size_t p0 = (size_t)blockIdx.x * PROOFS_PER_BLOCK;
-  const uint32_t np = (uint32_t)(count - p0 < PROOFS_PER_BLOCK ? count - p0 : PROOFS_PER_BLOCK);
-  const uint32_t n2 = np * depth * 2;
-  const size_t leaf0 = ((size_t)1 << depth) - 1 + first + p0;  // heap index of the block's first leaf
-  const size_t out0 = p0 * depth;
-  for (uint32_t e2 = threadIdx.x; e2 < n2; e2 += 256) {  // (five gathers in flight per lane measured slower: not latency-bound)
-    const uint32_t e = e2 >> 1, half = e2 & 1;
-    const uint32_t pl = __umulhi(e, magic);
-    const uint32_t lvl = e - pl * depth;
-    const size_t cur = ((leaf0 + pl + 1) >> lvl) - 1;
-    const bool right = (cur & 1) == 0;
-    const size_t sib = right ? cur - 1 : cur + 1;
-    elems[(out0 << 1) + e2] = canon[sib * 2 + half];
-    if (half == 0) bits[out0 + e] = right ? 1 : 0;
-  }
-}
-
-// Bulk emission, round 3.  k_proofs_canon's inner loop was gather -> store: every 16-byte store waited for an L2 round
-// trip, and with 32 waves per CU that caps the chip near 4 TB/s (0.19 ms for 692 MB; a fill reaches 6.8 TB/s).  A block
+// Bulk emission.  A gather -> store loop (round 2: canonical copies of all nodes, then one gather per 16 bytes) makes every
+// 16-byte store wait for an L2 round trip, and with 32 waves per CU that caps the chip near 4 TB/s (0.19 ms for 692 MB; a
+// fill reaches 6.8 TB/s, a copy 2 x 2.7 TB/s: tools/fill_bw.py).  A block
 // of PROOFS_PER_BLOCK consecutive proofs only needs ~170 distinct nodes (level l: the siblings of <= 64 >> l + 1
-// ancestors, a contiguous heap range), so they are converted to canonical form ONCE into LDS (no k_canon_nodes pass,
-// no 67 MB round trip through HBM) and the emission loop is LDS read -> 16-byte store: stores issue back to back, every
+// ancestors, a contiguous heap range), so they are converted to canonical form ONCE into LDS (no separate conversion
+// pass, no 67 MB round trip through HBM) and the emission loop is LDS read -> 16-byte store: stores issue back to back, every
 // store instruction of a wave covers 1 KiB without gaps, and the path bits of the block (1 280 contiguous bytes) leave
 // as 16-byte stores instead of one byte per element.
 constexpr uint32_t PATHS_LDS_NODES = PROOFS_PER_BLOCK * 2 + 4 * 32;   // sum over levels of <= (63 >> l) + 4 nodes, depth <= 30
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-template <bool NT>
 __global__ void __launch_bounds__(256) k_proofs_lds(const Fr* __restrict__ nodes, uint32_t depth, uint32_t magic,
                                                     size_t first, size_t count, u32x4_t* __restrict__ elems,
                                                     uint8_t* __restrict__ bits, uint32_t bits_vec) {
@@ -240,10 +199,7 @@ __global__ void __launch_bounds__(256) k_proofs_lds(const Fr* __restrict__ nodes
     const uint32_t lvl = e - pl * depth;
     const size_t cur1 = (leaf1 + pl) >> lvl;               // 1-based ancestor; its sibling is cur1 ^ 1
     const uint32_t slot = lvl_off[lvl] + (uint32_t)((cur1 ^ 1) - lvl_base[lvl]);
-    if (NT)
-      __builtin_nontemporal_store(sh[2 * slot + half], &elems[(out0 << 1) + e2]);
-    else
-      elems[(out0 << 1) + e2] = sh[2 * slot + half];
+    __builtin_nontemporal_store(sh[2 * slot + half], &elems[(out0 << 1) + e2]);   // written once, never read back here
   }
   // bits: bit = 1 when the node on the path is a right child, i.e. its 1-based heap index is odd (:296-300)
   const uint32_t nb = np * depth;
@@ -316,7 +272,7 @@ void MerkleTreeDev::init(int depth_, const uint8_t default_leaf_le[32]) {
 
 void MerkleTreeDev::rehash(size_t lo, size_t hi) {
   PoseidonView pv = poseidon_view(3);
-  static const size_t l3_max = (size_t)std::max(0, env_int_merkle("RLNAMD_MERKLE_L3", 21 * 1024));
+  const size_t l3_max = 21 * 1024;
   while (lo > 0) {
     lo = ((lo + 1) >> 1) - 1;
     hi = ((hi + 1) >> 1) - 1;
@@ -418,7 +374,6 @@ MerkleTreeDev& MerkleTreeDev::operator=(MerkleTreeDev&& o) noexcept {
     if (scat_host) (void)hipHostFree(scat_host);
     depth = o.depth;
     nodes = std::move(o.nodes);
-    canon = std::move(o.canon);
     zero_hashes = std::move(o.zero_hashes);
     stream = o.stream;
     scat_dev = std::move(o.scat_dev);
@@ -467,24 +422,12 @@ void MerkleTreeDev::proofs_device(size_t first, size_t count, uint8_t* d_elems, 
   if (count == 0 || depth == 0) return;
   if ((uintptr_t)d_elems & 15) throw Error("proofs_device: the path-element buffer must be 16-byte aligned");
   size_t total = count * (size_t)depth;
-  static const int paths_mode = env_int_merkle("RLNAMD_PATHS", 2);   // 2 = k_proofs_lds, 1 = k_canon_nodes + k_proofs_canon
-  if (total >= num_nodes() && paths_mode == 2) {
+  if (total >= num_nodes()) {   // bulk: fewer distinct nodes than path elements
     // (p0 * depth) bytes into d_bits is a multiple of 16 for every block when the base is 16-byte aligned
     const uint32_t bits_vec = (((uintptr_t)d_bits & 15) == 0 && (PROOFS_PER_BLOCK * (size_t)depth) % 16 == 0) ? 1u : 0u;
-    static const bool nt = env_int_merkle("RLNAMD_PATHS_NT", 1) != 0;
     const uint32_t magic = (uint32_t)(0x100000000ull / (uint32_t)depth) + 1;
-    if (nt)
-      hipLaunchKernelGGL(k_proofs_lds<true>, dim3(div_up(count, PROOFS_PER_BLOCK)), dim3(256), 0, stream, nodes.p,
-                         (uint32_t)depth, magic, first, count, (u32x4_t*)d_elems, d_bits, bits_vec);
-    else
-      hipLaunchKernelGGL(k_proofs_lds<false>, dim3(div_up(count, PROOFS_PER_BLOCK)), dim3(256), 0, stream, nodes.p,
-                         (uint32_t)depth, magic, first, count, (u32x4_t*)d_elems, d_bits, bits_vec);
-  } else if (total >= num_nodes()) {  // bulk: fewer conversions than path elements
-    if (canon.n != num_nodes() * 8) canon.alloc(num_nodes() * 8);
-    hipLaunchKernelGGL(k_canon_nodes, dim3(div_up(num_nodes(), 256)), dim3(256), 0, stream, nodes.p, num_nodes(), canon.p);
-    hipLaunchKernelGGL(k_proofs_canon, dim3(div_up(count, PROOFS_PER_BLOCK)), dim3(256), 0, stream, (const uint4*)canon.p,
-                       (uint32_t)depth, (uint32_t)(0x100000000ull / (uint32_t)depth) + 1, first, count, (uint4*)d_elems,
-                       d_bits);
+    hipLaunchKernelGGL(k_proofs_lds, dim3(div_up(count, PROOFS_PER_BLOCK)), dim3(256), 0, stream, nodes.p, (uint32_t)depth,
+                       magic, first, count, (u32x4_t*)d_elems, d_bits, bits_vec);
   } else {
     hipLaunchKernelGGL(k_proofs, dim3(div_up(total, 256)), dim3(256), 0, stream, nodes.p, depth, first, count,
                        (uint32_t*)d_elems, d_bits);

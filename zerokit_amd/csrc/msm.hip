@@ -436,11 +436,6 @@ uint32_t selftest_fq29(int group, uint32_t threads, uint32_t iters, const uint8_
   return h;
 }
 
-static bool env_two_level() {
-  static const bool on = !(getenv("RLNAMD_MSM_SORT2") && getenv("RLNAMD_MSM_SORT2")[0] == '0');
-  return on;
-}
-
 struct MsmG1::Impl {
   hipStream_t s = nullptr;
   size_t cap = 0, n = 0;
@@ -601,7 +596,7 @@ void MsmG1::enqueue_windows() {
   hipLaunchKernelGGL(k_tile_prefix, dim3(div_up(nkeys, 256)), dim3(256), 0, s, D.hist.p, D.count.p);
   hipLaunchKernelGGL(k_scan_window, dim3(MSM_W), dim3(1024), 0, s, D.count.p, D.offs.p, D.wtotal.p);
   hipLaunchKernelGGL(k_scan_add, dim3(div_up(nkeys + 1, 256)), dim3(256), 0, s, D.offs.p, D.wtotal.p);
-  if (D.tmp.p && env_two_level()) {
+  if (D.tmp.p) {   // n <= 2^24: two-level placement; larger workspaces scatter in one pass
     hipLaunchKernelGGL(k_part1, dim3(MSM_TILES, MSM_W), dim3(1024), 0, s, D.dig.p, n, tile_len, D.offs.p, D.hist.p, D.tmp.p);
     hipLaunchKernelGGL(k_part2, dim3(MSM_PARTS, MSM_W), dim3(1024), MSM_PART_CAP * 4, s, D.tmp.p, D.offs.p, D.sorted.p);
   } else {

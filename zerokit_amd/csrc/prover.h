@@ -40,6 +40,35 @@ struct ProverConfig {
   size_t max_batch = 1024;  // workspace capacity in proofs (rounded up to a multiple of 64)
 };
 
+// Every switch of the prover, read from the environment ONCE when a Prover is built (ProverTuning::from_env; printed by
+// rlnamd_prover_describe).  Sizes choose an operating point; the shape switches force one of two production shapes --
+// both are what batches of some size / pipeline state take anyway -- so that the parity tests can pin each of them
+// (tests/test_gpu_parity.py: test_small_batch_shape_variants_give_the_golden_bytes).  Tuning constants whose alternative
+// lost every A/B (NTT through Fr29, the 8 x 32 walk, copy-engine staging, one interpreter stream, ...) are gone.
+struct ProverTuning {
+  // ---- sizes
+  int window_bits = 8;                 // RLNAMD_WINDOW_BITS: comb schedule g1 + 10000 * g2, each c + 100 * wide
+  int slots = 5;                       // RLNAMD_SLOTS: workspace slots = batches in flight (2 .. 6)
+  uint32_t lanechunk_max = 128;        // RLNAMD_LANECHUNK: largest batch that takes the small-batch (latency) shapes
+  uint32_t lanechunk_walk_max = 48;    // RLNAMD_LANECHUNK_WALK: largest lone batch walked with lanes = chunks
+  uint32_t witlanes_max = 256;         // RLNAMD_WITLANES_MAX: largest lone batch interpreted with lanes = nodes
+  // ---- shapes (1 = default)
+  bool glv = true;                     // RLNAMD_GLV: walk the 127-bit GLV halves (0: the plain 255-bit walk)
+  bool wit29 = true;                   // RLNAMD_WIT29: interpreter in the 9 x 29 form (0: the 8 x 32 fallback k_witness)
+  int lone = -1;                       // RLNAMD_LONE: -1 detect whether a batch is alone on the device, 0 / 1 force
+  bool early_walk = true;              // RLNAMD_EARLY_WALK: small batches walk the h-independent rows beside the NTTs
+  bool early_fin = true;               // RLNAMD_EARLY_FIN: small batches finish A, B1 before the h rows are walked
+  bool fused_smul = true;              // RLNAMD_FUSED_SMUL: a lone small proof takes s A, r B1 as rows of the C segment
+  bool values_from_witness = true;     // RLNAMD_VALUES_WITNESS: small batches read the proof values off the witness
+  bool ntt_fuse9 = true;               // RLNAMD_NTT_FUSE9: small batches run nine NTT levels per kernel
+  // ---- diagnostics
+  bool marks_small = false;            // RLNAMD_MARKS_SMALL: record stage timing marks for small batches too
+  static ProverTuning from_env();
+  std::string describe() const;
+};
+// (the lanes = nodes interpreter reads RLNAMD_WITLANES / RLNAMD_WITROWS / RLNAMD_WL_REASSOC when its program is built:
+// witness_lanes.hip, witness_sched.cpp)
+
 struct ProofOut {            // one proof, host side
   uint8_t compressed[128];   // ark-serialize compressed Proof{a,b,c}
   uint8_t coords[256];       // affine A.x A.y | B.x.c0 B.x.c1 B.y.c0 B.y.c1 | C.x C.y  (canonical LE)
@@ -52,6 +81,7 @@ class Prover {
   Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_t graph_len, ProverConfig cfg);
   ~Prover();
 
+  const ProverTuning& tuning() const;
   const Zkey& zkey() const { return zk_; }
   const Graph& graph() const { return graph_; }
   size_t capacity() const { return B_; }

@@ -1,6 +1,6 @@
-// The 256-bit multiply is inlined (measured on MI355X: G1 MSM 44.5 -> 41.7 ms, G2 MSM 30.7 -> 22.5 ms per 1024
-// proofs against the out-of-line form, which costs call overhead and a VGPR-hungry calling convention);
-// -DRLN_NOINLINE_MUL restores the shared 2.5 KB body.
+// prover.hip -- host side of the batched prover: tables and walk plans, workspace slots, the stream pipeline
+// (Prover::enqueue), streamed submit / collect, wipes and the parity taps.  The kernels live in prover_front.hip,
+// prover_walks.hip and prover_back.hip (declarations: prover_kernels.h).
 #include "prover.h"
 
 #include <stdlib.h>
@@ -9,8 +9,8 @@
 #include <algorithm>
 #include <deque>
 
+#include "prover_kernels.h"
 #include "fq29.h"
-#include "walk29.h"
 #include "glv.h"
 #include "pairing.h"
 #include "poseidon.h"
@@ -22,1141 +22,6 @@ namespace rlnamd {
 
 const char* const kProverStageNames[PROVER_STAGES] = {"witness", "matvec", "ntt",      "recode",
                                                       "msm_g1",  "msm_g2", "finalize", "values"};
-
-// =====================================================================================================
-// 256-bit integer helpers on canonical limbs (witness-graph ops that are not field ops)
-// =====================================================================================================
-// =====================================================================================================
-// 1. witness: one lane per proof interprets the straight-line graph (graph.rs:246-272)
-// =====================================================================================================
-// Operand encoding of the device program (built once on the host, Prover::Prover): the top two bits of a / b / c say
-// where the value lives -- RING: produced at most 63 nodes earlier, read from the LDS ring; CONST: index into the
-// constant table, a wave-uniform scalar load; FAR: anything else, read from the value array in HBM.  In the shipped
-// circuits every operand is a constant (23 %), the previous node (33 %, forwarded in registers) or within the last 16
-// nodes; only the 124 reads of input nodes go to HBM.  The ring is 64 slots x 64 lanes x 32 B = 128 KiB of LDS -- one
-// wave per CU is all this kernel ever has (16 waves per 1024 proofs).
-constexpr uint32_t OPK_RING = 0u << 30, OPK_CONST = 1u << 30, OPK_FAR = 2u << 30, OPK_MASK = 3u << 30;
-constexpr uint32_t G_STORE = 1u << 31;  // flag on GNode.op: this node's value must reach HBM (witness signal, input, far operand)
-constexpr uint32_t WIT_RING = 32;        // node values kept in LDS (64 KiB)
-constexpr uint32_t WIT_LDS_CONSTS = 2048;  // constants kept in LDS (64 KiB)
-__device__ __forceinline__ Fr ring_load(const uint32_t* ring, uint32_t node, uint32_t lane) {
-  Fr r;
-  const uint32_t* s = ring + (node % WIT_RING) * 8 * 64 + lane;
-#pragma unroll
-  for (int k = 0; k < 8; k++) r.v[k] = s[k * 64];
-  return r;
-}
-__device__ __forceinline__ Fr operand_load(uint32_t enc, const uint32_t* ring, const Fr* __restrict__ consts,
-                                           const Fr* __restrict__ V, uint32_t B, uint32_t p, uint32_t lane) {
-  uint32_t kind = enc & OPK_MASK, id = enc & ~OPK_MASK;
-  if (kind == OPK_RING) return ring_load(ring, id, lane);
-  if (kind == OPK_CONST) {
-    if (id >= WIT_LDS_CONSTS) return consts[id];
-    Fr r;
-    const uint32_t* c = ring + WIT_RING * 8 * 64 + id * 8;  // broadcast read: every lane the same address
-#pragma unroll
-    for (int k = 0; k < 8; k++) r.v[k] = c[k];
-    return r;
-  }
-  return V[(size_t)id * B + p];
-}
-__global__ void __launch_bounds__(64) k_witness(const GNode* __restrict__ nodes, uint32_t n_nodes,
-                                                const Fr* __restrict__ consts, uint32_t n_consts,
-                                                const uint32_t* __restrict__ inputs, uint32_t n_inputs,
-                                                Fr* __restrict__ V, uint32_t* __restrict__ err, uint32_t B, uint32_t nb) {
-  extern __shared__ uint32_t ring[];  // [WIT_RING][8][64] node values, then [WIT_LDS_CONSTS][8] constants
-  __builtin_amdgcn_s_setprio(3);  // few, latency-bound waves: issue ahead of the MSM waves sharing the SIMD
-  const uint32_t lane = threadIdx.x;
-  uint32_t p = blockIdx.x * 64 + lane;
-  if (p >= nb) return;
-  uint32_t e = WERR_NONE;
-  Fr last = Fr::zero();
-  {
-    uint32_t* lc = ring + WIT_RING * 8 * 64;
-    const uint32_t* gc = (const uint32_t*)consts;
-    const uint32_t words = (n_consts < WIT_LDS_CONSTS ? n_consts : WIT_LDS_CONSTS) * 8;
-    for (uint32_t i = lane; i < words; i += 64) lc[i] = gc[i];
-    __syncthreads();
-  }
-  GNode ahead = nodes[0];
-#pragma unroll 1
-  for (uint32_t n = 0; n < n_nodes; n++) {
-    // the descriptor of the next node is fetched while this one executes (scalar load)
-    GNode nd = ahead;
-    if (n + 1 < n_nodes) ahead = nodes[n + 1];
-    const bool store = (nd.op & G_STORE) != 0;
-    nd.op &= ~G_STORE;
-    Fr v;
-    if (nd.op == G_INPUT) {
-      const uint32_t* src = inputs + ((size_t)p * n_inputs + nd.a) * 8;
-      if (limbs_geq(src, FrParams::MOD)) e = e ? e : WERR_INPUT_RANGE;  // u256_to_fr fails (graph.rs:42-45)
-      v = Fr::from_canonical(src);
-    } else if (nd.op == G_CONST) {
-      v = consts[nd.a];
-    } else {
-      // operand forwarding: chains (x^5 s-boxes, MDS sums) read the value produced one node earlier
-      // (reading the NEXT node's LDS operands ahead of time was tried: 33 ms instead of 19.5 -- register pressure)
-      Fr va = (nd.a == (OPK_RING | (n - 1))) ? last : operand_load(nd.a, ring, consts, V, B, p, lane);
-      if (nd.op == G_NEG) {
-        v = va.neg();
-      } else if (nd.op == G_ID) {
-        v = witness_slow_op(G_ID, va, va, &e);
-      } else {
-        Fr vb = (nd.b == (OPK_RING | (n - 1))) ? last : operand_load(nd.b, ring, consts, V, B, p, lane);
-        if (nd.op == G_MUL)
-          v = va * vb;
-        else if (nd.op == G_ADD)
-          v = va + vb;
-        else if (nd.op == G_SUB)
-          v = va - vb;
-        else if (nd.op == G_TERN) {
-          Fr vc = operand_load(nd.c, ring, consts, V, B, p, lane);
-          v = va.is_zero() ? vc : vb;  // graph.rs:214-224
-        } else {
-          uint32_t e2 = 0;
-          v = witness_slow_op(nd.op, va, vb, &e2);
-          if (e2 && !e) e = e2;
-        }
-      }
-    }
-    // only ~6 000 of the 23 414 node values are read outside this kernel (190 MB instead of 767 MB per batch)
-    if (store) V[(size_t)n * B + p] = v;
-    uint32_t* slot = ring + (n % WIT_RING) * 8 * 64 + lane;
-#pragma unroll
-    for (int k = 0; k < 8; k++) slot[k * 64] = v.v[k];
-    last = v;
-  }
-  err[p] = e;
-}
-
-// ---- The same interpreter with node values in the 9 x 29-bit form of fq29.h (default; RLNAMD_WIT29=0 keeps the one
-// above).  One wave per SIMD is all this kernel ever has, so its time is latency, and tools/microbench_lonewave.hip
-// shows what a lone wave pays on gfx950: ~12 cycles per LDS instruction issued (a 9 x ds_read_b32 operand is a 118-cycle
-// round trip, two of them 225), 25 - 70 cycles per uniform branch hop, ~5.7 cycles per dependent multiply-add.  The 8 x 32
-// interpreter spends two thirds of its 1 950 cycles per node on exactly that (profiled: an ADD node of 30 instructions
-// takes 1 250 - 1 750 cycles).  Hence:
-//   * values live in LDS as [slot][lane][12 words]: an operand is ds_read_b128 x 2 + ds_read_b32, conflict-free at
-//     the 48-byte lane stride; constants as [id][12 words] are the SAME address form with lane multiplier 0, so both
-//     operands of a node are read without a branch and share one round trip;
-//   * the descriptor is 16 bytes (one broadcast ds_read_b128, issued one node ahead, made wave-uniform when its turn
-//     comes); the program reaches LDS through coalesced vector loads, a chunk ahead (a scalar load in flight would turn
-//     every LDS wait into s_waitcnt lgkmcnt(0));
-//   * no register forwarding (a node waits for an LDS read anyway; the previous node's value comes back from the ring);
-//     the rare sources (a value further back than the ring, a constant beyond the LDS table), the reduction flag and the
-//     slow operations hide behind ONE flag test, taken before any operand is read;
-//   * a product is ~200 instructions against ~375 in the 8 x 32 form, and the ~6 000 witness signals leave in the limb
-//     form ([slot][proof][12 words], three 16-byte stores) for a throughput kernel to convert (k_v29_to_fr).
-//
-// Value discipline: every node value is normalised (limbs < 2^29) with a STATIC bound, computed on the host when the
-// device program is built (Prover::Prover): products < 1 + 0.006 a b (in units of r), sums a + b, differences
-// a + 8 (K8 - b, b < 7.9 r), inputs / constants / slow operations ~ 1.  A node whose bound would pass WIT29_BMAX
-// carries W29_RED: its value is multiplied by the Montgomery one (result < 1.1 r).  Every operand is therefore below
-// 7.5 r, inside what fq29.h's products (check_fq29_bounds.py: N(10)), K8 - b and the exact zero test (k r, k < 8) take.
-constexpr uint32_t W29_STORE = 1u << 8, W29_RED = 1u << 9, W29_RARE = 1u << 10;  // flags in descriptor word 0
-constexpr uint32_t W29_FMA = 25;             // program-only operation: a * b + c (an Add fused with its single-use product)
-constexpr uint32_t WIT29_RING = 32;          // node values kept in LDS: 32 x 64 x 48 B = 96 KiB
-constexpr uint32_t WIT29_LDS_CONSTS = 1024;  // constants kept in LDS: 48 KiB
-constexpr uint32_t WIT29_CH = 256;           // descriptors per program chunk: 64 lanes x 64 B; two chunks in LDS (8 KiB)
-constexpr uint32_t WIT29_LDS_BYTES = WIT29_RING * 64 * 48 + WIT29_LDS_CONSTS * 48 + 2 * WIT29_CH * 16;
-constexpr double WIT29_BMAX = 7.5;
-struct GNode29 {
-  uint32_t w0;       // op | flags | slot << 16 (slot: index into the compact array of stored values)
-  uint32_t a, b, c;  // operands as in GNode: OPK_RING | node, OPK_CONST | index, OPK_FAR | slot
-};
-// LDS byte address of an operand for this lane, without a branch (a uniform branch hop costs a lone wave 25 - 70
-// cycles): ring value (id % RING) * 64 * 48 + lane * 48, LDS constant RING * 64 * 48 + id * 48.  Only valid for the
-// operands of the fast path (ring or LDS constant); the rare path re-reads what else it needs.
-__device__ __forceinline__ uint32_t wit29_addr(uint32_t enc, uint32_t lane48) {
-  const uint32_t id = enc & ~OPK_MASK;
-  const uint32_t cm = 0u - ((enc >> 30) & 1u);   // all ones for OPK_CONST
-  const uint32_t ring_a = (id % WIT29_RING) * (64 * 48), const_a = WIT29_RING * 64 * 48 + id * 48;
-  return ((const_a & cm) | (ring_a & ~cm)) + (lane48 & ~cm);
-}
-__device__ __forceinline__ void wit29_read(Fr29& r, uint32_t addr, const uint32_t* ring) {
-  const char* a = (const char*)ring + addr;
-  const uint4 x = *(const uint4*)a, y = *(const uint4*)(a + 16);
-  r.v[0] = x.x; r.v[1] = x.y; r.v[2] = x.z; r.v[3] = x.w;
-  r.v[4] = y.x; r.v[5] = y.y; r.v[6] = y.z; r.v[7] = y.w;
-  r.v[8] = *(const uint32_t*)(a + 32);
-}
-struct Wit29Out {
-  Fr29 v;
-  uint32_t e;
-};
-// Everything that is not Mul / Add on ring / LDS-constant / forwarded operands.  Out of line and by value on purpose:
-// inlined, its slow operations (calls with stack arguments) made the compiler keep the hot path's operands in scratch.
-__device__ __noinline__ Wit29Out wit29_rare(uint32_t w0, uint32_t ea, uint32_t eb, uint32_t ec, const uint32_t* ring,
-                                            uint32_t lane,
-                                            const uint32_t* __restrict__ consts29, const uint32_t* __restrict__ inputs,
-                                            uint32_t n_inputs, const uint4* __restrict__ V29, uint32_t B, uint32_t p) {
-  Wit29Out o;
-  o.e = WERR_NONE;
-  const uint32_t op = w0 & 0xFF;
-  auto src = [&](Fr29& r, uint32_t enc) {   // any source, from scratch
-    const uint32_t kind = enc >> 30, id = enc & ~OPK_MASK;
-    if (kind == (OPK_FAR >> 30)) {
-      const uint4* g = V29 + ((size_t)id * B + p) * 3;
-      const uint4 x = g[0], y = g[1], z = g[2];
-      r.v[0] = x.x; r.v[1] = x.y; r.v[2] = x.z; r.v[3] = x.w;
-      r.v[4] = y.x; r.v[5] = y.y; r.v[6] = y.z; r.v[7] = y.w;
-      r.v[8] = z.x;
-    } else if (kind == (OPK_CONST >> 30) && id >= WIT29_LDS_CONSTS) {
-      const uint32_t* c = consts29 + (size_t)id * 9;
-#pragma unroll
-      for (int k = 0; k < 9; k++) r.v[k] = c[k];
-    } else {
-      wit29_read(r, wit29_addr(enc, lane * 48), ring);
-    }
-  };
-  Fr29 v, va, vb;
-  if (op == G_CONST) {
-    src(v, OPK_CONST | ea);
-  } else if (op == G_INPUT) {
-    const uint32_t* in = inputs + ((size_t)p * n_inputs + ea) * 8;
-    if (limbs_geq(in, FrParams::MOD)) o.e = WERR_INPUT_RANGE;  // u256_to_fr fails (graph.rs:42-45)
-    Fr x;
-#pragma unroll
-    for (int k = 0; k < 8; k++) x.v[k] = in[k];
-    v = Fr29::mul(Fr29::slice(x), Fr29::from_const(Fr29C::FROM_CANON));
-  } else {
-    src(va, ea);
-    if (op != G_NEG && op != G_ID) src(vb, eb);
-    if (op == G_MUL) {
-      v = Fr29::mul(va, vb);
-    } else if (op == W29_FMA) {
-      Fr29 vc;
-      src(vc, ec);
-      v = Fr29::mul_add(va, vb, vc);
-    } else if (op == G_ADD) {
-#pragma unroll
-      for (int k = 0; k < 9; k++) v.v[k] = va.v[k] + vb.v[k];
-      v.normalize();
-    } else if (op == G_SUB) {
-      v = Fr29::sub(va, Fr29C::K8, vb);
-    } else if (op == G_NEG) {
-      v = Fr29::neg_lazy(Fr29C::K8, va);
-      v.normalize();
-    } else if (op == G_ID) {
-      (void)witness_slow_op(G_ID, Fr::zero(), Fr::zero(), &o.e);
-      v = Fr29::zero();
-    } else if (op == G_TERN) {
-      Fr29 vc;
-      src(vc, ec);
-      const bool z = va.is_zero_mod_q();  // graph.rs:214-224
-#pragma unroll
-      for (int k = 0; k < 9; k++) v.v[k] = z ? vc.v[k] : vb.v[k];
-    } else {  // comparisons, shifts, bit operations, division ...: on canonical integers, in the 8 x 32 form
-      v = Fr29::from_fq(witness_slow_op(op, va.to_fq(), vb.to_fq(), &o.e));
-    }
-  }
-  if (w0 & W29_RED) v = Fr29::mul(v, Fr29::from_const(Fr29C::ONE));
-  o.v = v;
-  return o;
-}
-template <bool PROF>
-__global__ void __launch_bounds__(64) k_witness29(const GNode29* __restrict__ nodes, uint32_t n_nodes,
-                                                  const uint32_t* __restrict__ consts29, uint32_t n_consts,
-                                                  const uint32_t* __restrict__ inputs, uint32_t n_inputs,
-                                                  uint4* __restrict__ V29, uint32_t* __restrict__ err, uint32_t B,
-                                                  uint32_t nb, unsigned long long* __restrict__ prof) {
-  unsigned long long pc[4] = {0, 0, 0, 0}, pn[4] = {0, 0, 0, 0}, pw0 = 0, pc0 = 0;
-  if (PROF) { pc0 = clock64(); pw0 = wall_clock64(); }
-  // LDS: [WIT29_RING][64][12] node values, [WIT29_LDS_CONSTS][12] constants, [2 WIT29_CH][4] program words
-  extern __shared__ __attribute__((aligned(16))) uint32_t ring[];
-  __builtin_amdgcn_s_setprio(3);  // few, latency-bound waves: issue ahead of the MSM waves sharing the SIMD
-  const uint32_t lane = threadIdx.x, lane48 = lane * 48;
-  uint32_t p = blockIdx.x * 64 + lane;
-  if (p >= nb) return;
-  uint32_t e = WERR_NONE;
-  uint32_t* const lconsts = ring + WIT29_RING * 64 * 12;
-  uint32_t* const prog = lconsts + WIT29_LDS_CONSTS * 12;
-  {
-    const uint32_t nc = n_consts < WIT29_LDS_CONSTS ? n_consts : WIT29_LDS_CONSTS;
-    for (uint32_t i = lane; i < nc * 9; i += 64) lconsts[(i / 9) * 12 + i % 9] = consts29[i];
-  }
-  const uint4* const gsrc = (const uint4*)nodes;   // lane l of chunk k: descriptors [k CH + 4 l, + 4)
-  uint4 pf[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) pf[k] = gsrc[lane * 4 + k];
-#pragma unroll
-  for (int k = 0; k < 4; k++) ((uint4*)prog)[lane * 4 + k] = pf[k];
-#pragma unroll
-  for (int k = 0; k < 4; k++) pf[k] = gsrc[(size_t)WIT29_CH + lane * 4 + k];   // chunk 1
-  __syncthreads();
-  uint4 d_next = ((const uint4*)prog)[0];
-  const uint32_t n_chunks = (n_nodes + WIT29_CH - 1) / WIT29_CH;
-#pragma unroll 1
-  for (uint32_t ch = 0; ch < n_chunks; ch++) {
-    {   // chunk ch is in LDS; park chunk + 1, start loading chunk + 2
-#pragma unroll
-      for (int k = 0; k < 4; k++) ((uint4*)prog)[((ch + 1) & 1) * WIT29_CH + lane * 4 + k] = pf[k];
-#pragma unroll
-      for (int k = 0; k < 4; k++) pf[k] = gsrc[(size_t)(ch + 2) * WIT29_CH + lane * 4 + k];
-    }
-    const uint32_t n_end = (ch + 1) * WIT29_CH < n_nodes ? (ch + 1) * WIT29_CH : n_nodes;
-#pragma unroll 1
-    for (uint32_t n = ch * WIT29_CH; n < n_end; n++) {
-      const uint32_t w0 = __builtin_amdgcn_readfirstlane(d_next.x), ea = __builtin_amdgcn_readfirstlane(d_next.y),
-                     eb = __builtin_amdgcn_readfirstlane(d_next.z), ec = __builtin_amdgcn_readfirstlane(d_next.w);
-      unsigned long long tn = 0;
-      if (PROF) tn = clock64();
-      Fr29 v;
-      if (!(w0 & W29_RARE)) {
-        // Mul / Add on ring values and LDS constants: both operand reads and the next descriptor go out together and
-        // cost one LDS round trip.  The previous node's value is read back from the ring like any other (its write
-        // was issued a few instructions earlier and LDS is in order): forwarding it in registers cost 18 selects and
-        // saved nothing, because a node waits for at least one LDS read anyway.
-        Fr29 va, vb, vc;
-        wit29_read(va, wit29_addr(ea, lane48), ring);
-        wit29_read(vb, wit29_addr(eb, lane48), ring);
-        wit29_read(vc, wit29_addr(ec, lane48), ring);   // the addend of a * b + c (a harmless ring slot otherwise)
-        d_next = ((const uint4*)prog)[(n + 1) % (2 * WIT29_CH)];
-        if ((w0 & 0xFF) == W29_FMA) {
-          v = Fr29::mul_add(va, vb, vc);
-        } else if ((w0 & 0xFF) == G_MUL) {
-          v = Fr29::mul(va, vb);
-        } else {  // G_ADD
-#pragma unroll
-          for (int k = 0; k < 9; k++) v.v[k] = va.v[k] + vb.v[k];
-          v.normalize();
-        }
-      } else {
-        d_next = ((const uint4*)prog)[(n + 1) % (2 * WIT29_CH)];
-        const Wit29Out o = wit29_rare(w0, ea, eb, ec, ring, lane, consts29, inputs, n_inputs, V29, B, p);
-        v = o.v;
-        if (o.e && !e) e = o.e;
-      }
-      {  // every value goes to the ring (three LDS instructions: cheaper than asking whether anybody reads it)
-        char* a = (char*)ring + (n % WIT29_RING) * 64 * 48 + lane48;
-        *(uint4*)a = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
-        *(uint4*)(a + 16) = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
-        *(uint32_t*)(a + 32) = v.v[8];
-      }
-      if (w0 & W29_STORE) {
-        uint4* g = V29 + ((size_t)(w0 >> 16) * B + p) * 3;
-        g[0] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
-        g[1] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
-        g[2] = make_uint4(v.v[8], 0, 0, 0);
-      }
-      if (PROF) {
-        const uint32_t op = w0 & 0xFF;
-        const int cls = (op == G_MUL || op == W29_FMA) ? 0 : op == G_ADD ? 1 : (op == G_CONST || op == G_INPUT) ? 2 : 3;
-        pc[cls] += clock64() - tn;
-        pn[cls]++;
-      }
-    }
-  }
-  err[p] = e;
-  if (PROF && blockIdx.x == 0 && lane == 0) {
-    for (int k = 0; k < 4; k++) { prof[k] = pc[k]; prof[4 + k] = pn[k]; }
-    prof[8] = clock64() - pc0;
-    prof[9] = wall_clock64() - pw0;
-  }
-}
-// stored node values of the Fr29 interpreter -> the 8 x 32 Montgomery values every later kernel reads (V[node][proof])
-// lg (small batches): lanes = stored values of ONE proof (blockIdx.y) instead of lanes = proofs
-__global__ void __launch_bounds__(64) k_v29_to_fr(const uint4* __restrict__ V29, const uint32_t* __restrict__ slot2node,
-                                                  uint32_t nslots, Fr* __restrict__ V, uint32_t B, uint32_t nb,
-                                                  uint32_t lg = 0) {
-  const uint32_t p = lg ? blockIdx.y : blockIdx.x * 64 + threadIdx.x, sl = lg ? blockIdx.x * 64 + threadIdx.x : blockIdx.y;
-  if (p >= nb || sl >= nslots) return;
-  const uint4* g = V29 + ((size_t)sl * B + p) * 3;
-  const uint4 x = g[0], y = g[1], z = g[2];
-  Fr29 v;
-  v.v[0] = x.x; v.v[1] = x.y; v.v[2] = x.z; v.v[3] = x.w;
-  v.v[4] = y.x; v.v[5] = y.y; v.v[6] = y.z; v.v[7] = y.w;
-  v.v[8] = z.x;
-  V[(size_t)slot2node[sl] * B + p] = v.to_fq();
-}
-
-// =====================================================================================================
-// 2. a = A.w, b = B.w, c = a o b on the padded domain (qap.rs:40-67)
-// =====================================================================================================
-struct CsrView {
-  const uint32_t* ptr;
-  const uint32_t* col;  // already mapped to graph node ids
-  const Fr* coef;
-};
-// LG (small batches): lanes = rows of ONE proof (blockIdx.y) instead of lanes = proofs -- with lanes = proofs a single
-// proof launches 8 192 waves with one useful lane each, which also crowd the walks that run beside them
-// Long rows (LG): the circuit's matrices hold 2 entries in most rows and 60 + 60 in ninety of them (Poseidon's mix
-// layers), and a lane that walks 120 entries alone -- two dependent loads and a product each -- is the whole kernel
-// (0.40 ms for one proof).  Rows with more than MV_LONG entries in A or B are therefore taken out of the lanes = rows
-// part and given a wave each (blocks >= nshort): a lane per entry, then a shuffle tree of field additions (exact, so the
-// order of the sum does not matter).
-constexpr uint32_t MV_LONG = 8;
-__device__ __forceinline__ Fr fr_shfl_down(const Fr& x, int off) {
-  Fr r;
-#pragma unroll
-  for (int k = 0; k < 8; k++) r.v[k] = (uint32_t)__shfl_down((int)x.v[k], off, 64);
-  return r;
-}
-template <bool LG>
-__global__ void __launch_bounds__(256) k_matvec(CsrView A, CsrView Bm, const Fr* __restrict__ V,
-                                                const uint32_t* __restrict__ sig2node, uint32_t nc, uint32_t ni,
-                                                uint32_t n, Fr* __restrict__ abc, uint32_t B, uint32_t nb,
-                                                const uint32_t* __restrict__ long_rows = nullptr, uint32_t nshort = 0) {
-  uint32_t p = LG ? blockIdx.y : blockIdx.x * 64 + threadIdx.x;
-  if (LG && blockIdx.x >= nshort) {   // a wave per long row
-    const uint32_t row = long_rows[blockIdx.x - nshort], lane = threadIdx.x;
-    Fr a = Fr::zero(), b = Fr::zero();
-    for (uint32_t k = A.ptr[row] + lane; k < A.ptr[row + 1]; k += 64) a = a + A.coef[k] * V[(size_t)A.col[k] * B + p];
-    for (uint32_t k = Bm.ptr[row] + lane; k < Bm.ptr[row + 1]; k += 64) b = b + Bm.coef[k] * V[(size_t)Bm.col[k] * B + p];
-#pragma unroll
-    for (int off = 32; off; off >>= 1) {
-      a = a + fr_shfl_down(a, off);
-      b = b + fr_shfl_down(b, off);
-    }
-    if (lane == 0) {
-      const size_t o = (size_t)row * B + p;
-      abc[o] = a;
-      abc[(size_t)n * B + o] = b;
-      abc[2 * (size_t)n * B + o] = a * b;
-    }
-    return;
-  }
-  uint32_t row = LG ? blockIdx.x * 64 + threadIdx.x
-                    : __builtin_amdgcn_readfirstlane(blockIdx.y * blockDim.y + threadIdx.y);  // wave-uniform
-  if (row >= n) return;
-  if (p >= nb) return;
-  Fr a = Fr::zero(), b = Fr::zero();
-  if (row < nc) {
-    if (LG && long_rows && (A.ptr[row + 1] - A.ptr[row] > MV_LONG || Bm.ptr[row + 1] - Bm.ptr[row] > MV_LONG)) return;
-    for (uint32_t k = A.ptr[row]; k < A.ptr[row + 1]; k++) a = a + A.coef[k] * V[(size_t)A.col[k] * B + p];
-    for (uint32_t k = Bm.ptr[row]; k < Bm.ptr[row + 1]; k++) b = b + Bm.coef[k] * V[(size_t)Bm.col[k] * B + p];
-  } else if (row < nc + ni) {
-    a = V[(size_t)sig2node[row - nc] * B + p];  // a[nc..nc+ni] = w[0..ni] (qap.rs:54-58)
-  }
-  size_t o = (size_t)row * B + p;
-  abc[o] = a;
-  abc[(size_t)n * B + o] = b;
-  abc[2 * (size_t)n * B + o] = (row < nc) ? a * b : Fr::zero();
-}
-
-// =====================================================================================================
-// 3. radix-2^K register-blocked NTT passes over [index][proof] data (ark-poly Radix2EvaluationDomain
-//    fft/ifft semantics; call sites qap.rs:69-90).  DIF takes natural order to bit-reversed, DIT takes
-//    bit-reversed back to natural, so iNTT(DIF) -> coset scale -> NTT(DIT) needs no reordering pass.
-// =====================================================================================================
-#ifndef RLN_NTT_WAVES
-#define RLN_NTT_WAVES 1
-#endif
-__device__ __forceinline__ Fr29 load_fr29(const uint32_t* __restrict__ p) {
-  Fr29 w;
-#pragma unroll
-  for (int k = 0; k < 9; k++) w.v[k] = p[k];
-  return w;
-}
-// constants for Fr29::mul_mont: the Fr29 image (x 2^261, normalised) of 8 x 32 Montgomery values
-__global__ void __launch_bounds__(256) k_consts_to29(const Fr* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n) {
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  Fr29 v = Fr29::from_fq(src[t]);
-  v.normalize();
-#pragma unroll
-  for (int k = 0; k < 9; k++) dst[(size_t)t * 9 + k] = v.v[k];
-}
-// M29: twiddles as Fr29 constants and Fr29::mul_mont products; otherwise 8 x 32 twiddles and products (RLNAMD_NTT29=0)
-// LG (small batches): lanes = groups of ONE proof (blockIdx.x = proof) instead of lanes = proofs -- a single proof then
-// fills its waves (3 072 eight-point blocks = 48 waves per pass) instead of running 3 072 waves with one useful lane each
-// (all ten passes of one proof 0.78 -> see profiles/r3); twiddle indices become per-lane values.
-template <int K, bool DIF, bool M29, bool LG = false>
-__global__ void __launch_bounds__(256, RLN_NTT_WAVES) k_ntt_pass(Fr* __restrict__ data, const uint32_t* __restrict__ tw, int logn, int s0,
-                                                  const uint32_t* __restrict__ scale, uint32_t B, uint32_t nb) {
-  auto tmul = [&](const Fr& a, const uint32_t* __restrict__ tab, uint32_t idx) -> Fr {
-    if constexpr (M29)
-      return Fr29::mul_mont(a, load_fr29(tab + 9 * (size_t)idx));
-    else
-      return a * reinterpret_cast<const Fr*>(tab)[idx];
-  };
-  constexpr int R = 1 << K;
-  const uint32_t n = 1u << logn;
-  auto uni = [](uint32_t v) -> uint32_t { return LG ? v : __builtin_amdgcn_readfirstlane(v); };
-  uint32_t p = LG ? blockIdx.x : blockIdx.x * 64 + threadIdx.x;
-  uint32_t g = LG ? blockIdx.y * 64 + threadIdx.x
-                  : __builtin_amdgcn_readfirstlane(blockIdx.y * blockDim.y + threadIdx.y);  // one group per wave
-  if (g >= (n >> K)) return;
-  if (p >= nb) return;
-  Fr* x = data + (size_t)blockIdx.z * n * B + p;
-  uint32_t stride, base;
-  if (DIF) {
-    stride = n >> (s0 + K);  // h_last
-    uint32_t blk = g / stride, lo = g % stride;
-    base = blk * (n >> s0) + lo;
-  } else {
-    stride = 1u << s0;  // h_first
-    uint32_t blk = g / stride, lo = g % stride;
-    base = blk * (stride << K) + lo;
-  }
-  const uint32_t lo = g % stride;
-  Fr e[R];
-#pragma unroll
-  for (int m = 0; m < R; m++) e[m] = x[(size_t)(base + m * stride) * B];
-#pragma unroll
-  for (int t = 0; t < K; t++) {
-    const int half = DIF ? (R >> (t + 1)) : (1 << t);
-#pragma unroll
-    for (int m = 0; m < R; m++) {
-      if (m & half) continue;
-      uint32_t j = (uint32_t)(m & (half - 1)) * stride + lo;
-      uint32_t ti = DIF ? (j << (s0 + t)) : (j << (logn - 1 - (s0 + t)));
-      // the twiddle index is the same for all 64 lanes (lanes = proofs): force the scalar path so the
-      // twiddle rides in SGPRs instead of VGPRs.  Twiddles are held as Fr29 constants (w 2^261, 9 words): the
-      // product with an 8 x 32 value needs no conversion (Fr29::mul_mont, ~290 instead of ~375 instructions)
-      const uint32_t tix = uni(ti);
-      if (DIF) {
-        Fr u = e[m], v = e[m + half];
-        e[m] = u + v;
-        e[m + half] = tmul(u - v, tw, tix);
-      } else {
-        Fr u = e[m], v = tmul(e[m + half], tw, tix);
-        e[m] = u + v;
-        e[m + half] = u - v;
-      }
-    }
-  }
-#pragma unroll
-  for (int m = 0; m < R; m++) {
-    uint32_t pos = base + m * stride;
-    Fr o = e[m];
-    if (scale) o = tmul(o, scale, uni(pos));
-    x[(size_t)pos * B] = o;
-  }
-}
-
-// Small batches: nine levels in ONE kernel.  The 512 points {base + m stride} that nine consecutive levels close over
-// are one wave's work: three radix-8 sub-passes, eight points per lane, exchanged through 16 KB of LDS instead of
-// through HBM and two kernel boundaries (a lone proof's pass is all latency: 50 - 65 us for 6 us of arithmetic).  In the
-// set's local coordinates m = 0..511 the sub-passes are a 512-point transform's (local strides 64, 8, 1 for DIF and
-// 1, 8, 64 for DIT); their twiddles are the big transform's, indexed exactly as k_ntt_pass does for the pass
-// (s0 + 3 q, K = 3): global stride = stride * ls, lo = lo_set + lo_local * stride.  Same butterflies, same products, same
-// order per point: bit-identical to the passes it replaces.  Grid (proof, set, vector), one wave per workgroup.
-template <bool DIF>
-__global__ void __launch_bounds__(64) k_ntt_fused9(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0,
-                                                   const Fr* __restrict__ scale, uint32_t B, uint32_t nb) {
-  __shared__ Fr buf[512];
-  const uint32_t p = blockIdx.x, set = blockIdx.y, lane = threadIdx.x;
-  const uint32_t n = 1u << logn;
-  if (p >= nb) return;
-  Fr* x = data + (size_t)blockIdx.z * n * B + p;
-  uint32_t stride, base, lo;
-  if (DIF) {
-    stride = n >> (s0 + 9);
-    lo = set % stride;
-    base = (set / stride) * (n >> s0) + lo;
-  } else {
-    stride = 1u << s0;
-    lo = set % stride;
-    base = (set / stride) * (stride << 9) + lo;
-  }
-#pragma unroll 1
-  for (int q = 0; q < 3; q++) {
-    const uint32_t ls = DIF ? (64u >> (3 * q)) : (1u << (3 * q));
-    const uint32_t lo_l = lane % ls, base_l = (lane / ls) * (ls * 8) + lo_l;
-    const int s0q = s0 + 3 * q;
-    const uint32_t stride_q = stride * ls, lo_q = lo + lo_l * stride;
-    Fr e[8];
-    if (q == 0) {
-#pragma unroll
-      for (int m = 0; m < 8; m++) e[m] = x[(size_t)(base + (base_l + m * ls) * stride) * B];
-    } else {
-#pragma unroll
-      for (int m = 0; m < 8; m++) e[m] = buf[base_l + m * ls];
-    }
-#pragma unroll
-    for (int t = 0; t < 3; t++) {
-      const int half = DIF ? (8 >> (t + 1)) : (1 << t);
-#pragma unroll
-      for (int m = 0; m < 8; m++) {
-        if (m & half) continue;
-        const uint32_t j = (uint32_t)(m & (half - 1)) * stride_q + lo_q;
-        const uint32_t ti = DIF ? (j << (s0q + t)) : (j << (logn - 1 - (s0q + t)));
-        if (DIF) {
-          const Fr u = e[m], v = e[m + half];
-          e[m] = u + v;
-          e[m + half] = (u - v) * tw[ti];
-        } else {
-          const Fr u = e[m], v = e[m + half] * tw[ti];
-          e[m] = u + v;
-          e[m + half] = u - v;
-        }
-      }
-    }
-    if (q == 2) {
-#pragma unroll
-      for (int m = 0; m < 8; m++) {
-        const uint32_t pos = base + (base_l + m * ls) * stride;
-        Fr o = e[m];
-        if (scale) o = o * scale[pos];
-        x[(size_t)pos * B] = o;
-      }
-    } else {
-      __syncthreads();   // (one wave: orders the reads above against the writes below)
-#pragma unroll
-      for (int m = 0; m < 8; m++) buf[base_l + m * ls] = e[m];
-      __syncthreads();
-    }
-  }
-}
-
-// h = a o b - c  (qap.rs:84-95), written over the `a` vector
-__global__ void __launch_bounds__(256) k_hquot(Fr* __restrict__ abc, uint32_t n, uint32_t B, uint32_t nb, uint32_t lg) {
-  uint32_t p = lg ? blockIdx.y : blockIdx.x * 64 + threadIdx.x;   // lg: lanes = coefficients of one proof
-  uint32_t i = lg ? blockIdx.x * 64 + threadIdx.x : blockIdx.y * blockDim.y + threadIdx.y;
-  if (p >= nb || i >= n) return;
-  size_t o = (size_t)i * B + p;
-  abc[o] = abc[o] * abc[(size_t)n * B + o] - abc[2 * (size_t)n * B + o];
-}
-
-// =====================================================================================================
-// 4. scalars -> signed digits (window j: cw[j] bits), layout [scalar][half][window][proof] (int16)
-// =====================================================================================================
-// Digits of the magnitude `l` (NL limbs, destroyed) under schedule ws; the scalar's sign flips every digit.  A window
-// of c bits yields d in [-2^(c-1), 2^(c-1)]; both ends select table entry 2^(c-1) - 1, but only one of them fits an
-// int16 at c = 16, so a window value of exactly 2^(c-1) goes to the end the sign leaves representable.
-template <int NL>
-__device__ __forceinline__ void emit_digits(uint32_t* l, bool neg, const WinSched& ws, int16_t* __restrict__ out, uint32_t B) {
-  uint32_t carry = 0;
-#pragma unroll 1
-  for (int j = 0; j < ws.W; j++) {
-    const int c = ws.cw[j];
-    const uint32_t mask = (c >= 32) ? 0xFFFFFFFFu : ((1u << c) - 1), E = 1u << (c - 1);
-    uint32_t raw = (l[0] & mask) + carry;
-#pragma unroll
-    for (int i = 0; i < NL - 1; i++) l[i] = (l[i] >> c) | (l[i + 1] << (32 - c));
-    l[NL - 1] >>= c;
-    int d;
-    if (raw > E || (raw == E && !neg)) {
-      d = (int)raw - (int)(mask + 1);
-      carry = 1;
-    } else {
-      d = (int)raw;
-      carry = 0;
-    }
-    out[(size_t)j * B] = (int16_t)(neg ? -d : d);
-  }
-}
-// Scalar ids: [0, ns) witness signals, [ns, ns + n) quotient coefficients h, then r, s, -(r s).  dig1 holds the G1
-// schedule for all of them; dig2 the G2 schedule for the ones the G2 walk uses (witness, r, s, -(r s): id - n).
-// nh = 2: every scalar is split as k1 + lambda k2 (glv.h) and both halves are recoded; nh = 1: the plain 254-bit walk.
-__global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ V, const uint32_t* __restrict__ sig2node,
-                                                uint32_t ns, const Fr* __restrict__ H, uint32_t n,
-                                                const uint32_t* __restrict__ rs, WinSched ws1, WinSched ws2, uint32_t nh,
-                                                int16_t* __restrict__ dig1, int16_t* __restrict__ dig2, uint32_t B,
-                                                uint32_t nb, uint32_t part, uint32_t lg) {
-  // part 0: every scalar; 1: the witness scalars and r, s, -(r s) (all the G2 walk needs: it can start before the
-  // quotient h exists); 2: the coefficients of h only
-  // part 3 (small full proofs, fused plan): the products s w_i, r w_i and r s under the ids ns + n + 3 + ..., G1 only
-  uint32_t p = lg ? blockIdx.y : blockIdx.x * 64 + threadIdx.x;   // lg (small batches): lanes = scalars of one proof
-  uint32_t sid = lg ? blockIdx.x * 64 + threadIdx.x : blockIdx.y * blockDim.y + threadIdx.y;
-  if (part == 1) {
-    if (sid >= ns + 3) return;
-    if (sid >= ns) sid += n;
-  } else if (part == 2) {
-    if (sid >= n) return;
-    sid += ns;
-  } else if (part == 3) {
-    if (sid >= 2 * ns + 1) return;
-    sid += ns + n + 3;
-  }
-  if (p >= nb || sid >= 3 * ns + n + 4) return;
-  Fr x;
-  if (sid >= ns + n + 3) {
-    const uint32_t q = sid - (ns + n + 3);
-    const Fr r = Fr::from_canonical(rs + (size_t)p * 16), s = Fr::from_canonical(rs + (size_t)p * 16 + 8);
-    if (q < ns)
-      x = s * V[(size_t)sig2node[q] * B + p];
-    else if (q < 2 * ns)
-      x = r * V[(size_t)sig2node[q - ns] * B + p];
-    else
-      x = r * s;
-  } else if (sid < ns) {
-    x = V[(size_t)sig2node[sid] * B + p];
-  } else if (sid < ns + n) {
-    x = H[(size_t)(sid - ns) * B + p];
-  } else {
-    Fr r = Fr::from_canonical(rs + (size_t)p * 16);
-    Fr s = Fr::from_canonical(rs + (size_t)p * 16 + 8);
-    uint32_t which = sid - ns - n;  // 0: r, 1: s, 2: -(r s)
-    x = which == 0 ? r : which == 1 ? s : (r * s).neg();
-  }
-  uint32_t l[8];
-  x.to_canonical(l);
-  const bool g2 = sid < ns || (sid >= ns + n && sid < ns + n + 3);
-  const uint32_t sid2 = sid < ns ? sid : sid - n;
-  if (nh == 2) {
-    uint32_t k[2][4], neg[2];
-    glv_split(l, k[0], &neg[0], k[1], &neg[1]);
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      uint32_t t[4];
-      if (g2) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) t[i] = k[h][i];
-        emit_digits<4>(t, neg[h] != 0, ws2, dig2 + ((size_t)sid2 * 2 + h) * ws2.W * B + p, B);
-      }
-      emit_digits<4>(k[h], neg[h] != 0, ws1, dig1 + ((size_t)sid * 2 + h) * ws1.W * B + p, B);
-    }
-  } else {
-    if (g2) {
-      uint32_t t[8];
-#pragma unroll
-      for (int i = 0; i < 8; i++) t[i] = l[i];
-      emit_digits<8>(t, false, ws2, dig2 + (size_t)sid2 * ws2.W * B + p, B);
-    }
-    emit_digits<8>(l, false, ws1, dig1 + (size_t)sid * ws1.W * B + p, B);
-  }
-}
-
-// =====================================================================================================
-// 5. table-driven MSM: acc += +-T[point][window][|digit|-1]
-// =====================================================================================================
-template <class F>
-__global__ void __launch_bounds__(64) k_msm(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ sid,
-                                            const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks,
-                                            uint32_t nchunks, const int16_t* __restrict__ digits,
-                                            XYZZ<F>* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups,
-                                            uint32_t nh) {
-  // XCD-aware decode: hardware places block L on XCD L % 8; all proof groups of one chunk share the same
-  // table rows, so they are given consecutive slots on ONE XCD and meet in that XCD's L2.
-  uint32_t L = blockIdx.x;
-  uint32_t xcd = L & 7, q = L >> 3;
-  uint32_t chunk = (q / pgroups) * 8 + xcd, pg = q % pgroups;
-  if (chunk >= nchunks) return;
-  uint32_t p = pg * 64 + threadIdx.x;  // padded lanes run on zero digits
-  ChunkDesc cd = chunks[chunk];
-  XYZZ<F> acc = XYZZ<F>::inf();
-  const int W = ws.W;
-#pragma unroll 1
-  for (uint32_t i = cd.pt_begin; i < cd.pt_end; i++) {
-    // table row; the walk (full / partial / finish) is a list of rows.  Bit 31: the row is walked with the digits of
-    // the scalar's second GLV half (the sum of those rows is mapped through phi afterwards, k_glv_fold)
-    const uint32_t kk = rows[i], k = kk & 0x7FFFFFFFu;
-    const int16_t* dg = digits + ((size_t)sid[i] * nh + (kk >> 31)) * W * B + p;
-    const Affine<F>* row = table + (size_t)k * ws.stride;
-#pragma unroll 1
-    for (int j = 0; j < W; j++) {
-      int d = dg[(size_t)j * B];
-      if (d != 0) {
-        uint32_t e = (uint32_t)(d < 0 ? -d : d) - 1;
-        Affine<F> pt = row[ws.ro[j] + e];
-        if (d < 0) pt.y = pt.y.neg();
-        acc.madd(pt);
-      }
-    }
-  }
-  part[(size_t)chunk * B + p] = acc;
-}
-
-template <class A, class E>
-__global__ void __launch_bounds__(256) k_table_to29(const A* __restrict__ src, E* __restrict__ dst, size_t n) {
-  size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= n) return;
-  dst[t] = to_table29(src[t]);
-}
-
-// dst[r][p] = sum of src[i][p] over ranges[r] -- used twice (chunks -> groups -> segments) so the
-// per-proof reduction is a two-level tree instead of one long serial chain
-template <class F>
-__global__ void __launch_bounds__(64) k_sum_ranges(const XYZZ<F>* __restrict__ src, const ChunkDesc* __restrict__ ranges,
-                                                   uint32_t nranges, XYZZ<F>* __restrict__ dst, uint32_t B, uint32_t nb) {
-  __builtin_amdgcn_s_setprio(3);  // few, latency-bound waves: issue ahead of the MSM waves sharing the SIMD
-  uint32_t p = blockIdx.x * 64 + threadIdx.x;
-  uint32_t r = blockIdx.y;
-  if (p >= nb || r >= nranges) return;
-  ChunkDesc cd = ranges[r];
-  XYZZ<F> acc = XYZZ<F>::inf();
-  for (uint32_t i = cd.pt_begin; i < cd.pt_end; i++) acc.add(src[(size_t)i * B + p]);
-  dst[(size_t)r * B + p] = acc;
-}
-
-// The same reduction for small batches, lanes = partial sums instead of lanes = proofs: with one proof in the batch
-// k_sum_ranges leaves 63 lanes idle and a G2 segment is a serial chain of 16 + 30 general additions (~ 2 ms); here the
-// 64 lanes of the wave of (proof, segment) each add their share of the segment's chunks and meet in a six-level tree
-// through LDS: 8 + 6 additions.
-// which segments / tasks a launch covers (grid.y = n): a small batch finishes s A and r B1 from the h-independent rows
-// while the h rows are still being walked, so the back-end kernels run twice on disjoint task lists
-struct TaskSel {
-  uint8_t id[8];
-};
-static TaskSel task_sel(std::initializer_list<uint32_t> ids) {
-  TaskSel t{};
-  uint32_t k = 0;
-  for (uint32_t v : ids) t.id[k++] = (uint8_t)v;
-  return t;
-}
-constexpr uint32_t SUM_TREE_LANES = 512;
-template <class F>
-__global__ void __launch_bounds__(SUM_TREE_LANES) k_sum_tree(const XYZZ<F>* __restrict__ part, const ChunkDesc* __restrict__ segchunks,
-                                                  XYZZ<F>* __restrict__ dst, uint32_t B, uint32_t PB, TaskSel sel) {
-  // 512 lanes per (proof, segment): the short chunks of the small-batch plans leave ~2 000 partial sums per segment;
-  // four per lane and a nine-level tree (part stride PB, result stride B).  The additions are a dependent chain for the
-  // lone waves of a single proof (30 us each in Fq2), so the lane count is what sets the kernel's length: 256 lanes were
-  // 8 + 8 additions.  Only the upper half of a level passes through LDS.
-  __shared__ XYZZ<F> sh[SUM_TREE_LANES / 2];
-  __builtin_amdgcn_s_setprio(3);
-  const uint32_t p = blockIdx.x, sgi = sel.id[blockIdx.y], l = threadIdx.x;
-  const ChunkDesc cd = segchunks[sgi];
-  XYZZ<F> acc = XYZZ<F>::inf();
-  for (uint32_t i = cd.pt_begin + l; i < cd.pt_end; i += SUM_TREE_LANES) acc.add(part[(size_t)i * PB + p]);
-#pragma unroll 1
-  for (uint32_t stride = SUM_TREE_LANES / 2; stride >= 1; stride >>= 1) {
-    if (l >= stride && l < 2 * stride) sh[l - stride] = acc;
-    __syncthreads();
-    if (l < stride) acc.add(sh[l]);
-    __syncthreads();
-  }
-  if (l == 0) dst[(size_t)sgi * B + p] = acc;
-}
-
-// GLV: segment t holds sum k1_i P_i, segment nseg + t holds sum k2_i P_i; the result is the first plus phi of the
-// second, phi(X, Y, ZZ, ZZZ) = (beta X, Y, ZZ, ZZZ) (x = X / ZZ).  One Fq product per output point and proof.
-__global__ void __launch_bounds__(64) k_glv_fold(G1XYZZ* __restrict__ sums1, G2XYZZ* __restrict__ sums2, uint32_t nseg1,
-                                                 uint32_t B, uint32_t nb, TaskSel sel) {
-  __builtin_amdgcn_s_setprio(3);
-  uint32_t p = blockIdx.x * 64 + threadIdx.x;
-  if (p >= nb) return;
-  const uint32_t t = sel.id[blockIdx.y];
-  if (t < nseg1) {
-    G1XYZZ a = sums1[(size_t)t * B + p], b = sums1[(size_t)(nseg1 + t) * B + p];
-    b.X = b.X * Fq::from_canonical(GlvParams::BETA_G1);
-    a.add(b);
-    sums1[(size_t)t * B + p] = a;
-  } else {
-    G2XYZZ a = sums2[p], b = sums2[(size_t)B + p];
-    b.X = b.X.mul_fq(Fq::from_canonical(GlvParams::BETA_G2));
-    a.add(b);
-    sums2[p] = a;
-  }
-}
-
-// one-time comb table: row (k, j) = { d * 2^(c j) * P_k : d = 1..2^(c-1) } in affine form.
-// Built by doubling the known prefix (multiples 1..m -> m+1..2m are "T[i] + T[m]" and one doubling) with
-// one shared inversion per level (Montgomery's trick; prefix products parked in `scratch`).
-template <class F>
-__global__ void __launch_bounds__(64) k_table_build(const Affine<F>* __restrict__ pts, uint32_t npts, WinSched ws,
-                                                    Affine<F>* __restrict__ table, F* __restrict__ scratch) {
-  const uint32_t W = (uint32_t)ws.W;
-  size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
-  if (t >= (size_t)npts * W) return;
-  uint32_t k = (uint32_t)(t / W), j = (uint32_t)(t % W);
-  const uint32_t E = 1u << (ws.cw[j] - 1);
-  XYZZ<F> b = XYZZ<F>::from_affine(pts[k]);
-  for (uint32_t i = 0; i < (uint32_t)ws.bo[j]; i++) b = b.dbl();
-  Affine<F> base = b.to_affine();
-  const size_t off = (size_t)k * ws.stride + ws.ro[j];  // even: every row has >= 2 entries (cw >= 2)
-  Affine<F>* row = table + off;
-  F* pre = scratch + off / 2;
-  row[0] = base;
-  for (uint32_t m = 1; m < E; m <<= 1) {
-    const Affine<F> Pm = row[m - 1];
-    F run = F::one();
-    for (uint32_t i = 1; i <= m; i++) {
-      F den = (i < m) ? (row[i - 1].x - Pm.x) : Pm.y.dbl();
-      pre[i - 1] = run;
-      run = run * den;
-    }
-    F inv = run.inv();
-    for (uint32_t i = m; i >= 1; i--) {
-      F den, lam, x3, y3;
-      if (i < m) {
-        Affine<F> Pi = row[i - 1];
-        den = Pi.x - Pm.x;
-        F di = inv * pre[i - 1];
-        lam = (Pi.y - Pm.y) * di;
-        x3 = lam.sqr() - Pi.x - Pm.x;
-        y3 = lam * (Pi.x - x3) - Pi.y;
-      } else {
-        den = Pm.y.dbl();
-        F di = inv * pre[i - 1];
-        F x2 = Pm.x.sqr();
-        lam = (x2.dbl() + x2) * di;
-        x3 = lam.sqr() - Pm.x.dbl();
-        y3 = lam * (Pm.x - x3) - Pm.y;
-      }
-      inv = inv * den;
-      row[m + i - 1] = {x3, y3};
-    }
-  }
-}
-
-// =====================================================================================================
-// 6. finalize: A, B affine; C = s*A + r*B1 + (L + H - rs*delta) ; compressed encoding
-//    (partial_proof.rs:232-273; the alpha/beta/delta/query[0] terms are folded into the MSM segments)
-// =====================================================================================================
-__device__ __forceinline__ bool fq_is_neg_dev(const Fq& y) {
-  uint32_t c[8];
-  y.to_canonical(c);
-  return limbs_gt(c, FqParams::HALF);
-}
-__device__ __forceinline__ void store_fq(uint32_t* dst, const Fq& x) { x.to_canonical(dst); }
-
-// Partial proofs (partial_proof.rs:108-179, 182-274).  k_partial_out: the four sums of the "known" walk leave as
-// canonical affine coordinates [pi_a | rho | pi_b | pi_c] (320 B).  k_add_partial: the same four points, given
-// back with the full witness, are added to the sums of the "unknown + H + blinding" walk before finalize.
-__global__ void __launch_bounds__(64) k_partial_out(const G1XYZZ* __restrict__ sums1, const G2XYZZ* __restrict__ sums2,
-                                                    uint32_t* __restrict__ out, uint32_t B, uint32_t nb) {
-  uint32_t p = blockIdx.x * 64 + threadIdx.x;
-  if (p >= nb) return;
-  uint32_t* o = out + (size_t)p * 80;
-  const uint32_t t = blockIdx.y;  // 0 pi_a, 1 rho, 2 pi_c, 3 pi_b
-  if (t < 3) {
-    G1Affine a = sums1[(size_t)t * B + p].to_affine();
-    uint32_t* d = o + (t == 0 ? 0 : t == 1 ? 16 : 64);
-    a.x.to_canonical(d);
-    a.y.to_canonical(d + 8);
-  } else {
-    G2Affine b = sums2[p].to_affine();
-    b.x.c0.to_canonical(o + 32);
-    b.x.c1.to_canonical(o + 40);
-    b.y.c0.to_canonical(o + 48);
-    b.y.c1.to_canonical(o + 56);
-  }
-}
-__global__ void __launch_bounds__(64) k_add_partial(G1XYZZ* __restrict__ sums1, G2XYZZ* __restrict__ sums2,
-                                                    const uint32_t* __restrict__ pp, uint32_t B, uint32_t nb) {
-  uint32_t p = blockIdx.x * 64 + threadIdx.x;
-  if (p >= nb) return;
-  const uint32_t* o = pp + (size_t)p * 80;
-  const uint32_t t = blockIdx.y;
-  if (t < 3) {
-    const uint32_t* d = o + (t == 0 ? 0 : t == 1 ? 16 : 64);
-    G1Affine a{Fq::from_canonical(d), Fq::from_canonical(d + 8)};
-    G1XYZZ acc = sums1[(size_t)t * B + p];
-    acc.madd(a);
-    sums1[(size_t)t * B + p] = acc;
-  } else {
-    G2Affine b{{Fq::from_canonical(o + 32), Fq::from_canonical(o + 40)}, {Fq::from_canonical(o + 48), Fq::from_canonical(o + 56)}};
-    G2XYZZ acc = sums2[p];
-    acc.madd(b);
-    sums2[p] = acc;
-  }
-}
-
-// F1: the three MSM sums that become proof elements go to affine form in parallel (one inversion each)
-__global__ void __launch_bounds__(64) k_fin_affine(const G1XYZZ* __restrict__ sums1, const G2XYZZ* __restrict__ sums2,
-                                                   G1Affine* __restrict__ affA, G1Affine* __restrict__ affB1,
-                                                   G2Affine* __restrict__ affB2, uint32_t B, uint32_t nb, TaskSel sel) {
-  __builtin_amdgcn_s_setprio(3);  // few, latency-bound waves: issue ahead of the MSM waves sharing the SIMD
-  uint32_t p = blockIdx.x * 64 + threadIdx.x;
-  if (p >= nb) return;
-  const uint32_t task = sel.id[blockIdx.y];
-  if (task == 0)
-    affA[p] = sums1[p].to_affine();
-  else if (task == 1)
-    affB1[p] = sums1[(size_t)B + p].to_affine();
-  else
-    affB2[p] = sums2[p].to_affine();
-}
-
-// F2: the two variable-base products s*A and r*B1 (partial_proof.rs:257-260), one lane each, fixed 4-bit
-// windows over a 15-entry table parked in HBM: 252 doublings + 63 additions instead of a bit-serial
-// double-and-add whose lanes diverge on every scalar bit.
-__global__ void __launch_bounds__(64) k_fin_smul(const G1Affine* __restrict__ affA, const G1Affine* __restrict__ affB1,
-                                                 const uint32_t* __restrict__ rs, G1XYZZ* __restrict__ tbl,
-                                                 G1XYZZ* __restrict__ prod, uint32_t B, uint32_t nb) {
-  __builtin_amdgcn_s_setprio(3);  // few, latency-bound waves: issue ahead of the MSM waves sharing the SIMD
-  uint32_t p = blockIdx.x * 64 + threadIdx.x;
-  if (p >= nb) return;
-  const uint32_t task = blockIdx.y;  // 0: s*A, 1: r*B1
-  const G1Affine P = task == 0 ? affA[p] : affB1[p];
-  const uint32_t* k = rs + (size_t)p * 16 + (task == 0 ? 8 : 0);
-  G1XYZZ* T = tbl + (size_t)task * 16 * B + p;  // T[d] at T[d * B]
-  G1XYZZ cur = G1XYZZ::from_affine(P);
-  T[(size_t)1 * B] = cur;
-#pragma unroll 1
-  for (int d = 2; d < 16; d++) {
-    cur.madd(P);
-    T[(size_t)d * B] = cur;
-  }
-  // k P = (+-k1) P + (+-k2) phi(P), |k1|, |k2| < 2^126 (glv.h): one ladder of 32 four-bit windows for both halves
-  // (126 doublings instead of 252 on this latency path); phi(T[d]) = (beta X, Y, ZZ, ZZZ) is one product per use
-  uint32_t kk[8], k1[4], k2[4], n1, n2;
-#pragma unroll
-  for (int i = 0; i < 8; i++) kk[i] = k[i];
-  glv_split(kk, k1, &n1, k2, &n2);
-  const Fq beta = Fq::from_canonical(GlvParams::BETA_G1);
-  G1XYZZ acc = G1XYZZ::inf();
-#pragma unroll 1
-  for (int w = 31; w >= 0; w--) {
-    if (w != 31) {
-      acc = acc.dbl();
-      acc = acc.dbl();
-      acc = acc.dbl();
-      acc = acc.dbl();
-    }
-    const uint32_t d1 = (k1[w >> 3] >> ((w & 7) * 4)) & 15, d2 = (k2[w >> 3] >> ((w & 7) * 4)) & 15;
-    if (d1) {
-      G1XYZZ t = T[(size_t)d1 * B];
-      if (n1) t.Y = t.Y.neg();
-      acc.add(t);
-    }
-    if (d2) {
-      G1XYZZ t = T[(size_t)d2 * B];
-      t.X = t.X * beta;
-      if (n2) t.Y = t.Y.neg();
-      acc.add(t);
-    }
-  }
-  prod[(size_t)task * B + p] = acc;  // r == 0 gives infinity, matching g1_b = 0 (partial_proof.rs:242-248)
-}
-
-// F3: C = s*A + r*B1 + (L + H - rs*delta); canonical coordinates and the compressed encoding
-__global__ void __launch_bounds__(64) k_fin_out(const G1XYZZ* __restrict__ sums1, const G1XYZZ* __restrict__ prod,
-                                                const G1Affine* __restrict__ affA, const G2Affine* __restrict__ affB2,
-                                                uint32_t* __restrict__ coords, uint8_t* __restrict__ comp, uint32_t B,
-                                                uint32_t nb) {
-  __builtin_amdgcn_s_setprio(3);  // few, latency-bound waves: issue ahead of the MSM waves sharing the SIMD
-  uint32_t p = blockIdx.x * 64 + threadIdx.x;
-  if (p >= nb) return;
-  G1XYZZ Cacc = sums1[2 * (size_t)B + p];
-  Cacc.add(prod[p]);
-  Cacc.add(prod[(size_t)B + p]);
-  G1Affine C = Cacc.to_affine();
-  G1Affine A = affA[p];
-  G2Affine B2 = affB2[p];
-  uint32_t* o = coords + (size_t)p * 64;
-  store_fq(o, A.x);
-  store_fq(o + 8, A.y);
-  store_fq(o + 16, B2.x.c0);
-  store_fq(o + 24, B2.x.c1);
-  store_fq(o + 32, B2.y.c0);
-  store_fq(o + 40, B2.y.c1);
-  store_fq(o + 48, C.x);
-  store_fq(o + 56, C.y);
-  // ark-serialize compressed Proof{a,b,c}: x with flags in the top byte (0x80: y > -y, 0x40: infinity)
-  uint32_t w[32];
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    w[i] = o[i];
-    w[8 + i] = o[16 + i];
-    w[16 + i] = o[24 + i];
-    w[24 + i] = o[48 + i];
-  }
-  if (A.is_inf()) w[7] |= 0x40000000u; else if (fq_is_neg_dev(A.y)) w[7] |= 0x80000000u;
-  if (B2.is_inf()) w[23] |= 0x40000000u;
-  else if (B2.y.c1.is_zero() ? fq_is_neg_dev(B2.y.c0) : fq_is_neg_dev(B2.y.c1)) w[23] |= 0x80000000u;
-  if (C.is_inf()) w[31] |= 0x40000000u; else if (fq_is_neg_dev(C.y)) w[31] |= 0x80000000u;
-  uint32_t* cw = (uint32_t*)(comp + (size_t)p * 128);
-#pragma unroll
-  for (int i = 0; i < 32; i++) cw[i] = w[i];
-}
-
-// =====================================================================================================
-// 7. proof values by the Poseidon formulae (witness.rs:759-828): root, a1, y, nullifier
-// =====================================================================================================
-struct InputSlots {
-  uint32_t secret, limit, msg_id, path, path_idx, x, ext, depth;
-};
-__global__ void __launch_bounds__(64) k_proof_values(const uint32_t* __restrict__ inputs, uint32_t n_inputs,
-                                                     InputSlots sl, PoseidonView p2, PoseidonView p3, PoseidonView p4,
-                                                     uint32_t* __restrict__ values, uint32_t nb) {
-  __builtin_amdgcn_s_setprio(3);  // few, latency-bound waves: issue ahead of the MSM waves sharing the SIMD
-  uint32_t p = blockIdx.x * 64 + threadIdx.x;
-  if (p >= nb) return;
-  const uint32_t* in = inputs + (size_t)p * n_inputs * 8;
-  auto ld = [&](uint32_t slot) { return Fr::from_canonical(in + (size_t)slot * 8); };
-  Fr secret = ld(sl.secret), limit = ld(sl.limit), msg = ld(sl.msg_id), x = ld(sl.x), ext = ld(sl.ext);
-  Fr h1[1] = {secret};
-  Fr idc = poseidon_hash_dev<2>(h1, p2);
-  Fr h2[2] = {idc, limit};
-  Fr root = poseidon_hash_dev<3>(h2, p3);
-#pragma unroll 1
-  for (uint32_t i = 0; i < sl.depth; i++) {
-    Fr e = ld(sl.path + i);
-    const uint32_t* bi = in + (size_t)(sl.path_idx + i) * 8;
-    uint32_t nz = 0;
-    for (int q = 0; q < 8; q++) nz |= bi[q];
-    if (nz == 0) {
-      h2[0] = root;
-      h2[1] = e;
-    } else {
-      h2[0] = e;
-      h2[1] = root;
-    }
-    root = poseidon_hash_dev<3>(h2, p3);
-  }
-  Fr h3[3] = {secret, ext, msg};
-  Fr a1 = poseidon_hash_dev<4>(h3, p4);
-  Fr y = secret + x * a1;
-  h1[0] = a1;
-  Fr nullifier = poseidon_hash_dev<2>(h1, p2);
-  uint32_t* o = values + (size_t)p * 40;
-  y.to_canonical(o);
-  root.to_canonical(o + 8);
-  nullifier.to_canonical(o + 16);
-  x.to_canonical(o + 24);
-  ext.to_canonical(o + 32);
-}
-
-// public signals w[1..npub] of every proof straight from the witness (the circuit's own outputs; for the
-// single-message circuit they equal k_proof_values' y, root, nullifier, x, external_nullifier)
-__global__ void __launch_bounds__(256) k_public_signals(const Fr* __restrict__ V, const uint32_t* __restrict__ sig2node,
-                                                        uint32_t npub, uint32_t B, uint32_t nb, uint32_t* __restrict__ out) {
-  uint32_t p = blockIdx.x * 64 + threadIdx.x;
-  uint32_t k = blockIdx.y * blockDim.y + threadIdx.y;
-  if (p >= nb || k >= npub) return;
-  V[(size_t)sig2node[1 + k] * B + p].to_canonical(out + ((size_t)p * npub + k) * 8);
-}
-
-// Small batches: k_proof_values is a lone lane's chain of 24 Poseidon hashes (5.3 ms for one proof -- longer than the
-// whole rest of the proof once the interpreter runs in 2.9 ms), and the interpreter has just computed the same five
-// values as the circuit's outputs: take them from the witness (single-message circuit: w[1..5] = y, root, nullifier,
-// x, external_nullifier, the order of k_proof_values; rln.circom's public signals, protocol/proof.rs:37-52)
-__global__ void __launch_bounds__(64) k_values_from_witness(const Fr* __restrict__ V, const uint32_t* __restrict__ sig2node,
-                                                            uint32_t B, uint32_t nb, uint32_t* __restrict__ values) {
-  const uint32_t p = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
-  if (p >= nb) return;
-  V[(size_t)sig2node[1 + k] * B + p].to_canonical(values + (size_t)p * 40 + k * 8);
-}
-
-// gathers for the parity taps
-__global__ void k_gather_col(const Fr* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t count, uint32_t B,
-                             uint32_t p, uint32_t* __restrict__ out) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  uint32_t row = idx ? idx[i] : i;
-  src[(size_t)row * B + p].to_canonical(out + (size_t)i * 8);
-}
-
-// generate_zk_proof_with_witness (protocol/proof.rs:705-732): an externally calculated witness replaces the
-// graph interpreter's.  given = [proof][signal] canonical LE; each signal is stored at the node it aliases.
-__global__ void k_scatter_witness(const uint32_t* __restrict__ given, const uint32_t* __restrict__ sig2node,
-                                  uint32_t NS, Fr* __restrict__ V, uint32_t* __restrict__ err, uint32_t B, uint32_t nb) {
-  uint32_t p = blockIdx.x * 64 + threadIdx.x;
-  uint32_t j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (p >= nb || j >= NS) return;
-  V[(size_t)sig2node[j] * B + p] = Fr::from_canonical(given + ((size_t)p * NS + j) * 8);
-  if (j == 0) err[p] = WERR_NONE;
-}
-
-// Streamed inputs: the batch's inputs, (r, s) and partial points move from the slot's pinned staging buffer to its device
-// buffers by a kernel on the batch's own front-end stream (the pinned pages are device-visible).  A hipMemcpyAsync
-// here goes through the runtime's copy path (SDMA / blit + cross-queue signalling), which with the HIP runtime torch
-// bundles (7.0) cost 8 ms per 1024-proof batch against 0 with ROCm 7.2's -- the same-box A/B is in profiles/r3_*.
-// Single-wave workgroups: a 256-thread workgroup needs four free wave slots on one CU at the same instant, which the
-// single-wave MSM workgroups streaming through the chip rarely leave (rocprofv3: 3.0 ms on average, 26.7 ms at worst
-// for this 30 us copy when it was launched as 256-thread workgroups).
-__global__ void __launch_bounds__(64) k_stage_in(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16) {
-  uint32_t i = blockIdx.x * 64 + threadIdx.x;
-  if (i < n16) dst[i] = src[i];
-}
-
-// Zeroisation of what a finished batch leaves behind.  The reference zeroises the identity secret wherever it holds it
-// (IdSecret: Zeroize + ZeroizeOnDrop, rln/src/utils.rs:440-527) and the witness calculator's inputs buffer
-// (circuit/iden3calc.rs:45-56).  Here the secret sits in the inputs of the batch and in its witness values: columns
-// [0, n) of the stored rows of V (rows == nullptr: every row) and of V29.
-__global__ void __launch_bounds__(64) k_wipe_cols(Fr* __restrict__ V, const uint32_t* __restrict__ rows, uint32_t nrows,
-                                                  uint32_t B, uint32_t n) {
-  const uint32_t p = blockIdx.x * 64 + threadIdx.x, r = blockIdx.y;
-  if (p >= n || r >= nrows) return;
-  V[(size_t)(rows ? rows[r] : r) * B + p] = Fr::zero();
-}
-__global__ void __launch_bounds__(64) k_wipe_v29(uint4* __restrict__ V29, uint32_t nrows, uint32_t B, uint32_t n) {
-  const uint32_t j = blockIdx.x * 64 + threadIdx.x, r = blockIdx.y;
-  if (j >= 3 * n || r >= nrows) return;
-  V29[(size_t)r * B * 3 + j] = make_uint4(0, 0, 0, 0);
-}
 
 // =====================================================================================================
 // host side
@@ -1199,17 +64,15 @@ struct Slot {
 struct Prover::Impl {
   hipStream_t sA = nullptr, sAb = nullptr, sA2 = nullptr, sB = nullptr, sB2 = nullptr, sC = nullptr;
   hipStream_t sV[2] = {nullptr, nullptr};  // proof values (24 chained Poseidon hashes per proof, latency-bound)
-  int wstreams = 2;  // graph interpreters in flight (RLNAMD_WSTREAMS): 16 latency-bound waves each
+  hipStream_t sW = nullptr;   // wipes: a stream of their own -- on sC a wipe would queue behind the back ends of every later
+                              // batch, and the slot's next user would wait for all of them (measured: the pipeline drained)
   uint32_t seq = 0;  // batches enqueued: consecutive front ends alternate between sA and sA2
-  bool split_msm = true;   // G2 walk on its own stream: its workgroups fill the G1 kernel's tail (RLNAMD_MSM_SPLIT)
   float ms[PROVER_STAGES] = {0};
   DevBuf<unsigned long long> walk_clk;  // clock tap of the two walks: G1 cycles, G1 ticks, G2 cycles, G2 ticks
-  bool wit29 = true;             // RLNAMD_WIT29: graph interpreter in the 9 x 29-bit form (k_witness29)
-  uint32_t lanechunk_max = 128;  // RLNAMD_LANECHUNK: largest batch that takes the small-batch shapes
-  uint32_t lanechunk_walk_max = 48;  // RLNAMD_LANECHUNK_WALK: largest lone batch whose walks run with lanes = chunks
-  uint32_t witlanes_max = 256;   // RLNAMD_WITLANES_MAX: largest batch interpreted with lanes = nodes (a wave and 157 KB of LDS per proof)
+  ProverTuning tune;             // every switch, read once (prover.h)
+  bool wit29 = true;             // = tune.wit29
+  uint32_t lanechunk_max = 128, lanechunk_walk_max = 48, witlanes_max = 256;   // = tune.*
   DevBuf<GNode29> nodes29;
-  DevBuf<unsigned long long> wit_prof;
   DevBuf<uint32_t> consts29, slot2node;
   WitLanes witlanes;             // lanes = independent nodes: the interpreter of batches walked with lanes = chunks
   uint32_t nstore29 = 0, nprog29 = 0;   // stored values, program nodes (after fusion)
@@ -1224,14 +87,9 @@ struct Prover::Impl {
   uint32_t n_mv_long = 0;
   DevBuf<Fr> a_coef, b_coef;
   DevBuf<Fr> tw_f, tw_i, coset;
-  DevBuf<uint32_t> tw_f29, tw_i29, coset29;  // the same constants as Fr29 (9 words each) for Fr29::mul_mont
-  // MSM
-  DevBuf<G1Affine> t1;
-  DevBuf<G1Affine29> t1_29;  // G1 table in the 9 x 29-bit form (default; RLNAMD_FQ29=0 keeps the 8 x 32 walk)
-  bool use29 = true;
+  // MSM: the comb tables in the packed 9 x 29-bit form (one 64-byte line per G1 entry)
+  DevBuf<G1Affine29> t1_29;
   DevBuf<G2Affine29> t2_29;
-  bool use29_g2 = true;
-  DevBuf<G2Affine> t2;
   DevBuf<uint32_t> sid1, sid2;
   // a walk = a list of table rows cut into chunks, plus the two-level reduction ranges; one per mode
   struct Plan {
@@ -1259,12 +117,9 @@ struct Prover::Impl {
   DevBuf<uint32_t> inputs, rs;
   static constexpr int NSLOT = 6;
   Slot slot[NSLOT];
-  int nslot = 5, nstreamA = 2;  // RLNAMD_SLOTS / RLNAMD_ASTREAMS
+  int nslot = 5;                // Tuning::slots
   WinSched ws{}, ws2{};         // window schedules of the G1 and G2 comb tables
   uint32_t nh = 2;              // halves per scalar: 2 = GLV split (k1 + lambda k2), 1 = plain 254-bit walk
-  bool recode_front = true;     // RLNAMD_RECODE_FRONT
-  bool ntt29 = false;           // RLNAMD_NTT29: NTT products through Fr29::mul_mont (measured: no gain, see launch site)
-  uint32_t msm_lds = 0;         // RLNAMD_MSM_WAVES (waves per SIMD the G1 walk may occupy; 0 = no cap)
   int cur = 0;
   Slot* last = nullptr;
   uint64_t tickets = 0;         // submit() tickets handed out
@@ -1277,31 +132,35 @@ struct Prover::Impl {
     const size_t n = S.n ? S.n : batch_cap;
     const size_t B = batch_cap;
     if (!n) return;
-    RLN_HIP(hipStreamWaitEvent(sC, S.evC, 0));
+    RLN_HIP(hipStreamWaitEvent(sW, S.evC, 0));
+    auto zero = [&](void* dst, size_t bytes) {   // multiples of 32 bytes (a kernel: no copy-engine / blit path in the pipeline)
+      if (bytes) hipLaunchKernelGGL(k_wipe_bytes, dim3(div_up(bytes / 16, 256)), dim3(256), 0, sW, (uint4*)dst, (uint32_t)(bytes / 16));
+    };
     if (resident) {
-      RLN_HIP(hipMemsetAsync(inputs.p, 0, std::min(inputs.bytes(), n * (size_t)NI * 32), sC));
-      RLN_HIP(hipMemsetAsync(rs.p, 0, std::min(rs.bytes(), n * 64), sC));
-      if (wgiven.p) RLN_HIP(hipMemsetAsync(wgiven.p, 0, wgiven.bytes(), sC));
+      zero(inputs.p, std::min(inputs.bytes(), n * (size_t)NI * 32));
+      zero(rs.p, std::min(rs.bytes(), n * 64));
+      if (wgiven.p) zero(wgiven.p, wgiven.bytes());
       wgiven_n = 0;
     } else {
-      volatile uint8_t* h = S.h_in;   // volatile: the stores may not be elided (explicit_bzero semantics)
-      for (size_t i = 0; i < n * (size_t)NI * 32; i++) h[i] = 0;
-      for (size_t i = 0; i < n * 64; i++) h[B * (size_t)NI * 32 + i] = 0;
-      RLN_HIP(hipMemsetAsync(S.inputs.p, 0, n * (size_t)NI * 32, sC));
-      RLN_HIP(hipMemsetAsync(S.rs.p, 0, n * 64, sC));
+      // pinned staging: plain stores followed by a compiler barrier that keeps them (explicit_bzero semantics)
+      memset(S.h_in, 0, n * (size_t)NI * 32);
+      memset(S.h_in + B * (size_t)NI * 32, 0, n * 64);
+      __asm__ __volatile__("" : : "r"(S.h_in) : "memory");
+      zero(S.inputs.p, n * (size_t)NI * 32);
+      zero(S.rs.p, n * 64);
     }
     const uint32_t pg = div_up(n, 64);
     if (wit29 && S.V29.p) {
-      hipLaunchKernelGGL(k_wipe_cols, dim3(pg, nstore29), dim3(64), 0, sC, S.V.p, slot2node.p, nstore29, (uint32_t)B, (uint32_t)n);
-      hipLaunchKernelGGL(k_wipe_v29, dim3(div_up(3 * n, 64), nstore29 + 1), dim3(64), 0, sC, S.V29.p, nstore29 + 1, (uint32_t)B,
+      hipLaunchKernelGGL(k_wipe_cols, dim3(pg, nstore29), dim3(64), 0, sW, S.V.p, slot2node.p, nstore29, (uint32_t)B, (uint32_t)n);
+      hipLaunchKernelGGL(k_wipe_v29, dim3(div_up(3 * n, 64), nstore29 + 1), dim3(64), 0, sW, S.V29.p, nstore29 + 1, (uint32_t)B,
                          (uint32_t)n);
       // an externally supplied witness (upload_witness) was stored at the signal rows
-      hipLaunchKernelGGL(k_wipe_cols, dim3(pg, NS), dim3(64), 0, sC, S.V.p, sig2node.p, NS, (uint32_t)B, (uint32_t)n);
+      hipLaunchKernelGGL(k_wipe_cols, dim3(pg, NS), dim3(64), 0, sW, S.V.p, sig2node.p, NS, (uint32_t)B, (uint32_t)n);
     } else {
-      hipLaunchKernelGGL(k_wipe_cols, dim3(pg, N), dim3(64), 0, sC, S.V.p, (const uint32_t*)nullptr, N, (uint32_t)B, (uint32_t)n);
+      hipLaunchKernelGGL(k_wipe_cols, dim3(pg, N), dim3(64), 0, sW, S.V.p, (const uint32_t*)nullptr, N, (uint32_t)B, (uint32_t)n);
     }
     RLN_HIP(hipGetLastError());
-    RLN_HIP(hipEventRecord(S.evC, sC));
+    RLN_HIP(hipEventRecord(S.evC, sW));
     S.wiped = true;
   }
 
@@ -1314,6 +173,7 @@ struct Prover::Impl {
     RLN_HIP(hipStreamSynchronize(sB));
     if (sB2) RLN_HIP(hipStreamSynchronize(sB2));
     RLN_HIP(hipStreamSynchronize(sC));
+    RLN_HIP(hipStreamSynchronize(sW));
   }
 };
 
@@ -1321,6 +181,37 @@ static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
 }
+
+// The environment is read HERE and nowhere else in the prover, once per Prover (getenv is not safe against a concurrent
+// setenv, and a switch that flips between two reads inside one enqueue would give a batch with inconsistent shapes).
+ProverTuning ProverTuning::from_env() {
+  ProverTuning t;
+  t.window_bits = env_int("RLNAMD_WINDOW_BITS", t.window_bits);
+  t.slots = env_int("RLNAMD_SLOTS", t.slots);
+  t.lanechunk_max = (uint32_t)std::max(0, env_int("RLNAMD_LANECHUNK", (int)t.lanechunk_max));
+  t.lanechunk_walk_max = (uint32_t)std::max(0, env_int("RLNAMD_LANECHUNK_WALK", (int)t.lanechunk_walk_max));
+  t.witlanes_max = (uint32_t)std::max(0, env_int("RLNAMD_WITLANES_MAX", (int)t.witlanes_max));
+  t.glv = env_int("RLNAMD_GLV", 1) != 0;
+  t.wit29 = env_int("RLNAMD_WIT29", 1) != 0;
+  t.lone = env_int("RLNAMD_LONE", -1);
+  t.early_walk = env_int("RLNAMD_EARLY_WALK", 1) != 0;
+  t.early_fin = env_int("RLNAMD_EARLY_FIN", 1) != 0;
+  t.fused_smul = env_int("RLNAMD_FUSED_SMUL", 1) != 0;
+  t.values_from_witness = env_int("RLNAMD_VALUES_WITNESS", 1) != 0;
+  t.ntt_fuse9 = env_int("RLNAMD_NTT_FUSE9", 1) != 0;
+  t.marks_small = env_int("RLNAMD_MARKS_SMALL", 0) != 0;
+  return t;
+}
+std::string ProverTuning::describe() const {
+  char b[512];
+  snprintf(b, sizeof b,
+           "window_bits=%d slots=%d lanechunk=%u lanechunk_walk=%u witlanes_max=%u glv=%d wit29=%d lone=%d early_walk=%d "
+           "early_fin=%d fused_smul=%d values_from_witness=%d ntt_fuse9=%d marks_small=%d",
+           window_bits, slots, lanechunk_max, lanechunk_walk_max, witlanes_max, (int)glv, (int)wit29, lone, (int)early_walk,
+           (int)early_fin, (int)fused_smul, (int)values_from_witness, (int)ntt_fuse9, (int)marks_small);
+  return b;
+}
+const ProverTuning& Prover::tuning() const { return d_->tune; }
 
 static uint32_t bitrev(uint32_t x, int bits) {
   uint32_t r = 0;
@@ -1338,28 +229,6 @@ static void make_reduce_ranges(const std::vector<uint32_t>& segfirst, std::vecto
       groups.push_back({c, std::min(c + G, segfirst[sgi + 1])});
     segs.push_back({g0, (uint32_t)groups.size()});
   }
-}
-
-template <class F>
-static void build_table(const std::vector<Affine<F>>& pts, const WinSched& ws, DevBuf<Affine<F>>& table, hipStream_t s) {
-  size_t npts = pts.size();
-  const size_t stride = ws.stride;
-  table.alloc(npts * stride);
-  DevBuf<Affine<F>> d_pts(npts);
-  d_pts.upload(pts.data(), npts, s);
-  // scratch is half a table; build in slabs of points so it never exceeds ~4 GiB
-  size_t per_pt = stride / 2 * sizeof(F);
-  size_t slab = std::max<size_t>(1, ((size_t)4 << 30) / per_pt);
-  slab = std::min(slab, npts);
-  DevBuf<F> scratch(slab * stride / 2);
-  for (size_t k0 = 0; k0 < npts; k0 += slab) {
-    size_t cnt = std::min(slab, npts - k0);
-    size_t threads = cnt * ws.W;
-    hipLaunchKernelGGL(k_table_build<F>, dim3(div_up(threads, 64)), dim3(64), 0, s, d_pts.p + k0, (uint32_t)cnt, ws,
-                       table.p + k0 * stride, scratch.p);
-    RLN_HIP(hipGetLastError());
-  }
-  RLN_HIP(hipStreamSynchronize(s));
 }
 
 // G1 table in the 9 x 29 form: slabs are built in the 8 x 32 form (k_table_build reads its own rows back) and
@@ -1421,12 +290,14 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   // (see WinSched); g2 = 0: the G2 table takes the G1 schedule.  With the GLV split (default; RLNAMD_GLV=0 keeps the
   // plain 254-bit walk) the windows cover the 127-bit halves: spec 114 = 15 + 8 x 14 bits, 9 windows, 18 additions
   // per G1 point; spec 715 = 7 x 16 + 15 bits, 8 windows, 16 additions per G2 point.
-  const int wb = cfg.window_bits > 0 ? cfg.window_bits : env_int("RLNAMD_WINDOW_BITS", 8);
+  D.tune = ProverTuning::from_env();
+  const int wb = cfg.window_bits > 0 ? cfg.window_bits : D.tune.window_bits;
+  D.tune.window_bits = wb;
   const int spec1 = wb % 10000, spec2 = wb / 10000 ? wb / 10000 : spec1;
-  D.nh = env_int("RLNAMD_GLV", 1) != 0 ? 2 : 1;
+  D.nh = D.tune.glv ? 2 : 1;
   const int total = D.nh == 2 ? GlvParams::HALF_BITS : 255;
   c_ = spec1 % 100;
-  const int wide = spec1 >= 100 ? spec1 / 100 : env_int("RLNAMD_WINDOW_WIDE", 0);
+  const int wide = spec1 / 100;
   D.ws = make_sched(c_, wide, total);
   D.ws2 = make_sched(spec2 % 100, spec2 >= 100 ? spec2 / 100 : (wb / 10000 ? 0 : wide), total);
   W_ = D.ws.W * D.nh;
@@ -1461,31 +332,19 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     // of the MSM's thousands of workgroups
     int lo = 0, hi = 0;
     RLN_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    const char* pe = getenv("RLNAMD_PRIO");  // experiment knob: three chars h/l for streams A, B, C
-    auto pick = [&](int i, int dflt) { return (pe && strlen(pe) == 3) ? (pe[i] == 'h' ? hi : lo) : dflt; };
-    RLN_HIP(hipStreamCreateWithPriority(&D.sA, hipStreamNonBlocking, pick(0, hi)));
-    RLN_HIP(hipStreamCreateWithPriority(&D.sA2, hipStreamNonBlocking, pick(0, hi)));
-    RLN_HIP(hipStreamCreateWithPriority(&D.sAb, hipStreamNonBlocking, pick(0, hi)));
-    for (auto& v : D.sV) RLN_HIP(hipStreamCreateWithPriority(&v, hipStreamNonBlocking, pick(2, hi)));
-    D.wstreams = env_int("RLNAMD_WSTREAMS", 2);
-    RLN_HIP(hipStreamCreateWithPriority(&D.sB, hipStreamNonBlocking, pick(1, lo)));
-    RLN_HIP(hipStreamCreateWithPriority(&D.sC, hipStreamNonBlocking, pick(2, hi)));
-    D.nslot = std::min(std::max(env_int("RLNAMD_SLOTS", 5), 2), (int)Impl::NSLOT);
-    {
-      int mw = env_int("RLNAMD_MSM_WAVES", 0);
-      D.msm_lds = mw > 0 ? (uint32_t)(160 * 1024 / (4 * mw)) & ~255u : 0;
-    }
-    D.nstreamA = env_int("RLNAMD_ASTREAMS", 2);
-    D.use29 = env_int("RLNAMD_FQ29", 1) != 0;
-    D.use29_g2 = env_int("RLNAMD_FQ29_G2", D.use29 ? 1 : 0) != 0;
-    D.recode_front = env_int("RLNAMD_RECODE_FRONT", 1) != 0;
-    D.ntt29 = env_int("RLNAMD_NTT29", 0) != 0;
-    // the G1 walk is ~12 rounds of 2.8 ms workgroups: on one stream its last round leaves SIMDs idle until the G2
-    // walk may start; on two streams the walks of neighbouring batches fill each other's tails (+3.3 - 3.7 % measured)
-    D.split_msm = env_int("RLNAMD_MSM_SPLIT", 1) != 0;
+    RLN_HIP(hipStreamCreateWithPriority(&D.sA, hipStreamNonBlocking, hi));
+    RLN_HIP(hipStreamCreateWithPriority(&D.sA2, hipStreamNonBlocking, hi));
+    RLN_HIP(hipStreamCreateWithPriority(&D.sAb, hipStreamNonBlocking, hi));
+    for (auto& v : D.sV) RLN_HIP(hipStreamCreateWithPriority(&v, hipStreamNonBlocking, hi));
+    RLN_HIP(hipStreamCreateWithPriority(&D.sB, hipStreamNonBlocking, lo));
+    RLN_HIP(hipStreamCreateWithPriority(&D.sC, hipStreamNonBlocking, hi));
+    RLN_HIP(hipStreamCreateWithPriority(&D.sW, hipStreamNonBlocking, hi));
+    D.nslot = std::min(std::max(D.tune.slots, 2), (int)Impl::NSLOT);
     D.walk_clk.alloc(4);
     RLN_HIP(hipMemset(D.walk_clk.p, 0, 4 * sizeof(unsigned long long)));
-    if (D.split_msm) RLN_HIP(hipStreamCreateWithPriority(&D.sB2, hipStreamNonBlocking, pick(1, lo)));
+    // the G1 walk is ~12 rounds of 2.8 ms workgroups: on one stream its last round leaves SIMDs idle until the G2
+    // walk may start; on two streams the walks of neighbouring batches fill each other's tails (+3.3 - 3.7 % measured)
+    RLN_HIP(hipStreamCreateWithPriority(&D.sB2, hipStreamNonBlocking, lo));
   }
   hipStream_t s = D.sB;
 
@@ -1526,14 +385,14 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   RLN_HIP(hipFuncSetAttribute((const void*)k_witness, hipFuncAttributeMaxDynamicSharedMemorySize, WIT_RING * 8 * 64 * 4 + WIT_LDS_CONSTS * 32));
   D.consts.alloc(std::max<size_t>(graph_.constants.size(), 1));
   if (!graph_.constants.empty()) D.consts.upload(graph_.constants.data(), graph_.constants.size(), s);
-  D.wit29 = env_int("RLNAMD_WIT29", 1) != 0;
+  D.wit29 = D.tune.wit29;
   // Largest batch that takes the small-batch shapes (lanes = chunks walks, a wave per proof in the interpreter, early walks
   // and back end).  tools/lanechunk_sweep.py / tools/midstream.py: one batch alone is faster that way up to ~450 proofs
   // (64: 12.4 vs 23.2 ms, 128: 17.8 vs 27.4, 256: 28.4 vs 36.8), a STREAM of such batches up to ~150 (chunks of 64: 9.4 k
   // vs 8.1 k proofs/s, 128: equal, 256: 10.1 k vs 12.1 k) -- 128 wins or ties on both.
-  D.lanechunk_max = (uint32_t)std::max(0, env_int("RLNAMD_LANECHUNK", 128));
-  D.witlanes_max = (uint32_t)std::max(0, env_int("RLNAMD_WITLANES_MAX", 256));
-  D.lanechunk_walk_max = (uint32_t)std::max(0, env_int("RLNAMD_LANECHUNK_WALK", 48));
+  D.lanechunk_max = D.tune.lanechunk_max;
+  D.witlanes_max = D.tune.witlanes_max;
+  D.lanechunk_walk_max = D.tune.lanechunk_walk_max;
   // partial sums of a small batch: [chunk][stride]
   D.small_stride = std::max<uint32_t>(64, (std::min<uint32_t>(D.lanechunk_max, (uint32_t)B_) + 63) / 64 * 64);
   std::vector<GNode29> wit29_prog;
@@ -1563,7 +422,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     for (uint32_t sgn : graph_.signals) is_signal[sgn] = 1;
     std::vector<uint32_t> fused_mul(D.N, NONE);   // for an Add: the product folded into it
     std::vector<uint8_t> removed(D.N, 0);
-    const bool fuse = env_int("RLNAMD_WIT29_FUSE", 1) != 0;
+    const bool fuse = true;
     for (uint32_t n = 0; fuse && n < D.N; n++) {
       if (G[n].op != G_ADD) continue;
       for (uint32_t m : {G[n].b, G[n].a}) {
@@ -1681,8 +540,6 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     // 152 KiB of dynamic LDS: a device / partition with a smaller limit keeps the 8 x 32 interpreter (k_witness), the
     // same fallback as for graphs with 65 536 or more stored values -- a resource limit must not fail the constructor
     if (hipFuncSetAttribute((const void*)k_witness29<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            WIT29_LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_witness29<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             WIT29_LDS_BYTES) != hipSuccess) {
       (void)hipGetLastError();
       D.wit29 = false;
@@ -1754,13 +611,6 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     D.tw_f.upload(tf.data(), tf.size(), s);
     D.tw_i.upload(ti.data(), ti.size(), s);
     D.coset.upload(cs.data(), cs.size(), s);
-    D.tw_f29.alloc(tf.size() * 9);
-    D.tw_i29.alloc(ti.size() * 9);
-    D.coset29.alloc(cs.size() * 9);
-    hipLaunchKernelGGL(k_consts_to29, dim3(div_up(tf.size(), 256)), dim3(256), 0, s, D.tw_f.p, D.tw_f29.p, (uint32_t)tf.size());
-    hipLaunchKernelGGL(k_consts_to29, dim3(div_up(ti.size(), 256)), dim3(256), 0, s, D.tw_i.p, D.tw_i29.p, (uint32_t)ti.size());
-    hipLaunchKernelGGL(k_consts_to29, dim3(div_up(cs.size(), 256)), dim3(256), 0, s, D.coset.p, D.coset29.p, (uint32_t)cs.size());
-    RLN_HIP(hipGetLastError());
     RLN_HIP(hipStreamSynchronize(s));
   }
 
@@ -1884,11 +734,11 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     for (uint32_t k = 0; k < sids.size(); k++)
       vrows.push_back({k, sids[k], sids[k], row_seg[k], sids[k] >= D.NS && sids[k] < D.NS + D.n});
     // rows (x halves) per single-wave workgroup: ~150 additions each, as before the split (8 rows x 19 windows)
-    make_plans(vrows, 3, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK", D.nh == 2 ? 16 : 8)), D.plan1, &D.max_chunks1,
+    make_plans(vrows, 3, (uint32_t)(D.nh == 2 ? 16 : 8), D.plan1, &D.max_chunks1,
                &D.max_groups1, -1);
     {
       uint32_t unused = 0;
-      make_plans(vrows, 3, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_SMALL", 4)), D.plan1s, &D.max_chunks1s, &unused, -1);
+      make_plans(vrows, 3, 4u, D.plan1s, &D.max_chunks1s, &unused, -1);
     }
     {
       // Small full proofs, fused plan: s A + r B1 - r s delta = s alpha + r beta + r s delta + sum (s w_i) A_i + sum (r w_i) B1_i,
@@ -1914,10 +764,10 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
         }
       }
       uint32_t unused = 0;
-      make_plans(f, 3, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_SMALL", 4)), D.plan1f, &D.max_chunks1s, &unused,
+      make_plans(f, 3, 4u, D.plan1f, &D.max_chunks1s, &unused,
                  PROVE_FULL);
     }
-    if (D.use29) build_table29<Fq, G1Affine29>(pts, D.ws, D.t1_29, s); else build_table<Fq>(pts, D.ws, D.t1, s);
+    build_table29<Fq, G1Affine29>(pts, D.ws, D.t1_29, s);
   }
   {
     std::vector<G2Affine> pts;
@@ -1940,13 +790,13 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     D.sid2.upload(dsid.data(), dsid.size(), s);
     std::vector<VRow> vrows;
     for (uint32_t k = 0; k < sids.size(); k++) vrows.push_back({k, sids[k], dsid[k], 0u, false});
-    make_plans(vrows, 1, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_G2", D.nh == 2 ? 8 : 4)), D.plan2, &D.max_chunks2,
+    make_plans(vrows, 1, (uint32_t)(D.nh == 2 ? 8 : 4), D.plan2, &D.max_chunks2,
                &D.max_groups2, -1);
     {
       uint32_t unused = 0;
-      make_plans(vrows, 1, (uint32_t)std::max(1, env_int("RLNAMD_MSM_CHUNK_G2_SMALL", 2)), D.plan2s, &D.max_chunks2s, &unused, -1);
+      make_plans(vrows, 1, 2u, D.plan2s, &D.max_chunks2s, &unused, -1);
     }
-    if (D.use29_g2) build_table29<Fq2, G2Affine29>(pts, D.ws2, D.t2_29, s); else build_table<Fq2>(pts, D.ws2, D.t2, s);
+    build_table29<Fq2, G2Affine29>(pts, D.ws2, D.t2_29, s);
   }
 
   // ---- named input slots for the proof-values kernel (single message-id circuit, witness.rs:832-881);
@@ -2031,14 +881,14 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
 Prover::~Prover() {
   if (!d_) return;
   Impl& D = *d_;
-  for (hipStream_t st : {D.sA, D.sAb, D.sA2, D.sB, D.sB2, D.sC, D.sV[0], D.sV[1]})
+  for (hipStream_t st : {D.sA, D.sAb, D.sA2, D.sB, D.sB2, D.sC, D.sV[0], D.sV[1], D.sW})
     if (st) (void)hipStreamSynchronize(st);
   // freed device memory is not cleared by the runtime: nothing secret-dependent goes back to the allocator
   try {
-    if (D.sC) {
+    if (D.sW) {
       for (int k = 0; k < D.nslot; k++)
         if (D.slot[k].used && !D.slot[k].wiped && D.slot[k].evC) D.wipe_slot(D.slot[k], D.slot[k].ticket == 0);
-      (void)hipStreamSynchronize(D.sC);
+      (void)hipStreamSynchronize(D.sW);
     }
   } catch (...) {
   }
@@ -2055,11 +905,11 @@ Prover::~Prover() {
     for (auto& e : S.t)
       if (e) (void)hipEventDestroy(e);
   }
-  for (hipStream_t st : {D.sA, D.sAb, D.sA2, D.sB, D.sB2, D.sC, D.sV[0], D.sV[1]})
+  for (hipStream_t st : {D.sA, D.sAb, D.sA2, D.sB, D.sB2, D.sC, D.sV[0], D.sV[1], D.sW})
     if (st) (void)hipStreamDestroy(st);
 }
 
-size_t Prover::table_bytes() const { return d_->t1.bytes() + d_->t1_29.bytes() + d_->t2.bytes() + d_->t2_29.bytes(); }
+size_t Prover::table_bytes() const { return d_->t1_29.bytes() + d_->t2_29.bytes(); }
 size_t Prover::g1_rows() const { return d_->npts1; }
 size_t Prover::g2_rows() const { return d_->npts2; }
 
@@ -2083,15 +933,13 @@ void Prover::upload_witness(size_t n, const uint8_t* w_le) {
   D.wgiven_n = n;
 }
 
-template <bool DIF, bool M29>
-static void launch_ntt(Fr* data, const uint32_t* tw, int logn, const uint32_t* final_scale, uint32_t B, uint32_t nb,
-                       hipStream_t s, bool lanes_are_groups = false) {
+template <bool DIF>
+static void launch_ntt(Fr* data, const Fr* tw, int logn, const Fr* final_scale, uint32_t B, uint32_t nb, hipStream_t s,
+                       bool lanes_are_groups, bool fuse9) {
   int s0 = 0;
-  const bool fuse9 = env_int("RLNAMD_NTT_FUSE9", 1) != 0;
-  if (lanes_are_groups && !M29 && fuse9 && logn >= 9) {   // nine levels in one kernel (k_ntt_fused9)
-    const Fr* sc = (9 == logn) ? reinterpret_cast<const Fr*>(final_scale) : nullptr;
-    hipLaunchKernelGGL((k_ntt_fused9<DIF>), dim3(nb, (1u << logn) >> 9, 3), dim3(64), 0, s, data,
-                       reinterpret_cast<const Fr*>(tw), logn, 0, sc, B, nb);
+  if (lanes_are_groups && fuse9 && logn >= 9) {   // nine levels in one kernel (k_ntt_fused9)
+    const Fr* sc = (9 == logn) ? final_scale : nullptr;
+    hipLaunchKernelGGL((k_ntt_fused9<DIF>), dim3(nb, (1u << logn) >> 9, 3), dim3(64), 0, s, data, tw, logn, 0, sc, B, nb);
     RLN_HIP(hipGetLastError());
     s0 = 9;
   }
@@ -2099,30 +947,26 @@ static void launch_ntt(Fr* data, const uint32_t* tw, int logn, const uint32_t* f
     const int rem = logn - s0, K = rem >= 3 ? 3 : 1;
     const uint32_t groups = (1u << logn) >> K;
     dim3 block(64, 1), grid(nb, div_up(groups, 64), 3);
-    const uint32_t* sc = (s0 + K == logn) ? final_scale : nullptr;
+    const Fr* sc = (s0 + K == logn) ? final_scale : nullptr;
     if (K == 3)
-      hipLaunchKernelGGL((k_ntt_pass<3, DIF, M29, true>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb);
+      hipLaunchKernelGGL((k_ntt_pass<3, DIF, true>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb);
     else
-      hipLaunchKernelGGL((k_ntt_pass<1, DIF, M29, true>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb);
+      hipLaunchKernelGGL((k_ntt_pass<1, DIF, true>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb);
     RLN_HIP(hipGetLastError());
     s0 += K;
   }
   while (s0 < logn) {
-    int rem = logn - s0;
-    static const int maxk = env_int("RLNAMD_NTT_MAXK", 3);
-    int K = rem > maxk ? 3 : rem;  // 13 -> 3,3,3,3,1 (a 16-point block spills; measured 6.7 -> 5.0 ms)
-    if (K > maxk) K = maxk;
-    uint32_t groups = (1u << logn) >> K;
+    const int rem = logn - s0;
+    const int K = rem > 3 ? 3 : rem;  // 13 -> 3,3,3,3,1 (a 16-point block spills; measured 6.7 -> 5.0 ms)
+    const uint32_t groups = (1u << logn) >> K;
     // one wave per workgroup: a 4-wave workgroup needs four free wave slots on one CU at the same moment, which the
     // single-wave MSM workgroups streaming through the chip never leave (measured: mat-vec 0.6 -> 32 ms, NTT 5 -> 19 ms)
-    static const int wpb = env_int("RLNAMD_NTT_WPB", 1);
-    dim3 block(64, wpb), grid(div_up(nb, 64), div_up(groups, wpb), 3);
-    const uint32_t* sc = (s0 + K == logn) ? final_scale : nullptr;
+    dim3 block(64, 1), grid(div_up(nb, 64), groups, 3);
+    const Fr* sc = (s0 + K == logn) ? final_scale : nullptr;
     switch (K) {
-      case 1: hipLaunchKernelGGL((k_ntt_pass<1, DIF, M29>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb); break;
-      case 2: hipLaunchKernelGGL((k_ntt_pass<2, DIF, M29>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb); break;
-      case 3: hipLaunchKernelGGL((k_ntt_pass<3, DIF, M29>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb); break;
-      default: hipLaunchKernelGGL((k_ntt_pass<4, DIF, M29>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb); break;
+      case 1: hipLaunchKernelGGL((k_ntt_pass<1, DIF>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb); break;
+      case 2: hipLaunchKernelGGL((k_ntt_pass<2, DIF>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb); break;
+      default: hipLaunchKernelGGL((k_ntt_pass<3, DIF>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb); break;
     }
     RLN_HIP(hipGetLastError());
     s0 += K;
@@ -2181,11 +1025,7 @@ void Prover::wipe(uint64_t ticket) {
   if (ticket == 0) {
     D.sync_all();
     if (D.last) D.wipe_slot(*D.last, true);
-    else {
-      RLN_HIP(hipMemsetAsync(D.inputs.p, 0, D.inputs.bytes(), D.sC));
-      RLN_HIP(hipMemsetAsync(D.rs.p, 0, D.rs.bytes(), D.sC));
-    }
-    RLN_HIP(hipStreamSynchronize(D.sC));
+    RLN_HIP(hipStreamSynchronize(D.sW));
     return;
   }
   for (int k = 0; k < D.nslot; k++)
@@ -2249,21 +1089,20 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   Impl& D = *d_;
   // lone: nothing else in flight -- the batch may trade throughput for latency (the fused plan's + 25 % G1 rows, the
   // single-stream chains, the wave-per-proof interpreter above the small-batch threshold)
-  const int lone_force = env_int("RLNAMD_LONE", -1);   // -1: detect; 0 / 1: force (measurements, tests)
+  const ProverTuning& T = D.tune;
+  const int lone_force = T.lone;   // -1: detect; 0 / 1: force (measurements, tests)
   const bool lone = lone_force >= 0 ? lone_force != 0 : (!D.last || hipEventQuery(D.last->evC) == hipSuccess);
   (void)hipGetLastError();   // hipErrorNotReady is not an error here
-  const bool small = n <= D.lanechunk_max && n <= D.small_stride && D.use29 && D.use29_g2;   // lanes = chunks
+  const bool small = n <= D.lanechunk_max && n <= D.small_stride;   // lanes = chunks
   // Small batches (latency, not throughput): the whole front end stays on ONE stream (every cross-stream event hop costs
   // 0.1 - 0.15 ms), the digits of the witness scalars are recoded right behind the interpreter, and both walks start on
   // everything that does not depend on the quotient h while mat-vec / NTTs still run; only the h rows of the G1 walk
   // wait for them.
-  const bool early = n <= D.lanechunk_max && D.use29 && D.use29_g2 && D.split_msm && D.recode_front &&
-                     mode != PROVE_PARTIAL && env_int("RLNAMD_EARLY_WALK", 1) != 0;
+  const bool early = n <= D.lanechunk_max && mode != PROVE_PARTIAL && T.early_walk;
   // small full proofs: s A and r B1 are rows of the C segment (plan1f), no k_fin_smul
   // (up to 96 proofs: above, the walks are issue-bound even for a lone batch and the extra rows cost more than the ladder
   // they replace -- 128 proofs 16.6 -> 15.3 ms without them, 64 proofs 10.1 -> 10.3 ms)
-  const bool fused = lone && n <= 96 && early && small && mode == PROVE_FULL && D.nh == 2 && env_int("RLNAMD_FUSED_SMUL", 1) != 0 &&
-                     env_int("RLNAMD_EARLY_FIN", 1) != 0;   // (its back end is the split one below)
+  const bool fused = lone && n <= 96 && early && small && mode == PROVE_FULL && D.nh == 2 && T.fused_smul && T.early_fin;   // (its back end is the split one below)
   const Impl::Plan& P1 = fused ? D.plan1f[PROVE_FULL] : small ? D.plan1s[mode] : D.plan1[mode];
   const Impl::Plan& P2 = small ? D.plan2s[mode] : D.plan2[mode];
   const uint32_t PB = small ? D.small_stride : (uint32_t)B_;   // stride of the partial-sum arrays
@@ -2292,21 +1131,19 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // proofs, ~28 ms), A2 = mat-vec + NTTs + quotient (throughput kernels squeezed in beside the MSM, ~25 ms contended).
   // Chained on one stream they were the critical path (54 ms against 49 ms of MSM).
   const uint32_t sq = D.seq++;
-  hipStream_t sA = (D.nstreamA > 1 && D.wstreams > 1 && (sq & 1)) ? D.sAb : D.sA;
+  hipStream_t sA = (sq & 1) ? D.sAb : D.sA;   // two graph interpreters in flight: 16 latency-bound waves each
   const uint32_t B = (uint32_t)B_, nb = (uint32_t)n;
-  hipStream_t sA2 = (D.nstreamA > 1 && !early) ? D.sA2 : sA;
+  hipStream_t sA2 = !early ? D.sA2 : sA;
   const uint32_t pg = div_up(nb, 64);
   const uint32_t nbp = pg * 64;  // padded lanes compute on stale / zero inputs; results ignored
   // ---------------- stage A
   if (S.used) RLN_HIP(hipStreamWaitEvent(sA, S.evC, 0));  // slot free again
   if (streamed) {
-    static const bool h2d_kernel = env_int("RLNAMD_H2D_KERNEL", 1) != 0;
+    // by a kernel reading the pinned pages, not by hipMemcpyAsync: with the copy path in the pipeline every batch lost 8 ms
+    // under the HIP runtime the torch wheel bundles (cross-queue signalling; profiles/r3_rocprof_summary.md section 1)
     auto h2d = [&](void* dst, const uint8_t* src, size_t bytes) {   // sizes are multiples of 32
-      if (h2d_kernel)
-        hipLaunchKernelGGL(k_stage_in, dim3(div_up(bytes / 16, 64)), dim3(64), 0, sA, (const uint4*)src, (uint4*)dst,
-                           (uint32_t)(bytes / 16));
-      else
-        RLN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, sA));
+      hipLaunchKernelGGL(k_stage_in, dim3(div_up(bytes / 16, 64)), dim3(64), 0, sA, (const uint4*)src, (uint4*)dst,
+                         (uint32_t)(bytes / 16));
     };
     h2d(S.inputs.p, S.h_in, n * (size_t)D.NI * 32);
     h2d(S.rs.p, S.h_in + B_ * (size_t)D.NI * 32, n * 64);
@@ -2317,7 +1154,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // Timing marks (stage_ms): a timed event record is a barrier packet and a timestamp write on its stream -- three of
   // them sit between the interpreter and the mat-vec of a single proof (~0.1 ms of its 5 ms).  Small batches record
   // them only when asked to (RLNAMD_MARKS_SMALL=1; tools/single_latency.py); their stage_ms reads 0 otherwise.
-  const bool marks = nb > D.lanechunk_max || env_int("RLNAMD_MARKS_SMALL", 0) != 0;
+  const bool marks = nb > D.lanechunk_max || T.marks_small;
   S.marked = marks;
 #define MARK(i, stream)                                   \
   do {                                                    \
@@ -2329,18 +1166,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   const bool wl_used = D.wit29 && D.witlanes.ok && (nb <= D.lanechunk_max || (nb <= D.witlanes_max && lone));
   MARK(1, sA);
   if (D.wit29) {
-    static const bool prof = env_int("RLNAMD_WIT_PROF", 0) != 0;   // diagnostic: cycles per node class, on stderr
-    if (prof) {
-      DevBuf<unsigned long long>& pb = D.wit_prof;
-      if (!pb.p) pb.alloc(16);
-      hipLaunchKernelGGL(k_witness29<true>, dim3(pg), dim3(64), WIT29_LDS_BYTES, sA, D.nodes29.p, D.nprog29,
-                         D.consts29.p, (uint32_t)graph_.constants.size(), in_p, D.NI, S.V29.p, S.err.p, B, nbp, pb.p);
-      unsigned long long h[16];
-      RLN_HIP(hipStreamSynchronize(sA));
-      RLN_HIP(hipMemcpy(h, pb.p, sizeof(h), hipMemcpyDeviceToHost));
-      fprintf(stderr, "wit29 prof: mul %llu cyc / %llu, add %llu / %llu, const+input %llu / %llu, other %llu / %llu; total %llu cyc, %.3f ms, clock %.0f MHz\n",
-              h[0], h[4], h[1], h[5], h[2], h[6], h[3], h[7], h[8], h[9] / 1e5, h[9] ? 100.0 * h[8] / h[9] : 0.0);
-    } else if (wl_used) {
+    if (wl_used) {
       D.witlanes.launch(sA, D.consts29.p, in_p, D.NI, S.V29.p, S.err.p, B, nb);
     } else
     hipLaunchKernelGGL(k_witness29<false>, dim3(pg), dim3(64), WIT29_LDS_BYTES, sA, D.nodes29.p, D.nprog29,
@@ -2391,7 +1217,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     }
     MARK(14, D.sB);
     if (P1.n_early && walk_lp)
-      hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(div_up(P1.n_early, 8) * 8 * pg), dim3(64), D.msm_lds,
+      hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(div_up(P1.n_early, 8) * 8 * pg), dim3(64), 0,
                          D.sB, D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.n_early, S.digits.p, S.part1.p, D.ws, B, pg,
                          D.nh, nullptr, P1.early_ids.p, PB);
     else if (P1.n_early)
@@ -2414,30 +1240,17 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   }
   MARK(3, sA2);
   if (mode != PROVE_PARTIAL) {
-    // Twiddle products through Fr29::mul_mont need ~290 instead of ~375 instructions, but same-box A/B runs gave
-    // 20.21 / 20.26 k against 20.30 / 20.24 k proofs/s: beside the table walks the passes are bound by HBM and by
-    // waiting for SIMD slots, not by their instruction count.  Kept selectable (RLNAMD_NTT29=1), off by default.
-    if (D.ntt29) {
-      launch_ntt<true, true>(S.abc.p, D.tw_i29.p, D.logn, D.coset29.p, B, nbp, sA2);  // iNTT (DIF) + g^i / n
-      launch_ntt<false, true>(S.abc.p, D.tw_f29.p, D.logn, nullptr, B, nbp, sA2);     // NTT (DIT)
-    } else {
-      const bool lg = nb <= D.lanechunk_max;   // below a wave of proofs: lanes = groups
-      launch_ntt<true, false>(S.abc.p, (const uint32_t*)D.tw_i.p, D.logn, (const uint32_t*)D.coset.p, B, lg ? nb : nbp, sA2, lg);
-      launch_ntt<false, false>(S.abc.p, (const uint32_t*)D.tw_f.p, D.logn, nullptr, B, lg ? nb : nbp, sA2, lg);
-    }
+    const bool lg = nb <= D.lanechunk_max;   // below a wave of proofs: lanes = groups
+    launch_ntt<true>(S.abc.p, D.tw_i.p, D.logn, D.coset.p, B, lg ? nb : nbp, sA2, lg, T.ntt_fuse9);   // iNTT (DIF) + g^i / n
+    launch_ntt<false>(S.abc.p, D.tw_f.p, D.logn, nullptr, B, lg ? nb : nbp, sA2, lg, T.ntt_fuse9);    // NTT (DIT)
     if (nb <= D.lanechunk_max)
       hipLaunchKernelGGL(k_hquot, dim3(div_up(D.n, 64), nb), dim3(64, 1), 0, sA2, S.abc.p, D.n, B, nb, 1u);
     else
       hipLaunchKernelGGL(k_hquot, dim3(pg, D.n), dim3(64, 1), 0, sA2, S.abc.p, D.n, B, nbp, 0u);
   }
   MARK(4, sA2);
-  // digit recoding either closes the front end (the MSM stream then carries nothing but the two table walks) or
-  // opens the MSM stage (RLNAMD_RECODE_FRONT=0)
-  hipStream_t sR = D.recode_front ? sA2 : D.sB;
-  if (!D.recode_front) {
-    RLN_HIP(hipEventRecord(S.evA, sA2));
-    RLN_HIP(hipStreamWaitEvent(D.sB, S.evA, 0));
-  }
+  // digit recoding closes the front end: the MSM streams carry nothing but the two table walks
+  hipStream_t sR = sA2;
   MARK(5, sR);
   if (early_g2)
     hipLaunchKernelGGL(k_recode, dim3(div_up(D.n, 64), nb), dim3(64, 1), 0, sR, S.V.p, D.sig2node.p, D.NS, S.abc.p, D.n,
@@ -2447,21 +1260,21 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
                        S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nbp, 0u, 0u);
   MARK(6, sR);
   // ---------------- stage B
-  if (D.recode_front && !early) {
+  if (!early) {
     RLN_HIP(hipEventRecord(S.evA, sA2));
     RLN_HIP(hipStreamWaitEvent(D.sB, S.evA, 0));
   }
   if (!early) MARK(14, D.sB);
-  // below half a wave of proofs the walks run with lanes = chunks (walk29.h); RLNAMD_LANECHUNK overrides the threshold
+  // small batches walk with lanes = chunks (walk29.h); ProverTuning::lanechunk_max is the threshold
   const bool lanechunk = nb <= D.lanechunk_max;
-  hipStream_t s2 = D.split_msm ? D.sB2 : D.sB;
-  if (D.split_msm && !early) {   // (early: sB2 already waits for the witness + part-1 digits, all the G2 walk reads)
+  hipStream_t s2 = D.sB2;   // the G2 walk on its own stream: its workgroups fill the G1 kernel's tail
+  if (!early) {   // (early: sB2 already waits for the witness + part-1 digits, all the G2 walk reads)
     RLN_HIP(hipEventRecord(S.evR, D.sB));
     RLN_HIP(hipStreamWaitEvent(D.sB2, S.evR, 0));
   }
   if (early) {   // the h rows, on the front-end stream itself (no event hop); everything else is already walking
     if (P1.n_late && walk_lp)
-      hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(div_up(P1.n_late, 8) * 8 * pg), dim3(64), D.msm_lds,
+      hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(div_up(P1.n_late, 8) * 8 * pg), dim3(64), 0,
                          sA, D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.n_late, S.digits.p, S.part1.p, D.ws, B, pg,
                          D.nh, nullptr, P1.late_ids.p, PB);
     else if (P1.n_late)
@@ -2472,41 +1285,33 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     RLN_HIP(hipStreamWaitEvent(D.sB, S.evR, 0));   // evB below then covers both launches
   } else if (P1.nchunks) {
     uint32_t blocks = div_up(P1.nchunks, 8) * 8 * pg;
-    if (D.use29 && lanechunk)
+    if (lanechunk)
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>), dim3(div_up(P1.nchunks, 64), nb), dim3(64), 0, D.sB,
                          D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.nchunks, S.digits.p, S.part1.p, D.ws, B, PB, D.nh,
                          nullptr);
-    else if (D.use29)
-      // dynamic LDS that the kernel never touches caps it at D.msm_waves waves per SIMD: at 4 x 128 VGPRs the
-      // register file is full and the front end's NTT / mat-vec workgroups wait for an MSM workgroup (~1 ms) to retire
-      hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(blocks), dim3(64), D.msm_lds, D.sB, D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p,
-                         P1.nchunks, S.digits.p, S.part1.p, D.ws, B, pg, D.nh, D.walk_clk.p);
     else
-      hipLaunchKernelGGL(k_msm<Fq>, dim3(blocks), dim3(64), 0, D.sB, D.t1.p, P1.rsid.p, P1.rows.p, P1.chunks.p,
-                         P1.nchunks, S.digits.p, S.part1.p, D.ws, B, pg, D.nh);
+      hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(blocks), dim3(64), 0, D.sB, D.t1_29.p, P1.rsid.p,
+                         P1.rows.p, P1.chunks.p, P1.nchunks, S.digits.p, S.part1.p, D.ws, B, pg, D.nh, D.walk_clk.p);
   }
   MARK(7, D.sB);
   MARK(11, s2);
   if (P2.nchunks) {
     uint32_t blocks = div_up(P2.nchunks, 8) * 8 * pg;
-    if (D.use29_g2 && walk_lp)
+    if (walk_lp)
       hipLaunchKernelGGL((k_msm29<G2Acc29, G2Affine29, G2XYZZ, 2>), dim3(blocks), dim3(64), 0, s2, D.t2_29.p, P2.rsid.p,
                          P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, pg, D.nh, nullptr, nullptr, PB);
-    else if (D.use29_g2 && lanechunk)
+    else if (lanechunk)
       hipLaunchKernelGGL((k_msm29<G2Acc29, G2Affine29, G2XYZZ, 1, true>), dim3(div_up(P2.nchunks, 64), nb), dim3(64), 0, s2,
                          D.t2_29.p, P2.rsid.p, P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, PB, D.nh,
                          nullptr);
-    else if (D.use29_g2)
+    else
       hipLaunchKernelGGL((k_msm29<G2Acc29, G2Affine29, G2XYZZ, 2>), dim3(blocks), dim3(64), 0, s2, D.t2_29.p, P2.rsid.p,
                          P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, pg, D.nh,
                          D.walk_clk.p ? D.walk_clk.p + 2 : nullptr);
-    else
-      hipLaunchKernelGGL(k_msm<Fq2>, dim3(blocks), dim3(64), 0, s2, D.t2.p, P2.rsid.p, P2.rows.p, P2.chunks.p,
-                         P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, pg, D.nh);
   }
   MARK(8, s2);
   RLN_HIP(hipEventRecord(S.evB, D.sB));
-  if (D.split_msm) RLN_HIP(hipEventRecord(S.evB2, D.sB2));
+  RLN_HIP(hipEventRecord(S.evB2, D.sB2));
   // ---------------- stage C
   // proof values (Poseidon chain, latency-bound, depends on the inputs only): the back-end stream has slack
   hipStream_t sV = D.sV[sq & 1];
@@ -2517,7 +1322,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   if (streamed) RLN_HIP(hipStreamWaitEvent(sV, S.evU, 0));
   MARK(0, sV);
   // (whenever the batch is small enough for the lanes = nodes interpreter: the Poseidon chain alone is 5.3 ms)
-  const bool values_w = (early || wl_used) && D.have_values_kernel && D.ni == 6 && env_int("RLNAMD_VALUES_WITNESS", 1) != 0;
+  const bool values_w = (early || wl_used) && D.have_values_kernel && D.ni == 6 && T.values_from_witness;
   if (values_w) {   // small batches: the circuit's own outputs (see k_values_from_witness)
     RLN_HIP(hipStreamWaitEvent(sV, S.evX, 0));   // sA: witness stored
     hipLaunchKernelGGL(k_values_from_witness, dim3(pg, 5), dim3(64), 0, sV, S.V.p, D.sig2node.p, B, nbp, S.values.p);
@@ -2528,10 +1333,10 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // Small full proofs: A and B1 are sums over h-independent rows only, so their reduction, the two inversions and the two
   // variable-base products s A, r B1 (the longest kernel of the back end) run on the idle sA2 as soon as the early G1
   // walk is done -- beside the NTTs and the walk of the h rows, not behind them.  sums1 segments: h * 3 + {A, B1, C}.
-  const bool early_fin = early && mode == PROVE_FULL && D.nh == 2 && env_int("RLNAMD_EARLY_FIN", 1) != 0;
+  const bool early_fin = early && mode == PROVE_FULL && D.nh == 2 && T.early_fin;
   const TaskSel all6 = task_sel({0, 1, 2, 3, 4, 5}), all4 = task_sel({0, 1, 2, 3}), all3 = task_sel({0, 1, 2});
   // below a wave of proofs s A / r B1 are a lone lane's chain: NAF ladder in the 9 x 29 form (fin29.hip)
-  const bool fin29 = nb <= D.lanechunk_max && D.use29 && env_int("RLNAMD_FIN29", 1) != 0;
+  const bool fin29 = nb <= D.lanechunk_max;
   hipStream_t sF = D.sC;   // the stream of k_fin_out and of the copies to the host
   if (early_fin) {
     RLN_HIP(hipStreamWaitEvent(D.sA2, S.evE, 0));   // sB: the early G1 walk
@@ -2591,7 +1396,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     RLN_HIP(hipEventRecord(S.evV, sV));
     RLN_HIP(hipStreamWaitEvent(D.sC, S.evV, 0));
     RLN_HIP(hipStreamWaitEvent(D.sC, S.evB, 0));
-    if (D.split_msm) RLN_HIP(hipStreamWaitEvent(D.sC, S.evB2, 0));
+    RLN_HIP(hipStreamWaitEvent(D.sC, S.evB2, 0));
     MARK(9, D.sC);
   }
   if (early_fin) {

@@ -382,10 +382,6 @@ void WitLanes::build(const Graph& graph, const std::vector<uint32_t>& store_slot
     return;
   }
   ok = true;
-  const char* info = getenv("RLNAMD_WITLANES_INFO");
-  if (info && info[0] == '1')
-    fprintf(stderr, "witness lanes: %u steps (%u row, %u fma, %u sqr, %u add, %u misc), peak %u live values, %u constants\n",
-            nsteps, nrow, nfma, nsqr, nadd, nmisc, peak_slots, n_consts);
 }
 
 void WitLanes::launch(hipStream_t s, const uint32_t* d_consts29, const uint32_t* d_inputs, uint32_t n_inputs, uint4* V29,
