@@ -118,7 +118,7 @@ TREE_SCATTERED = 1000    # scattered updates followed by ONE root read
 
 def load_pmc(info, B):
     """the committed PMC passes of the walks, if they were taken on this schedule and this build of the walk"""
-    for name in ("r3_pmc_walks.json", "r2_pmc_walks.json"):
+    for name in ("r4_pmc_walks.json", "r3_pmc_walks.json", "r2_pmc_walks.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:  # noqa: BLE001
@@ -533,9 +533,11 @@ def main():
     results.clear()
     sync()
     t0 = time.perf_counter()
+    c0 = time.process_time()
     pump(args.steps * per_step)       # H2D of every batch's inputs ... D2H of its proofs, all inside
     sync()
     elapsed = time.perf_counter() - t0
+    cpu_timed = time.process_time() - c0
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -554,6 +556,33 @@ def main():
     # distinct inputs give distinct proofs: the stream really was K different batches
     distinct = len({r[0][:128] for r in results.values()}) == len(results)
 
+    # ---- what the HOST pays to feed one GPU (eight of them hang off one host): process CPU seconds over the
+    #      timed region, and the wall time of the two calls by themselves -- submit with a free slot (copy into pinned
+    #      memory + ~40 kernel launches) and collect of a finished batch (copy-out + the wipe's launches)
+    host_feed = None
+    if not finish and world == 1 and args.steps > 0:
+        t_sub, t_col = [], []
+        sync()
+        tk = []
+        for k in range(nslots):
+            t0 = time.perf_counter()
+            tk.append(prover.submit(batches[k % nbatches][0], batches[k % nbatches][1])[0])
+            t_sub.append(time.perf_counter() - t0)
+        prover.sync()
+        for t in tk:
+            t0 = time.perf_counter()
+            prover.collect_raw(t, B)
+            t_col.append(time.perf_counter() - t0)
+        sub_ms, col_ms = sorted(t_sub)[len(t_sub) // 2] * 1e3, sorted(t_col)[len(t_col) // 2] * 1e3
+        host_feed = {"cpu_s_over_timed_region": round(cpu_timed, 3), "wall_s_timed_region": round(elapsed, 3),
+                     "host_cores_busy": round(cpu_timed / elapsed, 3),
+                     "submit_ms_per_batch": round(sub_ms, 3), "collect_ms_per_batch": round(col_ms, 3),
+                     "host_us_per_proof": round((sub_ms + col_ms) * 1e3 / B, 3),
+                     "host_cores_for_8_gpus_at_this_rate": round(8 * (sub_ms + col_ms) / (elapsed / max(args.steps, 1) * 1e3), 3),
+                     "note": "submit = copy of the batch's inputs into the slot's pinned buffer + the launches of the whole "
+                             "pipeline; collect (batch already finished) = copy-out of proofs / values + the wipe's launches; "
+                             "host_cores_busy = process CPU time / wall over the timed region (includes the runtime's "
+                             "busy-wait inside collect: an upper bound on what feeding needs)"}
     clock_mhz = prover.walk_clock_mhz()   # mean shader clock under the two walks over the timed region
     stage_ms = prover.stage_ms()          # HIP-event spans, mean over the last five launches (overlapped with their neighbours)
     # the dominant kernel by itself: single batches with nothing else in flight (outside the timed region)
@@ -694,6 +723,8 @@ def main():
         line.update(side)
         if latency is not None:
             line["single_proof_latency"] = latency
+        if host_feed is not None:
+            line["host_feed"] = host_feed
         if "config5" in side:
             line["rccl_ranks"] = side["config5"]["rccl_ranks"]
         if world == 1 and not args.no_cpu_baseline:

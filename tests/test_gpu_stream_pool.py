@@ -253,6 +253,67 @@ def test_two_processes_sharing_the_device_msm_sharded_and_prove_sharded(prover):
     assert got["pub"] == [[str(v) for v in o["public_inputs"]] for o in ref]
 
 
+# ------------------------------------------------------------------------------- eight-way readiness on one device
+def test_config4_full_65536_over_eight_replicas_on_one_device_boundaries_vs_c_oracle():
+    """BASELINE config 4 at its FULL size through the multi-GPU code path: 65 536 proofs over EIGHT prover replicas
+    (rlnamd_pool with the one device listed eight times: eight host threads, eight sets of tables and workspaces, c = 8
+    tables so that they fit beside each other), contiguous shards of 8 192.  No error flag, no two proofs equal, every
+    shard boundary (last index of shard k, first of shard k + 1) and the ends byte-equal to oracle/c, a sample verified"""
+    from zerokit_amd import workload
+    from zerokit_amd.batch import ProverPool
+    n, shard = 65536, 8192
+    from zerokit_amd.batch import BatchProver
+    probe = BatchProver(max_batch=64, window_bits=8)       # the input slots come from the graph; any prover knows them
+    slots = dict(probe.slots)
+    probe.close()
+    pool = ProverPool(devices=[0] * 8, max_batch=1024, window_bits=8)
+    try:
+        assert pool.size == 8
+        inputs, rsb = workload.config2_packed(slots, pool.inputs_size, 0, n)
+        proofs, values, errs = pool.prove_raw(inputs, rsb)
+        assert not any(errs)
+        ms = pool.last_ms()
+        assert len(ms) == 8 and all(m > 0 for m in ms)
+        got_proofs, got_pub = _split(proofs, values, n)
+        assert len(set(got_proofs)) == n
+        idx = sorted({0, n - 1} | {k * shard - 1 for k in range(1, 8)} | {k * shard for k in range(1, 8)} |
+                     {k * shard + 1023 for k in range(8)} | {k * shard + 1024 for k in range(8)})
+        ws, rs = [], []
+        for i in idx:
+            w, r = workload.config2_range(i, 1)
+            ws += w
+            rs += r
+        ref_proofs, ref_pub = _oracle(ws, rs)
+        assert [got_proofs[i] for i in idx] == ref_proofs
+        assert [got_pub[i] for i in idx] == ref_pub
+        sample = list(range(0, n, 1009))
+        assert all(pool.verify_many([got_proofs[i] for i in sample], [got_pub[i] for i in sample]))
+    finally:
+        pool.close()
+
+
+def test_bench_under_torchrun_with_eight_ranks_on_one_device():
+    """`bench.py --gpus 8` exactly as the driver launches it (python -m torch.distributed.run, one process per rank), on
+    a box with ONE device: every rank is pinned to device 0 (RLNAMD_BENCH_DEVICE) with gloo in place of RCCL, which
+    refuses two ranks on one device, and small tables so that eight provers fit.  rc 0, exactly one JSON line on stdout,
+    n_gpus 8, config 4 (8 x 8 192 proofs per step), verified"""
+    import json
+    port = _free_port()
+    env = dict(os.environ, RLNAMD_BENCH_DEVICE="0", RLNAMD_BENCH_BACKEND="gloo", RLNAMD_WINDOW_BITS="8",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0",
+           "--no-side-configs"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 1 and d["unit"] == "proofs/s" and d["scaling"] == "weak"
+    assert d["config"]["verified"] is True and d["config"]["batch_per_gpu"] == 8192
+    assert abs(d["value"] - 8 * 8192 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+
+
 # ------------------------------------------------------------------- full sizes on the bench schedule (last: 228 GiB)
 @pytest.fixture(scope="module")
 def bench_prover():

@@ -1,0 +1,33 @@
+"""AddressSanitizer + UBSan build of the product's host code that parses bytes it does not control (SURVEY section 5:
+sanitizers belong to the CPU suite; the GPU pool refuses them).  tests/host/sanitize_main.cpp compiles zkey.cpp (arkzkey
+and graph parsers, point decompression), pairing.h (the verifier), tree_config.h (the config_path JSON) and
+witness_sched.cpp (the interpreter's scheduler) with g++ -fsanitize=address,undefined and runs them on the shipped
+resources, on a golden proof and on ~2 500 truncated / mutated inputs: every malformed input must end in an error,
+and the sanitizers must stay silent."""
+import json
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "zerokit_amd", "csrc")
+
+
+def test_host_parsers_verifier_and_scheduler_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "sanitize_main")
+    srcs = [os.path.join(ROOT, "tests", "host", "sanitize_main.cpp"), os.path.join(CSRC, "zkey.cpp"),
+            os.path.join(CSRC, "witness_sched.cpp")]
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__",
+                           "-I", "/opt/rocm/include", "-I", CSRC] + srcs + ["-o", exe])
+    vec = json.load(open(os.path.join(ROOT, "tests", "golden", "rln_h20_vectors.json")))
+    case = vec["cases"][0]
+    blob = bytes.fromhex(case["proof_compressed"]) + b"".join(int(x).to_bytes(32, "little") for x in case["public_inputs"])
+    pf = tmp_path / "proof.bin"
+    pf.write_bytes(blob)
+    res = os.path.join(ROOT, "zerokit_amd", "resources", "tree_depth_20")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe, os.path.join(res, "rln_final.arkzkey"), os.path.join(res, "graph.bin"), str(pf)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr and "LeakSanitizer" not in r.stderr
+    assert "0 failures" in r.stdout

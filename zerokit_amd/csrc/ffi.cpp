@@ -30,6 +30,7 @@
 #include "keccak.h"
 #include "merkle.h"
 #include "tree_any.h"
+#include "tree_config.h"   // TreeConfig, parse_tree_config, tree_config_from_file
 #include "pairing.h"
 #include "poseidon.h"
 #include "prover.h"
@@ -400,170 +401,6 @@ struct FFI_RLNPartialProof {  // PartialProof (partial_proof.rs:31-43): mask + f
   uint8_t coords[320];        // pi_a | rho | pi_b | pi_c
 };
 
-// ---- tree persistence --------------------------------------------------------------------------------------------
-// The reference keeps the default (pmtree-ft) tree in a sled database under `path` (pm_tree_adapter.rs:71-176,
-// 191-239).  sled's on-disk format belongs to a third-party crate (sled 0.34.7) that is not in the tree, so the state is
-// kept in ONE snapshot file of our own, `<path>/rlnamd_tree.bin`: the same config keys and lifecycle (load when
-// present, otherwise start empty; written by ffi_flush and when the object is freed), not readable by sled.  The
-// tree itself stays in HBM; a snapshot holds depth, next_index, the metadata bytes and the leaves below next_index.
-struct TreeConfig {
-  std::string path;
-  bool has_path = false;
-  bool temporary = true;   // DEFAULT_TEMPORARY (pm_tree_adapter.rs:67)
-  long tree_depth = -1;
-  // prover sizing, keys of THIS backend in the same JSON object (the reference's PmTreeConfig::from_str picks its keys
-  // out of a serde_json::Value and ignores the rest, so one config file serves both): "window_bits" = the comb schedule
-  // of rlnamd_prover_new (7150114 = the 228 GiB bench schedule), "max_batch" = workspace capacity in proofs.
-  // 0 / absent: RLNAMD_WINDOW_BITS / RLNAMD_MAX_BATCH, else the small defaults (c = 8 tables, 64 proofs).
-  long window_bits = 0, max_batch = 0;
-  // "devices": [0, 1, ...] -- two or more entries put an rlnamd_pool (a prover replica + a host thread per listed device)
-  // behind the object: ffi_generate_rln_proofs_batch then shards n > max_batch proofs over the devices by index
-  // (BASELINE config 4: 65 536 = 8 x 8 192).  Everything else -- single proofs, the tree, verification -- runs on the
-  // first listed device, which must be the calling thread's current device (device 0 unless the host chose otherwise).
-  std::vector<int> devices;
-  bool has_devices = false;
-  bool persistent() const { return !temporary && has_path; }
-  ProverConfig prover_config() const {
-    ProverConfig cfg;
-    const char* mb = getenv("RLNAMD_MAX_BATCH");
-    cfg.max_batch = max_batch > 0 ? (size_t)max_batch : (mb && *mb ? (size_t)atoll(mb) : 64);
-    cfg.window_bits = window_bits > 0 ? (int)window_bits : 0;   // 0: Prover takes RLNAMD_WINDOW_BITS or c = 8
-    return cfg;
-  }
-};
-
-// flat JSON object with string / number / bool / null values (PmTreeConfig::from_str, pm_tree_adapter.rs:139-176)
-TreeConfig parse_tree_config(const std::string& js) {
-  TreeConfig c;
-  size_t i = 0;
-  auto bad = [&](const char* what) -> Error {
-    return Error(std::string("Configuration error: Error while reading pmtree config: ") + what + " at column " +
-                 std::to_string(i));
-  };
-  auto ws = [&]() { while (i < js.size() && isspace((unsigned char)js[i])) i++; };
-  auto str = [&]() {
-    std::string o;
-    if (js[i] != '"') throw bad("expected a string");
-    for (i++; i < js.size() && js[i] != '"'; i++) {
-      if (js[i] == '\\' && i + 1 < js.size()) {
-        char e = js[++i];
-        o += e == 'n' ? '\n' : e == 't' ? '\t' : e;
-      } else {
-        o += js[i];
-      }
-    }
-    if (i >= js.size()) throw bad("unterminated string");
-    i++;
-    return o;
-  };
-  ws();
-  if (i >= js.size() || js[i] != '{') throw bad("expected value");
-  i++;
-  ws();
-  while (i < js.size() && js[i] != '}') {
-    std::string key = str();
-    ws();
-    if (i >= js.size() || js[i] != ':') throw bad("expected `:`");
-    i++;
-    ws();
-    if (i >= js.size()) throw bad("EOF while parsing a value");
-    if (js[i] == '"') {
-      std::string v = str();
-      if (key == "path") { c.path = v; c.has_path = true; }
-    } else if (!js.compare(i, 4, "true") || !js.compare(i, 5, "false")) {
-      bool v = js[i] == 't';
-      i += v ? 4 : 5;
-      if (key == "temporary") c.temporary = v;
-    } else if (!js.compare(i, 4, "null")) {
-      i += 4;
-    } else if (js[i] == '[' && key == "devices") {
-      // strict, as serde_json would read a Vec<i32>: `[` (int (`,` int)*)? `]`, no trailing comma, no bare `-`
-      std::vector<int> vals;
-      i++;
-      ws();
-      if (i < js.size() && js[i] == ']') {
-        i++;
-      } else {
-        for (;;) {
-          ws();
-          size_t j = i;
-          if (j < js.size() && js[j] == '-') j++;
-          size_t d0 = j;
-          while (j < js.size() && isdigit((unsigned char)js[j])) j++;
-          if (j == d0 || j - d0 > 9) throw bad("expected value");
-          vals.push_back(atoi(js.substr(i, j - i).c_str()));
-          i = j;
-          ws();
-          if (i >= js.size()) throw bad("EOF while parsing a list");
-          if (js[i] == ',') { i++; continue; }
-          if (js[i] == ']') { i++; break; }
-          throw bad("expected `,` or `]`");
-        }
-      }
-      for (int d : vals)
-        if (d < 0) throw Error("Configuration error: devices: negative device ordinal");
-      c.devices = vals;
-      c.has_devices = true;
-    } else if (js[i] == '[' || js[i] == '{') {
-      // any other array / object (a key this library does not know): skipped as a whole, like serde ignores unknown fields
-      int depth = 0;
-      bool in_str = false;
-      for (; i < js.size(); i++) {
-        const char ch = js[i];
-        if (in_str) {
-          if (ch == '\\') i++;
-          else if (ch == '"') in_str = false;
-          continue;
-        }
-        if (ch == '"') in_str = true;
-        else if (ch == '[' || ch == '{') depth++;
-        else if (ch == ']' || ch == '}') {
-          if (--depth == 0) { i++; break; }
-        }
-      }
-      if (depth != 0) throw bad("EOF while parsing a value");
-    } else if (isdigit((unsigned char)js[i]) || js[i] == '-') {
-      size_t j = i;
-      while (j < js.size() && (isdigit((unsigned char)js[j]) || strchr("+-.eE", js[j]))) j++;
-      long num = atol(js.substr(i, j - i).c_str());
-      if (key == "tree_depth") c.tree_depth = num;
-      if (key == "window_bits") c.window_bits = num;
-      if (key == "max_batch") c.max_batch = num;
-      i = j;
-    } else {
-      throw bad("expected value");
-    }
-    ws();
-    if (i < js.size() && js[i] == ',') { i++; ws(); }
-    else if (i < js.size() && js[i] != '}') throw bad("expected `,` or `}`");
-  }
-  if (i >= js.size()) throw bad("EOF while parsing an object");
-  // resolve_path (pm_tree_adapter.rs:93-100)
-  if (!c.temporary && !c.has_path) throw Error("Configuration error: Error while creating pmtree config: missing path");
-  struct stat st;
-  if (c.temporary && c.has_path && stat(c.path.c_str(), &st) == 0)
-    throw Error("Configuration error: Error while creating pmtree config: path already exists");
-  return c;
-}
-
-// the config_path argument of ffi_rln_new*: a JSON file; unreadable / missing / oversized file == "" == defaults
-// (ffi_rln.rs:28-45: `.unwrap_or_default()`)
-TreeConfig tree_config_from_file(const char* config_path) {
-  std::string js;
-  if (config_path && *config_path) {
-    FILE* f = fopen(config_path, "rb");
-    if (f) {
-      char buf[4096];
-      size_t n;
-      while ((n = fread(buf, 1, sizeof buf, f)) > 0 && js.size() <= (1u << 20)) js.append(buf, n);
-      fclose(f);
-      if (js.size() > (1u << 20)) js.clear();  // MAX_CONFIG_SIZE
-    }
-  }
-  if (js.empty()) return TreeConfig();
-  return parse_tree_config(js);
-}
-
 struct FFI_RLN {
   // generate / verify take &self in the reference and may be called from several threads (SURVEY section 8b,
   // "Threading"); the prover owns one set of device workspaces, so proving calls on one object take turns
@@ -615,6 +452,7 @@ struct FFI_RLN {
   void new_tree(size_t depth) {
     if (depth >= 64) throw Error("Merkle tree error: Tree depth exceeds maximum allowed (must be < 64)");  // InvalidDepth
     uint8_t zero[32] = {0};
+    bool dropped_old = false;
     // The replacement is built beside the old tree so that a failure changes nothing -- unless the device cannot hold
     // both dense trees (depth 28: 16 GiB each, next to up to 228 GiB of comb tables): then the old tree goes first and
     // the reset is no longer atomic (a failure after this point leaves an empty depth-0 tree behind, reported by the
@@ -625,10 +463,21 @@ struct FFI_RLN {
       if (tree.depth > 0 && !tree.sparse && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < need) {
         TreeAny empty;
         tree = std::move(empty);
+        dropped_old = true;
       }
     }
     TreeAny fresh;
-    fresh.init((int)depth, zero);
+    try {
+      fresh.init((int)depth, zero);
+    } catch (const std::exception& e) {
+      if (!dropped_old) throw;
+      // the non-atomic case: say what state the object is in now
+      leaf_set.clear();
+      next_index = 0;
+      metadata.clear();
+      throw Error(std::string(e.what()) + " (the previous tree had to be released first to make room and is lost: the "
+                  "object now holds an empty depth-0 tree; call ffi_set_tree again with a depth that fits)");
+    }
     // cached_leaves_indices: one byte per leaf for the dense tree; the sparse tree keeps none (write-only bookkeeping)
     std::vector<uint8_t> fresh_set(fresh.sparse ? 0 : (size_t)1 << depth, 0);
     tree = std::move(fresh);
@@ -648,6 +497,12 @@ struct FFI_RLN {
     if (cfg.tree_depth >= 0 && (size_t)cfg.tree_depth != depth)
       throw Error("Merkle tree error: Tree depth exceeds maximum allowed (must be < 64)");  // InvalidDepth
     store.clear();
+    // a snapshot holds the dense prefix of leaves below next_index; the sparse tree of depths 31 .. 63 has no such prefix
+    // (one leaf at index 2^35 would make it terabytes), so persistence stops at the dense tree
+    if (cfg.persistent() && depth > (size_t)TreeAny::MAX_DENSE_DEPTH)
+      throw Error("Configuration error: a persistent tree (temporary = false) is supported up to depth " +
+                  std::to_string(TreeAny::MAX_DENSE_DEPTH) + "; depth " + std::to_string(depth) +
+                  " takes the sparse in-memory tree, which has no snapshot form");
     new_tree(depth);
     if (!cfg.persistent()) return;
     if (mkdir(cfg.path.c_str(), 0777) != 0 && errno != EEXIST)

@@ -66,18 +66,21 @@ __global__ void __launch_bounds__(64) k_hash_parents_l3_list(Fr* __restrict__ no
 // dependent hashes, and as 20 launches each paid its launch latency on top of the hash.  One workgroup of TAIL_WAVES
 // waves, 21 three-lane hashes per wave and step; a level's results reach the next level through HBM (the workgroup's
 // own CU: workgroup-scope visibility after the barrier).  levels[l] = [off[l], off[l + 1]) of `list`, bottom-up.
-constexpr uint32_t TAIL_WAVES = 4, TAIL_HASHES = 21 * TAIL_WAVES;
+// (WAVES = 1 when no level holds more than 21 parents -- a single update, a handful of them: the barriers inside the hash
+// then cost nothing; WAVES = 4 otherwise: four waves meeting at ~260 barriers per hash run each level ~40 % slower)
+constexpr uint32_t TAIL_WAVES_MAX = 4, TAIL_HASHES = 21 * TAIL_WAVES_MAX;
 struct LevelOffsets {
   uint32_t off[34];
 };
-__global__ void __launch_bounds__(64 * TAIL_WAVES) k_hash_tail_list(Fr* __restrict__ nodes, const uint32_t* __restrict__ list,
-                                                                    LevelOffsets lo, int first, int nlevels, PoseidonView pv) {
-  __shared__ __attribute__((aligned(16))) uint32_t sh_all[TAIL_WAVES][66 * 12];
+template <uint32_t WAVES>
+__global__ void __launch_bounds__(64 * WAVES) k_hash_tail_list(Fr* __restrict__ nodes, const uint32_t* __restrict__ list,
+                                                               LevelOffsets lo, int first, int nlevels, PoseidonView pv) {
+  __shared__ __attribute__((aligned(16))) uint32_t sh_all[WAVES][66 * 12];
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane / 3, j = lane % 3;
   uint32_t* sh = sh_all[wave];
   for (int l = first; l < nlevels; l++) {
     const uint32_t b = lo.off[l], cnt = lo.off[l + 1] - b;
-    for (uint32_t i0 = 0; i0 < cnt; i0 += TAIL_HASHES) {
+    for (uint32_t i0 = 0; i0 < cnt; i0 += 21 * WAVES) {
       const uint32_t i = i0 + wave * 21 + g;
       const bool active = lane < 63 && i < cnt;
       const size_t p = active ? list[b + i] : 0;
@@ -360,8 +363,13 @@ void MerkleTreeDev::set_scattered(const uint64_t* idx, const uint8_t* leaves_le,
     else
       hipLaunchKernelGGL(k_hash_parents_list, dim3(div_up(cnt, 256)), dim3(256), 0, stream, nodes.p, d_list + lo.off[l], cnt, pv);
   }
-  if (l < depth)
-    hipLaunchKernelGGL(k_hash_tail_list, dim3(1), dim3(64 * TAIL_WAVES), 0, stream, nodes.p, d_list, lo, l, depth, pv);
+  if (l < depth) {
+    if (lo.off[l + 1] - lo.off[l] <= 21)   // counts only shrink: one wave covers every remaining level
+      hipLaunchKernelGGL(k_hash_tail_list<1>, dim3(1), dim3(64), 0, stream, nodes.p, d_list, lo, l, depth, pv);
+    else
+      hipLaunchKernelGGL(k_hash_tail_list<TAIL_WAVES_MAX>, dim3(1), dim3(64 * TAIL_WAVES_MAX), 0, stream, nodes.p, d_list, lo,
+                         l, depth, pv);
+  }
   RLN_HIP(hipGetLastError());
 }
 

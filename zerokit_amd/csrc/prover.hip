@@ -58,6 +58,8 @@ struct Slot {
   bool used = false;
   bool marked = false;          // the timing marks t[] of the slot's batch were recorded
   bool wiped = false;           // the batch's inputs and witness values have been overwritten (Prover::wipe)
+  hipEvent_t evZ = nullptr;     // ... and that wipe has finished.  Kept apart from evC: "is the device idle" (lone) asks evC
+  hipEvent_t free_event() const { return wiped ? evZ : evC; }   // what the slot's next user waits for
   size_t n = 0;
 };
 
@@ -160,7 +162,7 @@ struct Prover::Impl {
       hipLaunchKernelGGL(k_wipe_cols, dim3(pg, N), dim3(64), 0, sW, S.V.p, (const uint32_t*)nullptr, N, (uint32_t)B, (uint32_t)n);
     }
     RLN_HIP(hipGetLastError());
-    RLN_HIP(hipEventRecord(S.evC, sW));
+    RLN_HIP(hipEventRecord(S.evZ, sW));
     S.wiped = true;
   }
 
@@ -871,6 +873,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     RLN_HIP(hipEventCreateWithFlags(&S.evX, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evV, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evC, hipEventDisableTiming));
+    RLN_HIP(hipEventCreateWithFlags(&S.evZ, hipEventDisableTiming));
     for (auto& e : S.t) RLN_HIP(hipEventCreate(&e));
     RLN_HIP(hipMemsetAsync(S.digits.p, 0, S.digits.bytes(), s));
     RLN_HIP(hipMemsetAsync(S.digits2.p, 0, S.digits2.bytes(), s));
@@ -900,7 +903,7 @@ Prover::~Prover() {
     if (S.h_comp) (void)hipHostFree(S.h_comp);
     if (S.h_values) (void)hipHostFree(S.h_values);
     if (S.h_err) (void)hipHostFree(S.h_err);
-    for (hipEvent_t e : {S.evA, S.evB, S.evB2, S.evR, S.evC, S.evW, S.evV, S.evX})
+    for (hipEvent_t e : {S.evA, S.evB, S.evB2, S.evR, S.evC, S.evW, S.evV, S.evX, S.evZ})
       if (e) (void)hipEventDestroy(e);
     for (auto& e : S.t)
       if (e) (void)hipEventDestroy(e);
@@ -1116,7 +1119,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   if (streamed) {
     if (D.wgiven_n) throw Error("upload_witness applies to the resident-input run that follows it, not to submit");
     // the slot's previous batch must be finished before its staging buffer (and its result buffers) are reused
-    if (S.used) RLN_HIP(hipEventSynchronize(S.evC));
+    if (S.used) RLN_HIP(hipEventSynchronize(S.free_event()));
     memcpy(S.h_in, h_inputs, n * (size_t)D.NI * 32);
     memcpy(S.h_in + B_ * (size_t)D.NI * 32, h_rs, n * 64);
     if (h_pp320) memcpy(S.h_in + B_ * ((size_t)D.NI * 32 + 64), h_pp320, n * 320);
@@ -1137,7 +1140,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   const uint32_t pg = div_up(nb, 64);
   const uint32_t nbp = pg * 64;  // padded lanes compute on stale / zero inputs; results ignored
   // ---------------- stage A
-  if (S.used) RLN_HIP(hipStreamWaitEvent(sA, S.evC, 0));  // slot free again
+  if (S.used) RLN_HIP(hipStreamWaitEvent(sA, S.free_event(), 0));  // slot free again
   if (streamed) {
     // by a kernel reading the pinned pages, not by hipMemcpyAsync: with the copy path in the pipeline every batch lost 8 ms
     // under the HIP runtime the torch wheel bundles (cross-queue signalling; profiles/r3_rocprof_summary.md section 1)
@@ -1316,8 +1319,8 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // proof values (Poseidon chain, latency-bound, depends on the inputs only): the back-end stream has slack
   hipStream_t sV = D.sV[sq & 1];
   if (S.used) {
-    RLN_HIP(hipStreamWaitEvent(D.sC, S.evC, 0));
-    RLN_HIP(hipStreamWaitEvent(sV, S.evC, 0));
+    RLN_HIP(hipStreamWaitEvent(D.sC, S.free_event(), 0));
+    RLN_HIP(hipStreamWaitEvent(sV, S.free_event(), 0));
   }
   if (streamed) RLN_HIP(hipStreamWaitEvent(sV, S.evU, 0));
   MARK(0, sV);
@@ -1379,7 +1382,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     // segment stays on sC, behind evB, which covers both G1 walks.)
     if (lone) {
       sF = sA;
-      if (S.used) RLN_HIP(hipStreamWaitEvent(sF, S.evC, 0));
+      if (S.used) RLN_HIP(hipStreamWaitEvent(sF, S.free_event(), 0));
       MARK(9, sF);
       RLN_HIP(hipStreamWaitEvent(sF, S.evE, 0));   // the early G1 walk: the C segment's h-independent rows
     } else {
