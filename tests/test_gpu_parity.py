@@ -563,6 +563,8 @@ def test_lane_chunk_walk_and_clock_tap(monkeypatch):
     {"RLNAMD_WITROWS": "0"},          # lane-form products
     {"RLNAMD_EARLY_FIN": "0", "RLNAMD_FUSED_SMUL": "0"},
     {"RLNAMD_LANECHUNK_WALK": "0"},   # the short-chunk plans walked with lanes = proofs (the shape of 49..128 proofs)
+    {"RLNAMD_TINY": "0"},             # no one-entry chunks / two-stage sums: the small-batch plan for a single proof too
+    {"RLNAMD_TINY": "8"},             # ... and that shape for the batch of five as well
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_small_batch_shape_variants_give_the_golden_bytes(monkeypatch, env):
     """Every latency shape of the single-proof path has a switch that restores the shape it replaced (DESIGN section 4,

@@ -116,6 +116,20 @@ k_walk(const G1Affine29* __restrict__ table, size_t rows_total, const int16_t* _
       }
     }
     out[(size_t)(chunk * pgroups + pg) * 64 + threadIdx.x] = acc2.to_xyzz();
+  } else if (MODE == 8) {  // LANE PAIRS share a 128-byte line: lane 2k accumulates the first entry of the line, lane 2k+1 the
+    // second, both for proof k of the wave (32 proofs per wave) under the SAME digit -- what storing A_i / B1_i (same scalar
+    // w_i) side by side would do with one accumulator per lane: VGPRs and waves per SIMD as in the shipped walk, the two
+    // 64-byte halves of a line leave as one 128-byte request
+    const uint32_t pp = (pg * 32 + (threadIdx.x >> 1)) % B, m = threadIdx.x & 1;
+    const int16_t* dgp = digits + (size_t)(chunk % 64) * steps * B + pp;
+#pragma unroll 1
+    for (uint32_t j = 0; j < steps; j++) {
+      int d = dgp[(size_t)j * B];
+      if (d != 0) {
+        uint32_t e = (((uint32_t)(d < 0 ? -d : d) - 1) & ~1u) | m;
+        acc.madd(base[((size_t)j << cs) + e], d < 0);
+      }
+    }
   } else if (MODE == 3) {
     int dn = dg[0];
 #pragma unroll 1
@@ -216,6 +230,9 @@ int main(int argc, char** argv) {
   RUN(7, 2, "two accumulators, two separate 64-byte entries per step (2 waves)");
   RUN(6, 3, "two accumulators, one 128-byte line per two additions (3 waves)");
   RUN(6, 2, "two accumulators, one 128-byte line per two additions (2 waves)");
+  RUN(8, 4, "lane pairs share a 128-byte line, one accumulator per lane (4 waves)");
+  RUN(0, 4, "walk as k_msm29 (4 waves/SIMD), again");
+  RUN(8, 4, "lane pairs share a 128-byte line (4 waves), again");
   RUN(5, 4, "non-temporal entry loads (4 waves)");
   RUN(0, 4, "walk as k_msm29 again (4 waves/SIMD)");
   RUN(0, 3, "walk as k_msm29 (3 waves/SIMD)");

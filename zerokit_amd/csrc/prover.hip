@@ -100,12 +100,21 @@ struct Prover::Impl {
     DevBuf<uint32_t> rsid;                  // scalar id of every entry of `rows`
     DevBuf<uint32_t> early_ids, late_ids;   // chunk indices without / with rows that depend on the quotient h
     uint32_t nchunks = 0, ngroups = 0, nseg = 0, n_early = 0, n_late = 0;
+    // two-stage sum of the tiny plans: segblocks[seg] = the range of 512-chunk blocks of a segment (block b covers
+    // chunks [segfirst + 512 b, ...)), maxblk = the most blocks any segment has
+    DevBuf<ChunkDesc> segblocks;
+    uint32_t nblocks = 0, maxblk = 0;
   };
   Plan plan1[3], plan2[3];  // [PROVE_FULL, PROVE_PARTIAL, PROVE_FINISH]
   // the same walks cut into shorter chunks for batches walked with lanes = chunks: a walk lasts as long as its longest
   // chunk (a lane's serial chain of additions), and a handful of proofs cannot fill the chip anyway
   Plan plan1s[3], plan2s[3];
   Plan plan1f[3];               // [PROVE_FULL] only: the fused small-batch plan (s A and r B1 as rows of the C segment)
+  // tiny batches (<= tune.tiny_max proofs, alone on the device): ONE (row, half) per lane -- a lane's chain is 9 (G1) or
+  // 8 (G2) additions instead of 36 / 16 -- and the partial sums, four times as many, meet in a two-stage tree
+  Plan plan1tf[3], plan2t[3];   // [PROVE_FULL] only: the fused plan and the G2 plan with chunks of one entry
+  uint32_t max_chunks1t = 0, max_chunks2t = 0, max_blocks1t = 0, max_blocks2t = 0;
+  static constexpr uint32_t tiny_stride = 8;   // partial sums of a tiny batch: [chunk][8]
   uint32_t max_chunks1s = 0, max_chunks2s = 0, small_stride = 64;   // partial sums of a small batch: [chunk][64]
   uint32_t max_chunks1 = 0, max_chunks2 = 0, max_groups1 = 0, max_groups2 = 0;
   uint32_t npts1 = 0, npts2 = 0;
@@ -201,15 +210,16 @@ ProverTuning ProverTuning::from_env() {
   t.fused_smul = env_int("RLNAMD_FUSED_SMUL", 1) != 0;
   t.values_from_witness = env_int("RLNAMD_VALUES_WITNESS", 1) != 0;
   t.ntt_fuse9 = env_int("RLNAMD_NTT_FUSE9", 1) != 0;
+  t.tiny_max = (uint32_t)std::max(0, env_int("RLNAMD_TINY", (int)t.tiny_max));
   t.marks_small = env_int("RLNAMD_MARKS_SMALL", 0) != 0;
   return t;
 }
 std::string ProverTuning::describe() const {
   char b[512];
   snprintf(b, sizeof b,
-           "window_bits=%d slots=%d lanechunk=%u lanechunk_walk=%u witlanes_max=%u glv=%d wit29=%d lone=%d early_walk=%d "
+           "window_bits=%d slots=%d lanechunk=%u lanechunk_walk=%u witlanes_max=%u tiny=%u glv=%d wit29=%d lone=%d early_walk=%d "
            "early_fin=%d fused_smul=%d values_from_witness=%d ntt_fuse9=%d marks_small=%d",
-           window_bits, slots, lanechunk_max, lanechunk_walk_max, witlanes_max, (int)glv, (int)wit29, lone, (int)early_walk,
+           window_bits, slots, lanechunk_max, lanechunk_walk_max, witlanes_max, tiny_max, (int)glv, (int)wit29, lone, (int)early_walk,
            (int)early_fin, (int)fused_smul, (int)values_from_witness, (int)ntt_fuse9, (int)marks_small);
   return b;
 }
@@ -697,6 +707,20 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
       for (size_t sgi = 0; sgi + 1 < segfirst.size(); sgi++) segchunks.push_back({segfirst[sgi], segfirst[sgi + 1]});
       P.segchunks.alloc(segchunks.size());
       P.segchunks.upload(segchunks.data(), segchunks.size(), s);
+      {
+        std::vector<ChunkDesc> segblocks;
+        uint32_t nb = 0;
+        P.maxblk = 0;
+        for (size_t sgi = 0; sgi + 1 < segfirst.size(); sgi++) {
+          const uint32_t k = div_up(segfirst[sgi + 1] - segfirst[sgi], SUM_TREE_LANES);
+          segblocks.push_back({nb, nb + k});
+          nb += k;
+          P.maxblk = std::max(P.maxblk, k);
+        }
+        P.nblocks = nb;
+        P.segblocks.alloc(segblocks.size());
+        P.segblocks.upload(segblocks.data(), segblocks.size(), s);
+      }
       P.n_early = (uint32_t)early_ids.size();
       P.n_late = (uint32_t)late_ids.size();
       P.early_ids.alloc(std::max<size_t>(early_ids.size(), 1));
@@ -768,6 +792,8 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
       uint32_t unused = 0;
       make_plans(f, 3, 4u, D.plan1f, &D.max_chunks1s, &unused,
                  PROVE_FULL);
+      make_plans(f, 3, 1u, D.plan1tf, &D.max_chunks1t, &unused, PROVE_FULL);
+      D.max_blocks1t = D.plan1tf[PROVE_FULL].nblocks;
     }
     build_table29<Fq, G1Affine29>(pts, D.ws, D.t1_29, s);
   }
@@ -797,6 +823,8 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     {
       uint32_t unused = 0;
       make_plans(vrows, 1, 2u, D.plan2s, &D.max_chunks2s, &unused, -1);
+      make_plans(vrows, 1, 1u, D.plan2t, &D.max_chunks2t, &unused, PROVE_FULL);
+      D.max_blocks2t = D.plan2t[PROVE_FULL].nblocks;
     }
     build_table29<Fq2, G2Affine29>(pts, D.ws2, D.t2_29, s);
   }
@@ -840,11 +868,13 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     S.abc.alloc(3 * (size_t)D.n * B);
     S.digits.alloc((size_t)(3 * D.NS + D.n + 4) * D.nh * D.ws.W * B);   // + s w_i, r w_i, r s of the fused small-batch plan
     S.digits2.alloc((size_t)(D.NS + 3) * D.nh * D.ws2.W * B);
-    S.part1.alloc(std::max((size_t)D.max_chunks1 * B, (size_t)D.max_chunks1s * D.small_stride));
-    S.grp1.alloc((size_t)D.max_groups1 * B);
+    S.part1.alloc(std::max({(size_t)D.max_chunks1 * B, (size_t)D.max_chunks1s * D.small_stride,
+                            (size_t)D.max_chunks1t * Impl::tiny_stride}));
+    S.grp1.alloc(std::max((size_t)D.max_groups1 * B, (size_t)D.max_blocks1t * Impl::tiny_stride));
     S.sums1.alloc(3 * D.nh * B);
-    S.part2.alloc(std::max((size_t)D.max_chunks2 * B, (size_t)D.max_chunks2s * D.small_stride));
-    S.grp2.alloc((size_t)D.max_groups2 * B);
+    S.part2.alloc(std::max({(size_t)D.max_chunks2 * B, (size_t)D.max_chunks2s * D.small_stride,
+                            (size_t)D.max_chunks2t * Impl::tiny_stride}));
+    S.grp2.alloc(std::max((size_t)D.max_groups2 * B, (size_t)D.max_blocks2t * Impl::tiny_stride));
     S.sums2.alloc(D.nh * B);
     S.prod.alloc(2 * B);
     S.tbl.alloc(2 * 16 * B);
@@ -1106,9 +1136,11 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // (up to 96 proofs: above, the walks are issue-bound even for a lone batch and the extra rows cost more than the ladder
   // they replace -- 128 proofs 16.6 -> 15.3 ms without them, 64 proofs 10.1 -> 10.3 ms)
   const bool fused = lone && n <= 96 && early && small && mode == PROVE_FULL && D.nh == 2 && T.fused_smul && T.early_fin;   // (its back end is the split one below)
-  const Impl::Plan& P1 = fused ? D.plan1f[PROVE_FULL] : small ? D.plan1s[mode] : D.plan1[mode];
-  const Impl::Plan& P2 = small ? D.plan2s[mode] : D.plan2[mode];
-  const uint32_t PB = small ? D.small_stride : (uint32_t)B_;   // stride of the partial-sum arrays
+  // tiny: a lane per (row, half) and a two-stage sum (plan1tf / plan2t) -- only the fused full proof of a lone batch
+  const bool tiny = fused && n <= T.tiny_max && n <= Impl::tiny_stride;
+  const Impl::Plan& P1 = tiny ? D.plan1tf[PROVE_FULL] : fused ? D.plan1f[PROVE_FULL] : small ? D.plan1s[mode] : D.plan1[mode];
+  const Impl::Plan& P2 = tiny ? D.plan2t[PROVE_FULL] : small ? D.plan2s[mode] : D.plan2[mode];
+  const uint32_t PB = tiny ? Impl::tiny_stride : small ? D.small_stride : (uint32_t)B_;   // stride of the partial-sum arrays
   // mid-size small batches: the short-chunk plans walked with lanes = proofs (walk29.h).  A lone batch: above 48 proofs
   // (64: 11.3 -> 9.9 ms, 128: 18.1 -> 16.3 ms; 32: 6.9 ms against 8.4).  In a stream of batches the lanes = chunks form
   // pays its scattered gathers in throughput much earlier (streams of 64 / 128-proof batches: 9.5 -> 10.8 k, 10.7 -> 11.9 k
@@ -1341,19 +1373,41 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // below a wave of proofs s A / r B1 are a lone lane's chain: NAF ladder in the 9 x 29 form (fin29.hip)
   const bool fin29 = nb <= D.lanechunk_max;
   hipStream_t sF = D.sC;   // the stream of k_fin_out and of the copies to the host
+  // segment sums of a small batch: one 512-lane tree per (proof, segment); tiny batches (four times the partial sums) in
+  // two stages -- every 512-chunk block of a segment to one point, then the blocks of the segment -- so that the depth
+  // stays log2(partial sums) + 1 instead of growing with the serial share of a lane
+  auto sum1 = [&](hipStream_t st, std::initializer_list<uint32_t> segs) {
+    const TaskSel sel = task_sel(segs);
+    const uint32_t ns = (uint32_t)segs.size();
+    if (tiny) {
+      hipLaunchKernelGGL(k_sum_blocks<Fq>, dim3(nb, ns, std::max(P1.maxblk, 1u)), dim3(SUM_TREE_LANES), 0, st, S.part1.p, P1.segchunks.p,
+                         P1.segblocks.p, S.grp1.p, PB, sel);
+      hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, ns), dim3(SUM_TREE_LANES), 0, st, S.grp1.p, P1.segblocks.p, S.sums1.p, B, PB, sel);
+    } else {
+      hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, ns), dim3(SUM_TREE_LANES), 0, st, S.part1.p, P1.segchunks.p, S.sums1.p, B, PB, sel);
+    }
+  };
+  auto sum2 = [&](hipStream_t st) {
+    const TaskSel sel = task_sel({0, 1, 2, 3, 4, 5});
+    if (tiny) {
+      hipLaunchKernelGGL(k_sum_blocks<Fq2>, dim3(nb, P2.nseg, std::max(P2.maxblk, 1u)), dim3(SUM_TREE_LANES), 0, st, S.part2.p,
+                         P2.segchunks.p, P2.segblocks.p, S.grp2.p, PB, sel);
+      hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(SUM_TREE_LANES), 0, st, S.grp2.p, P2.segblocks.p, S.sums2.p, B, PB, sel);
+    } else {
+      hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(SUM_TREE_LANES), 0, st, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, sel);
+    }
+  };
   if (early_fin) {
     RLN_HIP(hipStreamWaitEvent(D.sA2, S.evE, 0));   // sB: the early G1 walk
     if (fused) {
       // fused plan: only A has to be reduced and inverted early; s A and r B1 are inside the C segment, B1 is never formed
-      hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, 2), dim3(SUM_TREE_LANES), 0, D.sA2, S.part1.p, P1.segchunks.p, S.sums1.p, B, PB,
-                         task_sel({0, 3}));
+      sum1(D.sA2, {0, 3});
       hipLaunchKernelGGL(k_glv_fold, dim3(pg, 1), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({0}));
       hipLaunchKernelGGL(k_fin_affine, dim3(pg, 1), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
                          S.affB2.p, B, nbp, task_sel({0}));
       RLN_HIP(hipMemsetAsync(S.prod.p, 0, S.prod.bytes(), D.sA2));   // ZZ = 0: two points at infinity for k_fin_out
     } else {
-      hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, 4), dim3(SUM_TREE_LANES), 0, D.sA2, S.part1.p, P1.segchunks.p, S.sums1.p, B,
-                         PB, task_sel({0, 1, 3, 4}));
+      sum1(D.sA2, {0, 1, 3, 4});
       hipLaunchKernelGGL(k_glv_fold, dim3(pg, 2), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({0, 1}));
       hipLaunchKernelGGL(k_fin_affine, dim3(pg, 2), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
                          S.affB2.p, B, nbp, task_sel({0, 1}));
@@ -1370,10 +1424,9 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     // it does not hold up the next batch's G2 walk)
     hipStream_t sG = lone ? s2 : D.sC;
     if (!lone) RLN_HIP(hipStreamWaitEvent(D.sC, S.evB2, 0));
-    hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(SUM_TREE_LANES), 0, sG, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, all6);
-    hipLaunchKernelGGL(k_glv_fold, dim3(pg, 1), dim3(64), 0, sG, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({3}));
-    hipLaunchKernelGGL(k_fin_affine, dim3(pg, 1), dim3(64), 0, sG, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
-                       S.affB2.p, B, nbp, task_sel({2}));
+    sum2(sG);
+    // B's side of the output right here (fold, inversion, bytes): see k_fin_out_b2
+    hipLaunchKernelGGL(k_fin_out_b2, dim3(pg), dim3(64), 0, sG, S.sums2.p, S.coords.p, S.comp.p, B, nbp);
     if (lone) RLN_HIP(hipEventRecord(S.evB2, s2));
     RLN_HIP(hipEventRecord(S.evV, sV));
     // The C segment, k_fin_out and the copies home on the front-end stream itself, right behind the walk of the h rows:
@@ -1389,11 +1442,11 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
       MARK(9, sF);
       RLN_HIP(hipStreamWaitEvent(sF, S.evB, 0));
     }
-    hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, 2), dim3(SUM_TREE_LANES), 0, sF, S.part1.p, P1.segchunks.p, S.sums1.p, B,
-                       PB, task_sel({2, 5}));
-    hipLaunchKernelGGL(k_glv_fold, dim3(pg, 1), dim3(64), 0, sF, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({2}));
-    RLN_HIP(hipStreamWaitEvent(sF, S.evB2, 0));
-    RLN_HIP(hipStreamWaitEvent(sF, S.evA, 0));
+    sum1(sF, {2, 5});
+    RLN_HIP(hipStreamWaitEvent(sF, S.evA, 0));   // A affine, s A and r B1
+    // A's and C's side of the output (fold of the C segment, inversion, bytes): see k_fin_out_ac
+    hipLaunchKernelGGL(k_fin_out_ac, dim3(pg), dim3(64), 0, sF, S.sums1.p, S.prod.p, S.affA.p, S.coords.p, S.comp.p, B, nbp);
+    if (lone) RLN_HIP(hipStreamWaitEvent(sF, S.evB2, 0));   // the copies home need B's bytes (not lone: sG = sF = sC, in order)
     RLN_HIP(hipStreamWaitEvent(sF, S.evV, 0));
   } else {
     RLN_HIP(hipEventRecord(S.evV, sV));
@@ -1435,8 +1488,9 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
         hipLaunchKernelGGL(k_fin_smul, dim3(pg, 2), dim3(64), 0, D.sC, S.affA.p, S.affB1.p, rs_p, S.tbl.p, S.prod.p, B,
                            nbp);
     }
-    hipLaunchKernelGGL(k_fin_out, dim3(pg), dim3(64), 0, sF, S.sums1.p, S.prod.p, S.affA.p, S.affB2.p, S.coords.p,
-                       S.comp.p, B, nbp);
+    if (!early_fin)
+      hipLaunchKernelGGL(k_fin_out, dim3(pg), dim3(64), 0, sF, S.sums1.p, S.prod.p, S.affA.p, S.affB2.p, S.coords.p,
+                         S.comp.p, B, nbp);
     RLN_HIP(hipGetLastError());
     RLN_HIP(hipMemcpyAsync(S.h_comp, S.comp.p, n * 128, hipMemcpyDeviceToHost, sF));
     RLN_HIP(hipMemcpyAsync(S.h_values, S.values.p, n * 160, hipMemcpyDeviceToHost, sF));

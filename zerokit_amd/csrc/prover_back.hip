@@ -169,6 +169,72 @@ __global__ void __launch_bounds__(64) k_fin_out(const G1XYZZ* __restrict__ sums1
   for (int i = 0; i < 32; i++) cw[i] = w[i];
 }
 
+// Small full proofs (split back end): the output is finished by TWO kernels on their own streams instead of a chain of
+// four -- k_fin_out_b2 behind the G2 sum (GLV fold, the Fq2 inversion, B's coordinates and compressed bytes) and
+// k_fin_out_ac behind the C sum (GLV fold of the C segment, + s A + r B1, the Fq inversion, A's and C's bytes).  They write
+// disjoint bytes of the same records, so nothing joins them but the copy home; the two inversions of a proof, which
+// k_fin_affine -> k_fin_out ran one after the other at the very end of the critical path, run side by side.  Same field
+// operations, same bytes as k_glv_fold + k_fin_affine + k_fin_out.
+__global__ void __launch_bounds__(64) k_fin_out_b2(const G2XYZZ* __restrict__ sums2, uint32_t* __restrict__ coords,
+                                                   uint8_t* __restrict__ comp, uint32_t B, uint32_t nb) {
+  __builtin_amdgcn_s_setprio(3);
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= nb) return;
+  G2XYZZ a = sums2[p], b = sums2[(size_t)B + p];   // first / second GLV halves (k_glv_fold)
+  b.X = b.X.mul_fq(Fq::from_canonical(GlvParams::BETA_G2));
+  a.add(b);
+  const G2Affine B2 = a.to_affine();
+  uint32_t* o = coords + (size_t)p * 64;
+  store_fq(o + 16, B2.x.c0);
+  store_fq(o + 24, B2.x.c1);
+  store_fq(o + 32, B2.y.c0);
+  store_fq(o + 40, B2.y.c1);
+  uint32_t* cw = (uint32_t*)(comp + (size_t)p * 128);
+  uint32_t w[16];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    w[i] = o[16 + i];
+    w[8 + i] = o[24 + i];
+  }
+  if (B2.is_inf()) w[15] |= 0x40000000u;
+  else if (B2.y.c1.is_zero() ? fq_is_neg_dev(B2.y.c0) : fq_is_neg_dev(B2.y.c1)) w[15] |= 0x80000000u;
+#pragma unroll
+  for (int i = 0; i < 16; i++) cw[8 + i] = w[i];
+}
+__global__ void __launch_bounds__(64) k_fin_out_ac(const G1XYZZ* __restrict__ sums1, const G1XYZZ* __restrict__ prod,
+                                                   const G1Affine* __restrict__ affA, uint32_t* __restrict__ coords,
+                                                   uint8_t* __restrict__ comp, uint32_t B, uint32_t nb) {
+  __builtin_amdgcn_s_setprio(3);
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= nb) return;
+  G1XYZZ Cacc = sums1[2 * (size_t)B + p], h2 = sums1[5 * (size_t)B + p];   // C segment: first / second GLV halves
+  h2.X = h2.X * Fq::from_canonical(GlvParams::BETA_G1);
+  Cacc.add(h2);
+  Cacc.add(prod[p]);
+  Cacc.add(prod[(size_t)B + p]);
+  const G1Affine C = Cacc.to_affine();
+  const G1Affine A = affA[p];
+  uint32_t* o = coords + (size_t)p * 64;
+  store_fq(o, A.x);
+  store_fq(o + 8, A.y);
+  store_fq(o + 48, C.x);
+  store_fq(o + 56, C.y);
+  uint32_t* cw = (uint32_t*)(comp + (size_t)p * 128);
+  uint32_t wa[8], wc[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    wa[i] = o[i];
+    wc[i] = o[48 + i];
+  }
+  if (A.is_inf()) wa[7] |= 0x40000000u; else if (fq_is_neg_dev(A.y)) wa[7] |= 0x80000000u;
+  if (C.is_inf()) wc[7] |= 0x40000000u; else if (fq_is_neg_dev(C.y)) wc[7] |= 0x80000000u;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    cw[i] = wa[i];
+    cw[24 + i] = wc[i];
+  }
+}
+
 // =====================================================================================================
 // 7. proof values by the Poseidon formulae (witness.rs:759-828): root, a1, y, nullifier
 // =====================================================================================================

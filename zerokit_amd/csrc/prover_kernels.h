@@ -103,6 +103,10 @@ __global__ void __launch_bounds__(64) k_sum_ranges(const XYZZ<F>* __restrict__ s
 template <class F>
 __global__ void __launch_bounds__(SUM_TREE_LANES) k_sum_tree(const XYZZ<F>* __restrict__ part, const ChunkDesc* __restrict__ segchunks,
                                                   XYZZ<F>* __restrict__ dst, uint32_t B, uint32_t PB, TaskSel sel);
+template <class F>
+__global__ void __launch_bounds__(SUM_TREE_LANES) k_sum_blocks(const XYZZ<F>* __restrict__ part, const ChunkDesc* __restrict__ segchunks,
+                                                    const ChunkDesc* __restrict__ segblocks, XYZZ<F>* __restrict__ dst, uint32_t PB,
+                                                    TaskSel sel);
 __global__ void __launch_bounds__(64) k_glv_fold(G1XYZZ* __restrict__ sums1, G2XYZZ* __restrict__ sums2, uint32_t nseg1,
                                                  uint32_t B, uint32_t nb, TaskSel sel);
 template <class F>
@@ -124,6 +128,11 @@ __global__ void __launch_bounds__(64) k_fin_out(const G1XYZZ* __restrict__ sums1
                                                 const G1Affine* __restrict__ affA, const G2Affine* __restrict__ affB2,
                                                 uint32_t* __restrict__ coords, uint8_t* __restrict__ comp, uint32_t B,
                                                 uint32_t nb);
+__global__ void __launch_bounds__(64) k_fin_out_b2(const G2XYZZ* __restrict__ sums2, uint32_t* __restrict__ coords,
+                                                   uint8_t* __restrict__ comp, uint32_t B, uint32_t nb);
+__global__ void __launch_bounds__(64) k_fin_out_ac(const G1XYZZ* __restrict__ sums1, const G1XYZZ* __restrict__ prod,
+                                                   const G1Affine* __restrict__ affA, uint32_t* __restrict__ coords,
+                                                   uint8_t* __restrict__ comp, uint32_t B, uint32_t nb);
 __global__ void __launch_bounds__(64) k_proof_values(const uint32_t* __restrict__ inputs, uint32_t n_inputs,
                                                      InputSlots sl, PoseidonView p2, PoseidonView p3, PoseidonView p4,
                                                      uint32_t* __restrict__ values, uint32_t nb);

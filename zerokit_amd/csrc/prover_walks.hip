@@ -61,6 +61,29 @@ __global__ void __launch_bounds__(SUM_TREE_LANES) k_sum_tree(const XYZZ<F>* __re
   if (l == 0) dst[(size_t)sgi * B + p] = acc;
 }
 
+// First stage of the two-stage sum (tiny batches): block z of segment sel.id[y] -- 512 consecutive partial sums -- to
+// one point, dst[(segblocks[seg].begin + z) * PB + p]; k_sum_tree over dst (segment ranges = segblocks) is the second.
+template <class F>
+__global__ void __launch_bounds__(SUM_TREE_LANES) k_sum_blocks(const XYZZ<F>* __restrict__ part, const ChunkDesc* __restrict__ segchunks,
+                                                    const ChunkDesc* __restrict__ segblocks, XYZZ<F>* __restrict__ dst, uint32_t PB,
+                                                    TaskSel sel) {
+  __shared__ XYZZ<F> sh[SUM_TREE_LANES / 2];
+  __builtin_amdgcn_s_setprio(3);
+  const uint32_t p = blockIdx.x, sgi = sel.id[blockIdx.y], l = threadIdx.x;
+  const ChunkDesc cd = segchunks[sgi], bd = segblocks[sgi];
+  if (blockIdx.z >= bd.pt_end - bd.pt_begin) return;   // (uniform for the workgroup)
+  const uint32_t i = cd.pt_begin + blockIdx.z * SUM_TREE_LANES + l;
+  XYZZ<F> acc = i < cd.pt_end ? part[(size_t)i * PB + p] : XYZZ<F>::inf();
+#pragma unroll 1
+  for (uint32_t stride = SUM_TREE_LANES / 2; stride >= 1; stride >>= 1) {
+    if (l >= stride && l < 2 * stride) sh[l - stride] = acc;
+    __syncthreads();
+    if (l < stride) acc.add(sh[l]);
+    __syncthreads();
+  }
+  if (l == 0) dst[(size_t)(bd.pt_begin + blockIdx.z) * PB + p] = acc;
+}
+
 // GLV: segment t holds sum k1_i P_i, segment nseg + t holds sum k2_i P_i; the result is the first plus phi of the
 // second, phi(X, Y, ZZ, ZZZ) = (beta X, Y, ZZ, ZZZ) (x = X / ZZ).  One Fq product per output point and proof.
 __global__ void __launch_bounds__(64) k_glv_fold(G1XYZZ* __restrict__ sums1, G2XYZZ* __restrict__ sums2, uint32_t nseg1,
@@ -140,6 +163,8 @@ template __global__ void k_sum_ranges<Fq>(const XYZZ<Fq>* __restrict__ src, cons
 template __global__ void k_sum_ranges<Fq2>(const XYZZ<Fq2>* __restrict__ src, const ChunkDesc* __restrict__ ranges, uint32_t nranges, XYZZ<Fq2>* __restrict__ dst, uint32_t B, uint32_t nb);
 template __global__ void k_sum_tree<Fq>(const XYZZ<Fq>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, XYZZ<Fq>* __restrict__ dst, uint32_t B, uint32_t PB, TaskSel sel);
 template __global__ void k_sum_tree<Fq2>(const XYZZ<Fq2>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, XYZZ<Fq2>* __restrict__ dst, uint32_t B, uint32_t PB, TaskSel sel);
+template __global__ void k_sum_blocks<Fq>(const XYZZ<Fq>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, const ChunkDesc* __restrict__ segblocks, XYZZ<Fq>* __restrict__ dst, uint32_t PB, TaskSel sel);
+template __global__ void k_sum_blocks<Fq2>(const XYZZ<Fq2>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, const ChunkDesc* __restrict__ segblocks, XYZZ<Fq2>* __restrict__ dst, uint32_t PB, TaskSel sel);
 template __global__ void k_table_build<Fq>(const Affine<Fq>* __restrict__ pts, uint32_t npts, WinSched ws, Affine<Fq>* __restrict__ table, Fq* __restrict__ scratch);
 template __global__ void k_table_build<Fq2>(const Affine<Fq2>* __restrict__ pts, uint32_t npts, WinSched ws, Affine<Fq2>* __restrict__ table, Fq2* __restrict__ scratch);
 template __global__ void k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4, false>(const G1Affine29* __restrict__ table, const uint32_t* __restrict__ sid, const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks, uint32_t nchunks, const int16_t* __restrict__ digits, G1XYZZ* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups, uint32_t nh, unsigned long long* __restrict__ clk, const uint32_t* __restrict__ chunk_ids, uint32_t pstride);
