@@ -421,7 +421,44 @@ struct G1Acc29 {
     for (int j = 0; j < 9; j++) D.v[j] = Q.v[j] + Fq29C::K6[j] - X.v[j];
     Y = Fq29::dot2(R, D, nY, PPP);                    // R (Q - X3) - Y PPP  < 1.3 q
   }
+
+  // this += o, both in this form (add-2008-s): the tree reductions of the small batches (k_sum_tree / k_sum_blocks), where
+  // a general addition is a lone lane's dependent chain and the 8 x 32 form costs 1.9 x the instructions.  The tail is
+  // madd's with (X, Y) -> (U1, S1): every product and the Y3 dot product take the operand classes madd's call sites
+  // take (check_fq29_bounds.py: "mul", "g1.Y3"), P and R are normalised differences < 3.1 q, and the results keep the
+  // accumulator invariants (X < 5.2 q, Y < 2.1 q, ZZ, ZZZ < 1.7 q).  Doubling / cancellation: through the 8 x 32 law.
+  __device__ __forceinline__ void add(const G1Acc29& o) {
+    if (o.is_inf()) return;
+    if (is_inf()) {
+      *this = o;
+      return;
+    }
+    const Fq29 U1 = Fq29::mul(X, o.ZZ), U2 = Fq29::mul(o.X, ZZ);       // < 1.06 q
+    const Fq29 S1 = Fq29::mul(Y, o.ZZZ), S2 = Fq29::mul(o.Y, ZZZ);     // < 1.03 q
+    const Fq29 P = Fq29::sub(U2, Fq29C::K2, U1), R = Fq29::sub(S2, Fq29C::K2, S1);   // in (0.9 q, 3.1 q), normalised
+    if (P.is_zero_mod_q()) {
+      G1XYZZ a = to_xyzz();
+      a.add(o.to_xyzz());
+      *this = from_xyzz(a);
+      return;
+    }
+    const Fq29 PP = Fq29::sqr(P);
+    ZZ = Fq29::mul(Fq29::mul(ZZ, o.ZZ), PP);
+    const Fq29 Q = Fq29::mul(U1, PP);
+    const Fq29 PPP = Fq29::mul(P, PP);
+    ZZZ = Fq29::mul(Fq29::mul(ZZZ, o.ZZZ), PPP);
+    Fq29 kT;
+#pragma unroll
+    for (int j = 0; j < 9; j++) kT.v[j] = Fq29C::K4T[j] - (PPP.v[j] + 2 * Q.v[j]);
+    X = Fq29::sqr_add(R, &kT);                        // X3 = R^2 - PPP - 2 Q
+    Fq29 D;
+#pragma unroll
+    for (int j = 0; j < 9; j++) D.v[j] = Q.v[j] + Fq29C::K6[j] - X.v[j];
+    const Fq29 nS1 = Fq29::neg_lazy(Fq29C::K4, S1);
+    Y = Fq29::dot2(R, D, nS1, PPP);                   // R (Q - X3) - S1 PPP
+  }
 };
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // G2: Fq2 = Fq[u]/(u^2 + 1) over Fq29.  Same lazy bounds as G1, component-wise.
@@ -580,6 +617,43 @@ struct G2Acc29 {
     const Fq29& nY1 = nY.c1;
     Fq29 y0 = Fq29::dot4<true>(R.c0, D.c0, nR1, D.c1, nY0, PPP.c0, Y.c1, PPP.c1);
     Fq29 y1 = Fq29::dot4<true>(R.c0, D.c1, R.c1, D.c0, nY0, PPP.c1, nY1, PPP.c0);
+    Y = {y0, y1};
+  }
+
+  // this += o (see G1Acc29::add): madd's tail with (X, Y) -> (U1, S1), the same operand classes at every call site
+  __device__ __forceinline__ void add(const G2Acc29& o) {
+    if (o.is_inf()) return;
+    if (is_inf()) {
+      *this = o;
+      return;
+    }
+    const Fq2_29 U1 = Fq2_29::mul(X, o.ZZ), U2 = Fq2_29::mul(o.X, ZZ);
+    const Fq2_29 S1 = Fq2_29::mul(Y, o.ZZZ), S2 = Fq2_29::mul(o.Y, ZZZ);
+    const Fq2_29 P = Fq2_29::sub(U2, Fq29C::K2, U1), R = Fq2_29::sub(S2, Fq29C::K2, S1);
+    if (P.is_zero_mod_q()) {
+      G2XYZZ a = to_xyzz();
+      a.add(o.to_xyzz());
+      *this = from_xyzz(a);
+      return;
+    }
+    const Fq2_29 PP = Fq2_29::sqr(P);
+    ZZ = Fq2_29::mul(Fq2_29::mul(ZZ, o.ZZ), PP);
+    const Fq2_29 Q = Fq2_29::mul(U1, PP);
+    const Fq2_29 PPP = Fq2_29::mul(P, PP);
+    ZZZ = Fq2_29::mul(Fq2_29::mul(ZZZ, o.ZZZ), PPP);
+    Fq2_29 kT;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      kT.c0.v[j] = Fq29C::K4T[j] - (PPP.c0.v[j] + 2 * Q.c0.v[j]);
+      kT.c1.v[j] = Fq29C::K4T[j] - (PPP.c1.v[j] + 2 * Q.c1.v[j]);
+    }
+    X = Fq2_29::sqr_add(R, kT);
+    const Fq2_29 D = Fq2_29::sub(Q, Fq29C::K6, X);
+    const Fq2_29 nS = Fq2_29::neg_lazy(Fq29C::K4, S1);
+    const Fq29 nR1 = Fq29::neg_lazy(Fq29C::K8, R.c1);
+    // Y3 = R D - S1 PPP: (R0 D0 - R1 D1 - S0 T0 + S1 T1, R0 D1 + R1 D0 - S0 T1 - S1 T0)
+    const Fq29 y0 = Fq29::dot4<true>(R.c0, D.c0, nR1, D.c1, nS.c0, PPP.c0, S1.c1, PPP.c1);
+    const Fq29 y1 = Fq29::dot4<true>(R.c0, D.c1, R.c1, D.c0, nS.c0, PPP.c1, nS.c1, PPP.c0);
     Y = {y0, y1};
   }
 };

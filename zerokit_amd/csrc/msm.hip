@@ -362,8 +362,8 @@ template <class Aff, class XY, class Aff29, class Acc29>
 __global__ void __launch_bounds__(64) k_selftest29(const Aff* __restrict__ pts, const Aff29* __restrict__ pts29,
                                                    uint32_t npts, uint32_t iters, uint32_t* __restrict__ bad) {
   uint32_t t = blockIdx.x * 64 + threadIdx.x;
-  XY a = XY::inf();
-  Acc29 b = Acc29::inf();
+  XY a = XY::inf(), sa = XY::inf();
+  Acc29 b = Acc29::inf(), sb = Acc29::inf();
   uint32_t st = t * 2654435761u + 12345u;
   for (uint32_t i = 0; i < iters; i++) {
     st = st * 1664525u + 1013904223u;
@@ -376,6 +376,10 @@ __global__ void __launch_bounds__(64) k_selftest29(const Aff* __restrict__ pts, 
     if (neg) p.y = p.y.neg();
     a.madd(p);
     b.madd(pts29[k], neg);
+    // general additions (Acc29::add, the small batches' sum trees): a snapshot of the walk is added back in later -- and once
+    // straight away, which is the doubling case of the general law
+    if (i % 9 == 2) { sa = a; sb = b; }
+    if (i % 9 == 6 || (i % 27 == 2 && (t & 1))) { a.add(sa); b.add(sb); }
     if (i % 13 == 7) {                              // a point and its negation back to back: cancels to the previous sum
       Aff q = pts[(k + 1) % npts];
       a.madd(q);

@@ -65,7 +65,9 @@ struct Slot {
 
 struct Prover::Impl {
   hipStream_t sA = nullptr, sAb = nullptr, sA2 = nullptr, sB = nullptr, sB2 = nullptr, sC = nullptr;
-  hipStream_t sV[2] = {nullptr, nullptr};  // proof values (24 chained Poseidon hashes per proof, latency-bound)
+  // EIGHT streams in all: ROCclr maps streams onto GPU_MAX_HW_QUEUES (8, set by common.cpp) hardware queues and two streams
+  // that share a queue serialise -- a ninth stream was measured as a 0.12 ms hole in the single-proof timeline
+  hipStream_t sV = nullptr;   // proof values (24 chained Poseidon hashes per proof, latency-bound: ~17 ms of a 46 ms step)
   hipStream_t sW = nullptr;   // wipes: a stream of their own -- on sC a wipe would queue behind the back ends of every later
                               // batch, and the slot's next user would wait for all of them (measured: the pipeline drained)
   uint32_t seq = 0;  // batches enqueued: consecutive front ends alternate between sA and sA2
@@ -178,8 +180,7 @@ struct Prover::Impl {
   void sync_all() {
     RLN_HIP(hipStreamSynchronize(sA));
     RLN_HIP(hipStreamSynchronize(sAb));
-    RLN_HIP(hipStreamSynchronize(sV[0]));
-    RLN_HIP(hipStreamSynchronize(sV[1]));
+    RLN_HIP(hipStreamSynchronize(sV));
     RLN_HIP(hipStreamSynchronize(sA2));
     RLN_HIP(hipStreamSynchronize(sB));
     if (sB2) RLN_HIP(hipStreamSynchronize(sB2));
@@ -347,7 +348,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     RLN_HIP(hipStreamCreateWithPriority(&D.sA, hipStreamNonBlocking, hi));
     RLN_HIP(hipStreamCreateWithPriority(&D.sA2, hipStreamNonBlocking, hi));
     RLN_HIP(hipStreamCreateWithPriority(&D.sAb, hipStreamNonBlocking, hi));
-    for (auto& v : D.sV) RLN_HIP(hipStreamCreateWithPriority(&v, hipStreamNonBlocking, hi));
+    RLN_HIP(hipStreamCreateWithPriority(&D.sV, hipStreamNonBlocking, hi));
     RLN_HIP(hipStreamCreateWithPriority(&D.sB, hipStreamNonBlocking, lo));
     RLN_HIP(hipStreamCreateWithPriority(&D.sC, hipStreamNonBlocking, hi));
     RLN_HIP(hipStreamCreateWithPriority(&D.sW, hipStreamNonBlocking, hi));
@@ -394,6 +395,8 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     D.nodes.upload(prog.data(), D.N, s);
     RLN_HIP(hipStreamSynchronize(s));
   }
+  RLN_HIP(hipFuncSetAttribute((const void*)k_sum_tree<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_TREE_LDS_G2));
+  RLN_HIP(hipFuncSetAttribute((const void*)k_sum_blocks<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_TREE_LDS_G2));
   RLN_HIP(hipFuncSetAttribute((const void*)k_witness, hipFuncAttributeMaxDynamicSharedMemorySize, WIT_RING * 8 * 64 * 4 + WIT_LDS_CONSTS * 32));
   D.consts.alloc(std::max<size_t>(graph_.constants.size(), 1));
   if (!graph_.constants.empty()) D.consts.upload(graph_.constants.data(), graph_.constants.size(), s);
@@ -914,7 +917,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
 Prover::~Prover() {
   if (!d_) return;
   Impl& D = *d_;
-  for (hipStream_t st : {D.sA, D.sAb, D.sA2, D.sB, D.sB2, D.sC, D.sV[0], D.sV[1], D.sW})
+  for (hipStream_t st : {D.sA, D.sAb, D.sA2, D.sB, D.sB2, D.sC, D.sV, D.sW})
     if (st) (void)hipStreamSynchronize(st);
   // freed device memory is not cleared by the runtime: nothing secret-dependent goes back to the allocator
   try {
@@ -938,7 +941,7 @@ Prover::~Prover() {
     for (auto& e : S.t)
       if (e) (void)hipEventDestroy(e);
   }
-  for (hipStream_t st : {D.sA, D.sAb, D.sA2, D.sB, D.sB2, D.sC, D.sV[0], D.sV[1], D.sW})
+  for (hipStream_t st : {D.sA, D.sAb, D.sA2, D.sB, D.sB2, D.sC, D.sV, D.sW})
     if (st) (void)hipStreamDestroy(st);
 }
 
@@ -1136,8 +1139,9 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // (up to 96 proofs: above, the walks are issue-bound even for a lone batch and the extra rows cost more than the ladder
   // they replace -- 128 proofs 16.6 -> 15.3 ms without them, 64 proofs 10.1 -> 10.3 ms)
   const bool fused = lone && n <= 96 && early && small && mode == PROVE_FULL && D.nh == 2 && T.fused_smul && T.early_fin;   // (its back end is the split one below)
-  // tiny: a lane per (row, half) and a two-stage sum (plan1tf / plan2t) -- only the fused full proof of a lone batch
-  const bool tiny = fused && n <= T.tiny_max && n <= Impl::tiny_stride;
+  // tiny: a lane per (row, half) and a two-stage sum (plan1tf / plan2t) -- only the fused full proof of a lone batch, and
+  // only when it walks with lanes = chunks (the lanes = proofs form of the mid-size batches needs 64 proofs of stride)
+  const bool tiny = fused && n <= T.tiny_max && n <= Impl::tiny_stride && n <= D.lanechunk_walk_max;
   const Impl::Plan& P1 = tiny ? D.plan1tf[PROVE_FULL] : fused ? D.plan1f[PROVE_FULL] : small ? D.plan1s[mode] : D.plan1[mode];
   const Impl::Plan& P2 = tiny ? D.plan2t[PROVE_FULL] : small ? D.plan2s[mode] : D.plan2[mode];
   const uint32_t PB = tiny ? Impl::tiny_stride : small ? D.small_stride : (uint32_t)B_;   // stride of the partial-sum arrays
@@ -1349,7 +1353,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   RLN_HIP(hipEventRecord(S.evB2, D.sB2));
   // ---------------- stage C
   // proof values (Poseidon chain, latency-bound, depends on the inputs only): the back-end stream has slack
-  hipStream_t sV = D.sV[sq & 1];
+  hipStream_t sV = D.sV;
   if (S.used) {
     RLN_HIP(hipStreamWaitEvent(D.sC, S.free_event(), 0));
     RLN_HIP(hipStreamWaitEvent(sV, S.free_event(), 0));
@@ -1380,21 +1384,21 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     const TaskSel sel = task_sel(segs);
     const uint32_t ns = (uint32_t)segs.size();
     if (tiny) {
-      hipLaunchKernelGGL(k_sum_blocks<Fq>, dim3(nb, ns, std::max(P1.maxblk, 1u)), dim3(SUM_TREE_LANES), 0, st, S.part1.p, P1.segchunks.p,
+      hipLaunchKernelGGL(k_sum_blocks<Fq>, dim3(nb, ns, std::max(P1.maxblk, 1u)), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G1, st, S.part1.p, P1.segchunks.p,
                          P1.segblocks.p, S.grp1.p, PB, sel);
-      hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, ns), dim3(SUM_TREE_LANES), 0, st, S.grp1.p, P1.segblocks.p, S.sums1.p, B, PB, sel);
+      hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, ns), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G1, st, S.grp1.p, P1.segblocks.p, S.sums1.p, B, PB, sel);
     } else {
-      hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, ns), dim3(SUM_TREE_LANES), 0, st, S.part1.p, P1.segchunks.p, S.sums1.p, B, PB, sel);
+      hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, ns), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G1, st, S.part1.p, P1.segchunks.p, S.sums1.p, B, PB, sel);
     }
   };
   auto sum2 = [&](hipStream_t st) {
     const TaskSel sel = task_sel({0, 1, 2, 3, 4, 5});
     if (tiny) {
-      hipLaunchKernelGGL(k_sum_blocks<Fq2>, dim3(nb, P2.nseg, std::max(P2.maxblk, 1u)), dim3(SUM_TREE_LANES), 0, st, S.part2.p,
+      hipLaunchKernelGGL(k_sum_blocks<Fq2>, dim3(nb, P2.nseg, std::max(P2.maxblk, 1u)), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G2, st, S.part2.p,
                          P2.segchunks.p, P2.segblocks.p, S.grp2.p, PB, sel);
-      hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(SUM_TREE_LANES), 0, st, S.grp2.p, P2.segblocks.p, S.sums2.p, B, PB, sel);
+      hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G2, st, S.grp2.p, P2.segblocks.p, S.sums2.p, B, PB, sel);
     } else {
-      hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(SUM_TREE_LANES), 0, st, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, sel);
+      hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G2, st, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, sel);
     }
   };
   if (early_fin) {
@@ -1457,8 +1461,8 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   }
   if (early_fin) {
   } else if (lanechunk) {   // small batch: lanes = partial sums (k_sum_tree)
-    hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, P1.nseg), dim3(SUM_TREE_LANES), 0, D.sC, S.part1.p, P1.segchunks.p, S.sums1.p, B, PB, all6);
-    hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(SUM_TREE_LANES), 0, D.sC, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, all6);
+    hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, P1.nseg), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G1, D.sC, S.part1.p, P1.segchunks.p, S.sums1.p, B, PB, all6);
+    hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G2, D.sC, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, all6);
   } else {
     if (P1.ngroups)
       hipLaunchKernelGGL(k_sum_ranges<Fq>, dim3(pg, P1.ngroups), dim3(64), 0, D.sC, S.part1.p, P1.groups.p, P1.ngroups,

@@ -53,6 +53,8 @@ inline TaskSel task_sel(std::initializer_list<uint32_t> ids) {
   return t;
 }
 constexpr uint32_t SUM_TREE_LANES = 512;
+// dynamic LDS of k_sum_tree / k_sum_blocks: the upper half of a level, one point in the 9 x 29 form per lane
+constexpr uint32_t SUM_TREE_LDS_G1 = SUM_TREE_LANES / 2 * 4 * 9 * 4, SUM_TREE_LDS_G2 = 2 * SUM_TREE_LDS_G1;
 struct InputSlots {
   uint32_t secret, limit, msg_id, path, path_idx, x, ext, depth;
 };

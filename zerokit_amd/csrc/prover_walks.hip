@@ -38,19 +38,28 @@ __global__ void __launch_bounds__(64) k_sum_ranges(const XYZZ<F>* __restrict__ s
 // through LDS: 8 + 6 additions.
 // which segments / tasks a launch covers (grid.y = n): a small batch finishes s A and r B1 from the h-independent rows
 // while the h rows are still being walked, so the back-end kernels run twice on disjoint task lists
+// (the tree adds in the 9 x 29 form of fq29.h -- G1Acc29::add / G2Acc29::add: a level is one general addition of a lone
+// lane, 14 field products, and that form needs 0.55 x the instructions of the 8 x 32 one; partial sums are converted once on
+// the way in and once on the way out, and cross the levels through LDS as they are: 144 / 288 bytes per point, dynamic LDS)
+template <class F> struct Acc29Of;
+template <> struct Acc29Of<Fq> { typedef G1Acc29 type; };
+template <> struct Acc29Of<Fq2> { typedef G2Acc29 type; };
+extern __shared__ uint4 sum_tree_lds[];
+
 template <class F>
 __global__ void __launch_bounds__(SUM_TREE_LANES) k_sum_tree(const XYZZ<F>* __restrict__ part, const ChunkDesc* __restrict__ segchunks,
                                                   XYZZ<F>* __restrict__ dst, uint32_t B, uint32_t PB, TaskSel sel) {
   // 512 lanes per (proof, segment): the short chunks of the small-batch plans leave ~2 000 partial sums per segment;
   // four per lane and a nine-level tree (part stride PB, result stride B).  The additions are a dependent chain for the
-  // lone waves of a single proof (30 us each in Fq2), so the lane count is what sets the kernel's length: 256 lanes were
-  // 8 + 8 additions.  Only the upper half of a level passes through LDS.
-  __shared__ XYZZ<F> sh[SUM_TREE_LANES / 2];
+  // lone waves of a single proof, so the lane count is what sets the kernel's length: 256 lanes were 8 + 8 additions.
+  // Only the upper half of a level passes through LDS.
+  typedef typename Acc29Of<F>::type Acc;
+  Acc* sh = reinterpret_cast<Acc*>(sum_tree_lds);
   __builtin_amdgcn_s_setprio(3);
   const uint32_t p = blockIdx.x, sgi = sel.id[blockIdx.y], l = threadIdx.x;
   const ChunkDesc cd = segchunks[sgi];
-  XYZZ<F> acc = XYZZ<F>::inf();
-  for (uint32_t i = cd.pt_begin + l; i < cd.pt_end; i += SUM_TREE_LANES) acc.add(part[(size_t)i * PB + p]);
+  Acc acc = Acc::inf();
+  for (uint32_t i = cd.pt_begin + l; i < cd.pt_end; i += SUM_TREE_LANES) acc.add(Acc::from_xyzz(part[(size_t)i * PB + p]));
 #pragma unroll 1
   for (uint32_t stride = SUM_TREE_LANES / 2; stride >= 1; stride >>= 1) {
     if (l >= stride && l < 2 * stride) sh[l - stride] = acc;
@@ -58,7 +67,7 @@ __global__ void __launch_bounds__(SUM_TREE_LANES) k_sum_tree(const XYZZ<F>* __re
     if (l < stride) acc.add(sh[l]);
     __syncthreads();
   }
-  if (l == 0) dst[(size_t)sgi * B + p] = acc;
+  if (l == 0) dst[(size_t)sgi * B + p] = acc.to_xyzz();
 }
 
 // First stage of the two-stage sum (tiny batches): block z of segment sel.id[y] -- 512 consecutive partial sums -- to
@@ -67,13 +76,14 @@ template <class F>
 __global__ void __launch_bounds__(SUM_TREE_LANES) k_sum_blocks(const XYZZ<F>* __restrict__ part, const ChunkDesc* __restrict__ segchunks,
                                                     const ChunkDesc* __restrict__ segblocks, XYZZ<F>* __restrict__ dst, uint32_t PB,
                                                     TaskSel sel) {
-  __shared__ XYZZ<F> sh[SUM_TREE_LANES / 2];
+  typedef typename Acc29Of<F>::type Acc;
+  Acc* sh = reinterpret_cast<Acc*>(sum_tree_lds);
   __builtin_amdgcn_s_setprio(3);
   const uint32_t p = blockIdx.x, sgi = sel.id[blockIdx.y], l = threadIdx.x;
   const ChunkDesc cd = segchunks[sgi], bd = segblocks[sgi];
   if (blockIdx.z >= bd.pt_end - bd.pt_begin) return;   // (uniform for the workgroup)
   const uint32_t i = cd.pt_begin + blockIdx.z * SUM_TREE_LANES + l;
-  XYZZ<F> acc = i < cd.pt_end ? part[(size_t)i * PB + p] : XYZZ<F>::inf();
+  Acc acc = i < cd.pt_end ? Acc::from_xyzz(part[(size_t)i * PB + p]) : Acc::inf();
 #pragma unroll 1
   for (uint32_t stride = SUM_TREE_LANES / 2; stride >= 1; stride >>= 1) {
     if (l >= stride && l < 2 * stride) sh[l - stride] = acc;
@@ -81,7 +91,7 @@ __global__ void __launch_bounds__(SUM_TREE_LANES) k_sum_blocks(const XYZZ<F>* __
     if (l < stride) acc.add(sh[l]);
     __syncthreads();
   }
-  if (l == 0) dst[(size_t)(bd.pt_begin + blockIdx.z) * PB + p] = acc;
+  if (l == 0) dst[(size_t)(bd.pt_begin + blockIdx.z) * PB + p] = acc.to_xyzz();
 }
 
 // GLV: segment t holds sum k1_i P_i, segment nseg + t holds sum k2_i P_i; the result is the first plus phi of the
