@@ -436,10 +436,8 @@ struct G1Acc29 {
     const Fq29 U1 = Fq29::mul(X, o.ZZ), U2 = Fq29::mul(o.X, ZZ);       // < 1.06 q
     const Fq29 S1 = Fq29::mul(Y, o.ZZZ), S2 = Fq29::mul(o.Y, ZZZ);     // < 1.03 q
     const Fq29 P = Fq29::sub(U2, Fq29C::K2, U1), R = Fq29::sub(S2, Fq29C::K2, S1);   // in (0.9 q, 3.1 q), normalised
-    if (P.is_zero_mod_q()) {
-      G1XYZZ a = to_xyzz();
-      a.add(o.to_xyzz());
-      *this = from_xyzz(a);
+    if (P.is_zero_mod_q()) {   // out of line: the rare path's registers are its own
+      add_same_x(this, &o);
       return;
     }
     const Fq29 PP = Fq29::sqr(P);
@@ -456,6 +454,11 @@ struct G1Acc29 {
     for (int j = 0; j < 9; j++) D.v[j] = Q.v[j] + Fq29C::K6[j] - X.v[j];
     const Fq29 nS1 = Fq29::neg_lazy(Fq29C::K4, S1);
     Y = Fq29::dot2(R, D, nS1, PPP);                   // R (Q - X3) - S1 PPP
+  }
+  static __device__ __noinline__ void add_same_x(G1Acc29* self, const G1Acc29* o) {
+    G1XYZZ a = self->to_xyzz();
+    a.add(o->to_xyzz());
+    *self = from_xyzz(a);
   }
 };
 
@@ -620,27 +623,49 @@ struct G2Acc29 {
     Y = {y0, y1};
   }
 
-  // this += o (see G1Acc29::add): madd's tail with (X, Y) -> (U1, S1), the same operand classes at every call site
-  __device__ __forceinline__ void add(const G2Acc29& o) {
-    if (o.is_inf()) return;
+  // this += *o (see G1Acc29::add): madd's tail with (X, Y) -> (U1, S1), the same operand classes at every call site.
+  // The operand is read from memory (LDS in the sum trees) coordinate by coordinate and in the order that lets the
+  // operands die early -- a G2 point is 72 words, and with both points, U1, U2, S1, S2 and a product's accumulators alive
+  // at once the kernel spilled 283 registers; the compiler barriers keep the loads where they are written.
+  __device__ __forceinline__ void add(const G2Acc29* o) {
+    if (o->is_inf()) return;
     if (is_inf()) {
-      *this = o;
+      *this = *o;
       return;
     }
-    const Fq2_29 U1 = Fq2_29::mul(X, o.ZZ), U2 = Fq2_29::mul(o.X, ZZ);
-    const Fq2_29 S1 = Fq2_29::mul(Y, o.ZZZ), S2 = Fq2_29::mul(o.Y, ZZZ);
-    const Fq2_29 P = Fq2_29::sub(U2, Fq29C::K2, U1), R = Fq2_29::sub(S2, Fq29C::K2, S1);
-    if (P.is_zero_mod_q()) {
-      G2XYZZ a = to_xyzz();
-      a.add(o.to_xyzz());
-      *this = from_xyzz(a);
+    Fq2_29 U1, P, S1, R;
+    {
+      const Fq2_29 oZZ = o->ZZ, oX = o->X;
+      U1 = Fq2_29::mul(X, oZZ);
+      const Fq2_29 U2 = Fq2_29::mul(oX, ZZ);
+      P = Fq2_29::sub(U2, Fq29C::K2, U1);
+    }
+    asm volatile("" ::: "memory");
+    {
+      const Fq2_29 oZZZ = o->ZZZ, oY = o->Y;
+      S1 = Fq2_29::mul(Y, oZZZ);
+      const Fq2_29 S2 = Fq2_29::mul(oY, ZZZ);
+      R = Fq2_29::sub(S2, Fq29C::K2, S1);
+    }
+    if (P.is_zero_mod_q()) {   // doubling / cancellation: through the 8 x 32 law, out of line (its registers are its own)
+      add_same_x(this, o);
       return;
     }
+    asm volatile("" ::: "memory");
+    {
+      const Fq2_29 oZZ = o->ZZ;
+      ZZ = Fq2_29::mul(ZZ, oZZ);
+    }
+    {
+      const Fq2_29 oZZZ = o->ZZZ;
+      ZZZ = Fq2_29::mul(ZZZ, oZZZ);
+    }
+    asm volatile("" ::: "memory");
     const Fq2_29 PP = Fq2_29::sqr(P);
-    ZZ = Fq2_29::mul(Fq2_29::mul(ZZ, o.ZZ), PP);
+    ZZ = Fq2_29::mul(ZZ, PP);
     const Fq2_29 Q = Fq2_29::mul(U1, PP);
     const Fq2_29 PPP = Fq2_29::mul(P, PP);
-    ZZZ = Fq2_29::mul(Fq2_29::mul(ZZZ, o.ZZZ), PPP);
+    ZZZ = Fq2_29::mul(ZZZ, PPP);
     Fq2_29 kT;
 #pragma unroll
     for (int j = 0; j < 9; j++) {
@@ -655,6 +680,12 @@ struct G2Acc29 {
     const Fq29 y0 = Fq29::dot4<true>(R.c0, D.c0, nR1, D.c1, nS.c0, PPP.c0, S1.c1, PPP.c1);
     const Fq29 y1 = Fq29::dot4<true>(R.c0, D.c1, R.c1, D.c0, nS.c0, PPP.c1, nS.c1, PPP.c0);
     Y = {y0, y1};
+  }
+  __device__ __forceinline__ void add(const G2Acc29& o) { add(&o); }
+  static __device__ __noinline__ void add_same_x(G2Acc29* self, const G2Acc29* o) {
+    G2XYZZ a = self->to_xyzz();
+    a.add(o->to_xyzz());
+    *self = from_xyzz(a);
   }
 };
 

@@ -1404,12 +1404,9 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   if (early_fin) {
     RLN_HIP(hipStreamWaitEvent(D.sA2, S.evE, 0));   // sB: the early G1 walk
     if (fused) {
-      // fused plan: only A has to be reduced and inverted early; s A and r B1 are inside the C segment, B1 is never formed
+      // fused plan: only A's segment sums are formed early; its fold and inversion ride in k_fin_out_ac_fused, and s A,
+      // r B1 are inside the C segment (B1 is never formed)
       sum1(D.sA2, {0, 3});
-      hipLaunchKernelGGL(k_glv_fold, dim3(pg, 1), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({0}));
-      hipLaunchKernelGGL(k_fin_affine, dim3(pg, 1), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
-                         S.affB2.p, B, nbp, task_sel({0}));
-      RLN_HIP(hipMemsetAsync(S.prod.p, 0, S.prod.bytes(), D.sA2));   // ZZ = 0: two points at infinity for k_fin_out
     } else {
       sum1(D.sA2, {0, 1, 3, 4});
       hipLaunchKernelGGL(k_glv_fold, dim3(pg, 2), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({0, 1}));
@@ -1449,7 +1446,10 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     sum1(sF, {2, 5});
     RLN_HIP(hipStreamWaitEvent(sF, S.evA, 0));   // A affine, s A and r B1
     // A's and C's side of the output (fold of the C segment, inversion, bytes): see k_fin_out_ac
-    hipLaunchKernelGGL(k_fin_out_ac, dim3(pg), dim3(64), 0, sF, S.sums1.p, S.prod.p, S.affA.p, S.coords.p, S.comp.p, B, nbp);
+    if (fused)
+      hipLaunchKernelGGL(k_fin_out_ac_fused, dim3(pg), dim3(64), 0, sF, S.sums1.p, S.affA.p, S.coords.p, S.comp.p, B, nbp);
+    else
+      hipLaunchKernelGGL(k_fin_out_ac, dim3(pg), dim3(64), 0, sF, S.sums1.p, S.prod.p, S.affA.p, S.coords.p, S.comp.p, B, nbp);
     if (lone) RLN_HIP(hipStreamWaitEvent(sF, S.evB2, 0));   // the copies home need B's bytes (not lone: sG = sF = sC, in order)
     RLN_HIP(hipStreamWaitEvent(sF, S.evV, 0));
   } else {

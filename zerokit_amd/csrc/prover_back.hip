@@ -235,6 +235,56 @@ __global__ void __launch_bounds__(64) k_fin_out_ac(const G1XYZZ* __restrict__ su
   }
 }
 
+// The same for the FUSED plan of a lone small proof (s A and r B1 are rows of the C segment: nothing to add to C, and A is
+// needed for its bytes only): A's GLV fold and inversion move in here as well and the two inversions share one
+// (Montgomery's trick: (a c)^-1, then two products) -- the chain sum -> fold -> inversion -> memset -> output that A's side
+// hung in front of this kernel is gone.  Same values: 1 / ZZZ is the same field element however it is obtained.
+__global__ void __launch_bounds__(64) k_fin_out_ac_fused(const G1XYZZ* __restrict__ sums1, G1Affine* __restrict__ affA,
+                                                         uint32_t* __restrict__ coords, uint8_t* __restrict__ comp, uint32_t B,
+                                                         uint32_t nb) {
+  __builtin_amdgcn_s_setprio(3);
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= nb) return;
+  const Fq beta = Fq::from_canonical(GlvParams::BETA_G1);
+  G1XYZZ Aacc = sums1[p], a2 = sums1[3 * (size_t)B + p];
+  a2.X = a2.X * beta;
+  Aacc.add(a2);
+  G1XYZZ Cacc = sums1[2 * (size_t)B + p], c2 = sums1[5 * (size_t)B + p];
+  c2.X = c2.X * beta;
+  Cacc.add(c2);
+  G1Affine A, C;
+  if (Aacc.is_inf() || Cacc.is_inf()) {
+    A = Aacc.to_affine();
+    C = Cacc.to_affine();
+  } else {
+    const Fq t = (Aacc.ZZZ * Cacc.ZZZ).inv();
+    const Fq ia = t * Cacc.ZZZ, ic = t * Aacc.ZZZ;     // 1 / A.ZZZ, 1 / C.ZZZ
+    const Fq iza = Aacc.ZZ * ia, izc = Cacc.ZZ * ic;   // 1 / Z = ZZ / ZZZ
+    A = {Aacc.X * iza.sqr(), Aacc.Y * ia};
+    C = {Cacc.X * izc.sqr(), Cacc.Y * ic};
+  }
+  affA[p] = A;
+  uint32_t* o = coords + (size_t)p * 64;
+  store_fq(o, A.x);
+  store_fq(o + 8, A.y);
+  store_fq(o + 48, C.x);
+  store_fq(o + 56, C.y);
+  uint32_t* cw = (uint32_t*)(comp + (size_t)p * 128);
+  uint32_t wa[8], wc[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    wa[i] = o[i];
+    wc[i] = o[48 + i];
+  }
+  if (A.is_inf()) wa[7] |= 0x40000000u; else if (fq_is_neg_dev(A.y)) wa[7] |= 0x80000000u;
+  if (C.is_inf()) wc[7] |= 0x40000000u; else if (fq_is_neg_dev(C.y)) wc[7] |= 0x80000000u;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    cw[i] = wa[i];
+    cw[24 + i] = wc[i];
+  }
+}
+
 // =====================================================================================================
 // 7. proof values by the Poseidon formulae (witness.rs:759-828): root, a1, y, nullifier
 // =====================================================================================================

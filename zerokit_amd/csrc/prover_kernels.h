@@ -135,6 +135,9 @@ __global__ void __launch_bounds__(64) k_fin_out_b2(const G2XYZZ* __restrict__ su
 __global__ void __launch_bounds__(64) k_fin_out_ac(const G1XYZZ* __restrict__ sums1, const G1XYZZ* __restrict__ prod,
                                                    const G1Affine* __restrict__ affA, uint32_t* __restrict__ coords,
                                                    uint8_t* __restrict__ comp, uint32_t B, uint32_t nb);
+__global__ void __launch_bounds__(64) k_fin_out_ac_fused(const G1XYZZ* __restrict__ sums1, G1Affine* __restrict__ affA,
+                                                         uint32_t* __restrict__ coords, uint8_t* __restrict__ comp, uint32_t B,
+                                                         uint32_t nb);
 __global__ void __launch_bounds__(64) k_proof_values(const uint32_t* __restrict__ inputs, uint32_t n_inputs,
                                                      InputSlots sl, PoseidonView p2, PoseidonView p3, PoseidonView p4,
                                                      uint32_t* __restrict__ values, uint32_t nb);

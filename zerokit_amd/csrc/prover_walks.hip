@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(SUM_TREE_LANES) k_sum_tree(const XYZZ<F>* __re
   for (uint32_t stride = SUM_TREE_LANES / 2; stride >= 1; stride >>= 1) {
     if (l >= stride && l < 2 * stride) sh[l - stride] = acc;
     __syncthreads();
-    if (l < stride) acc.add(sh[l]);
+    if (l < stride) acc.add(sh[l]);   // (G2: read from LDS coordinate by coordinate, see G2Acc29::add)
     __syncthreads();
   }
   if (l == 0) dst[(size_t)sgi * B + p] = acc.to_xyzz();
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(SUM_TREE_LANES) k_sum_blocks(const XYZZ<F>* __
   for (uint32_t stride = SUM_TREE_LANES / 2; stride >= 1; stride >>= 1) {
     if (l >= stride && l < 2 * stride) sh[l - stride] = acc;
     __syncthreads();
-    if (l < stride) acc.add(sh[l]);
+    if (l < stride) acc.add(sh[l]);   // (G2: read from LDS coordinate by coordinate, see G2Acc29::add)
     __syncthreads();
   }
   if (l == 0) dst[(size_t)(bd.pt_begin + blockIdx.z) * PB + p] = acc.to_xyzz();
