@@ -345,13 +345,16 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     // of the MSM's thousands of workgroups
     int lo = 0, hi = 0;
     RLN_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    // sW FIRST: kernels on the first stream a process creates run ~70 us slower each on this stack (kernel trace of single
+    // proofs: 0.085 against 0.006 ms for k_v29_to_fr, every NTT pass 0.08 against 0.016 ms -- every second proof, the ones
+    // whose front end landed there, took 3.3 instead of 2.8 ms); the wipes do not care
+    RLN_HIP(hipStreamCreateWithPriority(&D.sW, hipStreamNonBlocking, hi));
     RLN_HIP(hipStreamCreateWithPriority(&D.sA, hipStreamNonBlocking, hi));
     RLN_HIP(hipStreamCreateWithPriority(&D.sA2, hipStreamNonBlocking, hi));
     RLN_HIP(hipStreamCreateWithPriority(&D.sAb, hipStreamNonBlocking, hi));
     RLN_HIP(hipStreamCreateWithPriority(&D.sV, hipStreamNonBlocking, hi));
     RLN_HIP(hipStreamCreateWithPriority(&D.sB, hipStreamNonBlocking, lo));
     RLN_HIP(hipStreamCreateWithPriority(&D.sC, hipStreamNonBlocking, hi));
-    RLN_HIP(hipStreamCreateWithPriority(&D.sW, hipStreamNonBlocking, hi));
     D.nslot = std::min(std::max(D.tune.slots, 2), (int)Impl::NSLOT);
     D.walk_clk.alloc(4);
     RLN_HIP(hipMemset(D.walk_clk.p, 0, 4 * sizeof(unsigned long long)));
