@@ -63,7 +63,7 @@ def walk_source_hash():
     """identifies the code the table walks are compiled from; the PMC passes under profiles/ record it, and the VALU
     view is only emitted when it matches (an instruction count belongs to one build)"""
     h = hashlib.sha256()
-    for f in ("walk29.h", "fq29.h", "fq29_constants.h", "curve.h", "glv.h"):
+    for f in ("walk29.h", "walk29_impl.h", "fq29.h", "fq29_constants.h", "curve.h", "glv.h"):
         h.update(open(os.path.join(ROOT, "zerokit_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

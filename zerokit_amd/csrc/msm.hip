@@ -283,9 +283,14 @@ __global__ void __launch_bounds__(64) k_slice_acc(const G1Affine29* __restrict__
   else if (kend > hi) tail[s] = out;       // started here, continues in the next slice
   else buckets[key] = out;                 // ends exactly at the slice end
 }
+// A bucket cut into more than MSM_BIG_SLICES slices (skewed inputs: many equal scalars -- witness values that are 0 or 1,
+// or the all-equal test distribution, where ONE bucket per window holds every point and is 131 072 slices at 2^24) is not
+// joined by one lane's serial loop (1.8 s) but listed, and k_slice_fix_big gives it a 256-lane workgroup: every lane
+// adds its share of the heads, then an eight-level tree through LDS (7 ms).  Uniform scalars list nothing.
+constexpr uint32_t MSM_BIG_SLICES = 64, MSM_BIG_CAP = 4096, MSM_BIG_LANES = 256;
 __global__ void __launch_bounds__(64) k_slice_fix(const uint32_t* __restrict__ offs, uint32_t nkeys,
                                                   const G1XYZZ* __restrict__ head, const G1XYZZ* __restrict__ tail,
-                                                  G1XYZZ* __restrict__ buckets) {
+                                                  G1XYZZ* __restrict__ buckets, uint32_t* __restrict__ big) {
   uint32_t key = blockIdx.x * 64 + threadIdx.x;
   if (key >= nkeys) return;
   uint32_t start = offs[key], end = offs[key + 1];
@@ -295,9 +300,35 @@ __global__ void __launch_bounds__(64) k_slice_fix(const uint32_t* __restrict__ o
   }
   uint32_t s0 = start / MSM_SLICE, s1 = (end - 1) / MSM_SLICE;
   if (s0 == s1) return;  // written by its slice
+  if (s1 - s0 > MSM_BIG_SLICES) {
+    const uint32_t k = atomicAdd(big, 1u);
+    if (k < MSM_BIG_CAP) {   // (more than 4 096 such buckets would need > 2^25 entries per window: not with n <= 2^24 x 16 / 16)
+      big[1 + k] = key;
+      return;
+    }
+  }
   G1XYZZ acc = tail[s0];  // slice s0 saw it start (from_before == false) and run past its end
   for (uint32_t s = s0 + 1; s <= s1; s++) acc.add(head[s]);
   buckets[key] = acc;
+}
+__global__ void __launch_bounds__(MSM_BIG_LANES) k_slice_fix_big(const uint32_t* __restrict__ offs,
+                                                                 const G1XYZZ* __restrict__ head, const G1XYZZ* __restrict__ tail,
+                                                                 G1XYZZ* __restrict__ buckets, const uint32_t* __restrict__ big) {
+  __shared__ G1XYZZ sh[MSM_BIG_LANES / 2];
+  const uint32_t count = big[0] < MSM_BIG_CAP ? big[0] : MSM_BIG_CAP, l = threadIdx.x;
+  for (uint32_t b = blockIdx.x; b < count; b += gridDim.x) {   // (uniform for the workgroup)
+    const uint32_t key = big[1 + b];
+    const uint32_t s0 = offs[key] / MSM_SLICE, s1 = (offs[key + 1] - 1) / MSM_SLICE;
+    G1XYZZ acc = l == 0 ? tail[s0] : G1XYZZ::inf();
+    for (uint32_t s = s0 + 1 + l; s <= s1; s += MSM_BIG_LANES) acc.add(head[s]);
+    for (uint32_t stride = MSM_BIG_LANES / 2; stride >= 1; stride >>= 1) {
+      if (l >= stride && l < 2 * stride) sh[l - stride] = acc;
+      __syncthreads();
+      if (l < stride) acc.add(sh[l]);
+      __syncthreads();
+    }
+    if (l == 0) buckets[key] = acc;
+  }
 }
 
 // chunk [lo, lo+32) of one window: S = sum B_b, T = sum (b - lo + 1) B_b by the running-sum trick
@@ -449,6 +480,7 @@ struct MsmG1::Impl {
   DevBuf<uint16_t> dig;
   DevBuf<uint32_t> hist;
   DevBuf<G1XYZZ> buckets, chunkS, chunkT, grp, wsum, head, tail;
+  DevBuf<uint32_t> big;         // k_slice_fix: count + keys of the buckets cut into many slices
   size_t max_slices = 0;
   DevBuf<Range> r1, r2;
   DevBuf<G1XYZZ> gather;        // run_sharded: the window sums of every rank
@@ -478,6 +510,7 @@ MsmG1::MsmG1(size_t capacity) : d_(new Impl) {
   D.hist.alloc((size_t)nkeys * MSM_TILES);
   D.buckets.alloc(nkeys);
   D.max_slices = capacity * MSM_W / MSM_SLICE + 1;
+  D.big.alloc(1 + MSM_BIG_CAP);
   D.head.alloc(D.max_slices);
   D.tail.alloc(D.max_slices);
   D.chunkS.alloc(nch);
@@ -612,7 +645,10 @@ void MsmG1::enqueue_windows() {
   if (nslices)
     hipLaunchKernelGGL(k_slice_acc, dim3(div_up(nslices, 64)), dim3(64), 0, s, D.pts29.p, D.offs.p, D.sorted.p, nkeys,
                        D.buckets.p, D.head.p, D.tail.p);
-  hipLaunchKernelGGL(k_slice_fix, dim3(div_up(nkeys, 64)), dim3(64), 0, s, D.offs.p, nkeys, D.head.p, D.tail.p, D.buckets.p);
+  RLN_HIP(hipMemsetAsync(D.big.p, 0, 4, s));
+  hipLaunchKernelGGL(k_slice_fix, dim3(div_up(nkeys, 64)), dim3(64), 0, s, D.offs.p, nkeys, D.head.p, D.tail.p, D.buckets.p,
+                     D.big.p);
+  hipLaunchKernelGGL(k_slice_fix_big, dim3(64), dim3(MSM_BIG_LANES), 0, s, D.offs.p, D.head.p, D.tail.p, D.buckets.p, D.big.p);
   RLN_HIP(hipEventRecord(D.e[2], s));
   hipLaunchKernelGGL(k_bucket_red, dim3(div_up(nch, 64)), dim3(64), 0, s, D.buckets.p, D.chunkS.p, D.chunkT.p, nch);
   hipLaunchKernelGGL(k_chunk_fix, dim3(div_up(nch, 64)), dim3(64), 0, s, D.chunkS.p, D.chunkT.p, nch);

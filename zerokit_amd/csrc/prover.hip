@@ -58,6 +58,8 @@ struct Slot {
   bool used = false;
   bool marked = false;          // the timing marks t[] of the slot's batch were recorded
   bool wiped = false;           // the batch's inputs and witness values have been overwritten (Prover::wipe)
+  hipEvent_t evCb = nullptr;    // evC again with hipEventBlockingSync: what a host thread waiting for a BIG batch sleeps on (a
+                                // spinning wait per replica is a host core per GPU; small batches spin: latency)
   hipEvent_t evZ = nullptr;     // ... and that wipe has finished.  Kept apart from evC: "is the device idle" (lone) asks evC
   hipEvent_t free_event() const { return wiped ? evZ : evC; }   // what the slot's next user waits for
   size_t n = 0;
@@ -910,6 +912,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     RLN_HIP(hipEventCreateWithFlags(&S.evV, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evC, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evZ, hipEventDisableTiming));
+    RLN_HIP(hipEventCreateWithFlags(&S.evCb, hipEventDisableTiming | hipEventBlockingSync));
     for (auto& e : S.t) RLN_HIP(hipEventCreate(&e));
     RLN_HIP(hipMemsetAsync(S.digits.p, 0, S.digits.bytes(), s));
     RLN_HIP(hipMemsetAsync(S.digits2.p, 0, S.digits2.bytes(), s));
@@ -939,7 +942,7 @@ Prover::~Prover() {
     if (S.h_comp) (void)hipHostFree(S.h_comp);
     if (S.h_values) (void)hipHostFree(S.h_values);
     if (S.h_err) (void)hipHostFree(S.h_err);
-    for (hipEvent_t e : {S.evA, S.evB, S.evB2, S.evR, S.evC, S.evW, S.evV, S.evX, S.evZ})
+    for (hipEvent_t e : {S.evA, S.evB, S.evB2, S.evR, S.evC, S.evW, S.evV, S.evX, S.evZ, S.evCb})
       if (e) (void)hipEventDestroy(e);
     for (auto& e : S.t)
       if (e) (void)hipEventDestroy(e);
@@ -1037,7 +1040,7 @@ void Prover::collect(uint64_t ticket, size_t n, uint8_t* proofs, uint8_t* values
   if (!Sp) throw Error("collect: unknown or expired ticket (its workspace slot has been reused)");
   Slot& S = *Sp;
   if (n > S.n) throw Error("collect: more proofs requested than the batch holds");
-  RLN_HIP(hipEventSynchronize(S.evC));
+  RLN_HIP(hipEventSynchronize(S.n > D.lanechunk_max ? S.evCb : S.evC));
   if (S.mode == PROVE_PARTIAL) {
     if (partial320) memcpy(partial320, S.h_pp, n * 320);
   } else {
@@ -1505,6 +1508,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   RLN_HIP(hipMemcpyAsync(S.h_err, S.err.p, n * 4, hipMemcpyDeviceToHost, sF));
   MARK(10, sF);
   RLN_HIP(hipEventRecord(S.evC, sF));
+  if (n > D.lanechunk_max) RLN_HIP(hipEventRecord(S.evCb, sF));
   S.used = true;
   S.wiped = false;
   S.n = n;
