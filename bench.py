@@ -620,18 +620,32 @@ def main():
 
     # ---- the other single-GPU BASELINE configs, with the prover's HBM released
     side = {}
+    hung = False
     if not args.no_side_configs and not finish:
-        comm = None
-        try:
-            if world == 1:
-                side["config3"] = measure_config3()
-            comm = make_comm(rank, world, dist)
-            side["config5"] = measure_config5(comm, rank, world)
-        except Exception as e:  # noqa: BLE001
-            side["side_config_error"] = str(e)
-        finally:
-            if comm is not None:
-                comm.close()
+        # N > 1: the config-5 MSM is the one place with a collective (ncclAllGather through the C ABI).  It runs on a
+        # helper thread with a deadline: a rank that fails before its collective would leave the others blocked in theirs,
+        # and a blocked RCCL call cannot be cancelled -- the headline line must come out regardless.
+        import threading
+
+        def side_work():
+            comm = None
+            try:
+                check(lib().rlnamd_set_device(local_rank))   # the current device is per-thread state
+                if world == 1:
+                    side["config3"] = measure_config3()
+                comm = make_comm(rank, world, dist)
+                side["config5"] = measure_config5(comm, rank, world)
+            except Exception as e:  # noqa: BLE001
+                side["side_config_error"] = str(e)
+            finally:
+                if comm is not None:
+                    comm.close()
+        th = threading.Thread(target=side_work, daemon=True)
+        th.start()
+        th.join(timeout=300 if world == 1 else 180)
+        if th.is_alive():
+            hung = True
+            side = dict(side, side_config_error="side configs did not finish within the deadline (abandoned)")
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -730,6 +744,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ws0, rs0, side=side)
         OUT.emit(line)
+    if hung:            # a thread is stuck inside a collective: leave without the runtime's teardown
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0 if ok else 3)
     if use_dist:
         dist.destroy_process_group()
     if not ok:

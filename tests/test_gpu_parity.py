@@ -439,8 +439,9 @@ def test_msm_g1_adversarial_distributions_vs_oracle():
 
 def test_msm_g1_config5_full_size_2_24_vs_oracle():
     """BASELINE config 5 at FULL size: 2^24 generated points on one device against the oracle's closed form; the same
-    points as four 2^22 slices (the shards of a 4-way split) recombined from their window sums; and the all-equal-scalars
-    distribution at full size (16.7 M points in one bucket per window)."""
+    points as EIGHT 2^21 slices (the shards of the 8-way split of BASELINE.json) each against the oracle by itself and
+    recombined from their window sums; and the all-equal-scalars distribution at full size (16.7 M points in one bucket
+    per window: the oversized-bucket join of k_slice_fix_big)."""
     from oracle.c import binding as ob
     from zerokit_amd.batch import MsmG1
     n, seed = 1 << 24, 0xC0FFEE
@@ -450,8 +451,8 @@ def test_msm_g1_config5_full_size_2_24_vs_oracle():
     assert m.fetch(n - 1, 1)[0] == ob.msm_workload_item(seed, n - 1)
     blob, ms = m.run_windows()
     assert m.combine([blob]) == want
-    blobs, q = [], n // 4
-    for r in range(4):
+    blobs, q = [], n // 8
+    for r in range(8):
         m.generate(seed, r * q, q)
         blobs.append(m.run_windows()[0])
         assert m.combine(blobs[-1:]) == ob.msm_expected(seed, r * q, q)      # every shard by itself
