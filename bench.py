@@ -533,11 +533,11 @@ def main():
     results.clear()
     sync()
     t0 = time.perf_counter()
-    c0 = time.process_time()
+    c0, m0 = time.process_time(), time.thread_time()
     pump(args.steps * per_step)       # H2D of every batch's inputs ... D2H of its proofs, all inside
     sync()
     elapsed = time.perf_counter() - t0
-    cpu_timed = time.process_time() - c0
+    cpu_timed, cpu_main = time.process_time() - c0, time.thread_time() - m0
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -576,13 +576,15 @@ def main():
         sub_ms, col_ms = sorted(t_sub)[len(t_sub) // 2] * 1e3, sorted(t_col)[len(t_col) // 2] * 1e3
         host_feed = {"cpu_s_over_timed_region": round(cpu_timed, 3), "wall_s_timed_region": round(elapsed, 3),
                      "host_cores_busy": round(cpu_timed / elapsed, 3),
+                     "calling_thread_cores_busy": round(cpu_main / elapsed, 3),
                      "submit_ms_per_batch": round(sub_ms, 3), "collect_ms_per_batch": round(col_ms, 3),
                      "host_us_per_proof": round((sub_ms + col_ms) * 1e3 / B, 3),
                      "host_cores_for_8_gpus_at_this_rate": round(8 * (sub_ms + col_ms) / (elapsed / max(args.steps, 1) * 1e3), 3),
                      "note": "submit = copy of the batch's inputs into the slot's pinned buffer + the launches of the whole "
                              "pipeline; collect (batch already finished) = copy-out of proofs / values + the wipe's launches; "
-                             "host_cores_busy = process CPU time / wall over the timed region (includes the runtime's "
-                             "busy-wait inside collect: an upper bound on what feeding needs)"}
+                             "host_cores_busy = process CPU time / wall over the timed region, all threads (the HIP / ROCr "
+                             "runtime's own threads included); calling_thread_cores_busy = the thread that calls submit / "
+                             "collect (it sleeps on a blocking event while a big batch runs)"}
     clock_mhz = prover.walk_clock_mhz()   # mean shader clock under the two walks over the timed region
     stage_ms = prover.stage_ms()          # HIP-event spans, mean over the last five launches (overlapped with their neighbours)
     # the dominant kernel by itself: single batches with nothing else in flight (outside the timed region)
