@@ -632,7 +632,9 @@ def main():
         def side_work():
             comm = None
             try:
-                check(lib().rlnamd_set_device(local_rank))   # the current device is per-thread state
+                check(lib().rlnamd_set_device(local_rank))   # the current device is per-thread state (HIP and torch)
+                if use_dist and backend == "nccl":
+                    torch.cuda.set_device(local_rank)
                 if world == 1:
                     side["config3"] = measure_config3()
                 comm = make_comm(rank, world, dist)
