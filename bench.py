@@ -584,7 +584,7 @@ def main():
                              "pipeline; collect (batch already finished) = copy-out of proofs / values + the wipe's launches; "
                              "host_cores_busy = process CPU time / wall over the timed region, all threads (the HIP / ROCr "
                              "runtime's own threads included); calling_thread_cores_busy = the thread that calls submit / "
-                             "collect (it sleeps on a blocking event while a big batch runs)"}
+                             "collect (it polls and sleeps while a big batch runs: Prover::collect)"}
     clock_mhz = prover.walk_clock_mhz()   # mean shader clock under the two walks over the timed region
     stage_ms = prover.stage_ms()          # HIP-event spans, mean over the last five launches (overlapped with their neighbours)
     # the dominant kernel by itself: single batches with nothing else in flight (outside the timed region)

@@ -4,6 +4,7 @@
 #include "prover.h"
 
 #include <stdlib.h>
+#include <time.h>
 #include <string.h>
 
 #include <algorithm>
@@ -58,8 +59,6 @@ struct Slot {
   bool used = false;
   bool marked = false;          // the timing marks t[] of the slot's batch were recorded
   bool wiped = false;           // the batch's inputs and witness values have been overwritten (Prover::wipe)
-  hipEvent_t evCb = nullptr;    // evC again with hipEventBlockingSync: what a host thread waiting for a BIG batch sleeps on (a
-                                // spinning wait per replica is a host core per GPU; small batches spin: latency)
   hipEvent_t evZ = nullptr;     // ... and that wipe has finished.  Kept apart from evC: "is the device idle" (lone) asks evC
   hipEvent_t free_event() const { return wiped ? evZ : evC; }   // what the slot's next user waits for
   size_t n = 0;
@@ -190,6 +189,18 @@ struct Prover::Impl {
     RLN_HIP(hipStreamSynchronize(sW));
   }
 };
+
+// waits for `ev` with the calling thread asleep between polls (50 us: 0.1 % of a 45 ms batch)
+static void wait_yielding(hipEvent_t ev) {
+  for (;;) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess) return;
+    (void)hipGetLastError();   // hipErrorNotReady is not an error here
+    if (e != hipErrorNotReady) RLN_HIP(e);
+    struct timespec ts = {0, 50000};
+    nanosleep(&ts, nullptr);
+  }
+}
 
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -912,7 +923,6 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     RLN_HIP(hipEventCreateWithFlags(&S.evV, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evC, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evZ, hipEventDisableTiming));
-    RLN_HIP(hipEventCreateWithFlags(&S.evCb, hipEventDisableTiming | hipEventBlockingSync));
     for (auto& e : S.t) RLN_HIP(hipEventCreate(&e));
     RLN_HIP(hipMemsetAsync(S.digits.p, 0, S.digits.bytes(), s));
     RLN_HIP(hipMemsetAsync(S.digits2.p, 0, S.digits2.bytes(), s));
@@ -942,7 +952,7 @@ Prover::~Prover() {
     if (S.h_comp) (void)hipHostFree(S.h_comp);
     if (S.h_values) (void)hipHostFree(S.h_values);
     if (S.h_err) (void)hipHostFree(S.h_err);
-    for (hipEvent_t e : {S.evA, S.evB, S.evB2, S.evR, S.evC, S.evW, S.evV, S.evX, S.evZ, S.evCb})
+    for (hipEvent_t e : {S.evA, S.evB, S.evB2, S.evR, S.evC, S.evW, S.evV, S.evX, S.evZ})
       if (e) (void)hipEventDestroy(e);
     for (auto& e : S.t)
       if (e) (void)hipEventDestroy(e);
@@ -1040,7 +1050,10 @@ void Prover::collect(uint64_t ticket, size_t n, uint8_t* proofs, uint8_t* values
   if (!Sp) throw Error("collect: unknown or expired ticket (its workspace slot has been reused)");
   Slot& S = *Sp;
   if (n > S.n) throw Error("collect: more proofs requested than the batch holds");
-  RLN_HIP(hipEventSynchronize(S.n > D.lanechunk_max ? S.evCb : S.evC));
+  // a big batch is tens of milliseconds away: poll and sleep instead of hipEventSynchronize, whose wait spins in the runtime
+  // (a host core per GPU as measured, hipEventBlockingSync or not) -- eight replicas must not need eight cores to wait.
+  // Small batches keep the spinning wait: their latency is the product.
+  if (S.n > D.lanechunk_max) wait_yielding(S.evC); else RLN_HIP(hipEventSynchronize(S.evC));
   if (S.mode == PROVE_PARTIAL) {
     if (partial320) memcpy(partial320, S.h_pp, n * 320);
   } else {
@@ -1508,7 +1521,6 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   RLN_HIP(hipMemcpyAsync(S.h_err, S.err.p, n * 4, hipMemcpyDeviceToHost, sF));
   MARK(10, sF);
   RLN_HIP(hipEventRecord(S.evC, sF));
-  if (n > D.lanechunk_max) RLN_HIP(hipEventRecord(S.evCb, sF));
   S.used = true;
   S.wiped = false;
   S.n = n;
