@@ -677,9 +677,8 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   // A walk = a list of (table row, scalar id, output segment) entries cut into chunks.  `dig_sid` = the id the digits
   // of an entry live under (G2: the ids above the h block move down), `is_h` = the scalar is a coefficient of h.
   struct VRow { uint32_t k, sid, dig_sid, seg; bool is_h; };
-  // split_windows (chunk_pts = 1 only): every entry becomes TWO chunks, the lower and the upper half of its windows
   auto make_plans = [&](const std::vector<VRow>& vrows, uint32_t nseg, uint32_t chunk_pts, Impl::Plan* plans,
-                        uint32_t* max_chunks, uint32_t* max_groups, int only_mode, bool split_windows = false) {
+                        uint32_t* max_chunks, uint32_t* max_groups, int only_mode) {
     for (int mode = 0; mode < 3; mode++) {
       if (only_mode >= 0 && mode != only_mode) continue;
       std::vector<uint32_t> rows, rsid, segfirst, early_ids, late_ids;
@@ -701,11 +700,8 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
               }
             }
             for (uint32_t k = first; k < rows.size(); k += chunk_pts) {
-              const uint32_t end = (uint32_t)std::min<size_t>(k + chunk_pts, rows.size());
-              for (uint32_t half = 0; half < (split_windows ? 2u : 1u); half++) {
-                (late ? late_ids : early_ids).push_back((uint32_t)chunks.size());
-                chunks.push_back({k, split_windows ? (end | CHUNK_SPLIT | (half ? CHUNK_UPPER : 0u)) : end});
-              }
+              (late ? late_ids : early_ids).push_back((uint32_t)chunks.size());
+              chunks.push_back({k, (uint32_t)std::min<size_t>(k + chunk_pts, rows.size())});
             }
           }
         }
@@ -846,8 +842,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     {
       uint32_t unused = 0;
       make_plans(vrows, 1, 2u, D.plan2s, &D.max_chunks2s, &unused, -1);
-      // G2 is the critical chain of a single proof: 4 additions per lane instead of 8, one tree level more
-      make_plans(vrows, 1, 1u, D.plan2t, &D.max_chunks2t, &unused, PROVE_FULL, true);
+      make_plans(vrows, 1, 1u, D.plan2t, &D.max_chunks2t, &unused, PROVE_FULL);
       D.max_blocks2t = D.plan2t[PROVE_FULL].nblocks;
     }
     build_table29<Fq2, G2Affine29>(pts, D.ws2, D.t2_29, s);

@@ -25,9 +25,6 @@ struct WinSched {
 struct ChunkDesc {
   uint32_t pt_begin, pt_end;  // compact point range
 };
-// flags in ChunkDesc::pt_end, honoured by the lanes = chunks form of k_msm29 only (the plans that carry them are never
-// walked any other way): the chunk covers the lower / upper half of the windows instead of all of them
-constexpr uint32_t CHUNK_SPLIT = 1u << 31, CHUNK_UPPER = 1u << 30;
 
 // The same walk for G1 in the 9 x 29-bit form of fq29.h (tables and accumulator): 16.0 G mixed additions/s against
 // 12.6 G in the 8 x 32 form (tools/microbench29.hip).  Partial sums leave in the common XYZZ<Fq> form.

@@ -22,15 +22,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 
     const uint32_t idx = L * 64 + threadIdx.x, p = blockIdx.y;   // one proof per grid row
     if (idx >= nchunks) return;
     const uint32_t chunk = chunk_ids ? chunk_ids[idx] : idx;
-    ChunkDesc cd = chunks[chunk];
-    // window range of the chunk: all W windows, or -- tiny batches' G2 plan, CHUNK_SPLIT in pt_end -- the lower / upper
-    // half of them: a lane's chain is then W / 2 additions and the other half is somebody else's lane
-    uint32_t j0 = 0, j1 = (uint32_t)W;
-    if (cd.pt_end & CHUNK_SPLIT) {
-      const uint32_t wh = ((uint32_t)W + 1) / 2;
-      if (cd.pt_end & CHUNK_UPPER) j0 = wh; else j1 = wh;
-      cd.pt_end &= ~(CHUNK_SPLIT | CHUNK_UPPER);
-    }
+    const ChunkDesc cd = chunks[chunk];
     Acc acc = Acc::inf();
     // A lane here is a lone dependent chain: digit -> table entry -> addition.  With one or two waves per SIMD nothing hides
     // the two HBM round trips of every step (measured: 10 - 28 us per addition against 4.4 us of arithmetic), so the digit
@@ -40,8 +32,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 
       uint32_t i, j;
     };
     auto adv = [&](Cur& c) {
-      if (++c.j == j1) {
-        c.j = j0;
+      if (++c.j == (uint32_t)W) {
+        c.j = 0;
         c.i++;
       }
     };
@@ -55,7 +47,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 
       return table[(size_t)(rows[i] & 0x7FFFFFFFu) * ws.stride + ws.ro[c.j] + e];
     };
     if (cd.pt_end > cd.pt_begin) {
-      Cur c0{cd.pt_begin, j0}, c1 = c0, c2;
+      Cur c0{cd.pt_begin, 0}, c1 = c0, c2;
       adv(c1);
       c2 = c1;
       adv(c2);
