@@ -683,7 +683,8 @@ def test_deep_tree_depth_40_sparse():
 
 def test_reference_tree_tests_and_kat_on_the_sparse_tree():
     """the FFI tree tests of this file and of the V3 file (the reference's rln/tests/ffi.rs tree cases replayed) with the
-    sparse tree forced at every depth (RLNAMD_TREE_SPARSE_ABOVE=0): same roots, paths and errors as the dense HBM tree"""
+    sparse tree forced at every depth (RLNAMD_TREE_SPARSE_ABOVE=0): same roots, paths and errors as the dense HBM tree --
+    including the deferred-update stream with reads at random points (SparseTree::set_many behind the same queue)"""
     import os
     import subprocess
     import sys
@@ -692,7 +693,8 @@ def test_reference_tree_tests_and_kat_on_the_sparse_tree():
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", os.path.join(root, "tests", "test_gpu_ffi.py"),
                         os.path.join(root, "tests", "test_gpu_ffi_v3.py"), "-k",
                         "(merkle_operations or leaf_setting or atomic_operation or bad_index or out_of_bounds or "
-                        "get_leaf_and_metadata or persistent_tree or stateful_tree or c_program_links) and not sparse"],
+                        "get_leaf_and_metadata or persistent_tree or stateful_tree or c_program_links or deferred_tree_updates) "
+                        "and not sparse"],
                        env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout
