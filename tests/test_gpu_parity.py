@@ -579,6 +579,14 @@ def test_small_batch_shape_variants_give_the_golden_bytes(monkeypatch, env):
     ws, rs = [_w(c) for c in cases], [(int(c["r"]), int(c["s"])) for c in cases]
     p = BatchProver(max_batch=64)
     try:
+        # the switches are read once, when the prover is built, and rlnamd_prover_describe reports the values in force
+        names = {"RLNAMD_LONE": "lone", "RLNAMD_NTT_FUSE9": "ntt_fuse9", "RLNAMD_VALUES_WITNESS": "values_from_witness",
+                 "RLNAMD_EARLY_FIN": "early_fin", "RLNAMD_FUSED_SMUL": "fused_smul", "RLNAMD_LANECHUNK_WALK": "lanechunk_walk",
+                 "RLNAMD_TINY": "tiny"}
+        desc = p.describe().split()
+        for k, v in env.items():
+            if k in names:
+                assert "%s=%s" % (names[k], v) in desc, (k, desc)
         one = p.prove(ws[:1], rs[:1])[0]
         assert one["proof"].hex() == cases[0]["proof_compressed"]
         assert [str(v) for v in one["public_inputs"]] == cases[0]["public_inputs"]

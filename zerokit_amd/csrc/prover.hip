@@ -273,9 +273,9 @@ static void build_table29(const std::vector<Affine<F>>& pts, const WinSched& ws,
   DevBuf<Affine<F>> tmp(slab * stride);
   for (size_t k0 = 0; k0 < npts; k0 += slab) {
     size_t cnt = std::min(slab, npts - k0);
-    size_t threads = cnt * ws.W;
-    hipLaunchKernelGGL(k_table_build<F>, dim3(div_up(threads, 64)), dim3(64), 0, s, d_pts.p + k0, (uint32_t)cnt, ws,
-                       tmp.p, scratch.p);
+    const size_t nrows = cnt * ws.W;   // a wave per (point, window) row
+    hipLaunchKernelGGL(k_table_build<F>, dim3((unsigned)nrows), dim3(64), 0, s, d_pts.p + k0, (uint32_t)cnt, ws, tmp.p,
+                       scratch.p);
     hipLaunchKernelGGL((k_table_to29<Affine<F>, Entry>), dim3(div_up(cnt * stride, 256)), dim3(256), 0, s, tmp.p,
                        table.p + k0 * stride, cnt * stride);
     RLN_HIP(hipGetLastError());

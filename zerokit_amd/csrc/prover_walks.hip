@@ -116,45 +116,73 @@ __global__ void __launch_bounds__(64) k_glv_fold(G1XYZZ* __restrict__ sums1, G2X
 }
 
 // one-time comb table: row (k, j) = { d * 2^(c j) * P_k : d = 1..2^(c-1) } in affine form.
-// Built by doubling the known prefix (multiples 1..m -> m+1..2m are "T[i] + T[m]" and one doubling) with
-// one shared inversion per level (Montgomery's trick; prefix products parked in `scratch`).
+// Built by doubling the known prefix (multiples 1..m -> m+1..2m are "T[i] + T[m]" and one doubling) with ONE inversion
+// per level (Montgomery's trick; prefix products parked in `scratch`).  A WAVE per row (round 4; a lane per row left half
+// the SIMDs idle and made every level a serial chain of up to 16 384 products: 4.6 s for the 228 GiB schedule): the m
+// additions of a level are dealt to the lanes round-robin (item i -> lane (i - 1) mod 64: coalesced reads and writes),
+// every lane multiplies up the denominators of its own items, lane 0 inverts the 64 lane totals with the same trick
+// (189 products + 1 inversion), and every lane walks its items backwards with the inverse of its own total.  Which
+// denominators share an inversion does not change a quotient: the table entries are the same field elements.
 template <class F>
 __global__ void __launch_bounds__(64) k_table_build(const Affine<F>* __restrict__ pts, uint32_t npts, WinSched ws,
                                                     Affine<F>* __restrict__ table, F* __restrict__ scratch) {
-  const uint32_t W = (uint32_t)ws.W;
-  size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
-  if (t >= (size_t)npts * W) return;
-  uint32_t k = (uint32_t)(t / W), j = (uint32_t)(t % W);
+  __shared__ F tot[64], itot[64];
+  const uint32_t W = (uint32_t)ws.W, l = threadIdx.x;
+  const size_t r = blockIdx.x;
+  if (r >= (size_t)npts * W) return;   // (uniform)
+  const uint32_t k = (uint32_t)(r / W), j = (uint32_t)(r % W);
   const uint32_t E = 1u << (ws.cw[j] - 1);
-  XYZZ<F> b = XYZZ<F>::from_affine(pts[k]);
-  for (uint32_t i = 0; i < (uint32_t)ws.bo[j]; i++) b = b.dbl();
-  Affine<F> base = b.to_affine();
   const size_t off = (size_t)k * ws.stride + ws.ro[j];  // even: every row has >= 2 entries (cw >= 2)
   Affine<F>* row = table + off;
   F* pre = scratch + off / 2;
-  row[0] = base;
+  if (l == 0) {
+    XYZZ<F> b = XYZZ<F>::from_affine(pts[k]);
+    for (uint32_t i = 0; i < (uint32_t)ws.bo[j]; i++) b = b.dbl();
+    row[0] = b.to_affine();
+  }
+  __threadfence_block();
+  __syncthreads();
   for (uint32_t m = 1; m < E; m <<= 1) {
     const Affine<F> Pm = row[m - 1];
+    // items i = 1 .. m: T[m + i - 1] = T[i - 1] + T[m - 1] (i < m), T[2 m - 1] = 2 T[m - 1] (i = m)
     F run = F::one();
-    for (uint32_t i = 1; i <= m; i++) {
-      F den = (i < m) ? (row[i - 1].x - Pm.x) : Pm.y.dbl();
+    for (uint32_t i = 1 + l; i <= m; i += 64) {
+      const F den = (i < m) ? (row[i - 1].x - Pm.x) : Pm.y.dbl();
       pre[i - 1] = run;
       run = run * den;
     }
-    F inv = run.inv();
-    for (uint32_t i = m; i >= 1; i--) {
+    tot[l] = run;
+    __syncthreads();
+    if (l == 0) {   // 1 / tot[q] for all 64 lanes: one inversion
+      F acc = F::one();
+      for (uint32_t q = 0; q < 64; q++) {
+        itot[q] = acc;          // product of the totals before q
+        acc = acc * tot[q];
+      }
+      F inv = acc.inv();
+      for (uint32_t q = 64; q-- > 0;) {
+        const F t = tot[q];
+        itot[q] = inv * itot[q];
+        inv = inv * t;
+      }
+    }
+    __syncthreads();
+    F inv = itot[l];
+    const uint32_t cnt = m > l ? (m - 1 - l) / 64 + 1 : 0;   // items of this lane: l + 1, l + 65, ...
+    for (uint32_t t = cnt; t-- > 0;) {
+      const uint32_t i = 1 + l + 64 * t;
       F den, lam, x3, y3;
       if (i < m) {
-        Affine<F> Pi = row[i - 1];
+        const Affine<F> Pi = row[i - 1];
         den = Pi.x - Pm.x;
-        F di = inv * pre[i - 1];
+        const F di = inv * pre[i - 1];
         lam = (Pi.y - Pm.y) * di;
         x3 = lam.sqr() - Pi.x - Pm.x;
         y3 = lam * (Pi.x - x3) - Pi.y;
       } else {
         den = Pm.y.dbl();
-        F di = inv * pre[i - 1];
-        F x2 = Pm.x.sqr();
+        const F di = inv * pre[i - 1];
+        const F x2 = Pm.x.sqr();
         lam = (x2.dbl() + x2) * di;
         x3 = lam.sqr() - Pm.x.dbl();
         y3 = lam * (Pm.x - x3) - Pm.y;
@@ -162,6 +190,8 @@ __global__ void __launch_bounds__(64) k_table_build(const Affine<F>* __restrict_
       inv = inv * den;
       row[m + i - 1] = {x3, y3};
     }
+    __threadfence_block();   // the next level reads what this one wrote (other lanes' entries)
+    __syncthreads();
   }
 }
 
