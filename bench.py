@@ -157,10 +157,10 @@ def valu_view(pm, info, B, alone_ms, clock_mhz):
 
 def tree_update_stream(n):
     """the mutation stream oracle_tree_bench applies after its build: TREE_SINGLES single updates (a root read behind
-    each), then TREE_SCATTERED updates and one root read"""
-    from oracle.c import binding as ob
-    return (ob.scattered_updates(n, TREE_SINGLES, seed=0x7EE, tag=0x5157000000000000),
-            ob.scattered_updates(n, TREE_SCATTERED, seed=0x5CA7, tag=0x5CA7000000000000))
+    each), then TREE_SCATTERED updates and one root read (the product's own generator; oracle/c has its own)"""
+    from zerokit_amd import workload
+    return (workload.tree_update_stream(n, TREE_SINGLES, 0x7EE, 0x5157000000000000),
+            workload.tree_update_stream(n, TREE_SCATTERED, 0x5CA7, 0x5CA7000000000000))
 
 
 def measure_config3(steps=3):

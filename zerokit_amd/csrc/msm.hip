@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(64) k_slice_fix(const uint32_t* __restrict__ o
   if (s0 == s1) return;  // written by its slice
   if (s1 - s0 > MSM_BIG_SLICES) {
     const uint32_t k = atomicAdd(big, 1u);
-    if (k < MSM_BIG_CAP) {   // (more than 4 096 such buckets would need > 2^25 entries per window: not with n <= 2^24 x 16 / 16)
+    if (k < MSM_BIG_CAP) {   // (beyond the list's capacity: the serial join below -- correct, only slower)
       big[1 + k] = key;
       return;
     }

@@ -71,3 +71,16 @@ def config2_packed(slots, inputs_size, first, n, seed=0xC0FFEE, depth=20):
     buf[:, off, 0] = ((first + np.arange(n)) % 100).astype(np.uint8)
     rs = np.frombuffer(b"".join(_fr_bytes(d[:, 112:120].reshape(n, 2, 4))), dtype=np.uint8)
     return buf.tobytes(), rs.tobytes()
+
+
+def tree_update_stream(n, count, seed, tag):
+    """[(leaf index, leaf value)] of the tree-mutation workload of bench.py's config 3 (SplitMix64(seed) at position k mod n,
+    value tag + k); oracle/c applies the same stream from its own generator (oracle_tree_bench)"""
+    M = (1 << 64) - 1
+    out = []
+    for k in range(count):
+        z = (seed + (k + 1) * 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        out.append(((z ^ (z >> 31)) % n, tag + k))
+    return out
