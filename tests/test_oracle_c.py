@@ -68,3 +68,39 @@ def test_c_prove_many_threads_equal_single():
     for i in range(4):
         o = c.prove(ws[i], rs[i][0], rs[i][1])
         assert o["proof"] == proofs[i] and o["public_inputs"] == pub[i]
+
+
+def test_side_config_oracles_config3_and_config5():
+    """the oracle legs of configs 3 and 5 against the Python oracle: the config-5 closed form (sum k_i s_i) G and the
+    workload's points in C limbs == Python ints (all distribution variants), Pippenger over the materialised points == the
+    closed form, the C FullMerkleTree == oracle/pyref's (roots, paths), and the product's tree-update stream generator ==
+    the one oracle_tree_bench applies"""
+    import random
+    from oracle.c import binding as ob
+    from oracle.pyref import workload as owl
+    from oracle.pyref.bn254 import G1, G1_GEN
+    from oracle.pyref.rln import FullMerkleTree
+    from zerokit_amd import workload
+    seed = 0xC0FFEE
+    for mode in (0, 1, 2, 3):
+        assert ob.msm_expected(seed, 7, 500, mode, threads=3) == owl.msm_expected(seed, 7, 500, mode)
+        p, s = ob.msm_workload_item(seed, 11, mode)
+        k, s2 = owl.msm_item(seed, 11, mode)
+        assert p == G1.mul(G1_GEN, k) and s == s2
+        assert ob.msm_pippenger(seed, 7, 500, mode, threads=2)[0] == ob.msm_expected(seed, 7, 500, mode)
+    assert ob.msm_expected(seed, 0, 0) is None
+    rnd = random.Random(5)
+    t, o = ob.Tree(8), FullMerkleTree(8)
+    assert t.root() == o.root()
+    for _ in range(12):
+        i, v = rnd.randrange(256), rnd.randrange(1 << 253)
+        t.set(i, v)
+        o.set(i, v)
+    t.set_range(40, [1, 2, 3], threads=2)
+    for k, v in enumerate([1, 2, 3]):
+        o.set(40 + k, v)
+    assert t.root() == o.root()
+    pe, pb = o.proof(41)
+    assert t.proof(41) == (list(pe), list(pb))
+    t.close()
+    assert workload.tree_update_stream(1 << 20, 40, 0x5CA7, 0x5CA7000000000000) == ob.scattered_updates(1 << 20, 40)
