@@ -103,6 +103,11 @@ struct Prover::Impl {
     DevBuf<uint32_t> rsid;                  // scalar id of every entry of `rows`
     DevBuf<uint32_t> early_ids, late_ids;   // chunk indices without / with rows that depend on the quotient h
     uint32_t nchunks = 0, ngroups = 0, nseg = 0, n_early = 0, n_late = 0;
+    // pair chunks (throughput plan of the full proof only; walk29.h PairPlan): rows of the even members, their scalar ids,
+    // the chunk ranges over them and the two output chunk slots of every pair chunk
+    DevBuf<uint32_t> prows, prsid, pout;
+    DevBuf<ChunkDesc> pchunks;
+    uint32_t npchunks = 0;
     // two-stage sum of the tiny plans: segblocks[seg] = the range of 512-chunk blocks of a segment (block b covers
     // chunks [segfirst + 512 b, ...)), maxblk = the most blocks any segment has
     DevBuf<ChunkDesc> segblocks;
@@ -120,7 +125,7 @@ struct Prover::Impl {
   static constexpr uint32_t tiny_stride = 8;   // partial sums of a tiny batch: [chunk][8]
   uint32_t max_chunks1s = 0, max_chunks2s = 0, small_stride = 64;   // partial sums of a small batch: [chunk][64]
   uint32_t max_chunks1 = 0, max_chunks2 = 0, max_groups1 = 0, max_groups2 = 0;
-  uint32_t npts1 = 0, npts2 = 0;
+  uint32_t npts1 = 0, npts2 = 0, npaired1 = 0;   // npaired1: G1 points [0, npaired1) are pair members
   std::vector<uint8_t> known;  // per witness signal: computable from the partial witness (evaluate_partial)
   DevBuf<uint32_t> pp_in;      // resident partial-proof points for finish mode, 320 B per proof
   DevBuf<uint32_t> wgiven;     // externally calculated witnesses for the next run (upload_witness), else empty
@@ -260,15 +265,16 @@ static void make_reduce_ranges(const std::vector<uint32_t>& segfirst, std::vecto
 // G1 table in the 9 x 29 form: slabs are built in the 8 x 32 form (k_table_build reads its own rows back) and
 // converted into place
 template <class F, class Entry>
-static void build_table29(const std::vector<Affine<F>>& pts, const WinSched& ws, DevBuf<Entry>& table, hipStream_t s) {
+static void build_table29(const std::vector<Affine<F>>& pts, const WinSched& ws, DevBuf<Entry>& table, hipStream_t s,
+                          uint32_t npaired = 0) {
   size_t npts = pts.size();
   const size_t stride = ws.stride;
   table.alloc(npts * stride);
   DevBuf<Affine<F>> d_pts(npts);
   d_pts.upload(pts.data(), npts, s);
   size_t per_pt = stride / 2 * sizeof(F);
-  size_t slab = std::max<size_t>(1, ((size_t)4 << 30) / per_pt);
-  slab = std::min(slab, npts);
+  size_t slab = std::max<size_t>(2, (((size_t)4 << 30) / per_pt) & ~(size_t)1);   // even: a pair never straddles two slabs
+  slab = std::min(slab, (npts + 1) & ~(size_t)1);
   DevBuf<F> scratch(slab * stride / 2);
   DevBuf<Affine<F>> tmp(slab * stride);
   for (size_t k0 = 0; k0 < npts; k0 += slab) {
@@ -277,7 +283,7 @@ static void build_table29(const std::vector<Affine<F>>& pts, const WinSched& ws,
     hipLaunchKernelGGL(k_table_build<F>, dim3((unsigned)nrows), dim3(64), 0, s, d_pts.p + k0, (uint32_t)cnt, ws, tmp.p,
                        scratch.p);
     hipLaunchKernelGGL((k_table_to29<Affine<F>, Entry>), dim3(div_up(cnt * stride, 256)), dim3(256), 0, s, tmp.p,
-                       table.p + k0 * stride, cnt * stride);
+                       table.p + k0 * stride, cnt * stride, (uint32_t)stride, (uint32_t)k0, npaired);
     RLN_HIP(hipGetLastError());
   }
   RLN_HIP(hipStreamSynchronize(s));
@@ -677,12 +683,42 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   // A walk = a list of (table row, scalar id, output segment) entries cut into chunks.  `dig_sid` = the id the digits
   // of an entry live under (G2: the ids above the h block move down), `is_h` = the scalar is a coefficient of h.
   struct VRow { uint32_t k, sid, dig_sid, seg; bool is_h; };
+  // npaired: points [0, npaired) are pair members (walk29.h ROW_PAIRED; their row words carry the flag in every plan).
+  // pair_chunks: the throughput plan of the FULL proof walks them as pair chunks (lane pairs, one 128-byte line per two
+  // additions) instead of as single rows; every pair chunk owns a chunk slot in each of its two members' segments.
   auto make_plans = [&](const std::vector<VRow>& vrows, uint32_t nseg, uint32_t chunk_pts, Impl::Plan* plans,
-                        uint32_t* max_chunks, uint32_t* max_groups, int only_mode) {
+                        uint32_t* max_chunks, uint32_t* max_groups, int only_mode, uint32_t npaired = 0,
+                        bool pair_chunks = false) {
+    auto roww = [&](uint32_t k, uint32_t h) { return k | (k < npaired ? ROW_PAIRED : 0u) | (h << 31); };
     for (int mode = 0; mode < 3; mode++) {
       if (only_mode >= 0 && mode != only_mode) continue;
       std::vector<uint32_t> rows, rsid, segfirst, early_ids, late_ids;
       std::vector<ChunkDesc> chunks;
+      const bool pairs_here = pair_chunks && mode == PROVE_FULL && npaired > 0;
+      // pair chunks first: entries grouped by (half, segment of member 0, segment of member 1)
+      struct PairChunk { uint32_t h, sg0, sg1, begin, end; };
+      std::vector<PairChunk> pcs;
+      std::vector<uint32_t> prows, prsid, pout;
+      if (pairs_here) {
+        std::vector<const VRow*> byk(npaired, nullptr);
+        for (const VRow& v : vrows)
+          if (v.k < npaired) byk[v.k] = &v;
+        for (uint32_t h = 0; h < D.nh; h++)
+          for (uint32_t sg0 = 0; sg0 < nseg; sg0++)
+            for (uint32_t sg1 = 0; sg1 < nseg; sg1++) {
+              const uint32_t first = (uint32_t)prows.size();
+              for (uint32_t q = 0; q + 1 < npaired; q += 2) {
+                const VRow *a = byk[q], *b = byk[q + 1];
+                if (!a || !b || a->seg != sg0 || b->seg != sg1) continue;
+                if (a->dig_sid != b->dig_sid || a->is_h || b->is_h) throw Error("internal: pair members must share a witness scalar");
+                prows.push_back(roww(q, h));
+                prsid.push_back(a->dig_sid);
+              }
+              for (uint32_t k = first; k < prows.size(); k += chunk_pts)
+                pcs.push_back({h, sg0, sg1, k, (uint32_t)std::min<size_t>(k + chunk_pts, prows.size())});
+            }
+        pout.assign(2 * pcs.size(), 0);
+      }
       // reduction segment h * nseg + sg: the rows of output sg walked with GLV half h (bit 31 of the row entry)
       for (uint32_t h = 0; h < D.nh; h++)
         for (uint32_t sg = 0; sg < nseg; sg++) {
@@ -693,9 +729,10 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
             uint32_t first = (uint32_t)rows.size();
             for (const VRow& v : vrows) {
               if (v.seg != sg || (int)v.is_h != late) continue;
+              if (pairs_here && v.k < npaired) continue;   // walked by a pair chunk
               bool is_known = v.sid < D.NS && D.known[v.sid];
               if (mode == PROVE_FULL || (mode == PROVE_PARTIAL) == is_known) {
-                rows.push_back(v.k | (h << 31));
+                rows.push_back(roww(v.k, h));
                 rsid.push_back(v.dig_sid);
               }
             }
@@ -704,6 +741,13 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
               chunks.push_back({k, (uint32_t)std::min<size_t>(k + chunk_pts, rows.size())});
             }
           }
+          // chunk slots of this segment that pair chunks fill: empty ranges in `chunks` (the single-chunk path skips them)
+          for (size_t c = 0; c < pcs.size(); c++)
+            for (uint32_t m = 0; m < 2; m++)
+              if (pcs[c].h == h && (m ? pcs[c].sg1 : pcs[c].sg0) == sg) {
+                pout[2 * c + m] = (uint32_t)chunks.size();
+                chunks.push_back({0, 0});
+              }
         }
       segfirst.push_back((uint32_t)chunks.size());
       std::vector<ChunkDesc> groups, segs;
@@ -740,6 +784,19 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
         P.segblocks.alloc(segblocks.size());
         P.segblocks.upload(segblocks.data(), segblocks.size(), s);
       }
+      P.npchunks = (uint32_t)pcs.size();
+      if (P.npchunks) {
+        std::vector<ChunkDesc> pcd;
+        for (const PairChunk& c : pcs) pcd.push_back({c.begin, c.end});
+        P.prows.alloc(prows.size());
+        P.prsid.alloc(prsid.size());
+        P.pout.alloc(pout.size());
+        P.pchunks.alloc(pcd.size());
+        P.prows.upload(prows.data(), prows.size(), s);
+        P.prsid.upload(prsid.data(), prsid.size(), s);
+        P.pout.upload(pout.data(), pout.size(), s);
+        P.pchunks.upload(pcd.data(), pcd.size(), s);
+      }
       P.n_early = (uint32_t)early_ids.size();
       P.n_late = (uint32_t)late_ids.size();
       P.early_ids.alloc(std::max<size_t>(early_ids.size(), 1));
@@ -772,6 +829,37 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     for (uint32_t j = 0; j < zk_.l_query.size(); j++) push(zk_.l_query[j], D.ni + j, 2);
     for (uint32_t k = 0; k < D.n; k++) push(zk_.h_query[k], D.NS + k, 2);
     push(zk_.delta_g1, SID_NRS, 2);
+    // PAIRS: points walked under the same witness scalar (A_i, B1_i, L_i share w_i; a_query[0], alpha, b_g1_query[0],
+    // beta share w_0 = 1) are put side by side, two by two, at the front of the point list; their tables are interleaved
+    // (walk29.h ROW_PAIRED) and the throughput plan walks them with lane pairs.  A third row of a scalar stays single.
+    uint32_t npaired = 0;
+    {
+      std::vector<std::vector<uint32_t>> by_sid(D.NS);
+      for (uint32_t k = 0; k < sids.size(); k++)
+        if (sids[k] < D.NS) by_sid[sids[k]].push_back(k);
+      std::vector<uint32_t> order;
+      std::vector<uint8_t> taken(sids.size(), 0);
+      for (const auto& v : by_sid)
+        for (size_t t = 0; t + 1 < v.size(); t += 2) {
+          order.push_back(v[t]);
+          order.push_back(v[t + 1]);
+          taken[v[t]] = taken[v[t + 1]] = 1;
+        }
+      npaired = (uint32_t)order.size();
+      for (uint32_t k = 0; k < sids.size(); k++)
+        if (!taken[k]) order.push_back(k);
+      std::vector<G1Affine> p2(pts.size());
+      std::vector<uint32_t> s2(sids.size()), g2(sids.size());
+      for (size_t i = 0; i < order.size(); i++) {
+        p2[i] = pts[order[i]];
+        s2[i] = sids[order[i]];
+        g2[i] = row_seg[order[i]];
+      }
+      pts.swap(p2);
+      sids.swap(s2);
+      row_seg.swap(g2);
+    }
+    D.npaired1 = npaired;
     D.npts1 = (uint32_t)pts.size();
     D.sid1.alloc(sids.size());
     D.sid1.upload(sids.data(), sids.size(), s);
@@ -780,10 +868,10 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
       vrows.push_back({k, sids[k], sids[k], row_seg[k], sids[k] >= D.NS && sids[k] < D.NS + D.n});
     // rows (x halves) per single-wave workgroup: ~150 additions each, as before the split (8 rows x 19 windows)
     make_plans(vrows, 3, (uint32_t)(D.nh == 2 ? 16 : 8), D.plan1, &D.max_chunks1,
-               &D.max_groups1, -1);
+               &D.max_groups1, -1, npaired, true);
     {
       uint32_t unused = 0;
-      make_plans(vrows, 3, 4u, D.plan1s, &D.max_chunks1s, &unused, -1);
+      make_plans(vrows, 3, 4u, D.plan1s, &D.max_chunks1s, &unused, -1, npaired);
     }
     {
       // Small full proofs, fused plan: s A + r B1 - r s delta = s alpha + r beta + r s delta + sum (s w_i) A_i + sum (r w_i) B1_i,
@@ -810,11 +898,11 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
       }
       uint32_t unused = 0;
       make_plans(f, 3, 4u, D.plan1f, &D.max_chunks1s, &unused,
-                 PROVE_FULL);
-      make_plans(f, 3, 1u, D.plan1tf, &D.max_chunks1t, &unused, PROVE_FULL);
+                 PROVE_FULL, npaired);
+      make_plans(f, 3, 1u, D.plan1tf, &D.max_chunks1t, &unused, PROVE_FULL, npaired);
       D.max_blocks1t = D.plan1tf[PROVE_FULL].nblocks;
     }
-    build_table29<Fq, G1Affine29>(pts, D.ws, D.t1_29, s);
+    build_table29<Fq, G1Affine29>(pts, D.ws, D.t1_29, s, npaired);
   }
   {
     std::vector<G2Affine> pts;
@@ -1347,9 +1435,14 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>), dim3(div_up(P1.nchunks, 64), nb), dim3(64), 0, D.sB,
                          D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.nchunks, S.digits.p, S.part1.p, D.ws, B, PB, D.nh,
                          nullptr);
-    else
-      hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(blocks), dim3(64), 0, D.sB, D.t1_29.p, P1.rsid.p,
-                         P1.rows.p, P1.chunks.p, P1.nchunks, S.digits.p, S.part1.p, D.ws, B, pg, D.nh, D.walk_clk.p);
+    else {
+      // single chunks first, pair chunks (32 proofs x 2 members per wave: twice the proof groups) behind them
+      const PairPlan pp{P1.prows.p, P1.prsid.p, P1.pchunks.p, P1.pout.p, P1.npchunks};
+      const uint32_t pblocks = div_up(P1.npchunks, 8) * 8 * (2 * pg);
+      hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(blocks + pblocks), dim3(64), 0, D.sB, D.t1_29.p,
+                         P1.rsid.p, P1.rows.p, P1.chunks.p, P1.nchunks, S.digits.p, S.part1.p, D.ws, B, pg, D.nh,
+                         D.walk_clk.p, (const uint32_t*)nullptr, 0u, pp);
+    }
   }
   MARK(7, D.sB);
   MARK(11, s2);

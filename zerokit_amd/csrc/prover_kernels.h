@@ -98,7 +98,8 @@ __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ V, const 
 
 // ---- kernels of prover_walks.hip (k_msm29 itself is declared in walk29.h)
 template <class A, class E>
-__global__ void __launch_bounds__(256) k_table_to29(const A* __restrict__ src, E* __restrict__ dst, size_t n);
+__global__ void __launch_bounds__(256) k_table_to29(const A* __restrict__ src, E* __restrict__ dst, size_t n, uint32_t stride,
+                                                    uint32_t k0, uint32_t npaired);
 template <class F>
 __global__ void __launch_bounds__(64) k_sum_ranges(const XYZZ<F>* __restrict__ src, const ChunkDesc* __restrict__ ranges,
                                                    uint32_t nranges, XYZZ<F>* __restrict__ dst, uint32_t B, uint32_t nb);

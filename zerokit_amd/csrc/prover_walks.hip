@@ -10,11 +10,17 @@ namespace rlnamd {
 // =====================================================================================================
 // 5. table-driven MSM: acc += +-T[point][window][|digit|-1]
 // =====================================================================================================
+// slab of 8 x 32 rows -> the packed 9 x 29 entries in place.  Points below `npaired` (global index k0 + local index) are
+// pair members (walk29.h ROW_PAIRED): entry x of point 2 q + m goes to (2 q) stride + 2 x + m.
 template <class A, class E>
-__global__ void __launch_bounds__(256) k_table_to29(const A* __restrict__ src, E* __restrict__ dst, size_t n) {
+__global__ void __launch_bounds__(256) k_table_to29(const A* __restrict__ src, E* __restrict__ dst, size_t n, uint32_t stride,
+                                                    uint32_t k0, uint32_t npaired) {
   size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n) return;
-  dst[t] = to_table29(src[t]);
+  const uint32_t kl = (uint32_t)(t / stride), x = (uint32_t)(t % stride), k = k0 + kl;
+  size_t o = t;   // dst points at the slab's first point (k0, even)
+  if (k < npaired) o = (size_t)(kl & ~1u) * stride + 2 * (size_t)x + (kl & 1u);
+  dst[o] = to_table29(src[t]);
 }
 
 // dst[r][p] = sum of src[i][p] over ranges[r] -- used twice (chunks -> groups -> segments) so the
@@ -197,8 +203,8 @@ __global__ void __launch_bounds__(64) k_table_build(const Affine<F>* __restrict_
 
 
 // ---- explicit instantiations: every form the host launches
-template __global__ void k_table_to29<G1Affine, G1Affine29>(const G1Affine* __restrict__ src, G1Affine29* __restrict__ dst, size_t n);
-template __global__ void k_table_to29<G2Affine, G2Affine29>(const G2Affine* __restrict__ src, G2Affine29* __restrict__ dst, size_t n);
+template __global__ void k_table_to29<G1Affine, G1Affine29>(const G1Affine* __restrict__ src, G1Affine29* __restrict__ dst, size_t n, uint32_t stride, uint32_t k0, uint32_t npaired);
+template __global__ void k_table_to29<G2Affine, G2Affine29>(const G2Affine* __restrict__ src, G2Affine29* __restrict__ dst, size_t n, uint32_t stride, uint32_t k0, uint32_t npaired);
 template __global__ void k_sum_ranges<Fq>(const XYZZ<Fq>* __restrict__ src, const ChunkDesc* __restrict__ ranges, uint32_t nranges, XYZZ<Fq>* __restrict__ dst, uint32_t B, uint32_t nb);
 template __global__ void k_sum_ranges<Fq2>(const XYZZ<Fq2>* __restrict__ src, const ChunkDesc* __restrict__ ranges, uint32_t nranges, XYZZ<Fq2>* __restrict__ dst, uint32_t B, uint32_t nb);
 template __global__ void k_sum_tree<Fq>(const XYZZ<Fq>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, XYZZ<Fq>* __restrict__ dst, uint32_t B, uint32_t PB, TaskSel sel);
@@ -207,9 +213,9 @@ template __global__ void k_sum_blocks<Fq>(const XYZZ<Fq>* __restrict__ part, con
 template __global__ void k_sum_blocks<Fq2>(const XYZZ<Fq2>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, const ChunkDesc* __restrict__ segblocks, XYZZ<Fq2>* __restrict__ dst, uint32_t PB, TaskSel sel);
 template __global__ void k_table_build<Fq>(const Affine<Fq>* __restrict__ pts, uint32_t npts, WinSched ws, Affine<Fq>* __restrict__ table, Fq* __restrict__ scratch);
 template __global__ void k_table_build<Fq2>(const Affine<Fq2>* __restrict__ pts, uint32_t npts, WinSched ws, Affine<Fq2>* __restrict__ table, Fq2* __restrict__ scratch);
-template __global__ void k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4, false>(const G1Affine29* __restrict__ table, const uint32_t* __restrict__ sid, const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks, uint32_t nchunks, const int16_t* __restrict__ digits, G1XYZZ* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups, uint32_t nh, unsigned long long* __restrict__ clk, const uint32_t* __restrict__ chunk_ids, uint32_t pstride);
-template __global__ void k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>(const G1Affine29* __restrict__ table, const uint32_t* __restrict__ sid, const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks, uint32_t nchunks, const int16_t* __restrict__ digits, G1XYZZ* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups, uint32_t nh, unsigned long long* __restrict__ clk, const uint32_t* __restrict__ chunk_ids, uint32_t pstride);
-template __global__ void k_msm29<G2Acc29, G2Affine29, G2XYZZ, 2, false>(const G2Affine29* __restrict__ table, const uint32_t* __restrict__ sid, const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks, uint32_t nchunks, const int16_t* __restrict__ digits, G2XYZZ* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups, uint32_t nh, unsigned long long* __restrict__ clk, const uint32_t* __restrict__ chunk_ids, uint32_t pstride);
-template __global__ void k_msm29<G2Acc29, G2Affine29, G2XYZZ, 1, true>(const G2Affine29* __restrict__ table, const uint32_t* __restrict__ sid, const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks, uint32_t nchunks, const int16_t* __restrict__ digits, G2XYZZ* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups, uint32_t nh, unsigned long long* __restrict__ clk, const uint32_t* __restrict__ chunk_ids, uint32_t pstride);
+template __global__ void k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4, false>(const G1Affine29* __restrict__ table, const uint32_t* __restrict__ sid, const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks, uint32_t nchunks, const int16_t* __restrict__ digits, G1XYZZ* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups, uint32_t nh, unsigned long long* __restrict__ clk, const uint32_t* __restrict__ chunk_ids, uint32_t pstride, PairPlan pairs);
+template __global__ void k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>(const G1Affine29* __restrict__ table, const uint32_t* __restrict__ sid, const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks, uint32_t nchunks, const int16_t* __restrict__ digits, G1XYZZ* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups, uint32_t nh, unsigned long long* __restrict__ clk, const uint32_t* __restrict__ chunk_ids, uint32_t pstride, PairPlan pairs);
+template __global__ void k_msm29<G2Acc29, G2Affine29, G2XYZZ, 2, false>(const G2Affine29* __restrict__ table, const uint32_t* __restrict__ sid, const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks, uint32_t nchunks, const int16_t* __restrict__ digits, G2XYZZ* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups, uint32_t nh, unsigned long long* __restrict__ clk, const uint32_t* __restrict__ chunk_ids, uint32_t pstride, PairPlan pairs);
+template __global__ void k_msm29<G2Acc29, G2Affine29, G2XYZZ, 1, true>(const G2Affine29* __restrict__ table, const uint32_t* __restrict__ sid, const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks, uint32_t nchunks, const int16_t* __restrict__ digits, G2XYZZ* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups, uint32_t nh, unsigned long long* __restrict__ clk, const uint32_t* __restrict__ chunk_ids, uint32_t pstride, PairPlan pairs);
 
 }  // namespace rlnamd

@@ -26,6 +26,33 @@ struct ChunkDesc {
   uint32_t pt_begin, pt_end;  // compact point range
 };
 
+// A row word (the `rows` lists of the walk plans) = table point index | flags.
+//   ROW_HALF2   bit 31: the second GLV half of the scalar (k2; the sum goes through phi afterwards)
+//   ROW_PAIRED  bit 30: the point is a member of a PAIR (two points whose rows are walked under the SAME scalar: A_i and
+//               B1_i, or one of them and L_i).  The two members sit at consecutive point indices 2 q, 2 q + 1 and their
+//               tables are interleaved entry by entry: entry x of member m at ((2 q) stride + 2 x + m) -- the two entries a
+//               digit selects share one 128-byte line.  Any walk may read a paired point by itself (a strided row); the
+//               pair chunks of the throughput plan read both with a lane pair and halve the HBM requests of those rows.
+constexpr uint32_t ROW_HALF2 = 1u << 31, ROW_PAIRED = 1u << 30, ROW_INDEX = ROW_PAIRED - 1;
+// first entry of point k's table and the entry stride inside it (in entries)
+template <class Entry>
+__device__ __forceinline__ const Entry* row_base(const Entry* __restrict__ table, uint32_t roww, uint32_t stride, uint32_t* shift) {
+  const uint32_t k = roww & ROW_INDEX, il = (roww >> 30) & 1u;
+  *shift = il;
+  return table + (size_t)(il ? (k & ~1u) : k) * stride + (il ? (k & 1u) : 0u);
+}
+
+// Pair chunks of the throughput plan (null / 0: none).  A pair chunk is a range of `rows` entries, each the row word of the
+// EVEN member of a pair (+ ROW_HALF2); a wave walks it for 32 proofs with lane pairs: lane 2 t works for member 0, lane
+// 2 t + 1 for member 1 of the same proof and the same digit.  out[2 c + m] = the chunk slot of member m's partial sum.
+struct PairPlan {
+  const uint32_t* rows;
+  const uint32_t* sid;
+  const ChunkDesc* chunks;
+  const uint32_t* out;
+  uint32_t nchunks;
+};
+
 // The same walk for G1 in the 9 x 29-bit form of fq29.h (tables and accumulator): 16.0 G mixed additions/s against
 // 12.6 G in the 8 x 32 form (tools/microbench29.hip).  Partial sums leave in the common XYZZ<Fq> form.
 //
@@ -47,6 +74,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 
                                               uint32_t nchunks, const int16_t* __restrict__ digits,
                                               Out* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups,
                                               uint32_t nh, unsigned long long* __restrict__ clk,
-                                              const uint32_t* __restrict__ chunk_ids = nullptr, uint32_t pstride = 0);
+                                              const uint32_t* __restrict__ chunk_ids = nullptr, uint32_t pstride = 0,
+                                              PairPlan pairs = PairPlan{nullptr, nullptr, nullptr, nullptr, 0});
 
 }  // namespace rlnamd
