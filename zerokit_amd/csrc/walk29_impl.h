@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 
   }
   // Single chunks (a wave = one chunk x 64 proofs) come first in the grid, pair chunks (a wave = one pair chunk x 32
   // proofs x 2 members) behind them; both run the ONE loop below -- a second copy of the addition's 2 000 instructions
-  // was measured to cost the walk 3 % (instruction cache), more than pairing gains.
+  // was measured to cost the walk 3 %, more than pairing gains (profiles/r4_rocprof_summary.md section 3).
   const uint32_t nsb = ((nchunks + 7) / 8) * 8 * pgroups;
   const bool pm = L >= nsb;                      // uniform
   if (pm) L -= nsb;
