@@ -61,10 +61,15 @@ SHARD = 8192                                                # config 4: proofs p
 
 def walk_source_hash():
     """identifies the code the table walks are compiled from; the PMC passes under profiles/ record it, and the VALU
-    view is only emitted when it matches (an instruction count belongs to one build)"""
+    view is only emitted when it matches (an instruction count belongs to one build).  Comments and white space do not
+    count: they do not reach the compiler."""
+    import re
     h = hashlib.sha256()
     for f in ("walk29.h", "walk29_impl.h", "fq29.h", "fq29_constants.h", "curve.h", "glv.h"):
-        h.update(open(os.path.join(ROOT, "zerokit_amd", "csrc", f), "rb").read())
+        src = open(os.path.join(ROOT, "zerokit_amd", "csrc", f), "r").read()
+        src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+        src = re.sub(r"//[^\n]*", " ", src)
+        h.update(" ".join(src.split()).encode())
     return h.hexdigest()[:16]
 
 
