@@ -104,6 +104,29 @@ def test_streamed_partial_and_finish_match_full(prover):
     assert [o["public_inputs"] for o in fin] == [o["public_inputs"] for o in full]
 
 
+def test_big_batch_partial_and_finish_match_full_and_oracle(prover):
+    """the THROUGHPUT shapes of the three modes (200 proofs: lanes = proofs walks, pair chunks in every mode's plan):
+    partial + finish == full, and the full proofs equal oracle/c on a sample"""
+    from zerokit_amd import workload
+    n = 200
+    ws, rs = workload.config2_range(9000, n)
+    inp, rsb = workload.config2_packed(prover.slots, prover.inputs_size, 9000, n)
+    zero = dict(message_id=0, x=0, external_nullifier=0)
+    pinp = prover.pack_inputs([dict(w, **zero) for w in ws])
+    t, _ = prover.submit(pinp, prover.pack_rs([(0, 0)] * n), mode=1)
+    partials = prover.collect_partial(t, n)
+    t2, _ = prover.submit(inp, rsb, mode=2, partials=partials)
+    t3, _ = prover.submit(inp, rsb)
+    fin, full = prover.collect(t2, n), prover.collect(t3, n)
+    assert all(o["error"] == 0 for o in fin + full)
+    assert [o["proof"] for o in fin] == [o["proof"] for o in full]
+    assert [o["public_inputs"] for o in fin] == [o["public_inputs"] for o in full]
+    idx = [0, 63, 64, 127, 128, 199]
+    ref_proofs, ref_pub = _oracle([ws[i] for i in idx], [rs[i] for i in idx])
+    assert [full[i]["proof"] for i in idx] == ref_proofs
+    assert [full[i]["public_inputs"] for i in idx] == ref_pub
+
+
 # ---------------------------------------------------------------------------------------------------- pool
 def test_secrets_are_wiped_behind_collect_and_on_request(prover):
     """the reference zeroises the identity secret and the witness calculator's inputs (rln/src/utils.rs:440-527,

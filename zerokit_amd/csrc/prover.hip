@@ -684,8 +684,8 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   // of an entry live under (G2: the ids above the h block move down), `is_h` = the scalar is a coefficient of h.
   struct VRow { uint32_t k, sid, dig_sid, seg; bool is_h; };
   // npaired: points [0, npaired) are pair members (walk29.h ROW_PAIRED; their row words carry the flag in every plan).
-  // pair_chunks: the throughput plan of the FULL proof walks them as pair chunks (lane pairs, one 128-byte line per two
-  // additions) instead of as single rows; every pair chunk owns a chunk slot in each of its two members' segments.
+  // pair_chunks: the throughput plans (lanes = proofs, every mode) walk them as pair chunks (lane pairs, one 128-byte
+  // line per two additions) instead of as single rows; every pair chunk owns a chunk slot in each of its two members' segments.
   auto make_plans = [&](const std::vector<VRow>& vrows, uint32_t nseg, uint32_t chunk_pts, Impl::Plan* plans,
                         uint32_t* max_chunks, uint32_t* max_groups, int only_mode, uint32_t npaired = 0,
                         bool pair_chunks = false) {
@@ -694,7 +694,12 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
       if (only_mode >= 0 && mode != only_mode) continue;
       std::vector<uint32_t> rows, rsid, segfirst, early_ids, late_ids;
       std::vector<ChunkDesc> chunks;
-      const bool pairs_here = pair_chunks && mode == PROVE_FULL && npaired > 0;
+      const bool pairs_here = pair_chunks && npaired > 0;
+      // rows a mode walks: everything (full), the signals the partial witness fixes (partial), the others (finish)
+      auto walked = [&](const VRow& v) {
+        const bool is_known = v.sid < D.NS && D.known[v.sid];
+        return mode == PROVE_FULL || (mode == PROVE_PARTIAL) == is_known;
+      };
       // pair chunks first: entries grouped by (half, segment of member 0, segment of member 1)
       struct PairChunk { uint32_t h, sg0, sg1, begin, end; };
       std::vector<PairChunk> pcs;
@@ -711,6 +716,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
                 const VRow *a = byk[q], *b = byk[q + 1];
                 if (!a || !b || a->seg != sg0 || b->seg != sg1) continue;
                 if (a->dig_sid != b->dig_sid || a->is_h || b->is_h) throw Error("internal: pair members must share a witness scalar");
+                if (!walked(*a)) continue;   // (the members share the scalar, so the mode takes both or neither)
                 prows.push_back(roww(q, h));
                 prsid.push_back(a->dig_sid);
               }
@@ -730,8 +736,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
             for (const VRow& v : vrows) {
               if (v.seg != sg || (int)v.is_h != late) continue;
               if (pairs_here && v.k < npaired) continue;   // walked by a pair chunk
-              bool is_known = v.sid < D.NS && D.known[v.sid];
-              if (mode == PROVE_FULL || (mode == PROVE_PARTIAL) == is_known) {
+              if (walked(v)) {
                 rows.push_back(roww(v.k, h));
                 rsid.push_back(v.dig_sid);
               }
