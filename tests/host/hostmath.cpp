@@ -50,15 +50,15 @@ int hm_final_exp_check(uint32_t seed) {
   return ok;
 }
 
-// op: 0 add 1 sub 2 mul 3 inv 4 neg 5 sqr ; field: 0 Fr 1 Fq
+// op: 0 add 1 sub 2 mul 3 inv 4 neg 5 sqr 6 inv by the bit-by-bit binary Euclid ; field: 0 Fr 1 Fq
 void hm_fp_op(int field, int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
   if (field == 0) {
     Fr x = ld<Fr>(a), y = ld<Fr>(b), r;
-    r = op == 0 ? x + y : op == 1 ? x - y : op == 2 ? x * y : op == 3 ? x.inv() : op == 4 ? x.neg() : x.sqr();
+    r = op == 0 ? x + y : op == 1 ? x - y : op == 2 ? x * y : op == 3 ? x.inv() : op == 4 ? x.neg() : op == 6 ? x.inv_binary() : x.sqr();
     st(out, r);
   } else {
     Fq x = ld<Fq>(a), y = ld<Fq>(b), r;
-    r = op == 0 ? x + y : op == 1 ? x - y : op == 2 ? x * y : op == 3 ? x.inv() : op == 4 ? x.neg() : x.sqr();
+    r = op == 0 ? x + y : op == 1 ? x - y : op == 2 ? x * y : op == 3 ? x.inv() : op == 4 ? x.neg() : op == 6 ? x.inv_binary() : x.sqr();
     st(out, r);
   }
 }

@@ -17,7 +17,7 @@ def L():
     so = os.path.join(ROOT, "tests", "host", "libhostmath.so")
     src = os.path.join(ROOT, "tests", "host", "hostmath.cpp")
     hdrs = [os.path.join(ROOT, "zerokit_amd", "csrc", h) for h in ("field.h", "curve.h", "pairing.h", "glv.h",
-                                                                     "glv_constants.h")]
+                                                                     "glv_constants.h", "modinv30.h")]
     if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I",
                                os.path.join(ROOT, "zerokit_amd", "csrc"), src, "-o", so])
@@ -63,6 +63,30 @@ def test_prime_fields(L):
                     continue
                 L.hm_fp_op(field, op, b(x), b(y), out)
                 assert i(out.raw) == w, (field, op, x, y)
+
+
+def test_inversion_by_division_steps(L):
+    """Fp::inv (modinv30.h: batched division steps) against Python's pow and against the bit-by-bit binary Euclid it
+    replaced, both fields: structured values (powers of two, their neighbours, p - small, values whose Montgomery image
+    is small) and 3 000 random ones"""
+    rnd = random.Random(30)
+    for field, mod in ((0, R), (1, Q)):
+        rinv = pow(1 << 256, -1, mod)
+        xs = [1, 2, 3, mod - 1, mod - 2, (mod + 1) // 2, (mod - 1) // 2]
+        xs += [(1 << k) % mod for k in range(1, 256, 7)] + [((1 << k) - 1) % mod for k in range(2, 256, 11)]
+        xs += [(mod - (1 << k)) % mod for k in range(0, 254, 13)]
+        xs += [(k * rinv) % mod for k in (1, 2, 3, (1 << 30) - 1, 1 << 30, (1 << 60) + 1, mod - 1)]   # stored integer = k
+        xs += [rnd.randrange(1, mod) for _ in range(3000)]
+        out, out2 = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+        for x in xs:
+            L.hm_fp_op(field, 3, b(x), b(0), out)
+            assert i(out.raw) == pow(x, -1, mod), (field, x)
+        for x in xs[:400]:
+            L.hm_fp_op(field, 3, b(x), b(0), out)
+            L.hm_fp_op(field, 6, b(x), b(0), out2)
+            assert out.raw == out2.raw, (field, x)
+        L.hm_fp_op(field, 3, b(0), b(0), out)
+        assert i(out.raw) == 0
 
 
 def test_fq2(L):

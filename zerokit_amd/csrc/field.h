@@ -21,6 +21,8 @@
 #define RLN_HD inline
 #endif
 
+#include "modinv30.h"
+
 namespace rlnamd {
 
 #if defined(RLN_COUNT_HOST_MUL)
@@ -342,13 +344,32 @@ struct Fp {
     }
     return r;
   }
-  // Inverse; 0 -> 0.  Binary extended Euclid on the stored integer x = a R (about 2 x 254 shift / subtract steps on four
-  // 64-bit words instead of the 380 field products of a^(p-2): the verifier's affine line steps, to_affine and the Fq12
-  // inverse all end here), then x^-1 = a^-1 R^-1 is carried back to a^-1 R by two products with R^2.  Since round 3 the
-  // device takes the same route: an inversion is a lone dependent chain wherever it occurs (the three to_affine of a
-  // proof's back end, one per table-build level), ~20 k instructions instead of ~140 k -- 0.29 -> see profiles/r3 for one
-  // proof; lanes of a batch diverge inside the loop and still finish sooner.  -DRLN_DEVICE_FERMAT restores a^(p-2).
+  // Inverse; 0 -> 0.  Extended Euclid on the stored integer x = a R instead of the 380 field products of a^(p-2) (the
+  // verifier's affine line steps, to_affine and the Fq12 inverse all end here; on the device an inversion is a lone
+  // dependent chain wherever it occurs: the to_affine of a proof's back end, one per table-build level), then
+  // x^-1 = a^-1 R^-1 is carried back to a^-1 R by two products with R^2.
+  //   inv()         batched division steps, 30 per batch, branch-free inside a batch (modinv30.h): ~13 k instructions
+  //   inv_binary()  the bit-by-bit binary form it replaced in round 4 (~760 halvings with a branch each; kept as the
+  //                 cross-check of tests/host/hostmath.cpp).  -DRLN_DEVICE_FERMAT restores a^(p-2) on the device.
   RLN_HD Fp inv() const {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RLN_DEVICE_FERMAT)
+    uint32_t e[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) e[i] = P::PM2[i];
+    return pow(e);
+#else
+    if (is_zero()) return zero();
+    uint32_t m[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) m[i] = P::MOD[i];
+    Fp y, r2;
+    modinv30(v, m, P::INV32, y.v);
+#pragma unroll
+    for (int i = 0; i < 8; i++) r2.v[i] = P::R2[i];
+    return y * r2 * r2;
+#endif
+  }
+  RLN_HD Fp inv_binary() const {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(RLN_DEVICE_FERMAT)
     uint32_t e[8];
 #pragma unroll

@@ -228,7 +228,7 @@ ProverTuning ProverTuning::from_env() {
   t.early_fin = env_int("RLNAMD_EARLY_FIN", 1) != 0;
   t.fused_smul = env_int("RLNAMD_FUSED_SMUL", 1) != 0;
   t.values_from_witness = env_int("RLNAMD_VALUES_WITNESS", 1) != 0;
-  t.ntt_fuse9 = env_int("RLNAMD_NTT_FUSE9", 1) != 0;
+  t.ntt_lds = env_int("RLNAMD_NTT_LDS", 1) != 0;
   t.tiny_max = (uint32_t)std::max(0, env_int("RLNAMD_TINY", (int)t.tiny_max));
   t.marks_small = env_int("RLNAMD_MARKS_SMALL", 0) != 0;
   return t;
@@ -237,9 +237,9 @@ std::string ProverTuning::describe() const {
   char b[512];
   snprintf(b, sizeof b,
            "window_bits=%d slots=%d lanechunk=%u lanechunk_walk=%u witlanes_max=%u tiny=%u glv=%d wit29=%d lone=%d early_walk=%d "
-           "early_fin=%d fused_smul=%d values_from_witness=%d ntt_fuse9=%d marks_small=%d",
+           "early_fin=%d fused_smul=%d values_from_witness=%d ntt_lds=%d marks_small=%d",
            window_bits, slots, lanechunk_max, lanechunk_walk_max, witlanes_max, tiny_max, (int)glv, (int)wit29, lone, (int)early_walk,
-           (int)early_fin, (int)fused_smul, (int)values_from_witness, (int)ntt_fuse9, (int)marks_small);
+           (int)early_fin, (int)fused_smul, (int)values_from_witness, (int)ntt_lds, (int)marks_small);
   return b;
 }
 const ProverTuning& Prover::tuning() const { return d_->tune; }
@@ -1080,14 +1080,8 @@ void Prover::upload_witness(size_t n, const uint8_t* w_le) {
 
 template <bool DIF>
 static void launch_ntt(Fr* data, const Fr* tw, int logn, const Fr* final_scale, uint32_t B, uint32_t nb, hipStream_t s,
-                       bool lanes_are_groups, bool fuse9) {
+                       bool lanes_are_groups) {
   int s0 = 0;
-  if (lanes_are_groups && fuse9 && logn >= 9) {   // nine levels in one kernel (k_ntt_fused9)
-    const Fr* sc = (9 == logn) ? final_scale : nullptr;
-    hipLaunchKernelGGL((k_ntt_fused9<DIF>), dim3(nb, (1u << logn) >> 9, 3), dim3(64), 0, s, data, tw, logn, 0, sc, B, nb);
-    RLN_HIP(hipGetLastError());
-    s0 = 9;
-  }
   while (lanes_are_groups && s0 < logn) {   // small batch: blockIdx.x = proof, lanes = groups (radix-8 passes + a radix-2 tail)
     const int rem = logn - s0, K = rem >= 3 ? 3 : 1;
     const uint32_t groups = (1u << logn) >> K;
@@ -1262,6 +1256,10 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // pays its scattered gathers in throughput much earlier (streams of 64 / 128-proof batches: 9.5 -> 10.8 k, 10.7 -> 11.9 k
   // proofs/s), so there it stops at 16 proofs.
   const bool walk_lp = small && early && (n > D.lanechunk_walk_max || (!lone && n >= 16));
+  // proof stride of the digit arrays: compact where the walks run with lanes = chunks (k_recode); the batch capacity
+  // otherwise (the lanes = proofs walks have padding lanes that read beside the batch: those must stay digits of the
+  // same window)
+  const uint32_t dB = (early && !walk_lp) ? (uint32_t)n : (uint32_t)B_;
   Slot& S = D.slot[D.cur];
   const bool streamed = h_inputs != nullptr;
   if (streamed) {
@@ -1284,7 +1282,13 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   const uint32_t sq = D.seq++;
   hipStream_t sA = (sq & 1) ? D.sAb : D.sA;   // two graph interpreters in flight: 16 latency-bound waves each
   const uint32_t B = (uint32_t)B_, nb = (uint32_t)n;
-  hipStream_t sA2 = !early ? D.sA2 : sA;
+  // Lone small batches: the G2 chain (recode, walk, sums, inversion, B's bytes -- the longest thing behind the interpreter)
+  // stays on the interpreter's own stream, so nothing but kernel boundaries separates its links; the quotient chain
+  // (mat-vec, NTTs, h rows, C sums, A's and C's bytes), which has ~0.2 ms of slack since the NTTs run in LDS, takes the
+  // cross-stream hop (50 - 100 us each) instead.  In a stream of batches the front-end stream must be free for the
+  // batch after next: there the walks keep their own streams.
+  const bool g2_on_front = lone && early;
+  hipStream_t sA2 = !early ? D.sA2 : g2_on_front ? D.sB2 : sA;
   const uint32_t pg = div_up(nb, 64);
   const uint32_t nbp = pg * 64;  // padded lanes compute on stale / zero inputs; results ignored
   // ---------------- stage A
@@ -1350,17 +1354,16 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     // every cross-stream hop costs it 50 - 100 us, so it runs on ONE stream (sB2); the G1 walk's stream takes the hop.
     // (A lone batch; in a stream of batches the recodes stay on the front-end stream, where they do not queue behind the
     // previous batch's walks.)
-    hipStream_t sR1 = lone ? D.sB2 : sA, sR3 = lone ? D.sB : sA;
-    if (lone) RLN_HIP(hipStreamWaitEvent(D.sB2, S.evX, 0));
+    hipStream_t sR1 = sA, sR3 = lone ? D.sB : sA;
     hipLaunchKernelGGL(k_recode, dim3(div_up(D.NS + 3, 64), nb), dim3(64, 1), 0, sR1, S.V.p, D.sig2node.p, D.NS,
-                       S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nb, 1u, 1u);
+                       S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nb, 1u, 1u, dB);
     if (lone) {
-      RLN_HIP(hipEventRecord(S.evW, D.sB2));
+      RLN_HIP(hipEventRecord(S.evW, sA));
       RLN_HIP(hipStreamWaitEvent(D.sB, S.evW, 0));
     }
     if (fused)
       hipLaunchKernelGGL(k_recode, dim3(div_up(2 * D.NS + 1, 64), nb), dim3(64, 1), 0, sR3, S.V.p, D.sig2node.p, D.NS,
-                         S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nb, 3u, 1u);
+                         S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nb, 3u, 1u, dB);
     if (!lone) {
       RLN_HIP(hipEventRecord(S.evW, sA));
       RLN_HIP(hipStreamWaitEvent(D.sB, S.evW, 0));
@@ -1369,11 +1372,11 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     MARK(14, D.sB);
     if (P1.n_early && walk_lp)
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(div_up(P1.n_early, 8) * 8 * pg), dim3(64), 0,
-                         D.sB, D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.n_early, S.digits.p, S.part1.p, D.ws, B, pg,
+                         D.sB, D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.n_early, S.digits.p, S.part1.p, D.ws, dB, pg,
                          D.nh, nullptr, P1.early_ids.p, PB);
     else if (P1.n_early)
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>), dim3(div_up(P1.n_early, 64), nb), dim3(64), 0,
-                         D.sB, D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.n_early, S.digits.p, S.part1.p, D.ws, B, PB,
+                         D.sB, D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.n_early, S.digits.p, S.part1.p, D.ws, dB, PB,
                          D.nh, nullptr, P1.early_ids.p);
     RLN_HIP(hipEventRecord(S.evE, D.sB));
   }
@@ -1392,8 +1395,17 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   MARK(3, sA2);
   if (mode != PROVE_PARTIAL) {
     const bool lg = nb <= D.lanechunk_max;   // below a wave of proofs: lanes = groups
-    launch_ntt<true>(S.abc.p, D.tw_i.p, D.logn, D.coset.p, B, lg ? nb : nbp, sA2, lg, T.ntt_fuse9);   // iNTT (DIF) + g^i / n
-    launch_ntt<false>(S.abc.p, D.tw_f.p, D.logn, nullptr, B, lg ? nb : nbp, sA2, lg, T.ntt_fuse9);    // NTT (DIT)
+    if (lg && T.ntt_lds && D.logn >= 9 && D.logn <= 18) {
+      // iNTT, coset scaling and NTT as edge / mid / edge: one butterfly per lane per level (prover_front.hip: k_ntt_mid)
+      const dim3 grid(nb, D.n >> 9, 3);
+      if (D.logn > 9) hipLaunchKernelGGL(k_ntt_edge<true>, grid, dim3(256), 0, sA2, S.abc.p, D.tw_i.p, D.logn, B, nb);
+      hipLaunchKernelGGL(k_ntt_mid, grid, dim3(256), 0, sA2, S.abc.p, D.tw_i.p, D.tw_f.p, D.logn, D.coset.p, B, nb);
+      if (D.logn > 9) hipLaunchKernelGGL(k_ntt_edge<false>, grid, dim3(256), 0, sA2, S.abc.p, D.tw_f.p, D.logn, B, nb);
+      RLN_HIP(hipGetLastError());
+    } else {
+      launch_ntt<true>(S.abc.p, D.tw_i.p, D.logn, D.coset.p, B, lg ? nb : nbp, sA2, lg);   // iNTT (DIF) + g^i / n
+      launch_ntt<false>(S.abc.p, D.tw_f.p, D.logn, nullptr, B, lg ? nb : nbp, sA2, lg);    // NTT (DIT)
+    }
     if (nb <= D.lanechunk_max)
       hipLaunchKernelGGL(k_hquot, dim3(div_up(D.n, 64), nb), dim3(64, 1), 0, sA2, S.abc.p, D.n, B, nb, 1u);
     else
@@ -1405,10 +1417,10 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   MARK(5, sR);
   if (early_g2)
     hipLaunchKernelGGL(k_recode, dim3(div_up(D.n, 64), nb), dim3(64, 1), 0, sR, S.V.p, D.sig2node.p, D.NS, S.abc.p, D.n,
-                       rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nb, 2u, 1u);
+                       rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nb, 2u, 1u, dB);
   else
     hipLaunchKernelGGL(k_recode, dim3(pg, D.NS + D.n + 3), dim3(64, 1), 0, sR, S.V.p, D.sig2node.p, D.NS,
-                       S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nbp, 0u, 0u);
+                       S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nbp, 0u, 0u, dB);
   MARK(6, sR);
   // ---------------- stage B
   if (!early) {
@@ -1418,7 +1430,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   if (!early) MARK(14, D.sB);
   // small batches walk with lanes = chunks (walk29.h); ProverTuning::lanechunk_max is the threshold
   const bool lanechunk = nb <= D.lanechunk_max;
-  hipStream_t s2 = D.sB2;   // the G2 walk on its own stream: its workgroups fill the G1 kernel's tail
+  hipStream_t s2 = g2_on_front ? sA : D.sB2;   // the G2 walk on its own stream: its workgroups fill the G1 kernel's tail
   if (!early) {   // (early: sB2 already waits for the witness + part-1 digits, all the G2 walk reads)
     RLN_HIP(hipEventRecord(S.evR, D.sB));
     RLN_HIP(hipStreamWaitEvent(D.sB2, S.evR, 0));
@@ -1426,26 +1438,26 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   if (early) {   // the h rows, on the front-end stream itself (no event hop); everything else is already walking
     if (P1.n_late && walk_lp)
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(div_up(P1.n_late, 8) * 8 * pg), dim3(64), 0,
-                         sA, D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.n_late, S.digits.p, S.part1.p, D.ws, B, pg,
+                         sA2, D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.n_late, S.digits.p, S.part1.p, D.ws, dB, pg,
                          D.nh, nullptr, P1.late_ids.p, PB);
     else if (P1.n_late)
-      hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>), dim3(div_up(P1.n_late, 64), nb), dim3(64), 0, sA,
-                         D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.n_late, S.digits.p, S.part1.p, D.ws, B, PB, D.nh,
+      hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>), dim3(div_up(P1.n_late, 64), nb), dim3(64), 0, sA2,
+                         D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.n_late, S.digits.p, S.part1.p, D.ws, dB, PB, D.nh,
                          nullptr, P1.late_ids.p);
-    RLN_HIP(hipEventRecord(S.evR, sA));
+    RLN_HIP(hipEventRecord(S.evR, sA2));
     RLN_HIP(hipStreamWaitEvent(D.sB, S.evR, 0));   // evB below then covers both launches
   } else if (P1.nchunks) {
     uint32_t blocks = div_up(P1.nchunks, 8) * 8 * pg;
     if (lanechunk)
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>), dim3(div_up(P1.nchunks, 64), nb), dim3(64), 0, D.sB,
-                         D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.nchunks, S.digits.p, S.part1.p, D.ws, B, PB, D.nh,
+                         D.t1_29.p, P1.rsid.p, P1.rows.p, P1.chunks.p, P1.nchunks, S.digits.p, S.part1.p, D.ws, dB, PB, D.nh,
                          nullptr);
     else {
       // single chunks first, pair chunks (32 proofs x 2 members per wave: twice the proof groups) behind them
       const PairPlan pp{P1.prows.p, P1.prsid.p, P1.pchunks.p, P1.pout.p, P1.npchunks};
       const uint32_t pblocks = div_up(P1.npchunks, 8) * 8 * (2 * pg);
       hipLaunchKernelGGL((k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4>), dim3(blocks + pblocks), dim3(64), 0, D.sB, D.t1_29.p,
-                         P1.rsid.p, P1.rows.p, P1.chunks.p, P1.nchunks, S.digits.p, S.part1.p, D.ws, B, pg, D.nh,
+                         P1.rsid.p, P1.rows.p, P1.chunks.p, P1.nchunks, S.digits.p, S.part1.p, D.ws, dB, pg, D.nh,
                          D.walk_clk.p, (const uint32_t*)nullptr, 0u, pp);
     }
   }
@@ -1455,19 +1467,19 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     uint32_t blocks = div_up(P2.nchunks, 8) * 8 * pg;
     if (walk_lp)
       hipLaunchKernelGGL((k_msm29<G2Acc29, G2Affine29, G2XYZZ, 2>), dim3(blocks), dim3(64), 0, s2, D.t2_29.p, P2.rsid.p,
-                         P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, pg, D.nh, nullptr, nullptr, PB);
+                         P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, dB, pg, D.nh, nullptr, nullptr, PB);
     else if (lanechunk)
       hipLaunchKernelGGL((k_msm29<G2Acc29, G2Affine29, G2XYZZ, 1, true>), dim3(div_up(P2.nchunks, 64), nb), dim3(64), 0, s2,
-                         D.t2_29.p, P2.rsid.p, P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, PB, D.nh,
+                         D.t2_29.p, P2.rsid.p, P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, dB, PB, D.nh,
                          nullptr);
     else
       hipLaunchKernelGGL((k_msm29<G2Acc29, G2Affine29, G2XYZZ, 2>), dim3(blocks), dim3(64), 0, s2, D.t2_29.p, P2.rsid.p,
-                         P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, B, pg, D.nh,
+                         P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, dB, pg, D.nh,
                          D.walk_clk.p ? D.walk_clk.p + 2 : nullptr);
   }
   MARK(8, s2);
   RLN_HIP(hipEventRecord(S.evB, D.sB));
-  RLN_HIP(hipEventRecord(S.evB2, D.sB2));
+  RLN_HIP(hipEventRecord(S.evB2, s2));
   // ---------------- stage C
   // proof values (Poseidon chain, latency-bound, depends on the inputs only): the back-end stream has slack
   hipStream_t sV = D.sV;
@@ -1547,27 +1559,31 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     hipLaunchKernelGGL(k_fin_out_b2, dim3(pg), dim3(64), 0, sG, S.sums2.p, S.coords.p, S.comp.p, B, nbp);
     if (lone) RLN_HIP(hipEventRecord(S.evB2, s2));
     RLN_HIP(hipEventRecord(S.evV, sV));
-    // The C segment, k_fin_out and the copies home on the front-end stream itself, right behind the walk of the h rows:
-    // the chain interpreter -> NTT -> h -> walk -> sum -> output crosses no stream (each hop is 50 - 100 us).
+    // The C segment and A's / C's side of the output right behind the walk of the h rows, on that walk's stream: the
+    // chain NTT -> h -> walk -> sum -> output crosses no stream (each hop is 50 - 100 us).  The copies home follow B's
+    // bytes on the G2 chain's stream (lone: the front-end stream) and wait for this chain's event.
     // (Only for a lone batch: in a stream the front-end stream must be free for the batch after next -- there the C
     // segment stays on sC, behind evB, which covers both G1 walks.)
+    hipStream_t sAC = lone ? sA2 : sF;
     if (lone) {
       sF = sA;
-      if (S.used) RLN_HIP(hipStreamWaitEvent(sF, S.free_event(), 0));
       MARK(9, sF);
-      RLN_HIP(hipStreamWaitEvent(sF, S.evE, 0));   // the early G1 walk: the C segment's h-independent rows
+      RLN_HIP(hipStreamWaitEvent(sAC, S.evE, 0));   // the early G1 walk: the C segment's h-independent rows
     } else {
       MARK(9, sF);
       RLN_HIP(hipStreamWaitEvent(sF, S.evB, 0));
     }
-    sum1(sF, {2, 5});
-    RLN_HIP(hipStreamWaitEvent(sF, S.evA, 0));   // A affine, s A and r B1
+    sum1(sAC, {2, 5});
+    RLN_HIP(hipStreamWaitEvent(sAC, S.evA, 0));   // A affine, s A and r B1
     // A's and C's side of the output (fold of the C segment, inversion, bytes): see k_fin_out_ac
     if (fused)
-      hipLaunchKernelGGL(k_fin_out_ac_fused, dim3(pg), dim3(64), 0, sF, S.sums1.p, S.affA.p, S.coords.p, S.comp.p, B, nbp);
+      hipLaunchKernelGGL(k_fin_out_ac_fused, dim3(pg), dim3(64), 0, sAC, S.sums1.p, S.affA.p, S.coords.p, S.comp.p, B, nbp);
     else
-      hipLaunchKernelGGL(k_fin_out_ac, dim3(pg), dim3(64), 0, sF, S.sums1.p, S.prod.p, S.affA.p, S.coords.p, S.comp.p, B, nbp);
-    if (lone) RLN_HIP(hipStreamWaitEvent(sF, S.evB2, 0));   // the copies home need B's bytes (not lone: sG = sF = sC, in order)
+      hipLaunchKernelGGL(k_fin_out_ac, dim3(pg), dim3(64), 0, sAC, S.sums1.p, S.prod.p, S.affA.p, S.coords.p, S.comp.p, B, nbp);
+    if (lone) {   // (not lone: sG = sF = sC, in order)
+      RLN_HIP(hipEventRecord(S.evA, sAC));        // (the wait above took the A sums' record; from here: "A's and C's bytes are there")
+      RLN_HIP(hipStreamWaitEvent(sF, S.evA, 0));
+    }
     RLN_HIP(hipStreamWaitEvent(sF, S.evV, 0));
   } else {
     RLN_HIP(hipEventRecord(S.evV, sV));

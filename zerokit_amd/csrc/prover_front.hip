@@ -482,78 +482,99 @@ __global__ void __launch_bounds__(256, RLN_NTT_WAVES) k_ntt_pass(Fr* __restrict_
   }
 }
 
-// Small batches: nine levels in ONE kernel.  The 512 points {base + m stride} that nine consecutive levels close over
-// are one wave's work: three radix-8 sub-passes, eight points per lane, exchanged through 16 KB of LDS instead of
-// through HBM and two kernel boundaries (a lone proof's pass is all latency: 50 - 65 us for 6 us of arithmetic).  In the
-// set's local coordinates m = 0..511 the sub-passes are a 512-point transform's (local strides 64, 8, 1 for DIF and
-// 1, 8, 64 for DIT); their twiddles are the big transform's, indexed exactly as k_ntt_pass does for the pass
-// (s0 + 3 q, K = 3): global stride = stride * ls, lo = lo_set + lo_local * stride.  Same butterflies, same products, same
-// order per point: bit-identical to the passes it replaces.  Grid (proof, set, vector), one wave per workgroup.
-template <bool DIF>
-__global__ void __launch_bounds__(64) k_ntt_fused9(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0,
-                                                   const Fr* __restrict__ scale, uint32_t B, uint32_t nb) {
+// Small batches (lanes = groups), logn >= 9: the three transforms of the quotient in THREE kernels, one butterfly per lane
+// per level.  A lone proof's transform is all latency: with eight points per lane (k_ntt_pass, and the nine-level kernel
+// that stood here until round 4) a lane's chain is 12 twiddle products per pass -- 38 + 15 + 10 us inverse,
+// 57 + 15 + 42 us forward for 6 us of arithmetic.  Here a workgroup of 256 lanes (a wave per SIMD) owns 512 points in 16 KB
+// of LDS and every level costs a lane ONE product:
+//   k_ntt_edge<true>   inverse (DIF) levels 0 .. E-1, E = logn - 9: the sets {lo + 512 m}, 512 >> E of them per workgroup
+//   k_ntt_mid          inverse levels E .. logn-1 over 512 CONTIGUOUS points, the coset / 1/n scaling, and forward (DIT)
+//                      levels 0 .. 8 over the same points (DIF leaves bit-reversed order, DIT starts from it: the low
+//                      nine levels of both close over the same 512 positions) -- eighteen levels, one kernel
+//   k_ntt_edge<false>  forward levels 9 .. logn-1
+// Same butterflies, same twiddles, same products per point as the passes: bit-identical (Fr products are canonical).
+__global__ void __launch_bounds__(256) k_ntt_mid(Fr* __restrict__ data, const Fr* __restrict__ tw_i,
+                                                 const Fr* __restrict__ tw_f, int logn, const Fr* __restrict__ scale,
+                                                 uint32_t B, uint32_t nb) {
   __shared__ Fr buf[512];
-  const uint32_t p = blockIdx.x, set = blockIdx.y, lane = threadIdx.x;
-  const uint32_t n = 1u << logn;
+  const uint32_t p = blockIdx.x, l = threadIdx.x;
+  const uint32_t n = 1u << logn, base = blockIdx.y * 512;
   if (p >= nb) return;
   Fr* x = data + (size_t)blockIdx.z * n * B + p;
-  uint32_t stride, base, lo;
-  if (DIF) {
-    stride = n >> (s0 + 9);
-    lo = set % stride;
-    base = (set / stride) * (n >> s0) + lo;
-  } else {
-    stride = 1u << s0;
-    lo = set % stride;
-    base = (set / stride) * (stride << 9) + lo;
+  buf[l] = x[(size_t)(base + l) * B];
+  buf[l + 256] = x[(size_t)(base + l + 256) * B];
+  __syncthreads();
+  const int E = logn - 9;
+#pragma unroll 1
+  for (int t = 0; t < 8; t++) {   // inverse level E + t: half = 256 >> t
+    const uint32_t hl = 256u >> t, jl = l & (hl - 1), i0 = ((l >> (8 - t)) << (9 - t)) | jl, i1 = i0 + hl;
+    const Fr u = buf[i0], v = buf[i1];
+    buf[i0] = u + v;
+    buf[i1] = (u - v) * tw_i[(size_t)jl << (E + t)];
+    __syncthreads();
+  }
+  {   // the last inverse level (half = 1), the scaling and the first forward level (half = 1): the same two points
+    const uint32_t i0 = 2 * l, i1 = i0 + 1;
+    const Fr u = buf[i0], v = buf[i1];
+    Fr a = u + v, b = u - v;   // (both levels' twiddle is tw[0] = 1: the product would return its operand)
+    if (scale) {
+      a = a * scale[base + i0];
+      b = b * scale[base + i1];
+    }
+    buf[i0] = a + b;
+    buf[i1] = a - b;
+    __syncthreads();
   }
 #pragma unroll 1
-  for (int q = 0; q < 3; q++) {
-    const uint32_t ls = DIF ? (64u >> (3 * q)) : (1u << (3 * q));
-    const uint32_t lo_l = lane % ls, base_l = (lane / ls) * (ls * 8) + lo_l;
-    const int s0q = s0 + 3 * q;
-    const uint32_t stride_q = stride * ls, lo_q = lo + lo_l * stride;
-    Fr e[8];
-    if (q == 0) {
+  for (int s = 1; s < 9; s++) {   // forward level s: half = 1 << s
+    const uint32_t hl = 1u << s, jl = l & (hl - 1), i0 = ((l >> s) << (s + 1)) | jl, i1 = i0 + hl;
+    const Fr u = buf[i0], v = buf[i1] * tw_f[(size_t)jl << (logn - 1 - s)];
+    buf[i0] = u + v;
+    buf[i1] = u - v;
+    __syncthreads();
+  }
+  x[(size_t)(base + l) * B] = buf[l];
+  x[(size_t)(base + l + 256) * B] = buf[l + 256];
+}
+
+template <bool DIF>
+__global__ void __launch_bounds__(256) k_ntt_edge(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, uint32_t B,
+                                                  uint32_t nb) {
+  __shared__ Fr buf[512];
+  const uint32_t p = blockIdx.x, l = threadIdx.x;
+  const uint32_t n = 1u << logn;
+  if (p >= nb) return;
+  const int E = logn - 9;                       // 1 .. 9
+  const uint32_t cl = 512u >> E, lo0 = blockIdx.y * cl;   // local point i = m cl + c  <->  position lo0 + c + 512 m
+  Fr* x = data + (size_t)blockIdx.z * n * B + p;
 #pragma unroll
-      for (int m = 0; m < 8; m++) e[m] = x[(size_t)(base + (base_l + m * ls) * stride) * B];
+  for (int k = 0; k < 2; k++) {
+    const uint32_t i = l + 256 * k;
+    buf[i] = x[(size_t)(lo0 + (i & (cl - 1)) + 512 * (i >> (9 - E))) * B];
+  }
+  __syncthreads();
+  const uint32_t c = l & (cl - 1), q = l >> (9 - E);
+#pragma unroll 1
+  for (int t = 0; t < E; t++) {
+    const int lh = DIF ? E - 1 - t : t;         // log2 of the level's half in units of m
+    const uint32_t hm = 1u << lh, jm = q & (hm - 1), m0 = ((q >> lh) << (lh + 1)) | jm;
+    const uint32_t i0 = m0 * cl + c, i1 = i0 + hm * cl;
+    const size_t j = (size_t)jm * 512 + lo0 + c;
+    if (DIF) {
+      const Fr u = buf[i0], v = buf[i1];
+      buf[i0] = u + v;
+      buf[i1] = (u - v) * tw[j << t];
     } else {
-#pragma unroll
-      for (int m = 0; m < 8; m++) e[m] = buf[base_l + m * ls];
+      const Fr u = buf[i0], v = buf[i1] * tw[j << (logn - 1 - (9 + t))];
+      buf[i0] = u + v;
+      buf[i1] = u - v;
     }
+    __syncthreads();
+  }
 #pragma unroll
-    for (int t = 0; t < 3; t++) {
-      const int half = DIF ? (8 >> (t + 1)) : (1 << t);
-#pragma unroll
-      for (int m = 0; m < 8; m++) {
-        if (m & half) continue;
-        const uint32_t j = (uint32_t)(m & (half - 1)) * stride_q + lo_q;
-        const uint32_t ti = DIF ? (j << (s0q + t)) : (j << (logn - 1 - (s0q + t)));
-        if (DIF) {
-          const Fr u = e[m], v = e[m + half];
-          e[m] = u + v;
-          e[m + half] = (u - v) * tw[ti];
-        } else {
-          const Fr u = e[m], v = e[m + half] * tw[ti];
-          e[m] = u + v;
-          e[m + half] = u - v;
-        }
-      }
-    }
-    if (q == 2) {
-#pragma unroll
-      for (int m = 0; m < 8; m++) {
-        const uint32_t pos = base + (base_l + m * ls) * stride;
-        Fr o = e[m];
-        if (scale) o = o * scale[pos];
-        x[(size_t)pos * B] = o;
-      }
-    } else {
-      __syncthreads();   // (one wave: orders the reads above against the writes below)
-#pragma unroll
-      for (int m = 0; m < 8; m++) buf[base_l + m * ls] = e[m];
-      __syncthreads();
-    }
+  for (int k = 0; k < 2; k++) {
+    const uint32_t i = l + 256 * k;
+    x[(size_t)(lo0 + (i & (cl - 1)) + 512 * (i >> (9 - E))) * B] = buf[i];
   }
 }
 
@@ -601,7 +622,10 @@ __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ V, const 
                                                 uint32_t ns, const Fr* __restrict__ H, uint32_t n,
                                                 const uint32_t* __restrict__ rs, WinSched ws1, WinSched ws2, uint32_t nh,
                                                 int16_t* __restrict__ dig1, int16_t* __restrict__ dig2, uint32_t B,
-                                                uint32_t nb, uint32_t part, uint32_t lg) {
+                                                uint32_t nb, uint32_t part, uint32_t lg, uint32_t dB) {
+  // dB: the proof stride of the digit arrays ([scalar][half][window][dB]).  The batch capacity B in the throughput
+  // shapes; the batch SIZE for small batches -- with B = 64 a lone proof's digits sat one per 128-byte line (64 scattered
+  // two-byte stores per lane here, a miss per step in the walks); compact, a scalar's windows share one line.
   // part 0: every scalar; 1: the witness scalars and r, s, -(r s) (all the G2 walk needs: it can start before the
   // quotient h exists); 2: the coefficients of h only
   // part 3 (small full proofs, fused plan): the products s w_i, r w_i and r s under the ids ns + n + 3 + ..., G1 only
@@ -651,18 +675,18 @@ __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ V, const 
       if (g2) {
 #pragma unroll
         for (int i = 0; i < 4; i++) t[i] = k[h][i];
-        emit_digits<4>(t, neg[h] != 0, ws2, dig2 + ((size_t)sid2 * 2 + h) * ws2.W * B + p, B);
+        emit_digits<4>(t, neg[h] != 0, ws2, dig2 + ((size_t)sid2 * 2 + h) * ws2.W * dB + p, dB);
       }
-      emit_digits<4>(k[h], neg[h] != 0, ws1, dig1 + ((size_t)sid * 2 + h) * ws1.W * B + p, B);
+      emit_digits<4>(k[h], neg[h] != 0, ws1, dig1 + ((size_t)sid * 2 + h) * ws1.W * dB + p, dB);
     }
   } else {
     if (g2) {
       uint32_t t[8];
 #pragma unroll
       for (int i = 0; i < 8; i++) t[i] = l[i];
-      emit_digits<8>(t, false, ws2, dig2 + (size_t)sid2 * ws2.W * B + p, B);
+      emit_digits<8>(t, false, ws2, dig2 + (size_t)sid2 * ws2.W * dB + p, dB);
     }
-    emit_digits<8>(l, false, ws1, dig1 + (size_t)sid * ws1.W * B + p, B);
+    emit_digits<8>(l, false, ws1, dig1 + (size_t)sid * ws1.W * dB + p, dB);
   }
 }
 
@@ -681,7 +705,7 @@ template __global__ void k_ntt_pass<1, true, true>(Fr* __restrict__ data, const 
 template __global__ void k_ntt_pass<1, false, true>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0, const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
 template __global__ void k_ntt_pass<3, true, true>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0, const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
 template __global__ void k_ntt_pass<3, false, true>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0, const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
-template __global__ void k_ntt_fused9<true>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0, const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
-template __global__ void k_ntt_fused9<false>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0, const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
+template __global__ void k_ntt_edge<true>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, uint32_t B, uint32_t nb);
+template __global__ void k_ntt_edge<false>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, uint32_t B, uint32_t nb);
 
 }  // namespace rlnamd

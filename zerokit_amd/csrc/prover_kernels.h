@@ -86,15 +86,18 @@ __global__ void __launch_bounds__(256) k_consts_to29(const Fr* __restrict__ src,
 template <int K, bool DIF, bool LG = false>
 __global__ void __launch_bounds__(256, RLN_NTT_WAVES) k_ntt_pass(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0,
                                                   const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
+__global__ void __launch_bounds__(256) k_ntt_mid(Fr* __restrict__ data, const Fr* __restrict__ tw_i,
+                                                 const Fr* __restrict__ tw_f, int logn, const Fr* __restrict__ scale,
+                                                 uint32_t B, uint32_t nb);
 template <bool DIF>
-__global__ void __launch_bounds__(64) k_ntt_fused9(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0,
-                                                   const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
+__global__ void __launch_bounds__(256) k_ntt_edge(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, uint32_t B,
+                                                  uint32_t nb);
 __global__ void __launch_bounds__(256) k_hquot(Fr* __restrict__ abc, uint32_t n, uint32_t B, uint32_t nb, uint32_t lg);
 __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ V, const uint32_t* __restrict__ sig2node,
                                                 uint32_t ns, const Fr* __restrict__ H, uint32_t n,
                                                 const uint32_t* __restrict__ rs, WinSched ws1, WinSched ws2, uint32_t nh,
                                                 int16_t* __restrict__ dig1, int16_t* __restrict__ dig2, uint32_t B,
-                                                uint32_t nb, uint32_t part, uint32_t lg);
+                                                uint32_t nb, uint32_t part, uint32_t lg, uint32_t dB);
 
 // ---- kernels of prover_walks.hip (k_msm29 itself is declared in walk29.h)
 template <class A, class E>
