@@ -339,6 +339,10 @@ __device__ __forceinline__ G1Affine29 to_table29(const G1Affine& a) {
 // the all-zero limb pattern for non-zero operands... it can only return 0 for a zero product).
 struct G1Acc29 {
   Fq29 X, Y, ZZ, ZZZ;
+  static constexpr uint32_t LPP = 1;   // lanes per point (G2AccPair29: 2)
+  __device__ __forceinline__ void store_xyzz(G1XYZZ* dst) const { *dst = to_xyzz(); }
+  static __device__ __forceinline__ G1Acc29 load_xyzz(const G1XYZZ* src) { return from_xyzz(*src); }
+  __device__ __forceinline__ void store_lds(G1Acc29* dst) const { *dst = *this; }
 
   static __device__ __forceinline__ G1Acc29 inf() { return {Fq29::zero(), Fq29::zero(), Fq29::zero(), Fq29::zero()}; }
   __device__ __forceinline__ bool is_inf() const { return ZZ.limbs_all_zero(); }
@@ -519,11 +523,94 @@ __device__ __forceinline__ G2Affine29 to_table29(const G2Affine& a) {
   return e;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Who computes an Fq2 product.  Fq2LaneOps: the lane that holds the operands, both components (the throughput walks: a
+// lane = a proof).  Fq2PairOps: a PAIR of adjacent lanes holds the same operands and each computes ONE component, then
+// they swap (nine DPP moves) -- for the lone dependent chains of a single proof (tiny G2 walk, G2 sum trees), where a
+// lane's issue rate is the latency: an Fq2 product costs a lane one dot product instead of two (1.65 x fewer instructions
+// per addition, the selects and swaps included).  Lane 2 t computes c0 with exactly the operands Fq2LaneOps gives the c0
+// product, lane 2 t + 1 c1 with the c1 operands: the same call sites for check_fq29_bounds.py, the same field elements.
+// Both lanes of a pair must take the same branches (they hold the same values, so they do).
+struct Fq2LaneOps {
+  static constexpr uint32_t LPP = 1;   // lanes per point
+  static __device__ __forceinline__ Fq2_29 mul(const Fq2_29& a, const Fq2_29& b) { return Fq2_29::mul(a, b); }
+  static __device__ __forceinline__ Fq2_29 sqr(const Fq2_29& a) { return Fq2_29::sqr(a); }
+  static __device__ __forceinline__ Fq2_29 mul_add(const Fq2_29& a, const Fq2_29& b, const Fq2_29& add) { return Fq2_29::mul_add(a, b, add); }
+  static __device__ __forceinline__ Fq2_29 sqr_add(const Fq2_29& a, const Fq2_29& add) { return Fq2_29::sqr_add(a, add); }
+  // R D - S T with nS = K4 - S (lazy): four base products per component, one reduction each
+  static __device__ __forceinline__ Fq2_29 rd_minus_st(const Fq2_29& R, const Fq2_29& D, const Fq2_29& nS, const Fq2_29& S,
+                                                       const Fq2_29& T) {
+    const Fq29 nR1 = Fq29::neg_lazy(Fq29C::K8, R.c1);
+    return {Fq29::dot4<true>(R.c0, D.c0, nR1, D.c1, nS.c0, T.c0, S.c1, T.c1),
+            Fq29::dot4<true>(R.c0, D.c1, R.c1, D.c0, nS.c0, T.c1, nS.c1, T.c0)};
+  }
+};
+struct Fq2PairOps {
+  static constexpr uint32_t LPP = 2;
+  static __device__ __forceinline__ bool odd() { return (threadIdx.x & 1u) != 0; }
+  static __device__ __forceinline__ Fq29 pick(bool o, const Fq29& if_odd, const Fq29& if_even) {
+    Fq29 r;
+#pragma unroll
+    for (int j = 0; j < 9; j++) r.v[j] = o ? if_odd.v[j] : if_even.v[j];
+    return r;
+  }
+  // own component computed, the partner's fetched: quad_perm [1, 0, 3, 2]
+  static __device__ __forceinline__ Fq2_29 join(bool o, const Fq29& own) {
+    Fq29 other;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own.v[j], 0xB1, 0xF, 0xF, true);
+      asm volatile("" : "+v"(t));   // pins the move in front of the selects (a move sunk into a one-sided branch reads a switched-off lane)
+      other.v[j] = t;
+    }
+    return {pick(o, other, own), pick(o, own, other)};
+  }
+  static __device__ __forceinline__ Fq2_29 mul(const Fq2_29& a, const Fq2_29& b) {
+    const bool o = odd();
+    const Fq29 n1 = Fq29::neg_lazy(Fq29C::K8, a.c1);
+    return join(o, Fq29::dot2(a.c0, pick(o, b.c1, b.c0), pick(o, a.c1, n1), pick(o, b.c0, b.c1)));
+  }
+  static __device__ __forceinline__ Fq2_29 mul_add(const Fq2_29& a, const Fq2_29& b, const Fq2_29& add) {
+    const bool o = odd();
+    const Fq29 n1 = Fq29::neg_lazy(Fq29C::K8, a.c1);
+    return join(o, Fq29::dot2_add(a.c0, pick(o, b.c1, b.c0), pick(o, a.c1, n1), pick(o, b.c0, b.c1), pick(o, add.c1, add.c0)));
+  }
+  // c0 = (a0 + a1)(a0 - a1), c1 = (2 a0) a1
+  static __device__ __forceinline__ void sqr_operands(bool o, const Fq2_29& a, Fq29* x, Fq29* y) {
+    const Fq29 d = Fq29::sub(a.c0, Fq29C::K8, a.c1);
+#pragma unroll
+    for (int j = 0; j < 9; j++) x->v[j] = a.c0.v[j] + (o ? a.c0.v[j] : a.c1.v[j]);   // lazy
+    *y = pick(o, a.c1, d);
+  }
+  static __device__ __forceinline__ Fq2_29 sqr(const Fq2_29& a) {
+    const bool o = odd();
+    Fq29 x, y;
+    sqr_operands(o, a, &x, &y);
+    return join(o, Fq29::mul(x, y));
+  }
+  static __device__ __forceinline__ Fq2_29 sqr_add(const Fq2_29& a, const Fq2_29& add) {
+    const bool o = odd();
+    Fq29 x, y;
+    sqr_operands(o, a, &x, &y);
+    return join(o, Fq29::mul_add(x, y, pick(o, add.c1, add.c0)));
+  }
+  static __device__ __forceinline__ Fq2_29 rd_minus_st(const Fq2_29& R, const Fq2_29& D, const Fq2_29& nS, const Fq2_29& S,
+                                                       const Fq2_29& T) {
+    const bool o = odd();
+    const Fq29 nR1 = Fq29::neg_lazy(Fq29C::K8, R.c1);
+    return join(o, Fq29::dot4<true>(R.c0, pick(o, D.c1, D.c0), pick(o, R.c1, nR1), pick(o, D.c0, D.c1), nS.c0,
+                                    pick(o, T.c1, T.c0), pick(o, nS.c1, S.c1), pick(o, T.c0, T.c1)));
+  }
+};
+
 // Bounds as in G1Acc29 (X < 5.2 q, Y < 2.1 q, ZZ, ZZZ < 1.7 q per component); products of two Fq2 values add two
 // base products per component, which the 0.0059 factor absorbs (e.g. P P: 2 * 7.2^2 * 0.0059 + 1 < 1.7).
-struct G2Acc29 {
+// O = Fq2LaneOps (G2Acc29: a lane per point) or Fq2PairOps (G2AccPair29: a lane pair per point, both holding all of it).
+template <class O>
+struct G2AccT {
   Fq2_29 X, Y, ZZ, ZZZ;
-  static __device__ __forceinline__ G2Acc29 inf() {
+  static constexpr uint32_t LPP = O::LPP;
+  static __device__ __forceinline__ G2AccT inf() {
     Fq2_29 z{Fq29::zero(), Fq29::zero()};
     return {z, z, z, z};
   }
@@ -532,13 +619,52 @@ struct G2Acc29 {
     if (is_inf()) return G2XYZZ::inf();
     return {X.to_fq2(), Y.to_fq2(), ZZ.to_fq2(), ZZZ.to_fq2()};
   }
-  static __device__ __forceinline__ G2Acc29 from_xyzz(const G2XYZZ& p) {
+  static __device__ __forceinline__ G2AccT from_xyzz(const G2XYZZ& p) {
     if (p.is_inf()) return inf();
     return {Fq2_29::from_fq2(p.X), Fq2_29::from_fq2(p.Y), Fq2_29::from_fq2(p.ZZ), Fq2_29::from_fq2(p.ZZZ)};
   }
+  // *dst = this point in the common form / this = *src.  A lane pair converts and moves one component per lane.
+  __device__ __forceinline__ void store_xyzz(G2XYZZ* dst) const {
+    if (LPP == 1) {
+      *dst = to_xyzz();
+      return;
+    }
+    const bool o = Fq2PairOps::odd(), z = is_inf();
+    const Fq2_29* const c[4] = {&X, &Y, &ZZ, &ZZZ};
+    Fq2* const d[4] = {&dst->X, &dst->Y, &dst->ZZ, &dst->ZZZ};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const Fq v = z ? Fq::zero() : Fq2PairOps::pick(o, c[k]->c1, c[k]->c0).to_fq();
+      *(o ? &d[k]->c1 : &d[k]->c0) = v;
+    }
+  }
+  // the point into LDS for another pair / lane to add: a pair writes two coordinates per lane
+  __device__ __forceinline__ void store_lds(G2AccT* dst) const {
+    if (LPP == 1) {
+      *dst = *this;
+    } else if (Fq2PairOps::odd()) {
+      dst->ZZ = ZZ;
+      dst->ZZZ = ZZZ;
+    } else {
+      dst->X = X;
+      dst->Y = Y;
+    }
+  }
+  static __device__ __forceinline__ G2AccT load_xyzz(const G2XYZZ* src) {
+    if (LPP == 1) return from_xyzz(*src);
+    const bool o = Fq2PairOps::odd();
+    const Fq2* const c[4] = {&src->X, &src->Y, &src->ZZ, &src->ZZZ};
+    G2AccT r;
+    Fq2_29* const d[4] = {&r.X, &r.Y, &r.ZZ, &r.ZZZ};
+#pragma unroll
+    for (int k = 0; k < 4; k++) *d[k] = Fq2PairOps::join(o, Fq29::from_fq(o ? c[k]->c1 : c[k]->c0));
+    // (infinity in the common form is ZZ = 0: from_fq(0) has all limbs zero, so is_inf() holds)
+    return r;
+  }
 
-  // 2 (x, y), y normalised < 2 q per component (mdbl-2008-s-1)
-  static __device__ __forceinline__ G2Acc29 dbl_affine(const Fq2_29& x, const Fq2_29& y) {
+  // 2 (x, y), y normalised < 2 q per component (mdbl-2008-s-1).  Rare (a walk meets its own point): computed in full by
+  // the lane, and by both lanes of a pair alike.
+  static __device__ __forceinline__ G2AccT dbl_affine(const Fq2_29& x, const Fq2_29& y) {
     Fq2_29 U;
 #pragma unroll
     for (int j = 0; j < 9; j++) {
@@ -595,39 +721,33 @@ struct G2Acc29 {
     }
     const Fq2_29 kX = Fq2_29::neg_lazy(Fq29C::K6, X);
     const Fq2_29 nY = Fq2_29::neg_lazy(Fq29C::K4, Y);      // also the -Y of Y3 below
-    Fq2_29 P = Fq2_29::mul_add(px, ZZ, kX);
-    Fq2_29 R = Fq2_29::mul_add(py, ZZZ, nY);
+    Fq2_29 P = O::mul_add(px, ZZ, kX);
+    Fq2_29 R = O::mul_add(py, ZZZ, nY);
     if (P.is_zero_mod_q()) {  // same x: doubling or cancellation (rare), kept in this form: no extra registers
       if (R.is_zero_mod_q()) *this = dbl_affine(px, py); else *this = inf();
       return;
     }
-    Fq2_29 PP = Fq2_29::sqr(P);
-    ZZ = Fq2_29::mul(ZZ, PP);
-    Fq2_29 Q = Fq2_29::mul(X, PP);
-    Fq2_29 PPP = Fq2_29::mul(P, PP);
-    ZZZ = Fq2_29::mul(ZZZ, PPP);
+    Fq2_29 PP = O::sqr(P);
+    ZZ = O::mul(ZZ, PP);
+    Fq2_29 Q = O::mul(X, PP);
+    Fq2_29 PPP = O::mul(P, PP);
+    ZZZ = O::mul(ZZZ, PPP);
     Fq2_29 kT;
 #pragma unroll
     for (int j = 0; j < 9; j++) {
       kT.c0.v[j] = Fq29C::K4T[j] - (PPP.c0.v[j] + 2 * Q.c0.v[j]);
       kT.c1.v[j] = Fq29C::K4T[j] - (PPP.c1.v[j] + 2 * Q.c1.v[j]);
     }
-    X = Fq2_29::sqr_add(R, kT);                             // X3 = R^2 - PPP - 2 Q
+    X = O::sqr_add(R, kT);                                  // X3 = R^2 - PPP - 2 Q
     Fq2_29 D = Fq2_29::sub(Q, Fq29C::K6, X);
-    // Y3 = R D - Y PPP, four base products per component, one reduction each
-    Fq29 nR1 = Fq29::neg_lazy(Fq29C::K8, R.c1);
-    const Fq29& nY0 = nY.c0;
-    const Fq29& nY1 = nY.c1;
-    Fq29 y0 = Fq29::dot4<true>(R.c0, D.c0, nR1, D.c1, nY0, PPP.c0, Y.c1, PPP.c1);
-    Fq29 y1 = Fq29::dot4<true>(R.c0, D.c1, R.c1, D.c0, nY0, PPP.c1, nY1, PPP.c0);
-    Y = {y0, y1};
+    Y = O::rd_minus_st(R, D, nY, Y, PPP);                   // Y3 = R D - Y PPP
   }
 
   // this += *o (see G1Acc29::add): madd's tail with (X, Y) -> (U1, S1), the same operand classes at every call site.
   // The operand is read from memory (LDS in the sum trees) coordinate by coordinate and in the order that lets the
   // operands die early -- a G2 point is 72 words, and with both points, U1, U2, S1, S2 and a product's accumulators alive
   // at once the kernel spilled 283 registers; the compiler barriers keep the loads where they are written.
-  __device__ __forceinline__ void add(const G2Acc29* o) {
+  __device__ __forceinline__ void add(const G2AccT* o) {
     if (o->is_inf()) return;
     if (is_inf()) {
       *this = *o;
@@ -636,15 +756,15 @@ struct G2Acc29 {
     Fq2_29 U1, P, S1, R;
     {
       const Fq2_29 oZZ = o->ZZ, oX = o->X;
-      U1 = Fq2_29::mul(X, oZZ);
-      const Fq2_29 U2 = Fq2_29::mul(oX, ZZ);
+      U1 = O::mul(X, oZZ);
+      const Fq2_29 U2 = O::mul(oX, ZZ);
       P = Fq2_29::sub(U2, Fq29C::K2, U1);
     }
     asm volatile("" ::: "memory");
     {
       const Fq2_29 oZZZ = o->ZZZ, oY = o->Y;
-      S1 = Fq2_29::mul(Y, oZZZ);
-      const Fq2_29 S2 = Fq2_29::mul(oY, ZZZ);
+      S1 = O::mul(Y, oZZZ);
+      const Fq2_29 S2 = O::mul(oY, ZZZ);
       R = Fq2_29::sub(S2, Fq29C::K2, S1);
     }
     if (P.is_zero_mod_q()) {   // doubling / cancellation: through the 8 x 32 law, out of line (its registers are its own)
@@ -654,39 +774,37 @@ struct G2Acc29 {
     asm volatile("" ::: "memory");
     {
       const Fq2_29 oZZ = o->ZZ;
-      ZZ = Fq2_29::mul(ZZ, oZZ);
+      ZZ = O::mul(ZZ, oZZ);
     }
     {
       const Fq2_29 oZZZ = o->ZZZ;
-      ZZZ = Fq2_29::mul(ZZZ, oZZZ);
+      ZZZ = O::mul(ZZZ, oZZZ);
     }
     asm volatile("" ::: "memory");
-    const Fq2_29 PP = Fq2_29::sqr(P);
-    ZZ = Fq2_29::mul(ZZ, PP);
-    const Fq2_29 Q = Fq2_29::mul(U1, PP);
-    const Fq2_29 PPP = Fq2_29::mul(P, PP);
-    ZZZ = Fq2_29::mul(ZZZ, PPP);
+    const Fq2_29 PP = O::sqr(P);
+    ZZ = O::mul(ZZ, PP);
+    const Fq2_29 Q = O::mul(U1, PP);
+    const Fq2_29 PPP = O::mul(P, PP);
+    ZZZ = O::mul(ZZZ, PPP);
     Fq2_29 kT;
 #pragma unroll
     for (int j = 0; j < 9; j++) {
       kT.c0.v[j] = Fq29C::K4T[j] - (PPP.c0.v[j] + 2 * Q.c0.v[j]);
       kT.c1.v[j] = Fq29C::K4T[j] - (PPP.c1.v[j] + 2 * Q.c1.v[j]);
     }
-    X = Fq2_29::sqr_add(R, kT);
+    X = O::sqr_add(R, kT);
     const Fq2_29 D = Fq2_29::sub(Q, Fq29C::K6, X);
     const Fq2_29 nS = Fq2_29::neg_lazy(Fq29C::K4, S1);
-    const Fq29 nR1 = Fq29::neg_lazy(Fq29C::K8, R.c1);
-    // Y3 = R D - S1 PPP: (R0 D0 - R1 D1 - S0 T0 + S1 T1, R0 D1 + R1 D0 - S0 T1 - S1 T0)
-    const Fq29 y0 = Fq29::dot4<true>(R.c0, D.c0, nR1, D.c1, nS.c0, PPP.c0, S1.c1, PPP.c1);
-    const Fq29 y1 = Fq29::dot4<true>(R.c0, D.c1, R.c1, D.c0, nS.c0, PPP.c1, nS.c1, PPP.c0);
-    Y = {y0, y1};
+    Y = O::rd_minus_st(R, D, nS, S1, PPP);                  // Y3 = R D - S1 PPP
   }
-  __device__ __forceinline__ void add(const G2Acc29& o) { add(&o); }
-  static __device__ __noinline__ void add_same_x(G2Acc29* self, const G2Acc29* o) {
+  __device__ __forceinline__ void add(const G2AccT& o) { add(&o); }
+  static __device__ __noinline__ void add_same_x(G2AccT* self, const G2AccT* o) {
     G2XYZZ a = self->to_xyzz();
     a.add(o->to_xyzz());
     *self = from_xyzz(a);
   }
 };
+typedef G2AccT<Fq2LaneOps> G2Acc29;
+typedef G2AccT<Fq2PairOps> G2AccPair29;
 
 }  // namespace rlnamd

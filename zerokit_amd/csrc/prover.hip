@@ -417,8 +417,8 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     D.nodes.upload(prog.data(), D.N, s);
     RLN_HIP(hipStreamSynchronize(s));
   }
-  RLN_HIP(hipFuncSetAttribute((const void*)k_sum_tree<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_TREE_LDS_G2));
-  RLN_HIP(hipFuncSetAttribute((const void*)k_sum_blocks<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_TREE_LDS_G2));
+  RLN_HIP(hipFuncSetAttribute((const void*)(k_sum_tree<Fq2, G2Acc29>), hipFuncAttributeMaxDynamicSharedMemorySize, SUM_TREE_LDS_G2));
+  RLN_HIP(hipFuncSetAttribute((const void*)(k_sum_blocks<Fq2, G2Acc29>), hipFuncAttributeMaxDynamicSharedMemorySize, SUM_TREE_LDS_G2));
   RLN_HIP(hipFuncSetAttribute((const void*)k_witness, hipFuncAttributeMaxDynamicSharedMemorySize, WIT_RING * 8 * 64 * 4 + WIT_LDS_CONSTS * 32));
   D.consts.alloc(std::max<size_t>(graph_.constants.size(), 1));
   if (!graph_.constants.empty()) D.consts.upload(graph_.constants.data(), graph_.constants.size(), s);
@@ -688,7 +688,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   // line per two additions) instead of as single rows; every pair chunk owns a chunk slot in each of its two members' segments.
   auto make_plans = [&](const std::vector<VRow>& vrows, uint32_t nseg, uint32_t chunk_pts, Impl::Plan* plans,
                         uint32_t* max_chunks, uint32_t* max_groups, int only_mode, uint32_t npaired = 0,
-                        bool pair_chunks = false) {
+                        bool pair_chunks = false, uint32_t block_pts = SUM_TREE_LANES) {
     auto roww = [&](uint32_t k, uint32_t h) { return k | (k < npaired ? ROW_PAIRED : 0u) | (h << 31); };
     for (int mode = 0; mode < 3; mode++) {
       if (only_mode >= 0 && mode != only_mode) continue;
@@ -780,7 +780,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
         uint32_t nb = 0;
         P.maxblk = 0;
         for (size_t sgi = 0; sgi + 1 < segfirst.size(); sgi++) {
-          const uint32_t k = div_up(segfirst[sgi + 1] - segfirst[sgi], SUM_TREE_LANES);
+          const uint32_t k = div_up(segfirst[sgi + 1] - segfirst[sgi], block_pts);
           segblocks.push_back({nb, nb + k});
           nb += k;
           P.maxblk = std::max(P.maxblk, k);
@@ -935,7 +935,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     {
       uint32_t unused = 0;
       make_plans(vrows, 1, 2u, D.plan2s, &D.max_chunks2s, &unused, -1);
-      make_plans(vrows, 1, 1u, D.plan2t, &D.max_chunks2t, &unused, PROVE_FULL);
+      make_plans(vrows, 1, 1u, D.plan2t, &D.max_chunks2t, &unused, PROVE_FULL, 0, false, SUM_TREE_LANES / 2);   // walked and summed by lane pairs
       D.max_blocks2t = D.plan2t[PROVE_FULL].nblocks;
     }
     build_table29<Fq2, G2Affine29>(pts, D.ws2, D.t2_29, s);
@@ -1468,6 +1468,10 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     if (walk_lp)
       hipLaunchKernelGGL((k_msm29<G2Acc29, G2Affine29, G2XYZZ, 2>), dim3(blocks), dim3(64), 0, s2, D.t2_29.p, P2.rsid.p,
                          P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, dB, pg, D.nh, nullptr, nullptr, PB);
+    else if (tiny)   // a lane pair per (row, half): see Fq2PairOps
+      hipLaunchKernelGGL((k_msm29<G2AccPair29, G2Affine29, G2XYZZ, 1, true>), dim3(div_up(2 * P2.nchunks, 64), nb), dim3(64), 0, s2,
+                         D.t2_29.p, P2.rsid.p, P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, dB, PB, D.nh,
+                         nullptr);
     else if (lanechunk)
       hipLaunchKernelGGL((k_msm29<G2Acc29, G2Affine29, G2XYZZ, 1, true>), dim3(div_up(P2.nchunks, 64), nb), dim3(64), 0, s2,
                          D.t2_29.p, P2.rsid.p, P2.rows.p, P2.chunks.p, P2.nchunks, S.digits2.p, S.part2.p, D.ws2, dB, PB, D.nh,
@@ -1513,21 +1517,21 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     const TaskSel sel = task_sel(segs);
     const uint32_t ns = (uint32_t)segs.size();
     if (tiny) {
-      hipLaunchKernelGGL(k_sum_blocks<Fq>, dim3(nb, ns, std::max(P1.maxblk, 1u)), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G1, st, S.part1.p, P1.segchunks.p,
+      hipLaunchKernelGGL((k_sum_blocks<Fq, G1Acc29>), dim3(nb, ns, std::max(P1.maxblk, 1u)), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G1, st, S.part1.p, P1.segchunks.p,
                          P1.segblocks.p, S.grp1.p, PB, sel);
-      hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, ns), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G1, st, S.grp1.p, P1.segblocks.p, S.sums1.p, B, PB, sel);
+      hipLaunchKernelGGL((k_sum_tree<Fq, G1Acc29>), dim3(nb, ns), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G1, st, S.grp1.p, P1.segblocks.p, S.sums1.p, B, PB, sel);
     } else {
-      hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, ns), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G1, st, S.part1.p, P1.segchunks.p, S.sums1.p, B, PB, sel);
+      hipLaunchKernelGGL((k_sum_tree<Fq, G1Acc29>), dim3(nb, ns), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G1, st, S.part1.p, P1.segchunks.p, S.sums1.p, B, PB, sel);
     }
   };
   auto sum2 = [&](hipStream_t st) {
     const TaskSel sel = task_sel({0, 1, 2, 3, 4, 5});
-    if (tiny) {
-      hipLaunchKernelGGL(k_sum_blocks<Fq2>, dim3(nb, P2.nseg, std::max(P2.maxblk, 1u)), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G2, st, S.part2.p,
+    if (tiny) {   // a lane pair per point (fq29.h: Fq2PairOps): the plan's blocks are SUM_TREE_LANES / 2 partial sums
+      hipLaunchKernelGGL((k_sum_blocks<Fq2, G2AccPair29>), dim3(nb, P2.nseg, std::max(P2.maxblk, 1u)), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G2 / 2, st, S.part2.p,
                          P2.segchunks.p, P2.segblocks.p, S.grp2.p, PB, sel);
-      hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G2, st, S.grp2.p, P2.segblocks.p, S.sums2.p, B, PB, sel);
+      hipLaunchKernelGGL((k_sum_tree<Fq2, G2AccPair29>), dim3(nb, P2.nseg), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G2 / 2, st, S.grp2.p, P2.segblocks.p, S.sums2.p, B, PB, sel);
     } else {
-      hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G2, st, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, sel);
+      hipLaunchKernelGGL((k_sum_tree<Fq2, G2Acc29>), dim3(nb, P2.nseg), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G2, st, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, sel);
     }
   };
   if (early_fin) {
@@ -1594,8 +1598,8 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   }
   if (early_fin) {
   } else if (lanechunk) {   // small batch: lanes = partial sums (k_sum_tree)
-    hipLaunchKernelGGL(k_sum_tree<Fq>, dim3(nb, P1.nseg), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G1, D.sC, S.part1.p, P1.segchunks.p, S.sums1.p, B, PB, all6);
-    hipLaunchKernelGGL(k_sum_tree<Fq2>, dim3(nb, P2.nseg), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G2, D.sC, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, all6);
+    hipLaunchKernelGGL((k_sum_tree<Fq, G1Acc29>), dim3(nb, P1.nseg), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G1, D.sC, S.part1.p, P1.segchunks.p, S.sums1.p, B, PB, all6);
+    hipLaunchKernelGGL((k_sum_tree<Fq2, G2Acc29>), dim3(nb, P2.nseg), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G2, D.sC, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, all6);
   } else {
     if (P1.ngroups)
       hipLaunchKernelGGL(k_sum_ranges<Fq>, dim3(pg, P1.ngroups), dim3(64), 0, D.sC, S.part1.p, P1.groups.p, P1.ngroups,

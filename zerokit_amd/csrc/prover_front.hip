@@ -362,6 +362,7 @@ __global__ void __launch_bounds__(256) k_matvec(CsrView A, CsrView Bm, const Fr*
                                                 const uint32_t* __restrict__ sig2node, uint32_t nc, uint32_t ni,
                                                 uint32_t n, Fr* __restrict__ abc, uint32_t B, uint32_t nb,
                                                 const uint32_t* __restrict__ long_rows, uint32_t nshort) {
+  if (LG) __builtin_amdgcn_s_setprio(3);   // small batches: a link of the latency chain (see k_ntt_mid)
   uint32_t p = LG ? blockIdx.y : blockIdx.x * 64 + threadIdx.x;
   if (LG && blockIdx.x >= nshort) {   // a wave per long row
     const uint32_t row = long_rows[blockIdx.x - nshort], lane = threadIdx.x;
@@ -497,6 +498,7 @@ __global__ void __launch_bounds__(256) k_ntt_mid(Fr* __restrict__ data, const Fr
                                                  const Fr* __restrict__ tw_f, int logn, const Fr* __restrict__ scale,
                                                  uint32_t B, uint32_t nb) {
   __shared__ Fr buf[512];
+  __builtin_amdgcn_s_setprio(3);   // the quotient chain is short and the h rows wait for it: issue ahead of the walks' waves
   const uint32_t p = blockIdx.x, l = threadIdx.x;
   const uint32_t n = 1u << logn, base = blockIdx.y * 512;
   if (p >= nb) return;
@@ -541,6 +543,7 @@ template <bool DIF>
 __global__ void __launch_bounds__(256) k_ntt_edge(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, uint32_t B,
                                                   uint32_t nb) {
   __shared__ Fr buf[512];
+  __builtin_amdgcn_s_setprio(3);
   const uint32_t p = blockIdx.x, l = threadIdx.x;
   const uint32_t n = 1u << logn;
   if (p >= nb) return;
@@ -580,6 +583,7 @@ __global__ void __launch_bounds__(256) k_ntt_edge(Fr* __restrict__ data, const F
 
 // h = a o b - c  (qap.rs:84-95), written over the `a` vector
 __global__ void __launch_bounds__(256) k_hquot(Fr* __restrict__ abc, uint32_t n, uint32_t B, uint32_t nb, uint32_t lg) {
+  if (lg) __builtin_amdgcn_s_setprio(3);   // small batches: a link of the latency chain (see k_ntt_mid)
   uint32_t p = lg ? blockIdx.y : blockIdx.x * 64 + threadIdx.x;   // lg: lanes = coefficients of one proof
   uint32_t i = lg ? blockIdx.x * 64 + threadIdx.x : blockIdx.y * blockDim.y + threadIdx.y;
   if (p >= nb || i >= n) return;
@@ -629,6 +633,7 @@ __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ V, const 
   // part 0: every scalar; 1: the witness scalars and r, s, -(r s) (all the G2 walk needs: it can start before the
   // quotient h exists); 2: the coefficients of h only
   // part 3 (small full proofs, fused plan): the products s w_i, r w_i and r s under the ids ns + n + 3 + ..., G1 only
+  if (lg) __builtin_amdgcn_s_setprio(3);   // small batches: a link of the latency chain (see k_ntt_mid)
   uint32_t p = lg ? blockIdx.y : blockIdx.x * 64 + threadIdx.x;   // lg (small batches): lanes = scalars of one proof
   uint32_t sid = lg ? blockIdx.x * 64 + threadIdx.x : blockIdx.y * blockDim.y + threadIdx.y;
   if (part == 1) {

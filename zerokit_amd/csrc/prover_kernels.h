@@ -106,10 +106,10 @@ __global__ void __launch_bounds__(256) k_table_to29(const A* __restrict__ src, E
 template <class F>
 __global__ void __launch_bounds__(64) k_sum_ranges(const XYZZ<F>* __restrict__ src, const ChunkDesc* __restrict__ ranges,
                                                    uint32_t nranges, XYZZ<F>* __restrict__ dst, uint32_t B, uint32_t nb);
-template <class F>
+template <class F, class Acc>
 __global__ void __launch_bounds__(SUM_TREE_LANES) k_sum_tree(const XYZZ<F>* __restrict__ part, const ChunkDesc* __restrict__ segchunks,
                                                   XYZZ<F>* __restrict__ dst, uint32_t B, uint32_t PB, TaskSel sel);
-template <class F>
+template <class F, class Acc>
 __global__ void __launch_bounds__(SUM_TREE_LANES) k_sum_blocks(const XYZZ<F>* __restrict__ part, const ChunkDesc* __restrict__ segchunks,
                                                     const ChunkDesc* __restrict__ segblocks, XYZZ<F>* __restrict__ dst, uint32_t PB,
                                                     TaskSel sel);

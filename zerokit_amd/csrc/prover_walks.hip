@@ -52,52 +52,55 @@ template <> struct Acc29Of<Fq> { typedef G1Acc29 type; };
 template <> struct Acc29Of<Fq2> { typedef G2Acc29 type; };
 extern __shared__ uint4 sum_tree_lds[];
 
-template <class F>
+// Acc = Acc29Of<F>::type (a lane per point) or, for G2, G2AccPair29: a lane PAIR per point (fq29.h: Fq2PairOps) -- half
+// the points per workgroup, each addition 1.65 x shorter; what a lone proof's G2 chain wants.
+template <class F, class Acc>
 __global__ void __launch_bounds__(SUM_TREE_LANES) k_sum_tree(const XYZZ<F>* __restrict__ part, const ChunkDesc* __restrict__ segchunks,
                                                   XYZZ<F>* __restrict__ dst, uint32_t B, uint32_t PB, TaskSel sel) {
   // 512 lanes per (proof, segment): the short chunks of the small-batch plans leave ~2 000 partial sums per segment;
   // four per lane and a nine-level tree (part stride PB, result stride B).  The additions are a dependent chain for the
   // lone waves of a single proof, so the lane count is what sets the kernel's length: 256 lanes were 8 + 8 additions.
   // Only the upper half of a level passes through LDS.
-  typedef typename Acc29Of<F>::type Acc;
+  constexpr uint32_t NP = SUM_TREE_LANES / Acc::LPP;   // points in flight
   Acc* sh = reinterpret_cast<Acc*>(sum_tree_lds);
   __builtin_amdgcn_s_setprio(3);
-  const uint32_t p = blockIdx.x, sgi = sel.id[blockIdx.y], l = threadIdx.x;
+  const uint32_t p = blockIdx.x, sgi = sel.id[blockIdx.y], l = threadIdx.x / Acc::LPP;
   const ChunkDesc cd = segchunks[sgi];
   Acc acc = Acc::inf();
-  for (uint32_t i = cd.pt_begin + l; i < cd.pt_end; i += SUM_TREE_LANES) acc.add(Acc::from_xyzz(part[(size_t)i * PB + p]));
+  for (uint32_t i = cd.pt_begin + l; i < cd.pt_end; i += NP) acc.add(Acc::load_xyzz(&part[(size_t)i * PB + p]));
 #pragma unroll 1
-  for (uint32_t stride = SUM_TREE_LANES / 2; stride >= 1; stride >>= 1) {
-    if (l >= stride && l < 2 * stride) sh[l - stride] = acc;
+  for (uint32_t stride = NP / 2; stride >= 1; stride >>= 1) {
+    if (l >= stride && l < 2 * stride) acc.store_lds(&sh[l - stride]);
     __syncthreads();
-    if (l < stride) acc.add(sh[l]);   // (G2: read from LDS coordinate by coordinate, see G2Acc29::add)
+    if (l < stride) acc.add(sh[l]);   // (G2: read from LDS coordinate by coordinate, see G2AccT::add)
     __syncthreads();
   }
-  if (l == 0) dst[(size_t)sgi * B + p] = acc.to_xyzz();
+  if (l == 0) acc.store_xyzz(&dst[(size_t)sgi * B + p]);
 }
 
-// First stage of the two-stage sum (tiny batches): block z of segment sel.id[y] -- 512 consecutive partial sums -- to
+// First stage of the two-stage sum (tiny batches): block z of segment sel.id[y] -- NP consecutive partial sums -- to
 // one point, dst[(segblocks[seg].begin + z) * PB + p]; k_sum_tree over dst (segment ranges = segblocks) is the second.
-template <class F>
+template <class F, class Acc>
 __global__ void __launch_bounds__(SUM_TREE_LANES) k_sum_blocks(const XYZZ<F>* __restrict__ part, const ChunkDesc* __restrict__ segchunks,
                                                     const ChunkDesc* __restrict__ segblocks, XYZZ<F>* __restrict__ dst, uint32_t PB,
                                                     TaskSel sel) {
-  typedef typename Acc29Of<F>::type Acc;
+  constexpr uint32_t NP = SUM_TREE_LANES / Acc::LPP;
   Acc* sh = reinterpret_cast<Acc*>(sum_tree_lds);
   __builtin_amdgcn_s_setprio(3);
-  const uint32_t p = blockIdx.x, sgi = sel.id[blockIdx.y], l = threadIdx.x;
+  const uint32_t p = blockIdx.x, sgi = sel.id[blockIdx.y], l = threadIdx.x / Acc::LPP;
   const ChunkDesc cd = segchunks[sgi], bd = segblocks[sgi];
   if (blockIdx.z >= bd.pt_end - bd.pt_begin) return;   // (uniform for the workgroup)
-  const uint32_t i = cd.pt_begin + blockIdx.z * SUM_TREE_LANES + l;
-  Acc acc = i < cd.pt_end ? Acc::from_xyzz(part[(size_t)i * PB + p]) : Acc::inf();
+  const uint32_t i = cd.pt_begin + blockIdx.z * NP + l;
+  Acc acc = Acc::inf();
+  if (i < cd.pt_end) acc = Acc::load_xyzz(&part[(size_t)i * PB + p]);
 #pragma unroll 1
-  for (uint32_t stride = SUM_TREE_LANES / 2; stride >= 1; stride >>= 1) {
-    if (l >= stride && l < 2 * stride) sh[l - stride] = acc;
+  for (uint32_t stride = NP / 2; stride >= 1; stride >>= 1) {
+    if (l >= stride && l < 2 * stride) acc.store_lds(&sh[l - stride]);
     __syncthreads();
-    if (l < stride) acc.add(sh[l]);   // (G2: read from LDS coordinate by coordinate, see G2Acc29::add)
+    if (l < stride) acc.add(sh[l]);   // (G2: read from LDS coordinate by coordinate, see G2AccT::add)
     __syncthreads();
   }
-  if (l == 0) dst[(size_t)(bd.pt_begin + blockIdx.z) * PB + p] = acc.to_xyzz();
+  if (l == 0) acc.store_xyzz(&dst[(size_t)(bd.pt_begin + blockIdx.z) * PB + p]);
 }
 
 // GLV: segment t holds sum k1_i P_i, segment nseg + t holds sum k2_i P_i; the result is the first plus phi of the
@@ -207,15 +210,18 @@ template __global__ void k_table_to29<G1Affine, G1Affine29>(const G1Affine* __re
 template __global__ void k_table_to29<G2Affine, G2Affine29>(const G2Affine* __restrict__ src, G2Affine29* __restrict__ dst, size_t n, uint32_t stride, uint32_t k0, uint32_t npaired);
 template __global__ void k_sum_ranges<Fq>(const XYZZ<Fq>* __restrict__ src, const ChunkDesc* __restrict__ ranges, uint32_t nranges, XYZZ<Fq>* __restrict__ dst, uint32_t B, uint32_t nb);
 template __global__ void k_sum_ranges<Fq2>(const XYZZ<Fq2>* __restrict__ src, const ChunkDesc* __restrict__ ranges, uint32_t nranges, XYZZ<Fq2>* __restrict__ dst, uint32_t B, uint32_t nb);
-template __global__ void k_sum_tree<Fq>(const XYZZ<Fq>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, XYZZ<Fq>* __restrict__ dst, uint32_t B, uint32_t PB, TaskSel sel);
-template __global__ void k_sum_tree<Fq2>(const XYZZ<Fq2>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, XYZZ<Fq2>* __restrict__ dst, uint32_t B, uint32_t PB, TaskSel sel);
-template __global__ void k_sum_blocks<Fq>(const XYZZ<Fq>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, const ChunkDesc* __restrict__ segblocks, XYZZ<Fq>* __restrict__ dst, uint32_t PB, TaskSel sel);
-template __global__ void k_sum_blocks<Fq2>(const XYZZ<Fq2>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, const ChunkDesc* __restrict__ segblocks, XYZZ<Fq2>* __restrict__ dst, uint32_t PB, TaskSel sel);
+template __global__ void k_sum_tree<Fq, G1Acc29>(const XYZZ<Fq>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, XYZZ<Fq>* __restrict__ dst, uint32_t B, uint32_t PB, TaskSel sel);
+template __global__ void k_sum_tree<Fq2, G2Acc29>(const XYZZ<Fq2>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, XYZZ<Fq2>* __restrict__ dst, uint32_t B, uint32_t PB, TaskSel sel);
+template __global__ void k_sum_blocks<Fq, G1Acc29>(const XYZZ<Fq>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, const ChunkDesc* __restrict__ segblocks, XYZZ<Fq>* __restrict__ dst, uint32_t PB, TaskSel sel);
+template __global__ void k_sum_blocks<Fq2, G2Acc29>(const XYZZ<Fq2>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, const ChunkDesc* __restrict__ segblocks, XYZZ<Fq2>* __restrict__ dst, uint32_t PB, TaskSel sel);
+template __global__ void k_sum_tree<Fq2, G2AccPair29>(const XYZZ<Fq2>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, XYZZ<Fq2>* __restrict__ dst, uint32_t B, uint32_t PB, TaskSel sel);
+template __global__ void k_sum_blocks<Fq2, G2AccPair29>(const XYZZ<Fq2>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, const ChunkDesc* __restrict__ segblocks, XYZZ<Fq2>* __restrict__ dst, uint32_t PB, TaskSel sel);
 template __global__ void k_table_build<Fq>(const Affine<Fq>* __restrict__ pts, uint32_t npts, WinSched ws, Affine<Fq>* __restrict__ table, Fq* __restrict__ scratch);
 template __global__ void k_table_build<Fq2>(const Affine<Fq2>* __restrict__ pts, uint32_t npts, WinSched ws, Affine<Fq2>* __restrict__ table, Fq2* __restrict__ scratch);
 template __global__ void k_msm29<G1Acc29, G1Affine29, G1XYZZ, 4, false>(const G1Affine29* __restrict__ table, const uint32_t* __restrict__ sid, const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks, uint32_t nchunks, const int16_t* __restrict__ digits, G1XYZZ* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups, uint32_t nh, unsigned long long* __restrict__ clk, const uint32_t* __restrict__ chunk_ids, uint32_t pstride, PairPlan pairs);
 template __global__ void k_msm29<G1Acc29, G1Affine29, G1XYZZ, 2, true>(const G1Affine29* __restrict__ table, const uint32_t* __restrict__ sid, const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks, uint32_t nchunks, const int16_t* __restrict__ digits, G1XYZZ* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups, uint32_t nh, unsigned long long* __restrict__ clk, const uint32_t* __restrict__ chunk_ids, uint32_t pstride, PairPlan pairs);
 template __global__ void k_msm29<G2Acc29, G2Affine29, G2XYZZ, 2, false>(const G2Affine29* __restrict__ table, const uint32_t* __restrict__ sid, const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks, uint32_t nchunks, const int16_t* __restrict__ digits, G2XYZZ* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups, uint32_t nh, unsigned long long* __restrict__ clk, const uint32_t* __restrict__ chunk_ids, uint32_t pstride, PairPlan pairs);
 template __global__ void k_msm29<G2Acc29, G2Affine29, G2XYZZ, 1, true>(const G2Affine29* __restrict__ table, const uint32_t* __restrict__ sid, const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks, uint32_t nchunks, const int16_t* __restrict__ digits, G2XYZZ* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups, uint32_t nh, unsigned long long* __restrict__ clk, const uint32_t* __restrict__ chunk_ids, uint32_t pstride, PairPlan pairs);
+template __global__ void k_msm29<G2AccPair29, G2Affine29, G2XYZZ, 1, true>(const G2Affine29* __restrict__ table, const uint32_t* __restrict__ sid, const uint32_t* __restrict__ rows, const ChunkDesc* __restrict__ chunks, uint32_t nchunks, const int16_t* __restrict__ digits, G2XYZZ* __restrict__ part, WinSched ws, uint32_t B, uint32_t pgroups, uint32_t nh, unsigned long long* __restrict__ clk, const uint32_t* __restrict__ chunk_ids, uint32_t pstride, PairPlan pairs);
 
 }  // namespace rlnamd

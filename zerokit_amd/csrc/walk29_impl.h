@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 
   if (LANECHUNK) {
     // chunk_ids (may be null): the launch covers a subset of the plan's chunks -- the rows that do not depend on the
     // quotient h are walked while the NTTs still run, the h rows afterwards; partial sums land at their chunk's index
-    const uint32_t idx = L * 64 + threadIdx.x, p = blockIdx.y;   // one proof per grid row
+    const uint32_t idx = (L * 64 + threadIdx.x) / Acc::LPP, p = blockIdx.y;   // one proof per grid row; LPP lanes per chunk
     if (idx >= nchunks) return;
     const uint32_t chunk = chunk_ids ? chunk_ids[idx] : idx;
     const ChunkDesc cd = chunks[chunk];
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 
         adv(c2);
       }
     }
-    part[(size_t)chunk * pgroups + p] = acc.to_xyzz();   // LANECHUNK: `pgroups` carries the stride of `part`
+    acc.store_xyzz(&part[(size_t)chunk * pgroups + p]);   // LANECHUNK: `pgroups` carries the stride of `part`
     return;
   }
   // Single chunks (a wave = one chunk x 64 proofs) come first in the grid, pair chunks (a wave = one pair chunk x 32
