@@ -44,7 +44,7 @@ struct TreeConfig {
     ProverConfig cfg;
     const char* mb = getenv("RLNAMD_MAX_BATCH");
     cfg.max_batch = max_batch > 0 ? (size_t)max_batch : (mb && *mb ? (size_t)atoll(mb) : 64);
-    cfg.window_bits = window_bits > 0 ? (int)window_bits : 0;   // 0: Prover takes RLNAMD_WINDOW_BITS or c = 8
+    cfg.window_bits = window_bits > 0 ? (int)window_bits : 0;   // 0: Prover takes RLNAMD_WINDOW_BITS or its default schedule
     return cfg;
   }
 };
