@@ -21,7 +21,7 @@ from bench import walk_source_hash  # noqa: E402
 def tag(name):
     if "k_msm29" in name and "G1Acc29" in name:
         return "k_msm29<G1>"
-    if "k_msm29" in name and "G2Acc29" in name:
+    if "k_msm29" in name and ("G2Acc" in name):
         return "k_msm29<G2>"
     for k in ("k_witness29", "k_ntt_pass", "k_matvec", "k_recode", "k_sum_ranges", "k_fin_smul", "k_proof_values",
               "k_v29_to_fr", "k_hquot", "k_fin_affine", "k_fin_out", "k_glv_fold"):

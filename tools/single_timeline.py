@@ -14,7 +14,7 @@ def short(name):
     m = re.match(r"(?:void )?([A-Za-z0-9_]+)", name)
     tag = m.group(1) if m else name
     if "k_msm29" in name:
-        tag += "<G2>" if "G2Acc29" in name else "<G1>"
+        tag += "<G2>" if ("G2Acc" in name) else "<G1>"
     if "k_sum_tree" in name or "k_sum_ranges" in name:
         tag += "<Fq2>" if "Fp2" in name or "Fq2" in name else "<Fq>"
     return tag

@@ -3,7 +3,7 @@ f=glob.glob(sys.argv[1]+'/**/*kernel_trace.csv',recursive=True)[0]
 rows=[]
 for r in csv.DictReader(open(f)):
     n=r['Kernel_Name']; n=re.sub(r'rlnamd::','',n); m=re.match(r'(?:void )?([A-Za-z0-9_]+)',n); t=m.group(1)
-    if 'k_msm29' in n: t+='<G2>' if 'G2Acc29' in n else '<G1>'
+    if 'k_msm29' in n: t+='<G2>' if ('G2Acc' in n) else '<G1>'
     if 'k_sum' in n: t+='<Fq2>' if ('Fq2' in n or 'Fp2' in n) else '<Fq>'
     rows.append((int(r['Start_Timestamp']),int(r['End_Timestamp']),t,r.get('Queue_Id',''),r.get('Stream_Id','')))
 rows.sort()
