@@ -392,7 +392,7 @@ __global__ void k_combine(const G1XYZZ* __restrict__ wsums, uint32_t k, uint32_t
 template <class Aff, class XY, class Aff29, class Acc29>
 __global__ void __launch_bounds__(64) k_selftest29(const Aff* __restrict__ pts, const Aff29* __restrict__ pts29,
                                                    uint32_t npts, uint32_t iters, uint32_t* __restrict__ bad) {
-  uint32_t t = blockIdx.x * 64 + threadIdx.x;
+  uint32_t t = (blockIdx.x * 64 + threadIdx.x) / Acc29::LPP;   // (G2AccPair29: two adjacent lanes run the same sequence)
   XY a = XY::inf(), sa = XY::inf();
   Acc29 b = Acc29::inf(), sb = Acc29::inf();
   uint32_t st = t * 2654435761u + 12345u;
@@ -423,6 +423,16 @@ __global__ void __launch_bounds__(64) k_selftest29(const Aff* __restrict__ pts, 
   XY c = b.to_xyzz();
   Aff x = a.to_affine(), y = c.to_affine();
   if (!(x.x == y.x) || !(x.y == y.y)) atomicAdd(bad, 1u);
+  // the pair form's own ways in and out (one component per lane): through memory and back
+  if (Acc29::LPP == 2) {
+    __shared__ XY box[32];
+    XY* slot = &box[threadIdx.x / 2];
+    b.store_xyzz(slot);
+    __builtin_amdgcn_wave_barrier();
+    Acc29 b2 = Acc29::load_xyzz(slot);
+    Aff z = b2.to_xyzz().to_affine();
+    if (!(x.x == z.x) || !(x.y == z.y)) atomicAdd(bad, 1u);
+  }
 }
 template <class Aff, class Aff29>
 __global__ void k_selftest_conv(const Aff* __restrict__ src, Aff29* __restrict__ dst, uint32_t n) {
@@ -437,7 +447,7 @@ __global__ void k_selftest_points(Affine<F> g, Affine<F>* __restrict__ out, uint
   out[t] = scalar_mul(g, k).to_affine();
 }
 
-// returns the number of mismatching threads (0 = the two representations agree); group 1 = G1, 2 = G2
+// returns the number of mismatching threads (0 = the two representations agree); group 1 = G1, 2 = G2, 3 = G2 by lane pairs
 uint32_t selftest_fq29(int group, uint32_t threads, uint32_t iters, const uint8_t* g2_gen_xy_le) {
   require_gpu();
   const uint32_t NP = 1024;
@@ -462,6 +472,10 @@ uint32_t selftest_fq29(int group, uint32_t threads, uint32_t iters, const uint8_
     DevBuf<G2Affine29> p29(NP);
     hipLaunchKernelGGL(k_selftest_points<Fq2>, dim3(NP / 64), dim3(64), 0, 0, g, p.p, NP);
     hipLaunchKernelGGL((k_selftest_conv<G2Affine, G2Affine29>), dim3(NP / 64), dim3(64), 0, 0, p.p, p29.p, NP);
+    if (group == 3)   // the lane-pair form of the small batches' G2 chain (fq29.h: Fq2PairOps)
+      hipLaunchKernelGGL((k_selftest29<G2Affine, G2XYZZ, G2Affine29, G2AccPair29>), dim3(2 * threads / 64), dim3(64), 0, 0, p.p,
+                         p29.p, NP, iters, bad.p);
+    else
     hipLaunchKernelGGL((k_selftest29<G2Affine, G2XYZZ, G2Affine29, G2Acc29>), dim3(threads / 64), dim3(64), 0, 0, p.p,
                        p29.p, NP, iters, bad.p);
   }
