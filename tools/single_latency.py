@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 from zerokit_amd import workload  # noqa: E402
 from zerokit_amd.batch import BatchProver  # noqa: E402
 
-p = BatchProver(max_batch=64)
+p = BatchProver(max_batch=int(os.environ.get("MAXB", "64")))
 N = int(os.environ.get("N", "1"))   # proofs per batch
 ITER = int(os.environ.get("ITER", "8"))
 inp, rsb = workload.config2_packed(p.slots, p.inputs_size, 0, N)

@@ -48,7 +48,7 @@ struct ProverConfig {
 struct ProverTuning {
   // ---- sizes
   int window_bits = 120010;            // RLNAMD_WINDOW_BITS: comb schedule g1 + 10000 * g2, each c + 100 * wide;
-                                       // default G1 c = 10 (13 windows), G2 c = 12 (11 windows): 23 GiB, one proof 0.1 ms sooner than c = 8
+                                       // default G1 c = 10 (13 windows), G2 c = 12 (11 windows): 20 GiB, one proof 0.1 ms sooner than c = 8
   int slots = 5;                       // RLNAMD_SLOTS: workspace slots = batches in flight (2 .. 6)
   uint32_t lanechunk_max = 128;        // RLNAMD_LANECHUNK: largest batch that takes the small-batch (latency) shapes
   uint32_t lanechunk_walk_max = 48;    // RLNAMD_LANECHUNK_WALK: largest lone batch walked with lanes = chunks

@@ -31,7 +31,8 @@ struct TreeConfig {
   // prover sizing, keys of THIS backend in the same JSON object (the reference's PmTreeConfig::from_str picks its keys
   // out of a serde_json::Value and ignores the rest, so one config file serves both): "window_bits" = the comb schedule
   // of rlnamd_prover_new (7150114 = the 228 GiB bench schedule), "max_batch" = workspace capacity in proofs.
-  // 0 / absent: RLNAMD_WINDOW_BITS / RLNAMD_MAX_BATCH, else the small defaults (c = 8 tables, 64 proofs).
+  // 0 / absent: RLNAMD_WINDOW_BITS / RLNAMD_MAX_BATCH, else the defaults (20 GiB tables: G1 c = 10, G2 c = 12; 256 proofs --
+  // a single proof is as fast as with 64, a batch call streams at 15 k instead of 11 k proofs/s).
   long window_bits = 0, max_batch = 0;
   // "devices": [0, 1, ...] -- two or more entries put an rlnamd_pool (a prover replica + a host thread per listed device)
   // behind the object: ffi_generate_rln_proofs_batch then shards n > max_batch proofs over the devices by index
@@ -43,7 +44,7 @@ struct TreeConfig {
   ProverConfig prover_config() const {
     ProverConfig cfg;
     const char* mb = getenv("RLNAMD_MAX_BATCH");
-    cfg.max_batch = max_batch > 0 ? (size_t)max_batch : (mb && *mb ? (size_t)atoll(mb) : 64);
+    cfg.max_batch = max_batch > 0 ? (size_t)max_batch : (mb && *mb ? (size_t)atoll(mb) : 256);
     cfg.window_bits = window_bits > 0 ? (int)window_bits : 0;   // 0: Prover takes RLNAMD_WINDOW_BITS or its default schedule
     return cfg;
   }
