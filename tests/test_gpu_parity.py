@@ -225,6 +225,33 @@ def test_full_size_batch_1024_bit_exact_vs_c_oracle():
     p.close()
 
 
+def test_small_batch_sizes_across_the_shape_boundaries_vs_c_oracle():
+    """Every size at which the small-batch path changes shape (tiny plans with a lane pair per G2 point up to 4, lanes =
+    chunks up to 48 for a lone batch, lanes = proofs over the short chunks up to 128, the throughput shape above; compact
+    digit rows below, capacity-strided above), on the DEFAULT tables and through submit / collect: bit-identical to oracle/c"""
+    from oracle.c import binding as ob
+    from oracle.pyref import workload
+    from zerokit_amd.batch import BatchProver
+    nmax = 130
+    ws, rs = workload.config2_witnesses(nmax, seed=4242)
+    _, ref_proofs, ref_pub = ob.Circuit(20).prove_many(ws, rs)
+    p = BatchProver(max_batch=192)
+    try:
+        for n in (1, 2, 3, 4, 5, 15, 16, 17, 47, 48, 49, 64, 65, 96, 97, 128, 129, 130, 1):
+            inp, rsb = p.pack_inputs(ws[:n]), p.pack_rs(rs[:n])
+            t, _ = p.submit(inp, rsb)
+            out = p.collect(t, n)
+            assert all(o["error"] == 0 for o in out), n
+            assert [o["proof"] for o in out] == ref_proofs[:n], n
+            assert [o["public_inputs"] for o in out] == ref_pub[:n], n
+        # not alone on the device: three sizes enqueued back to back
+        ts = [p.submit(p.pack_inputs(ws[:n]), p.pack_rs(rs[:n]))[0] for n in (3, 40, 100)]
+        for t, n in zip(ts, (3, 40, 100)):
+            assert [o["proof"] for o in p.collect(t, n)] == ref_proofs[:n], n
+    finally:
+        p.close()
+
+
 def test_edge_case_witnesses_vs_c_oracle(prover):
     """boundary values of every input: zero / r-1 field elements, message_id = limit - 1, all-ones path index,
     r = 0 (g1_b = 0 branch), s = 0, r = s = r_mod - 1"""
