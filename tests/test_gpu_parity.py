@@ -226,7 +226,7 @@ def test_full_size_batch_1024_bit_exact_vs_c_oracle():
 
 
 def test_small_batch_sizes_across_the_shape_boundaries_vs_c_oracle():
-    """Every size at which the small-batch path changes shape (tiny plans with a lane pair per G2 point up to 4, lanes =
+    """Every size at which the small-batch path changes shape (tiny plans with a lane pair per G2 point up to 5, lanes =
     chunks up to 48 for a lone batch, lanes = proofs over the short chunks up to 128, the throughput shape above; compact
     digit rows below, capacity-strided above), on the DEFAULT tables and through submit / collect: bit-identical to oracle/c"""
     from oracle.c import binding as ob
@@ -237,7 +237,7 @@ def test_small_batch_sizes_across_the_shape_boundaries_vs_c_oracle():
     _, ref_proofs, ref_pub = ob.Circuit(20).prove_many(ws, rs)
     p = BatchProver(max_batch=192)
     try:
-        for n in (1, 2, 3, 4, 5, 15, 16, 17, 47, 48, 49, 64, 65, 96, 97, 128, 129, 130, 1):
+        for n in (1, 2, 3, 4, 5, 6, 15, 16, 17, 47, 48, 49, 64, 65, 96, 97, 128, 129, 130, 1):
             inp, rsb = p.pack_inputs(ws[:n]), p.pack_rs(rs[:n])
             t, _ = p.submit(inp, rsb)
             out = p.collect(t, n)

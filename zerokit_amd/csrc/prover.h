@@ -53,7 +53,7 @@ struct ProverTuning {
   uint32_t lanechunk_max = 128;        // RLNAMD_LANECHUNK: largest batch that takes the small-batch (latency) shapes
   uint32_t lanechunk_walk_max = 48;    // RLNAMD_LANECHUNK_WALK: largest lone batch walked with lanes = chunks
   uint32_t witlanes_max = 256;         // RLNAMD_WITLANES_MAX: largest lone batch interpreted with lanes = nodes
-  uint32_t tiny_max = 4;               // RLNAMD_TINY: largest lone batch walked with ONE (row, half) per lane (0: never)
+  uint32_t tiny_max = 5;               // RLNAMD_TINY: largest lone batch walked with ONE (row, half) per lane (0: never); 5 proofs 3.15 -> 3.0 ms, 6 even, 8 slower
   // ---- shapes (1 = default)
   bool glv = true;                     // RLNAMD_GLV: walk the 127-bit GLV halves (0: the plain 255-bit walk)
   bool wit29 = true;                   // RLNAMD_WIT29: interpreter in the 9 x 29 form (0: the 8 x 32 fallback k_witness)
