@@ -433,6 +433,25 @@ def test_persistent_tree_config(tmp_path):
     assert r.leaves_set() == 0
 
 
+def test_profile_key_names_an_operating_point(tmp_path):
+    """{"profile": "small"} = window_bits 8 / max_batch 64; explicit keys override what the profile implies; no key = the
+    defaults (G1 c = 10, G2 c = 12, 256 proofs)"""
+    import json
+    from zerokit_amd.public import RLN
+    cfgp = tmp_path / "cfg.json"
+    cfgp.write_text(json.dumps({"profile": "small"}))
+    info = RLN(20, tree_config=str(cfgp)).prover_info()
+    assert (int(info.capacity), int(info.window_bits), int(info.window_bits_g2)) == (64, 8, 8)
+    cfgp.write_text(json.dumps({"profile": "small", "max_batch": 128, "window_bits": 90009}))
+    info = RLN(20, tree_config=str(cfgp)).prover_info()
+    assert (int(info.capacity), int(info.window_bits), int(info.window_bits_g2)) == (128, 9, 9)
+    cfgp.write_text(json.dumps({"profile": "latency"}))
+    info = RLN(20, tree_config=str(cfgp)).prover_info()
+    assert (int(info.capacity), int(info.window_bits), int(info.window_bits_g2)) == (256, 10, 12)
+    info = RLN(20).prover_info()
+    assert (int(info.capacity), int(info.window_bits), int(info.window_bits_g2)) == (256, 10, 12)
+
+
 def test_config_path_sizes_the_prover_and_batch_streams_past_max_batch(tmp_path):
     """the `window_bits` / `max_batch` keys of the config_path JSON (beside the PmTreeConfig keys of
     pm_tree_adapter.rs:139-174, which stay honoured) size the prover behind ffi_rln_new, and

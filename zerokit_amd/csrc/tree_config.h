@@ -34,6 +34,13 @@ struct TreeConfig {
   // 0 / absent: RLNAMD_WINDOW_BITS / RLNAMD_MAX_BATCH, else the defaults (20 GiB tables: G1 c = 10, G2 c = 12; 256 proofs --
   // a single proof is as fast as with 64, a batch call streams at 15 k instead of 11 k proofs/s).
   long window_bits = 0, max_batch = 0;
+  // "profile": a name for the two numbers above, so that a caller need not know the schedule's encoding --
+  //   "latency"     the defaults (20 GiB of tables, 256 proofs of workspace): one proof 2.6 ms, batch calls 15 k proofs/s
+  //   "throughput"  the bench's operating point (window_bits 7150114: 228 GiB; max_batch 1024): batch calls 21 k proofs/s,
+  //                 5 - 7 s to build, nothing else of that size fits the device
+  //   "small"       window_bits 8, max_batch 64: 7.7 GiB, one proof 2.7 ms, batch calls 9 k proofs/s
+  // explicit "window_bits" / "max_batch" keys override what the profile implies; any other name is a configuration error.
+  std::string profile;
   // "devices": [0, 1, ...] -- two or more entries put an rlnamd_pool (a prover replica + a host thread per listed device)
   // behind the object: ffi_generate_rln_proofs_batch then shards n > max_batch proofs over the devices by index
   // (BASELINE config 4: 65 536 = 8 x 8 192).  Everything else -- single proofs, the tree, verification -- runs on the
@@ -44,8 +51,11 @@ struct TreeConfig {
   ProverConfig prover_config() const {
     ProverConfig cfg;
     const char* mb = getenv("RLNAMD_MAX_BATCH");
-    cfg.max_batch = max_batch > 0 ? (size_t)max_batch : (mb && *mb ? (size_t)atoll(mb) : 256);
-    cfg.window_bits = window_bits > 0 ? (int)window_bits : 0;   // 0: Prover takes RLNAMD_WINDOW_BITS or its default schedule
+    long pw = 0, pb = 0;   // what the profile implies
+    if (profile == "throughput") { pw = 7150114; pb = 1024; }
+    else if (profile == "small") { pw = 8; pb = 64; }
+    cfg.max_batch = max_batch > 0 ? (size_t)max_batch : pb > 0 ? (size_t)pb : (mb && *mb ? (size_t)atoll(mb) : 256);
+    cfg.window_bits = window_bits > 0 ? (int)window_bits : (int)pw;   // 0: Prover takes RLNAMD_WINDOW_BITS or its default schedule
     return cfg;
   }
 };
@@ -88,6 +98,11 @@ inline TreeConfig parse_tree_config(const std::string& js) {
     if (js[i] == '"') {
       std::string v = str();
       if (key == "path") { c.path = v; c.has_path = true; }
+      if (key == "profile") {
+        if (v != "latency" && v != "throughput" && v != "small")
+          throw Error("Configuration error: profile: expected \"latency\", \"throughput\" or \"small\", got \"" + v + "\"");
+        c.profile = v;
+      }
     } else if (!js.compare(i, 4, "true") || !js.compare(i, 5, "false")) {
       bool v = js[i] == 't';
       i += v ? 4 : 5;
