@@ -585,7 +585,6 @@ def test_lane_chunk_walk_and_clock_tap(monkeypatch):
 @pytest.mark.parametrize("env", [
     {"RLNAMD_LONE": "0"},             # as inside a stream of batches: plain small plan, back end on its own stream
     {"RLNAMD_LONE": "1"},
-    {"RLNAMD_NTT_LDS": "0"},        # radix-8 passes only
     {"RLNAMD_VALUES_WITNESS": "0"},   # proof values by the Poseidon chain instead of the circuit's public signals
     {"RLNAMD_WL_REASSOC": "0"},       # the interpreter's schedule with the circuit's sums in source order
     {"RLNAMD_WITROWS": "0"},          # lane-form products
@@ -607,7 +606,7 @@ def test_small_batch_shape_variants_give_the_golden_bytes(monkeypatch, env):
     p = BatchProver(max_batch=64)
     try:
         # the switches are read once, when the prover is built, and rlnamd_prover_describe reports the values in force
-        names = {"RLNAMD_LONE": "lone", "RLNAMD_NTT_LDS": "ntt_lds", "RLNAMD_VALUES_WITNESS": "values_from_witness",
+        names = {"RLNAMD_LONE": "lone", "RLNAMD_VALUES_WITNESS": "values_from_witness",
                  "RLNAMD_EARLY_FIN": "early_fin", "RLNAMD_FUSED_SMUL": "fused_smul", "RLNAMD_LANECHUNK_WALK": "lanechunk_walk",
                  "RLNAMD_TINY": "tiny"}
         desc = p.describe().split()

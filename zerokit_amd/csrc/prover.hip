@@ -228,7 +228,6 @@ ProverTuning ProverTuning::from_env() {
   t.early_fin = env_int("RLNAMD_EARLY_FIN", 1) != 0;
   t.fused_smul = env_int("RLNAMD_FUSED_SMUL", 1) != 0;
   t.values_from_witness = env_int("RLNAMD_VALUES_WITNESS", 1) != 0;
-  t.ntt_lds = env_int("RLNAMD_NTT_LDS", 1) != 0;
   t.tiny_max = (uint32_t)std::max(0, env_int("RLNAMD_TINY", (int)t.tiny_max));
   t.marks_small = env_int("RLNAMD_MARKS_SMALL", 0) != 0;
   return t;
@@ -237,9 +236,9 @@ std::string ProverTuning::describe() const {
   char b[512];
   snprintf(b, sizeof b,
            "window_bits=%d slots=%d lanechunk=%u lanechunk_walk=%u witlanes_max=%u tiny=%u glv=%d wit29=%d lone=%d early_walk=%d "
-           "early_fin=%d fused_smul=%d values_from_witness=%d ntt_lds=%d marks_small=%d",
+           "early_fin=%d fused_smul=%d values_from_witness=%d marks_small=%d",
            window_bits, slots, lanechunk_max, lanechunk_walk_max, witlanes_max, tiny_max, (int)glv, (int)wit29, lone, (int)early_walk,
-           (int)early_fin, (int)fused_smul, (int)values_from_witness, (int)ntt_lds, (int)marks_small);
+           (int)early_fin, (int)fused_smul, (int)values_from_witness, (int)marks_small);
   return b;
 }
 const ProverTuning& Prover::tuning() const { return d_->tune; }
@@ -1079,21 +1078,8 @@ void Prover::upload_witness(size_t n, const uint8_t* w_le) {
 }
 
 template <bool DIF>
-static void launch_ntt(Fr* data, const Fr* tw, int logn, const Fr* final_scale, uint32_t B, uint32_t nb, hipStream_t s,
-                       bool lanes_are_groups) {
+static void launch_ntt(Fr* data, const Fr* tw, int logn, const Fr* final_scale, uint32_t B, uint32_t nb, hipStream_t s) {
   int s0 = 0;
-  while (lanes_are_groups && s0 < logn) {   // small batch: blockIdx.x = proof, lanes = groups (radix-8 passes + a radix-2 tail)
-    const int rem = logn - s0, K = rem >= 3 ? 3 : 1;
-    const uint32_t groups = (1u << logn) >> K;
-    dim3 block(64, 1), grid(nb, div_up(groups, 64), 3);
-    const Fr* sc = (s0 + K == logn) ? final_scale : nullptr;
-    if (K == 3)
-      hipLaunchKernelGGL((k_ntt_pass<3, DIF, true>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb);
-    else
-      hipLaunchKernelGGL((k_ntt_pass<1, DIF, true>), grid, block, 0, s, data, tw, logn, s0, sc, B, nb);
-    RLN_HIP(hipGetLastError());
-    s0 += K;
-  }
   while (s0 < logn) {
     const int rem = logn - s0;
     const int K = rem > 3 ? 3 : rem;  // 13 -> 3,3,3,3,1 (a 16-point block spills; measured 6.7 -> 5.0 ms)
@@ -1395,7 +1381,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   MARK(3, sA2);
   if (mode != PROVE_PARTIAL) {
     const bool lg = nb <= D.lanechunk_max;   // below a wave of proofs: lanes = groups
-    if (lg && T.ntt_lds && D.logn >= 9 && D.logn <= 18) {
+    if (lg && D.logn >= 9 && D.logn <= 18) {
       // iNTT, coset scaling and NTT as edge / mid / edge: one butterfly per lane per level (prover_front.hip: k_ntt_mid)
       const dim3 grid(nb, D.n >> 9, 3);
       if (D.logn > 9) hipLaunchKernelGGL(k_ntt_edge<true>, grid, dim3(256), 0, sA2, S.abc.p, D.tw_i.p, D.logn, B, nb);
@@ -1403,8 +1389,8 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
       if (D.logn > 9) hipLaunchKernelGGL(k_ntt_edge<false>, grid, dim3(256), 0, sA2, S.abc.p, D.tw_f.p, D.logn, B, nb);
       RLN_HIP(hipGetLastError());
     } else {
-      launch_ntt<true>(S.abc.p, D.tw_i.p, D.logn, D.coset.p, B, lg ? nb : nbp, sA2, lg);   // iNTT (DIF) + g^i / n
-      launch_ntt<false>(S.abc.p, D.tw_f.p, D.logn, nullptr, B, lg ? nb : nbp, sA2, lg);    // NTT (DIT)
+      launch_ntt<true>(S.abc.p, D.tw_i.p, D.logn, D.coset.p, B, nbp, sA2);   // iNTT (DIF) + g^i / n
+      launch_ntt<false>(S.abc.p, D.tw_f.p, D.logn, nullptr, B, nbp, sA2);    // NTT (DIT)
     }
     if (nb <= D.lanechunk_max)
       hipLaunchKernelGGL(k_hquot, dim3(div_up(D.n, 64), nb), dim3(64, 1), 0, sA2, S.abc.p, D.n, B, nb, 1u);

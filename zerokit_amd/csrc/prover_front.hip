@@ -420,10 +420,9 @@ __global__ void __launch_bounds__(256) k_consts_to29(const Fr* __restrict__ src,
 #pragma unroll
   for (int k = 0; k < 9; k++) dst[(size_t)t * 9 + k] = v.v[k];
 }
-// LG (small batches): lanes = groups of ONE proof (blockIdx.x = proof) instead of lanes = proofs -- a single proof then
-// fills its waves (3 072 eight-point blocks = 48 waves per pass) instead of running 3 072 waves with one useful lane each
-// (all ten passes of one proof 0.78 -> see profiles/r3); twiddle indices become per-lane values.
-template <int K, bool DIF, bool LG>
+// (Small batches do not come here: k_ntt_edge / k_ntt_mid below; a circuit with fewer than 512 constraints would, with its
+// proofs in the lanes like any batch.)
+template <int K, bool DIF>
 __global__ void __launch_bounds__(256, RLN_NTT_WAVES) k_ntt_pass(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0,
                                                   const Fr* __restrict__ scale, uint32_t B, uint32_t nb) {
   // (twiddle products through Fr29::mul_mont -- ~290 instead of ~375 instructions -- were measured neutral twice: beside the
@@ -431,10 +430,9 @@ __global__ void __launch_bounds__(256, RLN_NTT_WAVES) k_ntt_pass(Fr* __restrict_
   auto tmul = [&](const Fr& a, const Fr* __restrict__ tab, uint32_t idx) -> Fr { return a * tab[idx]; };
   constexpr int R = 1 << K;
   const uint32_t n = 1u << logn;
-  auto uni = [](uint32_t v) -> uint32_t { return LG ? v : __builtin_amdgcn_readfirstlane(v); };
-  uint32_t p = LG ? blockIdx.x : blockIdx.x * 64 + threadIdx.x;
-  uint32_t g = LG ? blockIdx.y * 64 + threadIdx.x
-                  : __builtin_amdgcn_readfirstlane(blockIdx.y * blockDim.y + threadIdx.y);  // one group per wave
+  auto uni = [](uint32_t v) -> uint32_t { return __builtin_amdgcn_readfirstlane(v); };
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  uint32_t g = __builtin_amdgcn_readfirstlane(blockIdx.y * blockDim.y + threadIdx.y);  // one group per wave
   if (g >= (n >> K)) return;
   if (p >= nb) return;
   Fr* x = data + (size_t)blockIdx.z * n * B + p;
@@ -700,16 +698,12 @@ __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ V, const 
 template __global__ void k_witness29<false>(const GNode29* __restrict__ nodes, uint32_t n_nodes, const uint32_t* __restrict__ consts29, uint32_t n_consts, const uint32_t* __restrict__ inputs, uint32_t n_inputs, uint4* __restrict__ V29, uint32_t* __restrict__ err, uint32_t B, uint32_t nb, unsigned long long* __restrict__ prof);
 template __global__ void k_matvec<true>(CsrView A, CsrView Bm, const Fr* __restrict__ V, const uint32_t* __restrict__ sig2node, uint32_t nc, uint32_t ni, uint32_t n, Fr* __restrict__ abc, uint32_t B, uint32_t nb, const uint32_t* __restrict__ long_rows, uint32_t nshort);
 template __global__ void k_matvec<false>(CsrView A, CsrView Bm, const Fr* __restrict__ V, const uint32_t* __restrict__ sig2node, uint32_t nc, uint32_t ni, uint32_t n, Fr* __restrict__ abc, uint32_t B, uint32_t nb, const uint32_t* __restrict__ long_rows, uint32_t nshort);
-template __global__ void k_ntt_pass<1, true, false>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0, const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
-template __global__ void k_ntt_pass<1, false, false>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0, const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
-template __global__ void k_ntt_pass<2, true, false>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0, const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
-template __global__ void k_ntt_pass<2, false, false>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0, const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
-template __global__ void k_ntt_pass<3, true, false>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0, const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
-template __global__ void k_ntt_pass<3, false, false>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0, const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
-template __global__ void k_ntt_pass<1, true, true>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0, const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
-template __global__ void k_ntt_pass<1, false, true>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0, const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
-template __global__ void k_ntt_pass<3, true, true>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0, const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
-template __global__ void k_ntt_pass<3, false, true>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0, const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
+template __global__ void k_ntt_pass<1, true>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0, const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
+template __global__ void k_ntt_pass<1, false>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0, const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
+template __global__ void k_ntt_pass<2, true>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0, const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
+template __global__ void k_ntt_pass<2, false>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0, const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
+template __global__ void k_ntt_pass<3, true>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0, const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
+template __global__ void k_ntt_pass<3, false>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0, const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
 template __global__ void k_ntt_edge<true>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, uint32_t B, uint32_t nb);
 template __global__ void k_ntt_edge<false>(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, uint32_t B, uint32_t nb);
 

@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) k_matvec(CsrView A, CsrView Bm, const Fr*
                                                 uint32_t n, Fr* __restrict__ abc, uint32_t B, uint32_t nb,
                                                 const uint32_t* __restrict__ long_rows = nullptr, uint32_t nshort = 0);
 __global__ void __launch_bounds__(256) k_consts_to29(const Fr* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n);
-template <int K, bool DIF, bool LG = false>
+template <int K, bool DIF>
 __global__ void __launch_bounds__(256, RLN_NTT_WAVES) k_ntt_pass(Fr* __restrict__ data, const Fr* __restrict__ tw, int logn, int s0,
                                                   const Fr* __restrict__ scale, uint32_t B, uint32_t nb);
 __global__ void __launch_bounds__(256) k_ntt_mid(Fr* __restrict__ data, const Fr* __restrict__ tw_i,
