@@ -1335,11 +1335,10 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   const bool early_g2 = early;
   RLN_HIP(hipEventRecord(S.evX, sA));   // mat-vec / NTT (sA2) need the witness, not the recodes below
   if (early) {
-    // on the walks' own stream: mat-vec and the NTTs (sA) start at once, beside the recodes instead of behind them
-    // The G2 chain (recode, walk, sum, inversion: 1.3 ms for one proof) is the longest thing behind the interpreter and
-    // every cross-stream hop costs it 50 - 100 us, so it runs on ONE stream (sB2); the G1 walk's stream takes the hop.
-    // (A lone batch; in a stream of batches the recodes stay on the front-end stream, where they do not queue behind the
-    // previous batch's walks.)
+    // The witness digits right behind the interpreter, on its stream.  A lone batch keeps its whole G2 chain there
+    // (g2_on_front above); the early G1 walk (sB) and the quotient chain (sA2) take one cross-stream hop each.  In a stream
+    // of batches the recodes stay on the front-end stream too, where they do not queue behind the previous batch's walks,
+    // and both walks wait for them on their own streams.
     hipStream_t sR1 = sA, sR3 = lone ? D.sB : sA;
     hipLaunchKernelGGL(k_recode, dim3(div_up(D.NS + 3, 64), nb), dim3(64, 1), 0, sR1, S.V.p, D.sig2node.p, D.NS,
                        S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nb, 1u, 1u, dB);
@@ -1417,7 +1416,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // small batches walk with lanes = chunks (walk29.h); ProverTuning::lanechunk_max is the threshold
   const bool lanechunk = nb <= D.lanechunk_max;
   hipStream_t s2 = g2_on_front ? sA : D.sB2;   // the G2 walk on its own stream: its workgroups fill the G1 kernel's tail
-  if (!early) {   // (early: sB2 already waits for the witness + part-1 digits, all the G2 walk reads)
+  if (!early) {   // (early: the G2 walk's stream already has the witness + part-1 digits, all it reads)
     RLN_HIP(hipEventRecord(S.evR, D.sB));
     RLN_HIP(hipStreamWaitEvent(D.sB2, S.evR, 0));
   }
@@ -1489,7 +1488,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
                        poseidon_view(3), poseidon_view(4), S.values.p, nbp);
   MARK(13, sV);
   // Small full proofs: A and B1 are sums over h-independent rows only, so their reduction, the two inversions and the two
-  // variable-base products s A, r B1 (the longest kernel of the back end) run on the idle sA2 as soon as the early G1
+  // variable-base products s A, r B1 (the longest kernel of the back end) run on the idle D.sA2 as soon as the early G1
   // walk is done -- beside the NTTs and the walk of the h rows, not behind them.  sums1 segments: h * 3 + {A, B1, C}.
   const bool early_fin = early && mode == PROVE_FULL && D.nh == 2 && T.early_fin;
   const TaskSel all6 = task_sel({0, 1, 2, 3, 4, 5}), all4 = task_sel({0, 1, 2, 3}), all3 = task_sel({0, 1, 2});
