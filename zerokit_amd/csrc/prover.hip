@@ -1391,7 +1391,9 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
       launch_ntt<true>(S.abc.p, D.tw_i.p, D.logn, D.coset.p, B, nbp, sA2);   // iNTT (DIF) + g^i / n
       launch_ntt<false>(S.abc.p, D.tw_f.p, D.logn, nullptr, B, nbp, sA2);    // NTT (DIT)
     }
-    if (nb <= D.lanechunk_max)
+    if (early_g2) {
+      // (the recode below forms h = a o b - c itself)
+    } else if (nb <= D.lanechunk_max)
       hipLaunchKernelGGL(k_hquot, dim3(div_up(D.n, 64), nb), dim3(64, 1), 0, sA2, S.abc.p, D.n, B, nb, 1u);
     else
       hipLaunchKernelGGL(k_hquot, dim3(pg, D.n), dim3(64, 1), 0, sA2, S.abc.p, D.n, B, nbp, 0u);
@@ -1402,7 +1404,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   MARK(5, sR);
   if (early_g2)
     hipLaunchKernelGGL(k_recode, dim3(div_up(D.n, 64), nb), dim3(64, 1), 0, sR, S.V.p, D.sig2node.p, D.NS, S.abc.p, D.n,
-                       rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nb, 2u, 1u, dB);
+                       rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nb, 2u, 2u, dB);
   else
     hipLaunchKernelGGL(k_recode, dim3(pg, D.NS + D.n + 3), dim3(64, 1), 0, sR, S.V.p, D.sig2node.p, D.NS,
                        S.abc.p, D.n, rs_p, D.ws, D.ws2, D.nh, S.digits.p, S.digits2.p, B, nbp, 0u, 0u, dB);

@@ -621,7 +621,7 @@ __device__ __forceinline__ void emit_digits(uint32_t* l, bool neg, const WinSche
 // schedule for all of them; dig2 the G2 schedule for the ones the G2 walk uses (witness, r, s, -(r s): id - n).
 // nh = 2: every scalar is split as k1 + lambda k2 (glv.h) and both halves are recoded; nh = 1: the plain 254-bit walk.
 __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ V, const uint32_t* __restrict__ sig2node,
-                                                uint32_t ns, const Fr* __restrict__ H, uint32_t n,
+                                                uint32_t ns, const Fr* H, uint32_t n,
                                                 const uint32_t* __restrict__ rs, WinSched ws1, WinSched ws2, uint32_t nh,
                                                 int16_t* __restrict__ dig1, int16_t* __restrict__ dig2, uint32_t B,
                                                 uint32_t nb, uint32_t part, uint32_t lg, uint32_t dB) {
@@ -658,7 +658,11 @@ __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ V, const 
   } else if (sid < ns) {
     x = V[(size_t)sig2node[sid] * B + p];
   } else if (sid < ns + n) {
-    x = H[(size_t)(sid - ns) * B + p];
+    const size_t o = (size_t)(sid - ns) * B + p;
+    // lg == 2 (small batches): the quotient on the fly, h = a o b - c (k_hquot's line: same products, same bytes) -- one
+    // kernel and one boundary less on the chain the h rows wait for
+    x = lg == 2 ? H[o] * H[(size_t)n * B + o] - H[2 * (size_t)n * B + o] : H[o];
+    if (lg == 2) const_cast<Fr*>(H)[o] = x;   // where k_hquot leaves it (Prover::fetch_h reads it there); one lane per element
   } else {
     Fr r = Fr::from_canonical(rs + (size_t)p * 16);
     Fr s = Fr::from_canonical(rs + (size_t)p * 16 + 8);

@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) k_ntt_edge(Fr* __restrict__ data, const F
                                                   uint32_t nb);
 __global__ void __launch_bounds__(256) k_hquot(Fr* __restrict__ abc, uint32_t n, uint32_t B, uint32_t nb, uint32_t lg);
 __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ V, const uint32_t* __restrict__ sig2node,
-                                                uint32_t ns, const Fr* __restrict__ H, uint32_t n,
+                                                uint32_t ns, const Fr* H, uint32_t n,
                                                 const uint32_t* __restrict__ rs, WinSched ws1, WinSched ws2, uint32_t nh,
                                                 int16_t* __restrict__ dig1, int16_t* __restrict__ dig2, uint32_t B,
                                                 uint32_t nb, uint32_t part, uint32_t lg, uint32_t dB);
