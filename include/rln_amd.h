@@ -198,7 +198,7 @@ int rlnamd_msm_new(size_t capacity, rlnamd_msm** out);
 void rlnamd_msm_free(rlnamd_msm* m);
 /* Device self-test: the 9 x 29-bit-limb group law the MSM walks use (csrc/fq29.h) against the 8 x 32-bit one on
  * `threads` pseudo-random walks of `iters` signed additions each (doublings, cancellations, restarts from infinity
- * included).  group 1 = G1, 2 = G2, 3 = G2 computed by lane pairs (g2_gen_xy_le = generator x.c0 | x.c1 | y.c0 | y.c1,
+ * included).  group 1 = G1, 2 = G2, 3 = G2 computed by lane pairs, 4 = G1 general additions by lane pairs (g2_gen_xy_le = generator x.c0 | x.c1 | y.c0 | y.c1,
  * canonical LE; NULL for G1).
  * *mismatches = number of walks whose affine results differ (0 expected). */
 /* Parameter self-check, host only (no device, not a hashing path): derives the Poseidon parameters for `arity`

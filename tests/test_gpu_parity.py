@@ -687,6 +687,9 @@ def test_fq29_group_law_matches_the_8x32_group_law_on_device():
     bad = C.c_uint32(123)
     check(lib().rlnamd_selftest_fq29(3, 4096, 48, g2, C.byref(bad)))   # a lane pair per point (Fq2PairOps), incl. its loads / stores
     assert bad.value == 0
+    bad = C.c_uint32(123)
+    check(lib().rlnamd_selftest_fq29(4, 8192, 0, None, C.byref(bad)))   # G1 general additions by lane pairs (G1AccPair29)
+    assert bad.value == 0
 
 
 def _golden_batch(p, cases, ws, rs, tag):

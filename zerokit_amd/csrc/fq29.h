@@ -468,6 +468,118 @@ struct G1Acc29 {
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// G1 general addition by a lane PAIR (the sum trees of a lone proof: a level is one addition of a lone lane, all issue
+// latency).  Both lanes hold the whole point; the fourteen products of add-2008-s are dealt to the two lanes level by
+// level (lane 2 t the U / P / PPP / ZZZ side, lane 2 t + 1 the S / R / Q / ZZ / X3 / Y3 side), six product levels and the
+// Y3 dot product instead of fourteen products in a row; what the other side needs crosses by DPP (quad_perm [1, 0, 3, 2]).
+// Every product takes the operands G1Acc29::add gives it (R^2 + kT as mul_add(R, R, kT): the column sums of sqr_add), so
+// the bounds and the field elements are the same; a lane's idle slots compute on operands of the same classes.
+// Both lanes of a pair must take the same branches: they test the same values.
+struct G1AccPair29 {
+  Fq29 X, Y, ZZ, ZZZ;
+  static constexpr uint32_t LPP = 2;
+  static __device__ __forceinline__ bool odd() { return (threadIdx.x & 1u) != 0; }
+  static __device__ __forceinline__ Fq29 swap(const Fq29& v) {
+    Fq29 r;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.v[j], 0xB1, 0xF, 0xF, true);
+      asm volatile("" : "+v"(t));   // (see Fq2PairOps::join)
+      r.v[j] = t;
+    }
+    return r;
+  }
+  static __device__ __forceinline__ Fq29 pick(bool o, const Fq29& if_odd, const Fq29& if_even) {
+    Fq29 r;
+#pragma unroll
+    for (int j = 0; j < 9; j++) r.v[j] = o ? if_odd.v[j] : if_even.v[j];
+    return r;
+  }
+  static __device__ __forceinline__ G1AccPair29 inf() { return {Fq29::zero(), Fq29::zero(), Fq29::zero(), Fq29::zero()}; }
+  __device__ __forceinline__ bool is_inf() const { return ZZ.limbs_all_zero(); }
+  __device__ __forceinline__ G1XYZZ to_xyzz() const {
+    if (is_inf()) return G1XYZZ::inf();
+    return {X.to_fq(), Y.to_fq(), ZZ.to_fq(), ZZZ.to_fq()};
+  }
+  static __device__ __forceinline__ G1AccPair29 from_xyzz(const G1XYZZ& p) {
+    if (p.is_inf()) return inf();
+    return {Fq29::from_fq(p.X), Fq29::from_fq(p.Y), Fq29::from_fq(p.ZZ), Fq29::from_fq(p.ZZZ)};
+  }
+  // in and out of the common form: lane 2 t converts X and Y, lane 2 t + 1 ZZ and ZZZ
+  static __device__ __forceinline__ G1AccPair29 load_xyzz(const G1XYZZ* src) {
+    const bool o = odd();
+    const Fq29 a = Fq29::from_fq(o ? src->ZZ : src->X), b = Fq29::from_fq(o ? src->ZZZ : src->Y);
+    const Fq29 xa = swap(a), xb = swap(b);
+    return {pick(o, xa, a), pick(o, xb, b), pick(o, a, xa), pick(o, b, xb)};   // (infinity: ZZ = 0 converts to all-zero limbs)
+  }
+  __device__ __forceinline__ void store_xyzz(G1XYZZ* dst) const {
+    const bool o = odd(), z = is_inf();
+    const Fq a = z ? Fq::zero() : pick(o, ZZ, X).to_fq(), b = z ? Fq::zero() : pick(o, ZZZ, Y).to_fq();
+    *(o ? &dst->ZZ : &dst->X) = a;
+    *(o ? &dst->ZZZ : &dst->Y) = b;
+  }
+  __device__ __forceinline__ void store_lds(G1AccPair29* dst) const {
+    if (odd()) {
+      dst->ZZ = ZZ;
+      dst->ZZZ = ZZZ;
+    } else {
+      dst->X = X;
+      dst->Y = Y;
+    }
+  }
+  __device__ __forceinline__ void add(const G1AccPair29& o) {
+    if (o.is_inf()) return;
+    if (is_inf()) {
+      *this = o;
+      return;
+    }
+    const bool r = odd();
+    // level 1, 2:  U1 = X oZZ | S1 = Y oZZZ ;  U2 = oX ZZ | S2 = oY ZZZ ;  d = P | R
+    const Fq29 t1 = Fq29::mul(pick(r, Y, X), pick(r, o.ZZZ, o.ZZ));
+    const Fq29 t2 = Fq29::mul(pick(r, o.Y, o.X), pick(r, ZZZ, ZZ));
+    const Fq29 d = Fq29::sub(t2, Fq29C::K2, t1);          // P | R, in (0.9 q, 3.1 q), normalised
+    {
+      const Fq29 xd = swap(d);
+      const Fq29 P = pick(r, xd, d);
+      if (P.is_zero_mod_q()) {   // same x: doubling / cancellation, through the 8 x 32 law (both lanes, in full)
+        add_same_x(this, &o);
+        return;
+      }
+    }
+    // level 3:  PP = P P | ZZt = ZZ oZZ
+    const Fq29 t3 = Fq29::mul(pick(r, ZZ, d), pick(r, o.ZZ, d));
+    const Fq29 xU1 = swap(t1), xPP = swap(t3);
+    // level 4:  PPP = P PP | Q = U1 PP
+    const Fq29 t4 = Fq29::mul(pick(r, xU1, d), pick(r, xPP, t3));
+    // level 5:  ZZZt = ZZZ oZZZ | ZZ3 = ZZt PP
+    const Fq29 t5 = Fq29::mul(pick(r, t3, ZZZ), pick(r, xPP, o.ZZZ));
+    const Fq29 xPPP = swap(t4);
+    // level 6:  ZZZ3 = ZZZt PPP | X3 = R R + K4T - PPP - 2 Q
+    Fq29 kT;
+#pragma unroll
+    for (int j = 0; j < 9; j++) kT.v[j] = r ? Fq29C::K4T[j] - (xPPP.v[j] + 2 * t4.v[j]) : 0u;
+    const Fq29 t6 = Fq29::mul_add(pick(r, d, t5), pick(r, d, t4), kT);
+    // level 7 (the odd lane's; the even lane computes on operands of the same classes and drops the result):
+    //   Y3 = R (Q + K6 - X3) + (K4 - S1) PPP
+    Fq29 D;
+#pragma unroll
+    for (int j = 0; j < 9; j++) D.v[j] = t4.v[j] + Fq29C::K6[j] - t6.v[j];
+    const Fq29 nS1 = Fq29::neg_lazy(Fq29C::K4, t1);
+    const Fq29 t7 = Fq29::dot2(d, D, nS1, xPPP);
+    const Fq29 x5 = swap(t5), x6 = swap(t6), x7 = swap(t7);
+    X = pick(r, t6, x6);
+    Y = pick(r, t7, x7);
+    ZZ = pick(r, t5, x5);
+    ZZZ = pick(r, x6, t6);
+  }
+  static __device__ __noinline__ void add_same_x(G1AccPair29* self, const G1AccPair29* o) {
+    G1XYZZ a = self->to_xyzz();
+    a.add(o->to_xyzz());
+    *self = from_xyzz(a);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
 // G2: Fq2 = Fq[u]/(u^2 + 1) over Fq29.  Same lazy bounds as G1, component-wise.
 struct Fq2_29 {
   Fq29 c0, c1;

@@ -434,6 +434,39 @@ __global__ void __launch_bounds__(64) k_selftest29(const Aff* __restrict__ pts, 
     if (!(x.x == z.x) || !(x.y == z.y)) atomicAdd(bad, 1u);
   }
 }
+// G1AccPair29 (the lane-pair general addition of the small batches' G1 sum trees) against G1Acc29::add: sums of a few
+// table points added to each other, to themselves (doubling), to their negatives (cancellation) and to infinity, and the
+// pair form's one-coordinate-pair-per-lane loads and stores
+__global__ void __launch_bounds__(64) k_selftest_pair_g1(const G1Affine29* __restrict__ pts29, uint32_t npts, uint32_t* __restrict__ bad) {
+  const uint32_t t = (blockIdx.x * 64 + threadIdx.x) / 2;
+  uint32_t st = t * 2654435761u + 777u;
+  auto next = [&]() { st = st * 1664525u + 1013904223u; return (st >> 8) % npts; };
+  G1Acc29 u = G1Acc29::inf(), v = G1Acc29::inf();
+  const uint32_t k1 = next(), k2 = next(), k3 = next(), k4 = next(), k5 = next();
+  u.madd(pts29[k1], false);
+  u.madd(pts29[k2], true);
+  u.madd(pts29[k3], false);
+  const uint32_t kind = t % 5;
+  if (kind == 0) { v.madd(pts29[k4], false); v.madd(pts29[k5], true); }                                      // generic
+  else if (kind == 1) { v.madd(pts29[k1], false); v.madd(pts29[k2], true); v.madd(pts29[k3], false); }     // v = u: doubling
+  else if (kind == 2) { v.madd(pts29[k1], true); v.madd(pts29[k2], false); v.madd(pts29[k3], true); }      // v = -u: cancellation
+  else if (kind == 3) { u = G1Acc29::inf(); v.madd(pts29[k4], false); }                                      // infinity + v
+  // kind 4: u + infinity
+  const G1XYZZ ux = u.to_xyzz(), vx = v.to_xyzz();
+  G1AccPair29 pu = G1AccPair29::from_xyzz(ux), pv = G1AccPair29::from_xyzz(vx);
+  u.add(v);
+  pu.add(pv);
+  const G1Affine want = u.to_xyzz().to_affine(), got = pu.to_xyzz().to_affine();
+  if (!(want.x == got.x) || !(want.y == got.y)) atomicAdd(bad, 1u);
+  __shared__ G1XYZZ box[32];
+  __shared__ G1AccPair29 lbox[32];
+  pu.store_xyzz(&box[threadIdx.x / 2]);
+  pu.store_lds(&lbox[threadIdx.x / 2]);
+  __builtin_amdgcn_wave_barrier();
+  const G1Affine a1 = G1AccPair29::load_xyzz(&box[threadIdx.x / 2]).to_xyzz().to_affine();
+  const G1Affine a2 = lbox[threadIdx.x / 2].to_xyzz().to_affine();
+  if (!(want.x == a1.x) || !(want.y == a1.y) || !(want.x == a2.x) || !(want.y == a2.y)) atomicAdd(bad, 1u);
+}
 template <class Aff, class Aff29>
 __global__ void k_selftest_conv(const Aff* __restrict__ src, Aff29* __restrict__ dst, uint32_t n) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -447,19 +480,22 @@ __global__ void k_selftest_points(Affine<F> g, Affine<F>* __restrict__ out, uint
   out[t] = scalar_mul(g, k).to_affine();
 }
 
-// returns the number of mismatching threads (0 = the two representations agree); group 1 = G1, 2 = G2, 3 = G2 by lane pairs
+// returns the number of mismatching threads (0 = the two representations agree); group 1 = G1, 2 = G2, 3 = G2 by lane pairs, 4 = G1 general additions by lane pairs
 uint32_t selftest_fq29(int group, uint32_t threads, uint32_t iters, const uint8_t* g2_gen_xy_le) {
   require_gpu();
   const uint32_t NP = 1024;
   DevBuf<uint32_t> bad(1);
   RLN_HIP(hipMemset(bad.p, 0, 4));
   threads = (threads + 63) / 64 * 64;
-  if (group == 1) {
+  if (group == 1 || group == 4) {
     DevBuf<G1Affine> p(NP);
     DevBuf<G1Affine29> p29(NP);
     G1Affine g{Fq::from_u32(1), Fq::from_u32(2)};
     hipLaunchKernelGGL(k_selftest_points<Fq>, dim3(NP / 64), dim3(64), 0, 0, g, p.p, NP);
     hipLaunchKernelGGL((k_selftest_conv<G1Affine, G1Affine29>), dim3(NP / 64), dim3(64), 0, 0, p.p, p29.p, NP);
+    if (group == 4)   // the lane-pair general addition (fq29.h: G1AccPair29)
+      hipLaunchKernelGGL(k_selftest_pair_g1, dim3(2 * threads / 64), dim3(64), 0, 0, p29.p, NP, bad.p);
+    else
     hipLaunchKernelGGL((k_selftest29<G1Affine, G1XYZZ, G1Affine29, G1Acc29>), dim3(threads / 64), dim3(64), 0, 0, p.p,
                        p29.p, NP, iters, bad.p);
   } else {

@@ -903,7 +903,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
       uint32_t unused = 0;
       make_plans(f, 3, 4u, D.plan1f, &D.max_chunks1s, &unused,
                  PROVE_FULL, npaired);
-      make_plans(f, 3, 1u, D.plan1tf, &D.max_chunks1t, &unused, PROVE_FULL, npaired);
+      make_plans(f, 3, 1u, D.plan1tf, &D.max_chunks1t, &unused, PROVE_FULL, npaired, false, SUM_TREE_LANES / 2);   // summed by lane pairs
       D.max_blocks1t = D.plan1tf[PROVE_FULL].nblocks;
     }
     build_table29<Fq, G1Affine29>(pts, D.ws, D.t1_29, s, npaired);
@@ -1503,10 +1503,10 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   auto sum1 = [&](hipStream_t st, std::initializer_list<uint32_t> segs) {
     const TaskSel sel = task_sel(segs);
     const uint32_t ns = (uint32_t)segs.size();
-    if (tiny) {
-      hipLaunchKernelGGL((k_sum_blocks<Fq, G1Acc29>), dim3(nb, ns, std::max(P1.maxblk, 1u)), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G1, st, S.part1.p, P1.segchunks.p,
+    if (tiny) {   // a lane pair per point (fq29.h: G1AccPair29): the plan's blocks are SUM_TREE_LANES / 2 partial sums
+      hipLaunchKernelGGL((k_sum_blocks<Fq, G1AccPair29>), dim3(nb, ns, std::max(P1.maxblk, 1u)), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G1 / 2, st, S.part1.p, P1.segchunks.p,
                          P1.segblocks.p, S.grp1.p, PB, sel);
-      hipLaunchKernelGGL((k_sum_tree<Fq, G1Acc29>), dim3(nb, ns), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G1, st, S.grp1.p, P1.segblocks.p, S.sums1.p, B, PB, sel);
+      hipLaunchKernelGGL((k_sum_tree<Fq, G1AccPair29>), dim3(nb, ns), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G1 / 2, st, S.grp1.p, P1.segblocks.p, S.sums1.p, B, PB, sel);
     } else {
       hipLaunchKernelGGL((k_sum_tree<Fq, G1Acc29>), dim3(nb, ns), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G1, st, S.part1.p, P1.segchunks.p, S.sums1.p, B, PB, sel);
     }

@@ -211,8 +211,10 @@ template __global__ void k_table_to29<G2Affine, G2Affine29>(const G2Affine* __re
 template __global__ void k_sum_ranges<Fq>(const XYZZ<Fq>* __restrict__ src, const ChunkDesc* __restrict__ ranges, uint32_t nranges, XYZZ<Fq>* __restrict__ dst, uint32_t B, uint32_t nb);
 template __global__ void k_sum_ranges<Fq2>(const XYZZ<Fq2>* __restrict__ src, const ChunkDesc* __restrict__ ranges, uint32_t nranges, XYZZ<Fq2>* __restrict__ dst, uint32_t B, uint32_t nb);
 template __global__ void k_sum_tree<Fq, G1Acc29>(const XYZZ<Fq>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, XYZZ<Fq>* __restrict__ dst, uint32_t B, uint32_t PB, TaskSel sel);
+template __global__ void k_sum_tree<Fq, G1AccPair29>(const XYZZ<Fq>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, XYZZ<Fq>* __restrict__ dst, uint32_t B, uint32_t PB, TaskSel sel);
 template __global__ void k_sum_tree<Fq2, G2Acc29>(const XYZZ<Fq2>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, XYZZ<Fq2>* __restrict__ dst, uint32_t B, uint32_t PB, TaskSel sel);
 template __global__ void k_sum_blocks<Fq, G1Acc29>(const XYZZ<Fq>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, const ChunkDesc* __restrict__ segblocks, XYZZ<Fq>* __restrict__ dst, uint32_t PB, TaskSel sel);
+template __global__ void k_sum_blocks<Fq, G1AccPair29>(const XYZZ<Fq>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, const ChunkDesc* __restrict__ segblocks, XYZZ<Fq>* __restrict__ dst, uint32_t PB, TaskSel sel);
 template __global__ void k_sum_blocks<Fq2, G2Acc29>(const XYZZ<Fq2>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, const ChunkDesc* __restrict__ segblocks, XYZZ<Fq2>* __restrict__ dst, uint32_t PB, TaskSel sel);
 template __global__ void k_sum_tree<Fq2, G2AccPair29>(const XYZZ<Fq2>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, XYZZ<Fq2>* __restrict__ dst, uint32_t B, uint32_t PB, TaskSel sel);
 template __global__ void k_sum_blocks<Fq2, G2AccPair29>(const XYZZ<Fq2>* __restrict__ part, const ChunkDesc* __restrict__ segchunks, const ChunkDesc* __restrict__ segblocks, XYZZ<Fq2>* __restrict__ dst, uint32_t PB, TaskSel sel);
