@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak of the small-batch shapes (needs the GPU): thousands of DISTINCT witnesses proved one, two, three ... at a time
 on the default tables, every proof verified on the host (pairing, all cores) and every public-input vector compared with
-the same witnesses proved in one throughput-shaped batch.  Prints one JSON line.  N=<proofs> (default 6000)."""
+the same witnesses proved in one throughput-shaped batch.  Prints one JSON line.  N=<proofs> (default 6000), WBITS=<schedule> (default: the default tables)."""
 import json
 import os
 import sys
@@ -13,7 +13,7 @@ from zerokit_amd import workload  # noqa: E402
 from zerokit_amd.batch import BatchProver, resource_paths, verify_many_with_zkey  # noqa: E402
 
 N = int(os.environ.get("N", "6000"))
-p = BatchProver(max_batch=1024)
+p = BatchProver(max_batch=1024, window_bits=int(os.environ.get("WBITS", "0")))   # WBITS=7150114: the bench tables
 inp, rsb = workload.config2_packed(p.slots, p.inputs_size, 100000, N)
 isz = p.inputs_size * 32
 t0 = time.time()
