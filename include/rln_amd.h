@@ -141,6 +141,10 @@ int rlnamd_prover_walk_clock_mhz(rlnamd_prover* p, double mhz[2]);
 /* parity taps of the last run: full witness (num_signals*32) / h (domain_size*32) of proof `index` */
 int rlnamd_prover_fetch_witness(rlnamd_prover* p, size_t index, uint8_t* out_le);
 int rlnamd_prover_fetch_h(rlnamd_prover* p, size_t index, uint8_t* out_le);
+/* tap of the wipes: the number of 16-byte words that are not zero in the buffers of the slot the last batch used, whole
+ * buffers: [0] G1 window digits, [1] G2 window digits, [2] a | b | c (the quotient's operands, then h), [3] / [4] partial
+ * sums of the G1 / G2 walks, [5] staged inputs + (r, s).  All zero behind a collect that wipes. */
+int rlnamd_prover_residue(rlnamd_prover* p, uint64_t out[6]);
 /* ---- partial proofs (generate_partial_zk_proof / finish_zk_proof_with_rs, protocol/proof.rs:783-849;
  * Groth16Partial, partial_proof.rs:108-274).  mode: 0 full proof, 1 partial (inputs hold only identitySecret,
  * userMessageLimit, pathElements, identityPathIndex; other slots zero), 2 finish (full inputs + r, s + the

@@ -341,13 +341,21 @@ def test_ffi_round_trip_like_reference_tests():
     assert a.get_root() == RLN(20).get_root() and a.leaves_set() == 0
 
 
-def test_tree_scattered_updates_one_pass_vs_oracle():
-    """rlnamd_tree_set_leaves: k single-leaf writes + ONE bottom-up pass over the union of their paths equals k set()
+@pytest.mark.parametrize("host_max", ["0", None, "8", "4096"])
+def test_tree_scattered_updates_one_pass_vs_oracle(host_max, monkeypatch):
+    """(host_max: the largest pass that runs its dependent chain on a host core -- MerkleTreeDev::set_few: one gather of
+    the clean siblings, the path hashes with the library's host Poseidon, one scatter -- forced to never / the default /
+    8 / 4096, so that every k below goes through both forms.)
+    rlnamd_tree_set_leaves: k single-leaf writes + ONE bottom-up pass over the union of their paths equals k set()
     calls of FullMerkleTree (full_merkle_tree.rs:141-147,336-399) -- for k = 1 (the whole path in one launch), 21 / 84 /
     85 / 86 (around the capacity of the single-workgroup tail), 1 000, 30 000 (more dirty parents than the three-lane
     kernel takes) and on small depths (0, 1, 3); duplicates keep the last write; root, leaves and paths vs oracle/c"""
     from oracle.c import binding as ob
     from zerokit_amd.batch import PoseidonTree
+    if host_max is None:
+        monkeypatch.delenv("RLNAMD_TREE_HOST_MAX", raising=False)
+    else:
+        monkeypatch.setenv("RLNAMD_TREE_HOST_MAX", host_max)
     rnd = random.Random(77)
     for depth in (0, 1, 3):
         t, o = PoseidonTree(depth), ob.Tree(depth)
@@ -363,8 +371,10 @@ def test_tree_scattered_updates_one_pass_vs_oracle():
     t.fill_sequential(0, 1 << 14, 1)
     o.set_range(0, list(range(1, (1 << 14) + 1)), threads=4)
     assert t.root() == o.root()
-    for k in (1, 1, 21, 84, 85, 86, 1000, 30000):
+    for k in (1, 1, 2, 5, 6, 7, 8, 9, 21, 84, 85, 86, 1000, 30000):
         ups = [(rnd.randrange(1 << depth), rnd.randrange(1, R)) for _ in range(k)]
+        if k == 5:
+            ups += [(ups[0][0] ^ 1, 17), (ups[1][0] ^ 2, 18)]      # a sibling and a cousin of dirty leaves
         if k >= 21:
             ups += [(ups[0][0], 5), (ups[1][0], 0), (ups[0][0], 6)]      # rewrites: the last one wins
         t.set_leaves(ups)

@@ -140,6 +140,10 @@ def test_secrets_are_wiped_behind_collect_and_on_request(prover):
     ref = prover.prove(ws, rs)
     w0 = prover.fetch_witness(0)
     assert any(w0) and w0[0] == 1
+    # the window digits re-encode every witness scalar (and r, s) without loss; a | b | c and the walks' partial sums are
+    # images of the witness: all present before the wipe, all zero behind it
+    left = prover.residue()
+    assert left["digits_g1"] and left["digits_g2"] and left["abc"] and left["partial_g1"] and left["partial_g2"]
     prover.wipe()
     assert not any(prover.fetch_witness(0)) and not any(prover.fetch_witness(4))
     inp, rsb = prover.pack_inputs(ws), prover.pack_rs(rs)
@@ -158,6 +162,36 @@ def test_secrets_are_wiped_behind_collect_and_on_request(prover):
     prover.collect(t, n)
     assert prover.prove(ws, rs) == ref                          # nothing the next batch needs was wiped
     assert any(prover.fetch_witness(0))
+
+
+def test_nothing_derived_from_the_witness_outlives_a_collected_batch():
+    """the signed window digits are a lossless re-encoding of every witness scalar (identity secret, r, s),
+    a | b | c and the walks' partial sums are images of the witness.  On a prover of its own (so that no earlier
+    resident run left anything): behind every collect -- throughput shape (200 proofs, digit stride = capacity), small
+    shapes (70: lanes = proofs short chunks; 20; 3: one row per lane, compact digit rows) -- every 16-byte word of the
+    slot's digit rows, a | b | c, partial sums and staged inputs is zero; the bytes returned stay those of the oracle"""
+    from zerokit_amd import workload
+    from zerokit_amd.batch import BatchProver
+    p = BatchProver(max_batch=256)
+    try:
+        ws, rs = workload.config2_range(0, 423)
+        ref_proofs, _ = _oracle(ws, rs)
+        for first, n in ((0, 200), (200, 70), (270, 20), (290, 3), (293, 130)):
+            inp, rsb = workload.config2_packed(p.slots, p.inputs_size, first, n)
+            t, k = p.submit(inp, rsb)
+            got = p.collect(t, k)
+            left = p.residue()
+            assert not any(left.values()), (n, left)
+            assert [g["proof"] for g in got] == ref_proofs[first:first + n], n
+        # a resident run keeps everything for the parity taps until it is wiped
+        ws, rs = workload.config2_range(300, 5)
+        p.prove(ws, rs)
+        left = p.residue()
+        assert left["digits_g1"] and left["digits_g2"] and left["abc"] and left["partial_g1"] and left["partial_g2"]
+        p.wipe()
+        assert not any(p.residue().values()), p.residue()
+    finally:
+        p.close()
 
 
 def test_pool_of_one_and_two_replicas_on_one_device_equal_single_prover(prover):

@@ -120,6 +120,7 @@ SIGNATURES = {
     "rlnamd_prover_stage_name": (C.c_char_p, [C.c_int]),
     "rlnamd_prover_fetch_witness": (C.c_int, [P, C.c_size_t, C.c_char_p]),
     "rlnamd_prover_fetch_h": (C.c_int, [P, C.c_size_t, C.c_char_p]),
+    "rlnamd_prover_residue": (C.c_int, [P, C.POINTER(C.c_uint64)]),
     "rlnamd_verify": (C.c_int, [P, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]),
     "rlnamd_prover_num_public": (C.c_size_t, [P]),
     "rlnamd_prover_download_public": (C.c_int, [P, C.c_size_t, C.c_char_p]),

@@ -302,6 +302,12 @@ class BatchProver:
         check(lib().rlnamd_prover_fetch_h(self._h, index, buf))
         return [int.from_bytes(buf.raw[32 * i:32 * i + 32], "little") for i in range(n)]
 
+    def residue(self):
+        """tap of the wipes (rlnamd_prover_residue): non-zero 16-byte words left in the last batch's slot"""
+        out = (C.c_uint64 * 6)()
+        check(lib().rlnamd_prover_residue(self._h, out))
+        return dict(zip(("digits_g1", "digits_g2", "abc", "partial_g1", "partial_g2", "inputs"), (int(v) for v in out)))
+
     def verify_many(self, proofs, public_inputs, threads=0):
         """n independent verifications on host threads (rlnamd_verify_many); returns a list of bools"""
         n = len(proofs)

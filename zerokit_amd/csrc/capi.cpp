@@ -31,6 +31,7 @@ int fail(const std::exception& e) {
 
 struct rlnamd_tree {
   MerkleTreeDev t;
+  size_t host_max = 0;   // rlnamd_tree_set_leaves: up to this many distinct leaves take MerkleTreeDev::set_few
   DevBuf<uint8_t> bench_elems, bench_bits;
 };
 
@@ -110,6 +111,7 @@ int rlnamd_tree_new(size_t depth, rlnamd_tree** out) {
   uint8_t zero[32] = {0};
   if (depth > 30) throw Error("InvalidDepth");
   h->t.init((int)depth, zero);
+  h->host_max = MerkleTreeDev::host_max_from_env();
   *out = h.release();
   RLN_CATCH
 }
@@ -144,7 +146,8 @@ int rlnamd_tree_set_leaves(rlnamd_tree* t, const uint64_t* indices, const uint8_
     idx.push_back(ord[i].first);
     leaves.insert(leaves.end(), leaves_le + 32 * ord[i].second, leaves_le + 32 * ord[i].second + 32);
   }
-  t->t.set_scattered(idx.data(), leaves.data(), idx.size());
+  if (idx.size() <= t->host_max) t->t.set_few(idx.data(), leaves.data(), idx.size());
+  else t->t.set_scattered(idx.data(), leaves.data(), idx.size());
   RLN_HIP(hipStreamSynchronize(t->t.stream));
   RLN_CATCH
 }
@@ -388,6 +391,12 @@ int rlnamd_prover_fetch_h(rlnamd_prover* p, size_t index, uint8_t* out_le) {
   memcpy(out_le, h.data(), h.size());
   RLN_CATCH
 }
+int rlnamd_prover_residue(rlnamd_prover* p, uint64_t out[6]) {
+  RLN_TRY
+  static_assert(Prover::RESIDUE_FIELDS == 6, "rln_amd.h states six counters");
+  p->p->residue(out);
+  RLN_CATCH
+}
 
 int rlnamd_verify(rlnamd_prover* p, const uint8_t proof[128], const uint8_t values_le[160], int* ok) {
   RLN_TRY
@@ -417,6 +426,9 @@ int rlnamd_poseidon_params_check(const uint8_t* inputs_le, size_t arity, uint8_t
   }
   Fr d, sp;
   poseidon_params_eval_host(P, in.data(), &d, &sp);
+  // the host hash of the tree's single-path chain (MerkleTreeDev::set_few) is that sparse form with fixed-size state
+  if (poseidon_hash_host(poseidon_host_params((int)arity + 1), in.data()) != sp)
+    throw Error("internal: poseidon_hash_host differs from the sparse evaluation");
   uint32_t c[8];
   d.to_canonical(c);
   memcpy(out_dense_le, c, 32);

@@ -761,6 +761,11 @@ void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CF
   std::vector<FFI_RLNProof*> made;
   const size_t npub = P.num_public(), mo = P.graph().max_out;
   auto pack = [&](size_t off, size_t m, std::vector<uint8_t>& inputs, std::vector<uint8_t>& rsb) {
+    // one allocation for the whole call: a vector that grew would hand its earlier buffer -- identity secrets in it --
+    // back to the heap uncleared (ZeroOnExit sees the final buffer only)
+    const size_t most = std::max(m, std::min(n, P.capacity()));
+    if (inputs.capacity() < most * ni * 32) { secure_zero(inputs.data(), inputs.size()); inputs.clear(); inputs.reserve(most * ni * 32); }
+    if (rsb.capacity() < most * 64) { secure_zero(rsb.data(), rsb.size()); rsb.clear(); rsb.reserve(most * 64); }
     inputs.assign(m * ni * 32, 0);
     rsb.resize(m * 64);
     for (size_t i = 0; i < m; i++) {
@@ -852,7 +857,14 @@ void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CF
         }
         while (!q.empty()) take();
       } catch (...) {
-        P.sync();   // nothing of this call stays in flight behind the error
+        // nothing of this call stays in flight behind the error, and the batches still queued (never collected, so never
+        // wiped) do not keep their staged inputs and witnesses either
+        try {
+          P.sync();
+          for (const Pending& f : q) P.wipe(f.ticket);
+          P.sync();
+        } catch (...) {
+        }
         throw;
       }
     }
@@ -1742,7 +1754,7 @@ Vec_uint8_t ffi_vec_cfr_debug(const Vec_CFr_t* v) {
   return make_str(s + "]");
 }
 void ffi_vec_cfr_free(Vec_CFr_t v) {   // keygen hands the secrets out as a Vec<CFr>
-  if (v.ptr) secure_zero(v.ptr, v.len * sizeof(CFr));
+  if (v.ptr) secure_zero(v.ptr, std::max(v.len, v.cap) * sizeof(CFr));   // the whole allocation, not only the live elements
   free(v.ptr);
 }
 

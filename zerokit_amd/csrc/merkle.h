@@ -22,6 +22,10 @@ struct MerkleTreeDev {
   DevBuf<uint32_t> scat_dev;
   uint32_t* scat_host = nullptr;
   size_t scat_cap = 0;
+  bool root_known = false;      // root_host is the root of what the stream will have written (set_few)
+  Fr root_host;
+  DevBuf<uint8_t> proof_dev;    // proof_host's device scratch (depth * 33 bytes), allocated once
+  void reserve_staging(size_t words);
 
   MerkleTreeDev() = default;
   ~MerkleTreeDev();
@@ -40,6 +44,19 @@ struct MerkleTreeDev {
   // k leaves at strictly increasing indices `idx`, then ONE bottom-up pass over the union of their paths (the parents of
   // what changed, level by level; the top levels in a single launch).  Stream-ordered: returns without a host wait.
   void set_scattered(const uint64_t* idx, const uint8_t* leaves_le, size_t k);
+  // The same update for a HANDFUL of leaves, the dependent chain on a host core: one gather of the <= depth * k clean
+  // siblings of the dirty paths (a kernel writing pinned host memory), the hashes of the paths with the library's own
+  // host Poseidon (poseidon_hash_host: ~20 us each, against 146 us per link of the same chain on a lone wave), one
+  // scatter of the rewritten nodes behind it (stream-ordered, nobody waits for it).  The tree stays in HBM and every
+  // other reader finds it updated; the root is remembered on the host (root_known) so that the usual
+  // set_leaf -> get_root of a membership contract costs no second round trip.  (FullMerkleTree::set + update_hashes,
+  // full_merkle_tree.rs:197-223,336-399.)
+  void set_few(const uint64_t* idx, const uint8_t* leaves_le, size_t k);
+  // how many dirty leaves a pass may have and still take set_few: the device pass costs ~3.0 ms whatever k is (up to
+  // a few thousand), set_few 0.24 ms for one leaf and ~0.18 ms for every further one (measured, EPYC 9575F host: k = 8
+  // 1.49 ms).  RLNAMD_TREE_HOST_MAX overrides (0: never; tests force 0 / 8 / 4096).
+  static constexpr size_t HOST_MAX_DEFAULT = 14, HOST_MAX_LIMIT = 4096;
+  static size_t host_max_from_env();
   // leaves i -> Fr(first + i): synthetic fill generated on the device (bench / config 3), then rehash
   void fill_sequential_device(size_t start, size_t n, uint64_t first);
   void rehash(size_t lo_node, size_t hi_node);  // update_hashes :360-399

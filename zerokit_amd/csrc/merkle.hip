@@ -94,6 +94,18 @@ __global__ void __launch_bounds__(64 * WAVES) k_hash_tail_list(Fr* __restrict__ 
   }
 }
 
+// set_few: the clean siblings of a handful of dirty paths out (into pinned host memory), the rewritten nodes back in
+__global__ void __launch_bounds__(64) k_gather_nodes(const Fr* __restrict__ nodes, const uint32_t* __restrict__ list, uint32_t count,
+                                                     Fr* __restrict__ out) {
+  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i < count) out[i] = nodes[list[i]];
+}
+__global__ void __launch_bounds__(64) k_scatter_nodes(Fr* __restrict__ nodes, const uint32_t* __restrict__ list, uint32_t count,
+                                                      const Fr* __restrict__ vals) {
+  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i < count) nodes[list[i]] = vals[i];
+}
+
 // zero_hashes[depth] = default leaf; zero_hashes[l] = H(z[l+1], z[l+1])  -- single lane, init only
 __global__ void k_zero_hashes(Fr* zh, int depth, PoseidonView pv) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -257,6 +269,7 @@ void MerkleTreeDev::init(int depth_, const uint8_t default_leaf_le[32]) {
   require_gpu();
   if (depth_ < 0 || depth_ > 30) throw Error("InvalidDepth: tree depth must be in [0, 30] for the HBM-resident tree");
   depth = depth_;
+  root_known = false;
   nodes.alloc(num_nodes());
   PoseidonView pv = poseidon_view(3);
   DevBuf<Fr> zh(depth + 1);
@@ -274,6 +287,7 @@ void MerkleTreeDev::init(int depth_, const uint8_t default_leaf_le[32]) {
 }
 
 void MerkleTreeDev::rehash(size_t lo, size_t hi) {
+  root_known = false;
   PoseidonView pv = poseidon_view(3);
   const size_t l3_max = 21 * 1024;
   while (lo > 0) {
@@ -316,6 +330,7 @@ void MerkleTreeDev::set_scattered(const uint64_t* idx, const uint8_t* leaves_le,
   if (k > 0xFFFFFFFFull) throw Error("TooManySet");
   for (size_t i = 0; i < k; i++)
     if (idx[i] >= capacity() || (i && idx[i] <= idx[i - 1])) throw Error("set_scattered: indices must be increasing and inside the tree");
+  root_known = false;
   // host side: the dirty node lists, bottom-up.  Heap indices fit 32 bits (depth <= 30).
   LevelOffsets lo{};
   std::vector<uint32_t> lists;
@@ -336,14 +351,7 @@ void MerkleTreeDev::set_scattered(const uint64_t* idx, const uint8_t* leaves_le,
   }
   // staging: [k leaf indices][lists][k x 32 B leaves], pinned; the previous pass may still be reading it
   const size_t words = k + lists.size() + 8 * k;
-  RLN_HIP(hipStreamSynchronize(stream));
-  if (scat_cap < words) {
-    if (scat_host) (void)hipHostFree(scat_host);
-    scat_host = nullptr;
-    scat_cap = std::max<size_t>(words, 4096);
-    RLN_HIP(hipHostMalloc((void**)&scat_host, scat_cap * 4, hipHostMallocDefault));
-    scat_dev.alloc(scat_cap);
-  }
+  reserve_staging(words);
   for (size_t i = 0; i < k; i++) scat_host[i] = (uint32_t)idx[i];
   if (!lists.empty()) memcpy(scat_host + k, lists.data(), lists.size() * 4);
   memcpy(scat_host + k + lists.size(), leaves_le, 32 * k);
@@ -373,6 +381,105 @@ void MerkleTreeDev::set_scattered(const uint64_t* idx, const uint8_t* leaves_le,
   RLN_HIP(hipGetLastError());
 }
 
+// pinned staging of the dirty-path passes; the previous pass may still be reading it
+void MerkleTreeDev::reserve_staging(size_t words) {
+  RLN_HIP(hipStreamSynchronize(stream));
+  if (scat_cap < words) {
+    if (scat_host) (void)hipHostFree(scat_host);
+    scat_host = nullptr;
+    scat_cap = std::max<size_t>(words, 4096);
+    RLN_HIP(hipHostMalloc((void**)&scat_host, scat_cap * 4, hipHostMallocDefault));
+    scat_dev.alloc(scat_cap);
+  }
+}
+
+size_t MerkleTreeDev::host_max_from_env() {
+  const char* v = getenv("RLNAMD_TREE_HOST_MAX");
+  const size_t m = (v && *v) ? (size_t)strtoull(v, nullptr, 10) : HOST_MAX_DEFAULT;
+  return std::min(m, HOST_MAX_LIMIT);
+}
+
+void MerkleTreeDev::set_few(const uint64_t* idx, const uint8_t* leaves_le, size_t k) {
+  if (k == 0) return;
+  if (k > HOST_MAX_LIMIT) throw Error("set_few: a handful of leaves only (set_scattered takes the rest)");
+  for (size_t i = 0; i < k; i++)
+    if (idx[i] >= capacity() || (i && idx[i] <= idx[i - 1])) throw Error("set_few: indices must be increasing and inside the tree");
+  // Level by level (bottom-up), the dirty nodes of the level in increasing heap order: cur[l]; a dirty node's sibling is
+  // either dirty too (then it is its neighbour in cur[l]) or clean: fetched.  All of it follows from the indices alone.
+  struct Dirty { uint32_t node; int sib; };   // sib >= 0: index into the fetch list; -1: the neighbour in cur is the sibling
+  std::vector<std::vector<Dirty>> lv(depth + 1);
+  std::vector<uint32_t> fetch;
+  lv[0].reserve(k);
+  for (size_t i = 0; i < k; i++) lv[0].push_back({(uint32_t)(capacity() - 1 + idx[i]), -1});
+  for (int l = 0; l < depth; l++) {
+    std::vector<Dirty>& c = lv[l];
+    for (size_t i = 0; i < c.size(); i++) {
+      const uint32_t nd = c[i].node, sb = (nd & 1) ? nd + 1 : nd - 1;   // children of p: 2p + 1 (odd), 2p + 2
+      const bool paired = (nd & 1) ? (i + 1 < c.size() && c[i + 1].node == sb) : (i > 0 && c[i - 1].node == sb);
+      if (!paired) {
+        c[i].sib = (int)fetch.size();
+        fetch.push_back(sb);
+      }
+      const uint32_t p = (nd - 1) >> 1;
+      if (lv[l + 1].empty() || lv[l + 1].back().node != p) lv[l + 1].push_back({p, -1});
+    }
+  }
+  size_t nwrite = 0;
+  for (int l = 0; l <= depth; l++) nwrite += lv[l].size();
+  // staging (32-bit words): [fetch list][fetched Fr x nf][write list][written Fr x nwrite]
+  const size_t nf = fetch.size();
+  const size_t o_fetched = (nf + 7) / 8 * 8, o_wlist = o_fetched + 8 * nf, o_wvals = (o_wlist + nwrite + 7) / 8 * 8;
+  reserve_staging(o_wvals + 8 * nwrite);
+  Fr* fetched = reinterpret_cast<Fr*>(scat_host + o_fetched);
+  uint32_t* wlist = scat_host + o_wlist;
+  Fr* wvals = reinterpret_cast<Fr*>(scat_host + o_wvals);
+  if (nf) {
+    memcpy(scat_host, fetch.data(), nf * 4);
+    hipLaunchKernelGGL(k_gather_nodes, dim3(div_up(nf, 64)), dim3(64), 0, stream, nodes.p, scat_host, (uint32_t)nf, fetched);
+    RLN_HIP(hipGetLastError());
+  }
+  // (the host work that does not need the siblings overlaps the gather)
+  const PoseidonParams& P = poseidon_host_params(3);
+  std::vector<std::vector<Fr>> val(depth + 1);
+  val[0].resize(k);
+  for (size_t i = 0; i < k; i++) {
+    uint32_t c[8];
+    memcpy(c, leaves_le + 32 * i, 32);
+    val[0][i] = Fr::from_canonical(c);
+  }
+  if (nf) RLN_HIP(hipStreamSynchronize(stream));
+  for (int l = 0; l < depth; l++) {
+    const std::vector<Dirty>& c = lv[l];
+    val[l + 1].reserve(lv[l + 1].size());
+    for (size_t i = 0; i < c.size(); i++) {
+      const bool left = (c[i].node & 1) != 0;
+      Fr in[2];
+      if (c[i].sib >= 0) {
+        in[left ? 0 : 1] = val[l][i];
+        in[left ? 1 : 0] = fetched[c[i].sib];
+      } else if (left) {   // both children dirty: hashed once, at the left one
+        in[0] = val[l][i];
+        in[1] = val[l][i + 1];
+      } else {
+        continue;
+      }
+      val[l + 1].push_back(poseidon_hash_host(P, in));
+    }
+    if (val[l + 1].size() != lv[l + 1].size()) throw Error("internal: dirty-path bookkeeping");
+  }
+  size_t w = 0;
+  for (int l = 0; l <= depth; l++)
+    for (size_t i = 0; i < lv[l].size(); i++) {
+      wlist[w] = lv[l][i].node;
+      wvals[w] = val[l][i];
+      w++;
+    }
+  hipLaunchKernelGGL(k_scatter_nodes, dim3(div_up(nwrite, 64)), dim3(64), 0, stream, nodes.p, wlist, (uint32_t)nwrite, wvals);
+  RLN_HIP(hipGetLastError());
+  root_host = val[depth][0];
+  root_known = true;
+}
+
 MerkleTreeDev::~MerkleTreeDev() {
   if (scat_host) (void)hipHostFree(scat_host);
 }
@@ -387,6 +494,10 @@ MerkleTreeDev& MerkleTreeDev::operator=(MerkleTreeDev&& o) noexcept {
     scat_dev = std::move(o.scat_dev);
     scat_host = o.scat_host;
     scat_cap = o.scat_cap;
+    root_known = o.root_known;
+    root_host = o.root_host;
+    proof_dev = std::move(o.proof_dev);
+    o.root_known = false;
     o.scat_host = nullptr;
     o.scat_cap = 0;
     o.depth = 0;
@@ -405,8 +516,12 @@ void MerkleTreeDev::fill_sequential_device(size_t start, size_t n, uint64_t firs
 void MerkleTreeDev::get_node_host(size_t node, uint8_t out_le[32]) {
   if (node >= num_nodes()) throw Error("InvalidLeaf");
   Fr v;
-  RLN_HIP(hipMemcpyAsync(&v, nodes.p + node, sizeof(Fr), hipMemcpyDeviceToHost, stream));
-  RLN_HIP(hipStreamSynchronize(stream));
+  if (node == 0 && root_known) {
+    v = root_host;
+  } else {
+    RLN_HIP(hipMemcpyAsync(&v, nodes.p + node, sizeof(Fr), hipMemcpyDeviceToHost, stream));
+    RLN_HIP(hipStreamSynchronize(stream));
+  }
   uint32_t c[8];
   v.to_canonical(c);
   memcpy(out_le, c, 32);
@@ -446,11 +561,13 @@ void MerkleTreeDev::proofs_device(size_t first, size_t count, uint8_t* d_elems, 
 void MerkleTreeDev::proof_host(size_t leaf, uint8_t* elems_le, uint8_t* bits) {
   if (leaf >= capacity()) throw Error("InvalidLeaf");
   if (depth == 0) return;
-  DevBuf<uint8_t> e((size_t)depth * 32), b(depth);
-  proofs_device(leaf, 1, e.p, b.p);
-  RLN_HIP(hipMemcpyAsync(elems_le, e.p, (size_t)depth * 32, hipMemcpyDeviceToHost, stream));
-  RLN_HIP(hipMemcpyAsync(bits, b.p, depth, hipMemcpyDeviceToHost, stream));
+  // (the index bits follow from the leaf index -- full_merkle_tree.rs:296-300: 1 when the node on the path is a right
+  // child; a hipMalloc per call cost more than the proof)
+  if (proof_dev.n < (size_t)depth * 33 + 16) proof_dev.alloc((size_t)depth * 33 + 16);
+  proofs_device(leaf, 1, proof_dev.p, proof_dev.p + (size_t)depth * 32);
+  RLN_HIP(hipMemcpyAsync(elems_le, proof_dev.p, (size_t)depth * 32, hipMemcpyDeviceToHost, stream));
   RLN_HIP(hipStreamSynchronize(stream));
+  for (int l = 0; l < depth; l++) bits[l] = (uint8_t)(((leaf + capacity()) >> l) & 1);
 }
 
 size_t MerkleTreeDev::verify_proofs_device(size_t first, size_t count, const uint8_t* d_elems, const uint8_t* d_bits) {

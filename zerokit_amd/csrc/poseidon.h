@@ -40,6 +40,12 @@ PoseidonParams poseidon_derive_params(int t);
 // host: one hash with the dense rounds of the reference and one with the sparse partial rounds (parameter self-check)
 void poseidon_params_eval_host(const PoseidonParams& P, const Fr* in, Fr* out_dense, Fr* out_sparse);
 
+// host: ONE hash in the sparse form (the function of the kernels, on the host's 4 x 64-bit Montgomery product): the
+// dependent chain of a single Merkle path is 20 hashes one after the other -- on a core that is ~0.4 ms, on the GPU
+// 20 x 0.146 ms whatever is done to it (merkle.h: MerkleTreeDev::set_few).  in: t - 1 Montgomery residues.
+Fr poseidon_hash_host(const PoseidonParams& P, const Fr* in);
+const PoseidonParams& poseidon_host_params(int t);   // derived once per process
+
 // device-resident constant tables for t = 2..9
 struct PoseidonDev {
   int rf[POSEIDON_MAX_T + 1] = {0}, rp[POSEIDON_MAX_T + 1] = {0};

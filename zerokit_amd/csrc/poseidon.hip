@@ -220,6 +220,62 @@ void poseidon_params_eval_host(const PoseidonParams& P, const Fr* in, Fr* out_de
   *out_sparse = s[0];
 }
 
+Fr poseidon_hash_host(const PoseidonParams& P, const Fr* in) {
+  const int t = P.t, half = P.rf / 2;
+  if (t > POSEIDON_MAX_T) throw Error("unsupported Poseidon width");
+  Fr s[POSEIDON_MAX_T], n[POSEIDON_MAX_T];
+  auto pow5 = [](const Fr& x) { const Fr x2 = x.sqr(); return x2.sqr() * x; };
+  auto mix = [&]() {
+    for (int i = 0; i < t; i++) {
+      Fr acc = P.mds[i * t] * s[0];
+      for (int j = 1; j < t; j++) acc = acc + P.mds[i * t + j] * s[j];
+      n[i] = acc;
+    }
+    for (int i = 0; i < t; i++) s[i] = n[i];
+  };
+  s[0] = Fr::zero();
+  for (int j = 1; j < t; j++) s[j] = in[j - 1];
+  for (int r = 0; r < half; r++) {
+    for (int j = 0; j < t; j++) s[j] = pow5(s[j] + P.ark[(size_t)r * t + j]);
+    mix();
+  }
+  for (int r = 0; r < P.rp; r++) {
+    const Fr x0 = pow5(s[0] + P.k0[r]);
+    const Fr* row = P.row0.data() + (size_t)r * t;
+    const Fr* u = P.u.data() + (size_t)r * (t - 1);
+    Fr n0 = row[0] * x0;
+    for (int j = 1; j < t; j++) n0 = n0 + row[j] * s[j];
+    for (int j = 1; j < t; j++) s[j] = s[j] + u[j - 1] * x0;
+    s[0] = n0;
+  }
+  for (int i = 1; i < t; i++) {
+    Fr acc = Fr::zero();
+    for (int j = 1; j < t; j++) acc = acc + P.a_fin[(size_t)(i - 1) * (t - 1) + j - 1] * s[j];
+    n[i] = acc;
+  }
+  for (int i = 1; i < t; i++) s[i] = n[i];
+  for (int r = 0; r < half; r++) {
+    for (int j = 0; j < t; j++) s[j] = pow5(s[j] + P.ark2[(size_t)r * t + j]);
+    if (r + 1 < half) {
+      mix();
+    } else {   // only lane 0 of the last mix is the hash
+      Fr acc = P.mds[0] * s[0];
+      for (int j = 1; j < t; j++) acc = acc + P.mds[j] * s[j];
+      s[0] = acc;
+    }
+  }
+  return s[0];
+}
+
+const PoseidonParams& poseidon_host_params(int t) {
+  if (t < 2 || t > POSEIDON_MAX_T) throw Error("unsupported Poseidon width t=" + std::to_string(t));
+  static std::mutex mu;
+  static PoseidonParams cache[POSEIDON_MAX_T + 1];
+  std::lock_guard<std::mutex> lk(mu);
+  if (cache[t].t == 0) cache[t] = poseidon_derive_params(t);
+  return cache[t];
+}
+
 __global__ void k_fr_to29(const Fr* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;

@@ -160,6 +160,10 @@ class Prover {
   size_t num_public() const { return (size_t)zk_.num_instance_variables - 1; }
   void fetch_witness(size_t p, std::vector<uint8_t>* w_le);
   void fetch_h(size_t p, std::vector<uint8_t>* h_le);
+  // tap of the wipes: 16-byte words of the last batch's slot that are not zero, whole buffers --
+  // [G1 digits, G2 digits, a|b|c (h), G1 partial sums, G2 partial sums, staged inputs + (r, s)]
+  static constexpr int RESIDUE_FIELDS = 6;
+  void residue(uint64_t out[RESIDUE_FIELDS]);
 
  private:
   uint64_t enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint8_t* h_rs, const uint8_t* h_pp320);

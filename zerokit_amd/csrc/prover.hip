@@ -62,6 +62,8 @@ struct Slot {
   hipEvent_t evZ = nullptr;     // ... and that wipe has finished.  Kept apart from evC: "is the device idle" (lone) asks evC
   hipEvent_t free_event() const { return wiped ? evZ : evC; }   // what the slot's next user waits for
   size_t n = 0;
+  // what the batch's walks used (wipe_slot): proof stride of the digit rows, stride and row counts of the partial sums
+  uint32_t dB = 0, PB = 0, nch1 = 0, nch2 = 0;
 };
 
 struct Prover::Impl {
@@ -178,6 +180,26 @@ struct Prover::Impl {
     } else {
       hipLaunchKernelGGL(k_wipe_cols, dim3(pg, N), dim3(64), 0, sW, S.V.p, (const uint32_t*)nullptr, N, (uint32_t)B, (uint32_t)n);
     }
+    // The signed window digits are a lossless re-encoding of every witness scalar (the identity secret among them) and
+    // of r, s; A w, B w and the quotient are linear images of the witness; a walk's partial sum over a handful of rows is
+    // w_i P_i for guessable w_i.  Columns [0, n) of all of them, by the strides the batch used.
+    auto rows16 = [&](void* base, size_t nrows, size_t stride16, size_t n16) {
+      if (!base || !nrows || !n16) return;
+      hipLaunchKernelGGL(k_wipe_rows16, dim3(div_up(n16, 64), nrows), dim3(64), 0, sW, (uint4*)base, (uint32_t)nrows,
+                         (uint32_t)stride16, (uint32_t)std::min(n16, stride16));
+    };
+    const size_t dB = S.dB ? S.dB : B;
+    const size_t np = std::min<size_t>(B, (n + 63) / 64 * 64);   // the padding lanes of the last wave wrote their columns too
+    for (DevBuf<int16_t>* d : {&S.digits, &S.digits2}) {
+      if (!d->p) continue;
+      const size_t drows = d->n / B;
+      if (dB == B) rows16(d->p, drows, B / 8, np / 8);                            // [row][B] int16
+      else zero(d->p, std::min(d->bytes(), (drows * dB * 2 + 31) / 32 * 32));     // compact rows: contiguous
+    }
+    rows16(S.abc.p, S.abc.n / B, B * 2, np * 2);                                  // [3 n_constraints][B] x 32 bytes
+    const size_t PB = S.PB ? S.PB : B;
+    rows16(S.part1.p, S.PB ? S.nch1 : S.part1.n / PB, PB * (sizeof(G1XYZZ) / 16), std::min(np, PB) * (sizeof(G1XYZZ) / 16));
+    rows16(S.part2.p, S.PB ? S.nch2 : S.part2.n / PB, PB * (sizeof(G2XYZZ) / 16), std::min(np, PB) * (sizeof(G2XYZZ) / 16));
     RLN_HIP(hipGetLastError());
     RLN_HIP(hipEventRecord(S.evZ, sW));
     S.wiped = true;
@@ -1247,6 +1269,10 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // same window)
   const uint32_t dB = (early && !walk_lp) ? (uint32_t)n : (uint32_t)B_;
   Slot& S = D.slot[D.cur];
+  S.dB = dB;
+  S.PB = PB;
+  S.nch1 = P1.nchunks;
+  S.nch2 = P2.nchunks;
   const bool streamed = h_inputs != nullptr;
   if (streamed) {
     if (D.wgiven_n) throw Error("upload_witness applies to the resident-input run that follows it, not to submit");
@@ -1767,6 +1793,31 @@ void Prover::fetch_h(size_t p, std::vector<uint8_t>* h_le) {
   h_le->resize((size_t)D.n * 32);
   RLN_HIP(hipMemcpyAsync(h_le->data(), tmp.p, h_le->size(), hipMemcpyDeviceToHost, D.sC));
   RLN_HIP(hipStreamSynchronize(D.sC));
+}
+
+void Prover::residue(uint64_t out[RESIDUE_FIELDS]) {
+  Impl& D = *d_;
+  sync();
+  if (!D.last) throw Error("no run to read from");
+  Slot& S = *D.last;
+  DevBuf<unsigned long long> cnt(RESIDUE_FIELDS);
+  RLN_HIP(hipMemsetAsync(cnt.p, 0, cnt.bytes(), D.sC));
+  auto count = [&](int k, const void* p, size_t bytes) {
+    if (p && bytes >= 16)
+      hipLaunchKernelGGL(k_count_nonzero16, dim3(2048), dim3(256), 0, D.sC, (const uint4*)p, bytes / 16, cnt.p + k);
+  };
+  count(0, S.digits.p, S.digits.bytes());
+  count(1, S.digits2.p, S.digits2.bytes());
+  count(2, S.abc.p, S.abc.bytes());
+  count(3, S.part1.p, S.part1.bytes());
+  count(4, S.part2.p, S.part2.bytes());
+  count(5, S.inputs.p, S.inputs.bytes());
+  count(5, S.rs.p, S.rs.bytes());
+  RLN_HIP(hipGetLastError());
+  unsigned long long h[RESIDUE_FIELDS];
+  RLN_HIP(hipMemcpyAsync(h, cnt.p, sizeof h, hipMemcpyDeviceToHost, D.sC));
+  RLN_HIP(hipStreamSynchronize(D.sC));
+  for (int k = 0; k < RESIDUE_FIELDS; k++) out[k] = h[k];
 }
 
 }  // namespace rlnamd

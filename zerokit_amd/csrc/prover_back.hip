@@ -396,6 +396,22 @@ __global__ void __launch_bounds__(256) k_wipe_bytes(uint4* __restrict__ dst, uin
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i < n16) dst[i] = make_uint4(0, 0, 0, 0);
 }
+// rows of `stride16` 16-byte words each: the first n16 words of every row (the columns of a batch's proofs in the digit
+// rows, the quotient's operands and the walks' partial sums)
+__global__ void __launch_bounds__(64) k_wipe_rows16(uint4* __restrict__ base, uint32_t nrows, uint32_t stride16, uint32_t n16) {
+  const uint32_t j = blockIdx.x * 64 + threadIdx.x, r = blockIdx.y;
+  if (j >= n16 || r >= nrows) return;
+  base[(size_t)r * stride16 + j] = make_uint4(0, 0, 0, 0);
+}
+// parity tap of the wipes: how many 16-byte words of a buffer are not zero
+__global__ void __launch_bounds__(256) k_count_nonzero16(const uint4* __restrict__ src, size_t n16, unsigned long long* __restrict__ out) {
+  unsigned long long c = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+    const uint4 v = src[i];
+    c += (v.x | v.y | v.z | v.w) != 0;
+  }
+  if (c) atomicAdd(out, c);
+}
 __global__ void __launch_bounds__(64) k_wipe_v29(uint4* __restrict__ V29, uint32_t nrows, uint32_t B, uint32_t n) {
   const uint32_t j = blockIdx.x * 64 + threadIdx.x, r = blockIdx.y;
   if (j >= 3 * n || r >= nrows) return;

@@ -157,6 +157,8 @@ __global__ void __launch_bounds__(64) k_stage_in(const uint4* __restrict__ src, 
 __global__ void __launch_bounds__(64) k_wipe_cols(Fr* __restrict__ V, const uint32_t* __restrict__ rows, uint32_t nrows,
                                                   uint32_t B, uint32_t n);
 __global__ void __launch_bounds__(256) k_wipe_bytes(uint4* __restrict__ dst, uint32_t n16);
+__global__ void __launch_bounds__(64) k_wipe_rows16(uint4* __restrict__ base, uint32_t nrows, uint32_t stride16, uint32_t n16);
+__global__ void __launch_bounds__(256) k_count_nonzero16(const uint4* __restrict__ src, size_t n16, unsigned long long* __restrict__ out);
 __global__ void __launch_bounds__(64) k_wipe_v29(uint4* __restrict__ V29, uint32_t nrows, uint32_t B, uint32_t n);
 
 }  // namespace rlnamd

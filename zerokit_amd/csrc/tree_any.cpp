@@ -113,6 +113,8 @@ void TreeAny::init(int depth_, const uint8_t default_leaf_le[32]) {
   }
   depth = depth_;
   pend.reset(new Pending);
+  // up to host_max dirty leaves per pass take the host-core chain (MerkleTreeDev::set_few); 0 = always the device pass
+  host_max = MerkleTreeDev::host_max_from_env();
 }
 
 size_t TreeAny::pending_writes() const {
@@ -133,9 +135,13 @@ static void flush_locked(TreeAny& t) {
     idx.push_back(kv.first);
     leaves.insert(leaves.end(), kv.second.begin(), kv.second.end());
   }
-  w.clear();   // a failing pass must not be replayed for ever; the error reaches the reader that triggered it
+  // The writes leave the queue only when the pass has gone through: their writers were told "done" long ago (the FFI
+  // object has advanced its leaf bookkeeping), so a pass that throws (a HIP error, no pinned memory) must not lose them --
+  // the error reaches the reader that triggered it, and the next reader tries again.
   if (t.sparse) t.sp.set_many(idx.data(), leaves.data(), idx.size());
+  else if (idx.size() <= t.host_max) t.dense.set_few(idx.data(), leaves.data(), idx.size());
   else t.dense.set_scattered(idx.data(), leaves.data(), idx.size());
+  w.clear();
 }
 
 void TreeAny::flush_pending() {
