@@ -246,6 +246,16 @@ int rlnamd_pool_get_info(rlnamd_pool* p, rlnamd_prover_info* info);
 int rlnamd_pool_prove(rlnamd_pool* p, size_t n, const uint8_t* inputs_le, const uint8_t* rs_le, uint8_t* proofs,
                       uint8_t* values, uint32_t* errors);
 int rlnamd_pool_last_ms(rlnamd_pool* p, float* ms_per_replica);   /* host wall time of each replica's last shard */
+/* Assignment of a job's proofs to the replicas: 0 (default) = contiguous index shards, one per replica; 1 = dynamic, a
+ * cursor shared by the replicas over chunks of max_batch proofs (a slower device takes fewer chunks; at most three chunks
+ * in flight per replica).  The result is index-identical either way.  rlnamd_pool_last_proofs: how many proofs of the
+ * last job each replica made. */
+int rlnamd_pool_set_dynamic(rlnamd_pool* p, int on);
+int rlnamd_pool_last_proofs(rlnamd_pool* p, size_t* proofs_per_replica);
+/* test hook: replica `replica` fails (throws inside its worker) when it is handed its after_chunks-th next chunk; one
+ * shot.  The job that meets the fault returns an error naming the device, the other replicas finish their chunks, the
+ * witnesses of the failed replica's in-flight chunks are wiped, and the pool stays usable. */
+int rlnamd_pool_inject_fault(rlnamd_pool* p, size_t replica, size_t after_chunks);
 int rlnamd_pool_verify_many(rlnamd_pool* p, size_t n, const uint8_t* proofs, const uint8_t* values_le, size_t n_values,
                             int threads, uint8_t* ok);
 /* RCCL communicator for the one path with an exchange step, the config-5 MSM.  Multi-process (one process per GPU,

@@ -43,6 +43,12 @@ def lib():
         L.oracle_prove_many.restype = C.c_double
         L.oracle_prove_many.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_char_p,
                                         C.POINTER(C.c_int)]
+        L.oracle_num_public.restype = C.c_size_t
+        L.oracle_num_public.argtypes = [C.c_void_p]
+        L.oracle_input_slot.restype = C.c_int
+        L.oracle_input_slot.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.oracle_public_values.restype = None
+        L.oracle_public_values.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         L.oracle_tree_root.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_char_p]
         L.oracle_msm_expected.restype = None
         L.oracle_msm_expected.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_char_p]
@@ -70,8 +76,8 @@ def _b(x):
 
 
 class Circuit:
-    def __init__(self, depth=20):
-        d = os.path.join(_RES, "tree_depth_%d" % depth)
+    def __init__(self, depth=20, multi=False):
+        d = os.path.join(_RES, "tree_depth_%d%s" % (depth, "_multi_max_out_4" if multi else ""))
         z = open(os.path.join(d, "rln_final.arkzkey"), "rb").read()
         g = open(os.path.join(d, "graph.bin"), "rb").read()
         self.h = lib().oracle_load(z, len(z), g, len(g))
@@ -80,6 +86,14 @@ class Circuit:
         self.n_inputs = lib().oracle_num_inputs(self.h)
         self.n_signals = lib().oracle_num_signals(self.h)
         self.domain = lib().oracle_domain(self.h)
+        self.n_public = lib().oracle_num_public(self.h)
+        self.multi = multi
+        self.slots = {}
+        for name in ("identitySecret", "userMessageLimit", "messageId", "pathElements", "identityPathIndex", "x",
+                     "externalNullifier", "selectorUsed"):
+            off, ln = C.c_uint32(), C.c_uint32()
+            if lib().oracle_input_slot(self.h, name.encode(), C.byref(off), C.byref(ln)) == 0:
+                self.slots[name] = (off.value, ln.value)
 
     # slots of the shipped single-message graphs (graph.bin metadata; asserted in tests/test_oracle_c.py)
     SLOTS = dict(x=1, external_nullifier=2, identity_secret=3, user_message_limit=4, message_id=5, path_elements=6)
@@ -101,6 +115,50 @@ class Circuit:
         for i, e in enumerate(w["identity_path_index"]):
             put(6 + depth + i, e)
         return bytes(buf)
+
+    def pack_named(self, named):
+        """named: {graph signal name: [ints]} (witness.rs:832-881) -> the graph's inputs buffer, slot 0 = 1"""
+        buf = bytearray(self.n_inputs * 32)
+        buf[0] = 1
+        for name, vals in named.items():
+            off, ln = self.slots[name]
+            assert len(vals) == ln, (name, len(vals), ln)
+            for k, v in enumerate(vals):
+                buf[(off + k) * 32:(off + k + 1) * 32] = _b(v)
+        return bytes(buf)
+
+    def public_values(self, packed):
+        out = C.create_string_buffer(32 * self.n_public)
+        lib().oracle_public_values(self.h, packed, out)
+        return [int.from_bytes(out.raw[32 * k:32 * k + 32], "little") for k in range(self.n_public)]
+
+    def prove_packed(self, packed, r, s, want_witness=False):
+        """one proof from a packed inputs buffer (any shipped circuit) -> dict(proof, public_inputs[, witness])"""
+        proof = C.create_string_buffer(128)
+        wit = C.create_string_buffer(32 * self.n_signals) if want_witness else None
+        rc = lib().oracle_prove(self.h, packed, _b(r) + _b(s), proof, None, None, wit, None)
+        if rc:
+            raise RuntimeError("oracle_prove rc=%d" % rc)
+        out = dict(proof=proof.raw, public_inputs=self.public_values(packed))
+        if wit is not None:
+            out["witness"] = [int.from_bytes(wit.raw[32 * i:32 * i + 32], "little") for i in range(self.n_signals)]
+        return out
+
+    def prove_many_packed(self, inputs, rsb, threads=None):
+        """n proofs from packed buffers on host threads -> (seconds, [proof128], [public inputs])"""
+        n = len(rsb) // 64
+        assert len(inputs) == n * self.n_inputs * 32
+        threads = threads or os.cpu_count() or 1
+        proofs = C.create_string_buffer(128 * n)
+        values = C.create_string_buffer(32 * self.n_public * n)
+        rc = C.c_int(0)
+        secs = lib().oracle_prove_many(self.h, inputs, rsb, n, threads, proofs, values, C.byref(rc))
+        if rc.value:
+            raise RuntimeError("oracle_prove_many rc=%d" % rc.value)
+        np_ = self.n_public
+        pub = [[int.from_bytes(values.raw[32 * (np_ * i + k):32 * (np_ * i + k + 1)], "little") for k in range(np_)]
+               for i in range(n)]
+        return secs, [proofs.raw[128 * i:128 * (i + 1)] for i in range(n)], pub
 
     def prove(self, w, r, s, want_witness=False, want_h=False):
         proof = C.create_string_buffer(128)

@@ -1,6 +1,8 @@
 /* ORACLE -- test infrastructure, NOT product code.
  *
- * CPU restatement, in plain C, of the reference's RLN proving path for the depth-20 single-message circuit.
+ * CPU restatement, in plain C, of the reference's RLN proving path: the shipped single-message circuits (depth 20, depth
+ * 10) and the multi-message-id circuit (depth 20, max_out 4) -- the prover is generic over (arkzkey, graph), the proof
+ * values follow witness.rs:759-802 for both variants.
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
  * (zerokit_amd/) never links or calls it.
  *
@@ -278,6 +280,7 @@ typedef struct {
   /* graph */
   gnode* nodes; size_t n_nodes; fe* consts; uint32_t* signals; size_t n_signals; size_t n_inputs;
   uint32_t off_secret, off_limit, off_msg, off_path, off_idx, off_x, off_ext, depth;
+  uint32_t off_sel, n_msg, has_sel; /* multi-message-id circuit: selectorUsed[max_out], messageId[max_out] */
   /* ntt */
   int logn; size_t n; fe *tw, *twi, *coset; fe ninv;
 } circuit;
@@ -367,7 +370,7 @@ static int parse_graph(circuit* C, const uint8_t* d, size_t len) { /* storage.rs
         else if ((k2 >> 3) == 2 && (k2 & 7) == 2) { u64 sl = rd_varint(&p); const uint8_t* se = p + sl; while (p < se) { u64 k3 = rd_varint(&p); u64 v = rd_varint(&p); if ((k3 >> 3) == 1) off = (uint32_t)v; else if ((k3 >> 3) == 2) ln = (uint32_t)v; } }
         else pb_skip(&p, (int)(k2 & 7)); }
       if (!strcmp(name, "identitySecret")) C->off_secret = off; else if (!strcmp(name, "userMessageLimit")) C->off_limit = off;
-      else if (!strcmp(name, "messageId")) C->off_msg = off; else if (!strcmp(name, "pathElements")) { C->off_path = off; C->depth = ln; }
+      else if (!strcmp(name, "messageId")) { C->off_msg = off; C->n_msg = ln; } else if (!strcmp(name, "selectorUsed")) { C->off_sel = off; C->has_sel = 1; } else if (!strcmp(name, "pathElements")) { C->off_path = off; C->depth = ln; }
       else if (!strcmp(name, "identityPathIndex")) C->off_idx = off; else if (!strcmp(name, "x")) C->off_x = off;
       else if (!strcmp(name, "externalNullifier")) C->off_ext = off;
     } else pb_skip(&p, wt);
@@ -490,6 +493,45 @@ static void proof_values(const circuit* C, const uint8_t* in, uint8_t* out160) {
   fe_to_bytes(&FR, out160 + 96, &x); fe_to_bytes(&FR, out160 + 128, &ext);
 }
 
+/* Public inputs in the verifier's order for either variant: single (proof.rs:863-869) y, root, nullifier, x, ext = the 160
+ * bytes of proof_values; multi (witness.rs:777-802, proof.rs:870-885) ys[max_out], root, nullifiers[max_out], x, ext,
+ * selector_used[max_out], where an unused slot contributes y = 0 and nullifier = 0. */
+size_t oracle_num_public(void* h) { return (size_t)((circuit*)h)->n_inst - 1; }
+int oracle_input_slot(void* h, const char* name, uint32_t* off, uint32_t* len) {
+  const circuit* C = (const circuit*)h;
+  if (!strcmp(name, "identitySecret")) { *off = C->off_secret; *len = 1; } else if (!strcmp(name, "userMessageLimit")) { *off = C->off_limit; *len = 1; }
+  else if (!strcmp(name, "messageId")) { *off = C->off_msg; *len = C->n_msg; } else if (!strcmp(name, "pathElements")) { *off = C->off_path; *len = C->depth; }
+  else if (!strcmp(name, "identityPathIndex")) { *off = C->off_idx; *len = C->depth; } else if (!strcmp(name, "x")) { *off = C->off_x; *len = 1; }
+  else if (!strcmp(name, "externalNullifier")) { *off = C->off_ext; *len = 1; }
+  else if (!strcmp(name, "selectorUsed") && C->has_sel) { *off = C->off_sel; *len = C->n_msg; } else return -1;
+  return 0;
+}
+static void public_values(const circuit* C, const uint8_t* in, uint8_t* out) {
+  if (!C->has_sel) { proof_values(C, in, out); return; }
+  fe secret, limit, x, ext, idc, root, t[3], zero; memset(&zero, 0, sizeof zero);
+  fe_from_bytes(&FR, &secret, in + 32 * C->off_secret); fe_from_bytes(&FR, &limit, in + 32 * C->off_limit);
+  fe_from_bytes(&FR, &x, in + 32 * C->off_x); fe_from_bytes(&FR, &ext, in + 32 * C->off_ext);
+  poseidon(&idc, &secret, 1); t[0] = idc; t[1] = limit; poseidon(&root, t, 2);
+  for (uint32_t i = 0; i < C->depth; i++) {
+    fe e; fe_from_bytes(&FR, &e, in + 32 * (C->off_path + i));
+    const uint8_t* b = in + 32 * (C->off_idx + i); int nz = 0; for (int k = 0; k < 32; k++) nz |= b[k];
+    if (!nz) { t[0] = root; t[1] = e; } else { t[0] = e; t[1] = root; }
+    poseidon(&root, t, 2);
+  }
+  const uint32_t mo = C->n_msg;
+  for (uint32_t k = 0; k < mo; k++) {
+    const uint8_t* sb = in + 32 * (C->off_sel + k); int used = 0; for (int q = 0; q < 32; q++) used |= sb[q];
+    fe msg, a1, y, nul; fe_from_bytes(&FR, &msg, in + 32 * (C->off_msg + k));
+    t[0] = secret; t[1] = ext; t[2] = msg; poseidon(&a1, t, 3);
+    fe_mul(&FR, &y, &x, &a1); fe_add(&FR, &y, &y, &secret); poseidon(&nul, &a1, 1);
+    fe_to_bytes(&FR, out + 32 * k, used ? &y : &zero); fe_to_bytes(&FR, out + 32 * (mo + 1 + k), used ? &nul : &zero);
+    memset(out + 32 * (2 * mo + 3 + k), 0, 32); out[32 * (2 * mo + 3 + k)] = used ? 1 : 0;
+  }
+  fe_to_bytes(&FR, out + 32 * mo, &root); fe_to_bytes(&FR, out + 32 * (2 * mo + 1), &x); fe_to_bytes(&FR, out + 32 * (2 * mo + 2), &ext);
+}
+/* the public values alone (num_public x 32 B): what a verifier is handed beside the proof */
+void oracle_public_values(void* h, const uint8_t* inputs_le, uint8_t* out) { public_values((const circuit*)h, inputs_le, out); }
+
 /* One proof.  inputs: n_inputs x 32 B (slot 0 = 1); rs: r|s; outputs optional. Returns 0 on success. */
 int oracle_prove(void* hnd, const uint8_t* inputs_le, const uint8_t* rs_le, uint8_t* proof128, uint8_t* coords256,
                  uint8_t* values160, uint8_t* witness_le, uint8_t* h_le) {
@@ -536,18 +578,20 @@ int oracle_prove(void* hnd, const uint8_t* inputs_le, const uint8_t* rs_le, uint
   if (proof128) { g1_compress(&A, proof128); g2_compress(&B2, proof128 + 32); g1_compress(&Cc, proof128 + 96); }
   if (coords256) { fe_to_bytes(&FQ, coords256, &A.x); fe_to_bytes(&FQ, coords256 + 32, &A.y); fe_to_bytes(&FQ, coords256 + 64, &B2.x.c0); fe_to_bytes(&FQ, coords256 + 96, &B2.x.c1);
     fe_to_bytes(&FQ, coords256 + 128, &B2.y.c0); fe_to_bytes(&FQ, coords256 + 160, &B2.y.c1); fe_to_bytes(&FQ, coords256 + 192, &Cc.x); fe_to_bytes(&FQ, coords256 + 224, &Cc.y); }
-  if (values160) proof_values(C, inputs_le, values160);
+  if (values160) proof_values(C, inputs_le, values160); /* single-message circuits; oracle_public_values serves both */
   free(w); free(a); free(b); free(c); free(ws); free(hs);
   return 0;
 }
 
 typedef struct { void* h; const uint8_t *in, *rs; uint8_t *proofs, *values; size_t n, next; pthread_mutex_t* mu; int rc; } job;
 static void* worker(void* arg) {
-  job* J = (job*)arg; size_t ni = oracle_num_inputs(J->h);
+  job* J = (job*)arg; size_t ni = oracle_num_inputs(J->h), np = oracle_num_public(J->h);
   for (;;) {
     pthread_mutex_lock(J->mu); size_t i = J->next++; pthread_mutex_unlock(J->mu);
     if (i >= J->n) break;
-    int rc = oracle_prove(J->h, J->in + i * ni * 32, J->rs + i * 64, J->proofs ? J->proofs + i * 128 : NULL, NULL, J->values ? J->values + i * 160 : NULL, NULL, NULL);
+    /* values: num_public x 32 B per proof (160 B for the single-message circuits) */
+    int rc = oracle_prove(J->h, J->in + i * ni * 32, J->rs + i * 64, J->proofs ? J->proofs + i * 128 : NULL, NULL, NULL, NULL, NULL);
+    if (!rc && J->values) public_values((const circuit*)J->h, J->in + i * ni * 32, J->values + i * np * 32);
     if (rc) J->rc = rc;
   }
   return NULL;

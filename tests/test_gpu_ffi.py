@@ -509,6 +509,42 @@ def test_config_path_sizes_the_prover_and_batch_streams_past_max_batch(tmp_path)
     b = [m.generate_rln_proofs_batch([mws[i]], [rs[i]])[0] for i in (0, 64, 149)]   # one at a time: resident path
     for k, i in enumerate((0, 64, 149)):
         assert a[i].to_bytes_le() == b[k].to_bytes_le()
+    # ... and both judged by oracle/c on the same circuit (the library was compared with itself here): proof
+    # bytes and the values of witness.rs:777-802 for all 150
+    from oracle.c import binding as ob
+    o = ob.Circuit(20, multi=True)
+    named = []
+    for i in range(150):
+        w = ws[i + 1]
+        named.append({"identitySecret": [w["identity_secret"]], "userMessageLimit": [100],
+                      "messageId": [10 + i % 80, 3, 5, 7], "selectorUsed": [1, int(i % 2 == 0), 0, 1],
+                      "pathElements": w["path_elements"], "identityPathIndex": w["identity_path_index"], "x": [w["x"]],
+                      "externalNullifier": [w["external_nullifier"]]})
+    rsb = b"".join(r.to_bytes(32, "little") + s_.to_bytes(32, "little") for r, s_ in rs[:150])
+    _, oproofs, opub = o.prove_many_packed(b"".join(o.pack_named(w) for w in named), rsb)
+    for i in range(150):
+        assert oproofs[i] in a[i].to_bytes_le(), i
+        v = a[i].values
+        assert list(v.ys) + [v.root] + list(v.nullifiers) + [v.x, v.external_nullifier] + \
+            [int(bool(t)) for t in v.selector_used] == opub[i], i
+    del a, b, m
+    # the throughput shape behind the FFI on this circuit: one 200-proof batch in a 256-proof workspace (lanes = proofs,
+    # pair chunks), witnesses of the seeded multi-circuit workload
+    cfgp.write_text(json.dumps({"max_batch": 256}))
+    m = RLN.new_with_params(20, z, g, tree_config=str(cfgp))
+    named, rs2 = workload.circuit_range(7000, 200, 20, True)
+    mws = [RLNWitnessInput.new_multi(w["identitySecret"][0], w["userMessageLimit"][0], w["messageId"], w["pathElements"],
+                                     w["identityPathIndex"], w["x"][0], w["externalNullifier"][0],
+                                     [bool(t) for t in w["selectorUsed"]]) for w in named]
+    a = m.generate_rln_proofs_batch(mws, rs2)
+    rsb = b"".join(r.to_bytes(32, "little") + s_.to_bytes(32, "little") for r, s_ in rs2)
+    _, oproofs, opub = o.prove_many_packed(b"".join(o.pack_named(w) for w in named), rsb)
+    for i in range(200):
+        assert oproofs[i] in a[i].to_bytes_le(), i
+        v = a[i].values
+        assert list(v.ys) + [v.root] + list(v.nullifiers) + [v.x, v.external_nullifier] + \
+            [int(bool(t)) for t in v.selector_used] == opub[i], i
+    assert m.verify_with_roots(a[0], named[0]["x"][0], []) and m.verify_with_roots(a[199], named[199]["x"][0], [])
 
 
 def test_config_devices_puts_a_pool_behind_the_ffi_object(tmp_path):

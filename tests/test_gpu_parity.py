@@ -527,6 +527,61 @@ def test_other_circuits_depth10_and_multi_message_id():
         p.close()
 
 
+@pytest.mark.parametrize("depth,multi", [(10, False), (20, True)])
+def test_other_circuits_throughput_shape_vs_oracle(depth, multi):
+    """the path that makes the headline number (more than 128 proofs per batch: lanes = proofs walks,
+    pair chunks over the rows that share a witness scalar, GLV halves, the lanes = proofs interpreter and NTT passes) on
+    the OTHER shipped circuits -- depth 10 single, depth 20 multi-message-id (max_out 4: 15 public inputs in the order of
+    proof.rs:870-885, witness.rs:117-180) -- on the default tables and on a wide schedule (G1 14 + 9 x 13 bits, G2
+    3 x 16 + 6 x 15 bits: digits at both ends of the int16 range).  n = 129 (one proof past two waves) and 200, resident
+    and streamed: every proof's bytes and every public input equal oracle/c's (itself pinned to the pyref goldens of
+    these circuits in tests/test_oracle_c.py), every proof verifies on the host against those public inputs, and the
+    <= 64-proof latency shape of the same witnesses gives the same bytes."""
+    from oracle.c import binding as ob
+    from zerokit_amd import workload
+    from zerokit_amd.batch import BatchProver
+    o = ob.Circuit(depth, multi)
+    N = 200
+    named, rs = workload.circuit_range(1000, N, depth, multi)
+    rsb = b"".join(r.to_bytes(32, "little") + s.to_bytes(32, "little") for r, s in rs)
+    _, ref_proofs, ref_pub = o.prove_many_packed(b"".join(o.pack_named(w) for w in named), rsb)
+    assert len(set(ref_proofs)) == N
+    for wb in (0, 3150113):
+        p = BatchProver(max_batch=256, window_bits=wb, depth=depth, multi=multi)
+        try:
+            assert p.slots == o.slots and p.num_public == o.n_public
+            inp = p.pack_named_inputs(named)
+            assert inp == b"".join(o.pack_named(w) for w in named)
+            per = p.inputs_size * 32
+            for n in (129, 200, 64, 3):
+                k = p.upload(inp[:n * per], rs[:n])
+                p.run(k)
+                out, pub = p.download(k), p.download_public(k)
+                assert all(x["error"] == 0 for x in out), (wb, n)
+                assert [x["proof"] for x in out] == ref_proofs[:n], (wb, n)
+                assert pub == ref_pub[:n], (wb, n)
+                if n == 200:
+                    assert all(p.verify_public(out[i]["proof"], pub[i]) for i in range(n)), wb
+                    bad = list(pub[7])
+                    bad[0] ^= 1
+                    assert not p.verify_public(out[7]["proof"], bad)
+            # streamed (submit / collect), the public signals taken before the collect wipes the witness
+            import ctypes as C
+            from zerokit_amd import lib
+            from zerokit_amd._native import check
+            for n in (200, 129):
+                t, k = p.submit(inp[:n * per], rsb[:64 * n])
+                buf = C.create_string_buffer(32 * p.num_public * n)
+                check(lib().rlnamd_prover_collect_public(p._h, t, n, buf))
+                got = p.collect(t, k)
+                assert [g["proof"] for g in got] == ref_proofs[:n], (wb, n)
+                q = p.num_public
+                assert [[int.from_bytes(buf.raw[32 * (i * q + j):32 * (i * q + j + 1)], "little") for j in range(q)]
+                        for i in range(n)] == ref_pub[:n], (wb, n)
+        finally:
+            p.close()
+
+
 def test_both_graph_interpreters_give_the_golden_witness(monkeypatch):
     """The graph interpreter runs in the 9 x 29-bit limb form by default (k_witness29: static value bounds and G_RED
     reductions chosen on the host, stored signals converted by k_v29_to_fr); RLNAMD_WIT29=0 keeps the 8 x 32 one.  Both

@@ -104,3 +104,44 @@ def test_side_config_oracles_config3_and_config5():
     assert t.proof(41) == (list(pe), list(pb))
     t.close()
     assert workload.tree_update_stream(1 << 20, 40, 0x5CA7, 0x5CA7000000000000) == ob.scattered_updates(1 << 20, 40)
+
+
+def test_c_oracle_on_the_other_shipped_circuits_vs_goldens_and_pyref():
+    """oracle/c is generic over (arkzkey, graph): on the depth-10 single circuit and the depth-20 multi-message-id circuit
+    it reproduces the pyref-generated goldens (tests/golden/rln_other_circuits.json: proof bytes, public inputs in the
+    verifier's order) -- which pins it as the judge of the GPU's throughput shape on those circuits
+    (tests/test_gpu_parity.py::test_other_circuits_throughput_shape_vs_oracle).  On items of the seeded workload the
+    Poseidon-formula public values (witness.rs:759-802) equal the circuit's own public signals w[1..], and pyref's
+    proof_values_multi agrees."""
+    import json
+    import os
+    from oracle.c import binding as ob
+    from oracle.pyref import rln as pr
+    from zerokit_amd import workload
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = json.load(open(os.path.join(root, "tests", "golden", "rln_other_circuits.json")))["cases"]
+    assert {(c["depth"], c["multi"]) for c in cases} == {(10, False), (20, True)}
+    for c in cases:
+        o = ob.Circuit(c["depth"], c["multi"])
+        named = {k: [int(v) for v in vs] for k, vs in c["inputs"].items()}
+        out = o.prove_packed(o.pack_named(named), int(c["r"]), int(c["s"]), want_witness=True)
+        assert out["proof"].hex() == c["proof_compressed"], c["name"]
+        assert [str(v) for v in out["public_inputs"]] == c["public"], c["name"]
+        assert out["witness"][1:1 + o.n_public] == out["public_inputs"], c["name"]
+        ws, rs = workload.circuit_range(40, 3, c["depth"], c["multi"])
+        inp = b"".join(o.pack_named(w) for w in ws)
+        rsb = b"".join(r.to_bytes(32, "little") + s.to_bytes(32, "little") for r, s in rs)
+        _, proofs, pub = o.prove_many_packed(inp, rsb, threads=3)
+        for i, w in enumerate(ws):
+            one = o.prove_packed(o.pack_named(w), rs[i][0], rs[i][1], want_witness=True)
+            assert one["proof"] == proofs[i] and one["public_inputs"] == pub[i]
+            assert one["witness"][1:1 + o.n_public] == pub[i]
+            if c["multi"]:
+                assert pub[i] == pr.proof_values_multi(w["identitySecret"][0], w["userMessageLimit"][0], w["messageId"],
+                                                       w["selectorUsed"], w["pathElements"], w["identityPathIndex"],
+                                                       w["x"][0], w["externalNullifier"][0])
+                assert any(w["selectorUsed"]) and len(set(w["messageId"])) == 4 and max(w["messageId"]) < 100
+            else:
+                wi = pr.WitnessInput(w["identitySecret"][0], w["userMessageLimit"][0], w["messageId"][0], w["pathElements"],
+                                     w["identityPathIndex"], w["x"][0], w["externalNullifier"][0])
+                assert pub[i] == pr.public_inputs(pr.proof_values_from_witness(wi))

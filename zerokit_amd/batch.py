@@ -385,6 +385,18 @@ class ProverPool:
         check(lib().rlnamd_pool_last_ms(self._h, ms))
         return [float(x) for x in ms]
 
+    def set_dynamic(self, on=True):
+        """chunk-granular dynamic assignment (a cursor shared by the replicas) instead of contiguous shards"""
+        check(lib().rlnamd_pool_set_dynamic(self._h, 1 if on else 0))
+
+    def last_proofs(self):
+        k = (C.c_size_t * self.size)()
+        check(lib().rlnamd_pool_last_proofs(self._h, k))
+        return [int(x) for x in k]
+
+    def inject_fault(self, replica, after_chunks=0):
+        check(lib().rlnamd_pool_inject_fault(self._h, replica, after_chunks))
+
     def verify_many(self, proofs, public_inputs, threads=0):
         n = len(proofs)
         if n == 0:

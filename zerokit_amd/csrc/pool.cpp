@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -62,6 +63,7 @@ struct Replica {
   size_t lo = 0, hi = 0;
   std::string error;   // of construction or of the last job
   float last_ms = 0;   // wall time of the last shard on this replica
+  size_t last_proofs = 0, chunks_taken = 0;   // proofs of the last job this replica made; chunks it was handed (all jobs)
 };
 
 }  // namespace
@@ -73,6 +75,17 @@ struct rlnamd_pool {
   std::condition_variable done_cv;
   size_t pending = 0;
   size_t inputs_size = 0;
+  // Assignment of a job's proofs to the replicas.  static (default): contiguous index shards, one per replica (SURVEY
+  // 8e; equal devices finish together and a shard streams through every workspace slot).  dynamic: a cursor shared by
+  // the replicas over chunks of capacity() proofs -- a replica takes the next chunk whenever one of its (at most three)
+  // in-flight places is free, so a device that runs slower (a box-to-box clock spread of +- 3 % was measured, a
+  // throttled or shared device is worse) simply takes fewer.  The result is index-identical either way.
+  bool dynamic = false;
+  std::atomic<size_t> cursor{0};
+  // test hook (rlnamd_pool_inject_fault): replica `fault_replica` throws when it is handed its `fault_after`-th chunk
+  // (counted over the pool's lifetime); one shot
+  std::atomic<long> fault_replica{-1};
+  size_t fault_after = 0;
 
   void worker(Replica* R, const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_t graph_len, ProverConfig cfg) {
     try {
@@ -98,11 +111,34 @@ struct rlnamd_pool {
       lk.unlock();
       R->error.clear();
       try {
-        if (hi > lo) {
+        R->last_proofs = 0;
+        const bool dyn = dynamic;
+        if (dyn || hi > lo) {
           auto t0 = std::chrono::steady_clock::now();
-          const size_t nib = R->prover->inputs_per_proof() * 32;
-          R->prover->prove_stream(hi - lo, j.inputs + lo * nib, j.rs + lo * 64, j.proofs ? j.proofs + lo * 128 : nullptr,
-                                  j.values ? j.values + lo * 160 : nullptr, j.errors ? j.errors + lo : nullptr);
+          const size_t cap = R->prover->capacity();
+          size_t at = lo;
+          auto next = [&](size_t* off, size_t* cnt) {
+            size_t o;
+            if (dyn) {
+              o = cursor.fetch_add(cap);
+              if (o >= j.n) return false;
+              *cnt = std::min(cap, j.n - o);
+            } else {
+              if (at >= hi) return false;
+              o = at;
+              *cnt = std::min(cap, hi - at);
+              at += *cnt;
+            }
+            *off = o;
+            if (fault_replica.load() >= 0 && rep[(size_t)fault_replica.load()].get() == R && R->chunks_taken >= fault_after) {
+              fault_replica.store(-1);
+              throw Error("injected fault (rlnamd_pool_inject_fault)");
+            }
+            R->chunks_taken++;
+            R->last_proofs += *cnt;
+            return true;
+          };
+          R->prover->prove_stream_from(next, j.inputs, j.rs, j.proofs, j.values, j.errors, dyn ? 3 : 0);
           R->last_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
       } catch (const std::exception& e) {
@@ -210,6 +246,7 @@ int rlnamd_pool_prove(rlnamd_pool* p, size_t n, const uint8_t* inputs_le, const 
   if (!inputs_le || !rs_le) throw Error("rlnamd_pool_prove: inputs and rs are required");
   std::lock_guard<std::mutex> job_lk(p->job_mu);
   const size_t N = p->rep.size();
+  p->cursor.store(0);
   {
     std::lock_guard<std::mutex> dl(p->done_mu);
     p->pending = N;
@@ -238,6 +275,23 @@ int rlnamd_pool_prove(rlnamd_pool* p, size_t n, const uint8_t* inputs_le, const 
   RLN_CATCH
 }
 
+int rlnamd_pool_set_dynamic(rlnamd_pool* p, int on) {
+  std::lock_guard<std::mutex> job_lk(p->job_mu);
+  p->dynamic = on != 0;
+  return RLNAMD_OK;
+}
+int rlnamd_pool_inject_fault(rlnamd_pool* p, size_t replica, size_t after_chunks) {
+  RLN_TRY
+  if (replica >= p->rep.size()) throw Error("rlnamd_pool_inject_fault: no such replica");
+  std::lock_guard<std::mutex> job_lk(p->job_mu);
+  p->fault_after = p->rep[replica]->chunks_taken + after_chunks;
+  p->fault_replica.store((long)replica);
+  RLN_CATCH
+}
+int rlnamd_pool_last_proofs(rlnamd_pool* p, size_t* proofs_per_replica) {
+  for (size_t i = 0; i < p->rep.size(); i++) proofs_per_replica[i] = p->rep[i]->last_proofs;
+  return RLNAMD_OK;
+}
 int rlnamd_pool_last_ms(rlnamd_pool* p, float* ms_per_replica) {
   for (size_t i = 0; i < p->rep.size(); i++) ms_per_replica[i] = p->rep[i]->last_ms;
   return RLNAMD_OK;

@@ -19,6 +19,7 @@
 // mixed additions only, no bucket reduction, no data-dependent writes.  288 GB of HBM is what makes the
 // table affordable (c = 8: 10 GB; c = 12: 90 GB).
 #pragma once
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -130,6 +131,12 @@ class Prover {
   void collect_public(uint64_t ticket, size_t n, std::vector<uint8_t>* out_le);
   int slots() const;
   // n proofs (any n) through submit / collect in chunks of <= capacity(), results in index order
+  // the same stream with the chunks handed out by `next` (false: no more; chunks of at most capacity() proofs at any
+  // offsets into the caller's arrays): a replica of a pool takes its contiguous shard this way, or whatever a cursor
+  // shared with the other replicas gives it (rlnamd_pool, dynamic assignment).  max_in_flight 0 = every workspace slot.
+  typedef std::function<bool(size_t* off, size_t* cnt)> ChunkSource;
+  void prove_stream_from(const ChunkSource& next, const uint8_t* inputs, const uint8_t* rs, uint8_t* proofs, uint8_t* values,
+                         uint32_t* errors, int max_in_flight = 0);
   void prove_stream(size_t n, const uint8_t* inputs, const uint8_t* rs, uint8_t* proofs, uint8_t* values,
                     uint32_t* errors);
   // Partial proofs.  PROVE_PARTIAL: inputs carry only the partial witness (unknown slots zero); the result is

@@ -1206,10 +1206,23 @@ int Prover::slots() const { return d_->nslot; }
 // gets instead of an upload / run / download loop that drains the pipeline after every chunk.
 void Prover::prove_stream(size_t n, const uint8_t* inputs, const uint8_t* rs, uint8_t* proofs, uint8_t* values,
                           uint32_t* errors) {
+  size_t at = 0;
+  prove_stream_from([&](size_t* off, size_t* cnt) {
+    if (at >= n) return false;
+    *off = at;
+    *cnt = std::min(B_, n - at);
+    at += *cnt;
+    return true;
+  }, inputs, rs, proofs, values, errors);
+}
+
+void Prover::prove_stream_from(const ChunkSource& next, const uint8_t* inputs, const uint8_t* rs, uint8_t* proofs,
+                               uint8_t* values, uint32_t* errors, int max_in_flight) {
   Impl& D = *d_;
   struct Pending { uint64_t ticket; size_t off, cnt; };
   std::deque<Pending> q;
   const size_t NIB = (size_t)D.NI * 32;
+  const int depth = max_in_flight > 0 ? std::min(max_in_flight, D.nslot) : D.nslot;
   auto take = [&]() {
     Pending f = q.front();
     q.pop_front();
@@ -1217,9 +1230,12 @@ void Prover::prove_stream(size_t n, const uint8_t* inputs, const uint8_t* rs, ui
             errors ? errors + f.off : nullptr);
   };
   try {
-    for (size_t off = 0; off < n; off += B_) {
-      size_t cnt = std::min(B_, n - off);
-      if ((int)q.size() == D.nslot) take();   // the slot the next submit reuses
+    size_t off = 0, cnt = 0;
+    for (;;) {
+      if ((int)q.size() == depth) take();   // the slot the next submit reuses
+      if (!next(&off, &cnt)) break;         // (asked only when a slot is free: a shared cursor hands out no chunk early)
+      if (cnt == 0) continue;
+      if (cnt > B_) throw Error("prove_stream: a chunk larger than the prover workspace (max_batch)");
       q.push_back({submit(cnt, inputs + off * NIB, rs + off * 64), off, cnt});
     }
     while (!q.empty()) take();

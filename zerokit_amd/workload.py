@@ -84,3 +84,44 @@ def tree_update_stream(n, count, seed, tag):
         z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
         out.append(((z ^ (z >> 31)) % n, tag + k))
     return out
+
+
+def circuit_range(first, n, depth=20, multi=False, seed=0xC1AC0175, max_out=4, limit=100):
+    """witnesses first .. first + n for ANY shipped circuit (depth 10 / 20 single, depth 20 multi-message-id), as the
+    named inputs of witness.rs:832-881 -> ([{graph signal name: [ints]}], [(r, s)]).  One SplitMix64(seed) stream,
+    4 * (depth + 5) + depth + 2 draws per witness in the order secret, path elements, x, external nullifier, r, s
+    (4 draws each, reduced mod r), path bits (one draw each), message-id base, selector bits.  Valid by construction
+    under RLNWitnessInput::new_single / new_multi (witness.rs:78-180): message ids distinct and below the limit, at
+    least one selector set.  Used by the size tests of the other circuits and bench.py's operating points."""
+    per = 4 * (depth + 5) + depth + 2
+    M = (1 << 64) - 1
+
+    def draw(j):
+        z = (seed + (j + 1) * GAMMA) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+
+    named, rs = [], []
+    for i in range(first, first + n):
+        b = per * i
+        fr = lambda k: sum(draw(b + 4 * k + q) << (64 * q) for q in range(4)) % R  # noqa: E731
+        secret = fr(0)
+        path = [fr(1 + k) for k in range(depth)]
+        x, ext, r, s = fr(depth + 1), fr(depth + 2), fr(depth + 3), fr(depth + 4)
+        o = b + 4 * (depth + 5)
+        bits = [int(draw(o + k) & 1) for k in range(depth)]
+        base, selw = draw(o + depth), draw(o + depth + 1)
+        w = {"identitySecret": [secret], "userMessageLimit": [limit], "pathElements": path, "identityPathIndex": bits,
+             "x": [x], "externalNullifier": [ext]}
+        if multi:
+            sel = [int((selw >> k) & 1) for k in range(max_out)]
+            if not any(sel):
+                sel[int(base % max_out)] = 1
+            w["messageId"] = [int((base + 7 * k) % limit) for k in range(max_out)]   # 7 k mod 100 distinct for k < 4
+            w["selectorUsed"] = sel
+        else:
+            w["messageId"] = [int(base % limit)]
+        named.append(w)
+        rs.append((r, s))
+    return named, rs
