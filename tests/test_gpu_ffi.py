@@ -452,6 +452,24 @@ def test_profile_key_names_an_operating_point(tmp_path):
     assert (int(info.capacity), int(info.window_bits), int(info.window_bits_g2)) == (256, 10, 12)
 
 
+def test_default_object_falls_back_to_the_small_point_when_the_device_is_nearly_full(monkeypatch, tmp_path):
+    """every ffi_rln_new* without a sizing key allocates ~23 GiB.  With less than 26 GiB free the object is
+    built at the "small" point instead (same proofs), below 10 GiB the error names the `profile` key; an explicit
+    choice is never second-guessed.  (The free-memory reading is overridden by a test hook.)"""
+    import json
+    from zerokit_amd.public import RLN
+    monkeypatch.setenv("RLNAMD_ASSUME_FREE_GIB", "20")
+    info = RLN(20).prover_info()
+    assert (int(info.capacity), int(info.window_bits), int(info.window_bits_g2)) == (64, 8, 8)
+    cfgp = tmp_path / "cfg.json"
+    cfgp.write_text(json.dumps({"profile": "latency"}))
+    info = RLN(20, tree_config=str(cfgp)).prover_info()
+    assert (int(info.capacity), int(info.window_bits), int(info.window_bits_g2)) == (256, 10, 12)
+    monkeypatch.setenv("RLNAMD_ASSUME_FREE_GIB", "5")
+    with pytest.raises(Exception, match="profile"):
+        RLN(20)
+
+
 def test_config_path_sizes_the_prover_and_batch_streams_past_max_batch(tmp_path):
     """the `window_bits` / `max_batch` keys of the config_path JSON (beside the PmTreeConfig keys of
     pm_tree_adapter.rs:139-174, which stay honoured) size the prover behind ffi_rln_new, and

@@ -219,6 +219,46 @@ template <int ITER> __global__ void __launch_bounds__(256) k_rate_add_u32(uint32
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// more of the instructions the products are made of, same shape (32-bit destination / two sources; 64-bit shifts)
+#define RATE32(NAME, ASM)                                                                                     \
+  template <int ITER> __global__ void __launch_bounds__(256) NAME(uint32_t* out, uint32_t a) {                \
+    uint32_t x[8];                                                                                            \
+    for (int k = 0; k < 8; k++) x[k] = threadIdx.x + k;                                                       \
+    uint32_t va = a + threadIdx.x;                                                                            \
+    _Pragma("unroll 1") for (int i = 0; i < ITER; i++) {                                                      \
+      for (int r = 0; r < 2; r++) {                                                                           \
+        asm volatile(ASM : "+v"(x[0]) : "v"(va) : "vcc"); asm volatile(ASM : "+v"(x[1]) : "v"(va) : "vcc");   \
+        asm volatile(ASM : "+v"(x[2]) : "v"(va) : "vcc"); asm volatile(ASM : "+v"(x[3]) : "v"(va) : "vcc");   \
+        asm volatile(ASM : "+v"(x[4]) : "v"(va) : "vcc"); asm volatile(ASM : "+v"(x[5]) : "v"(va) : "vcc");   \
+        asm volatile(ASM : "+v"(x[6]) : "v"(va) : "vcc"); asm volatile(ASM : "+v"(x[7]) : "v"(va) : "vcc");   \
+      }                                                                                                       \
+    }                                                                                                         \
+    uint32_t s = 0;                                                                                           \
+    for (int k = 0; k < 8; k++) s += x[k];                                                                    \
+    out[blockIdx.x * 256 + threadIdx.x] = s;                                                                  \
+  }
+RATE32(k_rate_mul_lo, "v_mul_lo_u32 %0, %0, %1")
+RATE32(k_rate_mul_hi, "v_mul_hi_u32 %0, %0, %1")
+RATE32(k_rate_and, "v_and_b32 %0, %0, %1")
+RATE32(k_rate_add_co, "v_add_co_u32 %0, vcc, %0, %1")
+RATE32(k_rate_addc_co, "v_addc_co_u32 %0, vcc, %0, %1, vcc")
+RATE32(k_rate_alignbit, "v_alignbit_b32 %0, %0, %1, 29")
+RATE32(k_rate_lshl_add, "v_lshl_add_u32 %0, %0, 3, %1")
+RATE32(k_rate_mad_u32_u24, "v_mad_u32_u24 %0, %0, %1, %1")
+template <int ITER> __global__ void __launch_bounds__(256) k_rate_lshr64(unsigned long long* out, unsigned long long a) {
+  unsigned long long x[8];
+  for (int k = 0; k < 8; k++) x[k] = a + threadIdx.x + k;
+#pragma unroll 1
+  for (int i = 0; i < ITER; i++) {
+#define X(k) asm volatile("v_lshrrev_b64 %0, 1, %0" : "+v"(x[k]));
+    REP8(X) REP8(X)
+#undef X
+  }
+  unsigned long long s = 0;
+  for (int k = 0; k < 8; k++) s += x[k];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 template <class K> static float time_kernel(K launch, int reps = 5) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   launch(); (void)hipDeviceSynchronize();
@@ -344,6 +384,19 @@ int main() {
     printf("v_lshl_add_u64 : %8.1f G wave-instr/s\n", winst / ms / 1e6);
     ms = time_kernel([&] { hipLaunchKernelGGL(k_rate_add_u32<RI>, dim3(BLOCKS), dim3(T), 0, 0, (uint32_t*)buf, 3u); });
     printf("v_add_u32      : %8.1f G wave-instr/s\n", winst / ms / 1e6);
+#define RUN32(NAME, LABEL)                                                                                          \
+    ms = time_kernel([&] { hipLaunchKernelGGL(NAME<RI>, dim3(BLOCKS), dim3(T), 0, 0, (uint32_t*)buf, 3u); });       \
+    printf("%-15s: %8.1f G wave-instr/s\n", LABEL, winst / ms / 1e6);
+    RUN32(k_rate_mul_lo, "v_mul_lo_u32")
+    RUN32(k_rate_mul_hi, "v_mul_hi_u32")
+    RUN32(k_rate_mad_u32_u24, "v_mad_u32_u24")
+    RUN32(k_rate_and, "v_and_b32")
+    RUN32(k_rate_add_co, "v_add_co_u32")
+    RUN32(k_rate_addc_co, "v_addc_co_u32")
+    RUN32(k_rate_alignbit, "v_alignbit_b32")
+    RUN32(k_rate_lshl_add, "v_lshl_add_u32")
+    ms = time_kernel([&] { hipLaunchKernelGGL(k_rate_lshr64<RI>, dim3(BLOCKS), dim3(T), 0, 0, (unsigned long long*)buf, 3ull); });
+    printf("%-15s: %8.1f G wave-instr/s\n", "v_lshrrev_b64", winst / ms / 1e6);
   }
   return 0;
 }

@@ -427,7 +427,29 @@ struct FFI_RLN {
         throw Error(std::string("Configuration error: devices: ") + rlnamd_last_error());
       prover = std::shared_ptr<Prover>(rlnamd_pool_replica_prover(pool, 0), [](Prover*) {});
     } else {
-      prover.reset(new Prover(zkey, zkey_len, graph, graph_len, cfg));
+      // A default object (no "profile" / "window_bits" / "max_batch" key, no RLNAMD_* sizing) takes the latency point:
+      // ~20 GiB of comb tables + ~3 GiB of workspaces.  Several objects per process, or a device that other work has
+      // filled, may not have that: then the object is built at the "small" point (7.7 GiB + 0.8 GiB: the same bytes
+      // out, single proofs within 0.2 ms of the default, batch calls slower) instead of failing where the reference's
+      // constructor cannot fail for lack of memory; below that the error names the key to set.
+      ProverConfig use = cfg;
+      const bool sized_by_caller = tcfg.window_bits > 0 || tcfg.max_batch > 0 || !tcfg.profile.empty() ||
+                                   (getenv("RLNAMD_WINDOW_BITS") && *getenv("RLNAMD_WINDOW_BITS")) ||
+                                   (getenv("RLNAMD_MAX_BATCH") && *getenv("RLNAMD_MAX_BATCH"));
+      size_t free_b = 0, total_b = 0;
+      if (!sized_by_caller && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const size_t GiB = (size_t)1 << 30;
+        if (const char* t = getenv("RLNAMD_ASSUME_FREE_GIB"))   // test hook: the decision below without filling a device
+          if (*t) free_b = (size_t)atoll(t) * GiB;
+        if (free_b < 26 * GiB) {
+          if (free_b < 10 * GiB)
+            throw Error("Configuration error: " + std::to_string(free_b / GiB) + " GiB of device memory free; an RLN object needs ~23 GiB "
+                        "at the default operating point and ~9 GiB at {\"profile\": \"small\"} (config_path JSON)");
+          use.window_bits = 8;
+          use.max_batch = 64;
+        }
+      }
+      prover.reset(new Prover(zkey, zkey_len, graph, graph_len, use));
     }
   }
   TreeAny tree;   // dense in HBM up to depth 30, sparse (host-indexed, device-hashed) for 31 .. 63
