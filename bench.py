@@ -21,11 +21,20 @@ host memory and copies them to the device inside the timer, and every step's res
           `rccl_ranks` = size of the communicator created through the C ABI).
 
 Extra objects on the line (every fraction can be recomputed from the line itself plus profiles/):
-  roofline      the dominant kernel, k_msm29<G1>.  `frac` = `hbm_frac` = SURVEY 8(d)'s definition: algorithmic bytes per
-                launch (`algorithmic_bytes_per_launch` = `algorithmic_bytes_per_proof` x batch) / `launch_ms` / 8 TB/s --
-                the number BASELINE.json's north_star asks for.  The kernel is NOT HBM-bound (`limiter`: VALU issue);
-                `valu_frac` = `valu.insts_per_launch` / `launch_ms` / (1024 SIMDs x 2.4 GHz / 4) says how close the launch
-                is to the bound that does bind, `valu_frac_alone` the same with nothing else in flight.
+  roofline      top level = the contract's object for k_msm29<G1>, the kernel with most of the step's work (61 % of a
+                batch's VALU instructions): `frac` = `hbm_frac` = SURVEY 8(d)'s definition, algorithmic bytes per launch
+                (`algorithmic_bytes_per_proof` x batch) / `launch_ms` / 8 TB/s -- the number BASELINE.json's north_star
+                asks for.  Neither walk is HBM-bound: what binds is VALU ISSUE CYCLES at a power-limited clock, so
+                `kernels` prices BOTH walks (k_msm29<G2> is the longest launch of a step) on both axes, and `whole_step`
+                prices every kernel of one batch against the step time:
+                  issue cycles = sum over instructions of the cycles one wave-instruction occupies its SIMD --
+                  4 for the quarter-rate class (v_mad_u64_u32, v_mul_lo_u32, 64-bit adds / shifts, carries: measured
+                  450 - 590 G wave-instr/s), 2 for plain 32-bit ops (measured ~1 020 G/s); the mix of one addition from the
+                  ISA (profiles/r5_walk_isa_mix.json), the instruction counts from PMC (profiles/r5_pmc_walks.json), both
+                  gated by a hash of the walk's sources.  `issue_frac` = issue cycles / (1024 SIMDs x 2.4 GHz x time):
+                  cannot exceed 1 (the clock never exceeds 2.4 GHz); `issue_frac_at_held_clock` uses the clock the walk
+                  kernels measured for themselves.  `peaks` names the two issue rates (the 4-cycle one is what
+                  v_mad_u64_u32 can reach, 614.4 G/s; the 2-cycle one, 1 228.8 G/s, only plain 32-bit ops reach).
   stage_ms      {"overlapped": spans inside the pipelined timed region (each includes whatever shared the chip with it),
                  "alone": the same stages of ONE batch with nothing else in flight}
   cpu_baseline  oracle/c (kind "port") on the host's usable cores, N = 1 only: config 2 (`value`, proofs/s) plus
@@ -52,9 +61,16 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before torch / HIP initialis
 # per-proof algorithmic bytes
 BYTES_PER_PROOF = 7468404
 MSM_G1_BYTES_PER_PROOF = (5844 + 5844 + 8192 + 5838) * 96   # A, B1, H, L operands (point 64 B + scalar 32 B)
+MSM_G2_BYTES_PER_PROOF = 5844 * (128 + 32)                  # B2 operands (G2 point 128 B + scalar 32 B) = 935 040
 CONFIG3_BYTES = 792723424
 HBM_PEAK_GBPS = 8000.0
-VALU_PEAK_GINST_NOMINAL = 1024 * 2.4e9 / 4 / 1e9            # 1024 SIMDs, one VALU instruction per 4 cycles, 2.4 GHz
+SIMDS, CLOCK_NOMINAL_HZ = 1024, 2.4e9
+# issue rates in wave-instructions per second over the chip at the nominal clock.  Measured (tools/microbench_dfma.hip,
+# profiles/r5_microbench_dfma.txt, at the ~2.0 GHz the box held): v_mad_u64_u32 495 - 505 G/s, v_mul_lo_u32 / carries /
+# 64-bit adds and shifts 530 - 590 G/s (4 cycles per wave-instruction); v_add_u32 / v_and_b32 / v_mov_b32 ~1 020 G/s (2)
+QUARTER_RATE_PEAK_GINST = SIMDS * CLOCK_NOMINAL_HZ / 4 / 1e9   # 614.4: the mad slot (was mislabelled "VALU peak")
+PLAIN_RATE_PEAK_GINST = SIMDS * CLOCK_NOMINAL_HZ / 2 / 1e9     # 1228.8: the guide's VALU issue rate, plain 32-bit ops only
+ONE_TIME_KERNELS = ("k_table_build", "k_table_to29", "k_consts_to29", "k_fr_to29")   # constructor, not part of a batch
 STREAM_WRAP = 64                                            # distinct batches kept in host memory
 SHARD = 8192                                                # config 4: proofs per GPU
 
@@ -73,10 +89,9 @@ def walk_source_hash():
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(ws, rs, target_seconds=10.0, side=None):
+def cpu_baseline(ws, rs, target_seconds=10.0):
     """Times oracle/c (the C restatement of the arkworks CPU path) on bounded samples; returns the dict for the JSON
-    line or None when the oracle library has not been built.  `side`: the GPU results of configs 3 / 5, so that the same
-    run also says whether the two sides computed the same thing."""
+    line or None when the oracle library has not been built."""
     try:
         from oracle.c import binding as ob
     except Exception:
@@ -123,7 +138,7 @@ TREE_SCATTERED = 1000    # scattered updates followed by ONE root read
 
 def load_pmc(info, B):
     """the committed PMC passes of the walks, if they were taken on this schedule and this build of the walk"""
-    for name in ("r4_pmc_walks.json", "r3_pmc_walks.json", "r2_pmc_walks.json"):
+    for name in ("r5_pmc_walks.json", "r4_pmc_walks.json", "r3_pmc_walks.json", "r2_pmc_walks.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:  # noqa: BLE001
@@ -141,23 +156,92 @@ def load_pmc(info, B):
     return None
 
 
-def valu_view(pm, info, B, alone_ms, clock_mhz):
-    """VALU side of the roofline for the G1 walk: wave-instructions of one launch (PMC SQ_INSTS_VALU of the same build
-    and schedule) over the launch by itself, against 1024 SIMDs x clock / 4"""
-    if pm is None or alone_ms <= 0:
+def load_mix():
+    """the ISA mix of one addition of the two walks (tools/isa_mix.py), if it belongs to this build of the walk"""
+    try:
+        mx = json.load(open(os.path.join(ROOT, "profiles", "r5_walk_isa_mix.json")))
+    except Exception:  # noqa: BLE001
         return None
-    k = pm["kernels"]["k_msm29<G1>"]
-    per_wave_add = k["SQ_INSTS_VALU"] / (k["lane_additions_per_launch"] / 64)
-    insts = per_wave_add * int(info.g1_rows) * int(info.windows) * B / 64
-    rate = insts / (alone_ms * 1e-3) / 1e9
-    out = {"source": pm["_file"], "valu_insts_per_wave_addition": round(per_wave_add, 1),
-           "valu_insts_per_launch_G": round(insts / 1e9, 3), "achieved_Ginst_per_s": round(rate, 1),
-           "peak_Ginst_per_s_at_2400MHz": round(VALU_PEAK_GINST_NOMINAL, 1),
-           "frac_of_nominal_clock_peak": round(rate / VALU_PEAK_GINST_NOMINAL, 4)}
-    if clock_mhz > 0:
-        out["clock_mhz"] = round(clock_mhz, 1)
-        out["frac_of_peak_at_measured_clock"] = round(rate / (1024 * clock_mhz * 1e6 / 4 / 1e9), 4)
-    return out
+    return mx if mx.get("walk_source_hash") == walk_source_hash() else None
+
+
+def issue_view(pm, mix, info, B, stage_ms, stage_alone, clock_timed, clock_alone, ms_per_step):
+    """Both walks and the whole step against the bound that binds: VALU issue cycles (module docstring).  Returns
+    (kernels dict, whole_step dict) or (None, None) when the committed PMC / ISA files do not match this build."""
+    if pm is None or mix is None:
+        return None, None
+    spec = {"k_msm29<G1>": ("msm_g1", "g1_walk", int(info.g1_rows) * int(info.windows), MSM_G1_BYTES_PER_PROOF),
+            "k_msm29<G2>": ("msm_g2", "g2_walk", int(info.g2_rows) * int(info.windows_g2), MSM_G2_BYTES_PER_PROOF)}
+    kernels, walk_cycles, walk_mads = {}, {}, 0.0
+    for tag, (stage, clk, adds_per_proof, alg) in spec.items():
+        k, m = pm["kernels"].get(tag), mix["kernels"].get(tag)
+        if not k or not m:
+            return None, None
+        wave_adds = adds_per_proof * B / 64
+        insts = k["SQ_INSTS_VALU"] / (k["lane_additions_per_launch"] / 64) * wave_adds
+        cycles = m["issue_cycles_per_wave_addition"] * wave_adds
+        walk_cycles[tag] = cycles
+        walk_mads += m["v_mad_u64_u32"] * wave_adds
+        o = {"algorithmic_bytes_per_proof": alg, "algorithmic_bytes_per_launch": alg * B,
+             "lane_additions_per_launch": adds_per_proof * B,
+             "valu_insts_per_launch_G": round(insts / 1e9, 3), "valu_insts_per_wave_addition": round(insts / wave_adds, 1),
+             "mad_u64_u32_share": m["mad_u64_u32_share"], "quarter_rate_share": m["quarter_rate_share"],
+             "issue_cycles_per_wave_addition": m["issue_cycles_per_wave_addition"],
+             "issue_cycles_per_launch_G": round(cycles / 1e9, 3),
+             "vgprs": m["registers"].get("NumVgprs"), "scratch_bytes_per_lane": m["registers"].get("scratch_bytes_per_lane"),
+             "waves_per_simd": m["registers"].get("Occupancy")}
+        if "traffic_bytes_per_launch" in k:
+            o["traffic_GB_per_launch"] = round(k["traffic_bytes_per_launch"] / 1e9, 3)
+        for label, t_ms, mhz in (("", stage_ms.get(stage, 0.0), clock_timed.get(clk, 0.0)),
+                                 ("_alone", stage_alone.get(stage, 0.0), clock_alone.get(clk, 0.0))):
+            if t_ms <= 0:
+                continue
+            t = t_ms * 1e-3
+            o["launch_ms" + label] = round(t_ms, 3)
+            o["hbm_GBps" + label] = round(alg * B / t / 1e9, 3)
+            o["hbm_frac" + label] = round(alg * B / t / 1e9 / HBM_PEAK_GBPS, 6)
+            o["valu_Ginst_per_s" + label] = round(insts / t / 1e9, 1)
+            o["issue_frac" + label] = round(cycles / (SIMDS * CLOCK_NOMINAL_HZ * t), 4)
+            if mhz > 0:
+                o["clock_mhz" + label] = round(mhz, 1)
+                o["issue_frac_at_held_clock" + label] = round(cycles / (SIMDS * mhz * 1e6 * t), 4)
+        kernels[tag] = o
+    # every kernel of one batch: instruction counts from PMC x launches per batch; the walks at their ISA mix, the rest
+    # between "every instruction the counters do not class as 64-bit integer is a 2-cycle one" and "all are 4-cycle ones"
+    n_all, lo, hi, per_kernel = 0.0, 0.0, 0.0, {}
+    for tag, k in pm["kernels"].items():
+        lpb = k.get("launches_per_batch")
+        if not lpb or tag in ONE_TIME_KERNELS or "SQ_INSTS_VALU" not in k:
+            continue
+        n = k["SQ_INSTS_VALU"] * lpb
+        n_all += n
+        if tag in walk_cycles:
+            c_lo = c_hi = walk_cycles[tag]
+        else:
+            q = min(k.get("SQ_INSTS_VALU_INT64", 0.0) * lpb, n)
+            c_lo, c_hi = 4 * q + 2 * (n - q), 4 * n
+        lo += c_lo
+        hi += c_hi
+        per_kernel[tag] = round(n / 1e9, 4)
+    t = ms_per_step * 1e-3
+    held = [v for v in clock_timed.values() if v > 0]
+    mhz = sum(held) / len(held) if held else 0.0
+    denom = SIMDS * CLOCK_NOMINAL_HZ * t
+    whole = {"what": "every kernel of one 1024-proof batch (PMC instruction counts x launches per batch) against ms_per_step",
+             "valu_insts_per_batch_G": round(n_all / 1e9, 3), "valu_insts_by_kernel_G": dict(sorted(per_kernel.items(), key=lambda kv: -kv[1])),
+             "walks_share_of_insts": round(sum(per_kernel.get(w, 0) for w in walk_cycles) * 1e9 / n_all, 4),
+             "valu_Ginst_per_s": round(n_all / t / 1e9, 1),
+             "issue_cycles_per_batch_G": [round(lo / 1e9, 3), round(hi / 1e9, 3)],
+             "issue_frac": [round(lo / denom, 4), round(hi / denom, 4)],
+             "mad_u64_u32_slot_frac": round(4 * walk_mads / denom, 4),
+             "note": "issue_frac = [lower, upper] bound of busy VALU issue cycles / (1024 SIMDs x 2.4 GHz x ms_per_step): the "
+                     "walks (85 % of the instructions) at their measured ISA mix, the other kernels between 2 and 4 cycles per "
+                     "instruction; mad_u64_u32_slot_frac = the share of all issue cycles that v_mad_u64_u32 of the two walks "
+                     "alone occupies"}
+    if mhz > 0:
+        whole["clock_mhz_under_the_walks"] = round(mhz, 1)
+        whole["issue_frac_at_held_clock"] = [round(lo / (SIMDS * mhz * 1e6 * t), 4), round(hi / (SIMDS * mhz * 1e6 * t), 4)]
+    return kernels, whole
 
 
 def tree_update_stream(n):
@@ -291,17 +375,46 @@ def measure_config5(comm, rank, world, steps=3, log2n=24):
         m.close()
     ms = sum(times) / len(times) * 1e3
     gbps = n_total * 96 / (ms * 1e-3) / 1e9
+    # what each of eight GPUs would run: ONE 2^(log2n - 3)-point shard through the same call, on this device,
+    # with this one-rank communicator -- the 8-way time is that plus the all-gather of 8 x 2 KiB
+    shard, shard_res = None, None
+    if world == 1 and log2n >= 8:
+        ns = n_total // 8
+        m = MsmG1(ns)
+        try:
+            m.generate(0xC0FFEE, 0, ns)
+            m.run_sharded(comm)
+            ts, sst = [], {}
+            for _ in range(max(steps, 3)):
+                t0 = time.perf_counter()
+                shard_res, sst = m.run_sharded(comm)
+                ts.append(time.perf_counter() - t0)
+        finally:
+            m.close()
+        sms = sum(ts) / len(ts) * 1e3
+        shard = {"points": ns, "ms": round(sms, 3), "stage_ms": {k: round(v, 3) for k, v in sst.items()},
+                 "projected_8_way_ms": round(sms, 3),
+                 "projected_speedup_on_8_gpus": round(ms / sms, 2),
+                 "note": "one of the eight contiguous slices by point index, timed alone on this device through "
+                         "rlnamd_msm_run_sharded (sort, buckets, a one-rank ncclAllGather, the fold); on eight devices the "
+                         "all-gather moves 8 x 2 KiB over xGMI instead (tens of microseconds): NOT measured on hardware"}
     ok, judge = True, None
     if rank == 0:   # the closed form (sum k_i s_i) G comes from the ORACLE; the library states no expected value of its own
         try:
             from oracle.c import binding as ob
             ok, judge = res == ob.msm_expected(0xC0FFEE, 0, n_total), "oracle/c closed form (sum k_i s_i mod r) G"
+            if shard is not None:
+                shard["correct"] = bool(shard_res == ob.msm_expected(0xC0FFEE, 0, n_total // 8))
+                ok = ok and shard["correct"]
         except Exception as e:  # noqa: BLE001
             ok, judge = False, "oracle unavailable: %s" % e
     return {"workload": "config 5: single 2^%d-point BN254 G1 MSM, %d-way split, ncclAllGather of window sums"
                         % (log2n, world),
             "ms": round(ms, 3), "rccl_ranks": comm.ranks(), "correct": bool(ok), "checked_by": judge,
             "stage_ms_rank0": {k: round(v, 3) for k, v in st.items()},
+            "fold": os.environ.get("RLNAMD_MSM_FOLD", "host") + " (the 240 dependent doublings of the last step: 0.05 ms on a "
+                    "host core, 1.5 - 1.9 ms on a lone GPU lane)",
+            "shard_2^%d" % (log2n - 3): shard,
             "roofline": {"bound": "hbm", "limiter": "valu issue (bucket additions)",
                          "algorithmic_bytes_per_launch": n_total * 96, "achieved": round(gbps, 2),
                          "peak": HBM_PEAK_GBPS * world, "unit": "GB/s", "frac": round(gbps / (HBM_PEAK_GBPS * world), 5)}}
@@ -455,7 +568,7 @@ def main():
         return pool_main(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # test hooks for boxes with fewer devices than ranks (tools/gpu_r3_torchrun.sh): every rank on one device, gloo
+    # test hooks for boxes with fewer devices than ranks (tests/test_gpu_stream_pool.py::test_bench_under_torchrun_with_eight_ranks_on_one_device): every rank on one device, gloo
     # instead of RCCL (which refuses two ranks on one device); the driver never sets them
     backend = os.environ.get("RLNAMD_BENCH_BACKEND", "nccl")
     if "RLNAMD_BENCH_DEVICE" in os.environ:
@@ -464,7 +577,7 @@ def main():
     # A single-GPU run imports no torch at all: librln.so brings in the HIP runtime it was built for (/opt/rocm).  Under
     # torchrun torch is needed for the barrier and the max over ranks, and it goes FIRST: with librln.so (ROCm 7.2's
     # libamdhip64 / librccl) loaded before a torch wheel built for ROCm 7.0 the process aborted at exit ("double free or
-    # corruption", tools/gpu_r3_torchrun.sh).  The streamed path no longer depends on which runtime it gets: the inputs
+    # corruption", tests/test_gpu_stream_pool.py::test_bench_under_torchrun_with_eight_ranks_on_one_device).  The streamed path no longer depends on which runtime it gets: the inputs
     # are staged by a kernel, not by the copy path that was slow under the wheel's runtime (profiles/r3 section 1).
     use_dist = under_torchrun                              # under torchrun the process group is always created
     torch = dist = None
@@ -663,35 +776,45 @@ def main():
         msm_ms = stage_ms.get("msm_g1", 0.0)
         hbm_achieved = (MSM_G1_BYTES_PER_PROOF * B) / (msm_ms * 1e-3) / 1e9 if msm_ms > 0 else 0.0
         pm = load_pmc(info, B)
-        valu = valu_view(pm, info, B, g1_alone_ms, clock_alone_mhz.get("g1_walk", 0.0))
+        mix = load_mix()
+        ms_per_step = elapsed / steps * 1e3 / per_step       # per 1024-proof batch
+        kernels, whole = issue_view(pm, mix, info, B, stage_ms, stage_ms_alone, clock_mhz, clock_alone_mhz, ms_per_step)
         traffic = round(pm["kernels"]["k_msm29<G1>"]["traffic_bytes_per_launch"] / 1e9, 3) \
             if pm and "traffic_bytes_per_launch" in pm["kernels"]["k_msm29<G1>"] else None
-        # roofline of the dominant kernel, k_msm29<G1>.  SURVEY 8(d) / BASELINE.json define the fraction on the HBM side:
-        # ALGORITHMIC bytes per launch (A, B1, H, L operands: a 64-byte point + a 32-byte scalar each) / launch duration
-        # / 8 TB/s -- that is `frac` (= `hbm_frac`).  The kernel is not HBM-bound: what limits it is VALU issue, so the
-        # same launch is priced against that bound too (`valu_frac`: wave-instructions per launch from the committed PMC
-        # pass of this build and schedule / launch duration / (1024 SIMDs x 2.4 GHz / 4)).
+        # The contract's object (top level) is for k_msm29<G1>: SURVEY 8(d) / BASELINE.json define the fraction on the HBM
+        # side -- ALGORITHMIC bytes per launch (A, B1, H, L operands: a 64-byte point + a 32-byte scalar each) / launch
+        # duration / 8 TB/s.  Neither walk is HBM-bound; `kernels` and `whole_step` price them against VALU issue cycles.
         alg_bytes = MSM_G1_BYTES_PER_PROOF * B
-        roof = {"bound": "hbm", "limiter": "valu issue (one mixed addition = ~2 000 VALU wave-instructions; see valu_frac)",
-                "kernel": "k_msm29<G1> (G1 fixed-base table MSM, 9 x 29-bit limbs)",
+        roof = {"bound": "hbm",
+                "limiter": "VALU issue cycles at a power-limited clock (see kernels / whole_step: issue_frac)",
+                "kernel": "k_msm29<G1> (G1 fixed-base table MSM, 9 x 29-bit limbs): 61 % of a batch's VALU instructions; "
+                          "k_msm29<G2>, the longest launch of a step, is priced beside it under `kernels`",
                 "algorithmic_bytes_per_proof": MSM_G1_BYTES_PER_PROOF, "algorithmic_bytes_per_launch": alg_bytes,
                 "launch_ms": round(msm_ms, 3), "launch_ms_alone": round(g1_alone_ms, 3),
                 "achieved": round(hbm_achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(hbm_achieved / HBM_PEAK_GBPS, 6), "hbm_frac": round(hbm_achieved / HBM_PEAK_GBPS, 6),
                 "traffic": traffic,
                 "traffic_unit": "GB per launch (2*FETCH_SIZE + WRITE_SIZE, PMC pass of the same build: %s)"
-                                % (pm["_file"] if pm else "none")}
-        if valu:
-            insts = valu["valu_insts_per_launch_G"]
-            ach = insts / (msm_ms * 1e-3) if msm_ms > 0 else 0.0
-            roof["valu_frac"] = round(ach / VALU_PEAK_GINST_NOMINAL, 4)
-            roof["valu_frac_alone"] = valu["frac_of_nominal_clock_peak"]
-            roof["valu_achieved_Ginst_per_s"] = round(ach, 1)
-            roof["valu_peak_Ginst_per_s"] = round(VALU_PEAK_GINST_NOMINAL, 1)
+                                % (pm["_file"] if pm else "none"),
+                "peaks": {"hbm_GBps": HBM_PEAK_GBPS,
+                          "mad_slot_peak_Ginst_per_s": round(QUARTER_RATE_PEAK_GINST, 1),
+                          "valu_issue_peak_Ginst_per_s": round(PLAIN_RATE_PEAK_GINST, 1),
+                          "issue_cycles_per_s": SIMDS * CLOCK_NOMINAL_HZ,
+                          "note": "1024 SIMDs x 2.4 GHz; a wave-instruction of the quarter-rate class (v_mad_u64_u32, "
+                                  "v_mul_lo_u32, 64-bit adds / shifts, carries, FP64) occupies its SIMD for 4 cycles = the mad "
+                                  "slot, 614.4 G/s; a plain 32-bit op for 2 = the guide's VALU issue rate, 1 228.8 G/s "
+                                  "(profiles/r5_microbench_dfma.txt)"}}
+        if kernels:
+            roof["kernels"] = kernels
+            roof["whole_step"] = whole
+            roof["issue_frac"] = kernels["k_msm29<G1>"].get("issue_frac")
+            roof["issue_frac_alone"] = kernels["k_msm29<G1>"].get("issue_frac_alone")
+            roof["sources"] = {"pmc": pm["_file"], "isa_mix": "profiles/r5_walk_isa_mix.json",
+                               "walk_source_hash": walk_source_hash()}
         else:
-            roof["valu_frac"] = None
-            roof["valu_view_omitted"] = ("no PMC pass under profiles/ matches this schedule and this build of the walk "
-                                         "(walk_source_hash %s)" % walk_source_hash())
+            roof["kernels"] = roof["whole_step"] = None
+            roof["issue_view_omitted"] = ("no PMC pass / ISA mix under profiles/ matches this schedule and this build of the "
+                                          "walk (walk_source_hash %s)" % walk_source_hash())
         roof.update({
             # what the table-walk algorithm itself reads: one 64-byte entry per mixed addition (HBM capacity and traffic
             # traded for Pippenger's bucket reduction): not the algorithmic bytes of 8(d), reported beside them
@@ -699,10 +822,10 @@ def main():
             "table_walk_GBps_alone": round(g1_adds * 64 / (g1_alone_ms * 1e-3) / 1e9, 1) if g1_alone_ms > 0 else None,
             "madd_per_s": round(g1_adds / (msm_ms * 1e-3) / 1e9, 2) if msm_ms > 0 else None,
             "madd_per_s_alone": round(g1_adds / (g1_alone_ms * 1e-3) / 1e9, 2) if g1_alone_ms > 0 else None,
-            "valu": valu,
             "note": "launch_ms = mean HIP-event span of the last five launches of the timed region on the kernel's own "
-                    "stream (it shares the SIMDs with the G2 walk of the neighbouring batch; launch_ms_alone: nothing else in "
-                    "flight).  frac = algorithmic_bytes_per_launch / launch_ms / peak.  See DESIGN.md 4 and 6"})
+                    "stream (it shares the SIMDs with the G2 walk and the front / back ends of the neighbouring batches; "
+                    "launch_ms_alone: one batch with nothing else in flight, its two walks still side by side).  frac = "
+                    "algorithmic_bytes_per_launch / launch_ms / peak.  See DESIGN.md 4 and 6"})
         line = {
             "metric": "RLN Groth16 proofs/sec (BN254, h=20)" + (" -- finish_rln_proof from cached partial proofs "
                                                                  "(side measurement)" if finish else ""),
@@ -748,10 +871,23 @@ def main():
             line["single_proof_latency"] = latency
         if host_feed is not None:
             line["host_feed"] = host_feed
+        # how many ranks RCCL really had: the communicator created through the C ABI for config 5 when it ran, else the
+        # torch process group the barrier and the max-reduce went through.  A line that says n_gpus = N is only printed
+        # when that number is N; the gloo test hook for boxes with fewer devices than ranks says so.
         if "config5" in side:
             line["rccl_ranks"] = side["config5"]["rccl_ranks"]
+        elif use_dist and backend == "nccl":
+            line["rccl_ranks"] = dist.get_world_size()
+            line["rccl_ranks_source"] = "torch.distributed process group (backend nccl = RCCL)"
+        elif use_dist:
+            line["rccl_ranks"] = None
+            line["rccl_ranks_source"] = "test hook RLNAMD_BENCH_BACKEND=%s: no RCCL in this run" % backend
+        if use_dist and backend == "nccl" and line.get("rccl_ranks") != world:
+            print("bench: --gpus %d but RCCL had %s rank(s): refusing to print a line" % (world, line.get("rccl_ranks")),
+                  file=sys.stderr)
+            sys.exit(4)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(ws0, rs0, side=side)
+            line["cpu_baseline"] = cpu_baseline(ws0, rs0)
         OUT.emit(line)
     if hung:            # a thread is stuck inside a collective: leave without the runtime's teardown
         sys.stdout.flush()

@@ -474,6 +474,39 @@ def test_msm_g1_adversarial_distributions_vs_oracle():
     m.close()
 
 
+def test_msm_fold_on_the_host_and_on_the_device_agree_with_the_oracle(monkeypatch):
+    """the last step of config 5 -- adding the window sums of the contributors and 240 dependent doublings of one point --
+    runs on a host core by default (0.1 ms; a lone GPU lane needs 1.75 ms for the same chain) and on the device with
+    RLNAMD_MSM_FOLD=device: both equal the oracle's closed form, for one contributor and for a 3-way split, uniform and
+    skewed scalars; a window sum at infinity (all scalars below 2^16 leave the upper windows empty) included"""
+    from oracle.c import binding as ob
+    from zerokit_amd.batch import MsmG1
+    seed, n = 0xFEED, 3 * (1 << 14)
+    m = MsmG1(n)
+    try:
+        want = {mode: ob.msm_expected(seed, 0, n, mode) for mode in (0, 1)}
+        for fold in ("host", "device"):
+            monkeypatch.setenv("RLNAMD_MSM_FOLD", fold)
+            for mode in (0, 1):
+                m.generate(seed, 0, n, mode)
+                assert m.combine([m.run_windows()[0]]) == want[mode], (fold, mode)
+                blobs = []
+                for r in range(3):
+                    m.generate(seed, r * (n // 3), n // 3, mode)
+                    blobs.append(m.run_windows()[0])
+                assert m.combine(blobs) == want[mode], (fold, mode, "split")
+        # small scalars: set_host with scalars < 2^16 -> only window 0 holds anything
+        pts = [p for p, _ in m.fetch(0, 64)]
+        sc = [(7 * i + 1) for i in range(64)]
+        from oracle.pyref.bn254 import G1
+        acc = G1.msm_naive(pts, sc)
+        for fold in ("host", "device"):
+            monkeypatch.setenv("RLNAMD_MSM_FOLD", fold)
+            assert m.msm(pts, sc) == acc, fold
+    finally:
+        m.close()
+
+
 def test_msm_g1_config5_full_size_2_24_vs_oracle():
     """BASELINE config 5 at FULL size: 2^24 generated points on one device against the oracle's closed form; the same
     points as EIGHT 2^21 slices (the shards of the 8-way split of BASELINE.json) each against the oracle by itself and

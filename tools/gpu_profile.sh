@@ -34,6 +34,8 @@ pmc)
   pass write WRITE_SIZE
   pass tcc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum
   pass ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
+  pass wr TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
+  pass valu2 SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_ACTIVE_INST_VALU2 SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_IOPS
   python3 tools/pmc_collect.py $O $O/sq.json $O/pmc_walks.json; echo "collect rc=$?"
   find $O -name "*.csv" -size +6M -delete
   ;;

@@ -245,6 +245,14 @@ RATE32(k_rate_addc_co, "v_addc_co_u32 %0, vcc, %0, %1, vcc")
 RATE32(k_rate_alignbit, "v_alignbit_b32 %0, %0, %1, 29")
 RATE32(k_rate_lshl_add, "v_lshl_add_u32 %0, %0, 3, %1")
 RATE32(k_rate_mad_u32_u24, "v_mad_u32_u24 %0, %0, %1, %1")
+RATE32(k_rate_sub, "v_sub_u32 %0, %0, %1")
+RATE32(k_rate_or, "v_or_b32 %0, %0, %1")
+RATE32(k_rate_lshr32, "v_lshrrev_b32 %0, 3, %0")
+RATE32(k_rate_lshl32, "v_lshlrev_b32 %0, 1, %0")
+RATE32(k_rate_mov, "v_mov_b32 %0, %1")
+RATE32(k_rate_cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
+RATE32(k_rate_or3, "v_or3_b32 %0, %0, %1, %1")
+RATE32(k_rate_add3, "v_add3_u32 %0, %0, %1, %1")
 template <int ITER> __global__ void __launch_bounds__(256) k_rate_lshr64(unsigned long long* out, unsigned long long a) {
   unsigned long long x[8];
   for (int k = 0; k < 8; k++) x[k] = a + threadIdx.x + k;
@@ -395,6 +403,14 @@ int main() {
     RUN32(k_rate_addc_co, "v_addc_co_u32")
     RUN32(k_rate_alignbit, "v_alignbit_b32")
     RUN32(k_rate_lshl_add, "v_lshl_add_u32")
+    RUN32(k_rate_sub, "v_sub_u32")
+    RUN32(k_rate_or, "v_or_b32")
+    RUN32(k_rate_lshr32, "v_lshrrev_b32")
+    RUN32(k_rate_lshl32, "v_lshlrev_b32")
+    RUN32(k_rate_mov, "v_mov_b32")
+    RUN32(k_rate_cndmask, "v_cndmask_b32")
+    RUN32(k_rate_or3, "v_or3_b32")
+    RUN32(k_rate_add3, "v_add3_u32")
     ms = time_kernel([&] { hipLaunchKernelGGL(k_rate_lshr64<RI>, dim3(BLOCKS), dim3(T), 0, 0, (unsigned long long*)buf, 3ull); });
     printf("%-15s: %8.1f G wave-instr/s\n", "v_lshrrev_b64", winst / ms / 1e6);
   }

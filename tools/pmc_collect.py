@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Aggregates the rocprofv3 --pmc passes of tools/gpu_r3_pmc.sh (counter_collection.csv, one directory per pass) into
-profiles/r3_pmc_walks.json: per kernel the mean of every counter over its launches, plus the figures bench.py derives its
-VALU view and `roofline.traffic` from.  The schedule and the hash of the walk's source files are recorded so that
+"""Aggregates the rocprofv3 --pmc passes of `tools/gpu_profile.sh <tag> pmc` (counter_collection.csv, one directory per
+pass) into profiles/rN_pmc_walks.json: per kernel the mean of every counter over its launches and how many launches one
+batch makes of it, plus the figures bench.py derives its issue-slot view and `roofline.traffic` from.  The schedule and the hash of the walk's source files are recorded so that
 bench.py only uses the file for the build and schedule it was taken on.
 
     python tools/pmc_collect.py <dir with pass sub-directories> <bench json line of one pass> <out.json>
@@ -27,7 +27,9 @@ def tag(name):
               "k_v29_to_fr", "k_hquot", "k_fin_affine", "k_fin_out", "k_glv_fold"):
         if k in name:
             return k
-    return None
+    import re
+    m = re.search(r"\b(k_[a-z0-9_]+)", name)    # every other kernel of the library (staging, wipes, ...)
+    return m.group(1) if m else None
 
 
 def main():
@@ -59,7 +61,12 @@ def main():
         g2["valu_per_wave_addition"] = round(g2.get("SQ_INSTS_VALU", 0) / (g2["lane_additions_per_launch"] / 64), 1)
         if "FETCH_SIZE" in g2 and "WRITE_SIZE" in g2:
             g2["traffic_bytes_per_launch"] = int(2 * g2["FETCH_SIZE"] * 1024 + g2["WRITE_SIZE"] * 1024)
-    doc = {"source": "tools/gpu_r3_pmc.sh: rocprofv3 --pmc passes (counters only, one block per pass) of "
+    # launches of a kernel per 1024-proof batch (the G1 walk runs once per batch): lets a reader sum a counter over every
+    # kernel of one batch
+    per = g1.get("launches_seen", 0)
+    for k in kernels.values():
+        k["launches_per_batch"] = round(k["launches_seen"] / per, 3) if per else None
+    doc = {"source": "tools/gpu_profile.sh <tag> pmc: rocprofv3 --pmc passes (counters only, one block per pass) of "
                      "`bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-side-configs`; means over the launches seen",
            "walk_source_hash": walk_source_hash(),
            "schedule": {"window_bits": cfg["window_bits"], "windows": cfg["windows"],

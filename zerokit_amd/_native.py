@@ -4,7 +4,7 @@ The library is the product; this file only declares signatures.  It is loaded wi
 (when a program uses both) share one HIP runtime -- whichever of the two is loaded first brings in its
 libamdhip64.so.7 and the other binds to it (same SONAME).  A program that uses both should import torch FIRST: with this
 library (ROCm 7.2's runtime and RCCL) loaded before a torch wheel built for ROCm 7.0 the process aborted at exit with a
-double free (tools/gpu_r3_torchrun.sh).  Throughput does not depend on the order since the streamed inputs are staged by a
+double free (measured in round 3).  Throughput does not depend on the order since the streamed inputs are staged by a
 kernel instead of the copy path that was slow under the wheel's runtime (profiles/r3_rocprof_summary.md section 1);
 bench.py imports torch only under torchrun."""
 import ctypes as C

@@ -10,14 +10,16 @@
 //                    limb form (fq29.h), pieces of a bucket joined afterwards     <- the multiplier-bound kernel
 //   5. k_bucket_red  per (window, 32-bucket chunk): running-sum trick -> sum and weighted sum
 //      k_chunk_fix   weighted sum + chunk_base * sum
-//      k_sum_ranges  two-level tree over the chunks -> one point per window
-//   6. k_combine     adds the per-window sums of all contributing devices and runs Horner over the windows
+//      k_range_sum   two levels of 32-to-1 wave trees over the chunks -> one point per window
+//   6. the fold      adds the per-window sums of all contributing devices and runs Horner over the windows: 240 dependent
+//                    doublings of ONE point -- on a host core (0.1 ms; k_combine, the same on a lone GPU lane, 1.75 ms)
 // Multi-GPU: every rank runs 1-5 on its slice of the points; the 16 window sums (2 KB) are
 // exchanged with one all-gather and step 6 runs on every rank.  RCCL has no elliptic-curve reduce op, so the
 // "all-reduce of bucket partials" is realised as gather + local add.
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <vector>
 #include <rccl/rccl.h>
 
@@ -337,13 +339,15 @@ __global__ void __launch_bounds__(64) k_bucket_red(const G1XYZZ* __restrict__ bu
   uint32_t ch = blockIdx.x * 64 + threadIdx.x;
   if (ch >= nchunks) return;
   const G1XYZZ* b = buckets + (size_t)ch * MSM_CHUNK;
-  G1XYZZ run = G1XYZZ::inf(), wsum = G1XYZZ::inf();
+  // general additions in the 9 x 29 form (0.55 x the instructions of the 8 x 32 law; the chain of 64 of them per lane is
+  // pure latency at 2^21 points per device: 0.57 ms of a 6.9 ms shard)
+  G1Acc29 run = G1Acc29::inf(), wsum = G1Acc29::inf();
   for (int k = MSM_CHUNK - 1; k >= 0; k--) {
-    run.add(b[k]);
+    run.add(G1Acc29::from_xyzz(b[k]));
     wsum.add(run);
   }
-  chunkS[ch] = run;
-  chunkT[ch] = wsum;
+  chunkS[ch] = run.to_xyzz();
+  chunkT[ch] = wsum.to_xyzz();
 }
 
 // X = T + lo * S with lo = 32 * (chunk index within its window): bucket b holds digit value b + 1
@@ -362,13 +366,46 @@ __global__ void __launch_bounds__(64) k_chunk_fix(const G1XYZZ* __restrict__ chu
   chunkT[ch] = T;
 }
 
+// sums of ranges of 32 points: a wave per range, one point per lane of its first half, five levels of lane-to-lane
+// additions through LDS instead of one lane's 32 dependent additions (two such launches were 0.6 ms of a 2^21 shard)
 __global__ void __launch_bounds__(64) k_range_sum(const G1XYZZ* __restrict__ src, const Range* __restrict__ ranges,
                                                   uint32_t nr, G1XYZZ* __restrict__ dst) {
-  uint32_t r = blockIdx.x * 64 + threadIdx.x;
+  __shared__ G1XYZZ sh[32];
+  const uint32_t r = blockIdx.x, l = threadIdx.x;
   if (r >= nr) return;
-  G1XYZZ acc = G1XYZZ::inf();
-  for (uint32_t i = ranges[r].begin; i < ranges[r].end; i++) acc.add(src[i]);
-  dst[r] = acc;
+  const uint32_t b = ranges[r].begin, e = ranges[r].end;
+  G1Acc29 acc = G1Acc29::inf();
+  for (uint32_t i = b + l; i < e; i += 32)
+    if (l < 32) acc.add(G1Acc29::from_xyzz(src[i]));
+  for (uint32_t stride = 16; stride >= 1; stride >>= 1) {
+    if (l >= stride && l < 2 * stride) sh[l - stride] = acc.to_xyzz();
+    __syncthreads();
+    if (l < stride) acc.add(G1Acc29::from_xyzz(sh[l]));
+    __syncthreads();
+  }
+  if (l == 0) dst[r] = acc.to_xyzz();
+}
+
+// The same fold on the HOST (curve.h is __host__ __device__): 16 x k additions and 240 dependent doublings of ONE point.
+// On a lone GPU lane that chain is 1.75 ms (a doubling every ~7 us: k_combine); on a host core 0.1 ms -- and the result
+// is headed for the host anyway.  Default of run_sharded / combine; RLNAMD_MSM_FOLD=device keeps the kernel (parity
+// tests run both).
+static void fold_windows_host(const G1XYZZ* wsums, size_t k, uint8_t out_xy_le[64]) {
+  G1XYZZ total = G1XYZZ::inf();
+  for (int w = MSM_W - 1; w >= 0; w--) {
+    for (int d = 0; d < MSM_C; d++) total = total.dbl();
+    for (size_t r = 0; r < k; r++) total.add(wsums[r * MSM_W + w]);
+  }
+  G1Affine a = total.to_affine();
+  uint32_t c[8];
+  a.x.to_canonical(c);
+  memcpy(out_xy_le, c, 32);
+  a.y.to_canonical(c);
+  memcpy(out_xy_le + 32, c, 32);
+}
+static bool fold_on_device() {
+  const char* v = getenv("RLNAMD_MSM_FOLD");
+  return v && !strcmp(v, "device");
 }
 
 // window sums of `k` contributors ([k][W]) -> sum per window -> Horner over the windows -> affine
@@ -657,16 +694,28 @@ void MsmG1::run_sharded(void* nccl_comm, int nranks, uint8_t out_xy_le[64], floa
   ncclResult_t r = ncclAllGather(D.wsum.p, D.gather.p, MSM_W * sizeof(G1XYZZ), ncclUint8, (ncclComm_t)nccl_comm, D.s);
   if (r != ncclSuccess) throw Error(std::string("RCCL error: ") + ncclGetErrorString(r) + " (ncclAllGather of the window sums)");
   RLN_HIP(hipEventRecord(D.e[4], D.s));
-  hipLaunchKernelGGL(k_combine, dim3(1), dim3(64), 0, D.s, D.gather.p, (uint32_t)nranks, D.result.p);
-  RLN_HIP(hipGetLastError());
-  RLN_HIP(hipEventRecord(D.e[5], D.s));
-  RLN_HIP(hipMemcpyAsync(out_xy_le, D.result.p, 64, hipMemcpyDeviceToHost, D.s));
-  RLN_HIP(hipStreamSynchronize(D.s));
+  float host_fold_ms = -1.f;
+  if (fold_on_device()) {
+    hipLaunchKernelGGL(k_combine, dim3(1), dim3(64), 0, D.s, D.gather.p, (uint32_t)nranks, D.result.p);
+    RLN_HIP(hipGetLastError());
+    RLN_HIP(hipEventRecord(D.e[5], D.s));
+    RLN_HIP(hipMemcpyAsync(out_xy_le, D.result.p, 64, hipMemcpyDeviceToHost, D.s));
+    RLN_HIP(hipStreamSynchronize(D.s));
+  } else {
+    RLN_HIP(hipEventRecord(D.e[5], D.s));
+    std::vector<G1XYZZ> h((size_t)nranks * MSM_W);
+    RLN_HIP(hipMemcpyAsync(h.data(), D.gather.p, h.size() * sizeof(G1XYZZ), hipMemcpyDeviceToHost, D.s));
+    RLN_HIP(hipStreamSynchronize(D.s));
+    const auto t0 = std::chrono::steady_clock::now();
+    fold_windows_host(h.data(), (size_t)nranks, out_xy_le);
+    host_fold_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
   if (ms) {
     RLN_HIP(hipEventElapsedTime(&ms[0], D.e[0], D.e[1]));
     RLN_HIP(hipEventElapsedTime(&ms[1], D.e[1], D.e[3]));
     RLN_HIP(hipEventElapsedTime(&ms[2], D.e[3], D.e[4]));
-    RLN_HIP(hipEventElapsedTime(&ms[3], D.e[4], D.e[5]));
+    if (host_fold_ms >= 0) ms[3] = host_fold_ms;   // the fold on the host (wall time of the loop itself)
+    else RLN_HIP(hipEventElapsedTime(&ms[3], D.e[4], D.e[5]));
   }
 }
 
@@ -702,14 +751,20 @@ void MsmG1::enqueue_windows() {
   RLN_HIP(hipEventRecord(D.e[2], s));
   hipLaunchKernelGGL(k_bucket_red, dim3(div_up(nch, 64)), dim3(64), 0, s, D.buckets.p, D.chunkS.p, D.chunkT.p, nch);
   hipLaunchKernelGGL(k_chunk_fix, dim3(div_up(nch, 64)), dim3(64), 0, s, D.chunkS.p, D.chunkT.p, nch);
-  hipLaunchKernelGGL(k_range_sum, dim3(div_up(D.r1.n, 64)), dim3(64), 0, s, D.chunkT.p, D.r1.p, (uint32_t)D.r1.n, D.grp.p);
-  hipLaunchKernelGGL(k_range_sum, dim3(1), dim3(64), 0, s, D.grp.p, D.r2.p, (uint32_t)D.r2.n, D.wsum.p);
+  hipLaunchKernelGGL(k_range_sum, dim3(D.r1.n), dim3(64), 0, s, D.chunkT.p, D.r1.p, (uint32_t)D.r1.n, D.grp.p);
+  hipLaunchKernelGGL(k_range_sum, dim3(D.r2.n), dim3(64), 0, s, D.grp.p, D.r2.p, (uint32_t)D.r2.n, D.wsum.p);
   RLN_HIP(hipGetLastError());
   RLN_HIP(hipEventRecord(D.e[3], s));
 }
 
 void MsmG1::combine(const uint8_t* window_sums, size_t contributors, uint8_t out_xy_le[64]) {
   Impl& D = *d_;
+  if (!fold_on_device()) {
+    std::vector<G1XYZZ> h(contributors * MSM_W);
+    memcpy(h.data(), window_sums, h.size() * sizeof(G1XYZZ));
+    fold_windows_host(h.data(), contributors, out_xy_le);
+    return;
+  }
   DevBuf<G1XYZZ> in(contributors * MSM_W);
   DevBuf<uint32_t> out(16);
   RLN_HIP(hipMemcpyAsync(in.p, window_sums, contributors * MSM_W * sizeof(G1XYZZ), hipMemcpyHostToDevice, D.s));
