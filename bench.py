@@ -420,6 +420,149 @@ def measure_config5(comm, rank, world, steps=3, log2n=24):
                          "peak": HBM_PEAK_GBPS * world, "unit": "GB/s", "frac": round(gbps / (HBM_PEAK_GBPS * world), 5)}}
 
 
+def _stream_proofs_per_s(prover, batches, n_batches, B, collect_public=None):
+    """n_batches submits over the distinct `batches` with every workspace slot in flight -> (proofs/s, {k: raw result})"""
+    import collections as _c
+    nslots, inflight, results = prover.n_slots(), _c.deque(), {}
+
+    def take():
+        t, kk = inflight.popleft()
+        if collect_public is not None:
+            collect_public(t, kk)
+        results[kk] = prover.collect_raw(t, B)
+    prover.sync()
+    t0 = time.perf_counter()
+    for j in range(n_batches):
+        k = j % len(batches)
+        if len(inflight) == nslots:
+            take()
+        inflight.append((prover.submit(batches[k][0], batches[k][1])[0], k))
+    while inflight:
+        take()
+    prover.sync()
+    return n_batches * B / (time.perf_counter() - t0), results
+
+
+def operating_points_main(args):
+    """VERDICT r4 item 5 -- the operating points as measured data (outside any timed region of the headline): for the comb
+    schedules 8 / 120010 (the default object) / 12 / 114 / 7150114 (the bench) the table size, the constructor's time and
+    where it goes, proofs/s over a stream of distinct 1024-proof batches, and one proof per call; then TWO circuits
+    resident on one device (the single-message circuit at 114 and the multi-message-id circuit at 10) proving alternating
+    1024-proof batches.  Every row's sample of proofs is verified on the host."""
+    from zerokit_amd import lib, workload
+    from zerokit_amd._native import check
+    from zerokit_amd.batch import BatchProver
+    B, nb, K = args.batch, 6, max(args.steps, 12)
+    rows = []
+    packed = None
+    for wb in (8, 120010, 12, 114, 7150114):
+        t0 = time.time()
+        try:
+            p = BatchProver(max_batch=B, window_bits=wb)
+        except Exception as e:  # noqa: BLE001
+            rows.append({"window_bits": wb, "error": str(e)})
+            continue
+        init_s = time.time() - t0
+        try:
+            if packed is None:
+                packed = [workload.config2_packed(p.slots, p.inputs_size, B * k, B) for k in range(nb)]
+            _stream_proofs_per_s(p, packed, 3, B)
+            rate, res = _stream_proofs_per_s(p, packed, K, B)
+            vp, vv = [], []
+            for k, (proofs, values, errs) in sorted(res.items()):
+                for i in (0, B - 1):
+                    vp.append(proofs[128 * i:128 * i + 128])
+                    vv.append([int.from_bytes(values[160 * i + 32 * q:160 * i + 32 * q + 32], "little") for q in range(5)])
+            ok = all(not any(r[2]) for r in res.values()) and all(p.verify_many(vp, vv))
+            one = workload.config2_packed(p.slots, p.inputs_size, 0, 1)
+            ts = []
+            for i in range(7):
+                t1 = time.perf_counter()
+                t, _ = p.submit(*one)
+                p.collect_raw(t, 1)
+                ts.append((time.perf_counter() - t1) * 1e3)
+            rows.append({"window_bits": wb, "windows_g1": int(p.info.windows), "windows_g2": int(p.info.windows_g2),
+                         "table_gib": round(p.info.table_bytes / 2**30, 2), "max_batch": B,
+                         "init_s": round(init_s, 2), "init_ms": p.init_ms(),
+                         "proofs_per_s": round(rate, 1), "ms_per_1024": round(B / rate * 1e3, 2),
+                         "single_proof_ms_median": round(sorted(ts[2:])[len(ts[2:]) // 2], 3), "verified": bool(ok),
+                         "verified_proofs": len(vp)})
+        finally:
+            p.close()
+    # two circuits on one device
+    co = None
+    try:
+        t0 = time.time()
+        a = BatchProver(max_batch=B, window_bits=114)
+        m = BatchProver(max_batch=B, window_bits=10, depth=20, multi=True)
+        init_s = time.time() - t0
+        try:
+            named, rs = workload.circuit_range(0, 2 * B, 20, True)
+            mp = [(m.pack_named_inputs(named[k * B:(k + 1) * B]),
+                   b"".join(r.to_bytes(32, "little") + s_.to_bytes(32, "little") for r, s_ in rs[k * B:(k + 1) * B])) for k in range(2)]
+            pubs = {}
+
+            def grab(t, kk):
+                buf = C.create_string_buffer(32 * m.num_public * B)
+                check(lib().rlnamd_prover_collect_public(m._h, t, B, buf))
+                pubs[kk] = buf.raw
+            _stream_proofs_per_s(a, packed, 2, B)
+            _stream_proofs_per_s(m, mp, 2, B)
+            alone_a, _ = _stream_proofs_per_s(a, packed, K, B)
+            alone_m, _ = _stream_proofs_per_s(m, mp, K, B, grab)
+            # alternating: one batch of each circuit at a time, both provers' slots in flight
+            import collections as _c
+            qa, qm, ra, rm = _c.deque(), _c.deque(), {}, {}
+            a.sync()
+            m.sync()
+            t1 = time.perf_counter()
+            for j in range(K):
+                if len(qa) == a.n_slots():
+                    t, kk = qa.popleft()
+                    ra[kk] = a.collect_raw(t, B)
+                qa.append((a.submit(*packed[j % nb])[0], j % nb))
+                if len(qm) == m.n_slots():
+                    t, kk = qm.popleft()
+                    grab(t, kk)
+                    rm[kk] = m.collect_raw(t, B)
+                qm.append((m.submit(*mp[j % 2])[0], j % 2))
+            while qa:
+                t, kk = qa.popleft()
+                ra[kk] = a.collect_raw(t, B)
+            while qm:
+                t, kk = qm.popleft()
+                grab(t, kk)
+                rm[kk] = m.collect_raw(t, B)
+            a.sync()
+            m.sync()
+            both = 2 * K * B / (time.perf_counter() - t1)
+            q = m.num_public
+            ok = all(not any(r[2]) for r in list(ra.values()) + list(rm.values()))
+            for kk, r in rm.items():
+                for i in (0, B - 1):
+                    pub = [int.from_bytes(pubs[kk][32 * (i * q + j):32 * (i * q + j + 1)], "little") for j in range(q)]
+                    ok = ok and m.verify_public(r[0][128 * i:128 * i + 128], pub)
+            for kk, r in ra.items():
+                v = [int.from_bytes(r[1][32 * j:32 * j + 32], "little") for j in range(5)]
+                ok = ok and a.verify(r[0][:128], v)
+            co = {"what": "the depth-20 single-message circuit (schedule 114) and the depth-20 multi-message-id circuit (max_out 4, "
+                          "schedule 10) resident together on one device, 1024-proof workspaces each",
+                  "table_gib": [round(a.info.table_bytes / 2**30, 2), round(m.info.table_bytes / 2**30, 2)],
+                  "init_s_both": round(init_s, 2),
+                  "proofs_per_s_single_circuit_alone": round(alone_a, 1), "proofs_per_s_multi_circuit_alone": round(alone_m, 1),
+                  "proofs_per_s_alternating_batches_total": round(both, 1), "verified": bool(ok)}
+        finally:
+            a.close()
+            m.close()
+    except Exception as e:  # noqa: BLE001
+        co = {"error": str(e)}
+    name = C.create_string_buffer(128)
+    lib().rlnamd_device_name(name, 128)
+    OUT.emit({"metric": "RLN Groth16 proofs/sec (BN254, h=20) -- operating points (side measurement)", "unit": "proofs/s",
+              "device": name.value.decode(), "batch": B, "batches_per_row": K, "operating_points": rows,
+              "two_circuits_on_one_device": co})
+
+
 def merkle_main(args):
     OUT.emit(measure_config3(max(args.steps, 1)))
 
@@ -552,13 +695,15 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("RLNAMD_BENCH_BATCH", "1024")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-configs", action="store_true", help="skip the config3 / config5 objects")
-    ap.add_argument("--workload", default="proofs", choices=["proofs", "merkle", "msm", "finish"],
-                    help="proofs = BASELINE metric (default); merkle / msm / finish = side measurements")
+    ap.add_argument("--workload", default="proofs", choices=["proofs", "merkle", "msm", "finish", "operating-points"],
+                    help="proofs = BASELINE metric (default); merkle / msm / finish / operating-points = side measurements")
     args = ap.parse_args()
     if args.workload == "merkle":
         return merkle_main(args)
     if args.workload == "msm":
         return msm_main(args)
+    if args.workload == "operating-points":
+        return operating_points_main(args)
 
     under_torchrun = "WORLD_SIZE" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -603,6 +748,7 @@ def main():
     t0 = time.time()
     prover = open_prover(B, lambda wb: BatchProver(max_batch=B, window_bits=wb))
     init_s = time.time() - t0
+    init_ms = prover.init_ms()        # where the constructor's time went: parse / hipMalloc of the tables / table build / rest
     nslots = prover.n_slots()
 
     # ---- the witness stream of this rank, packed on the host before the timed region
@@ -852,8 +998,8 @@ def main():
                        "window_bits": int(info.window_bits), "windows": int(info.windows),
                        "window_bits_g2": int(info.window_bits_g2), "windows_g2": int(info.windows_g2),
                        "table_gib": round(info.table_bytes / 2**30, 2),
-                       "device": name.value.decode(), "init_s": round(init_s, 2), "verified": ok,
-                       "verified_proofs": len(vp), "distinct_batches_gave_distinct_proofs": bool(distinct)},
+                       "device": name.value.decode(), "init_s": round(init_s, 2), "init_ms": init_ms,
+                       "verified": ok, "verified_proofs": len(vp), "distinct_batches_gave_distinct_proofs": bool(distinct)},
             "achieved_GBps_whole_proof": round(value * BYTES_PER_PROOF / 1e9, 3),
             "stage_ms": {"overlapped": {k: round(v, 3) for k, v in stage_ms.items()},
                          "alone": {k: round(v, 3) for k, v in stage_ms_alone.items()},

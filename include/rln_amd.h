@@ -131,6 +131,9 @@ int rlnamd_prover_wipe(rlnamd_prover* p);
 /* the switches this prover was built with, "name=value ..." (ProverTuning, zerokit_amd/csrc/prover.h: every RLNAMD_*
  * variable the prover reads is read once, at construction, and listed there) */
 int rlnamd_prover_describe(rlnamd_prover* p, char* buf, size_t cap);
+/* where the constructor's wall time went, ms: [0] parsing the arkzkey / graph + the verifier's precomputation, [1] hipMalloc
+ * of the comb tables, [2] building them on the device, [3] the rest (walk plans, constants, workspaces, pinned staging) */
+int rlnamd_prover_init_ms(rlnamd_prover* p, float ms[4]);
 int rlnamd_prover_prove_stream(rlnamd_prover* p, size_t n, const uint8_t* inputs_le, const uint8_t* rs_le,
                                uint8_t* proofs, uint8_t* values, uint32_t* errors);
 int rlnamd_prover_stage_ms(rlnamd_prover* p, float ms[RLNAMD_PROVER_STAGES]);

@@ -121,6 +121,7 @@ SIGNATURES = {
     "rlnamd_prover_fetch_witness": (C.c_int, [P, C.c_size_t, C.c_char_p]),
     "rlnamd_prover_fetch_h": (C.c_int, [P, C.c_size_t, C.c_char_p]),
     "rlnamd_prover_residue": (C.c_int, [P, C.POINTER(C.c_uint64)]),
+    "rlnamd_prover_init_ms": (C.c_int, [P, C.POINTER(C.c_float)]),
     "rlnamd_verify": (C.c_int, [P, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]),
     "rlnamd_prover_num_public": (C.c_size_t, [P]),
     "rlnamd_prover_download_public": (C.c_int, [P, C.c_size_t, C.c_char_p]),

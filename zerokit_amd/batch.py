@@ -302,6 +302,12 @@ class BatchProver:
         check(lib().rlnamd_prover_fetch_h(self._h, index, buf))
         return [int.from_bytes(buf.raw[32 * i:32 * i + 32], "little") for i in range(n)]
 
+    def init_ms(self):
+        """where the constructor's time went (rlnamd_prover_init_ms)"""
+        ms = (C.c_float * 4)()
+        check(lib().rlnamd_prover_init_ms(self._h, ms))
+        return dict(zip(("parse", "table_alloc", "table_build", "rest"), (round(float(v), 1) for v in ms)))
+
     def residue(self):
         """tap of the wipes (rlnamd_prover_residue): non-zero 16-byte words left in the last batch's slot"""
         out = (C.c_uint64 * 6)()

@@ -372,6 +372,11 @@ int rlnamd_prover_describe(rlnamd_prover* p, char* buf, size_t cap) {
   }
   RLN_CATCH
 }
+int rlnamd_prover_init_ms(rlnamd_prover* p, float ms[4]) {
+  RLN_TRY
+  for (int k = 0; k < 4; k++) ms[k] = p->p->init_ms()[k];
+  RLN_CATCH
+}
 int rlnamd_prover_wipe(rlnamd_prover* p) {
   RLN_TRY
   p->p->wipe(0);

@@ -87,6 +87,9 @@ class Prover {
   const Zkey& zkey() const { return zk_; }
   const Graph& graph() const { return graph_; }
   size_t capacity() const { return B_; }
+  // constructor wall time: [0] parsing + verifier precomputation, [1] hipMalloc of the comb tables, [2] building them,
+  // [3] the rest (plans, constants, workspaces, pinned staging)
+  const float* init_ms() const { return init_ms_; }
   int window_bits() const { return c_; }      // G1 comb: narrow window width
   int windows() const { return W_; }          // table additions per G1 point and proof (windows x GLV halves)
   int window_bits_g2() const { return c2_; }
@@ -180,6 +183,7 @@ class Prover {
   Zkey zk_;
   Graph graph_;
   size_t B_ = 0;
+  float init_ms_[4] = {0, 0, 0, 0};
   int c_ = 8, W_ = 32, c2_ = 8, W2_ = 32;
   bool glv_ = true;
 };

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <deque>
 
 #include "prover_kernels.h"
@@ -285,12 +286,22 @@ static void make_reduce_ranges(const std::vector<uint32_t>& segfirst, std::vecto
 
 // G1 table in the 9 x 29 form: slabs are built in the 8 x 32 form (k_table_build reads its own rows back) and
 // converted into place
+// where the constructor's time goes (Prover::init_ms): [0] parsing the arkzkey / graph + the verifier's precomputation,
+// [1] hipMalloc of the comb tables, [2] building them (k_table_build / k_table_to29 + the wait), [3] everything else
+// (plans, constants, the workspaces of every slot, pinned staging)
+static thread_local float g_init_ms[4];
+static float ms_since(std::chrono::steady_clock::time_point t0) {
+  return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
 template <class F, class Entry>
 static void build_table29(const std::vector<Affine<F>>& pts, const WinSched& ws, DevBuf<Entry>& table, hipStream_t s,
                           uint32_t npaired = 0) {
   size_t npts = pts.size();
   const size_t stride = ws.stride;
+  auto t_alloc = std::chrono::steady_clock::now();
   table.alloc(npts * stride);
+  g_init_ms[1] += ms_since(t_alloc);
+  auto t_build = std::chrono::steady_clock::now();
   DevBuf<Affine<F>> d_pts(npts);
   d_pts.upload(pts.data(), npts, s);
   size_t per_pt = stride / 2 * sizeof(F);
@@ -308,6 +319,7 @@ static void build_table29(const std::vector<Affine<F>>& pts, const WinSched& ws,
     RLN_HIP(hipGetLastError());
   }
   RLN_HIP(hipStreamSynchronize(s));
+  g_init_ms[2] += ms_since(t_build);
 }
 
 // c-bit windows, the first `wide` of them one bit wider; W = the fewest windows that cover `total` bits: 255 for the
@@ -335,9 +347,12 @@ static WinSched make_sched(int c, int wide, int total) {
 Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_t graph_len, ProverConfig cfg)
     : d_(new Impl) {
   require_gpu();
+  const auto t_ctor = std::chrono::steady_clock::now();
+  for (float& v : g_init_ms) v = 0;
   zk_ = parse_arkzkey(zkey, zkey_len);
   graph_ = parse_graph(graph, graph_len);
   (void)prepared(zk_);  // verifier precomputation now, so concurrent verify calls only read it
+  g_init_ms[0] = ms_since(t_ctor);
   Impl& D = *d_;
   // window_bits = g1 + 10000 * g2, each spec = c + 100 * wide: c-bit windows, the first `wide` of them (c + 1)-bit
   // (see WinSched); g2 = 0: the G2 table takes the G1 schedule.  With the GLV split (default; RLNAMD_GLV=0 keeps the
@@ -1042,6 +1057,8 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     RLN_HIP(hipMemsetAsync(S.digits2.p, 0, S.digits2.bytes(), s));
   }
   RLN_HIP(hipStreamSynchronize(s));
+  g_init_ms[3] = ms_since(t_ctor) - g_init_ms[0] - g_init_ms[1] - g_init_ms[2];
+  for (int k = 0; k < 4; k++) init_ms_[k] = g_init_ms[k];
 }
 
 Prover::~Prover() {
