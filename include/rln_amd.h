@@ -124,7 +124,8 @@ int rlnamd_prover_collect_public(rlnamd_prover* p, uint64_t ticket, size_t n, ui
 /* Secrets do not outlive the batch.  The reference zeroises the identity secret wherever it holds it (IdSecret,
  * rln/src/utils.rs:440-527) and the witness calculator's inputs (rln/src/circuit/iden3calc.rs:45-56).  Here
  * rlnamd_prover_collect (and prove_stream, the pool, every ffi_* proving call) overwrites the batch's staged inputs --
- * pinned host buffer and device copy -- its (r, s) and its witness values behind the copy-out; a later
+ * pinned host buffer and device copy -- its (r, s), its witness values and what was derived from them (the signed window
+ * digits of both walks, a | b | c / h, the walks' partial sums: rlnamd_prover_residue) behind the copy-out; a later
  * rlnamd_prover_collect_public of that ticket is an error.  The resident-input calls (upload / run / download, kept for
  * the fetch_* parity taps) hold their data until rlnamd_prover_wipe or rlnamd_prover_free. */
 int rlnamd_prover_wipe(rlnamd_prover* p);
