@@ -556,6 +556,24 @@ def operating_points_main(args):
             m.close()
     except Exception as e:  # noqa: BLE001
         co = {"error": str(e)}
+    # the CPU port on the same two circuits (oracle/c, one proof per host thread): the multi-message-id circuit had no CPU
+    # figure before round 5
+    try:
+        from oracle.c import binding as ob
+        cores = ob.usable_cores()
+        k = max(cores, 16)
+        o1, om = ob.Circuit(20), ob.Circuit(20, multi=True)
+        n1, r1 = workload.circuit_range(0, k, 20, False)
+        nm, rm_ = workload.circuit_range(0, k, 20, True)
+        rsb = lambda rs_: b"".join(r.to_bytes(32, "little") + s_.to_bytes(32, "little") for r, s_ in rs_)  # noqa: E731
+        s1, _, _ = o1.prove_many_packed(b"".join(o1.pack_named(w) for w in n1), rsb(r1), threads=cores)
+        sm, _, _ = om.prove_many_packed(b"".join(om.pack_named(w) for w in nm), rsb(rm_), threads=cores)
+        if co is not None:
+            co["cpu_port"] = {"kind": "port", "cores": cores, "sample": "%d proofs of each circuit, one per host thread" % k,
+                              "single_circuit_proofs_per_s": round(k / s1, 2), "multi_circuit_proofs_per_s": round(k / sm, 2)}
+    except Exception as e:  # noqa: BLE001
+        if co is not None:
+            co["cpu_port"] = {"error": str(e)}
     name = C.create_string_buffer(128)
     lib().rlnamd_device_name(name, 128)
     OUT.emit({"metric": "RLN Groth16 proofs/sec (BN254, h=20) -- operating points (side measurement)", "unit": "proofs/s",

@@ -196,14 +196,21 @@ int rlnamd_parse_resources(const uint8_t* zkey, size_t zkey_len, const uint8_t* 
 int rlnamd_proof_compress(const uint8_t coords_le[256], uint8_t proof[128]);
 int rlnamd_proof_decompress(const uint8_t proof[128], uint8_t coords_le[256]);
 
-/* ---- variable-base G1 MSM (BASELINE config 5) ------------------------------------------------------------
- * Replaces VariableBaseMSM::msm_bigint (ark-ec 0.5.0; call sites rln/src/partial_proof.rs:98-104,255-256)
- * for large n with bases that are not fixed.  Multi-GPU: every rank runs rlnamd_msm_run on its slice of the
- * points, the window sums (rlnamd_msm_window_sums_bytes() bytes per rank) are all-gathered, and
- * rlnamd_msm_combine adds them and folds the windows. */
+/* ---- variable-base MSM on G1 / G2 (BASELINE config 5; north_star: "windowed Pippenger MSM on G1/G2") ---------
+ * Replaces VariableBaseMSM::msm_bigint (ark-ec 0.5.0; call sites rln/src/partial_proof.rs:98-104,255-256: generic
+ * over the group) for large n with bases that are not fixed.  Multi-GPU: every rank runs rlnamd_msm_run on its slice of
+ * the points, the window sums (rlnamd_msm_window_sums_bytes_of(m) bytes per rank) are all-gathered, and
+ * rlnamd_msm_combine adds them and folds the windows.
+ * rlnamd_msm_new = G1: points are 64 bytes (x | y), results 64 bytes.  rlnamd_msm_new_g2 = G2: points and results are
+ * 128 bytes (x.c0 | x.c1 | y.c0 | y.c1); every call below takes either handle (the *_xy_le buffers are
+ * rlnamd_msm_point_bytes(m) bytes per point); the synthetic workload of a G2 handle is P_i = k_i G2 (the generator of
+ * the twist's order-r subgroup) under the same SplitMix64 stream. */
 typedef struct rlnamd_msm rlnamd_msm;
 int rlnamd_msm_new(size_t capacity, rlnamd_msm** out);
+int rlnamd_msm_new_g2(size_t capacity, rlnamd_msm** out);
 void rlnamd_msm_free(rlnamd_msm* m);
+size_t rlnamd_msm_point_bytes(rlnamd_msm* m);
+size_t rlnamd_msm_window_sums_bytes_of(rlnamd_msm* m);
 /* Device self-test: the 9 x 29-bit-limb group law the MSM walks use (csrc/fq29.h) against the 8 x 32-bit one on
  * `threads` pseudo-random walks of `iters` signed additions each (doublings, cancellations, restarts from infinity
  * included).  group 1 = G1, 2 = G2, 3 = G2 computed by lane pairs, 4 = G1 general additions by lane pairs (g2_gen_xy_le = generator x.c0 | x.c1 | y.c0 | y.c1,

@@ -54,6 +54,10 @@ def lib():
         L.oracle_msm_expected.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_char_p]
         L.oracle_msm_workload_item.restype = None
         L.oracle_msm_workload_item.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_char_p, C.c_char_p]
+        L.oracle_msm_expected_g2.restype = None
+        L.oracle_msm_expected_g2.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_char_p]
+        L.oracle_msm_workload_item_g2.restype = None
+        L.oracle_msm_workload_item_g2.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_char_p, C.c_char_p]
         L.oracle_msm_pippenger.restype = C.c_double
         L.oracle_msm_pippenger.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, C.c_int, C.c_int, C.c_char_p,
                                            C.POINTER(C.c_double)]
@@ -232,6 +236,24 @@ def msm_workload_item(seed, i, mode=0):
     p, s = C.create_string_buffer(64), C.create_string_buffer(32)
     lib().oracle_msm_workload_item(seed, i, mode, p, s)
     return _xy(p.raw), int.from_bytes(s.raw, "little")
+
+
+def _g2(buf):
+    v = [int.from_bytes(buf[32 * k:32 * k + 32], "little") for k in range(4)]
+    return None if not any(v) else ((v[0], v[1]), (v[2], v[3]))
+
+
+def msm_expected_g2(seed, first, n, mode=0, threads=None):
+    """(sum k_i s_i mod r) G2 for the config-5 workload on the twist -> ((x.c0, x.c1), (y.c0, y.c1)) or None"""
+    out = C.create_string_buffer(128)
+    lib().oracle_msm_expected_g2(seed, first, n, mode, threads or usable_cores(), out)
+    return _g2(out.raw)
+
+
+def msm_workload_item_g2(seed, i, mode=0):
+    p, s = C.create_string_buffer(128), C.create_string_buffer(32)
+    lib().oracle_msm_workload_item_g2(seed, i, mode, p, s)
+    return _g2(p.raw), int.from_bytes(s.raw, "little")
 
 
 def msm_pippenger(seed, first, n, mode=0, threads=None):

@@ -686,6 +686,48 @@ void oracle_msm_workload_item(u64 seed, u64 i, int mode, uint8_t point_xy_le[64]
   memcpy(scalar_le, s, 32);
 }
 
+/* The same workload on G2 (north_star: "windowed Pippenger MSM on G1/G2"): P_i = k_i * G2, G2 = the generator of the
+ * twist's order-r subgroup (ark-bn254 g2::G2_GENERATOR_X / _Y).  out: x.c0 | x.c1 | y.c0 | y.c1, all zero = infinity */
+static const g2_aff* g2_generator(void) {
+  static g2_aff G; static int ready = 0;
+  if (!ready) {
+    static const u64 w[4][4] = {
+      {0x46debd5cd992f6edULL, 0x674322d4f75edaddULL, 0x426a00665e5c4479ULL, 0x1800deef121f1e76ULL},
+      {0x97e485b7aef312c2ULL, 0xf1aa493335a9e712ULL, 0x7260bfb731fb5d25ULL, 0x198e9393920d483aULL},
+      {0x4ce6cc0166fa7daaULL, 0xe3d1e7690c43d37bULL, 0x4aab71808dcb408fULL, 0x12c85ea5db8c6debULL},
+      {0x55acdadcd122975bULL, 0xbc4b313370b38ef3ULL, 0xec9e99ad690c3395ULL, 0x090689d0585ff075ULL}};
+    fe_from_u64x4(&FQ, &G.x.c0, w[0]); fe_from_u64x4(&FQ, &G.x.c1, w[1]); fe_from_u64x4(&FQ, &G.y.c0, w[2]); fe_from_u64x4(&FQ, &G.y.c1, w[3]);
+    G.inf = 0; ready = 1;
+  }
+  return &G;
+}
+static void g2_aff_to_bytes(const g2_aff* a, uint8_t out[128]) {
+  memset(out, 0, 128);
+  if (a->inf) return;
+  fe_to_bytes(&FQ, out, &a->x.c0); fe_to_bytes(&FQ, out + 32, &a->x.c1); fe_to_bytes(&FQ, out + 64, &a->y.c0); fe_to_bytes(&FQ, out + 96, &a->y.c1);
+}
+void oracle_msm_expected_g2(u64 seed, u64 first, u64 n, int mode, int threads, uint8_t out_le[128]) {
+  if (threads < 1) threads = 1;
+  if ((u64)threads > n) threads = n ? (int)n : 1;
+  cf_job* J = (cf_job*)calloc(threads, sizeof(cf_job)); pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
+  for (int t = 0; t < threads; t++) {
+    J[t].seed = seed; J[t].mode = mode; J[t].lo = first + n * t / threads; J[t].hi = first + n * (t + 1) / threads;
+    pthread_create(&th[t], NULL, cf_worker, &J[t]);
+  }
+  fe acc; memset(&acc, 0, sizeof acc);
+  for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); fe_add(&FR, &acc, &acc, &J[t].acc); }
+  free(J); free(th);
+  u64 e[4]; fe_to_u64x4(&FR, e, &acc);
+  g2_jac r; g2_mul(&r, g2_generator(), e); g2_aff a; g2_to_aff(&a, &r);
+  g2_aff_to_bytes(&a, out_le);
+}
+void oracle_msm_workload_item_g2(u64 seed, u64 i, int mode, uint8_t point_le[128], uint8_t scalar_le[32]) {
+  u64 k[4], s[4]; msm_wl_k(seed, i, mode, k); msm_wl_s(seed, i, mode, s);
+  g2_jac r; g2_mul(&r, g2_generator(), k); g2_aff a; g2_to_aff(&a, &r);
+  g2_aff_to_bytes(&a, point_le);
+  memcpy(scalar_le, s, 32);
+}
+
 /* CPU baseline of config 5: the points are materialised (fixed-base comb of G, batch-normalised -- untimed), then
  * msm_bigint's windowed Pippenger runs over them with the windows spread over the host threads, which is how ark-ec's
  * `parallel` feature spreads them (one rayon task per window, serial fold at the end). */

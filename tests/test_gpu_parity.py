@@ -507,6 +507,52 @@ def test_msm_fold_on_the_host_and_on_the_device_agree_with_the_oracle(monkeypatc
         m.close()
 
 
+def test_msm_g2_vs_oracle_small_generated_split_and_skewed(monkeypatch):
+    """north_star: "windowed Pippenger MSM on G1/G2" (`partial_proof.rs:98-104` is generic over the group).  The same
+    kernels on the twist (rlnamd_msm_new_g2): msm_bigint semantics on small inputs against the Python oracle with the edge
+    cases (empty, zero scalars, infinity bases, repeated and opposite points, maximal scalar: doubling and cancellation
+    inside the G2 law); the generated workload P_i = k_i G2 at 2^16 / 2^18 against oracle/c's closed form
+    (sum k_i s_i) G2 -- whole, as a 3-way split combined, with every scalar equal (one bucket per window: the big-bucket
+    join) and four distinct bases -- with the fold on the host and on the device; generated points spot-checked"""
+    from oracle.c import binding as ob
+    from oracle.pyref.bn254 import G2, G2_GEN
+    from zerokit_amd.batch import MsmG2
+    rnd = random.Random(22)
+    m = MsmG2(1 << 18)
+    try:
+        pts = [G2.mul(G2_GEN, rnd.randrange(1, R)) for _ in range(24)]
+        sc = [rnd.randrange(R) for _ in range(24)]
+        assert m.msm(pts, sc) == G2.msm_naive(pts, sc)
+        assert m.msm([], []) is None
+        assert m.msm(pts[:3], [0, 0, 0]) is None
+        assert m.msm([None, pts[0]], [5, 7]) == G2.mul(pts[0], 7)
+        assert m.msm([pts[0]] * 5, [1, 2, 3, 4, 5]) == G2.mul(pts[0], 15)
+        assert m.msm([pts[0], G2.neg(pts[0])], [9, 9]) is None
+        assert m.msm([pts[1]], [R - 1]) == G2.neg(pts[1])
+        assert m.msm([pts[4]] * 200, [7] * 200) == G2.mul(pts[4], 1400)
+        seed = 0x62
+        for fold in ("host", "device"):
+            monkeypatch.setenv("RLNAMD_MSM_FOLD", fold)
+            n = 1 << 16
+            m.generate(seed, 0, n)
+            assert m.fetch(n - 1, 1)[0] == ob.msm_workload_item_g2(seed, n - 1)
+            want = ob.msm_expected_g2(seed, 0, n)
+            assert m.combine([m.run_windows()[0]]) == want, fold
+            blobs = []
+            for r in range(3):
+                lo, hi = n * r // 3, n * (r + 1) // 3
+                m.generate(seed, lo, hi - lo)
+                blobs.append(m.run_windows()[0])
+            assert m.combine(blobs) == want, (fold, "split")
+        monkeypatch.delenv("RLNAMD_MSM_FOLD")
+        n = 1 << 18
+        for mode in (0, 1, 2, 3):
+            m.generate(seed, 7, n, mode)
+            assert m.combine([m.run_windows()[0]]) == ob.msm_expected_g2(seed, 7, n, mode), mode
+    finally:
+        m.close()
+
+
 def test_msm_g1_config5_full_size_2_24_vs_oracle():
     """BASELINE config 5 at FULL size: 2^24 generated points on one device against the oracle's closed form; the same
     points as EIGHT 2^21 slices (the shards of the 8-way split of BASELINE.json) each against the oracle by itself and

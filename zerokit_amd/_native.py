@@ -134,6 +134,9 @@ SIGNATURES = {
     "rlnamd_proof_compress": (C.c_int, [C.c_char_p, C.c_char_p]),
     "rlnamd_proof_decompress": (C.c_int, [C.c_char_p, C.c_char_p]),
     "rlnamd_msm_new": (C.c_int, [C.c_size_t, PP]),
+    "rlnamd_msm_new_g2": (C.c_int, [C.c_size_t, PP]),
+    "rlnamd_msm_point_bytes": (C.c_size_t, [P]),
+    "rlnamd_msm_window_sums_bytes_of": (C.c_size_t, [P]),
     "rlnamd_poseidon_params_check": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p]),
     "rlnamd_selftest_fq29": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_char_p, C.POINTER(C.c_uint32)]),
     "rlnamd_msm_free": (None, [P]),

@@ -512,12 +512,15 @@ class PoseidonTree:
 
 
 class MsmG1:
-    """Variable-base G1 MSM (VariableBaseMSM::msm_bigint, ark-ec 0.5.0; BASELINE config 5)."""
+    """Variable-base MSM (VariableBaseMSM::msm_bigint, ark-ec 0.5.0; BASELINE config 5) on G1; MsmG2 below is the same
+    object on the twist: points are (x, y) ints for G1, ((x.c0, x.c1), (y.c0, y.c1)) for G2, None = infinity."""
+    GROUP = 1
 
     def __init__(self, capacity):
         self._h = C.c_void_p()
-        check(lib().rlnamd_msm_new(capacity, C.byref(self._h)))
-        self.ws_bytes = int(lib().rlnamd_msm_window_sums_bytes())
+        check((lib().rlnamd_msm_new if self.GROUP == 1 else lib().rlnamd_msm_new_g2)(capacity, C.byref(self._h)))
+        self.ws_bytes = int(lib().rlnamd_msm_window_sums_bytes_of(self._h))
+        self.pt_bytes = int(lib().rlnamd_msm_point_bytes(self._h))
 
     def close(self):
         if self._h:
@@ -530,9 +533,22 @@ class MsmG1:
         except Exception:
             pass
 
+    def _pt_bytes(self, p):
+        if p is None:
+            return bytes(self.pt_bytes)
+        if self.GROUP == 1:
+            return _b(p[0], _Q) + _b(p[1], _Q)
+        return _b(p[0][0], _Q) + _b(p[0][1], _Q) + _b(p[1][0], _Q) + _b(p[1][1], _Q)
+
+    def _pt_from(self, raw):
+        v = [int.from_bytes(raw[32 * k:32 * k + 32], "little") for k in range(self.pt_bytes // 32)]
+        if not any(v):
+            return None
+        return (v[0], v[1]) if self.GROUP == 1 else ((v[0], v[1]), (v[2], v[3]))
+
     def set(self, points, scalars):
-        """points: list of (x, y) ints or None for infinity"""
-        pb = b"".join((_b(0) + _b(0)) if p is None else (_b(p[0], _Q) + _b(p[1], _Q)) for p in points)
+        """points: list of affine points (see the class docstring) or None for infinity"""
+        pb = b"".join(self._pt_bytes(p) for p in points)
         check(lib().rlnamd_msm_set(self._h, pb, b"".join(_b(s) for s in scalars), len(points)))
 
     EQUAL_SCALARS, FOUR_POINTS = 1, 2
@@ -543,14 +559,11 @@ class MsmG1:
         check(lib().rlnamd_msm_generate_mode(self._h, seed, first_index, n, mode))
 
     def fetch(self, first, count):
-        """-> [(point (x, y) or None, scalar)] of the loaded / generated workload"""
-        p, s = C.create_string_buffer(64 * count), C.create_string_buffer(32 * count)
+        """-> [(point or None, scalar)] of the loaded / generated workload"""
+        p, s = C.create_string_buffer(self.pt_bytes * count), C.create_string_buffer(32 * count)
         check(lib().rlnamd_msm_fetch(self._h, first, count, p, s))
-        out = []
-        for i in range(count):
-            x, y = int.from_bytes(p.raw[64 * i:64 * i + 32], "little"), int.from_bytes(p.raw[64 * i + 32:64 * i + 64], "little")
-            out.append((None if x == 0 and y == 0 else (x, y), int.from_bytes(s.raw[32 * i:32 * i + 32], "little")))
-        return out
+        return [(self._pt_from(p.raw[self.pt_bytes * i:self.pt_bytes * (i + 1)]),
+                 int.from_bytes(s.raw[32 * i:32 * i + 32], "little")) for i in range(count)]
 
     def run_windows(self):
         """-> (window-sum blob to all-gather, stage ms dict)"""
@@ -560,21 +573,24 @@ class MsmG1:
         return buf.raw, dict(sort_ms=float(ms[0]), bucket_acc_ms=float(ms[1]), bucket_reduce_ms=float(ms[2]))
 
     def combine(self, blobs):
-        out = C.create_string_buffer(64)
+        out = C.create_string_buffer(self.pt_bytes)
         check(lib().rlnamd_msm_combine(self._h, b"".join(blobs), len(blobs), out))
-        x, y = int.from_bytes(out.raw[:32], "little"), int.from_bytes(out.raw[32:], "little")
-        return None if x == 0 and y == 0 else (x, y)
+        return self._pt_from(out.raw)
 
     def run_sharded(self, comm: "Comm"):
         """config 5 on this rank of an RCCL communicator (collective): -> (point or None, stage ms dict)"""
-        out = C.create_string_buffer(64)
+        out = C.create_string_buffer(self.pt_bytes)
         ms = (C.c_float * 4)()
         check(lib().rlnamd_msm_run_sharded(self._h, comm._h, out, ms))
-        x, y = int.from_bytes(out.raw[:32], "little"), int.from_bytes(out.raw[32:], "little")
-        return (None if x == 0 and y == 0 else (x, y)), dict(sort_ms=float(ms[0]), buckets_ms=float(ms[1]),
-                                                              all_gather_ms=float(ms[2]), combine_ms=float(ms[3]))
+        return self._pt_from(out.raw), dict(sort_ms=float(ms[0]), buckets_ms=float(ms[1]),
+                                            all_gather_ms=float(ms[2]), combine_ms=float(ms[3]))
 
     def msm(self, points, scalars):
         self.set(points, scalars)
         blob, _ = self.run_windows()
         return self.combine([blob])
+
+
+class MsmG2(MsmG1):
+    """the same Pippenger on G2 (rlnamd_msm_new_g2): 128-byte points, 4 KiB of window sums per rank"""
+    GROUP = 2

@@ -416,7 +416,16 @@ int rlnamd_msm_new(size_t capacity, rlnamd_msm** out) {
   *out = h.release();
   RLN_CATCH
 }
+int rlnamd_msm_new_g2(size_t capacity, rlnamd_msm** out) {
+  RLN_TRY
+  std::unique_ptr<rlnamd_msm> h(new rlnamd_msm);
+  h->m2.reset(new MsmG2(capacity ? capacity : 1));
+  *out = h.release();
+  RLN_CATCH
+}
 void rlnamd_msm_free(rlnamd_msm* m) { delete m; }
+size_t rlnamd_msm_point_bytes(rlnamd_msm* m) { return m->m2 ? MsmG2::POINT_BYTES : MsmG1::POINT_BYTES; }
+size_t rlnamd_msm_window_sums_bytes_of(rlnamd_msm* m) { return m->m2 ? MsmG2::window_sums_bytes() : MsmG1::window_sums_bytes(); }
 int rlnamd_poseidon_params_check(const uint8_t* inputs_le, size_t arity, uint8_t out_dense_le[32], uint8_t out_sparse_le[32]) {
   RLN_TRY
   if (arity == 0) throw Error("Empty input provided");
@@ -448,40 +457,47 @@ int rlnamd_selftest_fq29(int group, uint32_t threads, uint32_t iters, const uint
 }
 int rlnamd_msm_set(rlnamd_msm* m, const uint8_t* points_xy_le, const uint8_t* scalars_le, size_t n) {
   RLN_TRY
-  m->m->set_host(points_xy_le, scalars_le, n);
+  if (m->m2) m->m2->set_host(points_xy_le, scalars_le, n);
+  else m->m->set_host(points_xy_le, scalars_le, n);
   RLN_CATCH
 }
 int rlnamd_msm_generate(rlnamd_msm* m, uint64_t seed, uint64_t first_index, size_t n) {
   RLN_TRY
-  m->m->generate(seed, first_index, n);
+  if (m->m2) m->m2->generate(seed, first_index, n);
+  else m->m->generate(seed, first_index, n);
   RLN_CATCH
 }
 int rlnamd_msm_generate_mode(rlnamd_msm* m, uint64_t seed, uint64_t first_index, size_t n, uint32_t mode) {
   RLN_TRY
   if (mode > 3) throw Error("rlnamd_msm_generate_mode: unknown mode bits");
-  m->m->generate(seed, first_index, n, mode);
+  if (m->m2) m->m2->generate(seed, first_index, n, mode);
+  else m->m->generate(seed, first_index, n, mode);
   RLN_CATCH
 }
 int rlnamd_msm_fetch(rlnamd_msm* m, size_t first, size_t count, uint8_t* points_xy_le, uint8_t* scalars_le) {
   RLN_TRY
-  m->m->fetch(first, count, points_xy_le, scalars_le);
+  if (m->m2) m->m2->fetch(first, count, points_xy_le, scalars_le);
+  else m->m->fetch(first, count, points_xy_le, scalars_le);
   RLN_CATCH
 }
 size_t rlnamd_msm_window_sums_bytes(void) { return MsmG1::window_sums_bytes(); }
 int rlnamd_msm_run(rlnamd_msm* m, uint8_t* window_sums, float ms[3]) {
   RLN_TRY
-  m->m->run_windows(window_sums, ms);
+  if (m->m2) m->m2->run_windows(window_sums, ms);
+  else m->m->run_windows(window_sums, ms);
   RLN_CATCH
 }
 int rlnamd_msm_run_sharded(rlnamd_msm* m, rlnamd_comm* c, uint8_t out_xy_le[64], float ms[4]) {
   RLN_TRY
   if (!c) throw Error("rlnamd_msm_run_sharded: no communicator");
-  m->m->run_sharded(rlnamd_comm_handle(c), rlnamd_comm_size(c), out_xy_le, ms);
+  if (m->m2) m->m2->run_sharded(rlnamd_comm_handle(c), rlnamd_comm_size(c), out_xy_le, ms);
+  else m->m->run_sharded(rlnamd_comm_handle(c), rlnamd_comm_size(c), out_xy_le, ms);
   RLN_CATCH
 }
 int rlnamd_msm_combine(rlnamd_msm* m, const uint8_t* window_sums, size_t contributors, uint8_t out_xy_le[64]) {
   RLN_TRY
-  m->m->combine(window_sums, contributors, out_xy_le);
+  if (m->m2) m->m2->combine(window_sums, contributors, out_xy_le);
+  else m->m->combine(window_sums, contributors, out_xy_le);
   RLN_CATCH
 }
 

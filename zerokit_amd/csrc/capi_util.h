@@ -33,8 +33,9 @@ void verify_many_common(const Zkey& zk, size_t n, const uint8_t* proofs, const u
 struct rlnamd_prover {
   std::unique_ptr<rlnamd::Prover> p;
 };
-struct rlnamd_msm {
+struct rlnamd_msm {   // one of the two (rlnamd_msm_new / rlnamd_msm_new_g2)
   std::unique_ptr<rlnamd::MsmG1> m;
+  std::unique_ptr<rlnamd::MsmG2> m2;
 };
 // pool.cpp
 rlnamd::Prover* rlnamd_pool_replica_prover(rlnamd_pool* p, size_t replica);   // owned by the pool

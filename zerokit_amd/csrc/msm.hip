@@ -40,6 +40,51 @@ struct Range {
   uint32_t begin, end;
 };
 
+// The group the buckets live in.  Digits, counting sort and offsets are group-blind; everything that touches a point is
+// templated on these (G2: VariableBaseMSM over the twist, `partial_proof.rs:98-104` is generic over the group).
+struct MsmOpsG1 {
+  typedef G1Affine Aff;
+  typedef G1Affine29 Aff29;
+  typedef G1Acc29 Acc;
+  typedef G1XYZZ XY;
+  static constexpr int AFF_WORDS = 16;   // canonical affine point in 32-bit words
+};
+struct MsmOpsG2 {
+  typedef G2Affine Aff;
+  typedef G2Affine29 Aff29;
+  typedef G2Acc29 Acc;
+  typedef G2XYZZ XY;
+  static constexpr int AFF_WORDS = 32;
+};
+__device__ __forceinline__ bool entry_is_inf(const G1Affine29& e) { return e.is_inf(); }
+__device__ __forceinline__ bool entry_is_inf(const G2Affine29& e) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) o |= e.x0[j] | e.x1[j] | e.y0[j] | e.y1[j];
+  return o == 0;
+}
+// canonical LE coordinates of an affine point: x | y (G1), x.c0 | x.c1 | y.c0 | y.c1 (G2); infinity = all zero
+static RLN_HD void affine_to_words(const G1Affine& a, uint32_t* o) {
+  a.x.to_canonical(o);
+  a.y.to_canonical(o + 8);
+}
+static RLN_HD void affine_to_words(const G2Affine& a, uint32_t* o) {
+  a.x.c0.to_canonical(o);
+  a.x.c1.to_canonical(o + 8);
+  a.y.c0.to_canonical(o + 16);
+  a.y.c1.to_canonical(o + 24);
+}
+static bool words_canonical_fq(const uint32_t* w, int coords) {
+  for (int c = 0; c < coords; c++)
+    if (limbs_geq(w + 8 * c, FqParams::MOD)) return false;
+  return true;
+}
+static void affine_from_words(const uint32_t* w, G1Affine* a) { *a = {Fq::from_canonical(w), Fq::from_canonical(w + 8)}; }
+static void affine_from_words(const uint32_t* w, G2Affine* a) {
+  a->x = {Fq::from_canonical(w), Fq::from_canonical(w + 8)};
+  a->y = {Fq::from_canonical(w + 16), Fq::from_canonical(w + 24)};
+}
+
 __device__ __forceinline__ uint64_t splitmix_at(uint64_t seed, uint64_t j) {
   uint64_t z = seed + (j + 1) * 0x9E3779B97F4A7C15ULL;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
@@ -50,8 +95,9 @@ __device__ __forceinline__ uint64_t splitmix_at(uint64_t seed, uint64_t j) {
 // synthetic workload: P_i = k_i * G, scalar s_i; k_i, s_i 253-bit values of the stream.
 // mode bit 0: every scalar is s_0 (one bucket per window receives every point); bit 1: k_i = k_(i mod 4) (four distinct
 // bases).  The expected result of a run is NOT computed here: tests and bench.py take it from the oracle.
-__global__ void __launch_bounds__(64) k_gen(uint64_t seed, uint64_t first, uint32_t n, uint32_t mode,
-                                            G1Affine* __restrict__ pts, uint32_t* __restrict__ scal) {
+template <class O>
+__global__ void __launch_bounds__(64) k_gen(uint64_t seed, uint64_t first, uint32_t n, uint32_t mode, typename O::Aff gen,
+                                            typename O::Aff* __restrict__ pts, uint32_t* __restrict__ scal) {
   uint32_t t = blockIdx.x * 64 + threadIdx.x;
   if (t >= n) return;
   uint64_t i = first + t;
@@ -66,8 +112,7 @@ __global__ void __launch_bounds__(64) k_gen(uint64_t seed, uint64_t first, uint3
   }
   k[7] &= 0x1FFFFFFFu;  // < 2^253 < r
   s[7] &= 0x1FFFFFFFu;
-  G1Affine g{Fq::from_u32(1), Fq::from_u32(2)};
-  pts[t] = scalar_mul(g, k).to_affine();
+  pts[t] = scalar_mul(gen, k).to_affine();
   for (int q = 0; q < 8; q++) scal[(size_t)t * 8 + q] = s[q];
 }
 
@@ -245,14 +290,17 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ offs, c
 // (prefetching the point as well costs 16 VGPRs and the fourth wave per SIMD: slower).
 constexpr uint32_t MSM_SLICE = 128;
 // the bases in the packed 9 x 29-bit-limb form the accumulator works in (fq29.h): one pass per MSM, 0.3 ms at 2^24
-__global__ void __launch_bounds__(256) k_pts_to29(const G1Affine* __restrict__ src, G1Affine29* __restrict__ dst, uint32_t n) {
+template <class O>
+__global__ void __launch_bounds__(256) k_pts_to29(const typename O::Aff* __restrict__ src, typename O::Aff29* __restrict__ dst, uint32_t n) {
   uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t < n) dst[t] = to_table29(src[t]);
 }
-__global__ void __launch_bounds__(64) k_slice_acc(const G1Affine29* __restrict__ pts, const uint32_t* __restrict__ offs,
+template <class O>
+__global__ void __launch_bounds__(64) k_slice_acc(const typename O::Aff29* __restrict__ pts, const uint32_t* __restrict__ offs,
                                                   const uint32_t* __restrict__ sorted, uint32_t nkeys,
-                                                  G1XYZZ* __restrict__ buckets, G1XYZZ* __restrict__ head,
-                                                  G1XYZZ* __restrict__ tail) {
+                                                  typename O::XY* __restrict__ buckets, typename O::XY* __restrict__ head,
+                                                  typename O::XY* __restrict__ tail) {
+  typedef typename O::Acc Acc;
   const uint32_t s = blockIdx.x * 64 + threadIdx.x;
   const uint32_t total = offs[nkeys];
   const uint64_t lo64 = (uint64_t)s * MSM_SLICE;
@@ -266,21 +314,21 @@ __global__ void __launch_bounds__(64) k_slice_acc(const G1Affine29* __restrict__
   }
   uint32_t key = a, kend = offs[key + 1];
   bool from_before = offs[key] < lo;
-  G1Acc29 acc = G1Acc29::inf();
+  Acc acc = Acc::inf();
   uint32_t v = sorted[lo];
   for (uint32_t j = lo; j < hi; j++) {
     if (j == kend) {  // bucket `key` ends inside this slice
       if (from_before) head[s] = acc.to_xyzz(); else buckets[key] = acc.to_xyzz();
-      acc = G1Acc29::inf();
+      acc = Acc::inf();
       from_before = false;
       do kend = offs[++key + 1]; while (kend == j);
     }
-    G1Affine29 cur = pts[v & 0x7FFFFFFFu];
+    typename O::Aff29 cur = pts[v & 0x7FFFFFFFu];
     uint32_t cv = v;
     if (j + 1 < hi) v = sorted[j + 1];
-    if (!cur.is_inf()) acc.madd(cur, (cv & 0x80000000u) != 0);
+    if (!entry_is_inf(cur)) acc.madd(cur, (cv & 0x80000000u) != 0);
   }
-  G1XYZZ out = acc.to_xyzz();
+  typename O::XY out = acc.to_xyzz();
   if (from_before) head[s] = out;          // started earlier (and may run on: the fix-up adds the later heads)
   else if (kend > hi) tail[s] = out;       // started here, continues in the next slice
   else buckets[key] = out;                 // ends exactly at the slice end
@@ -290,14 +338,16 @@ __global__ void __launch_bounds__(64) k_slice_acc(const G1Affine29* __restrict__
 // joined by one lane's serial loop (1.8 s) but listed, and k_slice_fix_big gives it a 256-lane workgroup: every lane
 // adds its share of the heads, then an eight-level tree through LDS (7 ms).  Uniform scalars list nothing.
 constexpr uint32_t MSM_BIG_SLICES = 64, MSM_BIG_CAP = 4096, MSM_BIG_LANES = 256;
+template <class O>
 __global__ void __launch_bounds__(64) k_slice_fix(const uint32_t* __restrict__ offs, uint32_t nkeys,
-                                                  const G1XYZZ* __restrict__ head, const G1XYZZ* __restrict__ tail,
-                                                  G1XYZZ* __restrict__ buckets, uint32_t* __restrict__ big) {
+                                                  const typename O::XY* __restrict__ head, const typename O::XY* __restrict__ tail,
+                                                  typename O::XY* __restrict__ buckets, uint32_t* __restrict__ big) {
+  typedef typename O::XY XY;
   uint32_t key = blockIdx.x * 64 + threadIdx.x;
   if (key >= nkeys) return;
   uint32_t start = offs[key], end = offs[key + 1];
   if (start == end) {
-    buckets[key] = G1XYZZ::inf();
+    buckets[key] = XY::inf();
     return;
   }
   uint32_t s0 = start / MSM_SLICE, s1 = (end - 1) / MSM_SLICE;
@@ -309,19 +359,21 @@ __global__ void __launch_bounds__(64) k_slice_fix(const uint32_t* __restrict__ o
       return;
     }
   }
-  G1XYZZ acc = tail[s0];  // slice s0 saw it start (from_before == false) and run past its end
+  XY acc = tail[s0];  // slice s0 saw it start (from_before == false) and run past its end
   for (uint32_t s = s0 + 1; s <= s1; s++) acc.add(head[s]);
   buckets[key] = acc;
 }
+template <class O>
 __global__ void __launch_bounds__(MSM_BIG_LANES) k_slice_fix_big(const uint32_t* __restrict__ offs,
-                                                                 const G1XYZZ* __restrict__ head, const G1XYZZ* __restrict__ tail,
-                                                                 G1XYZZ* __restrict__ buckets, const uint32_t* __restrict__ big) {
-  __shared__ G1XYZZ sh[MSM_BIG_LANES / 2];
+                                                                 const typename O::XY* __restrict__ head, const typename O::XY* __restrict__ tail,
+                                                                 typename O::XY* __restrict__ buckets, const uint32_t* __restrict__ big) {
+  typedef typename O::XY XY;
+  __shared__ XY sh[MSM_BIG_LANES / 2];
   const uint32_t count = big[0] < MSM_BIG_CAP ? big[0] : MSM_BIG_CAP, l = threadIdx.x;
   for (uint32_t b = blockIdx.x; b < count; b += gridDim.x) {   // (uniform for the workgroup)
     const uint32_t key = big[1 + b];
     const uint32_t s0 = offs[key] / MSM_SLICE, s1 = (offs[key + 1] - 1) / MSM_SLICE;
-    G1XYZZ acc = l == 0 ? tail[s0] : G1XYZZ::inf();
+    XY acc = l == 0 ? tail[s0] : XY::inf();
     for (uint32_t s = s0 + 1 + l; s <= s1; s += MSM_BIG_LANES) acc.add(head[s]);
     for (uint32_t stride = MSM_BIG_LANES / 2; stride >= 1; stride >>= 1) {
       if (l >= stride && l < 2 * stride) sh[l - stride] = acc;
@@ -334,16 +386,18 @@ __global__ void __launch_bounds__(MSM_BIG_LANES) k_slice_fix_big(const uint32_t*
 }
 
 // chunk [lo, lo+32) of one window: S = sum B_b, T = sum (b - lo + 1) B_b by the running-sum trick
-__global__ void __launch_bounds__(64) k_bucket_red(const G1XYZZ* __restrict__ buckets, G1XYZZ* __restrict__ chunkS,
-                                                   G1XYZZ* __restrict__ chunkT, uint32_t nchunks) {
+template <class O>
+__global__ void __launch_bounds__(64) k_bucket_red(const typename O::XY* __restrict__ buckets, typename O::XY* __restrict__ chunkS,
+                                                   typename O::XY* __restrict__ chunkT, uint32_t nchunks) {
+  typedef typename O::Acc Acc;
   uint32_t ch = blockIdx.x * 64 + threadIdx.x;
   if (ch >= nchunks) return;
-  const G1XYZZ* b = buckets + (size_t)ch * MSM_CHUNK;
+  const typename O::XY* b = buckets + (size_t)ch * MSM_CHUNK;
   // general additions in the 9 x 29 form (0.55 x the instructions of the 8 x 32 law; the chain of 64 of them per lane is
   // pure latency at 2^21 points per device: 0.57 ms of a 6.9 ms shard)
-  G1Acc29 run = G1Acc29::inf(), wsum = G1Acc29::inf();
+  Acc run = Acc::inf(), wsum = Acc::inf();
   for (int k = MSM_CHUNK - 1; k >= 0; k--) {
-    run.add(G1Acc29::from_xyzz(b[k]));
+    run.add(Acc::from_xyzz(b[k]));
     wsum.add(run);
   }
   chunkS[ch] = run.to_xyzz();
@@ -351,36 +405,40 @@ __global__ void __launch_bounds__(64) k_bucket_red(const G1XYZZ* __restrict__ bu
 }
 
 // X = T + lo * S with lo = 32 * (chunk index within its window): bucket b holds digit value b + 1
-__global__ void __launch_bounds__(64) k_chunk_fix(const G1XYZZ* __restrict__ chunkS, G1XYZZ* __restrict__ chunkT,
+template <class O>
+__global__ void __launch_bounds__(64) k_chunk_fix(const typename O::XY* __restrict__ chunkS, typename O::XY* __restrict__ chunkT,
                                                   uint32_t nchunks) {
+  typedef typename O::XY XY;
   uint32_t ch = blockIdx.x * 64 + threadIdx.x;
   if (ch >= nchunks) return;
   uint32_t lo = (ch % MSM_NCH) * MSM_CHUNK;
-  G1XYZZ S = chunkS[ch], acc = G1XYZZ::inf();
+  XY S = chunkS[ch], acc = XY::inf();
   for (int bit = 14; bit >= 0; bit--) {
     acc = acc.dbl();
     if ((lo >> bit) & 1) acc.add(S);
   }
-  G1XYZZ T = chunkT[ch];
+  XY T = chunkT[ch];
   T.add(acc);
   chunkT[ch] = T;
 }
 
 // sums of ranges of 32 points: a wave per range, one point per lane of its first half, five levels of lane-to-lane
 // additions through LDS instead of one lane's 32 dependent additions (two such launches were 0.6 ms of a 2^21 shard)
-__global__ void __launch_bounds__(64) k_range_sum(const G1XYZZ* __restrict__ src, const Range* __restrict__ ranges,
-                                                  uint32_t nr, G1XYZZ* __restrict__ dst) {
-  __shared__ G1XYZZ sh[32];
+template <class O>
+__global__ void __launch_bounds__(64) k_range_sum(const typename O::XY* __restrict__ src, const Range* __restrict__ ranges,
+                                                  uint32_t nr, typename O::XY* __restrict__ dst) {
+  typedef typename O::Acc Acc;
+  __shared__ typename O::XY sh[32];
   const uint32_t r = blockIdx.x, l = threadIdx.x;
   if (r >= nr) return;
   const uint32_t b = ranges[r].begin, e = ranges[r].end;
-  G1Acc29 acc = G1Acc29::inf();
+  Acc acc = Acc::inf();
   for (uint32_t i = b + l; i < e; i += 32)
-    if (l < 32) acc.add(G1Acc29::from_xyzz(src[i]));
+    if (l < 32) acc.add(Acc::from_xyzz(src[i]));
   for (uint32_t stride = 16; stride >= 1; stride >>= 1) {
     if (l >= stride && l < 2 * stride) sh[l - stride] = acc.to_xyzz();
     __syncthreads();
-    if (l < stride) acc.add(G1Acc29::from_xyzz(sh[l]));
+    if (l < stride) acc.add(Acc::from_xyzz(sh[l]));
     __syncthreads();
   }
   if (l == 0) dst[r] = acc.to_xyzz();
@@ -390,18 +448,17 @@ __global__ void __launch_bounds__(64) k_range_sum(const G1XYZZ* __restrict__ src
 // On a lone GPU lane that chain is 1.75 ms (a doubling every ~7 us: k_combine); on a host core 0.1 ms -- and the result
 // is headed for the host anyway.  Default of run_sharded / combine; RLNAMD_MSM_FOLD=device keeps the kernel (parity
 // tests run both).
-static void fold_windows_host(const G1XYZZ* wsums, size_t k, uint8_t out_xy_le[64]) {
-  G1XYZZ total = G1XYZZ::inf();
+template <class O>
+static void fold_windows_host(const typename O::XY* wsums, size_t k, uint8_t* out_le) {
+  typename O::XY total = O::XY::inf();
   for (int w = MSM_W - 1; w >= 0; w--) {
     for (int d = 0; d < MSM_C; d++) total = total.dbl();
     for (size_t r = 0; r < k; r++) total.add(wsums[r * MSM_W + w]);
   }
-  G1Affine a = total.to_affine();
-  uint32_t c[8];
-  a.x.to_canonical(c);
-  memcpy(out_xy_le, c, 32);
-  a.y.to_canonical(c);
-  memcpy(out_xy_le + 32, c, 32);
+  typename O::Aff a = total.to_affine();
+  uint32_t c[O::AFF_WORDS];
+  affine_to_words(a, c);
+  memcpy(out_le, c, sizeof c);
 }
 static bool fold_on_device() {
   const char* v = getenv("RLNAMD_MSM_FOLD");
@@ -409,16 +466,16 @@ static bool fold_on_device() {
 }
 
 // window sums of `k` contributors ([k][W]) -> sum per window -> Horner over the windows -> affine
-__global__ void k_combine(const G1XYZZ* __restrict__ wsums, uint32_t k, uint32_t* __restrict__ out_xy) {
+template <class O>
+__global__ void k_combine(const typename O::XY* __restrict__ wsums, uint32_t k, uint32_t* __restrict__ out_words) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  G1XYZZ total = G1XYZZ::inf();
+  typename O::XY total = O::XY::inf();
   for (int w = MSM_W - 1; w >= 0; w--) {
     for (int d = 0; d < MSM_C; d++) total = total.dbl();
     for (uint32_t r = 0; r < k; r++) total.add(wsums[(size_t)r * MSM_W + w]);
   }
-  G1Affine a = total.to_affine();
-  a.x.to_canonical(out_xy);
-  a.y.to_canonical(out_xy + 8);
+  typename O::Aff a = total.to_affine();
+  affine_to_words(a, out_words);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -558,27 +615,57 @@ uint32_t selftest_fq29(int group, uint32_t threads, uint32_t iters, const uint8_
   return h;
 }
 
-struct MsmG1::Impl {
+template <class O>
+struct MsmImpl {
+  typedef typename O::Aff Aff;
+  typedef typename O::Aff29 Aff29;
+  typedef typename O::XY XY;
   hipStream_t s = nullptr;
   size_t cap = 0, n = 0;
-  DevBuf<G1Affine> pts;
-  DevBuf<G1Affine29> pts29;
+  DevBuf<Aff> pts;
+  DevBuf<Aff29> pts29;
   DevBuf<uint32_t> scal, count, offs, sorted, tmp, wtotal;
   DevBuf<uint16_t> dig;
   DevBuf<uint32_t> hist;
-  DevBuf<G1XYZZ> buckets, chunkS, chunkT, grp, wsum, head, tail;
+  DevBuf<XY> buckets, chunkS, chunkT, grp, wsum, head, tail;
   DevBuf<uint32_t> big;         // k_slice_fix: count + keys of the buckets cut into many slices
   size_t max_slices = 0;
   DevBuf<Range> r1, r2;
-  DevBuf<G1XYZZ> gather;        // run_sharded: the window sums of every rank
+  DevBuf<XY> gather;            // run_sharded: the window sums of every rank
   DevBuf<uint32_t> result;
   hipEvent_t e[6];
+  Aff generator;                // of the synthetic workload (G1: (1, 2); G2: the twist's generator)
+
+  explicit MsmImpl(size_t capacity);
+  ~MsmImpl();
+  void set_host(const uint8_t* points_le, const uint8_t* scalars_le, size_t n);
+  void generate(uint64_t seed, uint64_t first_index, size_t n, uint32_t mode);
+  void fetch(size_t first, size_t count, uint8_t* points_le, uint8_t* scalars_le);
+  void run_windows(uint8_t* window_sums_out, float ms[3]);
+  void combine(const uint8_t* window_sums, size_t contributors, uint8_t* out_le);
+  void run_sharded(void* nccl_comm, int nranks, uint8_t* out_le, float ms[4]);
+  void enqueue_windows();
 };
 
-MsmG1::MsmG1(size_t capacity) : d_(new Impl) {
+static G1Affine msm_generator(const MsmOpsG1*) { return {Fq::from_u32(1), Fq::from_u32(2)}; }
+static G2Affine msm_generator(const MsmOpsG2*) {
+  // the generator of the order-r subgroup of the twist (ark-bn254 g2::G2_GENERATOR_X / _Y; EIP-197's P2), canonical LE words
+  static const uint32_t g[32] = {
+      0xd992f6ed, 0x46debd5c, 0xf75edadd, 0x674322d4, 0x5e5c4479, 0x426a0066, 0x121f1e76, 0x1800deef,   // x.c0
+      0xaef312c2, 0x97e485b7, 0x35a9e712, 0xf1aa4933, 0x31fb5d25, 0x7260bfb7, 0x920d483a, 0x198e9393,   // x.c1
+      0x66fa7daa, 0x4ce6cc01, 0x0c43d37b, 0xe3d1e769, 0x8dcb408f, 0x4aab7180, 0xdb8c6deb, 0x12c85ea5,   // y.c0
+      0xd122975b, 0x55acdadc, 0x70b38ef3, 0xbc4b3133, 0x690c3395, 0xec9e99ad, 0x585ff075, 0x090689d0};  // y.c1
+  G2Affine a;
+  affine_from_words(g, &a);
+  return a;
+}
+
+template <class O>
+MsmImpl<O>::MsmImpl(size_t capacity) {
   require_gpu();
-  Impl& D = *d_;
+  MsmImpl& D = *this;
   D.cap = capacity;
+  D.generator = msm_generator((const O*)nullptr);
   RLN_HIP(hipStreamCreateWithFlags(&D.s, hipStreamNonBlocking));
   for (auto& e : D.e) RLN_HIP(hipEventCreate(&e));
   RLN_HIP(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, MSM_NB * 4));
@@ -617,97 +704,102 @@ MsmG1::MsmG1(size_t capacity) : d_(new Impl) {
   RLN_HIP(hipStreamSynchronize(D.s));
 }
 
-MsmG1::~MsmG1() {
-  if (!d_) return;
-  if (d_->s) {
-    (void)hipStreamSynchronize(d_->s);
-    (void)hipStreamDestroy(d_->s);
+template <class O>
+MsmImpl<O>::~MsmImpl() {
+  if (s) {
+    (void)hipStreamSynchronize(s);
+    (void)hipStreamDestroy(s);
   }
-  for (auto& e : d_->e) (void)hipEventDestroy(e);
+  for (auto& ev : e) (void)hipEventDestroy(ev);
 }
 
-void MsmG1::set_host(const uint8_t* points_xy_le, const uint8_t* scalars_le, size_t n) {
-  Impl& D = *d_;
-  if (n > D.cap) throw Error("MSM larger than the workspace");
-  std::vector<G1Affine> p(n);
-  for (size_t i = 0; i < n; i++) {
-    uint32_t x[8], y[8];
-    memcpy(x, points_xy_le + 64 * i, 32);
-    memcpy(y, points_xy_le + 64 * i + 32, 32);
-    if (limbs_geq(x, FqParams::MOD) || limbs_geq(y, FqParams::MOD)) throw Error("Non-canonical field element");
-    p[i] = {Fq::from_canonical(x), Fq::from_canonical(y)};  // (0,0) encodes infinity
+template <class O>
+void MsmImpl<O>::set_host(const uint8_t* points_le, const uint8_t* scalars_le, size_t n_) {
+  MsmImpl& D = *this;
+  if (n_ > D.cap) throw Error("MSM larger than the workspace");
+  constexpr int AW = O::AFF_WORDS;
+  std::vector<Aff> p(n_);
+  for (size_t i = 0; i < n_; i++) {
+    uint32_t w[AW];
+    memcpy(w, points_le + 4 * AW * i, 4 * AW);
+    if (!words_canonical_fq(w, AW / 8)) throw Error("Non-canonical field element");
+    affine_from_words(w, &p[i]);  // all-zero coordinates encode infinity
   }
-  for (size_t i = 0; i < n; i++) {
-    uint32_t s[8];
-    memcpy(s, scalars_le + 32 * i, 32);
-    if (limbs_geq(s, FrParams::MOD)) throw Error("Non-canonical field element: value is not in [0, r-1]");
+  for (size_t i = 0; i < n_; i++) {
+    uint32_t sc[8];
+    memcpy(sc, scalars_le + 32 * i, 32);
+    if (limbs_geq(sc, FrParams::MOD)) throw Error("Non-canonical field element: value is not in [0, r-1]");
   }
-  RLN_HIP(hipMemcpyAsync(D.pts.p, p.data(), n * sizeof(G1Affine), hipMemcpyHostToDevice, D.s));
-  RLN_HIP(hipMemcpyAsync(D.scal.p, scalars_le, n * 32, hipMemcpyHostToDevice, D.s));
+  RLN_HIP(hipMemcpyAsync(D.pts.p, p.data(), n_ * sizeof(Aff), hipMemcpyHostToDevice, D.s));
+  RLN_HIP(hipMemcpyAsync(D.scal.p, scalars_le, n_ * 32, hipMemcpyHostToDevice, D.s));
   RLN_HIP(hipStreamSynchronize(D.s));
-  D.n = n;
+  D.n = n_;
 }
 
-void MsmG1::generate(uint64_t seed, uint64_t first_index, size_t n, uint32_t mode) {
-  Impl& D = *d_;
-  if (n > D.cap) throw Error("MSM larger than the workspace");
-  hipLaunchKernelGGL(k_gen, dim3(div_up(n, 64)), dim3(64), 0, D.s, seed, first_index, (uint32_t)n, mode, D.pts.p, D.scal.p);
+template <class O>
+void MsmImpl<O>::generate(uint64_t seed, uint64_t first_index, size_t n_, uint32_t mode) {
+  MsmImpl& D = *this;
+  if (n_ > D.cap) throw Error("MSM larger than the workspace");
+  hipLaunchKernelGGL(k_gen<O>, dim3(div_up(n_, 64)), dim3(64), 0, D.s, seed, first_index, (uint32_t)n_, mode, D.generator,
+                     D.pts.p, D.scal.p);
   RLN_HIP(hipGetLastError());
   RLN_HIP(hipStreamSynchronize(D.s));
-  D.n = n;
+  D.n = n_;
 }
 
-void MsmG1::fetch(size_t first, size_t count, uint8_t* points_xy_le, uint8_t* scalars_le) {
-  Impl& D = *d_;
-  if (first + count > D.n) throw Error("MSM fetch: range outside the loaded points");
-  std::vector<G1Affine> p(count);
-  RLN_HIP(hipMemcpy(p.data(), D.pts.p + first, count * sizeof(G1Affine), hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < count; i++) {
-    uint32_t c[8];
-    p[i].x.to_canonical(c);
-    memcpy(points_xy_le + 64 * i, c, 32);
-    p[i].y.to_canonical(c);
-    memcpy(points_xy_le + 64 * i + 32, c, 32);
+template <class O>
+void MsmImpl<O>::fetch(size_t first, size_t count_, uint8_t* points_le, uint8_t* scalars_le) {
+  MsmImpl& D = *this;
+  if (first + count_ > D.n) throw Error("MSM fetch: range outside the loaded points");
+  constexpr int AW = O::AFF_WORDS;
+  std::vector<Aff> p(count_);
+  RLN_HIP(hipMemcpy(p.data(), D.pts.p + first, count_ * sizeof(Aff), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < count_; i++) {
+    uint32_t c[AW];
+    affine_to_words(p[i], c);
+    memcpy(points_le + 4 * AW * i, c, 4 * AW);
   }
-  RLN_HIP(hipMemcpy(scalars_le, D.scal.p + first * 8, count * 32, hipMemcpyDeviceToHost));
+  RLN_HIP(hipMemcpy(scalars_le, D.scal.p + first * 8, count_ * 32, hipMemcpyDeviceToHost));
 }
 
-void MsmG1::run_windows(uint8_t* window_sums_out, float ms[3]) {
-  Impl& D = *d_;
+template <class O>
+void MsmImpl<O>::run_windows(uint8_t* window_sums_out, float ms[3]) {
+  MsmImpl& D = *this;
   enqueue_windows();
-  RLN_HIP(hipMemcpyAsync(window_sums_out, D.wsum.p, MSM_W * sizeof(G1XYZZ), hipMemcpyDeviceToHost, D.s));
+  RLN_HIP(hipMemcpyAsync(window_sums_out, D.wsum.p, MSM_W * sizeof(XY), hipMemcpyDeviceToHost, D.s));
   RLN_HIP(hipStreamSynchronize(D.s));
   if (ms)
     for (int i = 0; i < 3; i++) RLN_HIP(hipEventElapsedTime(&ms[i], D.e[i], D.e[i + 1]));
 }
 
 // One MSM over the points of ALL ranks of an RCCL communicator (BASELINE config 5): every rank reduces its
-// slice to the 16 window sums, ONE ncclAllGather moves the 2 KiB blocks over xGMI (RCCL has no elliptic-curve reduce
-// op: "all-reduce of partials" = gather + local add), and every rank adds them and folds the windows.  Everything is
-// enqueued on the object's stream; the only host wait is the final copy of the 64-byte result.
-void MsmG1::run_sharded(void* nccl_comm, int nranks, uint8_t out_xy_le[64], float ms[4]) {
-  Impl& D = *d_;
+// slice to the 16 window sums, ONE ncclAllGather moves the 2 KiB (G2: 4 KiB) blocks over xGMI (RCCL has no elliptic-curve
+// reduce op: "all-reduce of partials" = gather + local add), and every rank adds them and folds the windows.  Everything is
+// enqueued on the object's stream; the only host wait is the final copy.
+template <class O>
+void MsmImpl<O>::run_sharded(void* nccl_comm, int nranks, uint8_t* out_le, float ms[4]) {
+  MsmImpl& D = *this;
   if (nranks < 1) throw Error("run_sharded: empty communicator");
   enqueue_windows();
   if (D.gather.n < (size_t)nranks * MSM_W) D.gather.alloc((size_t)nranks * MSM_W);
-  if (!D.result.p) D.result.alloc(16);
-  ncclResult_t r = ncclAllGather(D.wsum.p, D.gather.p, MSM_W * sizeof(G1XYZZ), ncclUint8, (ncclComm_t)nccl_comm, D.s);
+  if (!D.result.p) D.result.alloc(O::AFF_WORDS);
+  ncclResult_t r = ncclAllGather(D.wsum.p, D.gather.p, MSM_W * sizeof(XY), ncclUint8, (ncclComm_t)nccl_comm, D.s);
   if (r != ncclSuccess) throw Error(std::string("RCCL error: ") + ncclGetErrorString(r) + " (ncclAllGather of the window sums)");
   RLN_HIP(hipEventRecord(D.e[4], D.s));
   float host_fold_ms = -1.f;
   if (fold_on_device()) {
-    hipLaunchKernelGGL(k_combine, dim3(1), dim3(64), 0, D.s, D.gather.p, (uint32_t)nranks, D.result.p);
+    hipLaunchKernelGGL(k_combine<O>, dim3(1), dim3(64), 0, D.s, D.gather.p, (uint32_t)nranks, D.result.p);
     RLN_HIP(hipGetLastError());
     RLN_HIP(hipEventRecord(D.e[5], D.s));
-    RLN_HIP(hipMemcpyAsync(out_xy_le, D.result.p, 64, hipMemcpyDeviceToHost, D.s));
+    RLN_HIP(hipMemcpyAsync(out_le, D.result.p, 4 * O::AFF_WORDS, hipMemcpyDeviceToHost, D.s));
     RLN_HIP(hipStreamSynchronize(D.s));
   } else {
     RLN_HIP(hipEventRecord(D.e[5], D.s));
-    std::vector<G1XYZZ> h((size_t)nranks * MSM_W);
-    RLN_HIP(hipMemcpyAsync(h.data(), D.gather.p, h.size() * sizeof(G1XYZZ), hipMemcpyDeviceToHost, D.s));
+    std::vector<XY> h((size_t)nranks * MSM_W);
+    RLN_HIP(hipMemcpyAsync(h.data(), D.gather.p, h.size() * sizeof(XY), hipMemcpyDeviceToHost, D.s));
     RLN_HIP(hipStreamSynchronize(D.s));
     const auto t0 = std::chrono::steady_clock::now();
-    fold_windows_host(h.data(), (size_t)nranks, out_xy_le);
+    fold_windows_host<O>(h.data(), (size_t)nranks, out_le);
     host_fold_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
   if (ms) {
@@ -719,14 +811,15 @@ void MsmG1::run_sharded(void* nccl_comm, int nranks, uint8_t out_xy_le[64], floa
   }
 }
 
-void MsmG1::enqueue_windows() {
-  Impl& D = *d_;
+template <class O>
+void MsmImpl<O>::enqueue_windows() {
+  MsmImpl& D = *this;
   const uint32_t n = (uint32_t)D.n, nkeys = MSM_W * MSM_NB, nch = MSM_W * MSM_NCH;
   hipStream_t s = D.s;
   RLN_HIP(hipEventRecord(D.e[0], s));
   const uint32_t tile_len = div_up(n ? n : 1, MSM_TILES);
   const size_t lds = MSM_NB * sizeof(uint32_t);
-  if (n) hipLaunchKernelGGL(k_pts_to29, dim3(div_up(n, 256)), dim3(256), 0, s, D.pts.p, D.pts29.p, n);
+  if (n) hipLaunchKernelGGL(k_pts_to29<O>, dim3(div_up(n, 256)), dim3(256), 0, s, D.pts.p, D.pts29.p, n);
   if (n) hipLaunchKernelGGL(k_digits, dim3(div_up(n, 256)), dim3(256), 0, s, D.scal.p, n, D.dig.p);
   hipLaunchKernelGGL(k_hist, dim3(MSM_TILES, MSM_W), dim3(1024), lds, s, D.dig.p, n, tile_len, D.hist.p);
   hipLaunchKernelGGL(k_tile_prefix, dim3(div_up(nkeys, 256)), dim3(256), 0, s, D.hist.p, D.count.p);
@@ -742,38 +835,57 @@ void MsmG1::enqueue_windows() {
   RLN_HIP(hipEventRecord(D.e[1], s));
   const uint32_t nslices = div_up((size_t)n * MSM_W, MSM_SLICE);
   if (nslices)
-    hipLaunchKernelGGL(k_slice_acc, dim3(div_up(nslices, 64)), dim3(64), 0, s, D.pts29.p, D.offs.p, D.sorted.p, nkeys,
+    hipLaunchKernelGGL(k_slice_acc<O>, dim3(div_up(nslices, 64)), dim3(64), 0, s, D.pts29.p, D.offs.p, D.sorted.p, nkeys,
                        D.buckets.p, D.head.p, D.tail.p);
   RLN_HIP(hipMemsetAsync(D.big.p, 0, 4, s));
-  hipLaunchKernelGGL(k_slice_fix, dim3(div_up(nkeys, 64)), dim3(64), 0, s, D.offs.p, nkeys, D.head.p, D.tail.p, D.buckets.p,
+  hipLaunchKernelGGL(k_slice_fix<O>, dim3(div_up(nkeys, 64)), dim3(64), 0, s, D.offs.p, nkeys, D.head.p, D.tail.p, D.buckets.p,
                      D.big.p);
-  hipLaunchKernelGGL(k_slice_fix_big, dim3(64), dim3(MSM_BIG_LANES), 0, s, D.offs.p, D.head.p, D.tail.p, D.buckets.p, D.big.p);
+  hipLaunchKernelGGL(k_slice_fix_big<O>, dim3(64), dim3(MSM_BIG_LANES), 0, s, D.offs.p, D.head.p, D.tail.p, D.buckets.p, D.big.p);
   RLN_HIP(hipEventRecord(D.e[2], s));
-  hipLaunchKernelGGL(k_bucket_red, dim3(div_up(nch, 64)), dim3(64), 0, s, D.buckets.p, D.chunkS.p, D.chunkT.p, nch);
-  hipLaunchKernelGGL(k_chunk_fix, dim3(div_up(nch, 64)), dim3(64), 0, s, D.chunkS.p, D.chunkT.p, nch);
-  hipLaunchKernelGGL(k_range_sum, dim3(D.r1.n), dim3(64), 0, s, D.chunkT.p, D.r1.p, (uint32_t)D.r1.n, D.grp.p);
-  hipLaunchKernelGGL(k_range_sum, dim3(D.r2.n), dim3(64), 0, s, D.grp.p, D.r2.p, (uint32_t)D.r2.n, D.wsum.p);
+  hipLaunchKernelGGL(k_bucket_red<O>, dim3(div_up(nch, 64)), dim3(64), 0, s, D.buckets.p, D.chunkS.p, D.chunkT.p, nch);
+  hipLaunchKernelGGL(k_chunk_fix<O>, dim3(div_up(nch, 64)), dim3(64), 0, s, D.chunkS.p, D.chunkT.p, nch);
+  hipLaunchKernelGGL(k_range_sum<O>, dim3(D.r1.n), dim3(64), 0, s, D.chunkT.p, D.r1.p, (uint32_t)D.r1.n, D.grp.p);
+  hipLaunchKernelGGL(k_range_sum<O>, dim3(D.r2.n), dim3(64), 0, s, D.grp.p, D.r2.p, (uint32_t)D.r2.n, D.wsum.p);
   RLN_HIP(hipGetLastError());
   RLN_HIP(hipEventRecord(D.e[3], s));
 }
 
-void MsmG1::combine(const uint8_t* window_sums, size_t contributors, uint8_t out_xy_le[64]) {
-  Impl& D = *d_;
+template <class O>
+void MsmImpl<O>::combine(const uint8_t* window_sums, size_t contributors, uint8_t* out_le) {
+  MsmImpl& D = *this;
   if (!fold_on_device()) {
-    std::vector<G1XYZZ> h(contributors * MSM_W);
-    memcpy(h.data(), window_sums, h.size() * sizeof(G1XYZZ));
-    fold_windows_host(h.data(), contributors, out_xy_le);
+    std::vector<XY> h(contributors * MSM_W);
+    memcpy(h.data(), window_sums, h.size() * sizeof(XY));
+    fold_windows_host<O>(h.data(), contributors, out_le);
     return;
   }
-  DevBuf<G1XYZZ> in(contributors * MSM_W);
-  DevBuf<uint32_t> out(16);
-  RLN_HIP(hipMemcpyAsync(in.p, window_sums, contributors * MSM_W * sizeof(G1XYZZ), hipMemcpyHostToDevice, D.s));
-  hipLaunchKernelGGL(k_combine, dim3(1), dim3(64), 0, D.s, in.p, (uint32_t)contributors, out.p);
+  DevBuf<XY> in(contributors * MSM_W);
+  DevBuf<uint32_t> out(O::AFF_WORDS);
+  RLN_HIP(hipMemcpyAsync(in.p, window_sums, contributors * MSM_W * sizeof(XY), hipMemcpyHostToDevice, D.s));
+  hipLaunchKernelGGL(k_combine<O>, dim3(1), dim3(64), 0, D.s, in.p, (uint32_t)contributors, out.p);
   RLN_HIP(hipGetLastError());
-  RLN_HIP(hipMemcpyAsync(out_xy_le, out.p, 64, hipMemcpyDeviceToHost, D.s));
+  RLN_HIP(hipMemcpyAsync(out_le, out.p, 4 * O::AFF_WORDS, hipMemcpyDeviceToHost, D.s));
   RLN_HIP(hipStreamSynchronize(D.s));
 }
 
-size_t MsmG1::window_sums_bytes() { return MSM_W * sizeof(G1XYZZ); }
+// ---- the two groups behind one interface (msm.h)
+struct MsmG1::Impl : MsmImpl<MsmOpsG1> {
+  using MsmImpl<MsmOpsG1>::MsmImpl;
+};
+struct MsmG2::Impl : MsmImpl<MsmOpsG2> {
+  using MsmImpl<MsmOpsG2>::MsmImpl;
+};
+#define RLN_MSM_WRAPPERS(T, O)                                                                                                \
+  T::T(size_t capacity) : d_(new Impl(capacity)) {}                                                                          \
+  T::~T() {}                                                                                                                 \
+  void T::set_host(const uint8_t* p, const uint8_t* s, size_t n) { d_->set_host(p, s, n); }                                  \
+  void T::generate(uint64_t seed, uint64_t first, size_t n, uint32_t mode) { d_->generate(seed, first, n, mode); }           \
+  void T::fetch(size_t first, size_t count, uint8_t* p, uint8_t* s) { d_->fetch(first, count, p, s); }                       \
+  void T::run_windows(uint8_t* out, float ms[3]) { d_->run_windows(out, ms); }                                               \
+  void T::combine(const uint8_t* ws, size_t k, uint8_t* out) { d_->combine(ws, k, out); }                                    \
+  void T::run_sharded(void* comm, int nranks, uint8_t* out, float ms[4]) { d_->run_sharded(comm, nranks, out, ms); }         \
+  size_t T::window_sums_bytes() { return MSM_W * sizeof(O::XY); }
+RLN_MSM_WRAPPERS(MsmG1, MsmOpsG1)
+RLN_MSM_WRAPPERS(MsmG2, MsmOpsG2)
 
 }  // namespace rlnamd

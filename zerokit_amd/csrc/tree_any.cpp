@@ -15,6 +15,22 @@ static void hash_pairs(const std::vector<uint8_t>& pairs, std::vector<uint8_t>& 
   const size_t n = pairs.size() / 64;
   out.resize(n * 32);
   if (!n) return;
+  // a handful of hashes (a single update is one per level, 31 .. 63 levels one after the other): the library's host
+  // Poseidon instead of an H2D + kernel + D2H round trip per level (see MerkleTreeDev::set_few; same threshold)
+  if (n <= MerkleTreeDev::host_max_from_env()) {
+    const PoseidonParams& P = poseidon_host_params(3);
+    for (size_t i = 0; i < n; i++) {
+      uint32_t c[8];
+      Fr in[2];
+      memcpy(c, pairs.data() + 64 * i, 32);
+      in[0] = Fr::from_canonical(c);
+      memcpy(c, pairs.data() + 64 * i + 32, 32);
+      in[1] = Fr::from_canonical(c);
+      poseidon_hash_host(P, in).to_canonical(c);
+      memcpy(out.data() + 32 * i, c, 32);
+    }
+    return;
+  }
   DevBuf<uint8_t> din(pairs.size()), dout(n * 32);
   RLN_HIP(hipMemcpy(din.p, pairs.data(), pairs.size(), hipMemcpyHostToDevice));
   poseidon_hash_batch_device(din.p, n, 2, dout.p, 0);
