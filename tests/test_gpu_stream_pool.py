@@ -407,6 +407,8 @@ def test_bench_under_torchrun_with_eight_ranks_on_one_device():
     assert d["n_gpus"] == 8 and d["steps"] == 1 and d["unit"] == "proofs/s" and d["scaling"] == "weak"
     assert d["config"]["verified"] is True and d["config"]["batch_per_gpu"] == 8192
     assert abs(d["value"] - 8 * 8192 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    # (under the real backend a line is only printed when RCCL had --gpus ranks; this run says it had none)
+    assert d["rccl_ranks"] is None and "test hook" in d["rccl_ranks_source"]
 
 
 # ------------------------------------------------------------------- full sizes on the bench schedule (last: 228 GiB)
