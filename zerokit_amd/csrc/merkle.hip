@@ -481,11 +481,14 @@ void MerkleTreeDev::set_few(const uint64_t* idx, const uint8_t* leaves_le, size_
 }
 
 MerkleTreeDev::~MerkleTreeDev() {
+  // (a scatter kernel of set_few / set_scattered may still be reading the pinned staging or writing the nodes)
+  if (scat_host || nodes.p) (void)hipStreamSynchronize(stream);
   if (scat_host) (void)hipHostFree(scat_host);
 }
 MerkleTreeDev::MerkleTreeDev(MerkleTreeDev&& o) noexcept { *this = std::move(o); }
 MerkleTreeDev& MerkleTreeDev::operator=(MerkleTreeDev&& o) noexcept {
   if (this != &o) {
+    if (scat_host || nodes.p) (void)hipStreamSynchronize(stream);
     if (scat_host) (void)hipHostFree(scat_host);
     depth = o.depth;
     nodes = std::move(o.nodes);
