@@ -411,6 +411,40 @@ def test_bench_under_torchrun_with_eight_ranks_on_one_device():
     assert d["rccl_ranks"] is None and "test hook" in d["rccl_ranks_source"]
 
 
+def _bench(args, env_extra, timeout=900):
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_bench_side_workloads_and_the_one_process_pool_mode_each_print_one_checked_line():
+    """the other ways bench.py is run, each to ONE JSON line whose `correct` / `verified` flag is the oracle's or the host
+    verifier's: plain `--gpus 2` (one process driving an rlnamd_pool; two replicas on this device through the test hook,
+    small tables), `--workload msm` (config 5 at 2^16 with the shard timing), `--workload merkle` (config 3), and the
+    default line's new objects on small tables (both walks under `roofline.kernels`, `whole_step`, `init_ms`)"""
+    d = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"RLNAMD_BENCH_POOL_DEVICES": "0,0", "RLNAMD_WINDOW_BITS": "8"})
+    assert d["n_gpus"] == 2 and d["config"]["verified"] is True and d["config"]["batch_per_gpu"] == 8192
+    assert abs(d["value"] - 2 * 8192 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3 and len(d["replica_ms_last_step"]) == 2
+    d = _bench(["--workload", "msm", "--steps", "2"], {"RLNAMD_MSM_LOG2": "16"})
+    assert d["correct"] is True and d["rccl_ranks"] == 1 and d["shard_2^13"]["correct"] is True
+    assert d["shard_2^13"]["points"] == 1 << 13 and d["stage_ms_rank0"]["combine_ms"] < 1.0      # the fold on the host
+    d = _bench(["--workload", "merkle", "--steps", "1"], {})
+    assert d["correct"] is True and d["paths_failed_device_verification"] == 0
+    assert d["updates_ffi"]["single_update_plus_root_ms_median"] < 1.5                              # the host chain (3 ms on the device)
+    d = _bench(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-side-configs", "--batch", "256"],
+               {"RLNAMD_WINDOW_BITS": "8"})
+    assert d["config"]["verified"] is True and set(d["config"]["init_ms"]) == {"parse", "table_alloc", "table_build", "rest"}
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and r["peaks"]["mad_slot_peak_Ginst_per_s"] == 614.4
+    # (the issue-cycle view belongs to the bench schedule and batch: on other tables the line says it was left out)
+    assert r["kernels"] is None and "issue_view_omitted" in r
+
+
 # ------------------------------------------------------------------- full sizes on the bench schedule (last: 228 GiB)
 @pytest.fixture(scope="module")
 def bench_prover():
