@@ -556,6 +556,37 @@ def operating_points_main(args):
             m.close()
     except Exception as e:  # noqa: BLE001
         co = {"error": str(e)}
+    # the other shipped circuits at a throughput point of their own (f3 had no throughput figure before round 5)
+    others = []
+    for label, depth, multi, wb in (("depth-20 multi-message-id (max_out 4)", 20, True, 114), ("depth-10 single", 10, False, 7150114)):
+        try:
+            t0 = time.time()
+            q = BatchProver(max_batch=B, window_bits=wb, depth=depth, multi=multi)
+            init_s = time.time() - t0
+            try:
+                named, rs = workload.circuit_range(0, 2 * B, depth, multi)
+                bt = [(q.pack_named_inputs(named[k * B:(k + 1) * B]),
+                       b"".join(r.to_bytes(32, "little") + s_.to_bytes(32, "little") for r, s_ in rs[k * B:(k + 1) * B])) for k in range(2)]
+                pubs = {}
+
+                def grab2(t, kk):
+                    buf = C.create_string_buffer(32 * q.num_public * B)
+                    check(lib().rlnamd_prover_collect_public(q._h, t, B, buf))
+                    pubs[kk] = buf.raw
+                _stream_proofs_per_s(q, bt, 2, B)
+                rate, res = _stream_proofs_per_s(q, bt, K, B, grab2)
+                npub = q.num_public
+                ok = all(not any(r[2]) for r in res.values())
+                for kk, r in res.items():
+                    for i in (0, B - 1):
+                        pub = [int.from_bytes(pubs[kk][32 * (i * npub + j):32 * (i * npub + j + 1)], "little") for j in range(npub)]
+                        ok = ok and q.verify_public(r[0][128 * i:128 * i + 128], pub)
+                others.append({"circuit": label, "window_bits": wb, "table_gib": round(q.info.table_bytes / 2**30, 2),
+                               "init_s": round(init_s, 2), "proofs_per_s": round(rate, 1), "verified": bool(ok)})
+            finally:
+                q.close()
+        except Exception as e:  # noqa: BLE001
+            others.append({"circuit": label, "window_bits": wb, "error": str(e)})
     # the CPU port on the same two circuits (oracle/c, one proof per host thread): the multi-message-id circuit had no CPU
     # figure before round 5
     try:
@@ -578,7 +609,7 @@ def operating_points_main(args):
     lib().rlnamd_device_name(name, 128)
     OUT.emit({"metric": "RLN Groth16 proofs/sec (BN254, h=20) -- operating points (side measurement)", "unit": "proofs/s",
               "device": name.value.decode(), "batch": B, "batches_per_row": K, "operating_points": rows,
-              "two_circuits_on_one_device": co})
+              "two_circuits_on_one_device": co, "other_circuits": others})
 
 
 def merkle_main(args):
