@@ -398,6 +398,24 @@ def measure_config5(comm, rank, world, steps=3, log2n=24):
                  "note": "one of the eight contiguous slices by point index, timed alone on this device through "
                          "rlnamd_msm_run_sharded (sort, buckets, a one-rank ncclAllGather, the fold); on eight devices the "
                          "all-gather moves 8 x 2 KiB over xGMI instead (tens of microseconds): NOT measured on hardware"}
+    # the same Pippenger on G2 (north_star: "windowed Pippenger MSM on G1/G2"): 2^(log2n - 2) points of the twist
+    g2, g2_res = None, None
+    if world == 1 and log2n >= 8:
+        from zerokit_amd.batch import MsmG2
+        n2 = n_total // 4
+        m = MsmG2(n2)
+        try:
+            m.generate(0xC0FFEE, 0, n2)
+            m.run_sharded(comm)
+            ts, gst = [], {}
+            for _ in range(max(steps, 3)):
+                t0 = time.perf_counter()
+                g2_res, gst = m.run_sharded(comm)
+                ts.append(time.perf_counter() - t0)
+        finally:
+            m.close()
+        g2 = {"points": n2, "ms": round(sum(ts) / len(ts) * 1e3, 3), "stage_ms": {k: round(v, 3) for k, v in gst.items()},
+              "G2_additions_per_s_G": round(n2 * 16 / (gst.get("buckets_ms", 0.0) * 1e-3) / 1e9, 2) if gst.get("buckets_ms") else None}
     ok, judge = True, None
     if rank == 0:   # the closed form (sum k_i s_i) G comes from the ORACLE; the library states no expected value of its own
         try:
@@ -406,6 +424,9 @@ def measure_config5(comm, rank, world, steps=3, log2n=24):
             if shard is not None:
                 shard["correct"] = bool(shard_res == ob.msm_expected(0xC0FFEE, 0, n_total // 8))
                 ok = ok and shard["correct"]
+            if g2 is not None:
+                g2["correct"] = bool(g2_res == ob.msm_expected_g2(0xC0FFEE, 0, n_total // 4))
+                ok = ok and g2["correct"]
         except Exception as e:  # noqa: BLE001
             ok, judge = False, "oracle unavailable: %s" % e
     return {"workload": "config 5: single 2^%d-point BN254 G1 MSM, %d-way split, ncclAllGather of window sums"
@@ -415,6 +436,7 @@ def measure_config5(comm, rank, world, steps=3, log2n=24):
             "fold": os.environ.get("RLNAMD_MSM_FOLD", "host") + " (the 240 dependent doublings of the last step: 0.05 ms on a "
                     "host core, 1.5 - 1.9 ms on a lone GPU lane)",
             "shard_2^%d" % (log2n - 3): shard,
+            "g2_2^%d" % (log2n - 2): g2,
             "roofline": {"bound": "hbm", "limiter": "valu issue (bucket additions)",
                          "algorithmic_bytes_per_launch": n_total * 96, "achieved": round(gbps, 2),
                          "peak": HBM_PEAK_GBPS * world, "unit": "GB/s", "frac": round(gbps / (HBM_PEAK_GBPS * world), 5)}}

@@ -433,6 +433,7 @@ def test_bench_side_workloads_and_the_one_process_pool_mode_each_print_one_check
     d = _bench(["--workload", "msm", "--steps", "2"], {"RLNAMD_MSM_LOG2": "16"})
     assert d["correct"] is True and d["rccl_ranks"] == 1 and d["shard_2^13"]["correct"] is True
     assert d["shard_2^13"]["points"] == 1 << 13 and d["stage_ms_rank0"]["combine_ms"] < 1.0      # the fold on the host
+    assert d["g2_2^14"]["correct"] is True and d["g2_2^14"]["points"] == 1 << 14                  # the same MSM on the twist
     d = _bench(["--workload", "merkle", "--steps", "1"], {})
     assert d["correct"] is True and d["paths_failed_device_verification"] == 0
     assert d["updates_ffi"]["single_update_plus_root_ms_median"] < 1.5                              # the host chain (3 ms on the device)
