@@ -30,9 +30,15 @@
 
 namespace rlnamd {
 
-constexpr int MSM_C = 16;
-constexpr int MSM_W = 16;                 // ceil(255 / 16)
-constexpr uint32_t MSM_NB = 1u << 15;     // buckets per window (signed digits)
+// window width: 16 by measurement (profiles/r5_rocprof_summary.md section 6: c = 13 .. 16 at 2^21 and 2^24 points;
+// RLN_MSM_C overrides at compile time, 11 .. 16 -- the digits are packed in 16 bits, the counters of a window live in LDS)
+#ifndef RLN_MSM_C
+#define RLN_MSM_C 16
+#endif
+constexpr int MSM_C = RLN_MSM_C;
+static_assert(MSM_C >= 11 && MSM_C <= 16, "window width");
+constexpr int MSM_W = (255 + MSM_C - 1) / MSM_C;   // 254-bit scalars plus the carry of the signed recoding
+constexpr uint32_t MSM_NB = 1u << (MSM_C - 1);     // buckets per window (signed digits)
 constexpr uint32_t MSM_CHUNK = 32;        // buckets per reduction chunk
 constexpr uint32_t MSM_NCH = MSM_NB / MSM_CHUNK;
 
@@ -116,7 +122,7 @@ __global__ void __launch_bounds__(64) k_gen(uint64_t seed, uint64_t first, uint3
   for (int q = 0; q < 8; q++) scal[(size_t)t * 8 + q] = s[q];
 }
 
-// Signed 16-bit digits, packed (sign << 15) | (|d| - 1); 0xFFFF marks a zero digit (|d| - 1 = 32767 never carries
+// Signed MSM_C-bit digits, packed (sign << 15) | (|d| - 1); 0xFFFF marks a zero digit (|d| - 1 = 32767 never carries
 // a sign: the most negative digit is -32767).  Coalesced [window][point] stores, no atomics.
 constexpr uint16_t DIG_ZERO = 0xFFFFu;
 __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scal, uint32_t n, uint16_t* __restrict__ dig) {
@@ -128,10 +134,12 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
   uint32_t carry = 0;
 #pragma unroll
   for (int w = 0; w < MSM_W; w++) {
-    uint32_t raw = ((l[w >> 1] >> ((w & 1) * 16)) & 0xFFFFu) + carry;
+    const int o = w * MSM_C, lo = o >> 5, sh = o & 31;
+    const uint64_t two = (uint64_t)(lo < 8 ? l[lo] : 0u) | ((uint64_t)(lo + 1 < 8 ? l[lo + 1] : 0u) << 32);
+    uint32_t raw = ((uint32_t)(two >> sh) & ((1u << MSM_C) - 1u)) + carry;
     uint32_t mag, sign;
     if (raw > MSM_NB) {
-      mag = 65536u - raw;
+      mag = (1u << MSM_C) - raw;
       sign = 1;
       carry = 1;
     } else {
