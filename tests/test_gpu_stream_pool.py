@@ -253,6 +253,21 @@ def test_pool_dynamic_assignment_is_index_identical_and_a_failed_replica_does_no
             assert again == ref and sum(pool.last_proofs()) == n
     finally:
         pool.close()
+    # eight replicas (one device), 64-proof chunks: 16 chunks drawn from the shared cursor by eight workers at once; a
+    # replica failing on its first chunk while seven others keep drawing
+    pool = ProverPool(devices=[0] * 8, max_batch=64, window_bits=8)
+    try:
+        pool.set_dynamic(True)
+        dyn = pool.prove_raw(inp, rsb)
+        assert dyn == ref and sum(pool.last_proofs()) == n and sum(1 for k in pool.last_proofs() if k) >= 4
+        pool.inject_fault(5, after_chunks=0)
+        with pytest.raises(RLNError, match="injected fault"):
+            pool.prove_raw(inp, rsb)
+        assert pool.prove_raw(inp, rsb) == ref
+        pool.set_dynamic(False)
+        assert pool.prove_raw(inp, rsb) == ref and pool.last_proofs() == [128] * 7 + [104]
+    finally:
+        pool.close()
 
 
 # ---------------------------------------------------------------------------------------------------- RCCL in C
