@@ -267,6 +267,15 @@ int rlnamd_pool_last_proofs(rlnamd_pool* p, size_t* proofs_per_replica);
  * shot.  The job that meets the fault returns an error naming the device, the other replicas finish their chunks, the
  * witnesses of the failed replica's in-flight chunks are wiped, and the pool stays usable. */
 int rlnamd_pool_inject_fault(rlnamd_pool* p, size_t replica, size_t after_chunks);
+/* Failover.  rounds = 0 (default): a failing replica fails the job as described above.  rounds > 0: everything the
+ * failed replica was handed in the job (finished or not) and what it had not reached of its shard is proved again by the
+ * replicas that finished, up to `rounds` times per job; the failed replica is quarantined -- later jobs are cut among the
+ * others -- until rlnamd_pool_revive.  The job fails only when no replica is left or the rounds are spent; its result
+ * is index-identical to a job without faults.  rlnamd_pool_health: per replica, quarantined (0 / 1) and the number of
+ * dispatches that ended in an error since the pool was built (either array may be NULL). */
+int rlnamd_pool_set_failover(rlnamd_pool* p, int rounds);
+int rlnamd_pool_health(rlnamd_pool* p, int* quarantined_per_replica, size_t* failures_per_replica);
+int rlnamd_pool_revive(rlnamd_pool* p, size_t replica);
 int rlnamd_pool_verify_many(rlnamd_pool* p, size_t n, const uint8_t* proofs, const uint8_t* values_le, size_t n_values,
                             int threads, uint8_t* ok);
 /* RCCL communicator for the one path with an exchange step, the config-5 MSM.  Multi-process (one process per GPU,

@@ -596,6 +596,16 @@ def test_config_devices_puts_a_pool_behind_the_ffi_object(tmp_path):
     elems, bits = rln.get_merkle_proof(5)
     one = rln.generate_rln_proof(RLNWitnessInput(secret, 100, 7, elems, bits, 99, 1234))
     assert rln.verify_rln_proof(one, 99)
+    # the pool's assignment and failover switches as keys of the same JSON: the same bytes out
+    del rln
+    cfgp.write_text(json.dumps({"devices": [0, 0, 0], "max_batch": 64, "dynamic_shards": True, "failover": 1}))
+    rln = RLN(20, tree_config=str(cfgp))
+    got = [pr.to_bytes_le() for pr in rln.generate_rln_proofs_batch(wi, rs)]
+    assert all(r["proof"] in g for r, g in zip(ref, got))
+    del rln
+    cfgp.write_text(json.dumps({"devices": [0, 0], "failover": 65}))
+    with pytest.raises(Exception, match="failover"):
+        RLN(20, tree_config=str(cfgp))
     # a device that does not exist is a configuration error, not a crash
     cfgp.write_text(json.dumps({"devices": [0, 57]}))
     with pytest.raises(Exception, match="does not exist"):

@@ -270,6 +270,65 @@ def test_pool_dynamic_assignment_is_index_identical_and_a_failed_replica_does_no
         pool.close()
 
 
+def test_pool_failover_reproves_a_failed_replicas_chunks_on_the_others(prover):
+    """rlnamd_pool_set_failover: a replica that throws in the middle of a job (test hook) no longer fails the job --
+    everything it had been handed, and what it had not reached of its static shard, is proved again by the replicas that
+    finished, the result is byte-identical to a single prover's, the failed replica is quarantined (later jobs are cut
+    among the others) until revive().  Static and dynamic assignment, two and eight replicas; with every replica
+    quarantined, and with the rounds spent, the job fails with the first error."""
+    from zerokit_amd import workload
+    from zerokit_amd._native import RLNError
+    from zerokit_amd.batch import ProverPool
+    n = 1000
+    inp, rsb = workload.config2_packed(prover.slots, prover.inputs_size, 9000, n)
+    ref = prover.prove_stream_raw(inp, rsb)
+    pool = ProverPool(devices=[0, 0], max_batch=128)
+    try:
+        pool.set_failover(1)
+        for dynamic in (False, True):
+            pool.set_dynamic(dynamic)
+            pool.inject_fault(1, after_chunks=1)        # replica 1: one chunk in flight, fails when it asks for the next
+            got = pool.prove_raw(inp, rsb)
+            assert got == ref, "failover changed a byte"
+            assert pool.health()[1][0] and not pool.health()[0][0]
+            took = pool.last_proofs()
+            assert took[1] == 0 and took[0] >= n, took   # replica 0 made its own chunks and replica 1's again
+            got = pool.prove_raw(inp, rsb)              # quarantined: the whole job on replica 0
+            assert got == ref and pool.last_proofs() == [n, 0]
+            pool.revive(1)
+            assert pool.prove_raw(inp, rsb) == ref and all(pool.last_proofs())
+        assert [f for _, f in pool.health()] == [0, 2]
+        # the survivor fails as well: nobody left
+        pool.set_dynamic(False)
+        pool.inject_fault(0, after_chunks=0)
+        pool.prove_raw(inp, rsb)                        # replica 0 quarantined, replica 1 takes over
+        assert [q for q, _ in pool.health()] == [True, False]
+        pool.inject_fault(1, after_chunks=2)
+        with pytest.raises(RLNError, match="no replica left"):
+            pool.prove_raw(inp, rsb)
+        with pytest.raises(RLNError, match="every replica is quarantined"):
+            pool.prove_raw(inp, rsb)
+        pool.revive(0)
+        pool.revive(1)
+        assert pool.prove_raw(inp, rsb) == ref
+    finally:
+        pool.close()
+    pool = ProverPool(devices=[0] * 8, max_batch=64, window_bits=8)
+    try:
+        pool.set_failover(2)
+        pool.set_dynamic(True)
+        pool.inject_fault(5, after_chunks=0)
+        assert pool.prove_raw(inp, rsb) == ref
+        assert [q for q, _ in pool.health()] == [k == 5 for k in range(8)]
+        pool.set_dynamic(False)
+        pool.inject_fault(2, after_chunks=1)            # static: seven shards, the third one fails after one chunk
+        assert pool.prove_raw(inp, rsb) == ref
+        assert [q for q, _ in pool.health()] == [k in (2, 5) for k in range(8)]
+        assert pool.prove_raw(inp, rsb) == ref and sum(pool.last_proofs()) == n
+    finally:
+        pool.close()
+
+
 # ---------------------------------------------------------------------------------------------------- RCCL in C
 def test_msm_run_sharded_single_rank_communicator_vs_closed_form():
     """config 5 through the C ABI only: RCCL communicator of one rank (rlnamd_comm_init_rank), 2^18 generated points,

@@ -403,6 +403,21 @@ class ProverPool:
     def inject_fault(self, replica, after_chunks=0):
         check(lib().rlnamd_pool_inject_fault(self._h, replica, after_chunks))
 
+    def set_failover(self, rounds=1):
+        """rounds > 0: the chunks of a failing replica are proved again by the others (the replica is quarantined until
+        revive()); 0: a failing replica fails the job"""
+        check(lib().rlnamd_pool_set_failover(self._h, rounds))
+
+    def health(self):
+        """[(quarantined, failed dispatches)] per replica"""
+        q = (C.c_int * self.size)()
+        f = (C.c_size_t * self.size)()
+        check(lib().rlnamd_pool_health(self._h, q, f))
+        return [(bool(a), int(b)) for a, b in zip(q, f)]
+
+    def revive(self, replica):
+        check(lib().rlnamd_pool_revive(self._h, replica))
+
     def verify_many(self, proofs, public_inputs, threads=0):
         n = len(proofs)
         if n == 0:

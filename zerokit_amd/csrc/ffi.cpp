@@ -425,6 +425,8 @@ struct FFI_RLN {
       if (rlnamd_pool_new(zkey, zkey_len, graph, graph_len, cfg.max_batch, cfg.window_bits, tcfg.devices.data(),
                           tcfg.devices.size(), &pool) != RLNAMD_OK)
         throw Error(std::string("Configuration error: devices: ") + rlnamd_last_error());
+      rlnamd_pool_set_dynamic(pool, tcfg.dynamic_shards ? 1 : 0);
+      rlnamd_pool_set_failover(pool, (int)tcfg.failover);
       prover = std::shared_ptr<Prover>(rlnamd_pool_replica_prover(pool, 0), [](Prover*) {});
     } else {
       // A default object (no "profile" / "window_bits" / "max_batch" key, no RLNAMD_* sizing) takes the latency point:

@@ -49,7 +49,10 @@ struct Job {
   uint8_t* proofs = nullptr;
   uint8_t* values = nullptr;
   uint32_t* errors = nullptr;
+  int mode = 0;   // 0: the contiguous shard [lo, hi); 1: the shared cursor over [0, n); 2: the shared cursor over the pool's redo list
 };
+
+using Chunk = std::pair<size_t, size_t>;   // first proof, proofs
 
 struct Replica {
   int device = 0;
@@ -64,6 +67,12 @@ struct Replica {
   std::string error;   // of construction or of the last job
   float last_ms = 0;   // wall time of the last shard on this replica
   size_t last_proofs = 0, chunks_taken = 0;   // proofs of the last job this replica made; chunks it was handed (all jobs)
+  // failover (rlnamd_pool_set_failover): what the last dispatch handed this replica, and what it never reached of its
+  // static shard -- if the dispatch failed, all of it is proved again elsewhere (the writes are idempotent)
+  std::vector<Chunk> taken;
+  size_t rest_lo = 0, rest_hi = 0;
+  size_t failures = 0;        // dispatches that ended in an error (pool lifetime)
+  bool quarantined = false;   // failed under failover: handed nothing until rlnamd_pool_revive
 };
 
 }  // namespace
@@ -86,6 +95,14 @@ struct rlnamd_pool {
   // (counted over the pool's lifetime); one shot
   std::atomic<long> fault_replica{-1};
   size_t fault_after = 0;
+  // Failover (off by default: a failing replica fails the job, and the caller sees which device and why).  With
+  // failover_rounds > 0 the chunks of a failed replica -- everything it was handed in the dispatch, finished or not, and
+  // what it had not reached of its static shard -- go onto a redo list that the surviving replicas draw from, up to that
+  // many times per job; the failed replica is quarantined (rlnamd_pool_health, rlnamd_pool_revive).  The job fails only
+  // when no replica is left or the rounds are spent.
+  int failover_rounds = 0;
+  std::vector<Chunk> redo;
+  std::atomic<size_t> redo_cursor{0};
 
   void worker(Replica* R, const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_t graph_len, ProverConfig cfg) {
     try {
@@ -110,42 +127,55 @@ struct rlnamd_pool {
       R->has_job = false;
       lk.unlock();
       R->error.clear();
+      R->taken.clear();
+      R->rest_lo = R->rest_hi = 0;
+      size_t made = 0;
       try {
-        R->last_proofs = 0;
-        const bool dyn = dynamic;
-        if (dyn || hi > lo) {
+        const int mode = j.mode;
+        if (mode != 0 || hi > lo) {
           auto t0 = std::chrono::steady_clock::now();
           const size_t cap = R->prover->capacity();
           size_t at = lo;
+          R->rest_lo = lo;
+          R->rest_hi = hi;
           auto next = [&](size_t* off, size_t* cnt) {
             size_t o;
-            if (dyn) {
+            if (mode == 1) {
               o = cursor.fetch_add(cap);
               if (o >= j.n) return false;
               *cnt = std::min(cap, j.n - o);
+            } else if (mode == 2) {
+              const size_t k = redo_cursor.fetch_add(1);
+              if (k >= redo.size()) return false;
+              o = redo[k].first;
+              *cnt = redo[k].second;
             } else {
               if (at >= hi) return false;
               o = at;
               *cnt = std::min(cap, hi - at);
               at += *cnt;
+              R->rest_lo = at;
             }
             *off = o;
+            R->taken.emplace_back(o, *cnt);   // (before the fault hook: a chunk that was drawn from a shared cursor is this replica's to account for)
             if (fault_replica.load() >= 0 && rep[(size_t)fault_replica.load()].get() == R && R->chunks_taken >= fault_after) {
               fault_replica.store(-1);
               throw Error("injected fault (rlnamd_pool_inject_fault)");
             }
             R->chunks_taken++;
-            R->last_proofs += *cnt;
+            made += *cnt;
             return true;
           };
-          R->prover->prove_stream_from(next, j.inputs, j.rs, j.proofs, j.values, j.errors, dyn ? 3 : 0);
+          R->prover->prove_stream_from(next, j.inputs, j.rs, j.proofs, j.values, j.errors, mode == 0 ? 0 : 3);
           R->last_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
+        R->last_proofs += made;
       } catch (const std::exception& e) {
         R->error = e.what();
       } catch (...) {
         R->error = "unknown exception in the replica's worker";
       }
+      if (!R->error.empty()) R->failures++;
       {
         std::lock_guard<std::mutex> dl(done_mu);
         pending--;
@@ -245,33 +275,64 @@ int rlnamd_pool_prove(rlnamd_pool* p, size_t n, const uint8_t* inputs_le, const 
   if (n == 0) return RLNAMD_OK;
   if (!inputs_le || !rs_le) throw Error("rlnamd_pool_prove: inputs and rs are required");
   std::lock_guard<std::mutex> job_lk(p->job_mu);
-  const size_t N = p->rep.size();
+  std::vector<Replica*> team;   // who is handed work in this round
+  for (auto& R : p->rep) {
+    R->last_proofs = 0;
+    if (!R->quarantined) team.push_back(R.get());
+  }
+  if (team.empty()) throw Error("rlnamd_pool_prove: every replica is quarantined (rlnamd_pool_revive)");
   p->cursor.store(0);
-  {
-    std::lock_guard<std::mutex> dl(p->done_mu);
-    p->pending = N;
-  }
-  // contiguous shards by index, in units of whole waves (64 proofs) so that no replica pads more than the last one
-  const size_t waves = (n + 63) / 64;
-  for (size_t i = 0; i < N; i++) {
-    Replica& R = *p->rep[i];
-    size_t lo = std::min(n, (waves * i / N) * 64), hi = std::min(n, (waves * (i + 1) / N) * 64);
-    if (i + 1 == N) hi = n;
+  std::string first_error;
+  for (int round = 0;; round++) {
+    const size_t N = team.size();
     {
-      std::lock_guard<std::mutex> lk(R.mu);
-      R.job = Job{n, inputs_le, rs_le, proofs, values, errors};
-      R.lo = lo;
-      R.hi = hi;
-      R.has_job = true;
+      std::lock_guard<std::mutex> dl(p->done_mu);
+      p->pending = N;
     }
-    R.cv.notify_all();
+    // round 0, static: contiguous shards by index, in units of whole waves (64 proofs) so that no replica pads more than
+    // the last one; later rounds: the redo list
+    const size_t waves = (n + 63) / 64;
+    for (size_t i = 0; i < N; i++) {
+      Replica& R = *team[i];
+      size_t lo = 0, hi = 0;
+      if (round == 0 && !p->dynamic) {
+        lo = std::min(n, (waves * i / N) * 64);
+        hi = std::min(n, (waves * (i + 1) / N) * 64);
+        if (i + 1 == N) hi = n;
+      }
+      {
+        std::lock_guard<std::mutex> lk(R.mu);
+        R.job = Job{n, inputs_le, rs_le, proofs, values, errors, round > 0 ? 2 : p->dynamic ? 1 : 0};
+        R.lo = lo;
+        R.hi = hi;
+        R.has_job = true;
+      }
+      R.cv.notify_all();
+    }
+    {
+      std::unique_lock<std::mutex> lk(p->done_mu);
+      p->done_cv.wait(lk, [&] { return p->pending == 0; });
+    }
+    std::vector<Chunk> again;
+    std::vector<Replica*> alive;
+    for (Replica* R : team) {
+      if (R->error.empty()) {
+        alive.push_back(R);
+        continue;
+      }
+      if (first_error.empty()) first_error = "device " + std::to_string(R->device) + ": " + R->error;
+      again.insert(again.end(), R->taken.begin(), R->taken.end());
+      const size_t cap = R->prover->capacity();
+      for (size_t at = R->rest_lo; at < R->rest_hi; at += cap) again.emplace_back(at, std::min(cap, R->rest_hi - at));
+      if (p->failover_rounds > 0) R->quarantined = true;
+    }
+    if (again.empty()) break;   // every chunk of the job has been proved by a replica that finished its dispatch
+    if (round >= p->failover_rounds) throw Error("rlnamd_pool_prove: " + first_error);
+    if (alive.empty()) throw Error("rlnamd_pool_prove: no replica left to take over (" + first_error + ")");
+    p->redo = std::move(again);
+    p->redo_cursor.store(0);
+    team = std::move(alive);
   }
-  {
-    std::unique_lock<std::mutex> lk(p->done_mu);
-    p->done_cv.wait(lk, [&] { return p->pending == 0; });
-  }
-  for (auto& R : p->rep)
-    if (!R->error.empty()) throw Error("rlnamd_pool_prove: device " + std::to_string(R->device) + ": " + R->error);
   RLN_CATCH
 }
 
@@ -286,6 +347,26 @@ int rlnamd_pool_inject_fault(rlnamd_pool* p, size_t replica, size_t after_chunks
   std::lock_guard<std::mutex> job_lk(p->job_mu);
   p->fault_after = p->rep[replica]->chunks_taken + after_chunks;
   p->fault_replica.store((long)replica);
+  RLN_CATCH
+}
+int rlnamd_pool_set_failover(rlnamd_pool* p, int rounds) {
+  std::lock_guard<std::mutex> job_lk(p->job_mu);
+  p->failover_rounds = rounds > 0 ? rounds : 0;
+  return RLNAMD_OK;
+}
+int rlnamd_pool_health(rlnamd_pool* p, int* quarantined_per_replica, size_t* failures_per_replica) {
+  std::lock_guard<std::mutex> job_lk(p->job_mu);
+  for (size_t i = 0; i < p->rep.size(); i++) {
+    if (quarantined_per_replica) quarantined_per_replica[i] = p->rep[i]->quarantined ? 1 : 0;
+    if (failures_per_replica) failures_per_replica[i] = p->rep[i]->failures;
+  }
+  return RLNAMD_OK;
+}
+int rlnamd_pool_revive(rlnamd_pool* p, size_t replica) {
+  RLN_TRY
+  if (replica >= p->rep.size()) throw Error("rlnamd_pool_revive: no such replica");
+  std::lock_guard<std::mutex> job_lk(p->job_mu);
+  p->rep[replica]->quarantined = false;
   RLN_CATCH
 }
 int rlnamd_pool_last_proofs(rlnamd_pool* p, size_t* proofs_per_replica) {

@@ -47,6 +47,11 @@ struct TreeConfig {
   // first listed device, which must be the calling thread's current device (device 0 unless the host chose otherwise).
   std::vector<int> devices;
   bool has_devices = false;
+  // with "devices": "dynamic_shards": true = rlnamd_pool_set_dynamic (the replicas draw chunks from a shared cursor instead
+  // of taking contiguous shards); "failover": k = rlnamd_pool_set_failover (a failing device's chunks are proved again
+  // by the others, up to k times per call, and the device is left out of later calls)
+  bool dynamic_shards = false;
+  long failover = 0;
   bool persistent() const { return !temporary && has_path; }
   ProverConfig prover_config() const {
     ProverConfig cfg;
@@ -107,6 +112,7 @@ inline TreeConfig parse_tree_config(const std::string& js) {
       bool v = js[i] == 't';
       i += v ? 4 : 5;
       if (key == "temporary") c.temporary = v;
+      if (key == "dynamic_shards") c.dynamic_shards = v;
     } else if (!js.compare(i, 4, "null")) {
       i += 4;
     } else if (js[i] == '[' && key == "devices") {
@@ -162,6 +168,10 @@ inline TreeConfig parse_tree_config(const std::string& js) {
       if (key == "tree_depth") c.tree_depth = num;
       if (key == "window_bits") c.window_bits = num;
       if (key == "max_batch") c.max_batch = num;
+      if (key == "failover") {
+        if (num < 0 || num > 64) throw Error("Configuration error: failover: expected 0 .. 64 rounds");
+        c.failover = num;
+      }
       i = j;
     } else {
       throw bad("expected value");
