@@ -615,7 +615,7 @@ def test_config_devices_puts_a_pool_behind_the_ffi_object(tmp_path):
 @pytest.mark.parametrize("host_max", ["0", None, "8", "4096"])
 def test_deferred_tree_updates_with_reads_at_random_points_vs_oracle(host_max, monkeypatch):
     """(host_max: how many dirty leaves a pass may hold and still run its dependent chain on a host core --
-    MerkleTreeDev::set_few -- forced to never / the default 14 / 8 / always-below-4096.)
+    MerkleTreeDev::set_few -- forced to never / the default 11 / 8 / always-below-4096.)
     ffi_set_leaf / ffi_set_next_leaf / ffi_delete_leaf only record the write; the first reader hashes the union of the
     dirty paths in one pass (TreeAny::set_leaf).  A random stream of the mutation calls of rln/src/ffi/ffi_tree.rs with
     reads (root, leaf, Merkle proof, leaves_set, a proof generated over the tree) at random points gives what

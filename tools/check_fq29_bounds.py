@@ -131,6 +131,10 @@ def main(verbose=True):
                 ("poseidon row (sparse partial round) dotn<4>", [(N, f.N(80))] * 4, True, None, False),
                 ("poseidon dotn<5> masked", [(N, f.N(80))] * 5, False, None, False),
                 ("poseidon mul_add(u_i, st[0], st[i])  (st[i] < 72 r)", [(N, N)], True, f.N(80), False),
+                # four lanes per hash (poseidon_hash4_lanes): x = s_0 + k with s_0 < 4 r; p_i = row0[i] s_i < 1.5 r
+                ("poseidon 4-lane mul(x, x | u_i | row0[0]), x = s_0 + k", [(add(N, f.N(1)), add(N, f.N(1)))], True, None, False),
+                ("poseidon 4-lane mul(row0[i], s_i)  (s_i < 72 r)", [(N, f.N(80))], True, None, False),
+                ("poseidon 4-lane s_0' = mul_add(b, x^4, p_1 + p_2)", [(N, N)], True, lazy2, False),
                 ("witness interpreter a * b + c (mul_add, every value below 7.5 r)", [(N, N)], True, N, False),
             ]
         sites += [

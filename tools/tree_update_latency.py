@@ -14,7 +14,7 @@ t = PoseidonTree(20)
 t.fill_sequential(0, 1 << 20, 1)
 t.root()
 out = {}
-for k in (1, 8, 84, 1000):
+for k in (1, 4, 8, 10, 12, 14, 16, 64, 1000):
     ts = []
     for r in range(12):
         ups = [((r * 7919 + j * 104729) % (1 << 20), 5 + r + j) for j in range(k)]

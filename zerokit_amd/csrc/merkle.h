@@ -52,10 +52,10 @@ struct MerkleTreeDev {
   // set_leaf -> get_root of a membership contract costs no second round trip.  (FullMerkleTree::set + update_hashes,
   // full_merkle_tree.rs:197-223,336-399.)
   void set_few(const uint64_t* idx, const uint8_t* leaves_le, size_t k);
-  // how many dirty leaves a pass may have and still take set_few: the device pass costs ~3.0 ms whatever k is (up to
-  // a few thousand), set_few 0.24 ms for one leaf and ~0.18 ms for every further one (measured, EPYC 9575F host: k = 8
-  // 1.49 ms).  RLNAMD_TREE_HOST_MAX overrides (0: never; tests force 0 / 8 / 4096).
-  static constexpr size_t HOST_MAX_DEFAULT = 14, HOST_MAX_LIMIT = 4096;
+  // how many dirty leaves a pass may have and still take set_few: the device pass costs ~2.2 ms whatever k is (up to
+  // a few thousand: 20 levels x 0.108 ms with four lanes per hash), set_few 0.24 ms for one leaf and ~0.18 ms for every
+  // further one (measured, EPYC 9575F host: k = 8 1.5 ms, k = 12 2.1 ms).  RLNAMD_TREE_HOST_MAX overrides (0: never; tests force 0 / 8 / 4096).
+  static constexpr size_t HOST_MAX_DEFAULT = 11, HOST_MAX_LIMIT = 4096;
   static size_t host_max_from_env();
   // leaves i -> Fr(first + i): synthetic fill generated on the device (bench / config 3), then rehash
   void fill_sequential_device(size_t start, size_t n, uint64_t first);

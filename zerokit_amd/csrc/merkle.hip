@@ -20,17 +20,18 @@ __global__ void __launch_bounds__(256) k_hash_parents(Fr* __restrict__ nodes, si
   nodes[p] = poseidon_hash_dev<3>(in, pv);
 }
 
-// the same for a level with fewer parents than the chip has lanes: three lanes per hash (poseidon_hash3_lanes), 21
-// parents per single-wave workgroup -- the hash latency, which is all such a level costs, drops by 1.8 x
+// the same for a level with fewer parents than the chip has lanes: four lanes per hash (poseidon_hash4_lanes), 16
+// parents per single-wave workgroup -- the hash latency, which is all such a level costs, drops by 2.3 x
+constexpr uint32_t LPH = POSEIDON_LANES_PER_HASH, HPW = POSEIDON_HASHES_PER_WAVE;
 __global__ void __launch_bounds__(64) k_hash_parents_l3(Fr* __restrict__ nodes, size_t first, size_t count, PoseidonView pv) {
-  __shared__ __attribute__((aligned(16))) uint32_t sh[66 * 12];   // lane 63 (a triple of its own) reads two slots past its own
-  const uint32_t lane = threadIdx.x, g = lane / 3, j = lane % 3;
-  const size_t i = (size_t)blockIdx.x * 21 + g;
-  const bool active = lane < 63 && i < count;
+  __shared__ __attribute__((aligned(16))) uint32_t sh[64 * 12];
+  const uint32_t lane = threadIdx.x, g = lane / LPH, j = lane % LPH;
+  const size_t i = (size_t)blockIdx.x * HPW + g;
+  const bool active = i < count;
   const size_t p = first + (active ? i : 0);
   Fr in = Fr::zero();
-  if (active && j != 0) in = nodes[2 * p + j];   // j = 1: left child 2 p + 1, j = 2: right child 2 p + 2
-  const Fr h = poseidon_hash3_lanes(in, pv, sh);
+  if (active && (j == 1 || j == 2)) in = nodes[2 * p + j];   // j = 1: left child 2 p + 1, j = 2: right child 2 p + 2
+  const Fr h = poseidon_hash4_lanes(in, pv, sh);
   if (active && j == 0) nodes[p] = h;
 }
 
@@ -52,41 +53,41 @@ __global__ void __launch_bounds__(256) k_hash_parents_list(Fr* __restrict__ node
 }
 __global__ void __launch_bounds__(64) k_hash_parents_l3_list(Fr* __restrict__ nodes, const uint32_t* __restrict__ list,
                                                              uint32_t count, PoseidonView pv) {
-  __shared__ __attribute__((aligned(16))) uint32_t sh[66 * 12];
-  const uint32_t lane = threadIdx.x, g = lane / 3, j = lane % 3;
-  const uint32_t i = blockIdx.x * 21 + g;
-  const bool active = lane < 63 && i < count;
+  __shared__ __attribute__((aligned(16))) uint32_t sh[64 * 12];
+  const uint32_t lane = threadIdx.x, g = lane / LPH, j = lane % LPH;
+  const uint32_t i = blockIdx.x * HPW + g;
+  const bool active = i < count;
   const size_t p = active ? list[i] : 0;
   Fr in = Fr::zero();
-  if (active && j != 0) in = nodes[2 * p + j];
-  const Fr h = poseidon_hash3_lanes(in, pv, sh);
+  if (active && (j == 1 || j == 2)) in = nodes[2 * p + j];
+  const Fr h = poseidon_hash4_lanes(in, pv, sh);
   if (active && j == 0) nodes[p] = h;
 }
 // The top of a dirty-path pass -- every level from `first` up to the root -- in ONE launch: a single update is 20
 // dependent hashes, and as 20 launches each paid its launch latency on top of the hash.  One workgroup of TAIL_WAVES
-// waves, 21 three-lane hashes per wave and step; a level's results reach the next level through HBM (the workgroup's
+// waves, 16 four-lane hashes per wave and step; a level's results reach the next level through HBM (the workgroup's
 // own CU: workgroup-scope visibility after the barrier).  levels[l] = [off[l], off[l + 1]) of `list`, bottom-up.
-// (WAVES = 1 when no level holds more than 21 parents -- a single update, a handful of them: the barriers inside the hash
+// (WAVES = 1 when no level holds more than 16 parents -- a single update, a handful of them: the barriers inside the hash
 // then cost nothing; WAVES = 4 otherwise: four waves meeting at ~260 barriers per hash run each level ~40 % slower)
-constexpr uint32_t TAIL_WAVES_MAX = 4, TAIL_HASHES = 21 * TAIL_WAVES_MAX;
+constexpr uint32_t TAIL_WAVES_MAX = 4, TAIL_HASHES = HPW * TAIL_WAVES_MAX;
 struct LevelOffsets {
   uint32_t off[34];
 };
 template <uint32_t WAVES>
 __global__ void __launch_bounds__(64 * WAVES) k_hash_tail_list(Fr* __restrict__ nodes, const uint32_t* __restrict__ list,
                                                                LevelOffsets lo, int first, int nlevels, PoseidonView pv) {
-  __shared__ __attribute__((aligned(16))) uint32_t sh_all[WAVES][66 * 12];
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane / 3, j = lane % 3;
+  __shared__ __attribute__((aligned(16))) uint32_t sh_all[WAVES][64 * 12];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane / LPH, j = lane % LPH;
   uint32_t* sh = sh_all[wave];
   for (int l = first; l < nlevels; l++) {
     const uint32_t b = lo.off[l], cnt = lo.off[l + 1] - b;
-    for (uint32_t i0 = 0; i0 < cnt; i0 += 21 * WAVES) {
-      const uint32_t i = i0 + wave * 21 + g;
-      const bool active = lane < 63 && i < cnt;
+    for (uint32_t i0 = 0; i0 < cnt; i0 += HPW * WAVES) {
+      const uint32_t i = i0 + wave * HPW + g;
+      const bool active = i < cnt;
       const size_t p = active ? list[b + i] : 0;
       Fr in = Fr::zero();
-      if (active && j != 0) in = nodes[2 * p + j];
-      const Fr h = poseidon_hash3_lanes(in, pv, sh);
+      if (active && (j == 1 || j == 2)) in = nodes[2 * p + j];
+      const Fr h = poseidon_hash4_lanes(in, pv, sh);
       if (active && j == 0) nodes[p] = h;
     }
     __threadfence();
@@ -289,15 +290,15 @@ void MerkleTreeDev::init(int depth_, const uint8_t default_leaf_le[32]) {
 void MerkleTreeDev::rehash(size_t lo, size_t hi) {
   root_known = false;
   PoseidonView pv = poseidon_view(3);
-  const size_t l3_max = 21 * 1024;
+  const size_t l3_max = HPW * 1024;
   while (lo > 0) {
     lo = ((lo + 1) >> 1) - 1;
     hi = ((hi + 1) >> 1) - 1;
     size_t cnt = hi - lo + 1;
-    // a level that cannot fill the chip anyway (at most one 21-hash wave per SIMD) costs one hash latency: three
-    // lanes per hash there (0.105 instead of 0.195 ms per level; a single-leaf update is 20 such levels)
+    // a level that cannot fill the chip anyway (at most one 16-hash wave per SIMD) costs one hash latency: four
+    // lanes per hash there
     if (cnt <= l3_max)
-      hipLaunchKernelGGL(k_hash_parents_l3, dim3(div_up(cnt, 21)), dim3(64), 0, stream, nodes.p, lo, cnt, pv);
+      hipLaunchKernelGGL(k_hash_parents_l3, dim3(div_up(cnt, HPW)), dim3(64), 0, stream, nodes.p, lo, cnt, pv);
     else
       hipLaunchKernelGGL(k_hash_parents, dim3(div_up(cnt, 256)), dim3(256), 0, stream, nodes.p, lo, cnt, pv);
   }
@@ -366,13 +367,13 @@ void MerkleTreeDev::set_scattered(const uint64_t* idx, const uint8_t* leaves_le,
   for (; l < depth; l++) {
     const uint32_t cnt = lo.off[l + 1] - lo.off[l];
     if (cnt <= TAIL_HASHES) break;   // counts only shrink towards the root: the rest is one launch
-    if (cnt <= 21 * 1024)
-      hipLaunchKernelGGL(k_hash_parents_l3_list, dim3(div_up(cnt, 21)), dim3(64), 0, stream, nodes.p, d_list + lo.off[l], cnt, pv);
+    if (cnt <= HPW * 1024)
+      hipLaunchKernelGGL(k_hash_parents_l3_list, dim3(div_up(cnt, HPW)), dim3(64), 0, stream, nodes.p, d_list + lo.off[l], cnt, pv);
     else
       hipLaunchKernelGGL(k_hash_parents_list, dim3(div_up(cnt, 256)), dim3(256), 0, stream, nodes.p, d_list + lo.off[l], cnt, pv);
   }
   if (l < depth) {
-    if (lo.off[l + 1] - lo.off[l] <= 21)   // counts only shrink: one wave covers every remaining level
+    if (lo.off[l + 1] - lo.off[l] <= HPW)   // counts only shrink: one wave covers every remaining level
       hipLaunchKernelGGL(k_hash_tail_list<1>, dim3(1), dim3(64), 0, stream, nodes.p, d_list, lo, l, depth, pv);
     else
       hipLaunchKernelGGL(k_hash_tail_list<TAIL_WAVES_MAX>, dim3(1), dim3(64 * TAIL_WAVES_MAX), 0, stream, nodes.p, d_list, lo,

@@ -247,20 +247,25 @@ __device__ __forceinline__ Fr poseidon_hash_dev(const Fr* in, const PoseidonView
   for (int r = 0; r < half; r++, ark += T * 9) poseidon_round29<T, true>(st, ark, pv.mds29);
   return st[0].to_fq();
 }
-// ---- t = 3 on THREE lanes per hash (latency form).  A hash on one lane is a chain of ~520 products, and a lone wave
+// ---- t = 3 on FOUR lanes per hash (latency form).  A hash on one lane is a chain of ~520 products, and a lone wave
 // issues them at 4.4 cycles per instruction whatever else the chip does: 0.2 ms per hash, which is what the top levels
-// of a tree build (fewer nodes than lanes), a single-leaf update (20 dependent hashes) and every other short chain of
-// hashes cost.  Here lane j of a triple holds state element j and the three lanes meet in LDS:
-//   full round     every lane: (s + ark_j)^5; exchange; lane j: row j of the MDS product          3 + 2 product slots
-//   partial round  slot 1  lane 0: (s + k)^2          lanes 1, 2: p_i = row0[i] s_i  (old s_i)
-//                  slot 2, 3  lane 0: ^4, ^5            lanes 1, 2: idle
-//                  broadcast x = s_0'; slot 4  lane 0: p_0 = row0[0] x   lanes 1, 2: s_i += u_i x
-//                  lanes 1, 2 hand p_i to lane 0: s_0 = p_0 + p_1 + p_2                            4 product slots
-// instead of 9 + 6 and 7.5 on one lane: the same field operations (bit-identical output), 1.8 x less latency.
-// Call with all 64 lanes of every wave of the workgroup (the waves meet at the same barriers: same trip counts); lane l of
-// a wave works for triple l / 3 (lane 63 idles); `sh` is 66 x 12 words of LDS PER WAVE.  `in`: the input of this lane (lanes 1 and 2 of the triple; ignored on lane 0); the hash is returned on lane 0.
-__device__ __forceinline__ Fr poseidon_hash3_lanes(const Fr& in, const PoseidonView& pv, uint32_t* sh) {
-  const uint32_t lane = threadIdx.x & 63, j = lane % 3, base = lane - j;
+// of a tree build (fewer nodes than lanes), a dirty-path pass and every other short chain of hashes cost.  Here lane j
+// (0 .. 2) of a quadruple holds state element j, lane 3 helps, and the lanes meet in LDS:
+//   full round     every lane: (s + ark_j)^5; exchange; lane j: row j of the MDS product          3 + 1 product slots
+//   partial round  x = s_0 + k is known to all four lanes; x^5 cannot be had in fewer than three multiplicative levels,
+//                  but nothing else has to wait for it:
+//     slot 1   lane 0: x^2            lane 1: a_1 = u_1 x     lane 2: a_2 = u_2 x     lane 3: b = row0[0] x
+//     slot 2   lane 0: x^4            lane 1: p_1 = row0[1] s_1                     lane 2: p_2 = row0[2] s_2
+//     slot 3   lane 0: s_0' = b x^4 + (p_1 + p_2)       lanes 1, 2: s_i' = a_i x^4 + s_i
+// -- the same field values as the sparse round on one lane (s_0' = row0 . (x^5, s_1, s_2), s_i' = s_i + u_i x^5), so the
+// output is bit-identical; 203 dependent product slots per hash (the three-lane form of rounds 3 - 4 had 260: 0.140 ->
+// 0.108 ms per level).  Lane 3 holds no state (it follows lane 2's code path on values nobody reads, so that the wave
+// stays uniform); 16 hashes per wave.  Call with all 64 lanes of every wave of the workgroup (the waves meet at the same
+// barriers); `in`: the input of lanes 1 and 2; the hash is returned on lane 0.  `sh`: 64 x 12 words of LDS per wave.
+// Operand classes: tools/check_fq29_bounds.py ("poseidon 4-lane ...").
+constexpr uint32_t POSEIDON_LANES_PER_HASH = 4, POSEIDON_HASHES_PER_WAVE = 64 / POSEIDON_LANES_PER_HASH;
+__device__ __forceinline__ Fr poseidon_hash4_lanes(const Fr& in, const PoseidonView& pv, uint32_t* sh) {
+  const uint32_t lane = threadIdx.x & 63, j = lane & 3, base = lane - j, jj = j == 3 ? 2 : j;
   auto put = [&](const Fr29& x) {
     uint32_t* d = sh + lane * 12;
     *(uint4*)d = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
@@ -282,59 +287,72 @@ __device__ __forceinline__ Fr poseidon_hash3_lanes(const Fr& in, const PoseidonV
     for (int k = 0; k < 9; k++) x.v[k] = c[k];
     return x;
   };
-  Fr29 s = j == 0 ? Fr29::zero() : Fr29::from_fq(in);
-  const int half = pv.rf / 2;
-  auto full_round = [&](const uint32_t* ark) {
-    const Fr29 a = cst(ark + j * 9);
+  auto sel = [&](bool c, const Fr29& a, const Fr29& b) {
+    Fr29 x;
 #pragma unroll
-    for (int k = 0; k < 9; k++) s.v[k] += a.v[k];
-    const Fr29 x2 = Fr29::sqr(s), x4 = Fr29::sqr(x2);
-    s = Fr29::mul(x4, s);
-    __syncthreads();
-    put(s);
-    __syncthreads();
-    const Fr29 t0 = get(base), t1 = get(base + 1), t2 = get(base + 2);
-    const uint32_t* m = pv.mds29 + j * 3 * 9;
-    s = Fr29::dot3<true>(cst(m), t0, cst(m + 9), t1, cst(m + 18), t2);
+    for (int k = 0; k < 9; k++) x.v[k] = c ? a.v[k] : b.v[k];
+    return x;
   };
-  const uint32_t* ark = pv.ark29;
+  Fr29 s = (j == 1 || j == 2) ? Fr29::from_fq(in) : Fr29::zero();
+  const int half = pv.rf / 2;
+  // A lone wave waits out every load it issues: the MDS row of this lane stays in registers, and the constants of round
+  // r + 1 are fetched while round r computes (a latency kernel has the whole register file to itself).
+  const Fr29 m0 = cst(pv.mds29 + jj * 27), m1 = cst(pv.mds29 + jj * 27 + 9), m2 = cst(pv.mds29 + jj * 27 + 18);
+  auto full_rounds = [&](const uint32_t* ark) {
+    Fr29 a = cst(ark + jj * 9);
 #pragma unroll 1
-  for (int r = 0; r < half; r++, ark += 27) full_round(ark);
+    for (int r = 0; r < half; r++) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) s.v[k] += a.v[k];
+      ark += r + 1 < half ? 27 : 0;
+      a = cst(ark + jj * 9);
+      const Fr29 x2 = Fr29::sqr(s), x4 = Fr29::sqr(x2);
+      s = Fr29::mul(x4, s);
+      __syncthreads();
+      put(s);
+      __syncthreads();
+      const Fr29 t0 = get(base), t1 = get(base + 1), t2 = get(base + 2);
+      s = Fr29::dot3<true>(m0, t0, m1, t1, m2, t2);
+    }
+  };
+  full_rounds(pv.ark29);
+  __syncthreads();
+  if (j == 0) put(s);
+  __syncthreads();
+  Fr29 s0 = get(base);
   const uint32_t *k0 = pv.k0, *row0 = pv.row0, *u = pv.u;
+  Fr29 k = cst(k0), c1 = cst(j == 1 ? u : j == 2 ? u + 9 : row0), c2 = cst(row0 + jj * 9);   // (lane 0 loads row0[0] into c1 and does not use it)
 #pragma unroll 1
-  for (int r = 0; r < pv.rp; r++, k0 += 9, row0 += 27, u += 18) {
-    // slot 1: lane 0 squares s + k, lanes 1, 2 multiply their (old) state by their entry of row0 -- one product
-    Fr29 x = s, y = cst(row0 + j * 9);
-    if (j == 0) {
-      const Fr29 k = cst(k0);
+  for (int r = 0; r < pv.rp; r++) {
+    Fr29 x = s0;
 #pragma unroll
-      for (int q = 0; q < 9; q++) x.v[q] += k.v[q];
-      y = x;
+    for (int q = 0; q < 9; q++) x.v[q] += k.v[q];
+    const Fr29 c1r = c1, c2r = c2;
+    if (r + 1 < pv.rp) {
+      k0 += 9;
+      row0 += 27;
+      u += 18;
     }
-    Fr29 t = Fr29::mul(x, y);   // lane 0: (s + k)^2; lanes 1, 2: p_i
-    if (j == 0) {
-      t = Fr29::sqr(t);
-      t = Fr29::mul(t, x);      // (s + k)^5
-    }
+    k = cst(k0);
+    c1 = cst(j == 1 ? u : j == 2 ? u + 9 : row0);
+    c2 = cst(row0 + jj * 9);
+    // slot 1: x times { x, u_1, u_2, row0[0] }
+    const Fr29 t1 = Fr29::mul(x, sel(j == 0, x, c1r));
+    // slot 2: lane 0 squares x^2; lanes 1, 2: row0[j] s_j (lane 3 follows lane 2 on its own, unread, state)
+    const Fr29 t2 = Fr29::mul(sel(j == 0, t1, c2r), sel(j == 0, t1, s));
     __syncthreads();
-    if (j == 0) put(t);
+    put(sel(j == 3, t1, t2));   // lane 0: x^4; lanes 1, 2: p_i; lane 3: b
     __syncthreads();
-    const Fr29 x5 = get(base);
-    // slot 4: lane 0: p_0 = row0[0] x5; lanes 1, 2: u_i x5
-    const Fr29 c = j == 0 ? cst(row0) : cst(u + (j - 1) * 9);
-    Fr29 zero_or_s = s;
-    if (j == 0) zero_or_s = Fr29::zero();
-    const Fr29 w = Fr29::mul_add(c, x5, zero_or_s);   // lane 0: p_0; lanes 1, 2: s_i + u_i x
-    if (j != 0) s = w;
-    __syncthreads();
-    if (j != 0) put(t);   // p_i
-    __syncthreads();
-    if (j == 0) {
-      const Fr29 p1 = get(base + 1), p2 = get(base + 2);
+    const Fr29 g0 = get(base), g1 = get(base + 1), g2 = get(base + 2), g3 = get(base + 3);
+    Fr29 p12;
 #pragma unroll
-      for (int q = 0; q < 9; q++) s.v[q] = w.v[q] + p1.v[q] + p2.v[q];
-      s.normalize();
-    }
+    for (int q = 0; q < 9; q++) p12.v[q] = g1.v[q] + g2.v[q];
+    // slot 3: lane 0: b x^4 + p_1 + p_2; lanes 1, 2: a_i x^4 + s_i
+    s = Fr29::mul_add(sel(j == 0, g3, t1), sel(j == 0, t2, g0), sel(j == 0, p12, s));
+    __syncthreads();
+    if (j == 0) put(s);
+    __syncthreads();
+    s0 = get(base);
   }
   {  // leftover A_(R_P) on lanes 1, 2: s_i <- a_fin[i-1][0] s_1 + a_fin[i-1][1] s_2
     __syncthreads();
@@ -342,14 +360,12 @@ __device__ __forceinline__ Fr poseidon_hash3_lanes(const Fr& in, const PoseidonV
     __syncthreads();
     if (j != 0) {
       const Fr29 t1 = get(base + 1), t2 = get(base + 2);
-      const uint32_t* a = pv.a_fin + (j - 1) * 2 * 9;
+      const uint32_t* a = pv.a_fin + (jj - 1) * 2 * 9;
       s = Fr29::dot2(cst(a), t1, cst(a + 9), t2);
     }
   }
-  ark = pv.ark2;
-#pragma unroll 1
-  for (int r = 0; r < half; r++, ark += 27) full_round(ark);
-  return s.to_fq();   // meaningful on lane 0 of the triple
+  full_rounds(pv.ark2);
+  return s.to_fq();   // meaningful on lane 0 of the quadruple
 }
 #endif
 
