@@ -41,7 +41,8 @@ int witsched_run(const uint8_t* graph, size_t len, const uint8_t* inputs_le, siz
     if (!P.ok) throw std::runtime_error("graph does not fit the lanes form");
     std::vector<Fr> lds(WL_SLOTS, Fr::zero()), stored(slot2node.size() + 1, Fr::zero());
     const uint32_t nc = P.n_consts;
-    for (uint32_t i = 0; i < nc; i++) lds[i] = g.constants[i];
+    if (P.consts.size() != nc) throw std::runtime_error("program constants");
+    for (uint32_t i = 0; i < nc; i++) lds[i] = P.consts[i];
     lds[nc] = Fr::zero();
     lds[nc + 1] = Fr::one();
     lds[nc + 2] = Fr::one().neg();

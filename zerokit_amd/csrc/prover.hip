@@ -1367,7 +1367,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   MARK(1, sA);
   if (D.wit29) {
     if (wl_used) {
-      D.witlanes.launch(sA, D.consts29.p, in_p, D.NI, S.V29.p, S.err.p, B, nb);
+      D.witlanes.launch(sA, in_p, D.NI, S.V29.p, S.err.p, B, nb);
     } else
     hipLaunchKernelGGL(k_witness29<false>, dim3(pg), dim3(64), WIT29_LDS_BYTES, sA, D.nodes29.p, D.nprog29,
                        D.consts29.p, (uint32_t)graph_.constants.size(), in_p, D.NI, S.V29.p, S.err.p, B, nbp, nullptr);

@@ -19,13 +19,13 @@ struct WitLanes {
   bool ok = false;            // false: the graph does not fit this form (too many constants / live values): use k_witness29
   uint32_t nsteps = 0, nrow = 0, nfma = 0, nsqr = 0, nadd = 0, nmisc = 0, peak_slots = 0, n_consts = 0;
   DevBuf<uint4> prog;         // [nsteps + padding][WL_W] micro-op descriptors
+  DevBuf<uint32_t> consts29;  // the PROGRAM's constants (the graph's, then the ones the scheduler folded) in the 9 x 29 form
   // store_slot[n]: index of node n in the compact array of stored values (V29), or 0xFFFFFFFF when it is not stored.
-  // d_consts29: the graph constants in the 9 x 29-bit Montgomery form, 9 words each (device memory).
   // trash_slot: a row of V29 nobody reads (the kernel stores every value; values that are not kept go there).
   void build(const Graph& g, const std::vector<uint32_t>& store_slot, uint32_t trash_slot, hipStream_t s);
   // one wave per proof; V29 / err as for k_witness29: V29[(slot * B + proof) * 3 .. + 3), err[proof]
-  void launch(hipStream_t s, const uint32_t* d_consts29, const uint32_t* d_inputs, uint32_t n_inputs, uint4* V29,
-              uint32_t* err, uint32_t B, uint32_t nb) const;
+  void launch(hipStream_t s, const uint32_t* d_inputs, uint32_t n_inputs, uint4* V29, uint32_t* err, uint32_t B,
+              uint32_t nb) const;
 };
 
 }  // namespace rlnamd

@@ -16,6 +16,7 @@
 #include <algorithm>
 
 #include "fq29.h"
+#include "prover_kernels.h"
 #include "witness_ops.h"
 
 namespace rlnamd {
@@ -375,7 +376,18 @@ void WitLanes::build(const Graph& graph, const std::vector<uint32_t>& store_slot
   static_assert(sizeof(WlDesc) == sizeof(uint4), "descriptor size");
   prog.alloc(P.img.size());
   prog.upload(reinterpret_cast<const uint4*>(P.img.data()), P.img.size(), s);
-  RLN_HIP(hipStreamSynchronize(s));
+  {
+    DevBuf<Fr> c8;
+    c8.alloc(std::max<size_t>(P.consts.size(), 1));
+    consts29.alloc(std::max<size_t>(P.consts.size(), 1) * 9);
+    if (!P.consts.empty()) {
+      c8.upload(P.consts.data(), P.consts.size(), s);
+      hipLaunchKernelGGL(k_consts_to29, dim3(div_up(P.consts.size(), 256)), dim3(256), 0, s, c8.p, consts29.p,
+                         (uint32_t)P.consts.size());
+      RLN_HIP(hipGetLastError());
+    }
+    RLN_HIP(hipStreamSynchronize(s));   // c8 goes out of scope
+  }
   if (hipFuncSetAttribute((const void*)k_witness_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, WL_LDS_BYTES) !=
       hipSuccess) {   // a device with less LDS per workgroup: keep k_witness29
     (void)hipGetLastError();
@@ -384,9 +396,9 @@ void WitLanes::build(const Graph& graph, const std::vector<uint32_t>& store_slot
   ok = true;
 }
 
-void WitLanes::launch(hipStream_t s, const uint32_t* d_consts29, const uint32_t* d_inputs, uint32_t n_inputs, uint4* V29,
-                      uint32_t* err, uint32_t B, uint32_t nb) const {
-  hipLaunchKernelGGL(k_witness_lanes, dim3(nb), dim3(64), WL_LDS_BYTES, s, prog.p, nsteps, d_consts29, n_consts, d_inputs,
+void WitLanes::launch(hipStream_t s, const uint32_t* d_inputs, uint32_t n_inputs, uint4* V29, uint32_t* err, uint32_t B,
+                      uint32_t nb) const {
+  hipLaunchKernelGGL(k_witness_lanes, dim3(nb), dim3(64), WL_LDS_BYTES, s, prog.p, nsteps, consts29.p, n_consts, d_inputs,
                      n_inputs, V29, err, B);
 }
 

@@ -11,9 +11,14 @@
 // multiplicand; when a result would still pass WL_BMAX it is followed by a reduction x * ONE + ZERO.
 #include "witness_sched.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
+#include <string.h>
+
 #include <algorithm>
+#include <array>
+#include <map>
 #include <stdexcept>
 
 namespace rlnamd {
@@ -26,6 +31,9 @@ struct MicroOp {
   uint32_t imm;                // WO_INPUT: index into the inputs buffer
 };
 constexpr uint32_t NONE = 0xFFFFFFFFu;
+// a * b + c as ONE node: emitted by hoist_linear_forms for its chains (the graph format has no such operation), passed
+// through by reassociate_sums, scheduled as a product step with its addend
+constexpr uint32_t G_FMA = 25;
 int env_int_wl(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
@@ -45,7 +53,7 @@ static void reassociate_sums(const Graph& in, const std::vector<uint32_t>& store
   const std::vector<GNode>& G = in.nodes;
   const uint32_t N = (uint32_t)G.size();
   auto nops = [&](const GNode& g) {
-    return (g.op == G_INPUT || g.op == G_CONST) ? 0 : (g.op == G_NEG || g.op == G_ID) ? 1 : g.op == G_TERN ? 3 : 2;
+    return (g.op == G_INPUT || g.op == G_CONST) ? 0 : (g.op == G_NEG || g.op == G_ID) ? 1 : (g.op == G_TERN || g.op == G_FMA) ? 3 : 2;
   };
   std::vector<uint32_t> uses(N, 0);
   std::vector<uint8_t> is_signal(N, 0);
@@ -165,15 +173,350 @@ static void reassociate_sums(const Graph& in, const std::vector<uint32_t>& store
   for (uint32_t sg : in.signals) out->signals.push_back(remap[sg]);
 }
 
+// Linear forms on the critical path.  Poseidon's partial round, as the circuit compiler leaves it, is FOUR dependent
+// products: x^2, x^4, y = x^4 x + c, then x' = K00 y + K01 s1' + K02 s2' with s_i' = s_i + K_i y.  Everything behind y is
+// linear, and a linear form can be re-expressed over EARLIER values:
+//     x' = (K00 + K01 K1 + K02 K2) y + (K01 K1' + K02 K2') y_prev + K01 s1_prev + K02 s2_prev
+// (two rounds of the s_i recurrence unrolled, like terms merged into one folded constant each), and the one late term
+// takes its constant on the early factor: kappa (x^4 x + c) = x^4 (kappa x) + kappa c -- kappa x is there one step after x,
+// beside x^2.  Three dependent products per round, the same number of products per round (the s_i updates keep their
+// definition; x' trades three products and two additions for five fused a * b + c).  Generic over the graph: a
+// materialised linear node (an Add / a product with one constant factor that is read more than once, stored, or a witness
+// signal) near the critical path is expanded through the linear nodes below it -- through private ones freely, through
+// at most two shared ones -- into sum coef_k atom_k + const over nonlinear atoms; the form is taken when the arrival
+// estimate of its fused chain beats the node's own.  Every value the graph outputs keeps its definition or an
+// algebraically equal one (field arithmetic is exact: bit-identical witness), what loses its last reader is dropped.
+// Shipped depth-20 circuit: multiplication depth 5 736 -> ~4 300; 6 122 -> 5 267 row-form steps (the row form has four
+// product slots per step, and the round now fills them), single proof 2.59 -> 2.29 ms.  RLNAMD_WL_HOIST=0 keeps the graph as it came.
+static void hoist_linear_forms(const Graph& in, const std::vector<uint32_t>& store_in, Graph* out,
+                               std::vector<uint32_t>* store_out) {
+  const std::vector<GNode>& G = in.nodes;
+  const uint32_t N = (uint32_t)G.size();
+  auto nops = [&](const GNode& g) {
+    return (g.op == G_INPUT || g.op == G_CONST) ? 0 : (g.op == G_NEG || g.op == G_ID) ? 1 : (g.op == G_TERN || g.op == G_FMA) ? 3 : 2;
+  };
+  auto cost = [&](const GNode& g) { return (g.op == G_INPUT || g.op == G_CONST || g.op == G_ADD) ? 0u : 1u; };
+  auto is_const = [&](uint32_t n) { return G[n].op == G_CONST; };
+  // criticality on the multiplication-depth estimate (additions free): only nodes within `near` of the longest path
+  std::vector<uint32_t> D(N, 0), TL(N, 0), uses(N, 0);
+  uint32_t CP = 0;
+  for (uint32_t n = 0; n < N; n++) {
+    const uint32_t o[3] = {G[n].a, G[n].b, G[n].c};
+    uint32_t d = 0;
+    for (int k = 0; k < nops(G[n]); k++) {
+      if (o[k] >= n) throw std::runtime_error("Graph error: node operand refers forward");
+      d = std::max(d, D[o[k]]);
+      uses[o[k]]++;
+    }
+    D[n] = d + cost(G[n]);
+  }
+  for (uint32_t n = N; n-- > 0;) {
+    const uint32_t o[3] = {G[n].a, G[n].b, G[n].c};
+    for (int k = 0; k < nops(G[n]); k++) TL[o[k]] = std::max(TL[o[k]], TL[n] + cost(G[n]));
+    CP = std::max(CP, D[n] + TL[n]);
+  }
+  const uint32_t near = (uint32_t)env_int_wl("RLNAMD_WL_NEAR", 0);
+  const size_t max_terms = (size_t)env_int_wl("RLNAMD_WL_TERMS", 6);
+  const int max_cross = env_int_wl("RLNAMD_WL_CROSS", 2);
+  std::vector<uint8_t> is_signal(N, 0);
+  for (uint32_t sg : in.signals) is_signal[sg] = 1;
+  auto private_node = [&](uint32_t n) { return uses[n] == 1 && !is_signal[n] && store_in[n] == NONE; };
+  auto linear = [&](uint32_t n) {
+    return G[n].op == G_ADD || (G[n].op == G_MUL && is_const(G[n].a) != is_const(G[n].b));
+  };
+  Graph H;
+  H.constants = in.constants;
+  std::vector<uint32_t> remap(N, NONE), st, T;   // T: estimated step at which a node of the new graph is there
+  auto emit = [&](const GNode& g, uint32_t t, uint32_t store) {
+    H.nodes.push_back(g);
+    st.push_back(store);
+    T.push_back(t);
+    return (uint32_t)H.nodes.size() - 1;
+  };
+  auto To = [&](uint32_t old) { return T[remap[old]]; };
+  std::map<std::array<uint32_t, 8>, uint32_t> const_node;   // value -> G_CONST node of the new graph
+  for (uint32_t n = 0; n < N; n++)
+    if (is_const(n)) {
+      std::array<uint32_t, 8> key;
+      memcpy(key.data(), in.constants[G[n].a].v, 32);
+      const_node.emplace(key, NONE);   // filled when the node is emitted below
+    }
+  auto const_of = [&](const Fr& v) {
+    std::array<uint32_t, 8> key;
+    memcpy(key.data(), v.v, 32);
+    auto it = const_node.find(key);
+    if (it != const_node.end() && it->second != NONE) return it->second;
+    H.constants.push_back(v);
+    const uint32_t nd = emit(GNode{G_CONST, (uint32_t)H.constants.size() - 1, 0, 0}, 0, NONE);
+    const_node[key] = nd;
+    return nd;
+  };
+  struct Term {
+    uint32_t atom;   // node of the OLD graph
+    Fr coef;
+  };
+  struct Form {
+    std::vector<Term> t;
+    Fr c = Fr::zero();
+    bool ok = true;
+  };
+  // expand `n` (times coef) into f; `cross`: shared linear nodes that may still be looked through
+  struct Expander {
+    const std::vector<GNode>& G;
+    const Graph& in;
+    decltype(linear)& lin;
+    decltype(private_node)& priv;
+    size_t max_terms;
+    void run(uint32_t n, const Fr& coef, int cross, bool top, Form& f) {
+      if (!f.ok) return;
+      const GNode& g = G[n];
+      if (g.op == G_CONST) {
+        f.c = f.c + coef * in.constants[g.a];
+        return;
+      }
+      if (lin(n) && (top || priv(n) || cross > 0)) {
+        const int cx = (top || priv(n)) ? cross : cross - 1;
+        if (g.op == G_ADD) {
+          run(g.a, coef, cx, false, f);
+          run(g.b, coef, cx, false, f);
+        } else {
+          const bool ka = G[g.a].op == G_CONST;
+          run(ka ? g.b : g.a, coef * in.constants[G[ka ? g.a : g.b].a], cx, false, f);
+        }
+        return;
+      }
+      for (Term& t : f.t)
+        if (t.atom == n) {
+          t.coef = t.coef + coef;
+          return;
+        }
+      f.t.push_back(Term{n, coef});
+      if (f.t.size() > max_terms) f.ok = false;
+    }
+  };
+  Expander ex{G, in, linear, private_node, max_terms};
+  // a term of a form, ready to be emitted
+  struct Piece {
+    uint32_t ready, tm;   // tm: NONE for a plain addend, else the step its product's operands are there
+    uint32_t atom;
+    Fr coef;
+    uint32_t late, early;   // late-factor form (NONE: plain K * atom)
+  };
+  size_t rewritten = 0;
+  for (uint32_t n = 0; n < N; n++) {
+    const GNode& g = G[n];
+    // ---- the node as it stands
+    GNode h = g;
+    uint32_t* o[3] = {&h.a, &h.b, &h.c};
+    uint32_t t_def = 0;
+    for (int k = 0; k < nops(g); k++) {
+      *o[k] = remap[*o[k]];
+      t_def = std::max(t_def, T[*o[k]]);
+    }
+    if (nops(g)) t_def++;
+    if (g.op == G_ADD && g.a != g.b)   // a plain Add fuses with a private product whose other operand is there in time
+      for (int k = 0; k < 2; k++) {
+        const uint32_t m = k ? g.b : g.a, c = k ? g.a : g.b;
+        if (G[m].op == G_MUL && private_node(m)) {
+          const uint32_t tm = std::max(To(G[m].a), To(G[m].b));
+          if (To(c) <= tm) t_def = std::min(t_def, tm + 1);
+        }
+      }
+    if (is_const(n)) {
+      std::array<uint32_t, 8> key;
+      memcpy(key.data(), in.constants[g.a].v, 32);
+      uint32_t& slot = const_node[key];
+      if (slot == NONE) slot = emit(h, 0, store_in[n]);
+      remap[n] = slot;
+      if (store_in[n] != NONE && st[slot] == NONE) st[slot] = store_in[n];
+      continue;
+    }
+    bool done = false;
+    if (linear(n) && !private_node(n) && CP - (D[n] + TL[n]) <= near) {
+      // ---- candidate forms: looked through 0, 1, .. max_cross shared linear nodes
+      uint32_t best_t = t_def;
+      std::vector<Piece> best;
+      Fr best_c = Fr::zero();
+      for (int cross = 0; cross <= max_cross; cross++) {
+        Form f;
+        ex.run(n, Fr::one(), cross, true, f);
+        if (!f.ok || f.t.empty()) continue;
+        // variant 0: the late-factor form only for the piece that arrives last; variant 1: wherever it is earlier
+        for (int variant = 0; variant < 2; variant++) {
+          std::vector<Piece> ps;
+          Fr c = f.c;
+          uint32_t last_ready = 0;
+          if (variant == 0)
+            for (const Term& tr : f.t)
+              if (!tr.coef.is_zero()) last_ready = std::max(last_ready, To(tr.atom) + (tr.coef == Fr::one() ? 0u : 1u));
+          for (const Term& tr : f.t) {
+            if (tr.coef.is_zero()) continue;
+            Piece p{0, NONE, tr.atom, tr.coef, NONE, NONE};
+            if (tr.coef == Fr::one()) {
+              p.ready = To(tr.atom);
+            } else {
+              // the late-factor form: atom = A * B, or (A * B) + const with the product private, A later than B
+              uint32_t P = NONE;
+              Fr pc = Fr::zero();
+              if (variant == 1 || To(tr.atom) + 1 == last_ready) {
+                if (G[tr.atom].op == G_MUL && !is_const(G[tr.atom].a) && !is_const(G[tr.atom].b)) {
+                  P = tr.atom;
+                } else if (G[tr.atom].op == G_ADD && is_const(G[tr.atom].a) != is_const(G[tr.atom].b)) {
+                  const uint32_t cn = is_const(G[tr.atom].a) ? G[tr.atom].a : G[tr.atom].b;
+                  const uint32_t pn = cn == G[tr.atom].a ? G[tr.atom].b : G[tr.atom].a;
+                  if (G[pn].op == G_MUL && !is_const(G[pn].a) && !is_const(G[pn].b) && private_node(pn)) {
+                    P = pn;
+                    pc = in.constants[G[cn].a];
+                  }
+                }
+              }
+              if (P != NONE && To(G[P].a) != To(G[P].b)) {
+                p.late = To(G[P].a) > To(G[P].b) ? G[P].a : G[P].b;
+                p.early = p.late == G[P].a ? G[P].b : G[P].a;
+                p.tm = std::max(To(p.late), To(p.early) + 1);
+                if (p.tm + 1 < To(tr.atom) + 2) {   // better than K * atom
+                  c = c + tr.coef * pc;
+                } else {
+                  p.late = p.early = NONE;
+                }
+              }
+              if (p.late == NONE) p.tm = To(tr.atom);
+              p.ready = p.tm + 1;
+            }
+            ps.push_back(p);
+          }
+          if (ps.empty()) continue;
+          std::stable_sort(ps.begin(), ps.end(), [](const Piece& x, const Piece& y) { return x.ready < y.ready; });
+          // the fused chain: constant first, then the pieces as they arrive
+          uint32_t acc = 0;
+          bool have = !c.is_zero();
+          for (size_t k = 0; k < ps.size(); k++) {
+            const Piece& p = ps[k];
+            if (have && ps.size() >= 3 && k + 2 == ps.size() && (k >= 2 || (k >= 1 && !c.is_zero()))) acc++;
+            if (!have) {
+              acc = p.ready;
+              have = true;
+            } else if (p.tm != NONE) {
+              acc = std::max(acc, p.tm) + 1;
+            } else {
+              acc = std::max(acc, p.ready) + 1;
+            }
+          }
+          if (acc < best_t) {
+            best_t = acc;
+            best = ps;
+            best_c = c;
+          }
+        }
+      }
+      if (!best.empty()) {
+        // the chain as explicit a * b + c nodes, in arrival order.  A row-form product leaves its result below 2.05 r +
+        // its addend, and what the last product adds to must stay below ~5 r for the sum to stay inside the interpreter's
+        // 7.5 r: a chain of three or more pieces is reduced once (x * ONE) before its last two -- a step off the
+        // critical path instead of a reduction behind it
+        uint32_t acc = NONE, acc_t = 0;
+        if (!best_c.is_zero()) acc = const_of(best_c);
+        for (size_t k = 0; k < best.size(); k++) {
+          const Piece& p = best[k];
+          if (acc != NONE && best.size() >= 3 && k + 2 == best.size() && (k >= 2 || (k >= 1 && !best_c.is_zero()))) {
+            acc_t++;
+            acc = emit(GNode{G_MUL, acc, const_of(Fr::one()), 0}, acc_t, NONE);
+          }
+          if (p.tm == NONE) {
+            const uint32_t node = remap[p.atom];
+            if (acc == NONE) {
+              acc = node;
+              acc_t = p.ready;
+            } else {
+              acc_t = std::max(acc_t, p.ready) + 1;
+              acc = emit(GNode{G_ADD, acc, node, 0}, acc_t, NONE);
+            }
+            continue;
+          }
+          uint32_t fa, fb;
+          if (p.late != NONE) {
+            fa = remap[p.late];
+            fb = emit(GNode{G_MUL, const_of(p.coef), remap[p.early], 0}, To(p.early) + 1, NONE);
+          } else {
+            fa = const_of(p.coef);
+            fb = remap[p.atom];
+          }
+          if (acc == NONE) {
+            acc_t = p.ready;
+            acc = emit(GNode{G_MUL, fa, fb, 0}, acc_t, NONE);
+          } else {
+            acc_t = std::max(acc_t, p.tm) + 1;
+            acc = emit(GNode{G_FMA, fa, fb, acc}, acc_t, NONE);
+          }
+        }
+        if (H.nodes[acc].op != G_ADD && H.nodes[acc].op != G_MUL && H.nodes[acc].op != G_FMA)   // a single plain term
+          acc = emit(GNode{G_ADD, acc, const_of(Fr::zero()), 0}, acc_t + 1, NONE);
+        st[acc] = store_in[n];
+        remap[n] = acc;
+        done = true;
+        rewritten++;
+      }
+    }
+    if (!done) remap[n] = emit(h, t_def, store_in[n]);
+  }
+  (void)rewritten;
+  // drop what lost its last reader, keep signals, stored values and inputs
+  const uint32_t M = (uint32_t)H.nodes.size();
+  std::vector<uint8_t> keep(M, 0);
+  for (uint32_t sg : in.signals) keep[remap[sg]] = 1;
+  for (uint32_t m = 0; m < M; m++)
+    if (st[m] != NONE || H.nodes[m].op == G_INPUT) keep[m] = 1;
+  for (uint32_t m = M; m-- > 0;) {
+    if (!keep[m]) continue;
+    const uint32_t o[3] = {H.nodes[m].a, H.nodes[m].b, H.nodes[m].c};
+    for (int k = 0; k < nops(H.nodes[m]); k++) keep[o[k]] = 1;
+  }
+  *out = Graph();
+  out->constants = H.constants;
+  out->input_mapping = in.input_mapping;
+  out->tree_depth = in.tree_depth;
+  out->max_out = in.max_out;
+  out->inputs_size = in.inputs_size;
+  // constants may have been emitted behind their first reader (const_of inside a form): readers first is not a graph, so
+  // the surviving constants go to the front
+  std::vector<uint32_t> pos(M, NONE);
+  store_out->clear();
+  for (int pass = 0; pass < 2; pass++)
+    for (uint32_t m = 0; m < M; m++) {
+      if (!keep[m] || (H.nodes[m].op == G_CONST) != (pass == 0)) continue;
+      GNode h = H.nodes[m];
+      uint32_t* o[3] = {&h.a, &h.b, &h.c};
+      for (int k = 0; k < nops(H.nodes[m]); k++) *o[k] = pos[*o[k]];
+      pos[m] = (uint32_t)out->nodes.size();
+      out->nodes.push_back(h);
+      store_out->push_back(st[m]);
+    }
+  out->signals.reserve(in.signals.size());
+  for (uint32_t sg : in.signals) out->signals.push_back(pos[remap[sg]]);
+}
+
 static WlProgram wl_schedule_graph(const Graph& graph, const std::vector<uint32_t>& store_slot, uint32_t trash_slot,
                                    bool rows);
 
 WlProgram wl_schedule(const Graph& graph, const std::vector<uint32_t>& store_slot, uint32_t trash_slot, bool rows) {
-  if (!env_int_wl("RLNAMD_WL_REASSOC", 1)) return wl_schedule_graph(graph, store_slot, trash_slot, rows);
-  Graph g2;
-  std::vector<uint32_t> st2;
-  reassociate_sums(graph, store_slot, &g2, &st2);
-  return wl_schedule_graph(g2, st2, trash_slot, rows);
+  if (!env_int_wl("RLNAMD_WL_REASSOC", 1)) {
+    WlProgram P = wl_schedule_graph(graph, store_slot, trash_slot, rows);
+    P.consts = graph.constants;
+    return P;
+  }
+  Graph g1, g2;
+  std::vector<uint32_t> st1, st2;
+  const Graph* src = &graph;
+  const std::vector<uint32_t>* st = &store_slot;
+  if (env_int_wl("RLNAMD_WL_HOIST", 1)) {
+    hoist_linear_forms(graph, store_slot, &g1, &st1);
+    src = &g1;
+    st = &st1;
+  }
+  reassociate_sums(*src, *st, &g2, &st2);
+  WlProgram P = wl_schedule_graph(g2, st2, trash_slot, rows);
+  P.consts = g2.constants;
+  return P;
 }
 
 static WlProgram wl_schedule_graph(const Graph& graph, const std::vector<uint32_t>& store_slot, uint32_t trash_slot,
@@ -189,7 +532,7 @@ static WlProgram wl_schedule_graph(const Graph& graph, const std::vector<uint32_
   const uint32_t FIX = (1u << 30) + N;    // value ids >= FIX address a fixed LDS slot (ZERO / ONE / MINUS_ONE)
   if (first_free + 64 >= DUMMY) return R;   // the constants alone (nearly) fill the LDS
   auto nops = [&](const GNode& g) {
-    return (g.op == G_INPUT || g.op == G_CONST) ? 0 : (g.op == G_NEG || g.op == G_ID) ? 1 : g.op == G_TERN ? 3 : 2;
+    return (g.op == G_INPUT || g.op == G_CONST) ? 0 : (g.op == G_NEG || g.op == G_ID) ? 1 : (g.op == G_TERN || g.op == G_FMA) ? 3 : 2;
   };
   std::vector<uint8_t> is_signal(N, 0);
   for (uint32_t sg : graph.signals) is_signal[sg] = 1;
@@ -226,7 +569,7 @@ static WlProgram wl_schedule_graph(const Graph& graph, const std::vector<uint32_
     }
   auto is_rare = [&](uint32_t n) {
     const uint32_t op = G[n].op;
-    return !(op == G_MUL || op == G_ADD || op == G_SUB || op == G_NEG);
+    return !(op == G_MUL || op == G_ADD || op == G_SUB || op == G_NEG || op == G_FMA);
   };
   struct Pending { uint32_t node, raw; };   // a raw value that still needs x * ONE + ZERO to become `node`
   std::vector<Pending> pending;
@@ -254,7 +597,7 @@ static WlProgram wl_schedule_graph(const Graph& graph, const std::vector<uint32_
     bool any_rare = false, any_mul = false;
     for (uint32_t n : ready) {
       any_rare |= is_rare(n);
-      any_mul |= G[n].op == G_MUL || G[n].op == G_SUB || G[n].op == G_NEG;
+      any_mul |= G[n].op == G_MUL || G[n].op == G_SUB || G[n].op == G_NEG || G[n].op == G_FMA;
     }
     if (any_rare) {
       kind = WK_MISC;
@@ -320,6 +663,10 @@ static WlProgram wl_schedule_graph(const Graph& graph, const std::vector<uint32_
           const uint32_t x = bound[g.a] >= bound[g.b] ? g.a : g.b, y = x == g.a ? g.b : g.a;
           m.src[0] = x; m.src[1] = FIX + ONE; m.src[2] = y;
           b = PB0 + 0.006 * bound[x] + bound[y];
+        } else if (g.op == G_FMA) {   // a * b + c as the graph pass left it
+          m.gop = G_MUL;
+          m.src[0] = g.a; m.src[1] = g.b; m.src[2] = g.c;
+          b = PB0 + 0.006 * bound[g.a] * bound[g.b] + bound[g.c];
         } else if (g.op == G_SUB) {   // a - b = b * (-1) + a
           m.src[0] = g.b; m.src[1] = FIX + MONE; m.src[2] = g.a;
           b = PB0 + 0.006 * bound[g.b] * 1.05 + bound[g.a];
@@ -368,6 +715,20 @@ static WlProgram wl_schedule_graph(const Graph& graph, const std::vector<uint32_
   }
   for (uint32_t n = 0; n < N; n++)
     if (!done[n]) throw std::runtime_error("witness lanes: graph node left unscheduled");
+  if (getenv("RLNAMD_WL_DEBUG")) {
+    size_t nops_total = 0, nadd1 = 0, nred = 0, nprod = 0, nfused = 0;
+    for (const auto& st_ : steps)
+      for (const MicroOp& m : st_) {
+        nops_total++;
+        if (m.lop != WO_COMPUTE) continue;
+        if (m.src[1] == FIX + ONE && m.src[2] == FIX + Z) nred++;
+        else if (m.src[1] == FIX + ONE || m.src[1] == FIX + MONE) nadd1++;
+        else if (m.src[2] != FIX + Z && m.src[2] != NONE) nfused++;
+        else nprod++;
+      }
+    fprintf(stderr, "wl debug: steps %zu micro-ops %zu: products %zu fused a*b+c %zu adds-as-products %zu reductions %zu\n",
+            steps.size(), nops_total, nprod, nfused, nadd1, nred);
+  }
   // ---- LDS slots from the liveness of the schedule
   const uint32_t nvals = next_tmp;
   const uint32_t FIXB = FIX;

@@ -30,6 +30,7 @@ struct WlProgram {
   bool ok = false;            // false: the graph does not fit this form (too many constants / live values)
   uint32_t nsteps = 0, nrow = 0, nfma = 0, nsqr = 0, nadd = 0, nmisc = 0, peak_slots = 0, n_consts = 0;
   std::vector<WlDesc> img;    // [nsteps + 2 WL_PF][WL_W]
+  std::vector<Fr> consts;     // the program's constants (LDS slots 0 .. n_consts - 1): the graph's, then the folded ones
 };
 // store_slot[n]: index of node n in the compact array of stored values, or 0xFFFFFFFF; trash_slot: a row nobody reads;
 // rows: products in row form (WK_ROW, at most WL_ROWS per step) instead of lane form (WK_FMA / WK_SQR)
