@@ -99,7 +99,9 @@ __device__ __noinline__ WlOut wl_misc(uint32_t dx, uint32_t dy, uint32_t dz, con
 // 2^261; its quotient K (the carry into column 9) is read off the top three low columns:  W = S_8 + (S_7 >> 29) +
 // (S_6 >> 58) misses less than 3 units of the exact 2^29 K, so K = (W + 16) >> 29.
 // Limbs: inputs "near-normalised" (< 2^29 + 4 below the top limb), columns < 9 (2^29.01)^2 + 9 2^29 2^30.1 < 2^63.3.
-// Values: m < 2^262 (lazy top limb), so the result is below a b / 2^261 + 2 r + c  -- the host's bounds use 2.4 r.
+// Values: m is taken mod 2^261 (top limb masked; the limbs below stay near-normalised: m < 2^261 (1 + 2^-27)), so the
+// result is below a b / 2^261 + 1.0001 r + c  -- the host's bounds use 1.06 r.  (Until round 5 the top limb stayed lazy:
+// m < 2^262, 2.05 r, and every third partial round of Poseidon paid a reduction step for it.)
 template <int CTRL>
 __device__ __forceinline__ uint32_t dppz(uint32_t v) {   // the neighbour's value; 0 where the source lane is outside the row
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
@@ -158,7 +160,7 @@ __device__ __forceinline__ uint32_t wl_row_mul_add16(const uint32_t (&a)[9], uin
   u += (uint64_t)PI[8] * dppz<WL_SHR(8)>(n);
   u += u1;
   uint32_t m = wl_carry3(u);
-  m = j < 9 ? m : 0;
+  m = j < 8 ? m : (j == 8 ? (m & M) : 0);   // mod 2^261: the top limb's lazy bits are multiples of 2^261 (m < 2^261 (1 + 2^-27))
   uint64_t U, U16;
   WL_MACS16(U, U16, PP, m)
   const uint64_t s = t + U;                               // column j

@@ -6,8 +6,8 @@
 //   MISC  inputs (canonical -> Montgomery) and the rare operations (comparisons, shifts, bit operations, division,
 //         TernCond ...: graph.rs:72-143, 314-466).
 // Bounds: values are kept below WL_BMAX r (fq29.h: products take operands up to 10 r, K8 - x up to 7.9 r).  A product
-// reduces its multiplicands (result < PB0 r + a b / 2^261 + c; PB0 = 1 in lane form, 2.05 in row form where m is only
-// reduced mod 2^261 limb-wise), so an Add riding in a product step takes the operand with the larger bound as
+// reduces its multiplicands (result < PB0 r + a b / 2^261 + c; PB0 = 1 in lane form, 1.06 in row form where m's limbs
+// below the top one are only near-normalised), so an Add riding in a product step takes the operand with the larger bound as
 // multiplicand; when a result would still pass WL_BMAX it is followed by a reduction x * ONE + ZERO.
 #include "witness_sched.h"
 
@@ -186,8 +186,8 @@ static void reassociate_sums(const Graph& in, const std::vector<uint32_t>& store
 // at most two shared ones -- into sum coef_k atom_k + const over nonlinear atoms; the form is taken when the arrival
 // estimate of its fused chain beats the node's own.  Every value the graph outputs keeps its definition or an
 // algebraically equal one (field arithmetic is exact: bit-identical witness), what loses its last reader is dropped.
-// Shipped depth-20 circuit: multiplication depth 5 736 -> ~4 300; 6 122 -> 5 267 row-form steps (the row form has four
-// product slots per step, and the round now fills them), single proof 2.59 -> 2.29 ms.  RLNAMD_WL_HOIST=0 keeps the graph as it came.
+// Shipped depth-20 circuit: multiplication depth 5 736 -> ~4 300; 6 122 -> 4 813 row-form steps (the row form has four
+// product slots per step: 18 600 micro-ops are 4 650 steps at the least).  RLNAMD_WL_HOIST=0 keeps the graph as it came.
 static void hoist_linear_forms(const Graph& in, const std::vector<uint32_t>& store_in, Graph* out,
                                std::vector<uint32_t>* store_out) {
   const std::vector<GNode>& G = in.nodes;
@@ -218,6 +218,9 @@ static void hoist_linear_forms(const Graph& in, const std::vector<uint32_t>& sto
   const uint32_t near = (uint32_t)env_int_wl("RLNAMD_WL_NEAR", 0);
   const size_t max_terms = (size_t)env_int_wl("RLNAMD_WL_TERMS", 6);
   const int max_cross = env_int_wl("RLNAMD_WL_CROSS", 2);
+  // a chain's partial sum grows by ~1.06 r per fused product (row form): reduced (x * ONE) after this many pieces, so that
+  // what the last products add to stays inside the interpreter's value range (WL_BMAX) without a reduction BEHIND them
+  const size_t reduce_every = (size_t)env_int_wl("RLNAMD_WL_REDUCE_EVERY", 5);
   std::vector<uint8_t> is_signal(N, 0);
   for (uint32_t sg : in.signals) is_signal[sg] = 1;
   auto private_node = [&](uint32_t n) { return uses[n] == 1 && !is_signal[n] && store_in[n] == NONE; };
@@ -302,7 +305,7 @@ static void hoist_linear_forms(const Graph& in, const std::vector<uint32_t>& sto
     Fr coef;
     uint32_t late, early;   // late-factor form (NONE: plain K * atom)
   };
-  size_t rewritten = 0;
+  size_t rewritten = 0, by_cross[8] = {0};
   for (uint32_t n = 0; n < N; n++) {
     const GNode& g = G[n];
     // ---- the node as it stands
@@ -337,6 +340,7 @@ static void hoist_linear_forms(const Graph& in, const std::vector<uint32_t>& sto
       uint32_t best_t = t_def;
       std::vector<Piece> best;
       Fr best_c = Fr::zero();
+      int best_cross = -1;
       for (int cross = 0; cross <= max_cross; cross++) {
         Form f;
         ex.run(n, Fr::one(), cross, true, f);
@@ -392,7 +396,7 @@ static void hoist_linear_forms(const Graph& in, const std::vector<uint32_t>& sto
           bool have = !c.is_zero();
           for (size_t k = 0; k < ps.size(); k++) {
             const Piece& p = ps[k];
-            if (have && ps.size() >= 3 && k + 2 == ps.size() && (k >= 2 || (k >= 1 && !c.is_zero()))) acc++;
+            if (have && reduce_every && k && k % reduce_every == 0 && k + 1 < ps.size()) acc++;
             if (!have) {
               acc = p.ready;
               have = true;
@@ -406,19 +410,17 @@ static void hoist_linear_forms(const Graph& in, const std::vector<uint32_t>& sto
             best_t = acc;
             best = ps;
             best_c = c;
+            best_cross = cross * 2 + variant;
           }
         }
       }
       if (!best.empty()) {
-        // the chain as explicit a * b + c nodes, in arrival order.  A row-form product leaves its result below 2.05 r +
-        // its addend, and what the last product adds to must stay below ~5 r for the sum to stay inside the interpreter's
-        // 7.5 r: a chain of three or more pieces is reduced once (x * ONE) before its last two -- a step off the
-        // critical path instead of a reduction behind it
+        // the chain as explicit a * b + c nodes, in arrival order
         uint32_t acc = NONE, acc_t = 0;
         if (!best_c.is_zero()) acc = const_of(best_c);
         for (size_t k = 0; k < best.size(); k++) {
           const Piece& p = best[k];
-          if (acc != NONE && best.size() >= 3 && k + 2 == best.size() && (k >= 2 || (k >= 1 && !best_c.is_zero()))) {
+          if (acc != NONE && reduce_every && k && k % reduce_every == 0 && k + 1 < best.size()) {
             acc_t++;
             acc = emit(GNode{G_MUL, acc, const_of(Fr::one()), 0}, acc_t, NONE);
           }
@@ -455,11 +457,14 @@ static void hoist_linear_forms(const Graph& in, const std::vector<uint32_t>& sto
         remap[n] = acc;
         done = true;
         rewritten++;
+        if (best_cross >= 0 && best_cross < 8) by_cross[best_cross]++;
       }
     }
     if (!done) remap[n] = emit(h, t_def, store_in[n]);
   }
-  (void)rewritten;
+  if (getenv("RLNAMD_WL_DEBUG"))
+    fprintf(stderr, "wl debug: %zu linear forms rewritten (shared nodes looked through x 2 + variant: %zu %zu %zu %zu %zu %zu)\n", rewritten,
+            by_cross[0], by_cross[1], by_cross[2], by_cross[3], by_cross[4], by_cross[5]);
   // drop what lost its last reader, keep signals, stored values and inputs
   const uint32_t M = (uint32_t)H.nodes.size();
   std::vector<uint8_t> keep(M, 0);
@@ -578,7 +583,7 @@ static WlProgram wl_schedule_graph(const Graph& graph, const std::vector<uint32_
   auto bnd = [&](uint32_t v) { return v < N ? bound[v] : tmp_bound[v - N]; };
   nfma = nadd = nmisc = nsqr = nrow = 0;
   // row form (one product per 16-lane row, wl_row_mul_add): at most WL_ROWS products per step, result < 2.05 r + ...
-  const double PB0 = rows ? 2.05 : 1.0;
+  const double PB0 = rows ? 1.06 : 1.0;
   const size_t fma_cap = rows ? WL_ROWS : WL_W;
   // height = longest chain of nodes from a node to a sink: when a step cannot take every ready node, the ones the
   // longest chains hang on go first
