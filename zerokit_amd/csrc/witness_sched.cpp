@@ -731,8 +731,8 @@ static WlProgram wl_schedule_graph(const Graph& graph, const std::vector<uint32_
         else if (m.src[2] != FIX + Z && m.src[2] != NONE) nfused++;
         else nprod++;
       }
-    fprintf(stderr, "wl debug: steps %zu micro-ops %zu: products %zu fused a*b+c %zu adds-as-products %zu reductions %zu\n",
-            steps.size(), nops_total, nprod, nfused, nadd1, nred);
+    fprintf(stderr, "wl debug: steps %zu micro-ops %zu: products %zu fused a*b+c %zu adds-as-products %zu reductions %zu; constants %u\n",
+            steps.size(), nops_total, nprod, nfused, nadd1, nred, n_consts);
   }
   // ---- LDS slots from the liveness of the schedule
   const uint32_t nvals = next_tmp;
