@@ -93,6 +93,31 @@ int main(int argc, char** argv) {
       if (!p.ok || p.nsteps == 0) { fprintf(stderr, "no schedule\n"); failures++; }
     }
   }
+  // 3b. graphs the scheduler's rewriting passes were not written for: a chain of 40 000 Adds over ONE value (a linear form
+  //     of one term however deep it is looked into), a chain of constant products, a sum of a node with itself -- a
+  //     schedule, a refusal (ok = false) or an Error, nothing else
+  for (int shape = 0; shape < 3; shape++) {
+    Graph h;
+    h.constants.push_back(Fr::one() + Fr::one());
+    h.inputs_size = 2;
+    h.nodes.push_back(GNode{G_INPUT, 1, 0, 0});
+    h.nodes.push_back(GNode{G_CONST, 0, 0, 0});
+    h.nodes.push_back(GNode{G_MUL, 0, 0, 0});                        // x * x: a product below the chains
+    uint32_t last = 2;
+    const uint32_t len = shape == 0 ? 40000u : 3000u;
+    for (uint32_t k = 0; k < len; k++) {
+      if (shape == 0) h.nodes.push_back(GNode{G_ADD, last, 2, 0});
+      else if (shape == 1) h.nodes.push_back(GNode{G_MUL, 1, last, 0});
+      else h.nodes.push_back(GNode{G_ADD, last, last, 0});
+      last = (uint32_t)h.nodes.size() - 1;
+    }
+    h.nodes.push_back(GNode{G_MUL, last, last, 0});
+    h.signals = {0, (uint32_t)h.nodes.size() - 1};
+    std::vector<uint32_t> st(h.nodes.size(), 0xFFFFFFFFu);
+    st[0] = 0;
+    st[h.nodes.size() - 1] = 1;
+    try { (void)wl_schedule(h, st, 2, true); parsed++; } catch (const std::exception&) { threw++; }
+  }
   // 4. config_path JSON: well-formed, malformed, hostile
   const char* cfgs[] = {"{}", "{\"temporary\": true}", "{\"devices\": [0, 1, 2]}", "{\"devices\": [0, ]}", "{\"devices\": [",
                         "{\"path\": \"/tmp/x\\\"y\", \"temporary\": false}", "{\"a\": [[[[{\"b\": \"]\"}]]]], \"max_batch\": 64}",

@@ -270,8 +270,12 @@ static void hoist_linear_forms(const Graph& in, const std::vector<uint32_t>& sto
     decltype(linear)& lin;
     decltype(private_node)& priv;
     size_t max_terms;
-    void run(uint32_t n, const Fr& coef, int cross, bool top, Form& f) {
+    void run(uint32_t n, const Fr& coef, int cross, bool top, Form& f, int depth = 0) {
       if (!f.ok) return;
+      if (depth > 48) {   // (a chain of thousands of private Adds over one atom merges into one term: bound the recursion)
+        f.ok = false;
+        return;
+      }
       const GNode& g = G[n];
       if (g.op == G_CONST) {
         f.c = f.c + coef * in.constants[g.a];
@@ -280,11 +284,11 @@ static void hoist_linear_forms(const Graph& in, const std::vector<uint32_t>& sto
       if (lin(n) && (top || priv(n) || cross > 0)) {
         const int cx = (top || priv(n)) ? cross : cross - 1;
         if (g.op == G_ADD) {
-          run(g.a, coef, cx, false, f);
-          run(g.b, coef, cx, false, f);
+          run(g.a, coef, cx, false, f, depth + 1);
+          run(g.b, coef, cx, false, f, depth + 1);
         } else {
           const bool ka = G[g.a].op == G_CONST;
-          run(ka ? g.b : g.a, coef * in.constants[G[ka ? g.a : g.b].a], cx, false, f);
+          run(ka ? g.b : g.a, coef * in.constants[G[ka ? g.a : g.b].a], cx, false, f, depth + 1);
         }
         return;
       }
