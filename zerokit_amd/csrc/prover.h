@@ -68,7 +68,7 @@ struct ProverTuning {
   static ProverTuning from_env();
   std::string describe() const;
 };
-// (the lanes = nodes interpreter reads RLNAMD_WITLANES / RLNAMD_WITROWS / RLNAMD_WL_REASSOC when its program is built:
+// (the lanes = nodes interpreter reads RLNAMD_WITLANES / RLNAMD_WITROWS / RLNAMD_WL_REASSOC / RLNAMD_WL_HOIST when its program is built:
 // witness_lanes.hip, witness_sched.cpp)
 
 struct ProofOut {            // one proof, host side
