@@ -53,7 +53,9 @@ struct ProverTuning {
   int slots = 5;                       // RLNAMD_SLOTS: workspace slots = batches in flight (2 .. 6)
   uint32_t lanechunk_max = 128;        // RLNAMD_LANECHUNK: largest batch that takes the small-batch (latency) shapes
   uint32_t lanechunk_walk_max = 48;    // RLNAMD_LANECHUNK_WALK: largest lone batch walked with lanes = chunks
-  uint32_t witlanes_max = 256;         // RLNAMD_WITLANES_MAX: largest lone batch interpreted with lanes = nodes
+  uint32_t witlanes_max = 1024;        // RLNAMD_WITLANES_MAX: largest lone batch interpreted with lanes = nodes (a wave and a CU's
+                                       // LDS per proof: ceil(n / 256) x 1.5 ms against 11 ms for lanes = proofs; lone 512 / 1 024-proof
+                                       // batches 46.9 -> 38.0 / 74.0 -> 68.5 ms, the first batch of a stream 5 ms earlier)
   uint32_t tiny_max = 5;               // RLNAMD_TINY: largest lone batch walked with ONE (row, half) per lane (0: never); 5 proofs 3.15 -> 3.0 ms, 6 even, 8 slower
   // ---- shapes (1 = default)
   bool glv = true;                     // RLNAMD_GLV: walk the 127-bit GLV halves (0: the plain 255-bit walk)

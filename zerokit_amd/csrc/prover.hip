@@ -79,7 +79,7 @@ struct Prover::Impl {
   DevBuf<unsigned long long> walk_clk;  // clock tap of the two walks: G1 cycles, G1 ticks, G2 cycles, G2 ticks
   ProverTuning tune;             // every switch, read once (prover.h)
   bool wit29 = true;             // = tune.wit29
-  uint32_t lanechunk_max = 128, lanechunk_walk_max = 48, witlanes_max = 256;   // = tune.*
+  uint32_t lanechunk_max = 128, lanechunk_walk_max = 48, witlanes_max = 1024;   // = tune.*
   DevBuf<GNode29> nodes29;
   DevBuf<uint32_t> consts29, slot2node;
   WitLanes witlanes;             // lanes = independent nodes: the interpreter of batches walked with lanes = chunks
@@ -1361,7 +1361,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     if (marks) RLN_HIP(hipEventRecord(S.t[i], stream));   \
   } while (0)
   // The lanes = nodes interpreter (a wave and 157 KB of LDS per proof, ~25 x the instructions per proof of k_witness29,
-  // 2.0 ms against 11 ms): always below the small-batch threshold; up to witlanes_max only for a LONE batch -- in a stream
+  // 1.5 ms per 256 proofs against 11 ms): always below the small-batch threshold; up to witlanes_max only for a LONE batch -- in a stream
   // of such batches it costs throughput (profiles/r3_rocprof_summary.md, section 10), and there the previous batch is still in flight.
   const bool wl_used = D.wit29 && D.witlanes.ok && (nb <= D.lanechunk_max || (nb <= D.witlanes_max && lone));
   MARK(1, sA);
