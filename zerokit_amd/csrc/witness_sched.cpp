@@ -221,6 +221,8 @@ static void hoist_linear_forms(const Graph& in, const std::vector<uint32_t>& sto
   // a chain's partial sum grows by ~1.06 r per fused product (row form): reduced (x * ONE) after this many pieces, so that
   // what the last products add to stays inside the interpreter's value range (WL_BMAX) without a reduction BEHIND them
   const size_t reduce_every = (size_t)env_int_wl("RLNAMD_WL_REDUCE_EVERY", 5);
+  // (a full round's outputs have three late-factor pieces each: one per form was tried -- 4 881 steps against 4 813)
+  const size_t max_late = (size_t)env_int_wl("RLNAMD_WL_MAX_LATE", 3);
   std::vector<uint8_t> is_signal(N, 0);
   for (uint32_t sg : in.signals) is_signal[sg] = 1;
   auto private_node = [&](uint32_t n) { return uses[n] == 1 && !is_signal[n] && store_in[n] == NONE; };
@@ -410,6 +412,9 @@ static void hoist_linear_forms(const Graph& in, const std::vector<uint32_t>& sto
               acc = std::max(acc, p.ready) + 1;
             }
           }
+          size_t n_late = 0;
+          for (const Piece& p : ps) n_late += p.late != NONE;
+          if (n_late > max_late) continue;
           if (acc < best_t) {
             best_t = acc;
             best = ps;
