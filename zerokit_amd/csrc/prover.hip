@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <deque>
 
@@ -67,6 +68,27 @@ struct Slot {
   uint32_t dB = 0, PB = 0, nch1 = 0, nch2 = 0;
 };
 
+// Provers alive per device, in this process.  `lone` (nothing of THIS prover in flight) lets a batch trade instructions for
+// latency; the wide form of that trade -- a wave and a CU's LDS per proof for up to 1 024 proofs -- is only taken when no
+// other prover shares the device: two provers proving alternating 1 024-proof batches each saw the other's batch as
+// "lone" and lost a quarter of their common rate to it (14.6 k -> 10.7 k proofs/s, measured).
+static std::atomic<int> g_provers_on_device[64];
+
+struct DeviceCount {   // (a member of Impl: a constructor that throws half-way still gives its count back)
+  int dev = -1;
+  void take() {
+    int d = 0;
+    if (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) {
+      dev = d;
+      g_provers_on_device[d]++;
+    }
+  }
+  bool shared() const { return dev >= 0 && g_provers_on_device[dev] > 1; }
+  ~DeviceCount() {
+    if (dev >= 0) g_provers_on_device[dev]--;
+  }
+};
+
 struct Prover::Impl {
   hipStream_t sA = nullptr, sAb = nullptr, sA2 = nullptr, sB = nullptr, sB2 = nullptr, sC = nullptr;
   // EIGHT streams in all: ROCclr maps streams onto GPU_MAX_HW_QUEUES (8, set by common.cpp) hardware queues and two streams
@@ -80,6 +102,7 @@ struct Prover::Impl {
   ProverTuning tune;             // every switch, read once (prover.h)
   bool wit29 = true;             // = tune.wit29
   uint32_t lanechunk_max = 128, lanechunk_walk_max = 48, witlanes_max = 1024;   // = tune.*
+  DeviceCount device;            // counted in g_provers_on_device while the object lives
   DevBuf<GNode29> nodes29;
   DevBuf<uint32_t> consts29, slot2node;
   WitLanes witlanes;             // lanes = independent nodes: the interpreter of batches walked with lanes = chunks
@@ -347,6 +370,7 @@ static WinSched make_sched(int c, int wide, int total) {
 Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_t graph_len, ProverConfig cfg)
     : d_(new Impl) {
   require_gpu();
+  d_->device.take();
   const auto t_ctor = std::chrono::steady_clock::now();
   for (float& v : g_init_ms) v = 0;
   zk_ = parse_arkzkey(zkey, zkey_len);
@@ -1363,7 +1387,8 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // The lanes = nodes interpreter (a wave and 157 KB of LDS per proof, ~25 x the instructions per proof of k_witness29,
   // 1.5 ms per 256 proofs against 11 ms): always below the small-batch threshold; up to witlanes_max only for a LONE batch -- in a stream
   // of such batches it costs throughput (profiles/r3_rocprof_summary.md, section 10), and there the previous batch is still in flight.
-  const bool wl_used = D.wit29 && D.witlanes.ok && (nb <= D.lanechunk_max || (nb <= D.witlanes_max && lone));
+  const uint32_t wl_lone_max = D.device.shared() ? std::min(D.witlanes_max, 256u) : D.witlanes_max;
+  const bool wl_used = D.wit29 && D.witlanes.ok && (nb <= D.lanechunk_max || (nb <= wl_lone_max && lone));
   MARK(1, sA);
   if (D.wit29) {
     if (wl_used) {

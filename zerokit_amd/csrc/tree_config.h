@@ -35,7 +35,7 @@ struct TreeConfig {
   // a single proof is as fast as with 64, a batch call streams at 15 k instead of 11 k proofs/s).
   long window_bits = 0, max_batch = 0;
   // "profile": a name for the two numbers above, so that a caller need not know the schedule's encoding --
-  //   "latency"     the defaults (20 GiB of tables, 256 proofs of workspace): one proof 2.6 ms, batch calls 15 k proofs/s
+  //   "latency"     the defaults (20 GiB of tables, 256 proofs of workspace): one proof 2.2 ms, batch calls 15 k proofs/s
   //   "throughput"  the bench's operating point (window_bits 7150114: 228 GiB; max_batch 1024): batch calls 21 k proofs/s,
   //                 5 - 7 s to build, nothing else of that size fits the device
   //   "small"       window_bits 8, max_batch 64: 7.7 GiB, one proof 2.7 ms, batch calls 9 k proofs/s
