@@ -76,6 +76,9 @@ static std::atomic<int> g_provers_on_device[64];
 
 struct DeviceCount {   // (a member of Impl: a constructor that throws half-way still gives its count back)
   int dev = -1;
+  DeviceCount() = default;
+  DeviceCount(const DeviceCount&) = delete;
+  DeviceCount& operator=(const DeviceCount&) = delete;
   void take() {
     int d = 0;
     if (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) {
