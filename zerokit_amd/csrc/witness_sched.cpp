@@ -179,7 +179,7 @@ static void reassociate_sums(const Graph& in, const std::vector<uint32_t>& store
 //     x' = (K00 + K01 K1 + K02 K2) y + (K01 K1' + K02 K2') y_prev + K01 s1_prev + K02 s2_prev
 // (two rounds of the s_i recurrence unrolled, like terms merged into one folded constant each), and the one late term
 // takes its constant on the early factor: kappa (x^4 x + c) = x^4 (kappa x) + kappa c -- kappa x is there one step after x,
-// beside x^2.  Three dependent products per round, the same number of products per round (the s_i updates keep their
+// beside x^2.  Three dependent products per round for two more micro-ops per round (the s_i updates keep their
 // definition; x' trades three products and two additions for five fused a * b + c).  Generic over the graph: a
 // materialised linear node (an Add / a product with one constant factor that is read more than once, stored, or a witness
 // signal) near the critical path is expanded through the linear nodes below it -- through private ones freely, through
@@ -427,6 +427,7 @@ static void hoist_linear_forms(const Graph& in, const std::vector<uint32_t>& sto
         // the chain as explicit a * b + c nodes, in arrival order
         uint32_t acc = NONE, acc_t = 0;
         if (!best_c.is_zero()) acc = const_of(best_c);
+        const uint32_t first_new = (uint32_t)H.nodes.size();   // (constants are shared: the chain's own nodes start here)
         for (size_t k = 0; k < best.size(); k++) {
           const Piece& p = best[k];
           if (acc != NONE && reduce_every && k && k % reduce_every == 0 && k + 1 < best.size()) {
@@ -460,7 +461,7 @@ static void hoist_linear_forms(const Graph& in, const std::vector<uint32_t>& sto
             acc = emit(GNode{G_FMA, fa, fb, acc}, acc_t, NONE);
           }
         }
-        if (H.nodes[acc].op != G_ADD && H.nodes[acc].op != G_MUL && H.nodes[acc].op != G_FMA)   // a single plain term
+        if (acc < first_new)   // a single plain term: a node that exists already (it has its own store slot) -- a copy carries this one's
           acc = emit(GNode{G_ADD, acc, const_of(Fr::zero()), 0}, acc_t + 1, NONE);
         st[acc] = store_in[n];
         remap[n] = acc;
@@ -545,6 +546,10 @@ static WlProgram wl_schedule_graph(const Graph& graph, const std::vector<uint32_
   const uint32_t DUMMY = WL_SLOTS - 1;
   const uint32_t FIX = (1u << 30) + N;    // value ids >= FIX address a fixed LDS slot (ZERO / ONE / MINUS_ONE)
   if (first_free + 64 >= DUMMY) return R;   // the constants alone (nearly) fill the LDS
+  // a constant that is itself a witness signal has a store slot and no micro-op that would fill it: such a graph keeps
+  // the other interpreter (none of the shipped circuits has one: their constant 1 is input 0)
+  for (uint32_t n = 0; n < N; n++)
+    if (graph.nodes[n].op == G_CONST && store_slot[n] != NONE) return R;
   auto nops = [&](const GNode& g) {
     return (g.op == G_INPUT || g.op == G_CONST) ? 0 : (g.op == G_NEG || g.op == G_ID) ? 1 : (g.op == G_TERN || g.op == G_FMA) ? 3 : 2;
   };
