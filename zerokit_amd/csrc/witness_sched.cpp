@@ -492,8 +492,7 @@ static void hoist_linear_forms(const Graph& in, const std::vector<uint32_t>& sto
   out->tree_depth = in.tree_depth;
   out->max_out = in.max_out;
   out->inputs_size = in.inputs_size;
-  // constants may have been emitted behind their first reader (const_of inside a form): readers first is not a graph, so
-  // the surviving constants go to the front
+  // (the surviving constants first, then the rest in emission order: every node still follows what it reads)
   std::vector<uint32_t> pos(M, NONE);
   store_out->clear();
   for (int pass = 0; pass < 2; pass++)
