@@ -1467,7 +1467,11 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   MARK(3, sA2);
   if (mode != PROVE_PARTIAL) {
     const bool lg = nb <= D.lanechunk_max;   // below a wave of proofs: lanes = groups
-    if (lg && D.logn >= 9 && D.logn <= 18) {
+    // (above ~100 proofs the walks beside the quotient chain leave the 4-wave workgroups of the LDS kernels waiting for
+    // four free wave slots on one CU: the single-wave passes then finish earlier -- 128 proofs 13.3 -> 12.6 ms, 96 and
+    // below no better or worse; RLNAMD_NTT_LG_MAX)
+    static const uint32_t ntt_lg_max = (uint32_t)env_int("RLNAMD_NTT_LG_MAX", 96);
+    if (lg && nb <= ntt_lg_max && D.logn >= 9 && D.logn <= 18) {
       // iNTT, coset scaling and NTT as edge / mid / edge: one butterfly per lane per level (prover_front.hip: k_ntt_mid)
       const dim3 grid(nb, D.n >> 9, 3);
       if (D.logn > 9) hipLaunchKernelGGL(k_ntt_edge<true>, grid, dim3(256), 0, sA2, S.abc.p, D.tw_i.p, D.logn, B, nb);
