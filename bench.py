@@ -465,6 +465,118 @@ def _stream_proofs_per_s(prover, batches, n_batches, B, collect_public=None):
     return n_batches * B / (time.perf_counter() - t0), results
 
 
+def _partial_inputs(prover, packed_inputs, n):
+    """the partial witness of witness.rs:887-937 as an inputs buffer: the message-dependent slots (messageId, x,
+    externalNullifier) zeroed -- evaluate_partial never reads them"""
+    import numpy as np
+    a = np.frombuffer(packed_inputs, dtype=np.uint8).reshape(n, prover.inputs_size, 32).copy()
+    for name in ("messageId", "x", "externalNullifier"):
+        off, ln = prover.slots[name]
+        a[:, off:off + ln, :] = 0
+    return a.tobytes()
+
+
+def measure_finish(prover, batches, full_results, B, full_rate, full_latency_ms, K=16):
+    """SURVEY 8(f) rank 2, the reference's one published performance claim (rln/README.md:370-375: finishing a cached
+    partial proof is "roughly 2.5-3x faster" than a full proof; criterion targets rln/benches/partial_proof.rs:57-75):
+    partial proofs of the members computed once (RLNAMD_MODE_PARTIAL, timed as its own rate), then ONLY
+    finish_zk_proof_with_rs per message (RLNAMD_MODE_FINISH) -- K batches of B streamed exactly like the headline, and
+    one finish per call.  Judges: every finished proof of a batch must be byte-identical to the FULL proof the timed
+    region made from the same (witness, r, s); a sample is verified on the host."""
+    nb = min(len(batches), 4)
+    zero_rs = bytes(64 * B)
+    prover.sync()
+    t0 = time.perf_counter()
+    tk = [prover.submit(_partial_inputs(prover, batches[k][0], B), zero_rs, 1)[0] for k in range(nb)]
+    parts = [prover.collect_partial(t, B) for t in tk]
+    prover.sync()
+    partial_s = time.perf_counter() - t0
+    nslots, inflight, res = prover.n_slots(), collections.deque(), {}
+
+    def take():
+        t, kk = inflight.popleft()
+        res[kk] = prover.collect_raw(t, B)
+
+    def stream(n_batches):
+        prover.sync()
+        t1 = time.perf_counter()
+        for j in range(n_batches):
+            k = j % nb
+            if len(inflight) == nslots:
+                take()
+            inflight.append((prover.submit(batches[k][0], batches[k][1], 2, parts[k])[0], k))
+        while inflight:
+            take()
+        prover.sync()
+        return n_batches * B / (time.perf_counter() - t1)
+    stream(2)
+    prover.walk_clock_mhz()
+    rate = stream(K)
+    clock = prover.walk_clock_mhz()
+    stage = prover.stage_ms()
+    same = all(k in full_results and res[k][0] == full_results[k][0] and not any(res[k][2]) for k in res) and len(res) == nb
+    vp, vv = [], []
+    for k, (proofs, values, errs) in sorted(res.items()):
+        for i in (0, B - 1):
+            vp.append(proofs[128 * i:128 * i + 128])
+            vv.append([int.from_bytes(values[160 * i + 32 * q:160 * i + 32 * q + 32], "little") for q in range(5)])
+    verified = bool(all(prover.verify_many(vp, vv)))
+    # one finish per call: submit + collect with nothing else in flight
+    n1 = prover.inputs_size * 32
+    one_in, one_rs, one_pp = batches[0][0][:n1], batches[0][1][:64], [parts[0][0]]
+    ts = []
+    for i in range(11):
+        t1 = time.perf_counter()
+        t, _ = prover.submit(one_in, one_rs, 2, one_pp)
+        pr, _, er = prover.collect_raw(t, 1)
+        if i >= 2:
+            ts.append((time.perf_counter() - t1) * 1e3)
+    lat = sorted(ts)[len(ts) // 2]
+    same1 = bool(0 in full_results and pr[:128] == full_results[0][0][:128] and not any(er))
+    out = {"what": "finish_zk_proof_with_rs from cached partial proofs (protocol/proof.rs:821-849): %d batches of %d streamed, "
+                   "H2D of inputs + partial points and D2H of proofs inside; the same witnesses, r, s as the headline's first "
+                   "%d batches" % (K, B, nb),
+           "proofs_per_s": round(rate, 1), "ms_per_batch": round(B / rate * 1e3, 3),
+           "full_proofs_per_s": round(full_rate, 1), "speedup_over_full": round(rate / full_rate, 3),
+           "single_call_ms_median": round(lat, 3), "single_call_ms_min": round(min(ts), 3),
+           "full_single_call_ms_median": full_latency_ms,
+           "single_call_speedup_over_full": round(full_latency_ms / lat, 3) if full_latency_ms else None,
+           "partial_generation_proofs_per_s": round(nb * B / partial_s, 1),
+           "reference_claim": "finish roughly 2.5-3x faster than a full proof (rln/README.md:370-375), one proof per call on a CPU",
+           "byte_identical_to_the_full_proofs": bool(same), "single_call_byte_identical": same1,
+           "verified": verified, "verified_proofs": len(vp),
+           "stage_ms_overlapped": {k: round(v, 3) for k, v in stage.items()},
+           "shader_clock_mhz": {k: round(v, 1) for k, v in clock.items()}}
+    out["correct"] = bool(same and same1 and verified)
+    return out, parts
+
+
+def cpu_finish_baseline(ws, rs, cores):
+    """oracle/c on the host: one full proof, one partial proof and one finish on ONE thread (the criterion targets of
+    rln/benches/partial_proof.rs:57-75), then `cores` finishes, one per thread"""
+    from oracle.c import binding as ob
+    c = ob.Circuit(20)
+    packed = [c.pack(w) for w in ws]
+    rsb = [r.to_bytes(32, "little") + s_.to_bytes(32, "little") for r, s_ in rs]
+    t0 = time.perf_counter()
+    full = c.prove_packed(packed[0], rs[0][0], rs[0][1])["proof"]
+    t1 = time.perf_counter()
+    part = c.prove_partial_packed(packed[0])
+    t2 = time.perf_counter()
+    fin = c.finish_packed(packed[0], rs[0][0], rs[0][1], part)
+    t3 = time.perf_counter()
+    n = min(len(ws), max(cores, 2))
+    parts = [part] + [c.prove_partial_packed(p) for p in packed[1:n]]
+    secs, proofs = c.finish_many_packed(b"".join(packed[:n]), b"".join(rsb[:n]), b"".join(parts), threads=cores)
+    return {"kind": "port", "cores": cores, "finish_proofs_per_s": round(n / secs, 3),
+            "single_thread_ms": {"full": round((t1 - t0) * 1e3, 2), "partial": round((t2 - t1) * 1e3, 2),
+                                 "finish": round((t3 - t2) * 1e3, 2)},
+            "finish_speedup_over_full": round((t1 - t0) / (t3 - t2), 3),
+            "finish_equals_full": bool(fin == full),
+            "sample": "%d finishes of the config-2 witnesses, one per thread on %d threads (oracle/c: the four MSMs over the "
+                      "rows evaluate_partial leaves unknown + all of h, full witness recomputed as the reference does)" % (n, cores)}, parts[0], fin
+
+
 def operating_points_main(args):
     """VERDICT r4 item 5 -- the operating points as measured data (outside any timed region of the headline): for the comb
     schedules 8 / 120010 (the default object) / 12 / 114 / 7150114 (the bench) the table size, the constructor's time and
@@ -765,7 +877,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("RLNAMD_BENCH_BATCH", "1024")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-side-configs", action="store_true", help="skip the config3 / config5 objects")
+    ap.add_argument("--no-side-configs", action="store_true", help="skip the config3 / config5 / finish objects")
+    ap.add_argument("--sustained-seconds", type=float, default=float(os.environ.get("RLNAMD_BENCH_SUSTAINED_S", "10")),
+                    help="after the timed region: this many seconds of back-to-back batches (0: skip)")
     ap.add_argument("--workload", default="proofs", choices=["proofs", "merkle", "msm", "finish", "operating-points"],
                     help="proofs = BASELINE metric (default); merkle / msm / finish / operating-points = side measurements")
     args = ap.parse_args()

@@ -42,7 +42,9 @@ int rlnamd_hash_to_field_le(const uint8_t* data, size_t len, uint8_t out_le[32])
 int rlnamd_hash_to_field_be(const uint8_t* data, size_t len, uint8_t out_le[32]);
 
 /* ---- HBM-resident Poseidon Merkle tree ---------------------------------------------------------------
- * FullMerkleTree semantics (utils/src/merkle_tree/full_merkle_tree.rs). */
+ * FullMerkleTree semantics (utils/src/merkle_tree/full_merkle_tree.rs).  Calls on one handle are serialised by the
+ * handle's own mutex (one stream and shared staging buffers per tree: readers touch object state too), so a handle may
+ * be shared between threads; different handles do not wait for each other. */
 typedef struct rlnamd_tree rlnamd_tree;
 int rlnamd_tree_new(size_t depth, rlnamd_tree** out);                         /* ::default(depth) :74-80 */
 void rlnamd_tree_free(rlnamd_tree* t);
@@ -147,7 +149,8 @@ int rlnamd_prover_fetch_witness(rlnamd_prover* p, size_t index, uint8_t* out_le)
 int rlnamd_prover_fetch_h(rlnamd_prover* p, size_t index, uint8_t* out_le);
 /* tap of the wipes: the number of 16-byte words that are not zero in the buffers of the slot the last batch used, whole
  * buffers: [0] G1 window digits, [1] G2 window digits, [2] a | b | c (the quotient's operands, then h), [3] / [4] partial
- * sums of the G1 / G2 walks, [5] staged inputs + (r, s).  All zero behind a collect that wipes. */
+ * sums of the G1 / G2 walks and everything their reduction leaves behind (block sums, the unblinded A / B / C sums, the
+ * affine points, the ladder's products and tables), [5] staged inputs + (r, s).  All zero behind a collect that wipes. */
 int rlnamd_prover_residue(rlnamd_prover* p, uint64_t out[6]);
 /* ---- partial proofs (generate_partial_zk_proof / finish_zk_proof_with_rs, protocol/proof.rs:783-849;
  * Groth16Partial, partial_proof.rs:108-274).  mode: 0 full proof, 1 partial (inputs hold only identitySecret,
@@ -274,6 +277,13 @@ int rlnamd_pool_inject_fault(rlnamd_pool* p, size_t replica, size_t after_chunks
  * is index-identical to a job without faults.  rlnamd_pool_health: per replica, quarantined (0 / 1) and the number of
  * dispatches that ended in an error since the pool was built (either array may be NULL). */
 int rlnamd_pool_set_failover(rlnamd_pool* p, int rounds);
+/* Probation.  jobs = 0 (default): a quarantined replica stays out until rlnamd_pool_revive.  jobs > 0: it sits out that
+ * many jobs and is then handed work again by itself (a replica that fails again is quarantined again, its chunks go to
+ * the others as before); when every replica is quarantined all of them are tried again at once instead of failing the
+ * call.  Behind an FFI object (config key "failover") this is on, 8 jobs unless "revive_after" says otherwise: a caller
+ * of include/rln.h has no handle on the pool.  Replica 0 of an FFI object's pool is also its single-proof prover and
+ * its tree's device: calls with n <= max_batch are NOT failed over. */
+int rlnamd_pool_set_probation(rlnamd_pool* p, size_t jobs);
 int rlnamd_pool_health(rlnamd_pool* p, int* quarantined_per_replica, size_t* failures_per_replica);
 int rlnamd_pool_revive(rlnamd_pool* p, size_t replica);
 int rlnamd_pool_verify_many(rlnamd_pool* p, size_t n, const uint8_t* proofs, const uint8_t* values_le, size_t n_values,

@@ -43,6 +43,19 @@ def lib():
         L.oracle_prove_many.restype = C.c_double
         L.oracle_prove_many.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_char_p,
                                         C.POINTER(C.c_int)]
+        L.oracle_known_mask.restype = None
+        L.oracle_known_mask.argtypes = [C.c_void_p, C.c_char_p]
+        L.oracle_prove_partial.restype = C.c_int
+        L.oracle_prove_partial.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]
+        L.oracle_finish.restype = C.c_int
+        L.oracle_finish.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]
+        L.oracle_finish_many.restype = C.c_double
+        L.oracle_finish_many.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_char_p,
+                                         C.POINTER(C.c_int)]
+        L.oracle_selftest_mul.restype = C.c_int
+        L.oracle_selftest_mul.argtypes = [C.c_uint64, C.c_size_t]
+        L.oracle_mul_kind.restype = C.c_char_p
+        L.oracle_mul_kind.argtypes = []
         L.oracle_num_public.restype = C.c_size_t
         L.oracle_num_public.argtypes = [C.c_void_p]
         L.oracle_input_slot.restype = C.c_int
@@ -163,6 +176,41 @@ class Circuit:
         pub = [[int.from_bytes(values.raw[32 * (np_ * i + k):32 * (np_ * i + k + 1)], "little") for k in range(np_)]
                for i in range(n)]
         return secs, [proofs.raw[128 * i:128 * (i + 1)] for i in range(n)], pub
+
+    def known_mask(self):
+        """evaluate_partial's knownness per witness signal (entry 0 = the constant 1): PartialProof::mask with a leading True"""
+        buf = C.create_string_buffer(self.n_signals)
+        lib().oracle_known_mask(self.h, buf)
+        return [bool(b) for b in buf.raw]
+
+    def prove_partial_packed(self, packed):
+        """generate_partial_zk_proof from a packed inputs buffer (unknown slots are not read) -> 320 bytes
+        (pi_a | rho | pi_b | pi_c, affine canonical LE: the layout of rlnamd_prover_download_partial)"""
+        out = C.create_string_buffer(320)
+        rc = lib().oracle_prove_partial(self.h, packed, out, None)
+        if rc:
+            raise RuntimeError("oracle_prove_partial rc=%d" % rc)
+        return out.raw
+
+    def finish_packed(self, packed, r, s, partial320):
+        """finish_zk_proof_with_rs -> the 128-byte compressed proof"""
+        proof = C.create_string_buffer(128)
+        rc = lib().oracle_finish(self.h, packed, _b(r) + _b(s), partial320, proof)
+        if rc:
+            raise RuntimeError("oracle_finish rc=%d" % rc)
+        return proof.raw
+
+    def finish_many_packed(self, inputs, rsb, partials, threads=None):
+        """n finishes on host threads -> (seconds, [proof128])"""
+        n = len(rsb) // 64
+        assert len(inputs) == n * self.n_inputs * 32 and len(partials) == 320 * n
+        threads = threads or os.cpu_count() or 1
+        proofs = C.create_string_buffer(128 * n)
+        rc = C.c_int(0)
+        secs = lib().oracle_finish_many(self.h, inputs, rsb, partials, n, threads, proofs, C.byref(rc))
+        if rc.value:
+            raise RuntimeError("oracle_finish_many rc=%d" % rc.value)
+        return secs, [proofs.raw[128 * i:128 * (i + 1)] for i in range(n)]
 
     def prove(self, w, r, s, want_witness=False, want_h=False):
         proof = C.create_string_buffer(128)

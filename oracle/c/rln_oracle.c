@@ -60,25 +60,28 @@ static inline void sub4(u64 r[4], const u64 a[4], const u64 b[4]) {
 }
 static inline int fe_is_zero(const fe* a) { return (a->v[0] | a->v[1] | a->v[2] | a->v[3]) == 0; }
 static inline int fe_eq(const fe* a, const fe* b) { return memcmp(a, b, sizeof(fe)) == 0; }
-static inline void fe_add(const field* F, fe* r, const fe* a, const fe* b) {
-  u128 c = 0; u64 t[4];
+static inline void fe_add(const field* F, fe* r, const fe* a, const fe* b) {   /* a, b < p < 2^254: no carry out of limb 3 */
+  u128 c = 0; u64 t[4], d[4];
   for (int i = 0; i < 4; i++) { c += (u128)a->v[i] + b->v[i]; t[i] = (u64)c; c >>= 64; }
-  if (ge4(t, F->p)) sub4(t, t, F->p);
-  memcpy(r->v, t, 32);
+  u128 br = 0;
+  for (int i = 0; i < 4; i++) { u128 x = (u128)t[i] - F->p[i] - (u64)br; d[i] = (u64)x; br = (x >> 64) & 1; }
+  const u64 keep = (u64)0 - (u64)br;   /* t < p: keep t */
+  for (int i = 0; i < 4; i++) r->v[i] = (t[i] & keep) | (d[i] & ~keep);
 }
 static inline void fe_sub(const field* F, fe* r, const fe* a, const fe* b) {
   u64 t[4]; u128 br = 0;
   for (int i = 0; i < 4; i++) { u128 x = (u128)a->v[i] - b->v[i] - (u64)br; t[i] = (u64)x; br = (x >> 64) & 1; }
-  if (br) { u128 c = 0; for (int i = 0; i < 4; i++) { c += (u128)t[i] + F->p[i]; t[i] = (u64)c; c >>= 64; } }
-  memcpy(r->v, t, 32);
+  const u64 m = (u64)0 - (u64)br;      /* borrowed: add p back */
+  u128 c = 0;
+  for (int i = 0; i < 4; i++) { c += (u128)t[i] + (F->p[i] & m); r->v[i] = (u64)c; c >>= 64; }
 }
 static inline void fe_neg(const field* F, fe* r, const fe* a) {
   if (fe_is_zero(a)) { *r = *a; return; }
   fe z = {{0, 0, 0, 0}}; fe_sub(F, r, &z, a);
 }
 static inline void fe_dbl(const field* F, fe* r, const fe* a) { fe_add(F, r, a, a); }
-/* CIOS Montgomery product */
-static inline void fe_mul(const field* F, fe* r, const fe* a, const fe* b) {
+/* CIOS Montgomery product, portable form (the form every round until 6 timed; kept as the cross-check of the one below) */
+static inline void fe_mul_portable(const field* F, fe* r, const fe* a, const fe* b) {
   u64 t[6] = {0, 0, 0, 0, 0, 0};
   for (int i = 0; i < 4; i++) {
     u128 c = 0;
@@ -92,6 +95,54 @@ static inline void fe_mul(const field* F, fe* r, const fe* a, const fe* b) {
   if (t[4] || ge4(t, F->p)) sub4(t, t, F->p);
   memcpy(r->v, t, 32);
 }
+#if defined(__x86_64__) && defined(__ADX__) && defined(__BMI2__)
+#define ORACLE_MUL_KIND "mulx/adcx/adox"
+/* What ark-ff 0.5.0 runs on x86-64 with the `asm` feature (ark-ff-asm 0.5.0, Cargo.lock; the reference's default build
+ * enables it through ark-ff's features): the "no-carry" CIOS product for moduli with a spare top bit (both BN254 moduli
+ * are 254 bits) as one mulx row per limb of b with two independent carry chains (adcx: the row's high halves, adox:
+ * the accumulation), the reduction row interleaved.  Checked against fe_mul_portable by oracle_selftest_mul. */
+static inline void fe_mul(const field* F, fe* r, const fe* a, const fe* b) {
+  u64 t0, t1, t2, t3, A, lo, hi;
+  const u64 *pa = a->v, *pb = b->v, *pp = F->p; u64 inv = F->inv;
+#define RED_ROW \
+    "movq %[inv], %%rdx\n\t imulq %[t0], %%rdx\n\t" \
+    "xorq %[lo], %[lo]\n\t" \
+    "mulxq 0(%[p]), %[lo], %[hi]\n\t adcxq %[t0], %[lo]\n\t movq %[hi], %[t0]\n\t" \
+    "adcxq %[t1], %[t0]\n\t mulxq 8(%[p]), %[lo], %[t1]\n\t adoxq %[lo], %[t0]\n\t" \
+    "adcxq %[t2], %[t1]\n\t mulxq 16(%[p]), %[lo], %[t2]\n\t adoxq %[lo], %[t1]\n\t" \
+    "adcxq %[t3], %[t2]\n\t mulxq 24(%[p]), %[lo], %[t3]\n\t adoxq %[lo], %[t2]\n\t" \
+    "movl $0, %k[lo]\n\t adcxq %[lo], %[t3]\n\t adoxq %[A], %[t3]\n\t"
+#define MUL_ROW(OFF) \
+    "xorq %[lo], %[lo]\n\t movq " #OFF "(%[b]), %%rdx\n\t" \
+    "mulxq 0(%[a]), %[lo], %[A]\n\t adoxq %[lo], %[t0]\n\t" \
+    "adcxq %[A], %[t1]\n\t mulxq 8(%[a]), %[lo], %[A]\n\t adoxq %[lo], %[t1]\n\t" \
+    "adcxq %[A], %[t2]\n\t mulxq 16(%[a]), %[lo], %[A]\n\t adoxq %[lo], %[t2]\n\t" \
+    "adcxq %[A], %[t3]\n\t mulxq 24(%[a]), %[lo], %[A]\n\t adoxq %[lo], %[t3]\n\t" \
+    "movl $0, %k[lo]\n\t adcxq %[lo], %[A]\n\t adoxq %[lo], %[A]\n\t"
+  __asm__(
+    "movq 0(%[b]), %%rdx\n\t"
+    "xorq %[lo], %[lo]\n\t"
+    "mulxq 0(%[a]), %[t0], %[t1]\n\t"
+    "mulxq 8(%[a]), %[lo], %[t2]\n\t adoxq %[lo], %[t1]\n\t"
+    "mulxq 16(%[a]), %[lo], %[t3]\n\t adoxq %[lo], %[t2]\n\t"
+    "mulxq 24(%[a]), %[lo], %[A]\n\t adoxq %[lo], %[t3]\n\t"
+    "movl $0, %k[lo]\n\t adoxq %[lo], %[A]\n\t"
+    RED_ROW MUL_ROW(8) RED_ROW MUL_ROW(16) RED_ROW MUL_ROW(24) RED_ROW
+    : [t0] "=&r"(t0), [t1] "=&r"(t1), [t2] "=&r"(t2), [t3] "=&r"(t3), [A] "=&r"(A), [lo] "=&r"(lo), [hi] "=&r"(hi)
+    : [a] "r"(pa), [b] "r"(pb), [p] "r"(pp), [inv] "r"(inv), "m"(*a), "m"(*b)
+    : "rdx", "cc");
+#undef RED_ROW
+#undef MUL_ROW
+  const u64 t[4] = {t0, t1, t2, t3};
+  u64 d[4]; u128 br = 0;   /* result < 2p: one conditional subtraction, without a branch */
+  for (int i = 0; i < 4; i++) { u128 x = (u128)t[i] - F->p[i] - (u64)br; d[i] = (u64)x; br = (x >> 64) & 1; }
+  const u64 keep = (u64)0 - (u64)br;
+  for (int i = 0; i < 4; i++) r->v[i] = (t[i] & keep) | (d[i] & ~keep);
+}
+#else
+#define ORACLE_MUL_KIND "portable (unsigned __int128)"
+static inline void fe_mul(const field* F, fe* r, const fe* a, const fe* b) { fe_mul_portable(F, r, a, b); }
+#endif
 static inline void fe_sqr(const field* F, fe* r, const fe* a) { fe_mul(F, r, a, a); }
 static void fe_from_u64x4(const field* F, fe* r, const u64 c[4]) { fe x; memcpy(x.v, c, 32); fe r2; memcpy(r2.v, F->r2, 32); fe_mul(F, r, &x, &r2); }
 static void fe_to_u64x4(const field* F, u64 c[4], const fe* a) { fe one = {{1, 0, 0, 0}}, t; fe_mul(F, &t, a, &one); memcpy(c, t.v, 32); }
@@ -119,7 +170,13 @@ static inline void f2_mul(fe2* r, const fe2* a, const fe2* b) {
   fe_add(&FQ, &s, &a->c0, &a->c1); fe_add(&FQ, &t, &b->c0, &b->c1); fe_mul(&FQ, &s, &s, &t);
   fe_sub(&FQ, &r->c0, &v0, &v1); fe_sub(&FQ, &s, &s, &v0); fe_sub(&FQ, &r->c1, &s, &v1);
 }
-static inline void f2_sqr(fe2* r, const fe2* a) { f2_mul(r, a, a); }
+/* complex squaring, two base-field products: (c0 + c1)(c0 - c1) + 2 c0 c1 u  (what ark-ff's QuadExtField::square_in_place
+ * does when the non-residue is -1) */
+static inline void f2_sqr(fe2* r, const fe2* a) {
+  fe s, d, m;
+  fe_add(&FQ, &s, &a->c0, &a->c1); fe_sub(&FQ, &d, &a->c0, &a->c1); fe_mul(&FQ, &m, &a->c0, &a->c1);
+  fe_mul(&FQ, &r->c0, &s, &d); fe_add(&FQ, &r->c1, &m, &m);
+}
 static inline int f2_is_zero(const fe2* a) { return fe_is_zero(&a->c0) && fe_is_zero(&a->c1); }
 static inline int f2_eq(const fe2* a, const fe2* b) { return fe_eq(&a->c0, &b->c0) && fe_eq(&a->c1, &b->c1); }
 static void f2_inv(fe2* r, const fe2* a) {
@@ -181,28 +238,43 @@ static void f2_inv(fe2* r, const fe2* a) {
     for (int i = 255; i >= 0; i--) { NAME##_dbl(&acc, &acc); if ((k[i >> 6] >> (i & 63)) & 1) NAME##_add_mixed(&acc, &acc, p); } \
     *r = acc;                                                                                               \
   }                                                                                                         \
-  /* windowed Pippenger over canonical 256-bit scalars (msm_bigint) */                                      \
-  static void NAME##_msm(NAME##_jac* out, const NAME##_aff* pts, const u64 (*sc)[4], size_t n) {            \
-    int c = 0; { size_t m = n; while (m > 1) { m >>= 1; c++; } c = n < 32 ? 3 : c * 69 / 100 + 2; } /* ark-ec: ln(n) + 2 */ \
-    int nw = (254 + c - 1) / c; size_t nb = ((size_t)1 << c) - 1;                                           \
-    NAME##_jac* buckets = (NAME##_jac*)malloc(nb * sizeof(NAME##_jac));                                     \
-    NAME##_jac total; NAME##_jac_inf(&total);                                                               \
-    for (int w = nw - 1; w >= 0; w--) {                                                                     \
-      for (int k = 0; k < c; k++) NAME##_dbl(&total, &total);                                               \
-      for (size_t b = 0; b < nb; b++) NAME##_jac_inf(&buckets[b]);                                          \
-      int bit = w * c;                                                                                      \
-      for (size_t i = 0; i < n; i++) {                                                                      \
-        if (pts[i].inf) continue;                                                                           \
-        u64 lo = sc[i][bit >> 6] >> (bit & 63);                                                             \
-        if ((bit & 63) + c > 64 && (bit >> 6) < 3) lo |= sc[i][(bit >> 6) + 1] << (64 - (bit & 63));        \
-        u64 d = lo & (((u64)1 << c) - 1);                                                                   \
-        if (d) NAME##_add_mixed(&buckets[d - 1], &buckets[d - 1], &pts[i]);                                 \
-      }                                                                                                     \
-      NAME##_jac run, ws; NAME##_jac_inf(&run); NAME##_jac_inf(&ws);                                        \
-      for (size_t b = nb; b-- > 0;) { NAME##_add(&run, &run, &buckets[b]); NAME##_add(&ws, &ws, &run); }    \
-      NAME##_add(&total, &total, &ws);                                                                      \
-    }                                                                                                       \
-    free(buckets); *out = total;                                                                            \
+  /* VariableBaseMSM::msm_bigint as ark-ec 0.5.0 runs it (msm_bigint_wnaf): window c = 3 below 32 points, else      \
+   * ln_without_floor(n) + 2 = floor(log2 n) * 69 / 100 + 2; every scalar cut into ceil(254 / c) SIGNED digits in       \
+   * [-2^(c-1), 2^(c-1)] (make_digits: a digit above half the radix borrows from the next), so a window has 2^(c-1)      \
+   * buckets and a negative digit subtracts the base; running-sum bucket reduction; windows folded high to low with c   \
+   * doublings each.  (Rounds 1-5 restated the unsigned form of ark-ec 0.4's msm_bigint: twice the buckets.) */        \
+  static void NAME##_msm(NAME##_jac* out, const NAME##_aff* pts, const u64 (*sc)[4], size_t n) {                        \
+    int c = 0; { size_t m = n; while (m > 1) { m >>= 1; c++; } c = n < 32 ? 3 : c * 69 / 100 + 2; }                     \
+    const int nw = (254 + c - 1) / c; const size_t nb = (size_t)1 << (c - 1);                                           \
+    int32_t* dig = (int32_t*)malloc(sizeof(int32_t) * (n ? n : 1) * (size_t)nw);                                        \
+    const u64 radix = (u64)1 << c, mask = radix - 1;                                                                    \
+    for (size_t i = 0; i < n; i++) {                                                                                    \
+      u64 carry = 0;                                                                                                    \
+      for (int w = 0; w < nw; w++) {                                                                                    \
+        const int bit = w * c, wi = bit >> 6, bi = bit & 63;                                                            \
+        u64 buf = (bi < 64 - c || wi == 3) ? sc[i][wi] >> bi : (sc[i][wi] >> bi) | (sc[i][wi + 1] << (64 - bi));        \
+        const u64 coef = carry + (buf & mask);                                                                          \
+        carry = (coef + radix / 2) >> c;                                                                                \
+        dig[i * nw + w] = (int32_t)((int64_t)coef - (int64_t)(carry << c));                                             \
+      }                                                                                                                 \
+      dig[i * nw + nw - 1] += (int32_t)(carry << c);                                                                    \
+    }                                                                                                                   \
+    NAME##_jac* buckets = (NAME##_jac*)malloc(nb * sizeof(NAME##_jac));                                                 \
+    NAME##_jac total; NAME##_jac_inf(&total);                                                                           \
+    for (int w = nw - 1; w >= 0; w--) {                                                                                 \
+      for (int k = 0; k < c; k++) NAME##_dbl(&total, &total);                                                           \
+      for (size_t b = 0; b < nb; b++) NAME##_jac_inf(&buckets[b]);                                                      \
+      for (size_t i = 0; i < n; i++) {                                                                                  \
+        if (pts[i].inf) continue;                                                                                       \
+        const int32_t d = dig[i * nw + w];                                                                              \
+        if (d > 0) NAME##_add_mixed(&buckets[d - 1], &buckets[d - 1], &pts[i]);                                         \
+        else if (d < 0) { NAME##_aff m = pts[i]; NEG(&m.y, &m.y); NAME##_add_mixed(&buckets[-d - 1], &buckets[-d - 1], &m); } \
+      }                                                                                                                 \
+      NAME##_jac run, ws; NAME##_jac_inf(&run); NAME##_jac_inf(&ws);                                                    \
+      for (size_t b = nb; b-- > 0;) { NAME##_add(&run, &run, &buckets[b]); NAME##_add(&ws, &ws, &run); }                \
+      NAME##_add(&total, &total, &ws);                                                                                  \
+    }                                                                                                                   \
+    free(buckets); free(dig); *out = total;                                                                             \
   }
 
 #define FQ_ADD(r, a, b) fe_add(&FQ, r, a, b)
@@ -583,22 +655,174 @@ int oracle_prove(void* hnd, const uint8_t* inputs_le, const uint8_t* rs_le, uint
   return 0;
 }
 
-typedef struct { void* h; const uint8_t *in, *rs; uint8_t *proofs, *values; size_t n, next; pthread_mutex_t* mu; int rc; } job;
+/* ---- partial proofs: generate_partial_zk_proof / finish_zk_proof_with_rs (protocol/proof.rs:783-849) over
+ * Groth16Partial (partial_proof.rs:108-274) and evaluate_partial (iden3calc/graph.rs:274-312).
+ * The partial witness of witness.rs:887-937 fixes identitySecret, userMessageLimit, pathElements, identityPathIndex;
+ * messageId, x, externalNullifier (and selectorUsed on the multi-message-id circuit) are unknown. */
+static void input_known(const circuit* C, uint8_t* k /* n_inputs */) {
+  memset(k, 1, C->n_inputs);
+  for (uint32_t i = 0; i < C->n_msg; i++) k[C->off_msg + i] = 0;
+  k[C->off_x] = 0; k[C->off_ext] = 0;
+  if (C->has_sel) for (uint32_t i = 0; i < C->n_msg; i++) k[C->off_sel + i] = 0;
+}
+/* graph.rs:274-312: a node is Some(..) iff every operand is; returns the per-NODE flags, mask_out = per witness signal */
+static void known_nodes(const circuit* C, uint8_t* kn /* n_nodes */, uint8_t* mask_out /* n_signals or NULL */) {
+  uint8_t* ik = (uint8_t*)malloc(C->n_inputs); input_known(C, ik);
+  for (size_t n = 0; n < C->n_nodes; n++) {
+    const gnode* nd = &C->nodes[n];
+    switch (nd->op) {
+      case 0: kn[n] = ik[nd->a]; break;
+      case 1: kn[n] = 1; break;
+      case 22: case 23: kn[n] = kn[nd->a]; break;
+      case 24: kn[n] = kn[nd->a] && kn[nd->b] && kn[nd->c]; break;
+      default: kn[n] = kn[nd->a] && kn[nd->b]; break;
+    }
+  }
+  if (mask_out) for (size_t i = 0; i < C->n_signals; i++) mask_out[i] = kn[C->signals[i]];
+  free(ik);
+}
+/* PartialProof::mask with entry 0 (the constant 1, always known) in front: n_signals bytes */
+void oracle_known_mask(void* h, uint8_t* mask_out) {
+  const circuit* C = (const circuit*)h; uint8_t* kn = (uint8_t*)malloc(C->n_nodes); known_nodes(C, kn, mask_out); free(kn);
+}
+static void g1_put(uint8_t* o, const g1_jac* p) { g1_aff a; g1_to_aff(&a, p); memset(o, 0, 64); if (!a.inf) { fe_to_bytes(&FQ, o, &a.x); fe_to_bytes(&FQ, o + 32, &a.y); } }
+static void g1_get(g1_aff* a, const uint8_t* i) { int nz = 0; for (int k = 0; k < 64; k++) nz |= i[k]; a->inf = !nz; fe_from_bytes(&FQ, &a->x, i); fe_from_bytes(&FQ, &a->y, i + 32); }
+/* the four MSMs of either half: rows whose mask equals `want` (signal i >= 1; L rows: i >= n_inst) */
+static void masked_msms(const circuit* C, const uint8_t* mask, int want, const u64 (*ws)[4], g1_jac* a, g1_jac* b1, g2_jac* b2, g1_jac* l, int with_b1) {
+  const size_t ns = C->n_signals, ni = C->n_inst;
+  size_t m = 0, ml = 0; for (size_t i = 1; i < ns; i++) if (!!mask[i] == want) { m++; if (i >= ni) ml++; }
+  g1_aff* pa = (g1_aff*)malloc(sizeof(g1_aff) * (m + 1)); g1_aff* pb = (g1_aff*)malloc(sizeof(g1_aff) * (m + 1));
+  g2_aff* p2 = (g2_aff*)malloc(sizeof(g2_aff) * (m + 1)); g1_aff* pl = (g1_aff*)malloc(sizeof(g1_aff) * (ml + 1));
+  u64(*sc)[4] = (u64(*)[4])malloc(sizeof(u64[4]) * (m + 1)); u64(*sl)[4] = (u64(*)[4])malloc(sizeof(u64[4]) * (ml + 1));
+  size_t k = 0, kl = 0;
+  for (size_t i = 1; i < ns; i++) if (!!mask[i] == want) {
+    pa[k] = C->aq[i]; pb[k] = C->b1q[i]; p2[k] = C->b2q[i]; memcpy(sc[k], ws[i], 32); k++;
+    if (i >= ni) { pl[kl] = C->lq[i - ni]; memcpy(sl[kl], ws[i], 32); kl++; }
+  }
+  if (m) g1_msm(a, pa, (const u64(*)[4])sc, m); else g1_jac_inf(a);
+  if (with_b1 && m) g1_msm(b1, pb, (const u64(*)[4])sc, m); else g1_jac_inf(b1);
+  if (m) g2_msm(b2, p2, (const u64(*)[4])sc, m); else g2_jac_inf(b2);
+  if (ml) g1_msm(l, pl, (const u64(*)[4])sl, ml); else g1_jac_inf(l);
+  free(pa); free(pb); free(p2); free(pl); free(sc); free(sl);
+}
+/* generate_partial_zk_proof (proof.rs:783-803 -> partial_proof.rs:108-179).  inputs: the full inputs buffer with the
+ * unknown slots at any value (they are not read: evaluate_partial leaves every node they reach None).
+ * out320 = pi_a | rho | pi_b | pi_c as affine canonical LE coordinates (64 + 64 + 128 + 64; infinity = zeros). */
+int oracle_prove_partial(void* hnd, const uint8_t* inputs_le, uint8_t* out320, uint8_t* mask_out) {
+  const circuit* C = (const circuit*)hnd; const size_t ns = C->n_signals;
+  uint8_t* kn = (uint8_t*)malloc(C->n_nodes); uint8_t* mask = (uint8_t*)malloc(ns); known_nodes(C, kn, mask);
+  /* evaluate_partial: known nodes take their values; unknown ones are never read by a known node */
+  uint8_t* in = (uint8_t*)malloc(32 * C->n_inputs); memcpy(in, inputs_le, 32 * C->n_inputs);
+  { uint8_t* ik = (uint8_t*)malloc(C->n_inputs); input_known(C, ik); for (size_t i = 0; i < C->n_inputs; i++) if (!ik[i]) memset(in + 32 * i, 0, 32); free(ik); }
+  fe* vals = (fe*)malloc(sizeof(fe) * C->n_nodes); fe* w = (fe*)malloc(sizeof(fe) * ns);
+  int rc = eval_graph(C, in, vals, w); free(vals); free(in); free(kn);
+  if (rc) { free(w); free(mask); return rc; }
+  u64(*ws)[4] = (u64(*)[4])malloc(sizeof(u64[4]) * ns);
+  for (size_t i = 0; i < ns; i++) fe_to_u64x4(&FR, ws[i], &w[i]);
+  g1_jac a, b1, l; g2_jac b2;
+  masked_msms(C, mask, 1, (const u64(*)[4])ws, &a, &b1, &b2, &l, 1);
+  g1_add_mixed(&a, &a, &C->alpha1); g1_add_mixed(&a, &a, &C->aq[0]);
+  g1_add_mixed(&b1, &b1, &C->beta1); g1_add_mixed(&b1, &b1, &C->b1q[0]);
+  g2_add_mixed(&b2, &b2, &C->beta2); g2_add_mixed(&b2, &b2, &C->b2q[0]);
+  g1_put(out320, &a); g1_put(out320 + 64, &b1);
+  { g2_aff q; g2_to_aff(&q, &b2); memset(out320 + 128, 0, 128);
+    if (!q.inf) { fe_to_bytes(&FQ, out320 + 128, &q.x.c0); fe_to_bytes(&FQ, out320 + 160, &q.x.c1); fe_to_bytes(&FQ, out320 + 192, &q.y.c0); fe_to_bytes(&FQ, out320 + 224, &q.y.c1); } }
+  g1_put(out320 + 256, &l);
+  if (mask_out) memcpy(mask_out, mask, ns);
+  free(w); free(ws); free(mask);
+  return 0;
+}
+/* finish_zk_proof_with_rs (proof.rs:821-849 -> partial_proof.rs:276-305 witness map + :182-274): the FULL witness is
+ * calculated again (calc_witness), h over all of it, the four MSMs over the rows the mask leaves unknown. */
+int oracle_finish(void* hnd, const uint8_t* inputs_le, const uint8_t* rs_le, const uint8_t* partial320, uint8_t* proof128) {
+  const circuit* C = (const circuit*)hnd;
+  size_t ns = C->n_signals, n = C->n, nc = C->n_cons, ni = C->n_inst;
+  fe* vals = (fe*)malloc(sizeof(fe) * C->n_nodes); fe* w = (fe*)malloc(sizeof(fe) * ns);
+  int rc = eval_graph(C, inputs_le, vals, w); free(vals);
+  if (rc) { free(w); return rc; }
+  uint8_t* kn = (uint8_t*)malloc(C->n_nodes); uint8_t* mask = (uint8_t*)malloc(ns); known_nodes(C, kn, mask); free(kn);
+  fe* a = (fe*)calloc(n, sizeof(fe)); fe* b = (fe*)calloc(n, sizeof(fe)); fe* c = (fe*)calloc(n, sizeof(fe));
+  for (size_t r = 0; r < nc; r++) {
+    fe acc; memset(&acc, 0, sizeof acc);
+    for (size_t k = C->a_ptr[r]; k < C->a_ptr[r + 1]; k++) { fe m; fe_mul(&FR, &m, &C->a_val[k], &w[C->a_col[k]]); fe_add(&FR, &acc, &acc, &m); }
+    a[r] = acc; memset(&acc, 0, sizeof acc);
+    for (size_t k = C->b_ptr[r]; k < C->b_ptr[r + 1]; k++) { fe m; fe_mul(&FR, &m, &C->b_val[k], &w[C->b_col[k]]); fe_add(&FR, &acc, &acc, &m); }
+    b[r] = acc; fe_mul(&FR, &c[r], &a[r], &b[r]);
+  }
+  for (size_t i = 0; i < ni; i++) a[nc + i] = w[i];
+  fe* v3[3] = {a, b, c};
+  for (int q = 0; q < 3; q++) { ntt(C, v3[q], 1); for (size_t i = 0; i < n; i++) fe_mul(&FR, &v3[q][i], &v3[q][i], &C->coset[i]); ntt(C, v3[q], 0); }
+  for (size_t i = 0; i < n; i++) { fe t; fe_mul(&FR, &t, &a[i], &b[i]); fe_sub(&FR, &a[i], &t, &c[i]); }
+  u64(*ws)[4] = (u64(*)[4])malloc(sizeof(u64[4]) * ns); u64(*hs)[4] = (u64(*)[4])malloc(sizeof(u64[4]) * n);
+  for (size_t i = 0; i < ns; i++) fe_to_u64x4(&FR, ws[i], &w[i]);
+  for (size_t i = 0; i < n; i++) fe_to_u64x4(&FR, hs[i], &a[i]);
+  u64 r[4], s[4], rsv[4]; memcpy(r, rs_le, 32); memcpy(s, rs_le + 32, 32);
+  { fe fr, fs, frs; fe_from_u64x4(&FR, &fr, r); fe_from_u64x4(&FR, &fs, s); fe_mul(&FR, &frs, &fr, &fs); fe_to_u64x4(&FR, rsv, &frs); }
+  const int rz = !(r[0] | r[1] | r[2] | r[3]);
+  g1_aff pi_a, rho, pi_c; g2_aff pi_b; g1_get(&pi_a, partial320); g1_get(&rho, partial320 + 64); g1_get(&pi_c, partial320 + 256);
+  { int nz = 0; for (int k = 0; k < 128; k++) nz |= partial320[128 + k]; pi_b.inf = !nz;
+    fe_from_bytes(&FQ, &pi_b.x.c0, partial320 + 128); fe_from_bytes(&FQ, &pi_b.x.c1, partial320 + 160);
+    fe_from_bytes(&FQ, &pi_b.y.c0, partial320 + 192); fe_from_bytes(&FQ, &pi_b.y.c1, partial320 + 224); }
+  g1_jac ga, gb1, lacc, hacc, gc, t1; g2_jac gb2, t2;
+  masked_msms(C, mask, 0, (const u64(*)[4])ws, &ga, &gb1, &gb2, &lacc, !rz);
+  g1_add_mixed(&ga, &ga, &pi_a); g1_mul(&t1, &C->delta1, r); g1_add(&ga, &ga, &t1);
+  if (!rz) { g1_add_mixed(&gb1, &gb1, &rho); g1_mul(&t1, &C->delta1, s); g1_add(&gb1, &gb1, &t1); } else g1_jac_inf(&gb1);
+  g2_add_mixed(&gb2, &gb2, &pi_b); g2_mul(&t2, &C->delta2, s); g2_add(&gb2, &gb2, &t2);
+  g1_add_mixed(&lacc, &lacc, &pi_c);
+  g1_msm(&hacc, C->hq, (const u64(*)[4])hs, n);
+  g1_aff A, B1; g2_aff B2; g1_to_aff(&A, &ga); g1_to_aff(&B1, &gb1); g2_to_aff(&B2, &gb2);
+  g1_mul(&gc, &A, s); g1_mul(&t1, &B1, r); g1_add(&gc, &gc, &t1);
+  g1_mul(&t1, &C->delta1, rsv); fe_neg(&FQ, &t1.Y, &t1.Y); g1_add(&gc, &gc, &t1);
+  g1_add(&gc, &gc, &lacc); g1_add(&gc, &gc, &hacc);
+  g1_aff Cc; g1_to_aff(&Cc, &gc);
+  if (proof128) { g1_compress(&A, proof128); g2_compress(&B2, proof128 + 32); g1_compress(&Cc, proof128 + 96); }
+  free(w); free(a); free(b); free(c); free(ws); free(hs); free(mask);
+  return 0;
+}
+/* 1 when fe_mul (whatever form this build took) equals the portable CIOS product on `iters` pseudo-random pairs and on
+ * the edge operands 0, 1, p - 1, both fields */
+int oracle_selftest_mul(u64 seed, size_t iters) {
+  const field* Fs[2] = {&FR, &FQ}; u64 s = seed ? seed : 88172645463325252ULL;
+  for (int f = 0; f < 2; f++) {
+    const field* F = Fs[f]; fe e[3]; memset(e, 0, sizeof e); e[1].v[0] = 1; memcpy(e[2].v, F->p, 32); e[2].v[0] -= 1;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { fe x, y; fe_mul(F, &x, &e[i], &e[j]); fe_mul_portable(F, &y, &e[i], &e[j]); if (!fe_eq(&x, &y)) return 0; }
+    for (size_t k = 0; k < iters; k++) {
+      fe a, b, x, y;
+      for (int i = 0; i < 4; i++) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; a.v[i] = s; s ^= s << 13; s ^= s >> 7; s ^= s << 17; b.v[i] = s; }
+      a.v[3] &= 0x0fffffffffffffffULL; b.v[3] &= 0x0fffffffffffffffULL; /* below both moduli */
+      fe_mul(F, &x, &a, &b); fe_mul_portable(F, &y, &a, &b);
+      if (!fe_eq(&x, &y)) return 0;
+    }
+  }
+  return 1;
+}
+const char* oracle_mul_kind(void) { return ORACLE_MUL_KIND; }
+
+typedef struct { void* h; const uint8_t *in, *rs; uint8_t *proofs, *values; size_t n, next; pthread_mutex_t* mu; int rc; const uint8_t* partial; } job;
 static void* worker(void* arg) {
   job* J = (job*)arg; size_t ni = oracle_num_inputs(J->h), np = oracle_num_public(J->h);
   for (;;) {
     pthread_mutex_lock(J->mu); size_t i = J->next++; pthread_mutex_unlock(J->mu);
     if (i >= J->n) break;
     /* values: num_public x 32 B per proof (160 B for the single-message circuits) */
-    int rc = oracle_prove(J->h, J->in + i * ni * 32, J->rs + i * 64, J->proofs ? J->proofs + i * 128 : NULL, NULL, NULL, NULL, NULL);
+    int rc = J->partial ? oracle_finish(J->h, J->in + i * ni * 32, J->rs + i * 64, J->partial + i * 320, J->proofs ? J->proofs + i * 128 : NULL)
+                        : oracle_prove(J->h, J->in + i * ni * 32, J->rs + i * 64, J->proofs ? J->proofs + i * 128 : NULL, NULL, NULL, NULL, NULL);
     if (!rc && J->values) public_values((const circuit*)J->h, J->in + i * ni * 32, J->values + i * np * 32);
     if (rc) J->rc = rc;
   }
   return NULL;
 }
 /* n proofs, one proof per host thread (the deployment mode rln/README.md:324-332 recommends); returns seconds */
+static double run_many(void* h, const uint8_t* inputs, const uint8_t* rs, const uint8_t* partial, size_t n, int threads, uint8_t* proofs, uint8_t* values, int* rc_out);
 double oracle_prove_many(void* h, const uint8_t* inputs, const uint8_t* rs, size_t n, int threads, uint8_t* proofs, uint8_t* values, int* rc_out) {
-  pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER; job J = {h, inputs, rs, proofs, values, n, 0, &mu, 0};
+  return run_many(h, inputs, rs, NULL, n, threads, proofs, values, rc_out);
+}
+/* n x finish_zk_proof_with_rs from n cached partial proofs (n x 320 B), one per host thread; returns seconds */
+double oracle_finish_many(void* h, const uint8_t* inputs, const uint8_t* rs, const uint8_t* partial320, size_t n, int threads, uint8_t* proofs, int* rc_out) {
+  return run_many(h, inputs, rs, partial320, n, threads, proofs, NULL, rc_out);
+}
+static double run_many(void* h, const uint8_t* inputs, const uint8_t* rs, const uint8_t* partial, size_t n, int threads, uint8_t* proofs, uint8_t* values, int* rc_out) {
+  pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER; job J = {h, inputs, rs, proofs, values, n, 0, &mu, 0, partial};
   struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
   pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
   for (int i = 0; i < threads; i++) pthread_create(&th[i], NULL, worker, &J);
@@ -732,17 +956,30 @@ void oracle_msm_workload_item_g2(u64 seed, u64 i, int mode, uint8_t point_le[128
  * msm_bigint's windowed Pippenger runs over them with the windows spread over the host threads, which is how ark-ec's
  * `parallel` feature spreads them (one rayon task per window, serial fold at the end). */
 typedef struct { const g1_aff* pts; const u64 (*sc)[4]; size_t n; int c, nw; g1_jac* wsum; int next; pthread_mutex_t mu; } pip_job;
+/* one window of msm_bigint_wnaf (see g1_msm): the signed digit of every scalar in window w, recomputed from the carry
+ * rule (the carry into window w depends only on the bits below it: digit_{w-1} > half the radix, recursively -- here
+ * evaluated by walking the scalar's windows up to w) */
+static inline int32_t signed_digit(const u64 sc[4], int c, int nw, int w) {
+  const u64 radix = (u64)1 << c, mask = radix - 1; u64 carry = 0; int32_t d = 0;
+  for (int k = 0; k <= w; k++) {
+    const int bit = k * c, wi = bit >> 6, bi = bit & 63;
+    const u64 buf = (bi < 64 - c || wi == 3) ? sc[wi] >> bi : (sc[wi] >> bi) | (sc[wi + 1] << (64 - bi));
+    const u64 coef = carry + (buf & mask);
+    carry = (coef + radix / 2) >> c;
+    d = (int32_t)((int64_t)coef - (int64_t)(carry << c));
+  }
+  if (w == nw - 1) d += (int32_t)(carry << c);
+  return d;
+}
 static void pip_window(const pip_job* J, int w, g1_jac* out) {
-  int c = J->c; size_t nb = ((size_t)1 << c) - 1;
+  int c = J->c; size_t nb = (size_t)1 << (c - 1);
   g1_jac* buckets = (g1_jac*)malloc(nb * sizeof(g1_jac));
   for (size_t b = 0; b < nb; b++) g1_jac_inf(&buckets[b]);
-  int bit = w * c;
   for (size_t i = 0; i < J->n; i++) {
     if (J->pts[i].inf) continue;
-    u64 lo = J->sc[i][bit >> 6] >> (bit & 63);
-    if ((bit & 63) + c > 64 && (bit >> 6) < 3) lo |= J->sc[i][(bit >> 6) + 1] << (64 - (bit & 63));
-    u64 d = lo & (((u64)1 << c) - 1);
-    if (d) g1_add_mixed(&buckets[d - 1], &buckets[d - 1], &J->pts[i]);
+    const int32_t d = signed_digit(J->sc[i], c, J->nw, w);
+    if (d > 0) g1_add_mixed(&buckets[d - 1], &buckets[d - 1], &J->pts[i]);
+    else if (d < 0) { g1_aff m = J->pts[i]; fe_neg(&FQ, &m.y, &m.y); g1_add_mixed(&buckets[-d - 1], &buckets[-d - 1], &m); }
   }
   g1_jac run, ws; g1_jac_inf(&run); g1_jac_inf(&ws);
   for (size_t b = nb; b-- > 0;) { g1_add(&run, &run, &buckets[b]); g1_add(&ws, &ws, &run); }

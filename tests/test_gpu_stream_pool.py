@@ -311,6 +311,21 @@ def test_pool_failover_reproves_a_failed_replicas_chunks_on_the_others(prover):
         pool.revive(0)
         pool.revive(1)
         assert pool.prove_raw(inp, rsb) == ref
+        # probation (what an FFI object's pool runs with: its callers cannot call revive): a quarantined replica sits
+        # out two jobs and is handed work again by itself; with nobody left everybody is tried again at once
+        pool.set_probation(2)
+        pool.inject_fault(1, after_chunks=1)
+        assert pool.prove_raw(inp, rsb) == ref and pool.health()[1][0]
+        for _ in range(2):
+            assert pool.prove_raw(inp, rsb) == ref and pool.last_proofs() == [n, 0]
+        assert pool.prove_raw(inp, rsb) == ref and all(pool.last_proofs()) and not pool.health()[1][0]
+        pool.inject_fault(0, after_chunks=0)
+        assert pool.prove_raw(inp, rsb) == ref and pool.health()[0][0]
+        pool.inject_fault(1, after_chunks=0)
+        with pytest.raises(RLNError, match="no replica left"):
+            pool.prove_raw(inp, rsb)
+        assert [q for q, _ in pool.health()] == [True, True]
+        assert pool.prove_raw(inp, rsb) == ref and all(pool.last_proofs())   # both back at once
     finally:
         pool.close()
     pool = ProverPool(devices=[0] * 8, max_batch=64, window_bits=8)

@@ -145,3 +145,43 @@ def test_c_oracle_on_the_other_shipped_circuits_vs_goldens_and_pyref():
                 wi = pr.WitnessInput(w["identitySecret"][0], w["userMessageLimit"][0], w["messageId"][0], w["pathElements"],
                                      w["identityPathIndex"], w["x"][0], w["externalNullifier"][0])
                 assert pub[i] == pr.public_inputs(pr.proof_values_from_witness(wi))
+
+
+def test_c_partial_and_finish_vs_pyref_fixture_and_goldens():
+    """oracle/c's generate_partial_zk_proof / finish_zk_proof_with_rs (proof.rs:783-849, partial_proof.rs:108-274,
+    graph.rs:274-312) against the pyref-generated fixture tests/golden/rln_h20_partial.json: the known-signal mask, the
+    four partial points byte for byte, and finish(partial) == the golden FULL proof of the same (witness, r, s) -- the
+    equality rln/tests/protocol.rs:222-248 asserts -- including the r = 0 branch (g1_b = 0, partial_proof.rs:242-248)."""
+    import hashlib
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "rln_h20_partial.json")))
+    c = ob.Circuit(20)
+    mask = c.known_mask()
+    assert (len(mask), sum(mask)) == (fx["mask_len"], fx["mask_known"]) and mask[0] and not mask[1] and mask[2]
+    assert hashlib.sha256(bytes(int(b) for b in mask)).hexdigest() == fx["mask_sha256"]
+    cases = {k["name"]: k for k in _cases()}
+    for f in fx["cases"]:
+        case = cases[f["name"]]
+        packed = c.pack(_w(case))
+        # the unknown slots are not read: garbage there gives the same partial proof
+        junk = bytearray(packed)
+        for slot in (1, 2, 5):
+            junk[32 * slot:32 * slot + 32] = (12345678901234567890 + slot).to_bytes(32, "little")
+        part = c.prove_partial_packed(packed)
+        assert part.hex() == f["partial320"], f["name"]
+        assert c.prove_partial_packed(bytes(junk)) == part
+        got = c.finish_packed(packed, int(case["r"]), int(case["s"]), part)
+        assert got.hex() == case["proof_compressed"], f["name"]
+    # many at once on threads == one by one
+    ws = [_w(cases[n]) for n in ("config2_0", "config2_1", "config2_2")]
+    rs = [(int(cases[n]["r"]), int(cases[n]["s"])) for n in ("config2_0", "config2_1", "config2_2")]
+    packed = [c.pack(w) for w in ws]
+    parts = [c.prove_partial_packed(p) for p in packed]
+    _, proofs = c.finish_many_packed(b"".join(packed), b"".join(ob._b(r) + ob._b(s) for r, s in rs), b"".join(parts), threads=3)
+    assert [p.hex() for p in proofs] == [cases[n]["proof_compressed"] for n in ("config2_0", "config2_1", "config2_2")]
+
+
+def test_c_field_product_forms_agree():
+    """the mulx / adcx / adox product this build took (where the CPU has ADX + BMI2) against the portable CIOS product
+    it replaced, both fields, random and edge operands"""
+    assert ob.lib().oracle_selftest_mul(0xC0FFEE, 300000) == 1
+    assert ob.lib().oracle_mul_kind() in (b"mulx/adcx/adox", b"portable (unsigned __int128)")

@@ -173,6 +173,7 @@ SIGNATURES = {
     "rlnamd_pool_set_failover": (C.c_int, [P, C.c_int]),
     "rlnamd_pool_health": (C.c_int, [P, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     "rlnamd_pool_revive": (C.c_int, [P, C.c_size_t]),
+    "rlnamd_pool_set_probation": (C.c_int, [P, C.c_size_t]),
     "rlnamd_pool_verify_many": (C.c_int, [P, C.c_size_t, C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_char_p]),
     "rlnamd_comm_unique_id": (C.c_int, [C.c_char_p]),
     "rlnamd_comm_init_rank": (C.c_int, [C.c_char_p, C.c_int, C.c_int, PP]),

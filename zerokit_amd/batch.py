@@ -418,6 +418,10 @@ class ProverPool:
     def revive(self, replica):
         check(lib().rlnamd_pool_revive(self._h, replica))
 
+    def set_probation(self, jobs):
+        """jobs > 0: a quarantined replica sits out that many jobs and is then handed work again by itself"""
+        check(lib().rlnamd_pool_set_probation(self._h, jobs))
+
     def verify_many(self, proofs, public_inputs, threads=0):
         n = len(proofs)
         if n == 0:

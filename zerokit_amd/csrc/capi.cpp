@@ -7,6 +7,7 @@
 #include <atomic>
 #include <system_error>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <string>
 
@@ -30,6 +31,9 @@ int fail(const std::exception& e) {
 }  // namespace rlnamd
 
 struct rlnamd_tree {
+  // every rlnamd_tree_* call on one handle takes this: the tree has ONE stream and shared scratch (proof_host's
+  // staging buffer, the host chain's pinned buffers), so readers mutate object state too
+  std::mutex mu;
   MerkleTreeDev t;
   size_t host_max = 0;   // rlnamd_tree_set_leaves: up to this many distinct leaves take MerkleTreeDev::set_few
   DevBuf<uint8_t> bench_elems, bench_bits;
@@ -119,6 +123,7 @@ void rlnamd_tree_free(rlnamd_tree* t) { delete t; }
 
 int rlnamd_tree_set_range(rlnamd_tree* t, size_t start, const uint8_t* leaves_le, size_t n) {
   RLN_TRY
+  std::lock_guard<std::mutex> tree_lk(t->mu);
   for (size_t i = 0; i < n; i++) {
     uint32_t tmp[8];
     memcpy(tmp, leaves_le + 32 * i, 32);
@@ -129,6 +134,7 @@ int rlnamd_tree_set_range(rlnamd_tree* t, size_t start, const uint8_t* leaves_le
 }
 int rlnamd_tree_set_leaves(rlnamd_tree* t, const uint64_t* indices, const uint8_t* leaves_le, size_t k) {
   RLN_TRY
+  std::lock_guard<std::mutex> tree_lk(t->mu);
   // any order, later entries win: brought to the strictly increasing form the pass wants
   std::vector<std::pair<uint64_t, size_t>> ord(k);
   for (size_t i = 0; i < k; i++) {
@@ -153,22 +159,26 @@ int rlnamd_tree_set_leaves(rlnamd_tree* t, const uint64_t* indices, const uint8_
 }
 int rlnamd_tree_root(rlnamd_tree* t, uint8_t out_le[32]) {
   RLN_TRY
+  std::lock_guard<std::mutex> tree_lk(t->mu);
   t->t.get_node_host(0, out_le);
   RLN_CATCH
 }
 int rlnamd_tree_get_leaf(rlnamd_tree* t, size_t index, uint8_t out_le[32]) {
   RLN_TRY
+  std::lock_guard<std::mutex> tree_lk(t->mu);
   if (index >= t->t.capacity()) throw Error("InvalidLeaf");
   t->t.get_node_host(t->t.capacity() - 1 + index, out_le);
   RLN_CATCH
 }
 int rlnamd_tree_proof(rlnamd_tree* t, size_t index, uint8_t* elems_le, uint8_t* bits) {
   RLN_TRY
+  std::lock_guard<std::mutex> tree_lk(t->mu);
   t->t.proof_host(index, elems_le, bits);
   RLN_CATCH
 }
 int rlnamd_tree_proofs(rlnamd_tree* t, size_t first, size_t count, uint8_t* elems_le, uint8_t* bits) {
   RLN_TRY
+  std::lock_guard<std::mutex> tree_lk(t->mu);
   if (count == 0 || t->t.depth == 0) return RLNAMD_OK;
   size_t d = t->t.depth;
   DevBuf<uint8_t> e(count * d * 32), b(count * d);
@@ -180,12 +190,14 @@ int rlnamd_tree_proofs(rlnamd_tree* t, size_t first, size_t count, uint8_t* elem
 }
 int rlnamd_tree_fill_sequential(rlnamd_tree* t, size_t start, size_t n, uint64_t first_value) {
   RLN_TRY
+  std::lock_guard<std::mutex> tree_lk(t->mu);
   t->t.fill_sequential_device(start, n, first_value);
   RLN_HIP(hipStreamSynchronize(t->t.stream));
   RLN_CATCH
 }
 int rlnamd_tree_bench(rlnamd_tree* t, size_t n_leaves, uint64_t first_value, int verify, float ms[2], size_t* bad) {
   RLN_TRY
+  std::lock_guard<std::mutex> tree_lk(t->mu);
   MerkleTreeDev& T = t->t;
   if (n_leaves > T.capacity()) throw Error("TooManySet");
   size_t d = T.depth;

@@ -427,6 +427,7 @@ struct FFI_RLN {
         throw Error(std::string("Configuration error: devices: ") + rlnamd_last_error());
       rlnamd_pool_set_dynamic(pool, tcfg.dynamic_shards ? 1 : 0);
       rlnamd_pool_set_failover(pool, (int)tcfg.failover);
+      rlnamd_pool_set_probation(pool, tcfg.failover > 0 ? (size_t)tcfg.revive_after : 0);
       prover = std::shared_ptr<Prover>(rlnamd_pool_replica_prover(pool, 0), [](Prover*) {});
     } else {
       // A default object (no "profile" / "window_bits" / "max_batch" key, no RLNAMD_* sizing) takes the latency point:

@@ -72,7 +72,8 @@ struct Replica {
   std::vector<Chunk> taken;
   size_t rest_lo = 0, rest_hi = 0;
   size_t failures = 0;        // dispatches that ended in an error (pool lifetime)
-  bool quarantined = false;   // failed under failover: handed nothing until rlnamd_pool_revive
+  bool quarantined = false;   // failed under failover: handed nothing until rlnamd_pool_revive (or its probation ends)
+  size_t sat_out = 0;         // jobs it has sat out since it was quarantined
 };
 
 }  // namespace
@@ -101,6 +102,11 @@ struct rlnamd_pool {
   // many times per job; the failed replica is quarantined (rlnamd_pool_health, rlnamd_pool_revive).  The job fails only
   // when no replica is left or the rounds are spent.
   int failover_rounds = 0;
+  // rlnamd_pool_set_probation: a quarantined replica sits out this many jobs and is then handed work again without a
+  // call to rlnamd_pool_revive (a transient error must not remove a device for the pool's lifetime: callers behind the
+  // FFI object have no handle on the pool); 0 = quarantine until revived.  A replica that fails again is quarantined
+  // again, and its chunks go to the others as before.
+  size_t probation_jobs = 0;
   std::vector<Chunk> redo;
   std::atomic<size_t> redo_cursor{0};
 
@@ -158,10 +164,10 @@ struct rlnamd_pool {
             }
             *off = o;
             R->taken.emplace_back(o, *cnt);   // (before the fault hook: a chunk that was drawn from a shared cursor is this replica's to account for)
-            if (fault_replica.load() >= 0 && rep[(size_t)fault_replica.load()].get() == R && R->chunks_taken >= fault_after) {
-              fault_replica.store(-1);
+            long fr = fault_replica.load();   // ONE load: another worker may clear it between two
+            if (fr >= 0 && (size_t)fr < rep.size() && rep[(size_t)fr].get() == R && R->chunks_taken >= fault_after &&
+                fault_replica.compare_exchange_strong(fr, -1))   // fires exactly once
               throw Error("injected fault (rlnamd_pool_inject_fault)");
-            }
             R->chunks_taken++;
             made += *cnt;
             return true;
@@ -278,8 +284,15 @@ int rlnamd_pool_prove(rlnamd_pool* p, size_t n, const uint8_t* inputs_le, const 
   std::vector<Replica*> team;   // who is handed work in this round
   for (auto& R : p->rep) {
     R->last_proofs = 0;
+    if (R->quarantined && p->probation_jobs > 0 && R->sat_out >= p->probation_jobs) R->quarantined = false;
     if (!R->quarantined) team.push_back(R.get());
+    else R->sat_out++;
   }
+  if (team.empty() && p->probation_jobs > 0)   // nobody left and probation is on: everybody gets another chance now
+    for (auto& R : p->rep) {
+      R->quarantined = false;
+      team.push_back(R.get());
+    }
   if (team.empty()) throw Error("rlnamd_pool_prove: every replica is quarantined (rlnamd_pool_revive)");
   p->cursor.store(0);
   std::string first_error;
@@ -324,7 +337,10 @@ int rlnamd_pool_prove(rlnamd_pool* p, size_t n, const uint8_t* inputs_le, const 
       again.insert(again.end(), R->taken.begin(), R->taken.end());
       const size_t cap = R->prover->capacity();
       for (size_t at = R->rest_lo; at < R->rest_hi; at += cap) again.emplace_back(at, std::min(cap, R->rest_hi - at));
-      if (p->failover_rounds > 0) R->quarantined = true;
+      if (p->failover_rounds > 0) {
+        R->quarantined = true;
+        R->sat_out = 0;
+      }
     }
     if (again.empty()) break;   // every chunk of the job has been proved by a replica that finished its dispatch
     if (round >= p->failover_rounds) throw Error("rlnamd_pool_prove: " + first_error);
@@ -352,6 +368,11 @@ int rlnamd_pool_inject_fault(rlnamd_pool* p, size_t replica, size_t after_chunks
 int rlnamd_pool_set_failover(rlnamd_pool* p, int rounds) {
   std::lock_guard<std::mutex> job_lk(p->job_mu);
   p->failover_rounds = rounds > 0 ? rounds : 0;
+  return RLNAMD_OK;
+}
+int rlnamd_pool_set_probation(rlnamd_pool* p, size_t jobs) {
+  std::lock_guard<std::mutex> job_lk(p->job_mu);
+  p->probation_jobs = jobs;
   return RLNAMD_OK;
 }
 int rlnamd_pool_health(rlnamd_pool* p, int* quarantined_per_replica, size_t* failures_per_replica) {

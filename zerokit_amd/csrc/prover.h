@@ -57,6 +57,8 @@ struct ProverTuning {
                                        // LDS per proof: ceil(n / 256) x 1.5 ms against 11 ms for lanes = proofs; lone 512 / 1 024-proof
                                        // batches 46.9 -> 38.0 / 74.0 -> 68.5 ms, the first batch of a stream 5 ms earlier)
   uint32_t tiny_max = 5;               // RLNAMD_TINY: largest lone batch walked with ONE (row, half) per lane (0: never); 5 proofs 3.15 -> 3.0 ms, 6 even, 8 slower
+  uint32_t ntt_lg_max = 96;            // RLNAMD_NTT_LG_MAX: largest small batch whose NTTs run as the three LDS kernels (above, the
+                                       // single-wave passes finish earlier beside the walks: 128 proofs 13.2 -> 12.6 ms)
   // ---- shapes (1 = default)
   bool glv = true;                     // RLNAMD_GLV: walk the 127-bit GLV halves (0: the plain 255-bit walk)
   bool wit29 = true;                   // RLNAMD_WIT29: interpreter in the 9 x 29 form (0: the 8 x 32 fallback k_witness)

@@ -227,6 +227,12 @@ struct Prover::Impl {
     const size_t PB = S.PB ? S.PB : B;
     rows16(S.part1.p, S.PB ? S.nch1 : S.part1.n / PB, PB * (sizeof(G1XYZZ) / 16), std::min(np, PB) * (sizeof(G1XYZZ) / 16));
     rows16(S.part2.p, S.PB ? S.nch2 : S.part2.n / PB, PB * (sizeof(G2XYZZ) / 16), std::min(np, PB) * (sizeof(G2XYZZ) / 16));
+    // what the sums leave behind: block sums of the same partials, the UNBLINDED A / B / C sums (with the
+    // public proof they give r delta and s delta), the affine A / B1 / B2, the ladder's products and tables.  A few MB:
+    // whole buffers, whatever shape the batch had.
+    auto whole = [&](auto& buf) { if (buf.p) zero(buf.p, buf.bytes() / 32 * 32); };
+    whole(S.grp1); whole(S.grp2); whole(S.sums1); whole(S.sums2); whole(S.prod); whole(S.tbl);
+    whole(S.affA); whole(S.affB1); whole(S.affB2);
     RLN_HIP(hipGetLastError());
     RLN_HIP(hipEventRecord(S.evZ, sW));
     S.wiped = true;
@@ -278,16 +284,17 @@ ProverTuning ProverTuning::from_env() {
   t.fused_smul = env_int("RLNAMD_FUSED_SMUL", 1) != 0;
   t.values_from_witness = env_int("RLNAMD_VALUES_WITNESS", 1) != 0;
   t.tiny_max = (uint32_t)std::max(0, env_int("RLNAMD_TINY", (int)t.tiny_max));
+  t.ntt_lg_max = (uint32_t)std::max(0, env_int("RLNAMD_NTT_LG_MAX", (int)t.ntt_lg_max));
   t.marks_small = env_int("RLNAMD_MARKS_SMALL", 0) != 0;
   return t;
 }
 std::string ProverTuning::describe() const {
   char b[512];
   snprintf(b, sizeof b,
-           "window_bits=%d slots=%d lanechunk=%u lanechunk_walk=%u witlanes_max=%u tiny=%u glv=%d wit29=%d lone=%d early_walk=%d "
-           "early_fin=%d fused_smul=%d values_from_witness=%d marks_small=%d",
-           window_bits, slots, lanechunk_max, lanechunk_walk_max, witlanes_max, tiny_max, (int)glv, (int)wit29, lone, (int)early_walk,
-           (int)early_fin, (int)fused_smul, (int)values_from_witness, (int)marks_small);
+           "window_bits=%d slots=%d lanechunk=%u lanechunk_walk=%u witlanes_max=%u tiny=%u ntt_lg_max=%u glv=%d wit29=%d lone=%d "
+           "early_walk=%d early_fin=%d fused_smul=%d values_from_witness=%d marks_small=%d",
+           window_bits, slots, lanechunk_max, lanechunk_walk_max, witlanes_max, tiny_max, ntt_lg_max, (int)glv, (int)wit29, lone,
+           (int)early_walk, (int)early_fin, (int)fused_smul, (int)values_from_witness, (int)marks_small);
   return b;
 }
 const ProverTuning& Prover::tuning() const { return d_->tune; }
@@ -1470,8 +1477,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     // (above ~100 proofs the walks beside the quotient chain leave the 4-wave workgroups of the LDS kernels waiting for
     // four free wave slots on one CU: the single-wave passes then finish earlier -- 128 proofs 13.3 -> 12.6 ms, 96 and
     // below no better or worse; RLNAMD_NTT_LG_MAX)
-    static const uint32_t ntt_lg_max = (uint32_t)env_int("RLNAMD_NTT_LG_MAX", 96);
-    if (lg && nb <= ntt_lg_max && D.logn >= 9 && D.logn <= 18) {
+    if (lg && nb <= D.tune.ntt_lg_max && D.logn >= 9 && D.logn <= 18) {
       // iNTT, coset scaling and NTT as edge / mid / edge: one butterfly per lane per level (prover_front.hip: k_ntt_mid)
       const dim3 grid(nb, D.n >> 9, 3);
       if (D.logn > 9) hipLaunchKernelGGL(k_ntt_edge<true>, grid, dim3(256), 0, sA2, S.abc.p, D.tw_i.p, D.logn, B, nb);
@@ -1876,6 +1882,11 @@ void Prover::residue(uint64_t out[RESIDUE_FIELDS]) {
   count(2, S.abc.p, S.abc.bytes());
   count(3, S.part1.p, S.part1.bytes());
   count(4, S.part2.p, S.part2.bytes());
+  for (auto* b : {&S.grp1, &S.sums1, &S.prod, &S.tbl}) count(3, b->p, b->bytes());
+  for (auto* b : {&S.grp2, &S.sums2}) count(4, b->p, b->bytes());
+  count(3, S.affA.p, S.affA.bytes());
+  count(3, S.affB1.p, S.affB1.bytes());
+  count(4, S.affB2.p, S.affB2.bytes());
   count(5, S.inputs.p, S.inputs.bytes());
   count(5, S.rs.p, S.rs.bytes());
   RLN_HIP(hipGetLastError());

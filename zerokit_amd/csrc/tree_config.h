@@ -49,9 +49,11 @@ struct TreeConfig {
   bool has_devices = false;
   // with "devices": "dynamic_shards": true = rlnamd_pool_set_dynamic (the replicas draw chunks from a shared cursor instead
   // of taking contiguous shards); "failover": k = rlnamd_pool_set_failover (a failing device's chunks are proved again
-  // by the others, up to k times per call, and the device is left out of later calls)
+  // by the others, up to k times per call, and the device is left out of the next "revive_after" batch calls -- 8 unless
+  // the key says otherwise, 0 = for the object's lifetime)
   bool dynamic_shards = false;
   long failover = 0;
+  long revive_after = 8;
   bool persistent() const { return !temporary && has_path; }
   ProverConfig prover_config() const {
     ProverConfig cfg;
@@ -171,6 +173,10 @@ inline TreeConfig parse_tree_config(const std::string& js) {
       if (key == "failover") {
         if (num < 0 || num > 64) throw Error("Configuration error: failover: expected 0 .. 64 rounds");
         c.failover = num;
+      }
+      if (key == "revive_after") {
+        if (num < 0 || num > 1000000) throw Error("Configuration error: revive_after: expected 0 .. 1000000 calls");
+        c.revive_after = num;
       }
       i = j;
     } else {
