@@ -37,6 +37,12 @@ Extra objects on the line (every fraction can be recomputed from the line itself
                   v_mad_u64_u32 can reach, 614.4 G/s; the 2-cycle one, 1 228.8 G/s, only plain 32-bit ops reach).
   stage_ms      {"overlapped": spans inside the pipelined timed region (each includes whatever shared the chip with it),
                  "alone": the same stages of ONE batch with nothing else in flight}
+  sustained     the same stream continued for --sustained-seconds (default 10 s) behind the timed region: proofs/s, the
+                clock the walks held, the ratio to `value` (which, at the driver's K = 20, is 0.9 s inside the boost window)
+  finish        finish_zk_proof_with_rs from cached partial proofs (the reference's one published claim,
+                rln/README.md:370-375): proofs/s at 1024 per batch and one finish per call, beside the full-proof
+                figures and beside oracle/c's full / partial / finish on the host (`finish.cpu_baseline`); every finished
+                proof byte-identical to the full proof of the same (witness, r, s); the partial points judged by oracle/c
   cpu_baseline  oracle/c (kind "port") on the host's usable cores, N = 1 only: config 2 (`value`, proofs/s) plus
                 `config3` (2^20-leaf tree build on all cores, one single-leaf update + root, 1 000 scattered updates + root)
                 and `config5` (msm_bigint Pippenger on all cores over a 2^20-point sample of the workload, x 16 stated)
@@ -89,7 +95,7 @@ def walk_source_hash():
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(ws, rs, target_seconds=10.0):
+def cpu_baseline(ws, rs, target_seconds=10.0, want=("config3", "config5")):
     """Times oracle/c (the C restatement of the arkworks CPU path) on bounded samples; returns the dict for the JSON
     line or None when the oracle library has not been built."""
     try:
@@ -101,6 +107,8 @@ def cpu_baseline(ws, rs, target_seconds=10.0):
     except Exception as e:  # noqa: BLE001
         return {"error": str(e)}
     cores = out["cores"]
+    if "config3" not in want and "config5" not in want:
+        return out
     try:   # config 3: FullMerkleTree::set_range over 2^20 leaves on all cores + the mutation calls (full_merkle_tree.rs)
         t = ob.tree_bench(20, 1 << 20, first_value=1, threads=cores, singles=TREE_SINGLES, scattered=TREE_SCATTERED)
         out["config3"] = {
@@ -877,7 +885,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("RLNAMD_BENCH_BATCH", "1024")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-side-configs", action="store_true", help="skip the config3 / config5 / finish objects")
+    ap.add_argument("--no-side-configs", action="store_true", help="= --side none")
+    ap.add_argument("--side", default="all", help="side objects of the default line, comma list of latency, finish, config3, "
+                                                  "config5 (all | none)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="bound of the cpu_baseline's config-2 sample")
     ap.add_argument("--sustained-seconds", type=float, default=float(os.environ.get("RLNAMD_BENCH_SUSTAINED_S", "10")),
                     help="after the timed region: this many seconds of back-to-back batches (0: skip)")
     ap.add_argument("--workload", default="proofs", choices=["proofs", "merkle", "msm", "finish", "operating-points"],
@@ -890,6 +901,11 @@ def main():
     if args.workload == "operating-points":
         return operating_points_main(args)
 
+    side_all = ("latency", "finish", "config3", "config5")
+    want = set() if (args.no_side_configs or args.side == "none") else \
+        set(side_all) if args.side == "all" else {x.strip() for x in args.side.split(",") if x.strip()}
+    if want - set(side_all):
+        raise SystemExit("bench: --side takes %s" % ", ".join(side_all))
     under_torchrun = "WORLD_SIZE" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if under_torchrun and world != args.gpus:
@@ -1034,6 +1050,10 @@ def main():
                              "host_cores_busy = process CPU time / wall over the timed region, all threads (the HIP / ROCr "
                              "runtime's own threads included); calling_thread_cores_busy = the thread that calls submit / "
                              "collect (it polls and sleeps while a big batch runs: Prover::collect)"}
+    if finish and 0 in results:   # the finished proofs of batch 0 against a FULL proof of the same (witness, r, s)
+        t, _ = prover.submit(batches[0][0], batches[0][1])
+        full0 = prover.collect_raw(t, B)
+        ok = bool(ok and full0[0] == results[0][0] and not any(full0[2]))
     clock_mhz = prover.walk_clock_mhz()   # mean shader clock under the two walks over the timed region
     stage_ms = prover.stage_ms()          # HIP-event spans, mean over the last five launches (overlapped with their neighbours)
     # the dominant kernel by itself: single batches with nothing else in flight (outside the timed region)
@@ -1054,7 +1074,7 @@ def main():
     # the other end of the same prover: ONE proof per call (what a caller of the reference does, rln/README.md:324-332),
     # submit -> collect with nothing else in flight; outside the timed region, reported beside the headline
     latency = None
-    if not finish and not args.no_side_configs and world == 1:
+    if not finish and "latency" in want and world == 1:
         one = workload.config2_packed(prover.slots, prover.inputs_size, first, 1)
         ts = []
         for i in range(9):
@@ -1067,12 +1087,60 @@ def main():
         latency = {"ms_min": round(min(ts), 3), "ms_median": round(sorted(ts)[len(ts) // 2], 3), "calls": len(ts),
                    "what": "one proof per call on the bench's prover (228 GiB tables): submit + collect, H2D and D2H included",
                    "same_bytes_as_in_the_batch": same}
+    # ---- the steady state: `value` above times K steps -- under a second at the driver's K = 20, i.e. inside
+    #      the boost window of the power management.  Here the same stream runs for --sustained-seconds with every slot
+    #      in flight; proofs/s, the clock the walks held and the ratio to `value` go on the line.
+    sustained = None
+    if not finish and world == 1 and args.sustained_seconds > 0 and args.steps > 0:
+        timed_first = {k: r[0][:256] for k, r in results.items()}
+        prover.walk_clock_mhz()
+        sync()
+        t0 = time.perf_counter()
+        j, errs_seen = 0, 0
+        while True:
+            if len(inflight) == nslots:
+                t, kk = inflight.popleft()
+                results[kk] = prover.collect_raw(t, B)
+                errs_seen += int(any(results[kk][2]))
+            if time.perf_counter() - t0 >= args.sustained_seconds:
+                break
+            inflight.append((prover.submit(batches[j % nbatches][0], batches[j % nbatches][1])[0], j % nbatches))
+            j += 1
+        while inflight:
+            t, kk = inflight.popleft()
+            results[kk] = prover.collect_raw(t, B)
+            errs_seen += int(any(results[kk][2]))
+        sync()
+        s_elapsed = time.perf_counter() - t0
+        s_clock = prover.walk_clock_mhz()
+        s_rate = j * B / s_elapsed
+        sustained = {"proofs_per_s": round(s_rate, 1), "seconds": round(s_elapsed, 2), "batches": j,
+                     "ms_per_batch": round(s_elapsed / max(j, 1) * 1e3, 3),
+                     "ratio_to_value": round(s_rate / (world * B * per_step * args.steps / elapsed), 4),
+                     "shader_clock_mhz": {k: round(v, 1) for k, v in s_clock.items()},
+                     "shader_clock_mhz_timed_region": {k: round(v, 1) for k, v in clock_mhz.items()},
+                     "same_bytes_as_the_timed_region": bool(errs_seen == 0 and all(results[k][0][:256] == v for k, v in timed_first.items())),
+                     "what": "the timed region's stream of distinct batches continued for --sustained-seconds with every "
+                             "workspace slot in flight (H2D and D2H inside): the rate at the clock the power management "
+                             "holds once its boost window is over.  `value` is the contract's K-step figure"}
+        ok = bool(ok and sustained["same_bytes_as_the_timed_region"])
+    # ---- SURVEY 8(f) rank 2 on the line: finish-from-partial, rate and latency, beside the full-proof figures
+    finish_obj, finish_part0 = None, None
+    if not finish and "finish" in want and world == 1 and args.steps > 0:
+        try:
+            finish_obj, parts = measure_finish(prover, batches, results, B, world * B * per_step * args.steps / elapsed,
+                                               latency["ms_median"] if latency else None)
+            finish_part0 = parts[0][0]
+            ok = bool(ok and finish_obj["correct"])
+        except Exception as e:  # noqa: BLE001
+            finish_obj = {"error": str(e), "correct": False}
+            ok = False
     prover.close()
 
     # ---- the other single-GPU BASELINE configs, with the prover's HBM released
     side = {}
     hung = False
-    if not args.no_side_configs and not finish:
+    if want & {"config3", "config5"} and not finish:
         # N > 1: the config-5 MSM is the one place with a collective (ncclAllGather through the C ABI).  It runs on a
         # helper thread with a deadline: a rank that fails before its collective would leave the others blocked in theirs,
         # and a blocked RCCL call cannot be cancelled -- the headline line must come out regardless.
@@ -1084,10 +1152,11 @@ def main():
                 check(lib().rlnamd_set_device(local_rank))   # the current device is per-thread state (HIP and torch)
                 if use_dist and backend == "nccl":
                     torch.cuda.set_device(local_rank)
-                if world == 1:
+                if world == 1 and "config3" in want:
                     side["config3"] = measure_config3()
-                comm = make_comm(rank, world, dist)
-                side["config5"] = measure_config5(comm, rank, world)
+                if "config5" in want:
+                    comm = make_comm(rank, world, dist)
+                    side["config5"] = measure_config5(comm, rank, world)
             except Exception as e:  # noqa: BLE001
                 side["side_config_error"] = str(e)
             finally:
@@ -1200,6 +1269,10 @@ def main():
         line.update(side)
         if latency is not None:
             line["single_proof_latency"] = latency
+        if sustained is not None:
+            line["sustained"] = sustained
+        if finish_obj is not None:
+            line["finish"] = finish_obj
         if host_feed is not None:
             line["host_feed"] = host_feed
         # how many ranks RCCL really had: the communicator created through the C ABI for config 5 when it ran, else the
@@ -1218,7 +1291,20 @@ def main():
                   file=sys.stderr)
             sys.exit(4)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(ws0, rs0)
+            line["cpu_baseline"] = cpu_baseline(ws0, rs0, args.cpu_seconds, want)
+            if finish_obj is not None and line["cpu_baseline"] and "cores" in line["cpu_baseline"]:
+                try:   # the reference's own comparison (full vs finish, one call on a CPU) restated beside the GPU's
+                    fb, part0, fin0 = cpu_finish_baseline(ws0, rs0, line["cpu_baseline"]["cores"])
+                    # the oracle judges the product's partial points and the product's finished proof of witness 0
+                    fb["gpu_partial_points_equal_oracle"] = bool(finish_part0 == part0)
+                    fb["gpu_finish_equals_oracle_finish"] = bool(0 in results and results[0][0][:128] == fin0)
+                    finish_obj["cpu_baseline"] = fb
+                    finish_obj["correct"] = bool(finish_obj["correct"] and fb["gpu_partial_points_equal_oracle"]
+                                                 and fb["gpu_finish_equals_oracle_finish"] and fb["finish_equals_full"])
+                    ok = bool(ok and finish_obj["correct"])
+                    line["config"]["verified"] = ok
+                except Exception as e:  # noqa: BLE001
+                    finish_obj["cpu_baseline"] = {"error": str(e)}
         OUT.emit(line)
     if hung:            # a thread is stuck inside a collective: leave without the runtime's teardown
         sys.stdout.flush()

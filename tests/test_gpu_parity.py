@@ -204,18 +204,19 @@ def test_batch_vs_python_oracle_random(prover):
 def test_full_size_batch_1024_bit_exact_vs_c_oracle():
     """BASELINE config 2 at full size: all 1024 proofs of the bench workload are bit-identical to the C oracle
     (proof bytes and public values), pipelined twice to cover both workspace slots, and a sample verifies."""
-    from oracle.c import binding as ob
+    from conftest import oracle_config2
     from oracle.pyref import workload
     from zerokit_amd.batch import BatchProver
     n = 1024
-    ws, rs = workload.config2_witnesses(n)
+    ws, rs, ref_proofs, ref_pub = oracle_config2(0, n)
+    w3, r3 = workload.config2_witnesses(3)       # the Python oracle's own generator of the same stream
+    assert (ws[:3], rs[:3]) == (w3, r3)
     p = BatchProver(max_batch=n)
     p.upload(p.pack_inputs(ws), rs)
     p.run_async(n)
     p.run_async(n)          # second slot; must reproduce the same bytes
     p.run_async(n)
     out = p.download(n)
-    _, ref_proofs, ref_pub = ob.Circuit(20).prove_many(ws, rs)
     assert all(o["error"] == 0 for o in out)
     assert [o["proof"] for o in out] == ref_proofs
     assert [o["public_inputs"] for o in out] == ref_pub
@@ -341,6 +342,50 @@ def test_ffi_round_trip_like_reference_tests():
     assert a.get_root() == RLN(20).get_root() and a.leaves_set() == 0
 
 
+_SCATTERED = {}
+
+
+def _scattered_plan_and_oracle():
+    """the update stream of test_tree_scattered_updates_one_pass_vs_oracle and what oracle/c's FullMerkleTree answers at
+    every step -- the same for each of the four host-chain thresholds, so the oracle walks it ONCE per session (30 000
+    set() calls of 20 hashes on one core)"""
+    if _SCATTERED:
+        return _SCATTERED
+    from oracle.c import binding as ob
+    rnd = random.Random(77)
+    small = []
+    for depth in (0, 1, 3):
+        o = ob.Tree(depth)
+        ups = [(rnd.randrange(1 << depth), rnd.randrange(1, R)) for _ in range(5)]
+        for i, v in ups:
+            o.set(i, v)
+        small.append((depth, ups, o.root()))
+        o.close()
+    depth = 20
+    o = ob.Tree(depth)
+    o.set_range(0, list(range(1, (1 << 14) + 1)), threads=4)
+    root0 = o.root()
+    steps = []
+    for k in (1, 1, 2, 5, 6, 7, 8, 9, 21, 84, 85, 86, 1000, 30000):
+        ups = [(rnd.randrange(1 << depth), rnd.randrange(1, R)) for _ in range(k)]
+        if k == 5:
+            ups += [(ups[0][0] ^ 1, 17), (ups[1][0] ^ 2, 18)]      # a sibling and a cousin of dirty leaves
+        if k >= 21:
+            ups += [(ups[0][0], 5), (ups[1][0], 0), (ups[0][0], 6)]      # rewrites: the last one wins
+        last = dict(ups)
+        for i, v in last.items():
+            o.set(i, v)
+        probe = list(last)[:3] + [0, (1 << depth) - 1]
+        steps.append((k, ups, last, o.root(), [(i, o.proof(i)) for i in probe]))
+    # neighbours: both children of one parent dirty, whole aligned blocks dirty
+    ups = [(i, 1000 + i) for i in range(4096, 4096 + 257)] + [(1 << 19, 1), ((1 << 19) + 1, 2)]
+    for i, v in ups:
+        o.set(i, v)
+    _SCATTERED.update(small=small, root0=root0, steps=steps, last_ups=ups, last_root=o.root())
+    o.close()
+    return _SCATTERED
+
+
 @pytest.mark.parametrize("host_max", ["0", None, "8", "4096"])
 def test_tree_scattered_updates_one_pass_vs_oracle(host_max, monkeypatch):
     """(host_max: the largest pass that runs its dependent chain on a host core -- MerkleTreeDev::set_few: one gather of
@@ -350,51 +395,32 @@ def test_tree_scattered_updates_one_pass_vs_oracle(host_max, monkeypatch):
     calls of FullMerkleTree (full_merkle_tree.rs:141-147,336-399) -- for k = 1 (the whole path in one launch), 21 / 84 /
     85 / 86 (around the capacity of the single-workgroup tail), 1 000, 30 000 (more dirty parents than the three-lane
     kernel takes) and on small depths (0, 1, 3); duplicates keep the last write; root, leaves and paths vs oracle/c"""
-    from oracle.c import binding as ob
     from zerokit_amd.batch import PoseidonTree
     if host_max is None:
         monkeypatch.delenv("RLNAMD_TREE_HOST_MAX", raising=False)
     else:
         monkeypatch.setenv("RLNAMD_TREE_HOST_MAX", host_max)
-    rnd = random.Random(77)
-    for depth in (0, 1, 3):
-        t, o = PoseidonTree(depth), ob.Tree(depth)
-        ups = [(rnd.randrange(1 << depth), rnd.randrange(1, R)) for _ in range(5)]
+    plan = _scattered_plan_and_oracle()
+    for depth, ups, root in plan["small"]:
+        t = PoseidonTree(depth)
         t.set_leaves(ups)
-        for i, v in ups:
-            o.set(i, v)
-        assert t.root() == o.root()
+        assert t.root() == root
         t.close()
-        o.close()
     depth = 20
-    t, o = PoseidonTree(depth), ob.Tree(depth)
+    t = PoseidonTree(depth)
     t.fill_sequential(0, 1 << 14, 1)
-    o.set_range(0, list(range(1, (1 << 14) + 1)), threads=4)
-    assert t.root() == o.root()
-    for k in (1, 1, 2, 5, 6, 7, 8, 9, 21, 84, 85, 86, 1000, 30000):
-        ups = [(rnd.randrange(1 << depth), rnd.randrange(1, R)) for _ in range(k)]
-        if k == 5:
-            ups += [(ups[0][0] ^ 1, 17), (ups[1][0] ^ 2, 18)]      # a sibling and a cousin of dirty leaves
-        if k >= 21:
-            ups += [(ups[0][0], 5), (ups[1][0], 0), (ups[0][0], 6)]      # rewrites: the last one wins
+    assert t.root() == plan["root0"]
+    for k, ups, last, root, proofs in plan["steps"]:
         t.set_leaves(ups)
-        last = dict(ups)
-        for i, v in last.items():
-            o.set(i, v)
-        assert t.root() == o.root(), k
-        for i in list(last)[:3] + [0, (1 << depth) - 1]:
+        assert t.root() == root, k
+        for i, proof in proofs:
             assert t.get(i) == last.get(i, t.get(i))
-            assert t.proof(i) == o.proof(i)
-    # neighbours: both children of one parent dirty, whole aligned blocks dirty
-    ups = [(i, 1000 + i) for i in range(4096, 4096 + 257)] + [(1 << 19, 1), ((1 << 19) + 1, 2)]
-    t.set_leaves(ups)
-    for i, v in ups:
-        o.set(i, v)
-    assert t.root() == o.root()
+            assert t.proof(i) == proof
+    t.set_leaves(plan["last_ups"])
+    assert t.root() == plan["last_root"]
     with pytest.raises(Exception):
         t.set_leaves([(1 << depth, 1)])
     t.close()
-    o.close()
 
 
 # ------------------------------------------------------------------------------------------ variable-base MSM

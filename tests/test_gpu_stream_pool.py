@@ -526,13 +526,27 @@ def test_bench_side_workloads_and_the_one_process_pool_mode_each_print_one_check
     d = _bench(["--workload", "merkle", "--steps", "1"], {})
     assert d["correct"] is True and d["paths_failed_device_verification"] == 0
     assert d["updates_ffi"]["single_update_plus_root_ms_median"] < 1.5                              # the host chain (3 ms on the device)
-    d = _bench(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-side-configs", "--batch", "256"],
-               {"RLNAMD_WINDOW_BITS": "8"})
+    # round 6: the default line also carries the steady-state leg and the finish-from-partial object (small tables,
+    # 256 per batch here)
+    d = _bench(["--steps", "3", "--warmup", "1", "--batch", "256", "--side", "finish,latency", "--sustained-seconds", "1.5",
+                "--cpu-seconds", "1"], {"RLNAMD_WINDOW_BITS": "8"})
     assert d["config"]["verified"] is True and set(d["config"]["init_ms"]) == {"parse", "table_alloc", "table_build", "rest"}
     r = d["roofline"]
     assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and r["peaks"]["mad_slot_peak_Ginst_per_s"] == 614.4
     # (the issue-cycle view belongs to the bench schedule and batch: on other tables the line says it was left out)
     assert r["kernels"] is None and "issue_view_omitted" in r
+    # finished proofs byte-identical to the full ones, partial points and the finished proof of witness 0 judged by
+    # oracle/c, the CPU port's full / partial / finish beside them; then `--workload finish` by itself
+    su, f = d["sustained"], d["finish"]
+    assert su["seconds"] >= 1.5 and su["same_bytes_as_the_timed_region"] is True and 0.5 < su["ratio_to_value"] < 1.5
+    assert su["batches"] * 256 / su["seconds"] == pytest.approx(su["proofs_per_s"], rel=1e-3)
+    assert f["correct"] is True and f["byte_identical_to_the_full_proofs"] is True and f["single_call_byte_identical"] is True
+    assert f["proofs_per_s"] > f["full_proofs_per_s"] and f["single_call_ms_median"] > 0
+    cb = f["cpu_baseline"]
+    assert cb["gpu_partial_points_equal_oracle"] is True and cb["gpu_finish_equals_oracle_finish"] is True
+    assert cb["finish_equals_full"] is True and cb["single_thread_ms"]["finish"] < cb["single_thread_ms"]["full"]
+    d = _bench(["--workload", "finish", "--steps", "3", "--warmup", "1", "--batch", "256"], {"RLNAMD_WINDOW_BITS": "8"})
+    assert d["config"]["verified"] is True and "finish_rln_proof" in d["metric"]
 
 
 # ------------------------------------------------------------------- full sizes on the bench schedule (last: 228 GiB)
@@ -559,8 +573,8 @@ def test_config2_full_size_on_the_bench_schedule_vs_c_oracle(bench_prover):
     n = 1024
     proofs, values, errs = p.prove_stream_raw(*workload.config2_packed(p.slots, p.inputs_size, 0, n))
     assert not any(errs)
-    ws, rs = workload.config2_range(0, n)
-    ref_proofs, ref_pub = _oracle(ws, rs)
+    from conftest import oracle_config2
+    ws, rs, ref_proofs, ref_pub = oracle_config2(0, n)
     got_proofs, got_pub = _split(proofs, values, n)
     assert got_proofs == ref_proofs
     assert got_pub == ref_pub
