@@ -37,7 +37,7 @@ Extra objects on the line (every fraction can be recomputed from the line itself
                   v_mad_u64_u32 can reach, 614.4 G/s; the 2-cycle one, 1 228.8 G/s, only plain 32-bit ops reach).
   stage_ms      {"overlapped": spans inside the pipelined timed region (each includes whatever shared the chip with it),
                  "alone": the same stages of ONE batch with nothing else in flight}
-  sustained     the same stream continued for --sustained-seconds (default 10 s) behind the timed region: proofs/s, the
+  sustained     the same stream continued for --sustained-seconds (default 20 s) behind the timed region: proofs/s, the
                 clock the walks held, the ratio to `value` (which, at the driver's K = 20, is 0.9 s inside the boost window)
   finish        finish_zk_proof_with_rs from cached partial proofs (the reference's one published claim,
                 rln/README.md:370-375): proofs/s at 1024 per batch and one finish per call, beside the full-proof
@@ -529,24 +529,38 @@ def measure_finish(prover, batches, full_results, B, full_rate, full_latency_ms,
             vp.append(proofs[128 * i:128 * i + 128])
             vv.append([int.from_bytes(values[160 * i + 32 * q:160 * i + 32 * q + 32], "little") for q in range(5)])
     verified = bool(all(prover.verify_many(vp, vv)))
-    # one finish per call: submit + collect with nothing else in flight
+    # one finish per call: submit + collect with nothing else in flight.  (a) with the partial run's cache handle
+    # (rlnamd_prover_collect_partial_cached / _submit_finish: the interpreter walks only the cone of the witness graph that
+    # depends on the message), (b) without one: the whole graph again, as the reference's finish_zk_proof_with_rs does
     n1 = prover.inputs_size * 32
-    one_in, one_rs, one_pp = batches[0][0][:n1], batches[0][1][:64], [parts[0][0]]
-    ts = []
-    for i in range(11):
+    one_in, one_rs = batches[0][0][:n1], batches[0][1][:64]
+    t, _ = prover.submit(_partial_inputs(prover, one_in, 1), bytes(64), 1)
+    one_pp, one_h, _ = prover.collect_partial_cached(t, 1)
+    cone0 = prover.partial_cache_info()
+    ts, ts_full = [], []
+    same1 = bool(one_pp[0] == parts[0][0])
+    for i in range(22):
+        cached = i % 2 == 0
         t1 = time.perf_counter()
-        t, _ = prover.submit(one_in, one_rs, 2, one_pp)
+        t, _ = prover.submit_finish(one_in, one_rs, one_pp, one_h if cached else [0])
         pr, _, er = prover.collect_raw(t, 1)
-        if i >= 2:
-            ts.append((time.perf_counter() - t1) * 1e3)
-    lat = sorted(ts)[len(ts) // 2]
-    same1 = bool(0 in full_results and pr[:128] == full_results[0][0][:128] and not any(er))
+        if i >= 4:
+            (ts if cached else ts_full).append((time.perf_counter() - t1) * 1e3)
+        same1 = bool(same1 and 0 in full_results and pr[:128] == full_results[0][0][:128] and not any(er))
+    cone1 = prover.partial_cache_info()
+    prover.release_partial(one_h)
+    lat, lat_full = sorted(ts)[len(ts) // 2], sorted(ts_full)[len(ts_full) // 2]
+    took_cone = cone1["cone_batches"] - cone0["cone_batches"] == 11 and one_h[0] != 0
     out = {"what": "finish_zk_proof_with_rs from cached partial proofs (protocol/proof.rs:821-849): %d batches of %d streamed, "
                    "H2D of inputs + partial points and D2H of proofs inside; the same witnesses, r, s as the headline's first "
                    "%d batches" % (K, B, nb),
            "proofs_per_s": round(rate, 1), "ms_per_batch": round(B / rate * 1e3, 3),
            "full_proofs_per_s": round(full_rate, 1), "speedup_over_full": round(rate / full_rate, 3),
            "single_call_ms_median": round(lat, 3), "single_call_ms_min": round(min(ts), 3),
+           "single_call_whole_graph_ms_median": round(lat_full, 3),
+           "single_call_took_the_cone": bool(took_cone),
+           "witness_program_steps": {"cone": cone1["cone_steps"], "full": cone1["full_steps"], "cone_nodes": cone1["cone_nodes"],
+                                     "cache_entry_bytes": cone1["entry_bytes"], "cache_entries": cone1["capacity"]},
            "full_single_call_ms_median": full_latency_ms,
            "single_call_speedup_over_full": round(full_latency_ms / lat, 3) if full_latency_ms else None,
            "partial_generation_proofs_per_s": round(nb * B / partial_s, 1),
@@ -889,7 +903,7 @@ def main():
     ap.add_argument("--side", default="all", help="side objects of the default line, comma list of latency, finish, config3, "
                                                   "config5 (all | none)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="bound of the cpu_baseline's config-2 sample")
-    ap.add_argument("--sustained-seconds", type=float, default=float(os.environ.get("RLNAMD_BENCH_SUSTAINED_S", "10")),
+    ap.add_argument("--sustained-seconds", type=float, default=float(os.environ.get("RLNAMD_BENCH_SUSTAINED_S", "20")),
                     help="after the timed region: this many seconds of back-to-back batches (0: skip)")
     ap.add_argument("--workload", default="proofs", choices=["proofs", "merkle", "msm", "finish", "operating-points"],
                     help="proofs = BASELINE metric (default); merkle / msm / finish / operating-points = side measurements")
@@ -1097,12 +1111,17 @@ def main():
         sync()
         t0 = time.perf_counter()
         j, errs_seen = 0, 0
+        windows, w_t, w_j = [], t0, 0      # the rate over consecutive quarters of the leg: does it still fall at the end?
         while True:
             if len(inflight) == nslots:
                 t, kk = inflight.popleft()
                 results[kk] = prover.collect_raw(t, B)
                 errs_seen += int(any(results[kk][2]))
-            if time.perf_counter() - t0 >= args.sustained_seconds:
+            now = time.perf_counter()
+            if now - w_t >= args.sustained_seconds / 4 and j > w_j:
+                windows.append(round((j - w_j) * B / (now - w_t), 1))
+                w_t, w_j = now, j
+            if now - t0 >= args.sustained_seconds:
                 break
             inflight.append((prover.submit(batches[j % nbatches][0], batches[j % nbatches][1])[0], j % nbatches))
             j += 1
@@ -1117,6 +1136,7 @@ def main():
         sustained = {"proofs_per_s": round(s_rate, 1), "seconds": round(s_elapsed, 2), "batches": j,
                      "ms_per_batch": round(s_elapsed / max(j, 1) * 1e3, 3),
                      "ratio_to_value": round(s_rate / (world * B * per_step * args.steps / elapsed), 4),
+                     "proofs_per_s_by_quarter": windows,
                      "shader_clock_mhz": {k: round(v, 1) for k, v in s_clock.items()},
                      "shader_clock_mhz_timed_region": {k: round(v, 1) for k, v in clock_mhz.items()},
                      "same_bytes_as_the_timed_region": bool(errs_seen == 0 and all(results[k][0][:256] == v for k, v in timed_first.items())),

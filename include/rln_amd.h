@@ -164,6 +164,27 @@ int rlnamd_prover_residue(rlnamd_prover* p, uint64_t out[6]);
 #define RLNAMD_MODE_FINISH 2
 int rlnamd_prover_run_mode(rlnamd_prover* p, size_t n, int mode);
 int rlnamd_prover_run_async_mode(rlnamd_prover* p, size_t n, int mode);
+/* Finish without re-walking what the partial witness fixed (round 6).  finish_zk_proof_with_rs recomputes the whole
+ * witness (protocol/proof.rs:822-849) although the identity commitment and the 20-level Merkle chain -- 21 488 of the
+ * depth-20 circuit's 23 414 graph nodes, eleven twelfths of its multiplication depth -- came out of the partial run.
+ * rlnamd_prover_collect_partial_cached = rlnamd_prover_collect of a RLNAMD_MODE_PARTIAL batch that also keeps, per
+ * proof, the stored values of the KNOWN nodes in a device-resident cache entry (0.26 MB on the depth-20 circuit;
+ * RLNAMD_PARTIAL_CACHE entries, 64 unless set) and returns an opaque handle per proof: 0 when the cache is full or off
+ * -- such a proof finishes through the full interpreter.  rlnamd_prover_submit_finish = a RLNAMD_MODE_FINISH submit
+ * with those handles: when every proof of a small batch (one the wave-per-proof interpreter takes) has a live handle,
+ * the known rows are restored from the cache and only the cone evaluate_partial (iden3calc/graph.rs:274-312) leaves
+ * unknown is interpreted.  Bytes are identical either way; a stale or foreign handle is treated as 0.  The PartialProof
+ * wire form (partial_proof.rs:31-43) is untouched -- the handle travels beside it and means nothing to another prover.
+ * An entry holds witness values, the identity secret among them: rlnamd_prover_release_partial overwrites and frees it,
+ * rlnamd_prover_free overwrites what is left.  rlnamd_prover_partial_cache_info: [0] capacity, [1] entries in use,
+ * [2] bytes per entry, [3] non-zero 16-byte words in the entries NOT in use (0: released entries were wiped),
+ * [4] batches that took the cone, [5] nodes of the cone, [6] steps of the cone program, [7] steps of the full program. */
+int rlnamd_prover_collect_partial_cached(rlnamd_prover* p, uint64_t ticket, size_t n, uint8_t* partial320, uint64_t* handles,
+                                         uint32_t* errors);
+int rlnamd_prover_submit_finish(rlnamd_prover* p, size_t n, const uint8_t* inputs_le, const uint8_t* rs_le,
+                                const uint8_t* partial320, const uint64_t* handles, uint64_t* ticket);
+int rlnamd_prover_release_partial(rlnamd_prover* p, const uint64_t* handles, size_t n);
+int rlnamd_prover_partial_cache_info(rlnamd_prover* p, uint64_t out[8]);
 int rlnamd_prover_upload_partial(rlnamd_prover* p, size_t n, const uint8_t* coords320);
 int rlnamd_prover_download_partial(rlnamd_prover* p, size_t n, uint8_t* coords320);
 int rlnamd_prover_known_mask(rlnamd_prover* p, uint8_t* out_num_signals);

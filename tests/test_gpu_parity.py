@@ -840,6 +840,91 @@ def test_partial_proof_then_finish_equals_full(prover):
     assert o["proof"] == prover.prove([w_new], [(5, 6)])[0]["proof"] and prover.verify(o["proof"], o["public_inputs"])
 
 
+def test_finish_from_a_cached_partial_interprets_only_the_unknown_cone(prover, monkeypatch):
+    """Round 6.  rlnamd_prover_collect_partial_cached keeps the stored values the partial witness fixes
+    on the device and hands back a handle; rlnamd_prover_submit_finish with live handles restores them and interprets only
+    the cone evaluate_partial (graph.rs:274-312) leaves unknown.  Checked: the partial points equal the pyref fixture and
+    oracle/c's; a finish through the cone, a finish with no handle and a finish with a stale handle all give the golden
+    FULL proof bytes (and oracle/c's finish); the cone counter moves only for live handles; the partial proof is
+    message-independent through the cone too; a batch whose handles are not all live falls back; a batch of 37 through
+    the cone equals oracle/c's finish proof by proof; released entries are wiped (residue 0) and reused."""
+    from oracle.c import binding as ob
+    from zerokit_amd import workload
+    from zerokit_amd.batch import BatchProver
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "rln_h20_partial.json")))
+    cases = {c["name"]: c for c in _cases()["cases"]}
+    oc = ob.Circuit(20)
+    p = prover
+    info0 = p.partial_cache_info()
+    assert info0["capacity"] >= 64 and info0["in_use"] == 0 and info0["cone_nodes"] > 1934 and info0["cone_steps"] * 8 < info0["full_steps"]
+    assert info0["entry_bytes"] > 5000 * 48
+
+    def partial_inputs(ws):
+        return p.pack_inputs([dict(w, message_id=0, x=0, external_nullifier=0) for w in ws])
+
+    def run_partial(ws):
+        t, n = p.submit(partial_inputs(ws), bytes(64 * len(ws)), 1)
+        return p.collect_partial_cached(t, n)
+
+    def run_finish(ws, rs, parts, handles):
+        t, n = p.submit_finish(p.pack_inputs(ws), p.pack_rs(rs), parts, handles)
+        return p.collect(t, n)
+    for f in fx["cases"]:
+        c = cases[f["name"]]
+        w, rs = _w(c), (int(c["r"]), int(c["s"]))
+        parts, hs, errs = run_partial([w])
+        assert hs[0] != 0 and errs == [0] and parts[0].hex() == f["partial320"] == oc.prove_partial_packed(oc.pack(w)).hex()
+        before = p.partial_cache_info()["cone_batches"]
+        golden = bytes.fromhex(c["proof_compressed"])
+        o = run_finish([w], [rs], parts, hs)[0]
+        assert o["proof"] == golden == oc.finish_packed(oc.pack(w), rs[0], rs[1], parts[0]) and o["error"] == 0
+        assert [str(v) for v in o["public_inputs"]] == c["public_inputs"]
+        assert p.partial_cache_info()["cone_batches"] == before + 1
+        assert run_finish([w], [rs], parts, [0])[0]["proof"] == golden          # no handle: the whole graph
+        assert p.partial_cache_info()["cone_batches"] == before + 1
+        # the partial proof is message-independent, through the cone too
+        w2 = dict(w, x=w["x"] ^ 5, message_id=7, external_nullifier=99)
+        o2 = run_finish([w2], [(5, 6)], parts, hs)[0]
+        assert o2["proof"] == p.prove([w2], [(5, 6)])[0]["proof"] and p.verify(o2["proof"], o2["public_inputs"])
+        assert p.partial_cache_info()["cone_batches"] == before + 2
+        p.release_partial(hs)
+        assert run_finish([w], [rs], parts, hs)[0]["proof"] == golden           # stale handle: the whole graph
+        info = p.partial_cache_info()
+        assert info["cone_batches"] == before + 2 and info["in_use"] == 0 and info["residue_in_free_entries"] == 0
+    # a batch through the cone against oracle/c's finish, every proof; then the same with one dead handle (falls back)
+    n = 37
+    ws, rs = workload.config2_range(5000, n)
+    parts, hs, errs = run_partial(ws)
+    assert all(hs) and not any(errs) and len(set(hs)) == n and p.partial_cache_info()["in_use"] == n
+    packed = [oc.pack(w) for w in ws]
+    _, want = oc.finish_many_packed(b"".join(packed), p.pack_rs(rs), b"".join(oc.prove_partial_packed(q) for q in packed))
+    before = p.partial_cache_info()["cone_batches"]
+    out = run_finish(ws, rs, parts, hs)
+    assert [o["proof"] for o in out] == want and not any(o["error"] for o in out)
+    assert [o["public_inputs"] for o in out] == [oc.public_values(q) for q in packed]
+    assert p.partial_cache_info()["cone_batches"] == before + 1
+    dead = list(hs)
+    p.release_partial(dead[3:4])
+    assert [o["proof"] for o in run_finish(ws, rs, parts, dead)] == want
+    assert p.partial_cache_info()["cone_batches"] == before + 1
+    p.release_partial(hs)
+    info = p.partial_cache_info()
+    assert info["in_use"] == 0 and info["residue_in_free_entries"] == 0
+    # a cache smaller than the batch: a prefix gets handles, the batch finishes through the whole graph, same bytes
+    monkeypatch.setenv("RLNAMD_PARTIAL_CACHE", "3")
+    q = BatchProver(max_batch=64, window_bits=8)
+    try:
+        t, k = q.submit(q.pack_inputs([dict(w, message_id=0, x=0, external_nullifier=0) for w in ws[:5]]), bytes(64 * 5), 1)
+        parts5, hs5, _ = q.collect_partial_cached(t, k)
+        assert [bool(h) for h in hs5] == [True, True, True, False, False] and parts5 == parts[:5]
+        t, k = q.submit_finish(q.pack_inputs(ws[:5]), q.pack_rs(rs[:5]), parts5, hs5)
+        assert [o["proof"] for o in q.collect(t, k)] == want[:5] and q.partial_cache_info()["cone_batches"] == 0
+        t, k = q.submit_finish(q.pack_inputs(ws[:3]), q.pack_rs(rs[:3]), parts5[:3], hs5[:3])
+        assert [o["proof"] for o in q.collect(t, k)] == want[:3] and q.partial_cache_info()["cone_batches"] == 1
+    finally:
+        q.close()
+
+
 def test_fq29_group_law_matches_the_8x32_group_law_on_device():
     """csrc/fq29.h (9 x 29-bit unsaturated limbs, the form both fixed-base walks and the Pippenger buckets use)
     against curve.h on 16 384 pseudo-random walks of 96 signed additions each, with repeated points (doubling),

@@ -539,9 +539,11 @@ def test_bench_side_workloads_and_the_one_process_pool_mode_each_print_one_check
     # oracle/c, the CPU port's full / partial / finish beside them; then `--workload finish` by itself
     su, f = d["sustained"], d["finish"]
     assert su["seconds"] >= 1.5 and su["same_bytes_as_the_timed_region"] is True and 0.5 < su["ratio_to_value"] < 1.5
-    assert su["batches"] * 256 / su["seconds"] == pytest.approx(su["proofs_per_s"], rel=1e-3)
+    assert su["batches"] * 256 / su["seconds"] == pytest.approx(su["proofs_per_s"], rel=2e-2) and len(su["proofs_per_s_by_quarter"]) >= 3
     assert f["correct"] is True and f["byte_identical_to_the_full_proofs"] is True and f["single_call_byte_identical"] is True
-    assert f["proofs_per_s"] > f["full_proofs_per_s"] and f["single_call_ms_median"] > 0
+    assert f["proofs_per_s"] > f["full_proofs_per_s"] and f["single_call_took_the_cone"] is True
+    assert 0 < f["single_call_ms_median"] < f["single_call_whole_graph_ms_median"]
+    assert f["witness_program_steps"]["cone"] * 8 < f["witness_program_steps"]["full"]
     cb = f["cpu_baseline"]
     assert cb["gpu_partial_points_equal_oracle"] is True and cb["gpu_finish_equals_oracle_finish"] is True
     assert cb["finish_equals_full"] is True and cb["single_thread_ms"]["finish"] < cb["single_thread_ms"]["full"]

@@ -119,3 +119,51 @@ def test_out_of_range_input_sets_the_error_flag(WS):
     stats = (ctypes.c_uint32 * 8)()
     assert WS.witsched_run(gb, len(gb), bytes(buf), size, 1, out, stats) == 0
     assert stats[7] == 1
+
+
+def _run_cone(lib, graph_bytes, named_inputs, rows):
+    from oracle.pyref import wtns_graph
+    g = wtns_graph.parse(graph_bytes)
+    size = g.inputs_size()
+    buf = bytearray(size * 32)
+    buf[0] = 1
+    for name, vals in named_inputs.items():
+        off, ln = g.input_mapping[name]
+        assert ln == len(vals)
+        for k, v in enumerate(vals):
+            buf[(off + k) * 32:(off + k + 1) * 32] = (int(v) % R).to_bytes(32, "little")
+    out = ctypes.create_string_buffer(32 * len(g.signals))
+    stats = (ctypes.c_uint32 * 12)()
+    rc = lib.witsched_run_cone(graph_bytes, len(graph_bytes), bytes(buf), size, rows, out, stats)
+    assert rc == 0, lib.witsched_error().decode()
+    return hashlib.sha256(out.raw).hexdigest(), list(stats)
+
+
+@pytest.mark.parametrize("rows", [0, 1])
+def test_the_unknown_cone_on_top_of_a_partial_run_gives_the_golden_witness(WS, rows):
+    """Round 6, finish without re-walking the known cone (witness_sched.h: wl_cone).  The FULL program over the PARTIAL
+    witness (message id, x, external nullifier zeroed: what generate_partial_zk_proof evaluates, graph.rs:274-312) leaves
+    the stored rows; every row of an unknown node is then overwritten with junk; the CONE program -- the nodes
+    evaluate_partial leaves None plus the 13 known ones they read -- runs over the full inputs on top of those rows.  The
+    witness read off the rows must be the golden one, on all three shipped circuits; and the cone is a twelfth of the
+    graph's depth (the 20-level Merkle chain is known)."""
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "rln_h20_vectors.json")))["cases"]
+    gb = _graph("tree_depth_20")
+    for c in cases[:3]:
+        w = c["witness"]
+        named = {"identitySecret": [w["identity_secret"]], "userMessageLimit": [w["user_message_limit"]],
+                 "messageId": [w["message_id"]], "pathElements": w["path_elements"],
+                 "identityPathIndex": w["identity_path_index"], "x": [w["x"]],
+                 "externalNullifier": [w["external_nullifier"]]}
+        digest, st = _run_cone(WS, gb, named, rows)
+        assert digest == c["witness_sha256"], c["name"]
+        assert st[7] == 0
+    # cone nodes, unknown nodes, recomputed known nodes, known stored rows
+    assert st[9] == 1934 and st[10] == 13 and st[8] > st[9] and st[11] > 5000
+    full_steps = _run(WS, gb, named, rows)[1][0]
+    assert st[0] * 8 < full_steps, (st[0], full_steps)
+    for c in json.load(open(os.path.join(ROOT, "tests", "golden", "rln_other_circuits.json")))["cases"]:
+        sub = "tree_depth_%d%s" % (c["depth"], "_multi_max_out_4" if c["multi"] else "")
+        digest, st = _run_cone(WS, _graph(sub), c["inputs"], rows)
+        assert digest == c["witness_sha256"], c["name"]
+        assert st[7] == 0

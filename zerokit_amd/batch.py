@@ -214,6 +214,37 @@ class BatchProver:
         check(lib().rlnamd_prover_collect(self._h, ticket, n, None, None, None, None, buf))
         return [buf.raw[320 * i:320 * (i + 1)] for i in range(n)]
 
+    def collect_partial_cached(self, ticket, n):
+        """collect of a mode-1 batch that keeps the known stored values on the device -> ([partial320], [handle], errors);
+        handle 0 = not cached (such a proof finishes through the full interpreter)"""
+        buf = C.create_string_buffer(320 * n)
+        hs = (C.c_uint64 * n)()
+        errs = (C.c_uint32 * n)()
+        check(lib().rlnamd_prover_collect_partial_cached(self._h, ticket, n, buf, hs, errs))
+        return [buf.raw[320 * i:320 * (i + 1)] for i in range(n)], [int(h) for h in hs], list(errs)
+
+    def submit_finish(self, inputs: bytes, rsb: bytes, partials, handles):
+        """finish_zk_proof_with_rs with the partial runs' cache handles: the cone of the witness graph only when every
+        handle is live (rlnamd_prover_submit_finish); returns (ticket, n)"""
+        n = len(inputs) // (self.inputs_size * 32)
+        pp = b"".join(partials)
+        if len(inputs) != n * self.inputs_size * 32 or len(rsb) != 64 * n or len(pp) != 320 * n or len(handles) != n:
+            raise RLNError("submit_finish: sizes do not match")
+        hs = (C.c_uint64 * n)(*handles)
+        t = C.c_uint64()
+        check(lib().rlnamd_prover_submit_finish(self._h, n, inputs, rsb, pp, hs, C.byref(t)))
+        return int(t.value), n
+
+    def release_partial(self, handles):
+        hs = (C.c_uint64 * len(handles))(*handles)
+        check(lib().rlnamd_prover_release_partial(self._h, hs, len(handles)))
+
+    def partial_cache_info(self):
+        out = (C.c_uint64 * 8)()
+        check(lib().rlnamd_prover_partial_cache_info(self._h, out))
+        return dict(zip(("capacity", "in_use", "entry_bytes", "residue_in_free_entries", "cone_batches", "cone_nodes",
+                         "cone_steps", "full_steps"), [int(v) for v in out]))
+
     def prove_stream_raw(self, inputs: bytes, rsb: bytes):
         """any n through rlnamd_prover_prove_stream (chunks of `capacity`, all slots in flight)"""
         n = len(inputs) // (self.inputs_size * 32)

@@ -306,6 +306,29 @@ int rlnamd_prover_collect(rlnamd_prover* p, uint64_t ticket, size_t n, uint8_t* 
   p->p->collect(ticket, n, proofs, values, errors, coords, partial320);
   RLN_CATCH
 }
+int rlnamd_prover_collect_partial_cached(rlnamd_prover* p, uint64_t ticket, size_t n, uint8_t* partial320, uint64_t* handles,
+                                         uint32_t* errors) {
+  RLN_TRY
+  p->p->collect_partial_cached(ticket, n, partial320, handles, errors);
+  RLN_CATCH
+}
+int rlnamd_prover_submit_finish(rlnamd_prover* p, size_t n, const uint8_t* inputs_le, const uint8_t* rs_le,
+                                const uint8_t* partial320, const uint64_t* handles, uint64_t* ticket) {
+  RLN_TRY
+  *ticket = p->p->submit_finish(n, inputs_le, rs_le, partial320, handles);
+  RLN_CATCH
+}
+int rlnamd_prover_release_partial(rlnamd_prover* p, const uint64_t* handles, size_t n) {
+  RLN_TRY
+  p->p->release_partial(handles, n);
+  RLN_CATCH
+}
+int rlnamd_prover_partial_cache_info(rlnamd_prover* p, uint64_t out[8]) {
+  RLN_TRY
+  static_assert(Prover::PARTIAL_CACHE_FIELDS == 8, "rln_amd.h states eight fields");
+  p->p->partial_cache_info(out);
+  RLN_CATCH
+}
 int rlnamd_prover_collect_public(rlnamd_prover* p, uint64_t ticket, size_t n, uint8_t* out_le) {
   RLN_TRY
   std::vector<uint8_t> v;

@@ -266,7 +266,7 @@ std::string json_str_array(const std::vector<std::string>& v) {
 struct FFI_RLN {
   // generate / verify take &self in the reference and may be called from several threads (SURVEY section 8b,
   // "Threading"); the prover owns one set of device workspaces, so proving calls on one object take turns
-  std::mutex prove_mu;
+  std::shared_ptr<std::mutex> prove_mu = std::make_shared<std::mutex>();   // (shared: a partial proof's cache entry is released under it)
   std::shared_ptr<Prover> prover;   // owned, or replica 0 of `pool` (then the pool owns it)
   rlnamd_pool* pool = nullptr;      // config "devices" with two or more entries: batch calls shard over the devices
   // The object lives on ONE device -- its tree, its prover (replica 0 of a pool) and every later call from the caller's
@@ -611,7 +611,7 @@ struct WipeResident {
 
 // generate_rln_proof for a slice of witnesses (public.rs:624-631)
 void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CFr* rs, FFI_RLNProof** out) {
-  std::lock_guard<std::mutex> guard(rln.prove_mu);
+  std::lock_guard<std::mutex> guard(*rln.prove_mu);
   Prover& P = *rln.prover;
   const size_t ni = P.inputs_per_proof();
   for (size_t i = 0; i < n; i++) check_against_graph(P, *ws[i]);
@@ -737,7 +737,7 @@ void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CF
 // the proof values come from the witness input (single: the values kernel over the inputs; multi: the public
 // signals, identical for any witness that satisfies the circuit).
 FFI_RLNProof* prove_with_witness(FFI_RLN& rln, const Vec_String_t* calc, const FFI_RLNWitnessInput& w) {
-  std::lock_guard<std::mutex> guard(rln.prove_mu);
+  std::lock_guard<std::mutex> guard(*rln.prove_mu);
   Prover& P = *rln.prover;
   std::vector<uint8_t> given;
   given.reserve((calc ? calc->len : 0) * 32);
@@ -773,7 +773,7 @@ FFI_RLNProof* prove_with_witness(FFI_RLN& rln, const Vec_String_t* calc, const F
 
 // generate_partial_zk_proof (proof.rs:783-803)
 FFI_RLNPartialProof* prove_partial(FFI_RLN& rln, const FFI_RLNPartialWitnessInput& pw) {
-  std::lock_guard<std::mutex> guard(rln.prove_mu);
+  std::lock_guard<std::mutex> guard(*rln.prove_mu);
   Prover& P = *rln.prover;
   size_t d = P.graph().tree_depth;
   if (pw.path_elements.size() != d)
@@ -789,12 +789,21 @@ FFI_RLNPartialProof* prove_partial(FFI_RLN& rln, const FFI_RLNPartialWitnessInpu
   w.external_nullifier = cfr_from_u64(0);
   std::vector<uint8_t> inputs(P.inputs_per_proof() * 32), rs(64, 0);
   ZeroOnExit z1{inputs};
-  WipeResident wr{P};
   fill_inputs(P, w, inputs.data());
-  P.upload(1, inputs.data(), rs.data());
-  P.run(1, PROVE_PARTIAL);
   std::unique_ptr<FFI_RLNPartialProof> pp(new FFI_RLNPartialProof);
-  P.download_partial(1, pp->coords);
+  // streamed, and the values the partial witness fixes stay on the device under a handle (round 6): finishing THIS object on
+  // this prover interprets only the cone of the graph that depends on the message (rln_amd.h)
+  uint32_t err = 0;
+  const uint64_t ticket = P.submit(1, inputs.data(), rs.data(), PROVE_PARTIAL);
+  P.collect_partial_cached(ticket, 1, pp->coords, &pp->handle, &err);
+  if (err) throw Error("Error calculating witness: graph evaluation failed (code " + std::to_string(err) + ")");
+  if (pp->handle)
+    pp->release = [wp = std::weak_ptr<Prover>(rln.prover), mu = rln.prove_mu](uint64_t h) {
+      if (auto p = wp.lock()) {
+        std::lock_guard<std::mutex> g(*mu);
+        p->release_partial(&h, 1);
+      }
+    };
   const std::vector<uint8_t>& known = P.known_mask();
   pp->mask.assign(known.begin() + 1, known.end());
   return pp.release();
@@ -803,7 +812,7 @@ FFI_RLNPartialProof* prove_partial(FFI_RLN& rln, const FFI_RLNPartialWitnessInpu
 // finish_zk_proof_with_rs (proof.rs:821-849) + proof values
 FFI_RLNProof* finish_proof(FFI_RLN& rln, const FFI_RLNPartialProof& pp, const FFI_RLNWitnessInput& w, const CFr& r,
                            const CFr& s) {
-  std::lock_guard<std::mutex> guard(rln.prove_mu);
+  std::lock_guard<std::mutex> guard(*rln.prove_mu);
   Prover& P = *rln.prover;
   check_against_graph(P, w);
   const std::vector<uint8_t>& known = P.known_mask();
@@ -811,10 +820,19 @@ FFI_RLNProof* finish_proof(FFI_RLN& rln, const FFI_RLNPartialProof& pp, const FF
     throw Error("Error producing proof: the partial proof's mask does not match this circuit (malformed verifying key)");
   std::vector<uint8_t> inputs(P.inputs_per_proof() * 32), rs(64);
   ZeroOnExit z1{inputs}, z2{rs};
-  WipeResident wr{P};
   fill_inputs(P, w, inputs.data());
   memcpy(rs.data(), r.le, 32);
   memcpy(rs.data() + 32, s.le, 32);
+  if (pp.handle && !w.multi) {   // the partial run's values are on this device: streamed, the cone only (a dead handle: the whole graph)
+    ProofOut po;
+    const uint64_t ticket = P.submit_finish(1, inputs.data(), rs.data(), pp.coords, &pp.handle);
+    P.collect(ticket, 1, po.compressed, &po.values[0][0], &po.error);
+    if (po.error) throw Error("Error calculating witness: graph evaluation failed (code " + std::to_string(po.error) + ")");
+    std::unique_ptr<FFI_RLNProof> pr(new FFI_RLNProof);
+    fill_outputs(po, pr.get());
+    return pr.release();
+  }
+  WipeResident wr{P};
   P.upload(1, inputs.data(), rs.data());
   P.upload_partial(1, pp.coords);
   P.run(1, PROVE_FINISH);

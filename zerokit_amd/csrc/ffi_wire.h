@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -167,6 +168,19 @@ struct FFI_RLNPartialWitnessInput {  // RLNPartialWitnessInput (protocol/witness
 struct FFI_RLNPartialProof {  // PartialProof (partial_proof.rs:31-43): mask + four points (affine, canonical LE)
   std::vector<uint8_t> mask;  // per assignment entry (witness signals 1..)
   uint8_t coords[320];        // pi_a | rho | pi_b | pi_c
+  // Beside the wire form, never inside it: the prover's cache entry with the values the partial witness fixed
+  // (rln_amd.h: rlnamd_prover_collect_partial_cached).  0 for a partial proof that came in as bytes or whose prover had no
+  // room: finishing it walks the whole graph.  The entry holds witness values: released (overwritten) with the object.
+  uint64_t handle = 0;
+  std::function<void(uint64_t)> release;
+  FFI_RLNPartialProof() = default;
+  FFI_RLNPartialProof(const FFI_RLNPartialProof& o) : mask(o.mask) { memcpy(coords, o.coords, 320); }   // a copy owns no entry
+  FFI_RLNPartialProof& operator=(const FFI_RLNPartialProof&) = delete;
+  ~FFI_RLNPartialProof() {
+    if (handle && release) {
+      try { release(handle); } catch (...) {}
+    }
+  }
 };
 
 namespace {

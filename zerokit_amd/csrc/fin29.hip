@@ -100,6 +100,90 @@ __global__ void __launch_bounds__(64) k_fin_smul29(const G1Affine* __restrict__ 
   prod[(size_t)task * B + p] = acc.to_xyzz();   // k == 0 gives infinity, matching g1_b = 0 (partial_proof.rs:242-248)
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Finish from a cached partial proof (round 6): s A + r B1 = [s pi_a + r rho] + sum_u (s w_i) A_i + sum_u (r w_i) B1_i + 2 r s delta
+// with A = pi_a + A_u + r delta, B1 = rho + B_u + s delta (partial_proof.rs:236-260).  Everything behind the bracket is
+// rows of the fixed-base walk under product scalars (the fused plan); the bracket is the only variable-base work left,
+// and its bases are known when the PARTIAL proof is made.  k_pp_powers (partial time, off the caller's path) stores
+// 2^(8 k) P and phi(2^(8 k) P) for P = pi_a, rho, k = 0 .. 15, affine, in the table form, beside the partial run's cached
+// values; k_pp_smul (finish time) gives every (point, GLV half, 8-bit chunk) of the two scalars a lane -- 8 doublings and
+// at most 8 mixed additions instead of the 129-step ladder of k_fin_smul29 (0.93 ms of a lone finish) -- and sums the 64
+// lane results in a tree through LDS.  Same group element: bytes cannot change.
+constexpr uint32_t PP_CHUNKS = 16;                        // 8-bit chunks of a 128-bit GLV half
+// cache entry, in uint4 units from `off16`: [point t][half h][chunk k] G1Affine29 (4 uint4 each)
+__global__ void __launch_bounds__(64) k_pp_powers(const uint32_t* __restrict__ pp, const uint32_t* __restrict__ entry_of,
+                                                  uint4* __restrict__ cache, uint32_t stride16, uint32_t off16) {
+  const uint32_t p = blockIdx.x, lane = threadIdx.x;
+  if (lane >= 2 * PP_CHUNKS) return;
+  const uint32_t t = lane / PP_CHUNKS, k = lane % PP_CHUNKS;
+  const uint32_t* d = pp + (size_t)p * 80 + (t == 0 ? 0 : 16);     // pi_a | rho (k_partial_out)
+  G1Affine P{Fq::from_canonical(d), Fq::from_canonical(d + 8)};
+  G1Affine29* out = (G1Affine29*)(cache + (size_t)entry_of[p] * stride16 + off16);
+  G1Affine29 e1{}, e2{};   // infinity stays (0, 0)
+  if (!P.is_inf()) {
+    G1Affine Q = P;
+    if (k) {
+      G1Acc29 acc = G1Acc29::inf();
+      acc.madd(to_table29(P), false);
+      for (uint32_t i = 0; i < 8 * k; i++) g1acc29_dbl(acc);
+      Q = acc.to_xyzz().to_affine();
+    }
+    if (!Q.is_inf()) {
+      e1 = to_table29(Q);
+      Q.x = Q.x * Fq::from_canonical(GlvParams::BETA_G1);
+      e2 = to_table29(Q);
+    }
+  }
+  out[(t * 2 + 0) * PP_CHUNKS + k] = e1;
+  out[(t * 2 + 1) * PP_CHUNKS + k] = e2;
+}
+
+// out[p] = s pi_a + r rho (XYZZ); rs: n x (r | s) canonical LE words
+__global__ void __launch_bounds__(64) k_pp_smul(const uint4* __restrict__ cache, const uint32_t* __restrict__ entry_of,
+                                                uint32_t stride16, uint32_t off16, const uint32_t* __restrict__ rs,
+                                                G1XYZZ* __restrict__ out) {
+  __shared__ G1Acc29 sh[64];
+  __builtin_amdgcn_s_setprio(3);
+  const uint32_t p = blockIdx.x, lane = threadIdx.x;
+  const uint32_t t = lane >> 5, h = (lane >> 4) & 1, k = lane & 15;
+  const uint32_t* sc = rs + (size_t)p * 16 + (t == 0 ? 8 : 0);   // pi_a under s, rho under r
+  uint32_t kk[8], k1[4], k2[4], n1, n2;
+#pragma unroll
+  for (int i = 0; i < 8; i++) kk[i] = sc[i];
+  glv_split(kk, k1, &n1, k2, &n2);
+  uint32_t word = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) word = (k >> 2) == (uint32_t)i ? (h ? k2[i] : k1[i]) : word;
+  const uint32_t chunk = (word >> ((k & 3) * 8)) & 0xFF;
+  const bool neg = (h ? n2 : n1) != 0;
+  const G1Affine29 e = ((const G1Affine29*)(cache + (size_t)entry_of[p] * stride16 + off16))[(t * 2 + h) * PP_CHUNKS + k];
+  G1Acc29 acc = G1Acc29::inf();
+  if (chunk && !e.is_inf()) {
+#pragma unroll 1
+    for (int b = 7; b >= 0; b--) {
+      g1acc29_dbl(acc);
+      if ((chunk >> b) & 1) acc.madd(e, neg);
+    }
+  }
+#pragma unroll 1
+  for (uint32_t w = 32; w >= 1; w >>= 1) {
+    sh[lane] = acc;
+    __syncthreads();
+    if (lane < w) acc.add(sh[lane + w]);
+    __syncthreads();
+  }
+  if (lane == 0) out[p] = acc.to_xyzz();
+}
+
+void launch_pp_powers(hipStream_t s, const uint32_t* pp, const uint32_t* entry_of, uint4* cache, uint32_t stride16,
+                      uint32_t off16, uint32_t n) {
+  hipLaunchKernelGGL(k_pp_powers, dim3(n), dim3(64), 0, s, pp, entry_of, cache, stride16, off16);
+}
+void launch_pp_smul(hipStream_t s, const uint4* cache, const uint32_t* entry_of, uint32_t stride16, uint32_t off16,
+                    const uint32_t* rs, G1XYZZ* out, uint32_t n) {
+  hipLaunchKernelGGL(k_pp_smul, dim3(n), dim3(64), 0, s, cache, entry_of, stride16, off16, rs, out);
+}
+
 void launch_fin_smul29(hipStream_t s, const G1Affine* affA, const G1Affine* affB1, const uint32_t* rs, G1XYZZ* prod,
                        uint32_t B, uint32_t nb) {
   hipLaunchKernelGGL(k_fin_smul29, dim3((nb + 63) / 64, 2), dim3(64), 0, s, affA, affB1, rs, prod, B, nb);

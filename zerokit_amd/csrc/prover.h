@@ -39,6 +39,7 @@ extern const char* const kProverStageNames[PROVER_STAGES];
 struct ProverConfig {
   int window_bits = 0;      // 0 = take RLNAMD_WINDOW_BITS or the default (120010: G1 c = 10, G2 c = 12); g1 + 10000 * g2, spec = c + 100 * wide
   size_t max_batch = 1024;  // workspace capacity in proofs (rounded up to a multiple of 64)
+  long partial_cache = -1;  // entries of the partial-proof cache (collect_partial_cached); -1 = RLNAMD_PARTIAL_CACHE or 64
 };
 
 // Every switch of the prover, read from the environment ONCE when a Prover is built (ProverTuning::from_env; printed by
@@ -57,6 +58,8 @@ struct ProverTuning {
                                        // LDS per proof: ceil(n / 256) x 1.5 ms against 11 ms for lanes = proofs; lone 512 / 1 024-proof
                                        // batches 46.9 -> 38.0 / 74.0 -> 68.5 ms, the first batch of a stream 5 ms earlier)
   uint32_t tiny_max = 5;               // RLNAMD_TINY: largest lone batch walked with ONE (row, half) per lane (0: never); 5 proofs 3.15 -> 3.0 ms, 6 even, 8 slower
+  uint32_t partial_cache = 64;         // RLNAMD_PARTIAL_CACHE: entries of the partial-proof cache (the known stored values of a
+                                       // partial run, ~0.26 MB each on the depth-20 circuit); 0: finish always re-walks the whole graph
   uint32_t ntt_lg_max = 96;            // RLNAMD_NTT_LG_MAX: largest small batch whose NTTs run as the three LDS kernels (above, the
                                        // single-wave passes finish earlier beside the walks: 128 proofs 13.2 -> 12.6 ms)
   // ---- shapes (1 = default)
@@ -150,6 +153,24 @@ class Prover {
   // four points per proof, canonical affine [pi_a x,y | rho x,y | pi_b x.c0,x.c1,y.c0,y.c1 | pi_c x,y] = 320 B
   // (create_partial_proof_from_assignment, partial_proof.rs:108-179).  PROVE_FINISH: full inputs + (r, s) +
   // the partial points uploaded with upload_partial (finish_partial_proof_with_assignment, :182-274).
+  // Finish without re-walking the known cone (round 6).  finish_zk_proof_with_rs calculates the whole witness again
+  // (protocol/proof.rs:822-849), although everything the partial witness fixes -- the identity commitment, the 20-level
+  // Merkle chain: 21 488 of the 23 414 nodes and 11 / 12 of the multiplication depth -- came out of the partial run.
+  // collect_partial_cached = collect of a PROVE_PARTIAL batch that also keeps, per proof, the stored values of the KNOWN
+  // nodes in a device-resident cache entry and hands back an opaque handle (0: the cache is full or off -- such a proof
+  // finishes through the full interpreter).  submit_finish = submit(PROVE_FINISH) with those handles: when every proof of
+  // a small batch has a live handle the front end restores the known rows from the cache and interprets only the cone
+  // evaluate_partial leaves unknown (witness_sched.h: wl_cone); bytes identical either way.  The PartialProof wire form
+  // (partial_proof.rs:31-43) is untouched: the handle travels beside it.  A cache entry holds witness values (the identity
+  // secret among them): release_partial overwrites it, ~Prover overwrites what is left.
+  void collect_partial_cached(uint64_t ticket, size_t n, uint8_t* partial320, uint64_t* handles, uint32_t* errors);
+  uint64_t submit_finish(size_t n, const uint8_t* inputs, const uint8_t* rs, const uint8_t* partial320, const uint64_t* handles);
+  void release_partial(const uint64_t* handles, size_t n);
+  // [0] capacity in entries, [1] entries in use, [2] bytes per entry, [3] 16-byte words that are not zero in the entries
+  // NOT in use (all of them zero: a released entry was wiped), [4] batches that took the cone so far, [5] nodes of the cone
+  // program, [6] steps of the cone program, [7] steps of the full program
+  static constexpr int PARTIAL_CACHE_FIELDS = 8;
+  void partial_cache_info(uint64_t out[PARTIAL_CACHE_FIELDS]);
   void upload_partial(size_t n, const uint8_t* coords320);
   void download_partial(size_t n, uint8_t* coords320);
   // per witness signal (length = number of signals): 1 when fixed by the partial witness (PartialProof::mask
@@ -180,7 +201,8 @@ class Prover {
   void residue(uint64_t out[RESIDUE_FIELDS]);
 
  private:
-  uint64_t enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint8_t* h_rs, const uint8_t* h_pp320);
+  uint64_t enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint8_t* h_rs, const uint8_t* h_pp320,
+                   const uint64_t* cone_handles = nullptr);
   void fetch_public_slot(void* slot, size_t n, std::vector<uint8_t>* out_le);
   struct Impl;
   std::unique_ptr<Impl> d_;

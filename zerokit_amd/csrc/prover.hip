@@ -19,6 +19,7 @@
 #include "poseidon.h"
 #include "witness_ops.h"
 #include "witness_lanes.h"
+#include "witness_sched.h"
 #include "fin29.h"
 
 namespace rlnamd {
@@ -49,6 +50,7 @@ struct Slot {
   // buffer they are copied from, so a caller with a stream of distinct batches never drains the pipeline
   DevBuf<uint32_t> inputs, rs, pp_in;
   uint8_t* h_in = nullptr;      // pinned staging: inputs | rs | partial points
+  uint32_t* h_cone = nullptr;   // pinned: partial-cache entry of every proof of the batch (read by k_cone_save / _restore)
   hipEvent_t evU = nullptr;     // H2D of this slot's inputs done
   hipEvent_t evE = nullptr;     // small batches: the walk of the h-independent G1 rows done
   uint64_t ticket = 0;          // submit() ticket of the batch the slot holds (0: resident-input run)
@@ -57,6 +59,7 @@ struct Slot {
   uint32_t* h_err = nullptr;
   hipEvent_t evA = nullptr, evB = nullptr, evB2 = nullptr, evR = nullptr, evC = nullptr, evW = nullptr, evV = nullptr;
   hipEvent_t evX = nullptr;     // the witness is in V (before the small-batch recodes that follow it on the same stream)
+  hipEvent_t evP = nullptr;     // fused finish: s pi_a + r rho is in `prod` (k_pp_smul)
   hipEvent_t t[15] = {};  // timing marks
   bool used = false;
   bool marked = false;          // the timing marks t[] of the slot's batch were recorded
@@ -156,6 +159,22 @@ struct Prover::Impl {
   uint32_t max_chunks1 = 0, max_chunks2 = 0, max_groups1 = 0, max_groups2 = 0;
   uint32_t npts1 = 0, npts2 = 0, npaired1 = 0;   // npaired1: G1 points [0, npaired1) are pair members
   std::vector<uint8_t> known;  // per witness signal: computable from the partial witness (evaluate_partial)
+  // ---- the partial-proof cache and the cone program (prover.h: collect_partial_cached / submit_finish)
+  WitLanes cone;                 // the unknown cone of evaluate_partial, scheduled like the full graph (witness_sched.h: wl_cone)
+  uint32_t cone_nodes = 0;
+  DevBuf<uint32_t> cone_rows;    // stored slots of the KNOWN nodes: what an entry keeps
+  uint32_t cone_nk = 0, cone_cap = 0;
+  uint32_t cone_stride = 0;      // uint4 units per entry: cone_nk * 3 of stored values, then PP_POWERS16 of powers (fin29.h)
+  DevBuf<uint4> cone_cache;      // [entry][cone_stride]
+  std::vector<uint32_t> cone_gen, cone_free;   // generation per entry (a stale handle is refused); free list
+  std::vector<uint8_t> cone_live;
+  hipEvent_t evConeSaved = nullptr, evConeRead = nullptr;   // sW: the last save / wipe of entries; front end: the last restore
+  uint64_t cone_batches = 0;
+  uint32_t cone_entry(uint64_t h) const {   // NONE when the handle is not a live entry of this prover
+    const uint32_t idx = (uint32_t)(h & 0xFFFFFFFFu), gen = (uint32_t)(h >> 32);
+    if (idx == 0 || idx > cone_cap || !cone_live[idx - 1] || cone_gen[idx - 1] != gen) return 0xFFFFFFFFu;
+    return idx - 1;
+  }
   DevBuf<uint32_t> pp_in;      // resident partial-proof points for finish mode, 320 B per proof
   DevBuf<uint32_t> wgiven;     // externally calculated witnesses for the next run (upload_witness), else empty
   size_t wgiven_n = 0;
@@ -285,15 +304,16 @@ ProverTuning ProverTuning::from_env() {
   t.values_from_witness = env_int("RLNAMD_VALUES_WITNESS", 1) != 0;
   t.tiny_max = (uint32_t)std::max(0, env_int("RLNAMD_TINY", (int)t.tiny_max));
   t.ntt_lg_max = (uint32_t)std::max(0, env_int("RLNAMD_NTT_LG_MAX", (int)t.ntt_lg_max));
+  t.partial_cache = (uint32_t)std::max(0, env_int("RLNAMD_PARTIAL_CACHE", (int)t.partial_cache));
   t.marks_small = env_int("RLNAMD_MARKS_SMALL", 0) != 0;
   return t;
 }
 std::string ProverTuning::describe() const {
   char b[512];
   snprintf(b, sizeof b,
-           "window_bits=%d slots=%d lanechunk=%u lanechunk_walk=%u witlanes_max=%u tiny=%u ntt_lg_max=%u glv=%d wit29=%d lone=%d "
+           "window_bits=%d slots=%d lanechunk=%u lanechunk_walk=%u witlanes_max=%u tiny=%u ntt_lg_max=%u partial_cache=%u glv=%d wit29=%d lone=%d "
            "early_walk=%d early_fin=%d fused_smul=%d values_from_witness=%d marks_small=%d",
-           window_bits, slots, lanechunk_max, lanechunk_walk_max, witlanes_max, tiny_max, ntt_lg_max, (int)glv, (int)wit29, lone,
+           window_bits, slots, lanechunk_max, lanechunk_walk_max, witlanes_max, tiny_max, ntt_lg_max, partial_cache, (int)glv, (int)wit29, lone,
            (int)early_walk, (int)early_fin, (int)fused_smul, (int)values_from_witness, (int)marks_small);
   return b;
 }
@@ -743,6 +763,37 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     }
     D.known.resize(D.NS);
     for (uint32_t i = 0; i < D.NS; i++) D.known[i] = node_known[graph_.signals[i]];
+    // ---- the cone program and the cache of known stored values (prover.h: collect_partial_cached / submit_finish)
+    const long want = cfg.partial_cache >= 0 ? cfg.partial_cache : (long)D.tune.partial_cache;
+    D.tune.partial_cache = (uint32_t)std::max(0l, want);
+    if (D.wit29 && D.witlanes.ok && want > 0) {
+      WlCone C = wl_cone(graph_);
+      if (C.node_known != node_known) throw Error("internal: the cone's known mask differs from the prover's");
+      std::vector<uint32_t> store_slot(D.N, 0xFFFFFFFFu), rows;
+      for (uint32_t i = 0; i < wit29_slot2node.size(); i++) {
+        store_slot[wit29_slot2node[i]] = i;
+        if (node_known[wit29_slot2node[i]]) rows.push_back(i);
+      }
+      D.cone.build(C.graph, wl_cone_store_slots(C, store_slot), (uint32_t)wit29_slot2node.size(), s);
+      D.cone_nodes = (uint32_t)C.node_of.size();
+      if (D.cone.ok && !rows.empty()) {
+        D.cone_nk = (uint32_t)rows.size();
+        D.cone_rows.alloc(rows.size());
+        D.cone_rows.upload(rows.data(), rows.size(), s);
+        RLN_HIP(hipStreamSynchronize(s));
+        D.cone_cap = (uint32_t)want;
+        D.cone_stride = D.cone_nk * 3 + PP_POWERS16;
+        D.cone_cache.alloc((size_t)D.cone_cap * D.cone_stride);
+        RLN_HIP(hipMemset(D.cone_cache.p, 0, D.cone_cache.bytes()));
+        D.cone_gen.assign(D.cone_cap, 1);
+        D.cone_live.assign(D.cone_cap, 0);
+        for (uint32_t e = D.cone_cap; e-- > 0;) D.cone_free.push_back(e);
+        RLN_HIP(hipEventCreateWithFlags(&D.evConeSaved, hipEventDisableTiming));
+        RLN_HIP(hipEventCreateWithFlags(&D.evConeRead, hipEventDisableTiming));
+      } else {
+        D.cone.ok = false;
+      }
+    }
   }
 
   // ---- MSM segments.  Scalar ids: [0, NS) witness, [NS, NS+n) h, then r, s, -(r s).
@@ -972,10 +1023,11 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
         }
       }
       uint32_t unused = 0;
-      make_plans(f, 3, 4u, D.plan1f, &D.max_chunks1s, &unused,
-                 PROVE_FULL, npaired);
-      make_plans(f, 3, 1u, D.plan1tf, &D.max_chunks1t, &unused, PROVE_FULL, npaired, false, SUM_TREE_LANES / 2);   // summed by lane pairs
-      D.max_blocks1t = D.plan1tf[PROVE_FULL].nblocks;
+      for (int m : {(int)PROVE_FULL, (int)PROVE_FINISH}) {   // finish: the rows of the unknown signals only (alpha, beta, the known w_i: in pi_a, rho)
+        make_plans(f, 3, 4u, D.plan1f, &D.max_chunks1s, &unused, m, npaired);
+        make_plans(f, 3, 1u, D.plan1tf, &D.max_chunks1t, &unused, m, npaired, false, SUM_TREE_LANES / 2);   // summed by lane pairs
+        D.max_blocks1t = std::max(D.max_blocks1t, D.plan1tf[m].nblocks);
+      }
     }
     build_table29<Fq, G1Affine29>(pts, D.ws, D.t1_29, s, npaired);
   }
@@ -1005,8 +1057,10 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     {
       uint32_t unused = 0;
       make_plans(vrows, 1, 2u, D.plan2s, &D.max_chunks2s, &unused, -1);
-      make_plans(vrows, 1, 1u, D.plan2t, &D.max_chunks2t, &unused, PROVE_FULL, 0, false, SUM_TREE_LANES / 2);   // walked and summed by lane pairs
-      D.max_blocks2t = D.plan2t[PROVE_FULL].nblocks;
+      for (int m : {(int)PROVE_FULL, (int)PROVE_FINISH}) {
+        make_plans(vrows, 1, 1u, D.plan2t, &D.max_chunks2t, &unused, m, 0, false, SUM_TREE_LANES / 2);   // walked and summed by lane pairs
+        D.max_blocks2t = std::max(D.max_blocks2t, D.plan2t[m].nblocks);
+      }
     }
     build_table29<Fq2, G2Affine29>(pts, D.ws2, D.t2_29, s);
   }
@@ -1071,6 +1125,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     RLN_HIP(hipMemsetAsync(S.rs.p, 0, S.rs.bytes(), s));
     RLN_HIP(hipMemsetAsync(S.pp_in.p, 0, S.pp_in.bytes(), s));
     RLN_HIP(hipHostMalloc((void**)&S.h_in, B * ((size_t)D.NI * 32 + 64 + 320), hipHostMallocDefault));
+    RLN_HIP(hipHostMalloc((void**)&S.h_cone, B * 4, hipHostMallocDefault));
     RLN_HIP(hipEventCreateWithFlags(&S.evU, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evE, hipEventDisableTiming));
     RLN_HIP(hipHostMalloc((void**)&S.h_pp, B * 320, hipHostMallocDefault));
@@ -1083,6 +1138,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     RLN_HIP(hipEventCreateWithFlags(&S.evR, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evW, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evX, hipEventDisableTiming));
+    RLN_HIP(hipEventCreateWithFlags(&S.evP, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evV, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evC, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evZ, hipEventDisableTiming));
@@ -1105,6 +1161,9 @@ Prover::~Prover() {
     if (D.sW) {
       for (int k = 0; k < D.nslot; k++)
         if (D.slot[k].used && !D.slot[k].wiped && D.slot[k].evC) D.wipe_slot(D.slot[k], D.slot[k].ticket == 0);
+      if (D.cone_cache.p)   // entries a caller never released hold witness values too
+        hipLaunchKernelGGL(k_wipe_bytes, dim3(div_up(D.cone_cache.bytes() / 16, 256)), dim3(256), 0, D.sW, D.cone_cache.p,
+                           (uint32_t)(D.cone_cache.bytes() / 16));
       (void)hipStreamSynchronize(D.sW);
     }
   } catch (...) {
@@ -1112,16 +1171,19 @@ Prover::~Prover() {
   for (Slot& S : D.slot) {
     if (S.h_pp) (void)hipHostFree(S.h_pp);
     if (S.h_in) (void)hipHostFree(S.h_in);
+    if (S.h_cone) (void)hipHostFree(S.h_cone);
     if (S.evU) (void)hipEventDestroy(S.evU);
     if (S.evE) (void)hipEventDestroy(S.evE);
     if (S.h_comp) (void)hipHostFree(S.h_comp);
     if (S.h_values) (void)hipHostFree(S.h_values);
     if (S.h_err) (void)hipHostFree(S.h_err);
-    for (hipEvent_t e : {S.evA, S.evB, S.evB2, S.evR, S.evC, S.evW, S.evV, S.evX, S.evZ})
+    for (hipEvent_t e : {S.evA, S.evB, S.evB2, S.evR, S.evC, S.evW, S.evV, S.evX, S.evZ, S.evP})
       if (e) (void)hipEventDestroy(e);
     for (auto& e : S.t)
       if (e) (void)hipEventDestroy(e);
   }
+  for (hipEvent_t e : {D.evConeSaved, D.evConeRead})
+    if (e) (void)hipEventDestroy(e);
   for (hipStream_t st : {D.sA, D.sAb, D.sA2, D.sB, D.sB2, D.sC, D.sV, D.sW})
     if (st) (void)hipStreamDestroy(st);
 }
@@ -1185,6 +1247,98 @@ uint64_t Prover::submit(size_t n, const uint8_t* inputs, const uint8_t* rs, int 
   if (!inputs || !rs) throw Error("submit: inputs and rs are required");
   if (mode == PROVE_FINISH && !partial320) throw Error("submit: finish mode needs the partial points");
   return enqueue(n, mode, inputs, rs, partial320);
+}
+
+uint64_t Prover::submit_finish(size_t n, const uint8_t* inputs, const uint8_t* rs, const uint8_t* partial320,
+                               const uint64_t* handles) {
+  if (n == 0) throw Error("empty batch");
+  if (!inputs || !rs || !partial320) throw Error("submit_finish: inputs, rs and the partial points are required");
+  return enqueue(n, PROVE_FINISH, inputs, rs, partial320, handles);
+}
+
+void Prover::collect_partial_cached(uint64_t ticket, size_t n, uint8_t* partial320, uint64_t* handles, uint32_t* errors) {
+  Impl& D = *d_;
+  Slot* Sp = nullptr;
+  for (int k = 0; k < D.nslot; k++)
+    if (D.slot[k].used && D.slot[k].ticket == ticket && ticket != 0) Sp = &D.slot[k];
+  if (!Sp) throw Error("collect: unknown or expired ticket (its workspace slot has been reused)");
+  Slot& S = *Sp;
+  if (S.mode != PROVE_PARTIAL) throw Error("collect_partial_cached: not a partial-proof batch");
+  if (n > S.n) throw Error("collect: more proofs requested than the batch holds");
+  if (S.wiped) throw Error("collect_partial_cached: the batch has been wiped");
+  RLN_HIP(hipEventSynchronize(S.evC));
+  // entries for as many proofs as the cache has room for (in order); the rest get handle 0.  A proof whose graph
+  // evaluation failed gets none either (its rows are not a witness).
+  size_t cached = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (handles) handles[i] = 0;
+    if (!handles || !D.cone.ok || D.cone_free.empty() || S.h_err[i] != 0 || cached != i) continue;   // (a prefix: the save kernel's grid is [0, cached))
+    const uint32_t e = D.cone_free.back();
+    D.cone_free.pop_back();
+    D.cone_live[e] = 1;
+    S.h_cone[i] = e;
+    handles[i] = ((uint64_t)D.cone_gen[e] << 32) | (uint64_t)(e + 1);
+    cached++;
+  }
+  if (cached) {
+    RLN_HIP(hipStreamWaitEvent(D.sW, S.evC, 0));
+    hipLaunchKernelGGL(k_cone_save, dim3(div_up(D.cone_nk * 3, 256), (uint32_t)cached), dim3(256), 0, D.sW, S.V29.p, D.cone_rows.p,
+                       D.cone_nk, (uint32_t)B_, S.h_cone, D.cone_cache.p, D.cone_stride);
+    // the powers of pi_a and rho behind them (fin29.hip: what lets a finish drop the ladder of s A and r B1); the caller
+    // does not wait for this -- the first finish that uses the entry does (evConeSaved)
+    launch_pp_powers(D.sW, S.pp_out.p, S.h_cone, D.cone_cache.p, D.cone_stride, D.cone_nk * 3, (uint32_t)cached);
+    RLN_HIP(hipGetLastError());
+    RLN_HIP(hipEventRecord(D.evConeSaved, D.sW));
+  }
+  collect(ticket, n, nullptr, nullptr, errors, nullptr, partial320, true);   // copy-out, then the wipe -- behind the save on sW
+}
+
+void Prover::release_partial(const uint64_t* handles, size_t n) {
+  Impl& D = *d_;
+  if (!D.cone_cap || !handles) return;
+  bool any = false;
+  for (size_t i = 0; i < n; i++) {
+    const uint32_t e = D.cone_entry(handles[i]);
+    if (e == 0xFFFFFFFFu) continue;
+    if (!any) RLN_HIP(hipStreamWaitEvent(D.sW, D.evConeRead, 0));   // a finish in flight may still read its entries
+    any = true;
+    uint4* at = D.cone_cache.p + (size_t)e * D.cone_stride;
+    hipLaunchKernelGGL(k_wipe_bytes, dim3(div_up(D.cone_stride, 256)), dim3(256), 0, D.sW, at, D.cone_stride);
+    D.cone_live[e] = 0;
+    D.cone_gen[e]++;
+    if (D.cone_gen[e] == 0) D.cone_gen[e] = 1;
+    D.cone_free.push_back(e);
+  }
+  if (any) {
+    RLN_HIP(hipGetLastError());
+    RLN_HIP(hipEventRecord(D.evConeSaved, D.sW));   // a later save / restore of a reused entry orders behind the wipe
+  }
+}
+
+void Prover::partial_cache_info(uint64_t out[PARTIAL_CACHE_FIELDS]) {
+  Impl& D = *d_;
+  for (int k = 0; k < PARTIAL_CACHE_FIELDS; k++) out[k] = 0;
+  out[0] = D.cone_cap;
+  out[1] = D.cone_cap - D.cone_free.size();
+  out[2] = (uint64_t)D.cone_stride * 16;
+  out[4] = D.cone_batches;
+  out[5] = D.cone_nodes;
+  out[6] = D.cone.ok ? D.cone.nsteps : 0;
+  out[7] = D.witlanes.ok ? D.witlanes.nsteps : 0;
+  if (!D.cone_cap) return;
+  sync();
+  RLN_HIP(hipStreamSynchronize(D.sW));
+  DevBuf<unsigned long long> cnt(1);
+  RLN_HIP(hipMemsetAsync(cnt.p, 0, cnt.bytes(), D.sC));
+  for (uint32_t e = 0; e < D.cone_cap; e++)
+    if (!D.cone_live[e])
+      hipLaunchKernelGGL(k_count_nonzero16, dim3(64), dim3(256), 0, D.sC, (const uint4*)(D.cone_cache.p + (size_t)e * D.cone_stride),
+                         (size_t)D.cone_stride, cnt.p);
+  RLN_HIP(hipGetLastError());
+  unsigned long long h = 0;
+  RLN_HIP(hipMemcpyAsync(&h, cnt.p, sizeof h, hipMemcpyDeviceToHost, D.sC));
+  RLN_HIP(hipStreamSynchronize(D.sC));
+  out[3] = h;
 }
 
 void Prover::collect(uint64_t ticket, size_t n, uint8_t* proofs, uint8_t* values, uint32_t* errors, uint8_t* coords,
@@ -1299,7 +1453,8 @@ void Prover::prove_stream_from(const ChunkSource& next, const uint8_t* inputs, c
   }
 }
 
-uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint8_t* h_rs, const uint8_t* h_pp320) {
+uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint8_t* h_rs, const uint8_t* h_pp320,
+                         const uint64_t* cone_handles) {
   if (n == 0) return 0;
   if (n > B_) throw Error("batch larger than the prover workspace (max_batch)");
   if (mode < PROVE_FULL || mode > PROVE_FINISH) throw Error("unknown prover mode");
@@ -1311,6 +1466,21 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   const bool lone = lone_force >= 0 ? lone_force != 0 : (!D.last || hipEventQuery(D.last->evC) == hipSuccess);
   (void)hipGetLastError();   // hipErrorNotReady is not an error here
   const bool small = n <= D.lanechunk_max && n <= D.small_stride;   // lanes = chunks
+  // The lanes = nodes interpreter (a wave and 157 KB of LDS per proof, ~25 x the instructions per proof of k_witness29,
+  // 1.5 ms per 256 proofs against 11 ms): always below the small-batch threshold; up to witlanes_max only for a LONE batch -- in a stream
+  // of such batches it costs throughput (profiles/r3_rocprof_summary.md, section 10), and there the previous batch is still in flight.
+  const uint32_t wl_lone_max = D.device.shared() ? std::min(D.witlanes_max, 256u) : D.witlanes_max;
+  const bool wl_used = D.wit29 && D.witlanes.ok && (n <= D.lanechunk_max || (n <= wl_lone_max && lone));
+  // Finish with the partial run's values at hand (prover.h: submit_finish): every proof of the batch has a live cache
+  // entry and the batch is one the wave-per-proof interpreter takes -> the known rows come back from the cache and only
+  // the cone evaluate_partial leaves unknown is interpreted (depth-20 circuit: 1 947 of 23 414 nodes, a twelfth of the
+  // multiplication depth).  Anything else -- a dead handle, a big batch -- walks the whole graph: same bytes.
+  std::vector<uint32_t> cone_entries;
+  bool cone = mode == PROVE_FINISH && cone_handles && h_inputs && wl_used && D.cone.ok;
+  for (size_t i = 0; i < n && cone; i++) {
+    const uint32_t e = D.cone_entry(cone_handles[i]);
+    if (e == 0xFFFFFFFFu) cone = false; else cone_entries.push_back(e);
+  }
   // Small batches (latency, not throughput): the whole front end stays on ONE stream (every cross-stream event hop costs
   // 0.1 - 0.15 ms), the digits of the witness scalars are recoded right behind the interpreter, and both walks start on
   // everything that does not depend on the quotient h while mat-vec / NTTs still run; only the h rows of the G1 walk
@@ -1319,12 +1489,15 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // small full proofs: s A and r B1 are rows of the C segment (plan1f), no k_fin_smul
   // (up to 96 proofs: above, the walks are issue-bound even for a lone batch and the extra rows cost more than the ladder
   // they replace -- 128 proofs 16.6 -> 15.3 ms without them, 64 proofs 10.1 -> 10.3 ms)
-  const bool fused = lone && n <= 96 && early && small && mode == PROVE_FULL && D.nh == 2 && T.fused_smul && T.early_fin;   // (its back end is the split one below)
+  // (round 6: a finish whose partial proofs are cached takes it too -- the variable-base part that is left, s pi_a + r rho,
+  // comes from the powers in the cache entries: k_pp_smul)
+  const bool fused = lone && n <= 96 && early && small && (mode == PROVE_FULL || (mode == PROVE_FINISH && cone)) && D.nh == 2 &&
+                     T.fused_smul && T.early_fin;   // (its back end is the split one below)
   // tiny: a lane per (row, half) and a two-stage sum (plan1tf / plan2t) -- only the fused full proof of a lone batch, and
   // only when it walks with lanes = chunks (the lanes = proofs form of the mid-size batches needs 64 proofs of stride)
   const bool tiny = fused && n <= T.tiny_max && n <= Impl::tiny_stride && n <= D.lanechunk_walk_max;
-  const Impl::Plan& P1 = tiny ? D.plan1tf[PROVE_FULL] : fused ? D.plan1f[PROVE_FULL] : small ? D.plan1s[mode] : D.plan1[mode];
-  const Impl::Plan& P2 = tiny ? D.plan2t[PROVE_FULL] : small ? D.plan2s[mode] : D.plan2[mode];
+  const Impl::Plan& P1 = tiny ? D.plan1tf[mode] : fused ? D.plan1f[mode] : small ? D.plan1s[mode] : D.plan1[mode];
+  const Impl::Plan& P2 = tiny ? D.plan2t[mode] : small ? D.plan2s[mode] : D.plan2[mode];
   const uint32_t PB = tiny ? Impl::tiny_stride : small ? D.small_stride : (uint32_t)B_;   // stride of the partial-sum arrays
   // mid-size small batches: the short-chunk plans walked with lanes = proofs (walk29.h).  A lone batch: above 48 proofs
   // (64: 11.3 -> 9.9 ms, 128: 18.1 -> 16.3 ms; 32: 6.9 ms against 8.4).  In a stream of batches the lanes = chunks form
@@ -1394,14 +1567,26 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   do {                                                    \
     if (marks) RLN_HIP(hipEventRecord(S.t[i], stream));   \
   } while (0)
-  // The lanes = nodes interpreter (a wave and 157 KB of LDS per proof, ~25 x the instructions per proof of k_witness29,
-  // 1.5 ms per 256 proofs against 11 ms): always below the small-batch threshold; up to witlanes_max only for a LONE batch -- in a stream
-  // of such batches it costs throughput (profiles/r3_rocprof_summary.md, section 10), and there the previous batch is still in flight.
-  const uint32_t wl_lone_max = D.device.shared() ? std::min(D.witlanes_max, 256u) : D.witlanes_max;
-  const bool wl_used = D.wit29 && D.witlanes.ok && (nb <= D.lanechunk_max || (nb <= wl_lone_max && lone));
+  if (cone) memcpy(S.h_cone, cone_entries.data(), n * sizeof(uint32_t));   // (the slot's previous batch has finished: see `streamed` above)
+  if (fused && mode == PROVE_FINISH) {   // s pi_a + r rho beside everything else: needs (r, s) and the entries' powers only
+    if (S.used) RLN_HIP(hipStreamWaitEvent(D.sC, S.free_event(), 0));
+    RLN_HIP(hipStreamWaitEvent(D.sC, S.evU, 0));
+    RLN_HIP(hipStreamWaitEvent(D.sC, D.evConeSaved, 0));
+    launch_pp_smul(D.sC, D.cone_cache.p, S.h_cone, D.cone_stride, D.cone_nk * 3, rs_p, S.prod.p, nb);
+    RLN_HIP(hipGetLastError());
+    RLN_HIP(hipEventRecord(S.evP, D.sC));
+    RLN_HIP(hipEventRecord(D.evConeRead, D.sC));
+  }
   MARK(1, sA);
   if (D.wit29) {
-    if (wl_used) {
+    if (cone) {
+      RLN_HIP(hipStreamWaitEvent(sA, D.evConeSaved, 0));   // sW: the entries are written by the partial batch's collect
+      hipLaunchKernelGGL(k_cone_restore, dim3(div_up(D.cone_nk * 3, 256), nb), dim3(256), 0, sA, D.cone_cache.p, D.cone_rows.p,
+                         D.cone_nk, B, S.h_cone, S.V29.p, D.cone_stride);
+      RLN_HIP(hipEventRecord(D.evConeRead, sA));
+      D.cone.launch(sA, in_p, D.NI, S.V29.p, S.err.p, B, nb);
+      D.cone_batches++;
+    } else if (wl_used) {
       D.witlanes.launch(sA, in_p, D.NI, S.V29.p, S.err.p, B, nb);
     } else
     hipLaunchKernelGGL(k_witness29<false>, dim3(pg), dim3(64), WIT29_LDS_BYTES, sA, D.nodes29.p, D.nprog29,
@@ -1589,7 +1774,10 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // Small full proofs: A and B1 are sums over h-independent rows only, so their reduction, the two inversions and the two
   // variable-base products s A, r B1 (the longest kernel of the back end) run on the idle D.sA2 as soon as the early G1
   // walk is done -- beside the NTTs and the walk of the h rows, not behind them.  sums1 segments: h * 3 + {A, B1, C}.
-  const bool early_fin = early && mode == PROVE_FULL && D.nh == 2 && T.early_fin;
+  // (round 6: PROVE_FINISH as well -- the partial points join their sums where each sum is complete, k_add_partial per
+  // task; until then a lone finish took the serial back end of the big batches and was SLOWER than a lone full proof)
+  const bool early_fin = early && (mode == PROVE_FULL || mode == PROVE_FINISH) && D.nh == 2 && T.early_fin;
+  const bool fin_pp = mode == PROVE_FINISH;
   const TaskSel all6 = task_sel({0, 1, 2, 3, 4, 5}), all4 = task_sel({0, 1, 2, 3}), all3 = task_sel({0, 1, 2});
   // below a wave of proofs s A / r B1 are a lone lane's chain: NAF ladder in the 9 x 29 form (fin29.hip)
   const bool fin29 = nb <= D.lanechunk_max;
@@ -1624,8 +1812,10 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
       // fused plan: only A's segment sums are formed early; its fold and inversion ride in k_fin_out_ac_fused, and s A,
       // r B1 are inside the C segment (B1 is never formed)
       sum1(D.sA2, {0, 3});
+      if (fin_pp) hipLaunchKernelGGL(k_add_partial, dim3(pg, 1), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, pp_p, B, nbp, task_sel({0}), (const G1XYZZ*)nullptr);
     } else {
       sum1(D.sA2, {0, 1, 3, 4});
+      if (fin_pp) hipLaunchKernelGGL(k_add_partial, dim3(pg, 2), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, pp_p, B, nbp, task_sel({0, 1}), (const G1XYZZ*)nullptr);
       hipLaunchKernelGGL(k_glv_fold, dim3(pg, 2), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, 3u, B, nbp, task_sel({0, 1}));
       hipLaunchKernelGGL(k_fin_affine, dim3(pg, 2), dim3(64), 0, D.sA2, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
                          S.affB2.p, B, nbp, task_sel({0, 1}));
@@ -1643,6 +1833,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     hipStream_t sG = lone ? s2 : D.sC;
     if (!lone) RLN_HIP(hipStreamWaitEvent(D.sC, S.evB2, 0));
     sum2(sG);
+    if (fin_pp) hipLaunchKernelGGL(k_add_partial, dim3(pg, 1), dim3(64), 0, sG, S.sums1.p, S.sums2.p, pp_p, B, nbp, task_sel({3}), (const G1XYZZ*)nullptr);
     // B's side of the output right here (fold, inversion, bytes): see k_fin_out_b2
     hipLaunchKernelGGL(k_fin_out_b2, dim3(pg), dim3(64), 0, sG, S.sums2.p, S.coords.p, S.comp.p, B, nbp);
     if (lone) RLN_HIP(hipEventRecord(S.evB2, s2));
@@ -1662,6 +1853,11 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
       RLN_HIP(hipStreamWaitEvent(sF, S.evB, 0));
     }
     sum1(sAC, {2, 5});
+    if (fin_pp) hipLaunchKernelGGL(k_add_partial, dim3(pg, 1), dim3(64), 0, sAC, S.sums1.p, S.sums2.p, pp_p, B, nbp, task_sel({2}), (const G1XYZZ*)nullptr);
+    if (fin_pp && fused) {   // + s pi_a + r rho (k_pp_smul, long done)
+      RLN_HIP(hipStreamWaitEvent(sAC, S.evP, 0));
+      hipLaunchKernelGGL(k_add_partial, dim3(pg, 1), dim3(64), 0, sAC, S.sums1.p, S.sums2.p, pp_p, B, nbp, task_sel({4}), (const G1XYZZ*)S.prod.p);
+    }
     RLN_HIP(hipStreamWaitEvent(sAC, S.evA, 0));   // A affine, s A and r B1
     // A's and C's side of the output (fold of the C segment, inversion, bytes): see k_fin_out_ac
     if (fused)
@@ -1702,8 +1898,8 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     RLN_HIP(hipGetLastError());
     RLN_HIP(hipMemcpyAsync(S.h_pp, S.pp_out.p, n * 320, hipMemcpyDeviceToHost, D.sC));
   } else {
-    if (mode == PROVE_FINISH)
-      hipLaunchKernelGGL(k_add_partial, dim3(pg, 4), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, pp_p, B, nbp);
+    if (mode == PROVE_FINISH && !early_fin)
+      hipLaunchKernelGGL(k_add_partial, dim3(pg, 4), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, pp_p, B, nbp, all4, (const G1XYZZ*)nullptr);
     if (!early_fin) {
       hipLaunchKernelGGL(k_fin_affine, dim3(pg, 3), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, S.affA.p, S.affB1.p,
                          S.affB2.p, B, nbp, all3);

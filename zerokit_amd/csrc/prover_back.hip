@@ -41,12 +41,19 @@ __global__ void __launch_bounds__(64) k_partial_out(const G1XYZZ* __restrict__ s
   }
 }
 __global__ void __launch_bounds__(64) k_add_partial(G1XYZZ* __restrict__ sums1, G2XYZZ* __restrict__ sums2,
-                                                    const uint32_t* __restrict__ pp, uint32_t B, uint32_t nb) {
+                                                    const uint32_t* __restrict__ pp, uint32_t B, uint32_t nb, TaskSel sel,
+                                                    const G1XYZZ* __restrict__ extra) {
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
   if (p >= nb) return;
   const uint32_t* o = pp + (size_t)p * 80;
-  const uint32_t t = blockIdx.y;
-  if (t < 3) {
+  // 0 pi_a -> A, 1 rho -> B1, 2 pi_c -> C, 3 pi_b -> B2 (the first GLV half's sums); 4: extra[p] -> C (s pi_a + r rho of the
+  // fused finish, k_pp_smul)
+  const uint32_t t = sel.id[blockIdx.y];
+  if (t == 4) {
+    G1XYZZ acc = sums1[2 * (size_t)B + p];
+    acc.add(extra[p]);
+    sums1[2 * (size_t)B + p] = acc;
+  } else if (t < 3) {
     const uint32_t* d = o + (t == 0 ? 0 : t == 1 ? 16 : 64);
     G1Affine a{Fq::from_canonical(d), Fq::from_canonical(d + 8)};
     G1XYZZ acc = sums1[(size_t)t * B + p];
@@ -377,6 +384,20 @@ __global__ void k_scatter_witness(const uint32_t* __restrict__ given, const uint
 // Single-wave workgroups: a 256-thread workgroup needs four free wave slots on one CU at the same instant, which the
 // single-wave MSM workgroups streaming through the chip rarely leave (rocprofv3: 3.0 ms on average, 26.7 ms at worst
 // for this 30 us copy when it was launched as 256-thread workgroups).
+__global__ void __launch_bounds__(256) k_cone_save(const uint4* __restrict__ V29, const uint32_t* __restrict__ rows, uint32_t nk,
+                                                   uint32_t B, const uint32_t* __restrict__ entry_of, uint4* __restrict__ cache, uint32_t stride16) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x, p = blockIdx.y;
+  if (i >= nk * 3) return;
+  const uint32_t k = i / 3, w = i % 3;
+  cache[(size_t)entry_of[p] * stride16 + (size_t)k * 3 + w] = V29[((size_t)rows[k] * B + p) * 3 + w];
+}
+__global__ void __launch_bounds__(256) k_cone_restore(const uint4* __restrict__ cache, const uint32_t* __restrict__ rows, uint32_t nk,
+                                                      uint32_t B, const uint32_t* __restrict__ entry_of, uint4* __restrict__ V29, uint32_t stride16) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x, p = blockIdx.y;
+  if (i >= nk * 3) return;
+  const uint32_t k = i / 3, w = i % 3;
+  V29[((size_t)rows[k] * B + p) * 3 + w] = cache[(size_t)entry_of[p] * stride16 + (size_t)k * 3 + w];
+}
 __global__ void __launch_bounds__(64) k_stage_in(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16) {
   uint32_t i = blockIdx.x * 64 + threadIdx.x;
   if (i < n16) dst[i] = src[i];

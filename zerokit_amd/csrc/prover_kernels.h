@@ -123,7 +123,8 @@ __global__ void __launch_bounds__(64) k_table_build(const Affine<F>* __restrict_
 __global__ void __launch_bounds__(64) k_partial_out(const G1XYZZ* __restrict__ sums1, const G2XYZZ* __restrict__ sums2,
                                                     uint32_t* __restrict__ out, uint32_t B, uint32_t nb);
 __global__ void __launch_bounds__(64) k_add_partial(G1XYZZ* __restrict__ sums1, G2XYZZ* __restrict__ sums2,
-                                                    const uint32_t* __restrict__ pp, uint32_t B, uint32_t nb);
+                                                    const uint32_t* __restrict__ pp, uint32_t B, uint32_t nb, TaskSel sel,
+                                                    const G1XYZZ* __restrict__ extra);
 __global__ void __launch_bounds__(64) k_fin_affine(const G1XYZZ* __restrict__ sums1, const G2XYZZ* __restrict__ sums2,
                                                    G1Affine* __restrict__ affA, G1Affine* __restrict__ affB1,
                                                    G2Affine* __restrict__ affB2, uint32_t B, uint32_t nb, TaskSel sel);
@@ -153,6 +154,12 @@ __global__ void k_gather_col(const Fr* __restrict__ src, const uint32_t* __restr
                              uint32_t p, uint32_t* __restrict__ out);
 __global__ void k_scatter_witness(const uint32_t* __restrict__ given, const uint32_t* __restrict__ sig2node,
                                   uint32_t NS, Fr* __restrict__ V, uint32_t* __restrict__ err, uint32_t B, uint32_t nb);
+// partial-proof cache (Prover::collect_partial_cached / submit_finish): rows[k] = stored slot of the k-th known value;
+// entry_of[p] (pinned host memory) = cache entry of proof p; an entry is [nk][3] uint4 in the 9 x 29 form of V29
+__global__ void __launch_bounds__(256) k_cone_save(const uint4* __restrict__ V29, const uint32_t* __restrict__ rows, uint32_t nk,
+                                                   uint32_t B, const uint32_t* __restrict__ entry_of, uint4* __restrict__ cache, uint32_t stride16);
+__global__ void __launch_bounds__(256) k_cone_restore(const uint4* __restrict__ cache, const uint32_t* __restrict__ rows, uint32_t nk,
+                                                      uint32_t B, const uint32_t* __restrict__ entry_of, uint4* __restrict__ V29, uint32_t stride16);
 __global__ void __launch_bounds__(64) k_stage_in(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16);
 __global__ void __launch_bounds__(64) k_wipe_cols(Fr* __restrict__ V, const uint32_t* __restrict__ rows, uint32_t nrows,
                                                   uint32_t B, uint32_t n);

@@ -825,4 +825,71 @@ static WlProgram wl_schedule_graph(const Graph& graph, const std::vector<uint32_
   return R;
 }
 
+
+// ------------------------------------------------------------------------------------------------- the unknown cone
+WlCone wl_cone(const Graph& g) {
+  const std::vector<GNode>& G = g.nodes;
+  const uint32_t N = (uint32_t)G.size();
+  auto nops = [&](const GNode& q) {
+    return (q.op == G_INPUT || q.op == G_CONST) ? 0 : (q.op == G_NEG || q.op == G_ID) ? 1 : q.op == G_TERN ? 3 : 2;
+  };
+  WlCone C;
+  std::vector<uint8_t> in_known(g.inputs_size, 1);
+  for (const char* name : {"messageId", "selectorUsed", "x", "externalNullifier"}) {
+    auto it = g.input_mapping.find(name);
+    if (it == g.input_mapping.end()) continue;
+    for (uint32_t k = 0; k < it->second.second; k++)
+      if (it->second.first + k < in_known.size()) in_known[it->second.first + k] = 0;
+  }
+  C.node_known.assign(N, 0);
+  for (uint32_t i = 0; i < N; i++) {
+    const GNode& q = G[i];
+    const uint32_t o[3] = {q.a, q.b, q.c};
+    bool k = true;
+    if (q.op == G_INPUT) k = q.a < in_known.size() && in_known[q.a];
+    else
+      for (int j = 0; j < nops(q); j++) {
+        if (o[j] >= i) throw std::runtime_error("Graph error: node operand refers forward");
+        k = k && C.node_known[o[j]];
+      }
+    C.node_known[i] = k;
+  }
+  // members: every unknown node; from there down, every operand (known ones included) until inputs and constants
+  std::vector<uint8_t> member(N, 0);
+  for (uint32_t i = N; i-- > 0;) {
+    if (!C.node_known[i]) member[i] = 1;
+    if (!member[i]) continue;
+    const uint32_t o[3] = {G[i].a, G[i].b, G[i].c};
+    for (int j = 0; j < nops(G[i]); j++) member[o[j]] = 1;
+  }
+  std::vector<uint32_t> remap(N, NONE);
+  for (uint32_t i = 0; i < N; i++) {
+    if (!member[i]) continue;
+    remap[i] = (uint32_t)C.node_of.size();
+    C.node_of.push_back(i);
+    GNode q = G[i];
+    const int k = nops(q);
+    if (k > 0) q.a = remap[q.a];
+    if (k > 1) q.b = remap[q.b];
+    if (k > 2) q.c = remap[q.c];
+    C.graph.nodes.push_back(q);
+    C.recomputed.push_back(C.node_known[i] && q.op != G_INPUT && q.op != G_CONST);
+  }
+  C.graph.constants = g.constants;
+  C.graph.input_mapping = g.input_mapping;
+  C.graph.tree_depth = g.tree_depth;
+  C.graph.max_out = g.max_out;
+  C.graph.inputs_size = g.inputs_size;
+  for (uint32_t sg : g.signals)
+    if (!C.node_known[sg]) C.graph.signals.push_back(remap[sg]);
+  return C;
+}
+
+std::vector<uint32_t> wl_cone_store_slots(const WlCone& cone, const std::vector<uint32_t>& store_slot_full) {
+  std::vector<uint32_t> st(cone.node_of.size(), NONE);
+  for (uint32_t c = 0; c < cone.node_of.size(); c++)
+    if (!cone.node_known[cone.node_of[c]]) st[c] = store_slot_full[cone.node_of[c]];
+  return st;
+}
+
 }  // namespace rlnamd

@@ -36,4 +36,25 @@ struct WlProgram {
 // rows: products in row form (WK_ROW, at most WL_ROWS per step) instead of lane form (WK_FMA / WK_SQR)
 WlProgram wl_schedule(const Graph& graph, const std::vector<uint32_t>& store_slot, uint32_t trash_slot, bool rows);
 
+
+// ---- finishing a partial proof without re-walking what the partial witness already fixed (round 6) ----------------------
+// evaluate_partial (/root/reference/rln/src/circuit/iden3calc/graph.rs:274-312): a node is known iff all its operands
+// are; the inputs the partial witness leaves open are the per-message ones (inputs_for_partial_witness_calculation,
+// protocol/witness.rs:887-937).  finish_zk_proof_with_rs (protocol/proof.rs:822-849) calculates the WHOLE witness again;
+// the values of the known nodes are the ones the partial run already produced.  wl_cone cuts the graph down to what a
+// finish has to compute when those values are at hand: the unknown nodes, plus the few known nodes they read that are
+// neither inputs nor constants (recomputed: in the shipped circuits 13 nodes, all shallow), plus the input / constant
+// nodes either kind reads -- a graph of its own in the original order, to be scheduled by wl_schedule like the full one
+// (depth-20 circuit: 1 934 of 23 414 nodes, multiplication depth 512 of 5 736: the 20-level Merkle chain is known).
+struct WlCone {
+  Graph graph;                        // inputs buffer, constants, input mapping as in the full graph; signals = the unknown ones
+  std::vector<uint32_t> node_of;      // cone node -> node of the full graph
+  std::vector<uint8_t> node_known;    // per node of the FULL graph: evaluate_partial's Some / None
+  std::vector<uint8_t> recomputed;    // per cone node: a known non-input node that is computed again (never stored)
+};
+WlCone wl_cone(const Graph& graph);
+// store slots of the cone's nodes from the full graph's: an unknown node keeps its slot (the same row of the stored
+// values), everything else is not stored -- the known rows come from the partial run
+std::vector<uint32_t> wl_cone_store_slots(const WlCone& cone, const std::vector<uint32_t>& store_slot_full);
+
 }  // namespace rlnamd
