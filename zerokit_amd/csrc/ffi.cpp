@@ -823,7 +823,7 @@ FFI_RLNProof* finish_proof(FFI_RLN& rln, const FFI_RLNPartialProof& pp, const FF
   fill_inputs(P, w, inputs.data());
   memcpy(rs.data(), r.le, 32);
   memcpy(rs.data() + 32, s.le, 32);
-  if (pp.handle && !w.multi) {   // the partial run's values are on this device: streamed, the cone only (a dead handle: the whole graph)
+  if (!w.multi) {   // streamed; with a live handle the partial run's values are on this device and only the cone is interpreted
     ProofOut po;
     const uint64_t ticket = P.submit_finish(1, inputs.data(), rs.data(), pp.coords, &pp.handle);
     P.collect(ticket, 1, po.compressed, &po.values[0][0], &po.error);

@@ -60,6 +60,7 @@ struct Slot {
   hipEvent_t evA = nullptr, evB = nullptr, evB2 = nullptr, evR = nullptr, evC = nullptr, evW = nullptr, evV = nullptr;
   hipEvent_t evX = nullptr;     // the witness is in V (before the small-batch recodes that follow it on the same stream)
   hipEvent_t evP = nullptr;     // fused finish: s pi_a + r rho is in `prod` (k_pp_smul)
+  DevBuf<uint4> pp_pow;         // ... from the powers of pi_a, rho made at finish time when no cache entry holds them (<= 96 proofs)
   hipEvent_t t[15] = {};  // timing marks
   bool used = false;
   bool marked = false;          // the timing marks t[] of the slot's batch were recorded
@@ -166,6 +167,7 @@ struct Prover::Impl {
   uint32_t cone_nk = 0, cone_cap = 0;
   uint32_t cone_stride = 0;      // uint4 units per entry: cone_nk * 3 of stored values, then PP_POWERS16 of powers (fin29.h)
   DevBuf<uint4> cone_cache;      // [entry][cone_stride]
+  DevBuf<uint32_t> iota96;       // 0 .. 95: "entry p of proof p" for the per-slot powers of a finish without cache entries
   std::vector<uint32_t> cone_gen, cone_free;   // generation per entry (a stale handle is refused); free list
   std::vector<uint8_t> cone_live;
   hipEvent_t evConeSaved = nullptr, evConeRead = nullptr;   // sW: the last save / wipe of entries; front end: the last restore
@@ -763,6 +765,13 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     }
     D.known.resize(D.NS);
     for (uint32_t i = 0; i < D.NS; i++) D.known[i] = node_known[graph_.signals[i]];
+    {
+      std::vector<uint32_t> io(96);
+      for (uint32_t i = 0; i < 96; i++) io[i] = i;
+      D.iota96.alloc(96);
+      D.iota96.upload(io.data(), 96, s);
+      RLN_HIP(hipStreamSynchronize(s));
+    }
     // ---- the cone program and the cache of known stored values (prover.h: collect_partial_cached / submit_finish)
     const long want = cfg.partial_cache >= 0 ? cfg.partial_cache : (long)D.tune.partial_cache;
     D.tune.partial_cache = (uint32_t)std::max(0l, want);
@@ -1139,6 +1148,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     RLN_HIP(hipEventCreateWithFlags(&S.evW, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evX, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evP, hipEventDisableTiming));
+    S.pp_pow.alloc((size_t)std::min<size_t>(B, 96) * PP_POWERS16);
     RLN_HIP(hipEventCreateWithFlags(&S.evV, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evC, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evZ, hipEventDisableTiming));
@@ -1489,10 +1499,10 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // small full proofs: s A and r B1 are rows of the C segment (plan1f), no k_fin_smul
   // (up to 96 proofs: above, the walks are issue-bound even for a lone batch and the extra rows cost more than the ladder
   // they replace -- 128 proofs 16.6 -> 15.3 ms without them, 64 proofs 10.1 -> 10.3 ms)
-  // (round 6: a finish whose partial proofs are cached takes it too -- the variable-base part that is left, s pi_a + r rho,
-  // comes from the powers in the cache entries: k_pp_smul)
-  const bool fused = lone && n <= 96 && early && small && (mode == PROVE_FULL || (mode == PROVE_FINISH && cone)) && D.nh == 2 &&
-                     T.fused_smul && T.early_fin;   // (its back end is the split one below)
+  // (round 6: a streamed finish takes it too -- the variable-base part that is left, s pi_a + r rho,
+  // comes from powers of the two points: k_pp_smul -- cached with the partial run's values, or made beside the interpreter)
+  const bool fused = lone && n <= 96 && early && small && (mode == PROVE_FULL || (mode == PROVE_FINISH && h_inputs && h_pp320)) &&
+                     D.nh == 2 && T.fused_smul && T.early_fin;   // (its back end is the split one below)
   // tiny: a lane per (row, half) and a two-stage sum (plan1tf / plan2t) -- only the fused full proof of a lone batch, and
   // only when it walks with lanes = chunks (the lanes = proofs form of the mid-size batches needs 64 proofs of stride)
   const bool tiny = fused && n <= T.tiny_max && n <= Impl::tiny_stride && n <= D.lanechunk_walk_max;
@@ -1571,11 +1581,16 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   if (fused && mode == PROVE_FINISH) {   // s pi_a + r rho beside everything else: needs (r, s) and the entries' powers only
     if (S.used) RLN_HIP(hipStreamWaitEvent(D.sC, S.free_event(), 0));
     RLN_HIP(hipStreamWaitEvent(D.sC, S.evU, 0));
-    RLN_HIP(hipStreamWaitEvent(D.sC, D.evConeSaved, 0));
-    launch_pp_smul(D.sC, D.cone_cache.p, S.h_cone, D.cone_stride, D.cone_nk * 3, rs_p, S.prod.p, nb);
+    if (cone) {
+      RLN_HIP(hipStreamWaitEvent(D.sC, D.evConeSaved, 0));
+      launch_pp_smul(D.sC, D.cone_cache.p, S.h_cone, D.cone_stride, D.cone_nk * 3, rs_p, S.prod.p, nb);
+      RLN_HIP(hipEventRecord(D.evConeRead, D.sC));
+    } else {   // no cache entries: the powers are made here, beside the interpreter of the whole graph (0.55 ms of its 1.5)
+      launch_pp_powers(D.sC, pp_p, D.iota96.p, S.pp_pow.p, PP_POWERS16, 0, nb);
+      launch_pp_smul(D.sC, S.pp_pow.p, D.iota96.p, PP_POWERS16, 0, rs_p, S.prod.p, nb);
+    }
     RLN_HIP(hipGetLastError());
     RLN_HIP(hipEventRecord(S.evP, D.sC));
-    RLN_HIP(hipEventRecord(D.evConeRead, D.sC));
   }
   MARK(1, sA);
   if (D.wit29) {
