@@ -706,7 +706,13 @@ def operating_points_main(args):
                   "table_gib": [round(a.info.table_bytes / 2**30, 2), round(m.info.table_bytes / 2**30, 2)],
                   "init_s_both": round(init_s, 2),
                   "proofs_per_s_single_circuit_alone": round(alone_a, 1), "proofs_per_s_multi_circuit_alone": round(alone_m, 1),
-                  "proofs_per_s_alternating_batches_total": round(both, 1), "verified": bool(ok)}
+                  "proofs_per_s_alternating_batches_total": round(both, 1),
+                  # equal numbers of proofs of both circuits: with the chip to itself a pair (one proof of each) costs
+                  # 1 / single + 1 / multi seconds -- the harmonic mean is what a perfect time-sharing of the device gives
+                  "time_weighted_mix_proofs_per_s": round(2.0 / (1.0 / alone_a + 1.0 / alone_m), 1),
+                  "alternating_over_time_weighted_mix": round(both / (2.0 / (1.0 / alone_a + 1.0 / alone_m)), 4),
+                  "device_shared_flags": [a.device_shared(), m.device_shared()],
+                  "verified": bool(ok)}
         finally:
             a.close()
             m.close()

@@ -164,6 +164,10 @@ int rlnamd_prover_residue(rlnamd_prover* p, uint64_t out[6]);
 #define RLNAMD_MODE_FINISH 2
 int rlnamd_prover_run_mode(rlnamd_prover* p, size_t n, int mode);
 int rlnamd_prover_run_async_mode(rlnamd_prover* p, size_t n, int mode);
+/* Who else proves on this prover's device: bit 0 = another prover of this process, bit 1 = a prover of ANOTHER process
+ * (every process with a prover on a device holds a read record lock on /dev/shm/rlnamd_<PCI bus id>.lock; probed at most
+ * every 50 ms).  A shared device keeps the wide latency shapes off (they assume the chip is this prover's). */
+int rlnamd_prover_device_shared(rlnamd_prover* p, int* who);
 /* Finish without re-walking what the partial witness fixed (round 6).  finish_zk_proof_with_rs recomputes the whole
  * witness (protocol/proof.rs:822-849) although the identity commitment and the 20-level Merkle chain -- 21 488 of the
  * depth-20 circuit's 23 414 graph nodes, eleven twelfths of its multiplication depth -- came out of the partial run.

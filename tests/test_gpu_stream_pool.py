@@ -398,12 +398,16 @@ m = MsmG1(hi - lo)
 res, _ = msm_sharded(m, 0xC0FFEE, n_total)            # the REAL device MSM on this rank's slice + all_gather + fold
 m.close()
 p = BatchProver(max_batch=64)
+dist.barrier()                                        # both ranks (and the test's own process) hold a prover on the device now
+import time
+time.sleep(0.06)                                      # (the neighbour probe is taken at most every 50 ms)
+shared = p.device_shared()
 ws, rs = workload.config2_range(0, 37)                # ragged: shards of 19 and 18
 out = prove_sharded(p.prove, ws, rs)                  # the REAL device prover as prove_fn
 p.close()
 if rank == 0:
     print("RESULT " + json.dumps({"msm": [str(res[0]), str(res[1])], "proofs": [o["proof"].hex() for o in out],
-                                  "pub": [[str(v) for v in o["public_inputs"]] for o in out]}))
+                                  "pub": [[str(v) for v in o["public_inputs"]] for o in out], "shared": shared}))
 dist.barrier()
 dist.destroy_process_group()
 """
@@ -412,10 +416,13 @@ dist.destroy_process_group()
 def test_two_processes_sharing_the_device_msm_sharded_and_prove_sharded(prover):
     """zerokit_amd.distributed with the product objects under world size 2: two processes share the one GPU
     (backend gloo); msm_sharded(MsmG1) at 2^18 equals the closed form, prove_sharded(BatchProver.prove) equals a
-    single-process run"""
+    single-process run; and every process SEES the others' provers on its device (rlnamd_prover_device_shared, bit 1)"""
     import json
+    import time
     from zerokit_amd import workload
     from zerokit_amd.batch import MsmG1
+    time.sleep(0.06)
+    assert prover.device_shared() & 2 == 0          # no other PROCESS proves on this device yet (round 6: the neighbour probe)
     port = _free_port()
     procs = []
     for r in range(2):
@@ -431,6 +438,7 @@ def test_two_processes_sharing_the_device_msm_sharded_and_prove_sharded(prover):
     from oracle.c import binding as ob
     exp = ob.msm_expected(0xC0FFEE, 0, 1 << 18)
     assert (int(got["msm"][0]), int(got["msm"][1])) == exp
+    assert got["shared"] & 2, "a prover in another process on the same device was not seen"
     ws, rs = workload.config2_range(0, 37)
     ref = prover.prove(ws, rs)
     assert got["proofs"] == [o["proof"].hex() for o in ref]

@@ -239,6 +239,12 @@ class BatchProver:
         hs = (C.c_uint64 * len(handles))(*handles)
         check(lib().rlnamd_prover_release_partial(self._h, hs, len(handles)))
 
+    def device_shared(self):
+        """bit 0: another prover of this process on the device; bit 1: a prover of another process"""
+        who = C.c_int()
+        check(lib().rlnamd_prover_device_shared(self._h, C.byref(who)))
+        return int(who.value)
+
     def partial_cache_info(self):
         out = (C.c_uint64 * 8)()
         check(lib().rlnamd_prover_partial_cache_info(self._h, out))

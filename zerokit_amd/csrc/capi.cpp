@@ -306,6 +306,11 @@ int rlnamd_prover_collect(rlnamd_prover* p, uint64_t ticket, size_t n, uint8_t* 
   p->p->collect(ticket, n, proofs, values, errors, coords, partial320);
   RLN_CATCH
 }
+int rlnamd_prover_device_shared(rlnamd_prover* p, int* who) {
+  RLN_TRY
+  *who = p->p->device_shared();
+  RLN_CATCH
+}
 int rlnamd_prover_collect_partial_cached(rlnamd_prover* p, uint64_t ticket, size_t n, uint8_t* partial320, uint64_t* handles,
                                          uint32_t* errors) {
   RLN_TRY

@@ -91,6 +91,10 @@ class Prover {
   ~Prover();
 
   const ProverTuning& tuning() const;
+  // who else proves on this device: bit 0 another prover of this process, bit 1 a prover of ANOTHER process (a record lock
+  // on /dev/shm/rlnamd_<PCI bus id>.lock, probed at most every 50 ms).  Either one keeps the wide latency shapes (a wave
+  // and a CU's LDS per proof for up to 1 024 proofs) off: they assume the chip is this prover's.
+  int device_shared() const;
   const Zkey& zkey() const { return zk_; }
   const Graph& graph() const { return graph_; }
   size_t capacity() const { return B_; }

@@ -413,9 +413,13 @@ __global__ void __launch_bounds__(64) k_wipe_cols(Fr* __restrict__ V, const uint
   if (p >= n || r >= nrows) return;
   V[(size_t)(rows ? rows[r] : r) * B + p] = Fr::zero();
 }
-__global__ void __launch_bounds__(256) k_wipe_bytes(uint4* __restrict__ dst, uint32_t n16) {
+// (a single wave per workgroup, four words per lane: a 4-wave workgroup waits for four free wave slots on ONE CU, which
+// two provers' walks sharing the chip rarely leave -- the slot's next user waits for its wipe)
+__global__ void __launch_bounds__(64) k_wipe_bytes(uint4* __restrict__ dst, uint32_t n16) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n16) dst[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (uint32_t k = 0; k < 4; k++)
+    if (i + 64 * k < n16) dst[i + 64 * k] = make_uint4(0, 0, 0, 0);
 }
 // rows of `stride16` 16-byte words each: the first n16 words of every row (the columns of a batch's proofs in the digit
 // rows, the quotient's operands and the walks' partial sums)
