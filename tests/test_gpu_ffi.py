@@ -186,10 +186,18 @@ def test_partial_and_finish_proof_ffi():
         RLNPartialProof.from_bytes_le(raw[:-1])
     for msg_id, x in ((1, 111), (2, 222)):                 # one partial proof, many messages
         w = RLNWitnessInput(secret, 100, msg_id, elems, bits, x, 999)
-        p_fin = rln.finish_rln_proof_with_rs(pp2, w, 44, 77)
+        p_fin = rln.finish_rln_proof_with_rs(pp2, w, 44, 77)      # pp2 came in as bytes: no cache handle, the whole graph
         p_full = rln.generate_rln_proof_with_rs(w, 44, 77)
         assert p_fin.to_bytes_le() == p_full.to_bytes_le()
+        # pp carries the prover's cache handle (round 6): the cone of the witness graph only -- the same bytes
+        assert rln.finish_rln_proof_with_rs(pp, w, 44, 77).to_bytes_le() == p_full.to_bytes_le()
         assert rln.verify_rln_proof(rln.finish_rln_proof(pp, w), x)
+    # a partial proof outlives nothing it should not: freeing it releases (wipes) its cache entry; another object's handle
+    # means nothing to a second RLN object (there the whole graph is walked: same bytes)
+    other = RLN(20)
+    other.set_leaf(7, rc)
+    assert other.finish_rln_proof_with_rs(pp, w, 44, 77).to_bytes_le() == p_full.to_bytes_le()
+    del other
     pw2 = RLNPartialWitnessInput.from_witness(w)
     assert rln.generate_partial_zk_proof(pw2).to_bytes_le() == raw
     with pytest.raises(RLNError, match="cannot be zero"):

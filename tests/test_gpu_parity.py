@@ -921,6 +921,14 @@ def test_finish_from_a_cached_partial_interprets_only_the_unknown_cone(prover, m
         assert [o["proof"] for o in q.collect(t, k)] == want[:5] and q.partial_cache_info()["cone_batches"] == 0
         t, k = q.submit_finish(q.pack_inputs(ws[:3]), q.pack_rs(rs[:3]), parts5[:3], hs5[:3])
         assert [o["proof"] for o in q.collect(t, k)] == want[:3] and q.partial_cache_info()["cone_batches"] == 1
+        # another prover's handles mean nothing here, even where index and generation coincide (both caches just started):
+        # the whole graph is walked, the bytes are the same
+        parts3, hs3, _ = run_partial(ws[:3])
+        assert all(hs3) and set(hs3).isdisjoint(hs5[:3])
+        before = p.partial_cache_info()["cone_batches"]
+        assert [o["proof"] for o in run_finish(ws[:3], rs[:3], parts3, hs5[:3])] == want[:3]
+        assert p.partial_cache_info()["cone_batches"] == before
+        p.release_partial(hs3)
     finally:
         q.close()
 

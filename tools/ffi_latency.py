@@ -40,6 +40,26 @@ def one_at_a_time():
         rln.generate_rln_proofs_batch(ws[:n])
         dt = time.perf_counter() - t
         out["batch_%d_ms" % n] = round(dt * 1e3, 2)
+    # the partial-proof split through the drop-in boundary (ffi_generate_partial_zk_proof / ffi_finish_rln_proof): the
+    # partial proof object carries the prover's cache handle, a partial proof that came in as bytes does not
+    from zerokit_amd.public import RLNPartialProof, RLNPartialWitnessInput
+    pw = RLNPartialWitnessInput(secret, 100, elems, bits)
+    pp = rln.generate_partial_zk_proof(pw)
+    pp_wire = RLNPartialProof.from_bytes_le(pp.to_bytes_le())
+    for label, obj in (("finish_ms", pp), ("finish_from_deserialised_partial_ms", pp_wire)):
+        ts = []
+        for i in range(9):
+            t = time.perf_counter()
+            q = rln.finish_rln_proof(obj, ws[2 + i])
+            ts.append(round((time.perf_counter() - t) * 1e3, 3))
+        out[label] = sorted(ts[2:])[len(ts[2:]) // 2]
+        out[label.replace("_ms", "_verifies")] = bool(rln.verify_rln_proof(q, 1000 + 2 + 8))
+    ts = []
+    for i in range(5):
+        t = time.perf_counter()
+        rln.generate_partial_zk_proof(pw)
+        ts.append(round((time.perf_counter() - t) * 1e3, 3))
+    out["generate_partial_ms"] = sorted(ts)[len(ts) // 2]
     t = time.perf_counter()
     rln.set_leaf(5, 99)
     rln.get_root()

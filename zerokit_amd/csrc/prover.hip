@@ -238,9 +238,15 @@ struct Prover::Impl {
   std::vector<uint8_t> cone_live;
   hipEvent_t evConeSaved = nullptr, evConeRead = nullptr;   // sW: the last save / wipe of entries; front end: the last restore
   uint64_t cone_batches = 0;
-  uint32_t cone_entry(uint64_t h) const {   // NONE when the handle is not a live entry of this prover
-    const uint32_t idx = (uint32_t)(h & 0xFFFFFFFFu), gen = (uint32_t)(h >> 32);
-    if (idx == 0 || idx > cone_cap || !cone_live[idx - 1] || cone_gen[idx - 1] != gen) return 0xFFFFFFFFu;
+  // handle = prover tag (20 bits, unique per Prover of the process: another prover's handle must not alias an entry here)
+  //          | generation of the entry (20 bits) | entry index + 1 (24 bits)
+  uint32_t cone_tag = 0;
+  uint64_t cone_handle(uint32_t e) const {
+    return ((uint64_t)cone_tag << 44) | ((uint64_t)(cone_gen[e] & 0xFFFFFu) << 24) | (uint64_t)(e + 1);
+  }
+  uint32_t cone_entry(uint64_t h) const {   // NONE when the handle is not a live entry of THIS prover
+    const uint32_t idx = (uint32_t)(h & 0xFFFFFFu), gen = (uint32_t)((h >> 24) & 0xFFFFFu), tag = (uint32_t)(h >> 44);
+    if (tag != cone_tag || idx == 0 || idx > cone_cap || !cone_live[idx - 1] || (cone_gen[idx - 1] & 0xFFFFFu) != gen) return 0xFFFFFFFFu;
     return idx - 1;
   }
   DevBuf<uint32_t> pp_in;      // resident partial-proof points for finish mode, 320 B per proof
@@ -857,7 +863,9 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
         D.cone_rows.alloc(rows.size());
         D.cone_rows.upload(rows.data(), rows.size(), s);
         RLN_HIP(hipStreamSynchronize(s));
-        D.cone_cap = (uint32_t)want;
+        D.cone_cap = (uint32_t)std::min<long>(want, (1l << 24) - 2);
+        static std::atomic<uint32_t> next_tag{1};
+        D.cone_tag = next_tag++ & 0xFFFFFu;
         D.cone_stride = D.cone_nk * 3 + PP_POWERS16;
         D.cone_cache.alloc((size_t)D.cone_cap * D.cone_stride);
         RLN_HIP(hipMemset(D.cone_cache.p, 0, D.cone_cache.bytes()));
@@ -1354,7 +1362,7 @@ void Prover::collect_partial_cached(uint64_t ticket, size_t n, uint8_t* partial3
     D.cone_free.pop_back();
     D.cone_live[e] = 1;
     S.h_cone[i] = e;
-    handles[i] = ((uint64_t)D.cone_gen[e] << 32) | (uint64_t)(e + 1);
+    handles[i] = D.cone_handle(e);
     cached++;
   }
   if (cached) {
@@ -1383,7 +1391,6 @@ void Prover::release_partial(const uint64_t* handles, size_t n) {
     hipLaunchKernelGGL(k_wipe_bytes, dim3(div_up(D.cone_stride, 256)), dim3(64), 0, D.sW, at, D.cone_stride);
     D.cone_live[e] = 0;
     D.cone_gen[e]++;
-    if (D.cone_gen[e] == 0) D.cone_gen[e] = 1;
     D.cone_free.push_back(e);
   }
   if (any) {

@@ -54,6 +54,10 @@ struct TreeConfig {
   bool dynamic_shards = false;
   long failover = 0;
   long revive_after = 8;
+  // "partial_cache": N -- entries of the prover's partial-proof cache (rln_amd.h: rlnamd_prover_collect_partial_cached; ~0.26 MB
+  // each on the depth-20 circuit): how many partial proofs made by ffi_generate_partial_zk_proof can be finished through the
+  // short path at a time.  -1: the prover's default (RLNAMD_PARTIAL_CACHE or 64); 0: off
+  long partial_cache = -1;
   bool persistent() const { return !temporary && has_path; }
   ProverConfig prover_config() const {
     ProverConfig cfg;
@@ -63,6 +67,7 @@ struct TreeConfig {
     else if (profile == "small") { pw = 8; pb = 64; }
     cfg.max_batch = max_batch > 0 ? (size_t)max_batch : pb > 0 ? (size_t)pb : (mb && *mb ? (size_t)atoll(mb) : 256);
     cfg.window_bits = window_bits > 0 ? (int)window_bits : (int)pw;   // 0: Prover takes RLNAMD_WINDOW_BITS or its default schedule
+    cfg.partial_cache = partial_cache;
     return cfg;
   }
 };
@@ -173,6 +178,10 @@ inline TreeConfig parse_tree_config(const std::string& js) {
       if (key == "failover") {
         if (num < 0 || num > 64) throw Error("Configuration error: failover: expected 0 .. 64 rounds");
         c.failover = num;
+      }
+      if (key == "partial_cache") {
+        if (num < 0 || num > 1000000) throw Error("Configuration error: partial_cache: expected 0 .. 1000000 entries");
+        c.partial_cache = num;
       }
       if (key == "revive_after") {
         if (num < 0 || num > 1000000) throw Error("Configuration error: revive_after: expected 0 .. 1000000 calls");
