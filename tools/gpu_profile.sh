@@ -1,11 +1,13 @@
 #!/bin/bash
 # The round's measurement pass on the GPU box (one maintained script instead of one-off wrappers):
-#   tools/gpu_profile.sh <tag> [what...]     what = latency | timeline | pmc | stats   (default: all four)
+#   tools/gpu_profile.sh <tag> [what...]     what = latency | timeline | pmc | stats | finish   (default: the first four)
 # Everything lands under gpurun_out/<tag>/; summaries worth keeping are copied into profiles/ by hand.
 #   latency   tools/ffi_latency.py (what a caller of include/rln.h sees) and tools/single_latency.py
 #   timeline  rocprofv3 --kernel-trace of ONE single proof -> tools/single_timeline.py
 #   pmc       counter passes over the bench (counters only, never combined with tracing), merged by tools/pmc_collect.py
-#   stats     rocprofv3 --kernel-trace --stats of the driver's bench command line
+#   stats     rocprofv3 --kernel-trace --stats of the driver's bench command line restricted to FULL proofs (the finish and
+#             sustained legs of the default line launch the same kernels with other durations: their averages would mix)
+#   finish    the same for `bench.py --workload finish`, tools/finish_latency.py and the timeline of one finish per call
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 TAG=${1:-prof}; shift
@@ -40,10 +42,22 @@ pmc)
   find $O -name "*.csv" -size +6M -delete
   ;;
 stats)
-  timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
+  timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --side latency,config3,config5 --sustained-seconds 0 > $O/bench_under_rocprof.json 2> $O/stats.err
   echo "stats rc=$?"
   f=$(find $O/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats.csv
   find $O/stats -name "*kernel_trace.csv" -size +6M -delete
   head -c 400 $O/bench_under_rocprof.json
+  ;;
+finish)
+  timeout 200 python3 tools/finish_latency.py 40 > $O/finish_latency.json 2> $O/finish_latency.err; echo "finish_latency rc=$?"; cat $O/finish_latency.json
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/ftrace -- python3 tools/finish_latency.py 12 > /dev/null 2> $O/ftrace.err
+  f=$(find $O/ftrace -name "*kernel_trace.csv" | head -1)
+  python3 tools/single_timeline.py $f k_cone_restore > $O/finish_single_call_timeline.txt 2>&1; tail -40 $O/finish_single_call_timeline.txt
+  find $O/ftrace -name "*.csv" -size +4M -delete
+  timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fstats -- python3 bench.py --workload finish --steps 20 --warmup 5 > $O/bench_finish_under_rocprof.json 2> $O/fstats.err
+  echo "finish stats rc=$?"
+  f=$(find $O/fstats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_finish.csv
+  find $O/fstats -name "*kernel_trace.csv" -size +6M -delete
+  head -c 300 $O/bench_finish_under_rocprof.json
   ;;
 esac; done
