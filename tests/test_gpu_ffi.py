@@ -251,6 +251,14 @@ def test_multi_message_rln_proof_ffi():
     assert v.ys + [v.root] + v.nullifiers + [v.x, v.external_nullifier] + [int(b) for b in v.selector_used] == pub
     assert v.ys[1] == 0 and v.ys[3] == 0 and v.nullifiers[1] == 0 and v.ys[0] != 0 and v.nullifiers[2] != 0
     assert rln.verify_with_roots(p, i["x"][0], [])
+    # partial + finish on the multi-message-id circuit (its cone: 7 773 unknown nodes of 29 254): with the object's cache
+    # handle and from the wire form, the full proof's bytes and public signals
+    from zerokit_amd.public import RLNPartialProof, RLNPartialWitnessInput
+    pp = rln.generate_partial_zk_proof(RLNPartialWitnessInput(i["identitySecret"][0], i["userMessageLimit"][0], i["pathElements"],
+                                                              i["identityPathIndex"]))
+    for partial in (pp, RLNPartialProof.from_bytes_le(pp.to_bytes_le())):
+        f = rln.finish_rln_proof_with_rs(partial, w, int(case["r"]), int(case["s"]))
+        assert f.to_bytes_le() == raw
     q = RLNProof.from_bytes_le(raw)
     assert q.to_bytes_le() == raw and RLNProof.from_bytes_be(p.to_bytes_be()).to_bytes_le() == raw
     assert rln.verify_with_roots(q, i["x"][0], [v.root])

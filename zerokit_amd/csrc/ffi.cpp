@@ -787,6 +787,11 @@ FFI_RLNPartialProof* prove_partial(FFI_RLN& rln, const FFI_RLNPartialWitnessInpu
   w.identity_path_index = pw.identity_path_index;
   w.x = cfr_from_u64(0);
   w.external_nullifier = cfr_from_u64(0);
+  if (P.graph().input_mapping.count("selectorUsed")) {   // the multi-message-id circuit: max_out open message slots (witness.rs:887-937)
+    w.multi = true;
+    w.message_ids.assign(P.graph().max_out, cfr_from_u64(0));
+    w.selector_used.assign(P.graph().max_out, 0);
+  }
   std::vector<uint8_t> inputs(P.inputs_per_proof() * 32), rs(64, 0);
   ZeroOnExit z1{inputs};
   fill_inputs(P, w, inputs.data());
@@ -823,30 +828,24 @@ FFI_RLNProof* finish_proof(FFI_RLN& rln, const FFI_RLNPartialProof& pp, const FF
   fill_inputs(P, w, inputs.data());
   memcpy(rs.data(), r.le, 32);
   memcpy(rs.data() + 32, s.le, 32);
-  if (!w.multi) {   // streamed; with a live handle the partial run's values are on this device and only the cone is interpreted
+  {   // streamed; with a live handle the partial run's values are on this device and only the cone is interpreted
     ProofOut po;
     const uint64_t ticket = P.submit_finish(1, inputs.data(), rs.data(), pp.coords, &pp.handle);
-    P.collect(ticket, 1, po.compressed, &po.values[0][0], &po.error);
+    std::vector<uint8_t> pub;
+    try {
+      P.collect(ticket, 1, po.compressed, &po.values[0][0], &po.error, nullptr, nullptr, !w.multi);
+      if (w.multi && !po.error) P.collect_public(ticket, 1, &pub);   // ys, root, nullifiers, x, ext, selectors (witness.rs:777-802)
+    } catch (...) {
+      if (w.multi) P.wipe(ticket);
+      throw;
+    }
+    if (w.multi) P.wipe(ticket);
     if (po.error) throw Error("Error calculating witness: graph evaluation failed (code " + std::to_string(po.error) + ")");
     std::unique_ptr<FFI_RLNProof> pr(new FFI_RLNProof);
     fill_outputs(po, pr.get());
+    if (w.multi) values_from_public(pub.data(), P.graph().max_out, &pr->values);
     return pr.release();
   }
-  WipeResident wr{P};
-  P.upload(1, inputs.data(), rs.data());
-  P.upload_partial(1, pp.coords);
-  P.run(1, PROVE_FINISH);
-  ProofOut po;
-  P.download(1, &po);
-  if (po.error) throw Error("Error calculating witness: graph evaluation failed (code " + std::to_string(po.error) + ")");
-  std::unique_ptr<FFI_RLNProof> pr(new FFI_RLNProof);
-  fill_outputs(po, pr.get());
-  if (w.multi) {
-    std::vector<uint8_t> pub;
-    P.fetch_public(1, &pub);
-    values_from_public(pub.data(), P.graph().max_out, &pr->values);
-  }
-  return pr.release();
 }
 
 
