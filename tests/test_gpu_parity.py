@@ -32,7 +32,11 @@ def _digest(vals):
 @pytest.fixture(scope="module")
 def prover():
     from zerokit_amd.batch import BatchProver
-    p = BatchProver(max_batch=128)
+    os.environ["RLNAMD_PARTIAL_CACHE"] = "160"      # (read once, when the prover is built: a 128-proof batch of cached partials fits)
+    try:
+        p = BatchProver(max_batch=128)
+    finally:
+        del os.environ["RLNAMD_PARTIAL_CACHE"]
     yield p
     p.close()
 
@@ -910,6 +914,20 @@ def test_finish_from_a_cached_partial_interprets_only_the_unknown_cone(prover, m
     p.release_partial(hs)
     info = p.partial_cache_info()
     assert info["in_use"] == 0 and info["residue_in_free_entries"] == 0
+    # every shape boundary of the finish path (tiny <= 5, fused <= 96, the lanes = proofs walks above 48, the cone up to the
+    # small-batch threshold 128): through the cone, byte-identical to the FULL proofs of the same prover
+    ws, rs = workload.config2_range(7000, 128)
+    full = p.prove(ws, rs)
+    for n in (2, 5, 6, 16, 48, 49, 96, 97, 128):
+        parts_n, hs_n, _ = run_partial(ws[:n])
+        assert all(hs_n)
+        before = p.partial_cache_info()["cone_batches"]
+        out = run_finish(ws[:n], rs[:n], parts_n, hs_n)
+        assert [o["proof"] for o in out] == [f["proof"] for f in full[:n]], n
+        assert [o["public_inputs"] for o in out] == [f["public_inputs"] for f in full[:n]]
+        assert p.partial_cache_info()["cone_batches"] == before + 1
+        p.release_partial(hs_n)
+    ws, rs = workload.config2_range(5000, 37)
     # a cache smaller than the batch: a prefix gets handles, the batch finishes through the whole graph, same bytes
     monkeypatch.setenv("RLNAMD_PARTIAL_CACHE", "3")
     q = BatchProver(max_batch=64, window_bits=8)

@@ -637,19 +637,31 @@ void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CF
   try {
     if (n <= P.capacity()) {
       // one batch: the latency path (a single proof walks with lanes = chunks, see Prover::run_async)
-      std::vector<uint8_t> inputs, rsb;
+      // (streamed since round 6: submit + collect is the resident upload / run / download without its two pipeline
+      // drains -- 0.1 ms of a single proof; the batch's inputs and witness are wiped behind the copy-out)
+      std::vector<uint8_t> inputs, rsb, proofs(n * 128), values(n * 160), pub;
       ZeroOnExit z1{inputs}, z2{rsb};
-      WipeResident wr{P};
+      std::vector<uint32_t> errs(n);
       pack(0, n, inputs, rsb);
-      std::vector<ProofOut> po(n);
-      P.prove(n, inputs.data(), rsb.data(), po.data());
-      std::vector<uint8_t> pub;
-      if (multi) P.fetch_public(n, &pub);  // ys, root, nullifiers, x, ext, selectors (witness.rs:777-802)
+      const uint64_t ticket = P.submit(n, inputs.data(), rsb.data());
+      try {
+        P.collect(ticket, n, proofs.data(), values.data(), errs.data(), nullptr, nullptr, !multi);
+        if (multi) P.collect_public(ticket, n, &pub);  // ys, root, nullifiers, x, ext, selectors (witness.rs:777-802)
+      } catch (...) {
+        if (multi) P.wipe(ticket);
+        throw;
+      }
+      if (multi) P.wipe(ticket);
       for (size_t i = 0; i < n; i++) {
-        if (po[i].error) throw Error("Error calculating witness: graph evaluation failed (code " +
-                                     std::to_string(po[i].error) + ")");
+        if (errs[i]) throw Error("Error calculating witness: graph evaluation failed (code " + std::to_string(errs[i]) + ")");
         std::unique_ptr<FFI_RLNProof> pr(new FFI_RLNProof);
-        fill_outputs(po[i], pr.get());
+        memcpy(pr->proof, proofs.data() + 128 * i, 128);
+        const uint8_t* v = values.data() + 160 * i;
+        memcpy(pr->values.y.le, v, 32);
+        memcpy(pr->values.root.le, v + 32, 32);
+        memcpy(pr->values.nullifier.le, v + 64, 32);
+        memcpy(pr->values.x.le, v + 96, 32);
+        memcpy(pr->values.external_nullifier.le, v + 128, 32);
         if (multi) values_from_public(pub.data() + i * npub * 32, mo, &pr->values);
         made.push_back(pr.release());
       }
