@@ -875,7 +875,20 @@ WlCone wl_cone(const Graph& g) {
     C.graph.nodes.push_back(q);
     C.recomputed.push_back(C.node_known[i] && q.op != G_INPUT && q.op != G_CONST);
   }
-  C.graph.constants = g.constants;
+  // only the constants the cone reads (the program copies its constants into LDS before its first step: 1 133 for the
+  // whole depth-20 graph, a third of a lone finish's interpreter time when the cone carried them all)
+  {
+    std::vector<uint32_t> cmap(g.constants.size(), NONE);
+    for (GNode& q : C.graph.nodes) {
+      if (q.op != G_CONST) continue;
+      if (q.a >= g.constants.size()) throw std::runtime_error("Graph error: constant index out of range");
+      if (cmap[q.a] == NONE) {
+        cmap[q.a] = (uint32_t)C.graph.constants.size();
+        C.graph.constants.push_back(g.constants[q.a]);
+      }
+      q.a = cmap[q.a];
+    }
+  }
   C.graph.input_mapping = g.input_mapping;
   C.graph.tree_depth = g.tree_depth;
   C.graph.max_out = g.max_out;
