@@ -534,8 +534,14 @@ def measure_finish(prover, batches, full_results, B, full_rate, full_latency_ms,
     # depends on the message), (b) without one: the whole graph again, as the reference's finish_zk_proof_with_rs does
     n1 = prover.inputs_size * 32
     one_in, one_rs = batches[0][0][:n1], batches[0][1][:64]
-    t, _ = prover.submit(_partial_inputs(prover, one_in, 1), bytes(64), 1)
-    one_pp, one_h, _ = prover.collect_partial_cached(t, 1)
+    one_pin, tp = _partial_inputs(prover, one_in, 1), []
+    for i in range(7):   # the third criterion target of rln/benches/partial_proof.rs:57-75: one partial proof per call
+        t1 = time.perf_counter()
+        t, _ = prover.submit(one_pin, bytes(64), 1)
+        one_pp, one_h, _ = prover.collect_partial_cached(t, 1)
+        tp.append((time.perf_counter() - t1) * 1e3)
+        if i < 6:
+            prover.release_partial(one_h)
     cone0 = prover.partial_cache_info()
     ts, ts_full = [], []
     same1 = bool(one_pp[0] == parts[0][0])
@@ -564,6 +570,7 @@ def measure_finish(prover, batches, full_results, B, full_rate, full_latency_ms,
            "full_single_call_ms_median": full_latency_ms,
            "single_call_speedup_over_full": round(full_latency_ms / lat, 3) if full_latency_ms else None,
            "partial_generation_proofs_per_s": round(nb * B / partial_s, 1),
+           "partial_single_call_ms_median": round(sorted(tp[2:])[len(tp[2:]) // 2], 3),
            "reference_claim": "finish roughly 2.5-3x faster than a full proof (rln/README.md:370-375), one proof per call on a CPU",
            "byte_identical_to_the_full_proofs": bool(same), "single_call_byte_identical": same1,
            "verified": verified, "verified_proofs": len(vp),

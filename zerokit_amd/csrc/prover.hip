@@ -236,7 +236,8 @@ struct Prover::Impl {
   DevBuf<uint32_t> iota96;       // 0 .. 95: "entry p of proof p" for the per-slot powers of a finish without cache entries
   std::vector<uint32_t> cone_gen, cone_free;   // generation per entry (a stale handle is refused); free list
   std::vector<uint8_t> cone_live;
-  hipEvent_t evConeSaved = nullptr, evConeRead = nullptr;   // sW: the last save / wipe of entries; front end: the last restore
+  hipEvent_t evConeSaved = nullptr;   // sW: the last save / wipe of entries
+  hipEvent_t evConeRead = nullptr, evConeRead2 = nullptr;   // the last read of entries: k_cone_restore (front-end stream), k_pp_smul (sC)
   uint64_t cone_batches = 0;
   // handle = prover tag (20 bits, unique per Prover of the process: another prover's handle must not alias an entry here)
   //          | generation of the entry (20 bits) | entry index + 1 (24 bits)
@@ -874,6 +875,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
         for (uint32_t e = D.cone_cap; e-- > 0;) D.cone_free.push_back(e);
         RLN_HIP(hipEventCreateWithFlags(&D.evConeSaved, hipEventDisableTiming));
         RLN_HIP(hipEventCreateWithFlags(&D.evConeRead, hipEventDisableTiming));
+        RLN_HIP(hipEventCreateWithFlags(&D.evConeRead2, hipEventDisableTiming));
       } else {
         D.cone.ok = false;
       }
@@ -1107,6 +1109,8 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
         }
       }
       uint32_t unused = 0;
+      make_plans(vrows, 3, 1u, D.plan1tf, &D.max_chunks1t, &unused, PROVE_PARTIAL, npaired, false, SUM_TREE_LANES / 2);   // a lone tiny partial proof: the plain rows
+      D.max_blocks1t = std::max(D.max_blocks1t, D.plan1tf[PROVE_PARTIAL].nblocks);
       for (int m : {(int)PROVE_FULL, (int)PROVE_FINISH}) {   // finish: the rows of the unknown signals only (alpha, beta, the known w_i: in pi_a, rho)
         make_plans(f, 3, 4u, D.plan1f, &D.max_chunks1s, &unused, m, npaired);
         make_plans(f, 3, 1u, D.plan1tf, &D.max_chunks1t, &unused, m, npaired, false, SUM_TREE_LANES / 2);   // summed by lane pairs
@@ -1141,7 +1145,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     {
       uint32_t unused = 0;
       make_plans(vrows, 1, 2u, D.plan2s, &D.max_chunks2s, &unused, -1);
-      for (int m : {(int)PROVE_FULL, (int)PROVE_FINISH}) {
+      for (int m : {(int)PROVE_FULL, (int)PROVE_PARTIAL, (int)PROVE_FINISH}) {
         make_plans(vrows, 1, 1u, D.plan2t, &D.max_chunks2t, &unused, m, 0, false, SUM_TREE_LANES / 2);   // walked and summed by lane pairs
         D.max_blocks2t = std::max(D.max_blocks2t, D.plan2t[m].nblocks);
       }
@@ -1267,7 +1271,7 @@ Prover::~Prover() {
     for (auto& e : S.t)
       if (e) (void)hipEventDestroy(e);
   }
-  for (hipEvent_t e : {D.evConeSaved, D.evConeRead})
+  for (hipEvent_t e : {D.evConeSaved, D.evConeRead, D.evConeRead2})
     if (e) (void)hipEventDestroy(e);
   for (hipStream_t st : {D.sA, D.sAb, D.sA2, D.sB, D.sB2, D.sC, D.sV, D.sW})
     if (st) (void)hipStreamDestroy(st);
@@ -1385,7 +1389,10 @@ void Prover::release_partial(const uint64_t* handles, size_t n) {
   for (size_t i = 0; i < n; i++) {
     const uint32_t e = D.cone_entry(handles[i]);
     if (e == 0xFFFFFFFFu) continue;
-    if (!any) RLN_HIP(hipStreamWaitEvent(D.sW, D.evConeRead, 0));   // a finish in flight may still read its entries
+    if (!any) {   // a finish in flight may still read its entries
+      RLN_HIP(hipStreamWaitEvent(D.sW, D.evConeRead, 0));
+      RLN_HIP(hipStreamWaitEvent(D.sW, D.evConeRead2, 0));
+    }
     any = true;
     uint4* at = D.cone_cache.p + (size_t)e * D.cone_stride;
     hipLaunchKernelGGL(k_wipe_bytes, dim3(div_up(D.cone_stride, 256)), dim3(64), 0, D.sW, at, D.cone_stride);
@@ -1579,7 +1586,10 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
                      D.nh == 2 && T.fused_smul && T.early_fin;   // (its back end is the split one below)
   // tiny: a lane per (row, half) and a two-stage sum (plan1tf / plan2t) -- only the fused full proof of a lone batch, and
   // only when it walks with lanes = chunks (the lanes = proofs form of the mid-size batches needs 64 proofs of stride)
-  const bool tiny = fused && n <= T.tiny_max && n <= Impl::tiny_stride && n <= D.lanechunk_walk_max;
+  // (round 6: a lone tiny PARTIAL proof as well -- its plan is the plain rows of the known signals, one per lane)
+  const bool tiny_partial = lone && small && mode == PROVE_PARTIAL && D.nh == 2 && n <= T.tiny_max && n <= Impl::tiny_stride &&
+                            n <= D.lanechunk_walk_max;
+  const bool tiny = (fused && n <= T.tiny_max && n <= Impl::tiny_stride && n <= D.lanechunk_walk_max) || tiny_partial;
   const Impl::Plan& P1 = tiny ? D.plan1tf[mode] : fused ? D.plan1f[mode] : small ? D.plan1s[mode] : D.plan1[mode];
   const Impl::Plan& P2 = tiny ? D.plan2t[mode] : small ? D.plan2s[mode] : D.plan2[mode];
   const uint32_t PB = tiny ? Impl::tiny_stride : small ? D.small_stride : (uint32_t)B_;   // stride of the partial-sum arrays
@@ -1658,7 +1668,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     if (cone) {
       RLN_HIP(hipStreamWaitEvent(D.sC, D.evConeSaved, 0));
       launch_pp_smul(D.sC, D.cone_cache.p, S.h_cone, D.cone_stride, D.cone_nk * 3, rs_p, S.prod.p, nb);
-      RLN_HIP(hipEventRecord(D.evConeRead, D.sC));
+      RLN_HIP(hipEventRecord(D.evConeRead2, D.sC));
     } else {   // no cache entries: the powers are made here, beside the interpreter of the whole graph (0.55 ms of its 1.5)
       launch_pp_powers(D.sC, pp_p, D.iota96.p, S.pp_pow.p, PP_POWERS16, 0, nb);
       launch_pp_smul(D.sC, S.pp_pow.p, D.iota96.p, PP_POWERS16, 0, rs_p, S.prod.p, nb);
@@ -1959,13 +1969,18 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     }
     RLN_HIP(hipStreamWaitEvent(sF, S.evV, 0));
   } else {
+    if (tiny_partial) {   // the G2 sums right behind the G2 walk, on its stream, beside the G1 sums on sC
+      sum2(s2);
+      RLN_HIP(hipEventRecord(S.evB2, s2));
+    }
     RLN_HIP(hipEventRecord(S.evV, sV));
     RLN_HIP(hipStreamWaitEvent(D.sC, S.evV, 0));
     RLN_HIP(hipStreamWaitEvent(D.sC, S.evB, 0));
+    if (tiny_partial) sum1(D.sC, {0, 1, 2, 3, 4, 5});
     RLN_HIP(hipStreamWaitEvent(D.sC, S.evB2, 0));
     MARK(9, D.sC);
   }
-  if (early_fin) {
+  if (early_fin || tiny_partial) {
   } else if (lanechunk) {   // small batch: lanes = partial sums (k_sum_tree)
     hipLaunchKernelGGL((k_sum_tree<Fq, G1Acc29>), dim3(nb, P1.nseg), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G1, D.sC, S.part1.p, P1.segchunks.p, S.sums1.p, B, PB, all6);
     hipLaunchKernelGGL((k_sum_tree<Fq2, G2Acc29>), dim3(nb, P2.nseg), dim3(SUM_TREE_LANES), SUM_TREE_LDS_G2, D.sC, S.part2.p, P2.segchunks.p, S.sums2.p, B, PB, all6);
