@@ -91,6 +91,14 @@ int rlnamd_prover_get_info(rlnamd_prover* p, rlnamd_prover_info* info);
 /* the same for the prover behind an object of include/rln.h (FFI_RLN_t* / FFI_RLNV3_t*, passed as void*): shows how
  * the "window_bits" / "max_batch" keys of the config_path JSON (or RLNAMD_WINDOW_BITS / RLNAMD_MAX_BATCH) sized it */
 int rlnamd_ffi_prover_info(const void* ffi_rln, rlnamd_prover_info* info);
+/* The member memo of an object whose config_path JSON carries "auto_partial": N (0 = off, the default).  With it,
+ * ffi_generate_rln_proof remembers the partial proof of up to N members (identity secret, limit, Merkle path): the first
+ * proof of a member at a root is made from scratch and its partial proof follows on the device behind the call; later
+ * proofs of that member at that root are finishes of it (rlnamd_prover_submit_finish: 0.8 instead of 2.1 ms), the same
+ * proof for the same (r, s).  Opt-in because of what it keeps: the member's witness values on the device and the key
+ * (identity secret included) in host memory until the entry is evicted, or the object freed.
+ * out: [0] members remembered, [1] proofs that were finishes, [2] proofs from scratch, [3] 1 while a partial proof is pending */
+int rlnamd_ffi_memo_stats(const void* ffi_rln, uint64_t out[4]);
 /* offset/len of a named input signal in the inputs buffer (iden3calc.rs:122-146); returns RLNAMD_ERR if absent */
 int rlnamd_prover_input_slot(rlnamd_prover* p, const char* name, uint32_t* offset, uint32_t* len);
 /* inputs: n * inputs_size * 32 bytes (slot 0 must hold 1); rs: n * 64 bytes (r then s). */

@@ -468,6 +468,66 @@ def test_profile_key_names_an_operating_point(tmp_path):
     assert (int(info.capacity), int(info.window_bits), int(info.window_bits_g2)) == (256, 10, 12)
 
 
+def test_auto_partial_member_memo_behind_generate_rln_proof(tmp_path):
+    """{"auto_partial": N} (round 6): ffi_generate_rln_proof remembers the partial proofs of up to N members.  The first proof
+    of a member at a root is made from scratch and its partial proof follows behind the call; later proofs of that member
+    are finishes through the cone -- byte-identical to what an object without the memo makes for the same (r, s); a tree
+    change (new path) is a new key; the least recently used member is evicted when N are held; the counters say which
+    path each call took; with the key absent nothing is remembered."""
+    import json
+    from zerokit_amd import hashers
+    from zerokit_amd.public import RLN, RLNWitnessInput
+    cfgp = tmp_path / "cfg.json"
+    cfgp.write_text(json.dumps({"auto_partial": 2}))
+    rln, plain = RLN(20, tree_config=str(cfgp)), RLN(20)
+    assert plain.memo_stats() == dict(members=0, finishes=0, from_scratch=0, pending=0)
+    secrets = [hashers.hash_to_field_le(b"memo-member-%d" % k) for k in range(3)]
+    for obj in (rln, plain):
+        for k, sec in enumerate(secrets):
+            obj.set_leaf(10 + k, hashers.poseidon_hash_pair(hashers.poseidon_hash([sec]), 100))
+    paths = [rln.get_merkle_proof(10 + k) for k in range(3)]
+
+    def wit(k, msg, x, path=None):
+        e, b = path or paths[k]
+        return RLNWitnessInput(secrets[k], 100, msg, e, b, x, 4242)
+
+    def same(k, msg, x, path=None):
+        a = rln.generate_rln_proof_with_rs(wit(k, msg, x, path), 44 + msg, 77 + x)
+        b = plain.generate_rln_proof_with_rs(wit(k, msg, x, path), 44 + msg, 77 + x)
+        assert a.to_bytes_le() == b.to_bytes_le()
+        assert rln.verify_rln_proof(a, x)
+    same(0, 1, 1000)                                   # member 0: from scratch, its partial proof enqueued
+    st = rln.memo_stats()
+    assert (st["from_scratch"], st["finishes"], st["pending"]) == (1, 0, 1)
+    same(0, 2, 1001)                                   # adopted at the start of this call: a finish
+    same(0, 3, 1002)
+    st = rln.memo_stats()
+    assert (st["members"], st["from_scratch"], st["finishes"], st["pending"]) == (1, 1, 2, 0)
+    same(1, 1, 2000)                                   # a second member
+    same(1, 2, 2001)
+    same(0, 4, 1003)                                   # both remembered
+    assert rln.memo_stats()["members"] == 2 and rln.memo_stats()["finishes"] == 4
+    same(2, 1, 3000)                                   # a third member: the least recently used one (member 1) goes
+    same(2, 2, 3001)
+    same(0, 5, 1004)                                   # member 0 is still there
+    st = rln.memo_stats()
+    assert (st["members"], st["from_scratch"], st["finishes"]) == (2, 3, 6)
+    same(1, 3, 2002)                                   # member 1 again: from scratch
+    assert rln.memo_stats()["from_scratch"] == 4
+    # the tree moves on: member 0's path changes, the old partial proof is not used for the new root
+    for obj in (rln, plain):
+        obj.set_leaf(500, 12345)
+    new_path = rln.get_merkle_proof(10)
+    assert new_path[0] != paths[0][0]
+    same(0, 6, 1005, new_path)
+    assert rln.memo_stats()["from_scratch"] == 5
+    same(0, 7, 1006, new_path)
+    assert rln.memo_stats()["finishes"] == 7
+    # random (r, s): the memo's finish verifies like any proof
+    p = rln.generate_rln_proof(wit(0, 8, 1007, new_path))
+    assert rln.verify_rln_proof(p, 1007) and rln.memo_stats()["finishes"] == 8
+
+
 def test_default_object_falls_back_to_the_small_point_when_the_device_is_nearly_full(monkeypatch, tmp_path):
     """every ffi_rln_new* without a sizing key allocates ~23 GiB.  With less than 26 GiB free the object is
     built at the "small" point instead (same proofs), below 10 GiB the error names the `profile` key; an explicit

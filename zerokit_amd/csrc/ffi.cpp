@@ -273,8 +273,74 @@ struct FFI_RLN {
   // thread use the CURRENT device -- so a "devices" list must start with the device that is current when the object is
   // made; anything else would put the tree and the single proofs on another GPU than the one the list names.
   int home_device = 0;
+  // "auto_partial": N in the config_path JSON (0 = off, the default).  The reference's own headline optimisation --
+  // cache the part of the proof that depends on the member, finish per message (rln/README.md:360-375) -- applied behind
+  // the UNCHANGED ffi_generate_rln_proof: the object remembers, for up to N members (identity secret, limit, Merkle
+  // path), the partial proof and the prover's cache handle.  The first proof of a member at a root is a full proof, and
+  // its partial proof is made on the device behind the call's return; every later proof of that member at that root is
+  // a finish through the cone (0.8 instead of 2.1 ms).  Same proof for the same (r, s): nothing a verifier can see.
+  // What it costs is a policy decision, hence opt-in: the member's witness values stay on the device, and the key
+  // (secret included) in host memory, until the entry is evicted (LRU), the tree moves on, or the object is freed.
+  size_t auto_partial = 0;
+  struct Memo {
+    std::vector<uint8_t> key;   // identity secret | limit | path elements | path index
+    uint8_t coords[320];
+    uint64_t handle = 0, stamp = 0;
+  };
+  std::vector<Memo> memo;
+  uint64_t memo_clock = 0, memo_hits = 0, memo_misses = 0;
+  uint64_t pending_ticket = 0;          // a partial batch of one proof enqueued behind the last miss ...
+  std::vector<uint8_t> pending_key;     // ... for this member
+  void memo_drop(Memo& m) {             // (caller holds prove_mu)
+    if (m.handle) prover->release_partial(&m.handle, 1);
+    secure_zero(m.key.data(), m.key.size());
+    m.key.clear();
+    m.handle = 0;
+  }
+  void memo_adopt_pending() {           // the partial proof enqueued behind the last miss, if any: collect it into the memo
+    if (!pending_ticket) return;
+    const uint64_t t = pending_ticket;
+    pending_ticket = 0;
+    Memo m;
+    m.key.swap(pending_key);
+    uint32_t err = 0;
+    try {
+      prover->collect_partial_cached(t, 1, m.coords, &m.handle, &err);
+    } catch (...) {
+      secure_zero(m.key.data(), m.key.size());
+      return;
+    }
+    if (err || !m.handle) {   // not a witness, or no room in the prover's cache: nothing to remember
+      memo_drop(m);
+      return;
+    }
+    m.stamp = ++memo_clock;
+    if (memo.size() >= auto_partial) {   // evict the least recently used member
+      size_t lru = 0;
+      for (size_t i = 1; i < memo.size(); i++)
+        if (memo[i].stamp < memo[lru].stamp) lru = i;
+      memo_drop(memo[lru]);
+      memo[lru] = std::move(m);
+    } else {
+      memo.push_back(std::move(m));
+    }
+  }
+  void memo_clear() {
+    if (pending_ticket && prover) {
+      try {
+        prover->wipe(pending_ticket);
+      } catch (...) {
+      }
+    }
+    pending_ticket = 0;
+    secure_zero(pending_key.data(), pending_key.size());
+    pending_key.clear();
+    for (Memo& m : memo) memo_drop(m);
+    memo.clear();
+  }
   void make_prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_t graph_len, const TreeConfig& tcfg) {
     const ProverConfig cfg = tcfg.prover_config();
+    auto_partial = tcfg.auto_partial > 0 ? (size_t)tcfg.auto_partial : 0;
     if (hipGetDevice(&home_device) != hipSuccess) home_device = 0;
     if (tcfg.has_devices) {
       if (tcfg.devices.empty()) throw Error("Configuration error: devices: empty list");
@@ -327,6 +393,10 @@ struct FFI_RLN {
   ~FFI_RLN() {
     try {
       flush();  // sled flushes when the database is dropped
+    } catch (...) {
+    }
+    try {
+      memo_clear();
     } catch (...) {
     }
     prover.reset();
@@ -635,7 +705,57 @@ void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CF
     }
   };
   try {
-    if (n <= P.capacity()) {
+    if (rln.auto_partial) rln.memo_adopt_pending();
+    if (rln.auto_partial && n == 1 && !multi) {
+      // the member memo (FFI_RLN::auto_partial): a finish through the cone when this member's partial proof is at hand,
+      // else a full proof with the member's partial proof enqueued behind it
+      const FFI_RLNWitnessInput& w = *ws[0];
+      std::vector<uint8_t> key;
+      key.reserve(64 + 33 * w.path_elements.size());
+      key.insert(key.end(), w.identity_secret.le, w.identity_secret.le + 32);
+      key.insert(key.end(), w.user_message_limit.le, w.user_message_limit.le + 32);
+      for (const CFr& e : w.path_elements) key.insert(key.end(), e.le, e.le + 32);
+      key.insert(key.end(), w.identity_path_index.begin(), w.identity_path_index.end());
+      ZeroOnExit zk{key};
+      std::vector<uint8_t> inputs, rsb;
+      ZeroOnExit z1{inputs}, z2{rsb};
+      pack(0, 1, inputs, rsb);
+      FFI_RLN::Memo* hit = nullptr;
+      for (FFI_RLN::Memo& m : rln.memo)
+        if (m.key == key) hit = &m;
+      uint8_t proof[128], values[160];
+      uint32_t err = 0;
+      uint64_t ticket;
+      if (hit) {
+        hit->stamp = ++rln.memo_clock;
+        rln.memo_hits++;
+        ticket = P.submit_finish(1, inputs.data(), rsb.data(), hit->coords, &hit->handle);
+      } else {
+        rln.memo_misses++;
+        ticket = P.submit(1, inputs.data(), rsb.data());
+      }
+      P.collect(ticket, 1, proof, values, &err);
+      if (err) throw Error("Error calculating witness: graph evaluation failed (code " + std::to_string(err) + ")");
+      if (!hit) {   // this member's partial proof, behind the caller's back: adopted by the next proving call
+        FFI_RLNWitnessInput pw = w;
+        pw.message_id = cfr_from_u64(0);
+        pw.x = cfr_from_u64(0);
+        pw.external_nullifier = cfr_from_u64(0);
+        std::vector<uint8_t> pin(ni * 32), zero_rs(64, 0);
+        ZeroOnExit z3{pin};
+        fill_inputs(P, pw, pin.data());
+        rln.pending_ticket = P.submit(1, pin.data(), zero_rs.data(), PROVE_PARTIAL);
+        rln.pending_key = key;
+      }
+      std::unique_ptr<FFI_RLNProof> pr(new FFI_RLNProof);
+      memcpy(pr->proof, proof, 128);
+      memcpy(pr->values.y.le, values, 32);
+      memcpy(pr->values.root.le, values + 32, 32);
+      memcpy(pr->values.nullifier.le, values + 64, 32);
+      memcpy(pr->values.x.le, values + 96, 32);
+      memcpy(pr->values.external_nullifier.le, values + 128, 32);
+      made.push_back(pr.release());
+    } else if (n <= P.capacity()) {
       // one batch: the latency path (a single proof walks with lanes = chunks, see Prover::run_async)
       // (streamed since round 6: submit + collect is the resident upload / run / download without its two pipeline
       // drains -- 0.1 ms of a single proof; the batch's inputs and witness are wiped behind the copy-out)
@@ -750,6 +870,7 @@ void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CF
 // signals, identical for any witness that satisfies the circuit).
 FFI_RLNProof* prove_with_witness(FFI_RLN& rln, const Vec_String_t* calc, const FFI_RLNWitnessInput& w) {
   std::lock_guard<std::mutex> guard(*rln.prove_mu);
+  if (rln.auto_partial) rln.memo_adopt_pending();
   Prover& P = *rln.prover;
   std::vector<uint8_t> given;
   given.reserve((calc ? calc->len : 0) * 32);
@@ -786,6 +907,7 @@ FFI_RLNProof* prove_with_witness(FFI_RLN& rln, const Vec_String_t* calc, const F
 // generate_partial_zk_proof (proof.rs:783-803)
 FFI_RLNPartialProof* prove_partial(FFI_RLN& rln, const FFI_RLNPartialWitnessInput& pw) {
   std::lock_guard<std::mutex> guard(*rln.prove_mu);
+  if (rln.auto_partial) rln.memo_adopt_pending();
   Prover& P = *rln.prover;
   size_t d = P.graph().tree_depth;
   if (pw.path_elements.size() != d)
@@ -830,6 +952,7 @@ FFI_RLNPartialProof* prove_partial(FFI_RLN& rln, const FFI_RLNPartialWitnessInpu
 FFI_RLNProof* finish_proof(FFI_RLN& rln, const FFI_RLNPartialProof& pp, const FFI_RLNWitnessInput& w, const CFr& r,
                            const CFr& s) {
   std::lock_guard<std::mutex> guard(*rln.prove_mu);
+  if (rln.auto_partial) rln.memo_adopt_pending();
   Prover& P = *rln.prover;
   check_against_graph(P, w);
   const std::vector<uint8_t>& known = P.known_mask();
@@ -964,6 +1087,18 @@ int rlnamd_ffi_prover_info(const void* ffi_rln, rlnamd_prover_info* info) {
   } catch (...) {
     return RLNAMD_ERR;
   }
+  return RLNAMD_OK;
+}
+// EXT (include/rln_amd.h): the member memo of an object built with "auto_partial": [0] members remembered, [1] proofs
+// that were finishes of a remembered partial proof, [2] proofs made from scratch, [3] 1 while a partial proof is pending
+int rlnamd_ffi_memo_stats(const void* ffi_rln, uint64_t out[4]) {
+  if (!ffi_rln || !out) return RLNAMD_ERR;
+  FFI_RLN& r = *(FFI_RLN*)ffi_rln;
+  std::lock_guard<std::mutex> guard(*r.prove_mu);
+  out[0] = r.memo.size();
+  out[1] = r.memo_hits;
+  out[2] = r.memo_misses;
+  out[3] = r.pending_ticket ? 1 : 0;
   return RLNAMD_OK;
 }
 size_t ffi_rln_get_tree_depth(FFI_RLN_t* const* rln) { return ((FFI_RLN*)*rln)->tree.depth; }

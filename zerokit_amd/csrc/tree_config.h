@@ -9,6 +9,7 @@
 #include <string.h>
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -58,6 +59,9 @@ struct TreeConfig {
   // each on the depth-20 circuit): how many partial proofs made by ffi_generate_partial_zk_proof can be finished through the
   // short path at a time.  -1: the prover's default (RLNAMD_PARTIAL_CACHE or 64); 0: off
   long partial_cache = -1;
+  // "auto_partial": N -- ffi_generate_rln_proof remembers the partial proofs of up to N members and finishes instead of
+  // proving from scratch when a member proves again at the same root (ffi.cpp: FFI_RLN::auto_partial).  0 (default): off
+  long auto_partial = 0;
   bool persistent() const { return !temporary && has_path; }
   ProverConfig prover_config() const {
     ProverConfig cfg;
@@ -67,7 +71,7 @@ struct TreeConfig {
     else if (profile == "small") { pw = 8; pb = 64; }
     cfg.max_batch = max_batch > 0 ? (size_t)max_batch : pb > 0 ? (size_t)pb : (mb && *mb ? (size_t)atoll(mb) : 256);
     cfg.window_bits = window_bits > 0 ? (int)window_bits : (int)pw;   // 0: Prover takes RLNAMD_WINDOW_BITS or its default schedule
-    cfg.partial_cache = partial_cache;
+    cfg.partial_cache = partial_cache >= 0 ? partial_cache : (auto_partial > 0 ? std::max(64l, auto_partial + 8) : -1);
     return cfg;
   }
 };
@@ -178,6 +182,10 @@ inline TreeConfig parse_tree_config(const std::string& js) {
       if (key == "failover") {
         if (num < 0 || num > 64) throw Error("Configuration error: failover: expected 0 .. 64 rounds");
         c.failover = num;
+      }
+      if (key == "auto_partial") {
+        if (num < 0 || num > 65536) throw Error("Configuration error: auto_partial: expected 0 .. 65536 members");
+        c.auto_partial = num;
       }
       if (key == "partial_cache") {
         if (num < 0 || num > 1000000) throw Error("Configuration error: partial_cache: expected 0 .. 1000000 entries");

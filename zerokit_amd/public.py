@@ -356,6 +356,13 @@ class RLN:
         return info
 
     # ---- Merkle-tree APIs (public.rs:298-593)
+    def memo_stats(self):
+        """the member memo of an object built with "auto_partial" (rlnamd_ffi_memo_stats)"""
+        out = (C.c_uint64 * 4)()
+        if lib().rlnamd_ffi_memo_stats(self._h, out) != 0:
+            raise RLNError("rlnamd_ffi_memo_stats failed")
+        return dict(zip(("members", "finishes", "from_scratch", "pending"), [int(v) for v in out]))
+
     def tree_depth(self):
         return int(lib().ffi_rln_get_tree_depth(C.byref(self._h)))
 
