@@ -291,6 +291,12 @@ int main(int argc, char** argv) {
       WlProgram p = wl_schedule(g, store_slot, ns, rows != 0);
       if (!p.ok || p.nsteps == 0) { fprintf(stderr, "no schedule\n"); failures++; }
     }
+    // round 6: the unknown cone of evaluate_partial cut out of the graph and scheduled like it (wl_cone)
+    {
+      WlCone c = wl_cone(g);
+      WlProgram p = wl_schedule(c.graph, wl_cone_store_slots(c, store_slot), ns, true);
+      if (!p.ok || p.nsteps == 0 || c.node_of.size() >= g.nodes.size() / 4) { fprintf(stderr, "no cone schedule\n"); failures++; }
+    }
   }
   // 3b. graphs the scheduler's rewriting passes were not written for: a chain of 40 000 Adds over ONE value (a linear form
   //     of one term however deep it is looked into), a chain of constant products, a sum of a node with itself -- a
