@@ -70,6 +70,7 @@ struct ProverTuning {
   bool early_fin = true;               // RLNAMD_EARLY_FIN: small batches finish A, B1 before the h rows are walked
   bool fused_smul = true;              // RLNAMD_FUSED_SMUL: a lone small proof takes s A, r B1 as rows of the C segment
   bool values_from_witness = true;     // RLNAMD_VALUES_WITNESS: small batches read the proof values off the witness
+  bool d2h_kernel = true;              // RLNAMD_D2H_KERNEL: big batches copy their results home by a single-wave kernel (0: hipMemcpyAsync)
   // ---- diagnostics
   bool marks_small = false;            // RLNAMD_MARKS_SMALL: record stage timing marks for small batches too
   static ProverTuning from_env();

@@ -381,15 +381,16 @@ ProverTuning ProverTuning::from_env() {
   t.ntt_lg_max = (uint32_t)std::max(0, env_int("RLNAMD_NTT_LG_MAX", (int)t.ntt_lg_max));
   t.partial_cache = (uint32_t)std::max(0, env_int("RLNAMD_PARTIAL_CACHE", (int)t.partial_cache));
   t.marks_small = env_int("RLNAMD_MARKS_SMALL", 0) != 0;
+  t.d2h_kernel = env_int("RLNAMD_D2H_KERNEL", 1) != 0;
   return t;
 }
 std::string ProverTuning::describe() const {
   char b[512];
   snprintf(b, sizeof b,
            "window_bits=%d slots=%d lanechunk=%u lanechunk_walk=%u witlanes_max=%u tiny=%u ntt_lg_max=%u partial_cache=%u glv=%d wit29=%d lone=%d "
-           "early_walk=%d early_fin=%d fused_smul=%d values_from_witness=%d marks_small=%d",
+           "early_walk=%d early_fin=%d fused_smul=%d values_from_witness=%d marks_small=%d d2h_kernel=%d",
            window_bits, slots, lanechunk_max, lanechunk_walk_max, witlanes_max, tiny_max, ntt_lg_max, partial_cache, (int)glv, (int)wit29, lone,
-           (int)early_walk, (int)early_fin, (int)fused_smul, (int)values_from_witness, (int)marks_small);
+           (int)early_walk, (int)early_fin, (int)fused_smul, (int)values_from_witness, (int)marks_small, (int)d2h_kernel);
   return b;
 }
 const ProverTuning& Prover::tuning() const { return d_->tune; }
@@ -1637,6 +1638,17 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   hipStream_t sA2 = !early ? D.sA2 : g2_on_front ? D.sB2 : sA;
   const uint32_t pg = div_up(nb, 64);
   const uint32_t nbp = pg * 64;  // padded lanes compute on stale / zero inputs; results ignored
+  // Results home.  Big batches: by a single-wave kernel writing the pinned pages (as the inputs come in: k_stage_in) -- the
+  // runtime's copy kernel behind hipMemcpyAsync is a multi-wave workgroup that waits for wave slots beside the walks
+  // (profiles/r6_kernel_stats.csv: __amd_rocclr_copyBuffer 0.45 ms on average, 17 ms at worst, for 0.3 MB).  Small batches
+  // keep the copy engine path (5 us each, nothing beside them).
+  const bool d2h_kernel = n > D.lanechunk_max && T.d2h_kernel;
+  auto d2h = [&](void* host, const void* dev, size_t bytes, hipStream_t st) {
+    if (d2h_kernel && bytes % 16 == 0)
+      hipLaunchKernelGGL(k_stage_in, dim3(div_up(bytes / 16, 64)), dim3(64), 0, st, (const uint4*)dev, (uint4*)host, (uint32_t)(bytes / 16));
+    else
+      RLN_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
+  };
   // ---------------- stage A
   if (S.used) RLN_HIP(hipStreamWaitEvent(sA, S.free_event(), 0));  // slot free again
   if (streamed) {
@@ -2000,7 +2012,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   if (mode == PROVE_PARTIAL) {
     hipLaunchKernelGGL(k_partial_out, dim3(pg, 4), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, S.pp_out.p, B, nbp);
     RLN_HIP(hipGetLastError());
-    RLN_HIP(hipMemcpyAsync(S.h_pp, S.pp_out.p, n * 320, hipMemcpyDeviceToHost, D.sC));
+    d2h(S.h_pp, S.pp_out.p, n * 320, D.sC);
   } else {
     if (mode == PROVE_FINISH && !early_fin)
       hipLaunchKernelGGL(k_add_partial, dim3(pg, 4), dim3(64), 0, D.sC, S.sums1.p, S.sums2.p, pp_p, B, nbp, all4, (const G1XYZZ*)nullptr);
@@ -2017,10 +2029,10 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
       hipLaunchKernelGGL(k_fin_out, dim3(pg), dim3(64), 0, sF, S.sums1.p, S.prod.p, S.affA.p, S.affB2.p, S.coords.p,
                          S.comp.p, B, nbp);
     RLN_HIP(hipGetLastError());
-    RLN_HIP(hipMemcpyAsync(S.h_comp, S.comp.p, n * 128, hipMemcpyDeviceToHost, sF));
-    RLN_HIP(hipMemcpyAsync(S.h_values, S.values.p, n * 160, hipMemcpyDeviceToHost, sF));
+    d2h(S.h_comp, S.comp.p, n * 128, sF);
+    d2h(S.h_values, S.values.p, n * 160, sF);
   }
-  RLN_HIP(hipMemcpyAsync(S.h_err, S.err.p, n * 4, hipMemcpyDeviceToHost, sF));
+  d2h(S.h_err, S.err.p, n * 4, sF);
   MARK(10, sF);
   RLN_HIP(hipEventRecord(S.evC, sF));
   S.used = true;
