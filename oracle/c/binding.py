@@ -397,6 +397,9 @@ def time_baseline(ws, rs, target_seconds=12.0):
     secs, _, _ = c.prove_many(ws[:n], rs[:n], threads=cores)
     return {"value": round(n / secs, 3), "unit": "proofs/s", "cores": cores, "kind": "port",
             "single_thread_ms_per_proof": round(t1 * 1e3, 2),
+            "field_product": lib().oracle_mul_kind().decode(),
             "sample": "%d proofs of the same config-2 witnesses, one proof per thread on %d threads "
-                      "(oracle/c: arkworks-equivalent CPU path restated in C, 4x64-bit Montgomery, Pippenger MSM)"
+                      "(oracle/c: arkworks-equivalent CPU path restated in C -- 4x64-bit Montgomery with the mulx / adcx / adox "
+                      "product ark-ff-asm emits where the CPU has ADX, msm_bigint with ark-ec 0.5.0's signed digits; round 5's "
+                      "port, portable product and unsigned digits, took 338 ms per proof on this kind of host)"
                       % (n, cores)}
