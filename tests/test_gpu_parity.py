@@ -951,6 +951,72 @@ def test_finish_from_a_cached_partial_interprets_only_the_unknown_cone(prover, m
         q.close()
 
 
+def test_partial_cache_lifetimes_under_a_random_sequence_of_calls(monkeypatch):
+    """The cache's lifetimes (entries written on the wipe stream, read on the front-end stream and by k_pp_smul, wiped on
+    release, indices reused with a new generation) under 120 pseudo-random calls on a prover with EIGHT entries: partial
+    batches of 1 - 6 members (a prefix gets handles when the cache runs out), finishes of random members with whatever
+    handle they hold (live, released, never given), releases, back to back without a sync between them.  Every finished
+    proof must equal the member's FULL proof for the same (r, s); at the end everything is released and the free entries
+    are zero."""
+    from zerokit_amd import workload
+    from zerokit_amd.batch import BatchProver
+    monkeypatch.setenv("RLNAMD_PARTIAL_CACHE", "8")
+    p = BatchProver(max_batch=64, window_bits=8)
+    try:
+        M = 12
+        ws, rs = workload.config2_range(31000, M)
+        full = [o["proof"] for o in p.prove(ws, rs)]
+        parts, handles = [None] * M, [0] * M
+        rnd = random.Random(20261003)
+        cone_before = p.partial_cache_info()["cone_batches"]
+        finishes = 0
+        for step in range(120):
+            op = rnd.random()
+            if op < 0.3:                                   # a partial batch of a few members
+                ids = rnd.sample(range(M), rnd.randint(1, 6))
+                p.release_partial([handles[i] for i in ids if handles[i]])
+                for i in ids:
+                    handles[i] = 0
+                t, n = p.submit(p.pack_inputs([dict(ws[i], message_id=0, x=0, external_nullifier=0) for i in ids]), bytes(64 * len(ids)), 1)
+                pp, hs, errs = p.collect_partial_cached(t, n)
+                assert not any(errs)
+                seen_zero = False
+                for i, q, h in zip(ids, pp, hs):
+                    parts[i], handles[i] = q, h
+                    assert not (seen_zero and h), "handles must be a prefix of the batch"
+                    seen_zero = seen_zero or h == 0
+            elif op < 0.85:                                # a finish of members that have a partial proof
+                have = [i for i in range(M) if parts[i] is not None]
+                if not have:
+                    continue
+                ids = rnd.sample(have, min(len(have), rnd.randint(1, 5)))
+                hs = [handles[i] if rnd.random() < 0.9 else 0 for i in ids]
+                t, n = p.submit_finish(p.pack_inputs([ws[i] for i in ids]), p.pack_rs([rs[i] for i in ids]), [parts[i] for i in ids], hs)
+                if rnd.random() < 0.3:                     # released while the finish that reads them is in flight
+                    p.release_partial([h for h in hs if h])
+                    for i, h in zip(ids, hs):
+                        if h:
+                            handles[i] = 0
+                out = p.collect(t, n)
+                assert [o["proof"] for o in out] == [full[i] for i in ids], (step, ids, hs)
+                finishes += 1
+            else:                                          # release a few, some of them twice
+                ids = rnd.sample(range(M), rnd.randint(1, 4))
+                p.release_partial([handles[i] for i in ids] + [handles[ids[0]]])
+                for i in ids:
+                    handles[i] = 0                         # (the partial proof itself stays usable: the whole graph)
+            info = p.partial_cache_info() if step % 20 == 19 else None
+            if info:
+                assert info["in_use"] == sum(1 for h in handles if h) <= 8
+        info = p.partial_cache_info()
+        assert finishes > 40 and 0 < info["cone_batches"] - cone_before < finishes      # both paths were taken
+        p.release_partial([h for h in handles if h])
+        info = p.partial_cache_info()
+        assert info["in_use"] == 0 and info["residue_in_free_entries"] == 0
+    finally:
+        p.close()
+
+
 def test_fq29_group_law_matches_the_8x32_group_law_on_device():
     """csrc/fq29.h (9 x 29-bit unsaturated limbs, the form both fixed-base walks and the Pippenger buckets use)
     against curve.h on 16 384 pseudo-random walks of 96 signed additions each, with repeated points (doubling),
