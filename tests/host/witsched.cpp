@@ -121,6 +121,64 @@ int witsched_run(const uint8_t* graph, size_t len, const uint8_t* inputs_le, siz
   }
 }
 
+// Segments behind hints (witness_sched.h: wl_segments) on the host.  hints_le: n_hints x 32 canonical LE -- the values
+// the caller claims for the chain between the hashes (the test computes them with the Python oracle's Poseidon).  The cut
+// nodes are found as the prover finds them: every computed node of a plain host evaluation whose value equals a hint.
+// Every segment program runs by itself on rows prefilled with junk; the witness read off the rows must be the full one,
+// and every cut node's computed value must equal its hint.  stats[0..7] = of the LONGEST segment; stats[8] = segments,
+// [9] = cut nodes, [10] = sum of all segments' steps, [11] = hint mismatches.
+int witsched_run_segments(const uint8_t* graph, size_t len, const uint8_t* inputs_le, size_t inputs_size,
+                          const uint8_t* hints_le, uint32_t n_hints, int rows, uint8_t* witness_out_le, uint32_t* stats) {
+  try {
+    Graph g = parse_graph(graph, len);
+    if (inputs_size != g.inputs_size) throw std::runtime_error("inputs size mismatch");
+    std::vector<uint32_t> store_slot, slot2node;
+    store_slots(g, &store_slot, &slot2node);
+    uint32_t e0 = 0;
+    std::vector<Fr> plain = wl_eval_host(g, inputs_le, &e0);
+    std::vector<Fr> hints(n_hints);
+    std::vector<std::vector<uint32_t>> cuts(n_hints);
+    for (uint32_t j = 0; j < n_hints; j++) {
+      uint32_t c[8];
+      memcpy(c, hints_le + 32 * (size_t)j, 32);
+      hints[j] = Fr::from_canonical(c);
+      for (uint32_t n = 0; n < g.nodes.size(); n++)
+        if (g.nodes[n].op != G_INPUT && g.nodes[n].op != G_CONST && plain[n] == hints[j]) cuts[j].push_back(n);
+      if (cuts[j].empty()) throw std::runtime_error("a hint matches no node of the graph");
+    }
+    // cut nodes are stored values too (the check reads them)
+    for (auto& cj : cuts)
+      for (uint32_t n : cj)
+        if (store_slot[n] == 0xFFFFFFFFu) { store_slot[n] = (uint32_t)slot2node.size(); slot2node.push_back(n); }
+    const uint32_t trash = (uint32_t)slot2node.size();
+    WlSegments S = wl_segments(g, cuts);
+    std::vector<uint8_t> ext(inputs_le, inputs_le + inputs_size * 32);
+    ext.insert(ext.end(), hints_le, hints_le + 32 * (size_t)n_hints);
+    Fr junk = Fr::one() + Fr::one() + Fr::one();
+    std::vector<Fr> stored(slot2node.size() + 1, junk);
+    uint32_t err = 0, longest = 0, total = 0;
+    WlProgram L;
+    for (size_t k = 0; k < S.graphs.size(); k++) {
+      WlProgram Q = wl_schedule(S.graphs[k], wl_segment_store_slots(S, k, store_slot), trash, rows != 0);
+      if (!Q.ok) throw std::runtime_error("a segment does not fit the lanes form");
+      err |= emulate(Q, ext.data(), stored);
+      total += Q.nsteps;
+      if (Q.nsteps >= longest) { longest = Q.nsteps; L = Q; }
+    }
+    uint32_t mism = 0;
+    for (size_t i = 0; i < S.cut_nodes.size(); i++)
+      if (!(stored[store_slot[S.cut_nodes[i]]] == hints[S.cut_hint[i]])) mism++;
+    witness_out(g, store_slot, stored, witness_out_le);
+    stats[0] = L.nsteps; stats[1] = L.nrow; stats[2] = L.nfma; stats[3] = L.nsqr; stats[4] = L.nadd; stats[5] = L.nmisc;
+    stats[6] = L.peak_slots; stats[7] = err;
+    stats[8] = (uint32_t)S.graphs.size(); stats[9] = (uint32_t)S.cut_nodes.size(); stats[10] = total; stats[11] = mism;
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return 1;
+  }
+}
+
 // The finish path of round 6 on the host: (1) the FULL program over the PARTIAL witness (the per-message inputs zeroed:
 // what RLNAMD_MODE_PARTIAL runs) leaves the stored rows; (2) every row of an unknown node is overwritten with junk (the
 // cone must produce all of them); (3) the CONE program (wl_cone: the unknown nodes + the few known ones they read) runs

@@ -951,6 +951,69 @@ def test_finish_from_a_cached_partial_interprets_only_the_unknown_cone(prover, m
         q.close()
 
 
+def test_one_and_two_proofs_per_call_interpret_the_graph_as_segments_behind_hints(monkeypatch):
+    """Round 6.  A lone batch of one or two proofs: the calling thread computes the values between the circuit's 22 chained
+    hashes (rlnamd_prover_hint_stats; the library's host Poseidon), the device interprets the 23 segments those values
+    separate at once and compares every cut node's own value with its hint.  Checked: the golden proof bytes and public
+    inputs (all golden cases, r = 0 among them), one and two proofs per call; three per call keep the whole-graph
+    interpreter; a partial proof through the segments equals the pyref fixture; an input >= r is still an error; with a
+    corrupted hint (test hook) the batch is run again over the whole graph and the caller sees the golden bytes; with
+    RLNAMD_HINTS=0 nothing is hinted and the bytes are the same."""
+    from zerokit_amd.batch import BatchProver
+    cases = _cases()["cases"]
+    fx = {c["name"]: c["partial320"] for c in json.load(open(os.path.join(ROOT, "tests", "golden", "rln_h20_partial.json")))["cases"]}
+
+    def run(p, idx):
+        ws = [_w(cases[i]) for i in idx]
+        rs = [(int(cases[i]["r"]), int(cases[i]["s"])) for i in idx]
+        t, n = p.submit(p.pack_inputs(ws), p.pack_rs(rs))
+        out = p.collect(t, n)
+        for o, i in zip(out, idx):
+            assert o["proof"].hex() == cases[i]["proof_compressed"] and o["error"] == 0, cases[i]["name"]
+            assert [str(v) for v in o["public_inputs"]] == cases[i]["public_inputs"]
+    p = BatchProver(max_batch=64, window_bits=8)
+    try:
+        st = p.hint_stats()
+        assert st["segments"] >= 22 and st["hints"] == 22 and st["longest_segment_steps"] * 8 < st["full_steps"], st
+        for i in range(len(cases)):
+            run(p, [i])
+        assert p.hint_stats()["hinted_batches"] == len(cases) and p.hint_stats()["fallbacks"] == 0
+        run(p, [0, 1])
+        run(p, [2, 3])
+        assert p.hint_stats()["hinted_batches"] == len(cases) + 2
+        run(p, [0, 1, 2])                                  # three per call: the whole graph
+        assert p.hint_stats()["hinted_batches"] == len(cases) + 2
+        for c in cases:                                    # a partial proof through the segments
+            if c["name"] in fx:
+                t, n = p.submit(p.pack_inputs([dict(_w(c), message_id=0, x=0, external_nullifier=0)]), bytes(64), 1)
+                assert p.collect_partial(t, 1)[0].hex() == fx[c["name"]]
+        assert p.hint_stats()["hinted_batches"] == len(cases) + 2 + len(fx) and p.hint_stats()["fallbacks"] == 0
+        bad = dict(_w(cases[0]), x=R)                      # x = r: not canonical (graph.rs:42-45)
+        inp = bytearray(p.pack_inputs([dict(bad, x=0)]))
+        off = p.slots["x"][0]
+        inp[32 * off:32 * off + 32] = R.to_bytes(32, "little")
+        t, n = p.submit(bytes(inp), p.pack_rs([(1, 2)]))
+        assert p.collect(t, n)[0]["error"] != 0
+    finally:
+        p.close()
+    monkeypatch.setenv("RLNAMD_HINT_FAULT", "9")
+    p = BatchProver(max_batch=64, window_bits=8)
+    try:
+        run(p, [0])
+        run(p, [1, 2])
+        assert p.hint_stats()["hinted_batches"] == 2 and p.hint_stats()["fallbacks"] == 2
+    finally:
+        p.close()
+    monkeypatch.delenv("RLNAMD_HINT_FAULT")
+    monkeypatch.setenv("RLNAMD_HINTS", "0")
+    p = BatchProver(max_batch=64, window_bits=8)
+    try:
+        run(p, [0])
+        assert p.hint_stats()["hinted_batches"] == 0 and p.hint_stats()["segments"] == 0
+    finally:
+        p.close()
+
+
 def test_partial_cache_lifetimes_under_a_random_sequence_of_calls(monkeypatch):
     """The cache's lifetimes (entries written on the wipe stream, read on the front-end stream and by k_pp_smul, wiped on
     release, indices reused with a new generation) under 120 pseudo-random calls on a prover with EIGHT entries: partial

@@ -167,3 +167,70 @@ def test_the_unknown_cone_on_top_of_a_partial_run_gives_the_golden_witness(WS, r
         digest, st = _run_cone(WS, _graph(sub), c["inputs"], rows)
         assert digest == c["witness_sha256"], c["name"]
         assert st[7] == 0
+
+
+def _rln_hints(named, depth):
+    """the values between the hashes of the single-message circuit (protocol/witness.rs:759-828): identity commitment, rate
+    commitment, the running hash after Merkle levels 1 .. depth - 1, a1 = Poseidon(secret, external nullifier, message id)"""
+    from oracle.pyref.poseidon import poseidon
+    secret, limit = int(named["identitySecret"][0]) % R, int(named["userMessageLimit"][0]) % R
+    idc = poseidon([secret])
+    node = poseidon([idc, limit])
+    hints = [idc, node]
+    for lvl in range(depth):
+        e, b = int(named["pathElements"][lvl]) % R, int(named["identityPathIndex"][lvl])
+        node = poseidon([e, node]) if b else poseidon([node, e])
+        if lvl < depth - 1:
+            hints.append(node)
+    hints.append(poseidon([secret, int(named["externalNullifier"][0]) % R, int(named["messageId"][0]) % R]))
+    return hints
+
+
+def _run_segments(lib, graph_bytes, named_inputs, hints, rows):
+    from oracle.pyref import wtns_graph
+    g = wtns_graph.parse(graph_bytes)
+    size = g.inputs_size()
+    buf = bytearray(size * 32)
+    buf[0] = 1
+    for name, vals in named_inputs.items():
+        off, ln = g.input_mapping[name]
+        for k, v in enumerate(vals):
+            buf[(off + k) * 32:(off + k + 1) * 32] = (int(v) % R).to_bytes(32, "little")
+    hb = b"".join(int(h).to_bytes(32, "little") for h in hints)
+    out = ctypes.create_string_buffer(32 * len(g.signals))
+    stats = (ctypes.c_uint32 * 12)()
+    rc = lib.witsched_run_segments(graph_bytes, len(graph_bytes), bytes(buf), size, hb, len(hints), rows, out, stats)
+    assert rc == 0, lib.witsched_error().decode()
+    return hashlib.sha256(out.raw).hexdigest(), list(stats)
+
+
+@pytest.mark.parametrize("rows", [0, 1])
+def test_segments_behind_hints_give_the_golden_witness(WS, rows):
+    """Round 6: the graph cut at the values between its 22 chained hashes (witness_sched.h: wl_segments) -- every segment a
+    program of its own over rows prefilled with junk, the hints from the Python oracle's Poseidon.  The witness read off the
+    rows is the golden one, every cut node's computed value equals its hint, and the longest segment is a twentieth of
+    the whole graph's program (one hash deep instead of twenty-two)."""
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "rln_h20_vectors.json")))["cases"]
+    gb = _graph("tree_depth_20")
+    for c in cases[:3]:
+        w = c["witness"]
+        named = {"identitySecret": [w["identity_secret"]], "userMessageLimit": [w["user_message_limit"]],
+                 "messageId": [w["message_id"]], "pathElements": w["path_elements"],
+                 "identityPathIndex": w["identity_path_index"], "x": [w["x"]],
+                 "externalNullifier": [w["external_nullifier"]]}
+        digest, st = _run_segments(WS, gb, named, _rln_hints(named, 20), rows)
+        assert digest == c["witness_sha256"], c["name"]
+        assert st[7] == 0 and st[11] == 0
+    full_steps = _run(WS, gb, named, rows)[1][0]
+    assert st[8] >= 22 and st[0] * 12 < full_steps, (st, full_steps)
+    # a wrong hint is seen: the cut node's own value differs from it
+    bad = _rln_hints(named, 20)
+    bad[7] = (bad[7] + 1) % R
+    with pytest.raises(AssertionError, match="matches no node"):
+        _run_segments(WS, gb, named, bad, rows)
+    # the depth-10 circuit
+    for c in json.load(open(os.path.join(ROOT, "tests", "golden", "rln_other_circuits.json")))["cases"]:
+        if c["multi"]:
+            continue
+        digest, st = _run_segments(WS, _graph("tree_depth_%d" % c["depth"]), c["inputs"], _rln_hints(c["inputs"], c["depth"]), rows)
+        assert digest == c["witness_sha256"] and st[7] == 0 and st[11] == 0

@@ -239,6 +239,12 @@ class BatchProver:
         hs = (C.c_uint64 * len(handles))(*handles)
         check(lib().rlnamd_prover_release_partial(self._h, hs, len(handles)))
 
+    def hint_stats(self):
+        """the witness graph as segments behind hints (rlnamd_prover_hint_stats)"""
+        out = (C.c_uint64 * 6)()
+        check(lib().rlnamd_prover_hint_stats(self._h, out))
+        return dict(zip(("segments", "hints", "longest_segment_steps", "full_steps", "hinted_batches", "fallbacks"), [int(v) for v in out]))
+
     def device_shared(self):
         """bit 0: another prover of this process on the device; bit 1: a prover of another process"""
         who = C.c_int()

@@ -306,6 +306,12 @@ int rlnamd_prover_collect(rlnamd_prover* p, uint64_t ticket, size_t n, uint8_t* 
   p->p->collect(ticket, n, proofs, values, errors, coords, partial320);
   RLN_CATCH
 }
+int rlnamd_prover_hint_stats(rlnamd_prover* p, uint64_t out[6]) {
+  RLN_TRY
+  static_assert(Prover::HINT_STATS_FIELDS == 6, "rln_amd.h states six fields");
+  p->p->hint_stats(out);
+  RLN_CATCH
+}
 int rlnamd_prover_device_shared(rlnamd_prover* p, int* who) {
   RLN_TRY
   *who = p->p->device_shared();

@@ -70,6 +70,10 @@ struct ProverTuning {
   bool early_fin = true;               // RLNAMD_EARLY_FIN: small batches finish A, B1 before the h rows are walked
   bool fused_smul = true;              // RLNAMD_FUSED_SMUL: a lone small proof takes s A, r B1 as rows of the C segment
   bool values_from_witness = true;     // RLNAMD_VALUES_WITNESS: small batches read the proof values off the witness
+  uint32_t hint_max = 2;               // RLNAMD_HINTS: largest lone batch interpreted as independent segments behind host-computed hints
+                                       // (the values between the circuit's chained hashes; 0: never).  A proof costs the calling thread
+                                       // ~0.3 ms of host hashing and saves ~1.3 ms of interpreter: one and two proofs per call gain
+  int hint_fault = 0;                  // RLNAMD_HINT_FAULT (test hook): j > 0 corrupts hint j - 1 of the first proof of every hinted batch
   bool d2h_kernel = true;              // RLNAMD_D2H_KERNEL: big batches copy their results home by a single-wave kernel (0: hipMemcpyAsync)
   // ---- diagnostics
   bool marks_small = false;            // RLNAMD_MARKS_SMALL: record stage timing marks for small batches too
@@ -174,6 +178,11 @@ class Prover {
   // [0] capacity in entries, [1] entries in use, [2] bytes per entry, [3] 16-byte words that are not zero in the entries
   // NOT in use (all of them zero: a released entry was wiped), [4] batches that took the cone so far, [5] nodes of the cone
   // program, [6] steps of the cone program, [7] steps of the full program
+  // the graph as segments behind hints (witness_sched.h: wl_segments): [0] segments, [1] hints per proof, [2] steps of the
+  // longest segment, [3] steps of the whole graph's program, [4] batches interpreted that way, [5] of those, batches whose
+  // hints did not check and were run again over the whole graph (0 unless the RLNAMD_HINT_FAULT test hook is set)
+  static constexpr int HINT_STATS_FIELDS = 6;
+  void hint_stats(uint64_t out[HINT_STATS_FIELDS]) const;
   static constexpr int PARTIAL_CACHE_FIELDS = 8;
   void partial_cache_info(uint64_t out[PARTIAL_CACHE_FIELDS]);
   void upload_partial(size_t n, const uint8_t* coords320);
@@ -206,6 +215,7 @@ class Prover {
   void residue(uint64_t out[RESIDUE_FIELDS]);
 
  private:
+  uint64_t settle_hints(uint64_t ticket);
   uint64_t enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint8_t* h_rs, const uint8_t* h_pp320,
                    const uint64_t* cone_handles = nullptr);
   void fetch_public_slot(void* slot, size_t n, std::vector<uint8_t>* out_le);

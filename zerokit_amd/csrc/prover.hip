@@ -37,6 +37,7 @@ const char* const kProverStageNames[PROVER_STAGES] = {"witness", "matvec", "ntt"
 // Everything one in-flight batch owns.  Two slots let batch k+1 run its latency-bound front end (witness
 // interpreter, NTT) and batch k-1 its back end (reduction, finalize) on their own streams while batch k
 // keeps the chip busy with the MSM.
+constexpr uint32_t HINT_PROOFS = 8;   // most proofs of a batch that is interpreted as segments (ProverTuning::hint_max <= this)
 struct Slot {
   DevBuf<uint32_t> err, coords, values;
   DevBuf<uint8_t> comp;
@@ -55,6 +56,8 @@ struct Slot {
   DevBuf<uint32_t> inputs, rs, pp_in;
   uint8_t* h_in = nullptr;      // pinned staging: inputs | rs | partial points
   uint32_t* h_cone = nullptr;   // pinned: partial-cache entry of every proof of the batch (read by k_cone_save / _restore)
+  uint32_t* h_hints = nullptr;  // pinned: the hints of a batch interpreted as segments (HINT_PROOFS x n_hints x 8 words)
+  bool hinted = false;          // ... and this batch was; cleared once its hints have checked (Prover::collect)
   hipEvent_t evU = nullptr;     // H2D of this slot's inputs done
   hipEvent_t evE = nullptr;     // small batches: the walk of the h-independent G1 rows done
   uint64_t ticket = 0;          // submit() ticket of the batch the slot holds (0: resident-input run)
@@ -226,6 +229,39 @@ struct Prover::Impl {
   uint32_t max_chunks1 = 0, max_chunks2 = 0, max_groups1 = 0, max_groups2 = 0;
   uint32_t npts1 = 0, npts2 = 0, npaired1 = 0;   // npaired1: G1 points [0, npaired1) are pair members
   std::vector<uint8_t> known;  // per witness signal: computable from the partial witness (evaluate_partial)
+  // ---- the graph as independent segments behind hints (witness_sched.h: wl_segments; Prover::enqueue): the values between
+  //      the circuit's chained hashes are computed on a host core (rln_hints: depth + 2 Poseidon hashes, ~0.3 ms), every
+  //      segment of the graph is interpreted at once on the device with them as extra inputs, and every cut node's own value
+  //      is compared with its hint afterwards (k_hint_check -> WERR_HINT -> the batch is run again over the whole graph)
+  WitSegs segs;
+  DevBuf<uint32_t> cut_node, cut_hint;
+  uint32_t n_cut = 0, n_hints = 0;
+  uint64_t hinted_batches = 0, hint_fallbacks = 0;
+  bool no_hints_now = false;     // set around the re-run of a batch whose hints did not check
+  void rln_hints(const uint8_t* in_le, Fr* out) const {   // idc, rate commitment, the running hash after levels 1 .. depth - 1, a1
+    auto rd = [&](uint32_t slot) {
+      uint32_t c[8];
+      memcpy(c, in_le + 32 * (size_t)slot, 32);
+      return Fr::from_canonical(c);
+    };
+    const PoseidonParams &P2 = poseidon_host_params(2), &P3 = poseidon_host_params(3), &P4 = poseidon_host_params(4);
+    const Fr secret = rd(slots.secret), limit = rd(slots.limit);
+    const Fr idc = poseidon_hash_host(P2, &secret);
+    Fr in2[2] = {idc, limit};
+    Fr node = poseidon_hash_host(P3, in2);
+    out[0] = idc;
+    out[1] = node;
+    for (uint32_t l = 0; l < slots.depth; l++) {
+      const Fr e = rd(slots.path + l);
+      const bool right = !rd(slots.path_idx + l).is_zero();   // the node is the right child: hash(sibling, node)
+      in2[0] = right ? e : node;
+      in2[1] = right ? node : e;
+      node = poseidon_hash_host(P3, in2);
+      if (l + 1 < slots.depth) out[2 + l] = node;
+    }
+    const Fr in3[3] = {secret, rd(slots.ext), rd(slots.msg_id)};
+    out[slots.depth + 1] = poseidon_hash_host(P4, in3);
+  }
   // ---- the partial-proof cache and the cone program (prover.h: collect_partial_cached / submit_finish)
   WitLanes cone;                 // the unknown cone of evaluate_partial, scheduled like the full graph (witness_sched.h: wl_cone)
   uint32_t cone_nodes = 0;
@@ -382,15 +418,17 @@ ProverTuning ProverTuning::from_env() {
   t.partial_cache = (uint32_t)std::max(0, env_int("RLNAMD_PARTIAL_CACHE", (int)t.partial_cache));
   t.marks_small = env_int("RLNAMD_MARKS_SMALL", 0) != 0;
   t.d2h_kernel = env_int("RLNAMD_D2H_KERNEL", 1) != 0;
+  t.hint_max = (uint32_t)std::min<int>(std::max(0, env_int("RLNAMD_HINTS", (int)t.hint_max)), (int)HINT_PROOFS);
+  t.hint_fault = env_int("RLNAMD_HINT_FAULT", 0);
   return t;
 }
 std::string ProverTuning::describe() const {
   char b[512];
   snprintf(b, sizeof b,
            "window_bits=%d slots=%d lanechunk=%u lanechunk_walk=%u witlanes_max=%u tiny=%u ntt_lg_max=%u partial_cache=%u glv=%d wit29=%d lone=%d "
-           "early_walk=%d early_fin=%d fused_smul=%d values_from_witness=%d marks_small=%d d2h_kernel=%d",
+           "early_walk=%d early_fin=%d fused_smul=%d values_from_witness=%d marks_small=%d d2h_kernel=%d hints=%u",
            window_bits, slots, lanechunk_max, lanechunk_walk_max, witlanes_max, tiny_max, ntt_lg_max, partial_cache, (int)glv, (int)wit29, lone,
-           (int)early_walk, (int)early_fin, (int)fused_smul, (int)values_from_witness, (int)marks_small, (int)d2h_kernel);
+           (int)early_walk, (int)early_fin, (int)fused_smul, (int)values_from_witness, (int)marks_small, (int)d2h_kernel, hint_max);
   return b;
 }
 const ProverTuning& Prover::tuning() const { return d_->tune; }
@@ -599,6 +637,82 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
   D.lanechunk_walk_max = D.tune.lanechunk_walk_max;
   // partial sums of a small batch: [chunk][stride]
   D.small_stride = std::max<uint32_t>(64, (std::min<uint32_t>(D.lanechunk_max, (uint32_t)B_) + 63) / 64 * 64);
+  // ---- named input slots (single message-id circuits; witness.rs:832-881): the proof-values kernel and the hints need them
+  D.have_values_kernel = false;
+  {
+    auto find = [&](const char* name, uint32_t want_len, uint32_t* off) {
+      auto it = graph_.input_mapping.find(name);
+      if (it == graph_.input_mapping.end() || it->second.second != want_len) return false;
+      *off = it->second.first;
+      return true;
+    };
+    D.slots.depth = graph_.tree_depth;
+    bool ok = graph_.max_out == 1 && D.ni == 6;
+    ok = ok && find("identitySecret", 1, &D.slots.secret) && find("userMessageLimit", 1, &D.slots.limit) &&
+         find("messageId", 1, &D.slots.msg_id) && find("pathElements", graph_.tree_depth, &D.slots.path) &&
+         find("identityPathIndex", graph_.tree_depth, &D.slots.path_idx) && find("x", 1, &D.slots.x) &&
+         find("externalNullifier", 1, &D.slots.ext);
+    D.have_values_kernel = ok;
+  }
+  // ---- where the graph can be cut (segments behind hints): the nodes that hold the values between the chained hashes,
+  //      found on a probe witness -- every computed node whose value equals one of rln_hints' -- so that nothing about the
+  //      circuit's node numbering is assumed; a circuit on which a hint matches no node keeps the whole-graph interpreter
+  std::vector<std::vector<uint32_t>> hint_cuts;
+  std::vector<uint8_t> is_cut(D.N, 0);
+  if (D.have_values_kernel && D.tune.hint_max > 0 && graph_.tree_depth + 2 <= 64) {
+    // two probes with complementary path bits and unrelated values: a node that merely carries the running hash on one
+    // side of a level's left / right selection equals the hint under one of them only
+    D.n_hints = graph_.tree_depth + 2;
+    hint_cuts.assign(D.n_hints, {});
+    std::vector<uint8_t> match(D.N, 1);
+    std::vector<uint32_t> match_hint(D.N, 0xFFFFFFFFu);
+    bool all = true;
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    for (int round = 0; round < 2 && all; round++) {
+      std::vector<uint8_t> probe((size_t)D.NI * 32, 0);
+      probe[0] = 1;
+      auto put = [&](uint32_t slot) {
+        for (int k = 0; k < 31; k++) {   // 248 pseudo-random bits: below r
+          st = st * 6364136223846793005ull + 1442695040888963407ull;
+          probe[32 * (size_t)slot + k] = (uint8_t)(st >> 56);
+        }
+      };
+      put(D.slots.secret); put(D.slots.x); put(D.slots.ext);
+      probe[32 * (size_t)D.slots.limit] = (uint8_t)(100 + round);
+      probe[32 * (size_t)D.slots.msg_id] = (uint8_t)(7 + round);
+      for (uint32_t l = 0; l < D.slots.depth; l++) {
+        put(D.slots.path + l);
+        probe[32 * (size_t)(D.slots.path_idx + l)] = (uint8_t)((l + round) & 1);
+      }
+      uint32_t perr = 0;
+      const std::vector<Fr> val = wl_eval_host(graph_, probe.data(), &perr);
+      std::vector<Fr> hv(D.n_hints);
+      D.rln_hints(probe.data(), hv.data());
+      all = perr == 0;
+      for (uint32_t n = 0; n < D.N && all; n++) {
+        if (!match[n]) continue;
+        if (graph_.nodes[n].op == G_INPUT || graph_.nodes[n].op == G_CONST) { match[n] = 0; continue; }
+        uint32_t j = round == 0 ? 0xFFFFFFFFu : match_hint[n];
+        if (round == 0) {
+          for (uint32_t q = 0; q < D.n_hints; q++)
+            if (val[n] == hv[q]) j = q;
+          match_hint[n] = j;
+        }
+        if (j == 0xFFFFFFFFu || !(val[n] == hv[j])) match[n] = 0;
+      }
+    }
+    for (uint32_t n = 0; n < D.N && all; n++)
+      if (match[n]) {
+        hint_cuts[match_hint[n]].push_back(n);
+        is_cut[n] = 1;
+      }
+    for (uint32_t j = 0; j < D.n_hints && all; j++) all = !hint_cuts[j].empty();
+    if (!all) {
+      hint_cuts.clear();
+      std::fill(is_cut.begin(), is_cut.end(), 0);
+      D.n_hints = 0;
+    }
+  }
   std::vector<GNode29> wit29_prog;
   std::vector<uint32_t> wit29_slot2node;
   if (D.wit29) {
@@ -630,7 +744,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     for (uint32_t n = 0; fuse && n < D.N; n++) {
       if (G[n].op != G_ADD) continue;
       for (uint32_t m : {G[n].b, G[n].a}) {
-        if (G[m].op == G_MUL && uses[m] == 1 && !is_signal[m] && !removed[m] && G[n].a != G[n].b) {
+        if (G[m].op == G_MUL && uses[m] == 1 && !is_signal[m] && !is_cut[m] && !removed[m] && G[n].a != G[n].b) {
           fused_mul[n] = m;
           removed[m] = 1;
           break;
@@ -656,7 +770,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     }
     auto pn_ops = [&](const PNode& q) { return q.op == W29_FMA ? 3 : nops(GNode{q.op, 0, 0, 0}); };
     std::vector<uint8_t> store(D.N, 0);
-    for (uint32_t n = 0; n < D.N; n++) store[n] = is_signal[n] || G[n].op == G_INPUT;
+    for (uint32_t n = 0; n < D.N; n++) store[n] = is_signal[n] || G[n].op == G_INPUT || is_cut[n];   // (a cut node is compared with its hint)
     for (uint32_t i = 0; i < P.size(); i++)
       for (int k = 0; k < pn_ops(P[i]); k++) {
         const uint32_t o = P[i].src[k];
@@ -740,6 +854,20 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
       std::vector<uint32_t> store_slot(D.N, 0xFFFFFFFFu);
       for (uint32_t i = 0; i < slot2node.size(); i++) store_slot[slot2node[i]] = i;
       D.witlanes.build(graph_, store_slot, (uint32_t)slot2node.size(), s);   // V29 has one row more than stored values
+      if (D.witlanes.ok && !hint_cuts.empty()) {
+        const WlSegments SG = wl_segments(graph_, hint_cuts);
+        D.segs.build(SG, store_slot, (uint32_t)slot2node.size(), s);
+        // worth it only where the cuts really shorten the program (the shipped circuits: 381 of 4 813 steps)
+        if (D.segs.ok && (D.segs.max_steps * 4 > D.witlanes.nsteps || D.segs.nseg > 256)) D.segs.ok = false;
+        if (D.segs.ok) {
+          D.n_cut = (uint32_t)SG.cut_nodes.size();
+          D.cut_node.alloc(D.n_cut);
+          D.cut_hint.alloc(D.n_cut);
+          D.cut_node.upload(SG.cut_nodes.data(), D.n_cut, s);
+          D.cut_hint.upload(SG.cut_hint.data(), D.n_cut, s);
+          RLN_HIP(hipStreamSynchronize(s));
+        }
+      }
     }
     // 152 KiB of dynamic LDS: a device / partition with a smaller limit keeps the 8 x 32 interpreter (k_witness), the
     // same fallback as for graphs with 65 536 or more stored values -- a resource limit must not fail the constructor
@@ -1154,24 +1282,6 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     build_table29<Fq2, G2Affine29>(pts, D.ws2, D.t2_29, s);
   }
 
-  // ---- named input slots for the proof-values kernel (single message-id circuit, witness.rs:832-881);
-  //      other circuits (multi message-id) take their public values from the witness instead
-  D.have_values_kernel = false;
-  {
-    auto find = [&](const char* name, uint32_t want_len, uint32_t* off) {
-      auto it = graph_.input_mapping.find(name);
-      if (it == graph_.input_mapping.end() || it->second.second != want_len) return false;
-      *off = it->second.first;
-      return true;
-    };
-    D.slots.depth = graph_.tree_depth;
-    bool ok = graph_.max_out == 1 && D.ni == 6;
-    ok = ok && find("identitySecret", 1, &D.slots.secret) && find("userMessageLimit", 1, &D.slots.limit) &&
-         find("messageId", 1, &D.slots.msg_id) && find("pathElements", graph_.tree_depth, &D.slots.path) &&
-         find("identityPathIndex", graph_.tree_depth, &D.slots.path_idx) && find("x", 1, &D.slots.x) &&
-         find("externalNullifier", 1, &D.slots.ext);
-    D.have_values_kernel = ok;
-  }
   poseidon_dev();
 
   // ---- workspace
@@ -1215,6 +1325,7 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
     RLN_HIP(hipMemsetAsync(S.pp_in.p, 0, S.pp_in.bytes(), s));
     RLN_HIP(hipHostMalloc((void**)&S.h_in, B * ((size_t)D.NI * 32 + 64 + 320), hipHostMallocDefault));
     RLN_HIP(hipHostMalloc((void**)&S.h_cone, B * 4, hipHostMallocDefault));
+    RLN_HIP(hipHostMalloc((void**)&S.h_hints, (size_t)HINT_PROOFS * 64 * 32, hipHostMallocDefault));
     RLN_HIP(hipEventCreateWithFlags(&S.evU, hipEventDisableTiming));
     RLN_HIP(hipEventCreateWithFlags(&S.evE, hipEventDisableTiming));
     RLN_HIP(hipHostMalloc((void**)&S.h_pp, B * 320, hipHostMallocDefault));
@@ -1262,6 +1373,7 @@ Prover::~Prover() {
     if (S.h_pp) (void)hipHostFree(S.h_pp);
     if (S.h_in) (void)hipHostFree(S.h_in);
     if (S.h_cone) (void)hipHostFree(S.h_cone);
+    if (S.h_hints) (void)hipHostFree(S.h_hints);
     if (S.evU) (void)hipEventDestroy(S.evU);
     if (S.evE) (void)hipEventDestroy(S.evE);
     if (S.h_comp) (void)hipHostFree(S.h_comp);
@@ -1348,6 +1460,7 @@ uint64_t Prover::submit_finish(size_t n, const uint8_t* inputs, const uint8_t* r
 
 void Prover::collect_partial_cached(uint64_t ticket, size_t n, uint8_t* partial320, uint64_t* handles, uint32_t* errors) {
   Impl& D = *d_;
+  ticket = settle_hints(ticket);
   Slot* Sp = nullptr;
   for (int k = 0; k < D.nslot; k++)
     if (D.slot[k].used && D.slot[k].ticket == ticket && ticket != 0) Sp = &D.slot[k];
@@ -1407,6 +1520,16 @@ void Prover::release_partial(const uint64_t* handles, size_t n) {
   }
 }
 
+void Prover::hint_stats(uint64_t out[HINT_STATS_FIELDS]) const {
+  const Impl& D = *d_;
+  out[0] = D.segs.ok ? D.segs.nseg : 0;
+  out[1] = D.segs.ok ? D.n_hints : 0;
+  out[2] = D.segs.ok ? D.segs.max_steps : 0;
+  out[3] = D.witlanes.ok ? D.witlanes.nsteps : 0;
+  out[4] = D.hinted_batches;
+  out[5] = D.hint_fallbacks;
+}
+
 void Prover::partial_cache_info(uint64_t out[PARTIAL_CACHE_FIELDS]) {
   Impl& D = *d_;
   for (int k = 0; k < PARTIAL_CACHE_FIELDS; k++) out[k] = 0;
@@ -1433,9 +1556,41 @@ void Prover::partial_cache_info(uint64_t out[PARTIAL_CACHE_FIELDS]) {
   out[3] = h;
 }
 
+// A batch that was interpreted as segments behind hints is only as good as its hints: a cut node whose own value differs
+// from the hint raised WERR_HINT (k_hint_check).  The library computes the hints itself, so this is not expected -- but it is
+// checked, and such a batch is run again here over the whole graph before anyone sees a byte of it.  Returns the ticket
+// that holds the batch's results from now on.
+uint64_t Prover::settle_hints(uint64_t ticket) {
+  Impl& D = *d_;
+  Slot* Sp = nullptr;
+  for (int k = 0; k < D.nslot; k++)
+    if (D.slot[k].used && D.slot[k].ticket == ticket && ticket != 0) Sp = &D.slot[k];
+  if (!Sp || !Sp->hinted) return ticket;
+  Slot& S = *Sp;
+  RLN_HIP(hipEventSynchronize(S.evC));
+  S.hinted = false;
+  bool bad = false;
+  for (size_t i = 0; i < S.n; i++) bad = bad || (S.h_err[i] & WERR_HINT) != 0;
+  if (!bad) return ticket;
+  D.hint_fallbacks++;
+  D.no_hints_now = true;
+  uint64_t again = 0;
+  try {
+    const uint8_t* in = S.h_in;
+    again = enqueue(S.n, S.mode, in, in + B_ * (size_t)D.NI * 32, S.mode == PROVE_FINISH ? in + B_ * ((size_t)D.NI * 32 + 64) : nullptr, nullptr);
+  } catch (...) {
+    D.no_hints_now = false;
+    throw;
+  }
+  D.no_hints_now = false;
+  if (!S.wiped) D.wipe_slot(S, false);
+  return again;
+}
+
 void Prover::collect(uint64_t ticket, size_t n, uint8_t* proofs, uint8_t* values, uint32_t* errors, uint8_t* coords,
                      uint8_t* partial320, bool wipe_after) {
   Impl& D = *d_;
+  ticket = settle_hints(ticket);
   Slot* Sp = nullptr;
   for (int k = 0; k < D.nslot; k++)
     if (D.slot[k].used && D.slot[k].ticket == ticket && ticket != 0) Sp = &D.slot[k];
@@ -1485,6 +1640,7 @@ void Prover::wipe(uint64_t ticket) {
 
 void Prover::collect_public(uint64_t ticket, size_t n, std::vector<uint8_t>* out_le) {
   Impl& D = *d_;
+  if (ticket != settle_hints(ticket)) throw Error("collect_public: the batch was run again (collect it first)");
   for (int k = 0; k < D.nslot; k++)
     if (D.slot[k].used && D.slot[k].ticket == ticket && ticket != 0) {
       if (n > D.slot[k].n) throw Error("collect: more proofs requested than the batch holds");
@@ -1573,6 +1729,8 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     const uint32_t e = D.cone_entry(cone_handles[i]);
     if (e == 0xFFFFFFFFu) cone = false; else cone_entries.push_back(e);
   }
+  // A lone batch of one or two proofs: the graph as independent segments behind hints computed on this thread (Impl::rln_hints)
+  const bool hinted = D.segs.ok && h_inputs && wl_used && !cone && lone && n <= T.hint_max && !D.no_hints_now;
   // Small batches (latency, not throughput): the whole front end stays on ONE stream (every cross-stream event hop costs
   // 0.1 - 0.15 ms), the digits of the witness scalars are recoded right behind the interpreter, and both walks start on
   // everything that does not depend on the quotient h while mat-vec / NTTs still run; only the h rows of the G1 walk
@@ -1674,6 +1832,16 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     if (marks) RLN_HIP(hipEventRecord(S.t[i], stream));   \
   } while (0)
   if (cone) memcpy(S.h_cone, cone_entries.data(), n * sizeof(uint32_t));   // (the slot's previous batch has finished: see `streamed` above)
+  S.hinted = hinted;
+  if (hinted) {
+    std::vector<Fr> hv(D.n_hints);
+    for (size_t i = 0; i < n; i++) {
+      D.rln_hints(h_inputs + i * (size_t)D.NI * 32, hv.data());
+      for (uint32_t j = 0; j < D.n_hints; j++) hv[j].to_canonical(S.h_hints + (i * D.n_hints + j) * 8);
+    }
+    if (T.hint_fault > 0 && (uint32_t)T.hint_fault <= D.n_hints) S.h_hints[(size_t)(T.hint_fault - 1) * 8] ^= 1u;   // test hook
+    D.hinted_batches++;
+  }
   if (fused && mode == PROVE_FINISH) {   // s pi_a + r rho beside everything else: needs (r, s) and the entries' powers only
     if (S.used) RLN_HIP(hipStreamWaitEvent(D.sC, S.free_event(), 0));
     RLN_HIP(hipStreamWaitEvent(D.sC, S.evU, 0));
@@ -1697,6 +1865,9 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
       RLN_HIP(hipEventRecord(D.evConeRead, sA));
       D.cone.launch(sA, in_p, D.NI, S.V29.p, S.err.p, B, nb);
       D.cone_batches++;
+    } else if (hinted) {
+      hipLaunchKernelGGL(k_wipe_bytes, dim3(1), dim3(64), 0, sA, (uint4*)S.err.p, (uint32_t)div_up(nb * 4, 16));   // the segments OR into it
+      D.segs.launch(sA, in_p, D.NI, S.h_hints, S.V29.p, S.err.p, B, nb);
     } else if (wl_used) {
       D.witlanes.launch(sA, in_p, D.NI, S.V29.p, S.err.p, B, nb);
     } else
@@ -1708,6 +1879,9 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     else
       hipLaunchKernelGGL(k_v29_to_fr, dim3(pg, D.nstore29), dim3(64, 1), 0, sA, S.V29.p, D.slot2node.p, D.nstore29, S.V.p,
                          B, nbp);
+    if (hinted)
+      hipLaunchKernelGGL(k_hint_check, dim3(div_up(D.n_cut, 64), nb), dim3(64), 0, sA, S.V.p, D.cut_node.p, D.cut_hint.p, D.n_cut,
+                         S.h_hints, D.n_hints, B, S.err.p);
   } else {
     hipLaunchKernelGGL(k_witness, dim3(pg), dim3(64), WIT_RING * 8 * 64 * 4 + WIT_LDS_CONSTS * 32, sA, D.nodes.p, D.N, D.consts.p,
                        (uint32_t)graph_.constants.size(), in_p, D.NI, S.V.p,

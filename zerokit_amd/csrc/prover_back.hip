@@ -1,6 +1,7 @@
 // prover_back.hip -- back end of the prover pipeline: partial-proof points in / out, affine conversion, s A and r B1,
 // the compressed proof, the proof values by the Poseidon formulae, the parity taps, input staging and the wipes.
 #include "prover_kernels.h"
+#include "witness_ops.h"
 
 #include "glv.h"
 #include "pairing.h"
@@ -384,6 +385,27 @@ __global__ void k_scatter_witness(const uint32_t* __restrict__ given, const uint
 // Single-wave workgroups: a 256-thread workgroup needs four free wave slots on one CU at the same instant, which the
 // single-wave MSM workgroups streaming through the chip rarely leave (rocprofv3: 3.0 ms on average, 26.7 ms at worst
 // for this 30 us copy when it was launched as 256-thread workgroups).
+// every cut node's own value (V, Montgomery 8 x 32, after k_v29_to_fr) against the hint the segments were given (canonical
+// LE words, pinned host memory): a difference raises WERR_HINT for the proof -- its batch is run again over the whole graph
+__global__ void __launch_bounds__(64) k_hint_check(const Fr* __restrict__ V, const uint32_t* __restrict__ cut_node,
+                                                   const uint32_t* __restrict__ cut_hint, uint32_t n_cut,
+                                                   const uint32_t* __restrict__ hints, uint32_t n_hints, uint32_t B,
+                                                   uint32_t* __restrict__ err) {
+  const uint32_t i = blockIdx.x * 64 + threadIdx.x, p = blockIdx.y;
+  if (i >= n_cut) return;
+  uint32_t c[8];
+  V[(size_t)cut_node[i] * B + p].to_canonical(c);
+  const uint32_t* h = hints + ((size_t)p * n_hints + cut_hint[i]) * 8;
+  uint32_t d = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) d |= c[k] ^ h[k];
+  if (d) {
+#ifdef RLN_HINT_DEBUG
+    printf("hint mismatch: cut %u node %u hint %u computed %08x %08x hint %08x %08x\n", i, cut_node[i], cut_hint[i], c[0], c[7], h[0], h[7]);
+#endif
+    atomicOr(&err[p], (uint32_t)WERR_HINT);
+  }
+}
 __global__ void __launch_bounds__(256) k_cone_save(const uint4* __restrict__ V29, const uint32_t* __restrict__ rows, uint32_t nk,
                                                    uint32_t B, const uint32_t* __restrict__ entry_of, uint4* __restrict__ cache, uint32_t stride16) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x, p = blockIdx.y;

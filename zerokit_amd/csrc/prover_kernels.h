@@ -156,6 +156,10 @@ __global__ void k_scatter_witness(const uint32_t* __restrict__ given, const uint
                                   uint32_t NS, Fr* __restrict__ V, uint32_t* __restrict__ err, uint32_t B, uint32_t nb);
 // partial-proof cache (Prover::collect_partial_cached / submit_finish): rows[k] = stored slot of the k-th known value;
 // entry_of[p] (pinned host memory) = cache entry of proof p; an entry is [nk][3] uint4 in the 9 x 29 form of V29
+__global__ void __launch_bounds__(64) k_hint_check(const Fr* __restrict__ V, const uint32_t* __restrict__ cut_node,
+                                                   const uint32_t* __restrict__ cut_hint, uint32_t n_cut,
+                                                   const uint32_t* __restrict__ hints, uint32_t n_hints, uint32_t B,
+                                                   uint32_t* __restrict__ err);
 __global__ void __launch_bounds__(256) k_cone_save(const uint4* __restrict__ V29, const uint32_t* __restrict__ rows, uint32_t nk,
                                                    uint32_t B, const uint32_t* __restrict__ entry_of, uint4* __restrict__ cache, uint32_t stride16);
 __global__ void __launch_bounds__(256) k_cone_restore(const uint4* __restrict__ cache, const uint32_t* __restrict__ rows, uint32_t nk,

@@ -28,4 +28,22 @@ struct WitLanes {
               uint32_t nb) const;
 };
 
+// The graph as independent segments behind hints (witness_sched.h: wl_segments): every segment a program of its own, all
+// of them in ONE launch -- grid (proofs, segments), a wave and a CU's LDS each.  hints: n x n_hints x 32 bytes canonical LE
+// (pinned host memory is fine: each is read once, by one lane); a segment's errors are OR-ed into err[p], which the
+// caller zeroes first.
+struct WlSegDesc {
+  uint32_t prog_off, nsteps, const_off, n_consts;   // uint4 units into prog; words into consts29
+};
+struct WitSegs {
+  bool ok = false;
+  uint32_t nseg = 0, n_hints = 0, max_steps = 0, total_steps = 0;
+  DevBuf<uint4> prog;
+  DevBuf<uint32_t> consts29;
+  DevBuf<WlSegDesc> descs;
+  void build(const struct WlSegments& S, const std::vector<uint32_t>& store_slot_full, uint32_t trash_slot, hipStream_t s);
+  void launch(hipStream_t s, const uint32_t* d_inputs, uint32_t n_inputs, const uint32_t* hints, uint4* V29, uint32_t* err,
+              uint32_t B, uint32_t nb) const;
+};
+
 }  // namespace rlnamd

@@ -50,15 +50,21 @@ struct WlOut {
   Fr29 v;
   uint32_t e;
 };
-__device__ __noinline__ WlOut wl_misc(uint32_t dx, uint32_t dy, uint32_t dz, const uint32_t* lds,
-                                      const uint32_t* __restrict__ inputs, uint32_t n_inputs, uint32_t p) {
+struct WlIn {   // where a step's inputs come from: the proof's inputs, and behind them (index >= n_inputs) its hints
+  const uint32_t* inputs;
+  const uint32_t* hints;
+  uint32_t n_inputs, n_hints;
+};
+__device__ __noinline__ WlOut wl_misc(uint32_t dx, uint32_t dy, uint32_t dz, const uint32_t* lds, const WlIn& I, uint32_t p) {
   const uint32_t lop = dx & 0xFF, gop = (dx >> 16) & 0xFF;
   WlOut o;
   o.e = WERR_NONE;
   uint32_t* const e = &o.e;
   Fr29 v = Fr29::zero();
   if (lop == WO_INPUT) {
-    const uint32_t* in = inputs + ((size_t)p * n_inputs + (dy >> 16)) * 8;   // the `a` field holds the input index
+    const uint32_t idx = dy >> 16;   // the `a` field holds the input index
+    const uint32_t* in = idx < I.n_inputs ? I.inputs + ((size_t)p * I.n_inputs + idx) * 8
+                                          : I.hints + ((size_t)p * I.n_hints + (idx - I.n_inputs)) * 8;
     if (limbs_geq(in, FrParams::MOD)) *e = WERR_INPUT_RANGE;  // u256_to_fr fails (graph.rs:42-45)
     Fr x;
 #pragma unroll
@@ -193,8 +199,8 @@ __device__ __forceinline__ uint32_t wl_row_mul_add16(const uint32_t (&a)[9], uin
 
 // The steps that are not row-form products (lane-form products when RLNAMD_WITROWS=0, plain additions, inputs and
 // the rare operations): out of line, so that the loop below is one compare and one branch away from its product.
-__device__ __noinline__ uint32_t wl_other_step(uint32_t kind, uint4 q, uint32_t* lds, const uint32_t* __restrict__ inputs,
-                                               uint32_t n_inputs, uint4* __restrict__ V29, uint32_t B, uint32_t p) {
+__device__ __noinline__ uint32_t wl_other_step(uint32_t kind, uint4 q, uint32_t* lds, const WlIn& I,
+                                               uint4* __restrict__ V29, uint32_t B, uint32_t p) {
   const uint32_t dst = q.y & 0xFFFF, sa = q.y >> 16, sb = q.z & 0xFFFF, sc = q.z >> 16;
   uint32_t e = WERR_NONE;
   Fr29 v;
@@ -217,7 +223,7 @@ __device__ __noinline__ uint32_t wl_other_step(uint32_t kind, uint4 q, uint32_t*
     for (int j = 0; j < 9; j++) v.v[j] = va.v[j] + vb.v[j];
     v.normalize();
   } else {
-    const WlOut o = wl_misc(q.x, q.y, q.z, lds, inputs, n_inputs, p);
+    const WlOut o = wl_misc(q.x, q.y, q.z, lds, I, p);
     v = o.v;
     e = o.e;
   }
@@ -252,10 +258,20 @@ __device__ __forceinline__ void wl_flush(uint32_t* lds, uint4* __restrict__ V29,
 __global__ void __launch_bounds__(64) k_witness_lanes(const uint4* __restrict__ prog, uint32_t nsteps,
                                                       const uint32_t* __restrict__ consts29, uint32_t n_consts,
                                                       const uint32_t* __restrict__ inputs, uint32_t n_inputs,
-                                                      uint4* __restrict__ V29, uint32_t* __restrict__ err, uint32_t B) {
+                                                      uint4* __restrict__ V29, uint32_t* __restrict__ err, uint32_t B,
+                                                      const WlSegDesc* __restrict__ segs, const uint32_t* __restrict__ hints,
+                                                      uint32_t n_hints) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __builtin_amdgcn_s_setprio(3);
   const uint32_t lane = threadIdx.x, p = blockIdx.x;
+  if (segs) {   // one of the graph's independent segments (grid.y), a program of its own
+    const WlSegDesc d0 = segs[blockIdx.y];
+    prog += d0.prog_off;
+    nsteps = d0.nsteps;
+    consts29 += d0.const_off;
+    n_consts = d0.n_consts;
+  }
+  const WlIn I{inputs, hints, n_inputs, n_hints};
   // constants, then ZERO, ONE, MINUS_ONE; the last slot is the write target of idle lanes
   for (uint32_t i = lane; i < n_consts * 9; i += 64) lds[(i / 9) * 12 + i % 9] = consts29[i];
   if (lane == 0) {
@@ -350,7 +366,7 @@ __global__ void __launch_bounds__(64) k_witness_lanes(const uint4* __restrict__ 
         if (kind == WK_ROW) {
           row_step(q, k);
         } else {
-          const uint32_t e1 = wl_other_step(kind, q, lds, inputs, n_inputs, V29, B, p);
+          const uint32_t e1 = wl_other_step(kind, q, lds, I, V29, B, p);
           if (e1 && !e) e = e1;
         }
       }
@@ -361,7 +377,13 @@ __global__ void __launch_bounds__(64) k_witness_lanes(const uint4* __restrict__ 
   wl_flush(lds, V29, B, p, lane);
   if (e) atomicOr(&lds[WL_SLOTS * 12], e);
   __builtin_amdgcn_wave_barrier();   // one wave: LDS operations complete in program order
-  if (lane == 0) err[p] = lds[WL_SLOTS * 12];
+  if (lane == 0) {
+    if (segs) {
+      if (lds[WL_SLOTS * 12]) atomicOr(&err[p], lds[WL_SLOTS * 12]);
+    } else {
+      err[p] = lds[WL_SLOTS * 12];
+    }
+  }
 }
 
 // ======================================================================================================= host
@@ -401,7 +423,57 @@ void WitLanes::build(const Graph& graph, const std::vector<uint32_t>& store_slot
 void WitLanes::launch(hipStream_t s, const uint32_t* d_inputs, uint32_t n_inputs, uint4* V29, uint32_t* err, uint32_t B,
                       uint32_t nb) const {
   hipLaunchKernelGGL(k_witness_lanes, dim3(nb), dim3(64), WL_LDS_BYTES, s, prog.p, nsteps, consts29.p, n_consts, d_inputs,
-                     n_inputs, V29, err, B);
+                     n_inputs, V29, err, B, (const WlSegDesc*)nullptr, (const uint32_t*)nullptr, 0u);
+}
+
+void WitSegs::build(const WlSegments& S, const std::vector<uint32_t>& store_slot_full, uint32_t trash_slot, hipStream_t s) {
+  ok = false;
+  const char* off = getenv("RLNAMD_WITLANES");
+  if (off && off[0] == '0') return;
+  const char* r = getenv("RLNAMD_WITROWS");
+  const bool rows = !(r && r[0] == '0');
+  std::vector<WlDesc> img;
+  std::vector<Fr> consts;
+  std::vector<WlSegDesc> d;
+  nseg = (uint32_t)S.graphs.size();
+  n_hints = S.n_hints;
+  max_steps = total_steps = 0;
+  for (size_t k = 0; k < S.graphs.size(); k++) {
+    WlProgram P = wl_schedule(S.graphs[k], wl_segment_store_slots(S, k, store_slot_full), trash_slot, rows);
+    if (!P.ok) return;
+    d.push_back({(uint32_t)img.size(), P.nsteps, (uint32_t)consts.size() * 9, P.n_consts});
+    img.insert(img.end(), P.img.begin(), P.img.end());
+    consts.insert(consts.end(), P.consts.begin(), P.consts.end());
+    max_steps = std::max(max_steps, P.nsteps);
+    total_steps += P.nsteps;
+  }
+  if (d.empty()) return;
+  prog.alloc(img.size());
+  prog.upload(reinterpret_cast<const uint4*>(img.data()), img.size(), s);
+  descs.alloc(d.size());
+  descs.upload(d.data(), d.size(), s);
+  {
+    DevBuf<Fr> c8;
+    c8.alloc(std::max<size_t>(consts.size(), 1));
+    consts29.alloc(std::max<size_t>(consts.size(), 1) * 9);
+    if (!consts.empty()) {
+      c8.upload(consts.data(), consts.size(), s);
+      hipLaunchKernelGGL(k_consts_to29, dim3(div_up(consts.size(), 256)), dim3(256), 0, s, c8.p, consts29.p, (uint32_t)consts.size());
+      RLN_HIP(hipGetLastError());
+    }
+    RLN_HIP(hipStreamSynchronize(s));
+  }
+  if (hipFuncSetAttribute((const void*)k_witness_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, WL_LDS_BYTES) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  ok = true;
+}
+
+void WitSegs::launch(hipStream_t s, const uint32_t* d_inputs, uint32_t n_inputs, const uint32_t* hints, uint4* V29,
+                     uint32_t* err, uint32_t B, uint32_t nb) const {
+  hipLaunchKernelGGL(k_witness_lanes, dim3(nb, nseg), dim3(64), WL_LDS_BYTES, s, prog.p, 0u, consts29.p, 0u, d_inputs, n_inputs,
+                     V29, err, B, descs.p, hints, n_hints);
 }
 
 }  // namespace rlnamd

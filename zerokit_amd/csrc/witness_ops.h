@@ -86,7 +86,8 @@ RLN_WOP void u_divmod(const U256& a, const U256& b, U256* q, U256* rem) {
   *rem = Rm;
 }
 
-enum WitnessErr : uint32_t { WERR_NONE = 0, WERR_INPUT_RANGE = 1, WERR_SHIFT = 2, WERR_BITOP = 3, WERR_UNO_ID = 4 };
+enum WitnessErr : uint32_t { WERR_NONE = 0, WERR_INPUT_RANGE = 1, WERR_SHIFT = 2, WERR_BITOP = 3, WERR_UNO_ID = 4,
+                             WERR_HINT = 0x100 };   // a flag: a cut node's value differs from the hint its consumers were given (Prover::collect runs the batch again)
 
 // Every operation that is not Mul/Add/Sub/Neg/TernCond/Const/Input: iden3calc/graph.rs:72-143, 314-466.
 RLN_WOP_NOINLINE Fr witness_slow_op(uint32_t op, Fr fa, Fr fb, uint32_t* err) {

@@ -10,6 +10,7 @@
 // below the top one are only near-normalised), so an Add riding in a product step takes the operand with the larger bound as
 // multiplicand; when a result would still pass WL_BMAX it is followed by a reduction x * ONE + ZERO.
 #include "witness_sched.h"
+#include "witness_ops.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -902,6 +903,147 @@ std::vector<uint32_t> wl_cone_store_slots(const WlCone& cone, const std::vector<
   std::vector<uint32_t> st(cone.node_of.size(), NONE);
   for (uint32_t c = 0; c < cone.node_of.size(); c++)
     if (!cone.node_known[cone.node_of[c]]) st[c] = store_slot_full[cone.node_of[c]];
+  return st;
+}
+
+
+// ------------------------------------------------------------------------------------------------- segments behind hints
+std::vector<Fr> wl_eval_host(const Graph& g, const uint8_t* inputs_le, uint32_t* err) {
+  const std::vector<GNode>& G = g.nodes;
+  std::vector<Fr> v(G.size(), Fr::zero());
+  *err = WERR_NONE;
+  for (uint32_t n = 0; n < G.size(); n++) {
+    const GNode& q = G[n];
+    switch (q.op) {
+      case G_INPUT: {
+        uint32_t c[8];
+        memcpy(c, inputs_le + (size_t)q.a * 32, 32);
+        if (limbs_geq(c, FrParams::MOD)) *err = WERR_INPUT_RANGE;
+        v[n] = Fr::from_canonical(c);
+        break;
+      }
+      case G_CONST: v[n] = g.constants[q.a]; break;
+      case G_MUL: v[n] = v[q.a] * v[q.b]; break;
+      case G_ADD: v[n] = v[q.a] + v[q.b]; break;
+      case G_SUB: v[n] = v[q.a] - v[q.b]; break;
+      case G_NEG: v[n] = v[q.a].neg(); break;
+      case G_TERN: v[n] = v[q.a].is_zero() ? v[q.c] : v[q.b]; break;
+      default: v[n] = witness_slow_op(q.op, v[q.a], q.op == G_ID ? Fr::zero() : v[q.b], err); break;
+    }
+  }
+  return v;
+}
+
+WlSegments wl_segments(const Graph& g, const std::vector<std::vector<uint32_t>>& cuts) {
+  const std::vector<GNode>& G = g.nodes;
+  const uint32_t N = (uint32_t)G.size();
+  auto nops = [&](const GNode& q) {
+    return (q.op == G_INPUT || q.op == G_CONST) ? 0 : (q.op == G_NEG || q.op == G_ID) ? 1 : q.op == G_TERN ? 3 : 2;
+  };
+  WlSegments S;
+  S.n_hints = (uint32_t)cuts.size();
+  std::vector<uint32_t> hint_of(N, NONE);
+  for (uint32_t j = 0; j < cuts.size(); j++)
+    for (uint32_t n : cuts[j]) {
+      if (n >= N || G[n].op == G_INPUT || G[n].op == G_CONST) throw std::runtime_error("wl_segments: a cut must be a computed node");
+      hint_of[n] = j;
+      S.cut_nodes.push_back(n);
+      S.cut_hint.push_back(j);
+    }
+  // key of a node: the hints it reaches backwards without crossing a cut
+  std::vector<std::vector<uint32_t>> key(N);
+  std::map<std::vector<uint32_t>, uint32_t> seg_of_key;
+  std::vector<uint32_t> seg(N, NONE);
+  for (uint32_t n = 0; n < N; n++) {
+    const GNode& q = G[n];
+    if (q.op == G_INPUT || q.op == G_CONST) continue;
+    const uint32_t o[3] = {q.a, q.b, q.c};
+    std::vector<uint32_t> k;
+    for (int j = 0; j < nops(q); j++) {
+      if (o[j] >= n) throw std::runtime_error("Graph error: node operand refers forward");
+      if (hint_of[o[j]] != NONE) k.push_back(hint_of[o[j]]);
+      else k.insert(k.end(), key[o[j]].begin(), key[o[j]].end());
+    }
+    std::sort(k.begin(), k.end());
+    k.erase(std::unique(k.begin(), k.end()), k.end());
+    auto it = seg_of_key.find(k);
+    if (it == seg_of_key.end()) it = seg_of_key.emplace(k, (uint32_t)seg_of_key.size()).first;
+    seg[n] = it->second;
+    key[n] = std::move(k);
+  }
+  const uint32_t K = (uint32_t)seg_of_key.size();
+  if (K == 0) return S;
+  // an input no computed node reads is still a stored value (it may be a witness signal): segment 0 takes those
+  std::vector<uint8_t> input_read(N, 0);
+  for (uint32_t n = 0; n < N; n++) {
+    const uint32_t o[3] = {G[n].a, G[n].b, G[n].c};
+    for (int j = 0; j < nops(G[n]); j++)
+      if (G[o[j]].op == G_INPUT) input_read[o[j]] = 1;
+  }
+  S.graphs.resize(K);
+  S.node_of.resize(K);
+  S.owned.resize(K);
+  // a segment: its own nodes and, downwards from them, everything they read until cuts, inputs and constants
+  for (uint32_t k = 0; k < K; k++) {
+    std::vector<uint8_t> member(N, 0);
+    for (uint32_t n = N; n-- > 0;) {
+      if (seg[n] == k || (k == 0 && G[n].op == G_INPUT && !input_read[n])) member[n] = 1;
+      if (!member[n]) continue;
+      const uint32_t o[3] = {G[n].a, G[n].b, G[n].c};
+      for (int j = 0; j < nops(G[n]); j++)
+        if (hint_of[o[j]] == NONE) member[o[j]] = 1;      // (a cut is read as a hint, not computed here)
+    }
+    Graph& H = S.graphs[k];
+    std::vector<uint32_t> remap(N, NONE), hint_node(S.n_hints, NONE);
+    auto operand = [&](uint32_t o) -> uint32_t {
+      if (hint_of[o] == NONE) return remap[o];
+      uint32_t& hn = hint_node[hint_of[o]];
+      if (hn == NONE) {   // the hint as an input of the segment, the first time it is read
+        hn = (uint32_t)H.nodes.size();
+        H.nodes.push_back(GNode{G_INPUT, g.inputs_size + hint_of[o], 0, 0});
+        S.node_of[k].push_back(NONE);
+        S.owned[k].push_back(0);
+      }
+      return hn;
+    };
+    for (uint32_t n = 0; n < N; n++) {
+      if (!member[n]) continue;
+      GNode q = G[n];
+      const int c = nops(q);
+      if (c > 0) q.a = operand(G[n].a);
+      if (c > 1) q.b = operand(G[n].b);
+      if (c > 2) q.c = operand(G[n].c);
+      remap[n] = (uint32_t)H.nodes.size();
+      H.nodes.push_back(q);
+      S.node_of[k].push_back(n);
+      S.owned[k].push_back(seg[n] == k || G[n].op == G_INPUT);
+    }
+    {   // only the constants the segment reads
+      std::vector<uint32_t> cmap(g.constants.size(), NONE);
+      for (GNode& q : H.nodes) {
+        if (q.op != G_CONST) continue;
+        if (q.a >= g.constants.size()) throw std::runtime_error("Graph error: constant index out of range");
+        if (cmap[q.a] == NONE) {
+          cmap[q.a] = (uint32_t)H.constants.size();
+          H.constants.push_back(g.constants[q.a]);
+        }
+        q.a = cmap[q.a];
+      }
+    }
+    H.input_mapping = g.input_mapping;
+    H.tree_depth = g.tree_depth;
+    H.max_out = g.max_out;
+    H.inputs_size = g.inputs_size + S.n_hints;
+    for (uint32_t sg : g.signals)
+      if (seg[sg] == k) H.signals.push_back(remap[sg]);
+  }
+  return S;
+}
+
+std::vector<uint32_t> wl_segment_store_slots(const WlSegments& S, size_t k, const std::vector<uint32_t>& store_slot_full) {
+  std::vector<uint32_t> st(S.node_of[k].size(), NONE);
+  for (uint32_t c = 0; c < st.size(); c++)
+    if (S.owned[k][c] && S.node_of[k][c] != NONE) st[c] = store_slot_full[S.node_of[k][c]];
   return st;
 }
 

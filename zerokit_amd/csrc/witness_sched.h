@@ -57,4 +57,28 @@ WlCone wl_cone(const Graph& graph);
 // values), everything else is not stored -- the known rows come from the partial run
 std::vector<uint32_t> wl_cone_store_slots(const WlCone& cone, const std::vector<uint32_t>& store_slot_full);
 
+
+// ---- independent segments of the graph given the values of a few nodes in advance (round 6) ------------------------------
+// The depth-20 circuit is 22 Poseidon hashes in a row (identity commitment, rate commitment, 20 Merkle levels): 4 300 of
+// its 4 800 interpreter steps are that one dependency chain, and a dependent 256-bit product costs a lone GPU wave 0.31 us
+// against 0.02 us on a host core.  The chain's VALUES are cheap to obtain elsewhere (22 host hashes); what the proof needs
+// from the device is every node of the graph -- the round states inside the hashes -- and those are independent of each
+// other once the value BETWEEN two hashes is given.  wl_segments cuts the graph at such nodes ("cuts", each with a hint
+// index): a node's key is the set of hints it reaches backwards without crossing another cut; nodes with one key form a
+// segment; a segment's graph is its nodes plus whatever else they read down to cuts (-> inputs of index inputs_size +
+// hint), inputs and constants (a node another segment owns is computed again: shallow in the shipped circuits).  The
+// segments are scheduled and run as programs of their own, all at once; every cut node is still COMPUTED by its owner
+// and compared with its hint afterwards, so a wrong hint is detected, never used (the caller then runs the whole graph).
+struct WlSegments {
+  uint32_t n_hints = 0;
+  std::vector<Graph> graphs;                      // inputs_size = the full graph's + n_hints
+  std::vector<std::vector<uint32_t>> node_of;     // per segment: segment node -> node of the full graph (NONE: a hint input)
+  std::vector<std::vector<uint8_t>> owned;        // per segment node: this segment stores it (its key is the segment's)
+  std::vector<uint32_t> cut_nodes, cut_hint;      // every cut node of the full graph and the hint it must equal
+};
+WlSegments wl_segments(const Graph& graph, const std::vector<std::vector<uint32_t>>& cuts);
+std::vector<uint32_t> wl_segment_store_slots(const WlSegments& S, size_t k, const std::vector<uint32_t>& store_slot_full);
+// plain evaluation of the graph on the host (graph.rs:246-272): inputs canonical LE, inputs_size x 32 bytes; err: WitnessErr
+std::vector<Fr> wl_eval_host(const Graph& graph, const uint8_t* inputs_le, uint32_t* err);
+
 }  // namespace rlnamd
