@@ -3,6 +3,8 @@
 // operations, so the CPU suite can check the SCHEDULE against the golden witness digests without a GPU.  The device
 // kernel differs only in how a value is represented (9 x 29-bit limbs, lazily reduced); residues mod r are the same.
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <stdexcept>
@@ -163,6 +165,8 @@ int witsched_run_segments(const uint8_t* graph, size_t len, const uint8_t* input
       if (!Q.ok) throw std::runtime_error("a segment does not fit the lanes form");
       err |= emulate(Q, ext.data(), stored);
       total += Q.nsteps;
+      if (getenv("WITSCHED_PRINT_SEGMENTS"))
+        fprintf(stderr, "segment %zu: %zu nodes, %u steps (row %u, misc %u), %u constants\n", k, S.graphs[k].nodes.size(), Q.nsteps, Q.nrow, Q.nmisc, Q.n_consts);
       if (Q.nsteps >= longest) { longest = Q.nsteps; L = Q; }
     }
     uint32_t mism = 0;

@@ -971,6 +971,45 @@ WlSegments wl_segments(const Graph& g, const std::vector<std::vector<uint32_t>>&
     seg[n] = it->second;
     key[n] = std::move(k);
   }
+  // nodes of one key that share nothing but inputs, constants and cuts are independent too (the identity commitment and
+  // a1 both start from the inputs: together they fill the four product rows of a step twice over): connected components,
+  // the small ones (a stray addition is not worth a wave and a CU's LDS) kept with the largest of their key
+  {
+    std::vector<uint32_t> parent(N);
+    for (uint32_t n = 0; n < N; n++) parent[n] = n;
+    auto find = [&](uint32_t x) {
+      while (parent[x] != x) x = parent[x] = parent[parent[x]];
+      return x;
+    };
+    for (uint32_t n = 0; n < N; n++) {
+      if (seg[n] == NONE) continue;
+      const uint32_t o[3] = {G[n].a, G[n].b, G[n].c};
+      for (int j = 0; j < nops(G[n]); j++)
+        if (seg[o[j]] == seg[n] && hint_of[o[j]] == NONE) parent[find(o[j])] = find(n);
+    }
+    std::map<uint32_t, uint32_t> comp_size;
+    for (uint32_t n = 0; n < N; n++)
+      if (seg[n] != NONE) comp_size[find(n)]++;
+    std::vector<uint32_t> biggest(seg_of_key.size(), NONE);   // per key: the root of its largest component
+    for (auto& cs : comp_size) {
+      const uint32_t k = seg[cs.first];
+      if (biggest[k] == NONE || comp_size[biggest[k]] < cs.second) biggest[k] = cs.first;
+    }
+    std::map<uint32_t, uint32_t> seg_of_comp;
+    uint32_t next = 0;
+    std::vector<uint32_t> seg2(N, NONE);
+    for (uint32_t n = 0; n < N; n++) {
+      if (seg[n] == NONE) continue;
+      uint32_t r = find(n);
+      if (comp_size[r] < 256) r = biggest[seg[n]];
+      auto it = seg_of_comp.find(r);
+      if (it == seg_of_comp.end()) it = seg_of_comp.emplace(r, next++).first;
+      seg2[n] = it->second;
+    }
+    seg.swap(seg2);
+    seg_of_key.clear();
+    for (uint32_t k = 0; k < next; k++) seg_of_key.emplace(std::vector<uint32_t>{k, 0xFFFFFFFFu}, k);   // (only its size is used below)
+  }
   const uint32_t K = (uint32_t)seg_of_key.size();
   if (K == 0) return S;
   // an input no computed node reads is still a stored value (it may be a witness signal): segment 0 takes those
