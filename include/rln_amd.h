@@ -172,12 +172,12 @@ int rlnamd_prover_residue(rlnamd_prover* p, uint64_t out[6]);
 #define RLNAMD_MODE_FINISH 2
 int rlnamd_prover_run_mode(rlnamd_prover* p, size_t n, int mode);
 int rlnamd_prover_run_async_mode(rlnamd_prover* p, size_t n, int mode);
-/* One or two proofs per call: the witness graph as independent segments behind hints.  The depth-20 circuit is 22 Poseidon
+/* A few proofs per call: the witness graph as independent segments behind hints.  The depth-20 circuit is 22 Poseidon
  * hashes in a row -- nine tenths of its interpreter steps are that one dependency chain, and a dependent 256-bit product
- * costs a lone GPU wave 0.31 us against 0.02 us on a host core.  For a lone batch of at most RLNAMD_HINTS (2) proofs the
- * calling thread computes the values BETWEEN the hashes (identity commitment, rate commitment, the running hash after
- * every Merkle level, a1: depth + 2 hashes with the library's host Poseidon, ~0.3 ms), the device interprets the 23
- * segments those values separate all at once (the longest 381 steps instead of 4 813) and then compares every cut node's
+ * costs a lone GPU wave 0.31 us against 0.02 us on a host core.  For a lone batch of at most RLNAMD_HINTS (8) proofs the
+ * calling thread (and a helper thread per further proof) computes the values BETWEEN the hashes (identity commitment, rate commitment, the running hash after
+ * every Merkle level, a1: depth + 2 hashes with the library's host Poseidon, ~0.3 ms), the device interprets the 24
+ * segments those values separate all at once (the longest 268 steps instead of 4 813) and then compares every cut node's
  * own value with the hint its consumers were given.  Every witness value is still computed on the device; a hint that does
  * not check (not expected: test hook RLNAMD_HINT_FAULT) makes collect run the batch again over the whole graph.
  * out: [0] segments, [1] hints per proof, [2] steps of the longest segment, [3] steps of the whole graph, [4] batches

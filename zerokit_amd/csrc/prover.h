@@ -70,9 +70,9 @@ struct ProverTuning {
   bool early_fin = true;               // RLNAMD_EARLY_FIN: small batches finish A, B1 before the h rows are walked
   bool fused_smul = true;              // RLNAMD_FUSED_SMUL: a lone small proof takes s A, r B1 as rows of the C segment
   bool values_from_witness = true;     // RLNAMD_VALUES_WITNESS: small batches read the proof values off the witness
-  uint32_t hint_max = 2;               // RLNAMD_HINTS: largest lone batch interpreted as independent segments behind host-computed hints
-                                       // (the values between the circuit's chained hashes; 0: never).  A proof costs the calling thread
-                                       // ~0.3 ms of host hashing and saves ~1.3 ms of interpreter: one and two proofs per call gain
+  uint32_t hint_max = 8;               // RLNAMD_HINTS: largest lone batch interpreted as independent segments behind host-computed hints
+                                       // (the values between the circuit's chained hashes; 0: never).  A proof's hints are ~0.3 ms of
+                                       // hashing on a host core (the proofs of a batch on a thread each) against ~1.3 ms of interpreter
   int hint_fault = 0;                  // RLNAMD_HINT_FAULT (test hook): j > 0 corrupts hint j - 1 of the first proof of every hinted batch
   bool d2h_kernel = true;              // RLNAMD_D2H_KERNEL: big batches copy their results home by a single-wave kernel (0: hipMemcpyAsync)
   // ---- diagnostics

@@ -15,6 +15,7 @@
 #include <chrono>
 #include <deque>
 #include <mutex>
+#include <thread>
 
 #include "prover_kernels.h"
 #include "fq29.h"
@@ -1834,11 +1835,15 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   if (cone) memcpy(S.h_cone, cone_entries.data(), n * sizeof(uint32_t));   // (the slot's previous batch has finished: see `streamed` above)
   S.hinted = hinted;
   if (hinted) {
-    std::vector<Fr> hv(D.n_hints);
-    for (size_t i = 0; i < n; i++) {
-      D.rln_hints(h_inputs + i * (size_t)D.NI * 32, hv.data());
+    auto hash_chain = [&](size_t i) {   // a proof's hints: one dependent chain of depth + 2 hashes
+      Fr hv[64];
+      D.rln_hints(h_inputs + i * (size_t)D.NI * 32, hv);
       for (uint32_t j = 0; j < D.n_hints; j++) hv[j].to_canonical(S.h_hints + (i * D.n_hints + j) * 8);
-    }
+    };
+    std::vector<std::thread> helpers;   // the chains of the batch's proofs are independent of each other: one thread each
+    for (size_t i = 1; i < n; i++) helpers.emplace_back(hash_chain, i);
+    hash_chain(0);
+    for (std::thread& th : helpers) th.join();
     if (T.hint_fault > 0 && (uint32_t)T.hint_fault <= D.n_hints) S.h_hints[(size_t)(T.hint_fault - 1) * 8] ^= 1u;   // test hook
     D.hinted_batches++;
   }
