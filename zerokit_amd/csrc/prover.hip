@@ -312,8 +312,22 @@ struct Prover::Impl {
     const size_t B = batch_cap;
     if (!n) return;
     RLN_HIP(hipStreamWaitEvent(sW, S.evC, 0));
+    // contiguous ranges are gathered and go out sixteen to a launch (k_wipe_ranges): a lone proof's collect used to make a
+    // dozen launches for as many tiny buffers before it returned
+    WipeRanges WR{};
+    auto flush = [&]() {
+      if (!WR.count) return;
+      hipLaunchKernelGGL(k_wipe_ranges, dim3(WR.first[WR.count]), dim3(64), 0, sW, WR);
+      WR.count = 0;
+    };
     auto zero = [&](void* dst, size_t bytes) {   // multiples of 32 bytes (a kernel: no copy-engine / blit path in the pipeline)
-      if (bytes) hipLaunchKernelGGL(k_wipe_bytes, dim3(div_up(bytes / 16, 256)), dim3(64), 0, sW, (uint4*)dst, (uint32_t)(bytes / 16));
+      if (!bytes) return;
+      if (WR.count == 16) flush();
+      if (WR.count == 0) WR.first[0] = 0;
+      WR.p[WR.count] = (uint4*)dst;
+      WR.n16[WR.count] = (uint32_t)(bytes / 16);
+      WR.first[WR.count + 1] = WR.first[WR.count] + (uint32_t)div_up(bytes / 16, 256);
+      WR.count++;
     };
     if (resident) {
       zero(inputs.p, std::min(inputs.bytes(), n * (size_t)NI * 32));
@@ -364,6 +378,7 @@ struct Prover::Impl {
     auto whole = [&](auto& buf) { if (buf.p) zero(buf.p, buf.bytes() / 32 * 32); };
     whole(S.grp1); whole(S.grp2); whole(S.sums1); whole(S.sums2); whole(S.prod); whole(S.tbl);
     whole(S.affA); whole(S.affB1); whole(S.affB2);
+    flush();
     RLN_HIP(hipGetLastError());
     RLN_HIP(hipEventRecord(S.evZ, sW));
     S.wiped = true;

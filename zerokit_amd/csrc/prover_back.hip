@@ -443,6 +443,17 @@ __global__ void __launch_bounds__(64) k_wipe_bytes(uint4* __restrict__ dst, uint
   for (uint32_t k = 0; k < 4; k++)
     if (i + 64 * k < n16) dst[i + 64 * k] = make_uint4(0, 0, 0, 0);
 }
+__global__ void __launch_bounds__(64) k_wipe_ranges(WipeRanges R) {
+  const uint32_t b = blockIdx.x;
+  uint32_t r = 0;
+  while (r + 1 < R.count && b >= R.first[r + 1]) r++;
+  const uint32_t i = (b - R.first[r]) * 256 + threadIdx.x;
+  uint4* const dst = R.p[r];
+  const uint32_t n16 = R.n16[r];
+#pragma unroll
+  for (uint32_t k = 0; k < 4; k++)
+    if (i + 64 * k < n16) dst[i + 64 * k] = make_uint4(0, 0, 0, 0);
+}
 // rows of `stride16` 16-byte words each: the first n16 words of every row (the columns of a batch's proofs in the digit
 // rows, the quotient's operands and the walks' partial sums)
 __global__ void __launch_bounds__(64) k_wipe_rows16(uint4* __restrict__ base, uint32_t nrows, uint32_t stride16, uint32_t n16) {

@@ -167,6 +167,15 @@ __global__ void __launch_bounds__(256) k_cone_restore(const uint4* __restrict__ 
 __global__ void __launch_bounds__(64) k_stage_in(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16);
 __global__ void __launch_bounds__(64) k_wipe_cols(Fr* __restrict__ V, const uint32_t* __restrict__ rows, uint32_t nrows,
                                                   uint32_t B, uint32_t n);
+// several contiguous ranges in ONE launch (a small batch's wipes are a dozen tiny buffers: a dozen launches on the calling
+// thread before collect returns); block b belongs to the range r with first[r] <= b < first[r + 1], 256 words per block
+struct WipeRanges {
+  uint4* p[16];
+  uint32_t n16[16];
+  uint32_t first[17];
+  uint32_t count;
+};
+__global__ void __launch_bounds__(64) k_wipe_ranges(WipeRanges R);
 __global__ void __launch_bounds__(64) k_wipe_bytes(uint4* __restrict__ dst, uint32_t n16);   // grid: div_up(n16, 256) workgroups of 64 lanes
 __global__ void __launch_bounds__(64) k_wipe_rows16(uint4* __restrict__ base, uint32_t nrows, uint32_t stride16, uint32_t n16);
 __global__ void __launch_bounds__(256) k_count_nonzero16(const uint4* __restrict__ src, size_t n16, unsigned long long* __restrict__ out);
