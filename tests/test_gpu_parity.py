@@ -633,6 +633,15 @@ def test_other_circuits_depth10_and_multi_message_id():
         assert not p.verify_public(out[0]["proof"], bad)
         if not c["multi"]:
             assert out[0]["public_inputs"] == pub[0]          # Poseidon-formula values == witness outputs
+        # round 6: one proof per call through the segments behind hints, on these circuits too (the multi-message-id
+        # circuit: an a1 hint per message slot): the golden bytes, every hint checked, none failed
+        st = p.hint_stats()
+        assert st["segments"] > c["depth"] and st["hints"] == c["depth"] + 1 + (4 if c["multi"] else 1), st
+        t, k = p.submit(p.pack_named_inputs([named]), p.pack_rs([(int(c["r"]), int(c["s"]))]))
+        got = p.collect_raw(t, k)
+        assert got[0].hex() == c["proof_compressed"] and not any(got[2]), c["name"]
+        st = p.hint_stats()
+        assert st["hinted_batches"] == 1 and st["fallbacks"] == 0, st
         p.close()
 
 

@@ -260,9 +260,13 @@ struct Prover::Impl {
       node = poseidon_hash_host(P3, in2);
       if (l + 1 < slots.depth) out[2 + l] = node;
     }
-    const Fr in3[3] = {secret, rd(slots.ext), rd(slots.msg_id)};
-    out[slots.depth + 1] = poseidon_hash_host(P4, in3);
+    for (uint32_t k = 0; k < hint_msgs; k++) {   // a1 of every message slot (one on the single-message circuits)
+      const Fr in3[3] = {secret, rd(slots.ext), rd(hint_msg_off + k)};
+      out[slots.depth + 1 + k] = poseidon_hash_host(P4, in3);
+    }
   }
+  bool have_hint_slots = false;          // the named inputs rln_hints reads exist (single- and multi-message-id circuits)
+  uint32_t hint_msg_off = 0, hint_msgs = 1;
   // ---- the partial-proof cache and the cone program (prover.h: collect_partial_cached / submit_finish)
   WitLanes cone;                 // the unknown cone of evaluate_partial, scheduled like the full graph (witness_sched.h: wl_cone)
   uint32_t cone_nodes = 0;
@@ -669,16 +673,24 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
          find("identityPathIndex", graph_.tree_depth, &D.slots.path_idx) && find("x", 1, &D.slots.x) &&
          find("externalNullifier", 1, &D.slots.ext);
     D.have_values_kernel = ok;
+    // the hints need the same names, with one message id per message slot (the multi-message-id circuit: max_out of them)
+    uint32_t unused = 0;
+    D.hint_msgs = graph_.max_out;
+    D.have_hint_slots = find("identitySecret", 1, &D.slots.secret) && find("userMessageLimit", 1, &D.slots.limit) &&
+                        find("messageId", graph_.max_out, &D.hint_msg_off) && find("pathElements", graph_.tree_depth, &D.slots.path) &&
+                        find("identityPathIndex", graph_.tree_depth, &D.slots.path_idx) && find("x", 1, &D.slots.x) &&
+                        find("externalNullifier", 1, &D.slots.ext) &&
+                        (graph_.max_out == 1 || find("selectorUsed", graph_.max_out, &unused));
   }
   // ---- where the graph can be cut (segments behind hints): the nodes that hold the values between the chained hashes,
   //      found on a probe witness -- every computed node whose value equals one of rln_hints' -- so that nothing about the
   //      circuit's node numbering is assumed; a circuit on which a hint matches no node keeps the whole-graph interpreter
   std::vector<std::vector<uint32_t>> hint_cuts;
   std::vector<uint8_t> is_cut(D.N, 0);
-  if (D.have_values_kernel && D.tune.hint_max > 0 && graph_.tree_depth + 2 <= 64) {
+  if (D.have_hint_slots && D.tune.hint_max > 0 && graph_.tree_depth + 1 + graph_.max_out <= 64) {
     // two probes with complementary path bits and unrelated values: a node that merely carries the running hash on one
     // side of a level's left / right selection equals the hint under one of them only
-    D.n_hints = graph_.tree_depth + 2;
+    D.n_hints = graph_.tree_depth + 1 + graph_.max_out;
     hint_cuts.assign(D.n_hints, {});
     std::vector<uint8_t> match(D.N, 1);
     std::vector<uint32_t> match_hint(D.N, 0xFFFFFFFFu);
@@ -695,7 +707,12 @@ Prover::Prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_
       };
       put(D.slots.secret); put(D.slots.x); put(D.slots.ext);
       probe[32 * (size_t)D.slots.limit] = (uint8_t)(100 + round);
-      probe[32 * (size_t)D.slots.msg_id] = (uint8_t)(7 + round);
+      for (uint32_t k = 0; k < D.hint_msgs; k++) probe[32 * (size_t)(D.hint_msg_off + k)] = (uint8_t)(7 + round + 3 * k);
+      {
+        auto it = graph_.input_mapping.find("selectorUsed");   // every message slot in use
+        if (it != graph_.input_mapping.end())
+          for (uint32_t k = 0; k < it->second.second; k++) probe[32 * (size_t)(it->second.first + k)] = 1;
+      }
       for (uint32_t l = 0; l < D.slots.depth; l++) {
         put(D.slots.path + l);
         probe[32 * (size_t)(D.slots.path_idx + l)] = (uint8_t)((l + round) & 1);
