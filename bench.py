@@ -1128,7 +1128,22 @@ def main():
             if i >= 2:
                 ts.append((time.perf_counter() - t0) * 1e3)
         same = bool(pr[:128] == results[0][0][:128] and not any(er)) if 0 in results else None
+        few = {}
+        for k in (2, 4, 8):   # a few proofs per call (the segments-behind-hints form up to RLNAMD_HINTS = 8 proofs)
+            if k > B:
+                continue
+            kin, krs = workload.config2_packed(prover.slots, prover.inputs_size, first, k)
+            tk = []
+            for i in range(7):
+                t0 = time.perf_counter()
+                t, _ = prover.submit(kin, krs)
+                kp, _, ke = prover.collect_raw(t, k)
+                if i >= 2:
+                    tk.append((time.perf_counter() - t0) * 1e3)
+            few[str(k)] = round(sorted(tk)[len(tk) // 2], 3)
+            same = bool(same and kp[:128 * k] == results[0][0][:128 * k] and not any(ke)) if 0 in results else same
         latency = {"ms_min": round(min(ts), 3), "ms_median": round(sorted(ts)[len(ts) // 2], 3), "calls": len(ts),
+                   "ms_median_by_proofs_per_call": few, "witness_graph_as_segments": prover.hint_stats(),
                    "what": "one proof per call on the bench's prover (228 GiB tables): submit + collect, H2D and D2H included",
                    "same_bytes_as_in_the_batch": same}
     # ---- the steady state: `value` above times K steps -- under a second at the driver's K = 20, i.e. inside
