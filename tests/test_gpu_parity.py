@@ -967,7 +967,8 @@ def test_up_to_eight_proofs_per_call_interpret_the_graph_as_segments_behind_hint
     inputs (all golden cases, r = 0 among them), one, two and eight proofs per call; nine per call keep the whole-graph
     interpreter; a partial proof through the segments equals the pyref fixture; an input >= r is still an error; with a
     corrupted hint (test hook) the batch is run again over the whole graph and the caller sees the golden bytes; with
-    RLNAMD_HINTS=0 nothing is hinted and the bytes are the same."""
+    RLNAMD_HINTS=0 nothing is hinted and the bytes are the same; a member proving again at the same root finds the chain
+    part of its hints remembered (hint_stats()["chains_remembered"]) and gets the same bytes."""
     from zerokit_amd.batch import BatchProver
     cases = _cases()["cases"]
     fx = {c["name"]: c["partial320"] for c in json.load(open(os.path.join(ROOT, "tests", "golden", "rln_h20_partial.json")))["cases"]}
@@ -987,9 +988,12 @@ def test_up_to_eight_proofs_per_call_interpret_the_graph_as_segments_behind_hint
         for i in range(len(cases)):
             run(p, [i])
         assert p.hint_stats()["hinted_batches"] == len(cases) and p.hint_stats()["fallbacks"] == 0
+        seen = p.hint_stats()["chains_remembered"]          # members the golden cases share count here already
         run(p, [0, 1])
         run(p, [2, 3])
         assert p.hint_stats()["hinted_batches"] == len(cases) + 2
+        # the same members at the same root again: their chains of hints are remembered (two host hashes each), same bytes
+        assert p.hint_stats()["chains_remembered"] == seen + 4, p.hint_stats()
         run(p, [0, 1, 2, 3, 4, 5, 0, 1])                   # eight per call: still segments (a host thread per proof hashes its hints)
         assert p.hint_stats()["hinted_batches"] == len(cases) + 3
         run(p, [0, 1, 2, 3, 4, 5, 0, 1, 2])                # nine per call: the whole graph

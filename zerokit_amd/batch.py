@@ -241,9 +241,10 @@ class BatchProver:
 
     def hint_stats(self):
         """the witness graph as segments behind hints (rlnamd_prover_hint_stats)"""
-        out = (C.c_uint64 * 6)()
+        out = (C.c_uint64 * 7)()
         check(lib().rlnamd_prover_hint_stats(self._h, out))
-        return dict(zip(("segments", "hints", "longest_segment_steps", "full_steps", "hinted_batches", "fallbacks"), [int(v) for v in out]))
+        return dict(zip(("segments", "hints", "longest_segment_steps", "full_steps", "hinted_batches", "fallbacks", "chains_remembered"),
+                        [int(v) for v in out]))
 
     def device_shared(self):
         """bit 0: another prover of this process on the device; bit 1: a prover of another process"""

@@ -306,9 +306,9 @@ int rlnamd_prover_collect(rlnamd_prover* p, uint64_t ticket, size_t n, uint8_t* 
   p->p->collect(ticket, n, proofs, values, errors, coords, partial320);
   RLN_CATCH
 }
-int rlnamd_prover_hint_stats(rlnamd_prover* p, uint64_t out[6]) {
+int rlnamd_prover_hint_stats(rlnamd_prover* p, uint64_t out[7]) {
   RLN_TRY
-  static_assert(Prover::HINT_STATS_FIELDS == 6, "rln_amd.h states six fields");
+  static_assert(Prover::HINT_STATS_FIELDS == 7, "rln_amd.h states seven fields");
   p->p->hint_stats(out);
   RLN_CATCH
 }

@@ -180,8 +180,9 @@ class Prover {
   // program, [6] steps of the cone program, [7] steps of the full program
   // the graph as segments behind hints (witness_sched.h: wl_segments): [0] segments, [1] hints per proof, [2] steps of the
   // longest segment, [3] steps of the whole graph's program, [4] batches interpreted that way, [5] of those, batches whose
-  // hints did not check and were run again over the whole graph (0 unless the RLNAMD_HINT_FAULT test hook is set)
-  static constexpr int HINT_STATS_FIELDS = 6;
+  // hints did not check and were run again over the whole graph (0 unless the RLNAMD_HINT_FAULT test hook is set), [6] proofs
+  // whose chain of hints was found among the last sixteen (the same member at the same root: two host hashes instead of 22)
+  static constexpr int HINT_STATS_FIELDS = 7;
   void hint_stats(uint64_t out[HINT_STATS_FIELDS]) const;
   static constexpr int PARTIAL_CACHE_FIELDS = 8;
   void partial_cache_info(uint64_t out[PARTIAL_CACHE_FIELDS]);

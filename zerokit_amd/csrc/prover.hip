@@ -239,6 +239,22 @@ struct Prover::Impl {
   uint32_t n_cut = 0, n_hints = 0;
   uint64_t hinted_batches = 0, hint_fallbacks = 0;
   bool no_hints_now = false;     // set around the re-run of a batch whose hints did not check
+  // The chain part of a member's hints -- rate commitment and the running hash after every level -- is a function of PUBLIC
+  // values only: the identity commitment (hint 0, hashed from the secret on every call) and the tree's nodes along the
+  // member's path.  A node that proves message after message with one identity while the root stands asks for the same
+  // chain again and again: the last few are remembered under a fingerprint of (identity commitment, limit, path
+  // elements, path bits) -- no secret in it, none in what is stored -- and a call that finds its chain hashes twice
+  // (identity commitment, a1) instead of depth + 2 times.  Nothing is trusted for it: k_hint_check compares every hint
+  // with the device's own value, a fingerprint collision or a stale entry costs one run over the whole graph.
+  struct ChainEntry {
+    uint64_t fp[2] = {0, 0};
+    uint64_t stamp = 0;
+    std::vector<Fr> chain;   // hints 1 .. depth
+  };
+  mutable std::mutex chain_mu;
+  mutable std::vector<ChainEntry> chain_cache;
+  mutable uint64_t chain_clock = 0, chain_hits = 0;
+  static constexpr size_t CHAIN_ENTRIES = 16;
   void rln_hints(const uint8_t* in_le, Fr* out) const {   // idc, rate commitment, the running hash after levels 1 .. depth - 1, a1
     auto rd = [&](uint32_t slot) {
       uint32_t c[8];
@@ -248,17 +264,66 @@ struct Prover::Impl {
     const PoseidonParams &P2 = poseidon_host_params(2), &P3 = poseidon_host_params(3), &P4 = poseidon_host_params(4);
     const Fr secret = rd(slots.secret), limit = rd(slots.limit);
     const Fr idc = poseidon_hash_host(P2, &secret);
-    Fr in2[2] = {idc, limit};
-    Fr node = poseidon_hash_host(P3, in2);
     out[0] = idc;
-    out[1] = node;
-    for (uint32_t l = 0; l < slots.depth; l++) {
-      const Fr e = rd(slots.path + l);
-      const bool right = !rd(slots.path_idx + l).is_zero();   // the node is the right child: hash(sibling, node)
-      in2[0] = right ? e : node;
-      in2[1] = right ? node : e;
-      node = poseidon_hash_host(P3, in2);
-      if (l + 1 < slots.depth) out[2 + l] = node;
+    // fingerprint of the public values the chain depends on (two multiply-xorshift lanes over the 32-bit words)
+    uint64_t fp[2] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full};
+    auto mix = [&](const uint32_t* w, int n) {
+      for (int k = 0; k < n; k++) {
+        fp[0] = (fp[0] ^ w[k]) * 0xFF51AFD7ED558CCDull;
+        fp[0] ^= fp[0] >> 29;
+        fp[1] = (fp[1] + w[k]) * 0xC4CEB9FE1A85EC53ull;
+        fp[1] ^= fp[1] >> 31;
+      }
+    };
+    auto mix_slots = [&](uint32_t first, uint32_t count) {
+      for (uint32_t k = 0; k < count; k++) {
+        uint32_t w[8];
+        memcpy(w, in_le + 32 * (size_t)(first + k), 32);
+        mix(w, 8);
+      }
+    };
+    mix(idc.v, 8);
+    mix_slots(slots.limit, 1);
+    mix_slots(slots.path, slots.depth);
+    mix_slots(slots.path_idx, slots.depth);
+    bool found = false;
+    {
+      std::lock_guard<std::mutex> lk(chain_mu);
+      for (ChainEntry& e : chain_cache)
+        if (e.fp[0] == fp[0] && e.fp[1] == fp[1] && e.chain.size() == slots.depth) {
+          for (uint32_t l = 0; l < slots.depth; l++) out[1 + l] = e.chain[l];
+          e.stamp = ++chain_clock;
+          chain_hits++;
+          found = true;
+          break;
+        }
+    }
+    if (!found) {
+      Fr in2[2] = {idc, limit};
+      Fr node = poseidon_hash_host(P3, in2);
+      out[1] = node;
+      for (uint32_t l = 0; l < slots.depth; l++) {
+        const Fr e = rd(slots.path + l);
+        const bool right = !rd(slots.path_idx + l).is_zero();   // the node is the right child: hash(sibling, node)
+        in2[0] = right ? e : node;
+        in2[1] = right ? node : e;
+        node = poseidon_hash_host(P3, in2);
+        if (l + 1 < slots.depth) out[2 + l] = node;
+      }
+      std::lock_guard<std::mutex> lk(chain_mu);
+      ChainEntry* slot = nullptr;
+      if (chain_cache.size() < CHAIN_ENTRIES) {
+        chain_cache.emplace_back();
+        slot = &chain_cache.back();
+      } else {
+        slot = &chain_cache[0];
+        for (ChainEntry& e : chain_cache)
+          if (e.stamp < slot->stamp) slot = &e;
+      }
+      slot->fp[0] = fp[0];
+      slot->fp[1] = fp[1];
+      slot->stamp = ++chain_clock;
+      slot->chain.assign(out + 1, out + 1 + slots.depth);
     }
     for (uint32_t k = 0; k < hint_msgs; k++) {   // a1 of every message slot (one on the single-message circuits)
       const Fr in3[3] = {secret, rd(slots.ext), rd(hint_msg_off + k)};
@@ -1561,6 +1626,7 @@ void Prover::hint_stats(uint64_t out[HINT_STATS_FIELDS]) const {
   out[3] = D.witlanes.ok ? D.witlanes.nsteps : 0;
   out[4] = D.hinted_batches;
   out[5] = D.hint_fallbacks;
+  out[6] = D.chain_hits;
 }
 
 void Prover::partial_cache_info(uint64_t out[PARTIAL_CACHE_FIELDS]) {
