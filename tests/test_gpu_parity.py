@@ -1020,6 +1020,15 @@ def test_up_to_eight_proofs_per_call_interpret_the_graph_as_segments_behind_hint
     finally:
         p.close()
     monkeypatch.delenv("RLNAMD_HINT_FAULT")
+    monkeypatch.setenv("RLNAMD_HINT_CHAINS", "0")           # nothing remembered between calls: every chain hashed, same bytes
+    p = BatchProver(max_batch=64, window_bits=8)
+    try:
+        run(p, [0])
+        run(p, [0])
+        assert p.hint_stats()["hinted_batches"] == 2 and p.hint_stats()["chains_remembered"] == 0
+    finally:
+        p.close()
+    monkeypatch.delenv("RLNAMD_HINT_CHAINS")
     monkeypatch.setenv("RLNAMD_HINTS", "0")
     p = BatchProver(max_batch=64, window_bits=8)
     try:

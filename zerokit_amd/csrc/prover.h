@@ -73,6 +73,7 @@ struct ProverTuning {
   uint32_t hint_max = 8;               // RLNAMD_HINTS: largest lone batch interpreted as independent segments behind host-computed hints
                                        // (the values between the circuit's chained hashes; 0: never).  A proof's hints are ~0.3 ms of
                                        // hashing on a host core (the proofs of a batch on a thread each) against ~1.3 ms of interpreter
+  uint32_t hint_chains = 16;           // RLNAMD_HINT_CHAINS: members whose public chain of hints (rate commitment, the hash after every level) is remembered on the host; 0: none
   int hint_fault = 0;                  // RLNAMD_HINT_FAULT (test hook): j > 0 corrupts hint j - 1 of the first proof of every hinted batch
   bool d2h_kernel = true;              // RLNAMD_D2H_KERNEL: big batches copy their results home by a single-wave kernel (0: hipMemcpyAsync)
   // ---- diagnostics

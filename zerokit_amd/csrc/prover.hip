@@ -254,7 +254,6 @@ struct Prover::Impl {
   mutable std::mutex chain_mu;
   mutable std::vector<ChainEntry> chain_cache;
   mutable uint64_t chain_clock = 0, chain_hits = 0;
-  static constexpr size_t CHAIN_ENTRIES = 16;
   void rln_hints(const uint8_t* in_le, Fr* out) const {   // idc, rate commitment, the running hash after levels 1 .. depth - 1, a1
     auto rd = [&](uint32_t slot) {
       uint32_t c[8];
@@ -287,7 +286,8 @@ struct Prover::Impl {
     mix_slots(slots.path, slots.depth);
     mix_slots(slots.path_idx, slots.depth);
     bool found = false;
-    {
+    const size_t CHAIN_ENTRIES = tune.hint_chains;
+    if (CHAIN_ENTRIES) {
       std::lock_guard<std::mutex> lk(chain_mu);
       for (ChainEntry& e : chain_cache)
         if (e.fp[0] == fp[0] && e.fp[1] == fp[1] && e.chain.size() == slots.depth) {
@@ -310,20 +310,22 @@ struct Prover::Impl {
         node = poseidon_hash_host(P3, in2);
         if (l + 1 < slots.depth) out[2 + l] = node;
       }
-      std::lock_guard<std::mutex> lk(chain_mu);
-      ChainEntry* slot = nullptr;
-      if (chain_cache.size() < CHAIN_ENTRIES) {
-        chain_cache.emplace_back();
-        slot = &chain_cache.back();
-      } else {
-        slot = &chain_cache[0];
-        for (ChainEntry& e : chain_cache)
-          if (e.stamp < slot->stamp) slot = &e;
+      if (CHAIN_ENTRIES) {
+        std::lock_guard<std::mutex> lk(chain_mu);
+        ChainEntry* slot = nullptr;
+        if (chain_cache.size() < CHAIN_ENTRIES) {
+          chain_cache.emplace_back();
+          slot = &chain_cache.back();
+        } else {
+          slot = &chain_cache[0];
+          for (ChainEntry& e : chain_cache)
+            if (e.stamp < slot->stamp) slot = &e;
+        }
+        slot->fp[0] = fp[0];
+        slot->fp[1] = fp[1];
+        slot->stamp = ++chain_clock;
+        slot->chain.assign(out + 1, out + 1 + slots.depth);
       }
-      slot->fp[0] = fp[0];
-      slot->fp[1] = fp[1];
-      slot->stamp = ++chain_clock;
-      slot->chain.assign(out + 1, out + 1 + slots.depth);
     }
     for (uint32_t k = 0; k < hint_msgs; k++) {   // a1 of every message slot (one on the single-message circuits)
       const Fr in3[3] = {secret, rd(slots.ext), rd(hint_msg_off + k)};
@@ -505,6 +507,7 @@ ProverTuning ProverTuning::from_env() {
   t.d2h_kernel = env_int("RLNAMD_D2H_KERNEL", 1) != 0;
   t.hint_max = (uint32_t)std::min<int>(std::max(0, env_int("RLNAMD_HINTS", (int)t.hint_max)), (int)HINT_PROOFS);
   t.hint_fault = env_int("RLNAMD_HINT_FAULT", 0);
+  t.hint_chains = (uint32_t)std::min(std::max(0, env_int("RLNAMD_HINT_CHAINS", (int)t.hint_chains)), 1024);
   return t;
 }
 std::string ProverTuning::describe() const {
