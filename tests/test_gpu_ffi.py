@@ -528,6 +528,49 @@ def test_auto_partial_member_memo_behind_generate_rln_proof(tmp_path):
     assert rln.verify_rln_proof(p, 1007) and rln.memo_stats()["finishes"] == 8
 
 
+def test_concurrent_proving_with_the_member_memo(tmp_path):
+    """generate_rln_proof takes &self (public.rs:624): four threads prove for three members on ONE object whose memo holds
+    two ({"auto_partial": 2}) -- adoptions of pending partial proofs, finishes through the cone, evictions and proofs from
+    scratch interleave as the scheduler likes.  Every proof equals, byte for byte, the proof an object without the memo
+    makes for the same witness and (r, s), and verifies; the counters add up to the calls."""
+    import json
+    import threading
+    from zerokit_amd import hashers
+    from zerokit_amd.public import RLN, RLNWitnessInput
+    cfgp = tmp_path / "cfg.json"
+    cfgp.write_text(json.dumps({"auto_partial": 2}))
+    rln, plain = RLN(20, tree_config=str(cfgp)), RLN(20)
+    secrets = [hashers.hash_to_field_le(b"memo-thread-member-%d" % k) for k in range(3)]
+    for obj in (rln, plain):
+        for k, sec in enumerate(secrets):
+            obj.set_leaf(20 + k, hashers.poseidon_hash_pair(hashers.poseidon_hash([sec]), 100))
+    paths = [rln.get_merkle_proof(20 + k) for k in range(3)]
+    made, errors = {}, []
+
+    def work(tid):
+        try:
+            for j in range(6):
+                k = (tid + j) % 3
+                msg, x = (tid * 6 + j) % 100, 5000 + 100 * tid + j
+                w = RLNWitnessInput(secrets[k], 100, msg, paths[k][0], paths[k][1], x, 4242)
+                made[(tid, j)] = (k, msg, x, rln.generate_rln_proof_with_rs(w, 9 + x, 3 + msg).to_bytes_le())
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors and len(made) == 24, errors
+    for k, msg, x, got in made.values():
+        w = RLNWitnessInput(secrets[k], 100, msg, paths[k][0], paths[k][1], x, 4242)
+        ref = plain.generate_rln_proof_with_rs(w, 9 + x, 3 + msg)
+        assert got == ref.to_bytes_le() and plain.verify_rln_proof(ref, x)
+    st = rln.memo_stats()
+    assert st["finishes"] + st["from_scratch"] == 24 and st["members"] <= 2 and st["finishes"] > 0, st
+
+
 def test_default_object_falls_back_to_the_small_point_when_the_device_is_nearly_full(monkeypatch, tmp_path):
     """every ffi_rln_new* without a sizing key allocates ~23 GiB.  With less than 26 GiB free the object is
     built at the "small" point instead (same proofs), below 10 GiB the error names the `profile` key; an explicit
