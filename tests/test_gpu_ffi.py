@@ -532,7 +532,8 @@ def test_concurrent_proving_with_the_member_memo(tmp_path):
     """generate_rln_proof takes &self (public.rs:624): four threads prove for three members on ONE object whose memo holds
     two ({"auto_partial": 2}) -- adoptions of pending partial proofs, finishes through the cone, evictions and proofs from
     scratch interleave as the scheduler likes.  Every proof equals, byte for byte, the proof an object without the memo
-    makes for the same witness and (r, s), and verifies; the counters add up to the calls."""
+    makes for the same witness and (r, s), and verifies; the counters add up to the calls; afterwards the memo still turns
+    a member's repeated proofs into finishes."""
     import json
     import threading
     from zerokit_amd import hashers
@@ -568,7 +569,14 @@ def test_concurrent_proving_with_the_member_memo(tmp_path):
         ref = plain.generate_rln_proof_with_rs(w, 9 + x, 3 + msg)
         assert got == ref.to_bytes_le() and plain.verify_rln_proof(ref, x)
     st = rln.memo_stats()
-    assert st["finishes"] + st["from_scratch"] == 24 and st["members"] <= 2 and st["finishes"] > 0, st
+    # (how many of the 24 were finishes is the scheduler's choice: three members taking turns through a memo of two can
+    # miss every time)
+    assert st["finishes"] + st["from_scratch"] == 24 and st["members"] <= 2, st
+    for j in range(3):          # and the memo still works after all that: the same member three times in a row
+        w = RLNWitnessInput(secrets[0], 100, 90 + j, paths[0][0], paths[0][1], 7000 + j, 4242)
+        a, b = rln.generate_rln_proof_with_rs(w, 5 + j, 6 + j), plain.generate_rln_proof_with_rs(w, 5 + j, 6 + j)
+        assert a.to_bytes_le() == b.to_bytes_le()
+    assert rln.memo_stats()["finishes"] >= st["finishes"] + 2, rln.memo_stats()
 
 
 def test_default_object_falls_back_to_the_small_point_when_the_device_is_nearly_full(monkeypatch, tmp_path):
