@@ -1139,7 +1139,7 @@ def main():
                 ta.append((time.perf_counter() - t0) * 1e3)
         same = bool(pr[:128] == results[0][0][:128] and not any(er)) if 0 in results else None
         few = {}
-        for k in (2, 4, 8):   # a few proofs per call (the segments-behind-hints form up to RLNAMD_HINTS = 8 proofs)
+        for k in (2, 4, 8):   # a few proofs per call (the segments-behind-hints form, RLNAMD_HINTS = 24 proofs at most)
             if k > B:
                 continue
             tk = []

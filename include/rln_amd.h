@@ -99,6 +99,14 @@ int rlnamd_ffi_prover_info(const void* ffi_rln, rlnamd_prover_info* info);
  * (identity secret included) in host memory until the entry is evicted, or the object freed.
  * out: [0] members remembered, [1] proofs that were finishes, [2] proofs from scratch, [3] 1 while a partial proof is pending */
 int rlnamd_ffi_memo_stats(const void* ffi_rln, uint64_t out[4]);
+/* Concurrent callers.  generate_rln_proof takes &self in the reference (rln/src/public.rs:624) and an RLN object may be
+ * shared by threads; the prover proves one batch at a time, so the single-proof calls (ffi_generate_rln_proof,
+ * ffi_rln_v3_generate_proof and their _with_rs twins) that arrive while a proof is on the device are gathered and go out
+ * together, as one batch, when it returns -- each call gets its own proof or its own error text, a lone caller is a
+ * batch of one as before.  "gather_calls": N in the config_path JSON (or RLNAMD_GATHER_CALLS) caps a batch (default:
+ * the workspace's capacity; 0 or 1: off); an object with "auto_partial" keeps its calls apart.
+ * out: [0] batches led, [1] calls that went out in them, [2] the largest batch, [3] the cap (0: off) */
+int rlnamd_ffi_gather_stats(const void* ffi_rln, uint64_t out[4]);
 /* offset/len of a named input signal in the inputs buffer (iden3calc.rs:122-146); returns RLNAMD_ERR if absent */
 int rlnamd_prover_input_slot(rlnamd_prover* p, const char* name, uint32_t* offset, uint32_t* len);
 /* inputs: n * inputs_size * 32 bytes (slot 0 must hold 1); rs: n * 64 bytes (r then s). */
@@ -174,7 +182,7 @@ int rlnamd_prover_run_mode(rlnamd_prover* p, size_t n, int mode);
 int rlnamd_prover_run_async_mode(rlnamd_prover* p, size_t n, int mode);
 /* A few proofs per call: the witness graph as independent segments behind hints.  The depth-20 circuit is 22 Poseidon
  * hashes in a row -- nine tenths of its interpreter steps are that one dependency chain, and a dependent 256-bit product
- * costs a lone GPU wave 0.31 us against 0.02 us on a host core.  For a lone batch of at most RLNAMD_HINTS (8) proofs the
+ * costs a lone GPU wave 0.31 us against 0.02 us on a host core.  For a lone batch of at most RLNAMD_HINTS (24) proofs the
  * calling thread (and a helper thread per further proof) computes the values BETWEEN the hashes (identity commitment, rate commitment, the running hash after
  * every Merkle level, a1: depth + 2 hashes with the library's host Poseidon, ~0.3 ms), the device interprets the 24
  * segments those values separate all at once (the longest 268 steps instead of 4 813) and then compares every cut node's

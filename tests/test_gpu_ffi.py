@@ -528,6 +528,76 @@ def test_auto_partial_member_memo_behind_generate_rln_proof(tmp_path):
     assert rln.verify_rln_proof(p, 1007) and rln.memo_stats()["finishes"] == 8
 
 
+def test_concurrent_single_proof_calls_are_gathered_into_batches(tmp_path):
+    """generate_rln_proof takes &self (public.rs:624).  Calls that arrive from other threads while a proof is on the device
+    go out together as one batch when it returns (ffi.cpp: prove_one).  Eight threads, sixteen calls each, on one object:
+    every proof equals, byte for byte, what an object with {"gather_calls": 0} makes alone for that witness and (r, s),
+    and verifies; batches of more than one call were led; a call whose witness cannot be evaluated (x = r, not canonical:
+    graph.rs:42-45 -- refused before the device sees it -- and a path of the wrong length) gets ITS error text while
+    the calls gathered with it get their proofs; the V3 entry point is gathered too."""
+    import json
+    import threading
+    from zerokit_amd import hashers
+    from zerokit_amd.public import RLN, RLNError, RLNWitnessInput
+    cfgp = tmp_path / "cfg.json"
+    cfgp.write_text(json.dumps({"gather_calls": 0}))
+    rln, alone = RLN(20), RLN(20, tree_config=str(cfgp))
+    assert alone.gather_stats()["cap"] == 0 and rln.gather_stats()["cap"] > 1
+    secrets = [hashers.hash_to_field_le(b"gathered-member-%d" % k) for k in range(4)]
+    for obj in (rln, alone):
+        for k, sec in enumerate(secrets):
+            obj.set_leaf(30 + k, hashers.poseidon_hash_pair(hashers.poseidon_hash([sec]), 100))
+    paths = [rln.get_merkle_proof(30 + k) for k in range(4)]
+    made, errors, refused = {}, [], {}
+
+    def work(tid):
+        try:
+            for j in range(16):
+                k = (tid + j) % 4
+                msg, x = (tid * 16 + j) % 100, 9000 + 100 * tid + j
+                if tid == 3 and j % 5 == 2:      # a witness the circuit cannot take, in the middle of the others
+                    try:
+                        rln.generate_rln_proof_with_rs(RLNWitnessInput(secrets[k], 100, msg, paths[k][0][:-1], paths[k][1][:-1], x, 4242), 1, 2)
+                        refused[(tid, j)] = None
+                    except RLNError as e:
+                        refused[(tid, j)] = str(e)
+                    continue
+                w = RLNWitnessInput(secrets[k], 100, msg, paths[k][0], paths[k][1], x, 4242)
+                made[(tid, j)] = (k, msg, x, rln.generate_rln_proof_with_rs(w, 9 + x, 3 + msg).to_bytes_le())
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors and len(made) + len(refused) == 128 and len(refused) == 3, errors
+    assert all(m and "path_elements has length 19" in m for m in refused.values()), refused
+    for k, msg, x, got in made.values():
+        w = RLNWitnessInput(secrets[k], 100, msg, paths[k][0], paths[k][1], x, 4242)
+        ref = alone.generate_rln_proof_with_rs(w, 9 + x, 3 + msg)
+        assert got == ref.to_bytes_le() and alone.verify_rln_proof(ref, x)
+    st, sa = rln.gather_stats(), alone.gather_stats()
+    assert st["calls"] == 128 and st["largest"] > 1 and st["batches"] < 128, st
+    assert sa["batches"] == 0, sa
+    # random (r, s) through the same door: each call its own blinding, every proof verifies
+    outs = {}
+
+    def rnd(tid):
+        w = RLNWitnessInput(secrets[tid % 4], 100, 10 + tid, paths[tid % 4][0], paths[tid % 4][1], 400 + tid, 4242)
+        outs[tid] = [rln.generate_rln_proof(w) for _ in range(4)]
+    threads = [threading.Thread(target=rnd, args=(t,)) for t in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert len(outs) == 6
+    for tid, ps in outs.items():
+        assert all(rln.verify_rln_proof(p, 400 + tid) for p in ps)
+        assert len({p.to_bytes_le() for p in ps}) == 4
+
+
 def test_concurrent_proving_with_the_member_memo(tmp_path):
     """generate_rln_proof takes &self (public.rs:624): four threads prove for three members on ONE object whose memo holds
     two ({"auto_partial": 2}) -- adoptions of pending partial proofs, finishes through the cone, evictions and proofs from

@@ -960,12 +960,13 @@ def test_finish_from_a_cached_partial_interprets_only_the_unknown_cone(prover, m
         q.close()
 
 
-def test_up_to_eight_proofs_per_call_interpret_the_graph_as_segments_behind_hints(monkeypatch):
+def test_a_few_proofs_per_call_interpret_the_graph_as_segments_behind_hints(monkeypatch):
     """Round 6.  A lone batch of one or two proofs: the calling thread computes the values between the circuit's 22 chained
     hashes (rlnamd_prover_hint_stats; the library's host Poseidon), the device interprets the 23 segments those values
     separate at once and compares every cut node's own value with its hint.  Checked: the golden proof bytes and public
-    inputs (all golden cases, r = 0 among them), one, two and eight proofs per call; nine per call keep the whole-graph
-    interpreter; a partial proof through the segments equals the pyref fixture; an input >= r is still an error; with a
+    inputs (all golden cases, r = 0 among them), one, two, eight, nine and twenty-four proofs per call; twenty-five per call
+    keep the whole-graph interpreter; a partial proof through the segments equals the pyref fixture; an input >= r is still an
+    error; with a
     corrupted hint (test hook) the batch is run again over the whole graph and the caller sees the golden bytes; with
     RLNAMD_HINTS=0 nothing is hinted and the bytes are the same; a member proving again at the same root finds the chain
     part of its hints remembered (hint_stats()["chains_remembered"]) and gets the same bytes."""
@@ -996,13 +997,17 @@ def test_up_to_eight_proofs_per_call_interpret_the_graph_as_segments_behind_hint
         assert p.hint_stats()["chains_remembered"] == seen + 4, p.hint_stats()
         run(p, [0, 1, 2, 3, 4, 5, 0, 1])                   # eight per call: still segments (a host thread per proof hashes its hints)
         assert p.hint_stats()["hinted_batches"] == len(cases) + 3
-        run(p, [0, 1, 2, 3, 4, 5, 0, 1, 2])                # nine per call: the whole graph
-        assert p.hint_stats()["hinted_batches"] == len(cases) + 3
+        run(p, [0, 1, 2, 3, 4, 5, 0, 1, 2])                # nine per call: segments as well since the chains are shared out
+        assert p.hint_stats()["hinted_batches"] == len(cases) + 4      # over eight host threads (RLNAMD_HINTS = 24)
+        run(p, [i % len(cases) for i in range(24)])
+        assert p.hint_stats()["hinted_batches"] == len(cases) + 5
+        run(p, [i % len(cases) for i in range(25)])        # twenty-five per call: the whole graph
+        assert p.hint_stats()["hinted_batches"] == len(cases) + 5
         for c in cases:                                    # a partial proof through the segments
             if c["name"] in fx:
                 t, n = p.submit(p.pack_inputs([dict(_w(c), message_id=0, x=0, external_nullifier=0)]), bytes(64), 1)
                 assert p.collect_partial(t, 1)[0].hex() == fx[c["name"]]
-        assert p.hint_stats()["hinted_batches"] == len(cases) + 3 + len(fx) and p.hint_stats()["fallbacks"] == 0
+        assert p.hint_stats()["hinted_batches"] == len(cases) + 5 + len(fx) and p.hint_stats()["fallbacks"] == 0
         bad = dict(_w(cases[0]), x=R)                      # x = r: not canonical (graph.rs:42-45)
         inp = bytearray(p.pack_inputs([dict(bad, x=0)]))
         off = p.slots["x"][0]

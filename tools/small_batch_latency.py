@@ -14,10 +14,12 @@ from zerokit_amd.batch import BatchProver  # noqa: E402
 
 p = BatchProver(max_batch=64)
 out = {"hints": os.environ.get("RLNAMD_HINTS", "default")}
-for n in (1, 2, 3, 4, 5, 6, 8):
+for n in (1, 2, 3, 4, 5, 6, 8, 12, 16, 24, 32, 48, 64):
     inp, rsb = workload.config2_packed(p.slots, p.inputs_size, 100, n)
     ts = []
     for i in range(11):
+        if os.environ.get("COLD"):   # other members on every call: their chains of hints are hashed, not remembered
+            inp, rsb = workload.config2_packed(p.slots, p.inputs_size, 1000 + 64 * i + 1000 * n, n)
         t0 = time.perf_counter()
         t, _ = p.submit(inp, rsb)
         p.collect_raw(t, n)

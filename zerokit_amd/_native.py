@@ -157,6 +157,7 @@ SIGNATURES = {
     "rlnamd_msm_combine": (C.c_int, [P, C.c_char_p, C.c_size_t, C.c_char_p]),
     "rlnamd_ffi_prover_info": (C.c_int, [P, C.POINTER(ProverInfo)]),
     "rlnamd_ffi_memo_stats": (C.c_int, [P, C.POINTER(C.c_uint64)]),
+    "rlnamd_ffi_gather_stats": (C.c_int, [P, C.POINTER(C.c_uint64)]),
     "rlnamd_prover_slots": (C.c_int, [P]),
     "rlnamd_prover_submit": (C.c_int, [P, C.c_size_t, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p,
                                       C.POINTER(C.c_uint64)]),

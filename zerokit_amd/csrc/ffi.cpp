@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <fstream>
 #include <memory>
+#include <condition_variable>
 #include <deque>
 #include <mutex>
 #include <random>
@@ -282,6 +283,27 @@ struct FFI_RLN {
   // What it costs is a policy decision, hence opt-in: the member's witness values stay on the device, and the key
   // (secret included) in host memory, until the entry is evicted (LRU), the tree moves on, or the object is freed.
   size_t auto_partial = 0;
+  // generate_rln_proof takes &self and may be called from several threads (public.rs:624); the prover has one set of
+  // workspaces per batch in flight, so single-proof calls used to take turns: T threads got the rate of one (1.2 k
+  // proofs/s at 0.8 ms per call).  Now the calls that arrive while a proof is on the device are gathered: the first
+  // caller that finds no batch running leads -- it takes everything queued (its own request included), proves it as ONE
+  // batch, hands every request its proof or its own error text, and steps down; a caller whose request went out with
+  // somebody else's batch just wakes up with its result.  A lone caller leads a batch of one: the path it always took.
+  struct Gather {
+    struct Req {
+      FFI_RLNWitnessInput* w = nullptr;
+      CFr rs[2];
+      bool has_rs = false, done = false;
+      FFI_RLNProof* out = nullptr;
+      std::string err;
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Req*> q;
+    bool leader = false;
+    size_t most = 0;                        // 0: off
+    uint64_t batches = 0, calls = 0, largest = 0;
+  } gather;
   struct Memo {
     std::vector<uint8_t> key;   // identity secret | limit | path elements | path index
     uint8_t coords[320];
@@ -341,6 +363,9 @@ struct FFI_RLN {
   void make_prover(const uint8_t* zkey, size_t zkey_len, const uint8_t* graph, size_t graph_len, const TreeConfig& tcfg) {
     const ProverConfig cfg = tcfg.prover_config();
     auto_partial = tcfg.auto_partial > 0 ? (size_t)tcfg.auto_partial : 0;
+    gather_wanted = tcfg.gather_calls;
+    if (const char* e = getenv("RLNAMD_GATHER_CALLS"))
+      if (*e) gather_wanted = atol(e);
     if (hipGetDevice(&home_device) != hipSuccess) home_device = 0;
     if (tcfg.has_devices) {
       if (tcfg.devices.empty()) throw Error("Configuration error: devices: empty list");
@@ -382,7 +407,11 @@ struct FFI_RLN {
       }
       prover.reset(new Prover(zkey, zkey_len, graph, graph_len, use));
     }
+    // (the member memo works on batches of one: an object with "auto_partial" keeps its calls apart)
+    const size_t cap = prover->capacity();
+    gather.most = auto_partial ? 0 : gather_wanted < 0 ? cap : gather_wanted <= 1 ? 0 : std::min((size_t)gather_wanted, cap);
   }
+  long gather_wanted = -1;
   TreeAny tree;   // dense in HBM up to depth 30, sparse (host-indexed, device-hashed) for 31 .. 63
   bool stateless = false;  // V3 only (RLNV3<Stateless, _>): no tree, tree calls return an error
   size_t next_index = 0;
@@ -865,6 +894,90 @@ void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CF
   for (size_t i = 0; i < n; i++) out[i] = made[i];
 }
 
+// the gathered calls of FFI_RLN::Gather as one batch; never throws: every request leaves with a proof or its error text
+void run_gathered(FFI_RLN& rln, const std::vector<FFI_RLN::Gather::Req*>& batch) {
+  const size_t n = batch.size();
+  std::vector<FFI_RLNWitnessInput*> ws(n);
+  std::vector<CFr> rs(2 * n);
+  struct WipeRs {
+    std::vector<CFr>& v;
+    ~WipeRs() { secure_zero(v.data(), v.size() * sizeof(CFr)); }
+  } wipe_rs{rs};
+  for (size_t i = 0; i < n; i++) {
+    ws[i] = batch[i]->w;
+    rs[2 * i] = batch[i]->has_rs ? batch[i]->rs[0] : random_fr();      // proof.rs:743-745
+    rs[2 * i + 1] = batch[i]->has_rs ? batch[i]->rs[1] : random_fr();
+  }
+  auto alone = [&](size_t i) {
+    try {
+      FFI_RLNProof* o = nullptr;
+      prove_many(rln, &ws[i], 1, &rs[2 * i], &o);
+      batch[i]->out = o;
+    } catch (const std::exception& e) {
+      batch[i]->err = e.what();
+      if (batch[i]->err.empty()) batch[i]->err = "Error producing proof";
+    }
+  };
+  if (n == 1) return alone(0);
+  try {
+    std::vector<FFI_RLNProof*> outs(n, nullptr);
+    prove_many(rln, ws.data(), n, rs.data(), outs.data());
+    for (size_t i = 0; i < n; i++) batch[i]->out = outs[i];
+  } catch (const std::exception&) {
+    // somebody's witness does not evaluate (or does not fit the circuit): the reference would fail that call only, so
+    // every request is proved on its own and keeps its own error
+    for (size_t i = 0; i < n; i++) alone(i);
+  }
+}
+
+// generate_rln_proof for ONE witness from any thread (FFI_RLN::Gather); rs: (r, s) or null (sampled)
+FFI_RLNProof* prove_one(FFI_RLN& rln, FFI_RLNWitnessInput* w, const CFr* rs) {
+  FFI_RLN::Gather& G = rln.gather;
+  if (G.most == 0) {
+    FFI_RLNProof* out = nullptr;
+    prove_many(rln, &w, 1, rs, &out);
+    return out;
+  }
+  FFI_RLN::Gather::Req me;
+  me.w = w;
+  if (rs) {
+    me.rs[0] = rs[0];
+    me.rs[1] = rs[1];
+    me.has_rs = true;
+  }
+  struct WipeReq {
+    FFI_RLN::Gather::Req& r;
+    ~WipeReq() { secure_zero(r.rs, sizeof r.rs); }
+  } wipe_me{me};
+  {
+    std::unique_lock<std::mutex> lk(G.mu);
+    G.q.push_back(&me);
+    while (!me.done) {
+      if (G.leader) {
+        G.cv.wait(lk);
+        continue;
+      }
+      G.leader = true;   // nobody is proving: lead, with everything that is queued now
+      std::vector<FFI_RLN::Gather::Req*> batch;
+      while (!G.q.empty() && batch.size() < G.most) {
+        batch.push_back(G.q.front());
+        G.q.pop_front();
+      }
+      lk.unlock();
+      run_gathered(rln, batch);
+      lk.lock();
+      for (FFI_RLN::Gather::Req* r : batch) r->done = true;   // (not touched again: its owner may return now)
+      G.batches++;
+      G.calls += batch.size();
+      G.largest = std::max<uint64_t>(G.largest, batch.size());
+      G.leader = false;
+      G.cv.notify_all();
+    }
+  }
+  if (!me.err.empty()) throw Error(me.err);
+  return me.out;
+}
+
 // generate_rln_proof_with_witness (public.rs:643-658): the Groth16 proof is made from the supplied witness;
 // the proof values come from the witness input (single: the values kernel over the inputs; multi: the public
 // signals, identical for any witness that satisfies the circuit).
@@ -1101,6 +1214,18 @@ int rlnamd_ffi_memo_stats(const void* ffi_rln, uint64_t out[4]) {
   out[3] = r.pending_ticket ? 1 : 0;
   return RLNAMD_OK;
 }
+// EXT (include/rln_amd.h): the gathering of concurrent single-proof calls: [0] batches led, [1] calls that went out in
+// them, [2] the largest batch, [3] the most calls one batch may take (0: off)
+int rlnamd_ffi_gather_stats(const void* ffi_rln, uint64_t out[4]) {
+  if (!ffi_rln || !out) return RLNAMD_ERR;
+  FFI_RLN& r = *(FFI_RLN*)ffi_rln;
+  std::lock_guard<std::mutex> guard(r.gather.mu);
+  out[0] = r.gather.batches;
+  out[1] = r.gather.calls;
+  out[2] = r.gather.largest;
+  out[3] = r.gather.most;
+  return RLNAMD_OK;
+}
 size_t ffi_rln_get_tree_depth(FFI_RLN_t* const* rln) { return ((FFI_RLN*)*rln)->tree.depth; }
 size_t ffi_rln_get_max_out(FFI_RLN_t* const* rln) { return ((FFI_RLN*)*rln)->prover->graph().max_out; }
 
@@ -1108,21 +1233,15 @@ size_t ffi_rln_get_max_out(FFI_RLN_t* const* rln) { return ((FFI_RLN*)*rln)->pro
 CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_generate_rln_proof(FFI_RLN_t* const* rln,
                                                             FFI_RLNWitnessInput_t* const* witness) {
   return guard_ptr<CResult_FFI_RLNProof_ptr_Vec_uint8_t>([&]() -> FFI_RLNProof_t* {
-    FFI_RLNProof* out = nullptr;
-    FFI_RLNWitnessInput* w = (FFI_RLNWitnessInput*)*witness;
-    prove_many(*(FFI_RLN*)*rln, &w, 1, nullptr, &out);
-    return (FFI_RLNProof_t*)out;
+    return (FFI_RLNProof_t*)prove_one(*(FFI_RLN*)*rln, (FFI_RLNWitnessInput*)*witness, nullptr);
   });
 }
 CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_generate_rln_proof_with_rs(FFI_RLN_t* const* rln,
                                                                     FFI_RLNWitnessInput_t* const* witness,
                                                                     const CFr_t* r, const CFr_t* s) {
   return guard_ptr<CResult_FFI_RLNProof_ptr_Vec_uint8_t>([&]() -> FFI_RLNProof_t* {
-    FFI_RLNProof* out = nullptr;
-    FFI_RLNWitnessInput* w = (FFI_RLNWitnessInput*)*witness;
     CFr rs[2] = {R(r), R(s)};
-    prove_many(*(FFI_RLN*)*rln, &w, 1, rs, &out);
-    return (FFI_RLNProof_t*)out;
+    return (FFI_RLNProof_t*)prove_one(*(FFI_RLN*)*rln, (FFI_RLNWitnessInput*)*witness, rs);
   });
 }
 CBoolResult_t ffi_generate_rln_proofs_batch(FFI_RLN_t* const* rln, FFI_RLNWitnessInput_t* const* witnesses, size_t n,

@@ -70,10 +70,11 @@ struct ProverTuning {
   bool early_fin = true;               // RLNAMD_EARLY_FIN: small batches finish A, B1 before the h rows are walked
   bool fused_smul = true;              // RLNAMD_FUSED_SMUL: a lone small proof takes s A, r B1 as rows of the C segment
   bool values_from_witness = true;     // RLNAMD_VALUES_WITNESS: small batches read the proof values off the witness
-  uint32_t hint_max = 8;               // RLNAMD_HINTS: largest lone batch interpreted as independent segments behind host-computed hints
+  uint32_t hint_max = 24;              // RLNAMD_HINTS: largest lone batch interpreted as independent segments behind host-computed hints (cold chains on 8 host threads: 12 / 16 / 24 proofs 3.2 / 3.7 / 4.3 -> 2.5 / 3.0 / 3.9 ms, even at 32)
                                        // (the values between the circuit's chained hashes; 0: never).  A proof's hints are ~0.3 ms of
                                        // hashing on a host core (the proofs of a batch on a thread each) against ~1.3 ms of interpreter
   uint32_t hint_chains = 16;           // RLNAMD_HINT_CHAINS: members whose public chain of hints (rate commitment, the hash after every level) is remembered on the host; 0: none
+  uint32_t hint_threads = 8;           // RLNAMD_HINT_THREADS: host threads (the caller's included) that hash the hint chains of a batch's proofs
   int hint_fault = 0;                  // RLNAMD_HINT_FAULT (test hook): j > 0 corrupts hint j - 1 of the first proof of every hinted batch
   bool d2h_kernel = true;              // RLNAMD_D2H_KERNEL: big batches copy their results home by a single-wave kernel (0: hipMemcpyAsync)
   // ---- diagnostics

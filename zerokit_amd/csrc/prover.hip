@@ -38,7 +38,7 @@ const char* const kProverStageNames[PROVER_STAGES] = {"witness", "matvec", "ntt"
 // Everything one in-flight batch owns.  Two slots let batch k+1 run its latency-bound front end (witness
 // interpreter, NTT) and batch k-1 its back end (reduction, finalize) on their own streams while batch k
 // keeps the chip busy with the MSM.
-constexpr uint32_t HINT_PROOFS = 8;   // most proofs of a batch that is interpreted as segments (ProverTuning::hint_max <= this)
+constexpr uint32_t HINT_PROOFS = 64;   // most proofs of a batch that is interpreted as segments (ProverTuning::hint_max <= this)
 struct Slot {
   DevBuf<uint32_t> err, coords, values;
   DevBuf<uint8_t> comp;
@@ -507,6 +507,7 @@ ProverTuning ProverTuning::from_env() {
   t.d2h_kernel = env_int("RLNAMD_D2H_KERNEL", 1) != 0;
   t.hint_max = (uint32_t)std::min<int>(std::max(0, env_int("RLNAMD_HINTS", (int)t.hint_max)), (int)HINT_PROOFS);
   t.hint_fault = env_int("RLNAMD_HINT_FAULT", 0);
+  t.hint_threads = (uint32_t)std::min(std::max(1, env_int("RLNAMD_HINT_THREADS", (int)t.hint_threads)), 64);
   t.hint_chains = (uint32_t)std::min(std::max(0, env_int("RLNAMD_HINT_CHAINS", (int)t.hint_chains)), 1024);
   return t;
 }
@@ -1941,9 +1942,15 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
       D.rln_hints(h_inputs + i * (size_t)D.NI * 32, hv);
       for (uint32_t j = 0; j < D.n_hints; j++) hv[j].to_canonical(S.h_hints + (i * D.n_hints + j) * 8);
     };
-    std::vector<std::thread> helpers;   // the chains of the batch's proofs are independent of each other: one thread each
-    for (size_t i = 1; i < n; i++) helpers.emplace_back(hash_chain, i);
-    hash_chain(0);
+    // the chains of the batch's proofs are independent of each other: the calling thread and up to hint_threads - 1
+    // helpers take them in turn
+    const size_t nth = std::min<size_t>(n, std::max<uint32_t>(1u, T.hint_threads));
+    std::vector<std::thread> helpers;
+    for (size_t k = 1; k < nth; k++)
+      helpers.emplace_back([&, k]() {
+        for (size_t i = k; i < n; i += nth) hash_chain(i);
+      });
+    for (size_t i = 0; i < n; i += nth) hash_chain(i);
     for (std::thread& th : helpers) th.join();
     if (T.hint_fault > 0 && (uint32_t)T.hint_fault <= D.n_hints) S.h_hints[(size_t)(T.hint_fault - 1) * 8] ^= 1u;   // test hook
     D.hinted_batches++;

@@ -62,6 +62,10 @@ struct TreeConfig {
   // "auto_partial": N -- ffi_generate_rln_proof remembers the partial proofs of up to N members and finishes instead of
   // proving from scratch when a member proves again at the same root (ffi.cpp: FFI_RLN::auto_partial).  0 (default): off
   long auto_partial = 0;
+  // "gather_calls": N -- single-proof calls that arrive from other threads while a proof is on the device go out together,
+  // as one batch of up to N, when it returns (ffi.cpp: prove_one).  -1 (default): on, up to the workspace's capacity;
+  // 0 or 1: every call is its own batch, one after the other
+  long gather_calls = -1;
   bool persistent() const { return !temporary && has_path; }
   ProverConfig prover_config() const {
     ProverConfig cfg;
@@ -186,6 +190,10 @@ inline TreeConfig parse_tree_config(const std::string& js) {
       if (key == "auto_partial") {
         if (num < 0 || num > 65536) throw Error("Configuration error: auto_partial: expected 0 .. 65536 members");
         c.auto_partial = num;
+      }
+      if (key == "gather_calls") {
+        if (num < 0 || num > 65536) throw Error("Configuration error: gather_calls: expected 0 .. 65536 calls");
+        c.gather_calls = num;
       }
       if (key == "partial_cache") {
         if (num < 0 || num > 1000000) throw Error("Configuration error: partial_cache: expected 0 .. 1000000 entries");
