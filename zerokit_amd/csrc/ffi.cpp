@@ -959,12 +959,29 @@ FFI_RLNProof* prove_one(FFI_RLN& rln, FFI_RLNWitnessInput* w, const CFr* rs) {
       }
       G.leader = true;   // nobody is proving: lead, with everything that is queued now
       std::vector<FFI_RLN::Gather::Req*> batch;
+      try {
+        batch.reserve(std::min(G.q.size(), G.most));
+      } catch (...) {      // (out of memory before anything was taken: step down, this call fails, the others go on)
+        G.leader = false;
+        for (auto it = G.q.begin(); it != G.q.end(); ++it)
+          if (*it == &me) {
+            G.q.erase(it);
+            break;
+          }
+        G.cv.notify_all();
+        throw;
+      }
       while (!G.q.empty() && batch.size() < G.most) {
-        batch.push_back(G.q.front());
+        batch.push_back(G.q.front());   // (reserved: cannot throw)
         G.q.pop_front();
       }
       lk.unlock();
-      run_gathered(rln, batch);
+      try {
+        run_gathered(rln, batch);
+      } catch (...) {      // run_gathered catches what proving throws; this is for its own allocations
+        for (FFI_RLN::Gather::Req* r : batch)
+          if (!r->out && r->err.empty()) r->err = "Error producing proof: out of memory";
+      }
       lk.lock();
       for (FFI_RLN::Gather::Req* r : batch) r->done = true;   // (not touched again: its owner may return now)
       G.batches++;
