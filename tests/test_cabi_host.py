@@ -465,9 +465,10 @@ def test_config_path_is_parsed_before_any_device_is_needed(tmp_path):
     assert "partial_cache: expected" in new('{"partial_cache": -1}')
     assert "auto_partial: expected" in new('{"auto_partial": 100000}')
     assert "gather_calls: expected" in new('{"gather_calls": -2}')
+    assert "gather_window_us: expected" in new('{"gather_window_us": 1000000}')
     if lib().rlnamd_device_count() == 0:
         for ok_cfg in ('{"window_bits": 7150114, "max_batch": 1024}', '{"profile": "throughput"}', '{"profile": "small", "max_batch": 128}',
-                       '{"devices": [0, 1, 2, 3], "temporary": true}', '{"devices": [0, 1], "failover": 2, "revive_after": 0}', '{"partial_cache": 1024}', '{"auto_partial": 16}', '{"gather_calls": 0}', '{"gather_calls": 32}',
+                       '{"devices": [0, 1, 2, 3], "temporary": true}', '{"devices": [0, 1], "failover": 2, "revive_after": 0}', '{"partial_cache": 1024}', '{"auto_partial": 16}', '{"gather_calls": 0}', '{"gather_calls": 32, "gather_window_us": 0}',
                        '{"cache_capacity": 1073741824, "flush_every_ms": 500, "mode": "HighThroughput", "use_compression": false}',
                        # unknown keys carry any JSON value (PmTreeConfig::from_str ignores them)
                        '{"foo": ["a]", {"b": [1, 2]}], "bar": {"x": {"y": "}"}}, "devices": [0]}', '{"devices": []}'):

@@ -66,6 +66,9 @@ struct TreeConfig {
   // as one batch of up to N, when it returns (ffi.cpp: prove_one).  -1 (default): on, up to the workspace's capacity;
   // 0 or 1: every call is its own batch, one after the other
   long gather_calls = -1;
+  // "gather_window_us": how long the leader of a gathered batch waits for callers it saw within the last millisecond
+  // (100 unless given; 0: it takes what is queued)
+  long gather_window_us = 100;
   bool persistent() const { return !temporary && has_path; }
   ProverConfig prover_config() const {
     ProverConfig cfg;
@@ -194,6 +197,10 @@ inline TreeConfig parse_tree_config(const std::string& js) {
       if (key == "gather_calls") {
         if (num < 0 || num > 65536) throw Error("Configuration error: gather_calls: expected 0 .. 65536 calls");
         c.gather_calls = num;
+      }
+      if (key == "gather_window_us") {
+        if (num < 0 || num > 100000) throw Error("Configuration error: gather_window_us: expected 0 .. 100000 microseconds");
+        c.gather_window_us = num;
       }
       if (key == "partial_cache") {
         if (num < 0 || num > 1000000) throw Error("Configuration error: partial_cache: expected 0 .. 1000000 entries");
