@@ -192,7 +192,7 @@ int rlnamd_prover_run_async_mode(rlnamd_prover* p, size_t n, int mode);
  * own value with the hint its consumers were given.  Every witness value is still computed on the device; a hint that does
  * not check (not expected: test hook RLNAMD_HINT_FAULT) makes collect run the batch again over the whole graph.
  * The chain part of a member's hints (rate commitment, the running hash after every level) depends on public values only:
- * the last sixteen are remembered under a fingerprint of (identity commitment, limit, path), so a member that proves
+ * the last 64 (RLNAMD_HINT_CHAINS) are remembered under a fingerprint of (identity commitment, limit, path), so a member that proves
  * again at the same root costs the host two hashes (identity commitment, a1) instead of depth + 2.
  * out: [0] segments, [1] hints per proof, [2] steps of the longest segment, [3] steps of the whole graph, [4] batches
  * interpreted as segments, [5] of those, batches run again, [6] proofs whose chain was remembered. */

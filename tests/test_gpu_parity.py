@@ -969,10 +969,12 @@ def test_a_few_proofs_per_call_interpret_the_graph_as_segments_behind_hints(monk
     error; with a
     corrupted hint (test hook) the batch is run again over the whole graph and the caller sees the golden bytes; with
     RLNAMD_HINTS=0 nothing is hinted and the bytes are the same; a member proving again at the same root finds the chain
-    part of its hints remembered (hint_stats()["chains_remembered"]) and gets the same bytes."""
+    part of its hints remembered (hint_stats()["chains_remembered"]) and gets the same bytes; 25 and 64 proofs per call take
+    the segments when the members' chains are remembered and the whole graph when they are not."""
     from zerokit_amd.batch import BatchProver
     cases = _cases()["cases"]
     fx = {c["name"]: c["partial320"] for c in json.load(open(os.path.join(ROOT, "tests", "golden", "rln_h20_partial.json")))["cases"]}
+    monkeypatch.setenv("RLNAMD_HINTS_WARM", "0")            # (first without the rule for batches above 24: see the end)
 
     def run(p, idx):
         ws = [_w(cases[i]) for i in idx]
@@ -1034,6 +1036,20 @@ def test_a_few_proofs_per_call_interpret_the_graph_as_segments_behind_hints(monk
     finally:
         p.close()
     monkeypatch.delenv("RLNAMD_HINT_CHAINS")
+    # above 24 proofs per call (up to 64) the segments are taken when the members' chains are remembered: a batch of
+    # members never seen keeps the whole graph, the same 25 after their chains were hashed once do not -- same bytes
+    monkeypatch.delenv("RLNAMD_HINTS_WARM")
+    p = BatchProver(max_batch=64, window_bits=8)
+    try:
+        run(p, [i % len(cases) for i in range(25)])
+        assert p.hint_stats()["hinted_batches"] == 0
+        run(p, list(range(len(cases))))
+        run(p, [i % len(cases) for i in range(25)])
+        run(p, [i % len(cases) for i in range(64)])
+        st = p.hint_stats()
+        assert st["hinted_batches"] == 3 and st["fallbacks"] == 0 and st["chains_remembered"] >= 25 + 64, st
+    finally:
+        p.close()
     monkeypatch.setenv("RLNAMD_HINTS", "0")
     p = BatchProver(max_batch=64, window_bits=8)
     try:

@@ -73,7 +73,8 @@ struct ProverTuning {
   uint32_t hint_max = 24;              // RLNAMD_HINTS: largest lone batch interpreted as independent segments behind host-computed hints (cold chains on 8 host threads: 12 / 16 / 24 proofs 3.2 / 3.7 / 4.3 -> 2.5 / 3.0 / 3.9 ms, even at 32)
                                        // (the values between the circuit's chained hashes; 0: never).  A proof's hints are ~0.3 ms of
                                        // hashing on a host core (the proofs of a batch on a thread each) against ~1.3 ms of interpreter
-  uint32_t hint_chains = 16;           // RLNAMD_HINT_CHAINS: members whose public chain of hints (rate commitment, the hash after every level) is remembered on the host; 0: none
+  uint32_t hint_chains = 64;           // RLNAMD_HINT_CHAINS: members whose public chain of hints (rate commitment, the hash after every level) is remembered on the host; 0: none
+  uint32_t hint_max_warm = 64;         // RLNAMD_HINTS_WARM: ... and up to this many when at most 2.5 chains per host thread have to be hashed (the others are remembered: hint_chains)
   uint32_t hint_threads = 8;           // RLNAMD_HINT_THREADS: host threads (the caller's included) that hash the hint chains of a batch's proofs
   int hint_fault = 0;                  // RLNAMD_HINT_FAULT (test hook): j > 0 corrupts hint j - 1 of the first proof of every hinted batch
   bool d2h_kernel = true;              // RLNAMD_D2H_KERNEL: big batches copy their results home by a single-wave kernel (0: hipMemcpyAsync)
@@ -183,7 +184,7 @@ class Prover {
   // the graph as segments behind hints (witness_sched.h: wl_segments): [0] segments, [1] hints per proof, [2] steps of the
   // longest segment, [3] steps of the whole graph's program, [4] batches interpreted that way, [5] of those, batches whose
   // hints did not check and were run again over the whole graph (0 unless the RLNAMD_HINT_FAULT test hook is set), [6] proofs
-  // whose chain of hints was found among the last sixteen (the same member at the same root: two host hashes instead of 22)
+  // whose chain of hints was found among the remembered ones (the same member at the same root: two host hashes instead of 22)
   static constexpr int HINT_STATS_FIELDS = 7;
   void hint_stats(uint64_t out[HINT_STATS_FIELDS]) const;
   static constexpr int PARTIAL_CACHE_FIELDS = 8;

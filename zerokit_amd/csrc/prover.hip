@@ -254,16 +254,21 @@ struct Prover::Impl {
   mutable std::mutex chain_mu;
   mutable std::vector<ChainEntry> chain_cache;
   mutable uint64_t chain_clock = 0, chain_hits = 0;
-  void rln_hints(const uint8_t* in_le, Fr* out) const {   // idc, rate commitment, the running hash after levels 1 .. depth - 1, a1
+  // the first step of a proof's hints by itself: identity commitment, the chain's fingerprint, and whether that chain is
+  // remembered -- what a batch above hint_max needs to know before it decides for the segments (enqueue)
+  struct HintProbe {
+    Fr idc;
+    uint64_t fp[2];
+    bool found;
+  };
+  void rln_hint_probe(const uint8_t* in_le, HintProbe* pr) const {
     auto rd = [&](uint32_t slot) {
       uint32_t c[8];
       memcpy(c, in_le + 32 * (size_t)slot, 32);
       return Fr::from_canonical(c);
     };
-    const PoseidonParams &P2 = poseidon_host_params(2), &P3 = poseidon_host_params(3), &P4 = poseidon_host_params(4);
-    const Fr secret = rd(slots.secret), limit = rd(slots.limit);
-    const Fr idc = poseidon_hash_host(P2, &secret);
-    out[0] = idc;
+    const Fr secret = rd(slots.secret);
+    pr->idc = poseidon_hash_host(poseidon_host_params(2), &secret);
     // fingerprint of the public values the chain depends on (two multiply-xorshift lanes over the 32-bit words)
     uint64_t fp[2] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full};
     auto mix = [&](const uint32_t* w, int n) {
@@ -281,10 +286,36 @@ struct Prover::Impl {
         mix(w, 8);
       }
     };
-    mix(idc.v, 8);
+    mix(pr->idc.v, 8);
     mix_slots(slots.limit, 1);
     mix_slots(slots.path, slots.depth);
     mix_slots(slots.path_idx, slots.depth);
+    pr->fp[0] = fp[0];
+    pr->fp[1] = fp[1];
+    pr->found = false;
+    if (tune.hint_chains) {
+      std::lock_guard<std::mutex> lk(chain_mu);
+      for (const ChainEntry& e : chain_cache)
+        if (e.fp[0] == fp[0] && e.fp[1] == fp[1] && e.chain.size() == slots.depth) pr->found = true;
+    }
+  }
+  // idc, rate commitment, the running hash after levels 1 .. depth - 1, a1 (probe: rln_hint_probe's result for these inputs, or null)
+  void rln_hints(const uint8_t* in_le, Fr* out, const HintProbe* probe = nullptr) const {
+    auto rd = [&](uint32_t slot) {
+      uint32_t c[8];
+      memcpy(c, in_le + 32 * (size_t)slot, 32);
+      return Fr::from_canonical(c);
+    };
+    const PoseidonParams &P3 = poseidon_host_params(3), &P4 = poseidon_host_params(4);
+    HintProbe mine;
+    if (!probe) {
+      rln_hint_probe(in_le, &mine);
+      probe = &mine;
+    }
+    const Fr secret = rd(slots.secret), limit = rd(slots.limit);
+    const Fr idc = probe->idc;
+    out[0] = idc;
+    const uint64_t fp[2] = {probe->fp[0], probe->fp[1]};
     bool found = false;
     const size_t CHAIN_ENTRIES = tune.hint_chains;
     if (CHAIN_ENTRIES) {
@@ -508,6 +539,7 @@ ProverTuning ProverTuning::from_env() {
   t.hint_max = (uint32_t)std::min<int>(std::max(0, env_int("RLNAMD_HINTS", (int)t.hint_max)), (int)HINT_PROOFS);
   t.hint_fault = env_int("RLNAMD_HINT_FAULT", 0);
   t.hint_threads = (uint32_t)std::min(std::max(1, env_int("RLNAMD_HINT_THREADS", (int)t.hint_threads)), 64);
+  t.hint_max_warm = (uint32_t)std::min<int>(std::max(0, env_int("RLNAMD_HINTS_WARM", (int)t.hint_max_warm)), (int)HINT_PROOFS);
   t.hint_chains = (uint32_t)std::min(std::max(0, env_int("RLNAMD_HINT_CHAINS", (int)t.hint_chains)), 1024);
   return t;
 }
@@ -1833,7 +1865,38 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     if (e == 0xFFFFFFFFu) cone = false; else cone_entries.push_back(e);
   }
   // A lone batch of one or two proofs: the graph as independent segments behind hints computed on this thread (Impl::rln_hints)
-  const bool hinted = D.segs.ok && h_inputs && wl_used && !cone && lone && n <= T.hint_max && !D.no_hints_now;
+  // (up to hint_max proofs whatever their chains cost; above it, up to HINT_PROOFS, when few enough of the proofs' chains
+  // have to be hashed -- the others are remembered, Impl::rln_hints -- that the host threads are done in ~0.5 ms)
+  bool hinted = D.segs.ok && h_inputs && wl_used && !cone && lone && n <= std::max(T.hint_max, T.hint_max_warm) && !D.no_hints_now;
+  std::vector<Impl::HintProbe> probes;
+  const size_t hint_nth = std::min<size_t>(std::max<size_t>(n, 1), std::max<uint32_t>(1u, T.hint_threads));
+  auto on_hint_threads = [&](auto&& per_proof) {   // proofs i = k, k + nth, ... on thread k; the caller is thread 0
+    std::vector<std::thread> helpers;
+    for (size_t k = 1; k < hint_nth; k++)
+      helpers.emplace_back([&, k]() {
+        for (size_t i = k; i < n; i += hint_nth) per_proof(i);
+      });
+    for (size_t i = 0; i < n; i += hint_nth) per_proof(i);
+    for (std::thread& th : helpers) th.join();
+  };
+  if (hinted && n > T.hint_max) {
+    probes.resize(n);
+    // the first two proofs on this thread (15 us): a batch of members never seen ends here, before a helper thread is started
+    for (size_t i = 0; i < 2 && hinted; i++) {
+      D.rln_hint_probe(h_inputs + i * (size_t)D.NI * 32, &probes[i]);
+      hinted = probes[i].found;
+    }
+  }
+  if (hinted && n > T.hint_max) {
+    on_hint_threads([&](size_t i) {
+      if (i >= 2) D.rln_hint_probe(h_inputs + i * (size_t)D.NI * 32, &probes[i]);
+    });
+    size_t to_hash = 0;
+    for (const Impl::HintProbe& pr : probes) to_hash += pr.found ? 0 : 1;
+    // a chain is ~0.2 ms on a host core against ~1.3 ms the segments save: at most 2.5 chains per thread
+    hinted = 2 * to_hash <= 5 * hint_nth;
+  }
+  if (!hinted) probes.clear();
   // Small batches (latency, not throughput): the whole front end stays on ONE stream (every cross-stream event hop costs
   // 0.1 - 0.15 ms), the digits of the witness scalars are recoded right behind the interpreter, and both walks start on
   // everything that does not depend on the quotient h while mat-vec / NTTs still run; only the h rows of the G1 walk
@@ -1937,21 +2000,13 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   if (cone) memcpy(S.h_cone, cone_entries.data(), n * sizeof(uint32_t));   // (the slot's previous batch has finished: see `streamed` above)
   S.hinted = hinted;
   if (hinted) {
-    auto hash_chain = [&](size_t i) {   // a proof's hints: one dependent chain of depth + 2 hashes
+    // a proof's hints: one dependent chain of depth + 2 hashes; the chains of the batch's proofs are independent of each
+    // other: the calling thread and up to hint_threads - 1 helpers take them in turn
+    on_hint_threads([&](size_t i) {
       Fr hv[64];
-      D.rln_hints(h_inputs + i * (size_t)D.NI * 32, hv);
+      D.rln_hints(h_inputs + i * (size_t)D.NI * 32, hv, probes.empty() ? nullptr : &probes[i]);
       for (uint32_t j = 0; j < D.n_hints; j++) hv[j].to_canonical(S.h_hints + (i * D.n_hints + j) * 8);
-    };
-    // the chains of the batch's proofs are independent of each other: the calling thread and up to hint_threads - 1
-    // helpers take them in turn
-    const size_t nth = std::min<size_t>(n, std::max<uint32_t>(1u, T.hint_threads));
-    std::vector<std::thread> helpers;
-    for (size_t k = 1; k < nth; k++)
-      helpers.emplace_back([&, k]() {
-        for (size_t i = k; i < n; i += nth) hash_chain(i);
-      });
-    for (size_t i = 0; i < n; i += nth) hash_chain(i);
-    for (std::thread& th : helpers) th.join();
+    });
     if (T.hint_fault > 0 && (uint32_t)T.hint_fault <= D.n_hints) S.h_hints[(size_t)(T.hint_fault - 1) * 8] ^= 1u;   // test hook
     D.hinted_batches++;
   }
