@@ -1,0 +1,107 @@
+/* T threads of a plain C program share ONE RLN object and call ffi_generate_rln_proof in a loop (generate_rln_proof takes
+ * &self, rln/src/public.rs:624): calls per second and milliseconds per call for T = 1 .. 64, every proof verified at the
+ * end of a run's first and last call.  The library gathers the calls that arrive while a proof is on the device into one
+ * batch (include/rln_amd.h: rlnamd_ffi_gather_stats); RLNAMD_GATHER_CALLS=0 in the environment gives the behaviour
+ * before (one call at a time).  One JSON line.
+ *   gcc -O2 -std=c11 -I include tools/ffi_threads.c -L zerokit_amd/lib -lrln -lpthread -Wl,-rpath,$PWD/zerokit_amd/lib -o tools/ffi_threads */
+#define _POSIX_C_SOURCE 200809L
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "rln.h"
+
+extern int rlnamd_ffi_gather_stats(const void* ffi_rln, uint64_t out[5]);
+
+static FFI_RLN_t* rln;
+static const CFr_t *id_secret, *limit_c;
+static CFr_t* ext;
+static FFI_MerkleProof_t* mp;
+static int calls_per_thread;
+static int failures;
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+
+static void* work(void* arg) {
+  const long tid = (long)arg;
+  for (int j = 0; j < calls_per_thread; j++) {
+    CFr_t* x = ffi_uint_to_cfr((uint32_t)(1 + tid * 100000 + j));
+    CFr_t* msg = ffi_uint_to_cfr((uint32_t)((tid + j) % 100));
+    CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t w =
+        ffi_rln_witness_input_new_single(id_secret, limit_c, msg, &mp->path_elements, &mp->path_index, x, ext);
+    if (!w.ok) {
+      __sync_fetch_and_add(&failures, 1);
+      return NULL;
+    }
+    CResult_FFI_RLNProof_ptr_Vec_uint8_t p = ffi_generate_rln_proof(&rln, &w.ok);
+    if (!p.ok) {
+      __sync_fetch_and_add(&failures, 1);
+      ffi_c_string_free(p.err);
+    } else {
+      if (j == 0 || j == calls_per_thread - 1) {
+        CBoolResult_t v = ffi_verify_rln_proof(&rln, &p.ok, x);
+        if (!v.ok) __sync_fetch_and_add(&failures, 1);
+        if (v.err.ptr) ffi_c_string_free(v.err);
+      }
+      ffi_rln_proof_free(p.ok);
+    }
+    ffi_rln_witness_input_free(w.ok);
+    ffi_cfr_free(x);
+    ffi_cfr_free(msg);
+  }
+  return NULL;
+}
+
+int main(void) {
+  CResult_FFI_RLN_ptr_Vec_uint8_t r = ffi_rln_new(20, "");
+  if (!r.ok) {
+    fprintf(stderr, "ffi_rln_new: %s\n", r.err.ptr);
+    return 2;
+  }
+  rln = r.ok;
+  Vec_CFr_t keys = ffi_key_gen();
+  id_secret = ffi_vec_cfr_get(&keys, 0);
+  CFr_t* limit = ffi_uint_to_cfr(100);
+  limit_c = limit;
+  CFr_t* rate = ffi_poseidon_hash_pair(ffi_vec_cfr_get(&keys, 1), limit);
+  CBoolResult_t ok = ffi_set_leaf(&rln, 7, rate);
+  if (!ok.ok) return 3;
+  CResult_FFI_MerkleProof_ptr_Vec_uint8_t m = ffi_get_merkle_proof(&rln, 7);
+  if (!m.ok) return 4;
+  mp = m.ok;
+  ext = ffi_uint_to_cfr(424242);
+  calls_per_thread = 4;
+  work((void*)99);   /* warm */
+  const int ts[] = {1, 2, 4, 8, 16, 32, 64};
+  printf("{\"gather_calls_env\": \"%s\", \"threads\": {", getenv("RLNAMD_GATHER_CALLS") ? getenv("RLNAMD_GATHER_CALLS") : "");
+  for (unsigned k = 0; k < sizeof ts / sizeof ts[0]; k++) {
+    const int T = ts[k];
+    calls_per_thread = T <= 8 ? 300 : 100;
+    pthread_t th[64];
+    const double t0 = now_s();
+    for (long t = 0; t < T; t++) pthread_create(&th[t], NULL, work, (void*)t);
+    for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
+    const double dt = now_s() - t0;
+    printf("%s\"%d\": {\"calls_per_s\": %.1f, \"ms_per_call\": %.3f}", k ? ", " : "", T, T * calls_per_thread / dt,
+           dt / calls_per_thread * 1e3);
+  }
+  uint64_t st[5] = {0, 0, 0, 0, 0};
+  rlnamd_ffi_gather_stats(rln, st);
+  printf("}, \"gather_stats\": {\"batches\": %llu, \"calls\": %llu, \"largest\": %llu, \"cap\": %llu, \"waited\": %llu}, "
+         "\"failures\": %d}\n",
+         (unsigned long long)st[0], (unsigned long long)st[1], (unsigned long long)st[2], (unsigned long long)st[3],
+         (unsigned long long)st[4], failures);
+  ffi_merkle_proof_free(mp);
+  ffi_vec_cfr_free(keys);
+  ffi_cfr_free(limit);
+  ffi_cfr_free(rate);
+  ffi_cfr_free(ext);
+  ffi_rln_free(rln);
+  return failures ? 1 : 0;
+}

@@ -993,7 +993,7 @@ FFI_RLNProof* prove_one(FFI_RLN& rln, FFI_RLNWitnessInput* w, const CFr* rs) {
           }
         }
         // (only a batch of ONE is worth waiting for: with two or more queued the batches fill by themselves, and waiting
-        // for the rest was measured to cost 8 threads 12 %)
+        // for the rest was measured to cost 8 Python threads 12 % and to give C callers nothing)
         if (G.q.size() == 1 && expect >= 2 && G.most >= 2) {
           G.waited++;
           const auto until = t0 + std::chrono::microseconds(G.window_us);
