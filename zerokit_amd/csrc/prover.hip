@@ -1872,12 +1872,23 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   const size_t hint_nth = std::min<size_t>(std::max<size_t>(n, 1), std::max<uint32_t>(1u, T.hint_threads));
   auto on_hint_threads = [&](auto&& per_proof) {   // proofs i = k, k + nth, ... on thread k; the caller is thread 0
     std::vector<std::thread> helpers;
-    for (size_t k = 1; k < hint_nth; k++)
-      helpers.emplace_back([&, k]() {
+    std::atomic<bool> failed{false};     // (an exception must not leave a helper thread: it would end the process)
+    auto strand = [&](size_t k) {
+      try {
         for (size_t i = k; i < n; i += hint_nth) per_proof(i);
-      });
-    for (size_t i = 0; i < n; i += hint_nth) per_proof(i);
+      } catch (...) {
+        failed = true;
+      }
+    };
+    try {
+      for (size_t k = 1; k < hint_nth; k++) helpers.emplace_back(strand, k);
+    } catch (...) {   // no more threads to be had: the caller's thread takes what the missing ones would have
+      const size_t started = helpers.size() + 1;
+      for (size_t k = started; k < hint_nth; k++) strand(k);
+    }
+    strand(0);
     for (std::thread& th : helpers) th.join();
+    if (failed) throw Error("out of memory while hashing the hints of a batch");
   };
   if (hinted && n > T.hint_max) {
     probes.resize(n);
