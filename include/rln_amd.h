@@ -105,11 +105,12 @@ int rlnamd_ffi_memo_stats(const void* ffi_rln, uint64_t out[4]);
  * together, as one batch, when it returns -- each call gets its own proof or its own error text, a lone caller is a
  * batch of one as before.  "gather_calls": N in the config_path JSON (or RLNAMD_GATHER_CALLS) caps a batch (default:
  * the workspace's capacity; 0 or 1: off); an object with "auto_partial" keeps its calls apart.  Threads that call in a
- * loop arrive just behind each other's results: the leader gives the callers it saw within the last millisecond
- * "gather_window_us" (100; RLNAMD_GATHER_WINDOW_US; 0: none) to arrive before it takes the batch; a lone caller never waits.
+ * loop arrive just behind their results: the leader gives the callers it saw within the last 20 ms "gather_window_us"
+ * (200; RLNAMD_GATHER_WINDOW_US; 0: none) to arrive before it takes the batch, so that T threads go out as batches of T
+ * instead of two halves taking turns; a lone caller never waits, callers slower than the window make it stop waiting.
  * out: [0] batches led, [1] calls that went out in them, [2] the largest batch, [3] the cap (0: off), [4] batches whose
- * leader waited for a recent caller */
-int rlnamd_ffi_gather_stats(const void* ffi_rln, uint64_t out[5]);
+ * leader waited for a recent caller, [5] nanoseconds the leaders spent proving their batches */
+int rlnamd_ffi_gather_stats(const void* ffi_rln, uint64_t out[6]);
 /* offset/len of a named input signal in the inputs buffer (iden3calc.rs:122-146); returns RLNAMD_ERR if absent */
 int rlnamd_prover_input_slot(rlnamd_prover* p, const char* name, uint32_t* offset, uint32_t* len);
 /* inputs: n * inputs_size * 32 bytes (slot 0 must hold 1); rs: n * 64 bytes (r then s). */

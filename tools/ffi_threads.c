@@ -13,7 +13,7 @@
 
 #include "rln.h"
 
-extern int rlnamd_ffi_gather_stats(const void* ffi_rln, uint64_t out[5]);
+extern int rlnamd_ffi_gather_stats(const void* ffi_rln, uint64_t out[6]);
 
 static FFI_RLN_t* rln;
 static const CFr_t *id_secret, *limit_c;
@@ -84,14 +84,21 @@ int main(void) {
     const int T = ts[k];
     calls_per_thread = T <= 8 ? 300 : 100;
     pthread_t th[64];
+    uint64_t g0[6] = {0, 0, 0, 0, 0, 0};
+    rlnamd_ffi_gather_stats(rln, g0);
     const double t0 = now_s();
     for (long t = 0; t < T; t++) pthread_create(&th[t], NULL, work, (void*)t);
     for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
     const double dt = now_s() - t0;
-    printf("%s\"%d\": {\"calls_per_s\": %.1f, \"ms_per_call\": %.3f}", k ? ", " : "", T, T * calls_per_thread / dt,
-           dt / calls_per_thread * 1e3);
+    uint64_t g1[6] = {0, 0, 0, 0, 0, 0};
+    rlnamd_ffi_gather_stats(rln, g1);
+    const double nb = (double)(g1[0] - g0[0]);
+    printf("%s\"%d\": {\"calls_per_s\": %.1f, \"ms_per_call\": %.3f, \"calls_per_batch\": %.2f, \"ms_proving_per_batch\": %.3f, "
+           "\"ms_between_batches\": %.3f}",
+           k ? ", " : "", T, T * calls_per_thread / dt, dt / calls_per_thread * 1e3, nb ? (g1[1] - g0[1]) / nb : 0.0,
+           nb ? (g1[5] - g0[5]) * 1e-6 / nb : 0.0, nb ? (dt * 1e3 - (g1[5] - g0[5]) * 1e-6) / nb : 0.0);
   }
-  uint64_t st[5] = {0, 0, 0, 0, 0};
+  uint64_t st[6] = {0, 0, 0, 0, 0, 0};
   rlnamd_ffi_gather_stats(rln, st);
   printf("}, \"gather_stats\": {\"batches\": %llu, \"calls\": %llu, \"largest\": %llu, \"cap\": %llu, \"waited\": %llu}, "
          "\"failures\": %d}\n",

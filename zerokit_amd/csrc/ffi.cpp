@@ -305,13 +305,14 @@ struct FFI_RLN {
     bool leader = false;
     size_t most = 0;                        // 0: off
     uint64_t batches = 0, calls = 0, largest = 0;
-    // A few threads that call in a loop arrive one after the other, each just behind the other's result, and would lead
-    // batches of one in turn.  The leader therefore knows who else called within the last millisecond and gives those
-    // callers window_us to arrive (spinning, off the lock) before it takes a batch of one: two threads go out as
-    // batches of two.  A caller that is alone never waits.
+    // Threads that call in a loop arrive just behind their results, after the next leader has taken its batch.  The
+    // leader therefore knows who else called within the last 20 ms and gives those callers window_us to arrive
+    // (spinning, off the lock) before it takes the batch.  A caller that is alone never waits.
     std::vector<std::pair<std::thread::id, std::chrono::steady_clock::time_point>> recent;
-    long window_us = 100;                   // RLNAMD_GATHER_WINDOW_US / "gather_window_us"; 0: take what is there
+    long window_us = 200;                   // RLNAMD_GATHER_WINDOW_US / "gather_window_us"; 0: take what is there
+    uint64_t misses = 0, no_wait_until = 0; // the wait's back-off (see prove_one)
     uint64_t waited = 0;                    // batches whose leader waited for a recent caller
+    uint64_t busy_ns = 0;                   // time the leaders spent proving their batches
   } gather;
   struct Memo {
     std::vector<uint8_t> key;   // identity secret | limit | path elements | path index
@@ -980,11 +981,17 @@ FFI_RLNProof* prove_one(FFI_RLN& rln, FFI_RLNWitnessInput* w, const CFr* rs) {
         continue;
       }
       G.leader = true;   // nobody is proving: lead, with everything that is queued now
-      if (G.window_us > 0) {
+      if (G.window_us > 0 && G.batches >= G.no_wait_until) {
+        // Threads that call in a loop come back just behind their results.  Without a wait they split into two halves
+        // that take turns (one half on the device while the other gathers: T threads, batches of T / 2, two batch times
+        // per call); with it the leader gives everybody it saw within the last 20 ms window_us to arrive and the T calls
+        // go out together -- one (longer) batch time per call.  Callers that stopped cost a few leaders the window until
+        // they age out; callers that are slower than the window (an interpreter between the calls) make the leader
+        // give up waiting for the next 64 batches after three misses in a row.
         const auto t0 = std::chrono::steady_clock::now();
         size_t expect = 0;
         for (size_t i = 0; i < G.recent.size();) {
-          if (t0 - G.recent[i].second > std::chrono::milliseconds(1)) {
+          if (t0 - G.recent[i].second > std::chrono::milliseconds(20)) {
             G.recent[i] = G.recent.back();
             G.recent.pop_back();
           } else {
@@ -992,15 +999,20 @@ FFI_RLNProof* prove_one(FFI_RLN& rln, FFI_RLNWitnessInput* w, const CFr* rs) {
             i++;
           }
         }
-        // (only a batch of ONE is worth waiting for: with two or more queued the batches fill by themselves, and waiting
-        // for the rest was measured to cost 8 Python threads 12 % and to give C callers nothing)
-        if (G.q.size() == 1 && expect >= 2 && G.most >= 2) {
+        expect = std::min(expect, G.most);
+        if (G.q.size() < expect) {
           G.waited++;
           const auto until = t0 + std::chrono::microseconds(G.window_us);
-          while (G.q.size() < 2 && std::chrono::steady_clock::now() < until) {
+          while (G.q.size() < expect && std::chrono::steady_clock::now() < until) {
             lk.unlock();
             std::this_thread::yield();
             lk.lock();
+          }
+          if (G.q.size() >= expect) {
+            G.misses = 0;
+          } else if (++G.misses >= 3) {
+            G.misses = 0;
+            G.no_wait_until = G.batches + 64;
           }
         }
       }
@@ -1022,6 +1034,7 @@ FFI_RLNProof* prove_one(FFI_RLN& rln, FFI_RLNWitnessInput* w, const CFr* rs) {
         G.q.pop_front();
       }
       lk.unlock();
+      const auto t_run = std::chrono::steady_clock::now();
       try {
         run_gathered(rln, batch);
       } catch (...) {      // run_gathered catches what proving throws; this is for its own allocations
@@ -1030,6 +1043,7 @@ FFI_RLNProof* prove_one(FFI_RLN& rln, FFI_RLNWitnessInput* w, const CFr* rs) {
       }
       lk.lock();
       for (FFI_RLN::Gather::Req* r : batch) r->done = true;   // (not touched again: its owner may return now)
+      G.busy_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_run).count();
       G.batches++;
       G.calls += batch.size();
       G.largest = std::max<uint64_t>(G.largest, batch.size());
@@ -1279,8 +1293,8 @@ int rlnamd_ffi_memo_stats(const void* ffi_rln, uint64_t out[4]) {
 }
 // EXT (include/rln_amd.h): the gathering of concurrent single-proof calls: [0] batches led, [1] calls that went out in
 // them, [2] the largest batch, [3] the most calls one batch may take (0: off), [4] batches whose leader waited for a
-// recent caller
-int rlnamd_ffi_gather_stats(const void* ffi_rln, uint64_t out[5]) {
+// recent caller, [5] nanoseconds the leaders spent proving their batches
+int rlnamd_ffi_gather_stats(const void* ffi_rln, uint64_t out[6]) {
   if (!ffi_rln || !out) return RLNAMD_ERR;
   FFI_RLN& r = *(FFI_RLN*)ffi_rln;
   std::lock_guard<std::mutex> guard(r.gather.mu);
@@ -1289,6 +1303,7 @@ int rlnamd_ffi_gather_stats(const void* ffi_rln, uint64_t out[5]) {
   out[2] = r.gather.largest;
   out[3] = r.gather.most;
   out[4] = r.gather.waited;
+  out[5] = r.gather.busy_ns;
   return RLNAMD_OK;
 }
 size_t ffi_rln_get_tree_depth(FFI_RLN_t* const* rln) { return ((FFI_RLN*)*rln)->tree.depth; }

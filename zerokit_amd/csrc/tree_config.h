@@ -66,9 +66,9 @@ struct TreeConfig {
   // as one batch of up to N, when it returns (ffi.cpp: prove_one).  -1 (default): on, up to the workspace's capacity;
   // 0 or 1: every call is its own batch, one after the other
   long gather_calls = -1;
-  // "gather_window_us": how long the leader of a gathered batch waits for callers it saw within the last millisecond
-  // (100 unless given; 0: it takes what is queued)
-  long gather_window_us = 100;
+  // "gather_window_us": how long the leader of a gathered batch waits for callers it saw within the last 20 ms
+  // (200 unless given; 0: it takes what is queued)
+  long gather_window_us = 200;
   bool persistent() const { return !temporary && has_path; }
   ProverConfig prover_config() const {
     ProverConfig cfg;
