@@ -109,8 +109,9 @@ int rlnamd_ffi_memo_stats(const void* ffi_rln, uint64_t out[4]);
  * (200; RLNAMD_GATHER_WINDOW_US; 0: none) to arrive before it takes the batch, so that T threads go out as batches of T
  * instead of two halves taking turns; a lone caller never waits, callers slower than the window make it stop waiting.
  * out: [0] batches led, [1] calls that went out in them, [2] the largest batch, [3] the cap (0: off), [4] batches whose
- * leader waited for a recent caller, [5] nanoseconds the leaders spent proving their batches */
-int rlnamd_ffi_gather_stats(const void* ffi_rln, uint64_t out[6]);
+ * leader waited for a recent caller, [5] nanoseconds the leaders spent proving their batches; ffi_finish_rln_proof and
+ * its twins (single message-id) are gathered the same way in a queue of their own: [6] its batches, [7] its calls */
+int rlnamd_ffi_gather_stats(const void* ffi_rln, uint64_t out[8]);
 /* offset/len of a named input signal in the inputs buffer (iden3calc.rs:122-146); returns RLNAMD_ERR if absent */
 int rlnamd_prover_input_slot(rlnamd_prover* p, const char* name, uint32_t* offset, uint32_t* len);
 /* inputs: n * inputs_size * 32 bytes (slot 0 must hold 1); rs: n * 64 bytes (r then s). */

@@ -598,6 +598,60 @@ def test_concurrent_single_proof_calls_are_gathered_into_batches(tmp_path):
         assert len({p.to_bytes_le() for p in ps}) == 4
 
 
+def test_concurrent_finishes_of_partial_proofs_are_gathered_into_batches(tmp_path):
+    """The reference's partial proofs exist to be finished quickly per message (rln/README.md:360-375); finishes from
+    several threads on one object are gathered like full proofs (ffi.cpp: finish_one).  Two members' partial proofs (one
+    with its cache handle, one deserialised from bytes: no handle), eight threads finishing for both: every proof equals,
+    byte for byte, the full proof an object that gathers nothing makes for the same witness and (r, s), and verifies;
+    batches of more than one finish were led; a finish whose witness does not fit the circuit gets its own error."""
+    import json
+    import threading
+    from zerokit_amd import hashers
+    from zerokit_amd.public import RLN, RLNError, RLNPartialProof, RLNPartialWitnessInput, RLNWitnessInput
+    cfgp = tmp_path / "cfg.json"
+    cfgp.write_text(json.dumps({"gather_calls": 0}))
+    rln, alone = RLN(20), RLN(20, tree_config=str(cfgp))
+    secrets = [hashers.hash_to_field_le(b"finish-member-%d" % k) for k in range(2)]
+    for obj in (rln, alone):
+        for k, sec in enumerate(secrets):
+            obj.set_leaf(40 + k, hashers.poseidon_hash_pair(hashers.poseidon_hash([sec]), 100))
+    paths = [rln.get_merkle_proof(40 + k) for k in range(2)]
+    partials = [rln.generate_partial_zk_proof(RLNPartialWitnessInput(secrets[k], 100, paths[k][0], paths[k][1])) for k in range(2)]
+    partials[1] = RLNPartialProof.from_bytes_le(partials[1].to_bytes_le())      # no cache handle: finished over the whole graph
+    made, errors, refused = {}, [], []
+
+    def work(tid):
+        try:
+            for j in range(10):
+                k = (tid + j) % 2
+                msg, x = (tid * 10 + j) % 100, 3000 + 100 * tid + j
+                if tid == 5 and j == 4:
+                    try:
+                        rln.finish_rln_proof_with_rs(partials[k], RLNWitnessInput(secrets[k], 100, msg, paths[k][0][:-1], paths[k][1][:-1], x, 4242), 1, 2)
+                        refused.append(None)
+                    except RLNError as e:
+                        refused.append(str(e))
+                    continue
+                w = RLNWitnessInput(secrets[k], 100, msg, paths[k][0], paths[k][1], x, 4242)
+                made[(tid, j)] = (k, msg, x, rln.finish_rln_proof_with_rs(partials[k], w, 9 + x, 3 + msg).to_bytes_le())
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors and len(made) == 79, errors
+    assert refused and refused[0] and "path_elements has length 19" in refused[0], refused
+    for k, msg, x, got in made.values():
+        w = RLNWitnessInput(secrets[k], 100, msg, paths[k][0], paths[k][1], x, 4242)
+        ref = alone.generate_rln_proof_with_rs(w, 9 + x, 3 + msg)
+        assert got == ref.to_bytes_le() and alone.verify_rln_proof(ref, x)
+    st = rln.gather_stats()
+    assert st["finish_calls"] == 80 and st["finish_batches"] < 80, st
+
+
 def test_concurrent_proving_with_the_member_memo(tmp_path):
     """generate_rln_proof takes &self (public.rs:624): four threads prove for three members on ONE object whose memo holds
     two ({"auto_partial": 2}) -- adoptions of pending partial proofs, finishes through the cone, evictions and proofs from

@@ -2,7 +2,8 @@
  * &self, rln/src/public.rs:624): calls per second and milliseconds per call for T = 1 .. 64, every proof verified at the
  * end of a run's first and last call.  The library gathers the calls that arrive while a proof is on the device into one
  * batch (include/rln_amd.h: rlnamd_ffi_gather_stats); RLNAMD_GATHER_CALLS=0 in the environment gives the behaviour
- * before (one call at a time).  One JSON line.
+ * before (one call at a time).  With the argument `finish` the threads finish the member's partial proof instead
+ * (ffi_finish_rln_proof; its ms_proving_per_batch is not reported).  One JSON line.
  *   gcc -O2 -std=c11 -I include tools/ffi_threads.c -L zerokit_amd/lib -lrln -lpthread -Wl,-rpath,$PWD/zerokit_amd/lib -o tools/ffi_threads */
 #define _POSIX_C_SOURCE 200809L
 #include <pthread.h>
@@ -13,7 +14,7 @@
 
 #include "rln.h"
 
-extern int rlnamd_ffi_gather_stats(const void* ffi_rln, uint64_t out[6]);
+extern int rlnamd_ffi_gather_stats(const void* ffi_rln, uint64_t out[8]);
 
 static FFI_RLN_t* rln;
 static const CFr_t *id_secret, *limit_c;
@@ -21,6 +22,7 @@ static CFr_t* ext;
 static FFI_MerkleProof_t* mp;
 static int calls_per_thread;
 static int failures;
+static FFI_RLNPartialProof_t* partial;   /* argv[1] = "finish": the threads finish this member's partial proof instead */
 
 static double now_s(void) {
   struct timespec ts;
@@ -39,7 +41,8 @@ static void* work(void* arg) {
       __sync_fetch_and_add(&failures, 1);
       return NULL;
     }
-    CResult_FFI_RLNProof_ptr_Vec_uint8_t p = ffi_generate_rln_proof(&rln, &w.ok);
+    CResult_FFI_RLNProof_ptr_Vec_uint8_t p =
+        partial ? ffi_finish_rln_proof(&rln, &partial, &w.ok) : ffi_generate_rln_proof(&rln, &w.ok);
     if (!p.ok) {
       __sync_fetch_and_add(&failures, 1);
       ffi_c_string_free(p.err);
@@ -58,7 +61,7 @@ static void* work(void* arg) {
   return NULL;
 }
 
-int main(void) {
+int main(int argc, char** argv) {
   CResult_FFI_RLN_ptr_Vec_uint8_t r = ffi_rln_new(20, "");
   if (!r.ok) {
     fprintf(stderr, "ffi_rln_new: %s\n", r.err.ptr);
@@ -76,34 +79,46 @@ int main(void) {
   if (!m.ok) return 4;
   mp = m.ok;
   ext = ffi_uint_to_cfr(424242);
+  if (argc > 1 && strcmp(argv[1], "finish") == 0) {
+    CResult_FFI_RLNPartialWitnessInput_ptr_Vec_uint8_t pw =
+        ffi_rln_partial_witness_input_new(id_secret, limit_c, &mp->path_elements, &mp->path_index);
+    if (!pw.ok) return 5;
+    CResult_FFI_RLNPartialProof_ptr_Vec_uint8_t pp = ffi_generate_partial_zk_proof(&rln, &pw.ok);
+    if (!pp.ok) return 6;
+    partial = pp.ok;
+    ffi_rln_partial_witness_input_free(pw.ok);
+  }
   calls_per_thread = 4;
   work((void*)99);   /* warm */
   const int ts[] = {1, 2, 4, 8, 16, 32, 64};
-  printf("{\"gather_calls_env\": \"%s\", \"threads\": {", getenv("RLNAMD_GATHER_CALLS") ? getenv("RLNAMD_GATHER_CALLS") : "");
+  printf("{\"calls\": \"%s\", \"gather_calls_env\": \"%s\", \"threads\": {", partial ? "ffi_finish_rln_proof" : "ffi_generate_rln_proof",
+         getenv("RLNAMD_GATHER_CALLS") ? getenv("RLNAMD_GATHER_CALLS") : "");
   for (unsigned k = 0; k < sizeof ts / sizeof ts[0]; k++) {
     const int T = ts[k];
     calls_per_thread = T <= 8 ? 300 : 100;
     pthread_t th[64];
-    uint64_t g0[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t g0[8] = {0};
     rlnamd_ffi_gather_stats(rln, g0);
     const double t0 = now_s();
     for (long t = 0; t < T; t++) pthread_create(&th[t], NULL, work, (void*)t);
     for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
     const double dt = now_s() - t0;
-    uint64_t g1[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t g1[8] = {0};
     rlnamd_ffi_gather_stats(rln, g1);
-    const double nb = (double)(g1[0] - g0[0]);
+    const int bi = partial ? 6 : 0, ci = partial ? 7 : 1;
+    const double nb = (double)(g1[bi] - g0[bi]);
     printf("%s\"%d\": {\"calls_per_s\": %.1f, \"ms_per_call\": %.3f, \"calls_per_batch\": %.2f, \"ms_proving_per_batch\": %.3f, "
            "\"ms_between_batches\": %.3f}",
-           k ? ", " : "", T, T * calls_per_thread / dt, dt / calls_per_thread * 1e3, nb ? (g1[1] - g0[1]) / nb : 0.0,
+           k ? ", " : "", T, T * calls_per_thread / dt, dt / calls_per_thread * 1e3, nb ? (g1[ci] - g0[ci]) / nb : 0.0,
            nb ? (g1[5] - g0[5]) * 1e-6 / nb : 0.0, nb ? (dt * 1e3 - (g1[5] - g0[5]) * 1e-6) / nb : 0.0);
   }
-  uint64_t st[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t st[8] = {0};
   rlnamd_ffi_gather_stats(rln, st);
   printf("}, \"gather_stats\": {\"batches\": %llu, \"calls\": %llu, \"largest\": %llu, \"cap\": %llu, \"waited\": %llu}, "
          "\"failures\": %d}\n",
          (unsigned long long)st[0], (unsigned long long)st[1], (unsigned long long)st[2], (unsigned long long)st[3],
          (unsigned long long)st[4], failures);
+  if (partial) ffi_rln_partial_proof_free(partial);
   ffi_merkle_proof_free(mp);
   ffi_vec_cfr_free(keys);
   ffi_cfr_free(limit);

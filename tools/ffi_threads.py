@@ -45,6 +45,25 @@ for name, cfg in (("gathered", None), ("one_call_at_a_time", {"gather_calls": 0}
         dt = time.perf_counter() - t0
         res[str(T)] = {"calls_per_s": round(T * calls / dt, 1), "ms_per_call_per_thread": round(dt / calls * 1e3, 3)}
     out[name] = res
+    if name in ("gathered", "one_call_at_a_time"):   # the same with finishes of the member's partial proof
+        from zerokit_amd.public import RLNPartialWitnessInput
+        part = rln.generate_partial_zk_proof(RLNPartialWitnessInput(secret, 100, e, b))
+        fres = {}
+        for T in (1, 2, 4, 8, 16, 32, 64):
+            calls = 150 if T <= 8 else 60
+
+            def fwork(tid):
+                for j in range(calls):
+                    rln.finish_rln_proof(part, RLNWitnessInput(secret, 100, (tid + j) % 100, e, b, 1 + tid * 1000 + j, 4242))
+            ths = [threading.Thread(target=fwork, args=(t,)) for t in range(T)]
+            t0 = time.perf_counter()
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            dt = time.perf_counter() - t0
+            fres[str(T)] = {"calls_per_s": round(T * calls / dt, 1), "ms_per_call_per_thread": round(dt / calls * 1e3, 3)}
+        out[name + "_finishes"] = fres
     if name == "gathered":
         out["gather_stats"] = rln.gather_stats()
     if name == "auto_partial":

@@ -294,6 +294,7 @@ struct FFI_RLN {
   struct Gather {
     struct Req {
       FFI_RLNWitnessInput* w = nullptr;
+      const FFI_RLNPartialProof* pp = nullptr;   // the finish queue: the partial proof to finish
       CFr rs[2];
       bool has_rs = false, done = false;
       FFI_RLNProof* out = nullptr;
@@ -313,7 +314,101 @@ struct FFI_RLN {
     uint64_t misses = 0, no_wait_until = 0; // the wait's back-off (see prove_one)
     uint64_t waited = 0;                    // batches whose leader waited for a recent caller
     uint64_t busy_ns = 0;                   // time the leaders spent proving their batches
-  } gather;
+    // queue `me`, lead or follow until it is done; run(batch) proves a batch and never throws
+    template <class Run>
+    void pass(Req& me, Run&& run) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        q.push_back(&me);
+        {   // this thread among the recent callers
+          const auto now = std::chrono::steady_clock::now();
+          bool seen = false;
+          for (auto& e : recent)
+            if (e.first == std::this_thread::get_id()) {
+              e.second = now;
+              seen = true;
+            }
+          if (!seen && recent.size() < 256) recent.emplace_back(std::this_thread::get_id(), now);
+        }
+        while (!me.done) {
+          if (leader) {
+            cv.wait(lk);
+            continue;
+          }
+          leader = true;   // nobody is proving: lead, with everything that is queued now
+          if (window_us > 0 && batches >= no_wait_until) {
+            // Threads that call in a loop come back just behind their results.  Without a wait they split into two halves
+            // that take turns (one half on the device while the other gathers: T threads, batches of T / 2, two batch times
+            // per call); with it the leader gives everybody it saw within the last 20 ms window_us to arrive and the T calls
+            // go out together -- one (longer) batch time per call.  Callers that stopped cost a few leaders the window until
+            // they age out; callers that are slower than the window (an interpreter between the calls) make the leader
+            // give up waiting for the next 64 batches after three misses in a row.
+            const auto t0 = std::chrono::steady_clock::now();
+            size_t expect = 0;
+            for (size_t i = 0; i < recent.size();) {
+              if (t0 - recent[i].second > std::chrono::milliseconds(20)) {
+                recent[i] = recent.back();
+                recent.pop_back();
+              } else {
+                expect++;
+                i++;
+              }
+            }
+            expect = std::min(expect, most);
+            if (q.size() < expect) {
+              waited++;
+              const auto until = t0 + std::chrono::microseconds(window_us);
+              while (q.size() < expect && std::chrono::steady_clock::now() < until) {
+                lk.unlock();
+                std::this_thread::yield();
+                lk.lock();
+              }
+              if (q.size() >= expect) {
+                misses = 0;
+              } else if (++misses >= 3) {
+                misses = 0;
+                no_wait_until = batches + 64;
+              }
+            }
+          }
+          std::vector<Req*> batch;
+          try {
+            batch.reserve(std::min(q.size(), most));
+          } catch (...) {      // (out of memory before anything was taken: step down, this call fails, the others go on)
+            leader = false;
+            for (auto it = q.begin(); it != q.end(); ++it)
+              if (*it == &me) {
+                q.erase(it);
+                break;
+              }
+            cv.notify_all();
+            throw;
+          }
+          while (!q.empty() && batch.size() < most) {
+            batch.push_back(q.front());   // (reserved: cannot throw)
+            q.pop_front();
+          }
+          lk.unlock();
+          const auto t_run = std::chrono::steady_clock::now();
+          try {
+            run(batch);
+          } catch (...) {      // run_gathered catches what proving throws; this is for its own allocations
+            for (Req* r : batch)
+              if (!r->out && r->err.empty()) r->err = "Error producing proof: out of memory";
+          }
+          lk.lock();
+          for (Req* r : batch) r->done = true;   // (not touched again: its owner may return now)
+          busy_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_run).count();
+          batches++;
+          calls += batch.size();
+          largest = std::max<uint64_t>(largest, batch.size());
+          leader = false;
+          cv.notify_all();
+        }
+      }
+    }
+  } gather,   // ffi_generate_rln_proof and its twins
+    gather_fin;   // ffi_finish_rln_proof and its twins: finishes of partial proofs gathered the same way
   struct Memo {
     std::vector<uint8_t> key;   // identity secret | limit | path elements | path index
     uint8_t coords[320];
@@ -423,6 +518,8 @@ struct FFI_RLN {
     // (the member memo works on batches of one: an object with "auto_partial" keeps its calls apart)
     const size_t cap = prover->capacity();
     gather.most = auto_partial ? 0 : gather_wanted < 0 ? cap : gather_wanted <= 1 ? 0 : std::min((size_t)gather_wanted, cap);
+    gather_fin.most = gather.most;
+    gather_fin.window_us = gather.window_us;
   }
   long gather_wanted = -1;
   TreeAny tree;   // dense in HBM up to depth 30, sparse (host-indexed, device-hashed) for 31 .. 63
@@ -962,95 +1059,7 @@ FFI_RLNProof* prove_one(FFI_RLN& rln, FFI_RLNWitnessInput* w, const CFr* rs) {
     FFI_RLN::Gather::Req& r;
     ~WipeReq() { secure_zero(r.rs, sizeof r.rs); }
   } wipe_me{me};
-  {
-    std::unique_lock<std::mutex> lk(G.mu);
-    G.q.push_back(&me);
-    {   // this thread among the recent callers
-      const auto now = std::chrono::steady_clock::now();
-      bool seen = false;
-      for (auto& e : G.recent)
-        if (e.first == std::this_thread::get_id()) {
-          e.second = now;
-          seen = true;
-        }
-      if (!seen && G.recent.size() < 256) G.recent.emplace_back(std::this_thread::get_id(), now);
-    }
-    while (!me.done) {
-      if (G.leader) {
-        G.cv.wait(lk);
-        continue;
-      }
-      G.leader = true;   // nobody is proving: lead, with everything that is queued now
-      if (G.window_us > 0 && G.batches >= G.no_wait_until) {
-        // Threads that call in a loop come back just behind their results.  Without a wait they split into two halves
-        // that take turns (one half on the device while the other gathers: T threads, batches of T / 2, two batch times
-        // per call); with it the leader gives everybody it saw within the last 20 ms window_us to arrive and the T calls
-        // go out together -- one (longer) batch time per call.  Callers that stopped cost a few leaders the window until
-        // they age out; callers that are slower than the window (an interpreter between the calls) make the leader
-        // give up waiting for the next 64 batches after three misses in a row.
-        const auto t0 = std::chrono::steady_clock::now();
-        size_t expect = 0;
-        for (size_t i = 0; i < G.recent.size();) {
-          if (t0 - G.recent[i].second > std::chrono::milliseconds(20)) {
-            G.recent[i] = G.recent.back();
-            G.recent.pop_back();
-          } else {
-            expect++;
-            i++;
-          }
-        }
-        expect = std::min(expect, G.most);
-        if (G.q.size() < expect) {
-          G.waited++;
-          const auto until = t0 + std::chrono::microseconds(G.window_us);
-          while (G.q.size() < expect && std::chrono::steady_clock::now() < until) {
-            lk.unlock();
-            std::this_thread::yield();
-            lk.lock();
-          }
-          if (G.q.size() >= expect) {
-            G.misses = 0;
-          } else if (++G.misses >= 3) {
-            G.misses = 0;
-            G.no_wait_until = G.batches + 64;
-          }
-        }
-      }
-      std::vector<FFI_RLN::Gather::Req*> batch;
-      try {
-        batch.reserve(std::min(G.q.size(), G.most));
-      } catch (...) {      // (out of memory before anything was taken: step down, this call fails, the others go on)
-        G.leader = false;
-        for (auto it = G.q.begin(); it != G.q.end(); ++it)
-          if (*it == &me) {
-            G.q.erase(it);
-            break;
-          }
-        G.cv.notify_all();
-        throw;
-      }
-      while (!G.q.empty() && batch.size() < G.most) {
-        batch.push_back(G.q.front());   // (reserved: cannot throw)
-        G.q.pop_front();
-      }
-      lk.unlock();
-      const auto t_run = std::chrono::steady_clock::now();
-      try {
-        run_gathered(rln, batch);
-      } catch (...) {      // run_gathered catches what proving throws; this is for its own allocations
-        for (FFI_RLN::Gather::Req* r : batch)
-          if (!r->out && r->err.empty()) r->err = "Error producing proof: out of memory";
-      }
-      lk.lock();
-      for (FFI_RLN::Gather::Req* r : batch) r->done = true;   // (not touched again: its owner may return now)
-      G.busy_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_run).count();
-      G.batches++;
-      G.calls += batch.size();
-      G.largest = std::max<uint64_t>(G.largest, batch.size());
-      G.leader = false;
-      G.cv.notify_all();
-    }
-  }
+  G.pass(me, [&](const std::vector<FFI_RLN::Gather::Req*>& batch) { run_gathered(rln, batch); });
   if (!me.err.empty()) throw Error(me.err);
   return me.out;
 }
@@ -1173,6 +1182,98 @@ FFI_RLNProof* finish_proof(FFI_RLN& rln, const FFI_RLNPartialProof& pp, const FF
   }
 }
 
+// finish_proof for a batch of single-message-id requests (FFI_RLN::gather_fin): ONE submit_finish / collect; throws on
+// the first request that cannot be finished (the caller then finishes each on its own, so that every request keeps its error)
+void finish_many(FFI_RLN& rln, const std::vector<FFI_RLN::Gather::Req*>& batch, const std::vector<CFr>& rs,
+                 std::vector<FFI_RLNProof*>& outs) {
+  std::lock_guard<std::mutex> guard(*rln.prove_mu);
+  if (rln.auto_partial) rln.memo_adopt_pending();
+  Prover& P = *rln.prover;
+  const size_t n = batch.size(), ni = P.inputs_per_proof();
+  const std::vector<uint8_t>& known = P.known_mask();
+  std::vector<uint8_t> inputs(n * ni * 32), rsb(n * 64), coords(n * 320), proofs(n * 128), values(n * 160);
+  ZeroOnExit z1{inputs}, z2{rsb};
+  std::vector<uint64_t> handles(n);
+  std::vector<uint32_t> errs(n);
+  for (size_t i = 0; i < n; i++) {
+    const FFI_RLNWitnessInput& w = *batch[i]->w;
+    const FFI_RLNPartialProof& pp = *batch[i]->pp;
+    check_against_graph(P, w);
+    if (w.multi) throw Error("finish_many: single message-id requests only");
+    if (pp.mask.size() + 1 != known.size() || !std::equal(pp.mask.begin(), pp.mask.end(), known.begin() + 1))
+      throw Error("Error producing proof: the partial proof's mask does not match this circuit (malformed verifying key)");
+    fill_inputs(P, w, inputs.data() + i * ni * 32);
+    memcpy(rsb.data() + i * 64, rs[2 * i].le, 32);
+    memcpy(rsb.data() + i * 64 + 32, rs[2 * i + 1].le, 32);
+    memcpy(coords.data() + i * 320, pp.coords, 320);
+    handles[i] = pp.handle;
+  }
+  const uint64_t ticket = P.submit_finish(n, inputs.data(), rsb.data(), coords.data(), handles.data());
+  P.collect(ticket, n, proofs.data(), values.data(), errs.data());
+  for (size_t i = 0; i < n; i++)
+    if (errs[i]) throw Error("Error calculating witness: graph evaluation failed (code " + std::to_string(errs[i]) + ")");
+  for (size_t i = 0; i < n; i++) {
+    std::unique_ptr<FFI_RLNProof> pr(new FFI_RLNProof);
+    memcpy(pr->proof, proofs.data() + 128 * i, 128);
+    const uint8_t* v = values.data() + 160 * i;
+    memcpy(pr->values.y.le, v, 32);
+    memcpy(pr->values.root.le, v + 32, 32);
+    memcpy(pr->values.nullifier.le, v + 64, 32);
+    memcpy(pr->values.x.le, v + 96, 32);
+    memcpy(pr->values.external_nullifier.le, v + 128, 32);
+    outs[i] = pr.release();
+  }
+}
+
+// ffi_finish_rln_proof from any thread: finishes that arrive while a batch is on the device go out together (as
+// prove_one does it for full proofs); r, s: the blinding factors (sampled by the caller of this function when the ABI
+// does not give them)
+FFI_RLNProof* finish_one(FFI_RLN& rln, const FFI_RLNPartialProof& pp, FFI_RLNWitnessInput& w, const CFr& r, const CFr& s) {
+  FFI_RLN::Gather& G = rln.gather_fin;
+  if (G.most == 0 || w.multi) return finish_proof(rln, pp, w, r, s);
+  FFI_RLN::Gather::Req me;
+  me.w = &w;
+  me.pp = &pp;
+  me.rs[0] = r;
+  me.rs[1] = s;
+  me.has_rs = true;
+  struct WipeReq {
+    FFI_RLN::Gather::Req& q;
+    ~WipeReq() { secure_zero(q.rs, sizeof q.rs); }
+  } wipe_me{me};
+  G.pass(me, [&](const std::vector<FFI_RLN::Gather::Req*>& batch) {
+    const size_t n = batch.size();
+    auto alone = [&](size_t i) {
+      try {
+        batch[i]->out = finish_proof(rln, *batch[i]->pp, *batch[i]->w, batch[i]->rs[0], batch[i]->rs[1]);
+      } catch (const std::exception& e) {
+        batch[i]->err = e.what();
+        if (batch[i]->err.empty()) batch[i]->err = "Error producing proof";
+      }
+    };
+    if (n == 1) return alone(0);
+    std::vector<FFI_RLNProof*> outs(n, nullptr);
+    try {
+      std::vector<CFr> rs(2 * n);
+      struct WipeRs {
+        std::vector<CFr>& v;
+        ~WipeRs() { secure_zero(v.data(), v.size() * sizeof(CFr)); }
+      } wipe_rs{rs};
+      for (size_t i = 0; i < n; i++) {
+        rs[2 * i] = batch[i]->rs[0];
+        rs[2 * i + 1] = batch[i]->rs[1];
+      }
+      finish_many(rln, batch, rs, outs);
+      for (size_t i = 0; i < n; i++) batch[i]->out = outs[i];
+    } catch (const std::exception&) {
+      for (FFI_RLNProof* o : outs) delete o;
+      for (size_t i = 0; i < n; i++) alone(i);
+    }
+  });
+  if (!me.err.empty()) throw Error(me.err);
+  return me.out;
+}
+
 
 bool verify_zk(FFI_RLN& rln, const FFI_RLNProof& pr) {  // verify_zk_proof (proof.rs:856-894)
   G1Affine A, C;
@@ -1293,8 +1394,8 @@ int rlnamd_ffi_memo_stats(const void* ffi_rln, uint64_t out[4]) {
 }
 // EXT (include/rln_amd.h): the gathering of concurrent single-proof calls: [0] batches led, [1] calls that went out in
 // them, [2] the largest batch, [3] the most calls one batch may take (0: off), [4] batches whose leader waited for a
-// recent caller, [5] nanoseconds the leaders spent proving their batches
-int rlnamd_ffi_gather_stats(const void* ffi_rln, uint64_t out[6]) {
+// recent caller, [5] nanoseconds the leaders spent proving their batches, [6] / [7] batches and calls of the finish queue
+int rlnamd_ffi_gather_stats(const void* ffi_rln, uint64_t out[8]) {
   if (!ffi_rln || !out) return RLNAMD_ERR;
   FFI_RLN& r = *(FFI_RLN*)ffi_rln;
   std::lock_guard<std::mutex> guard(r.gather.mu);
@@ -1304,6 +1405,11 @@ int rlnamd_ffi_gather_stats(const void* ffi_rln, uint64_t out[6]) {
   out[3] = r.gather.most;
   out[4] = r.gather.waited;
   out[5] = r.gather.busy_ns;
+  {
+    std::lock_guard<std::mutex> g2(r.gather_fin.mu);
+    out[6] = r.gather_fin.batches;
+    out[7] = r.gather_fin.calls;
+  }
   return RLNAMD_OK;
 }
 size_t ffi_rln_get_tree_depth(FFI_RLN_t* const* rln) { return ((FFI_RLN*)*rln)->tree.depth; }
@@ -1439,8 +1545,8 @@ CResult_FFI_RLNPartialProof_ptr_Vec_uint8_t ffi_generate_partial_zk_proof(
 CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_finish_rln_proof(FFI_RLN_t* const* rln, FFI_RLNPartialProof_t* const* partial,
                                                           FFI_RLNWitnessInput_t* const* witness) {
   return guard_ptr<CResult_FFI_RLNProof_ptr_Vec_uint8_t>([&]() -> FFI_RLNProof_t* {
-    return (FFI_RLNProof_t*)finish_proof(*(FFI_RLN*)*rln, *(FFI_RLNPartialProof*)*partial,
-                                         *(FFI_RLNWitnessInput*)*witness, random_fr(), random_fr());
+    return (FFI_RLNProof_t*)finish_one(*(FFI_RLN*)*rln, *(FFI_RLNPartialProof*)*partial,
+                                       *(FFI_RLNWitnessInput*)*witness, random_fr(), random_fr());
   });
 }
 CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_finish_rln_proof_with_rs(FFI_RLN_t* const* rln,
@@ -1448,8 +1554,8 @@ CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_finish_rln_proof_with_rs(FFI_RLN_t* con
                                                                   FFI_RLNWitnessInput_t* const* witness,
                                                                   const CFr_t* r, const CFr_t* s) {
   return guard_ptr<CResult_FFI_RLNProof_ptr_Vec_uint8_t>([&]() -> FFI_RLNProof_t* {
-    return (FFI_RLNProof_t*)finish_proof(*(FFI_RLN*)*rln, *(FFI_RLNPartialProof*)*partial,
-                                         *(FFI_RLNWitnessInput*)*witness, R(r), R(s));
+    return (FFI_RLNProof_t*)finish_one(*(FFI_RLN*)*rln, *(FFI_RLNPartialProof*)*partial,
+                                       *(FFI_RLNWitnessInput*)*witness, R(r), R(s));
   });
 }
 uint8_t ffi_rln_partial_proof_get_version_byte(FFI_RLNPartialProof_t* const*) { return 0x00; }

@@ -365,10 +365,11 @@ class RLN:
 
     def gather_stats(self):
         """concurrent single-proof calls gathered into batches (rlnamd_ffi_gather_stats)"""
-        out = (C.c_uint64 * 6)()
+        out = (C.c_uint64 * 8)()
         if lib().rlnamd_ffi_gather_stats(self._h, out) != 0:
             raise RLNError("rlnamd_ffi_gather_stats failed")
-        return dict(zip(("batches", "calls", "largest", "cap", "waited", "busy_ns"), [int(v) for v in out]))
+        return dict(zip(("batches", "calls", "largest", "cap", "waited", "busy_ns", "finish_batches", "finish_calls"),
+                        [int(v) for v in out]))
 
     def tree_depth(self):
         return int(lib().ffi_rln_get_tree_depth(C.byref(self._h)))
