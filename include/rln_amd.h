@@ -104,7 +104,8 @@ int rlnamd_ffi_memo_stats(const void* ffi_rln, uint64_t out[4]);
  * ffi_rln_v3_generate_proof and their _with_rs twins) that arrive while a proof is on the device are gathered and go out
  * together, as one batch, when it returns -- each call gets its own proof or its own error text, a lone caller is a
  * batch of one as before.  "gather_calls": N in the config_path JSON (or RLNAMD_GATHER_CALLS) caps a batch (default:
- * the workspace's capacity; 0 or 1: off); an object with "auto_partial" keeps its calls apart.  Threads that call in a
+ * the workspace's capacity; 0 or 1: off); on an object with "auto_partial" the gathered calls of remembered members go
+ * out as one batch of finishes, the others one by one.  Threads that call in a
  * loop arrive just behind their results: the leader gives the callers it saw within the last 20 ms "gather_window_us"
  * (200; RLNAMD_GATHER_WINDOW_US; 0: none) to arrive before it takes the batch, so that T threads go out as batches of T
  * instead of two halves taking turns; a lone caller never waits, callers slower than the window make it stop waiting.

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """ffi_generate_rln_proof from T threads on ONE object, one member: calls per second with the calls gathered into batches
 (the default), with {"gather_calls": 0} (every call its own batch, one after the other: what the object did before) and
-with {"auto_partial": 2} (a remembered member's proofs are finishes through the cone; its calls are kept apart).
+with {"auto_partial": 2} (a remembered member's proofs are finishes through the cone: its gathered calls are batches of finishes).
 One JSON line."""
 import json
 import os

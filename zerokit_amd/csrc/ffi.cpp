@@ -515,9 +515,8 @@ struct FFI_RLN {
       }
       prover.reset(new Prover(zkey, zkey_len, graph, graph_len, use));
     }
-    // (the member memo works on batches of one: an object with "auto_partial" keeps its calls apart)
     const size_t cap = prover->capacity();
-    gather.most = auto_partial ? 0 : gather_wanted < 0 ? cap : gather_wanted <= 1 ? 0 : std::min((size_t)gather_wanted, cap);
+    gather.most = gather_wanted < 0 ? cap : gather_wanted <= 1 ? 0 : std::min((size_t)gather_wanted, cap);
     gather_fin.most = gather.most;
     gather_fin.window_us = gather.window_us;
   }
@@ -818,6 +817,16 @@ struct WipeResident {
   }
 };
 
+// the member memo's key (FFI_RLN::auto_partial): identity secret | limit | path elements | path index
+void memo_key(const FFI_RLNWitnessInput& w, std::vector<uint8_t>& key) {
+  key.clear();
+  key.reserve(64 + 33 * w.path_elements.size());
+  key.insert(key.end(), w.identity_secret.le, w.identity_secret.le + 32);
+  key.insert(key.end(), w.user_message_limit.le, w.user_message_limit.le + 32);
+  for (const CFr& e : w.path_elements) key.insert(key.end(), e.le, e.le + 32);
+  key.insert(key.end(), w.identity_path_index.begin(), w.identity_path_index.end());
+}
+
 // generate_rln_proof for a slice of witnesses (public.rs:624-631)
 void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CFr* rs, FFI_RLNProof** out) {
   std::lock_guard<std::mutex> guard(*rln.prove_mu);
@@ -850,11 +859,7 @@ void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CF
       // else a full proof with the member's partial proof enqueued behind it
       const FFI_RLNWitnessInput& w = *ws[0];
       std::vector<uint8_t> key;
-      key.reserve(64 + 33 * w.path_elements.size());
-      key.insert(key.end(), w.identity_secret.le, w.identity_secret.le + 32);
-      key.insert(key.end(), w.user_message_limit.le, w.user_message_limit.le + 32);
-      for (const CFr& e : w.path_elements) key.insert(key.end(), e.le, e.le + 32);
-      key.insert(key.end(), w.identity_path_index.begin(), w.identity_path_index.end());
+      memo_key(w, key);
       ZeroOnExit zk{key};
       std::vector<uint8_t> inputs, rsb;
       ZeroOnExit z1{inputs}, z2{rsb};
@@ -1029,6 +1034,76 @@ void run_gathered(FFI_RLN& rln, const std::vector<FFI_RLN::Gather::Req*>& batch)
     }
   };
   if (n == 1) return alone(0);
+  if (rln.auto_partial) {
+    // An object with the member memo: the requests of remembered members go out as ONE batch of finishes through the
+    // cone; the others one by one, the way a lone call goes (a full proof, the member's partial proof behind it).
+    std::vector<size_t> hit, rest;
+    try {
+      std::lock_guard<std::mutex> guard(*rln.prove_mu);
+      rln.memo_adopt_pending();
+      Prover& P = *rln.prover;
+      const size_t ni = P.inputs_per_proof();
+      std::vector<FFI_RLN::Memo*> hm;
+      std::vector<uint8_t> key;
+      ZeroOnExit zk{key};
+      for (size_t i = 0; i < n; i++) {
+        FFI_RLN::Memo* found = nullptr;
+        if (!ws[i]->multi) {
+          memo_key(*ws[i], key);
+          for (FFI_RLN::Memo& m : rln.memo)
+            if (m.key == key) found = &m;
+        }
+        if (found) {
+          hit.push_back(i);
+          hm.push_back(found);
+        } else {
+          rest.push_back(i);
+        }
+      }
+      if (hit.size() >= 2) {
+        const size_t nh = hit.size();
+        std::vector<uint8_t> inputs(nh * ni * 32), rsb(nh * 64), coords(nh * 320), proofs(nh * 128), values(nh * 160);
+        ZeroOnExit z1{inputs}, z2{rsb};
+        std::vector<uint64_t> handles(nh);
+        std::vector<uint32_t> errs(nh);
+        for (size_t k = 0; k < nh; k++) {
+          check_against_graph(P, *ws[hit[k]]);
+          fill_inputs(P, *ws[hit[k]], inputs.data() + k * ni * 32);
+          memcpy(rsb.data() + k * 64, rs[2 * hit[k]].le, 32);
+          memcpy(rsb.data() + k * 64 + 32, rs[2 * hit[k] + 1].le, 32);
+          memcpy(coords.data() + k * 320, hm[k]->coords, 320);
+          handles[k] = hm[k]->handle;
+        }
+        const uint64_t ticket = P.submit_finish(nh, inputs.data(), rsb.data(), coords.data(), handles.data());
+        P.collect(ticket, nh, proofs.data(), values.data(), errs.data());
+        for (size_t k = 0; k < nh; k++) {
+          hm[k]->stamp = ++rln.memo_clock;
+          rln.memo_hits++;
+          if (errs[k]) {
+            batch[hit[k]]->err = "Error calculating witness: graph evaluation failed (code " + std::to_string(errs[k]) + ")";
+            continue;
+          }
+          std::unique_ptr<FFI_RLNProof> pr(new FFI_RLNProof);
+          memcpy(pr->proof, proofs.data() + 128 * k, 128);
+          const uint8_t* v = values.data() + 160 * k;
+          memcpy(pr->values.y.le, v, 32);
+          memcpy(pr->values.root.le, v + 32, 32);
+          memcpy(pr->values.nullifier.le, v + 64, 32);
+          memcpy(pr->values.x.le, v + 96, 32);
+          memcpy(pr->values.external_nullifier.le, v + 128, 32);
+          batch[hit[k]]->out = pr.release();
+        }
+      } else {
+        rest.insert(rest.end(), hit.begin(), hit.end());
+        hit.clear();
+      }
+    } catch (const std::exception&) {   // the finish batch as a whole did not go through: whoever has no result yet goes alone
+      for (size_t i : hit)
+        if (!batch[i]->out && batch[i]->err.empty()) rest.push_back(i);
+    }
+    for (size_t i : rest) alone(i);
+    return;
+  }
   try {
     std::vector<FFI_RLNProof*> outs(n, nullptr);
     prove_many(rln, ws.data(), n, rs.data(), outs.data());
