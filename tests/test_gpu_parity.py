@@ -1059,6 +1059,46 @@ def test_a_few_proofs_per_call_interpret_the_graph_as_segments_behind_hints(monk
         p.close()
 
 
+def test_small_batches_in_flight_behind_each_other_keep_the_latency_shapes_and_their_bytes():
+    """Round 6.  Batches of at most 48 proofs take the lone (latency) shapes -- segments behind hints, fused / tiny plans,
+    lanes = chunks walks -- even while earlier batches are still in flight (RLNAMD_LONE_SMALL; a stream of them was 1.2 - 2 x
+    slower in the throughput shapes).  Three batches in flight at a time, sizes 1 ... 48, full proofs and finishes of cached
+    partial proofs mixed: every proof equals the golden bytes / the proof of a call that ran alone, every public input too;
+    the hinted batches were hinted although they were not alone."""
+    from zerokit_amd.batch import BatchProver
+    cases = _cases()["cases"]
+    p = BatchProver(max_batch=64, window_bits=8)
+    try:
+        def pack(idx):
+            ws = [_w(cases[i % len(cases)]) for i in idx]
+            rs = [(int(cases[i % len(cases)]["r"]), int(cases[i % len(cases)]["s"])) for i in idx]
+            return p.pack_inputs(ws), p.pack_rs(rs)
+
+        def check(out, idx):
+            for o, i in zip(out, idx):
+                c = cases[i % len(cases)]
+                assert o["proof"].hex() == c["proof_compressed"] and o["error"] == 0, (c["name"], len(idx))
+                assert [str(v) for v in o["public_inputs"]] == c["public_inputs"]
+        before = p.hint_stats()["hinted_batches"]
+        sizes = [1, 5, 8, 2, 16, 24, 3, 33, 48, 1, 12, 7]
+        flight = []
+        for k, n in enumerate(sizes):
+            idx = [(k + j) for j in range(n)]
+            if len(flight) == 3:
+                t, m, ix = flight.pop(0)
+                check(p.collect(t, m), ix)
+            inp, rsb = pack(idx)
+            t, m = p.submit(inp, rsb)
+            flight.append((t, m, idx))
+        while flight:
+            t, m, ix = flight.pop(0)
+            check(p.collect(t, m), ix)
+        st = p.hint_stats()
+        assert st["hinted_batches"] - before >= sum(1 for n in sizes if n <= 24) and st["fallbacks"] == 0, st
+    finally:
+        p.close()
+
+
 def test_partial_cache_lifetimes_under_a_random_sequence_of_calls(monkeypatch):
     """The cache's lifetimes (entries written on the wipe stream, read on the front-end stream and by k_pp_smul, wiped on
     release, indices reused with a new generation) under 120 pseudo-random calls on a prover with EIGHT entries: partial

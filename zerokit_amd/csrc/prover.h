@@ -66,6 +66,7 @@ struct ProverTuning {
   bool glv = true;                     // RLNAMD_GLV: walk the 127-bit GLV halves (0: the plain 255-bit walk)
   bool wit29 = true;                   // RLNAMD_WIT29: interpreter in the 9 x 29 form (0: the 8 x 32 fallback k_witness)
   int lone = -1;                       // RLNAMD_LONE: -1 detect whether a batch is alone on the device, 0 / 1 force
+  uint32_t lone_small_max = 48;        // RLNAMD_LONE_SMALL: batches of at most this many proofs take the lone (latency) shapes even behind a batch in flight
   bool early_walk = true;              // RLNAMD_EARLY_WALK: small batches walk the h-independent rows beside the NTTs
   bool early_fin = true;               // RLNAMD_EARLY_FIN: small batches finish A, B1 before the h rows are walked
   bool fused_smul = true;              // RLNAMD_FUSED_SMUL: a lone small proof takes s A, r B1 as rows of the C segment

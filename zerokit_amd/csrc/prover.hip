@@ -527,6 +527,7 @@ ProverTuning ProverTuning::from_env() {
   t.glv = env_int("RLNAMD_GLV", 1) != 0;
   t.wit29 = env_int("RLNAMD_WIT29", 1) != 0;
   t.lone = env_int("RLNAMD_LONE", -1);
+  t.lone_small_max = (uint32_t)std::max(0, env_int("RLNAMD_LONE_SMALL", (int)t.lone_small_max));
   t.early_walk = env_int("RLNAMD_EARLY_WALK", 1) != 0;
   t.early_fin = env_int("RLNAMD_EARLY_FIN", 1) != 0;
   t.fused_smul = env_int("RLNAMD_FUSED_SMUL", 1) != 0;
@@ -1846,7 +1847,11 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // single-stream chains, the wave-per-proof interpreter above the small-batch threshold)
   const ProverTuning& T = D.tune;
   const int lone_force = T.lone;   // -1: detect; 0 / 1: force (measurements, tests)
-  const bool lone = lone_force >= 0 ? lone_force != 0 : (!D.last || hipEventQuery(D.last->evC) == hipSuccess);
+  // (round 6: up to lone_small_max proofs the lone shapes are taken behind a batch that is still in flight as well -- a
+  // stream of such batches was measured 1.2 - 2 x slower in the throughput shapes: three batches of 16 in flight 11.9 ms,
+  // 5.7 ms in the lone shapes; above 48 the two are the same)
+  const bool lone = lone_force >= 0 ? lone_force != 0
+                                    : (n <= T.lone_small_max || !D.last || hipEventQuery(D.last->evC) == hipSuccess);
   (void)hipGetLastError();   // hipErrorNotReady is not an error here
   const bool small = n <= D.lanechunk_max && n <= D.small_stride;   // lanes = chunks
   // The lanes = nodes interpreter (a wave and 157 KB of LDS per proof, ~25 x the instructions per proof of k_witness29,
