@@ -72,6 +72,44 @@ def test_v3_generate_verify_and_errors(single, multi):
     assert single.get_root() == 0 and single.leaves_set() == 0
 
 
+def test_v3_calls_from_several_threads_are_gathered(single, multi):
+    """ffi_rln_v3_generate_proof goes through the same door as the V1 entry point (ffi.cpp: prove_one): six threads on one
+    RLNV3 object, single and multi message-id, every proof verifies with its own x; a witness of the wrong depth among them
+    gets the V3 error text while the calls gathered with it get their proofs; the multi-message-id object's batches keep the
+    public signals of every call apart."""
+    import threading
+    from zerokit_amd._native import RLNError
+    for obj, mk in ((single, _sw), (multi, _mw)):
+        outs, errors, refused = {}, [], []
+
+        def work(tid):
+            try:
+                for j in range(5):
+                    x = 100 * tid + j + 1
+                    if obj is single and tid == 2 and j == 2:
+                        try:
+                            obj.generate_proof(_sw(7, depth=21, x=x))
+                            refused.append(None)
+                        except RLNError as e:
+                            refused.append(str(e))
+                        continue
+                    outs[(tid, j)] = (x, obj.generate_proof(mk(1000 + tid, x=x)))
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(6)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        assert len(outs) == (29 if obj is single else 30)
+        for x, p in outs.values():
+            assert obj.verify(p, x) and obj.verify(p, x + 1) is False
+        if obj is single:
+            assert refused and refused[0] and "has length 21, but circuit tree_depth is 20" in refused[0], refused
+
+
 def test_v3_golden_proofs_and_wire_formats(single, multi):
     """fixed (r, s): the committed oracle proofs through the V3 objects; LE / mixed serialisations round-trip"""
     from zerokit_amd.public_v3 import RLNProofV3, RLNWitnessInputV3
