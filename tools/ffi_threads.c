@@ -3,7 +3,8 @@
  * end of a run's first and last call.  The library gathers the calls that arrive while a proof is on the device into one
  * batch (include/rln_amd.h: rlnamd_ffi_gather_stats); RLNAMD_GATHER_CALLS=0 in the environment gives the behaviour
  * before (one call at a time).  With the argument `finish` the threads finish the member's partial proof instead
- * (ffi_finish_rln_proof; its ms_proving_per_batch is not reported).  One JSON line.
+ * (ffi_finish_rln_proof; its ms_proving_per_batch is not reported); a second argument is the object's config_path.
+ * One JSON line.
  *   gcc -O2 -std=c11 -I include tools/ffi_threads.c -L zerokit_amd/lib -lrln -lpthread -Wl,-rpath,$PWD/zerokit_amd/lib -o tools/ffi_threads */
 #define _POSIX_C_SOURCE 200809L
 #include <pthread.h>
@@ -62,7 +63,8 @@ static void* work(void* arg) {
 }
 
 int main(int argc, char** argv) {
-  CResult_FFI_RLN_ptr_Vec_uint8_t r = ffi_rln_new(20, "");
+  /* argv[2]: a config_path JSON for the object, e.g. one holding {"profile": "throughput"} */
+  CResult_FFI_RLN_ptr_Vec_uint8_t r = ffi_rln_new(20, argc > 2 ? argv[2] : "");
   if (!r.ok) {
     fprintf(stderr, "ffi_rln_new: %s\n", r.err.ptr);
     return 2;
