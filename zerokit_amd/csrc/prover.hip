@@ -545,12 +545,14 @@ ProverTuning ProverTuning::from_env() {
   return t;
 }
 std::string ProverTuning::describe() const {
-  char b[512];
+  char b[768];
   snprintf(b, sizeof b,
            "window_bits=%d slots=%d lanechunk=%u lanechunk_walk=%u witlanes_max=%u tiny=%u ntt_lg_max=%u partial_cache=%u glv=%d wit29=%d lone=%d "
-           "early_walk=%d early_fin=%d fused_smul=%d values_from_witness=%d marks_small=%d d2h_kernel=%d hints=%u",
+           "lone_small=%u early_walk=%d early_fin=%d fused_smul=%d values_from_witness=%d marks_small=%d d2h_kernel=%d hints=%u hints_warm=%u "
+           "hint_threads=%u hint_chains=%u",
            window_bits, slots, lanechunk_max, lanechunk_walk_max, witlanes_max, tiny_max, ntt_lg_max, partial_cache, (int)glv, (int)wit29, lone,
-           (int)early_walk, (int)early_fin, (int)fused_smul, (int)values_from_witness, (int)marks_small, (int)d2h_kernel, hint_max);
+           lone_small_max, (int)early_walk, (int)early_fin, (int)fused_smul, (int)values_from_witness, (int)marks_small, (int)d2h_kernel,
+           hint_max, hint_max_warm, hint_threads, hint_chains);
   return b;
 }
 const ProverTuning& Prover::tuning() const { return d_->tune; }
