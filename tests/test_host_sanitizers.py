@@ -43,3 +43,16 @@ def test_host_parsers_verifier_and_scheduler_under_asan_ubsan(tmp_path):
     import re
     m = re.search(r"wire parsers: (\d+) inputs, (\d+) parsed, (\d+) refused with a reference error text, 0 failures", r.stdout)
     assert m and int(m.group(1)) >= 10000 and int(m.group(3)) > 5000, r.stdout[-600:]
+
+
+def test_gather_queue_under_thread_sanitizer(tmp_path):
+    """zerokit_amd/csrc/gather.h -- the queue behind ffi_generate_rln_proof / ffi_finish_rln_proof that gathers the calls
+    of several threads into batches -- under ThreadSanitizer (tests/host/gather_tsan.cpp): 1 ... 24 threads calling in a
+    loop, with and without the leader's wait for recent callers; every call gets its own result, one batch at a time, no
+    batch above the cap, a run that throws marks its whole batch, a lone caller never waits; no data race reported."""
+    exe = str(tmp_path / "gather_tsan")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-I", CSRC,
+                           os.path.join(ROOT, "tests", "host", "gather_tsan.cpp"), "-o", exe, "-lpthread"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "ThreadSanitizer" not in r.stderr and "0 failures" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])

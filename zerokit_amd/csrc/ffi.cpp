@@ -37,6 +37,7 @@
 #include "pairing.h"
 #include "poseidon.h"
 #include "prover.h"
+#include "gather.h"
 #include "ffi_wire.h"   // CFr, the FFI object structs, Cursor / V3Reader, every (de)serialiser and validation
 
 using namespace rlnamd;
@@ -285,130 +286,21 @@ struct FFI_RLN {
   // What it costs is a policy decision, hence opt-in: the member's witness values stay on the device, and the key
   // (secret included) in host memory, until the entry is evicted (LRU), the tree moves on, or the object is freed.
   size_t auto_partial = 0;
-  // generate_rln_proof takes &self and may be called from several threads (public.rs:624); the prover has one set of
-  // workspaces per batch in flight, so single-proof calls used to take turns: T threads got the rate of one (1.2 k
-  // proofs/s at 0.8 ms per call).  Now the calls that arrive while a proof is on the device are gathered: the first
-  // caller that finds no batch running leads -- it takes everything queued (its own request included), proves it as ONE
-  // batch, hands every request its proof or its own error text, and steps down; a caller whose request went out with
-  // somebody else's batch just wakes up with its result.  A lone caller leads a batch of one: the path it always took.
-  struct Gather {
-    struct Req {
-      FFI_RLNWitnessInput* w = nullptr;
-      const FFI_RLNPartialProof* pp = nullptr;   // the finish queue: the partial proof to finish
-      CFr rs[2];
-      bool has_rs = false, done = false;
-      FFI_RLNProof* out = nullptr;
-      std::string err;
-    };
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<Req*> q;
-    bool leader = false;
-    size_t most = 0;                        // 0: off
-    uint64_t batches = 0, calls = 0, largest = 0;
-    // Threads that call in a loop arrive just behind their results, after the next leader has taken its batch.  The
-    // leader therefore knows who else called within the last 20 ms and gives those callers window_us to arrive
-    // (spinning, off the lock) before it takes the batch.  A caller that is alone never waits.
-    std::vector<std::pair<std::thread::id, std::chrono::steady_clock::time_point>> recent;
-    long window_us = 200;                   // RLNAMD_GATHER_WINDOW_US / "gather_window_us"; 0: take what is there
-    uint64_t misses = 0, no_wait_until = 0; // the wait's back-off (see prove_one)
-    uint64_t waited = 0;                    // batches whose leader waited for a recent caller
-    uint64_t busy_ns = 0;                   // time the leaders spent proving their batches
-    // queue `me`, lead or follow until it is done; run(batch) proves a batch and never throws
-    template <class Run>
-    void pass(Req& me, Run&& run) {
-      {
-        std::unique_lock<std::mutex> lk(mu);
-        q.push_back(&me);
-        {   // this thread among the recent callers
-          const auto now = std::chrono::steady_clock::now();
-          bool seen = false;
-          for (auto& e : recent)
-            if (e.first == std::this_thread::get_id()) {
-              e.second = now;
-              seen = true;
-            }
-          if (!seen && recent.size() < 256) recent.emplace_back(std::this_thread::get_id(), now);
-        }
-        while (!me.done) {
-          if (leader) {
-            cv.wait(lk);
-            continue;
-          }
-          leader = true;   // nobody is proving: lead, with everything that is queued now
-          if (window_us > 0 && batches >= no_wait_until) {
-            // Threads that call in a loop come back just behind their results.  Without a wait they split into two halves
-            // that take turns (one half on the device while the other gathers: T threads, batches of T / 2, two batch times
-            // per call); with it the leader gives everybody it saw within the last 20 ms window_us to arrive and the T calls
-            // go out together -- one (longer) batch time per call.  Callers that stopped cost a few leaders the window until
-            // they age out; callers that are slower than the window (an interpreter between the calls) make the leader
-            // give up waiting for the next 64 batches after three misses in a row.
-            const auto t0 = std::chrono::steady_clock::now();
-            size_t expect = 0;
-            for (size_t i = 0; i < recent.size();) {
-              if (t0 - recent[i].second > std::chrono::milliseconds(20)) {
-                recent[i] = recent.back();
-                recent.pop_back();
-              } else {
-                expect++;
-                i++;
-              }
-            }
-            expect = std::min(expect, most);
-            if (q.size() < expect) {
-              waited++;
-              const auto until = t0 + std::chrono::microseconds(window_us);
-              while (q.size() < expect && std::chrono::steady_clock::now() < until) {
-                lk.unlock();
-                std::this_thread::yield();
-                lk.lock();
-              }
-              if (q.size() >= expect) {
-                misses = 0;
-              } else if (++misses >= 3) {
-                misses = 0;
-                no_wait_until = batches + 64;
-              }
-            }
-          }
-          std::vector<Req*> batch;
-          try {
-            batch.reserve(std::min(q.size(), most));
-          } catch (...) {      // (out of memory before anything was taken: step down, this call fails, the others go on)
-            leader = false;
-            for (auto it = q.begin(); it != q.end(); ++it)
-              if (*it == &me) {
-                q.erase(it);
-                break;
-              }
-            cv.notify_all();
-            throw;
-          }
-          while (!q.empty() && batch.size() < most) {
-            batch.push_back(q.front());   // (reserved: cannot throw)
-            q.pop_front();
-          }
-          lk.unlock();
-          const auto t_run = std::chrono::steady_clock::now();
-          try {
-            run(batch);
-          } catch (...) {      // run_gathered catches what proving throws; this is for its own allocations
-            for (Req* r : batch)
-              if (!r->out && r->err.empty()) r->err = "Error producing proof: out of memory";
-          }
-          lk.lock();
-          for (Req* r : batch) r->done = true;   // (not touched again: its owner may return now)
-          busy_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_run).count();
-          batches++;
-          calls += batch.size();
-          largest = std::max<uint64_t>(largest, batch.size());
-          leader = false;
-          cv.notify_all();
-        }
-      }
+  // single calls from several threads gathered into batches: gather.h
+  struct GatherReq {
+    FFI_RLNWitnessInput* w = nullptr;
+    const FFI_RLNPartialProof* pp = nullptr;   // the finish queue: the partial proof to finish
+    CFr rs[2];
+    bool has_rs = false, done = false;
+    FFI_RLNProof* out = nullptr;
+    std::string err;
+    void gather_failed() {
+      if (!out && err.empty()) err = "Error producing proof: out of memory";
     }
-  } gather,   // ffi_generate_rln_proof and its twins
-    gather_fin;   // ffi_finish_rln_proof and its twins: finishes of partial proofs gathered the same way
+  };
+  typedef GatherQueue<GatherReq> Gather;
+  Gather gather,   // ffi_generate_rln_proof and its twins
+      gather_fin;   // ffi_finish_rln_proof and its twins: finishes of partial proofs gathered the same way
   struct Memo {
     std::vector<uint8_t> key;   // identity secret | limit | path elements | path index
     uint8_t coords[320];
@@ -1010,7 +902,7 @@ void prove_many(FFI_RLN& rln, FFI_RLNWitnessInput* const* ws, size_t n, const CF
 }
 
 // the gathered calls of FFI_RLN::Gather as one batch; never throws: every request leaves with a proof or its error text
-void run_gathered(FFI_RLN& rln, const std::vector<FFI_RLN::Gather::Req*>& batch) {
+void run_gathered(FFI_RLN& rln, const std::vector<FFI_RLN::GatherReq*>& batch) {
   const size_t n = batch.size();
   std::vector<FFI_RLNWitnessInput*> ws(n);
   std::vector<CFr> rs(2 * n);
@@ -1123,7 +1015,7 @@ FFI_RLNProof* prove_one(FFI_RLN& rln, FFI_RLNWitnessInput* w, const CFr* rs) {
     prove_many(rln, &w, 1, rs, &out);
     return out;
   }
-  FFI_RLN::Gather::Req me;
+  FFI_RLN::GatherReq me;
   me.w = w;
   if (rs) {
     me.rs[0] = rs[0];
@@ -1131,10 +1023,10 @@ FFI_RLNProof* prove_one(FFI_RLN& rln, FFI_RLNWitnessInput* w, const CFr* rs) {
     me.has_rs = true;
   }
   struct WipeReq {
-    FFI_RLN::Gather::Req& r;
+    FFI_RLN::GatherReq& r;
     ~WipeReq() { secure_zero(r.rs, sizeof r.rs); }
   } wipe_me{me};
-  G.pass(me, [&](const std::vector<FFI_RLN::Gather::Req*>& batch) { run_gathered(rln, batch); });
+  G.pass(me, [&](const std::vector<FFI_RLN::GatherReq*>& batch) { run_gathered(rln, batch); });
   if (!me.err.empty()) throw Error(me.err);
   return me.out;
 }
@@ -1259,7 +1151,7 @@ FFI_RLNProof* finish_proof(FFI_RLN& rln, const FFI_RLNPartialProof& pp, const FF
 
 // finish_proof for a batch of single-message-id requests (FFI_RLN::gather_fin): ONE submit_finish / collect; throws on
 // the first request that cannot be finished (the caller then finishes each on its own, so that every request keeps its error)
-void finish_many(FFI_RLN& rln, const std::vector<FFI_RLN::Gather::Req*>& batch, const std::vector<CFr>& rs,
+void finish_many(FFI_RLN& rln, const std::vector<FFI_RLN::GatherReq*>& batch, const std::vector<CFr>& rs,
                  std::vector<FFI_RLNProof*>& outs) {
   std::lock_guard<std::mutex> guard(*rln.prove_mu);
   if (rln.auto_partial) rln.memo_adopt_pending();
@@ -1306,17 +1198,17 @@ void finish_many(FFI_RLN& rln, const std::vector<FFI_RLN::Gather::Req*>& batch, 
 FFI_RLNProof* finish_one(FFI_RLN& rln, const FFI_RLNPartialProof& pp, FFI_RLNWitnessInput& w, const CFr& r, const CFr& s) {
   FFI_RLN::Gather& G = rln.gather_fin;
   if (G.most == 0 || w.multi) return finish_proof(rln, pp, w, r, s);
-  FFI_RLN::Gather::Req me;
+  FFI_RLN::GatherReq me;
   me.w = &w;
   me.pp = &pp;
   me.rs[0] = r;
   me.rs[1] = s;
   me.has_rs = true;
   struct WipeReq {
-    FFI_RLN::Gather::Req& q;
+    FFI_RLN::GatherReq& q;
     ~WipeReq() { secure_zero(q.rs, sizeof q.rs); }
   } wipe_me{me};
-  G.pass(me, [&](const std::vector<FFI_RLN::Gather::Req*>& batch) {
+  G.pass(me, [&](const std::vector<FFI_RLN::GatherReq*>& batch) {
     const size_t n = batch.size();
     auto alone = [&](size_t i) {
       try {
