@@ -398,7 +398,8 @@ def test_persistent_tree_config(tmp_path):
     from zerokit_amd.public import RLN
     store = tmp_path / "tree_db"
     cfg = tmp_path / "cfg.json"
-    cfg.write_text(json.dumps({"path": str(store), "temporary": False, "cache_capacity": 1 << 20,
+    cfg.write_text(json.dumps({"profile": "small",      # (the tree is the subject: the smallest tables build fastest)
+                               "path": str(store), "temporary": False, "cache_capacity": 1 << 20,
                                "flush_every_ms": 500, "mode": "HighThroughput", "use_compression": False}))
     leaves = _leaves(11)
     r = RLN(20, str(cfg))
