@@ -76,7 +76,7 @@ struct ProverTuning {
                                        // hashing on a host core (the proofs of a batch on a thread each) against ~1.3 ms of interpreter
   uint32_t hint_chains = 64;           // RLNAMD_HINT_CHAINS: members whose public chain of hints (rate commitment, the hash after every level) is remembered on the host; 0: none
   uint32_t hint_max_warm = 64;         // RLNAMD_HINTS_WARM: ... and up to this many when at most 2.5 chains per host thread have to be hashed (the others are remembered: hint_chains)
-  uint32_t hint_threads = 8;           // RLNAMD_HINT_THREADS: host threads (the caller's included) that hash the hint chains of a batch's proofs
+  uint32_t hint_threads = 8;           // RLNAMD_HINT_THREADS: host threads (the caller's included) that hash the hint chains of a batch's proofs; at most half of the host's hardware threads unless set
   int hint_fault = 0;                  // RLNAMD_HINT_FAULT (test hook): j > 0 corrupts hint j - 1 of the first proof of every hinted batch
   bool d2h_kernel = true;              // RLNAMD_D2H_KERNEL: big batches copy their results home by a single-wave kernel (0: hipMemcpyAsync)
   // ---- diagnostics

@@ -539,7 +539,11 @@ ProverTuning ProverTuning::from_env() {
   t.d2h_kernel = env_int("RLNAMD_D2H_KERNEL", 1) != 0;
   t.hint_max = (uint32_t)std::min<int>(std::max(0, env_int("RLNAMD_HINTS", (int)t.hint_max)), (int)HINT_PROOFS);
   t.hint_fault = env_int("RLNAMD_HINT_FAULT", 0);
-  t.hint_threads = (uint32_t)std::min(std::max(1, env_int("RLNAMD_HINT_THREADS", (int)t.hint_threads)), 64);
+  {   // (at most half of the host's hardware threads unless the switch says otherwise)
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int dflt = hw ? (int)std::min<unsigned>(t.hint_threads, std::max(1u, hw / 2)) : (int)t.hint_threads;
+    t.hint_threads = (uint32_t)std::min(std::max(1, env_int("RLNAMD_HINT_THREADS", dflt)), 64);
+  }
   t.hint_max_warm = (uint32_t)std::min<int>(std::max(0, env_int("RLNAMD_HINTS_WARM", (int)t.hint_max_warm)), (int)HINT_PROOFS);
   t.hint_chains = (uint32_t)std::min(std::max(0, env_int("RLNAMD_HINT_CHAINS", (int)t.hint_chains)), 1024);
   return t;
