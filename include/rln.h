@@ -97,6 +97,14 @@ CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_generate_rln_proof_with_rs(FFI_RLN_t* c
 CBoolResult_t ffi_generate_rln_proofs_batch(FFI_RLN_t* const* rln, FFI_RLNWitnessInput_t* const* witnesses, size_t n,
                                             const CFr_t* rs, FFI_RLNProof_t** out);
 
+/* EXT: n finishes in one call (single message-id): partials[i] is the partial proof witnesses[i] is finished from -- the
+ * same pointer may repeat, one member's partial proof finished for n messages being what partial proofs are for
+ * (rln/README.md:360-375); rs: NULL or 2n CFr; out: n proof pointers filled on success.  Any n: chunks of the
+ * workspace's capacity, streamed.  The first request that cannot be finished fails the call. */
+CBoolResult_t ffi_finish_rln_proofs_batch(FFI_RLN_t* const* rln, FFI_RLNPartialProof_t* const* partials,
+                                          FFI_RLNWitnessInput_t* const* witnesses, size_t n, const CFr_t* rs,
+                                          FFI_RLNProof_t** out);
+
 FFI_RLNProofValues_t* ffi_rln_proof_get_values(FFI_RLNProof_t* const* proof);                 /* ffi_rln.rs:158 */
 uint8_t ffi_rln_proof_get_version_byte(FFI_RLNProof_t* const* proof);                         /* ffi_rln.rs:165 */
 CResult_Vec_uint8_Vec_uint8_t ffi_rln_proof_to_bytes_le(FFI_RLNProof_t* const* proof);        /* ffi_rln.rs:170 */

@@ -653,6 +653,36 @@ def test_concurrent_finishes_of_partial_proofs_are_gathered_into_batches(tmp_pat
     assert st["finish_calls"] == 80 and st["finish_batches"] < 80, st
 
 
+def test_finish_rln_proofs_batch_ext():
+    """EXT ffi_finish_rln_proofs_batch: one member's partial proof finished for many messages in ONE call (what partial
+    proofs are for, rln/README.md:360-375).  300 finishes over two members' partial proofs (more than the object's 256-proof
+    workspace: two chunks) equal, byte for byte, the full proofs ffi_generate_rln_proofs_batch makes for the same witnesses
+    and (r, s); random blinding verifies; a witness that does not fit fails the call with the reference's text."""
+    from zerokit_amd import hashers
+    from zerokit_amd.public import RLN, RLNError, RLNPartialWitnessInput, RLNWitnessInput
+    rln = RLN(20)
+    secrets = [hashers.hash_to_field_le(b"batch-finish-%d" % k) for k in range(2)]
+    for k, sec in enumerate(secrets):
+        rln.set_leaf(50 + k, hashers.poseidon_hash_pair(hashers.poseidon_hash([sec]), 1000))
+    paths = [rln.get_merkle_proof(50 + k) for k in range(2)]
+    parts = [rln.generate_partial_zk_proof(RLNPartialWitnessInput(secrets[k], 1000, paths[k][0], paths[k][1])) for k in range(2)]
+    n = 300
+    ws = [RLNWitnessInput(secrets[i % 2], 1000, i, paths[i % 2][0], paths[i % 2][1], 7000 + i, 4242) for i in range(n)]
+    rs = [(11 + i, 5 + 3 * i) for i in range(n)]
+    fin = rln.finish_rln_proofs_batch([parts[i % 2] for i in range(n)], ws, rs)
+    full = rln.generate_rln_proofs_batch(ws, rs)
+    assert len(fin) == n
+    for i in range(n):
+        assert fin[i].to_bytes_le() == full[i].to_bytes_le(), i
+    assert all(rln.verify_rln_proof(fin[i], 7000 + i) for i in (0, 1, 255, 256, 299))
+    rnd = rln.finish_rln_proofs_batch([parts[0]] * 5, [ws[2 * i] for i in range(5)])
+    assert all(rln.verify_rln_proof(rnd[i], 7000 + 2 * i) for i in range(5))
+    assert rnd[0].to_bytes_le() != fin[0].to_bytes_le()
+    bad = RLNWitnessInput(secrets[0], 1000, 1, paths[0][0][:-1], paths[0][1][:-1], 1, 4242)
+    with pytest.raises(RLNError, match="path_elements has length 19"):
+        rln.finish_rln_proofs_batch([parts[0]] * 3, [ws[0], bad, ws[2]], rs[:3])
+
+
 def test_concurrent_proving_with_the_member_memo(tmp_path):
     """generate_rln_proof takes &self (public.rs:624): four threads prove for three members on ONE object whose memo holds
     two ({"auto_partial": 2}) -- adoptions of pending partial proofs, finishes through the cone, evictions and proofs from

@@ -203,6 +203,7 @@ SIGNATURES = {
     "ffi_generate_rln_proof": (CResultPtr, [PP, PP]),
     "ffi_generate_rln_proof_with_rs": (CResultPtr, [PP, PP, CFRP, CFRP]),
     "ffi_generate_rln_proofs_batch": (CBoolResult, [PP, PP, C.c_size_t, CFRP, PP]),
+    "ffi_finish_rln_proofs_batch": (CBoolResult, [PP, PP, PP, C.c_size_t, CFRP, PP]),
     "ffi_verify_rln_proof": (CBoolResult, [PP, PP, CFRP]),
     "ffi_verify_with_roots": (CBoolResult, [PP, PP, C.POINTER(VecCFr), CFRP]),
     "ffi_rln_proof_get_values": (P, [PP]),

@@ -1525,6 +1525,85 @@ CResult_FFI_RLNProof_ptr_Vec_uint8_t ffi_finish_rln_proof_with_rs(FFI_RLN_t* con
                                        *(FFI_RLNWitnessInput*)*witness, R(r), R(s));
   });
 }
+CBoolResult_t ffi_finish_rln_proofs_batch(FFI_RLN_t* const* rln, FFI_RLNPartialProof_t* const* partials,
+                                          FFI_RLNWitnessInput_t* const* witnesses, size_t n, const CFr_t* rs,
+                                          FFI_RLNProof_t** out) {
+  return guard_bool([&]() {
+    FFI_RLN& r = *(FFI_RLN*)*rln;
+    std::lock_guard<std::mutex> guard(*r.prove_mu);
+    if (r.auto_partial) r.memo_adopt_pending();
+    Prover& P = *r.prover;
+    const size_t cap = P.capacity(), ni = P.inputs_per_proof();
+    const std::vector<uint8_t>& known = P.known_mask();
+    std::vector<FFI_RLNProof*> made;
+    // chunks of the workspace's capacity, every slot in flight: the host packs chunk k + 1 while the device finishes chunk k
+    struct Pending { uint64_t ticket; size_t m; };
+    std::deque<Pending> q;
+    std::vector<uint8_t> inputs, rsb, coords, proofs, values;
+    ZeroOnExit z1{inputs}, z2{rsb};
+    std::vector<uint64_t> handles;
+    std::vector<uint32_t> errs;
+    inputs.reserve(std::min(n, cap) * ni * 32);   // one allocation: a vector that grew would leave secrets behind uncleared
+    rsb.reserve(std::min(n, cap) * 64);
+    auto take = [&]() {
+      const Pending f = q.front();
+      q.pop_front();
+      proofs.resize(f.m * 128);
+      values.resize(f.m * 160);
+      errs.resize(f.m);
+      P.collect(f.ticket, f.m, proofs.data(), values.data(), errs.data());
+      for (size_t i = 0; i < f.m; i++) {
+        if (errs[i]) throw Error("Error calculating witness: graph evaluation failed (code " + std::to_string(errs[i]) + ")");
+        std::unique_ptr<FFI_RLNProof> pr(new FFI_RLNProof);
+        memcpy(pr->proof, proofs.data() + 128 * i, 128);
+        const uint8_t* v = values.data() + 160 * i;
+        memcpy(pr->values.y.le, v, 32);
+        memcpy(pr->values.root.le, v + 32, 32);
+        memcpy(pr->values.nullifier.le, v + 64, 32);
+        memcpy(pr->values.x.le, v + 96, 32);
+        memcpy(pr->values.external_nullifier.le, v + 128, 32);
+        made.push_back(pr.release());
+      }
+    };
+    try {
+      for (size_t off = 0; off < n; off += cap) {
+        const size_t m = std::min(cap, n - off);
+        inputs.assign(m * ni * 32, 0);
+        rsb.resize(m * 64);
+        coords.resize(m * 320);
+        handles.resize(m);
+        for (size_t i = 0; i < m; i++) {
+          const FFI_RLNWitnessInput& w = *(const FFI_RLNWitnessInput*)witnesses[off + i];
+          const FFI_RLNPartialProof& pp = *(const FFI_RLNPartialProof*)partials[off + i];
+          check_against_graph(P, w);
+          if (w.multi) throw Error("ffi_finish_rln_proofs_batch: single message-id witnesses only");
+          if (pp.mask.size() + 1 != known.size() || !std::equal(pp.mask.begin(), pp.mask.end(), known.begin() + 1))
+            throw Error("Error producing proof: the partial proof's mask does not match this circuit (malformed verifying key)");
+          fill_inputs(P, w, inputs.data() + i * ni * 32);
+          const CFr rr = rs ? R(&rs[2 * (off + i)]) : random_fr(), ss = rs ? R(&rs[2 * (off + i) + 1]) : random_fr();
+          memcpy(rsb.data() + i * 64, rr.le, 32);
+          memcpy(rsb.data() + i * 64 + 32, ss.le, 32);
+          memcpy(coords.data() + i * 320, pp.coords, 320);
+          handles[i] = pp.handle;
+        }
+        if ((int)q.size() == P.slots()) take();
+        q.push_back({P.submit_finish(m, inputs.data(), rsb.data(), coords.data(), handles.data()), m});
+      }
+      while (!q.empty()) take();
+    } catch (...) {
+      try {   // nothing of this call stays in flight behind the error; the batches never collected are wiped
+        P.sync();
+        for (const Pending& f : q) P.wipe(f.ticket);
+        P.sync();
+      } catch (...) {
+      }
+      for (FFI_RLNProof* o : made) delete o;
+      throw;
+    }
+    for (size_t i = 0; i < n; i++) out[i] = (FFI_RLNProof_t*)made[i];
+    return true;
+  });
+}
 uint8_t ffi_rln_partial_proof_get_version_byte(FFI_RLNPartialProof_t* const*) { return 0x00; }
 CResult_Vec_uint8_Vec_uint8_t ffi_rln_partial_proof_to_bytes_le(FFI_RLNPartialProof_t* const* partial) {
   return guard_bytes([&]() { return partial_proof_bytes(*(FFI_RLNPartialProof*)*partial); });

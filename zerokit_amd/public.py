@@ -460,6 +460,19 @@ class RLN:
         _ok_bool(lib().ffi_generate_rln_proofs_batch(C.byref(self._h), hs, n, rsp, outs))
         return [RLNProof(C.c_void_p(outs[i])) for i in range(n)]
 
+    def finish_rln_proofs_batch(self, partials, witnesses, rs=None):
+        """EXT: n finishes in one call; partials[i] (the same object may repeat) is what witnesses[i] is finished from"""
+        n = len(witnesses)
+        ps = (C.c_void_p * n)(*[p._h.value for p in partials])
+        hs = (C.c_void_p * n)(*[w._h.value for w in witnesses])
+        outs = (C.c_void_p * n)()
+        rsp = None
+        if rs is not None:
+            flat, _k = _vec_cfr([v for pair in rs for v in pair])
+            rsp = flat.ptr
+        _ok_bool(lib().ffi_finish_rln_proofs_batch(C.byref(self._h), ps, hs, n, rsp, outs))
+        return [RLNProof(C.c_void_p(outs[i])) for i in range(n)]
+
     def generate_rln_proof_with_witness(self, calculated_witness, witness: RLNWitnessInput) -> RLNProof:
         """public.rs:643-658: calculated_witness = the full witness as ints (or decimal strings)"""
         strs = [str(v).encode() for v in calculated_witness]
