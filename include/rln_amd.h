@@ -107,7 +107,7 @@ int rlnamd_ffi_memo_stats(const void* ffi_rln, uint64_t out[4]);
  * the workspace's capacity; 0 or 1: off); on an object with "auto_partial" the gathered calls of remembered members go
  * out as one batch of finishes, the others one by one.  Threads that call in a
  * loop arrive just behind their results: the leader gives the callers it saw within the last 20 ms "gather_window_us"
- * (200; RLNAMD_GATHER_WINDOW_US; 0: none) to arrive before it takes the batch, so that T threads go out as batches of T
+ * (500; RLNAMD_GATHER_WINDOW_US; 0: none) to arrive before it takes the batch, so that T threads go out as batches of T
  * instead of two halves taking turns; a lone caller never waits, callers slower than the window make it stop waiting.
  * out: [0] batches led, [1] calls that went out in them, [2] the largest batch, [3] the cap (0: off), [4] batches whose
  * leader waited for a recent caller, [5] nanoseconds the leaders spent proving their batches; ffi_finish_rln_proof and

@@ -3,7 +3,8 @@
  * end of a run's first and last call.  The library gathers the calls that arrive while a proof is on the device into one
  * batch (include/rln_amd.h: rlnamd_ffi_gather_stats); RLNAMD_GATHER_CALLS=0 in the environment gives the behaviour
  * before (one call at a time).  With the argument `finish` the threads finish the member's partial proof instead
- * (ffi_finish_rln_proof; its ms_proving_per_batch is not reported); a second argument is the object's config_path.
+ * (ffi_finish_rln_proof; its ms_proving_per_batch is not reported); a second argument is the object's config_path ("" for
+ * none), a third the number of members to prove for in turn (1: one member, its chain of hints remembered).
  * One JSON line.
  *   gcc -O2 -std=c11 -I include tools/ffi_threads.c -L zerokit_amd/lib -lrln -lpthread -Wl,-rpath,$PWD/zerokit_amd/lib -o tools/ffi_threads */
 #define _POSIX_C_SOURCE 200809L
@@ -21,6 +22,12 @@ static FFI_RLN_t* rln;
 static const CFr_t *id_secret, *limit_c;
 static CFr_t* ext;
 static FFI_MerkleProof_t* mp;
+/* argv[3] = M > 1: M members are registered and every call proves for another one ((thread, call) -> member), as a service
+ * that proves for its users would: the chains of hints are not remembered from call to call */
+#define MAX_MEMBERS 4096
+static int n_members = 1;
+static Vec_CFr_t member_keys[MAX_MEMBERS];
+static FFI_MerkleProof_t* member_mp[MAX_MEMBERS];
 static int calls_per_thread;
 static int failures;
 static FFI_RLNPartialProof_t* partial;   /* argv[1] = "finish": the threads finish this member's partial proof instead */
@@ -36,8 +43,11 @@ static void* work(void* arg) {
   for (int j = 0; j < calls_per_thread; j++) {
     CFr_t* x = ffi_uint_to_cfr((uint32_t)(1 + tid * 100000 + j));
     CFr_t* msg = ffi_uint_to_cfr((uint32_t)((tid + j) % 100));
+    const int mem = n_members > 1 ? (int)((tid * 7919 + j * 104729L) % n_members) : 0;
+    const CFr_t* sec = n_members > 1 ? ffi_vec_cfr_get(&member_keys[mem], 0) : id_secret;
+    FFI_MerkleProof_t* path = n_members > 1 ? member_mp[mem] : mp;
     CResult_FFI_RLNWitnessInput_ptr_Vec_uint8_t w =
-        ffi_rln_witness_input_new_single(id_secret, limit_c, msg, &mp->path_elements, &mp->path_index, x, ext);
+        ffi_rln_witness_input_new_single(sec, limit_c, msg, &path->path_elements, &path->path_index, x, ext);
     if (!w.ok) {
       __sync_fetch_and_add(&failures, 1);
       return NULL;
@@ -81,6 +91,21 @@ int main(int argc, char** argv) {
   if (!m.ok) return 4;
   mp = m.ok;
   ext = ffi_uint_to_cfr(424242);
+  if (argc > 3 && atoi(argv[3]) > 1) {
+    n_members = atoi(argv[3]) > MAX_MEMBERS ? MAX_MEMBERS : atoi(argv[3]);
+    for (int i = 0; i < n_members; i++) {
+      member_keys[i] = ffi_key_gen();
+      CFr_t* rc = ffi_poseidon_hash_pair(ffi_vec_cfr_get(&member_keys[i], 1), limit);
+      CBoolResult_t o = ffi_set_leaf(&rln, 100 + (size_t)i, rc);
+      if (!o.ok) return 7;
+      ffi_cfr_free(rc);
+    }
+    for (int i = 0; i < n_members; i++) {
+      CResult_FFI_MerkleProof_ptr_Vec_uint8_t q = ffi_get_merkle_proof(&rln, 100 + (size_t)i);
+      if (!q.ok) return 8;
+      member_mp[i] = q.ok;
+    }
+  }
   if (argc > 1 && strcmp(argv[1], "finish") == 0) {
     CResult_FFI_RLNPartialWitnessInput_ptr_Vec_uint8_t pw =
         ffi_rln_partial_witness_input_new(id_secret, limit_c, &mp->path_elements, &mp->path_index);
@@ -93,7 +118,7 @@ int main(int argc, char** argv) {
   calls_per_thread = 4;
   work((void*)99);   /* warm */
   const int ts[] = {1, 2, 4, 8, 16, 32, 64};
-  printf("{\"calls\": \"%s\", \"gather_calls_env\": \"%s\", \"threads\": {", partial ? "ffi_finish_rln_proof" : "ffi_generate_rln_proof",
+  printf("{\"calls\": \"%s\", \"members\": %d, \"gather_calls_env\": \"%s\", \"threads\": {", partial ? "ffi_finish_rln_proof" : "ffi_generate_rln_proof", n_members,
          getenv("RLNAMD_GATHER_CALLS") ? getenv("RLNAMD_GATHER_CALLS") : "");
   for (unsigned k = 0; k < sizeof ts / sizeof ts[0]; k++) {
     const int T = ts[k];

@@ -294,6 +294,14 @@ struct FFI_RLN {
     bool has_rs = false, done = false;
     FFI_RLNProof* out = nullptr;
     std::string err;
+    // the caller's own thread packs its inputs and hashes its hints before it queues (prove_one): the chains of a
+    // gathered batch are then hashed by as many threads as there are callers, not by the leader
+    std::vector<uint8_t> inputs;
+    std::vector<uint32_t> hints;
+    ~GatherReq() {
+      secure_zero(inputs.data(), inputs.size());
+      secure_zero(hints.data(), hints.size() * 4);
+    }
     void gather_failed() {
       if (!out && err.empty()) err = "Error producing proof: out of memory";
     }
@@ -915,6 +923,56 @@ void run_gathered(FFI_RLN& rln, const std::vector<FFI_RLN::GatherReq*>& batch) {
     rs[2 * i] = batch[i]->has_rs ? batch[i]->rs[0] : random_fr();      // proof.rs:743-745
     rs[2 * i + 1] = batch[i]->has_rs ? batch[i]->rs[1] : random_fr();
   }
+  // every request brought its packed inputs and its hints (single message-id): one submit_hinted, nothing hashed here
+  bool packed = !rln.auto_partial && n <= 64;
+  for (size_t i = 0; i < n && packed; i++) packed = !batch[i]->hints.empty() && !batch[i]->inputs.empty() && !ws[i]->multi;
+  if (packed) {
+    try {
+      std::lock_guard<std::mutex> guard(*rln.prove_mu);
+      Prover& P = *rln.prover;
+      const size_t ni = P.inputs_per_proof(), hw = P.hint_words();
+      std::vector<uint8_t> inputs(n * ni * 32), rsb(n * 64), proofs(n * 128), values(n * 160);
+      ZeroOnExit z1{inputs}, z2{rsb};
+      std::vector<uint32_t> hints(n * hw), errs(n);
+      struct WipeHints {
+        std::vector<uint32_t>& v;
+        ~WipeHints() { secure_zero(v.data(), v.size() * 4); }
+      } wipe_hints{hints};
+      for (size_t i = 0; i < n; i++) {
+        if (batch[i]->inputs.size() != ni * 32 || batch[i]->hints.size() != hw) throw Error("gathered request of another shape");
+        memcpy(inputs.data() + i * ni * 32, batch[i]->inputs.data(), ni * 32);
+        memcpy(hints.data() + i * hw, batch[i]->hints.data(), hw * 4);
+        memcpy(rsb.data() + i * 64, rs[2 * i].le, 32);
+        memcpy(rsb.data() + i * 64 + 32, rs[2 * i + 1].le, 32);
+      }
+      const uint64_t ticket = P.submit_hinted(n, inputs.data(), rsb.data(), hints.data());
+      P.collect(ticket, n, proofs.data(), values.data(), errs.data());
+      for (size_t i = 0; i < n; i++) {
+        if (errs[i]) {
+          batch[i]->err = "Error calculating witness: graph evaluation failed (code " + std::to_string(errs[i]) + ")";
+          continue;
+        }
+        std::unique_ptr<FFI_RLNProof> pr(new FFI_RLNProof);
+        memcpy(pr->proof, proofs.data() + 128 * i, 128);
+        const uint8_t* v = values.data() + 160 * i;
+        memcpy(pr->values.y.le, v, 32);
+        memcpy(pr->values.root.le, v + 32, 32);
+        memcpy(pr->values.nullifier.le, v + 64, 32);
+        memcpy(pr->values.x.le, v + 96, 32);
+        memcpy(pr->values.external_nullifier.le, v + 128, 32);
+        batch[i]->out = pr.release();
+      }
+      return;
+    } catch (const std::exception&) {
+      // the batch as a whole did not go through: below, the way every batch goes that brings no hints
+      for (size_t i = 0; i < n; i++)
+        if (batch[i]->out) {
+          delete batch[i]->out;
+          batch[i]->out = nullptr;
+        }
+      for (size_t i = 0; i < n; i++) batch[i]->err.clear();
+    }
+  }
   auto alone = [&](size_t i) {
     try {
       FFI_RLNProof* o = nullptr;
@@ -1026,6 +1084,26 @@ FFI_RLNProof* prove_one(FFI_RLN& rln, FFI_RLNWitnessInput* w, const CFr* rs) {
     FFI_RLN::GatherReq& r;
     ~WipeReq() { secure_zero(r.rs, sizeof r.rs); }
   } wipe_me{me};
+  // this thread's share of the batch's host work, before it queues: the packed inputs and the hints of its proof
+  // (Prover::hints_for; graph and slots are read-only: no lock).  A witness that does not fit leaves both empty and gets
+  // its error from the proving path.
+  if (!rln.auto_partial && !w->multi) {
+    try {
+      const Prover& P = *rln.prover;
+      const size_t hw = P.hint_words();
+      if (hw) {
+        check_against_graph(P, *w);
+        me.inputs.resize(P.inputs_per_proof() * 32);
+        fill_inputs(P, *w, me.inputs.data());
+        me.hints.resize(hw);
+        P.hints_for(me.inputs.data(), me.hints.data());
+      }
+    } catch (const std::exception&) {
+      secure_zero(me.inputs.data(), me.inputs.size());
+      me.inputs.clear();
+      me.hints.clear();
+    }
+  }
   G.pass(me, [&](const std::vector<FFI_RLN::GatherReq*>& batch) { run_gathered(rln, batch); });
   if (!me.err.empty()) throw Error(me.err);
   return me.out;

@@ -33,7 +33,7 @@ struct GatherQueue {
   // leader therefore knows who else called within the last 20 ms and gives those callers window_us to arrive
   // (spinning, off the lock) before it takes the batch.  A caller that is alone never waits.
   std::vector<std::pair<std::thread::id, std::chrono::steady_clock::time_point>> recent;
-  long window_us = 200;                   // RLNAMD_GATHER_WINDOW_US / "gather_window_us"; 0: take what is there
+  long window_us = 500;                   // RLNAMD_GATHER_WINDOW_US / "gather_window_us"; 0: take what is there
   uint64_t misses = 0, no_wait_until = 0; // the wait's back-off (see pass)
   uint64_t waited = 0;                    // batches whose leader waited for a recent caller
   uint64_t busy_ns = 0;                   // time the leaders spent proving their batches

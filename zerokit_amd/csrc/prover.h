@@ -143,6 +143,15 @@ class Prover {
   // submits later.  This is the path of SURVEY 8(d)'s timed region: H2D of witness inputs -> D2H of proofs.
   uint64_t submit(size_t n, const uint8_t* inputs, const uint8_t* rs, int mode = PROVE_FULL,
                   const uint8_t* partial320 = nullptr);
+  // The hints of a lone small batch (the values between the circuit's chained hashes: prover.hip, Impl::rln_hints) may be
+  // computed ahead of the call, by any thread, one proof at a time: hint_words() 32-bit words per proof (0: this circuit
+  // has no such form), hints_for() fills them from one proof's packed inputs.  submit_hinted() is submit() for a full
+  // proof batch of at most 64 proofs whose hints are at hand (n x hint_words() words): nothing is hashed inside the call,
+  // and the batch takes the segments whatever its members' chains would have cost.  The device checks every hint as
+  // always; hints that do not belong to the inputs cost a run over the whole graph, never a wrong proof.
+  uint32_t hint_words() const;
+  void hints_for(const uint8_t* inputs, uint32_t* hints) const;
+  uint64_t submit_hinted(size_t n, const uint8_t* inputs, const uint8_t* rs, const uint32_t* hints);
   // wipe_after (default): the batch's inputs -- pinned staging and device copies -- its (r, s) and its witness values are
   // overwritten behind the copy-out (the reference zeroises the identity secret and the witness calculator's inputs,
   // rln/src/utils.rs:440-527, circuit/iden3calc.rs:45-56).  Pass false to read more of the batch (collect_public), then
@@ -222,7 +231,7 @@ class Prover {
  private:
   uint64_t settle_hints(uint64_t ticket);
   uint64_t enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint8_t* h_rs, const uint8_t* h_pp320,
-                   const uint64_t* cone_handles = nullptr);
+                   const uint64_t* cone_handles = nullptr, const uint32_t* pre_hints = nullptr);
   void fetch_public_slot(void* slot, size_t n, std::vector<uint8_t>* out_le);
   struct Impl;
   std::unique_ptr<Impl> d_;

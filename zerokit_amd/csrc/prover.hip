@@ -1599,6 +1599,25 @@ uint64_t Prover::submit_finish(size_t n, const uint8_t* inputs, const uint8_t* r
   return enqueue(n, PROVE_FINISH, inputs, rs, partial320, handles);
 }
 
+uint32_t Prover::hint_words() const {
+  const Impl& D = *d_;
+  return D.segs.ok && D.tune.hint_max > 0 ? D.n_hints * 8 : 0;
+}
+
+void Prover::hints_for(const uint8_t* inputs, uint32_t* hints) const {
+  const Impl& D = *d_;
+  if (!D.segs.ok) throw Error("hints_for: this prover interprets no segments (hint_words() is 0)");
+  Fr hv[64];
+  D.rln_hints(inputs, hv);
+  for (uint32_t j = 0; j < D.n_hints; j++) hv[j].to_canonical(hints + (size_t)j * 8);
+}
+
+uint64_t Prover::submit_hinted(size_t n, const uint8_t* inputs, const uint8_t* rs, const uint32_t* hints) {
+  if (n == 0) throw Error("empty batch");
+  if (!inputs || !rs) throw Error("submit: inputs and rs are required");
+  return enqueue(n, PROVE_FULL, inputs, rs, nullptr, nullptr, hint_words() && n <= HINT_PROOFS ? hints : nullptr);
+}
+
 void Prover::collect_partial_cached(uint64_t ticket, size_t n, uint8_t* partial320, uint64_t* handles, uint32_t* errors) {
   Impl& D = *d_;
   ticket = settle_hints(ticket);
@@ -1844,7 +1863,7 @@ void Prover::prove_stream_from(const ChunkSource& next, const uint8_t* inputs, c
 }
 
 uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint8_t* h_rs, const uint8_t* h_pp320,
-                         const uint64_t* cone_handles) {
+                         const uint64_t* cone_handles, const uint32_t* pre_hints) {
   if (n == 0) return 0;
   if (n > B_) throw Error("batch larger than the prover workspace (max_batch)");
   if (mode < PROVE_FULL || mode > PROVE_FINISH) throw Error("unknown prover mode");
@@ -1878,7 +1897,9 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   // A lone batch of one or two proofs: the graph as independent segments behind hints computed on this thread (Impl::rln_hints)
   // (up to hint_max proofs whatever their chains cost; above it, up to HINT_PROOFS, when few enough of the proofs' chains
   // have to be hashed -- the others are remembered, Impl::rln_hints -- that the host threads are done in ~0.5 ms)
-  bool hinted = D.segs.ok && h_inputs && wl_used && !cone && lone && n <= std::max(T.hint_max, T.hint_max_warm) && !D.no_hints_now;
+  // (or whatever the batch's size up to HINT_PROOFS when the caller brings the hints: submit_hinted)
+  bool hinted = D.segs.ok && h_inputs && wl_used && !cone && lone && !D.no_hints_now &&
+                n <= (pre_hints ? HINT_PROOFS : std::max(T.hint_max, T.hint_max_warm));
   std::vector<Impl::HintProbe> probes;
   const size_t hint_nth = std::min<size_t>(std::max<size_t>(n, 1), std::max<uint32_t>(1u, T.hint_threads));
   auto on_hint_threads = [&](auto&& per_proof) {   // proofs i = k, k + nth, ... on thread k; the caller is thread 0
@@ -1901,7 +1922,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
     for (std::thread& th : helpers) th.join();
     if (failed) throw Error("out of memory while hashing the hints of a batch");
   };
-  if (hinted && n > T.hint_max) {
+  if (hinted && !pre_hints && n > T.hint_max) {
     probes.resize(n);
     // the first two proofs on this thread (15 us): a batch of members never seen ends here, before a helper thread is started
     for (size_t i = 0; i < 2 && hinted; i++) {
@@ -1909,7 +1930,7 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
       hinted = probes[i].found;
     }
   }
-  if (hinted && n > T.hint_max) {
+  if (hinted && !pre_hints && n > T.hint_max) {
     on_hint_threads([&](size_t i) {
       if (i >= 2) D.rln_hint_probe(h_inputs + i * (size_t)D.NI * 32, &probes[i]);
     });
@@ -2024,11 +2045,14 @@ uint64_t Prover::enqueue(size_t n, int mode, const uint8_t* h_inputs, const uint
   if (hinted) {
     // a proof's hints: one dependent chain of depth + 2 hashes; the chains of the batch's proofs are independent of each
     // other: the calling thread and up to hint_threads - 1 helpers take them in turn
-    on_hint_threads([&](size_t i) {
-      Fr hv[64];
-      D.rln_hints(h_inputs + i * (size_t)D.NI * 32, hv, probes.empty() ? nullptr : &probes[i]);
-      for (uint32_t j = 0; j < D.n_hints; j++) hv[j].to_canonical(S.h_hints + (i * D.n_hints + j) * 8);
-    });
+    if (pre_hints)
+      memcpy(S.h_hints, pre_hints, n * (size_t)D.n_hints * 32);
+    else
+      on_hint_threads([&](size_t i) {
+        Fr hv[64];
+        D.rln_hints(h_inputs + i * (size_t)D.NI * 32, hv, probes.empty() ? nullptr : &probes[i]);
+        for (uint32_t j = 0; j < D.n_hints; j++) hv[j].to_canonical(S.h_hints + (i * D.n_hints + j) * 8);
+      });
     if (T.hint_fault > 0 && (uint32_t)T.hint_fault <= D.n_hints) S.h_hints[(size_t)(T.hint_fault - 1) * 8] ^= 1u;   // test hook
     D.hinted_batches++;
   }

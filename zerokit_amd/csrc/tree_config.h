@@ -67,8 +67,8 @@ struct TreeConfig {
   // 0 or 1: every call is its own batch, one after the other
   long gather_calls = -1;
   // "gather_window_us": how long the leader of a gathered batch waits for callers it saw within the last 20 ms
-  // (200 unless given; 0: it takes what is queued)
-  long gather_window_us = 200;
+  // (500 unless given; 0: it takes what is queued)
+  long gather_window_us = 500;
   bool persistent() const { return !temporary && has_path; }
   ProverConfig prover_config() const {
     ProverConfig cfg;
