@@ -200,6 +200,17 @@ int rlnamd_prover_run_async_mode(rlnamd_prover* p, size_t n, int mode);
  * out: [0] segments, [1] hints per proof, [2] steps of the longest segment, [3] steps of the whole graph, [4] batches
  * interpreted as segments, [5] of those, batches run again, [6] proofs whose chain was remembered. */
 int rlnamd_prover_hint_stats(rlnamd_prover* p, uint64_t out[7]);
+/* The hints may be computed ahead of the call, by any thread, one proof at a time -- a server whose request threads each
+ * hash their own proof's chain while the device is busy: rlnamd_prover_hint_words() 32-bit words per proof (0: this
+ * circuit has no such form), rlnamd_prover_hints_for() fills them from one proof's packed inputs (host only, no device
+ * call, safe beside a running batch), rlnamd_prover_submit_hinted() is rlnamd_prover_submit (full proofs) for a batch of
+ * at most 64 proofs whose hints (n x hint_words) are at hand: nothing is hashed inside the call and the batch takes the
+ * segments whatever its members' chains would have cost.  The device checks every hint as always: hints that do not
+ * belong to the inputs cost a run over the whole graph, never a wrong proof. */
+uint32_t rlnamd_prover_hint_words(rlnamd_prover* p);
+int rlnamd_prover_hints_for(rlnamd_prover* p, const uint8_t* inputs_le, uint32_t* hints);
+int rlnamd_prover_submit_hinted(rlnamd_prover* p, size_t n, const uint8_t* inputs_le, const uint8_t* rs_le,
+                                const uint32_t* hints, uint64_t* ticket);
 /* Who else proves on this prover's device: bit 0 = another prover of this process, bit 1 = a prover of ANOTHER process
  * (every process with a prover on a device holds a read record lock on /dev/shm/rlnamd_<PCI bus id>.lock; probed at most
  * every 50 ms).  A shared device keeps the wide latency shapes off (they assume the chip is this prover's). */

@@ -970,7 +970,8 @@ def test_a_few_proofs_per_call_interpret_the_graph_as_segments_behind_hints(monk
     corrupted hint (test hook) the batch is run again over the whole graph and the caller sees the golden bytes; with
     RLNAMD_HINTS=0 nothing is hinted and the bytes are the same; a member proving again at the same root finds the chain
     part of its hints remembered (hint_stats()["chains_remembered"]) and gets the same bytes; 25 and 64 proofs per call take
-    the segments when the members' chains are remembered and the whole graph when they are not."""
+    the segments when the members' chains are remembered and the whole graph when they are not; hints computed ahead of
+    the call (hints_for / submit_hinted) give the golden bytes, and so do hints that belong to other inputs (one rerun)."""
     from zerokit_amd.batch import BatchProver
     cases = _cases()["cases"]
     fx = {c["name"]: c["partial320"] for c in json.load(open(os.path.join(ROOT, "tests", "golden", "rln_h20_partial.json")))["cases"]}
@@ -1016,6 +1017,27 @@ def test_a_few_proofs_per_call_interpret_the_graph_as_segments_behind_hints(monk
         inp[32 * off:32 * off + 32] = R.to_bytes(32, "little")
         t, n = p.submit(bytes(inp), p.pack_rs([(1, 2)]))
         assert p.collect(t, n)[0]["error"] != 0
+    finally:
+        p.close()
+    # the hints computed ahead of the call (rlnamd_prover_hints_for / _submit_hinted): 40 proofs in one batch take the
+    # segments although their chains were never seen; hints that belong to other inputs cost a rerun, not a wrong proof
+    p = BatchProver(max_batch=64, window_bits=8)
+    try:
+        idx = [i % len(cases) for i in range(40)]
+        inp = p.pack_inputs([_w(cases[i]) for i in idx])
+        rsb = p.pack_rs([(int(cases[i]["r"]), int(cases[i]["s"])) for i in idx])
+        hints = p.hints_for(inp)
+        assert hints is not None and len(hints) == 40 and len(hints[0]) == 22 * 8
+        t, n = p.submit_hinted(inp, rsb, hints)
+        for o, i in zip(p.collect(t, n), idx):
+            assert o["proof"].hex() == cases[i]["proof_compressed"] and o["error"] == 0
+        st = p.hint_stats()
+        assert st["hinted_batches"] == 1 and st["fallbacks"] == 0, st
+        t, n = p.submit_hinted(inp, rsb, hints[1:] + hints[:1])     # every proof with its neighbour's hints
+        for o, i in zip(p.collect(t, n), idx):
+            assert o["proof"].hex() == cases[i]["proof_compressed"] and o["error"] == 0
+        st = p.hint_stats()
+        assert st["hinted_batches"] == 2 and st["fallbacks"] == 1, st
     finally:
         p.close()
     monkeypatch.setenv("RLNAMD_HINT_FAULT", "9")

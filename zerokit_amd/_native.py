@@ -128,6 +128,10 @@ SIGNATURES = {
     "rlnamd_prover_release_partial": (C.c_int, [P, C.POINTER(C.c_uint64), C.c_size_t]),
     "rlnamd_prover_device_shared": (C.c_int, [P, C.POINTER(C.c_int)]),
     "rlnamd_prover_hint_stats": (C.c_int, [P, C.POINTER(C.c_uint64)]),
+    "rlnamd_prover_hint_words": (C.c_uint32, [P]),
+    "rlnamd_prover_hints_for": (C.c_int, [P, C.c_char_p, C.POINTER(C.c_uint32)]),
+    "rlnamd_prover_submit_hinted": (C.c_int, [P, C.c_size_t, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint32),
+                                    C.POINTER(C.c_uint64)]),
     "rlnamd_prover_partial_cache_info": (C.c_int, [P, C.POINTER(C.c_uint64)]),
     "rlnamd_prover_init_ms": (C.c_int, [P, C.POINTER(C.c_float)]),
     "rlnamd_verify": (C.c_int, [P, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]),

@@ -187,6 +187,33 @@ class BatchProver:
         check(lib().rlnamd_prover_submit(self._h, n, inputs, rsb, mode, pp, C.byref(t)))
         return int(t.value), n
 
+    def hints_for(self, inputs: bytes):
+        """the hints of the proofs packed in `inputs`, one proof at a time on this thread (rlnamd_prover_hints_for): a list
+        of ctypes arrays, or None when the circuit has no segments form"""
+        hw = int(lib().rlnamd_prover_hint_words(self._h))
+        if not hw:
+            return None
+        isz = self.inputs_size * 32
+        out = []
+        for i in range(len(inputs) // isz):
+            h = (C.c_uint32 * hw)()
+            check(lib().rlnamd_prover_hints_for(self._h, inputs[i * isz:(i + 1) * isz], h))
+            out.append(h)
+        return out
+
+    def submit_hinted(self, inputs: bytes, rsb: bytes, hints):
+        """submit() for full proofs whose hints (hints_for) are at hand: nothing is hashed inside the call"""
+        n = len(inputs) // (self.inputs_size * 32)
+        if len(inputs) != n * self.inputs_size * 32 or len(rsb) != 64 * n or len(hints) != n:
+            raise RLNError("submit_hinted: inputs / rs / hints sizes do not match")
+        hw = len(hints[0])
+        flat = (C.c_uint32 * (hw * n))()
+        for i, h in enumerate(hints):
+            flat[i * hw:(i + 1) * hw] = h[:]
+        t = C.c_uint64()
+        check(lib().rlnamd_prover_submit_hinted(self._h, n, inputs, rsb, flat, C.byref(t)))
+        return int(t.value), n
+
     def describe(self):
         """the switches this prover was built with (ProverTuning)"""
         buf = C.create_string_buffer(1024)

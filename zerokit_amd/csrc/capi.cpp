@@ -306,6 +306,18 @@ int rlnamd_prover_collect(rlnamd_prover* p, uint64_t ticket, size_t n, uint8_t* 
   p->p->collect(ticket, n, proofs, values, errors, coords, partial320);
   RLN_CATCH
 }
+uint32_t rlnamd_prover_hint_words(rlnamd_prover* p) { return p->p->hint_words(); }
+int rlnamd_prover_hints_for(rlnamd_prover* p, const uint8_t* inputs_le, uint32_t* hints) {
+  RLN_TRY
+  p->p->hints_for(inputs_le, hints);
+  RLN_CATCH
+}
+int rlnamd_prover_submit_hinted(rlnamd_prover* p, size_t n, const uint8_t* inputs_le, const uint8_t* rs_le,
+                                const uint32_t* hints, uint64_t* ticket) {
+  RLN_TRY
+  *ticket = p->p->submit_hinted(n, inputs_le, rs_le, hints);
+  RLN_CATCH
+}
 int rlnamd_prover_hint_stats(rlnamd_prover* p, uint64_t out[7]) {
   RLN_TRY
   static_assert(Prover::HINT_STATS_FIELDS == 7, "rln_amd.h states seven fields");
